@@ -1,0 +1,1190 @@
+/*
+ * nidx_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See nidx_oracle.h.
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -mavx2 -mfma; every FMA is an explicit fmaf)
+ * Citations are file:line relative to /root/reference/nidx/.
+ */
+#include "nidx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * a1. dense_f32::{dot,cosine}_similarity (nidx_vector/src/vector_types/dense_f32.rs:29-39)
+ *     -> simsimd 6.5.16 `f32::dot` / `f32::cosine` [third party, restated].
+ * ------------------------------------------------------------------------------------------ */
+
+static void sums_serial(const float *x, const float *y, size_t n, double *ab, double *xx, double *yy) {
+    /* SimSIMD portable macro (SIMSIMD_MAKE_DOT / SIMSIMD_MAKE_COS, f32 accumulators) */
+    float sab = 0.0f, sxx = 0.0f, syy = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float xi = x[i], yi = y[i];
+        sab += xi * yi;
+        sxx += xi * xi;
+        syy += yi * yi;
+    }
+    *ab = sab; *xx = sxx; *yy = syy;
+}
+
+static void sums_serial_fma(const float *x, const float *y, size_t n, double *ab, double *xx, double *yy) {
+    /* one k-ordered fmaf chain == gfx950 v_mfma_f32_32x32x2_f32 / 16x16x4_f32 numerics */
+    float sab = 0.0f, sxx = 0.0f, syy = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float xi = x[i], yi = y[i];
+        sab = fmaf(xi, yi, sab);
+        sxx = fmaf(xi, xi, sxx);
+        syy = fmaf(yi, yi, syy);
+    }
+    *ab = sab; *xx = sxx; *yy = syy;
+}
+
+static double reduce8_f64(const float a[8]) {
+    /* _simsimd_reduce_f32x8_haswell: widen halves to f64, add, horizontal add */
+    double s0 = (double)a[0] + (double)a[4];
+    double s1 = (double)a[1] + (double)a[5];
+    double s2 = (double)a[2] + (double)a[6];
+    double s3 = (double)a[3] + (double)a[7];
+    double t0 = s0 + s2;
+    double t1 = s1 + s3;
+    return t0 + t1;
+}
+
+static void sums_haswell(const float *x, const float *y, size_t n, double *ab, double *xx, double *yy) {
+    float vab[8] = {0}, vxx[8] = {0}, vyy[8] = {0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        for (int l = 0; l < 8; l++) {
+            float xi = x[i + l], yi = y[i + l];
+            vab[l] = fmaf(xi, yi, vab[l]);
+            vxx[l] = fmaf(xi, xi, vxx[l]);
+            vyy[l] = fmaf(yi, yi, vyy[l]);
+        }
+    }
+    double sab = reduce8_f64(vab), sxx = reduce8_f64(vxx), syy = reduce8_f64(vyy);
+    for (; i < n; i++) {
+        float xi = x[i], yi = y[i];
+        sab += (double)(xi * yi);
+        sxx += (double)(xi * xi);
+        syy += (double)(yi * yi);
+    }
+    *ab = sab; *xx = sxx; *yy = syy;
+}
+
+static float butterfly64(float a[64]) {
+    /* __shfl_xor butterfly, offsets 32,16,8,4,2,1: every lane ends with the same value */
+    float b[64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) b[l] = a[l] + a[l ^ off];
+        memcpy(a, b, sizeof(b));
+    }
+    return a[0];
+}
+
+static void sums_wave64(const float *x, const float *y, size_t n, double *ab, double *xx, double *yy) {
+    /* canonical order of the HIP kernels: lane l owns elements j*256 + 4l .. +3 (one 16 B load per
+     * lane per 1 KiB row chunk), fmaf chain in (j, component) order, then the xor butterfly. */
+    float vab[64], vxx[64], vyy[64];
+    for (int l = 0; l < 64; l++) {
+        float sab = 0.0f, sxx = 0.0f, syy = 0.0f;
+        for (size_t base = (size_t)l * 4; base < n; base += 256) {
+            for (size_t c = 0; c < 4 && base + c < n; c++) {
+                float xi = x[base + c], yi = y[base + c];
+                sab = fmaf(xi, yi, sab);
+                sxx = fmaf(xi, xi, sxx);
+                syy = fmaf(yi, yi, syy);
+            }
+        }
+        vab[l] = sab; vxx[l] = sxx; vyy[l] = syy;
+    }
+    *ab = butterfly64(vab);
+    *xx = butterfly64(vxx);
+    *yy = butterfly64(vyy);
+}
+
+static void sums_d(const float *x, const float *y, size_t n, int order, double *ab, double *xx, double *yy) {
+    switch (order) {
+        case ORC_ORDER_SERIAL: sums_serial(x, y, n, ab, xx, yy); break;
+        case ORC_ORDER_SERIAL_FMA: sums_serial_fma(x, y, n, ab, xx, yy); break;
+        case ORC_ORDER_HASWELL: sums_haswell(x, y, n, ab, xx, yy); break;
+        default: sums_wave64(x, y, n, ab, xx, yy); break;
+    }
+}
+
+void orc_sums(const float *x, const float *y, size_t n, int order, float *ab, float *xx, float *yy) {
+    double a, b, c;
+    sums_d(x, y, n, order, &a, &b, &c);
+    *ab = (float)a; *xx = (float)b; *yy = (float)c;
+}
+
+static float cosine_from_sums_d(double ab, double xx, double yy) {
+    /* SimSIMD cosine distance: a2==b2==0 -> 0; ab==0 -> 1; else clamp(1 - ab/(|a||b|), >= 0).
+     * SimSIMD normalises with rsqrt + one Newton step (hardware approximation, not bit
+     * reproducible); restated with exact f64 sqrt/div.  nidx then does `1.0 - (dist as f32)`
+     * in f32 (dense_f32.rs:32). */
+    double dist;
+    if (xx == 0.0 && yy == 0.0) {
+        dist = 0.0;
+    } else if (ab == 0.0) {
+        dist = 1.0;
+    } else {
+        double d = 1.0 - ab / (sqrt(xx) * sqrt(yy));
+        dist = d > 0.0 ? d : 0.0;
+    }
+    return 1.0f - (float)dist;
+}
+
+float orc_cosine_from_sums(float ab, float xx, float yy) {
+    return cosine_from_sums_d((double)ab, (double)xx, (double)yy);
+}
+
+float orc_dot(const float *x, const float *y, size_t n, int order) {
+    double ab, xx, yy;
+    sums_d(x, y, n, order, &ab, &xx, &yy);
+    return (float)ab; /* dense_f32.rs:38 `as f32` */
+}
+
+float orc_cosine(const float *x, const float *y, size_t n, int order) {
+    double ab, xx, yy;
+    sums_d(x, y, n, order, &ab, &xx, &yy);
+    return cosine_from_sums_d(ab, xx, yy);
+}
+
+float orc_similarity(const float *x, const float *y, size_t n, int similarity, int order) {
+    /* VectorConfig::similarity_function (config.rs:163-168) */
+    return similarity == ORC_SIM_COSINE ? orc_cosine(x, y, n, order) : orc_dot(x, y, n, order);
+}
+
+/* a11. utils::normalize_vector (nidx_vector/src/utils.rs:20-23): f32 sequential fold of x.powi(2) */
+void orc_normalize(const float *in, float *out, size_t n) {
+    float acc = 0.0f;
+    for (size_t i = 0; i < n; i++) acc = acc + in[i] * in[i];
+    float magnitude = sqrtf(acc);
+    for (size_t i = 0; i < n; i++) out[i] = in[i] / magnitude;
+}
+
+/* Rust f32::total_cmp */
+static inline int32_t total_key(float f) {
+    int32_t b;
+    memcpy(&b, &f, 4);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+int orc_total_cmp(float a, float b) {
+    int32_t ka = total_key(a), kb = total_key(b);
+    return (ka > kb) - (ka < kb);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small containers
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t addr; float score; } cnx_t;
+
+/* Ranking order used wherever the reference leaves ties unspecified (sort_unstable, BinaryHeap
+ * on a score-only Ord): higher score first, then LOWER address first.  `better(a,b)` is a strict
+ * total order. */
+static inline int better(cnx_t a, cnx_t b) {
+    int c = orc_total_cmp(a.score, b.score);
+    if (c != 0) return c > 0;
+    return a.addr < b.addr;
+}
+
+typedef struct { cnx_t *d; size_t len, cap; int max_heap; } heap_t;
+
+static void heap_init(heap_t *h, int max_heap) { h->d = NULL; h->len = h->cap = 0; h->max_heap = max_heap; }
+static void heap_free(heap_t *h) { free(h->d); }
+/* top-of-heap predicate: in a max-heap the best element is on top, in a min-heap the worst */
+static inline int heap_above(const heap_t *h, cnx_t a, cnx_t b) { return h->max_heap ? better(a, b) : better(b, a); }
+static void heap_push(heap_t *h, cnx_t v) {
+    if (h->len == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->d = (cnx_t *)realloc(h->d, h->cap * sizeof(cnx_t)); }
+    size_t i = h->len++;
+    h->d[i] = v;
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (!heap_above(h, h->d[i], h->d[p])) break;
+        cnx_t t = h->d[i]; h->d[i] = h->d[p]; h->d[p] = t;
+        i = p;
+    }
+}
+static cnx_t heap_pop(heap_t *h) {
+    cnx_t top = h->d[0];
+    h->d[0] = h->d[--h->len];
+    size_t i = 0;
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < h->len && heap_above(h, h->d[l], h->d[m])) m = l;
+        if (r < h->len && heap_above(h, h->d[r], h->d[m])) m = r;
+        if (m == i) break;
+        cnx_t t = h->d[i]; h->d[i] = h->d[m]; h->d[m] = t;
+        i = m;
+    }
+    return top;
+}
+
+/* open-addressing u32 set (stands for FxHashSet<VectorAddr> / BitSet) */
+typedef struct { uint32_t *slots; size_t cap, len; } u32set_t;
+static void set_init(u32set_t *s, size_t cap_pow2) {
+    s->cap = cap_pow2; s->len = 0;
+    s->slots = (uint32_t *)malloc(cap_pow2 * sizeof(uint32_t));
+    memset(s->slots, 0xff, cap_pow2 * sizeof(uint32_t));
+}
+static void set_free(u32set_t *s) { free(s->slots); }
+static int set_insert(u32set_t *s, uint32_t v); /* returns 1 if newly inserted */
+static void set_grow(u32set_t *s) {
+    u32set_t n;
+    set_init(&n, s->cap * 2);
+    for (size_t i = 0; i < s->cap; i++) if (s->slots[i] != 0xffffffffu) set_insert(&n, s->slots[i]);
+    free(s->slots);
+    *s = n;
+}
+static int set_insert(u32set_t *s, uint32_t v) {
+    if ((s->len + 1) * 2 > s->cap) set_grow(s);
+    size_t i = ((size_t)v * 2654435761u) & (s->cap - 1);
+    while (s->slots[i] != 0xffffffffu) {
+        if (s->slots[i] == v) return 0;
+        i = (i + 1) & (s->cap - 1);
+    }
+    s->slots[i] = v;
+    s->len++;
+    return 1;
+}
+static inline int bit_get(const uint64_t *bits, uint32_t i) { return (int)((bits[i >> 6] >> (i & 63)) & 1u); }
+
+/* ------------------------------------------------------------------------------------------
+ * HNSW graph in RAM (nidx_vector/src/hnsw/ram_hnsw.rs:33-143)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t n_slots;        /* capacity of slot_of */
+    int32_t *slot_of;        /* node -> slot or -1 (node not in this layer) */
+    uint32_t n_present;
+    uint32_t cap_present;
+    uint32_t *node_of;       /* slot -> node */
+    uint32_t **adj;          /* slot -> edges */
+    float **w;               /* slot -> edge weights */
+    uint32_t *deg;
+    uint32_t *acap;
+} layer_t;
+
+struct orc_hnsw {
+    uint32_t n_layers;
+    layer_t *layers;
+    uint32_t ep_node, ep_layer;
+    uint32_t n_nodes;        /* 1 + highest node id added */
+};
+
+orc_hnsw *orc_hnsw_new(void) {
+    orc_hnsw *g = (orc_hnsw *)calloc(1, sizeof(orc_hnsw));
+    return g;
+}
+
+static void layer_free(layer_t *l) {
+    for (uint32_t s = 0; s < l->n_present; s++) { free(l->adj[s]); free(l->w[s]); }
+    free(l->slot_of); free(l->node_of); free(l->adj); free(l->w); free(l->deg); free(l->acap);
+}
+
+void orc_hnsw_free(orc_hnsw *g) {
+    if (!g) return;
+    for (uint32_t l = 0; l < g->n_layers; l++) layer_free(&g->layers[l]);
+    free(g->layers);
+    free(g);
+}
+
+static void layer_add_node(layer_t *l, uint32_t node) {
+    if (node >= l->n_slots) {
+        uint32_t ncap = l->n_slots ? l->n_slots : 1024;
+        while (ncap <= node) ncap *= 2;
+        l->slot_of = (int32_t *)realloc(l->slot_of, ncap * sizeof(int32_t));
+        for (uint32_t i = l->n_slots; i < ncap; i++) l->slot_of[i] = -1;
+        l->n_slots = ncap;
+    }
+    if (l->slot_of[node] >= 0) return;
+    if (l->n_present == l->cap_present) {
+        uint32_t nc = l->cap_present ? l->cap_present * 2 : 256;
+        l->node_of = (uint32_t *)realloc(l->node_of, nc * sizeof(uint32_t));
+        l->adj = (uint32_t **)realloc(l->adj, nc * sizeof(uint32_t *));
+        l->w = (float **)realloc(l->w, nc * sizeof(float *));
+        l->deg = (uint32_t *)realloc(l->deg, nc * sizeof(uint32_t));
+        l->acap = (uint32_t *)realloc(l->acap, nc * sizeof(uint32_t));
+        l->cap_present = nc;
+    }
+    uint32_t s = l->n_present++;
+    l->slot_of[node] = (int32_t)s;
+    l->node_of[s] = node;
+    l->adj[s] = NULL; l->w[s] = NULL; l->deg[s] = 0; l->acap[s] = 0;
+}
+
+static inline int layer_contains(const layer_t *l, uint32_t node) {
+    return node < l->n_slots && l->slot_of[node] >= 0;
+}
+
+static void layer_set_edges(layer_t *l, uint32_t node, const cnx_t *e, uint32_t n) {
+    uint32_t s = (uint32_t)l->slot_of[node];
+    if (n > l->acap[s]) {
+        l->acap[s] = n + 4;
+        l->adj[s] = (uint32_t *)realloc(l->adj[s], l->acap[s] * sizeof(uint32_t));
+        l->w[s] = (float *)realloc(l->w[s], l->acap[s] * sizeof(float));
+    }
+    for (uint32_t i = 0; i < n; i++) { l->adj[s][i] = e[i].addr; l->w[s][i] = e[i].score; }
+    l->deg[s] = n;
+}
+
+/* RAMHnsw::add_node (ram_hnsw.rs:86-95) */
+void orc_hnsw_add_node(orc_hnsw *g, uint32_t node, uint32_t top_layer) {
+    if (g->n_layers <= top_layer) {
+        g->layers = (layer_t *)realloc(g->layers, (top_layer + 1) * sizeof(layer_t));
+        for (uint32_t l = g->n_layers; l <= top_layer; l++) memset(&g->layers[l], 0, sizeof(layer_t));
+        g->n_layers = top_layer + 1;
+    }
+    for (uint32_t l = 0; l <= top_layer; l++) layer_add_node(&g->layers[l], node);
+    if (node + 1 > g->n_nodes) g->n_nodes = node + 1;
+}
+
+/* RAMHnsw::update_entry_point (ram_hnsw.rs:98-107).  The reference takes "the first key of the top
+ * layer's FxHashMap" (hash-iteration order, unspecified); the oracle takes the LOWEST node id of
+ * the top layer. */
+void orc_hnsw_update_entry_point(orc_hnsw *g) {
+    if (g->n_layers > g->ep_layer + 1) {
+        const layer_t *top = &g->layers[g->n_layers - 1];
+        uint32_t best = 0xffffffffu;
+        for (uint32_t s = 0; s < top->n_present; s++) if (top->node_of[s] < best) best = top->node_of[s];
+        g->ep_node = best;
+        g->ep_layer = g->n_layers - 1;
+    }
+}
+
+void orc_hnsw_set_edges(orc_hnsw *g, uint32_t layer, uint32_t node, const uint32_t *edges, const float *w, uint32_t n) {
+    cnx_t *tmp = (cnx_t *)malloc((n ? n : 1) * sizeof(cnx_t));
+    for (uint32_t i = 0; i < n; i++) { tmp[i].addr = edges[i]; tmp[i].score = w ? w[i] : 0.0f; }
+    layer_set_edges(&g->layers[layer], node, tmp, n);
+    free(tmp);
+}
+
+uint32_t orc_hnsw_num_layers(const orc_hnsw *g) { return g->n_layers; }
+uint32_t orc_hnsw_num_nodes(const orc_hnsw *g) { return g->n_nodes; }
+void orc_hnsw_entry_point(const orc_hnsw *g, uint32_t *node, uint32_t *layer) { *node = g->ep_node; *layer = g->ep_layer; }
+void orc_hnsw_set_entry_point(orc_hnsw *g, uint32_t node, uint32_t layer) { g->ep_node = node; g->ep_layer = layer; }
+int orc_hnsw_contains(const orc_hnsw *g, uint32_t layer, uint32_t node) {
+    return layer < g->n_layers && layer_contains(&g->layers[layer], node);
+}
+uint32_t orc_hnsw_edges(const orc_hnsw *g, uint32_t layer, uint32_t node, uint32_t *out, float *w_out, uint32_t cap) {
+    if (!orc_hnsw_contains(g, layer, node)) return 0;
+    const layer_t *l = &g->layers[layer];
+    uint32_t s = (uint32_t)l->slot_of[node];
+    for (uint32_t i = 0; i < l->deg[s] && i < cap; i++) {
+        if (out) out[i] = l->adj[s][i];
+        if (w_out) w_out[i] = l->w[s][i];
+    }
+    return l->deg[s];
+}
+
+/* RAMHnsw::fix_broken_graph (ram_hnsw.rs:118-142) */
+void orc_hnsw_fix_broken_graph(orc_hnsw *g) {
+    for (uint32_t li = 1; li < g->n_layers; li++) {
+        layer_t *l = &g->layers[li];
+        for (uint32_t s = 0; s < l->n_present; s++) {
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < l->deg[s]; i++) {
+                if (layer_contains(l, l->adj[s][i])) { l->adj[s][k] = l->adj[s][i]; l->w[s][k] = l->w[s][i]; k++; }
+            }
+            l->deg[s] = k;
+        }
+    }
+    while (g->n_layers > 0 && g->layers[g->n_layers - 1].n_present == 0) {
+        layer_free(&g->layers[g->n_layers - 1]);
+        g->n_layers--;
+    }
+    if (g->n_layers > 0 && g->ep_layer >= g->n_layers) {
+        g->ep_layer = g->n_layers - 1;
+        const layer_t *top = &g->layers[g->n_layers - 1];
+        if (!layer_contains(top, g->ep_node)) {
+            uint32_t best = 0xffffffffu;
+            for (uint32_t s = 0; s < top->n_present; s++) if (top->node_of[s] < best) best = top->node_of[s];
+            g->ep_node = best;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Retriever (segment.rs:288-357) and HnswSearcher (hnsw/search.rs:174-384)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const orc_segment *seg;
+    const float *query;      /* SearchVector::Query, or stored vector for SearchVector::Stored */
+    float min_score;
+    orc_stats *stats;
+} retr_t;
+
+static inline const float *seg_vec(const orc_segment *seg, uint32_t a) { return seg->vectors + (size_t)a * seg->dim; }
+static inline uint32_t seg_paragraph(const orc_segment *seg, uint32_t a) { return seg->vec_paragraph ? seg->vec_paragraph[a] : a; }
+
+static inline float retr_sim(const retr_t *r, uint32_t a) {
+    if (r->stats) r->stats->distance_evals++;
+    return orc_similarity(seg_vec(r->seg, a), r->query, r->seg->dim, r->seg->similarity, r->seg->order);
+}
+
+/* out-edge access: RAM graph */
+static inline uint32_t graph_edges(const orc_hnsw *g, uint32_t layer, uint32_t node, const uint32_t **edges) {
+    const layer_t *l = &g->layers[layer];
+    if (!layer_contains(l, node)) { *edges = NULL; return 0; }
+    uint32_t s = (uint32_t)l->slot_of[node];
+    *edges = l->adj[s];
+    return l->deg[s];
+}
+
+/* a3. HnswSearcher::layer_search (hnsw/search.rs:242-304).  Heaps pop in the `better` total order
+ * where the reference's score-only Ord leaves ties to BinaryHeap internals. Output: (score desc). */
+static size_t layer_search(const retr_t *r, const orc_hnsw *g, uint32_t layer, size_t k,
+                           const uint32_t *eps, size_t n_ep, cnx_t **out) {
+    u32set_t visited;
+    heap_t cand, res;
+    set_init(&visited, 1024);
+    heap_init(&cand, 1);
+    heap_init(&res, 0);
+    for (size_t i = 0; i < n_ep; i++) {
+        set_insert(&visited, eps[i]);
+        cnx_t c = {eps[i], retr_sim(r, eps[i])};
+        heap_push(&cand, c);
+        heap_push(&res, c);
+    }
+    while (cand.len > 0) {
+        cnx_t c = heap_pop(&cand);
+        float ws = res.d[0].score;
+        if (c.score < ws) break; /* candidate worse than the worst result */
+        const uint32_t *edges;
+        uint32_t deg = graph_edges(g, layer, c.addr, &edges);
+        if (r->stats) { r->stats->expansions++; r->stats->edges_read += deg; }
+        for (uint32_t i = 0; i < deg; i++) {
+            uint32_t y = edges[i];
+            if (!set_insert(&visited, y)) continue;
+            float s = retr_sim(r, y);
+            if (s > ws || res.len < k) {
+                cnx_t n = {y, s};
+                heap_push(&cand, n);
+                heap_push(&res, n);
+                if (res.len > k) heap_pop(&res);
+                ws = res.d[0].score;
+            }
+        }
+    }
+    /* into_sorted_vec of Reverse<_>: descending score */
+    size_t n = res.len;
+    cnx_t *o = (cnx_t *)malloc((n ? n : 1) * sizeof(cnx_t));
+    for (size_t i = n; i-- > 0;) o[i] = heap_pop(&res); /* min-heap pops worst first */
+    *out = o;
+    heap_free(&cand); heap_free(&res); set_free(&visited);
+    return n;
+}
+
+/* NodeFilter::passes + RepCounter (hnsw/search.rs:129-172,386-412) */
+typedef struct {
+    const orc_segment *seg;
+    const uint64_t *filter;
+    int dedupe;              /* !with_duplicates */
+    int multi;
+    const cnx_t *results;    /* accepted so far (their vectors form the RepCounter) */
+    size_t n_results;
+    u32set_t paragraphs;
+} nodefilter_t;
+
+static int filter_passes(nodefilter_t *f, uint32_t v) {
+    uint32_t p = seg_paragraph(f->seg, v);
+    if (f->filter && !bit_get(f->filter, p)) return 0;
+    if (f->dedupe) {
+        const float *vec = seg_vec(f->seg, v);
+        for (size_t i = 0; i < f->n_results; i++)
+            if (memcmp(seg_vec(f->seg, f->results[i].addr), vec, (size_t)f->seg->dim * 4) == 0) return 0;
+    }
+    if (f->multi && !set_insert(&f->paragraphs, p)) return 0;
+    return 1;
+}
+
+static int cmp_cnx_asc(const void *pa, const void *pb) {
+    /* ascending in `better` order reversed: the LAST element is the best */
+    cnx_t a = *(const cnx_t *)pa, b = *(const cnx_t *)pb;
+    if (better(a, b)) return 1;
+    if (better(b, a)) return -1;
+    return 0;
+}
+
+/* a5. closest_up_nodes (hnsw/search.rs:188-240) */
+static size_t closest_up_nodes(const retr_t *r, const orc_hnsw *g, cnx_t *entry, size_t n_entry, size_t k,
+                               nodefilter_t *filter, cnx_t *results) {
+    u32set_t visited;
+    set_init(&visited, 1024);
+    size_t cap = n_entry + 64, len = n_entry;
+    cnx_t *cand = (cnx_t *)malloc(cap * sizeof(cnx_t));
+    memcpy(cand, entry, n_entry * sizeof(cnx_t));
+    for (size_t i = 0; i < n_entry; i++) set_insert(&visited, entry[i].addr);
+    qsort(cand, len, sizeof(cnx_t), cmp_cnx_asc);
+    size_t n_res = 0;
+    while (len > 0) {
+        cnx_t c = cand[--len];
+        if (c.score < r->min_score) break;
+        filter->results = results;
+        filter->n_results = n_res;
+        if (!isnan(c.score) && filter_passes(filter, c.addr)) results[n_res++] = c;
+        if (n_res == k) break;
+        const uint32_t *edges;
+        uint32_t deg = graph_edges(g, 0, c.addr, &edges);
+        if (r->stats) { r->stats->expansions++; r->stats->edges_read += deg; }
+        for (uint32_t i = 0; i < deg; i++) {
+            uint32_t y = edges[i];
+            if (!set_insert(&visited, y)) continue;
+            float s = retr_sim(r, y);
+            if (s >= r->min_score) {
+                if (len == cap) { cap *= 2; cand = (cnx_t *)realloc(cand, cap * sizeof(cnx_t)); }
+                cand[len].addr = y; cand[len].score = s; len++;
+            }
+        }
+        qsort(cand, len, sizeof(cnx_t), cmp_cnx_asc);
+    }
+    free(cand);
+    set_free(&visited);
+    return n_res;
+}
+
+#define EF_SEARCH 30          /* hnsw/params.rs:46 */
+#define EF_CONSTRUCTION 100   /* hnsw/params.rs:43 */
+#define HNSW_M 30             /* hnsw/params.rs:40 */
+#define HNSW_M_MAX 30         /* hnsw/params.rs:37 */
+#define HNSW_M_MAX_0 60       /* hnsw/params.rs:34 */
+
+static void stable_sort_desc(cnx_t *a, size_t n) {
+    /* filtered_result.sort_by(|a, b| b.1.total_cmp(&a.1)) — stable insertion sort */
+    for (size_t i = 1; i < n; i++) {
+        cnx_t v = a[i];
+        size_t j = i;
+        while (j > 0 && orc_total_cmp(a[j - 1].score, v.score) < 0) { a[j] = a[j - 1]; j--; }
+        a[j] = v;
+    }
+}
+
+/* a4. HnswSearcher::search (hnsw/search.rs:306-383), non-RaBitQ branch */
+static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const uint64_t *filter_bits,
+                          int with_duplicates, int multi, cnx_t *results) {
+    if (k == 0 || g->n_layers == 0) return 0;
+    uint32_t layer = g->ep_layer;
+    uint32_t *eps = (uint32_t *)malloc(sizeof(uint32_t));
+    size_t n_ep = 1;
+    eps[0] = g->ep_node;
+    while (layer != 0) {
+        cnx_t *lr;
+        size_t n = layer_search(r, g, layer, 1, eps, n_ep, &lr);
+        eps = (uint32_t *)realloc(eps, (n ? n : 1) * sizeof(uint32_t));
+        for (size_t i = 0; i < n; i++) eps[i] = lr[i].addr;
+        n_ep = n;
+        free(lr);
+        layer--;
+    }
+    size_t last_k = k > EF_SEARCH ? k : EF_SEARCH;
+    cnx_t *neigh;
+    size_t n = layer_search(r, g, 0, last_k, eps, n_ep, &neigh);
+    free(eps);
+    nodefilter_t nf;
+    nf.seg = r->seg; nf.filter = filter_bits; nf.dedupe = !with_duplicates; nf.multi = multi;
+    nf.results = NULL; nf.n_results = 0;
+    set_init(&nf.paragraphs, 64);
+    size_t n_res = closest_up_nodes(r, g, neigh, n, k, &nf, results);
+    set_free(&nf.paragraphs);
+    free(neigh);
+    stable_sort_desc(results, n_res);
+    return n_res;
+}
+
+int orc_layer_search(const orc_segment *seg, const float *query, int query_is_stored, uint32_t stored_addr,
+                     int layer, size_t k, const uint32_t *entry_points, size_t n_ep,
+                     uint32_t *out_vec, float *out_score, orc_stats *stats) {
+    retr_t r = {seg, query_is_stored ? seg_vec(seg, stored_addr) : query, -1.0f, stats};
+    cnx_t *o;
+    size_t n = layer_search(&r, seg->graph, (uint32_t)layer, k, entry_points, n_ep, &o);
+    for (size_t i = 0; i < n; i++) { out_vec[i] = o[i].addr; out_score[i] = o[i].score; }
+    free(o);
+    return (int)n;
+}
+
+int orc_hnsw_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                    size_t k, float min_score, int with_duplicates, int multi_vector,
+                    uint32_t *out_vec, float *out_score, orc_stats *stats) {
+    retr_t r = {seg, query, min_score, stats};
+    const uint64_t *bits = filter ? filter : seg->alive;
+    cnx_t *res = (cnx_t *)malloc((k ? k : 1) * sizeof(cnx_t));
+    size_t n = hnsw_search(&r, seg->graph, k, bits, with_duplicates, multi_vector, res);
+    for (size_t i = 0; i < n; i++) { out_vec[i] = res[i].addr; out_score[i] = res[i].score; }
+    free(res);
+    return (int)n;
+}
+
+/* a6. use_hnsw (segment.rs:626-660) */
+int orc_use_hnsw(size_t total_nodes, size_t matching_nodes, size_t top_k, int has_rabitq) {
+    size_t full_cost, search_mult, rerank_mult;
+    const size_t RERANKING_FACTOR = 100; /* rabitq.rs:30-36 */
+    if (has_rabitq) { full_cost = 16; search_mult = RERANKING_FACTOR * 3 / 4; rerank_mult = RERANKING_FACTOR / 2; }
+    else { full_cost = 1; search_mult = 1; rerank_mult = 0; }
+    float l = logf((float)total_nodes) - 2.0f;
+    float hnsw_rq = (l * l) * logf((float)top_k) * (float)search_mult;
+    size_t hnsw_full = (top_k * rerank_mult) + (top_k * HNSW_M * total_nodes / matching_nodes);
+    size_t bf_rq = matching_nodes;
+    size_t bf_full = top_k * rerank_mult;
+    size_t hnsw_rq_u; /* Rust `as usize`: saturating, NaN -> 0 */
+    if (!(hnsw_rq > 0.0f)) hnsw_rq_u = 0;
+    else if (hnsw_rq >= 18446744073709551615.0f) hnsw_rq_u = SIZE_MAX;
+    else hnsw_rq_u = (size_t)hnsw_rq;
+    size_t hnsw_cost = hnsw_rq_u + hnsw_full * full_cost;
+    size_t bf_cost = bf_rq + bf_full * full_cost;
+    return hnsw_cost < bf_cost;
+}
+
+/* a7. OpenSegment::brute_force_search (segment.rs:569-623), non-RaBitQ branch.
+ * sort_unstable_by leaves ties unspecified -> `better` order (score desc, addr asc). */
+static int cmp_cnx_better_first(const void *pa, const void *pb) { return -cmp_cnx_asc(pa, pb); }
+
+int orc_brute_force_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                           size_t k, float min_score, uint32_t *out_vec, float *out_score) {
+    const uint64_t *bits = filter ? filter : seg->alive;
+    retr_t r = {seg, query, min_score, NULL};
+    size_t cap = 1024, len = 0;
+    cnx_t *scored = (cnx_t *)malloc(cap * sizeof(cnx_t));
+    for (uint32_t p = 0; p < seg->n_paragraphs; p++) {
+        if (bits && !bit_get(bits, p)) continue;
+        uint32_t first = seg->para_first_vec ? seg->para_first_vec[p] : p;
+        uint32_t num = seg->para_num_vec ? seg->para_num_vec[p] : 1;
+        if (num == 0) continue;
+        cnx_t best = {first, retr_sim(&r, first)};
+        for (uint32_t v = first + 1; v < first + num; v++) {
+            float s = retr_sim(&r, v);
+            /* Iterator::max_by returns the LAST maximum */
+            if (orc_total_cmp(s, best.score) >= 0) { best.addr = v; best.score = s; }
+        }
+        if (best.score >= min_score) {
+            if (len == cap) { cap *= 2; scored = (cnx_t *)realloc(scored, cap * sizeof(cnx_t)); }
+            scored[len++] = best;
+        }
+    }
+    qsort(scored, len, sizeof(cnx_t), cmp_cnx_better_first);
+    size_t n = len < k ? len : k;
+    for (size_t i = 0; i < n; i++) { out_vec[i] = scored[i].addr; out_score[i] = scored[i].score; }
+    free(scored);
+    return (int)n;
+}
+
+/* OpenSegment::_search (segment.rs:496-567) */
+int orc_segment_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                       size_t k, float min_score, int with_duplicates,
+                       uint32_t *out_vec, float *out_score, int *method_out) {
+    const uint64_t *bits = filter ? filter : seg->alive;
+    size_t matching = 0;
+    for (uint32_t p = 0; p < seg->n_paragraphs; p++) matching += bits ? (size_t)bit_get(bits, p) : 1;
+    if (method_out) *method_out = 0;
+    if (matching == 0) return 0;
+    if (seg->graph && orc_use_hnsw(seg->n_paragraphs, matching, k, 0)) {
+        if (method_out) *method_out = 1;
+        int n = orc_hnsw_search(seg, query, bits, k, min_score, with_duplicates, 0, out_vec, out_score, NULL);
+        return n > (int)k ? (int)k : n;
+    }
+    if (method_out) *method_out = 2;
+    return orc_brute_force_search(seg, query, bits, k, min_score, out_vec, out_score);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a12. HnswBuilder (hnsw/build.rs:28-167).  Sequential insertion (the reference inserts with
+ * rayon and is non-deterministic, segment.rs:908); graph identity is therefore unpinned.
+ * ------------------------------------------------------------------------------------------ */
+
+/* rand 0.10 SmallRng on 64-bit = Xoshiro256++ seeded through SplitMix64 [third party, restated] */
+typedef struct { uint64_t s[4]; } xoshiro_t;
+static uint64_t splitmix64(uint64_t *state) {
+    uint64_t z = (*state += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static void xoshiro_seed(xoshiro_t *r, uint64_t seed) { for (int i = 0; i < 4; i++) r->s[i] = splitmix64(&seed); }
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t xoshiro_next(xoshiro_t *r) {
+    uint64_t *s = r->s;
+    uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+static double uniform01(xoshiro_t *r) {
+    /* Uniform<f64>::new(0.0, 1.0): 52 random mantissa bits in [1,2) minus 1 */
+    uint64_t bits = (xoshiro_next(r) >> 12) | 0x3ff0000000000000ULL;
+    double d;
+    memcpy(&d, &bits, 8);
+    return (d - 1.0) * 1.0 + 0.0;
+}
+
+/* get_random_layer (build.rs:97-101): round(-ln(u) * 1/ln(M)) — `round`, not floor */
+static uint32_t random_layer(xoshiro_t *r) {
+    double sample = uniform01(r);
+    double picked = -log(sample) * (1.0 / log((double)HNSW_M));
+    double rounded = round(picked);
+    if (!(rounded > 0.0)) return 0;
+    if (rounded > 64.0) return 64;
+    return (uint32_t)rounded;
+}
+
+void orc_hnsw_levels(uint64_t seed, uint32_t n, uint32_t *levels_out) {
+    xoshiro_t r;
+    xoshiro_seed(&r, seed);
+    for (uint32_t i = 0; i < n; i++) levels_out[i] = random_layer(&r);
+}
+
+/* select_neighbours_heuristic (build.rs:57-95) */
+static size_t select_neighbours(const orc_segment *seg, size_t k, const cnx_t *cands, size_t n_cands, cnx_t *results) {
+    size_t n_res = 0;
+    heap_t discarded;
+    heap_init(&discarded, 1);
+    for (size_t i = 0; i < n_cands; i++) {
+        if (n_res == k) break;
+        cnx_t x = cands[i];
+        int check = 1;
+        for (size_t j = 0; j < n_res; j++) {
+            float inter = orc_similarity(seg_vec(seg, x.addr), seg_vec(seg, results[j].addr), seg->dim, seg->similarity, seg->order);
+            if (!(x.score > inter)) { check = 0; break; }
+        }
+        if (check) results[n_res++] = x;
+        else heap_push(&discarded, x);
+    }
+    if (n_res < k) {
+        while (n_res < k && discarded.len > 0) results[n_res++] = heap_pop(&discarded);
+        /* results.sort_unstable_by(|y, x| x.1.total_cmp(&y.1)) -> `better` order */
+        qsort(results, n_res, sizeof(cnx_t), cmp_cnx_better_first);
+    }
+    heap_free(&discarded);
+    return n_res;
+}
+
+static inline uint32_t m_max_for_layer(uint32_t layer) { return layer == 0 ? HNSW_M_MAX_0 : HNSW_M_MAX; }
+static inline size_t prune_m(size_t m) { return m * 95 / 100; }
+
+/* layer_insert (build.rs:104-119) */
+static void layer_insert(const orc_segment *seg, layer_t *layer, uint32_t x, const cnx_t *found, size_t n_found, uint32_t mmax) {
+    cnx_t neigh[HNSW_M + 1];
+    size_t n = select_neighbours(seg, HNSW_M, found, n_found, neigh);
+    layer_set_edges(layer, x, neigh, (uint32_t)n);
+    cnx_t tmp[HNSW_M_MAX_0 + 2], pruned[HNSW_M_MAX_0 + 2];
+    for (size_t i = 0; i < n; i++) {
+        uint32_t y = neigh[i].addr;
+        uint32_t s = (uint32_t)layer->slot_of[y];
+        uint32_t d = layer->deg[s];
+        for (uint32_t j = 0; j < d; j++) { tmp[j].addr = layer->adj[s][j]; tmp[j].score = layer->w[s][j]; }
+        tmp[d].addr = x; tmp[d].score = neigh[i].score;
+        d++;
+        if (d > mmax) {
+            size_t np = select_neighbours(seg, prune_m(mmax), tmp, d, pruned);
+            layer_set_edges(layer, y, pruned, (uint32_t)np);
+        } else {
+            layer_set_edges(layer, y, tmp, d);
+        }
+    }
+}
+
+/* insert (build.rs:121-166) */
+static void hnsw_insert(const orc_segment *seg, orc_hnsw *g, uint32_t node) {
+    retr_t r = {seg, seg_vec(seg, node), -1.0f, NULL};
+    uint32_t *eps = (uint32_t *)malloc(sizeof(uint32_t));
+    size_t n_ep = 1;
+    eps[0] = g->ep_node;
+    cnx_t **found = (cnx_t **)calloc(g->n_layers, sizeof(cnx_t *));
+    size_t *n_found = (size_t *)calloc(g->n_layers, sizeof(size_t));
+    int node_in_layer = 0;
+    for (uint32_t l = g->n_layers; l-- > 0;) {
+        if (!node_in_layer && (l == 0 || layer_contains(&g->layers[l], node))) node_in_layer = 1;
+        size_t k = node_in_layer ? EF_CONSTRUCTION : 1;
+        cnx_t *res;
+        size_t n = layer_search(&r, g, l, k, eps, n_ep, &res);
+        eps = (uint32_t *)realloc(eps, (n ? n : 1) * sizeof(uint32_t));
+        for (size_t i = 0; i < n; i++) eps[i] = res[i].addr;
+        n_ep = n;
+        if (node_in_layer) { found[l] = res; n_found[l] = n; }
+        else free(res);
+    }
+    for (uint32_t l = 0; l < g->n_layers; l++) {
+        if (found[l]) {
+            layer_insert(seg, &g->layers[l], node, found[l], n_found[l], m_max_for_layer(l));
+            free(found[l]);
+        }
+    }
+    free(found); free(n_found); free(eps);
+}
+
+orc_hnsw *orc_hnsw_build(const orc_segment *seg, uint64_t level_seed) {
+    orc_hnsw *g = orc_hnsw_new();
+    xoshiro_t rng;
+    xoshiro_seed(&rng, level_seed);
+    /* initialize_graph (build.rs:50-55) */
+    for (uint32_t i = 0; i < seg->n_vectors; i++) orc_hnsw_add_node(g, i, random_layer(&rng));
+    if (seg->n_vectors == 0) return g;
+    orc_hnsw_update_entry_point(g); /* single layer: stays RAMHnsw::new's default (node 0, layer 0) */
+    for (uint32_t i = 0; i < seg->n_vectors; i++) hnsw_insert(seg, g, i);
+    return g;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a13. DiskHnswV2 byte format (hnsw/disk/v2.rs:16-49,109-245)
+ * ------------------------------------------------------------------------------------------ */
+static inline void put_u32(uint8_t *buf, size_t cap, size_t pos, uint32_t v) {
+    if (buf && pos + 4 <= cap) { buf[pos] = (uint8_t)v; buf[pos + 1] = (uint8_t)(v >> 8); buf[pos + 2] = (uint8_t)(v >> 16); buf[pos + 3] = (uint8_t)(v >> 24); }
+}
+static inline uint32_t get_u32(const uint8_t *buf, size_t pos) {
+    return (uint32_t)buf[pos] | ((uint32_t)buf[pos + 1] << 8) | ((uint32_t)buf[pos + 2] << 16) | ((uint32_t)buf[pos + 3] << 24);
+}
+
+size_t orc_hnsw_serialize_v2(const orc_hnsw *g, uint32_t num_nodes, uint8_t *graph, size_t graph_cap,
+                             float *edges, size_t edges_cap, size_t *n_edges_out) {
+    size_t pos = 0, ne = 0;
+    if (num_nodes == 0) { if (n_edges_out) *n_edges_out = 0; return 0; }
+    size_t *node_end = (size_t *)malloc(num_nodes * sizeof(size_t));
+    size_t *layer_start = (size_t *)malloc((g->n_layers ? g->n_layers : 1) * sizeof(size_t));
+    for (uint32_t node = 0; node < num_nodes; node++) {
+        size_t node_begin = pos;
+        for (uint32_t l = 0; l < g->n_layers; l++) {
+            const uint32_t *e;
+            uint32_t deg = graph_edges(g, l, node, &e);
+            layer_start[l] = pos - node_begin;
+            put_u32(graph, graph_cap, pos, deg); pos += 4;
+            if (deg) {
+                const layer_t *ly = &g->layers[l];
+                uint32_t s = (uint32_t)ly->slot_of[node];
+                for (uint32_t i = 0; i < deg; i++) {
+                    put_u32(graph, graph_cap, pos, e[i]); pos += 4;
+                    if (edges && ne < edges_cap) edges[ne] = ly->w[s][i];
+                    ne++;
+                }
+            }
+        }
+        size_t node_len = (pos - node_begin) + (size_t)g->n_layers * 4;
+        for (uint32_t l = g->n_layers; l-- > 0;) {
+            put_u32(graph, graph_cap, pos, (uint32_t)(node_len - layer_start[l])); pos += 4;
+        }
+        node_end[node] = pos;
+    }
+    for (uint32_t node = num_nodes; node-- > 0;) { put_u32(graph, graph_cap, pos, (uint32_t)node_end[node]); pos += 4; }
+    put_u32(graph, graph_cap, pos, g->ep_layer); pos += 4;
+    put_u32(graph, graph_cap, pos, g->ep_node); pos += 4;
+    free(node_end); free(layer_start);
+    if (n_edges_out) *n_edges_out = ne;
+    return pos;
+}
+
+void orc_disk_v2_entry_point(const uint8_t *graph, size_t len, uint32_t *node, uint32_t *layer) {
+    *node = get_u32(graph, len - 4);
+    *layer = get_u32(graph, len - 8);
+}
+
+uint32_t orc_disk_v2_edges(const uint8_t *graph, size_t len, uint32_t layer, uint32_t node, uint32_t *out, uint32_t cap) {
+    size_t indexing_end = len - 8;
+    size_t pos = indexing_end - ((size_t)node + 1) * 4;
+    size_t node_end = get_u32(graph, pos);
+    size_t lpos = node_end - ((size_t)layer + 1) * 4;
+    size_t off = get_u32(graph, lpos);
+    size_t start = node_end - off;
+    uint32_t n = get_u32(graph, start);
+    for (uint32_t i = 0; i < n && i < cap; i++) out[i] = get_u32(graph, start + 4 + (size_t)i * 4);
+    return n;
+}
+
+orc_hnsw *orc_hnsw_deserialize_v2(const uint8_t *graph, size_t len, const float *edges, size_t n_edges) {
+    orc_hnsw *g = orc_hnsw_new();
+    if (len == 0) return g;
+    size_t end = len, ne = 0;
+    orc_disk_v2_entry_point(graph, len, &g->ep_node, &g->ep_layer);
+    uint32_t node = 0;
+    cnx_t tmp[4096];
+    for (;;) {
+        size_t indexing_pos = end - ((size_t)node + 3) * 4;
+        size_t node_end = get_u32(graph, indexing_pos);
+        uint32_t l = 0;
+        for (;;) {
+            if (g->n_layers == l) {
+                g->layers = (layer_t *)realloc(g->layers, (l + 1) * sizeof(layer_t));
+                memset(&g->layers[l], 0, sizeof(layer_t));
+                g->n_layers = l + 1;
+            }
+            size_t layer_pos = node_end - ((size_t)l + 1) * 4;
+            size_t off = get_u32(graph, layer_pos);
+            size_t start = node_end - off;
+            uint32_t n = get_u32(graph, start);
+            size_t cnx_start = start + 4, cnx_end = cnx_start + (size_t)n * 4;
+            if (l == 0 || n > 0) {
+                layer_add_node(&g->layers[l], node);
+                for (uint32_t i = 0; i < n && i < 4096; i++) {
+                    tmp[i].addr = get_u32(graph, cnx_start + (size_t)i * 4);
+                    tmp[i].score = (edges && ne < n_edges) ? edges[ne] : 0.0f;
+                    ne++;
+                }
+                layer_set_edges(&g->layers[l], node, tmp, n);
+            }
+            if (cnx_end == layer_pos) break;
+            l++;
+        }
+        if (node + 1 > g->n_nodes) g->n_nodes = node + 1;
+        if (node_end == indexing_pos) break;
+        node++;
+    }
+    return g;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9. Searcher::_search + Fssc (searcher.rs:149-199,241-290)
+ * ------------------------------------------------------------------------------------------ */
+int orc_searcher_search(const orc_segment *segs, const uint64_t *const *para_keys, size_t n_segs,
+                        const float *query_in, const uint64_t *const *filters, size_t k, float min_score,
+                        int with_duplicates, int normalize_query, orc_scored_paragraph *out) {
+    if (n_segs == 0) return 0;
+    uint32_t dim = segs[0].dim;
+    float *query = (float *)malloc((size_t)dim * sizeof(float));
+    if (normalize_query) orc_normalize(query_in, query, dim);
+    else memcpy(query, query_in, (size_t)dim * sizeof(float));
+
+    orc_scored_paragraph *buff = (orc_scored_paragraph *)malloc((k + 1) * sizeof(orc_scored_paragraph));
+    size_t n_buff = 0;
+    /* Fssc.seen: vector bytes already offered */
+    size_t seen_cap = 64, n_seen = 0;
+    const float **seen = (const float **)malloc(seen_cap * sizeof(float *));
+    uint32_t *tv = (uint32_t *)malloc((k ? k : 1) * sizeof(uint32_t));
+    float *ts = (float *)malloc((k ? k : 1) * sizeof(float));
+
+    for (size_t s = 0; s < n_segs; s++) {
+        const orc_segment *seg = &segs[s];
+        int n = orc_segment_search(seg, query, filters ? filters[s] : NULL, k, min_score, with_duplicates, tv, ts, NULL);
+        for (int i = 0; i < n; i++) {
+            const float *vec = seg_vec(seg, tv[i]);
+            if (!with_duplicates) {
+                int dup = 0;
+                for (size_t j = 0; j < n_seen; j++) if (memcmp(seen[j], vec, (size_t)dim * 4) == 0) { dup = 1; break; }
+                if (dup) continue;
+                if (n_seen == seen_cap) { seen_cap *= 2; seen = (const float **)realloc(seen, seen_cap * sizeof(float *)); }
+                seen[n_seen++] = vec;
+            }
+            uint32_t p = seg_paragraph(seg, tv[i]);
+            orc_scored_paragraph cand = {para_keys ? para_keys[s][p] : (((uint64_t)s << 32) | p), ts[i], (uint32_t)s, tv[i]};
+            if (n_buff == k) {
+                /* among buffered entries with a lower score than the candidate, evict the lowest */
+                int victim = -1;
+                for (size_t j = 0; j < n_buff; j++) {
+                    if (cand.score > buff[j].score && (victim < 0 || buff[j].score < buff[victim].score)) victim = (int)j;
+                }
+                if (victim < 0) continue;
+                buff[victim] = buff[--n_buff];
+            }
+            /* HashSet::insert keyed by paragraph id: no-op when the id is already buffered */
+            int present = 0;
+            for (size_t j = 0; j < n_buff; j++) if (buff[j].paragraph_key == cand.paragraph_key) { present = 1; break; }
+            if (!present && k > 0) buff[n_buff++] = cand;
+        }
+    }
+    /* sort desc by score; HashSet iteration order is unspecified -> ties by (segment, vector) */
+    for (size_t i = 1; i < n_buff; i++) {
+        orc_scored_paragraph v = buff[i];
+        size_t j = i;
+        while (j > 0) {
+            const orc_scored_paragraph *u = &buff[j - 1];
+            int lower = (u->score < v.score) ||
+                        (u->score == v.score && (u->segment > v.segment || (u->segment == v.segment && u->vector > v.vector)));
+            if (!lower) break;
+            buff[j] = buff[j - 1];
+            j--;
+        }
+        buff[j] = v;
+    }
+    memcpy(out, buff, n_buff * sizeof(orc_scored_paragraph));
+    free(buff); free(seen); free(tv); free(ts); free(query);
+    return (int)n_buff;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a15/a16. BM25 — tantivy 0.26.1 [third party, restated]: K1=1.2, B=0.75, 1-byte fieldnorms.
+ * ------------------------------------------------------------------------------------------ */
+uint32_t orc_fieldnorm_from_id(uint8_t id) {
+    /* FIELD_NORMS_TABLE: 0..=40 exact, then groups of 8 with doubling step (2,4,8,...) */
+    if (id <= 40) return id;
+    uint32_t i = (uint32_t)id - 41;
+    uint32_t grp = i / 8, pos = i % 8;
+    uint64_t base = 24u + ((uint64_t)1 << (grp + 4));
+    uint64_t step = (uint64_t)1 << (grp + 1);
+    return (uint32_t)(base + (uint64_t)(pos + 1) * step);
+}
+
+uint8_t orc_fieldnorm_to_id(uint32_t fieldnorm) {
+    /* largest id whose table value is <= fieldnorm */
+    int lo = 0, hi = 255;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (orc_fieldnorm_from_id((uint8_t)mid) <= fieldnorm) lo = mid; else hi = mid - 1;
+    }
+    return (uint8_t)lo;
+}
+
+#define BM25_K1 1.2f
+#define BM25_B 0.75f
+
+float orc_bm25_idf(uint64_t doc_freq, uint64_t doc_count) {
+    float x = ((float)(doc_count - doc_freq) + 0.5f) / ((float)doc_freq + 0.5f);
+    return logf(1.0f + x);
+}
+
+void orc_bm25_tf_cache(float average_fieldnorm, float cache[256]) {
+    for (int id = 0; id < 256; id++) {
+        float fieldnorm = (float)orc_fieldnorm_from_id((uint8_t)id);
+        cache[id] = BM25_K1 * (1.0f - BM25_B + BM25_B * fieldnorm / average_fieldnorm);
+    }
+}
+
+typedef struct { float score; uint64_t docaddr; } bm_hit_t;
+
+/* TopDocs order: score desc, then DocAddress asc */
+static inline int bm_better(bm_hit_t a, bm_hit_t b) {
+    int c = orc_total_cmp(a.score, b.score);
+    if (c != 0) return c > 0;
+    return a.docaddr < b.docaddr;
+}
+
+/* is_after (nidx_paragraph/src/reader.rs:379-390) */
+static int is_after(const orc_search_after *after, float score, uint64_t docaddr) {
+    if (!after || !after->has_after) return 1;
+    int c = orc_total_cmp(score, after->score);
+    if (c < 0) return 1;
+    if (c > 0) return 0;
+    if (after->tie_break == 0) return 1;
+    if (after->tie_break == 1) return docaddr > after->docaddr;
+    return 0;
+}
+
+int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                    size_t k, const orc_search_after *after, uint32_t segment_ord,
+                    uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+    uint32_t n = idx->n_docs;
+    float *acc = (float *)calloc(n ? n : 1, sizeof(float));
+    uint8_t *should_hit = (uint8_t *)calloc(n ? n : 1, 1);
+    uint16_t *must_cnt = (uint16_t *)calloc(n ? n : 1, sizeof(uint16_t));
+    uint8_t *excluded = (uint8_t *)calloc(n ? n : 1, 1);
+    float cache[256];
+    float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
+    orc_bm25_tf_cache(avg, cache);
+    size_t n_must = 0, n_should = 0;
+    /* term-at-a-time in clause order: per-doc f32 sums accumulate in clause order */
+    for (size_t c = 0; c < n_clauses; c++) {
+        const orc_bm25_clause *cl = &clauses[c];
+        uint64_t b = idx->term_offsets[cl->term], e = idx->term_offsets[cl->term + 1];
+        float weight = 0.0f;
+        if (cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(e - b, idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+        if (cl->occur == ORC_OCCUR_MUST) n_must++;
+        if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
+        for (uint64_t i = b; i < e; i++) {
+            uint32_t d = idx->doc_ids[i];
+            if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
+            float s;
+            if (cl->mode == ORC_CONST_SCORE) s = cl->boost;
+            else {
+                float tf = cl->mode == ORC_TF_BASIC ? 1.0f : (float)idx->tfs[i];
+                s = weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
+            }
+            acc[d] = acc[d] + s;
+            if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++; else should_hit[d] = 1;
+        }
+    }
+    bm_hit_t *top = (bm_hit_t *)malloc((k + 1) * sizeof(bm_hit_t));
+    size_t n_top = 0;
+    uint64_t total = 0;
+    for (uint32_t d = 0; d < n; d++) {
+        if (excluded[d]) continue;
+        if (must_cnt[d] != n_must) continue;
+        if (n_must == 0 && !should_hit[d]) continue;
+        if (idx->alive && !bit_get(idx->alive, d)) continue;
+        total++;
+        uint64_t docaddr = ((uint64_t)segment_ord << 32) | d;
+        float s = acc[d];
+        if (!is_after(after, s, docaddr)) s = -INFINITY; /* tweak_score (reader.rs:350-376) */
+        bm_hit_t h = {s, docaddr};
+        if (k == 0) continue;
+        if (n_top == k && !bm_better(h, top[n_top - 1])) continue;
+        size_t j = n_top < k ? n_top++ : k - 1;
+        while (j > 0 && bm_better(h, top[j - 1])) { top[j] = top[j - 1]; j--; }
+        top[j] = h;
+    }
+    (void)n_should;
+    for (size_t i = 0; i < n_top; i++) { out_docaddr[i] = top[i].docaddr; out_score[i] = top[i].score; }
+    if (total_out) *total_out = total;
+    free(top); free(acc); free(should_hit); free(must_cnt); free(excluded);
+    return (int)n_top;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a18. shard merge (nidx/src/searcher/shard_merge.rs:332-348, 197-250, 274-330) over
+ * itertools::kmerge_by [third party, restated: binary heap of list heads, sift_down]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { size_t list, pos; } head_t;
+typedef int (*less_fn)(const void *ctx, head_t a, head_t b);
+
+static void km_sift_down(head_t *heap, size_t len, size_t index, less_fn less, const void *ctx) {
+    size_t pos = index, child = 2 * pos + 1;
+    while (child + 1 < len) {
+        child += (size_t)(less(ctx, heap[child + 1], heap[child]) != 0);
+        if (!less(ctx, heap[child], heap[pos])) return;
+        head_t t = heap[pos]; heap[pos] = heap[child]; heap[child] = t;
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (child + 1 == len && less(ctx, heap[child], heap[pos])) {
+        head_t t = heap[pos]; heap[pos] = heap[child]; heap[child] = t;
+    }
+}
+
+static size_t kmerge(const size_t *lens, size_t n_lists, size_t limit, less_fn less, const void *ctx, head_t *order_out) {
+    head_t *heap = (head_t *)malloc((n_lists ? n_lists : 1) * sizeof(head_t));
+    size_t len = 0;
+    for (size_t l = 0; l < n_lists; l++) if (lens[l] > 0) { heap[len].list = l; heap[len].pos = 0; len++; }
+    for (size_t i = len / 2; i-- > 0;) km_sift_down(heap, len, i, less, ctx);
+    size_t n_out = 0;
+    while (len > 0 && n_out < limit) {
+        order_out[n_out++] = heap[0];
+        if (heap[0].pos + 1 < lens[heap[0].list]) heap[0].pos++;
+        else { heap[0] = heap[len - 1]; len--; }
+        km_sift_down(heap, len, 0, less, ctx);
+    }
+    free(heap);
+    return n_out;
+}
+
+static int vec_less(const void *ctx, head_t a, head_t b) {
+    const orc_vec_hit *const *lists = (const orc_vec_hit *const *)ctx;
+    return lists[a.list][a.pos].score >= lists[b.list][b.pos].score; /* kmerge_by(|a, b| a.score >= b.score) */
+}
+
+size_t orc_merge_vector(const orc_vec_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_vec_hit *out) {
+    head_t *order = (head_t *)malloc((limit ? limit : 1) * sizeof(head_t));
+    size_t n = kmerge(lens, n_lists, limit, vec_less, lists, order);
+    for (size_t i = 0; i < n; i++) out[i] = lists[order[i].list][order[i].pos];
+    free(order);
+    return n;
+}
+
+static int bytes_cmp(const uint8_t *a, size_t la, const uint8_t *b, size_t lb) {
+    size_t m = la < lb ? la : lb;
+    int c = m ? memcmp(a, b, m) : 0;
+    if (c != 0) return c;
+    return (la > lb) - (la < lb);
+}
+
+static int bm25_less(const void *ctx, head_t a, head_t b) {
+    /* a before b iff bm25.total_cmp, then shard_id cmp, then docaddr reversed is Greater */
+    const orc_bm25_hit *const *lists = (const orc_bm25_hit *const *)ctx;
+    const orc_bm25_hit *x = &lists[a.list][a.pos], *y = &lists[b.list][b.pos];
+    int c = orc_total_cmp(x->bm25, y->bm25);
+    if (c == 0) c = bytes_cmp(x->shard_id, x->shard_id_len, y->shard_id, y->shard_id_len);
+    if (c == 0) c = -((x->docaddr > y->docaddr) - (x->docaddr < y->docaddr));
+    return c > 0;
+}
+
+size_t orc_merge_bm25(const orc_bm25_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_bm25_hit *out) {
+    head_t *order = (head_t *)malloc((limit ? limit : 1) * sizeof(head_t));
+    size_t n = kmerge(lens, n_lists, limit, bm25_less, lists, order);
+    for (size_t i = 0; i < n; i++) out[i] = lists[order[i].list][order[i].pos];
+    free(order);
+    return n;
+}

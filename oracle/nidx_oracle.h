@@ -1,0 +1,194 @@
+/*
+ * nidx_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the arithmetic on nucliadb's nidx search hot path
+ * (nidx_vector HNSW / brute-force k-NN, tantivy-style BM25 scoring, shard merge),
+ * used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+ * the checker for the HIP implementation under nucliadb_amd/.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) that
+ * it follows.  The reference is Rust + two crates.io libraries that are NOT in
+ * /root/reference (simsimd 6.5.16, tantivy 0.26.1; nidx/Cargo.lock:4552-4555,
+ * 4894-4897) and cannot be compiled here (no cargo/rustc, no network), so the
+ * library arithmetic is restated from its published algorithm.
+ *
+ * PARITY PINNING: the oracle is pinned against every golden the reference's own
+ * tests hold for this path (tests/test_oracle_golden.py).  Those
+ * goldens pin ordering, loose score thresholds, recall floors, the HNSW disk
+ * byte format and the shard-merge comparators.  They do NOT pin an exact cosine
+ * bit pattern, any BM25 score value, or HNSW graph identity: for those the
+ * oracle DEFINES the golden value ("parity unpinned" — stated in DESIGN.md).
+ */
+#ifndef NIDX_ORACLE_H
+#define NIDX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- similarity (nidx_vector/src/config.rs:32-37: only Dot and Cosine exist) ---- */
+enum { ORC_SIM_DOT = 0, ORC_SIM_COSINE = 1 };
+
+/* Summation orders for the f32 inner products.  SimSIMD dispatches on the host
+ * CPU at run time, so the reference's own bit pattern is machine dependent; the
+ * orders below are the ones we restate / define:
+ *   SERIAL     SimSIMD's portable macro: f32 accumulators, mul then add, i ascending
+ *   SERIAL_FMA one fmaf chain, i ascending  (== v_mfma_f32_* numerics on gfx950)
+ *   HASWELL    8 f32 FMA lanes, lanes reduced in f64, scalar tail (AVX2 kernel shape)
+ *   WAVE64     the canonical order of the HIP kernels: 64 lanes x float4, 6-step xor butterfly
+ */
+enum { ORC_ORDER_SERIAL = 0, ORC_ORDER_SERIAL_FMA = 1, ORC_ORDER_HASWELL = 2, ORC_ORDER_WAVE64 = 3 };
+
+void orc_sums(const float *x, const float *y, size_t n, int order, float *ab, float *xx, float *yy);
+float orc_dot(const float *x, const float *y, size_t n, int order);
+float orc_cosine(const float *x, const float *y, size_t n, int order);
+float orc_cosine_from_sums(float ab, float xx, float yy);
+float orc_similarity(const float *x, const float *y, size_t n, int similarity, int order);
+void orc_normalize(const float *in, float *out, size_t n);
+
+/* f32 total order used by every sort on the path (Rust f32::total_cmp). */
+int orc_total_cmp(float a, float b);
+
+/* ---- segment: brute force, cost model, HNSW ---- */
+typedef struct orc_hnsw orc_hnsw;
+
+typedef struct {
+    const float *vectors;      /* [n_vectors][dim] contiguous f32 */
+    uint32_t n_vectors;
+    uint32_t dim;
+    int similarity;            /* ORC_SIM_* */
+    int order;                 /* ORC_ORDER_* */
+    const uint32_t *vec_paragraph;   /* [n_vectors] paragraph addr of each vector (NULL => identity) */
+    uint32_t n_paragraphs;
+    const uint32_t *para_first_vec;  /* [n_paragraphs] (NULL => identity, 1 vector each) */
+    const uint32_t *para_num_vec;    /* [n_paragraphs] */
+    const uint64_t *alive;     /* bitset over paragraph addrs, NULL => all alive */
+    const orc_hnsw *graph;     /* may be NULL (brute force only) */
+} orc_segment;
+
+typedef struct {
+    uint64_t distance_evals;   /* similarity() calls */
+    uint64_t expansions;       /* nodes whose edge list was walked */
+    uint64_t edges_read;       /* u32 edge words read */
+} orc_stats;
+
+int orc_use_hnsw(size_t total_nodes, size_t matching_nodes, size_t top_k, int has_rabitq);
+
+/* Returns number of results (<= k). filter: bitset over paragraph addrs or NULL (=> seg->alive). */
+int orc_brute_force_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                           size_t k, float min_score, uint32_t *out_vec, float *out_score);
+int orc_hnsw_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                    size_t k, float min_score, int with_duplicates, int multi_vector,
+                    uint32_t *out_vec, float *out_score, orc_stats *stats);
+/* OpenSegment::_search: routes with orc_use_hnsw. method_out: 0 none, 1 hnsw, 2 brute force */
+int orc_segment_search(const orc_segment *seg, const float *query, const uint64_t *filter,
+                       size_t k, float min_score, int with_duplicates,
+                       uint32_t *out_vec, float *out_score, int *method_out);
+
+/* layer_search exposed for unit tests: returns count, results sorted (score desc, addr asc) */
+int orc_layer_search(const orc_segment *seg, const float *query, int query_is_stored, uint32_t stored_addr,
+                     int layer, size_t k, const uint32_t *entry_points, size_t n_ep,
+                     uint32_t *out_vec, float *out_score, orc_stats *stats);
+
+/* ---- HNSW graph ---- */
+orc_hnsw *orc_hnsw_new(void);
+void orc_hnsw_free(orc_hnsw *g);
+/* Sequential (deterministic) build over seg->vectors, insertion order 0..n-1. */
+orc_hnsw *orc_hnsw_build(const orc_segment *seg, uint64_t level_seed);
+/* Level draw of HnswBuilder::get_random_layer for the first `n` nodes */
+void orc_hnsw_levels(uint64_t seed, uint32_t n, uint32_t *levels_out);
+uint32_t orc_hnsw_num_layers(const orc_hnsw *g);
+uint32_t orc_hnsw_num_nodes(const orc_hnsw *g);
+void orc_hnsw_entry_point(const orc_hnsw *g, uint32_t *node, uint32_t *layer);
+void orc_hnsw_set_entry_point(orc_hnsw *g, uint32_t node, uint32_t layer);
+/* edges of `node` at `layer`: returns degree, copies up to cap entries */
+uint32_t orc_hnsw_edges(const orc_hnsw *g, uint32_t layer, uint32_t node, uint32_t *out, float *w_out, uint32_t cap);
+int orc_hnsw_contains(const orc_hnsw *g, uint32_t layer, uint32_t node);
+void orc_hnsw_add_node(orc_hnsw *g, uint32_t node, uint32_t top_layer);
+void orc_hnsw_set_edges(orc_hnsw *g, uint32_t layer, uint32_t node, const uint32_t *edges, const float *w, uint32_t n);
+void orc_hnsw_update_entry_point(orc_hnsw *g);
+void orc_hnsw_fix_broken_graph(orc_hnsw *g);
+/* DiskHnswV2 byte format. Returns bytes needed; writes when buffers are large enough. */
+size_t orc_hnsw_serialize_v2(const orc_hnsw *g, uint32_t num_nodes, uint8_t *graph, size_t graph_cap,
+                             float *edges, size_t edges_cap, size_t *n_edges_out);
+orc_hnsw *orc_hnsw_deserialize_v2(const uint8_t *graph, size_t len, const float *edges, size_t n_edges);
+/* Reads edges straight from the serialized image (DiskHnswV2::get_out_edges) */
+uint32_t orc_disk_v2_edges(const uint8_t *graph, size_t len, uint32_t layer, uint32_t node, uint32_t *out, uint32_t cap);
+void orc_disk_v2_entry_point(const uint8_t *graph, size_t len, uint32_t *node, uint32_t *layer);
+
+/* ---- Searcher: multi segment merge (Fssc) ---- */
+typedef struct {
+    uint64_t paragraph_key;  /* stands for the paragraph id string (equal string <=> equal key) */
+    float score;
+    uint32_t segment;
+    uint32_t vector;
+} orc_scored_paragraph;
+
+/* segments searched in array order; para_keys[s][paragraph addr] = key id.
+ * Returns count, out sorted by score desc. */
+int orc_searcher_search(const orc_segment *segs, const uint64_t *const *para_keys, size_t n_segs,
+                        const float *query, const uint64_t *const *filters, size_t k, float min_score,
+                        int with_duplicates, int normalize_query, orc_scored_paragraph *out);
+
+/* ---- BM25 (tantivy 0.26.1 restated) ---- */
+uint32_t orc_fieldnorm_from_id(uint8_t id);
+uint8_t orc_fieldnorm_to_id(uint32_t fieldnorm);
+float orc_bm25_idf(uint64_t doc_freq, uint64_t doc_count);
+void orc_bm25_tf_cache(float average_fieldnorm, float cache[256]);
+
+typedef struct {
+    uint32_t n_docs;               /* max_doc: includes deleted docs (statistics do not shrink) */
+    uint64_t total_num_tokens;
+    uint32_t n_terms;
+    const uint64_t *term_offsets;  /* [n_terms+1] into doc_ids/tfs */
+    const uint32_t *doc_ids;       /* ascending per term */
+    const uint32_t *tfs;
+    const uint8_t *fieldnorm_ids;  /* [n_docs] */
+    const uint64_t *alive;         /* bitset or NULL */
+} orc_bm25_index;
+
+enum { ORC_OCCUR_SHOULD = 0, ORC_OCCUR_MUST = 1, ORC_OCCUR_MUST_NOT = 2 };
+enum { ORC_TF_FREQ = 0, ORC_TF_BASIC = 1, ORC_CONST_SCORE = 2 };
+
+typedef struct {
+    uint32_t term;     /* term id in the index */
+    int occur;         /* ORC_OCCUR_* */
+    int mode;          /* ORC_TF_FREQ: BM25 with stored tf; ORC_TF_BASIC: tf == 1; ORC_CONST_SCORE: score = boost */
+    float boost;
+} orc_bm25_clause;
+
+typedef struct {
+    int has_after;
+    float score;
+    int tie_break;     /* 0 keep, 1 keep-after(docaddr), 2 other */
+    uint64_t docaddr;
+} orc_search_after;
+
+/* Returns number of hits written (<= k); total_out = matching alive docs (Count collector). */
+int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                    size_t k, const orc_search_after *after, uint32_t segment_ord,
+                    uint64_t *out_docaddr, float *out_score, uint64_t *total_out);
+
+/* ---- shard merge (nidx/src/searcher/shard_merge.rs) ---- */
+typedef struct {
+    float score;
+    uint64_t id;       /* opaque payload */
+} orc_vec_hit;
+size_t orc_merge_vector(const orc_vec_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_vec_hit *out);
+
+typedef struct {
+    float bm25;
+    uint64_t docaddr;
+    const uint8_t *shard_id;
+    size_t shard_id_len;
+    uint64_t payload;
+} orc_bm25_hit;
+size_t orc_merge_bm25(const orc_bm25_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_bm25_hit *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

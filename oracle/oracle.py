@@ -1,0 +1,522 @@
+"""ctypes wrapper over oracle/_build/libnidx_oracle.so — CPU ORACLE, test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (nucliadb_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libnidx_oracle.so")
+
+SIM_DOT, SIM_COSINE = 0, 1
+ORDER_SERIAL, ORDER_SERIAL_FMA, ORDER_HASWELL, ORDER_WAVE64 = 0, 1, 2, 3
+OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT = 0, 1, 2
+TF_FREQ, TF_BASIC, CONST_SCORE = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "nidx_oracle.c")
+    hdr = os.path.join(_HERE, "nidx_oracle.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class _Segment(C.Structure):
+    _fields_ = [
+        ("vectors", C.c_void_p),
+        ("n_vectors", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("similarity", C.c_int),
+        ("order", C.c_int),
+        ("vec_paragraph", C.c_void_p),
+        ("n_paragraphs", C.c_uint32),
+        ("para_first_vec", C.c_void_p),
+        ("para_num_vec", C.c_void_p),
+        ("alive", C.c_void_p),
+        ("graph", C.c_void_p),
+    ]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("distance_evals", C.c_uint64), ("expansions", C.c_uint64), ("edges_read", C.c_uint64)]
+
+
+class _ScoredParagraph(C.Structure):
+    _fields_ = [("paragraph_key", C.c_uint64), ("score", C.c_float), ("segment", C.c_uint32), ("vector", C.c_uint32)]
+
+
+class _Bm25Index(C.Structure):
+    _fields_ = [
+        ("n_docs", C.c_uint32),
+        ("total_num_tokens", C.c_uint64),
+        ("n_terms", C.c_uint32),
+        ("term_offsets", C.c_void_p),
+        ("doc_ids", C.c_void_p),
+        ("tfs", C.c_void_p),
+        ("fieldnorm_ids", C.c_void_p),
+        ("alive", C.c_void_p),
+    ]
+
+
+class _Bm25Clause(C.Structure):
+    _fields_ = [("term", C.c_uint32), ("occur", C.c_int), ("mode", C.c_int), ("boost", C.c_float)]
+
+
+class _SearchAfter(C.Structure):
+    _fields_ = [("has_after", C.c_int), ("score", C.c_float), ("tie_break", C.c_int), ("docaddr", C.c_uint64)]
+
+
+class _VecHit(C.Structure):
+    _fields_ = [("score", C.c_float), ("id", C.c_uint64)]
+
+
+class _Bm25Hit(C.Structure):
+    _fields_ = [
+        ("bm25", C.c_float),
+        ("docaddr", C.c_uint64),
+        ("shard_id", C.c_void_p),
+        ("shard_id_len", C.c_size_t),
+        ("payload", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    f32p = C.POINTER(C.c_float)
+    L.orc_dot.restype = C.c_float
+    L.orc_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.orc_cosine.restype = C.c_float
+    L.orc_cosine.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.orc_similarity.restype = C.c_float
+    L.orc_similarity.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_cosine_from_sums.restype = C.c_float
+    L.orc_cosine_from_sums.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.orc_sums.restype = None
+    L.orc_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, f32p, f32p, f32p]
+    L.orc_normalize.restype = None
+    L.orc_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_total_cmp.restype = C.c_int
+    L.orc_total_cmp.argtypes = [C.c_float, C.c_float]
+    L.orc_use_hnsw.restype = C.c_int
+    L.orc_use_hnsw.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_brute_force_search.restype = C.c_int
+    L.orc_brute_force_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_hnsw_search.restype = C.c_int
+    L.orc_hnsw_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.POINTER(_Stats)]
+    L.orc_segment_search.restype = C.c_int
+    L.orc_segment_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_layer_search.restype = C.c_int
+    L.orc_layer_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_size_t, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(_Stats)]
+    L.orc_hnsw_new.restype = C.c_void_p
+    L.orc_hnsw_free.argtypes = [C.c_void_p]
+    L.orc_hnsw_build.restype = C.c_void_p
+    L.orc_hnsw_build.argtypes = [C.POINTER(_Segment), C.c_uint64]
+    L.orc_hnsw_levels.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    L.orc_hnsw_num_layers.restype = C.c_uint32
+    L.orc_hnsw_num_layers.argtypes = [C.c_void_p]
+    L.orc_hnsw_num_nodes.restype = C.c_uint32
+    L.orc_hnsw_num_nodes.argtypes = [C.c_void_p]
+    L.orc_hnsw_entry_point.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.orc_hnsw_set_entry_point.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_hnsw_edges.restype = C.c_uint32
+    L.orc_hnsw_edges.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.orc_hnsw_contains.restype = C.c_int
+    L.orc_hnsw_contains.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_hnsw_add_node.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_hnsw_set_edges.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.orc_hnsw_update_entry_point.argtypes = [C.c_void_p]
+    L.orc_hnsw_fix_broken_graph.argtypes = [C.c_void_p]
+    L.orc_hnsw_serialize_v2.restype = C.c_size_t
+    L.orc_hnsw_serialize_v2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]
+    L.orc_hnsw_deserialize_v2.restype = C.c_void_p
+    L.orc_hnsw_deserialize_v2.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.orc_disk_v2_edges.restype = C.c_uint32
+    L.orc_disk_v2_edges.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.orc_disk_v2_entry_point.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.orc_searcher_search.restype = C.c_int
+    L.orc_searcher_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_float, C.c_int, C.c_int, C.POINTER(_ScoredParagraph)]
+    L.orc_fieldnorm_from_id.restype = C.c_uint32
+    L.orc_fieldnorm_from_id.argtypes = [C.c_uint8]
+    L.orc_fieldnorm_to_id.restype = C.c_uint8
+    L.orc_fieldnorm_to_id.argtypes = [C.c_uint32]
+    L.orc_bm25_idf.restype = C.c_float
+    L.orc_bm25_idf.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_bm25_tf_cache.argtypes = [C.c_float, C.c_void_p]
+    L.orc_bm25_search.restype = C.c_int
+    L.orc_bm25_search.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t,
+                                  C.POINTER(_SearchAfter), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_merge_vector.restype = C.c_size_t
+    L.orc_merge_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.orc_merge_bm25.restype = C.c_size_t
+    L.orc_merge_bm25.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- distances
+def dot(x, y, order=ORDER_WAVE64) -> float:
+    x, y = _f32(x), _f32(y)
+    return float(np.float32(lib().orc_dot(_ptr(x), _ptr(y), x.size, order)))
+
+
+def cosine(x, y, order=ORDER_WAVE64) -> float:
+    x, y = _f32(x), _f32(y)
+    return float(np.float32(lib().orc_cosine(_ptr(x), _ptr(y), x.size, order)))
+
+
+def similarity(x, y, sim, order=ORDER_WAVE64) -> float:
+    x, y = _f32(x), _f32(y)
+    return float(np.float32(lib().orc_similarity(_ptr(x), _ptr(y), x.size, sim, order)))
+
+
+def sums(x, y, order=ORDER_WAVE64):
+    x, y = _f32(x), _f32(y)
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_sums(_ptr(x), _ptr(y), x.size, order, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def normalize(x) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_normalize(_ptr(x), _ptr(out), x.size)
+    return out
+
+
+def total_cmp(a: float, b: float) -> int:
+    return lib().orc_total_cmp(a, b)
+
+
+def use_hnsw(total: int, matching: int, k: int, rabitq: bool = False) -> bool:
+    return bool(lib().orc_use_hnsw(total, matching, k, int(rabitq)))
+
+
+def bitset(n: int, ones=None, fill: bool = False) -> np.ndarray:
+    words = np.zeros((n + 63) // 64, dtype=np.uint64)
+    if fill:
+        idx = np.arange(n)
+    elif ones is not None:
+        idx = np.asarray(list(ones), dtype=np.int64)
+    else:
+        idx = np.zeros(0, dtype=np.int64)
+    if idx.size:
+        np.bitwise_or.at(words, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+    return words
+
+
+# ---------------------------------------------------------------- HNSW graph
+class Hnsw:
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_hnsw_free(self.h)
+            self.h = None
+
+    @staticmethod
+    def new() -> "Hnsw":
+        return Hnsw(lib().orc_hnsw_new())
+
+    @property
+    def num_layers(self) -> int:
+        return lib().orc_hnsw_num_layers(self.h)
+
+    @property
+    def num_nodes(self) -> int:
+        return lib().orc_hnsw_num_nodes(self.h)
+
+    @property
+    def entry_point(self):
+        n, l = C.c_uint32(), C.c_uint32()
+        lib().orc_hnsw_entry_point(self.h, C.byref(n), C.byref(l))
+        return n.value, l.value
+
+    def set_entry_point(self, node, layer):
+        lib().orc_hnsw_set_entry_point(self.h, node, layer)
+
+    def add_node(self, node, top_layer):
+        lib().orc_hnsw_add_node(self.h, node, top_layer)
+
+    def set_edges(self, layer, node, edges, weights=None):
+        e = np.ascontiguousarray(edges, dtype=np.uint32)
+        w = None if weights is None else _f32(weights)
+        lib().orc_hnsw_set_edges(self.h, layer, node, _ptr(e), _ptr(w), e.size)
+
+    def contains(self, layer, node) -> bool:
+        return bool(lib().orc_hnsw_contains(self.h, layer, node))
+
+    def edges(self, layer, node):
+        e = np.empty(256, dtype=np.uint32)
+        w = np.empty(256, dtype=np.float32)
+        n = lib().orc_hnsw_edges(self.h, layer, node, _ptr(e), _ptr(w), 256)
+        return e[:n].copy(), w[:n].copy()
+
+    def update_entry_point(self):
+        lib().orc_hnsw_update_entry_point(self.h)
+
+    def fix_broken_graph(self):
+        lib().orc_hnsw_fix_broken_graph(self.h)
+
+    def serialize_v2(self, num_nodes=None):
+        """-> (hnsw.graph bytes, hnsw.edges f32 array)"""
+        n = self.num_nodes if num_nodes is None else num_nodes
+        ne = C.c_size_t()
+        size = lib().orc_hnsw_serialize_v2(self.h, n, None, 0, None, 0, C.byref(ne))
+        graph = np.zeros(size, dtype=np.uint8)
+        edges = np.zeros(ne.value, dtype=np.float32)
+        lib().orc_hnsw_serialize_v2(self.h, n, _ptr(graph), size, _ptr(edges), edges.size, C.byref(ne))
+        return graph, edges
+
+    @staticmethod
+    def deserialize_v2(graph: np.ndarray, edges: np.ndarray | None = None) -> "Hnsw":
+        graph = np.ascontiguousarray(graph, dtype=np.uint8)
+        e = None if edges is None else _f32(edges)
+        return Hnsw(lib().orc_hnsw_deserialize_v2(_ptr(graph), graph.size, _ptr(e), 0 if e is None else e.size))
+
+    def to_csr(self, layer: int, n: int):
+        """(offsets[n+1] u64, edges u32) of one layer, for uploading to the device index."""
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        chunks = []
+        for i in range(n):
+            e, _ = self.edges(layer, i)
+            chunks.append(e)
+            offs[i + 1] = offs[i] + e.size
+        return offs, (np.concatenate(chunks) if chunks else np.zeros(0, np.uint32)).astype(np.uint32)
+
+
+def hnsw_levels(seed: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint32)
+    lib().orc_hnsw_levels(seed, n, _ptr(out))
+    return out
+
+
+def disk_v2_edges(graph: np.ndarray, layer: int, node: int) -> np.ndarray:
+    out = np.empty(256, dtype=np.uint32)
+    n = lib().orc_disk_v2_edges(_ptr(graph), graph.size, layer, node, _ptr(out), 256)
+    return out[:n].copy()
+
+
+def disk_v2_entry_point(graph: np.ndarray):
+    n, l = C.c_uint32(), C.c_uint32()
+    lib().orc_disk_v2_entry_point(_ptr(graph), graph.size, C.byref(n), C.byref(l))
+    return n.value, l.value
+
+
+# ---------------------------------------------------------------- segment
+@dataclass
+class Stats:
+    distance_evals: int = 0
+    expansions: int = 0
+    edges_read: int = 0
+
+
+class Segment:
+    """One vector segment as the reference's OpenSegment sees it (segment.rs:39-90)."""
+
+    def __init__(self, vectors, similarity=SIM_COSINE, order=ORDER_WAVE64, vec_paragraph=None, para_first_vec=None,
+                 para_num_vec=None, alive=None, graph: Hnsw | None = None, n_paragraphs=None):
+        self.vectors = _f32(vectors)
+        assert self.vectors.ndim == 2
+        self.n, self.dim = self.vectors.shape
+        self.similarity, self.order = similarity, order
+        self.vec_paragraph = None if vec_paragraph is None else np.ascontiguousarray(vec_paragraph, dtype=np.uint32)
+        self.para_first_vec = None if para_first_vec is None else np.ascontiguousarray(para_first_vec, dtype=np.uint32)
+        self.para_num_vec = None if para_num_vec is None else np.ascontiguousarray(para_num_vec, dtype=np.uint32)
+        self.n_paragraphs = self.n if n_paragraphs is None else n_paragraphs
+        self.alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint64)
+        self.graph = graph
+
+    def c(self) -> _Segment:
+        s = _Segment()
+        s.vectors = self.vectors.ctypes.data
+        s.n_vectors, s.dim = self.n, self.dim
+        s.similarity, s.order = self.similarity, self.order
+        s.vec_paragraph = None if self.vec_paragraph is None else self.vec_paragraph.ctypes.data
+        s.n_paragraphs = self.n_paragraphs
+        s.para_first_vec = None if self.para_first_vec is None else self.para_first_vec.ctypes.data
+        s.para_num_vec = None if self.para_num_vec is None else self.para_num_vec.ctypes.data
+        s.alive = None if self.alive is None else self.alive.ctypes.data
+        s.graph = None if self.graph is None else self.graph.h
+        return s
+
+    def build_graph(self, seed: int = 2) -> Hnsw:
+        cs = self.c()
+        self.graph = Hnsw(lib().orc_hnsw_build(C.byref(cs), seed))
+        return self.graph
+
+    def brute_force(self, query, k, min_score=-1.0, filter_bits=None):
+        q = _f32(query)
+        ov, os_ = np.empty(max(k, 1), np.uint32), np.empty(max(k, 1), np.float32)
+        cs = self.c()
+        n = lib().orc_brute_force_search(C.byref(cs), _ptr(q), _ptr(filter_bits), k, min_score, _ptr(ov), _ptr(os_))
+        return ov[:n].copy(), os_[:n].copy()
+
+    def hnsw_search(self, query, k, min_score=-1.0, with_duplicates=True, filter_bits=None, multi=False, stats: Stats | None = None):
+        q = _f32(query)
+        ov, os_ = np.empty(max(k, 1), np.uint32), np.empty(max(k, 1), np.float32)
+        cs = self.c()
+        st = _Stats()
+        n = lib().orc_hnsw_search(C.byref(cs), _ptr(q), _ptr(filter_bits), k, min_score, int(with_duplicates), int(multi),
+                                  _ptr(ov), _ptr(os_), C.byref(st))
+        if stats is not None:
+            stats.distance_evals += st.distance_evals
+            stats.expansions += st.expansions
+            stats.edges_read += st.edges_read
+        return ov[:n].copy(), os_[:n].copy()
+
+    def search(self, query, k, min_score=-1.0, with_duplicates=True, filter_bits=None):
+        """OpenSegment::_search: cost-model routed. -> (vec addrs, scores, method)"""
+        q = _f32(query)
+        ov, os_ = np.empty(max(k, 1), np.uint32), np.empty(max(k, 1), np.float32)
+        cs = self.c()
+        m = C.c_int()
+        n = lib().orc_segment_search(C.byref(cs), _ptr(q), _ptr(filter_bits), k, min_score, int(with_duplicates),
+                                     _ptr(ov), _ptr(os_), C.byref(m))
+        return ov[:n].copy(), os_[:n].copy(), {0: "none", 1: "hnsw", 2: "brute force"}[m.value]
+
+    def layer_search(self, query, layer, k, entry_points, stored_addr=None):
+        q = _f32(query) if query is not None else np.zeros(self.dim, np.float32)
+        eps = np.ascontiguousarray(entry_points, dtype=np.uint32)
+        ov, os_ = np.empty(max(k, eps.size, 1), np.uint32), np.empty(max(k, eps.size, 1), np.float32)
+        cs = self.c()
+        n = lib().orc_layer_search(C.byref(cs), _ptr(q), int(stored_addr is not None), stored_addr or 0, layer, k,
+                                   _ptr(eps), eps.size, _ptr(ov), _ptr(os_), None)
+        return ov[:n].copy(), os_[:n].copy()
+
+
+def searcher_search(segments, para_keys, query, k, min_score=-1.0, with_duplicates=False, normalize_query=False, filters=None):
+    """Searcher::_search across segments with the Fssc merge. -> list of (key, score, segment, vector)"""
+    n = len(segments)
+    segs = (_Segment * n)(*[s.c() for s in segments])
+    keys = [np.ascontiguousarray(k_, dtype=np.uint64) for k_ in para_keys]
+    key_ptrs = (C.c_void_p * n)(*[k_.ctypes.data for k_ in keys])
+    fl = None
+    if filters is not None:
+        fl = (C.c_void_p * n)(*[None if f is None else f.ctypes.data for f in filters])
+    q = _f32(query)
+    out = (_ScoredParagraph * max(k, 1))()
+    m = lib().orc_searcher_search(segs, key_ptrs, n, _ptr(q), fl, k, min_score, int(with_duplicates), int(normalize_query), out)
+    return [(out[i].paragraph_key, float(np.float32(out[i].score)), out[i].segment, out[i].vector) for i in range(m)]
+
+
+# ---------------------------------------------------------------- BM25
+def fieldnorm_table() -> np.ndarray:
+    return np.array([lib().orc_fieldnorm_from_id(i) for i in range(256)], dtype=np.uint32)
+
+
+def fieldnorm_to_id(n: int) -> int:
+    return lib().orc_fieldnorm_to_id(n)
+
+
+def bm25_idf(doc_freq: int, doc_count: int) -> float:
+    return float(np.float32(lib().orc_bm25_idf(doc_freq, doc_count)))
+
+
+def bm25_tf_cache(avg: float) -> np.ndarray:
+    out = np.empty(256, np.float32)
+    lib().orc_bm25_tf_cache(avg, _ptr(out))
+    return out
+
+
+class Bm25Index:
+    def __init__(self, term_offsets, doc_ids, tfs, fieldnorm_ids, total_num_tokens, alive=None):
+        self.term_offsets = np.ascontiguousarray(term_offsets, dtype=np.uint64)
+        self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.uint32)
+        self.tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
+        self.fieldnorm_ids = np.ascontiguousarray(fieldnorm_ids, dtype=np.uint8)
+        self.total_num_tokens = int(total_num_tokens)
+        self.alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint64)
+
+    def c(self) -> _Bm25Index:
+        s = _Bm25Index()
+        s.n_docs = self.fieldnorm_ids.size
+        s.total_num_tokens = self.total_num_tokens
+        s.n_terms = self.term_offsets.size - 1
+        s.term_offsets = self.term_offsets.ctypes.data
+        s.doc_ids = self.doc_ids.ctypes.data
+        s.tfs = self.tfs.ctypes.data
+        s.fieldnorm_ids = self.fieldnorm_ids.ctypes.data
+        s.alive = None if self.alive is None else self.alive.ctypes.data
+        return s
+
+    def search(self, clauses, k, after=None, segment_ord=0):
+        """clauses: list of (term, occur, mode, boost). -> (docaddr u64[], score f32[], total)"""
+        cl = (_Bm25Clause * max(len(clauses), 1))()
+        for i, (t, o, m, b) in enumerate(clauses):
+            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = t, o, m, b
+        sa = _SearchAfter()
+        if after is not None:
+            sa.has_after, sa.score, sa.tie_break, sa.docaddr = 1, after[0], after[1], after[2]
+        od, os_ = np.empty(max(k, 1), np.uint64), np.empty(max(k, 1), np.float32)
+        total = C.c_uint64()
+        ci = self.c()
+        n = lib().orc_bm25_search(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(od), _ptr(os_), C.byref(total))
+        return od[:n].copy(), os_[:n].copy(), total.value
+
+
+# ---------------------------------------------------------------- shard merge
+def merge_vector(lists, limit):
+    """lists: list of [(score, id)] each sorted desc. -> merged [(score, id)]"""
+    n = len(lists)
+    arrs = [(_VecHit * max(len(l), 1))(*[_VecHit(s, i) for s, i in l]) for l in lists]
+    ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(a) for a in arrs])
+    lens = (C.c_size_t * max(n, 1))(*[len(l) for l in lists])
+    out = (_VecHit * max(limit, 1))()
+    m = lib().orc_merge_vector(ptrs, lens, n, limit, out)
+    return [(float(np.float32(out[i].score)), out[i].id) for i in range(m)]
+
+
+def merge_bm25(lists, limit):
+    """lists: list of [(bm25, docaddr, shard_id bytes, payload)]. -> merged list of the same tuples"""
+    n = len(lists)
+    keep = []
+    arrs = []
+    for l in lists:
+        a = (_Bm25Hit * max(len(l), 1))()
+        for i, (s, d, sid, p) in enumerate(l):
+            buf = C.create_string_buffer(bytes(sid), len(sid))
+            keep.append(buf)
+            a[i].bm25, a[i].docaddr, a[i].shard_id, a[i].shard_id_len, a[i].payload = s, d, C.addressof(buf), len(sid), p
+        arrs.append(a)
+    ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(a) for a in arrs])
+    lens = (C.c_size_t * max(n, 1))(*[len(l) for l in lists])
+    out = (_Bm25Hit * max(limit, 1))()
+    m = lib().orc_merge_bm25(ptrs, lens, n, limit, out)
+    res = []
+    for i in range(m):
+        sid = C.string_at(out[i].shard_id, out[i].shard_id_len) if out[i].shard_id_len else b""
+        res.append((float(np.float32(out[i].bm25)), out[i].docaddr, sid, out[i].payload))
+    return res
