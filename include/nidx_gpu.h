@@ -1,0 +1,260 @@
+/*
+ * nidx_gpu.h — C ABI of the MI355X-native nidx search hot path (libnidx_gpu.so).
+ *
+ * This is the drop-in boundary: the plain-C surface a Rust `extern "C"` shim
+ * (or ctypes / cgo) binds in place of the L3→L2 Rust trait calls of the reference.  Each entry
+ * point cites the reference interface it replaces (paths relative to /root/reference/nidx/).
+ *
+ * Conventions
+ *  - every function returns int32: 0 = NIDX_OK, <0 = error code; the message of the last error
+ *    on the calling thread is read with nidx_gpu_last_error().  No exceptions / panics cross
+ *    the ABI.
+ *  - handles are opaque, immutable after open, and safe to use from many host threads
+ *    (the reference's searchers are `Sync + Send` Arc's in an LRU cache,
+ *    src/searcher/index_cache.rs:164-177); calls on one handle are serialised on one HIP stream.
+ *  - "host" pointers are ordinary process memory, "device" pointers are HBM addresses on the
+ *    device the handle was opened on (hipMalloc / a torch tensor's data_ptr()).
+ *  - outputs are caller-owned buffers.
+ *  - no torch / C++ types in any signature.
+ */
+#ifndef NIDX_GPU_H
+#define NIDX_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: mirror nidx_vector::VectorErr (nidx_vector/src/lib.rs:202-234) ---- */
+#define NIDX_OK 0
+#define NIDX_ERR_IO (-1)
+#define NIDX_ERR_INCONSISTENT_DIMENSIONS (-2) /* VectorErr::InconsistentDimensions (searcher.rs:255-262) */
+#define NIDX_ERR_INVALID_CONFIGURATION (-3)   /* VectorErr::InvalidConfiguration (config.rs:190-198) */
+#define NIDX_ERR_EMPTY_MERGE (-4)             /* VectorErr::EmptyMerge */
+#define NIDX_ERR_INVALID_ARGUMENT (-5)
+#define NIDX_ERR_UNSUPPORTED (-6)
+#define NIDX_ERR_DEVICE (-7)                  /* HIP runtime error, or no gfx950 device present */
+#define NIDX_ERR_INVALID_GRAPH (-8)           /* malformed hnsw.graph image */
+#define NIDX_ERR_INEXACT (-9)                 /* a bounded on-chip pool overflowed: result would differ from the reference */
+
+/* Copies the calling thread's last error message (NUL terminated) and returns its length. */
+int32_t nidx_gpu_last_error(char *buf, size_t len);
+/* ABI version of this header; bumped on any signature change. */
+int32_t nidx_gpu_abi_version(void);
+int32_t nidx_gpu_device_count(int32_t *count_out);
+/* Selects the HIP device used by handles opened afterwards on this thread (one process per GPU). */
+int32_t nidx_gpu_set_device(int32_t device);
+
+/* =====================================================================================
+ * Vector index — replaces nidx_vector::VectorSearcher / VectorIndexer
+ * (nidx_vector/src/lib.rs:65-148) and everything under them on the hot path.
+ * ===================================================================================== */
+
+enum { NIDX_SIMILARITY_DOT = 0, NIDX_SIMILARITY_COSINE = 1 }; /* config.rs:32-37 — the only two */
+enum { NIDX_CARDINALITY_SINGLE = 0, NIDX_CARDINALITY_MULTI = 1 };
+
+/* Summation order of the f32 inner products (see DESIGN.md "numerics").  The reference's own
+ * order is whatever SimSIMD dispatches to on the host CPU; ours is fixed per kernel family. */
+enum {
+    NIDX_ORDER_WAVE64 = 3,     /* 64 lanes x float4, fmaf chain, xor butterfly (scan + HNSW kernels) */
+    NIDX_ORDER_SERIAL_FMA = 1  /* one k-ordered fmaf chain (f32 MFMA kernels) */
+};
+
+/* VectorConfig (nidx_vector/src/config.rs:102-124) — the fields the hot path reads. */
+typedef struct {
+    uint32_t dimension;          /* VectorType::DenseF32 { dimension } */
+    int32_t similarity;          /* NIDX_SIMILARITY_* */
+    int32_t normalize_vectors;   /* normalise the QUERY at search time (searcher.rs:246-252) */
+    int32_t vector_cardinality;  /* NIDX_CARDINALITY_*; only SINGLE is implemented */
+} nidx_gpu_vector_config_t;
+
+/* One open segment as the reference has it after segment::open + apply_deletions
+ * (nidx_vector/src/segment.rs:39-90, 428-445): the caller passes the mmap'd files as they lie. */
+typedef struct {
+    /* vectors.bin (data_store/v2/vector_store.rs:30-40,131-147): n_vectors rows, each
+     * `dimension` f32 LE followed — when row_stride_bytes == 4*dimension+4 — by the u32
+     * paragraph address.  A packed [n][dimension] f32 matrix is row_stride_bytes == 4*dimension. */
+    const void *vectors;
+    uint64_t row_stride_bytes;
+    uint32_t n_vectors;
+    /* paragraph address of each vector; NULL => read from the row trailer, or identity when packed */
+    const uint32_t *paragraph_of_vector;
+    uint32_t n_paragraphs;
+    /* hnsw.graph image (hnsw/disk/v2.rs:16-49); NULL/0 => no graph (brute force only) until
+     * nidx_gpu_vector_build_hnsw is called */
+    const uint8_t *hnsw_graph;
+    uint64_t hnsw_graph_len;
+    /* alive bitset over paragraph addresses after apply_deletions (segment.rs:81,428-445);
+     * bit i = word[i>>6] >> (i&63).  NULL => all alive */
+    const uint64_t *alive_bitset;
+    /* 64-bit identity of each paragraph key (equal key string <=> equal id) used by the
+     * cross-segment merge Fssc (searcher.rs:67-96,175-198); NULL => ids unique per segment */
+    const uint64_t *paragraph_key_ids;
+} nidx_gpu_vector_segment_t;
+
+typedef struct nidx_gpu_vector_index nidx_gpu_vector_index_t;
+
+/* VectorSearcher::open (lib.rs:126-130): uploads every segment to HBM.  Segments are searched in
+ * array order, like Searcher::_search's sequential loop (searcher.rs:270-287). */
+int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_gpu_vector_segment_t *segments,
+                             uint32_t n_segments, nidx_gpu_vector_index_t **index_out);
+void nidx_gpu_vector_close(nidx_gpu_vector_index_t *index);
+/* VectorSearcher::space_usage (lib.rs:141-143): bytes of HBM held by the handle. */
+int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64_t *bytes_out);
+int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint32_t *n_out);
+int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out);
+
+enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2 };
+
+/* The request fields the hot path reads (nidx_vector/src/request_types.rs:19-35). */
+typedef struct {
+    uint32_t k;               /* result_per_page (no_results) */
+    float min_score;
+    int32_t with_duplicates;  /* proto default false => dedupe by vector bytes */
+    int32_t method;           /* NIDX_METHOD_AUTO = the use_hnsw cost model (segment.rs:626-660) */
+} nidx_gpu_vector_search_params_t;
+
+/* VectorSearcher::search for a BATCH of queries (the reference takes one query per call,
+ * searcher.rs:241-290; a batch is n independent calls).  Host buffers, synchronous.
+ *   queries           [n_queries][dimension] f32
+ *   segment_filters   NULL, or n_segments pointers (each NULL or a bitset over that segment's
+ *                     paragraph addresses) = inverted_indexes.filter(formula), already ANDed
+ *                     with nothing: the alive bitset is applied here (segment.rs:516-529)
+ *   out_segment/out_paragraph/out_vector/out_score   [n_queries][k]; rows hold out_count[q] hits,
+ *                     score descending (Fssc -> Vec, searcher.rs:156-161)
+ *   out_method        NULL or [n_segments]: NIDX_METHOD_* chosen per segment (same for every query)
+ * Errors: NIDX_ERR_INCONSISTENT_DIMENSIONS is raised by nidx_gpu_vector_search_dim. */
+int32_t nidx_gpu_vector_search(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                               const nidx_gpu_vector_search_params_t *params,
+                               const uint64_t *const *segment_filters, uint32_t *out_segment,
+                               uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                               uint32_t *out_count, int32_t *out_method);
+/* Same, checking the query length like Searcher::_search (searcher.rs:255-262). */
+int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                                   uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
+                                   const uint64_t *const *segment_filters, uint32_t *out_segment,
+                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                                   uint32_t *out_count, int32_t *out_method);
+
+/* OpenSegment::search on ONE segment with everything resident in HBM (segment.rs:477-567):
+ * device pointers, asynchronous on `stream` (a hipStream_t; NULL = the null stream).
+ *   d_queries [n_queries][dimension] f32 (already normalised if the index wants that)
+ *   d_filter  NULL or device bitset over paragraph addrs (ANDed with alive on device)
+ *   d_out_vector/d_out_score [n_queries][k], d_out_count [n_queries]
+ *   d_stats   NULL or [n_queries][4] u32: distance evals, expansions, visited-set peak, flags */
+int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment,
+                                              const float *d_queries, uint32_t n_queries,
+                                              const nidx_gpu_vector_search_params_t *params,
+                                              const uint64_t *d_filter, uint32_t *d_out_vector,
+                                              float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats,
+                                              void *stream);
+
+/* use_hnsw (segment.rs:626-660) — exposed so callers can route exactly like the reference. */
+int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq);
+
+/* Pairwise similarity of rows (host in/out), the numerics of dense_f32::{dot,cosine}_similarity
+ * (vector_types/dense_f32.rs:29-39) in the given summation order: out[i] = sim(x[i], y[i]). */
+int32_t nidx_gpu_similarity(const float *x, const float *y, uint32_t n_pairs, uint32_t dimension,
+                            int32_t similarity, int32_t order, float *out);
+/* utils::normalize_vector (utils.rs:20-23) for n rows, host in/out. */
+int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, float *out);
+
+/* HnswBuilder (hnsw/build.rs:28-167) on the device for one segment of an open index: level
+ * draw from SmallRng::seed_from_u64(level_seed) (build.rs:36-55; the reference uses 2), batched
+ * concurrent inserts with M=30/M0=60/efC=100 (hnsw/params.rs:20-46).  Replaces any graph the
+ * segment had.  Like the reference's rayon build the graph is not unique; parity is recall. */
+int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed);
+/* DiskHnswV2::serialize_to (hnsw/disk/v2.rs:109-218): writes the segment's graph as hnsw.graph /
+ * hnsw.edges bytes.  Call with NULL buffers to get the sizes. */
+int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *graph_out,
+                                       uint64_t graph_cap, uint64_t *graph_len_out, float *edges_out,
+                                       uint64_t edges_cap, uint64_t *n_edges_out);
+
+/* =====================================================================================
+ * BM25 index — replaces the tantivy scoring under TextSearcher::search
+ * (nidx_text/src/reader.rs:367-451) and ParagraphSearcher::search
+ * (nidx_paragraph/src/reader.rs:244-348): term-at-a-time BM25 + TopDocs.
+ * ===================================================================================== */
+
+/* One tantivy segment's postings for the scored text field, already term-id resolved. */
+typedef struct {
+    uint32_t n_docs;              /* max_doc (deleted docs included: statistics do not shrink) */
+    uint64_t total_num_tokens;    /* Σ fieldnorm over docs (tantivy FieldNormReader totals) */
+    uint32_t n_terms;
+    const uint64_t *term_offsets; /* [n_terms+1] into doc_ids / tfs */
+    const uint32_t *doc_ids;      /* ascending within a term */
+    const uint32_t *tfs;          /* term frequency per posting */
+    const uint8_t *fieldnorm_ids; /* [n_docs] 1-byte fieldnorm ids */
+    const uint64_t *alive_bitset; /* open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74); NULL = all */
+} nidx_gpu_bm25_segment_t;
+
+typedef struct nidx_gpu_bm25_index nidx_gpu_bm25_index_t;
+
+int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments,
+                           nidx_gpu_bm25_index_t **index_out);
+void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index);
+int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *bytes_out);
+
+enum { NIDX_OCCUR_SHOULD = 0, NIDX_OCCUR_MUST = 1, NIDX_OCCUR_MUST_NOT = 2 };
+/* NIDX_TF_FREQ: BM25 with the stored tf (nidx_text, IndexRecordOption::WithFreqs);
+ * NIDX_TF_BASIC: tf == 1 (nidx_paragraph keyword terms, query_parser/keyword_parser.rs:62-67);
+ * NIDX_CONST_SCORE: ConstScorer(boost) (prefilter SetQuery, nidx_paragraph/src/search_query.rs:105-139) */
+enum { NIDX_TF_FREQ = 0, NIDX_TF_BASIC = 1, NIDX_CONST_SCORE = 2 };
+
+typedef struct {
+    uint32_t term;   /* term id (per-index dictionary order; the same id in every segment) */
+    int32_t occur;   /* NIDX_OCCUR_* */
+    int32_t mode;    /* NIDX_TF_* / NIDX_CONST_SCORE */
+    float boost;
+} nidx_gpu_bm25_clause_t;
+
+/* search-after cursor (nidx_paragraph/src/reader.rs:350-390) */
+typedef struct {
+    int32_t has_after;
+    float score;
+    int32_t tie_break;   /* 0: keep all ties, 1: keep docaddr > cursor, 2: drop ties */
+    uint64_t docaddr;
+} nidx_gpu_bm25_search_after_t;
+
+/* A batch of BooleanQuery's over term clauses, TopDocs::with_limit(k).order_by_score() + Count
+ * (nidx_text/src/reader.rs:433-435).  Query q owns clauses[clause_offsets[q] .. clause_offsets[q+1]).
+ *   after            NULL or [n_queries]
+ *   out_docaddr      [n_queries][k]  (segment_ord << 32) | doc_id  (nidx_text/src/reader.rs:310)
+ *   out_score        [n_queries][k]  score desc, docaddr asc on ties
+ *   out_count        [n_queries]     hits written
+ *   out_total        [n_queries]     matching alive docs (Count collector)
+ *   out_postings     NULL or [n_queries]: postings scored (the BASELINE "docs scored" unit) */
+int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses,
+                             const uint64_t *clause_offsets, uint32_t n_queries, uint32_t k,
+                             const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr,
+                             float *out_score, uint32_t *out_count, uint64_t *out_total,
+                             uint64_t *out_postings);
+
+/* tantivy Bm25Weight pieces, exposed for the host query layer and for tests. */
+float nidx_gpu_bm25_idf(uint64_t doc_freq, uint64_t doc_count);
+uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id);
+uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm);
+
+/* =====================================================================================
+ * Shard merge — replaces src/searcher/shard_merge.rs:197-348 (host side; the multi-GPU
+ * exchange that feeds it is an RCCL all-gather driven from the host language).
+ * ===================================================================================== */
+
+/* merge_vector_responses (shard_merge.rs:332-348): kmerge_by(a.score >= b.score).take(limit).
+ * lists[i] = scores of shard i (sorted desc), ids[i] = their payloads. Returns count in *n_out. */
+int32_t nidx_gpu_merge_vector(const float *const *scores, const uint64_t *const *ids, const uint32_t *lens,
+                              uint32_t n_lists, uint32_t limit, float *out_score, uint64_t *out_id,
+                              uint32_t *out_list, uint32_t *n_out);
+/* sort_documents_fn / sort_paragraphs_fn (shard_merge.rs:211-234,289-312): a before b iff
+ * bm25 greater (total_cmp), else shard_id greater (bytes), else docaddr smaller. */
+int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *docaddrs, const uint32_t *lens,
+                            const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists,
+                            uint32_t limit, float *out_score, uint64_t *out_docaddr, uint32_t *out_list,
+                            uint32_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIDX_GPU_H */

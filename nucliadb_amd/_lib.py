@@ -1,0 +1,168 @@
+"""ctypes binding of libnidx_gpu.so (include/nidx_gpu.h).
+
+The library is the product: there is no Python / CPU fallback.  Importing this module on a machine
+where the shared object is missing raises ImportError, and every compute entry point raises
+NidxGpuError(NIDX_ERR_DEVICE) when no gfx950 device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnidx_gpu.so")
+
+NIDX_OK = 0
+NIDX_ERR_IO = -1
+NIDX_ERR_INCONSISTENT_DIMENSIONS = -2
+NIDX_ERR_INVALID_CONFIGURATION = -3
+NIDX_ERR_EMPTY_MERGE = -4
+NIDX_ERR_INVALID_ARGUMENT = -5
+NIDX_ERR_UNSUPPORTED = -6
+NIDX_ERR_DEVICE = -7
+NIDX_ERR_INVALID_GRAPH = -8
+NIDX_ERR_INEXACT = -9
+
+SIMILARITY_DOT, SIMILARITY_COSINE = 0, 1
+METHOD_AUTO, METHOD_HNSW, METHOD_BRUTE_FORCE = 0, 1, 2
+ORDER_WAVE64, ORDER_SERIAL_FMA = 3, 1
+OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT = 0, 1, 2
+TF_FREQ, TF_BASIC, CONST_SCORE = 0, 1, 2
+
+
+class NidxGpuError(RuntimeError):
+    """An error code returned across the C ABI (the analogue of nidx_vector::VectorErr)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class VectorConfigC(C.Structure):
+    _fields_ = [
+        ("dimension", C.c_uint32),
+        ("similarity", C.c_int32),
+        ("normalize_vectors", C.c_int32),
+        ("vector_cardinality", C.c_int32),
+    ]
+
+
+class VectorSegmentC(C.Structure):
+    _fields_ = [
+        ("vectors", C.c_void_p),
+        ("row_stride_bytes", C.c_uint64),
+        ("n_vectors", C.c_uint32),
+        ("paragraph_of_vector", C.c_void_p),
+        ("n_paragraphs", C.c_uint32),
+        ("hnsw_graph", C.c_void_p),
+        ("hnsw_graph_len", C.c_uint64),
+        ("alive_bitset", C.c_void_p),
+        ("paragraph_key_ids", C.c_void_p),
+    ]
+
+
+class VectorSearchParamsC(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32),
+        ("min_score", C.c_float),
+        ("with_duplicates", C.c_int32),
+        ("method", C.c_int32),
+    ]
+
+
+class Bm25SegmentC(C.Structure):
+    _fields_ = [
+        ("n_docs", C.c_uint32),
+        ("total_num_tokens", C.c_uint64),
+        ("n_terms", C.c_uint32),
+        ("term_offsets", C.c_void_p),
+        ("doc_ids", C.c_void_p),
+        ("tfs", C.c_void_p),
+        ("fieldnorm_ids", C.c_void_p),
+        ("alive_bitset", C.c_void_p),
+    ]
+
+
+class Bm25ClauseC(C.Structure):
+    _fields_ = [("term", C.c_uint32), ("occur", C.c_int32), ("mode", C.c_int32), ("boost", C.c_float)]
+
+
+class Bm25SearchAfterC(C.Structure):
+    _fields_ = [("has_after", C.c_int32), ("score", C.c_float), ("tie_break", C.c_int32), ("docaddr", C.c_uint64)]
+
+
+# name -> (restype, argtypes); the list every `-m "not gpu"` export test walks.
+SIGNATURES = {
+    "nidx_gpu_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
+    "nidx_gpu_abi_version": (C.c_int32, []),
+    "nidx_gpu_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "nidx_gpu_set_device": (C.c_int32, [C.c_int32]),
+    "nidx_gpu_vector_open": (C.c_int32, [C.POINTER(VectorConfigC), C.POINTER(VectorSegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "nidx_gpu_vector_close": (None, [C.c_void_p]),
+    "nidx_gpu_vector_space_usage": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "nidx_gpu_vector_num_segments": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_segment_records": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_vector_search_dim": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(VectorSearchParamsC),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_vector_segment_search_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                          C.POINTER(VectorSearchParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_use_hnsw": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
+    "nidx_gpu_similarity": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]),
+    "nidx_gpu_normalize": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nidx_gpu_vector_build_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "nidx_gpu_vector_serialize_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                                   C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nidx_gpu_bm25_open": (C.c_int32, [C.POINTER(Bm25SegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "nidx_gpu_bm25_close": (None, [C.c_void_p]),
+    "nidx_gpu_bm25_space_usage": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "nidx_gpu_bm25_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_idf": (C.c_float, [C.c_uint64, C.c_uint64]),
+    "nidx_gpu_fieldnorm_from_id": (C.c_uint32, [C.c_uint8]),
+    "nidx_gpu_fieldnorm_to_id": (C.c_uint8, [C.c_uint32]),
+    "nidx_gpu_merge_vector": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libnidx_gpu.so (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib().nidx_gpu_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != NIDX_OK:
+        raise NidxGpuError(rc, last_error())
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = lib().nidx_gpu_device_count(C.byref(n))
+    return n.value if rc == NIDX_OK else 0

@@ -1,0 +1,157 @@
+// device_common.h — shared device helpers for the gfx950 kernels of libnidx_gpu.
+//
+// Numerics contract (DESIGN.md "numerics"): every inner product on the scan/HNSW path is summed in
+// the WAVE64 order — lane l owns elements j*256+4l..+3 (one 16-byte load per lane per 1 KiB row
+// chunk), an fmaf chain in (j, component) order per lane, then a 6-step xor butterfly (offsets
+// 32,16,8,4,2,1) so that every lane holds the same f32 sum.  The file is compiled with
+// -ffp-contract=off: every FMA below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NIDX_WAVE 64
+
+namespace nidx {
+
+// f32::total_cmp key (Rust): monotone int32 image of an f32 bit pattern.
+__host__ __device__ inline int32_t total_key(float f) {
+    int32_t b = __builtin_bit_cast(int32_t, f);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+
+// Strict total order used wherever the reference leaves ties to container internals
+// (BinaryHeap on a score-only Ord, sort_unstable): higher score first, then LOWER address.
+// Packed as one u64 so that a > b  <=>  a ranks before b.
+__host__ __device__ inline uint64_t rank_key(float score, uint32_t addr) {
+    uint32_t k = (uint32_t)total_key(score) ^ 0x80000000u;  // unsigned-monotone
+    return ((uint64_t)k << 32) | (uint64_t)(~addr);
+}
+__host__ __device__ inline float rank_key_score(uint64_t key) {
+    uint32_t k = (uint32_t)(key >> 32) ^ 0x80000000u;
+    int32_t b = (int32_t)k;
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return __builtin_bit_cast(float, b);
+}
+__host__ __device__ inline uint32_t rank_key_addr(uint64_t key) { return ~(uint32_t)key; }
+// The empty slot: ranks after every real entry (real keys have addr != 0xffffffff or score bits > 0).
+#define NIDX_EMPTY_KEY 0ull
+
+// xor butterfly: every lane ends with the same value, pairing a[l] + a[l^off] at each level.
+__device__ inline float wave_butterfly_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint64_t shfl_up_u64(uint64_t v, int delta) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// dense_f32::cosine_similarity (vector_types/dense_f32.rs:29-34) on pre-summed f32 terms:
+// SimSIMD distance semantics (zero-norm cases, clamp >= 0) evaluated in f64, then `1.0 - (d as f32)`.
+__host__ __device__ inline float cosine_from_sums(float ab, float xx, float yy) {
+    double dab = (double)ab, dxx = (double)xx, dyy = (double)yy;
+    double dist;
+    if (dxx == 0.0 && dyy == 0.0) {
+        dist = 0.0;
+    } else if (dab == 0.0) {
+        dist = 1.0;
+    } else {
+        double d = 1.0 - dab / (sqrt(dxx) * sqrt(dyy));
+        dist = d > 0.0 ? d : 0.0;
+    }
+    return 1.0f - (float)dist;
+}
+
+__device__ inline bool bit_test(const uint64_t *bits, uint32_t i) { return (bits[i >> 6] >> (i & 63)) & 1ull; }
+
+// A sorted (best first) list of up to 64 (score, addr) entries held one per lane as rank keys.
+// insert() keeps the 64 best; returns the key that fell off the end (NIDX_EMPTY_KEY if none).
+struct WaveSortedList {
+    uint64_t key;  // lane i holds rank i
+    __device__ inline void init() { key = NIDX_EMPTY_KEY; }
+    __device__ inline uint64_t insert(uint64_t nk, int lane) {
+        // position = number of entries ranking before nk
+        unsigned long long before = __ballot(key > nk);
+        int pos = __popcll(before);
+        uint64_t dropped = shfl_u64(key, 63);
+        uint64_t up = shfl_up_u64(key, 1);
+        if (lane > pos) key = up;
+        if (lane == pos) key = nk;
+        return pos >= 64 ? nk : dropped;
+    }
+    __device__ inline uint64_t at(int rank) const { return shfl_u64(key, rank); }
+};
+
+// ---- transposed multi-value butterfly -------------------------------------------------------
+// Reduces QT per-lane partial sums across the wave with one shuffle per PAIR of values at the
+// first log2(QT) levels.  Value v ends up (identically) in every lane l with query_of_lane(l) == v,
+// and equals bit for bit what wave_butterfly_sum would give for it (same pairs a[l] + a[l^off]).
+template <int QT>
+struct QReduce;
+
+template <>
+struct QReduce<1> {
+    static __device__ inline float run(float (&a)[1], int) { return wave_butterfly_sum(a[0]); }
+    static __device__ inline int query_of_lane(int) { return 0; }
+    static __device__ inline int group_mask() { return 63; }
+};
+
+template <int QT>
+struct QReduce {
+    // Halving levels: at offset `off` lanes with (lane & off) keep the upper half of the query set.
+    static __device__ inline float run(float (&a)[QT], int lane) {
+        float v[QT];
+#pragma unroll
+        for (int i = 0; i < QT; i++) v[i] = a[i];
+        int off = 32;
+#pragma unroll
+        for (int n = QT; n > 1; n >>= 1, off >>= 1) {
+            const bool up = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < n / 2; i++) {
+                float keep = up ? v[i + n / 2] : v[i];
+                float send = up ? v[i] : v[i + n / 2];
+                v[i] = keep + __shfl_xor(send, off, 64);
+            }
+        }
+        float r = v[0];
+        for (; off >= 1; off >>= 1) r = r + __shfl_xor(r, off, 64);
+        return r;
+    }
+    static __device__ inline int query_of_lane(int lane) {
+        int q = 0, off = 32;
+#pragma unroll
+        for (int n = QT; n > 1; n >>= 1, off >>= 1)
+            if (lane & off) q += n / 2;
+        return q;
+    }
+    // lanes with (lane & group_mask()) == 0 lead a group that shares one query's value
+    static __device__ inline int group_mask() { return (64 / QT) - 1; }
+};
+
+__device__ inline float4 load_row_chunk(const float *row, uint32_t dp, int j, int lane) {
+    uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+    if (e < dp) return *reinterpret_cast<const float4 *>(row + e);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ inline float fma4(const float4 &x, const float4 &y, float acc) {
+    acc = fmaf(x.x, y.x, acc);
+    acc = fmaf(x.y, y.y, acc);
+    acc = fmaf(x.z, y.z, acc);
+    acc = fmaf(x.w, y.w, acc);
+    return acc;
+}
+
+}  // namespace nidx

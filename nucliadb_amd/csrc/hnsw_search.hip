@@ -1,0 +1,240 @@
+// hnsw_search.hip — batched HNSW k-NN query kernel (gfx950): one workgroup per query.
+//
+// Replaces HnswSearcher::search (nidx_vector/src/hnsw/search.rs:306-383, non-RaBitQ branch):
+//   greedy descent with k=1 through the upper layers, layer-0 search with ef = max(k, EF_SEARCH),
+//   closest_up_nodes (filter / de-duplication / min_score walk), final stable sort by score.
+// Bound: HBM (random 4*D-byte row gathers + 256-byte edge records).  Algorithmic bytes per query =
+// evals * 4*D + expansions * 256 (both counted by the kernel).
+#include "hnsw_device.h"
+
+namespace nidx {
+
+// Vector bytes equal?  (RepCounter keys on the stored bytes, search.rs:386-412.)  Wave-0 only.
+template <int NJ>
+__device__ inline bool rows_equal(const SegDev &seg, uint32_t a, uint32_t b, int lane) {
+    const float *ra = seg.vectors + (size_t)a * seg.dp, *rb = seg.vectors + (size_t)b * seg.dp;
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+        if (e < seg.dp) {
+            uint4 x = *reinterpret_cast<const uint4 *>(ra + e);
+            uint4 y = *reinterpret_cast<const uint4 *>(rb + e);
+            eq = eq && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+        }
+    }
+    return __all(eq);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
+    uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
+    __shared__ uint32_t res_addr[64];
+    __shared__ float res_score[64];
+
+    const int lane = threadIdx.x & 63;
+    const bool ctl = (threadIdx.x >> 6) == 0;
+    const uint32_t qi = blockIdx.x;
+    const bool cosine = a.seg.similarity == 1;
+    const int k = (int)a.k;
+
+    QueryRegs<NJ> q;
+    load_query<NJ>(q, a.queries + (size_t)qi * a.seg.dp, a.seg.dp, lane, cosine);
+
+    SearchCounters st = {0, 0, 0, 0};
+    WaveTopK<1> res;
+    res.init();
+
+    // ---- upper layers: k = 1 (search.rs:318-324) ----
+    if (threadIdx.x == 0) {
+        sh.eps[0] = a.g.ep_node;
+        sh.ctrl[2] = 1;
+    }
+    __syncthreads();
+    for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
+        layer_search_block<NJ, 1>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
+        if (ctl) {
+            uint64_t key = res.l[0].key;
+            if (lane < res.len) sh.eps[lane] = rank_key_addr(key);
+            if (lane == 0) sh.ctrl[2] = res.len;
+        }
+        __syncthreads();
+    }
+    // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
+    const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
+    layer_search_block<NJ, 1>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
+
+    // ---- closest_up_nodes (search.rs:188-240) ----
+    // candidates = the ef neighbours; visited = exactly those; pop best, accept if it passes the
+    // filter, stop at k accepted, otherwise expand its unvisited layer-0 neighbours that score
+    // >= min_score.
+    const uint32_t vis_cap = 1u << a.vis_log2;
+    vis_clear(vis, vis_cap);
+    __syncthreads();
+    int pool_len = 0, n_res = 0;
+    uint32_t vis_count = 0;
+    uint64_t dropped_best = NIDX_EMPTY_KEY;
+    if (ctl) {
+        uint64_t key = res.l[0].key;
+        if (lane < res.len) {
+            vis_insert(vis, a.vis_log2, rank_key_addr(key));
+            sh.pool[lane] = key;
+        }
+        pool_len = res.len;
+        vis_count = res.len;
+    }
+    for (;;) {
+        if (ctl) {
+            int cont = 0, n_new = 0;
+            uint64_t ck = pool_pop(sh.pool, pool_len, lane);
+            if (ck != NIDX_EMPTY_KEY) {
+                float cs = rank_key_score(ck);
+                uint32_t c = rank_key_addr(ck);
+                if (dropped_best > ck) st.flags |= NIDX_FLAG_POOL_INEXACT;
+                if (!(cs < a.min_score)) {
+                    bool accept = !(cs != cs);
+                    if (accept) {
+                        uint32_t p = a.seg.para_of_vec ? a.seg.para_of_vec[c] : c;
+                        if (a.seg.alive && !bit_test(a.seg.alive, p)) accept = false;
+                        if (accept && a.filter && !bit_test(a.filter, p)) accept = false;
+                    }
+                    if (accept && !a.with_duplicates) {
+                        // identical bytes => identical score bits: only then compare the rows
+                        for (int i = 0; i < n_res && accept; i++) {
+                            if (__builtin_bit_cast(uint32_t, res_score[i]) == __builtin_bit_cast(uint32_t, cs) &&
+                                rows_equal<NJ>(a.seg, res_addr[i], c, lane))
+                                accept = false;
+                        }
+                    }
+                    if (accept) {
+                        if (lane == 0) {
+                            res_addr[n_res] = c;
+                            res_score[n_res] = cs;
+                        }
+                        n_res++;
+                    }
+                    if (n_res < k) {
+                        cont = 1;
+                        uint32_t deg;
+                        uint32_t w = load_edge_word(a.g, c, 0, lane, deg);
+                        bool is_edge = lane >= 1 && lane <= (int)deg;
+                        bool fresh = is_edge && vis_insert(vis, a.vis_log2, w);
+                        unsigned long long m = __ballot(fresh);
+                        int pos = __popcll(m & ((1ull << lane) - 1ull));
+                        if (fresh) sh.nb_addr[pos] = w;
+                        n_new = __popcll(m);
+                        st.expansions++;
+                        vis_count += n_new;
+                        if (vis_count > vis_cap - vis_cap / 4) {
+                            st.flags |= NIDX_FLAG_VISITED_OVERFLOW;
+                            cont = 0;
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+                sh.ctrl[0] = cont;
+                sh.ctrl[1] = n_new;
+            }
+        }
+        __syncthreads();
+        if (!sh.ctrl[0]) break;
+        int n_new = sh.ctrl[1];
+        eval_neighbours<NJ>(a.seg, q, sh, n_new, cosine);
+        __syncthreads();
+        if (ctl && n_new > 0) {
+            float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
+            uint32_t addr = sh.nb_addr[lane];
+            st.evals += n_new;
+            unsigned long long todo = __ballot(lane < n_new && s >= a.min_score);
+            while (todo) {
+                int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                uint64_t nk = rank_key(__shfl(s, j, 64), __shfl(addr, j, 64));
+                if (pool_len == NIDX_POOL_CAP) {
+                    // evict the worst candidate; remember the best one ever evicted so that popping
+                    // past it is reported instead of silently diverging from the reference
+                    uint64_t worst = ~0ull;
+                    for (int i = lane; i < pool_len; i += 64) worst = sh.pool[i] < worst ? sh.pool[i] : worst;
+                    worst = wave_min_u64(worst);
+                    if (nk < worst) {
+                        dropped_best = nk > dropped_best ? nk : dropped_best;
+                        continue;
+                    }
+                    dropped_best = worst > dropped_best ? worst : dropped_best;
+                    int idx = 0x7fffffff;
+                    for (int i = lane; i < pool_len; i += 64)
+                        if (sh.pool[i] == worst && i < idx) idx = i;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        int o = __shfl_xor(idx, off, 64);
+                        idx = o < idx ? o : idx;
+                    }
+                    if (lane == 0) sh.pool[idx] = nk;
+                } else {
+                    if (lane == 0) sh.pool[pool_len] = nk;
+                    pool_len++;
+                }
+            }
+        }
+    }
+
+    // ---- filtered_result.sort_by(|a, b| b.1.total_cmp(&a.1)) — stable (search.rs:381) ----
+    if (ctl) {
+        st.visited = st.visited > vis_count ? st.visited : vis_count;
+        float s = lane < n_res ? res_score[lane] : 0.f;
+        uint32_t ad = lane < n_res ? res_addr[lane] : 0xffffffffu;
+        int32_t key = total_key(s);
+        int rank = 0;
+        for (int j = 0; j < n_res; j++) {
+            int32_t kj = __shfl(key, j, 64);
+            rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
+        }
+        if (lane < n_res) {
+            a.out_vec[(size_t)qi * k + rank] = ad;
+            a.out_score[(size_t)qi * k + rank] = s;
+        }
+        if (lane >= n_res && lane < k) {
+            a.out_vec[(size_t)qi * k + lane] = 0xffffffffu;
+            a.out_score[(size_t)qi * k + lane] = 0.f;
+        }
+        if (lane == 0) {
+            a.out_count[qi] = (uint32_t)n_res;
+            if (a.stats) {
+                a.stats[(size_t)qi * 4 + NIDX_STAT_EVALS] = st.evals;
+                a.stats[(size_t)qi * 4 + NIDX_STAT_EXPANSIONS] = st.expansions;
+                a.stats[(size_t)qi * 4 + NIDX_STAT_VISITED] = st.visited;
+                a.stats[(size_t)qi * 4 + NIDX_STAT_FLAGS] = st.flags;
+            }
+        }
+    }
+}
+
+template <int NJ>
+static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
+    size_t smem = sizeof(SearchShared) + ((size_t)4 << a.vis_log2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((hnsw_search_kernel<NJ>), dim3(a.n_queries), dim3(64 * waves), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
+    if (a.n_queries == 0) return hipSuccess;
+    int nj = (int)((a.seg.dp + 255u) / 256u);
+    if (waves_per_query < 1) waves_per_query = 1;
+    if (waves_per_query > 4) waves_per_query = 4;
+    if (nj <= 1) return launch_nj<1>(a, waves_per_query, s);
+    if (nj <= 2) return launch_nj<2>(a, waves_per_query, s);
+    if (nj <= 3) return launch_nj<3>(a, waves_per_query, s);
+    if (nj <= 4) return launch_nj<4>(a, waves_per_query, s);
+    if (nj <= 6) return launch_nj<6>(a, waves_per_query, s);
+    if (nj <= 8) return launch_nj<8>(a, waves_per_query, s);
+    if (nj <= 12) return launch_nj<12>(a, waves_per_query, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace nidx

@@ -1,0 +1,56 @@
+// host_common.h — error plumbing and small RAII helpers for the C ABI implementation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nidx_gpu.h"
+
+namespace nidx {
+
+void set_error(const char *fmt, ...);
+int32_t fail(int32_t code, const char *fmt, ...);
+int32_t hip_fail(hipError_t e, const char *what);
+
+#define NIDX_HIP(expr)                                         \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return ::nidx::hip_fail(_e, #expr); \
+    } while (0)
+
+// Device buffer that frees itself; tracks bytes for space_usage().
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    // grow-only scratch
+    hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(n); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace nidx

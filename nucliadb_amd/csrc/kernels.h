@@ -1,0 +1,87 @@
+// kernels.h — host-visible launch interfaces of the gfx950 kernels (internal to libnidx_gpu).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nidx {
+
+// ---- exact scan (vector_scan.hip) ----
+struct ScanArgs {
+    const float *vectors;         // [n][dp]
+    const float *norm2;           // [n] WAVE64-order |x|^2 (cosine) or nullptr
+    uint32_t n, dp;
+    const float *queries;         // [n_queries][dp], zero padded
+    uint32_t n_queries;
+    const uint64_t *alive;        // bitset over paragraph addrs or nullptr
+    const uint64_t *filter;       // bitset over paragraph addrs or nullptr
+    const uint32_t *para_of_vec;  // nullptr = identity
+    int similarity;               // 0 dot, 1 cosine
+    float min_score;
+    uint32_t k;                   // <= 64
+    uint32_t qt;                  // query tile (filled by launch_scan)
+    uint64_t *partial;            // [n_queries][nblk][k] rank keys
+};
+uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp);
+uint32_t scan_num_blocks(uint32_t n);
+hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s);
+hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
+                             uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s);
+hipError_t launch_row_norms(const float *vectors, uint32_t n, uint32_t dp, float *norm2, hipStream_t s);
+hipError_t launch_pair_similarity(const float *x, const float *y, uint32_t n, uint32_t dp, int similarity, float *out,
+                                  hipStream_t s);
+
+// ---- HNSW graph in HBM ----
+// layer 0: fixed 256-byte records [deg, e0..e59, pad x3]; upper layers: 128-byte records
+// [deg, e0..e29, pad]; a node with top layer L >= 1 owns L consecutive upper records starting at
+// upper_base[node] (record of layer l is upper_base[node] + l - 1).
+#define NIDX_L0_STRIDE 64
+#define NIDX_UP_STRIDE 32
+#define NIDX_M 30          /* hnsw/params.rs:40 */
+#define NIDX_M_MAX 30      /* hnsw/params.rs:37 */
+#define NIDX_M_MAX0 60     /* hnsw/params.rs:34 */
+#define NIDX_EF_CONSTRUCTION 100 /* hnsw/params.rs:43 */
+#define NIDX_EF_SEARCH 30  /* hnsw/params.rs:46 */
+
+struct GraphDev {
+    uint32_t *l0;          // [n][64]
+    uint32_t *upper_base;  // [n] or 0xffffffff
+    uint32_t *upper;       // [n_upper][32]
+    uint32_t ep_node, ep_layer;
+    uint32_t n;
+};
+
+struct SegDev {
+    const float *vectors;  // [n][dp]
+    const float *norm2;    // [n]
+    uint32_t n, dp, dim;
+    const uint32_t *para_of_vec;  // nullptr = identity
+    const uint64_t *alive;        // nullptr = all
+    int similarity;
+};
+
+// per-query counters written by the search kernel
+#define NIDX_STAT_EVALS 0
+#define NIDX_STAT_EXPANSIONS 1
+#define NIDX_STAT_VISITED 2
+#define NIDX_STAT_FLAGS 3
+#define NIDX_FLAG_VISITED_OVERFLOW 1u
+#define NIDX_FLAG_POOL_INEXACT 2u
+
+struct HnswSearchArgs {
+    SegDev seg;
+    GraphDev g;
+    const float *queries;   // [n_queries][dp]
+    uint32_t n_queries;
+    const uint64_t *filter; // nullptr or bitset over paragraph addrs
+    uint32_t k;             // <= 64
+    float min_score;
+    int with_duplicates;
+    uint32_t vis_log2;      // visited table = 1<<vis_log2 u32 slots in LDS
+    uint32_t *out_vec;      // [n_queries][k]
+    float *out_score;       // [n_queries][k]
+    uint32_t *out_count;    // [n_queries]
+    uint32_t *stats;        // nullptr or [n_queries][4]
+};
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
+
+}  // namespace nidx

@@ -1,0 +1,111 @@
+// shard_merge.cpp — multi-shard result merge (host), include/nidx_gpu.h "Shard merge".
+//
+// Restates nidx/src/searcher/shard_merge.rs: merge_vector_responses (:332-348) and the BM25
+// comparators sort_documents_fn / sort_paragraphs_fn (:211-234, :289-312), both driven through
+// itertools::kmerge_by — a binary heap of list heads ordered by the "comes first" predicate,
+// rebuilt with sift_down after every pop (third-party algorithm, restated).  The per-shard lists are
+// what each GPU produced; with one shard per GPU they arrive through an RCCL all-gather.
+#include <string.h>
+
+#include <vector>
+
+#include "device_common.h"
+#include "host_common.h"
+
+namespace nidx {
+namespace {
+
+struct Head {
+    uint32_t list, pos;
+};
+
+template <typename First>
+void sift_down(std::vector<Head> &heap, size_t len, size_t index, const First &first) {
+    size_t pos = index, child = 2 * pos + 1;
+    while (child + 1 < len) {
+        if (first(heap[child + 1], heap[child])) child++;
+        if (!first(heap[child], heap[pos])) return;
+        std::swap(heap[pos], heap[child]);
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (child + 1 == len && first(heap[child], heap[pos])) std::swap(heap[pos], heap[child]);
+}
+
+template <typename First>
+uint32_t kmerge(const uint32_t *lens, uint32_t n_lists, uint32_t limit, const First &first, std::vector<Head> &order) {
+    std::vector<Head> heap;
+    for (uint32_t l = 0; l < n_lists; l++)
+        if (lens[l] > 0) heap.push_back(Head{l, 0});
+    size_t len = heap.size();
+    for (size_t i = len / 2; i-- > 0;) sift_down(heap, len, i, first);
+    order.clear();
+    while (len > 0 && order.size() < limit) {
+        order.push_back(heap[0]);
+        if (heap[0].pos + 1 < lens[heap[0].list]) heap[0].pos++;
+        else {
+            heap[0] = heap[len - 1];
+            len--;
+        }
+        sift_down(heap, len, 0, first);
+    }
+    return (uint32_t)order.size();
+}
+
+int cmp_bytes(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {
+    uint32_t m = la < lb ? la : lb;
+    int c = m ? memcmp(a, b, m) : 0;
+    if (c) return c;
+    return (la > lb) - (la < lb);
+}
+
+}  // namespace
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" {
+
+int32_t nidx_gpu_merge_vector(const float *const *scores, const uint64_t *const *ids, const uint32_t *lens,
+                              uint32_t n_lists, uint32_t limit, float *out_score, uint64_t *out_id, uint32_t *out_list,
+                              uint32_t *n_out) {
+    if (!n_out || (n_lists && (!scores || !lens))) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<Head> order;
+    // kmerge_by(|a, b| a.score >= b.score)
+    auto first = [&](const Head &a, const Head &b) { return scores[a.list][a.pos] >= scores[b.list][b.pos]; };
+    uint32_t n = kmerge(lens, n_lists, limit, first, order);
+    for (uint32_t i = 0; i < n; i++) {
+        if (out_score) out_score[i] = scores[order[i].list][order[i].pos];
+        if (out_id && ids) out_id[i] = ids[order[i].list][order[i].pos];
+        if (out_list) out_list[i] = order[i].list;
+    }
+    *n_out = n;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *docaddrs, const uint32_t *lens,
+                            const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists,
+                            uint32_t limit, float *out_score, uint64_t *out_docaddr, uint32_t *out_list,
+                            uint32_t *n_out) {
+    if (!n_out || (n_lists && (!scores || !docaddrs || !lens || !shard_ids || !shard_id_lens)))
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<Head> order;
+    // a_bm25.total_cmp(b_bm25).then(a.shard_id.cmp(b.shard_id)).then(a_docaddr.cmp(b_docaddr).reverse()).is_gt()
+    auto first = [&](const Head &a, const Head &b) {
+        int32_t ka = total_key(scores[a.list][a.pos]), kb = total_key(scores[b.list][b.pos]);
+        if (ka != kb) return ka > kb;
+        int c = cmp_bytes(shard_ids[a.list], shard_id_lens[a.list], shard_ids[b.list], shard_id_lens[b.list]);
+        if (c) return c > 0;
+        return docaddrs[a.list][a.pos] < docaddrs[b.list][b.pos];
+    };
+    uint32_t n = kmerge(lens, n_lists, limit, first, order);
+    for (uint32_t i = 0; i < n; i++) {
+        if (out_score) out_score[i] = scores[order[i].list][order[i].pos];
+        if (out_docaddr) out_docaddr[i] = docaddrs[order[i].list][order[i].pos];
+        if (out_list) out_list[i] = order[i].list;
+    }
+    *n_out = n;
+    return NIDX_OK;
+}
+
+}  // extern "C"

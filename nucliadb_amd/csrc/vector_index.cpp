@@ -1,0 +1,639 @@
+// vector_index.cpp — C ABI implementation of the vector index (include/nidx_gpu.h).
+//
+// Host-side mirror of nidx_vector's Searcher / OpenSegment glue around the gfx950 kernels:
+//   open      VectorSearcher::open -> segment::open + apply_deletions   (lib.rs:126-200, segment.rs:39-90)
+//   search    Searcher::_search: sequential segments + Fssc merge        (searcher.rs:149-199,241-290)
+//             OpenSegment::_search: filter ∩ alive, use_hnsw routing      (segment.rs:496-567,626-660)
+// All arithmetic on vectors happens in the kernels; this file only moves data, routes and merges.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <mutex>
+
+#include "device_common.h"
+#include "hnsw_graph.h"
+#include "host_common.h"
+#include "kernels.h"
+#include "vector_index.h"
+
+namespace nidx {
+
+// ---- errors -----------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+int32_t fail(int32_t code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+int32_t hip_fail(hipError_t e, const char *what) {
+    return fail(NIDX_ERR_DEVICE, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+}
+
+// ---- use_hnsw (segment.rs:626-660) ----------------------------------------------------------------
+bool use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, bool has_rabitq) {
+    const uint64_t RERANKING_FACTOR = 100;  // rabitq.rs:30-36
+    uint64_t full_cost, search_mult, rerank_mult;
+    if (has_rabitq) {
+        full_cost = 16;
+        search_mult = RERANKING_FACTOR * 3 / 4;
+        rerank_mult = RERANKING_FACTOR / 2;
+    } else {
+        full_cost = 1;
+        search_mult = 1;
+        rerank_mult = 0;
+    }
+    float l = logf((float)total_nodes) - 2.0f;
+    float hnsw_rq = (l * l) * logf((float)top_k) * (float)search_mult;
+    uint64_t hnsw_full = top_k * rerank_mult + (matching_nodes ? top_k * NIDX_M * total_nodes / matching_nodes : 0);
+    // Rust `as usize`: NaN -> 0, negative -> 0, saturating
+    uint64_t hnsw_rq_u;
+    if (!(hnsw_rq > 0.0f)) hnsw_rq_u = 0;
+    else if (hnsw_rq >= 18446744073709551615.0f) hnsw_rq_u = UINT64_MAX;
+    else hnsw_rq_u = (uint64_t)hnsw_rq;
+    uint64_t hnsw_cost = hnsw_rq_u + hnsw_full * full_cost;
+    uint64_t bf_cost = matching_nodes + top_k * rerank_mult * full_cost;
+    return hnsw_cost < bf_cost;
+}
+
+// ---- utils::normalize_vector (utils.rs:20-23): f32 fold of x.powi(2), then x / sqrt ---------------
+void normalize_row(const float *in, float *out, uint32_t d) {
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < d; i++) {
+        float sq = in[i] * in[i];
+        acc = acc + sq;
+    }
+    float mag = sqrtf(acc);
+    for (uint32_t i = 0; i < d; i++) out[i] = in[i] / mag;
+}
+
+static uint64_t popcount_and(const uint64_t *a, const uint64_t *b, uint32_t nbits) {
+    uint64_t c = 0;
+    uint32_t words = (nbits + 63) / 64;
+    for (uint32_t w = 0; w < words; w++) {
+        uint64_t x = a ? a[w] : ~0ull;
+        if (b) x &= b[w];
+        if (w == words - 1 && (nbits & 63)) x &= (1ull << (nbits & 63)) - 1ull;
+        c += (uint64_t)__builtin_popcountll(x);
+    }
+    return c;
+}
+
+// ---- open ---------------------------------------------------------------------------------------
+int32_t VectorSegment::upload_graph(const HostGraph &hg) {
+    NIDX_HIP(g_l0.alloc(hg.l0.size() * 4));
+    NIDX_HIP(g_upper_base.alloc(hg.upper_base.size() * 4));
+    NIDX_HIP(g_upper.alloc(std::max<size_t>(hg.upper.size(), NIDX_UP_STRIDE) * 4));
+    NIDX_HIP(hipMemcpy(g_l0.p, hg.l0.data(), hg.l0.size() * 4, hipMemcpyHostToDevice));
+    NIDX_HIP(hipMemcpy(g_upper_base.p, hg.upper_base.data(), hg.upper_base.size() * 4, hipMemcpyHostToDevice));
+    if (!hg.upper.empty()) NIDX_HIP(hipMemcpy(g_upper.p, hg.upper.data(), hg.upper.size() * 4, hipMemcpyHostToDevice));
+    ep_node = hg.ep_node;
+    ep_layer = hg.ep_layer;
+    top_layer = hg.top_layer;
+    has_graph = true;
+    return NIDX_OK;
+}
+
+GraphDev VectorSegment::graph_dev() const {
+    GraphDev g;
+    g.l0 = g_l0.as<uint32_t>();
+    g.upper_base = g_upper_base.as<uint32_t>();
+    g.upper = g_upper.as<uint32_t>();
+    g.ep_node = ep_node;
+    g.ep_layer = ep_layer;
+    g.n = n;
+    return g;
+}
+
+SegDev VectorSegment::seg_dev(int similarity) const {
+    SegDev s;
+    s.vectors = vectors.as<float>();
+    s.norm2 = norm2.as<float>();
+    s.n = n;
+    s.dp = dp;
+    s.dim = dim;
+    s.para_of_vec = identity_para ? nullptr : para_of_vec.as<uint32_t>();
+    s.alive = all_alive ? nullptr : alive.as<uint64_t>();
+    s.similarity = similarity;
+    return s;
+}
+
+uint64_t VectorSegment::bytes() const {
+    return vectors.bytes + norm2.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
+           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes;
+}
+
+static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_vector_segment_t &in, VectorSegment &seg,
+                            hipStream_t stream) {
+    const uint32_t d = cfg.dimension;
+    seg.n = in.n_vectors;
+    seg.dim = d;
+    seg.dp = (d + 3u) & ~3u;
+    seg.n_paragraphs = in.n_paragraphs;
+    const uint64_t packed = (uint64_t)d * 4, trailer = packed + 4;
+    if (in.n_vectors > 0 && in.vectors == nullptr) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment has no vectors pointer");
+    if (in.row_stride_bytes < packed)
+        // a store written for another dimension: segment::create rejects it (segment.rs:200-211)
+        return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "Inconsistent dimensions. Index=%u Vector=%llu", d,
+                    (unsigned long long)(in.row_stride_bytes / 4));
+    // paragraph of each vector
+    std::vector<uint32_t> pov;
+    if (in.paragraph_of_vector) {
+        pov.assign(in.paragraph_of_vector, in.paragraph_of_vector + in.n_vectors);
+    } else if (in.row_stride_bytes == trailer) {
+        pov.resize(in.n_vectors);
+        const uint8_t *base = (const uint8_t *)in.vectors;
+        for (uint32_t i = 0; i < in.n_vectors; i++) memcpy(&pov[i], base + (uint64_t)i * trailer + packed, 4);
+    }
+    seg.identity_para = true;
+    for (uint32_t i = 0; i < pov.size(); i++)
+        if (pov[i] != i) { seg.identity_para = false; break; }
+    if (pov.empty() && in.n_paragraphs != in.n_vectors)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "packed vectors need n_paragraphs == n_vectors or paragraph_of_vector");
+    if (!pov.empty()) {
+        std::vector<uint8_t> seen(in.n_paragraphs, 0);
+        for (uint32_t i = 0; i < in.n_vectors; i++) {
+            if (pov[i] >= in.n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "paragraph address out of range");
+            if (seen[pov[i]]) return fail(NIDX_ERR_UNSUPPORTED, "paragraphs with more than one vector are not supported yet");
+            seen[pov[i]] = 1;
+        }
+    }
+    seg.para_host = pov;
+    if (!seg.identity_para) {
+        NIDX_HIP(seg.para_of_vec.alloc((size_t)in.n_vectors * 4));
+        NIDX_HIP(hipMemcpy(seg.para_of_vec.p, pov.data(), (size_t)in.n_vectors * 4, hipMemcpyHostToDevice));
+    }
+    // vectors -> [n][dp], zero padded; the 4-byte paragraph trailer of vectors.bin is dropped
+    if (in.n_vectors > 0) {
+        NIDX_HIP(seg.vectors.alloc((size_t)in.n_vectors * seg.dp * 4));
+        if (seg.dp != d) NIDX_HIP(hipMemset(seg.vectors.p, 0, seg.vectors.bytes));
+        NIDX_HIP(hipMemcpy2D(seg.vectors.p, (size_t)seg.dp * 4, in.vectors, in.row_stride_bytes, packed, in.n_vectors,
+                             hipMemcpyHostToDevice));
+        NIDX_HIP(seg.norm2.alloc((size_t)in.n_vectors * 4));
+        NIDX_HIP(launch_row_norms(seg.vectors.as<float>(), seg.n, seg.dp, seg.norm2.as<float>(), stream));
+    }
+    // alive bitset
+    const uint32_t words = (in.n_paragraphs + 63) / 64;
+    seg.alive_host.assign(words, ~0ull);
+    seg.all_alive = true;
+    if (in.alive_bitset) {
+        memcpy(seg.alive_host.data(), in.alive_bitset, (size_t)words * 8);
+        seg.all_alive = popcount_and(seg.alive_host.data(), nullptr, in.n_paragraphs) == in.n_paragraphs;
+    }
+    if (words && (in.n_paragraphs & 63)) seg.alive_host[words - 1] &= (1ull << (in.n_paragraphs & 63)) - 1ull;
+    seg.alive_count = popcount_and(seg.alive_host.data(), nullptr, in.n_paragraphs);
+    if (!seg.all_alive) {
+        NIDX_HIP(seg.alive.alloc((size_t)words * 8));
+        NIDX_HIP(hipMemcpy(seg.alive.p, seg.alive_host.data(), (size_t)words * 8, hipMemcpyHostToDevice));
+    }
+    if (in.paragraph_key_ids) seg.key_ids.assign(in.paragraph_key_ids, in.paragraph_key_ids + in.n_paragraphs);
+    // graph
+    seg.has_graph = false;
+    if (in.hnsw_graph && in.hnsw_graph_len > 0 && in.n_vectors > 0) {
+        HostGraph hg;
+        std::string err;
+        int rc = parse_disk_v2(in.hnsw_graph, in.hnsw_graph_len, in.n_vectors, hg, err);
+        if (rc != NIDX_OK) return fail(rc, "%s", err.c_str());
+        int32_t r = seg.upload_graph(hg);
+        if (r != NIDX_OK) return r;
+    }
+    NIDX_HIP(hipStreamSynchronize(stream));
+    return NIDX_OK;
+}
+
+// ---- one segment, device resident -------------------------------------------------------------------
+int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
+                                           bool with_duplicates, int method, const uint64_t *d_filter,
+                                           uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,
+                                           uint32_t *d_stats, uint32_t vis_log2, hipStream_t st) {
+    VectorSegment &seg = segs[s];
+    if (nq == 0) return NIDX_OK;
+    if (method == NIDX_METHOD_HNSW) {
+        HnswSearchArgs a;
+        a.seg = seg.seg_dev(cfg.similarity);
+        a.g = seg.graph_dev();
+        a.queries = d_queries;
+        a.n_queries = nq;
+        a.filter = d_filter;
+        a.k = k;
+        a.min_score = min_score;
+        a.with_duplicates = with_duplicates ? 1 : 0;
+        a.vis_log2 = vis_log2;
+        a.out_vec = d_out_vec;
+        a.out_score = d_out_score;
+        a.out_count = d_out_count;
+        a.stats = d_stats;
+        NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
+        return NIDX_OK;
+    }
+    // brute force
+    uint32_t nblk = scan_num_blocks(seg.n);
+    size_t need = (size_t)nq * nblk * k * 8;
+    NIDX_HIP(scratch_partial.reserve(need));
+    ScanArgs a;
+    a.vectors = seg.vectors.as<float>();
+    a.norm2 = seg.norm2.as<float>();
+    a.n = seg.n;
+    a.dp = seg.dp;
+    a.queries = d_queries;
+    a.n_queries = nq;
+    a.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
+    a.filter = d_filter;
+    a.para_of_vec = seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>();
+    a.similarity = cfg.similarity;
+    a.min_score = min_score;
+    a.k = k;
+    a.qt = 0;
+    a.partial = scratch_partial.as<uint64_t>();
+    NIDX_HIP(launch_scan(a, nblk, st));
+    NIDX_HIP(launch_merge_topk(a.partial, nq, nblk, k, d_out_vec, d_out_score, d_out_count, st));
+    return NIDX_OK;
+}
+
+// ---- Fssc (searcher.rs:149-199) -----------------------------------------------------------------------
+namespace {
+struct Cand {
+    float score;
+    uint32_t seg, vec, para;
+    uint64_t key;
+};
+}  // namespace
+
+int32_t VectorIndex::rows_equal_host(uint32_t sa, uint32_t va, uint32_t sb, uint32_t vb, bool &eq) {
+    std::vector<float> a(segs[sa].dp), b(segs[sb].dp);
+    NIDX_HIP(hipMemcpy(a.data(), segs[sa].vectors.as<float>() + (size_t)va * segs[sa].dp, (size_t)segs[sa].dp * 4,
+                       hipMemcpyDeviceToHost));
+    NIDX_HIP(hipMemcpy(b.data(), segs[sb].vectors.as<float>() + (size_t)vb * segs[sb].dp, (size_t)segs[sb].dp * 4,
+                       hipMemcpyDeviceToHost));
+    eq = memcmp(a.data(), b.data(), (size_t)cfg.dimension * 4) == 0;
+    return NIDX_OK;
+}
+
+int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
+                                 const uint64_t *const *segment_filters, uint32_t *out_segment, uint32_t *out_paragraph,
+                                 uint32_t *out_vector, float *out_score, uint32_t *out_count, int32_t *out_method) {
+    std::lock_guard<std::mutex> lock(mu);
+    NIDX_HIP(hipSetDevice(device));
+    const uint32_t k = p.k;
+    const uint32_t d = cfg.dimension;
+    for (uint32_t q = 0; q < nq; q++) out_count[q] = 0;
+    if (out_method)
+        for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
+    if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
+    if (k > 64) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 64 is not supported yet (got %u)", k);
+    if (p.method < 0 || p.method > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
+
+    // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
+    const uint32_t dp = (d + 3u) & ~3u;
+    std::vector<float> qpad((size_t)nq * dp, 0.f);
+    for (uint32_t q = 0; q < nq; q++) {
+        if (cfg.normalize_vectors) normalize_row(queries + (size_t)q * d, &qpad[(size_t)q * dp], d);
+        else memcpy(&qpad[(size_t)q * dp], queries + (size_t)q * d, (size_t)d * 4);
+    }
+    NIDX_HIP(scratch_queries.reserve(qpad.size() * 4));
+    NIDX_HIP(hipMemcpyAsync(scratch_queries.p, qpad.data(), qpad.size() * 4, hipMemcpyHostToDevice, stream));
+    NIDX_HIP(scratch_out_vec.reserve((size_t)nq * k * 4));
+    NIDX_HIP(scratch_out_score.reserve((size_t)nq * k * 4));
+    NIDX_HIP(scratch_out_count.reserve((size_t)nq * 4));
+    NIDX_HIP(scratch_stats.reserve((size_t)nq * 16));
+
+    const size_t S = segs.size();
+    std::vector<std::vector<uint32_t>> hv(S), hc(S);
+    std::vector<std::vector<float>> hs(S);
+    for (size_t s = 0; s < S; s++) {
+        VectorSegment &seg = segs[s];
+        const uint64_t *filt = segment_filters ? segment_filters[s] : nullptr;
+        // matching = |filter ∩ alive| (segment.rs:516-531)
+        uint64_t matching = filt ? popcount_and(seg.alive_host.data(), filt, seg.n_paragraphs) : seg.alive_count;
+        hc[s].assign(nq, 0);
+        if (matching == 0 || seg.n == 0) continue;
+        int method = p.method;
+        if (method == NIDX_METHOD_AUTO)
+            method = (seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, false)) ? NIDX_METHOD_HNSW
+                                                                                      : NIDX_METHOD_BRUTE_FORCE;
+        if (method == NIDX_METHOD_HNSW && !seg.has_graph)
+            return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %zu has no HNSW graph", s);
+        if (out_method) out_method[s] = method;
+        const uint64_t *d_filter = nullptr;
+        if (filt) {
+            size_t bytes = (size_t)((seg.n_paragraphs + 63) / 64) * 8;
+            NIDX_HIP(scratch_filter.reserve(bytes));
+            NIDX_HIP(hipMemcpyAsync(scratch_filter.p, filt, bytes, hipMemcpyHostToDevice, stream));
+            d_filter = scratch_filter.as<uint64_t>();
+        }
+        uint32_t vis_log2 = default_vis_log2;
+        for (;;) {
+            int32_t rc = segment_search_device((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score,
+                                               p.with_duplicates != 0, method, d_filter, scratch_out_vec.as<uint32_t>(),
+                                               scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
+                                               scratch_stats.as<uint32_t>(), vis_log2, stream);
+            if (rc != NIDX_OK) return rc;
+            if (method != NIDX_METHOD_HNSW) break;
+            std::vector<uint32_t> stats((size_t)nq * 4);
+            NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, stream));
+            NIDX_HIP(hipStreamSynchronize(stream));
+            uint32_t flags = 0;
+            for (uint32_t q = 0; q < nq; q++) flags |= stats[(size_t)q * 4 + NIDX_STAT_FLAGS];
+            if (flags == 0) break;
+            if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15)
+                return fail(NIDX_ERR_INEXACT, "HNSW search overflowed an on-chip structure (flags=%u, visited table 2^%u)",
+                            flags, vis_log2);
+            vis_log2 = 15;  // visited table was too small: retry once with the largest one (128 KiB of LDS)
+        }
+        hv[s].resize((size_t)nq * k);
+        hs[s].resize((size_t)nq * k);
+        NIDX_HIP(hipMemcpyAsync(hv[s].data(), scratch_out_vec.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+        NIDX_HIP(hipMemcpyAsync(hs[s].data(), scratch_out_score.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+        NIDX_HIP(hipMemcpyAsync(hc[s].data(), scratch_out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+        NIDX_HIP(hipStreamSynchronize(stream));
+    }
+
+    // Fssc per query
+    std::vector<Cand> buff, offered;
+    for (uint32_t q = 0; q < nq; q++) {
+        buff.clear();
+        offered.clear();
+        for (size_t s = 0; s < S; s++) {
+            for (uint32_t i = 0; i < hc[s][q]; i++) {
+                Cand c;
+                c.score = hs[s][(size_t)q * k + i];
+                c.seg = (uint32_t)s;
+                c.vec = hv[s][(size_t)q * k + i];
+                c.para = segs[s].para_host.empty() ? c.vec : segs[s].para_host[c.vec];
+                c.key = segs[s].key_ids.empty() ? (((uint64_t)s << 32) | c.para) : segs[s].key_ids[c.para];
+                if (!p.with_duplicates) {
+                    // Fssc.seen: vector bytes already offered.  Equal bytes imply equal score bits for
+                    // one query, so rows are only fetched back on a bit-identical score.
+                    bool dup = false;
+                    for (const Cand &o : offered) {
+                        if (memcmp(&o.score, &c.score, 4) != 0) continue;
+                        bool eq = false;
+                        int32_t rc = rows_equal_host(o.seg, o.vec, c.seg, c.vec, eq);
+                        if (rc != NIDX_OK) return rc;
+                        if (eq) { dup = true; break; }
+                    }
+                    if (dup) continue;
+                    offered.push_back(c);
+                }
+                if (buff.size() == k) {
+                    int victim = -1;
+                    for (size_t j = 0; j < buff.size(); j++)
+                        if (c.score > buff[j].score && (victim < 0 || buff[j].score < buff[victim].score)) victim = (int)j;
+                    if (victim < 0) continue;
+                    buff[victim] = buff.back();
+                    buff.pop_back();
+                }
+                bool present = false;
+                for (const Cand &b : buff)
+                    if (b.key == c.key) { present = true; break; }
+                if (!present) buff.push_back(c);
+            }
+        }
+        // sort desc by score (partial_cmp); the HashSet order of equal scores is unspecified -> (segment, vector)
+        std::stable_sort(buff.begin(), buff.end(), [](const Cand &a, const Cand &b) {
+            if (a.score > b.score) return true;
+            if (a.score < b.score) return false;
+            if (a.seg != b.seg) return a.seg < b.seg;
+            return a.vec < b.vec;
+        });
+        out_count[q] = (uint32_t)buff.size();
+        for (size_t i = 0; i < buff.size(); i++) {
+            if (out_segment) out_segment[(size_t)q * k + i] = buff[i].seg;
+            if (out_paragraph) out_paragraph[(size_t)q * k + i] = buff[i].para;
+            if (out_vector) out_vector[(size_t)q * k + i] = buff[i].vec;
+            if (out_score) out_score[(size_t)q * k + i] = buff[i].score;
+        }
+    }
+    return NIDX_OK;
+}
+
+}  // namespace nidx
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+using namespace nidx;
+
+extern "C" {
+
+int32_t nidx_gpu_last_error(char *buf, size_t len) {
+    if (buf && len) {
+        size_t n = g_last_error.size() < len - 1 ? g_last_error.size() : len - 1;
+        memcpy(buf, g_last_error.data(), n);
+        buf[n] = 0;
+    }
+    return (int32_t)g_last_error.size();
+}
+
+int32_t nidx_gpu_abi_version(void) { return 1; }
+
+int32_t nidx_gpu_device_count(int32_t *count_out) {
+    if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count_out = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *count_out = n;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_set_device(int32_t device) {
+    NIDX_HIP(hipSetDevice(device));
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_gpu_vector_segment_t *segments,
+                             uint32_t n_segments, nidx_gpu_vector_index_t **index_out) {
+    if (!config || !index_out || (n_segments && !segments)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *index_out = nullptr;
+    if (config->dimension == 0) return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: Vector dimension cannot be 0");
+    if (config->similarity != NIDX_SIMILARITY_DOT && config->similarity != NIDX_SIMILARITY_COSINE)
+        return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: unknown similarity %d", config->similarity);
+    if (config->vector_cardinality != NIDX_CARDINALITY_SINGLE)
+        return fail(NIDX_ERR_UNSUPPORTED, "multi-vector cardinality is not supported yet");
+    if (config->dimension > 3072) return fail(NIDX_ERR_UNSUPPORTED, "dimension > 3072 is not supported yet");
+    std::unique_ptr<VectorIndex> idx(new VectorIndex());
+    idx->cfg = *config;
+    NIDX_HIP(hipGetDevice(&idx->device));
+    NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    idx->segs.resize(n_segments);
+    for (uint32_t s = 0; s < n_segments; s++) {
+        int32_t rc = open_segment(*config, segments[s], idx->segs[s], idx->stream);
+        if (rc != NIDX_OK) return rc;
+    }
+    *index_out = reinterpret_cast<nidx_gpu_vector_index_t *>(idx.release());
+    return NIDX_OK;
+}
+
+void nidx_gpu_vector_close(nidx_gpu_vector_index_t *index) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) {
+        (void)hipStreamSynchronize(idx->stream);
+        (void)hipStreamDestroy(idx->stream);
+    }
+    delete idx;
+}
+
+int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64_t *bytes_out) {
+    const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
+    if (!idx || !bytes_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    uint64_t b = 0;
+    for (const VectorSegment &s : idx->segs) b += s.bytes();
+    *bytes_out = b;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint32_t *n_out) {
+    const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
+    if (!idx || !n_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *n_out = (uint32_t)idx->segs.size();
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out) {
+    const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
+    if (!idx || !n_out || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
+    *n_out = idx->segs[segment].n_paragraphs;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_search(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                               const nidx_gpu_vector_search_params_t *params, const uint64_t *const *segment_filters,
+                               uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                               uint32_t *out_count, int32_t *out_method) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    return idx->search_host(queries, n_queries, *params, segment_filters, out_segment, out_paragraph, out_vector,
+                            out_score, out_count, out_method);
+}
+
+int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                                   uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
+                                   const uint64_t *const *segment_filters, uint32_t *out_segment,
+                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count,
+                                   int32_t *out_method) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL index");
+    if (query_dimension != idx->cfg.dimension)
+        return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "Inconsistent dimensions. Index=%u Vector=%u", idx->cfg.dimension,
+                    query_dimension);
+    return nidx_gpu_vector_search(index, queries, n_queries, params, segment_filters, out_segment, out_paragraph,
+                                  out_vector, out_score, out_count, out_method);
+}
+
+int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,
+                                              uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
+                                              const uint64_t *d_filter, uint32_t *d_out_vector, float *d_out_score,
+                                              uint32_t *d_out_count, uint32_t *d_stats, void *stream) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !params || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    if (params->k == 0 || params->k > 64) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..64 (got %u)", params->k);
+    if (idx->cfg.dimension & 3u)
+        return fail(NIDX_ERR_UNSUPPORTED, "device-resident queries need a dimension that is a multiple of 4");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    VectorSegment &seg = idx->segs[segment];
+    int method = params->method;
+    if (method == NIDX_METHOD_AUTO) {
+        if (d_filter) return fail(NIDX_ERR_INVALID_ARGUMENT, "NIDX_METHOD_AUTO with a device filter: pick the method explicitly");
+        method = (seg.has_graph && use_hnsw(seg.n_paragraphs, seg.alive_count, params->k, false)) ? NIDX_METHOD_HNSW
+                                                                                                   : NIDX_METHOD_BRUTE_FORCE;
+    }
+    if (method == NIDX_METHOD_HNSW && !seg.has_graph) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment has no HNSW graph");
+    return idx->segment_search_device(segment, d_queries, n_queries, params->k, params->min_score,
+                                      params->with_duplicates != 0, method, d_filter, d_out_vector, d_out_score,
+                                      d_out_count, d_stats, idx->default_vis_log2, (hipStream_t)stream);
+}
+
+int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq) {
+    return use_hnsw(total_nodes, matching_nodes, top_k, has_rabitq != 0) ? 1 : 0;
+}
+
+int32_t nidx_gpu_similarity(const float *x, const float *y, uint32_t n_pairs, uint32_t dimension, int32_t similarity,
+                            int32_t order, float *out) {
+    if (!x || !y || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (order != NIDX_ORDER_WAVE64) return fail(NIDX_ERR_UNSUPPORTED, "only NIDX_ORDER_WAVE64 is implemented here");
+    if (n_pairs == 0) return NIDX_OK;
+    const uint32_t dp = (dimension + 3u) & ~3u;
+    DevBuf dx, dy, dout;
+    NIDX_HIP(dx.alloc((size_t)n_pairs * dp * 4));
+    NIDX_HIP(dy.alloc((size_t)n_pairs * dp * 4));
+    NIDX_HIP(dout.alloc((size_t)n_pairs * 4));
+    if (dp != dimension) {
+        NIDX_HIP(hipMemset(dx.p, 0, dx.bytes));
+        NIDX_HIP(hipMemset(dy.p, 0, dy.bytes));
+    }
+    NIDX_HIP(hipMemcpy2D(dx.p, (size_t)dp * 4, x, (size_t)dimension * 4, (size_t)dimension * 4, n_pairs, hipMemcpyHostToDevice));
+    NIDX_HIP(hipMemcpy2D(dy.p, (size_t)dp * 4, y, (size_t)dimension * 4, (size_t)dimension * 4, n_pairs, hipMemcpyHostToDevice));
+    NIDX_HIP(launch_pair_similarity(dx.as<float>(), dy.as<float>(), n_pairs, dp, similarity, dout.as<float>(), nullptr));
+    NIDX_HIP(hipMemcpy(out, dout.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, float *out) {
+    if (!in || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (uint32_t i = 0; i < n; i++) normalize_row(in + (size_t)i * dimension, out + (size_t)i * dimension, dimension);
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *graph_out,
+                                       uint64_t graph_cap, uint64_t *graph_len_out, float *edges_out, uint64_t edges_cap,
+                                       uint64_t *n_edges_out) {
+    const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    const VectorSegment &seg = idx->segs[segment];
+    if (!seg.has_graph) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment has no HNSW graph");
+    HostGraph hg;
+    hg.n = seg.n;
+    hg.ep_node = seg.ep_node;
+    hg.ep_layer = seg.ep_layer;
+    hg.top_layer = seg.top_layer;
+    hg.l0.resize(seg.g_l0.bytes / 4);
+    hg.upper_base.resize(seg.g_upper_base.bytes / 4);
+    NIDX_HIP(hipSetDevice(idx->device));
+    NIDX_HIP(hipMemcpy(hg.l0.data(), seg.g_l0.p, seg.g_l0.bytes, hipMemcpyDeviceToHost));
+    NIDX_HIP(hipMemcpy(hg.upper_base.data(), seg.g_upper_base.p, seg.g_upper_base.bytes, hipMemcpyDeviceToHost));
+    uint32_t n_upper = 0;
+    for (uint32_t i = 0; i < seg.n; i++) n_upper += seg.top_layer[i];
+    hg.upper.resize((size_t)n_upper * NIDX_UP_STRIDE);
+    if (n_upper) NIDX_HIP(hipMemcpy(hg.upper.data(), seg.g_upper.p, hg.upper.size() * 4, hipMemcpyDeviceToHost));
+    if (seg.g_l0_w.p) {
+        hg.l0_w.resize(hg.l0.size());
+        NIDX_HIP(hipMemcpy(hg.l0_w.data(), seg.g_l0_w.p, hg.l0_w.size() * 4, hipMemcpyDeviceToHost));
+        hg.upper_w.resize(hg.upper.size());
+        if (n_upper) NIDX_HIP(hipMemcpy(hg.upper_w.data(), seg.g_upper_w.p, hg.upper_w.size() * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint8_t> graph;
+    std::vector<float> edges;
+    serialize_disk_v2(hg, graph, edges);
+    if (graph_len_out) *graph_len_out = graph.size();
+    if (n_edges_out) *n_edges_out = edges.size();
+    if (graph_out) {
+        if (graph_cap < graph.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "graph buffer too small");
+        memcpy(graph_out, graph.data(), graph.size());
+    }
+    if (edges_out) {
+        if (edges_cap < edges.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "edges buffer too small");
+        memcpy(edges_out, edges.data(), edges.size() * 4);
+    }
+    return NIDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// vector_index.h — the opaque nidx_gpu_vector_index_t (one process-local, device-resident Searcher).
+#pragma once
+#include <mutex>
+#include <vector>
+
+#include "hnsw_graph.h"
+#include "host_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+bool use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, bool has_rabitq);
+void normalize_row(const float *in, float *out, uint32_t d);
+
+// One OpenSegment in HBM (nidx_vector/src/segment.rs:288-357 Retriever + graph).
+struct VectorSegment {
+    uint32_t n = 0, dim = 0, dp = 0, n_paragraphs = 0;
+    DevBuf vectors;      // [n][dp] f32, zero padded
+    DevBuf norm2;        // [n] f32, WAVE64-order |x|^2
+    DevBuf para_of_vec;  // [n] u32 (absent when identity)
+    DevBuf alive;        // bitset over paragraph addrs (absent when all alive)
+    bool identity_para = true, all_alive = true;
+    std::vector<uint32_t> para_host;   // empty when identity
+    std::vector<uint64_t> alive_host;  // always present
+    uint64_t alive_count = 0;
+    std::vector<uint64_t> key_ids;     // Fssc identity of each paragraph (optional)
+    // HNSW graph
+    bool has_graph = false;
+    DevBuf g_l0, g_upper_base, g_upper;  // kernels.h GraphDev geometry
+    DevBuf g_l0_w, g_upper_w;            // edge weights (built graphs only)
+    uint32_t ep_node = 0, ep_layer = 0;
+    std::vector<uint8_t> top_layer;
+
+    int32_t upload_graph(const HostGraph &hg);
+    GraphDev graph_dev() const;
+    SegDev seg_dev(int similarity) const;
+    uint64_t bytes() const;
+};
+
+struct VectorIndex {
+    nidx_gpu_vector_config_t cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<VectorSegment> segs;
+    // tunables
+    int waves_per_query = 4;
+    uint32_t default_vis_log2 = 13;
+    // grow-only scratch, guarded by mu
+    DevBuf scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
+        scratch_stats;
+
+    int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
+                                  bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
+                                  float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
+                                  hipStream_t st);
+    int32_t rows_equal_host(uint32_t sa, uint32_t va, uint32_t sb, uint32_t vb, bool &eq);
+    int32_t search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
+                        const uint64_t *const *segment_filters, uint32_t *out_segment, uint32_t *out_paragraph,
+                        uint32_t *out_vector, float *out_score, uint32_t *out_count, int32_t *out_method);
+    int32_t build_hnsw(uint32_t segment, uint64_t level_seed);
+};
+
+}  // namespace nidx

@@ -1,0 +1,325 @@
+// vector_scan.hip — exact k-NN scan kernels (gfx950), WAVE64 summation order.
+//
+// Replaces OpenSegment::brute_force_search (nidx_vector/src/segment.rs:569-623) and the
+// dense_f32::{dot,cosine}_similarity calls under it (vector_types/dense_f32.rs:29-39):
+//   for every alive/filter-passing paragraph: similarity(query, vector); keep >= min_score;
+//   order by (score desc, address asc); take k.
+//
+// Layout: vectors[N][Dp] f32 in HBM, Dp = dimension rounded up to 4 floats, zero padded, so one
+// wave reads one row as Dp/256 fully coalesced 1 KiB transactions (16 B per lane).  A tile of QT
+// queries lives in registers (QT*NJ float4 per lane); the row is read once per tile.  The QT dot
+// products of a row are reduced with a transposed butterfly (one shuffle per PAIR of queries at
+// the first log2(QT) levels) that is bit-identical to a per-query xor butterfly.  Every wave keeps
+// a sorted top-k per query one-entry-per-lane; a block merges its 4 waves through LDS; a second
+// kernel merges the per-block lists.
+//
+// Bound: HBM.  Algorithmic bytes per (row, query tile) = 4*D.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+// ---------------------------------------------------------------------------------------------
+// row norms: norm2[r] = sum x^2 in WAVE64 order (the `xx` term of the oracle's orc_sums)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ vectors, uint32_t n, uint32_t dp,
+                                                        float *__restrict__ norm2) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nj = (int)((dp + 255u) / 256u);
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        const float *row = vectors + (size_t)r * dp;
+        float acc = 0.f;
+        for (int j = 0; j < nj; j++) {
+            float4 x = load_row_chunk(row, dp, j, lane);
+            acc = fma4(x, x, acc);
+        }
+        acc = wave_butterfly_sum(acc);
+        if (lane == 0) norm2[r] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pairwise similarity (a1 numerics check): out[i] = sim(x[i], y[i]), one wave per pair
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_similarity_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                              uint32_t n, uint32_t dp, int similarity,
+                                                              float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nj = (int)((dp + 255u) / 256u);
+    for (uint32_t r = wave; r < n; r += nwaves) {
+        float ab = 0.f, xx = 0.f, yy = 0.f;
+        for (int j = 0; j < nj; j++) {
+            float4 a = load_row_chunk(x + (size_t)r * dp, dp, j, lane);
+            float4 b = load_row_chunk(y + (size_t)r * dp, dp, j, lane);
+            // (ab, xx, yy) interleaved per component exactly like orc_sums' wave64 order
+            ab = fma4(a, b, ab);
+            xx = fma4(a, a, xx);
+            yy = fma4(b, b, yy);
+        }
+        ab = wave_butterfly_sum(ab);
+        xx = wave_butterfly_sum(xx);
+        yy = wave_butterfly_sum(yy);
+        if (lane == 0) out[r] = similarity == 1 ? cosine_from_sums(ab, xx, yy) : ab;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan + per-block top-k
+// ---------------------------------------------------------------------------------------------
+template <int NJ, int QT>
+__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;  // wave in block
+    const uint32_t tile = blockIdx.y;
+    const uint32_t q0 = tile * QT;
+    const uint32_t wave = blockIdx.x * 4 + wib;
+    const uint32_t nwaves = gridDim.x * 4;
+    const int myq = QReduce<QT>::query_of_lane(lane);
+    const bool cosine = a.similarity == 1;
+
+    // query tile -> registers; queries past n_queries replicate the last one (their lists are dropped)
+    float4 qv[QT][NJ];
+    double sqrt_qq = 0.0;  // sqrt(|q|^2) of this lane's query
+    float qq_mine = 0.f;
+    {
+        float qq[QT];
+#pragma unroll
+        for (int q = 0; q < QT; q++) {
+            uint32_t qi = q0 + q < a.n_queries ? q0 + q : a.n_queries - 1;
+            const float *qrow = a.queries + (size_t)qi * a.dp;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                qv[q][j] = load_row_chunk(qrow, a.dp, j, lane);
+                acc = fma4(qv[q][j], qv[q][j], acc);
+            }
+            qq[q] = acc;
+        }
+        if (cosine) {
+            qq_mine = QReduce<QT>::run(qq, lane);
+            sqrt_qq = sqrt((double)qq_mine);
+        }
+    }
+
+    WaveSortedList top[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) top[q].init();
+    uint64_t thr = NIDX_EMPTY_KEY;  // k-th key of this lane's query (EMPTY while the list is short)
+    const int k = (int)a.k;
+
+    auto passes = [&](uint32_t r) -> bool {
+        uint32_t p = a.para_of_vec ? a.para_of_vec[r] : r;
+        if (a.alive && !bit_test(a.alive, p)) return false;
+        if (a.filter && !bit_test(a.filter, p)) return false;
+        return true;
+    };
+
+    uint32_t r = wave;
+    while (r < a.n && !passes(r)) r += nwaves;
+    float4 cur[NJ];
+    if (r < a.n) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) cur[j] = load_row_chunk(a.vectors + (size_t)r * a.dp, a.dp, j, lane);
+    }
+    while (r < a.n) {
+        uint32_t rn = r + nwaves;
+        while (rn < a.n && !passes(rn)) rn += nwaves;
+        float4 nxt[NJ];
+        if (rn < a.n) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) nxt[j] = load_row_chunk(a.vectors + (size_t)rn * a.dp, a.dp, j, lane);
+        }
+        float acc[QT];
+#pragma unroll
+        for (int q = 0; q < QT; q++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) s = fma4(cur[j], qv[q][j], s);
+            acc[q] = s;
+        }
+        float ab = QReduce<QT>::run(acc, lane);
+        float score;
+        if (cosine) {
+            float xx = a.norm2[r];
+            // cosine_from_sums with sqrt(|q|^2) hoisted (same f64 operations, same order)
+            double dab = (double)ab, dxx = (double)xx;
+            double dist;
+            if (dxx == 0.0 && (double)qq_mine == 0.0) dist = 0.0;
+            else if (dab == 0.0) dist = 1.0;
+            else {
+                double d = 1.0 - dab / (sqrt(dxx) * sqrt_qq);
+                dist = d > 0.0 ? d : 0.0;
+            }
+            score = 1.0f - (float)dist;
+        } else {
+            score = ab;
+        }
+        uint64_t ck = rank_key(score, r);
+        bool ok = (score >= a.min_score) && (ck > thr) && ((lane & QReduce<QT>::group_mask()) == 0);
+        unsigned long long m = __ballot(ok);
+        while (m) {
+            int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            uint64_t nk = shfl_u64(ck, src);
+            int q = QReduce<QT>::query_of_lane(src);
+#pragma unroll
+            for (int qq = 0; qq < QT; qq++) {
+                if (qq == q) {
+                    top[qq].insert(nk, lane);
+                    uint64_t kth = top[qq].at(k - 1);
+                    if (myq == qq) thr = kth;
+                }
+            }
+        }
+        r = rn;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) cur[j] = nxt[j];
+    }
+
+    // block merge through LDS: waves 1..3 publish, wave 0 folds them in
+    __shared__ uint64_t lds[3][QT][64];
+    if (wib > 0) {
+#pragma unroll
+        for (int q = 0; q < QT; q++) lds[wib - 1][q][lane] = top[q].key;
+    }
+    __syncthreads();
+    if (wib == 0) {
+#pragma unroll
+        for (int q = 0; q < QT; q++) {
+            for (int w = 0; w < 3; w++) {
+                for (int i = 0; i < k; i++) {
+                    uint64_t nk = lds[w][q][i];
+                    if (nk == NIDX_EMPTY_KEY) break;
+                    uint64_t kth = top[q].at(k - 1);
+                    if (nk > kth) top[q].insert(nk, lane);
+                    else break;  // lists are sorted: the rest rank even lower
+                }
+            }
+            if (q0 + q < a.n_queries && lane < k)
+                a.partial[((size_t)(q0 + q) * gridDim.x + blockIdx.x) * k + lane] = top[q].key;
+        }
+    }
+}
+
+// merge per-block lists: one block per query
+__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ partial, uint32_t lists_per_query,
+                                                         uint32_t k, uint32_t *__restrict__ out_vec,
+                                                         float *__restrict__ out_score,
+                                                         uint32_t *__restrict__ out_count) {
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint64_t *src = partial + (size_t)q * lists_per_query * k;
+    const uint32_t total = lists_per_query * k;
+    WaveSortedList top;
+    top.init();
+    uint64_t kth = NIDX_EMPTY_KEY;
+    for (uint32_t base = wib * 64; base < total; base += 256) {
+        uint32_t i = base + lane;
+        uint64_t ck = i < total ? src[i] : NIDX_EMPTY_KEY;
+        unsigned long long m = __ballot(ck > kth);
+        while (m) {
+            int s = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            uint64_t nk = shfl_u64(ck, s);
+            if (nk > kth) {
+                top.insert(nk, lane);
+                kth = top.at((int)k - 1);
+            }
+        }
+    }
+    __shared__ uint64_t lds[3][64];
+    if (wib > 0) lds[wib - 1][lane] = top.key;
+    __syncthreads();
+    if (wib == 0) {
+        for (int w = 0; w < 3; w++)
+            for (uint32_t i = 0; i < k; i++) {
+                uint64_t nk = lds[w][i];
+                if (nk == NIDX_EMPTY_KEY) break;
+                if (nk > kth) {
+                    top.insert(nk, lane);
+                    kth = top.at((int)k - 1);
+                } else break;
+            }
+        unsigned long long valid = __ballot(top.key != NIDX_EMPTY_KEY && lane < (int)k);
+        if (lane < (int)k) {
+            bool v = top.key != NIDX_EMPTY_KEY;
+            out_vec[(size_t)q * k + lane] = v ? rank_key_addr(top.key) : 0xffffffffu;
+            out_score[(size_t)q * k + lane] = v ? rank_key_score(top.key) : 0.f;
+        }
+        if (lane == 0) out_count[q] = (uint32_t)__popcll(valid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+template <int NJ, bool WIDE>
+static hipError_t launch_scan_nj(const ScanArgs &a, uint32_t nblk, hipStream_t s) {
+    if (a.qt == 1) {
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, 1>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
+    } else if (a.qt == 4 || !WIDE) {
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, 4>), dim3(nblk, (a.n_queries + 3) / 4), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, (WIDE ? 8 : 4)>), dim3(nblk, (a.n_queries + 7) / 8), dim3(256), 0, s,
+                           a);
+    }
+    return hipGetLastError();
+}
+
+// queries per pass over the rows: 8 while the tile fits the register file (D <= 1024), else 4
+uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp) {
+    if (n_queries == 1) return 1;
+    if (n_queries <= 4 || dp > 1024) return 4;
+    return 8;
+}
+
+uint32_t scan_num_blocks(uint32_t n) {
+    uint32_t b = (n + 15) / 16;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return b;
+}
+
+hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
+    a.qt = scan_query_tile(a.n_queries, a.dp);
+    int nj = (int)((a.dp + 255u) / 256u);
+    if (nj <= 1) return launch_scan_nj<1, true>(a, nblk, s);
+    if (nj <= 2) return launch_scan_nj<2, true>(a, nblk, s);
+    if (nj <= 3) return launch_scan_nj<3, true>(a, nblk, s);
+    if (nj <= 4) return launch_scan_nj<4, true>(a, nblk, s);
+    if (nj <= 6) return launch_scan_nj<6, false>(a, nblk, s);
+    if (nj <= 8) return launch_scan_nj<8, false>(a, nblk, s);
+    if (nj <= 12) return launch_scan_nj<12, false>(a, nblk, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
+                             uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s) {
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
+                       out_score, out_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norms(const float *vectors, uint32_t n, uint32_t dp, float *norm2, hipStream_t s) {
+    uint32_t blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, s, vectors, n, dp, norm2);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_similarity(const float *x, const float *y, uint32_t n, uint32_t dp, int similarity, float *out,
+                                  hipStream_t s) {
+    uint32_t blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pair_similarity_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, dp, similarity, out);
+    return hipGetLastError();
+}
+
+}  // namespace nidx

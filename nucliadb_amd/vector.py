@@ -1,0 +1,416 @@
+"""Host-side mirror of the reference's `nidx_vector` public interface over libnidx_gpu.
+
+Same names, argument meaning and error behaviour as the Rust crate so the parity tests read like
+the reference's own (`nidx/nidx_vector/tests/*.rs`):
+
+    VectorConfig            nidx_vector/src/config.rs:102-124
+    Elem, segment_create    nidx_vector/src/data_types.rs / segment.rs:199-239 (in-memory segment)
+    VectorSearchRequest     nidx_vector/src/request_types.rs:19-35
+    PrefilterResult/FieldId nidx_types/src/prefilter.rs:23-43
+    VectorSearcher          nidx_vector/src/lib.rs:120-148  (open / search / space_usage)
+
+Everything that touches vector data (similarity, HNSW traversal, brute-force scan, top-k) runs in
+the HIP kernels behind the C ABI; this module only keeps what the reference keeps host-side: keys,
+labels, sentence metadata, deletions -> alive bitsets, label/key-prefix formulas -> filter bitsets.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import uuid as _uuid
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import NidxGpuError  # noqa: F401  (re-exported)
+
+
+class Similarity(Enum):
+    Dot = 0
+    Cosine = 1
+
+
+class VectorCardinality(Enum):
+    Single = 0
+    Multi = 1
+
+
+@dataclass
+class VectorConfig:
+    """nidx_vector::config::VectorConfig (config.rs:102-124): the fields the hot path reads."""
+
+    dimension: int
+    similarity: Similarity = Similarity.Dot
+    normalize_vectors: bool = False
+    vector_cardinality: VectorCardinality = VectorCardinality.Single
+
+    @classmethod
+    def for_paragraphs(cls, dimension: int) -> "VectorConfig":
+        return cls(dimension=dimension)
+
+    def to_c(self) -> _lib.VectorConfigC:
+        return _lib.VectorConfigC(self.dimension, self.similarity.value, int(self.normalize_vectors), self.vector_cardinality.value)
+
+
+@dataclass
+class Elem:
+    """One indexed sentence (data_types / indexer.rs:94-145): key, vector, labels, metadata."""
+
+    key: str
+    vector: Sequence[float]
+    labels: List[str] = field(default_factory=list)
+    metadata: bytes = b""
+
+
+# ---- boolean filter expressions (nidx_types/src/query_language.rs:23-40) ---------------------------
+@dataclass
+class Literal:
+    label: str
+
+
+@dataclass
+class Not:
+    operand: "BooleanExpression"
+
+
+@dataclass
+class And:
+    operands: List["BooleanExpression"]
+
+
+@dataclass
+class Or:
+    operands: List["BooleanExpression"]
+
+
+BooleanExpression = Union[Literal, Not, And, Or]
+
+
+class FilterOperator(Enum):
+    And = 0
+    Or = 1
+
+
+@dataclass
+class FieldId:
+    resource_id: _uuid.UUID
+    field_id: Optional[str] = None  # e.g. "/a/title"; None = every field of the resource
+
+
+class PrefilterResult:
+    """nidx_types::prefilter::PrefilterResult: None_ / All / Some(fields)."""
+
+    def __init__(self, kind: str, fields: Optional[List[FieldId]] = None):
+        self.kind = kind
+        self.fields = fields or []
+
+    @classmethod
+    def none(cls) -> "PrefilterResult":
+        return cls("none")
+
+    @classmethod
+    def all(cls) -> "PrefilterResult":
+        return cls("all")
+
+    @classmethod
+    def some(cls, fields: List[FieldId]) -> "PrefilterResult":
+        return cls("some", fields)
+
+
+PrefilterResult.All = PrefilterResult.all()  # type: ignore[attr-defined]
+PrefilterResult.None_ = PrefilterResult.none()  # type: ignore[attr-defined]
+
+
+@dataclass
+class VectorSearchRequest:
+    vector: Sequence[float] = ()
+    result_per_page: int = 0
+    with_duplicates: bool = False
+    vector_set: str = ""
+    min_score: float = 0.0
+    filtering_formula: Optional[BooleanExpression] = None
+    segment_filtering_formula: Optional[BooleanExpression] = None
+    filter_operator: FilterOperator = FilterOperator.And
+
+
+@dataclass
+class DocumentScored:
+    """nodereader.proto DocumentScored (:130-136)."""
+
+    doc_id: str
+    score: float
+    metadata: Optional[bytes]
+    labels: List[str]
+
+
+@dataclass
+class VectorSearchResponse:
+    documents: List[DocumentScored]
+
+
+# ---- segments ------------------------------------------------------------------------------------------
+def _key_norm(key: str) -> str:
+    """Paragraph keys start with a hyphenated uuid; the inverted index stores it in simple form."""
+    head, sep, rest = key.partition("/")
+    try:
+        head = _uuid.UUID(head).hex
+    except ValueError:
+        pass
+    return head + sep + rest
+
+
+class VectorSegment:
+    """An in-memory vector segment: what segment::create writes to disk (segment.rs:199-239) minus
+    the files.  `graph` is an hnsw.graph image (DiskHnswV2) or None."""
+
+    def __init__(self, keys: List[str], vectors: np.ndarray, labels: List[List[str]], metadata: List[bytes],
+                 tags: Optional[set] = None, graph: Optional[bytes] = None):
+        self.keys = keys
+        self.vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        self.labels = labels
+        self.metadata = metadata
+        self.tags = set(tags or ())
+        self.graph = graph
+        self.records = len(keys)
+        self._norm_keys = [_key_norm(k) for k in keys]
+        self._label_index: dict = {}
+        for i, ls in enumerate(labels):
+            for lab in ls:
+                self._label_index.setdefault(lab, []).append(i)
+
+    # ParagraphInvertedIndexes::filter (inverted_index/paragraph.rs:124-184) on the host
+    def _eval(self, expr) -> np.ndarray:
+        n = self.records
+        if isinstance(expr, Literal):
+            m = np.zeros(n, dtype=bool)
+            m[self._label_index.get(expr.label, [])] = True
+            return m
+        if isinstance(expr, _KeyPrefixSet):
+            m = np.zeros(n, dtype=bool)
+            for i, k in enumerate(self._norm_keys):
+                if any(k.startswith(p) for p in expr.prefixes):
+                    m[i] = True
+            return m
+        if isinstance(expr, Not):
+            return ~self._eval(expr.operand)
+        if isinstance(expr, And):
+            m = np.ones(n, dtype=bool)
+            for o in expr.operands:
+                m &= self._eval(o)
+            return m
+        if isinstance(expr, Or):
+            m = np.zeros(n, dtype=bool)
+            for o in expr.operands:
+                m |= self._eval(o)
+            return m
+        raise TypeError(f"unknown expression {expr!r}")
+
+    def ids_for_deletion_key(self, key: str) -> List[int]:
+        """apply_deletions' lookup (segment.rs:428-445): a resource uuid or `uuid/type/name`."""
+        parts = key.split("/")
+        try:
+            rid = _uuid.UUID(parts[0]).hex
+        except ValueError:
+            return []
+        if len(parts) == 1:
+            prefix = rid + "/"
+        elif len(parts) >= 3:
+            prefix = f"{rid}/{parts[1]}/{parts[2]}/"
+        else:
+            return []
+        return [i for i, k in enumerate(self._norm_keys) if k.startswith(prefix) or k == prefix[:-1]]
+
+
+@dataclass
+class _KeyPrefixSet:
+    prefixes: List[str]
+
+
+def segment_create(elems: Iterable[Elem], config: VectorConfig, tags: Optional[set] = None) -> VectorSegment:
+    """segment::create (segment.rs:199-239): dimension check, optional normalisation is the
+    indexer's job (indexer.rs:107-111).  The HNSW graph is built later on the device
+    (VectorSearcher.build_hnsw) or supplied as an hnsw.graph image."""
+    elems = list(elems)
+    for e in elems:
+        if len(e.vector) != config.dimension:
+            raise NidxGpuError(_lib.NIDX_ERR_INCONSISTENT_DIMENSIONS,
+                               f"Inconsistent dimensions. Index={config.dimension} Vector={len(e.vector)}")
+    vectors = np.array([e.vector for e in elems], dtype=np.float32).reshape(len(elems), config.dimension)
+    return VectorSegment([e.key for e in elems], vectors, [list(e.labels) for e in elems], [e.metadata for e in elems], tags)
+
+
+def _bitset(mask: np.ndarray) -> np.ndarray:
+    n = mask.shape[0]
+    words = (n + 63) // 64
+    padded = np.zeros(words * 64, dtype=np.uint8)
+    padded[:n] = mask
+    return np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words).copy()
+
+
+def _segment_matches(expr, tags: set) -> bool:
+    """searcher.rs:206-219 segment_matches."""
+    if isinstance(expr, Literal):
+        return expr.label in tags
+    if isinstance(expr, Not):
+        return not _segment_matches(expr.operand, tags)
+    if isinstance(expr, And):
+        return all(_segment_matches(o, tags) for o in expr.operands)
+    if isinstance(expr, Or):
+        return any(_segment_matches(o, tags) for o in expr.operands)
+    raise TypeError(expr)
+
+
+class VectorSearcher:
+    """nidx_vector::VectorSearcher (lib.rs:120-148)."""
+
+    def __init__(self):
+        self._handle = C.c_void_p()
+        self._segments: List[VectorSegment] = []
+        self._keep = []  # buffers referenced by the C structs during open
+        self.config: Optional[VectorConfig] = None
+        self.last_methods: List[int] = []
+
+    @classmethod
+    def open(cls, config: VectorConfig, segments: Sequence[Tuple[VectorSegment, int]],
+             deletions: Sequence[Tuple[str, int]] = ()) -> "VectorSearcher":
+        """VectorSearcher::open(config, impl OpenIndexMetadata) (lib.rs:126-200): segments sorted by
+        seq, walked newest -> oldest accumulating the deletions with seq > segment seq."""
+        self = cls()
+        self.config = config
+        segs = sorted(segments, key=lambda t: t[1])
+        dels = sorted(deletions, key=lambda t: t[1])
+        ordered: List[Tuple[VectorSegment, np.ndarray]] = []
+        so_far: List[str] = []
+        di = len(dels) - 1
+        for seg, seq in reversed(segs):
+            while di >= 0 and dels[di][1] > seq:
+                so_far.append(dels[di][0])
+                di -= 1
+            alive = np.ones(seg.records, dtype=bool)
+            for key in so_far:
+                alive[seg.ids_for_deletion_key(key)] = False
+            ordered.append((seg, alive))
+        # open_segments pushes in that (newest first) order and _search walks them in it
+        c_segs = (_lib.VectorSegmentC * max(1, len(ordered)))()
+        key_table: dict = {}  # Fssc equates hits by paragraph id string (searcher.rs:67-96): intern the keys
+        for i, (seg, alive) in enumerate(ordered):
+            if seg.vectors.shape[1] != config.dimension and seg.records:
+                raise NidxGpuError(_lib.NIDX_ERR_INCONSISTENT_DIMENSIONS,
+                                   f"Inconsistent dimensions. Index={config.dimension} Vector={seg.vectors.shape[1]}")
+            bits = _bitset(alive)
+            graph = np.frombuffer(seg.graph, dtype=np.uint8) if seg.graph else None
+            key_ids = np.array([key_table.setdefault(k, len(key_table)) for k in seg.keys], dtype=np.uint64)
+            self._keep += [bits, graph, seg.vectors, key_ids]
+            c_segs[i].vectors = seg.vectors.ctypes.data
+            c_segs[i].row_stride_bytes = config.dimension * 4
+            c_segs[i].n_vectors = seg.records
+            c_segs[i].paragraph_of_vector = None
+            c_segs[i].n_paragraphs = seg.records
+            c_segs[i].hnsw_graph = graph.ctypes.data if graph is not None else None
+            c_segs[i].hnsw_graph_len = len(seg.graph) if seg.graph else 0
+            c_segs[i].alive_bitset = bits.ctypes.data
+            c_segs[i].paragraph_key_ids = key_ids.ctypes.data if seg.records else None
+            self._segments.append(seg)
+        cfg = config.to_c()
+        _lib.check(_lib.lib().nidx_gpu_vector_open(C.byref(cfg), c_segs, len(ordered), C.byref(self._handle)))
+        self._keep = []  # everything was copied to HBM / host vectors by open
+        return self
+
+    def close(self):
+        if self._handle:
+            _lib.lib().nidx_gpu_vector_close(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def space_usage(self) -> int:
+        out = C.c_uint64(0)
+        _lib.check(_lib.lib().nidx_gpu_vector_space_usage(self._handle, C.byref(out)))
+        return out.value
+
+    def build_hnsw(self, segment: int = 0, level_seed: int = 2):
+        """HnswBuilder on the device (hnsw/build.rs); the reference seeds the level RNG with 2."""
+        _lib.check(_lib.lib().nidx_gpu_vector_build_hnsw(self._handle, segment, level_seed))
+
+    def serialize_hnsw(self, segment: int = 0) -> Tuple[bytes, np.ndarray]:
+        glen, nedges = C.c_uint64(0), C.c_uint64(0)
+        L = _lib.lib()
+        _lib.check(L.nidx_gpu_vector_serialize_hnsw(self._handle, segment, None, 0, C.byref(glen), None, 0, C.byref(nedges)))
+        graph = np.zeros(max(1, glen.value), dtype=np.uint8)
+        edges = np.zeros(max(1, nedges.value), dtype=np.float32)
+        _lib.check(L.nidx_gpu_vector_serialize_hnsw(self._handle, segment, graph.ctypes.data, glen.value, C.byref(glen),
+                                                    edges.ctypes.data, nedges.value, C.byref(nedges)))
+        return graph[: glen.value].tobytes(), edges[: nedges.value]
+
+    # -- Searcher::search (searcher.rs:292-343) ---------------------------------------------------------
+    def _formula(self, request: VectorSearchRequest, prefilter: PrefilterResult):
+        clauses = []
+        if prefilter.kind == "some":
+            prefixes = []
+            for f in prefilter.fields:
+                prefixes.append(f.resource_id.hex + (f.field_id or ""))
+            clauses.append(_KeyPrefixSet(prefixes))
+        if request.filtering_formula is not None:
+            clauses.append(request.filtering_formula)
+        if not clauses:
+            return None
+        return Or(clauses) if request.filter_operator == FilterOperator.Or else And(clauses)
+
+    def search_batch(self, request: VectorSearchRequest, queries: np.ndarray, prefilter: PrefilterResult = None,
+                     method: int = _lib.METHOD_AUTO):
+        """Batched form of search(): `queries` [B][D].  Returns (segment, paragraph, vector, score, count)."""
+        prefilter = prefilter or PrefilterResult.all()
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim != 2:
+            raise ValueError("queries must be [B][D]")
+        B, D = queries.shape
+        k = max(0, int(request.result_per_page))
+        S = len(self._segments)
+        formula = self._formula(request, prefilter)
+        filt_arrays, filt_ptrs = [], (C.c_void_p * max(1, S))()
+        for s, seg in enumerate(self._segments):
+            # segment tag filter (searcher.rs:272-277): a non-matching segment is skipped = empty filter
+            skip = request.segment_filtering_formula is not None and not _segment_matches(request.segment_filtering_formula, seg.tags)
+            if skip:
+                bits = _bitset(np.zeros(seg.records, dtype=bool))
+            elif formula is not None:
+                bits = _bitset(seg._eval(formula))
+            else:
+                bits = None
+            filt_arrays.append(bits)
+            filt_ptrs[s] = bits.ctypes.data if bits is not None else None
+        any_filter = any(b is not None for b in filt_arrays)
+        kk = max(1, k)
+        out_seg = np.zeros((B, kk), dtype=np.uint32)
+        out_par = np.zeros((B, kk), dtype=np.uint32)
+        out_vec = np.zeros((B, kk), dtype=np.uint32)
+        out_score = np.zeros((B, kk), dtype=np.float32)
+        out_count = np.zeros(B, dtype=np.uint32)
+        out_method = np.zeros(max(1, S), dtype=np.int32)
+        params = _lib.VectorSearchParamsC(k, float(request.min_score), int(request.with_duplicates), method)
+        rc = _lib.lib().nidx_gpu_vector_search_dim(
+            self._handle, queries.ctypes.data, B, D, C.byref(params), filt_ptrs if any_filter else None,
+            out_seg.ctypes.data, out_par.ctypes.data, out_vec.ctypes.data, out_score.ctypes.data,
+            out_count.ctypes.data, out_method.ctypes.data)
+        _lib.check(rc)
+        self.last_methods = out_method[:S].tolist()
+        return out_seg, out_par, out_vec, out_score, out_count
+
+    def search(self, request: VectorSearchRequest, prefilter: PrefilterResult = None,
+               method: int = _lib.METHOD_AUTO) -> VectorSearchResponse:
+        prefilter = prefilter or PrefilterResult.all()
+        q = np.asarray(request.vector, dtype=np.float32).reshape(1, -1)
+        seg, par, _vec, score, count = self.search_batch(request, q, prefilter, method)
+        docs = []
+        for i in range(int(count[0])):
+            s, p = int(seg[0, i]), int(par[0, i])
+            sg = self._segments[s]
+            md = sg.metadata[p]
+            docs.append(DocumentScored(sg.keys[p], float(score[0, i]), md if md else None, list(sg.labels[p])))
+        return VectorSearchResponse(docs)

@@ -1,0 +1,132 @@
+"""CPU-side checks of the C ABI library: it loads, exports every symbol include/nidx_gpu.h declares,
+fails loudly without a device, and its host-only entry points agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as g
+
+    g.build()
+    return _lib.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    header = open(os.path.join(ROOT, "include", "nidx_gpu.h")).read()
+    declared = set(re.findall(r"\b(nidx_gpu_[a-z0-9_]+)\s*\(", header))
+    declared -= {"nidx_gpu_vector_index_t", "nidx_gpu_bm25_index_t"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/nidx_gpu.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert L.nidx_gpu_abi_version() == 1
+
+
+def test_no_cpu_fallback_when_device_missing(L):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = _lib.VectorConfigC(4, 0, 0, 0)
+    x = np.zeros((2, 4), np.float32)
+    seg = _lib.VectorSegmentC(x.ctypes.data, 16, 2, None, 2, None, 0, None, None)
+    h = C.c_void_p()
+    rc = L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h))
+    assert rc == _lib.NIDX_ERR_DEVICE and not h
+    assert "HIP error" in _lib.last_error()
+    out = np.zeros(2, np.float32)
+    rc = L.nidx_gpu_similarity(x.ctypes.data, x.ctypes.data, 2, 4, 1, _lib.ORDER_WAVE64, out.ctypes.data)
+    assert rc == _lib.NIDX_ERR_DEVICE
+
+
+def test_config_errors(L):
+    h = C.c_void_p()
+    cfg = _lib.VectorConfigC(0, 0, 0, 0)
+    assert L.nidx_gpu_vector_open(C.byref(cfg), None, 0, C.byref(h)) == _lib.NIDX_ERR_INVALID_CONFIGURATION
+    assert "dimension cannot be 0" in _lib.last_error()
+    cfg = _lib.VectorConfigC(8, 7, 0, 0)
+    assert L.nidx_gpu_vector_open(C.byref(cfg), None, 0, C.byref(h)) == _lib.NIDX_ERR_INVALID_CONFIGURATION
+
+
+def test_use_hnsw_matches_oracle(L, orc):
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        total = int(rng.integers(1, 3_000_000))
+        matching = int(rng.integers(1, total + 1))
+        k = int(rng.integers(1, 200))
+        for rq in (0, 1):
+            assert bool(L.nidx_gpu_use_hnsw(total, matching, k, rq)) == orc.use_hnsw(total, matching, k, bool(rq))
+    # the crossover quoted in SURVEY §8a6: k=10 unfiltered -> HNSW from a few hundred records up
+    assert not L.nidx_gpu_use_hnsw(100, 100, 10, 0)
+    assert L.nidx_gpu_use_hnsw(100_000, 100_000, 10, 0)
+
+
+def test_normalize_matches_oracle(L, orc):
+    rng = np.random.default_rng(6)
+    for d in (3, 10, 64, 758, 768):
+        x = rng.normal(size=(5, d)).astype(np.float32)
+        out = np.empty_like(x)
+        assert L.nidx_gpu_normalize(x.ctypes.data, 5, d, out.ctypes.data) == 0
+        for i in range(5):
+            assert np.array_equal(out[i].view(np.uint32), orc.normalize(x[i]).view(np.uint32))
+
+
+def _merge_vector(L, lists, limit):
+    n = len(lists)
+    sc = [np.array([s for s, _ in l], np.float32) for l in lists]
+    ids = [np.array([i for _, i in l], np.uint64) for l in lists]
+    lens = np.array([len(l) for l in lists], np.uint32)
+    scp = (C.c_void_p * n)(*[a.ctypes.data for a in sc])
+    idp = (C.c_void_p * n)(*[a.ctypes.data for a in ids])
+    os_, oi, ol = np.zeros(limit, np.float32), np.zeros(limit, np.uint64), np.zeros(limit, np.uint32)
+    cnt = C.c_uint32()
+    assert L.nidx_gpu_merge_vector(scp, idp, lens.ctypes.data, n, limit, os_.ctypes.data, oi.ctypes.data, ol.ctypes.data, C.byref(cnt)) == 0
+    return [(float(os_[i]), int(oi[i])) for i in range(cnt.value)]
+
+
+def test_merge_vector_matches_oracle(L, orc):
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        n = int(rng.integers(1, 9))
+        lists = []
+        for s in range(n):
+            m = int(rng.integers(0, 12))
+            # coarse scores => many cross-shard ties, the case kmerge's heap order decides
+            sc = np.sort(rng.integers(0, 6, m).astype(np.float32) / 4)[::-1]
+            lists.append([(float(x), (s << 32) | i) for i, x in enumerate(sc)])
+        limit = int(rng.integers(1, 25))
+        assert _merge_vector(L, lists, limit) == orc.merge_vector(lists, limit)
+
+
+def test_merge_bm25_matches_oracle(L, orc):
+    rng = np.random.default_rng(8)
+    for trial in range(200):
+        n = int(rng.integers(1, 9))
+        shard_ids = [bytes(rng.integers(97, 100, int(rng.integers(1, 4))).astype(np.uint8)) for _ in range(n)]
+        lists = []
+        for s in range(n):
+            m = int(rng.integers(0, 12))
+            sc = np.sort(rng.integers(0, 5, m).astype(np.float32))[::-1]
+            addr = np.sort(rng.integers(0, 50, m).astype(np.uint64))
+            lists.append([(float(sc[i]), int(addr[i]), shard_ids[s], (s << 16) | i) for i in range(m)])
+        limit = int(rng.integers(1, 25))
+        want = orc.merge_bm25(lists, limit)
+        sc = [np.array([h[0] for h in l], np.float32) for l in lists]
+        da = [np.array([h[1] for h in l], np.uint64) for l in lists]
+        lens = np.array([len(l) for l in lists], np.uint32)
+        sid = [np.frombuffer(b, np.uint8).copy() for b in shard_ids]
+        sidl = np.array([len(b) for b in shard_ids], np.uint32)
+        P = lambda arrs: (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        os_, od, ol = np.zeros(limit, np.float32), np.zeros(limit, np.uint64), np.zeros(limit, np.uint32)
+        cnt = C.c_uint32()
+        assert L.nidx_gpu_merge_bm25(P(sc), P(da), lens.ctypes.data, P(sid), sidl.ctypes.data, n, limit, os_.ctypes.data,
+                                     od.ctypes.data, ol.ctypes.data, C.byref(cnt)) == 0
+        got = [(float(os_[i]), int(od[i]), shard_ids[int(ol[i])]) for i in range(cnt.value)]
+        assert got == [(w[0], w[1], w[2]) for w in want], (got, want)

@@ -1,0 +1,238 @@
+"""GPU parity tests of the vector path: HIP kernels (through the C ABI) vs the CPU oracle on the same
+seeded inputs.  Bar: bit-exact vector addresses, ranks AND score bit patterns (both sides sum in the
+WAVE64 order); SURVEY §8c asks for cosine within 1e-5, which bit-exactness implies."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import (Similarity, VectorConfig, VectorSearcher, VectorSearchRequest, VectorSegment)
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_rows(rng, n, d):
+    # the reference's own generator (segment.rs:682-695): uniform(-1,1) then L2-normalised
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    return x
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def make_segment(x, graph=None):
+    n = x.shape[0]
+    return VectorSegment([f"k{i}" for i in range(n)], x, [[] for _ in range(n)], [b""] * n, graph=graph)
+
+
+def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_duplicates=True, filter_bits=None, alive=None):
+    """Single segment straight through the C ABI (no Python filter logic in between)."""
+    L = _lib.lib()
+    n, d = x.shape
+    cfg = _lib.VectorConfigC(d, sim, 0, 0)
+    g = np.frombuffer(graph, np.uint8) if graph is not None else None
+    seg = _lib.VectorSegmentC(x.ctypes.data, d * 4, n, None, n, g.ctypes.data if g is not None else None,
+                              len(graph) if graph is not None else 0, alive.ctypes.data if alive is not None else None, None)
+    h = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)))
+    try:
+        q = np.ascontiguousarray(queries, np.float32)
+        B = q.shape[0]
+        ov, osc, oc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
+        params = _lib.VectorSearchParamsC(k, min_score, int(with_duplicates), method)
+        fp = None
+        if filter_bits is not None:
+            fp = (C.c_void_p * 1)(filter_bits.ctypes.data)
+        _lib.check(L.nidx_gpu_vector_search(h, q.ctypes.data, B, C.byref(params), fp, None, None, ov.ctypes.data,
+                                            osc.ctypes.data, oc.ctypes.data, None))
+        return ov, osc, oc
+    finally:
+        L.nidx_gpu_vector_close(h)
+
+
+# ---- a1: dense_f32::{dot,cosine}_similarity -----------------------------------------------------------
+@pytest.mark.parametrize("d", [3, 10, 64, 256, 758, 768, 1024, 1536])
+def test_similarity_bits_match_oracle(orc, d):
+    rng = np.random.default_rng(d)
+    n = 257
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    y = rng.normal(size=(n, d)).astype(np.float32)
+    x[0] = 0  # zero-norm edge cases of SimSIMD's cosine
+    y[1] = 0
+    x[2] = 0
+    y[2] = 0
+    y[3] = x[3]
+    L = _lib.lib()
+    for sim in (0, 1):
+        out = np.zeros(n, np.float32)
+        _lib.check(L.nidx_gpu_similarity(x.ctypes.data, y.ctypes.data, n, d, sim, _lib.ORDER_WAVE64, out.ctypes.data))
+        want = np.array([orc.similarity(x[i], y[i], sim) for i in range(n)], np.float32)
+        assert np.array_equal(bits(out), bits(want)), np.nonzero(bits(out) != bits(want))
+    # and the reference's own accuracy bar (dense_f32.rs:66-84): |ours - naive| < 0.01
+    naive = np.einsum("ij,ij->i", x.astype(np.float64), y.astype(np.float64))
+    out = np.zeros(n, np.float32)
+    _lib.check(L.nidx_gpu_similarity(x.ctypes.data, y.ctypes.data, n, d, 0, _lib.ORDER_WAVE64, out.ctypes.data))
+    assert np.max(np.abs(out - naive)) < 0.01
+
+
+# ---- a7: brute_force_search ----------------------------------------------------------------------------
+@pytest.mark.parametrize("sim", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 3), (5, 3, 2, 10), (4000, 64, 9, 10), (20000, 768, 17, 10), (3000, 758, 5, 7),
+                                      (2500, 1024, 8, 64), (1200, 1536, 3, 5)])
+def test_brute_force_matches_oracle(orc, sim, n, d, nq, k):
+    rng = np.random.default_rng(n * 31 + d)
+    x = unit_rows(rng, n, d) if d > 3 else rng.normal(size=(n, d)).astype(np.float32)
+    q = rng.normal(size=(nq, d)).astype(np.float32)
+    ov, osc, oc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE)
+    oseg = orc.Segment(x, similarity=sim)
+    for i in range(nq):
+        wv, ws = oseg.brute_force(q[i], k)
+        assert oc[i] == len(wv)
+        assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i], wv)
+        assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_brute_force_filters_min_score_and_ties(orc):
+    rng = np.random.default_rng(99)
+    n, d, k = 6000, 128, 10
+    x = unit_rows(rng, n, d)
+    x[100:140] = x[7]          # 41 identical rows -> 41-way exact score ties: order must be address asc
+    q = np.vstack([x[7][None, :], rng.normal(size=(4, d)).astype(np.float32)])
+    alive = orc.bitset(n, fill=True)
+    for dead in (7, 100, 101, 5999):
+        alive[dead >> 6] &= ~np.uint64(1 << (dead & 63))
+    filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.3)[0].tolist() + list(range(100, 140)))
+    both = alive & filt
+    for sim in (0, 1):
+        oseg = orc.Segment(x, similarity=sim, alive=alive)
+        for kwargs, obits in (({"alive": alive}, alive), ({"alive": alive, "filter_bits": filt}, both)):
+            for ms in (-1.0, 0.1, 0.99):
+                ov, osc, oc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE, min_score=ms, **kwargs)
+                for i in range(q.shape[0]):
+                    wv, ws = oseg.brute_force(q[i], k, min_score=ms, filter_bits=obits)
+                    assert oc[i] == len(wv), (sim, ms, i)
+                    assert np.array_equal(ov[i, : oc[i]], wv)
+                    assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+# ---- a3/a4/a5: HNSW search over an oracle-built graph (DiskHnswV2 image) --------------------------------
+@pytest.fixture(scope="module")
+def hnsw_case(orc):
+    rng = np.random.default_rng(1234567890)
+    n, d = 3000, 96
+    x = unit_rows(rng, n, d)
+    x[50:58] = x[49]  # duplicate vectors: exercises RepCounter (with_duplicates=false)
+    oseg = orc.Segment(x, similarity=orc.SIM_COSINE)
+    g = oseg.build_graph(seed=2)
+    gbytes, _ = g.serialize_v2(n)
+    return x, oseg, bytes(gbytes)
+
+
+@pytest.mark.parametrize("k", [1, 10, 30, 50])
+@pytest.mark.parametrize("with_dup", [True, False])
+def test_hnsw_search_matches_oracle(orc, hnsw_case, k, with_dup):
+    x, oseg, gbytes = hnsw_case
+    rng = np.random.default_rng(k)
+    q = np.vstack([x[49][None, :], x[1234][None, :], unit_rows(rng, 30, x.shape[1])])
+    ov, osc, oc = gpu_search(x, 1, q, k, method=_lib.METHOD_HNSW, graph=gbytes, with_duplicates=with_dup)
+    for i in range(q.shape[0]):
+        wv, ws = oseg.hnsw_search(q[i], k, with_duplicates=with_dup)
+        assert oc[i] == len(wv), (i, oc[i], len(wv))
+        assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i, : oc[i]], wv)
+        assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_hnsw_search_filter_and_min_score(orc, hnsw_case):
+    x, oseg, gbytes = hnsw_case
+    n = x.shape[0]
+    rng = np.random.default_rng(3)
+    q = unit_rows(rng, 16, x.shape[1])
+    for sel in (0.5, 0.05):
+        filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < sel)[0].tolist())
+        for ms in (-1.0, 0.2):
+            ov, osc, oc = gpu_search(x, 1, q, 10, method=_lib.METHOD_HNSW, graph=gbytes, filter_bits=filt, min_score=ms)
+            for i in range(q.shape[0]):
+                wv, ws = oseg.hnsw_search(q[i], 10, min_score=ms, filter_bits=filt)
+                assert oc[i] == len(wv), (sel, ms, i, oc[i], len(wv))
+                assert np.array_equal(ov[i, : oc[i]], wv)
+                assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_auto_routing_follows_use_hnsw(orc, hnsw_case):
+    x, oseg, gbytes = hnsw_case
+    n = x.shape[0]
+    rng = np.random.default_rng(4)
+    q = unit_rows(rng, 4, x.shape[1])
+    # unfiltered: HNSW; 20 matching rows: brute force (segment.rs:626-660)
+    few = orc.bitset(n, ones=list(range(0, n, n // 20))[:20])
+    for filt in (None, few):
+        ov, osc, oc = gpu_search(x, 1, q, 10, method=_lib.METHOD_AUTO, graph=gbytes, filter_bits=filt)
+        for i in range(q.shape[0]):
+            wv, ws, method = oseg.search(q[i], 10, filter_bits=filt)
+            assert method == ("hnsw" if filt is None else "brute force")
+            assert np.array_equal(ov[i, : oc[i]], wv) and np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_hnsw_dot_d768(orc):
+    rng = np.random.default_rng(77)
+    n, d = 1500, 768
+    x = unit_rows(rng, n, d)
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT)
+    g = oseg.build_graph(seed=2)
+    gbytes, _ = g.serialize_v2(n)
+    q = unit_rows(rng, 12, d)
+    ov, osc, oc = gpu_search(x, 0, q, 10, method=_lib.METHOD_HNSW, graph=bytes(gbytes))
+    for i in range(q.shape[0]):
+        wv, ws = oseg.hnsw_search(q[i], 10)
+        assert np.array_equal(ov[i, : oc[i]], wv) and np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_graph_image_round_trip(orc, hnsw_case):
+    """hnsw.graph in -> HBM layout -> hnsw.graph out must be byte identical (disk/v2.rs:339-473)."""
+    x, oseg, gbytes = hnsw_case
+    s = VectorSearcher.open(VectorConfig(x.shape[1], Similarity.Cosine), [(make_segment(x, gbytes), 1)])
+    out, _edges = s.serialize_hnsw(0)
+    s.close()
+    assert out == gbytes
+
+
+# ---- a9: multi-segment Fssc merge ----------------------------------------------------------------------------
+def test_multi_segment_fssc_matches_oracle(orc):
+    rng = np.random.default_rng(11)
+    d, k = 64, 10
+    xs = [unit_rows(rng, n, d) for n in (700, 300, 1200)]
+    xs[1][5] = xs[0][17]      # same vector bytes in two segments: dropped unless with_duplicates
+    xs[2][9] = xs[0][17]
+    q = np.vstack([xs[0][17][None, :], unit_rows(rng, 6, d)])
+    osegs = [orc.Segment(x, similarity=orc.SIM_DOT) for x in xs]
+    keys, base = [], 0
+    for x in xs:
+        keys.append(np.arange(base, base + x.shape[0], dtype=np.uint64))
+        base += x.shape[0]
+    segs = [VectorSegment([f"s{si}-{i}" for i in range(x.shape[0])], x, [[] for _ in range(x.shape[0])], [b""] * x.shape[0])
+            for si, x in enumerate(xs)]
+    # open() searches newest first: give the oracle the same order
+    searcher = VectorSearcher.open(VectorConfig(d, Similarity.Dot), [(segs[0], 3), (segs[1], 2), (segs[2], 1)])
+    for with_dup in (False, True):
+        req = VectorSearchRequest(result_per_page=k, min_score=-1.0, with_duplicates=with_dup)
+        seg, par, vec, score, count = searcher.search_batch(req, q)
+        for i in range(q.shape[0]):
+            want = orc.searcher_search(osegs, keys, q[i], k, with_duplicates=with_dup)
+            got = [(int(seg[i, j]), int(vec[i, j])) for j in range(count[i])]
+            assert got == [(w[2], w[3]) for w in want], (with_dup, i)
+            assert np.array_equal(bits(score[i, : count[i]]), bits([w[1] for w in want]))
+    searcher.close()
+
+
+# ---- error behaviour (searcher.rs:255-262) -----------------------------------------------------------------
+def test_inconsistent_dimensions():
+    x = np.eye(8, dtype=np.float32)
+    s = VectorSearcher.open(VectorConfig(8), [(make_segment(x), 1)])
+    with pytest.raises(_lib.NidxGpuError) as e:
+        s.search(VectorSearchRequest(vector=[0.0] * 7, result_per_page=3, min_score=-1.0))
+    assert e.value.code == _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS
+    assert "Inconsistent dimensions. Index=8 Vector=7" in e.value.message
+    s.close()
