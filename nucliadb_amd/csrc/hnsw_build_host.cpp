@@ -1,0 +1,145 @@
+// hnsw_build_host.cpp — host driver of the device HNSW build (nidx_gpu_vector_build_hnsw).
+//
+// HnswBuilder::initialize_graph (hnsw/build.rs:50-55): every node draws its top layer from
+// SmallRng::seed_from_u64(seed) and is added, edge-less, to layers 0..=top; the entry point is a
+// node of the top layer (ram_hnsw.rs:99-107 takes the first key of an FxHashMap, i.e. an arbitrary
+// one; we take the lowest address).  Then the nodes are inserted in address order in batches
+// (hnsw_build.hip) whose size grows with the graph: a batch never exceeds 1/16 of the nodes
+// already inserted, so at most ~6 % of a node's potential neighbours are invisible to it — the
+// same kind of race the reference's rayon workers have.
+#include <algorithm>
+
+#include "host_common.h"
+#include "vector_index.h"
+
+namespace nidx {
+
+static const uint32_t kMaxBatch = 8192;
+
+int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
+    std::lock_guard<std::mutex> lock(mu);
+    NIDX_HIP(hipSetDevice(device));
+    VectorSegment &seg = segs[si];
+    const uint32_t n = seg.n;
+    seg.has_graph = false;
+    if (n == 0) return NIDX_OK;
+    if (n >= (1u << 30)) return fail(NIDX_ERR_UNSUPPORTED, "segments of 2^30 or more vectors are not supported");
+    std::vector<uint8_t> levels;
+    draw_levels(level_seed, n, levels);
+    uint32_t max_level = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (levels[i] > 15) levels[i] = 15;  // 4 bits of layer in the request key; P(level > 15) ~ 30^-15
+        max_level = std::max<uint32_t>(max_level, levels[i]);
+    }
+    HostGraph hg;
+    hg.n = n;
+    hg.ep_layer = max_level;
+    hg.ep_node = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (levels[i] == max_level) { hg.ep_node = i; break; }
+    hg.top_layer = levels;
+    hg.upper_base.assign(n, 0xffffffffu);
+    uint32_t n_upper = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (levels[i] > 0) {
+            hg.upper_base[i] = n_upper;
+            n_upper += levels[i];
+        }
+    // edge-less graph in HBM
+    NIDX_HIP(seg.g_l0.alloc((size_t)n * NIDX_L0_STRIDE * 4));
+    NIDX_HIP(seg.g_l0_w.alloc((size_t)n * NIDX_L0_STRIDE * 4));
+    NIDX_HIP(seg.g_upper_base.alloc((size_t)n * 4));
+    NIDX_HIP(seg.g_upper.alloc((size_t)std::max<uint32_t>(n_upper, 1) * NIDX_UP_STRIDE * 4));
+    NIDX_HIP(seg.g_upper_w.alloc((size_t)std::max<uint32_t>(n_upper, 1) * NIDX_UP_STRIDE * 4));
+    NIDX_HIP(hipMemsetAsync(seg.g_l0.p, 0, seg.g_l0.bytes, stream));
+    NIDX_HIP(hipMemsetAsync(seg.g_l0_w.p, 0, seg.g_l0_w.bytes, stream));
+    NIDX_HIP(hipMemsetAsync(seg.g_upper.p, 0, seg.g_upper.bytes, stream));
+    NIDX_HIP(hipMemsetAsync(seg.g_upper_w.p, 0, seg.g_upper_w.bytes, stream));
+    NIDX_HIP(hipMemcpyAsync(seg.g_upper_base.p, hg.upper_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    seg.ep_node = hg.ep_node;
+    seg.ep_layer = hg.ep_layer;
+    seg.top_layer = levels;
+
+    // batch plan + per-node slot index inside its batch
+    struct Batch { uint32_t start, size, n_slots; };
+    std::vector<Batch> batches;
+    std::vector<uint32_t> slot_base(n);
+    uint32_t max_slots = 0;
+    for (uint32_t start = 0; start < n;) {
+        uint32_t size = std::min<uint32_t>(std::min<uint32_t>(kMaxBatch, std::max<uint32_t>(1, start / 16)), n - start);
+        uint32_t slots = 0;
+        for (uint32_t i = start; i < start + size; i++) {
+            slot_base[i] = slots;
+            slots += (uint32_t)levels[i] + 1;
+        }
+        batches.push_back(Batch{start, size, slots});
+        max_slots = std::max(max_slots, slots);
+        start += size;
+    }
+    DevBuf d_levels, d_slot_base, d_found, d_found_len, d_slot_node, d_slot_layer, d_req_key, d_req_key2, d_req_val,
+        d_req_val2, d_tmp, d_flags;
+    NIDX_HIP(d_levels.alloc(n));
+    NIDX_HIP(d_slot_base.alloc((size_t)n * 4));
+    NIDX_HIP(hipMemcpyAsync(d_levels.p, levels.data(), n, hipMemcpyHostToDevice, stream));
+    NIDX_HIP(hipMemcpyAsync(d_slot_base.p, slot_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    NIDX_HIP(d_found.alloc((size_t)max_slots * NIDX_BUILD_FOUND_STRIDE * 8));
+    NIDX_HIP(d_found_len.alloc((size_t)max_slots * 4));
+    NIDX_HIP(d_slot_node.alloc((size_t)max_slots * 4));
+    NIDX_HIP(d_slot_layer.alloc((size_t)max_slots * 4));
+    const size_t max_req = (size_t)max_slots * NIDX_BUILD_REQ_STRIDE;
+    NIDX_HIP(d_req_key.alloc(max_req * 8));
+    NIDX_HIP(d_req_key2.alloc(max_req * 8));
+    NIDX_HIP(d_req_val.alloc(max_req * 4));
+    NIDX_HIP(d_req_val2.alloc(max_req * 4));
+    size_t tmp_bytes = 0;
+    NIDX_HIP(build_sort_tmp_bytes((uint32_t)max_req, &tmp_bytes));
+    NIDX_HIP(d_tmp.alloc(std::max<size_t>(tmp_bytes, 16)));
+    NIDX_HIP(d_flags.alloc(4));
+    NIDX_HIP(hipMemsetAsync(d_flags.p, 0, 4, stream));
+
+    BuildBatch b;
+    b.seg = seg.seg_dev(cfg.similarity);
+    b.seg.alive = nullptr;  // deleted paragraphs stay in the graph (the alive bitset is a search-time filter)
+    b.g = seg.graph_dev();
+    b.l0_w = seg.g_l0_w.as<float>();
+    b.upper_w = seg.g_upper_w.as<float>();
+    b.levels = d_levels.as<uint8_t>();
+    b.found = d_found.as<uint64_t>();
+    b.found_len = d_found_len.as<uint32_t>();
+    b.slot_node = d_slot_node.as<uint32_t>();
+    b.slot_layer = d_slot_layer.as<uint32_t>();
+    b.req_key = d_req_key.as<uint64_t>();
+    b.req_key_sorted = d_req_key2.as<uint64_t>();
+    b.req_val = d_req_val.as<float>();
+    b.req_val_sorted = d_req_val2.as<float>();
+    b.sort_tmp = d_tmp.p;
+    b.sort_tmp_bytes = tmp_bytes;
+    b.vis_log2 = build_vis_log2;
+    b.flags = d_flags.as<uint32_t>();
+    for (const Batch &bt : batches) {
+        b.batch_start = bt.start;
+        b.batch_size = bt.size;
+        b.slot_base = d_slot_base.as<uint32_t>() + bt.start;
+        b.n_slots = bt.n_slots;
+        NIDX_HIP(launch_build_batch(b, stream));
+    }
+    uint32_t flags = 0;
+    NIDX_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, stream));
+    NIDX_HIP(hipStreamSynchronize(stream));
+    // a visited-table overflow only ends one construction search early (the graph is approximate by
+    // nature); a candidate-pool overflow cannot happen below 412 exact ties and is reported
+    if (flags & NIDX_FLAG_POOL_INEXACT) return fail(NIDX_ERR_INEXACT, "HNSW build: candidate pool overflow");
+    last_build_flags = flags;
+    seg.has_graph = true;
+    return NIDX_OK;
+}
+
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    return idx->build_hnsw(segment, level_seed);
+}

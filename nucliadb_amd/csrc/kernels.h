@@ -84,4 +84,27 @@ struct HnswSearchArgs {
 };
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
 
+// ---- HNSW build (hnsw_build.hip): one batch of concurrent inserts ----
+#define NIDX_BUILD_FOUND_STRIDE 128
+#define NIDX_BUILD_REQ_STRIDE 32
+struct BuildBatch {
+    SegDev seg;
+    GraphDev g;
+    float *l0_w, *upper_w;      // edge weights, same geometry as g.l0 / g.upper
+    const uint8_t *levels;      // [n] top layer of each node
+    uint32_t batch_start, batch_size;
+    const uint32_t *slot_base;  // [batch_size] first (node, layer) slot of each node of the batch
+    uint32_t n_slots;
+    uint64_t *found;            // [n_slots][128]
+    uint32_t *found_len, *slot_node, *slot_layer;  // [n_slots]
+    uint64_t *req_key, *req_key_sorted;            // [n_slots*32]
+    float *req_val, *req_val_sorted;               // [n_slots*32]
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
+    uint32_t vis_log2;
+    uint32_t *flags;            // [1]
+};
+hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
+hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
+
 }  // namespace nidx

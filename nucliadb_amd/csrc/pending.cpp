@@ -6,9 +6,6 @@ using namespace nidx;
 
 extern "C" {
 
-int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *, uint32_t, uint64_t) {
-    return fail(NIDX_ERR_UNSUPPORTED, "nidx_gpu_vector_build_hnsw: device HNSW build not implemented yet");
-}
 int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *, uint32_t, nidx_gpu_bm25_index_t **) {
     return fail(NIDX_ERR_UNSUPPORTED, "nidx_gpu_bm25_open: BM25 kernels not implemented yet");
 }

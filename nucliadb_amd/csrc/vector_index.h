@@ -46,6 +46,8 @@ struct VectorIndex {
     // tunables
     int waves_per_query = 4;
     uint32_t default_vis_log2 = 13;
+    uint32_t build_vis_log2 = 14;
+    uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
     DevBuf scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats;

@@ -1,0 +1,151 @@
+"""Device HNSW build (HnswBuilder, hnsw/build.rs): the graph is not unique in the reference either
+(rayon inserts, segment.rs:908), so parity is structural invariants + recall, against the oracle's
+sequential build and against the reference's own recall floor (segment.rs:841-912)."""
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import Similarity, VectorConfig, VectorSearcher, VectorSearchRequest, VectorSegment
+
+pytestmark = pytest.mark.gpu
+
+
+def normalize(v):
+    return (v / np.sqrt((v * v).sum(-1, keepdims=True))).astype(np.float32)
+
+
+def random_vector(rng, d, n=None):
+    return normalize(rng.uniform(-1, 1, (d,) if n is None else (n, d)).astype(np.float32))
+
+
+def nearby(rng, close_to, distance):
+    return normalize(close_to + random_vector(rng, close_to.shape[-1]) * np.float32(distance))
+
+
+def clustered(rng, d, clusters, per):
+    """The reference's recall recipe (segment.rs:849-862): chained centres, half the points at
+    radius 0.01 and half at 0.03."""
+    rows = []
+    center = random_vector(rng, d)
+    for _ in range(clusters):
+        for _ in range(per // 2):
+            rows.append(nearby(rng, center, 0.01))
+        for _ in range(per // 2):
+            rows.append(nearby(rng, center, 0.03))
+        center = nearby(rng, center, 0.1)
+    x = np.array(rows, np.float32)
+    return x[rng.permutation(len(x))]  # the reference inserts in BTreeMap key order = random
+
+
+def seg_of(x, graph=None):
+    n = x.shape[0]
+    return VectorSegment([f"k{i}" for i in range(n)], x, [[] for _ in range(n)], [b""] * n, graph=graph)
+
+
+def recall_at(searcher, q, k, method):
+    req = VectorSearchRequest(result_per_page=k, min_score=-1.0, with_duplicates=True)
+    _, _, exact, _, ec = searcher.search_batch(req, q, method=_lib.METHOD_BRUTE_FORCE)
+    _, _, got, _, gc = searcher.search_batch(req, q, method=method)
+    hit = 0
+    for i in range(q.shape[0]):
+        hit += len(set(exact[i, : ec[i]].tolist()) & set(got[i, : gc[i]].tolist()))
+    return hit / (q.shape[0] * k)
+
+
+def check_invariants(orc, graph_bytes, n, levels):
+    g = orc.Hnsw.deserialize_v2(np.frombuffer(graph_bytes, np.uint8))
+    ep_node, ep_layer = orc.disk_v2_entry_point(np.frombuffer(graph_bytes, np.uint8))
+    assert ep_layer == levels.max() and levels[ep_node] == ep_layer
+    gb = np.frombuffer(graph_bytes, np.uint8)
+    deg0 = np.zeros(n, np.int64)
+    for layer in range(int(ep_layer) + 1):
+        mmax = 60 if layer == 0 else 30
+        for node in range(n):
+            e = orc.disk_v2_edges(gb, layer, node)
+            if levels[node] < layer:
+                assert len(e) == 0, "edges on a layer the node is not in"
+                continue
+            assert len(e) <= mmax
+            assert len(set(e.tolist())) == len(e), "duplicate edge"
+            assert node not in e, "self loop"
+            assert all(levels[t] >= layer for t in e), "edge to a node outside the layer (ram_hnsw.rs:123-128)"
+            if layer == 0:
+                deg0[node] = len(e)
+    return deg0
+
+
+def test_levels_match_reference_rng(orc):
+    """The level draw is Xoshiro256++/SplitMix64 + round(-ln(u)/ln 30) (build.rs:97-101); the built
+    graph's layer membership must equal the oracle's draw for the same seed."""
+    rng = np.random.default_rng(5)
+    n, d = 3000, 32
+    x = random_vector(rng, d, n)
+    s = VectorSearcher.open(VectorConfig(d, Similarity.Dot), [(seg_of(x), 1)])
+    s.build_hnsw(0, level_seed=2)
+    graph, edges = s.serialize_hnsw(0)
+    s.close()
+    levels = orc.hnsw_levels(2, n)
+    deg0 = check_invariants(orc, graph, n, levels)
+    assert (deg0 > 0).all(), "every node must be linked on layer 0"
+    assert deg0.mean() > 20
+    assert len(edges) > 0 and np.isfinite(edges).all()
+
+
+def test_recall_clustered_data_reference_floor(orc):
+    """segment.rs:841-912: 4 chained clusters x 160 vectors of 256-d, 100 nearby queries, recall@5 >= 0.95."""
+    rng = np.random.default_rng(1234567890)
+    d = 256
+    x = clustered(rng, d, 4, 160)
+    q = np.array([nearby(rng, x[rng.integers(0, len(x))], 0.05) for _ in range(100)], np.float32)
+    s = VectorSearcher.open(VectorConfig(d, Similarity.Dot), [(seg_of(x), 1)])
+    s.build_hnsw(0, level_seed=2)
+    r = recall_at(s, q, 5, _lib.METHOD_HNSW)
+    s.close()
+    assert r >= 0.95, r
+
+
+@pytest.mark.parametrize("sim", [Similarity.Cosine, Similarity.Dot])
+def test_recall_not_below_oracle_build(orc, sim):
+    """Same data, same search kernel: a graph built on the device must serve recall@10 at least as
+    well (within 1 %) as the oracle's sequential reference-rule build."""
+    rng = np.random.default_rng(42)
+    d, k = 64, 10
+    x = np.vstack([clustered(rng, d, 12, 160), random_vector(rng, d, 2000)])
+    x = x[rng.permutation(len(x))]
+    q = np.vstack([np.array([nearby(rng, x[rng.integers(0, len(x))], 0.05) for _ in range(150)], np.float32),
+                   random_vector(rng, d, 106)])
+    oseg = orc.Segment(x, similarity=sim.value)
+    og, _ = oseg.build_graph(seed=2).serialize_v2(len(x))
+    cfg = VectorConfig(d, sim)
+    s_or = VectorSearcher.open(cfg, [(seg_of(x, bytes(og)), 1)])
+    r_or = recall_at(s_or, q, k, _lib.METHOD_HNSW)
+    s_or.close()
+    s_gpu = VectorSearcher.open(cfg, [(seg_of(x), 1)])
+    s_gpu.build_hnsw(0, level_seed=2)
+    r_gpu = recall_at(s_gpu, q, k, _lib.METHOD_HNSW)
+    graph, _ = s_gpu.serialize_hnsw(0)
+    s_gpu.close()
+    check_invariants(orc, graph, len(x), orc.hnsw_levels(2, len(x)))
+    assert r_gpu >= r_or - 0.01, (r_gpu, r_or)
+    assert r_gpu >= 0.9, r_gpu
+
+
+def test_built_graph_is_searchable_by_the_oracle(orc):
+    """Drop-in both ways: the hnsw.graph image written by the device build must be readable by the
+    reference-format reader (oracle's DiskHnswV2 restatement) and give the same answers there."""
+    rng = np.random.default_rng(8)
+    n, d, k = 2500, 48, 10
+    x = random_vector(rng, d, n)
+    q = random_vector(rng, d, 20)
+    s = VectorSearcher.open(VectorConfig(d, Similarity.Cosine), [(seg_of(x), 1)])
+    s.build_hnsw(0, level_seed=2)
+    graph, edges = s.serialize_hnsw(0)
+    req = VectorSearchRequest(result_per_page=k, min_score=-1.0, with_duplicates=True)
+    _, _, vec, score, count = s.search_batch(req, q, method=_lib.METHOD_HNSW)
+    s.close()
+    og = orc.Hnsw.deserialize_v2(np.frombuffer(graph, np.uint8), edges)
+    oseg = orc.Segment(x, similarity=orc.SIM_COSINE, graph=og)
+    for i in range(len(q)):
+        wv, ws = oseg.hnsw_search(q[i], k)
+        assert np.array_equal(vec[i, : count[i]], wv)
+        assert np.array_equal(score[i, : count[i]].view(np.uint32), ws.view(np.uint32))
