@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py — the nidx vector hot path on MI355X: batched 768-d cosine HNSW k-NN (BASELINE.json configs[1]).
+
+One process per GPU.  Every rank owns one index shard (n_vectors x dim, synthetic, resident in HBM,
+HNSW graph built on the device before the timed region), receives the full query batch, searches
+its shard with the hand-written HIP kernel through the C ABI (device pointers, torch's current
+stream), and — when world_size > 1 — all-gathers the per-shard top-k over RCCL and merges them
+with merge_vector_responses' rule on the device.  A "step" = one batch of `--batch` queries.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement), extended with
+  roofline      dominant kernel (hnsw_search_kernel): algorithmic bytes per launch / HIP-event time vs 8 TB/s
+  cpu_baseline  the CPU oracle (restated reference algorithm) on this box's host cores, bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--n-vectors", type=int, default=1_000_000, help="vectors per shard (per GPU)")
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--workload", choices=["hnsw", "scan"], default="hnsw")
+    p.add_argument("--recall-queries", type=int, default=256)
+    p.add_argument("--cpu-queries", type=int, default=2048, help="bounded sample for the cpu_baseline leg (0 = skip)")
+    p.add_argument("--cpu-threads", type=int, default=0)
+    p.add_argument("--waves-per-query", type=int, default=0, help="tuning: workgroup waves per query (env NIDX_GPU_WAVES_PER_QUERY)")
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        a.gpus = world
+    if a.waves_per_query:
+        os.environ["NIDX_GPU_WAVES_PER_QUERY"] = str(a.waves_per_query)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nucliadb_amd import _lib
+
+    L = _lib.lib()
+    _lib.check(L.nidx_gpu_set_device(local_rank))
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+
+    # ---- synthetic shard: the reference's generator (segment.rs:682-695), uniform(-1,1) then normalised
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234567890 + rank)
+    x = torch.rand((n, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    x /= x.norm(dim=1, keepdim=True)
+    x_host = x.cpu().numpy()
+    del x
+    torch.cuda.empty_cache()
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    cseg = _lib.VectorSegmentC(x_host.ctypes.data, d * 4, n, None, n, None, 0, None, None)
+    h = C.c_void_p()
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
+    open_s = time.time() - t0
+    build_s = 0.0
+    if a.workload == "hnsw":
+        t0 = time.time()
+        _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
+        build_s = time.time() - t0
+
+    # ---- query batches (seed 2, identical on every rank)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2)
+    n_pool = 8
+    qpool = torch.rand((n_pool, B, d), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
+    qpool /= qpool.norm(dim=2, keepdim=True)
+    out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    method = _lib.METHOD_HNSW if a.workload == "hnsw" else _lib.METHOD_BRUTE_FORCE
+    params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def search(qb, with_stats=False, m=None):
+        p = params if m is None else _lib.VectorSearchParamsC(k, -1.0, 1, m)
+        _lib.check(L.nidx_gpu_vector_segment_search_device(
+            h, 0, qb.data_ptr(), B, C.byref(p), None, out_vec.data_ptr(), out_score.data_ptr(), out_count.data_ptr(),
+            stats.data_ptr() if with_stats else None, stream))
+
+    if world > 1:
+        g_score = torch.zeros((world, B, k), dtype=torch.float32, device=dev)
+        g_id = torch.zeros((world, B, k), dtype=torch.int64, device=dev)
+        g_count = torch.zeros((world, B), dtype=torch.int32, device=dev)
+        m_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
+        m_id = torch.zeros((B, k), dtype=torch.int64, device=dev)
+        m_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def exchange():
+        # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
+        ids = (out_vec.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
+        dist.all_gather_into_tensor(g_score, out_score)
+        dist.all_gather_into_tensor(g_id, ids)
+        dist.all_gather_into_tensor(g_count, out_count)
+        _lib.check(L.nidx_gpu_merge_vector_device(g_score.data_ptr(), g_id.data_ptr(), g_count.data_ptr(), world, B, k, k,
+                                                  m_score.data_ptr(), m_id.data_ptr(), m_count.data_ptr(), stream))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        search(qpool[i % n_pool])
+        if world > 1:
+            exchange()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev0[i].record()
+        search(qpool[i % n_pool])
+        ev1[i].record()
+        if world > 1:
+            exchange()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
+
+    # ---- algorithmic bytes per launch: evals*4D + expansions*256 B, counted by the kernel
+    bytes_per_launch, evals_q, exp_q, flags = [], [], [], 0
+    if a.workload == "hnsw":
+        for i in range(min(n_pool, a.steps)):
+            search(qpool[i], with_stats=True)
+            torch.cuda.synchronize()
+            s = stats.cpu().numpy().astype(np.int64)
+            bytes_per_launch.append(float((s[:, 0] * 4 * d + s[:, 1] * 256).sum()))
+            evals_q.append(float(s[:, 0].mean()))
+            exp_q.append(float(s[:, 1].mean()))
+            flags |= int(np.bitwise_or.reduce(s[:, 3]))
+        alg_bytes = float(np.mean(bytes_per_launch))
+    else:
+        tiles = (B + 7) // 8
+        alg_bytes = float(n) * d * 4  # the shard is read once per batch algorithmically
+        evals_q, exp_q = [float(n)], [0.0]
+        del tiles
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # ---- recall@k against the exact scan (oracle-verified kernel) on the same shard
+    recall = None
+    if a.workload == "hnsw" and a.recall_queries > 0:
+        rq = min(a.recall_queries, B)
+        search(qpool[0])
+        torch.cuda.synchronize()
+        got = out_vec[:rq].cpu().numpy()
+        search(qpool[0], m=_lib.METHOD_BRUTE_FORCE)
+        torch.cuda.synchronize()
+        exact = out_vec[:rq].cpu().numpy()
+        recall = float(np.mean([len(set(got[i]) & set(exact[i])) / k for i in range(rq)]))
+
+    # ---- CPU baseline: the oracle (restated reference algorithm, AVX2-shaped sums) on the host cores
+    cpu = None
+    if rank == 0 and a.cpu_queries > 0:
+        cpu = cpu_baseline(a, L, h, x_host, qpool[0].cpu().numpy(), qpool[1].cpu().numpy())
+
+    L.nidx_gpu_vector_close(h)
+    if rank == 0:
+        total_q = world * B * a.steps
+        line = {
+            "metric": "queries/sec (768-dim cosine k-NN, HNSW M=30 ef=30, k=10)" if a.workload == "hnsw" else "queries/sec (exact cosine scan)",
+            "value": total_q / elapsed,
+            "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d x %d-dim cosine, k=%d, batch=%d queries, 1 shard per GPU" % (a.workload, n, d, k, B),
+                "vectors_per_shard": n, "dim": d, "batch": B, "k": k, "shards": world,
+                "corpus_vectors": n * world, "merged_queries_per_s": B * a.steps / elapsed,
+                "recall_at_%d" % k: recall, "hnsw_build_s": build_s, "open_s": open_s,
+                "distance_evals_per_query": float(np.mean(evals_q)), "expansions_per_query": float(np.mean(exp_q)),
+                "kernel_flags": flags, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world,
+            },
+            "roofline": {
+                "kernel": "hnsw_search_kernel<3>" if a.workload == "hnsw" else "scan_topk_kernel",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, L, h, x_host, q0, q1):
+    """The oracle's HNSW search (oracle/nidx_oracle.c, reference constants) over the SAME graph the
+    device built, one query per thread (the reference serves one request per blocking thread,
+    shard_search.rs:139-153), on a bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as orc
+
+    orc.build()
+    n, d, k = a.n_vectors, a.dim, a.k
+    threads = a.cpu_threads or min(64, os.cpu_count() or 1)
+    if a.workload == "hnsw":
+        glen, nedges = C.c_uint64(0), C.c_uint64(0)
+        L.nidx_gpu_vector_serialize_hnsw(h, 0, None, 0, C.byref(glen), None, 0, C.byref(nedges))
+        graph = np.zeros(glen.value, np.uint8)
+        edges = np.zeros(max(1, nedges.value), np.float32)
+        L.nidx_gpu_vector_serialize_hnsw(h, 0, graph.ctypes.data, glen.value, C.byref(glen), edges.ctypes.data, nedges.value, C.byref(nedges))
+        og = orc.Hnsw.deserialize_v2(graph, edges[: nedges.value])
+    else:
+        og = None
+    oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL, graph=og)
+    qs = np.vstack([q0, q1])
+    nq = min(a.cpu_queries if a.workload == "hnsw" else max(threads, 64), qs.shape[0])
+
+    def one(i):
+        if a.workload == "hnsw":
+            return oseg.hnsw_search(qs[i], k)
+        return oseg.brute_force(qs[i], k)
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(min(threads, nq))))  # warm the page cache / thread pool
+        t0 = time.perf_counter()
+        list(ex.map(one, range(nq)))
+        dt = time.perf_counter() - t0
+    return {"value": nq / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": "%d queries of the same batch over the same %d x %d shard%s, oracle (C restatement of the reference "
+                      "algorithm, AVX2-shaped f32 sums), one query per thread" % (nq, n, d, " and device-built graph" if og else "")}
+
+
+if __name__ == "__main__":
+    main()

@@ -247,6 +247,12 @@ uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm);
 int32_t nidx_gpu_merge_vector(const float *const *scores, const uint64_t *const *ids, const uint32_t *lens,
                               uint32_t n_lists, uint32_t limit, float *out_score, uint64_t *out_id,
                               uint32_t *out_list, uint32_t *n_out);
+/* The same merge for a whole batch with everything in HBM (what each GPU runs after the RCCL
+ * all-gather of the per-shard top-k): d_scores/d_ids [n_lists][n_queries][k], d_counts
+ * [n_lists][n_queries]; outputs [n_queries][limit] / [n_queries].  Asynchronous on `stream`. */
+int32_t nidx_gpu_merge_vector_device(const float *d_scores, const uint64_t *d_ids, const uint32_t *d_counts,
+                                     uint32_t n_lists, uint32_t n_queries, uint32_t k, uint32_t limit,
+                                     float *d_out_score, uint64_t *d_out_id, uint32_t *d_out_count, void *stream);
 /* sort_documents_fn / sort_paragraphs_fn (shard_merge.rs:211-234,289-312): a before b iff
  * bm25 greater (total_cmp), else shard_id greater (bytes), else docaddr smaller. */
 int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *docaddrs, const uint32_t *lens,

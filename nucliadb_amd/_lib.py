@@ -126,6 +126,8 @@ SIGNATURES = {
     "nidx_gpu_fieldnorm_to_id": (C.c_uint8, [C.c_uint32]),
     "nidx_gpu_merge_vector": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_merge_vector_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
 }

@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
         if (ki == ~0ull || (ki >> 30) != (k0 >> 30)) break;
         uint32_t x = (uint32_t)(ki & 0x3fffffffu);
         uint64_t nk = rank_key(vals[i], x);
+        // The reference would push a second copy when y already links to x (possible only for the entry
+        // point, which collects reverse links before its own insertion): a duplicate edge is dead weight.
+        if (__ballot(lane < deg && rank_key_addr(e) == x)) continue;
         if (lane == deg) e = nk;  // other_edges.push((x, dist))
         deg++;
         if (deg > mmax) {

@@ -6,6 +6,7 @@
 //             OpenSegment::_search: filter ∩ alive, use_hnsw routing      (segment.rs:496-567,626-660)
 // All arithmetic on vectors happens in the kernels; this file only moves data, routes and merges.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -470,6 +471,10 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     if (config->dimension > 3072) return fail(NIDX_ERR_UNSUPPORTED, "dimension > 3072 is not supported yet");
     std::unique_ptr<VectorIndex> idx(new VectorIndex());
     idx->cfg = *config;
+    // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels
+    if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
+    if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     NIDX_HIP(hipGetDevice(&idx->device));
     NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
     idx->segs.resize(n_segments);
