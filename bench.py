@@ -98,7 +98,7 @@ def main():
     out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
     out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
-    stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    stats = torch.zeros((B, 8), dtype=torch.int32, device=dev)
     method = _lib.METHOD_HNSW if a.workload == "hnsw" else _lib.METHOD_BRUTE_FORCE
     params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
     stream = torch.cuda.current_stream().cuda_stream

@@ -106,6 +106,11 @@ int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64
 int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint32_t *n_out);
 int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out);
 
+/* Launch-shape knobs of the HNSW kernels (no effect on results): "waves_per_query" 1..4,
+ * "eval_rows" 2|4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15.  Also read at
+ * open from the environment as NIDX_GPU_<NAME>. */
+int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value);
+
 enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2 };
 
 /* The request fields the hot path reads (nidx_vector/src/request_types.rs:19-35). */
@@ -143,7 +148,8 @@ int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *
  *   d_queries [n_queries][dimension] f32 (already normalised if the index wants that)
  *   d_filter  NULL or device bitset over paragraph addrs (ANDed with alive on device)
  *   d_out_vector/d_out_score [n_queries][k], d_out_count [n_queries]
- *   d_stats   NULL or [n_queries][4] u32: distance evals, expansions, visited-set peak, flags */
+ *   d_stats   NULL or [n_queries][8] u32: distance evals, expansions, visited-set peak, flags,
+ *             then wave-0 cycle counts: control / distance / admission / total */
 int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment,
                                               const float *d_queries, uint32_t n_queries,
                                               const nidx_gpu_vector_search_params_t *params,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "nidx_gpu_set_device": (C.c_int32, [C.c_int32]),
     "nidx_gpu_vector_open": (C.c_int32, [C.POINTER(VectorConfigC), C.POINTER(VectorSegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),
     "nidx_gpu_vector_close": (None, [C.c_void_p]),
+    "nidx_gpu_vector_set_tunable": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32]),
     "nidx_gpu_vector_space_usage": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nidx_gpu_vector_num_segments": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_vector_segment_records": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
 
     QueryRegs<NJ> q;  // SearchVector::Stored(x)
     load_query<NJ>(q, a.seg.vectors + (size_t)x * a.seg.dp, a.seg.dp, lane, cosine);
-    SearchCounters st = {0, 0, 0, 0};
+    SearchCounters st = {0, 0, 0, 0, 0, 0, 0};
     WaveTopK<2> res;
     res.init();
     if (threadIdx.x == 0) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const bool in_layer = layer <= level;
         const int k = in_layer ? NIDX_EF_CONSTRUCTION : 1;
-        layer_search_block<NJ, 2>(a.seg, a.g, layer, k, q, sh, vis, a.vis_log2, res, st);
+        layer_search_block<NJ, 2, 4>(a.seg, a.g, layer, k, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             // next layer's entry points = every result (build.rs:146)
             uint64_t k0 = res.l[0].key, k1 = res.l[1].key;

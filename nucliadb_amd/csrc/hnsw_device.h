@@ -172,18 +172,21 @@ __device__ inline void pool_prune(uint64_t *pool, int &pool_len, float ws, int l
 
 struct SearchCounters {
     uint32_t evals, expansions, visited, flags;
+    // wave-0 cycle accounting (s_memtime): controller pop/edge/visited, distance phase, admission
+    uint64_t cyc_ctl, cyc_eval, cyc_ins;
 };
 
 // ---- distances of sh.nb_addr[0..n) -> sh.nb_ab / sh.nb_xx (all waves) ------------------------
-template <int NJ>
+// EVR rows are in flight per wave at a time (EVR * NJ 16-byte loads per lane).
+template <int NJ, int EVR>
 __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q, SearchShared &sh, int n, bool cosine) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
-    for (int base = wave * 4; base < n; base += nwaves * 4) {
-        float4 row[4][NJ];
+    for (int base = wave * EVR; base < n; base += nwaves * EVR) {
+        float4 row[EVR][NJ];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < EVR; i++) {
             if (base + i < n) {
                 const float *r = seg.vectors + (size_t)sh.nb_addr[base + i] * seg.dp;
 #pragma unroll
@@ -194,9 +197,9 @@ __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q
             }
         }
         if (cosine) {
-            float v[8];
+            float v[2 * EVR];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < EVR; i++) {
                 float ab = 0.f, xx = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
@@ -204,29 +207,29 @@ __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q
                     xx = fma4(row[i][j], row[i][j], xx);
                 }
                 v[i] = ab;
-                v[4 + i] = xx;
+                v[EVR + i] = xx;
             }
-            float r = QReduce<8>::run(v, lane);
-            int which = QReduce<8>::query_of_lane(lane);
-            if ((lane & QReduce<8>::group_mask()) == 0) {
-                int i = which & 3;
+            float r = QReduce<2 * EVR>::run(v, lane);
+            int which = QReduce<2 * EVR>::query_of_lane(lane);
+            if ((lane & QReduce<2 * EVR>::group_mask()) == 0) {
+                int i = which % EVR;
                 if (base + i < n) {
-                    if (which < 4) sh.nb_ab[base + i] = r;
+                    if (which < EVR) sh.nb_ab[base + i] = r;
                     else sh.nb_xx[base + i] = r;
                 }
             }
         } else {
-            float v[4];
+            float v[EVR];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < EVR; i++) {
                 float ab = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; j++) ab = fma4(row[i][j], q.qv[j], ab);
                 v[i] = ab;
             }
-            float r = QReduce<4>::run(v, lane);
-            int which = QReduce<4>::query_of_lane(lane);
-            if ((lane & QReduce<4>::group_mask()) == 0 && base + which < n) sh.nb_ab[base + which] = r;
+            float r = QReduce<EVR>::run(v, lane);
+            int which = QReduce<EVR>::query_of_lane(lane);
+            if ((lane & QReduce<EVR>::group_mask()) == 0 && base + which < n) sh.nb_ab[base + which] = r;
         }
     }
 }
@@ -246,7 +249,7 @@ __device__ inline uint32_t load_edge_word(const GraphDev &g, uint32_t node, int 
 
 // ---- HnswSearcher::layer_search (search.rs:242-304) ------------------------------------------
 // Entry points: sh.eps[0..sh.ctrl[2]).  Result: `res` (wave 0), best first.  All threads call.
-template <int NJ, int EFL>
+template <int NJ, int EFL, int EVR>
 __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, int layer, int k,
                                           const QueryRegs<NJ> &q, SearchShared &sh, uint32_t *vis, uint32_t vis_log2,
                                           WaveTopK<EFL> &res, SearchCounters &st) {
@@ -280,7 +283,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
             sh.nb_addr[lane] = ep;
         }
         __syncthreads();
-        eval_neighbours<NJ>(seg, q, sh, chunk, cosine);
+        eval_neighbours<NJ, EVR>(seg, q, sh, chunk, cosine);
         __syncthreads();
         if (ctl) {
             float s = lane < chunk ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
@@ -298,6 +301,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
     }
 
     for (;;) {
+        uint64_t t_a = clock64();
         if (ctl) {
             int cont = 0;
             n_new = 0;
@@ -329,10 +333,14 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
             }
         }
         __syncthreads();
+        uint64_t t_b = clock64();
+        st.cyc_ctl += t_b - t_a;
         if (!sh.ctrl[0]) break;
         n_new = sh.ctrl[1];
-        eval_neighbours<NJ>(seg, q, sh, n_new, cosine);
+        eval_neighbours<NJ, EVR>(seg, q, sh, n_new, cosine);
         __syncthreads();
+        uint64_t t_c = clock64();
+        st.cyc_eval += t_c - t_b;
         if (ctl && n_new > 0) {
             float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
             uint32_t addr = sh.nb_addr[lane];
@@ -365,6 +373,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
             }
         }
         // the controller's LDS reads of nb_* above complete before it rewrites them: same wave
+        st.cyc_ins += clock64() - t_c;
     }
     st.visited = st.visited > vis_count ? st.visited : vis_count;
 }

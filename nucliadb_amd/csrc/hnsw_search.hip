@@ -26,8 +26,8 @@ __device__ inline bool rows_equal(const SegDev &seg, uint32_t a, uint32_t b, int
     return __all(eq);
 }
 
-template <int NJ>
-__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+template <int NJ, int EVR, int MINW>
+__global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     QueryRegs<NJ> q;
     load_query<NJ>(q, a.queries + (size_t)qi * a.seg.dp, a.seg.dp, lane, cosine);
 
-    SearchCounters st = {0, 0, 0, 0};
+    SearchCounters st = {0, 0, 0, 0, 0, 0, 0};
+    const uint64_t t_start = clock64();
     WaveTopK<1> res;
     res.init();
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     }
     __syncthreads();
     for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
-        layer_search_block<NJ, 1>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
+        layer_search_block<NJ, 1, EVR>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             uint64_t key = res.l[0].key;
             if (lane < res.len) sh.eps[lane] = rank_key_addr(key);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     }
     // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
     const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
-    layer_search_block<NJ, 1>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
+    layer_search_block<NJ, 1, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
 
     // ---- closest_up_nodes (search.rs:188-240) ----
     // candidates = the ef neighbours; visited = exactly those; pop best, accept if it passes the
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
         __syncthreads();
         if (!sh.ctrl[0]) break;
         int n_new = sh.ctrl[1];
-        eval_neighbours<NJ>(a.seg, q, sh, n_new, cosine);
+        eval_neighbours<NJ, EVR>(a.seg, q, sh, n_new, cosine);
         __syncthreads();
         if (ctl && n_new > 0) {
             float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
@@ -203,23 +204,40 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
         if (lane == 0) {
             a.out_count[qi] = (uint32_t)n_res;
             if (a.stats) {
-                a.stats[(size_t)qi * 4 + NIDX_STAT_EVALS] = st.evals;
-                a.stats[(size_t)qi * 4 + NIDX_STAT_EXPANSIONS] = st.expansions;
-                a.stats[(size_t)qi * 4 + NIDX_STAT_VISITED] = st.visited;
-                a.stats[(size_t)qi * 4 + NIDX_STAT_FLAGS] = st.flags;
+                uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
+                o[NIDX_STAT_EVALS] = st.evals;
+                o[NIDX_STAT_EXPANSIONS] = st.expansions;
+                o[NIDX_STAT_VISITED] = st.visited;
+                o[NIDX_STAT_FLAGS] = st.flags;
+                o[NIDX_STAT_CYC_CTL] = (uint32_t)st.cyc_ctl;
+                o[NIDX_STAT_CYC_EVAL] = (uint32_t)st.cyc_eval;
+                o[NIDX_STAT_CYC_INS] = (uint32_t)st.cyc_ins;
+                o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
             }
         }
     }
 }
 
-template <int NJ>
-static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
+template <int NJ, int EVR, int MINW>
+static hipError_t launch_v(const HnswSearchArgs &a, int waves, hipStream_t s) {
     size_t smem = sizeof(SearchShared) + ((size_t)4 << a.vis_log2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ, EVR, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hnsw_search_kernel<NJ>), dim3(a.n_queries), dim3(64 * waves), smem, s, a);
+    hipLaunchKernelGGL((hnsw_search_kernel<NJ, EVR, MINW>), dim3(a.n_queries), dim3(64 * waves), smem, s, a);
     return hipGetLastError();
+}
+
+template <int NJ>
+static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
+    // rows in flight per wave / register budget: tuned per dimension class (DESIGN.md "HNSW kernel")
+    if (a.eval_rows == 2) return a.min_waves >= 4 ? launch_v<NJ, 2, 4>(a, waves, s) : launch_v<NJ, 2, 2>(a, waves, s);
+    return a.min_waves >= 4 ? launch_v<NJ, 4, 4>(a, waves, s) : launch_v<NJ, 4, 2>(a, waves, s);
+}
+
+template <int NJ>
+static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s) {
+    return launch_v<NJ, 2, 1>(a, waves, s);
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
@@ -231,9 +249,9 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipS
     if (nj <= 2) return launch_nj<2>(a, waves_per_query, s);
     if (nj <= 3) return launch_nj<3>(a, waves_per_query, s);
     if (nj <= 4) return launch_nj<4>(a, waves_per_query, s);
-    if (nj <= 6) return launch_nj<6>(a, waves_per_query, s);
-    if (nj <= 8) return launch_nj<8>(a, waves_per_query, s);
-    if (nj <= 12) return launch_nj<12>(a, waves_per_query, s);
+    if (nj <= 6) return launch_wide<6>(a, waves_per_query, s);
+    if (nj <= 8) return launch_wide<8>(a, waves_per_query, s);
+    if (nj <= 12) return launch_wide<12>(a, waves_per_query, s);
     return hipErrorInvalidValue;
 }
 

@@ -64,6 +64,11 @@ struct SegDev {
 #define NIDX_STAT_EXPANSIONS 1
 #define NIDX_STAT_VISITED 2
 #define NIDX_STAT_FLAGS 3
+#define NIDX_STAT_CYC_CTL 4    /* wave-0 cycles: pop + edge record + visited test */
+#define NIDX_STAT_CYC_EVAL 5   /* cycles in the distance phase (all waves, incl. barriers) */
+#define NIDX_STAT_CYC_INS 6    /* cycles replaying the admission rule */
+#define NIDX_STAT_CYC_TOTAL 7
+#define NIDX_STAT_STRIDE 8
 #define NIDX_FLAG_VISITED_OVERFLOW 1u
 #define NIDX_FLAG_POOL_INEXACT 2u
 
@@ -80,7 +85,9 @@ struct HnswSearchArgs {
     uint32_t *out_vec;      // [n_queries][k]
     float *out_score;       // [n_queries][k]
     uint32_t *out_count;    // [n_queries]
-    uint32_t *stats;        // nullptr or [n_queries][4]
+    uint32_t *stats;        // nullptr or [n_queries][NIDX_STAT_STRIDE]
+    int eval_rows;          // rows in flight per wave in the distance phase: 2 or 4
+    int min_waves;          // register budget: 2 (<=256 VGPR) or 4 (<=128 VGPR) waves per SIMD
 };
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
 

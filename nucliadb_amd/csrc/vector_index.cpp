@@ -238,6 +238,8 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.out_score = d_out_score;
         a.out_count = d_out_count;
         a.stats = d_stats;
+        a.eval_rows = eval_rows;
+        a.min_waves = min_waves;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -310,7 +312,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     NIDX_HIP(scratch_out_vec.reserve((size_t)nq * k * 4));
     NIDX_HIP(scratch_out_score.reserve((size_t)nq * k * 4));
     NIDX_HIP(scratch_out_count.reserve((size_t)nq * 4));
-    NIDX_HIP(scratch_stats.reserve((size_t)nq * 16));
+    NIDX_HIP(scratch_stats.reserve((size_t)nq * NIDX_STAT_STRIDE * 4));
 
     const size_t S = segs.size();
     std::vector<std::vector<uint32_t>> hv(S), hc(S);
@@ -344,11 +346,11 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
                                                scratch_stats.as<uint32_t>(), vis_log2, stream);
             if (rc != NIDX_OK) return rc;
             if (method != NIDX_METHOD_HNSW) break;
-            std::vector<uint32_t> stats((size_t)nq * 4);
+            std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
             NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, stream));
             NIDX_HIP(hipStreamSynchronize(stream));
             uint32_t flags = 0;
-            for (uint32_t q = 0; q < nq; q++) flags |= stats[(size_t)q * 4 + NIDX_STAT_FLAGS];
+            for (uint32_t q = 0; q < nq; q++) flags |= stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS];
             if (flags == 0) break;
             if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15)
                 return fail(NIDX_ERR_INEXACT, "HNSW search overflowed an on-chip structure (flags=%u, visited table 2^%u)",
@@ -473,6 +475,8 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     idx->cfg = *config;
     // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels
     if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) idx->eval_rows = atoi(e) == 2 ? 2 : 4;
+    if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) idx->min_waves = atoi(e) >= 4 ? 4 : 2;
     if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     NIDX_HIP(hipGetDevice(&idx->device));
@@ -495,6 +499,20 @@ void nidx_gpu_vector_close(nidx_gpu_vector_index_t *index) {
         (void)hipStreamDestroy(idx->stream);
     }
     delete idx;
+}
+
+int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !name) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    std::string n(name);
+    if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
+    else if (n == "eval_rows") idx->eval_rows = value == 2 ? 2 : 4;
+    else if (n == "min_waves") idx->min_waves = value >= 4 ? 4 : 2;
+    else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown tunable %s", name);
+    return NIDX_OK;
 }
 
 int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64_t *bytes_out) {

@@ -45,6 +45,8 @@ struct VectorIndex {
     std::vector<VectorSegment> segs;
     // tunables
     int waves_per_query = 4;
+    int eval_rows = 2;   // rows in flight per wave (HNSW distance phase); tuned on MI355X, profiles/r01_tune_hnsw.txt
+    int min_waves = 4;   // register budget class of the HNSW kernel (4 => <=128 VGPR, 16 waves per CU)
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
