@@ -1,0 +1,208 @@
+// bm25.hip — term-at-a-time BM25 scoring + TopDocs for a batch of boolean term queries (gfx950).
+//
+// Replaces what tantivy does under TextReaderService::do_search (nidx_text/src/reader.rs:433-435)
+// and ParagraphReaderService's Searcher::do_search (nidx_paragraph/src/reader.rs:244-348):
+//   Bm25Weight::score(fieldnorm_id, tf) = weight * tf / (tf + K1*(1 - B + B*fieldnorm/avg)),
+//   BooleanQuery of Should / Must / MustNot term clauses (clause scores summed in clause order),
+//   TopDocs::with_limit(k) ordered (score desc, DocAddress asc), Count, the search-after score tweak
+//   (reader.rs:350-390), deletions as an alive bitset (nidx_tantivy/src/index_reader.rs:39-74).
+//
+// One workgroup per (query, segment).  The postings of a query's clauses are consumed in lockstep
+// doc-id windows [lo, hi): hi is chosen so that every clause contributes at most PER postings, all
+// of a window's (doc -> partial score) pairs live in an LDS hash table, clauses are applied one
+// after the other with a barrier in between — so each doc's f32 sum is built in clause order,
+// exactly like the oracle's term-at-a-time loop — and the finished window is folded into per-wave
+// top-k lists.  Postings are read once, coalesced (doc ids and tfs are separate arrays).
+// Bound: HBM; algorithmic bytes per posting scored = 9 (u32 doc + u32 tf + u8 fieldnorm id).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+#define BM25_TABLE 4096
+#define BM25_MAX_DISTINCT 2048
+#define BM25_EMPTY 0xffffffffu
+
+struct Bm25Shared {
+    uint32_t key[BM25_TABLE];
+    float acc[BM25_TABLE];
+    uint16_t flags[BM25_TABLE];  // bit0 should-hit, bit1 excluded, bits 8.. must count
+    float tf_cache[256];
+    unsigned long long cursor[BM25_MAX_CLAUSES];
+    unsigned long long end[BM25_MAX_CLAUSES];
+    uint32_t hi;
+    uint32_t taken;
+    unsigned long long total;
+    unsigned long long postings;
+    uint64_t merge[3][64];
+};
+
+__global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
+    __shared__ Bm25Shared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint64_t c0 = a.clause_offsets[q], c1 = a.clause_offsets[q + 1];
+    const int C = (int)(c1 - c0);
+    const Bm25ClauseDev *cl = a.clauses + c0;
+    const int k = (int)a.k;
+
+    for (int i = tid; i < BM25_TABLE; i += 256) {
+        sh.key[i] = BM25_EMPTY;
+        sh.acc[i] = 0.f;
+        sh.flags[i] = 0;
+    }
+    if (tid < 256) sh.tf_cache[tid] = a.tf_cache[tid];
+    int n_must = 0;
+    for (int c = 0; c < C; c++) n_must += cl[c].occur == 1 ? 1 : 0;
+    if (tid < C) {
+        sh.cursor[tid] = a.term_offsets[cl[tid].term];
+        sh.end[tid] = a.term_offsets[cl[tid].term + 1];
+    }
+    if (tid == 0) {
+        sh.total = 0;
+        sh.postings = 0;
+    }
+    __syncthreads();
+    const uint32_t per = C > 0 ? (uint32_t)(BM25_MAX_DISTINCT / C) : 1u;
+
+    WaveSortedList top;
+    top.init();
+    uint64_t kth = NIDX_EMPTY_KEY;
+    // search-after cursor (reader.rs:379-390)
+    const bool has_after = a.after != nullptr && a.after[q].has_after != 0;
+    const int32_t after_key = has_after ? total_key(a.after[q].score) : 0;
+    const int after_tie = has_after ? a.after[q].tie_break : 0;
+    const uint64_t after_addr = has_after ? a.after[q].docaddr : 0;
+
+    for (;;) {
+        // ---- window end: smallest doc id that some clause could not fit ----
+        if (tid == 0) sh.hi = 0xffffffffu;
+        __syncthreads();
+        bool any_left = false;
+        for (int c = 0; c < C; c++) any_left = any_left || sh.cursor[c] < sh.end[c];
+        if (!any_left) break;
+        if (tid < C) {
+            unsigned long long cur = sh.cursor[tid], e = sh.end[tid];
+            if (cur + per < e) atomicMin(&sh.hi, a.doc_ids[cur + per]);
+        }
+        __syncthreads();
+        const uint32_t hi = sh.hi;
+        // ---- clauses in order ----
+        for (int c = 0; c < C; c++) {
+            if (tid == 0) sh.taken = 0;
+            __syncthreads();
+            const unsigned long long cur = sh.cursor[c], e = sh.end[c];
+            const int occur = cl[c].occur, mode = cl[c].mode;
+            const float weight = cl[c].weight;
+            uint32_t mine = 0;
+            for (unsigned long long i = cur + tid; i < e && i < cur + per; i += 256) {
+                uint32_t d = a.doc_ids[i];
+                if (d >= hi) break;  // hi == 0xffffffff: every clause's remainder fits
+                mine++;
+                // slot of doc d
+                uint32_t h = (d * 2654435761u) >> 20;
+                for (;;) {
+                    uint32_t old = atomicCAS(&sh.key[h], BM25_EMPTY, d);
+                    if (old == BM25_EMPTY || old == d) break;
+                    h = (h + 1) & (BM25_TABLE - 1);
+                }
+                if (occur == 2) {
+                    sh.flags[h] |= 2;  // MustNot
+                } else {
+                    float s;
+                    if (mode == 2) s = weight;  // ConstScorer(boost)
+                    else {
+                        float tf = mode == 1 ? 1.0f : (float)a.tfs[i];
+                        float norm = sh.tf_cache[a.fieldnorm_ids[d]];
+                        s = weight * (tf / (tf + norm));
+                    }
+                    sh.acc[h] = sh.acc[h] + s;
+                    if (occur == 1) sh.flags[h] += 0x100;
+                    else sh.flags[h] |= 1;
+                }
+            }
+            if (mine) atomicAdd(&sh.taken, mine);
+            __syncthreads();
+            if (tid == 0) {
+                sh.cursor[c] = cur + sh.taken;
+                sh.postings += sh.taken;
+            }
+            __syncthreads();
+        }
+        // ---- fold the window into the top-k, count matches, clear the table ----
+        uint32_t matched_here = 0;
+        for (int base = wib * 64; base < BM25_TABLE; base += 256) {
+            int i = base + lane;
+            uint32_t d = sh.key[i];
+            bool ok = false;
+            uint64_t ck = NIDX_EMPTY_KEY;
+            if (d != BM25_EMPTY) {
+                uint16_t f = sh.flags[i];
+                ok = !(f & 2) && (int)(f >> 8) == n_must && (n_must > 0 || (f & 1));
+                if (ok && a.alive) ok = bit_test(a.alive, d);
+                if (ok) {
+                    float s = sh.acc[i];
+                    if (has_after) {
+                        // tweak_score: -inf for docs not after the cursor
+                        uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
+                        int32_t sk = total_key(s);
+                        bool after = sk < after_key || (sk == after_key && (after_tie == 0 || (after_tie == 1 && addr > after_addr)));
+                        if (!after) s = -INFINITY;
+                    }
+                    ck = rank_key(s, d);
+                }
+                sh.key[i] = BM25_EMPTY;
+                sh.acc[i] = 0.f;
+                sh.flags[i] = 0;
+            }
+            unsigned long long okm = __ballot(ok);
+            matched_here += (uint32_t)__popcll(okm);
+            unsigned long long m = __ballot(ok && ck > kth);
+            while (m) {
+                int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                uint64_t nk = shfl_u64(ck, src);
+                if (nk > kth) {
+                    top.insert(nk, lane);
+                    kth = top.at(k - 1);
+                }
+            }
+        }
+        if (lane == 0 && matched_here) atomicAdd(&sh.total, (unsigned long long)matched_here);
+        __syncthreads();
+    }
+
+    // ---- merge the four waves' lists ----
+    if (wib > 0) sh.merge[wib - 1][lane] = top.key;
+    __syncthreads();
+    if (wib == 0) {
+        for (int w = 0; w < 3; w++)
+            for (int i = 0; i < k; i++) {
+                uint64_t nk = sh.merge[w][i];
+                if (nk == NIDX_EMPTY_KEY) break;
+                if (nk > kth) {
+                    top.insert(nk, lane);
+                    kth = top.at(k - 1);
+                } else break;
+            }
+        bool valid = top.key != NIDX_EMPTY_KEY && lane < k;
+        unsigned long long vm = __ballot(valid);
+        if (lane < k) {
+            a.out_doc[(size_t)q * k + lane] = valid ? rank_key_addr(top.key) : 0xffffffffu;
+            a.out_score[(size_t)q * k + lane] = valid ? rank_key_score(top.key) : 0.f;
+        }
+        if (lane == 0) {
+            a.out_count[q] = (uint32_t)__popcll(vm);
+            a.out_total[q] = sh.total;
+            a.out_postings[q] = sh.postings;
+        }
+    }
+}
+
+hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_queries, hipStream_t s) {
+    if (n_queries == 0) return hipSuccess;
+    hipLaunchKernelGGL(bm25_search_kernel, dim3(n_queries), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace nidx

@@ -1,0 +1,252 @@
+// bm25_index.cpp — C ABI implementation of the BM25 index (include/nidx_gpu.h "BM25 index").
+//
+// Host side of tantivy's Bm25Weight [third party, restated; tantivy 0.26.1 query/bm25.rs,
+// fieldnorm/code.rs]: K1 = 1.2, B = 0.75; idf = ln(1 + (N - n + 0.5)/(n + 0.5));
+// weight = idf * (1 + K1) * boost; tf-norm cache[id] = K1 * (1 - B + B * fieldnorm(id) / avg);
+// statistics are searcher-wide: N = sum of segment max_doc, n = sum of segment doc_freq,
+// avg = sum of tokens / N — and are not reduced by deletions.  Scoring itself is bm25.hip.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <mutex>
+
+#include "device_common.h"
+#include "host_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+static const float kK1 = 1.2f, kB = 0.75f;
+
+static uint32_t fieldnorm_from_id(uint8_t id) {
+    // FIELD_NORMS_TABLE: 0..=40 exact, then eight values per octave with the step doubling
+    if (id <= 40) return id;
+    uint32_t v = 40;
+    for (uint32_t i = 41; i <= id; i++) v += 2u << ((i - 41) / 8);
+    return v;
+}
+
+static uint8_t fieldnorm_to_id(uint32_t fieldnorm) {
+    // the largest id whose value is <= fieldnorm
+    int lo = 0, hi = 255;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (fieldnorm_from_id((uint8_t)mid) <= fieldnorm) lo = mid;
+        else hi = mid - 1;
+    }
+    return (uint8_t)lo;
+}
+
+static float bm25_idf(uint64_t doc_freq, uint64_t doc_count) {
+    float x = ((float)(doc_count - doc_freq) + 0.5f) / ((float)doc_freq + 0.5f);
+    return logf(1.0f + x);
+}
+
+struct Bm25Segment {
+    uint32_t n_docs = 0, n_terms = 0;
+    std::vector<uint64_t> term_offsets_host;
+    DevBuf term_offsets, doc_ids, tfs, fieldnorm_ids, alive;
+    bool all_alive = true;
+    uint64_t bytes() const { return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes; }
+};
+
+struct Bm25Index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<Bm25Segment> segs;
+    uint64_t total_docs = 0, total_tokens = 0;
+    uint32_t n_terms = 0;
+    DevBuf tf_cache;
+    DevBuf s_clauses, s_offsets, s_after, s_doc, s_score, s_count, s_total, s_postings;
+};
+
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" {
+
+float nidx_gpu_bm25_idf(uint64_t doc_freq, uint64_t doc_count) { return bm25_idf(doc_freq, doc_count); }
+uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id) { return fieldnorm_from_id(id); }
+uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm) { return fieldnorm_to_id(fieldnorm); }
+
+int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments, nidx_gpu_bm25_index_t **index_out) {
+    if (!index_out || (n_segments && !segments)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *index_out = nullptr;
+    std::unique_ptr<Bm25Index> idx(new Bm25Index());
+    NIDX_HIP(hipGetDevice(&idx->device));
+    NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    idx->segs.resize(n_segments);
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const nidx_gpu_bm25_segment_t &in = segments[s];
+        Bm25Segment &seg = idx->segs[s];
+        if (!in.term_offsets || (in.n_docs && !in.fieldnorm_ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL arrays", s);
+        if (s > 0 && in.n_terms != idx->n_terms)
+            return fail(NIDX_ERR_INVALID_ARGUMENT, "every segment must use the same term-id space (n_terms differs)");
+        idx->n_terms = in.n_terms;
+        seg.n_docs = in.n_docs;
+        seg.n_terms = in.n_terms;
+        seg.term_offsets_host.assign(in.term_offsets, in.term_offsets + in.n_terms + 1);
+        const uint64_t n_post = seg.term_offsets_host[in.n_terms];
+        if (n_post && (!in.doc_ids || !in.tfs)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL postings", s);
+        NIDX_HIP(seg.term_offsets.alloc((size_t)(in.n_terms + 1) * 8));
+        NIDX_HIP(hipMemcpy(seg.term_offsets.p, in.term_offsets, (size_t)(in.n_terms + 1) * 8, hipMemcpyHostToDevice));
+        NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4));
+        NIDX_HIP(seg.tfs.alloc(std::max<size_t>(n_post, 1) * 4));
+        if (n_post) {
+            NIDX_HIP(hipMemcpy(seg.doc_ids.p, in.doc_ids, n_post * 4, hipMemcpyHostToDevice));
+            NIDX_HIP(hipMemcpy(seg.tfs.p, in.tfs, n_post * 4, hipMemcpyHostToDevice));
+        }
+        NIDX_HIP(seg.fieldnorm_ids.alloc(std::max<size_t>(in.n_docs, 1)));
+        if (in.n_docs) NIDX_HIP(hipMemcpy(seg.fieldnorm_ids.p, in.fieldnorm_ids, in.n_docs, hipMemcpyHostToDevice));
+        seg.all_alive = in.alive_bitset == nullptr;
+        if (in.alive_bitset) {
+            size_t words = ((size_t)in.n_docs + 63) / 64;
+            NIDX_HIP(seg.alive.alloc(std::max<size_t>(words, 1) * 8));
+            if (words) NIDX_HIP(hipMemcpy(seg.alive.p, in.alive_bitset, words * 8, hipMemcpyHostToDevice));
+        }
+        idx->total_docs += in.n_docs;
+        idx->total_tokens += in.total_num_tokens;
+    }
+    float avg = idx->total_docs ? (float)idx->total_tokens / (float)idx->total_docs : 0.0f;
+    float cache[256];
+    for (int id = 0; id < 256; id++) {
+        float fieldnorm = (float)fieldnorm_from_id((uint8_t)id);
+        cache[id] = kK1 * (1.0f - kB + kB * fieldnorm / avg);
+    }
+    NIDX_HIP(idx->tf_cache.alloc(sizeof(cache)));
+    NIDX_HIP(hipMemcpy(idx->tf_cache.p, cache, sizeof(cache), hipMemcpyHostToDevice));
+    *index_out = reinterpret_cast<nidx_gpu_bm25_index_t *>(idx.release());
+    return NIDX_OK;
+}
+
+void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) {
+        (void)hipStreamSynchronize(idx->stream);
+        (void)hipStreamDestroy(idx->stream);
+    }
+    delete idx;
+}
+
+int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *bytes_out) {
+    const Bm25Index *idx = reinterpret_cast<const Bm25Index *>(index);
+    if (!idx || !bytes_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    uint64_t b = idx->tf_cache.bytes;
+    for (const Bm25Segment &s : idx->segs) b += s.bytes();
+    *bytes_out = b;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses,
+                             const uint64_t *clause_offsets, uint32_t nq, uint32_t k,
+                             const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr, float *out_score,
+                             uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !clause_offsets || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    for (uint32_t q = 0; q < nq; q++) {
+        out_count[q] = 0;
+        if (out_total) out_total[q] = 0;
+        if (out_postings) out_postings[q] = 0;
+    }
+    if (nq == 0) return NIDX_OK;
+    if (k > 64) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > 64 is not supported yet (got %u)", k);
+    const uint64_t n_clauses = clause_offsets[nq];
+    if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
+    // Bm25Weight per clause from searcher-wide statistics
+    std::vector<Bm25ClauseDev> dev_clauses(n_clauses);
+    for (uint32_t q = 0; q < nq; q++) {
+        if (clause_offsets[q + 1] < clause_offsets[q]) return fail(NIDX_ERR_INVALID_ARGUMENT, "clause_offsets not monotone");
+        if (clause_offsets[q + 1] - clause_offsets[q] > BM25_MAX_CLAUSES)
+            return fail(NIDX_ERR_UNSUPPORTED, "more than %d clauses in one query", BM25_MAX_CLAUSES);
+    }
+    for (uint64_t c = 0; c < n_clauses; c++) {
+        const nidx_gpu_bm25_clause_t &cl = clauses[c];
+        if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
+        if (cl.occur < 0 || cl.occur > 2 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        uint64_t df = 0;
+        for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
+        float w = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
+        dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, cl.mode, w};
+    }
+    const uint32_t kk = std::max<uint32_t>(k, 1);
+    NIDX_HIP(idx->s_clauses.reserve(std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev)));
+    NIDX_HIP(idx->s_offsets.reserve((size_t)(nq + 1) * 8));
+    NIDX_HIP(idx->s_doc.reserve((size_t)nq * kk * 4));
+    NIDX_HIP(idx->s_score.reserve((size_t)nq * kk * 4));
+    NIDX_HIP(idx->s_count.reserve((size_t)nq * 4));
+    NIDX_HIP(idx->s_total.reserve((size_t)nq * 8));
+    NIDX_HIP(idx->s_postings.reserve((size_t)nq * 8));
+    if (n_clauses)
+        NIDX_HIP(hipMemcpyAsync(idx->s_clauses.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev), hipMemcpyHostToDevice, idx->stream));
+    NIDX_HIP(hipMemcpyAsync(idx->s_offsets.p, clause_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    static_assert(sizeof(Bm25AfterDev) == sizeof(nidx_gpu_bm25_search_after_t), "search-after layout");
+    if (after) {
+        NIDX_HIP(idx->s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
+        NIDX_HIP(hipMemcpyAsync(idx->s_after.p, after, (size_t)nq * sizeof(Bm25AfterDev), hipMemcpyHostToDevice, idx->stream));
+    }
+    struct Hit { float score; uint64_t docaddr; };
+    std::vector<std::vector<Hit>> merged(nq);
+    std::vector<uint32_t> h_doc((size_t)nq * kk), h_count(nq);
+    std::vector<float> h_score((size_t)nq * kk);
+    std::vector<unsigned long long> h_total(nq), h_post(nq);
+    for (size_t s = 0; s < idx->segs.size(); s++) {
+        Bm25Segment &seg = idx->segs[s];
+        Bm25Args a;
+        a.term_offsets = seg.term_offsets.as<unsigned long long>();
+        a.doc_ids = seg.doc_ids.as<uint32_t>();
+        a.tfs = seg.tfs.as<uint32_t>();
+        a.fieldnorm_ids = seg.fieldnorm_ids.as<uint8_t>();
+        a.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
+        a.tf_cache = idx->tf_cache.as<float>();
+        a.clauses = idx->s_clauses.as<Bm25ClauseDev>();
+        a.clause_offsets = idx->s_offsets.as<unsigned long long>();
+        a.after = after ? idx->s_after.as<Bm25AfterDev>() : nullptr;
+        a.k = kk;
+        a.segment_ord = (uint32_t)s;
+        a.out_doc = idx->s_doc.as<uint32_t>();
+        a.out_score = idx->s_score.as<float>();
+        a.out_count = idx->s_count.as<uint32_t>();
+        a.out_total = idx->s_total.as<unsigned long long>();
+        a.out_postings = idx->s_postings.as<unsigned long long>();
+        NIDX_HIP(launch_bm25_search(a, nq, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, h_doc.size() * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, h_score.size() * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_total.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_postings.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipStreamSynchronize(idx->stream));
+        for (uint32_t q = 0; q < nq; q++) {
+            if (out_total) out_total[q] += h_total[q];
+            if (out_postings) out_postings[q] += h_post[q];
+            if (k == 0) continue;
+            for (uint32_t i = 0; i < h_count[q]; i++)
+                merged[q].push_back(Hit{h_score[(size_t)q * kk + i], ((uint64_t)s << 32) | h_doc[(size_t)q * kk + i]});
+        }
+    }
+    for (uint32_t q = 0; q < nq && k > 0; q++) {
+        std::vector<Hit> &m = merged[q];
+        // TopDocs order across segments: score desc (total order), DocAddress asc
+        std::sort(m.begin(), m.end(), [](const Hit &x, const Hit &y) {
+            int32_t kx = total_key(x.score), ky = total_key(y.score);
+            if (kx != ky) return kx > ky;
+            return x.docaddr < y.docaddr;
+        });
+        uint32_t n = (uint32_t)std::min<size_t>(m.size(), k);
+        out_count[q] = n;
+        for (uint32_t i = 0; i < n; i++) {
+            if (out_docaddr) out_docaddr[(size_t)q * k + i] = m[i].docaddr;
+            if (out_score) out_score[(size_t)q * k + i] = m[i].score;
+        }
+    }
+    return NIDX_OK;
+}
+
+}  // extern "C"

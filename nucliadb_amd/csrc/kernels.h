@@ -114,4 +114,38 @@ struct BuildBatch {
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
 hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
 
+// ---- BM25 (bm25.hip) ----
+#define BM25_MAX_CLAUSES 64
+struct Bm25ClauseDev {
+    uint32_t term;
+    int occur;     // 0 should, 1 must, 2 must-not
+    int mode;      // 0 stored tf, 1 tf == 1, 2 constant score
+    float weight;  // idf * (1 + K1) * boost, or the constant score
+};
+struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
+    int has_after;
+    float score;
+    int tie_break;
+    unsigned long long docaddr;
+};
+struct Bm25Args {
+    const unsigned long long *term_offsets;
+    const uint32_t *doc_ids;
+    const uint32_t *tfs;
+    const uint8_t *fieldnorm_ids;
+    const uint64_t *alive;   // nullptr = all
+    const float *tf_cache;   // [256] K1*(1-B+B*fieldnorm/avg)
+    const Bm25ClauseDev *clauses;
+    const unsigned long long *clause_offsets;
+    const Bm25AfterDev *after;  // nullptr or [n_queries]
+    uint32_t k;                 // <= 64
+    uint32_t segment_ord;
+    uint32_t *out_doc;          // [n_queries][k]
+    float *out_score;           // [n_queries][k]
+    uint32_t *out_count;        // [n_queries]
+    unsigned long long *out_total;
+    unsigned long long *out_postings;
+};
+hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_queries, hipStream_t s);
+
 }  // namespace nidx

@@ -1,0 +1,146 @@
+"""GPU parity tests of the BM25 path: the HIP term-at-a-time kernel (through the C ABI) vs the CPU
+oracle (tantivy's formulas restated) — bit-exact scores, doc addresses, ranks and totals.
+The reference's own tests pin only counts and score thresholds (BM25 parity unpinned);
+those are mirrored at the bottom."""
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment, Clause, SearchAfter, tokenize
+
+pytestmark = pytest.mark.gpu
+S, M, N = _lib.OCCUR_SHOULD, _lib.OCCUR_MUST, _lib.OCCUR_MUST_NOT
+FREQ, BASIC, CONST = _lib.TF_FREQ, _lib.TF_BASIC, _lib.CONST_SCORE
+
+
+def zipf_corpus(rng, n_docs, vocab, mean_len=48):
+    """T-zipf of SURVEY §8d, scaled: term ids ~ Zipf(1.0), doc length ~ lognormal clipped to [4, 2000]."""
+    lens = np.clip(np.round(rng.lognormal(np.log(mean_len), 0.6, n_docs)), 4, 2000).astype(np.int64)
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    flat = rng.choice(vocab, size=int(lens.sum()), p=p)
+    return np.split(flat, np.cumsum(lens)[:-1])
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def compare(orc, seg, searcher, queries, k, after=None, segment_ord=0):
+    docaddr, score, count, total, postings = searcher.search_batch(queries, k, after)
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive)
+    for i, q in enumerate(queries):
+        a = None if after is None or after[i] is None else (after[i].score, after[i].tie_break, after[i].docaddr)
+        wd, ws, wt = oidx.search([(c.term, c.occur, c.mode, c.boost) for c in q], k, after=a, segment_ord=segment_ord)
+        assert total[i] == wt, (i, total[i], wt)
+        assert count[i] == len(wd), (i, count[i], len(wd))
+        assert np.array_equal(docaddr[i, : count[i]], wd), (i, docaddr[i, : count[i]], wd)
+        assert np.array_equal(bits(score[i, : count[i]]), bits(ws)), (i, score[i, : count[i]], ws)
+        assert postings[i] == sum(int(seg.term_offsets[c.term + 1] - seg.term_offsets[c.term]) for c in q)
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    rng = np.random.default_rng(1234567890)
+    vocab = 5000
+    docs = zipf_corpus(rng, 60000, vocab)
+    return Bm25Segment.from_term_docs(docs, vocab), vocab
+
+
+def test_fieldnorm_table_and_idf(orc):
+    L = _lib.lib()
+    table = orc.fieldnorm_table()
+    assert [L.nidx_gpu_fieldnorm_from_id(i) for i in range(256)] == table.tolist()
+    for n in list(range(0, 3000)) + [2**20, 2**31, 2**32 - 1]:
+        assert L.nidx_gpu_fieldnorm_to_id(n) == orc.fieldnorm_to_id(n)
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        N_ = int(rng.integers(1, 20_000_000))
+        n_ = int(rng.integers(0, N_ + 1))
+        assert np.float32(L.nidx_gpu_bm25_idf(n_, N_)).view(np.uint32) == np.float32(orc.bm25_idf(n_, N_)).view(np.uint32)
+
+
+def test_or_queries_match_oracle(orc, corpus):
+    seg, vocab = corpus
+    rng = np.random.default_rng(1)
+    s = Bm25Searcher.open([seg])
+    queries = [[Clause(int(t)) for t in rng.integers(0, vocab, int(rng.integers(1, 6)))] for _ in range(64)]
+    queries += [[Clause(0), Clause(1), Clause(2)], [Clause(3, boost=2.5), Clause(4000)], []]  # very dense lists; empty query
+    compare(orc, seg, s, queries, 20)
+    compare(orc, seg, s, queries, 1)
+    compare(orc, seg, s, queries, 64)
+    s.close()
+
+
+def test_boolean_mix_and_modes(orc, corpus):
+    seg, vocab = corpus
+    rng = np.random.default_rng(2)
+    s = Bm25Searcher.open([seg])
+    queries = []
+    for _ in range(80):
+        q = []
+        for _ in range(int(rng.integers(1, 7))):
+            q.append(Clause(int(rng.integers(0, 300)), int(rng.choice([S, S, M, N])), int(rng.choice([FREQ, BASIC, CONST])),
+                            float(rng.choice([1.0, 0.5, 2.0]))))
+        queries.append(q)
+    # the paragraph shape (nidx_paragraph/src/search_query.rs:185-243): Should Basic terms + Must const filters
+    queries.append([Clause(10, S, BASIC), Clause(11, S, BASIC), Clause(1, M, CONST, 1.0), Clause(0, M, BASIC)])
+    queries.append([Clause(5, N), Clause(6, N)])          # only MustNot: nothing matches
+    queries.append([Clause(7, M), Clause(7, M)])          # the same term twice
+    compare(orc, seg, s, queries, 20)
+    s.close()
+
+
+def test_alive_bitset_and_search_after(orc):
+    rng = np.random.default_rng(3)
+    vocab = 800
+    docs = zipf_corpus(rng, 20000, vocab, mean_len=12)
+    alive = orc.bitset(20000, ones=np.nonzero(rng.random(20000) < 0.7)[0].tolist())
+    seg = Bm25Segment.from_term_docs(docs, vocab, alive=alive)
+    s = Bm25Searcher.open([seg])
+    queries = [[Clause(int(t), S, BASIC) for t in rng.integers(0, 60, 3)] for _ in range(24)]  # tf == 1: many exact ties
+    compare(orc, seg, s, queries, 20)
+    # page through with the (score, docaddr) cursor like nidx/tests/integration/search_after.rs
+    docaddr, score, count, total, _ = s.search_batch(queries, 20)
+    after = [SearchAfter(float(score[i, 7]), 1, int(docaddr[i, 7])) if count[i] > 7 else None for i in range(len(queries))]
+    compare(orc, seg, s, queries, 20, after=after)
+    after = [SearchAfter(float(score[i, 3]), t, int(docaddr[i, 3])) if count[i] > 3 else None for i, t in zip(range(len(queries)), [0, 1, 2] * 8)]
+    compare(orc, seg, s, queries, 20, after=after)
+    s.close()
+
+
+def test_multi_segment_equals_one_segment():
+    """Statistics are searcher-wide (tantivy Bm25Weight::for_terms): splitting the corpus into segments
+    must not change any score, and DocAddress = (segment_ord << 32) | doc orders ties."""
+    rng = np.random.default_rng(4)
+    vocab = 1000
+    docs = zipf_corpus(rng, 9000, vocab, mean_len=10)
+    whole = Bm25Segment.from_term_docs(docs, vocab)
+    parts = [Bm25Segment.from_term_docs(docs[:4000], vocab), Bm25Segment.from_term_docs(docs[4000:], vocab)]
+    queries = [[Clause(int(t)) for t in rng.integers(0, 100, 3)] for _ in range(32)]
+    s1, s2 = Bm25Searcher.open([whole]), Bm25Searcher.open(parts)
+    d1, sc1, c1, t1, _ = s1.search_batch(queries, 20)
+    d2, sc2, c2, t2, _ = s2.search_batch(queries, 20)
+    assert np.array_equal(t1, t2) and np.array_equal(c1, c2)
+    for i in range(len(queries)):
+        g = [(int(a) >> 32) * 4000 + (int(a) & 0xFFFFFFFF) for a in d2[i, : c2[i]]]
+        assert g == [int(a) for a in d1[i, : c1[i]]]
+        assert np.array_equal(bits(sc1[i, : c1[i]]), bits(sc2[i, : c2[i]]))
+    s1.close()
+    s2.close()
+
+
+def test_reference_min_score_counts():
+    """nidx_text/tests/test_search.rs:311-332 and nidx_paragraph/tests/reader.rs:315-342: a one-word
+    query scores well below 30 — hits survive min_score 0 and vanish at 30/100 while `total` stays."""
+    texts = ["This is one of the best ways to test", "should enough", "shoupd enough test", "enough test for it to be a test",
+             "some other text that does not match"]
+    vocab: dict = {}
+    docs = [np.array([vocab.setdefault(t, len(vocab)) for t in tokenize(x)], dtype=np.int64) for x in texts]
+    seg = Bm25Segment.from_term_docs(docs, len(vocab))
+    s = Bm25Searcher.open([seg])
+    docaddr, score, count, total, _ = s.search_batch([[Clause(vocab["should"])], [Clause(vocab["enough"]), Clause(vocab["test"])]], 10)
+    assert count[0] == 1 and total[0] == 1 and 0 < score[0, 0] < 30
+    assert count[1] == 4 and total[1] == 4 and (score[1, :4] < 30).all() and (score[1, :4] > 0).all()
+    assert sum(1 for x in score[1, :4] if x >= 30) == 0
+    s.close()
