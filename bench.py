@@ -109,22 +109,12 @@ def main():
             h, 0, qb.data_ptr(), B, C.byref(p), None, out_vec.data_ptr(), out_score.data_ptr(), out_count.data_ptr(),
             stats.data_ptr() if with_stats else None, stream))
 
-    if world > 1:
-        g_score = torch.zeros((world, B, k), dtype=torch.float32, device=dev)
-        g_id = torch.zeros((world, B, k), dtype=torch.int64, device=dev)
-        g_count = torch.zeros((world, B), dtype=torch.int32, device=dev)
-        m_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
-        m_id = torch.zeros((B, k), dtype=torch.int64, device=dev)
-        m_count = torch.zeros((B,), dtype=torch.int32, device=dev)
-
     def exchange():
         # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
+        from nucliadb_amd.shard_merge import exchange_and_merge_vector
+
         ids = (out_vec.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
-        dist.all_gather_into_tensor(g_score, out_score)
-        dist.all_gather_into_tensor(g_id, ids)
-        dist.all_gather_into_tensor(g_count, out_count)
-        _lib.check(L.nidx_gpu_merge_vector_device(g_score.data_ptr(), g_id.data_ptr(), g_count.data_ptr(), world, B, k, k,
-                                                  m_score.data_ptr(), m_id.data_ptr(), m_count.data_ptr(), stream))
+        return exchange_and_merge_vector(out_score, ids, out_count, k)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,146 @@
+"""The reference's own nidx_vector tests, replayed through the host mirror (same names and argument
+meaning) on the GPU path: nidx/nidx_vector/tests/{test_basic_search,test_min_score}.rs,
+nidx/tests/integration/vector_normalization.rs, nidx_vector/src/searcher.rs test_key_prefix_search."""
+import uuid
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import (And, Elem, FieldId, FilterOperator, Literal, Not, Or, PrefilterResult, Similarity,
+                                 VectorConfig, VectorSearcher, VectorSearchRequest, segment_create)
+
+pytestmark = pytest.mark.gpu
+DIMENSION = 64
+
+
+def sentence(i, d=DIMENSION):
+    v = [0.0] * d
+    v[i] = 1.0
+    return v
+
+
+@pytest.mark.parametrize("similarity", [Similarity.Dot, Similarity.Cosine])
+def test_basic_search(similarity):
+    """test_basic_search.rs:38-145: 64 orthogonal one-hot vectors."""
+    config = VectorConfig.for_paragraphs(DIMENSION)
+    config.similarity = similarity
+    rid = str(uuid.uuid4())
+    segment = segment_create([Elem(f"{rid}/a/title/0-{i}", sentence(i)) for i in range(DIMENSION)], config)
+    searcher = VectorSearcher.open(config, [(segment, 1)])
+    results = searcher.search(VectorSearchRequest(vector=sentence(5), result_per_page=10, min_score=-1.0), PrefilterResult.All)
+    assert len(results.documents) == 10
+    assert results.documents[0].doc_id == f"{rid}/a/title/0-5"
+    assert results.documents[0].score > 0.9999
+    assert results.documents[1].score < 0.0001
+    vector = [0.0] * DIMENSION
+    vector[42], vector[43], vector[44], vector[45] = 0.7, 0.59, 0.35, 0.2
+    results = searcher.search(VectorSearchRequest(vector=vector, result_per_page=10, min_score=-1.0), PrefilterResult.All)
+    assert len(results.documents) == 10
+    for rank, (idx, floor) in enumerate([(42, 0.6), (43, 0.5), (44, 0.3), (45, 0.15)]):
+        assert results.documents[rank].doc_id == f"{rid}/a/title/0-{idx}"
+        assert results.documents[rank].score > floor
+    assert results.documents[5].score == 0.0
+    searcher.close()
+
+
+def _resource(dim, labels=(), value=None):
+    rid = str(uuid.uuid4())
+    v = [0.0] * dim if value is None else value
+    return rid, [Elem(f"{rid}/a/title/0-5", v, labels=list(labels))]
+
+
+def test_deletions():
+    """test_basic_search.rs:147-216: resource-level and field-level deletions with seq ordering."""
+    config = VectorConfig.for_paragraphs(4)
+    r1, e1 = _resource(4)
+    r2, e2 = _resource(4)
+    s1, s2 = segment_create(e1, config), segment_create(e2, config)
+    request = VectorSearchRequest(vector=[0.0] * 4, result_per_page=10, min_score=-1.0)
+    searcher = VectorSearcher.open(config, [(s1, 1), (s2, 2)])
+    assert len(searcher.search(request, PrefilterResult.All).documents) == 2
+    searcher = VectorSearcher.open(config, [(s1, 1), (s2, 2)], [(r1, 3)])
+    docs = searcher.search(request, PrefilterResult.All).documents
+    assert len(docs) == 1 and docs[0].doc_id.startswith(r2)
+    searcher = VectorSearcher.open(config, [(s1, 1), (s2, 2)], [(f"{r2}/a/title", 3)])
+    docs = searcher.search(request, PrefilterResult.All).documents
+    assert len(docs) == 1 and docs[0].doc_id.startswith(r1)
+    # a deletion older than the segment does not apply (lib.rs:166-200: seq > segment seq)
+    searcher = VectorSearcher.open(config, [(s1, 5), (s2, 6)], [(r1, 3)])
+    assert len(searcher.search(request, PrefilterResult.All).documents) == 2
+
+
+def test_filtered_search():
+    """test_basic_search.rs:218-400: boolean label formulas + prefilter AND/OR."""
+    config = VectorConfig.for_paragraphs(4)
+    work = [(["0", "8"]), (["1", "9"]), (["2", "8"]), (["3", "9"])]
+    rids, segs = [], []
+    for i, labels in enumerate(work):
+        rid, elems = _resource(4, labels)
+        rids.append(rid)
+        segs.append((segment_create(elems, config), i + 1))
+    searcher = VectorSearcher.open(config, segs)
+
+    def search(formula=None, prefilter=PrefilterResult.All, op=FilterOperator.And):
+        req = VectorSearchRequest(vector=[0.0] * 4, result_per_page=10, min_score=-1.0, filtering_formula=formula, filter_operator=op)
+        return {d.doc_id.split("/")[0] for d in searcher.search(req, prefilter).documents}
+
+    assert search() == set(rids)
+    assert search(Literal("0")) == {rids[0]}
+    assert search(Literal("8")) == {rids[0], rids[2]}
+    assert search(And([Literal("8"), Literal("2")])) == {rids[2]}
+    assert search(Or([Literal("0"), Literal("3")])) == {rids[0], rids[3]}
+    assert search(Not(Literal("9"))) == {rids[0], rids[2]}
+    assert search(And([Literal("8"), Not(Literal("0"))])) == {rids[2]}
+    some = PrefilterResult.some([FieldId(uuid.UUID(rids[1]), "/a/title"), FieldId(uuid.UUID(rids[2]), None)])
+    assert search(prefilter=some) == {rids[1], rids[2]}
+    assert search(Literal("8"), some) == {rids[2]}
+    assert search(Literal("0"), some, FilterOperator.Or) == {rids[0], rids[1], rids[2]}
+    wrong_field = PrefilterResult.some([FieldId(uuid.UUID(rids[1]), "/a/other")])
+    assert search(prefilter=wrong_field) == set()
+
+
+def test_min_score():
+    """test_min_score.rs:61-164: 5 one-hot vectors, min_score 0.5 keeps exactly the matching one."""
+    config = VectorConfig.for_paragraphs(5)
+    rid = str(uuid.uuid4())
+    segment = segment_create([Elem(f"{rid}/a/title/0-{i}", sentence(i, 5)) for i in range(5)], config)
+    searcher = VectorSearcher.open(config, [(segment, 1)])
+    q = sentence(2, 5)
+    assert len(searcher.search(VectorSearchRequest(vector=q, result_per_page=10, min_score=0.5), PrefilterResult.All).documents) == 1
+    assert len(searcher.search(VectorSearchRequest(vector=q, result_per_page=10, min_score=-1.0), PrefilterResult.All).documents) == 5
+    # and through the HNSW path (closest_up_nodes cuts at min_score, hnsw/search.rs:205-216)
+    searcher.build_hnsw(0)
+    for ms, n in ((0.5, 1), (-1.0, 5)):
+        req = VectorSearchRequest(vector=q, result_per_page=10, min_score=ms, with_duplicates=True)
+        assert len(searcher.search(req, PrefilterResult.All, method=_lib.METHOD_HNSW).documents) == n
+
+
+def test_vector_normalization():
+    """nidx/tests/integration/vector_normalization.rs:31-91: normalised index, Dot, 20 colinear vectors."""
+    config = VectorConfig(dimension=10, similarity=Similarity.Dot, normalize_vectors=True)
+    rid = str(uuid.uuid4())
+    elems = []
+    for i in range(1, 21):
+        v = np.full(10, float(i), np.float32)
+        out = np.empty_like(v)
+        _lib.check(_lib.lib().nidx_gpu_normalize(v.ctypes.data, 1, 10, out.ctypes.data))  # indexer.rs:107-111
+        elems.append(Elem(f"{rid}/a/title/0-{i}", out.tolist()))
+    searcher = VectorSearcher.open(config, [(segment_create(elems, config), 1)])
+    req = VectorSearchRequest(vector=[500.0] * 10, result_per_page=20, min_score=0.999, with_duplicates=True)
+    docs = searcher.search(req, PrefilterResult.All).documents
+    assert len(docs) == 20 and all(d.score >= 0.999 for d in docs)
+    # with_duplicates = false (the proto default): the 20 vectors are byte-identical after normalisation
+    req.with_duplicates = False
+    assert len(searcher.search(req, PrefilterResult.All).documents) == 1
+
+
+def test_metadata_and_labels_round_trip():
+    """test_basic_search.rs:402-470."""
+    config = VectorConfig.for_paragraphs(4)
+    rid = str(uuid.uuid4())
+    elems = [Elem(f"{rid}/a/title/0-{i}", sentence(i, 4), labels=[f"l{i}"], metadata=bytes([i, i + 1])) for i in range(4)]
+    searcher = VectorSearcher.open(config, [(segment_create(elems, config), 1)])
+    docs = searcher.search(VectorSearchRequest(vector=sentence(2, 4), result_per_page=1, min_score=-1.0), PrefilterResult.All).documents
+    assert docs[0].doc_id.endswith("0-2") and docs[0].labels == ["l2"] and docs[0].metadata == bytes([2, 3])
+    assert searcher.space_usage() > 0
