@@ -44,9 +44,13 @@ def test_basic_search(similarity):
     searcher.close()
 
 
+_rand = np.random.default_rng(7)
+
+
 def _resource(dim, labels=(), value=None):
+    """tests/common/mod.rs:46-80: one sentence `[0.5, 0.5, 0.5, rand::random()]` per resource."""
     rid = str(uuid.uuid4())
-    v = [0.0] * dim if value is None else value
+    v = [0.5] * (dim - 1) + [float(_rand.random())] if value is None else value
     return rid, [Elem(f"{rid}/a/title/0-5", v, labels=list(labels))]
 
 
@@ -130,9 +134,11 @@ def test_vector_normalization():
     req = VectorSearchRequest(vector=[500.0] * 10, result_per_page=20, min_score=0.999, with_duplicates=True)
     docs = searcher.search(req, PrefilterResult.All).documents
     assert len(docs) == 20 and all(d.score >= 0.999 for d in docs)
-    # with_duplicates = false (the proto default): the 20 vectors are byte-identical after normalisation
+    # with_duplicates = false (the proto default): hits are de-duplicated by vector BYTES
+    # (Fssc.seen, searcher.rs:175-181) — one hit per distinct bit pattern after normalisation
     req.with_duplicates = False
-    assert len(searcher.search(req, PrefilterResult.All).documents) == 1
+    distinct = len({np.asarray(e.vector, np.float32).tobytes() for e in elems})
+    assert len(searcher.search(req, PrefilterResult.All).documents) == distinct < 20
 
 
 def test_metadata_and_labels_round_trip():
