@@ -161,6 +161,17 @@ def main():
         evals_q, exp_q = [float(n)], [0.0]
         del tiles
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed
+    # rocprofv3 --pmc passes of this same command are quoted when the workload is the profiled one.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        w = pmc["workload"]
+        if a.workload == "hnsw" and (w["n_vectors"], w["dim"], w["batch"], w["k"]) == (n, d, B, k):
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], pmc["source"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     # ---- recall@k against the exact scan (oracle-verified kernel) on the same shard
     recall = None
@@ -204,9 +215,9 @@ def main():
                 "kernel_flags": flags, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world,
             },
             "roofline": {
-                "kernel": "hnsw_search_kernel<3>" if a.workload == "hnsw" else "scan_topk_kernel",
+                "kernel": "hnsw_search_kernel<3,2,4>" if a.workload == "hnsw" else "scan_topk_kernel",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
             },
             "cpu_baseline": cpu,

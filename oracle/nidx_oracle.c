@@ -7,6 +7,9 @@
 #include "nidx_oracle.h"
 
 #include <math.h>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -53,6 +56,20 @@ static double reduce8_f64(const float a[8]) {
 static void sums_haswell(const float *x, const float *y, size_t n, double *ab, double *xx, double *yy) {
     float vab[8] = {0}, vxx[8] = {0}, vyy[8] = {0};
     size_t i = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+    /* the same 8 independent fmaf lanes, issued as the AVX2 instructions SimSIMD's haswell kernel
+     * uses (bit-identical to the scalar lanes below; this is what makes the CPU baseline fair) */
+    __m256 aab = _mm256_setzero_ps(), axx = _mm256_setzero_ps(), ayy = _mm256_setzero_ps();
+    for (; i + 8 <= n; i += 8) {
+        __m256 vx = _mm256_loadu_ps(x + i), vy = _mm256_loadu_ps(y + i);
+        aab = _mm256_fmadd_ps(vx, vy, aab);
+        axx = _mm256_fmadd_ps(vx, vx, axx);
+        ayy = _mm256_fmadd_ps(vy, vy, ayy);
+    }
+    _mm256_storeu_ps(vab, aab);
+    _mm256_storeu_ps(vxx, axx);
+    _mm256_storeu_ps(vyy, ayy);
+#else
     for (; i + 8 <= n; i += 8) {
         for (int l = 0; l < 8; l++) {
             float xi = x[i + l], yi = y[i + l];
@@ -61,6 +78,7 @@ static void sums_haswell(const float *x, const float *y, size_t n, double *ab, d
             vyy[l] = fmaf(yi, yi, vyy[l]);
         }
     }
+#endif
     double sab = reduce8_f64(vab), sxx = reduce8_f64(vxx), syy = reduce8_f64(vyy);
     for (; i < n; i++) {
         float xi = x[i], yi = y[i];
