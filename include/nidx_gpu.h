@@ -238,6 +238,10 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
                              float *out_score, uint32_t *out_count, uint64_t *out_total,
                              uint64_t *out_postings);
 
+/* Device time (HIP events on the handle's stream) spent in the scoring kernel(s) of the last
+ * nidx_gpu_bm25_search call, summed over segments. */
+int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out);
+
 /* tantivy Bm25Weight pieces, exposed for the host query layer and for tests. */
 float nidx_gpu_bm25_idf(uint64_t doc_freq, uint64_t doc_count);
 uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id);

@@ -122,6 +122,7 @@ SIGNATURES = {
     "nidx_gpu_bm25_space_usage": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "nidx_gpu_bm25_idf": (C.c_float, [C.c_uint64, C.c_uint64]),
     "nidx_gpu_fieldnorm_from_id": (C.c_uint32, [C.c_uint8]),
     "nidx_gpu_fieldnorm_to_id": (C.c_uint8, [C.c_uint32]),

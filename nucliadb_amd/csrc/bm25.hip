@@ -7,7 +7,10 @@
 //   TopDocs::with_limit(k) ordered (score desc, DocAddress asc), Count, the search-after score tweak
 //   (reader.rs:350-390), deletions as an alive bitset (nidx_tantivy/src/index_reader.rs:39-74).
 //
-// One workgroup per (query, segment).  The postings of a query's clauses are consumed in lockstep
+// One workgroup per work item = (query, doc-id slice of the segment): the host cuts every query into
+// slices of roughly equal posting count so that a query with a 400 k-posting term does not become the
+// tail of the launch; a slice's cursors are found with a wave-wide 64-ary search.  Inside a work item
+// the postings of the query's clauses are consumed in lockstep
 // doc-id windows [lo, hi): hi is chosen so that every clause contributes at most PER postings, all
 // of a window's (doc -> partial score) pairs live in an LDS hash table, clauses are applied one
 // after the other with a barrier in between — so each doc's f32 sum is built in clause order,
@@ -40,7 +43,8 @@ struct Bm25Shared {
 __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     __shared__ Bm25Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-    const uint32_t q = blockIdx.x;
+    const Bm25Work work = a.work[blockIdx.x];
+    const uint32_t q = work.query;
     const uint64_t c0 = a.clause_offsets[q], c1 = a.clause_offsets[q + 1];
     const int C = (int)(c1 - c0);
     const Bm25ClauseDev *cl = a.clauses + c0;
@@ -54,9 +58,44 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     if (tid < 256) sh.tf_cache[tid] = a.tf_cache[tid];
     int n_must = 0;
     for (int c = 0; c < C; c++) n_must += cl[c].occur == 1 ? 1 : 0;
-    if (tid < C) {
-        sh.cursor[tid] = a.term_offsets[cl[tid].term];
-        sh.end[tid] = a.term_offsets[cl[tid].term + 1];
+    if (work.n_slices <= 1) {
+        if (tid < C) {
+            sh.cursor[tid] = a.term_offsets[cl[tid].term];
+            sh.end[tid] = a.term_offsets[cl[tid].term + 1];
+        }
+    } else {
+        // doc range of this slice; per clause a wave finds the first posting >= lo and >= hi
+        const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
+        const uint32_t hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
+        for (int c = wib; c < C; c += 4) {
+            const unsigned long long b = a.term_offsets[cl[c].term], e = a.term_offsets[cl[c].term + 1];
+            unsigned long long res[2];
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const uint32_t target = w == 0 ? lo_doc : hi_doc;
+                unsigned long long left = b, right = e;  // first index in [left, right] whose doc >= target
+                while (right - left > 64) {
+                    unsigned long long step = (right - left + 63) / 64;
+                    unsigned long long probe = left + step * (unsigned long long)lane;
+                    bool ge = probe < right ? a.doc_ids[probe] >= target : true;
+                    unsigned long long m = __ballot(ge);
+                    int first = m ? __ffsll((long long)m) - 1 : 64;
+                    unsigned long long nl = first == 0 ? left : left + step * (unsigned long long)(first - 1);
+                    unsigned long long nr = left + step * (unsigned long long)first;
+                    left = nl;
+                    right = nr < right ? nr : right;
+                }
+                unsigned long long probe = left + (unsigned long long)lane;
+                bool ge = probe < right ? a.doc_ids[probe] >= target : true;
+                unsigned long long m = __ballot(ge);
+                int first = m ? __ffsll((long long)m) - 1 : 64;
+                res[w] = left + (unsigned long long)first < right ? left + (unsigned long long)first : right;
+            }
+            if (lane == 0) {
+                sh.cursor[c] = res[0];
+                sh.end[c] = res[1];
+            }
+        }
     }
     if (tid == 0) {
         sh.total = 0;
@@ -188,20 +227,20 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         bool valid = top.key != NIDX_EMPTY_KEY && lane < k;
         unsigned long long vm = __ballot(valid);
         if (lane < k) {
-            a.out_doc[(size_t)q * k + lane] = valid ? rank_key_addr(top.key) : 0xffffffffu;
-            a.out_score[(size_t)q * k + lane] = valid ? rank_key_score(top.key) : 0.f;
+            a.out_doc[(size_t)blockIdx.x * k + lane] = valid ? rank_key_addr(top.key) : 0xffffffffu;
+            a.out_score[(size_t)blockIdx.x * k + lane] = valid ? rank_key_score(top.key) : 0.f;
         }
         if (lane == 0) {
-            a.out_count[q] = (uint32_t)__popcll(vm);
-            a.out_total[q] = sh.total;
-            a.out_postings[q] = sh.postings;
+            a.out_count[blockIdx.x] = (uint32_t)__popcll(vm);
+            a.out_total[blockIdx.x] = sh.total;
+            a.out_postings[blockIdx.x] = sh.postings;
         }
     }
 }
 
-hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_queries, hipStream_t s) {
-    if (n_queries == 0) return hipSuccess;
-    hipLaunchKernelGGL(bm25_search_kernel, dim3(n_queries), dim3(256), 0, s, a);
+hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s) {
+    if (n_work == 0) return hipSuccess;
+    hipLaunchKernelGGL(bm25_search_kernel, dim3(n_work), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

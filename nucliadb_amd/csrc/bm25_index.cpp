@@ -60,7 +60,9 @@ struct Bm25Index {
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
     DevBuf tf_cache;
-    DevBuf s_clauses, s_offsets, s_after, s_doc, s_score, s_count, s_total, s_postings;
+    DevBuf s_clauses, s_offsets, s_after, s_work, s_doc, s_score, s_count, s_total, s_postings;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
+    float last_kernel_ms = 0.f;
 };
 
 }  // namespace nidx
@@ -79,6 +81,8 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     std::unique_ptr<Bm25Index> idx(new Bm25Index());
     NIDX_HIP(hipGetDevice(&idx->device));
     NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    NIDX_HIP(hipEventCreate(&idx->ev0));
+    NIDX_HIP(hipEventCreate(&idx->ev1));
     idx->segs.resize(n_segments);
     for (uint32_t s = 0; s < n_segments; s++) {
         const nidx_gpu_bm25_segment_t &in = segments[s];
@@ -131,7 +135,16 @@ void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index) {
         (void)hipStreamSynchronize(idx->stream);
         (void)hipStreamDestroy(idx->stream);
     }
+    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     delete idx;
+}
+
+int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out) {
+    const Bm25Index *idx = reinterpret_cast<const Bm25Index *>(index);
+    if (!idx || !ms_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *ms_out = idx->last_kernel_ms;
+    return NIDX_OK;
 }
 
 int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *bytes_out) {
@@ -179,11 +192,6 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
     const uint32_t kk = std::max<uint32_t>(k, 1);
     NIDX_HIP(idx->s_clauses.reserve(std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev)));
     NIDX_HIP(idx->s_offsets.reserve((size_t)(nq + 1) * 8));
-    NIDX_HIP(idx->s_doc.reserve((size_t)nq * kk * 4));
-    NIDX_HIP(idx->s_score.reserve((size_t)nq * kk * 4));
-    NIDX_HIP(idx->s_count.reserve((size_t)nq * 4));
-    NIDX_HIP(idx->s_total.reserve((size_t)nq * 8));
-    NIDX_HIP(idx->s_postings.reserve((size_t)nq * 8));
     if (n_clauses)
         NIDX_HIP(hipMemcpyAsync(idx->s_clauses.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev), hipMemcpyHostToDevice, idx->stream));
     NIDX_HIP(hipMemcpyAsync(idx->s_offsets.p, clause_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->stream));
@@ -192,14 +200,35 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         NIDX_HIP(idx->s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
         NIDX_HIP(hipMemcpyAsync(idx->s_after.p, after, (size_t)nq * sizeof(Bm25AfterDev), hipMemcpyHostToDevice, idx->stream));
     }
+    idx->last_kernel_ms = 0.f;
     struct Hit { float score; uint64_t docaddr; };
     std::vector<std::vector<Hit>> merged(nq);
-    std::vector<uint32_t> h_doc((size_t)nq * kk), h_count(nq);
-    std::vector<float> h_score((size_t)nq * kk);
-    std::vector<unsigned long long> h_total(nq), h_post(nq);
+    std::vector<Bm25Work> work;
+    std::vector<uint32_t> h_doc, h_count;
+    std::vector<float> h_score;
+    std::vector<unsigned long long> h_total, h_post;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
+        // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
+        work.clear();
+        for (uint32_t q = 0; q < nq; q++) {
+            uint64_t p = 0;
+            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++)
+                p += seg.term_offsets_host[clauses[c].term + 1] - seg.term_offsets_host[clauses[c].term];
+            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + BM25_SLICE_POSTINGS - 1) / BM25_SLICE_POSTINGS));
+            for (uint32_t sl = 0; sl < slices; sl++) work.push_back(Bm25Work{q, sl, slices});
+        }
+        const size_t nw = work.size();
+        NIDX_HIP(idx->s_work.reserve(nw * sizeof(Bm25Work)));
+        NIDX_HIP(idx->s_doc.reserve(nw * kk * 4));
+        NIDX_HIP(idx->s_score.reserve(nw * kk * 4));
+        NIDX_HIP(idx->s_count.reserve(nw * 4));
+        NIDX_HIP(idx->s_total.reserve(nw * 8));
+        NIDX_HIP(idx->s_postings.reserve(nw * 8));
+        NIDX_HIP(hipMemcpyAsync(idx->s_work.p, work.data(), nw * sizeof(Bm25Work), hipMemcpyHostToDevice, idx->stream));
         Bm25Args a;
+        a.work = idx->s_work.as<Bm25Work>();
+        a.n_docs = seg.n_docs;
         a.term_offsets = seg.term_offsets.as<unsigned long long>();
         a.doc_ids = seg.doc_ids.as<uint32_t>();
         a.tfs = seg.tfs.as<uint32_t>();
@@ -216,19 +245,30 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         a.out_count = idx->s_count.as<uint32_t>();
         a.out_total = idx->s_total.as<unsigned long long>();
         a.out_postings = idx->s_postings.as<unsigned long long>();
-        NIDX_HIP(launch_bm25_search(a, nq, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, h_doc.size() * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, h_score.size() * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_total.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_postings.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
+        NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
+        NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
+        h_doc.resize(nw * kk);
+        h_score.resize(nw * kk);
+        h_count.resize(nw);
+        h_total.resize(nw);
+        h_post.resize(nw);
+        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, nw * kk * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, nw * kk * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_count.p, nw * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_total.p, nw * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_postings.p, nw * 8, hipMemcpyDeviceToHost, idx->stream));
         NIDX_HIP(hipStreamSynchronize(idx->stream));
-        for (uint32_t q = 0; q < nq; q++) {
-            if (out_total) out_total[q] += h_total[q];
-            if (out_postings) out_postings[q] += h_post[q];
+        float ms = 0.f;
+        NIDX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+        idx->last_kernel_ms += ms;
+        for (size_t w = 0; w < nw; w++) {
+            const uint32_t q = work[w].query;
+            if (out_total) out_total[q] += h_total[w];
+            if (out_postings) out_postings[q] += h_post[w];
             if (k == 0) continue;
-            for (uint32_t i = 0; i < h_count[q]; i++)
-                merged[q].push_back(Hit{h_score[(size_t)q * kk + i], ((uint64_t)s << 32) | h_doc[(size_t)q * kk + i]});
+            for (uint32_t i = 0; i < h_count[w]; i++)
+                merged[q].push_back(Hit{h_score[w * kk + i], ((uint64_t)s << 32) | h_doc[w * kk + i]});
         }
     }
     for (uint32_t q = 0; q < nq && k > 0; q++) {

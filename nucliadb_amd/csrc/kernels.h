@@ -128,7 +128,14 @@ struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
     int tie_break;
     unsigned long long docaddr;
 };
+struct Bm25Work {  // one workgroup: query `query`, doc-id slice `slice` of `n_slices`
+    uint32_t query, slice, n_slices;
+};
+#define BM25_SLICE_POSTINGS 8192  /* target postings per work item */
+#define BM25_MAX_SLICES 256
 struct Bm25Args {
+    const Bm25Work *work;
+    uint32_t n_docs;
     const unsigned long long *term_offsets;
     const uint32_t *doc_ids;
     const uint32_t *tfs;
@@ -140,12 +147,12 @@ struct Bm25Args {
     const Bm25AfterDev *after;  // nullptr or [n_queries]
     uint32_t k;                 // <= 64
     uint32_t segment_ord;
-    uint32_t *out_doc;          // [n_queries][k]
-    float *out_score;           // [n_queries][k]
-    uint32_t *out_count;        // [n_queries]
+    uint32_t *out_doc;          // [n_work][k]
+    float *out_score;           // [n_work][k]
+    uint32_t *out_count;        // [n_work]
     unsigned long long *out_total;
     unsigned long long *out_postings;
 };
-hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_queries, hipStream_t s);
+hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s);
 
 }  // namespace nidx
