@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--workload", choices=["hnsw", "scan", "bm25"], default="hnsw")
+    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bm25"], default="hnsw")
     p.add_argument("--n-docs", type=int, default=10_000_000, help="bm25: documents per shard")
     p.add_argument("--vocab", type=int, default=1_000_000)
     p.add_argument("--recall-queries", type=int, default=256)
@@ -105,7 +105,7 @@ def main():
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
     out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
     stats = torch.zeros((B, 8), dtype=torch.int32, device=dev)
-    method = _lib.METHOD_HNSW if a.workload == "hnsw" else _lib.METHOD_BRUTE_FORCE
+    method = {"hnsw": _lib.METHOD_HNSW, "scan": _lib.METHOD_BRUTE_FORCE, "mfma": _lib.METHOD_BRUTE_FORCE_MFMA}[a.workload]
     params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -162,11 +162,11 @@ def main():
             flags |= int(np.bitwise_or.reduce(s[:, 3]))
         alg_bytes = float(np.mean(bytes_per_launch))
     else:
-        tiles = (B + 7) // 8
         alg_bytes = float(n) * d * 4  # the shard is read once per batch algorithmically
         evals_q, exp_q = [float(n)], [0.0]
-        del tiles
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    alg_flops = 2.0 * n * d * B
+    achieved_tf = alg_flops / (kernel_ms * 1e-3) / 1e12
     # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed
     # rocprofv3 --pmc passes of this same command are quoted when the workload is the profiled one.
     traffic, traffic_src = None, None
@@ -208,7 +208,7 @@ def main():
     if rank == 0:
         total_q = world * B * a.steps
         line = {
-            "metric": "queries/sec (768-dim cosine k-NN, HNSW M=30 ef=30, k=10)" if a.workload == "hnsw" else "queries/sec (exact cosine scan)",
+            "metric": "queries/sec (768-dim cosine k-NN, HNSW M=30 ef=30, k=10)" if a.workload == "hnsw" else "queries/sec (exact cosine k-NN, %s)" % a.workload,
             "value": total_q / elapsed,
             "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
             "n_gpus": world,
@@ -230,12 +230,16 @@ def main():
                 "distance_evals_per_query": float(np.mean(evals_q)), "expansions_per_query": float(np.mean(exp_q)),
                 "kernel_flags": flags, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world,
             },
-            "roofline": {
-                "kernel": "hnsw_search_kernel<3,2,4>" if a.workload == "hnsw" else "scan_topk_kernel",
+            "roofline": ({
+                "kernel": "mfma_scan_kernel (+ merge_topk_kernel)", "bound": "mfma", "achieved": achieved_tf, "peak": 157.3,
+                "unit": "TFLOP/s", "frac": achieved_tf / 157.3, "traffic": None, "algorithmic_flops_per_launch": alg_flops,
+                "hbm_GBps_algorithmic": achieved, "kernel_ms": kernel_ms,
+            } if a.workload == "mfma" else {
+                "kernel": "hnsw_search_kernel<3,2,4>" if a.workload == "hnsw" else "scan_topk_kernel (+ merge_topk_kernel)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
-            },
+            }),
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -415,7 +419,7 @@ def cpu_baseline(a, L, h, x_host, q0, q1):
         og = None
     oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL, graph=og)
     qs = np.vstack([q0, q1])
-    nq = min(a.cpu_queries if a.workload == "hnsw" else max(threads, 64), qs.shape[0])
+    nq = min(a.cpu_queries if a.workload == "hnsw" else threads, qs.shape[0])
 
     def one(i):
         if a.workload == "hnsw":

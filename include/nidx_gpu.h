@@ -111,7 +111,10 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
  * open from the environment as NIDX_GPU_<NAME>. */
 int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value);
 
-enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2 };
+/* NIDX_METHOD_BRUTE_FORCE_MFMA: the same exact scan as a dense GEMM on the f32 matrix cores (one
+ * pass over the corpus per batch, k <= 16).  It sums in NIDX_ORDER_SERIAL_FMA, so its scores differ
+ * from the other methods' (NIDX_ORDER_WAVE64) in the last bits: never chosen by AUTO. */
+enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2, NIDX_METHOD_BRUTE_FORCE_MFMA = 3 };
 
 /* The request fields the hot path reads (nidx_vector/src/request_types.rs:19-35). */
 typedef struct {

@@ -30,6 +30,26 @@ hipError_t launch_row_norms(const float *vectors, uint32_t n, uint32_t dp, float
 hipError_t launch_pair_similarity(const float *x, const float *y, uint32_t n, uint32_t dp, int similarity, float *out,
                                   hipStream_t s);
 
+// ---- batched exact scan on the f32 matrix cores (vector_mfma.hip) ----
+struct MfmaScanArgs {
+    const float *vectors;   // [n][dp]
+    const float *norm2;     // [n] SERIAL_FMA-order |x|^2 (cosine) or nullptr
+    uint32_t n, dp;
+    const float *queries;   // [n_queries][dp]
+    const float *q_norm2;   // [n_queries] SERIAL_FMA-order |q|^2
+    uint32_t n_queries;
+    const uint64_t *alive, *filter;
+    const uint32_t *para_of_vec;
+    int similarity;
+    float min_score;
+    uint32_t k;             // <= 16
+    uint64_t *partial;      // [n_queries][stripes][k]
+};
+#define NIDX_MFMA_KMAX 16
+hipError_t launch_serial_norms(const float *rows, uint32_t n, uint32_t dp, float *out, hipStream_t s);
+uint32_t mfma_scan_stripes(uint32_t n, uint32_t n_queries);
+hipError_t launch_mfma_scan(const MfmaScanArgs &a, uint32_t stripes, hipStream_t s);
+
 // ---- HNSW graph in HBM ----
 // layer 0: fixed 256-byte records [deg, e0..e59, pad x3]; upper layers: 128-byte records
 // [deg, e0..e29, pad]; a node with top layer L >= 1 owns L consecutive upper records starting at

@@ -134,7 +134,7 @@ SegDev VectorSegment::seg_dev(int similarity) const {
 }
 
 uint64_t VectorSegment::bytes() const {
-    return vectors.bytes + norm2.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
+    return vectors.bytes + norm2.bytes + norm2_serial.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
            g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes;
 }
 
@@ -243,6 +243,35 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
+    if (method == NIDX_METHOD_BRUTE_FORCE_MFMA) {
+        if (k > NIDX_MFMA_KMAX) return fail(NIDX_ERR_UNSUPPORTED, "the MFMA scan keeps at most %d hits per query (got k=%u)", NIDX_MFMA_KMAX, k);
+        if (cfg.similarity == NIDX_SIMILARITY_COSINE && !seg.norm2_serial.p) {
+            NIDX_HIP(seg.norm2_serial.alloc((size_t)seg.n * 4));
+            NIDX_HIP(launch_serial_norms(seg.vectors.as<float>(), seg.n, seg.dp, seg.norm2_serial.as<float>(), st));
+        }
+        NIDX_HIP(scratch_qnorm.reserve((size_t)nq * 4));
+        NIDX_HIP(launch_serial_norms(d_queries, nq, seg.dp, scratch_qnorm.as<float>(), st));
+        const uint32_t stripes = mfma_scan_stripes(seg.n, nq);
+        NIDX_HIP(scratch_partial.reserve((size_t)nq * stripes * k * 8));
+        MfmaScanArgs m;
+        m.vectors = seg.vectors.as<float>();
+        m.norm2 = seg.norm2_serial.as<float>();
+        m.n = seg.n;
+        m.dp = seg.dp;
+        m.queries = d_queries;
+        m.q_norm2 = scratch_qnorm.as<float>();
+        m.n_queries = nq;
+        m.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
+        m.filter = d_filter;
+        m.para_of_vec = seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>();
+        m.similarity = cfg.similarity;
+        m.min_score = min_score;
+        m.k = k;
+        m.partial = scratch_partial.as<uint64_t>();
+        NIDX_HIP(launch_mfma_scan(m, stripes, st));
+        NIDX_HIP(launch_merge_topk(m.partial, nq, stripes, k, d_out_vec, d_out_score, d_out_count, st));
+        return NIDX_OK;
+    }
     // brute force
     uint32_t nblk = scan_num_blocks(seg.n);
     size_t need = (size_t)nq * nblk * k * 8;
@@ -298,7 +327,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
     if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
     if (k > 64) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 64 is not supported yet (got %u)", k);
-    if (p.method < 0 || p.method > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
+    if (p.method < 0 || p.method > 3) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
     // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
     const uint32_t dp = (d + 3u) & ~3u;

@@ -17,6 +17,7 @@ struct VectorSegment {
     uint32_t n = 0, dim = 0, dp = 0, n_paragraphs = 0;
     DevBuf vectors;      // [n][dp] f32, zero padded
     DevBuf norm2;        // [n] f32, WAVE64-order |x|^2
+    DevBuf norm2_serial; // [n] f32, SERIAL_FMA-order |x|^2 (filled on the first MFMA scan)
     DevBuf para_of_vec;  // [n] u32 (absent when identity)
     DevBuf alive;        // bitset over paragraph addrs (absent when all alive)
     bool identity_para = true, all_alive = true;
@@ -51,7 +52,7 @@ struct VectorIndex {
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
-    DevBuf scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
+    DevBuf scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats;
 
     int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,

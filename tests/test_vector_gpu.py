@@ -236,3 +236,56 @@ def test_inconsistent_dimensions():
     assert e.value.code == _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS
     assert "Inconsistent dimensions. Index=8 Vector=7" in e.value.message
     s.close()
+
+
+# ---- a7 batched: the f32-MFMA GEMM scan (SERIAL_FMA order) ---------------------------------------------------
+@pytest.mark.parametrize("sim", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 3), (130, 20, 3, 10), (4000, 64, 9, 10), (20000, 768, 200, 10), (3000, 758, 5, 7),
+                                      (2500, 1024, 130, 16), (1200, 1536, 3, 5)])
+def test_mfma_scan_matches_oracle_serial_fma(orc, sim, n, d, nq, k):
+    rng = np.random.default_rng(n * 17 + d)
+    x = unit_rows(rng, n, d) if d > 8 else rng.normal(size=(n, d)).astype(np.float32)
+    q = rng.normal(size=(nq, d)).astype(np.float32)
+    ov, osc, oc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE_MFMA)
+    oseg = orc.Segment(x, similarity=sim, order=orc.ORDER_SERIAL_FMA)
+    for i in list(range(min(nq, 12))) + [nq - 1]:
+        wv, ws = oseg.brute_force(q[i], k)
+        assert oc[i] == len(wv), (i, oc[i], len(wv))
+        assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i], wv)
+        assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_mfma_scan_filters_min_score_and_ties(orc):
+    rng = np.random.default_rng(98)
+    n, d, k = 6000, 128, 10
+    x = unit_rows(rng, n, d)
+    x[100:140] = x[7]
+    q = np.vstack([x[7][None, :], rng.normal(size=(4, d)).astype(np.float32)])
+    alive = orc.bitset(n, fill=True)
+    for dead in (7, 100, 101, 5999):
+        alive[dead >> 6] &= ~np.uint64(1 << (dead & 63))
+    filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.3)[0].tolist() + list(range(100, 140)))
+    both = alive & filt
+    for sim in (0, 1):
+        oseg = orc.Segment(x, similarity=sim, alive=alive, order=orc.ORDER_SERIAL_FMA)
+        for kwargs, obits in (({"alive": alive}, alive), ({"alive": alive, "filter_bits": filt}, both)):
+            for ms in (-1.0, 0.1, 0.99):
+                ov, osc, oc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE_MFMA, min_score=ms, **kwargs)
+                for i in range(q.shape[0]):
+                    wv, ws = oseg.brute_force(q[i], k, min_score=ms, filter_bits=obits)
+                    assert oc[i] == len(wv), (sim, ms, i)
+                    assert np.array_equal(ov[i, : oc[i]], wv)
+                    assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_mfma_and_wave64_scans_agree_within_1e5():
+    """Two summation orders, one answer up to f32 round-off: same ids wherever the score gap exceeds
+    the round-off, scores within the 1e-5 the north star allows for cosine."""
+    rng = np.random.default_rng(5)
+    x = unit_rows(rng, 30000, 768)
+    q = unit_rows(rng, 64, 768)
+    v1, s1, c1 = gpu_search(x, 1, q, 10, method=_lib.METHOD_BRUTE_FORCE)
+    v2, s2, c2 = gpu_search(x, 1, q, 10, method=_lib.METHOD_BRUTE_FORCE_MFMA)
+    assert np.array_equal(c1, c2)
+    assert np.max(np.abs(s1 - s2)) < 1e-5
+    assert np.mean(v1 == v2) > 0.99
