@@ -60,19 +60,31 @@ def main():
         a.gpus = world
     if a.waves_per_query:
         os.environ["NIDX_GPU_WAVES_PER_QUERY"] = str(a.waves_per_query)
+    # NIDX_BENCH_SAME_DEVICE=1 (validation only): every rank uses GPU 0 and the collectives go over gloo,
+    # so the N>1 code path can be exercised on a single-GPU box.  The driver never sets it.
+    same_device = os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from nucliadb_amd import _lib
 
     L = _lib.lib()
     _lib.check(L.nidx_gpu_set_device(local_rank))
     if a.workload == "bm25":
-        return bench_bm25(a, L, dev, rank, world)
+        bench_bm25(a, L, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
 
     # ---- synthetic shard: the reference's generator (segment.rs:682-695), uniform(-1,1) then normalised
@@ -244,6 +256,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()  # rank 0 runs the CPU baseline; keep the group alive until it is done
         dist.destroy_process_group()
 
 

@@ -34,14 +34,15 @@ struct Bm25Shared {
     unsigned long long cursor[BM25_MAX_CLAUSES];
     unsigned long long end[BM25_MAX_CLAUSES];
     uint32_t hi;
-    uint32_t taken;
+    uint32_t taken_c[BM25_MAX_CLAUSES];
     unsigned long long total;
     unsigned long long postings;
-    uint64_t merge[3][64];
 };
 
+template <int KL>
 __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     __shared__ Bm25Shared sh;
+    __shared__ uint64_t merge[3][64 * KL];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const Bm25Work work = a.work[blockIdx.x];
     const uint32_t q = work.query;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     __syncthreads();
     const uint32_t per = C > 0 ? (uint32_t)(BM25_MAX_DISTINCT / C) : 1u;
 
-    WaveSortedList top;
+    WaveTopK<KL> top;  // k <= 64*KL
     top.init();
     uint64_t kth = NIDX_EMPTY_KEY;
     // search-after cursor (reader.rs:379-390)
@@ -126,19 +127,50 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         }
         __syncthreads();
         const uint32_t hi = sh.hi;
-        // ---- clauses in order ----
+        // ---- load phase: the window holds <= 2048 posting slots (slot g belongs to clause g / per);
+        //      every thread fetches its 8 slots for ALL clauses up front, so a window costs three
+        //      dependent memory round trips (doc id -> tf + fieldnorm gather) instead of three per clause
+        uint32_t p_doc[8];
+        float p_score[8];
+        int p_clause[8];
+        if (tid < BM25_MAX_CLAUSES) sh.taken_c[tid] = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t g = (uint32_t)tid + 256u * m;
+            const int c = (int)(g / per);
+            p_clause[m] = -1;
+            p_doc[m] = 0;
+            p_score[m] = 0.f;
+            if (c < C) {
+                const unsigned long long i = sh.cursor[c] + (g - (uint32_t)c * per);
+                if (i < sh.end[c]) {
+                    const uint32_t d = a.doc_ids[i];
+                    if (d < hi) {  // hi == 0xffffffff: every clause's remainder fits
+                        p_clause[m] = c;
+                        p_doc[m] = d;
+                        const int mode = cl[c].mode;
+                        if (cl[c].occur != 2) {
+                            if (mode == 2) p_score[m] = cl[c].weight;  // ConstScorer(boost)
+                            else {
+                                const float tf = mode == 1 ? 1.0f : (float)a.tfs[i];
+                                const float norm = sh.tf_cache[a.fieldnorm_ids[d]];
+                                p_score[m] = cl[c].weight * (tf / (tf + norm));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // taken_c zeroed
+        // ---- apply phase: clause by clause (barrier in between) so every doc's f32 sum is built in clause order
         for (int c = 0; c < C; c++) {
-            if (tid == 0) sh.taken = 0;
-            __syncthreads();
-            const unsigned long long cur = sh.cursor[c], e = sh.end[c];
-            const int occur = cl[c].occur, mode = cl[c].mode;
-            const float weight = cl[c].weight;
+            const int occur = cl[c].occur;
             uint32_t mine = 0;
-            for (unsigned long long i = cur + tid; i < e && i < cur + per; i += 256) {
-                uint32_t d = a.doc_ids[i];
-                if (d >= hi) break;  // hi == 0xffffffff: every clause's remainder fits
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                if (p_clause[m] != c) continue;
                 mine++;
-                // slot of doc d
+                const uint32_t d = p_doc[m];
                 uint32_t h = (d * 2654435761u) >> 20;
                 for (;;) {
                     uint32_t old = atomicCAS(&sh.key[h], BM25_EMPTY, d);
@@ -148,25 +180,17 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                 if (occur == 2) {
                     sh.flags[h] |= 2;  // MustNot
                 } else {
-                    float s;
-                    if (mode == 2) s = weight;  // ConstScorer(boost)
-                    else {
-                        float tf = mode == 1 ? 1.0f : (float)a.tfs[i];
-                        float norm = sh.tf_cache[a.fieldnorm_ids[d]];
-                        s = weight * (tf / (tf + norm));
-                    }
-                    sh.acc[h] = sh.acc[h] + s;
+                    sh.acc[h] = sh.acc[h] + p_score[m];
                     if (occur == 1) sh.flags[h] += 0x100;
                     else sh.flags[h] |= 1;
                 }
             }
-            if (mine) atomicAdd(&sh.taken, mine);
+            if (mine) atomicAdd(&sh.taken_c[c], mine);
             __syncthreads();
-            if (tid == 0) {
-                sh.cursor[c] = cur + sh.taken;
-                sh.postings += sh.taken;
-            }
-            __syncthreads();
+        }
+        if (tid < C) {
+            sh.cursor[tid] += sh.taken_c[tid];
+            atomicAdd(&sh.postings, (unsigned long long)sh.taken_c[tid]);
         }
         // ---- fold the window into the top-k, count matches, clear the table ----
         uint32_t matched_here = 0;
@@ -201,10 +225,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                 int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 uint64_t nk = shfl_u64(ck, src);
-                if (nk > kth) {
-                    top.insert(nk, lane);
-                    kth = top.at(k - 1);
-                }
+                if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }
         if (lane == 0 && matched_here) atomicAdd(&sh.total, (unsigned long long)matched_here);
@@ -212,26 +233,33 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     }
 
     // ---- merge the four waves' lists ----
-    if (wib > 0) sh.merge[wib - 1][lane] = top.key;
+    if (wib > 0) {
+#pragma unroll
+        for (int i = 0; i < KL; i++) merge[wib - 1][64 * i + lane] = top.mine(i);
+    }
     __syncthreads();
     if (wib == 0) {
         for (int w = 0; w < 3; w++)
             for (int i = 0; i < k; i++) {
-                uint64_t nk = sh.merge[w][i];
+                uint64_t nk = merge[w][i];
                 if (nk == NIDX_EMPTY_KEY) break;
-                if (nk > kth) {
-                    top.insert(nk, lane);
-                    kth = top.at(k - 1);
-                } else break;
+                if (nk > kth) kth = top.insert_kth(nk, k, lane);
+                else break;
             }
-        bool valid = top.key != NIDX_EMPTY_KEY && lane < k;
-        unsigned long long vm = __ballot(valid);
-        if (lane < k) {
-            a.out_doc[(size_t)blockIdx.x * k + lane] = valid ? rank_key_addr(top.key) : 0xffffffffu;
-            a.out_score[(size_t)blockIdx.x * k + lane] = valid ? rank_key_score(top.key) : 0.f;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KL; i++) {
+            const int e = 64 * i + lane;
+            const uint64_t key = top.mine(i);
+            const bool valid = key != NIDX_EMPTY_KEY && e < k;
+            cnt += (uint32_t)__popcll(__ballot(valid));
+            if (e < k) {
+                a.out_doc[(size_t)blockIdx.x * k + e] = valid ? rank_key_addr(key) : 0xffffffffu;
+                a.out_score[(size_t)blockIdx.x * k + e] = valid ? rank_key_score(key) : 0.f;
+            }
         }
         if (lane == 0) {
-            a.out_count[blockIdx.x] = (uint32_t)__popcll(vm);
+            a.out_count[blockIdx.x] = cnt;
             a.out_total[blockIdx.x] = sh.total;
             a.out_postings[blockIdx.x] = sh.postings;
         }
@@ -240,7 +268,8 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
 
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s) {
     if (n_work == 0) return hipSuccess;
-    hipLaunchKernelGGL(bm25_search_kernel, dim3(n_work), dim3(256), 0, s, a);
+    if (a.k > 64) hipLaunchKernelGGL(bm25_search_kernel<4>, dim3(n_work), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(bm25_search_kernel<1>, dim3(n_work), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -170,7 +170,7 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         if (out_postings) out_postings[q] = 0;
     }
     if (nq == 0) return NIDX_OK;
-    if (k > 64) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > 64 is not supported yet (got %u)", k);
+    if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > 256 is not supported (got %u)", k);
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics

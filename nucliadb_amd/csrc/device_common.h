@@ -93,6 +93,52 @@ struct WaveSortedList {
     __device__ inline uint64_t at(int rank) const { return shfl_u64(key, rank); }
 };
 
+// Up to 64*NL best entries: NL sorted lists chained (what falls off list i is inserted into list i+1).
+// `len` is the number of live entries; insert() with cap < 64*NL evicts the worst when full.
+template <int NL>
+struct WaveTopK {
+    WaveSortedList l[NL];
+    int len;
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < NL; i++) l[i].init();
+        len = 0;
+    }
+    __device__ inline uint64_t at(int rank) const {
+        uint64_t v = l[0].at(rank & 63);
+#pragma unroll
+        for (int i = 1; i < NL; i++) {
+            uint64_t t = l[i].at(rank & 63);
+            if ((rank >> 6) == i) v = t;
+        }
+        return v;
+    }
+    // entry of rank 64*i + lane, for every i (this lane's slice of the lists)
+    __device__ inline uint64_t mine(int i) const { return l[i].key; }
+    __device__ inline void insert(uint64_t nk, int cap, int lane) {
+        uint64_t d = l[0].insert(nk, lane);
+#pragma unroll
+        for (int i = 1; i < NL; i++)
+            if (d != NIDX_EMPTY_KEY) d = l[i].insert(d, lane);
+        len++;
+        if (len > cap) {  // drop rank `cap`
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                if ((cap >> 6) == i && lane == (cap & 63)) l[i].key = NIDX_EMPTY_KEY;
+            len = cap;
+        }
+    }
+    // insert while tracking only the k best (no len bookkeeping): returns the new k-th key
+    __device__ inline uint64_t insert_kth(uint64_t nk, int k, int lane) {
+        uint64_t d = l[0].insert(nk, lane);
+#pragma unroll
+        for (int i = 1; i < NL; i++)
+            if (d != NIDX_EMPTY_KEY) d = l[i].insert(d, lane);
+        return at(k - 1);
+    }
+    __device__ inline float worst_score() const { return rank_key_score(at(len - 1)); }
+};
+
 // ---- transposed multi-value butterfly -------------------------------------------------------
 // Reduces QT per-lane partial sums across the wave with one shuffle per PAIR of values at the
 // first log2(QT) levels.  Value v ends up (identically) in every lane l with query_of_lane(l) == v,

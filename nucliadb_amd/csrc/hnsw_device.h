@@ -27,7 +27,7 @@ struct SearchShared {
     uint32_t nb_addr[64];          // neighbours to evaluate
     float nb_ab[64];               // <x, q>
     float nb_xx[64];               // |x|^2
-    uint32_t eps[128];             // entry points for the next layer search
+    uint32_t eps[256];             // entry points for the next layer search
     int ctrl[8];                   // [0] continue, [1] n_new, [2] n_eps
 };
 
@@ -79,36 +79,6 @@ __device__ inline bool vis_insert(uint32_t *vis, uint32_t log2cap, uint32_t v) {
         h = (h + 1) & mask;
     }
 }
-
-// ---- result set: up to 64*EFL best entries, sorted, one per lane per list ----------------------
-template <int EFL>
-struct WaveTopK {
-    WaveSortedList l[EFL];
-    int len;
-    __device__ inline void init() {
-#pragma unroll
-        for (int i = 0; i < EFL; i++) l[i].init();
-        len = 0;
-    }
-    __device__ inline uint64_t at(int rank) const {
-        if (EFL == 1) return l[0].at(rank);
-        uint64_t a = l[0].at(rank & 63), b = l[EFL - 1].at(rank & 63);
-        return rank < 64 ? a : b;
-    }
-    // insert keeping at most `cap` entries (cap <= 64*EFL)
-    __device__ inline void insert(uint64_t nk, int cap, int lane) {
-        uint64_t d = l[0].insert(nk, lane);
-        if (EFL > 1 && d != NIDX_EMPTY_KEY) l[EFL - 1].insert(d, lane);
-        len++;
-        if (len > cap) {
-            // drop rank `cap`
-            if (cap < 64) { if (lane == cap) l[0].key = NIDX_EMPTY_KEY; }
-            else if (EFL > 1) { if (lane == cap - 64) l[EFL - 1].key = NIDX_EMPTY_KEY; }
-            len = cap;
-        }
-    }
-    __device__ inline float worst_score() const { return rank_key_score(at(len - 1)); }
-};
 
 // ---- candidate pool: unsorted array in LDS, arg-max pop --------------------------------------
 __device__ inline uint64_t wave_max_u64(uint64_t v) {

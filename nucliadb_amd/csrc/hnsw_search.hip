@@ -26,13 +26,13 @@ __device__ inline bool rows_equal(const SegDev &seg, uint32_t a, uint32_t b, int
     return __all(eq);
 }
 
-template <int NJ, int EVR, int MINW>
+template <int NJ, int EVR, int MINW, int EFL>
 __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
-    __shared__ uint32_t res_addr[64];
-    __shared__ float res_score[64];
+    __shared__ uint32_t res_addr[64 * EFL];
+    __shared__ float res_score[64 * EFL];
 
     const int lane = threadIdx.x & 63;
     const bool ctl = (threadIdx.x >> 6) == 0;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
 
     SearchCounters st = {0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_start = clock64();
-    WaveTopK<1> res;
+    WaveTopK<EFL> res;  // ef = max(k, EF_SEARCH) <= 64*EFL
     res.init();
 
     // ---- upper layers: k = 1 (search.rs:318-324) ----
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     }
     __syncthreads();
     for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
-        layer_search_block<NJ, 1, EVR>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
+        layer_search_block<NJ, EFL, EVR>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             uint64_t key = res.l[0].key;
             if (lane < res.len) sh.eps[lane] = rank_key_addr(key);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     }
     // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
     const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
-    layer_search_block<NJ, 1, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
+    layer_search_block<NJ, EFL, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
 
     // ---- closest_up_nodes (search.rs:188-240) ----
     // candidates = the ef neighbours; visited = exactly those; pop best, accept if it passes the
@@ -78,10 +78,13 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     uint32_t vis_count = 0;
     uint64_t dropped_best = NIDX_EMPTY_KEY;
     if (ctl) {
-        uint64_t key = res.l[0].key;
-        if (lane < res.len) {
-            vis_insert(vis, a.vis_log2, rank_key_addr(key));
-            sh.pool[lane] = key;
+#pragma unroll
+        for (int i = 0; i < EFL; i++) {
+            uint64_t key = res.mine(i);
+            if (64 * i + lane < res.len) {
+                vis_insert(vis, a.vis_log2, rank_key_addr(key));
+                sh.pool[64 * i + lane] = key;
+            }
         }
         pool_len = res.len;
         vis_count = res.len;
@@ -185,21 +188,23 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     // ---- filtered_result.sort_by(|a, b| b.1.total_cmp(&a.1)) — stable (search.rs:381) ----
     if (ctl) {
         st.visited = st.visited > vis_count ? st.visited : vis_count;
-        float s = lane < n_res ? res_score[lane] : 0.f;
-        uint32_t ad = lane < n_res ? res_addr[lane] : 0xffffffffu;
-        int32_t key = total_key(s);
-        int rank = 0;
-        for (int j = 0; j < n_res; j++) {
-            int32_t kj = __shfl(key, j, 64);
-            rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
-        }
-        if (lane < n_res) {
-            a.out_vec[(size_t)qi * k + rank] = ad;
-            a.out_score[(size_t)qi * k + rank] = s;
-        }
-        if (lane >= n_res && lane < k) {
-            a.out_vec[(size_t)qi * k + lane] = 0xffffffffu;
-            a.out_score[(size_t)qi * k + lane] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EFL; i++) {
+            const int e = 64 * i + lane;
+            if (e < n_res) {
+                const float s = res_score[e];
+                const int32_t key = total_key(s);
+                int rank = 0;
+                for (int j = 0; j < n_res; j++) {
+                    int32_t kj = total_key(res_score[j]);
+                    rank += (kj > key || (kj == key && j < e)) ? 1 : 0;
+                }
+                a.out_vec[(size_t)qi * k + rank] = res_addr[e];
+                a.out_score[(size_t)qi * k + rank] = s;
+            } else if (e < k) {
+                a.out_vec[(size_t)qi * k + e] = 0xffffffffu;
+                a.out_score[(size_t)qi * k + e] = 0.f;
+            }
         }
         if (lane == 0) {
             a.out_count[qi] = (uint32_t)n_res;
@@ -218,30 +223,38 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     }
 }
 
-template <int NJ, int EVR, int MINW>
+template <int NJ, int EVR, int MINW, int EFL>
 static hipError_t launch_v(const HnswSearchArgs &a, int waves, hipStream_t s) {
     size_t smem = sizeof(SearchShared) + ((size_t)4 << a.vis_log2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ, EVR, MINW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ, EVR, MINW, EFL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hnsw_search_kernel<NJ, EVR, MINW>), dim3(a.n_queries), dim3(64 * waves), smem, s, a);
+    hipLaunchKernelGGL((hnsw_search_kernel<NJ, EVR, MINW, EFL>), dim3(a.n_queries), dim3(64 * waves), smem, s, a);
     return hipGetLastError();
 }
 
 template <int NJ>
 static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
-    // rows in flight per wave / register budget: tuned per dimension class (DESIGN.md "HNSW kernel")
-    if (a.eval_rows == 2) return a.min_waves >= 4 ? launch_v<NJ, 2, 4>(a, waves, s) : launch_v<NJ, 2, 2>(a, waves, s);
-    return a.min_waves >= 4 ? launch_v<NJ, 4, 4>(a, waves, s) : launch_v<NJ, 4, 2>(a, waves, s);
+    const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
+    // large result pages (ef > 64) are the rare path: one shape each
+    if (ef > 128) return launch_v<NJ, 2, 2, 4>(a, waves, s);
+    if (ef > 64) return launch_v<NJ, 2, 2, 2>(a, waves, s);
+    // rows in flight per wave / register budget: tuned on MI355X (profiles/r01_tune_hnsw.txt)
+    if (a.eval_rows == 2) return a.min_waves >= 4 ? launch_v<NJ, 2, 4, 1>(a, waves, s) : launch_v<NJ, 2, 2, 1>(a, waves, s);
+    return a.min_waves >= 4 ? launch_v<NJ, 4, 4, 1>(a, waves, s) : launch_v<NJ, 4, 2, 1>(a, waves, s);
 }
 
 template <int NJ>
 static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s) {
-    return launch_v<NJ, 2, 1>(a, waves, s);
+    const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
+    if (ef > 128) return launch_v<NJ, 2, 1, 4>(a, waves, s);
+    if (ef > 64) return launch_v<NJ, 2, 1, 2>(a, waves, s);
+    return launch_v<NJ, 2, 1, 1>(a, waves, s);
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
+    if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
     int nj = (int)((a.seg.dp + 255u) / 256u);
     if (waves_per_query < 1) waves_per_query = 1;
     if (waves_per_query > 4) waves_per_query = 4;

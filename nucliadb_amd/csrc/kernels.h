@@ -17,11 +17,11 @@ struct ScanArgs {
     const uint32_t *para_of_vec;  // nullptr = identity
     int similarity;               // 0 dot, 1 cosine
     float min_score;
-    uint32_t k;                   // <= 64
+    uint32_t k;                   // <= 256
     uint32_t qt;                  // query tile (filled by launch_scan)
     uint64_t *partial;            // [n_queries][nblk][k] rank keys
 };
-uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp);
+uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp, uint32_t k);
 uint32_t scan_num_blocks(uint32_t n);
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s);
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
@@ -98,7 +98,7 @@ struct HnswSearchArgs {
     const float *queries;   // [n_queries][dp]
     uint32_t n_queries;
     const uint64_t *filter; // nullptr or bitset over paragraph addrs
-    uint32_t k;             // <= 64
+    uint32_t k;             // <= 256
     float min_score;
     int with_duplicates;
     uint32_t vis_log2;      // visited table = 1<<vis_log2 u32 slots in LDS
@@ -165,7 +165,7 @@ struct Bm25Args {
     const Bm25ClauseDev *clauses;
     const unsigned long long *clause_offsets;
     const Bm25AfterDev *after;  // nullptr or [n_queries]
-    uint32_t k;                 // <= 64
+    uint32_t k;                 // <= 256
     uint32_t segment_ord;
     uint32_t *out_doc;          // [n_work][k]
     float *out_score;           // [n_work][k]

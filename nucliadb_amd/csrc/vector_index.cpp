@@ -326,7 +326,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     if (out_method)
         for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
     if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
-    if (k > 64) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 64 is not supported yet (got %u)", k);
+    if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 256 is not supported (got %u)", k);
     if (p.method < 0 || p.method > 3) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
     // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
@@ -597,7 +597,7 @@ int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, ui
                                               uint32_t *d_out_count, uint32_t *d_stats, void *stream) {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
-    if (params->k == 0 || params->k > 64) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..64 (got %u)", params->k);
+    if (params->k == 0 || params->k > 256) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..256 (got %u)", params->k);
     if (idx->cfg.dimension & 3u)
         return fail(NIDX_ERR_UNSUPPORTED, "device-resident queries need a dimension that is a multiple of 4");
     std::lock_guard<std::mutex> lock(idx->mu);

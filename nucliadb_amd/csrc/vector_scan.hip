@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void pair_similarity_kernel(const float *__res
 // ---------------------------------------------------------------------------------------------
 // scan + per-block top-k
 // ---------------------------------------------------------------------------------------------
-template <int NJ, int QT>
+template <int NJ, int QT, int KL>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;  // wave in block
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         }
     }
 
-    WaveSortedList top[QT];
+    WaveTopK<KL> top[QT];  // k <= 64*KL
 #pragma unroll
     for (int q = 0; q < QT; q++) top[q].init();
     uint64_t thr = NIDX_EMPTY_KEY;  // k-th key of this lane's query (EMPTY while the list is short)
@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
             for (int qq = 0; qq < QT; qq++) {
                 if (qq == q) {
-                    top[qq].insert(nk, lane);
-                    uint64_t kth = top[qq].at(k - 1);
+                    uint64_t kth = top[qq].insert_kth(nk, k, lane);
                     if (myq == qq) thr = kth;
                 }
             }
@@ -181,31 +180,37 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     }
 
     // block merge through LDS: waves 1..3 publish, wave 0 folds them in
-    __shared__ uint64_t lds[3][QT][64];
+    __shared__ uint64_t lds[3][QT][64 * KL];
     if (wib > 0) {
 #pragma unroll
-        for (int q = 0; q < QT; q++) lds[wib - 1][q][lane] = top[q].key;
+        for (int q = 0; q < QT; q++)
+#pragma unroll
+            for (int i = 0; i < KL; i++) lds[wib - 1][q][64 * i + lane] = top[q].mine(i);
     }
     __syncthreads();
     if (wib == 0) {
 #pragma unroll
         for (int q = 0; q < QT; q++) {
+            uint64_t kth = top[q].at(k - 1);
             for (int w = 0; w < 3; w++) {
                 for (int i = 0; i < k; i++) {
                     uint64_t nk = lds[w][q][i];
                     if (nk == NIDX_EMPTY_KEY) break;
-                    uint64_t kth = top[q].at(k - 1);
-                    if (nk > kth) top[q].insert(nk, lane);
+                    if (nk > kth) kth = top[q].insert_kth(nk, k, lane);
                     else break;  // lists are sorted: the rest rank even lower
                 }
             }
-            if (q0 + q < a.n_queries && lane < k)
-                a.partial[((size_t)(q0 + q) * gridDim.x + blockIdx.x) * k + lane] = top[q].key;
+            if (q0 + q < a.n_queries) {
+#pragma unroll
+                for (int i = 0; i < KL; i++)
+                    if (64 * i + lane < k) a.partial[((size_t)(q0 + q) * gridDim.x + blockIdx.x) * k + 64 * i + lane] = top[q].mine(i);
+            }
         }
     }
 }
 
 // merge per-block lists: one block per query
+template <int KL>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ partial, uint32_t lists_per_query,
                                                          uint32_t k, uint32_t *__restrict__ out_vec,
                                                          float *__restrict__ out_score,
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     const uint32_t q = blockIdx.x;
     const uint64_t *src = partial + (size_t)q * lists_per_query * k;
     const uint32_t total = lists_per_query * k;
-    WaveSortedList top;
+    WaveTopK<KL> top;
     top.init();
     uint64_t kth = NIDX_EMPTY_KEY;
     for (uint32_t base = wib * 64; base < total; base += 256) {
@@ -226,32 +231,36 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
             int s = __ffsll((long long)m) - 1;
             m &= m - 1;
             uint64_t nk = shfl_u64(ck, s);
-            if (nk > kth) {
-                top.insert(nk, lane);
-                kth = top.at((int)k - 1);
-            }
+            if (nk > kth) kth = top.insert_kth(nk, (int)k, lane);
         }
     }
-    __shared__ uint64_t lds[3][64];
-    if (wib > 0) lds[wib - 1][lane] = top.key;
+    __shared__ uint64_t lds[3][64 * KL];
+    if (wib > 0) {
+#pragma unroll
+        for (int i = 0; i < KL; i++) lds[wib - 1][64 * i + lane] = top.mine(i);
+    }
     __syncthreads();
     if (wib == 0) {
         for (int w = 0; w < 3; w++)
             for (uint32_t i = 0; i < k; i++) {
                 uint64_t nk = lds[w][i];
                 if (nk == NIDX_EMPTY_KEY) break;
-                if (nk > kth) {
-                    top.insert(nk, lane);
-                    kth = top.at((int)k - 1);
-                } else break;
+                if (nk > kth) kth = top.insert_kth(nk, (int)k, lane);
+                else break;
             }
-        unsigned long long valid = __ballot(top.key != NIDX_EMPTY_KEY && lane < (int)k);
-        if (lane < (int)k) {
-            bool v = top.key != NIDX_EMPTY_KEY;
-            out_vec[(size_t)q * k + lane] = v ? rank_key_addr(top.key) : 0xffffffffu;
-            out_score[(size_t)q * k + lane] = v ? rank_key_score(top.key) : 0.f;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KL; i++) {
+            const uint32_t e = 64 * i + lane;
+            const uint64_t key = top.mine(i);
+            const bool v = key != NIDX_EMPTY_KEY && e < k;
+            cnt += (uint32_t)__popcll(__ballot(v));
+            if (e < k) {
+                out_vec[(size_t)q * k + e] = v ? rank_key_addr(key) : 0xffffffffu;
+                out_score[(size_t)q * k + e] = v ? rank_key_score(key) : 0.f;
+            }
         }
-        if (lane == 0) out_count[q] = (uint32_t)__popcll(valid);
+        if (lane == 0) out_count[q] = cnt;
     }
 }
 
@@ -260,21 +269,24 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
 // ---------------------------------------------------------------------------------------------
 template <int NJ, bool WIDE>
 static hipError_t launch_scan_nj(const ScanArgs &a, uint32_t nblk, hipStream_t s) {
-    if (a.qt == 1) {
-        hipLaunchKernelGGL((scan_topk_kernel<NJ, 1>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
+    if (a.k > 64) {  // large result pages: 4 chained lists per query, at most 4 queries per pass
+        if (a.qt == 1) hipLaunchKernelGGL((scan_topk_kernel<NJ, 1, 4>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((scan_topk_kernel<NJ, 4, 4>), dim3(nblk, (a.n_queries + 3) / 4), dim3(256), 0, s, a);
+    } else if (a.qt == 1) {
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, 1, 1>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
     } else if (a.qt == 4 || !WIDE) {
-        hipLaunchKernelGGL((scan_topk_kernel<NJ, 4>), dim3(nblk, (a.n_queries + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, 4, 1>), dim3(nblk, (a.n_queries + 3) / 4), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((scan_topk_kernel<NJ, (WIDE ? 8 : 4)>), dim3(nblk, (a.n_queries + 7) / 8), dim3(256), 0, s,
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, (WIDE ? 8 : 4), 1>), dim3(nblk, (a.n_queries + 7) / 8), dim3(256), 0, s,
                            a);
     }
     return hipGetLastError();
 }
 
-// queries per pass over the rows: 8 while the tile fits the register file (D <= 1024), else 4
-uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp) {
+// queries per pass over the rows: 8 while the tile fits the register file (D <= 1024, k <= 64), else 4
+uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp, uint32_t k) {
     if (n_queries == 1) return 1;
-    if (n_queries <= 4 || dp > 1024) return 4;
+    if (n_queries <= 4 || dp > 1024 || k > 64) return 4;
     return 8;
 }
 
@@ -286,7 +298,8 @@ uint32_t scan_num_blocks(uint32_t n) {
 }
 
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
-    a.qt = scan_query_tile(a.n_queries, a.dp);
+    if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
+    a.qt = scan_query_tile(a.n_queries, a.dp, a.k);
     int nj = (int)((a.dp + 255u) / 256u);
     if (nj <= 1) return launch_scan_nj<1, true>(a, nblk, s);
     if (nj <= 2) return launch_scan_nj<2, true>(a, nblk, s);
@@ -300,8 +313,12 @@ hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
 
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s) {
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
-                       out_score, out_count);
+    if (k > 64)
+        hipLaunchKernelGGL(merge_topk_kernel<4>, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
+                           out_score, out_count);
+    else
+        hipLaunchKernelGGL(merge_topk_kernel<1>, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
+                           out_score, out_count);
     return hipGetLastError();
 }
 

@@ -69,6 +69,7 @@ def test_or_queries_match_oracle(orc, corpus):
     compare(orc, seg, s, queries, 20)
     compare(orc, seg, s, queries, 1)
     compare(orc, seg, s, queries, 64)
+    compare(orc, seg, s, queries, 201)   # paragraph search asks for k+1 with result_per_page up to 200
     s.close()
 
 
