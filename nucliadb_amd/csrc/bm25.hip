@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     }
     __syncthreads();
     const uint32_t per = C > 0 ? (uint32_t)(BM25_MAX_DISTINCT / C) : 1u;
+    unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0;
+    const unsigned long long cy_t0 = clock64();
 
     WaveTopK<KL> top;  // k <= 64*KL
     top.init();
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         }
         __syncthreads();
         const uint32_t hi = sh.hi;
+        const unsigned long long cy_a = clock64();
         // ---- load phase: the window holds <= 2048 posting slots (slot g belongs to clause g / per);
         //      every thread fetches its 8 slots for ALL clauses up front, so a window costs three
         //      dependent memory round trips (doc id -> tf + fieldnorm gather) instead of three per clause
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             }
         }
         __syncthreads();  // taken_c zeroed
+        const unsigned long long cy_b = clock64();
         // ---- apply phase: clause by clause (barrier in between) so every doc's f32 sum is built in clause order
         for (int c = 0; c < C; c++) {
             const int occur = cl[c].occur;
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             sh.cursor[tid] += sh.taken_c[tid];
             atomicAdd(&sh.postings, (unsigned long long)sh.taken_c[tid]);
         }
+        const unsigned long long cy_c = clock64();
         // ---- fold the window into the top-k, count matches, clear the table ----
         uint32_t matched_here = 0;
         for (int base = wib * 64; base < BM25_TABLE; base += 256) {
@@ -230,6 +235,18 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         }
         if (lane == 0 && matched_here) atomicAdd(&sh.total, (unsigned long long)matched_here);
         __syncthreads();
+        cy_load += cy_b - cy_a;
+        cy_apply += cy_c - cy_b;
+        cy_fold += clock64() - cy_c;
+        n_win++;
+    }
+    if (a.dbg && tid == 0) {
+        atomicAdd(&a.dbg[0], cy_load);
+        atomicAdd(&a.dbg[1], cy_apply);
+        atomicAdd(&a.dbg[2], cy_fold);
+        atomicAdd(&a.dbg[3], clock64() - cy_t0);
+        atomicAdd(&a.dbg[4], n_win);
+        atomicAdd(&a.dbg[5], 1ull);
     }
 
     // ---- merge the four waves' lists ----

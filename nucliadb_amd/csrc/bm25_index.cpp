@@ -6,6 +6,7 @@
 // statistics are searcher-wide: N = sum of segment max_doc, n = sum of segment doc_freq,
 // avg = sum of tokens / N — and are not reduced by deletions.  Scoring itself is bm25.hip.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -245,6 +246,13 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         a.out_count = idx->s_count.as<uint32_t>();
         a.out_total = idx->s_total.as<unsigned long long>();
         a.out_postings = idx->s_postings.as<unsigned long long>();
+        a.dbg = nullptr;
+        DevBuf dbgbuf;
+        if (getenv("NIDX_GPU_BM25_DEBUG")) {
+            NIDX_HIP(dbgbuf.alloc(6 * 8));
+            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, 48, idx->stream));
+            a.dbg = dbgbuf.as<unsigned long long>();
+        }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
         NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
@@ -262,6 +270,12 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         float ms = 0.f;
         NIDX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
         idx->last_kernel_ms += ms;
+        if (a.dbg) {
+            unsigned long long d[6];
+            NIDX_HIP(hipMemcpy(d, a.dbg, 48, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu cycles/item: load=%llu apply=%llu fold=%llu total=%llu kernel_ms=%.3f\n", d[5], d[4],
+                    d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), ms);
+        }
         for (size_t w = 0; w < nw; w++) {
             const uint32_t q = work[w].query;
             if (out_total) out_total[q] += h_total[w];

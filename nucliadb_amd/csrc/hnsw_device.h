@@ -166,8 +166,13 @@ __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q
                 for (int j = 0; j < NJ; j++) row[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        // reduce width: next power of two >= the number of per-lane partial sums
+        constexpr int NV_COS = 2 * EVR <= 2 ? 2 : (2 * EVR <= 4 ? 4 : 8);
+        constexpr int NV_DOT = EVR <= 1 ? 1 : (EVR <= 2 ? 2 : 4);
         if (cosine) {
-            float v[2 * EVR];
+            float v[NV_COS];
+#pragma unroll
+            for (int i = 0; i < NV_COS; i++) v[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < EVR; i++) {
                 float ab = 0.f, xx = 0.f;
@@ -176,20 +181,22 @@ __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q
                     ab = fma4(row[i][j], q.qv[j], ab);
                     xx = fma4(row[i][j], row[i][j], xx);
                 }
-                v[i] = ab;
-                v[EVR + i] = xx;
+                v[2 * i] = ab;
+                v[2 * i + 1] = xx;
             }
-            float r = QReduce<2 * EVR>::run(v, lane);
-            int which = QReduce<2 * EVR>::query_of_lane(lane);
-            if ((lane & QReduce<2 * EVR>::group_mask()) == 0) {
-                int i = which % EVR;
-                if (base + i < n) {
-                    if (which < EVR) sh.nb_ab[base + i] = r;
+            float r = QReduce<NV_COS>::run(v, lane);
+            int which = QReduce<NV_COS>::query_of_lane(lane);
+            if ((lane & QReduce<NV_COS>::group_mask()) == 0) {
+                int i = which >> 1;
+                if (i < EVR && base + i < n) {
+                    if ((which & 1) == 0) sh.nb_ab[base + i] = r;
                     else sh.nb_xx[base + i] = r;
                 }
             }
         } else {
-            float v[EVR];
+            float v[NV_DOT];
+#pragma unroll
+            for (int i = 0; i < NV_DOT; i++) v[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < EVR; i++) {
                 float ab = 0.f;
@@ -197,9 +204,9 @@ __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q
                 for (int j = 0; j < NJ; j++) ab = fma4(row[i][j], q.qv[j], ab);
                 v[i] = ab;
             }
-            float r = QReduce<EVR>::run(v, lane);
-            int which = QReduce<EVR>::query_of_lane(lane);
-            if ((lane & QReduce<EVR>::group_mask()) == 0 && base + which < n) sh.nb_ab[base + which] = r;
+            float r = QReduce<NV_DOT>::run(v, lane);
+            int which = QReduce<NV_DOT>::query_of_lane(lane);
+            if ((lane & QReduce<NV_DOT>::group_mask()) == 0 && which < EVR && base + which < n) sh.nb_ab[base + which] = r;
         }
     }
 }

@@ -240,6 +240,7 @@ static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
     if (ef > 128) return launch_v<NJ, 2, 2, 4>(a, waves, s);
     if (ef > 64) return launch_v<NJ, 2, 2, 2>(a, waves, s);
     // rows in flight per wave / register budget: tuned on MI355X (profiles/r01_tune_hnsw.txt)
+    if (a.eval_rows == 3) return a.min_waves >= 4 ? launch_v<NJ, 3, 4, 1>(a, waves, s) : launch_v<NJ, 3, 2, 1>(a, waves, s);
     if (a.eval_rows == 2) return a.min_waves >= 4 ? launch_v<NJ, 2, 4, 1>(a, waves, s) : launch_v<NJ, 2, 2, 1>(a, waves, s);
     return a.min_waves >= 4 ? launch_v<NJ, 4, 4, 1>(a, waves, s) : launch_v<NJ, 4, 2, 1>(a, waves, s);
 }

@@ -172,6 +172,7 @@ struct Bm25Args {
     uint32_t *out_count;        // [n_work]
     unsigned long long *out_total;
     unsigned long long *out_postings;
+    unsigned long long *dbg;  // nullptr, or 6 counters: cycles load/apply/fold/total, windows, work items
 };
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s);
 

@@ -504,7 +504,7 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     idx->cfg = *config;
     // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels
     if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
-    if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) idx->eval_rows = atoi(e) == 2 ? 2 : 4;
+    if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) idx->eval_rows = std::max(2, std::min(4, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) idx->min_waves = atoi(e) >= 4 ? 4 : 2;
     if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
@@ -536,7 +536,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     std::lock_guard<std::mutex> lock(idx->mu);
     std::string n(name);
     if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
-    else if (n == "eval_rows") idx->eval_rows = value == 2 ? 2 : 4;
+    else if (n == "eval_rows") idx->eval_rows = std::max(2, std::min(4, (int)value));
     else if (n == "min_waves") idx->min_waves = value >= 4 ? 4 : 2;
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
