@@ -98,14 +98,16 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
     if (ctl && lane == 0 && st.flags) atomicOr(a.flags, st.flags);
 }
 
-// Wave-cooperative similarity of stored vector `c` (in registers) against 4 stored rows.
+// Similarities of up to 4 candidate rows (in registers) against up to 4 stored rows: 16 dot products
+// reduced with one transposed butterfly (WAVE64 order, bit-identical to a per-pair butterfly).
+// out[c][y] valid for c < nc, y < ny.
 template <int NJ>
-__device__ inline void sims4(const SegDev &seg, const float4 (&cv)[NJ], float c_norm2, const uint32_t (&ys)[4], int cnt,
-                             bool cosine, int lane, float (&out)[4]) {
+__device__ inline void sims4x4(const SegDev &seg, const float4 (&cv)[4][NJ], const float (&c_norm2)[4], int nc,
+                               const uint32_t (&ys)[4], int ny, bool cosine, int lane, float (&out)[4][4]) {
     float4 row[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (i < cnt) {
+        if (i < ny) {
             const float *r = seg.vectors + (size_t)ys[i] * seg.dp;
 #pragma unroll
             for (int j = 0; j < NJ; j++) row[i][j] = load_row_chunk(r, seg.dp, j, lane);
@@ -114,58 +116,109 @@ __device__ inline void sims4(const SegDev &seg, const float4 (&cv)[NJ], float c_
             for (int j = 0; j < NJ; j++) row[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float v[4];
+    float v[16];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float ab = 0.f;
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int j = 0; j < NJ; j++) ab = fma4(cv[j], row[i][j], ab);
-        v[i] = ab;
-    }
-    float r = QReduce<4>::run(v, lane);
-    // broadcast the four sums to every lane
+        for (int i = 0; i < 4; i++) {
+            float ab = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        // value i lives in lanes whose query_of_lane == i: lane (i&1)*16 + (i>>1)*32
-        int src = ((i >> 1) << 5) | ((i & 1) << 4);
-        float ab = __shfl(r, src, 64);
-        out[i] = (i < cnt) ? (cosine ? cosine_from_sums(ab, c_norm2, seg.norm2[ys[i]]) : ab) : 0.f;
-    }
+            for (int j = 0; j < NJ; j++) ab = fma4(cv[c][j], row[i][j], ab);
+            v[c * 4 + i] = ab;
+        }
+    float r = QReduce<16>::run(v, lane);
+    // value w lives in the 4-lane group whose query_of_lane == w: bits 5..2 of the lane, MSB first
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int w = c * 4 + i;
+            const int src = (((w >> 3) & 1) << 5) | (((w >> 2) & 1) << 4) | (((w >> 1) & 1) << 3) | ((w & 1) << 2);
+            float ab = __shfl(r, src, 64);
+            out[c][i] = (c < nc && i < ny) ? (cosine ? cosine_from_sums(ab, c_norm2[c], seg.norm2[ys[i]]) : ab) : 0.f;
+        }
 }
 
 // select_neighbours_heuristic (build.rs:57-95) for one wave.
-//   cand[0..n) in LDS: rank keys in the order the reference iterates them
+//   cand[0..n): rank keys in the order the reference iterates them
 //   out[0..) in LDS: selected rank keys.  Returns the count.
+// Candidates are examined four at a time: all four are compared with the set kept so far (the kept
+// rows are fetched once per group instead of once per candidate), then the group is resolved in
+// order, each survivor also being compared with the survivors before it in the group — the same
+// decisions, in the same order, as the one-by-one loop.
 template <int NJ>
 __device__ inline int select_neighbours_wave(const SegDev &seg, const uint64_t *cand, int n, int k, uint64_t *out,
                                              uint64_t *discard, bool cosine, int lane) {
     int n_res = 0, n_dis = 0;
-    for (int i = 0; i < n && n_res < k; i++) {
-        uint64_t ck = cand[i];
-        uint32_t c = rank_key_addr(ck);
-        float cs = rank_key_score(ck);
-        float4 cv[NJ];
+    for (int i0 = 0; i0 < n && n_res < k; i0 += 4) {
+        const int g = n - i0 < 4 ? n - i0 : 4;
+        uint64_t ck[4];
+        uint32_t caddr[4];
+        float cs[4], cn[4];
+        float4 cv[4][NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) cv[j] = load_row_chunk(seg.vectors + (size_t)c * seg.dp, seg.dp, j, lane);
-        float cn = cosine ? seg.norm2[c] : 0.f;
-        bool check = true;
-        for (int b = 0; b < n_res && check; b += 4) {
+        for (int t = 0; t < 4; t++) {
+            ck[t] = t < g ? cand[i0 + t] : 0ull;
+            caddr[t] = rank_key_addr(ck[t]);
+            cs[t] = rank_key_score(ck[t]);
+            cn[t] = (t < g && cosine) ? seg.norm2[caddr[t]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                cv[t][j] = t < g ? load_row_chunk(seg.vectors + (size_t)caddr[t] * seg.dp, seg.dp, j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        bool fail[4] = {false, false, false, false};
+        const int kept_before = n_res;
+        for (int b = 0; b < kept_before; b += 4) {
             uint32_t ys[4];
-            int cnt = n_res - b < 4 ? n_res - b : 4;
+            const int cnt = kept_before - b < 4 ? kept_before - b : 4;
 #pragma unroll
             for (int t = 0; t < 4; t++) ys[t] = t < cnt ? rank_key_addr(out[b + t]) : 0u;
-            float s[4];
-            sims4<NJ>(seg, cv, cn, ys, cnt, cosine, lane, s);
+            float s[4][4];
+            sims4x4<NJ>(seg, cv, cn, g, ys, cnt, cosine, lane, s);
+            bool all_failed = true;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (c < g && t < cnt && !(cs[c] > s[c][t])) fail[c] = true;  // needs sim(x,new) > sim(x,y) for all kept y
+                if (c < g && !fail[c]) all_failed = false;
+            }
+            if (all_failed) break;
+        }
+        // similarities inside the group (candidate vs earlier candidate of the group)
+        float sg[4][4];
+        {
+            uint32_t ys[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) ys[t] = caddr[t];
+            bool need = false;
+#pragma unroll
+            for (int c = 1; c < 4; c++)
+                if (c < g && !fail[c]) need = true;
+            if (need) sims4x4<NJ>(seg, cv, cn, g, ys, g, cosine, lane, sg);
+            else {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) sg[c][t] = 0.f;
+            }
+        }
+        bool kept[4] = {false, false, false, false};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c >= g || n_res >= k) continue;  // `if results.len() == k { break }` before looking at the candidate
+            bool check = !fail[c];
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                if (t < cnt && !(cs > s[t])) check = false;  // keep only if sim(x,new) > sim(x,y) for all kept y
-        }
-        if (check) {
-            if (lane == 0) out[n_res] = ck;
-            n_res++;
-        } else {
-            if (lane == 0) discard[n_dis] = ck;
-            n_dis++;
+                if (t < c && kept[t] && !(cs[c] > sg[c][t])) check = false;
+            if (check) {
+                kept[c] = true;
+                if (lane == 0) out[n_res] = ck[c];
+                n_res++;
+            } else {
+                if (lane == 0) discard[n_dis] = ck[c];
+                n_dis++;
+            }
         }
     }
     if (n_res < k && n_dis > 0) {
