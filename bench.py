@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bm25"], default="hnsw")
+    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25"], default="hnsw")
     p.add_argument("--n-docs", type=int, default=10_000_000, help="bm25: documents per shard")
     p.add_argument("--vocab", type=int, default=1_000_000)
     p.add_argument("--recall-queries", type=int, default=256)
@@ -117,7 +117,8 @@ def main():
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
     out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
     stats = torch.zeros((B, 8), dtype=torch.int32, device=dev)
-    method = {"hnsw": _lib.METHOD_HNSW, "scan": _lib.METHOD_BRUTE_FORCE, "mfma": _lib.METHOD_BRUTE_FORCE_MFMA}[a.workload]
+    method = {"hnsw": _lib.METHOD_HNSW, "scan": _lib.METHOD_BRUTE_FORCE, "mfma": _lib.METHOD_BRUTE_FORCE_MFMA,
+              "bf16": _lib.METHOD_BRUTE_FORCE_BF16}[a.workload]
     params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -193,7 +194,7 @@ def main():
 
     # ---- recall@k against the exact scan (oracle-verified kernel) on the same shard
     recall = None
-    if a.workload == "hnsw" and a.recall_queries > 0:
+    if a.workload in ("hnsw", "bf16") and a.recall_queries > 0:
         rq = min(a.recall_queries, B)
         search(qpool[0])
         torch.cuda.synchronize()
@@ -247,6 +248,11 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved_tf / 157.3, "traffic": None, "algorithmic_flops_per_launch": alg_flops,
                 "hbm_GBps_algorithmic": achieved, "kernel_ms": kernel_ms,
             } if a.workload == "mfma" else {
+                "kernel": "bf16_scan_kernel + merge_topk_kernel + rescore_select_kernel", "bound": "mfma", "achieved": achieved_tf,
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": None,
+                "algorithmic_flops_per_launch": alg_flops, "hbm_GBps_algorithmic_bf16": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9,
+                "hbm_frac": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kernel_ms,
+            } if a.workload == "bf16" else {
                 "kernel": "hnsw_search_kernel<3,2,4>" if a.workload == "hnsw" else "scan_topk_kernel (+ merge_topk_kernel)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

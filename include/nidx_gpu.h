@@ -113,8 +113,13 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
 
 /* NIDX_METHOD_BRUTE_FORCE_MFMA: the same exact scan as a dense GEMM on the f32 matrix cores (one
  * pass over the corpus per batch, k <= 16).  It sums in NIDX_ORDER_SERIAL_FMA, so its scores differ
- * from the other methods' (NIDX_ORDER_WAVE64) in the last bits: never chosen by AUTO. */
-enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2, NIDX_METHOD_BRUTE_FORCE_MFMA = 3 };
+ * from the other methods' (NIDX_ORDER_WAVE64) in the last bits: never chosen by AUTO.
+ * NIDX_METHOD_BRUTE_FORCE_BF16: the batched fallback on the bf16 matrix cores (k <= 32): candidates are
+ * ranked with bf16 operands, the 32 best per query are re-scored from the f32 rows in
+ * NIDX_ORDER_WAVE64 — returned scores are exact, the id set is the exact top-k up to bf16 ranking
+ * error (recall measured in DESIGN.md).  Explicit only. */
+enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2, NIDX_METHOD_BRUTE_FORCE_MFMA = 3,
+       NIDX_METHOD_BRUTE_FORCE_BF16 = 4 };
 
 /* The request fields the hot path reads (nidx_vector/src/request_types.rs:19-35). */
 typedef struct {

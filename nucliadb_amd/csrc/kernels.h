@@ -50,6 +50,39 @@ hipError_t launch_serial_norms(const float *rows, uint32_t n, uint32_t dp, float
 uint32_t mfma_scan_stripes(uint32_t n, uint32_t n_queries);
 hipError_t launch_mfma_scan(const MfmaScanArgs &a, uint32_t stripes, hipStream_t s);
 
+// ---- bf16-MFMA brute-force fallback with exact re-scoring (vector_bf16.hip) ----
+#define NIDX_BF16_CAND 32  /* approximate candidates kept per query before the exact re-score */
+struct Bf16ScanArgs {
+    const unsigned short *vectors16;  // [n][dp16] bf16
+    const float *norm2;               // [n] |x|^2 (cosine) or nullptr
+    uint32_t n, dp16;
+    const unsigned short *queries16;  // [n_queries][dp16] bf16
+    const float *q_norm2;             // [n_queries]
+    uint32_t n_queries;
+    const uint64_t *alive, *filter;
+    const uint32_t *para_of_vec;
+    int similarity;
+    uint64_t *partial;                // [n_queries][stripes][NIDX_BF16_CAND]
+};
+struct RescoreArgs {
+    const float *vectors;   // [n][dp] f32
+    const float *queries;   // [n_queries][dp] f32
+    uint32_t dp, n_queries;
+    const uint32_t *cand_vec;    // [n_queries][n_cand_max]
+    const uint32_t *cand_count;  // [n_queries]
+    uint32_t n_cand_max;
+    int similarity;
+    float min_score;
+    uint32_t k;             // <= 64
+    uint32_t *out_vec;
+    float *out_score;
+    uint32_t *out_count;
+};
+hipError_t launch_to_bf16(const float *in, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s);
+uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries);
+hipError_t launch_bf16_scan(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s);
+hipError_t launch_rescore_select(const RescoreArgs &a, hipStream_t s);
+
 // ---- HNSW graph in HBM ----
 // layer 0: fixed 256-byte records [deg, e0..e59, pad x3]; upper layers: 128-byte records
 // [deg, e0..e29, pad]; a node with top layer L >= 1 owns L consecutive upper records starting at

@@ -134,7 +134,7 @@ SegDev VectorSegment::seg_dev(int similarity) const {
 }
 
 uint64_t VectorSegment::bytes() const {
-    return vectors.bytes + norm2.bytes + norm2_serial.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
+    return vectors.bytes + norm2.bytes + norm2_serial.bytes + vectors16.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
            g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes;
 }
 
@@ -272,6 +272,55 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         NIDX_HIP(launch_merge_topk(m.partial, nq, stripes, k, d_out_vec, d_out_score, d_out_count, st));
         return NIDX_OK;
     }
+    if (method == NIDX_METHOD_BRUTE_FORCE_BF16) {
+        if (k > NIDX_BF16_CAND) return fail(NIDX_ERR_UNSUPPORTED, "the bf16 fallback re-scores %d candidates per query (got k=%u)", NIDX_BF16_CAND, k);
+        if (!seg.vectors16.p) {
+            seg.dp16 = (seg.dp + 63u) & ~63u;
+            NIDX_HIP(seg.vectors16.alloc((size_t)seg.n * seg.dp16 * 2));
+            NIDX_HIP(launch_to_bf16(seg.vectors.as<float>(), seg.n, seg.dp, seg.dp16, seg.vectors16.as<unsigned short>(), st));
+        }
+        NIDX_HIP(scratch_q16.reserve((size_t)nq * seg.dp16 * 2));
+        NIDX_HIP(launch_to_bf16(d_queries, nq, seg.dp, seg.dp16, scratch_q16.as<unsigned short>(), st));
+        NIDX_HIP(scratch_qnorm.reserve((size_t)nq * 4));
+        NIDX_HIP(launch_row_norms(d_queries, nq, seg.dp, scratch_qnorm.as<float>(), st));
+        const uint32_t stripes = bf16_scan_stripes(seg.n, nq);
+        NIDX_HIP(scratch_partial.reserve((size_t)nq * stripes * NIDX_BF16_CAND * 8));
+        NIDX_HIP(scratch_cand_vec.reserve((size_t)nq * NIDX_BF16_CAND * 4));
+        NIDX_HIP(scratch_cand_score.reserve((size_t)nq * NIDX_BF16_CAND * 4));
+        NIDX_HIP(scratch_cand_count.reserve((size_t)nq * 4));
+        Bf16ScanArgs b;
+        b.vectors16 = seg.vectors16.as<unsigned short>();
+        b.norm2 = seg.norm2.as<float>();
+        b.n = seg.n;
+        b.dp16 = seg.dp16;
+        b.queries16 = scratch_q16.as<unsigned short>();
+        b.q_norm2 = scratch_qnorm.as<float>();
+        b.n_queries = nq;
+        b.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
+        b.filter = d_filter;
+        b.para_of_vec = seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>();
+        b.similarity = cfg.similarity;
+        b.partial = scratch_partial.as<uint64_t>();
+        NIDX_HIP(launch_bf16_scan(b, stripes, st));
+        NIDX_HIP(launch_merge_topk(b.partial, nq, stripes, NIDX_BF16_CAND, scratch_cand_vec.as<uint32_t>(),
+                                   scratch_cand_score.as<float>(), scratch_cand_count.as<uint32_t>(), st));
+        RescoreArgs r;
+        r.vectors = seg.vectors.as<float>();
+        r.queries = d_queries;
+        r.dp = seg.dp;
+        r.n_queries = nq;
+        r.cand_vec = scratch_cand_vec.as<uint32_t>();
+        r.cand_count = scratch_cand_count.as<uint32_t>();
+        r.n_cand_max = NIDX_BF16_CAND;
+        r.similarity = cfg.similarity;
+        r.min_score = min_score;
+        r.k = k;
+        r.out_vec = d_out_vec;
+        r.out_score = d_out_score;
+        r.out_count = d_out_count;
+        NIDX_HIP(launch_rescore_select(r, st));
+        return NIDX_OK;
+    }
     // brute force
     uint32_t nblk = scan_num_blocks(seg.n);
     size_t need = (size_t)nq * nblk * k * 8;
@@ -327,7 +376,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
     if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
     if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 256 is not supported (got %u)", k);
-    if (p.method < 0 || p.method > 3) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
+    if (p.method < 0 || p.method > 4) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
     // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
     const uint32_t dp = (d + 3u) & ~3u;

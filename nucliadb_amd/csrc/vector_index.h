@@ -18,6 +18,8 @@ struct VectorSegment {
     DevBuf vectors;      // [n][dp] f32, zero padded
     DevBuf norm2;        // [n] f32, WAVE64-order |x|^2
     DevBuf norm2_serial; // [n] f32, SERIAL_FMA-order |x|^2 (filled on the first MFMA scan)
+    DevBuf vectors16;    // [n][dp16] bf16 copy (filled on the first bf16 scan)
+    uint32_t dp16 = 0;
     DevBuf para_of_vec;  // [n] u32 (absent when identity)
     DevBuf alive;        // bitset over paragraph addrs (absent when all alive)
     bool identity_para = true, all_alive = true;
@@ -52,7 +54,7 @@ struct VectorIndex {
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
-    DevBuf scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
+    DevBuf scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats;
 
     int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,

@@ -290,3 +290,41 @@ def test_mfma_and_wave64_scans_agree_within_1e5():
     assert np.array_equal(c1, c2)
     assert np.max(np.abs(s1 - s2)) < 1e-5
     assert np.mean(v1 == v2) > 0.99
+
+
+# ---- batched fallback on the bf16 matrix cores with exact re-scoring (BASELINE configs[4]) -------------------
+@pytest.mark.parametrize("sim", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [(500, 64, 7, 10), (30000, 768, 130, 10), (9000, 1024, 40, 16), (2000, 100, 5, 32)])
+def test_bf16_fallback_scores_exact_and_recall(orc, sim, n, d, nq, k):
+    """Returned scores must be bit-identical to the exact (WAVE64) similarity of the returned ids and
+    sorted by (score desc, address asc); the id set may differ from the exact top-k only through bf16
+    ranking error, which on these data must stay below 1 %."""
+    rng = np.random.default_rng(n + d)
+    x = unit_rows(rng, n, d)
+    q = unit_rows(rng, nq, d)
+    v_ex, s_ex, c_ex = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE)
+    v_bf, s_bf, c_bf = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16)
+    assert np.array_equal(c_ex, c_bf)
+    hits = 0
+    for i in range(nq):
+        hits += len(set(v_ex[i, : c_ex[i]].tolist()) & set(v_bf[i, : c_bf[i]].tolist()))
+        for j in range(min(c_bf[i], 4)):
+            want = orc.similarity(x[v_bf[i, j]], q[i], sim)
+            assert bits([s_bf[i, j]])[0] == bits([want])[0]
+        keys = [(-float(s_bf[i, j]), int(v_bf[i, j])) for j in range(c_bf[i])]
+        assert keys == sorted(keys)
+    assert hits / float(c_ex.sum()) >= 0.99
+
+
+def test_bf16_fallback_filter_and_min_score(orc):
+    rng = np.random.default_rng(21)
+    n, d, k = 8000, 128, 10
+    x = unit_rows(rng, n, d)
+    q = unit_rows(rng, 9, d)
+    filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.2)[0].tolist())
+    v_ex, s_ex, c_ex = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE, filter_bits=filt, min_score=0.15)
+    v_bf, s_bf, c_bf = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, filter_bits=filt, min_score=0.15)
+    assert np.array_equal(c_ex, c_bf)
+    for i in range(len(q)):
+        assert np.array_equal(v_ex[i, : c_ex[i]], v_bf[i, : c_bf[i]])
+        assert np.array_equal(bits(s_ex[i, : c_ex[i]]), bits(s_bf[i, : c_bf[i]]))
