@@ -22,8 +22,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define BF_BM 128
 #define BF_BN 128
-#define BF_BK 64                 /* bf16 elements per chunk = 128 B per row */
-#define BF_PITCH_B 144           /* bytes per LDS row: 128 + 16 pad => b128 reads hit 16 distinct slots */
+#define BF_BK 32                 /* bf16 elements per chunk = 64 B per row */
+#define BF_PITCH_B 80            /* bytes per LDS row: 64 + 16 pad => b128 reads hit 16 distinct slots (5i mod 16) */
 #define BF_KP NIDX_BF16_CAND     /* candidates kept per query */
 
 struct Bf16Shared {
@@ -55,24 +55,24 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
 }
 
 __device__ inline void bf_stage_load(const unsigned short *base, uint32_t n_rows, uint32_t row0, uint32_t dp16, uint32_t k0,
-                                     int tid, uint4 (&regs)[4]) {
+                                     int tid, uint4 (&regs)[2]) {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        uint32_t row = row0 + (uint32_t)(tid >> 3) + 32u * it;
-        uint32_t k = k0 + 8u * (uint32_t)(tid & 7);
+    for (int it = 0; it < 2; it++) {
+        uint32_t row = row0 + (uint32_t)(tid >> 2) + 64u * it;
+        uint32_t k = k0 + 8u * (uint32_t)(tid & 3);
         if (row < n_rows && k < dp16) regs[it] = *reinterpret_cast<const uint4 *>(base + (size_t)row * dp16 + k);
         else regs[it] = make_uint4(0, 0, 0, 0);
     }
 }
-__device__ inline void bf_stage_store(unsigned char (&tile)[BF_BM][BF_PITCH_B], int tid, const uint4 (&regs)[4]) {
+__device__ inline void bf_stage_store(unsigned char (&tile)[BF_BM][BF_PITCH_B], int tid, const uint4 (&regs)[2]) {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        int row = (tid >> 3) + 32 * it;
-        *reinterpret_cast<uint4 *>(&tile[row][16 * (tid & 7)]) = regs[it];
+    for (int it = 0; it < 2; it++) {
+        int row = (tid >> 2) + 64 * it;
+        *reinterpret_cast<uint4 *>(&tile[row][16 * (tid & 3)]) = regs[it];
     }
 }
 
-__global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
+__global__ __launch_bounds__(256, 2) void bf16_scan_kernel(Bf16ScanArgs a) {
     __shared__ Bf16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-        uint4 gq[4], gx[4], nq_[4], nx_[4];
+        uint4 gq[2], gx[2], nq_[2], nx_[2];
         bf_stage_load(a.queries16, a.n_queries, q0, a.dp16, 0, tid, gq);
         bf_stage_load(a.vectors16, a.n, r0, a.dp16, 0, tid, gx);
         bf_stage_store(sh.q[0], tid, gq);
@@ -127,15 +127,15 @@ __global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
                 bf_stage_load(a.queries16, a.n_queries, q0, a.dp16, (kc + 2) * BF_BK, tid, nq_);
                 bf_stage_load(a.vectors16, a.n, r0, a.dp16, (kc + 2) * BF_BK, tid, nx_);
             }
-            // 4 k-steps of 16: lane (li, half) supplies k = 16*s + 8*half .. +7 of its row
-            bf16x8 av[4];
+            // BF_BK/16 k-steps of 16: lane (li, half) supplies k = 16*s + 8*half .. +7 of its row
+            bf16x8 av[BF_BK / 16];
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int s = 0; s < BF_BK / 16; s++)
                 av[s] = *reinterpret_cast<const bf16x8 *>(&sh.q[st][32 * wave + li][32 * s + 16 * half]);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < BF_BK / 16; s++) {
                     bf16x8 bv = *reinterpret_cast<const bf16x8 *>(&sh.x[st][32 * t + li][32 * s + 16 * half]);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], bv, acc[t], 0, 0, 0);
                 }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
                 bf_stage_store(sh.x[st ^ 1], tid, gx);
             }
 #pragma unroll
-            for (int it = 0; it < 4; it++) {
+            for (int it = 0; it < 2; it++) {
                 gq[it] = nq_[it];
                 gx[it] = nx_[it];
             }
@@ -153,20 +153,34 @@ __global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
         }
 
         // ---- epilogue: approximate scores -> per-query candidate lists ----
+        // per-lane copies of the 16 queries' 1/|q| and current thresholds (a stale threshold only lets a
+        // few extra candidates through to the exact key test below)
+        float qinv[16], thr[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int qi = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+            qinv[r] = sh.q_rinv[qi];
+            thr[r] = sh.thr_score[qi];
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int j = 32 * t + li;
             const uint32_t row = r0 + (uint32_t)j;
             const bool row_ok = sh.row_ok[j] != 0;
             const float rinv = sh.row_rinv[j];
+            uint32_t mask = 0;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int qi = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float approx = acc[t][r] * rinv * sh.q_rinv[qi];
-                const bool pre = row_ok && approx > sh.thr_score[qi];
-                unsigned long long m = __ballot(pre);
+                const float approx = acc[t][r] * rinv * qinv[r];
+                mask |= (row_ok && approx > thr[r]) ? (1u << r) : 0u;
+            }
+            if (!__ballot(mask != 0)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                unsigned long long m = __ballot((mask >> r) & 1u);
                 if (!m) continue;
-                const uint64_t key = rank_key(approx, row);
+                const int qi = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const uint64_t key = rank_key(acc[t][r] * rinv * qinv[r], row);
                 while (m) {
                     int src = __ffsll((long long)m) - 1;
                     m &= m - 1;
@@ -183,6 +197,8 @@ __global__ __launch_bounds__(256, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
                         sh.thr_score[sq] = rank_key_score(kth);
                     }
                 }
+                // refresh this lane's view of the thresholds it just may have raised
+                thr[r] = sh.thr_score[qi];
             }
         }
     }
@@ -249,7 +265,7 @@ hipError_t launch_to_bf16(const float *in, uint32_t n, uint32_t dp, uint32_t dp1
 
 uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries) {
     uint32_t tiles = (n + BF_BN - 1) / BF_BN, qb = (n_queries + BF_BM - 1) / BF_BM;
-    uint32_t s = 256 / (qb ? qb : 1);  // one workgroup per CU
+    uint32_t s = 512 / (qb ? qb : 1);  // two workgroups per CU
     if (s < 1) s = 1;
     if (s > tiles) s = tiles;
     return s ? s : 1;
