@@ -26,7 +26,7 @@ NIDX_ERR_INEXACT = -9
 SIMILARITY_DOT, SIMILARITY_COSINE = 0, 1
 METHOD_AUTO, METHOD_HNSW, METHOD_BRUTE_FORCE, METHOD_BRUTE_FORCE_MFMA, METHOD_BRUTE_FORCE_BF16 = 0, 1, 2, 3, 4
 ORDER_WAVE64, ORDER_SERIAL_FMA = 3, 1
-OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT = 0, 1, 2
+OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT, OCCUR_SHOULD_GROUP = 0, 1, 2, 3
 TF_FREQ, TF_BASIC, CONST_SCORE = 0, 1, 2
 
 

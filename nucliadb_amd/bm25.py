@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 
-Occur = type("Occur", (), {"Should": _lib.OCCUR_SHOULD, "Must": _lib.OCCUR_MUST, "MustNot": _lib.OCCUR_MUST_NOT})
+Occur = type("Occur", (), {"Should": _lib.OCCUR_SHOULD, "Must": _lib.OCCUR_MUST, "MustNot": _lib.OCCUR_MUST_NOT, "ShouldGroup": _lib.OCCUR_SHOULD_GROUP})
 TfMode = type("TfMode", (), {"Freq": _lib.TF_FREQ, "Basic": _lib.TF_BASIC, "Const": _lib.CONST_SCORE})
 
 

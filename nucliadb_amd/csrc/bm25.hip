@@ -29,7 +29,7 @@ namespace nidx {
 struct Bm25Shared {
     uint32_t key[BM25_TABLE];
     float acc[BM25_TABLE];
-    uint16_t flags[BM25_TABLE];  // bit0 should-hit, bit1 excluded, bits 8.. must count
+    uint16_t flags[BM25_TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
     float tf_cache[256];
     unsigned long long cursor[BM25_MAX_CLAUSES];
     unsigned long long end[BM25_MAX_CLAUSES];
@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         sh.flags[i] = 0;
     }
     if (tid < 256) sh.tf_cache[tid] = a.tf_cache[tid];
-    int n_must = 0;
-    for (int c = 0; c < C; c++) n_must += cl[c].occur == 1 ? 1 : 0;
+    int n_must = 0, n_group = 0;
+    for (int c = 0; c < C; c++) {
+        n_must += cl[c].occur == 1 ? 1 : 0;
+        n_group += cl[c].occur == 3 ? 1 : 0;
+    }
     if (work.n_slices <= 1) {
         if (tid < C) {
             sh.cursor[tid] = a.term_offsets[cl[tid].term];
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                 } else {
                     sh.acc[h] = sh.acc[h] + p_score[m];
                     if (occur == 1) sh.flags[h] += 0x100;
+                    else if (occur == 3) sh.flags[h] |= 4;
                     else sh.flags[h] |= 1;
                 }
             }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             uint64_t ck = NIDX_EMPTY_KEY;
             if (d != BM25_EMPTY) {
                 uint16_t f = sh.flags[i];
-                ok = !(f & 2) && (int)(f >> 8) == n_must && (n_must > 0 || (f & 1));
+                ok = !(f & 2) && (int)(f >> 8) == n_must && (n_group == 0 || (f & 4)) && (n_must > 0 || n_group > 0 || (f & 1));
                 if (ok && a.alive) ok = bit_test(a.alive, d);
                 if (ok) {
                     float s = sh.acc[i];

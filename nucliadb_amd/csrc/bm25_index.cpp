@@ -184,7 +184,7 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
     for (uint64_t c = 0; c < n_clauses; c++) {
         const nidx_gpu_bm25_clause_t &cl = clauses[c];
         if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
-        if (cl.occur < 0 || cl.occur > 2 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        if (cl.occur < 0 || cl.occur > 3 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
         uint64_t df = 0;
         for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
         float w = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;

@@ -171,7 +171,7 @@ hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
 #define BM25_MAX_CLAUSES 64
 struct Bm25ClauseDev {
     uint32_t term;
-    int occur;     // 0 should, 1 must, 2 must-not
+    int occur;     // 0 should, 1 must, 2 must-not, 3 should of a required group
     int mode;      // 0 stored tf, 1 tf == 1, 2 constant score
     float weight;  // idf * (1 + K1) * boost, or the constant score
 };

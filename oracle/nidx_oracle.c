@@ -1081,6 +1081,8 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
     uint8_t *should_hit = (uint8_t *)calloc(n ? n : 1, 1);
     uint16_t *must_cnt = (uint16_t *)calloc(n ? n : 1, sizeof(uint16_t));
     uint8_t *excluded = (uint8_t *)calloc(n ? n : 1, 1);
+    uint8_t *group_hit = (uint8_t *)calloc(n ? n : 1, 1);
+    size_t n_group = 0;
     float cache[256];
     float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
     orc_bm25_tf_cache(avg, cache);
@@ -1093,6 +1095,7 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
         if (cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(e - b, idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
+        if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
         for (uint64_t i = b; i < e; i++) {
             uint32_t d = idx->doc_ids[i];
             if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
@@ -1103,7 +1106,9 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
                 s = weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
             }
             acc[d] = acc[d] + s;
-            if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++; else should_hit[d] = 1;
+            if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
+            else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+            else should_hit[d] = 1;
         }
     }
     bm_hit_t *top = (bm_hit_t *)malloc((k + 1) * sizeof(bm_hit_t));
@@ -1112,7 +1117,8 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
     for (uint32_t d = 0; d < n; d++) {
         if (excluded[d]) continue;
         if (must_cnt[d] != n_must) continue;
-        if (n_must == 0 && !should_hit[d]) continue;
+        if (n_group > 0 && !group_hit[d]) continue;
+        if (n_must == 0 && n_group == 0 && !should_hit[d]) continue;
         if (idx->alive && !bit_get(idx->alive, d)) continue;
         total++;
         uint64_t docaddr = ((uint64_t)segment_ord << 32) | d;
@@ -1128,7 +1134,7 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
     (void)n_should;
     for (size_t i = 0; i < n_top; i++) { out_docaddr[i] = top[i].docaddr; out_score[i] = top[i].score; }
     if (total_out) *total_out = total;
-    free(top); free(acc); free(should_hit); free(must_cnt); free(excluded);
+    free(top); free(acc); free(should_hit); free(must_cnt); free(excluded); free(group_hit);
     return (int)n_top;
 }
 

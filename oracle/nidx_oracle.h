@@ -150,7 +150,10 @@ typedef struct {
     const uint64_t *alive;         /* bitset or NULL */
 } orc_bm25_index;
 
-enum { ORC_OCCUR_SHOULD = 0, ORC_OCCUR_MUST = 1, ORC_OCCUR_MUST_NOT = 2 };
+/* ORC_OCCUR_SHOULD_GROUP: a Should clause of a nested Must(BooleanQuery[Should..]) — the shape of
+ * nidx_paragraph's keyword query under its Must filters (search_query.rs:185-243): scored like Should,
+ * and a document must match at least one clause of the group. */
+enum { ORC_OCCUR_SHOULD = 0, ORC_OCCUR_MUST = 1, ORC_OCCUR_MUST_NOT = 2, ORC_OCCUR_SHOULD_GROUP = 3 };
 enum { ORC_TF_FREQ = 0, ORC_TF_BASIC = 1, ORC_CONST_SCORE = 2 };
 
 typedef struct {

@@ -17,7 +17,7 @@ _SO = os.path.join(_HERE, "_build", "libnidx_oracle.so")
 
 SIM_DOT, SIM_COSINE = 0, 1
 ORDER_SERIAL, ORDER_SERIAL_FMA, ORDER_HASWELL, ORDER_WAVE64 = 0, 1, 2, 3
-OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT = 0, 1, 2
+OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT, OCCUR_SHOULD_GROUP = 0, 1, 2, 3
 TF_FREQ, TF_BASIC, CONST_SCORE = 0, 1, 2
 
 
