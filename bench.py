@@ -192,6 +192,21 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- the same batch through the host-buffer entry point (queries in / hits out over PCIe): reported
+    # beside `value`, never as `value`
+    host_qps = None
+    if a.workload == "hnsw":
+        qh = qpool[0].cpu().numpy()
+        hv, hs_, hc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
+        hp = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+        reps = 5
+        for i in range(reps + 1):
+            if i == 1:
+                t1 = time.perf_counter()
+            _lib.check(L.nidx_gpu_vector_search(h, qh.ctypes.data, B, C.byref(hp), None, None, None, hv.ctypes.data,
+                                                hs_.ctypes.data, hc.ctypes.data, None))
+        host_qps = B * reps / (time.perf_counter() - t1)
+
     # ---- recall@k against the exact scan (oracle-verified kernel) on the same shard
     recall = None
     if a.workload in ("hnsw", "bf16") and a.recall_queries > 0:
@@ -241,7 +256,7 @@ def main():
                 "clustered_vectors": a.clustered_n if recall_clustered is not None else None,
                 "clustered_build_s": clustered_build_s, "hnsw_build_s": build_s, "open_s": open_s,
                 "distance_evals_per_query": float(np.mean(evals_q)), "expansions_per_query": float(np.mean(exp_q)),
-                "kernel_flags": flags, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world,
+                "kernel_flags": flags, "host_buffer_queries_per_s": host_qps, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world,
             },
             "roofline": ({
                 "kernel": "mfma_scan_kernel (+ merge_topk_kernel)", "bound": "mfma", "achieved": achieved_tf, "peak": 157.3,
