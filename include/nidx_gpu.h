@@ -151,6 +151,43 @@ int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *
                                    uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
                                    uint32_t *out_count, int32_t *out_method);
 
+/* ---- filter formulas evaluated on the device -------------------------------------------------------
+ * Replaces ParagraphInvertedIndexes::filter (inverted_index/paragraph.rs:124-184).  A segment's label and
+ * field-key posting lists (what index.map holds behind label.fst / field.fst) are uploaded once; a
+ * request's Formula arrives as a postfix program whose atoms name posting lists by id (the host keeps the
+ * string -> list-id lookup the FSTs do). */
+typedef struct {
+    uint32_t n_lists;
+    const uint64_t *list_offsets; /* [n_lists+1] into paragraph_ids */
+    const uint32_t *paragraph_ids; /* paragraph addresses */
+} nidx_gpu_filter_index_t;
+int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_t segment,
+                                         const nidx_gpu_filter_index_t *lists);
+
+enum {
+    NIDX_FILTER_PUSH_LISTS = 0, /* push the union of posting lists lists[a .. b) (an AtomClause) */
+    NIDX_FILTER_AND = 1,        /* pop 2, push their intersection */
+    NIDX_FILTER_OR = 2,         /* pop 2, push their union */
+    NIDX_FILTER_NOT = 3,        /* complement the top (BooleanOperator::Not = complement of the AND of its operands) */
+    NIDX_FILTER_PUSH_ALL = 4,
+    NIDX_FILTER_PUSH_NONE = 5
+};
+typedef struct { int32_t op; uint32_t a, b; } nidx_gpu_filter_op_t;
+typedef struct {
+    const nidx_gpu_filter_op_t *ops; /* NULL / 0 => no filter on this segment */
+    uint32_t n_ops;
+    const uint32_t *lists;           /* list-id table referenced by PUSH_LISTS */
+    uint32_t n_lists;
+} nidx_gpu_filter_program_t;
+
+/* nidx_gpu_vector_search_dim with the filter of every segment given as a program (segment_programs:
+ * NULL or [n_segments]).  out_matching: NULL or [n_segments] = |filter ∩ alive| per segment. */
+int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                                        uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
+                                        const nidx_gpu_filter_program_t *segment_programs, uint32_t *out_segment,
+                                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                                        uint32_t *out_count, int32_t *out_method, uint64_t *out_matching);
+
 /* OpenSegment::search on ONE segment with everything resident in HBM (segment.rs:477-567):
  * device pointers, asynchronous on `stream` (a hipStream_t; NULL = the null stream).
  *   d_queries [n_queries][dimension] f32 (already normalised if the index wants that)

@@ -62,6 +62,21 @@ class VectorSegmentC(C.Structure):
     ]
 
 
+class FilterIndexC(C.Structure):
+    _fields_ = [("n_lists", C.c_uint32), ("list_offsets", C.c_void_p), ("paragraph_ids", C.c_void_p)]
+
+
+class FilterOpC(C.Structure):
+    _fields_ = [("op", C.c_int32), ("a", C.c_uint32), ("b", C.c_uint32)]
+
+
+class FilterProgramC(C.Structure):
+    _fields_ = [("ops", C.c_void_p), ("n_ops", C.c_uint32), ("lists", C.c_void_p), ("n_lists", C.c_uint32)]
+
+
+FILTER_PUSH_LISTS, FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PUSH_ALL, FILTER_PUSH_NONE = 0, 1, 2, 3, 4, 5
+
+
 class VectorSearchParamsC(C.Structure):
     _fields_ = [
         ("k", C.c_uint32),
@@ -108,6 +123,10 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_vector_search_dim": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(VectorSearchParamsC),
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_vector_set_filter_index": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(FilterIndexC)]),
+    "nidx_gpu_vector_search_filtered": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(VectorSearchParamsC),
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]),
     "nidx_gpu_vector_segment_search_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                                           C.POINTER(VectorSearchParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -167,6 +167,15 @@ struct BuildBatch {
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
 hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
 
+// ---- filter formulas on the device (filter.hip) ----
+hipError_t launch_bitset_fill(uint64_t *out, uint32_t n_words, uint32_t n_bits, int ones, hipStream_t s);
+hipError_t launch_bitset_scatter(const unsigned long long *list_offsets, const uint32_t *ids, const uint32_t *lists,
+                                 uint32_t n_lists, uint32_t n_bits, uint64_t *out, hipStream_t s);
+hipError_t launch_bitset_binop(uint64_t *a, const uint64_t *b, uint32_t n_words, int op, hipStream_t s);
+hipError_t launch_bitset_not(uint64_t *a, uint32_t n_words, uint32_t n_bits, hipStream_t s);
+hipError_t launch_bitset_and_count(const uint64_t *a, const uint64_t *alive, uint64_t *out, uint32_t n_words,
+                                   unsigned long long *count, hipStream_t s);
+
 // ---- BM25 (bm25.hip) ----
 #define BM25_MAX_CLAUSES 64
 struct Bm25ClauseDev {

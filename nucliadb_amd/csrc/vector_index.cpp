@@ -135,7 +135,7 @@ SegDev VectorSegment::seg_dev(int similarity) const {
 
 uint64_t VectorSegment::bytes() const {
     return vectors.bytes + norm2.bytes + norm2_serial.bytes + vectors16.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
-           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes;
+           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes + f_offsets.bytes + f_ids.bytes;
 }
 
 static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_vector_segment_t &in, VectorSegment &seg,
@@ -364,9 +364,81 @@ int32_t VectorIndex::rows_equal_host(uint32_t sa, uint32_t va, uint32_t sb, uint
     return NIDX_OK;
 }
 
+// ParagraphInvertedIndexes::filter on the device (filter.hip): postfix program over posting-list unions.
+int32_t VectorIndex::eval_filter_program(uint32_t si, const nidx_gpu_filter_program_t &prog, uint64_t &matching) {
+    VectorSegment &seg = segs[si];
+    const uint32_t n_bits = seg.n_paragraphs, words = (n_bits + 63) / 64;
+    matching = 0;
+    // validate + stack depth
+    int depth = 0, max_depth = 0;
+    for (uint32_t i = 0; i < prog.n_ops; i++) {
+        const nidx_gpu_filter_op_t &op = prog.ops[i];
+        switch (op.op) {
+            case NIDX_FILTER_PUSH_LISTS:
+                if (op.a > op.b || op.b > prog.n_lists) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: list range out of bounds");
+                if (op.b > op.a && !seg.f_n_lists) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no filter index", si);
+                for (uint32_t l = op.a; l < op.b; l++)
+                    if (prog.lists[l] >= seg.f_n_lists) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: unknown posting list %u", prog.lists[l]);
+                depth++;
+                break;
+            case NIDX_FILTER_PUSH_ALL:
+            case NIDX_FILTER_PUSH_NONE: depth++; break;
+            case NIDX_FILTER_AND:
+            case NIDX_FILTER_OR:
+                if (depth < 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: stack underflow");
+                depth--;
+                break;
+            case NIDX_FILTER_NOT:
+                if (depth < 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: stack underflow");
+                break;
+            default: return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: unknown op %d", op.op);
+        }
+        max_depth = std::max(max_depth, depth);
+    }
+    if (depth != 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program must leave exactly one bitset (leaves %d)", depth);
+    NIDX_HIP(scratch_fstack.reserve((size_t)max_depth * std::max<uint32_t>(words, 1) * 8));
+    NIDX_HIP(scratch_filter.reserve((size_t)std::max<uint32_t>(words, 1) * 8));
+    NIDX_HIP(scratch_fcount.reserve(8));
+    if (prog.n_lists) {
+        NIDX_HIP(scratch_flists.reserve((size_t)prog.n_lists * 4));
+        NIDX_HIP(hipMemcpyAsync(scratch_flists.p, prog.lists, (size_t)prog.n_lists * 4, hipMemcpyHostToDevice, stream));
+    }
+    NIDX_HIP(hipMemsetAsync(scratch_fcount.p, 0, 8, stream));
+    uint64_t *stack = scratch_fstack.as<uint64_t>();
+    auto slot = [&](int d) { return stack + (size_t)d * words; };
+    depth = 0;
+    for (uint32_t i = 0; i < prog.n_ops; i++) {
+        const nidx_gpu_filter_op_t &op = prog.ops[i];
+        switch (op.op) {
+            case NIDX_FILTER_PUSH_LISTS:
+                NIDX_HIP(launch_bitset_fill(slot(depth), words, n_bits, 0, stream));
+                NIDX_HIP(launch_bitset_scatter(seg.f_offsets.as<unsigned long long>(), seg.f_ids.as<uint32_t>(),
+                                               scratch_flists.as<uint32_t>() + op.a, op.b - op.a, n_bits, slot(depth), stream));
+                depth++;
+                break;
+            case NIDX_FILTER_PUSH_ALL: NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 1, stream)); break;
+            case NIDX_FILTER_PUSH_NONE: NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 0, stream)); break;
+            case NIDX_FILTER_AND:
+            case NIDX_FILTER_OR:
+                NIDX_HIP(launch_bitset_binop(slot(depth - 2), slot(depth - 1), words, op.op == NIDX_FILTER_AND ? 0 : 1, stream));
+                depth--;
+                break;
+            case NIDX_FILTER_NOT: NIDX_HIP(launch_bitset_not(slot(depth - 1), words, n_bits, stream)); break;
+        }
+    }
+    NIDX_HIP(launch_bitset_and_count(slot(0), seg.all_alive ? nullptr : seg.alive.as<uint64_t>(), scratch_filter.as<uint64_t>(),
+                                     words, scratch_fcount.as<unsigned long long>(), stream));
+    unsigned long long c = 0;
+    NIDX_HIP(hipMemcpyAsync(&c, scratch_fcount.p, 8, hipMemcpyDeviceToHost, stream));
+    NIDX_HIP(hipStreamSynchronize(stream));
+    matching = c;
+    return NIDX_OK;
+}
+
 int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
-                                 const uint64_t *const *segment_filters, uint32_t *out_segment, uint32_t *out_paragraph,
-                                 uint32_t *out_vector, float *out_score, uint32_t *out_count, int32_t *out_method) {
+                                 const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
+                                 uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                                 uint32_t *out_count, int32_t *out_method, uint64_t *out_matching) {
     std::lock_guard<std::mutex> lock(mu);
     NIDX_HIP(hipSetDevice(device));
     const uint32_t k = p.k;
@@ -398,8 +470,14 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     for (size_t s = 0; s < S; s++) {
         VectorSegment &seg = segs[s];
         const uint64_t *filt = segment_filters ? segment_filters[s] : nullptr;
+        const bool has_prog = programs && programs[s].ops && programs[s].n_ops;
         // matching = |filter ∩ alive| (segment.rs:516-531)
         uint64_t matching = filt ? popcount_and(seg.alive_host.data(), filt, seg.n_paragraphs) : seg.alive_count;
+        if (has_prog) {
+            int32_t rc = eval_filter_program((uint32_t)s, programs[s], matching);
+            if (rc != NIDX_OK) return rc;
+        }
+        if (out_matching) out_matching[s] = matching;
         hc[s].assign(nq, 0);
         if (matching == 0 || seg.n == 0) continue;
         int method = p.method;
@@ -410,7 +488,9 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
             return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %zu has no HNSW graph", s);
         if (out_method) out_method[s] = method;
         const uint64_t *d_filter = nullptr;
-        if (filt) {
+        if (has_prog) {
+            d_filter = scratch_filter.as<uint64_t>();
+        } else if (filt) {
             size_t bytes = (size_t)((seg.n_paragraphs + 63) / 64) * 8;
             NIDX_HIP(scratch_filter.reserve(bytes));
             NIDX_HIP(hipMemcpyAsync(scratch_filter.p, filt, bytes, hipMemcpyHostToDevice, stream));
@@ -622,8 +702,8 @@ int32_t nidx_gpu_vector_search(nidx_gpu_vector_index_t *index, const float *quer
                                uint32_t *out_count, int32_t *out_method) {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
-    return idx->search_host(queries, n_queries, *params, segment_filters, out_segment, out_paragraph, out_vector,
-                            out_score, out_count, out_method);
+    return idx->search_host(queries, n_queries, *params, segment_filters, nullptr, out_segment, out_paragraph, out_vector,
+                            out_score, out_count, out_method, nullptr);
 }
 
 int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
@@ -638,6 +718,40 @@ int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *
                     query_dimension);
     return nidx_gpu_vector_search(index, queries, n_queries, params, segment_filters, out_segment, out_paragraph,
                                   out_vector, out_score, out_count, out_method);
+}
+
+int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_t segment, const nidx_gpu_filter_index_t *lists) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !lists || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    if (lists->n_lists && !lists->list_offsets) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL list_offsets");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    VectorSegment &seg = idx->segs[segment];
+    const uint64_t n_ids = lists->n_lists ? lists->list_offsets[lists->n_lists] : 0;
+    if (n_ids && !lists->paragraph_ids) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL paragraph_ids");
+    for (uint64_t i = 0; i < n_ids; i++)
+        if (lists->paragraph_ids[i] >= seg.n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "posting %llu out of range", (unsigned long long)i);
+    NIDX_HIP(seg.f_offsets.alloc((size_t)(lists->n_lists + 1) * 8));
+    NIDX_HIP(seg.f_ids.alloc(std::max<size_t>(n_ids, 1) * 4));
+    if (lists->n_lists) NIDX_HIP(hipMemcpy(seg.f_offsets.p, lists->list_offsets, (size_t)(lists->n_lists + 1) * 8, hipMemcpyHostToDevice));
+    if (n_ids) NIDX_HIP(hipMemcpy(seg.f_ids.p, lists->paragraph_ids, n_ids * 4, hipMemcpyHostToDevice));
+    seg.f_n_lists = lists->n_lists;
+    seg.f_n_ids = n_ids;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
+                                        uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
+                                        const nidx_gpu_filter_program_t *segment_programs, uint32_t *out_segment,
+                                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count,
+                                        int32_t *out_method, uint64_t *out_matching) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (query_dimension != idx->cfg.dimension)
+        return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "Inconsistent dimensions. Index=%u Vector=%u", idx->cfg.dimension,
+                    query_dimension);
+    return idx->search_host(queries, n_queries, *params, nullptr, segment_programs, out_segment, out_paragraph, out_vector,
+                            out_score, out_count, out_method, out_matching);
 }
 
 int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,

@@ -27,6 +27,10 @@ struct VectorSegment {
     std::vector<uint64_t> alive_host;  // always present
     uint64_t alive_count = 0;
     std::vector<uint64_t> key_ids;     // Fssc identity of each paragraph (optional)
+    // label / field-key posting lists for device-side filter formulas (optional)
+    DevBuf f_offsets, f_ids;
+    uint32_t f_n_lists = 0;
+    uint64_t f_n_ids = 0;
     // HNSW graph
     bool has_graph = false;
     DevBuf g_l0, g_upper_base, g_upper;  // kernels.h GraphDev geometry
@@ -54,7 +58,7 @@ struct VectorIndex {
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
-    DevBuf scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
+    DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats;
 
     int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
@@ -63,8 +67,11 @@ struct VectorIndex {
                                   hipStream_t st);
     int32_t rows_equal_host(uint32_t sa, uint32_t va, uint32_t sb, uint32_t vb, bool &eq);
     int32_t search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
-                        const uint64_t *const *segment_filters, uint32_t *out_segment, uint32_t *out_paragraph,
-                        uint32_t *out_vector, float *out_score, uint32_t *out_count, int32_t *out_method);
+                        const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
+                        uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                        uint32_t *out_count, int32_t *out_method, uint64_t *out_matching);
+    // evaluates `prog` for segment s into scratch_filter (already intersected with alive); returns |filter ∩ alive|
+    int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed);
 };
 

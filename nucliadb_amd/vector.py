@@ -179,19 +179,70 @@ class VectorSegment:
         for i, ls in enumerate(labels):
             for lab in ls:
                 self._label_index.setdefault(lab, []).append(i)
+        # posting lists as the reference's inverted indexes key them (inverted_index/paragraph.rs:63-103):
+        #   labels:  labels_key(l) = l[1:] + "/"   (prefix-searchable: a label matches its children)
+        #   fields:  FieldKey "uuid/type/name" of the paragraph key
+        lists: dict = {}
+        for i, ls in enumerate(labels):
+            for lab in ls:
+                lists.setdefault("L:" + lab[1:] + "/", []).append(i)
+        for i, k in enumerate(self._norm_keys):
+            parts = k.split("/")
+            if len(parts) >= 3:
+                lists.setdefault("F:" + "/".join(parts[:3]), []).append(i)
+        self.list_keys = sorted(lists)
+        self.list_id = {k: j for j, k in enumerate(self.list_keys)}
+        self.list_offsets = np.zeros(len(self.list_keys) + 1, dtype=np.uint64)
+        for j, k in enumerate(self.list_keys):
+            self.list_offsets[j + 1] = self.list_offsets[j] + len(lists[k])
+        self.list_ids = np.array([i for k in self.list_keys for i in lists[k]], dtype=np.uint32)
+
+    def lists_for(self, expr) -> List[int]:
+        """The string -> posting-list lookup the FSTs do (label.fst prefix search, field.fst lookups)."""
+        if isinstance(expr, Literal):
+            p = "L:" + expr.label[1:] + "/"
+            return [self.list_id[k] for k in self.list_keys if k.startswith(p)]
+        out = []
+        for pre in expr.prefixes:  # _KeyPrefixSet: "{uuid_simple}{field_id}" or "{uuid_simple}"
+            key = "F:" + pre
+            out += [self.list_id[k] for k in self.list_keys if k == key or k.startswith(key + "/")]
+        return sorted(set(out))
+
+    def compile(self, expr):
+        """BooleanExpression -> postfix program for nidx_gpu_vector_search_filtered."""
+        ops, lists = [], []
+
+        def emit(e):
+            if isinstance(e, (Literal, _KeyPrefixSet)):
+                ids = self.lists_for(e)
+                ops.append((_lib.FILTER_PUSH_LISTS, len(lists), len(lists) + len(ids)))
+                lists.extend(ids)
+            elif isinstance(e, Not):
+                emit(e.operand)
+                ops.append((_lib.FILTER_NOT, 0, 0))
+            elif isinstance(e, (And, Or)):
+                if not e.operands:
+                    ops.append((_lib.FILTER_PUSH_ALL if isinstance(e, And) else _lib.FILTER_PUSH_NONE, 0, 0))
+                    return
+                emit(e.operands[0])
+                for o in e.operands[1:]:
+                    emit(o)
+                    ops.append((_lib.FILTER_AND if isinstance(e, And) else _lib.FILTER_OR, 0, 0))
+            else:
+                raise TypeError(f"unknown expression {e!r}")
+
+        emit(expr)
+        return ops, lists
 
     # ParagraphInvertedIndexes::filter (inverted_index/paragraph.rs:124-184) on the host
     def _eval(self, expr) -> np.ndarray:
         n = self.records
-        if isinstance(expr, Literal):
+        if isinstance(expr, (Literal, _KeyPrefixSet)):
+            # an atom is the union of the posting lists the FST lookup returns (label: prefix search at a
+            # path boundary; field keys: the field, or every field of the resource)
             m = np.zeros(n, dtype=bool)
-            m[self._label_index.get(expr.label, [])] = True
-            return m
-        if isinstance(expr, _KeyPrefixSet):
-            m = np.zeros(n, dtype=bool)
-            for i, k in enumerate(self._norm_keys):
-                if any(k.startswith(p) for p in expr.prefixes):
-                    m[i] = True
+            for j in self.lists_for(expr):
+                m[self.list_ids[int(self.list_offsets[j]): int(self.list_offsets[j + 1])]] = True
             return m
         if isinstance(expr, Not):
             return ~self._eval(expr.operand)
@@ -315,6 +366,10 @@ class VectorSearcher:
             self._segments.append(seg)
         cfg = config.to_c()
         _lib.check(_lib.lib().nidx_gpu_vector_open(C.byref(cfg), c_segs, len(ordered), C.byref(self._handle)))
+        for i, seg in enumerate(self._segments):
+            if len(seg.list_keys):
+                fi = _lib.FilterIndexC(len(seg.list_keys), seg.list_offsets.ctypes.data, seg.list_ids.ctypes.data if len(seg.list_ids) else None)
+                _lib.check(_lib.lib().nidx_gpu_vector_set_filter_index(self._handle, i, C.byref(fi)))
         self._keep = []  # everything was copied to HBM / host vectors by open
         return self
 
@@ -363,8 +418,10 @@ class VectorSearcher:
         return Or(clauses) if request.filter_operator == FilterOperator.Or else And(clauses)
 
     def search_batch(self, request: VectorSearchRequest, queries: np.ndarray, prefilter: PrefilterResult = None,
-                     method: int = _lib.METHOD_AUTO):
-        """Batched form of search(): `queries` [B][D].  Returns (segment, paragraph, vector, score, count)."""
+                     method: int = _lib.METHOD_AUTO, device_filter: bool = True):
+        """Batched form of search(): `queries` [B][D].  Returns (segment, paragraph, vector, score, count).
+        device_filter=True sends the formula as a program evaluated on the GPU (filter.hip); False builds the
+        bitsets with numpy and uploads them (kept for cross-checking the two routes)."""
         prefilter = prefilter or PrefilterResult.all()
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2:
@@ -373,19 +430,6 @@ class VectorSearcher:
         k = max(0, int(request.result_per_page))
         S = len(self._segments)
         formula = self._formula(request, prefilter)
-        filt_arrays, filt_ptrs = [], (C.c_void_p * max(1, S))()
-        for s, seg in enumerate(self._segments):
-            # segment tag filter (searcher.rs:272-277): a non-matching segment is skipped = empty filter
-            skip = request.segment_filtering_formula is not None and not _segment_matches(request.segment_filtering_formula, seg.tags)
-            if skip:
-                bits = _bitset(np.zeros(seg.records, dtype=bool))
-            elif formula is not None:
-                bits = _bitset(seg._eval(formula))
-            else:
-                bits = None
-            filt_arrays.append(bits)
-            filt_ptrs[s] = bits.ctypes.data if bits is not None else None
-        any_filter = any(b is not None for b in filt_arrays)
         kk = max(1, k)
         out_seg = np.zeros((B, kk), dtype=np.uint32)
         out_par = np.zeros((B, kk), dtype=np.uint32)
@@ -393,20 +437,54 @@ class VectorSearcher:
         out_score = np.zeros((B, kk), dtype=np.float32)
         out_count = np.zeros(B, dtype=np.uint32)
         out_method = np.zeros(max(1, S), dtype=np.int32)
+        out_matching = np.zeros(max(1, S), dtype=np.uint64)
         params = _lib.VectorSearchParamsC(k, float(request.min_score), int(request.with_duplicates), method)
-        rc = _lib.lib().nidx_gpu_vector_search_dim(
-            self._handle, queries.ctypes.data, B, D, C.byref(params), filt_ptrs if any_filter else None,
-            out_seg.ctypes.data, out_par.ctypes.data, out_vec.ctypes.data, out_score.ctypes.data,
-            out_count.ctypes.data, out_method.ctypes.data)
+        skips = [request.segment_filtering_formula is not None and not _segment_matches(request.segment_filtering_formula, seg.tags)
+                 for seg in self._segments]  # segment tag filter (searcher.rs:272-277): a non-matching segment is skipped
+        if device_filter:
+            progs = (_lib.FilterProgramC * max(1, S))()
+            keep = []
+            for s, seg in enumerate(self._segments):
+                if skips[s]:
+                    ops, lists = [(_lib.FILTER_PUSH_NONE, 0, 0)], []
+                elif formula is not None:
+                    ops, lists = seg.compile(formula)
+                else:
+                    continue
+                c_ops = (_lib.FilterOpC * len(ops))(*[_lib.FilterOpC(*o) for o in ops])
+                c_lists = np.array(lists, dtype=np.uint32)
+                keep += [c_ops, c_lists]
+                progs[s] = _lib.FilterProgramC(C.addressof(c_ops), len(ops), c_lists.ctypes.data if len(lists) else None, len(lists))
+            rc = _lib.lib().nidx_gpu_vector_search_filtered(
+                self._handle, queries.ctypes.data, B, D, C.byref(params), progs if keep else None,
+                out_seg.ctypes.data, out_par.ctypes.data, out_vec.ctypes.data, out_score.ctypes.data,
+                out_count.ctypes.data, out_method.ctypes.data, out_matching.ctypes.data)
+        else:
+            filt_arrays, filt_ptrs = [], (C.c_void_p * max(1, S))()
+            for s, seg in enumerate(self._segments):
+                if skips[s]:
+                    bits = _bitset(np.zeros(seg.records, dtype=bool))
+                elif formula is not None:
+                    bits = _bitset(seg._eval(formula))
+                else:
+                    bits = None
+                filt_arrays.append(bits)
+                filt_ptrs[s] = bits.ctypes.data if bits is not None else None
+            any_filter = any(b is not None for b in filt_arrays)
+            rc = _lib.lib().nidx_gpu_vector_search_dim(
+                self._handle, queries.ctypes.data, B, D, C.byref(params), filt_ptrs if any_filter else None,
+                out_seg.ctypes.data, out_par.ctypes.data, out_vec.ctypes.data, out_score.ctypes.data,
+                out_count.ctypes.data, out_method.ctypes.data)
         _lib.check(rc)
         self.last_methods = out_method[:S].tolist()
+        self.last_matching = out_matching[:S].tolist()
         return out_seg, out_par, out_vec, out_score, out_count
 
     def search(self, request: VectorSearchRequest, prefilter: PrefilterResult = None,
-               method: int = _lib.METHOD_AUTO) -> VectorSearchResponse:
+               method: int = _lib.METHOD_AUTO, device_filter: bool = True) -> VectorSearchResponse:
         prefilter = prefilter or PrefilterResult.all()
         q = np.asarray(request.vector, dtype=np.float32).reshape(1, -1)
-        seg, par, _vec, score, count = self.search_batch(request, q, prefilter, method)
+        seg, par, _vec, score, count = self.search_batch(request, q, prefilter, method, device_filter)
         docs = []
         for i in range(int(count[0])):
             s, p = int(seg[0, i]), int(par[0, i])

@@ -77,7 +77,8 @@ def test_deletions():
 def test_filtered_search():
     """test_basic_search.rs:218-400: boolean label formulas + prefilter AND/OR."""
     config = VectorConfig.for_paragraphs(4)
-    work = [(["0", "8"]), (["1", "9"]), (["2", "8"]), (["3", "9"])]
+    L = lambda i: f"/l/labelset/label_{i}"  # noqa: E731  (test_basic_search.rs:232-241)
+    work = [[L(i), L((i % 2) + 8)] for i in range(4)]
     rids, segs = [], []
     for i, labels in enumerate(work):
         rid, elems = _resource(4, labels)
@@ -90,16 +91,18 @@ def test_filtered_search():
         return {d.doc_id.split("/")[0] for d in searcher.search(req, prefilter).documents}
 
     assert search() == set(rids)
-    assert search(Literal("0")) == {rids[0]}
-    assert search(Literal("8")) == {rids[0], rids[2]}
-    assert search(And([Literal("8"), Literal("2")])) == {rids[2]}
-    assert search(Or([Literal("0"), Literal("3")])) == {rids[0], rids[3]}
-    assert search(Not(Literal("9"))) == {rids[0], rids[2]}
-    assert search(And([Literal("8"), Not(Literal("0"))])) == {rids[2]}
+    assert search(Literal(L(0))) == {rids[0]}
+    assert search(Literal(L(8))) == {rids[0], rids[2]}
+    assert search(And([Literal(L(8)), Literal(L(2))])) == {rids[2]}
+    assert search(Or([Literal(L(0)), Literal(L(3))])) == {rids[0], rids[3]}
+    assert search(Not(Literal(L(9)))) == {rids[0], rids[2]}
+    assert search(And([Literal(L(8)), Not(Literal(L(0)))])) == {rids[2]}
+    assert search(Literal("/l/labelset")) == set(rids)          # label.fst prefix search: a parent matches its children
+    assert search(Literal("/l/labelset/label")) == set()        # ...but only at a path boundary
     some = PrefilterResult.some([FieldId(uuid.UUID(rids[1]), "/a/title"), FieldId(uuid.UUID(rids[2]), None)])
     assert search(prefilter=some) == {rids[1], rids[2]}
-    assert search(Literal("8"), some) == {rids[2]}
-    assert search(Literal("0"), some, FilterOperator.Or) == {rids[0], rids[1], rids[2]}
+    assert search(Literal(L(8)), some) == {rids[2]}
+    assert search(Literal(L(0)), some, FilterOperator.Or) == {rids[0], rids[1], rids[2]}
     wrong_field = PrefilterResult.some([FieldId(uuid.UUID(rids[1]), "/a/other")])
     assert search(prefilter=wrong_field) == set()
 
@@ -150,3 +153,51 @@ def test_metadata_and_labels_round_trip():
     docs = searcher.search(VectorSearchRequest(vector=sentence(2, 4), result_per_page=1, min_score=-1.0), PrefilterResult.All).documents
     assert docs[0].doc_id.endswith("0-2") and docs[0].labels == ["l2"] and docs[0].metadata == bytes([2, 3])
     assert searcher.space_usage() > 0
+
+
+def test_device_filter_programs_match_host_bitsets():
+    """Random label / key-prefix formulas: the postfix program evaluated on the GPU (filter.hip) and the
+    numpy bitset route must select the same paragraphs, report the same matching count and route alike."""
+    rng = np.random.default_rng(3)
+    d, n = 16, 700
+    config = VectorConfig.for_paragraphs(d)
+    rids = [str(uuid.uuid4()) for _ in range(40)]
+    labels_pool = ["/l/a", "/l/a/x", "/l/b", "/l/c", "/e/person/ann", "/e/person", "/t/z"]
+    elems = []
+    for i in range(n):
+        rid = rids[int(rng.integers(0, len(rids)))]
+        field = ["a/title", "t/body", "f/file"][int(rng.integers(0, 3))]
+        labs = [l for l in labels_pool if rng.random() < 0.25]
+        v = rng.normal(size=d).astype(np.float32)
+        elems.append(Elem(f"{rid}/{field}/{i}-{i + 5}", v.tolist(), labels=labs))
+    segs = [(segment_create(elems[:400], config), 1), (segment_create(elems[400:], config), 2)]
+    searcher = VectorSearcher.open(config, segs)
+    q = rng.normal(size=(3, d)).astype(np.float32)
+
+    def rand_expr(depth=0):
+        r = rng.random()
+        if depth > 2 or r < 0.4:
+            return Literal(labels_pool[int(rng.integers(0, len(labels_pool)))])
+        if r < 0.55:
+            return Not(rand_expr(depth + 1))
+        ops = [rand_expr(depth + 1) for _ in range(int(rng.integers(1, 4)))]
+        return And(ops) if r < 0.8 else Or(ops)
+
+    for trial in range(40):
+        formula = rand_expr() if trial % 5 else None
+        pre = PrefilterResult.All
+        if trial % 3 == 0:
+            pre = PrefilterResult.some([FieldId(uuid.UUID(rids[int(rng.integers(0, 40))]), None if rng.random() < 0.5 else "/a/title")
+                                        for _ in range(int(rng.integers(1, 6)))])
+        op = FilterOperator.Or if trial % 4 == 0 else FilterOperator.And
+        req = VectorSearchRequest(result_per_page=10, min_score=-10.0, with_duplicates=True, filtering_formula=formula, filter_operator=op)
+        a = searcher.search_batch(req, q, pre, device_filter=True)
+        methods_dev, matching_dev = list(searcher.last_methods), list(searcher.last_matching)
+        b = searcher.search_batch(req, q, pre, device_filter=False)
+        assert methods_dev == searcher.last_methods
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), trial
+        if formula is not None or pre.kind == "some":
+            want = [int((seg._eval(searcher._formula(req, pre))).sum()) for seg in searcher._segments]
+            assert matching_dev == want, (trial, matching_dev, want)
+    searcher.close()
