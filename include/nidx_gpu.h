@@ -107,7 +107,8 @@ int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint3
 int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out);
 
 /* Launch-shape knobs of the HNSW kernels (no effect on results): "waves_per_query" 1..4,
- * "eval_rows" 2|4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15.  Also read at
+ * "eval_rows" 2..4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15, and the request coalescer's
+ * "coalesce_window_us" / "coalesce_max_batch".  The kernel knobs are also read at
  * open from the environment as NIDX_GPU_<NAME>. */
 int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value);
 
@@ -201,6 +202,17 @@ int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, ui
                                               const uint64_t *d_filter, uint32_t *d_out_vector,
                                               float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats,
                                               void *stream);
+
+/* One query per call, the shape of the reference's request path (one blocking thread per Search request,
+ * src/searcher/shard_search.rs:139-153; one vector per request, nodereader.proto:402).  Thread safe:
+ * concurrent callers with equal params are coalesced into one batched launch (window and batch size via
+ * the tunables "coalesce_window_us", default 100, and "coalesce_max_batch", default 1024).  Unfiltered;
+ * outputs are [k] rows.  Blocks until this query's hits are ready. */
+int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *query, uint32_t query_dimension,
+                                   const nidx_gpu_vector_search_params_t *params, uint32_t *out_segment,
+                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
+/* Launches and queries served through nidx_gpu_vector_search_one so far. */
+int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out);
 
 /* use_hnsw (segment.rs:626-660) — exposed so callers can route exactly like the reference. */
 int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq);

@@ -130,6 +130,9 @@ SIGNATURES = {
     "nidx_gpu_vector_segment_search_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                                           C.POINTER(VectorSearchParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_vector_search_one": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_coalescer_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_use_hnsw": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
     "nidx_gpu_similarity": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]),
     "nidx_gpu_normalize": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),

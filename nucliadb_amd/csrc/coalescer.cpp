@@ -1,0 +1,157 @@
+// coalescer.cpp — request coalescing for single-query callers (nidx_gpu_vector_search_one).
+//
+// The reference serves every Search request on its own blocking thread with ONE query vector
+// (nidx/src/searcher/shard_search.rs:139-153, nodereader.proto:402); a GPU wants batches.  Concurrent
+// callers of nidx_gpu_vector_search_one are therefore merged: the first caller to arrive becomes the
+// leader, waits a short window (or until the batch is full) for more requests with the same
+// parameters, runs ONE batched search, and hands every caller its rows.  Results are identical to
+// calling nidx_gpu_vector_search with a batch of one (the kernels are per-query deterministic).
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+
+#include "host_common.h"
+#include "vector_index.h"
+
+namespace nidx {
+
+struct OneRequest {
+    const float *query;
+    nidx_gpu_vector_search_params_t params;
+    uint32_t *out_segment, *out_paragraph, *out_vector;
+    float *out_score;
+    uint32_t *out_count;
+    int32_t rc = NIDX_OK;
+    std::string error;
+    bool done = false;
+};
+
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<OneRequest *> pending;
+    bool leader_active = false;
+    uint64_t n_batches = 0, n_queries = 0;
+    uint32_t window_us = 100, max_batch = 1024;
+};
+
+static bool same_params(const nidx_gpu_vector_search_params_t &a, const nidx_gpu_vector_search_params_t &b) {
+    return a.k == b.k && a.with_duplicates == b.with_duplicates && a.method == b.method &&
+           std::memcmp(&a.min_score, &b.min_score, 4) == 0;
+}
+
+int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
+                                uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
+    if (!coalescer) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!coalescer) coalescer = std::make_shared<Coalescer>();
+    }
+    Coalescer &c = *coalescer;
+    OneRequest req{query, p, out_segment, out_paragraph, out_vector, out_score, out_count};
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.pending.push_back(&req);
+    c.cv.notify_all();
+    while (!req.done) {
+        if (c.leader_active) {
+            c.cv.wait(lk);
+            continue;
+        }
+        // become the leader: gather a batch of requests that share this request's parameters
+        c.leader_active = true;
+        auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c.window_us);
+        while (c.pending.size() < c.max_batch && c.cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
+        std::vector<OneRequest *> batch;
+        const nidx_gpu_vector_search_params_t lead = c.pending.front()->params;
+        for (auto it = c.pending.begin(); it != c.pending.end() && batch.size() < c.max_batch;) {
+            if (same_params((*it)->params, lead)) {
+                batch.push_back(*it);
+                it = c.pending.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lk.unlock();
+        const uint32_t B = (uint32_t)batch.size(), k = lead.k, d = cfg.dimension;
+        std::vector<float> q((size_t)B * d);
+        for (uint32_t i = 0; i < B; i++) std::memcpy(&q[(size_t)i * d], batch[i]->query, (size_t)d * 4);
+        const size_t kk = std::max<uint32_t>(k, 1);
+        std::vector<uint32_t> seg(B * kk), par(B * kk), vec(B * kk), cnt(B);
+        std::vector<float> sc(B * kk);
+        int32_t rc = search_host(q.data(), B, lead, nullptr, nullptr, seg.data(), par.data(), vec.data(), sc.data(), cnt.data(),
+                                 nullptr, nullptr);
+        char err[512] = {0};
+        if (rc != NIDX_OK) nidx_gpu_last_error(err, sizeof(err));
+        lk.lock();
+        for (uint32_t i = 0; i < B; i++) {
+            OneRequest *r = batch[i];
+            r->rc = rc;
+            if (rc != NIDX_OK) r->error = err;
+            else {
+                *r->out_count = cnt[i];
+                for (uint32_t j = 0; j < cnt[i]; j++) {
+                    if (r->out_segment) r->out_segment[j] = seg[i * kk + j];
+                    if (r->out_paragraph) r->out_paragraph[j] = par[i * kk + j];
+                    if (r->out_vector) r->out_vector[j] = vec[i * kk + j];
+                    if (r->out_score) r->out_score[j] = sc[i * kk + j];
+                }
+            }
+            r->done = true;
+        }
+        c.n_batches++;
+        c.n_queries += B;
+        c.leader_active = false;
+        c.cv.notify_all();
+    }
+    if (req.rc != NIDX_OK) set_error("%s", req.error.c_str());
+    return req.rc;
+}
+
+void VectorIndex::coalescer_stats(uint64_t &batches, uint64_t &queries) {
+    batches = queries = 0;
+    if (!coalescer) return;
+    std::lock_guard<std::mutex> lk(coalescer->mu);
+    batches = coalescer->n_batches;
+    queries = coalescer->n_queries;
+}
+
+void VectorIndex::coalescer_config(int32_t window_us, int32_t max_batch) {
+    if (!coalescer) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!coalescer) coalescer = std::make_shared<Coalescer>();
+    }
+    std::lock_guard<std::mutex> lk(coalescer->mu);
+    if (window_us >= 0) coalescer->window_us = (uint32_t)window_us;
+    if (max_batch > 0) coalescer->max_batch = (uint32_t)max_batch;
+}
+
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" {
+
+int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *query, uint32_t query_dimension,
+                                   const nidx_gpu_vector_search_params_t *params, uint32_t *out_segment,
+                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !query || !params || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (query_dimension != idx->cfg.dimension)
+        return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "Inconsistent dimensions. Index=%u Vector=%u", idx->cfg.dimension,
+                    query_dimension);
+    *out_count = 0;
+    if (params->k == 0) return NIDX_OK;
+    return idx->search_one(query, *params, out_segment, out_paragraph, out_vector, out_score, out_count);
+}
+
+int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !batches_out || !queries_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    idx->coalescer_stats(*batches_out, *queries_out);
+    return NIDX_OK;
+}
+
+}  // extern "C"

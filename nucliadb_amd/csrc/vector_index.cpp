@@ -668,6 +668,8 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "eval_rows") idx->eval_rows = std::max(2, std::min(4, (int)value));
     else if (n == "min_waves") idx->min_waves = value >= 4 ? 4 : 2;
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else if (n == "coalesce_window_us") { idx->mu.unlock(); idx->coalescer_config(value, -1); idx->mu.lock(); }
+    else if (n == "coalesce_max_batch") { idx->mu.unlock(); idx->coalescer_config(-1, value); idx->mu.lock(); }
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown tunable %s", name);
     return NIDX_OK;

@@ -1,5 +1,6 @@
 // vector_index.h — the opaque nidx_gpu_vector_index_t (one process-local, device-resident Searcher).
 #pragma once
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -44,6 +45,8 @@ struct VectorSegment {
     uint64_t bytes() const;
 };
 
+struct Coalescer;
+
 struct VectorIndex {
     nidx_gpu_vector_config_t cfg{};
     int device = 0;
@@ -73,6 +76,12 @@ struct VectorIndex {
     // evaluates `prog` for segment s into scratch_filter (already intersected with alive); returns |filter ∩ alive|
     int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed);
+    // request coalescing for single-query callers (coalescer.cpp)
+    std::shared_ptr<Coalescer> coalescer;
+    int32_t search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
+                       uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
+    void coalescer_stats(uint64_t &batches, uint64_t &queries);
+    void coalescer_config(int32_t window_us, int32_t max_batch);
 };
 
 }  // namespace nidx

@@ -201,3 +201,46 @@ def test_device_filter_programs_match_host_bitsets():
             want = [int((seg._eval(searcher._formula(req, pre))).sum()) for seg in searcher._segments]
             assert matching_dev == want, (trial, matching_dev, want)
     searcher.close()
+
+
+def test_single_query_callers_are_coalesced():
+    """One query per call from many threads (the reference's request shape): every caller gets exactly
+    the rows a batch-of-one search returns, and the calls are served in fewer launches than queries."""
+    import ctypes as C
+    import threading
+
+    rng = np.random.default_rng(9)
+    n, d, k, T = 4000, 64, 10, 48
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    config = VectorConfig(d, Similarity.Cosine)
+    seg = segment_create([Elem(f"{uuid.uuid4()}/a/t/{i}", x[i].tolist()) for i in range(n)], config)
+    s = VectorSearcher.open(config, [(seg, 1)])
+    s.build_hnsw(0)
+    L = _lib.lib()
+    _lib.check(L.nidx_gpu_vector_set_tunable(s._handle, b"coalesce_window_us", 20000))
+    q = rng.normal(size=(T, d)).astype(np.float32)
+    req = VectorSearchRequest(result_per_page=k, min_score=-1.0, with_duplicates=True)
+    _, _, want_vec, want_score, want_count = s.search_batch(req, q)
+    got = [None] * T
+    params = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_AUTO)
+
+    def one(i):
+        ov, os_, oc = np.zeros(k, np.uint32), np.zeros(k, np.float32), C.c_uint32()
+        rc = L.nidx_gpu_vector_search_one(s._handle, q[i].ctypes.data, d, C.byref(params), None, None, ov.ctypes.data,
+                                          os_.ctypes.data, C.byref(oc))
+        got[i] = (rc, ov, os_, oc.value)
+
+    threads = [threading.Thread(target=one, args=(i,)) for i in range(T)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for i in range(T):
+        rc, ov, os_, oc = got[i]
+        assert rc == 0 and oc == want_count[i]
+        assert np.array_equal(ov[:oc], want_vec[i, :oc]) and np.array_equal(os_[:oc].view(np.uint32), want_score[i, :oc].view(np.uint32))
+    b, nq = C.c_uint64(), C.c_uint64()
+    _lib.check(L.nidx_gpu_vector_coalescer_stats(s._handle, C.byref(b), C.byref(nq)))
+    assert nq.value == T and b.value < T // 2, (b.value, nq.value)
+    # a wrong dimension is an error for that caller only
+    oc = C.c_uint32()
+    assert L.nidx_gpu_vector_search_one(s._handle, q[0].ctypes.data, d - 1, C.byref(params), None, None, None, None, C.byref(oc)) == _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS
+    s.close()
