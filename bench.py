@@ -439,12 +439,15 @@ def clustered_recall(a, L, dev):
     oc = torch.zeros((nq,), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
+    st = torch.zeros((nq, 8), dtype=torch.int32, device=dev)
     for name, m in (("hnsw", _lib.METHOD_HNSW), ("exact", _lib.METHOD_BRUTE_FORCE)):
         p = _lib.VectorSearchParamsC(k, -1.0, 1, m)
         _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, q.data_ptr(), nq, C.byref(p), None, ov.data_ptr(), os_.data_ptr(),
-                                                           oc.data_ptr(), None, stream))
+                                                           oc.data_ptr(), st.data_ptr(), stream))
         torch.cuda.synchronize()
         res[name] = ov.cpu().numpy().copy()
+        if name == "hnsw" and int(st[:, 3].max().item()) != 0:
+            raise RuntimeError("HNSW kernel raised overflow flags on the clustered shard: %d" % int(st[:, 3].max().item()))
     L.nidx_gpu_vector_close(h)
     rec = float(np.mean([len(set(res["hnsw"][i]) & set(res["exact"][i])) / k for i in range(nq)]))
     return rec, build_s

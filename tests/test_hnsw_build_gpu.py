@@ -149,3 +149,26 @@ def test_built_graph_is_searchable_by_the_oracle(orc):
         wv, ws = oseg.hnsw_search(q[i], k)
         assert np.array_equal(vec[i, : count[i]], wv)
         assert np.array_equal(score[i, : count[i]].view(np.uint32), ws.view(np.uint32))
+
+
+def test_device_graph_at_768d_is_searched_identically_by_the_oracle(orc):
+    """The headline shape (D = 768, cosine) end to end: build on the device, serialise to hnsw.graph,
+    load that image into the oracle, and the oracle's CPU search must return bit-identical hits."""
+    rng = np.random.default_rng(77)
+    n, d, k = 12000, 768, 10
+    x = np.vstack([clustered(rng, d, 30, 160), random_vector(rng, d, n - 4800)])
+    x = x[rng.permutation(len(x))]
+    q = np.vstack([np.array([nearby(rng, x[rng.integers(0, n)], 0.05) for _ in range(12)], np.float32), random_vector(rng, d, 12)])
+    s = VectorSearcher.open(VectorConfig(d, Similarity.Cosine), [(seg_of(x), 1)])
+    s.build_hnsw(0, level_seed=2)
+    graph, edges = s.serialize_hnsw(0)
+    req = VectorSearchRequest(result_per_page=k, min_score=-1.0, with_duplicates=False)
+    _, _, vec, score, count = s.search_batch(req, q, method=_lib.METHOD_HNSW)
+    r = recall_at(s, q, k, _lib.METHOD_HNSW)
+    s.close()
+    oseg = orc.Segment(x, similarity=orc.SIM_COSINE, graph=orc.Hnsw.deserialize_v2(np.frombuffer(graph, np.uint8), edges))
+    for i in range(len(q)):
+        wv, ws = oseg.hnsw_search(q[i], k, with_duplicates=False)
+        assert np.array_equal(vec[i, : count[i]], wv), i
+        assert np.array_equal(score[i, : count[i]].view(np.uint32), ws.view(np.uint32))
+    assert r >= 0.5  # half the queries are uniform random points (no structure to find)
