@@ -37,6 +37,7 @@ struct BuildArgs {
     float *req_val;             // [n_slots*32]
     uint32_t vis_log2;
     uint32_t *flags;            // [1] OR of NIDX_FLAG_*
+    unsigned long long *dbg;    // nullptr or 5 counters: appends, prunes, prune cycles, total cycles, targets
 };
 
 #define FOUND_STRIDE NIDX_BUILD_FOUND_STRIDE
@@ -127,15 +128,24 @@ __device__ inline void sims4x4(const SegDev &seg, const float4 (&cv)[4][NJ], con
             v[c * 4 + i] = ab;
         }
     float r = QReduce<16>::run(v, lane);
-    // value w lives in the 4-lane group whose query_of_lane == w: bits 5..2 of the lane, MSB first
+    // value w = 4*c + i lives in the 4-lane group whose query_of_lane == w.  That group turns its sum into the
+    // similarity (ONE f64 cosine per lane instead of sixteen), then the 16 results are broadcast.
+    const int w_mine = QReduce<16>::query_of_lane(lane);
+    const int c_mine = w_mine >> 2, i_mine = w_mine & 3;
+    float mine = r;
+    if (cosine) {
+        const float cn = c_mine == 0 ? c_norm2[0] : (c_mine == 1 ? c_norm2[1] : (c_mine == 2 ? c_norm2[2] : c_norm2[3]));
+        const uint32_t y = i_mine == 0 ? ys[0] : (i_mine == 1 ? ys[1] : (i_mine == 2 ? ys[2] : ys[3]));
+        mine = (c_mine < nc && i_mine < ny) ? cosine_from_sums(r, cn, seg.norm2[y]) : 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int w = c * 4 + i;
             const int src = (((w >> 3) & 1) << 5) | (((w >> 2) & 1) << 4) | (((w >> 1) & 1) << 3) | ((w & 1) << 2);
-            float ab = __shfl(r, src, 64);
-            out[c][i] = (c < nc && i < ny) ? (cosine ? cosine_from_sums(ab, c_norm2[c], seg.norm2[ys[i]]) : ab) : 0.f;
+            const float sim = __shfl(mine, src, 64);
+            out[c][i] = (c < nc && i < ny) ? sim : 0.f;
         }
 }
 
@@ -307,6 +317,8 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
     int deg = (int)rec[0];
     // lane j holds edge j as a rank key (score = stored weight)
     uint64_t e = lane < deg ? rank_key(wrec[1 + lane], rec[1 + lane]) : 0ull;
+    unsigned long long n_prune = 0, n_app = 0, cy_prune = 0;
+    const unsigned long long t0 = clock64();
     for (uint32_t i = i0; i < n_req; i++) {
         uint64_t ki = keys[i];
         if (ki == ~0ull || (ki >> 30) != (k0 >> 30)) break;
@@ -317,12 +329,23 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
         if (__ballot(lane < deg && rank_key_addr(e) == x)) continue;
         if (lane == deg) e = nk;  // other_edges.push((x, dist))
         deg++;
+        n_app++;
         if (deg > mmax) {
+            const unsigned long long tp = clock64();
             s_cand[wib][lane] = e;  // stored order
             int m = select_neighbours_wave<NJ>(a.seg, s_cand[wib], deg, pm, s_out[wib], s_dis[wib], cosine, lane);
             e = lane < m ? s_out[wib][lane] : 0ull;
             deg = m;
+            n_prune++;
+            cy_prune += clock64() - tp;
         }
+    }
+    if (a.dbg && lane == 0) {
+        atomicAdd(&a.dbg[0], n_app);
+        atomicAdd(&a.dbg[1], n_prune);
+        atomicAdd(&a.dbg[2], cy_prune);
+        atomicAdd(&a.dbg[3], clock64() - t0);
+        atomicAdd(&a.dbg[4], 1ull);
     }
     if (lane == 0) rec[0] = (uint32_t)deg;
     if (lane < deg) {
@@ -373,6 +396,7 @@ hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s) {
     a.req_val = b.req_val;
     a.vis_log2 = b.vis_log2;
     a.flags = b.flags;
+    a.dbg = b.dbg;
     int nj = (int)((a.seg.dp + 255u) / 256u);
 #define NIDX_BUILD_CASE(N) \
     return launch_batch<N>(a, b.n_slots, b.sort_tmp, b.sort_tmp_bytes, b.req_key_sorted, b.req_val_sorted, s)

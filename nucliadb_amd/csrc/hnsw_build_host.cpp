@@ -7,6 +7,8 @@
 // (hnsw_build.hip) whose size grows with the graph: a batch never exceeds 1/16 of the nodes
 // already inserted, so at most ~6 % of a node's potential neighbours are invisible to it — the
 // same kind of race the reference's rayon workers have.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "host_common.h"
@@ -116,6 +118,13 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     b.sort_tmp_bytes = tmp_bytes;
     b.vis_log2 = build_vis_log2;
     b.flags = d_flags.as<uint32_t>();
+    DevBuf d_dbg;
+    b.dbg = nullptr;
+    if (getenv("NIDX_GPU_BUILD_DEBUG")) {
+        NIDX_HIP(d_dbg.alloc(40));
+        NIDX_HIP(hipMemsetAsync(d_dbg.p, 0, 40, stream));
+        b.dbg = d_dbg.as<unsigned long long>();
+    }
     for (const Batch &bt : batches) {
         b.batch_start = bt.start;
         b.batch_size = bt.size;
@@ -126,6 +135,12 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     uint32_t flags = 0;
     NIDX_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, stream));
     NIDX_HIP(hipStreamSynchronize(stream));
+    if (b.dbg) {
+        unsigned long long d5[5];
+        NIDX_HIP(hipMemcpy(d5, b.dbg, 40, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[build dbg] reverse links: appends=%llu prunes=%llu targets=%llu cycles/prune=%llu prune share of wave cycles=%.2f\n", d5[0], d5[1], d5[4],
+                d5[1] ? d5[2] / d5[1] : 0, d5[3] ? (double)d5[2] / (double)d5[3] : 0.0);
+    }
     // a visited-table overflow only ends one construction search early (the graph is approximate by
     // nature); a candidate-pool overflow cannot happen below 412 exact ties and is reported
     if (flags & NIDX_FLAG_POOL_INEXACT) return fail(NIDX_ERR_INEXACT, "HNSW build: candidate pool overflow");

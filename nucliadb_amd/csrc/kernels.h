@@ -163,6 +163,7 @@ struct BuildBatch {
     size_t sort_tmp_bytes;
     uint32_t vis_log2;
     uint32_t *flags;            // [1]
+    unsigned long long *dbg;    // nullptr or [5] (NIDX_GPU_BUILD_DEBUG)
 };
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
 hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
