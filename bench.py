@@ -77,6 +77,13 @@ def main():
 
     from nucliadb_amd import _lib
 
+    if not os.path.exists(_lib.LIB_PATH):  # fresh checkout: the .so is a build product (git-ignored)
+        if local_rank == 0:
+            import __graft_entry__ as g
+
+            g.build()
+        if world > 1:
+            dist.barrier()
     L = _lib.lib()
     _lib.check(L.nidx_gpu_set_device(local_rank))
     if a.workload == "bm25":
