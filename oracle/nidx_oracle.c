@@ -1138,6 +1138,75 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
     return (int)n_top;
 }
 
+/* Document-at-a-time form of orc_bm25_search (what tantivy's union/intersection scorers do): the clause
+ * cursors advance together over ascending doc ids and every doc's clause scores are summed in clause
+ * order — the same f32 arithmetic as the term-at-a-time loop above, without the dense accumulator.  Used
+ * as the CPU baseline of bench.py (a dense 4*n_docs-byte accumulator per query would be a strawman). */
+int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                         size_t k, const orc_search_after *after, uint32_t segment_ord,
+                         uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+    float cache[256];
+    float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
+    orc_bm25_tf_cache(avg, cache);
+    uint64_t *cur = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
+    uint64_t *end = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
+    float *weight = (float *)malloc((n_clauses ? n_clauses : 1) * sizeof(float));
+    size_t n_must = 0, n_group = 0;
+    for (size_t c = 0; c < n_clauses; c++) {
+        const orc_bm25_clause *cl = &clauses[c];
+        cur[c] = idx->term_offsets[cl->term];
+        end[c] = idx->term_offsets[cl->term + 1];
+        weight[c] = cl->mode == ORC_CONST_SCORE ? cl->boost : orc_bm25_idf(end[c] - cur[c], idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+        if (cl->occur == ORC_OCCUR_MUST) n_must++;
+        if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
+    }
+    bm_hit_t *top = (bm_hit_t *)malloc((k + 1) * sizeof(bm_hit_t));
+    size_t n_top = 0;
+    uint64_t total = 0;
+    for (;;) {
+        uint32_t d = 0xffffffffu;
+        for (size_t c = 0; c < n_clauses; c++)
+            if (cur[c] < end[c] && idx->doc_ids[cur[c]] < d) d = idx->doc_ids[cur[c]];
+        if (d == 0xffffffffu) break;
+        float acc = 0.0f;
+        size_t must = 0;
+        int should = 0, group = 0, excluded = 0;
+        for (size_t c = 0; c < n_clauses; c++) {
+            if (cur[c] >= end[c] || idx->doc_ids[cur[c]] != d) continue;
+            const orc_bm25_clause *cl = &clauses[c];
+            uint64_t i = cur[c]++;
+            if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded = 1; continue; }
+            float s;
+            if (cl->mode == ORC_CONST_SCORE) s = cl->boost;
+            else {
+                float tf = cl->mode == ORC_TF_BASIC ? 1.0f : (float)idx->tfs[i];
+                s = weight[c] * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
+            }
+            acc = acc + s;
+            if (cl->occur == ORC_OCCUR_MUST) must++;
+            else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group = 1;
+            else should = 1;
+        }
+        if (excluded || must != n_must) continue;
+        if (n_group > 0 && !group) continue;
+        if (n_must == 0 && n_group == 0 && !should) continue;
+        if (idx->alive && !bit_get(idx->alive, d)) continue;
+        total++;
+        uint64_t docaddr = ((uint64_t)segment_ord << 32) | d;
+        if (!is_after(after, acc, docaddr)) acc = -INFINITY;
+        bm_hit_t h = {acc, docaddr};
+        if (k == 0) continue;
+        if (n_top == k && !bm_better(h, top[n_top - 1])) continue;
+        size_t j = n_top < k ? n_top++ : k - 1;
+        while (j > 0 && bm_better(h, top[j - 1])) { top[j] = top[j - 1]; j--; }
+        top[j] = h;
+    }
+    for (size_t i = 0; i < n_top; i++) { out_docaddr[i] = top[i].docaddr; out_score[i] = top[i].score; }
+    if (total_out) *total_out = total;
+    free(top); free(cur); free(end); free(weight);
+    return (int)n_top;
+}
+
 /* ------------------------------------------------------------------------------------------
  * a18. shard merge (nidx/src/searcher/shard_merge.rs:332-348, 197-250, 274-330) over
  * itertools::kmerge_by [third party, restated: binary heap of list heads, sift_down]

@@ -175,6 +175,11 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
                     size_t k, const orc_search_after *after, uint32_t segment_ord,
                     uint64_t *out_docaddr, float *out_score, uint64_t *total_out);
 
+/* Same results, document-at-a-time (no dense accumulator): the CPU baseline of bench.py. */
+int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                         size_t k, const orc_search_after *after, uint32_t segment_ord,
+                         uint64_t *out_docaddr, float *out_score, uint64_t *total_out);
+
 /* ---- shard merge (nidx/src/searcher/shard_merge.rs) ---- */
 typedef struct {
     float score;

@@ -169,6 +169,8 @@ def lib():
     L.orc_bm25_search.restype = C.c_int
     L.orc_bm25_search.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t,
                                   C.POINTER(_SearchAfter), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_bm25_search_daat.restype = C.c_int
+    L.orc_bm25_search_daat.argtypes = L.orc_bm25_search.argtypes
     L.orc_merge_vector.restype = C.c_size_t
     L.orc_merge_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     L.orc_merge_bm25.restype = C.c_size_t
@@ -472,8 +474,9 @@ class Bm25Index:
         s.alive = None if self.alive is None else self.alive.ctypes.data
         return s
 
-    def search(self, clauses, k, after=None, segment_ord=0):
-        """clauses: list of (term, occur, mode, boost). -> (docaddr u64[], score f32[], total)"""
+    def search(self, clauses, k, after=None, segment_ord=0, daat=False):
+        """clauses: list of (term, occur, mode, boost). -> (docaddr u64[], score f32[], total).
+        daat=True runs the document-at-a-time form (same results, no dense accumulator)."""
         cl = (_Bm25Clause * max(len(clauses), 1))()
         for i, (t, o, m, b) in enumerate(clauses):
             cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = t, o, m, b
@@ -483,7 +486,8 @@ class Bm25Index:
         od, os_ = np.empty(max(k, 1), np.uint64), np.empty(max(k, 1), np.float32)
         total = C.c_uint64()
         ci = self.c()
-        n = lib().orc_bm25_search(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(od), _ptr(os_), C.byref(total))
+        fn = lib().orc_bm25_search_daat if daat else lib().orc_bm25_search
+        n = fn(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(od), _ptr(os_), C.byref(total))
         return od[:n].copy(), os_[:n].copy(), total.value
 
 

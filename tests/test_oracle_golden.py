@@ -402,3 +402,29 @@ def test_bm25_counts_min_score_and_order(orc):
     # MUST + MUST_NOT
     docs, _, total = idx.search([(0, orc.OCCUR_MUST, 0, 1.0), (1, orc.OCCUR_MUST_NOT, 0, 1.0)], 10)
     assert docs.tolist() == [0, 1, 3] and total == 3
+
+
+def test_bm25_daat_equals_term_at_a_time(orc):
+    """The document-at-a-time form used as bench.py's CPU baseline gives bit-identical hits, order and totals."""
+    rng = np.random.default_rng(31)
+    vocab, n_docs = 120, 3000
+    lens = rng.integers(2, 25, n_docs)
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    flat = rng.choice(vocab, size=int(lens.sum()), p=p)
+    doc_of = np.repeat(np.arange(n_docs), lens)
+    uniq, counts = np.unique(flat.astype(np.int64) * (n_docs + 1) + doc_of, return_counts=True)
+    t, d = uniq // (n_docs + 1), uniq % (n_docs + 1)
+    off = np.zeros(vocab + 1, np.uint64)
+    np.add.at(off, t + 1, 1)
+    off = np.cumsum(off).astype(np.uint64)
+    ids = np.array([orc.fieldnorm_to_id(int(x)) for x in lens], np.uint8)
+    alive = orc.bitset(n_docs, ones=np.nonzero(rng.random(n_docs) < 0.8)[0].tolist())
+    idx = orc.Bm25Index(off, d.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive)
+    for _ in range(60):
+        q = [(int(rng.integers(0, 50)), int(rng.choice([0, 0, 1, 2, 3])), int(rng.choice([0, 1, 2])), float(rng.choice([1.0, 0.5])))
+             for _ in range(int(rng.integers(1, 6)))]
+        after = None if rng.random() < 0.7 else (float(rng.random() * 3), int(rng.integers(0, 3)), int(rng.integers(0, n_docs)))
+        a = idx.search(q, 15, after=after, segment_ord=2)
+        b = idx.search(q, 15, after=after, segment_ord=2, daat=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and a[2] == b[2]
