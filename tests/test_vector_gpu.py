@@ -294,7 +294,8 @@ def test_mfma_and_wave64_scans_agree_within_1e5():
 
 # ---- batched fallback on the bf16 matrix cores with exact re-scoring (BASELINE configs[4]) -------------------
 @pytest.mark.parametrize("sim", [0, 1])
-@pytest.mark.parametrize("n,d,nq,k", [(500, 64, 7, 10), (30000, 768, 130, 10), (9000, 1024, 40, 16), (2000, 100, 5, 32)])
+@pytest.mark.parametrize("n,d,nq,k", [(500, 64, 7, 10), (30000, 768, 130, 10), (9000, 1024, 40, 16), (2000, 100, 5, 32),
+                                      (150000, 64, 140, 10), (140000, 200, 33, 32)])  # the last two take the two-pass (sample bound + append) route
 def test_bf16_fallback_scores_exact_and_recall(orc, sim, n, d, nq, k):
     """Returned scores must be bit-identical to the exact (WAVE64) similarity of the returned ids and
     sorted by (score desc, address asc); the id set may differ from the exact top-k only through bf16
