@@ -103,7 +103,7 @@ def main():
     del x
     torch.cuda.empty_cache()
     cfg = _lib.VectorConfigC(d, 1, 0, 0)
-    cseg = _lib.VectorSegmentC(x_host.ctypes.data, d * 4, n, None, n, None, 0, None, None)
+    cseg = _lib.VectorSegmentC(x_host.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
     h = C.c_void_p()
     t0 = time.time()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
@@ -435,7 +435,7 @@ def clustered_recall(a, L, dev):
     xh = x.cpu().numpy()
     del x
     cfg = _lib.VectorConfigC(d, 1, 0, 0)
-    cseg = _lib.VectorSegmentC(xh.ctypes.data, d * 4, n, None, n, None, 0, None, None)
+    cseg = _lib.VectorSegmentC(xh.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
     h = C.c_void_p()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
     t0 = time.time()

@@ -86,6 +86,12 @@ typedef struct {
      * nidx_gpu_vector_build_hnsw is called */
     const uint8_t *hnsw_graph;
     uint64_t hnsw_graph_len;
+    /* merge with graph reuse (segment.rs:137-167): the image may cover only the first hnsw_graph_nodes
+     * vectors (0 = all); such a segment is searchable after nidx_gpu_vector_extend_hnsw inserted the rest.
+     * hnsw_edges = the weights of hnsw.edges in graph order (needed by later prunes; NULL = all 0). */
+    uint32_t hnsw_graph_nodes;
+    const float *hnsw_edges;
+    uint64_t n_hnsw_edges;
     /* alive bitset over paragraph addresses after apply_deletions (segment.rs:81,428-445);
      * bit i = word[i>>6] >> (i&63).  NULL => all alive */
     const uint64_t *alive_bitset;
@@ -229,6 +235,11 @@ int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, floa
  * concurrent inserts with M=30/M0=60/efC=100 (hnsw/params.rs:20-46).  Replaces any graph the
  * segment had.  Like the reference's rayon build the graph is not unique; parity is recall. */
 int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed);
+/* segment::merge's graph reuse (segment.rs:137-167): the segment was opened with an hnsw.graph image of
+ * its first hnsw_graph_nodes vectors (the largest, deletion-free operand of the merge); draw levels
+ * for the remaining nodes from a fresh SmallRng::seed_from_u64(level_seed) (build.rs:50-55,
+ * initialize_graph(skip_nodes, total)) and insert only those. */
+int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed);
 /* DiskHnswV2::serialize_to (hnsw/disk/v2.rs:109-218): writes the segment's graph as hnsw.graph /
  * hnsw.edges bytes.  Call with NULL buffers to get the sizes. */
 int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *graph_out,

@@ -57,6 +57,9 @@ class VectorSegmentC(C.Structure):
         ("n_paragraphs", C.c_uint32),
         ("hnsw_graph", C.c_void_p),
         ("hnsw_graph_len", C.c_uint64),
+        ("hnsw_graph_nodes", C.c_uint32),
+        ("hnsw_edges", C.c_void_p),
+        ("n_hnsw_edges", C.c_uint64),
         ("alive_bitset", C.c_void_p),
         ("paragraph_key_ids", C.c_void_p),
     ]
@@ -137,6 +140,7 @@ SIGNATURES = {
     "nidx_gpu_similarity": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]),
     "nidx_gpu_normalize": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_vector_build_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "nidx_gpu_vector_extend_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "nidx_gpu_vector_serialize_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_open": (C.c_int32, [C.POINTER(Bm25SegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),

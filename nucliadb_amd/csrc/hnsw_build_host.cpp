@@ -18,16 +18,22 @@ namespace nidx {
 
 static const uint32_t kMaxBatch = 8192;
 
-int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
+int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     std::lock_guard<std::mutex> lock(mu);
     NIDX_HIP(hipSetDevice(device));
     VectorSegment &seg = segs[si];
     const uint32_t n = seg.n;
+    if (extend && !seg.base_graph) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u was not opened with a partial hnsw graph", si);
+    const uint32_t n0 = extend ? seg.base_nodes : 0;  // nodes [0, n0) keep their graph (segment.rs:143-153)
+    const HostGraph *base = extend ? seg.base_graph.get() : nullptr;
     seg.has_graph = false;
     if (n == 0) return NIDX_OK;
     if (n >= (1u << 30)) return fail(NIDX_ERR_UNSUPPORTED, "segments of 2^30 or more vectors are not supported");
-    std::vector<uint8_t> levels;
-    draw_levels(level_seed, n, levels);
+    // initialize_graph(skip_nodes = n0, total = n): a fresh RNG draws the levels of the NEW nodes only
+    std::vector<uint8_t> drawn, levels(n);
+    draw_levels(level_seed, n - n0, drawn);
+    for (uint32_t i = 0; i < n0; i++) levels[i] = base->top_layer[i];
+    for (uint32_t i = n0; i < n; i++) levels[i] = drawn[i - n0];
     uint32_t max_level = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (levels[i] > 15) levels[i] = 15;  // 4 bits of layer in the request key; P(level > 15) ~ 30^-15
@@ -37,8 +43,17 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     hg.n = n;
     hg.ep_layer = max_level;
     hg.ep_node = 0;
-    for (uint32_t i = 0; i < n; i++)
-        if (levels[i] == max_level) { hg.ep_node = i; break; }
+    if (base && base->ep_layer >= max_level) {
+        // update_entry_point (ram_hnsw.rs:99-107) only moves the entry point when a higher layer appeared
+        hg.ep_node = base->ep_node;
+        hg.ep_layer = base->ep_layer;
+    } else {
+        for (uint32_t i = n0; i < n; i++)
+            if (levels[i] == max_level) { hg.ep_node = i; break; }
+        if (!base)
+            for (uint32_t i = 0; i < n; i++)
+                if (levels[i] == max_level) { hg.ep_node = i; break; }
+    }
     hg.top_layer = levels;
     hg.upper_base.assign(n, 0xffffffffu);
     uint32_t n_upper = 0;
@@ -58,6 +73,25 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     NIDX_HIP(hipMemsetAsync(seg.g_upper.p, 0, seg.g_upper.bytes, stream));
     NIDX_HIP(hipMemsetAsync(seg.g_upper_w.p, 0, seg.g_upper_w.bytes, stream));
     NIDX_HIP(hipMemcpyAsync(seg.g_upper_base.p, hg.upper_base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    if (base && n0 > 0) {
+        // the reused graph: layer-0 records keep their place; upper records move to the new numbering
+        NIDX_HIP(hipMemcpyAsync(seg.g_l0.p, base->l0.data(), (size_t)n0 * NIDX_L0_STRIDE * 4, hipMemcpyHostToDevice, stream));
+        NIDX_HIP(hipMemcpyAsync(seg.g_l0_w.p, base->l0_w.data(), (size_t)n0 * NIDX_L0_STRIDE * 4, hipMemcpyHostToDevice, stream));
+        std::vector<uint32_t> up(hg.upper_base.empty() ? 0 : (size_t)n_upper * NIDX_UP_STRIDE, 0u);
+        std::vector<float> upw(up.size(), 0.f);
+        for (uint32_t i = 0; i < n0; i++)
+            for (uint32_t l = 1; l <= base->top_layer[i] && base->upper_base[i] != 0xffffffffu; l++) {
+                const size_t src = ((size_t)base->upper_base[i] + (l - 1)) * NIDX_UP_STRIDE;
+                const size_t dst = ((size_t)hg.upper_base[i] + (l - 1)) * NIDX_UP_STRIDE;
+                std::copy(base->upper.begin() + src, base->upper.begin() + src + NIDX_UP_STRIDE, up.begin() + dst);
+                std::copy(base->upper_w.begin() + src, base->upper_w.begin() + src + NIDX_UP_STRIDE, upw.begin() + dst);
+            }
+        if (!up.empty()) {
+            NIDX_HIP(hipMemcpyAsync(seg.g_upper.p, up.data(), up.size() * 4, hipMemcpyHostToDevice, stream));
+            NIDX_HIP(hipMemcpyAsync(seg.g_upper_w.p, upw.data(), upw.size() * 4, hipMemcpyHostToDevice, stream));
+        }
+        NIDX_HIP(hipStreamSynchronize(stream));  // `up` / `upw` go out of scope
+    }
     seg.ep_node = hg.ep_node;
     seg.ep_layer = hg.ep_layer;
     seg.top_layer = levels;
@@ -67,8 +101,13 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     std::vector<Batch> batches;
     std::vector<uint32_t> slot_base(n);
     uint32_t max_slots = 0;
-    for (uint32_t start = 0; start < n;) {
-        uint32_t size = std::min<uint32_t>(std::min<uint32_t>(kMaxBatch, std::max<uint32_t>(1, start / 16)), n - start);
+    for (uint32_t start = n0; start < n;) {
+        // a batch's nodes do not see each other, so it stays a small fraction of the graph they search.
+        // When extending, the appended rows may be a distribution of their own (another segment's
+        // clusters): ramp on the number of NEW nodes already linked, not on the reused graph's size.
+        uint32_t ramp = start / 16;
+        if (extend) ramp = std::min<uint32_t>(ramp, std::max<uint32_t>(32, (start - n0) / 8));
+        uint32_t size = std::min<uint32_t>(std::min<uint32_t>(kMaxBatch, std::max<uint32_t>(1, ramp)), n - start);
         uint32_t slots = 0;
         for (uint32_t i = start; i < start + size; i++) {
             slot_base[i] = slots;
@@ -146,6 +185,8 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed) {
     if (flags & NIDX_FLAG_POOL_INEXACT) return fail(NIDX_ERR_INEXACT, "HNSW build: candidate pool overflow");
     last_build_flags = flags;
     seg.has_graph = true;
+    seg.base_graph.reset();
+    seg.base_nodes = 0;
     return NIDX_OK;
 }
 
@@ -156,5 +197,11 @@ using namespace nidx;
 extern "C" int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
-    return idx->build_hnsw(segment, level_seed);
+    return idx->build_hnsw(segment, level_seed, false);
+}
+
+extern "C" int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    return idx->build_hnsw(segment, level_seed, true);
 }

@@ -86,6 +86,57 @@ int parse_disk_v2(const uint8_t *buf, uint64_t len, uint32_t n_nodes, HostGraph 
     return NIDX_OK;
 }
 
+int attach_edge_weights(HostGraph &g, const uint8_t *buf, uint64_t len, const float *edges, uint64_t n_edges, std::string &err) {
+    g.l0_w.assign(g.l0.size(), 0.f);
+    g.upper_w.assign(g.upper.size(), 0.f);
+    if (!edges || g.n == 0 || len == 0) return NIDX_OK;
+    // the weights were written node by node, layer by layer, edge by edge: walk the image the same way
+    const uint32_t n_layers = g.ep_layer + 1;
+    const uint64_t indexing_end = len - 8;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < g.n; i++) {
+        uint32_t end = rd32(buf + indexing_end - ((uint64_t)i + 1) * 4);
+        for (uint32_t l = 0; l < n_layers; l++) {
+            uint32_t off = rd32(buf + end - (l + 1) * 4);
+            uint32_t deg = rd32(buf + (end - off));
+            float *w = nullptr;
+            if (l == 0) w = &g.l0_w[(size_t)i * NIDX_L0_STRIDE];
+            else if (l <= g.top_layer[i] && g.upper_base[i] != 0xffffffffu)
+                w = &g.upper_w[((size_t)g.upper_base[i] + (l - 1)) * NIDX_UP_STRIDE];
+            if (pos + deg > n_edges) { err = "hnsw.edges shorter than the graph"; return NIDX_ERR_INVALID_GRAPH; }
+            for (uint32_t e = 0; e < deg; e++)
+                if (w) w[1 + e] = edges[pos + e];
+            pos += deg;
+        }
+    }
+    return NIDX_OK;
+}
+
+void fix_broken_graph(HostGraph &g) {
+    for (uint32_t i = 0; i < g.n; i++) {
+        for (uint32_t l = 1; l <= g.top_layer[i]; l++) {
+            if (g.upper_base[i] == 0xffffffffu) break;
+            const size_t r = ((size_t)g.upper_base[i] + (l - 1)) * NIDX_UP_STRIDE;
+            uint32_t *rec = &g.upper[r];
+            float *w = g.upper_w.empty() ? nullptr : &g.upper_w[r];
+            uint32_t out = 0;
+            for (uint32_t e = 0; e < rec[0]; e++) {
+                uint32_t to = rec[1 + e];
+                if (g.top_layer[to] >= l) {
+                    rec[1 + out] = to;
+                    if (w) w[1 + out] = w[1 + e];
+                    out++;
+                }
+            }
+            rec[0] = out;
+        }
+    }
+    if (g.n && g.top_layer[g.ep_node] < g.ep_layer) {  // entry point not on its layer: take another node that is
+        for (uint32_t i = 0; i < g.n; i++)
+            if (g.top_layer[i] >= g.ep_layer) { g.ep_node = i; break; }
+    }
+}
+
 void serialize_disk_v2(const HostGraph &g, std::vector<uint8_t> &graph, std::vector<float> &edges) {
     graph.clear();
     edges.clear();

@@ -25,6 +25,11 @@ struct HostGraph {
 
 // Parses an hnsw.graph image for `n_nodes` nodes.  Returns 0 or a NIDX_ERR_* code (message in err).
 int parse_disk_v2(const uint8_t *buf, uint64_t len, uint32_t n_nodes, HostGraph &out, std::string &err);
+// Fills l0_w / upper_w from an hnsw.edges stream (weights in graph order, disk/v2.rs:46-49).
+int attach_edge_weights(HostGraph &g, const uint8_t *graph_buf, uint64_t graph_len, const float *edges, uint64_t n_edges,
+                        std::string &err);
+// RAMHnsw::fix_broken_graph (ram_hnsw.rs:109-143): drop links to nodes that are not in the layer.
+void fix_broken_graph(HostGraph &g);
 // DiskHnswV2::serialize_into: returns the image; edges (weights) in graph order.
 void serialize_disk_v2(const HostGraph &g, std::vector<uint8_t> &graph, std::vector<float> &edges);
 

@@ -205,12 +205,23 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
     // graph
     seg.has_graph = false;
     if (in.hnsw_graph && in.hnsw_graph_len > 0 && in.n_vectors > 0) {
-        HostGraph hg;
+        const uint32_t g_nodes = in.hnsw_graph_nodes ? in.hnsw_graph_nodes : in.n_vectors;
+        if (g_nodes > in.n_vectors) return fail(NIDX_ERR_INVALID_ARGUMENT, "hnsw_graph_nodes exceeds n_vectors");
+        std::unique_ptr<HostGraph> hg(new HostGraph());
         std::string err;
-        int rc = parse_disk_v2(in.hnsw_graph, in.hnsw_graph_len, in.n_vectors, hg, err);
+        int rc = parse_disk_v2(in.hnsw_graph, in.hnsw_graph_len, g_nodes, *hg, err);
         if (rc != NIDX_OK) return fail(rc, "%s", err.c_str());
-        int32_t r = seg.upload_graph(hg);
-        if (r != NIDX_OK) return r;
+        if (g_nodes < in.n_vectors) {
+            // the reusable part of a merge (segment.rs:143-153): kept on the host until extend_hnsw
+            rc = attach_edge_weights(*hg, in.hnsw_graph, in.hnsw_graph_len, in.hnsw_edges, in.n_hnsw_edges, err);
+            if (rc != NIDX_OK) return fail(rc, "%s", err.c_str());
+            fix_broken_graph(*hg);
+            seg.base_nodes = g_nodes;
+            seg.base_graph = std::move(hg);
+        } else {
+            int32_t r = seg.upload_graph(*hg);
+            if (r != NIDX_OK) return r;
+        }
     }
     NIDX_HIP(hipStreamSynchronize(stream));
     return NIDX_OK;
@@ -600,7 +611,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len) {
     return (int32_t)g_last_error.size();
 }
 
-int32_t nidx_gpu_abi_version(void) { return 1; }
+int32_t nidx_gpu_abi_version(void) { return 2; }
 
 int32_t nidx_gpu_device_count(int32_t *count_out) {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");

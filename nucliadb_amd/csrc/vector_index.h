@@ -38,6 +38,9 @@ struct VectorSegment {
     DevBuf g_l0_w, g_upper_w;            // edge weights (built graphs only)
     uint32_t ep_node = 0, ep_layer = 0;
     std::vector<uint8_t> top_layer;
+    // merge with graph reuse: the graph of the first base_nodes vectors, waiting for extend_hnsw
+    uint32_t base_nodes = 0;
+    std::unique_ptr<HostGraph> base_graph;
 
     int32_t upload_graph(const HostGraph &hg);
     GraphDev graph_dev() const;
@@ -75,7 +78,7 @@ struct VectorIndex {
                         uint32_t *out_count, int32_t *out_method, uint64_t *out_matching);
     // evaluates `prog` for segment s into scratch_filter (already intersected with alive); returns |filter ∩ alive|
     int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
-    int32_t build_hnsw(uint32_t segment, uint64_t level_seed);
+    int32_t build_hnsw(uint32_t segment, uint64_t level_seed, bool extend = false);
     // request coalescing for single-query callers (coalescer.cpp)
     std::shared_ptr<Coalescer> coalescer;
     int32_t search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,

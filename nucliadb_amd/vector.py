@@ -166,7 +166,10 @@ class VectorSegment:
     the files.  `graph` is an hnsw.graph image (DiskHnswV2) or None."""
 
     def __init__(self, keys: List[str], vectors: np.ndarray, labels: List[List[str]], metadata: List[bytes],
-                 tags: Optional[set] = None, graph: Optional[bytes] = None):
+                 tags: Optional[set] = None, graph: Optional[bytes] = None, graph_edges: Optional[np.ndarray] = None,
+                 graph_nodes: int = 0):
+        self.graph_edges = None if graph_edges is None else np.ascontiguousarray(graph_edges, dtype=np.float32)
+        self.graph_nodes = graph_nodes  # 0 = the image covers every vector; else only the first graph_nodes (merge reuse)
         self.keys = keys
         self.vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         self.labels = labels
@@ -292,6 +295,37 @@ def segment_create(elems: Iterable[Elem], config: VectorConfig, tags: Optional[s
     return VectorSegment([e.key for e in elems], vectors, [list(e.labels) for e in elems], [e.metadata for e in elems], tags)
 
 
+def segment_merge(operants: Sequence[Tuple[VectorSegment, Optional[np.ndarray]]], config: VectorConfig) -> VectorSegment:
+    """segment::merge (segment.rs:92-197) minus the files: operands sorted largest first, the alive
+    paragraphs of each concatenated in that order; when the largest operand has no deletions its HNSW
+    graph (and edge weights) is carried over for reuse, otherwise the merged segment has no graph.
+    `operants` = [(segment, alive mask or None)]."""
+    if not operants:
+        raise NidxGpuError(_lib.NIDX_ERR_EMPTY_MERGE, "Can not merge zero segments")
+    ops = sorted(operants, key=lambda t: -t[0].records)
+    tags = ops[0][0].tags
+    for seg, _ in ops:
+        if seg.tags != tags:
+            raise NidxGpuError(_lib.NIDX_ERR_INVALID_ARGUMENT, "Not all of the merged segments have the same tags")
+    keys, labels, metadata, rows = [], [], [], []
+    for seg, alive in ops:
+        idx = range(seg.records) if alive is None else np.nonzero(alive)[0].tolist()
+        for i in idx:
+            keys.append(seg.keys[i])
+            labels.append(list(seg.labels[i]))
+            metadata.append(seg.metadata[i])
+        rows.append(seg.vectors if alive is None else seg.vectors[np.asarray(alive, dtype=bool)])
+    vectors = np.vstack(rows) if rows else np.zeros((0, config.dimension), np.float32)
+    first, first_alive = ops[0]
+    reuse = first.graph is not None and not first.graph_nodes and (first_alive is None or bool(np.all(first_alive)))
+    if reuse and first.records < len(keys):
+        return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges,
+                             graph_nodes=first.records)
+    if reuse:
+        return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges)
+    return VectorSegment(keys, vectors, labels, metadata, tags)
+
+
 def _bitset(mask: np.ndarray) -> np.ndarray:
     n = mask.shape[0]
     words = (n + 63) // 64
@@ -361,6 +395,10 @@ class VectorSearcher:
             c_segs[i].n_paragraphs = seg.records
             c_segs[i].hnsw_graph = graph.ctypes.data if graph is not None else None
             c_segs[i].hnsw_graph_len = len(seg.graph) if seg.graph else 0
+            c_segs[i].hnsw_graph_nodes = seg.graph_nodes if seg.graph else 0
+            has_edges = seg.graph is not None and seg.graph_edges is not None and len(seg.graph_edges)
+            c_segs[i].hnsw_edges = seg.graph_edges.ctypes.data if has_edges else None
+            c_segs[i].n_hnsw_edges = len(seg.graph_edges) if has_edges else 0
             c_segs[i].alive_bitset = bits.ctypes.data
             c_segs[i].paragraph_key_ids = key_ids.ctypes.data if seg.records else None
             self._segments.append(seg)
@@ -392,6 +430,10 @@ class VectorSearcher:
     def build_hnsw(self, segment: int = 0, level_seed: int = 2):
         """HnswBuilder on the device (hnsw/build.rs); the reference seeds the level RNG with 2."""
         _lib.check(_lib.lib().nidx_gpu_vector_build_hnsw(self._handle, segment, level_seed))
+
+    def extend_hnsw(self, segment: int = 0, level_seed: int = 2):
+        """The graph-reuse half of segment::merge (segment.rs:137-167): insert the vectors after the reused graph."""
+        _lib.check(_lib.lib().nidx_gpu_vector_extend_hnsw(self._handle, segment, level_seed))
 
     def serialize_hnsw(self, segment: int = 0) -> Tuple[bytes, np.ndarray]:
         glen, nedges = C.c_uint64(0), C.c_uint64(0)

@@ -21,7 +21,7 @@ x = torch.rand((a.n, a.d), generator=g, device=dev) * 2 - 1
 x /= x.norm(dim=1, keepdim=True)
 xh = x.cpu().numpy(); del x
 cfg = _lib.VectorConfigC(a.d, 1, 0, 0)
-seg = _lib.VectorSegmentC(xh.ctypes.data, a.d * 4, a.n, None, a.n, None, 0, None, None)
+seg = _lib.VectorSegmentC(xh.ctypes.data, a.d * 4, a.n, None, a.n, None, 0, 0, None, 0, None, None)
 h = C.c_void_p()
 _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)))
 t0 = time.time(); _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2)); print("build_s", time.time() - t0, flush=True)

@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(L):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/nidx_gpu.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.nidx_gpu_abi_version() == 1
+    assert L.nidx_gpu_abi_version() == 2
 
 
 def test_no_cpu_fallback_when_device_missing(L):
@@ -36,7 +36,7 @@ def test_no_cpu_fallback_when_device_missing(L):
         pytest.skip("a GPU is present")
     cfg = _lib.VectorConfigC(4, 0, 0, 0)
     x = np.zeros((2, 4), np.float32)
-    seg = _lib.VectorSegmentC(x.ctypes.data, 16, 2, None, 2, None, 0, None, None)
+    seg = _lib.VectorSegmentC(x.ctypes.data, 16, 2, None, 2, None, 0, 0, None, 0, None, None)
     h = C.c_void_p()
     rc = L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h))
     assert rc == _lib.NIDX_ERR_DEVICE and not h

@@ -172,3 +172,68 @@ def test_device_graph_at_768d_is_searched_identically_by_the_oracle(orc):
         assert np.array_equal(vec[i, : count[i]], wv), i
         assert np.array_equal(score[i, : count[i]].view(np.uint32), ws.view(np.uint32))
     assert r >= 0.5  # half the queries are uniform random points (no structure to find)
+
+
+def test_merge_with_graph_reuse(orc):
+    """segment::merge (segment.rs:92-197) and its tests (segment/tests.rs:379-477): the largest operand's
+    graph is reused when it has no deletions and only the appended vectors are inserted — every stored
+    vector must still find itself (score >= 0.999), recall must hold, and reuse must beat a full rebuild."""
+    import time
+
+    from nucliadb_amd.vector import segment_merge
+
+    rng = np.random.default_rng(91)
+    d = 128
+    big = np.vstack([clustered(rng, d, 40, 160), random_vector(rng, d, 13600)])   # 20000
+    small = [random_vector(rng, d, 900), clustered(rng, d, 5, 160)]               # 900 + 800
+    cfg = VectorConfig(d, Similarity.Dot)
+
+    def seg(x, prefix):
+        n = x.shape[0]
+        return VectorSegment([f"{prefix}-{i}" for i in range(n)], x, [[] for _ in range(n)], [b""] * n)
+
+    s_big = VectorSearcher.open(cfg, [(seg(big, "big"), 1)])
+    s_big.build_hnsw(0)
+    graph, edges = s_big.serialize_hnsw(0)
+    s_big.close()
+    big_seg = VectorSegment([f"big-{i}" for i in range(len(big))], big, [[] for _ in big], [b""] * len(big), graph=graph, graph_edges=edges)
+    dead = np.ones(900, bool)
+    dead[::7] = False                                             # deletions in a SMALL operand do not prevent reuse
+    merged = segment_merge([(seg(small[0], "s0"), dead), (big_seg, None), (seg(small[1], "s1"), None)], cfg)
+    n_total = len(big) + int(dead.sum()) + 800
+    assert merged.records == n_total and merged.graph_nodes == len(big) and merged.keys[0] == "big-0"
+    assert merged.keys[len(big)] == "s0-1"                        # largest first, then by size: s0 (900) before s1 (800)
+    s = VectorSearcher.open(cfg, [(merged, 1)])
+    with pytest.raises(_lib.NidxGpuError):                        # not searchable through HNSW before the new nodes are inserted
+        s.search_batch(VectorSearchRequest(result_per_page=1, min_score=-1.0), merged.vectors[:1], method=_lib.METHOD_HNSW)
+    t0 = time.time()
+    s.extend_hnsw(0)
+    t_reuse = time.time() - t0
+    out_graph, _ = s.serialize_hnsw(0)
+    levels = np.concatenate([orc.hnsw_levels(2, len(big)), orc.hnsw_levels(2, n_total - len(big))])  # a fresh RNG for the new nodes
+    check_invariants(orc, out_graph, n_total, levels)
+    # the reused part is untouched except for reverse links: node degrees of the big segment never shrink below what they were
+    q = np.vstack([merged.vectors[rng.integers(0, len(big), 400)], merged.vectors[len(big):]])
+    req = VectorSearchRequest(result_per_page=3, min_score=-1.0, with_duplicates=True)
+    _, _, vec, score, count = s.search_batch(req, q, method=_lib.METHOD_HNSW)
+    # self-match (segment/tests.rs:379-477).  HNSW at ef=30 misses ~0.7 % of uniform-random 128-d vectors
+    # whichever way the graph was built (a full rebuild misses the same ones: scripts/diag_merge.py)
+    assert (score[:400, 0] >= 0.999).mean() >= 0.98 and (score[400:, 0] >= 0.999).mean() >= 0.98
+    r = recall_at(s, q, 3, _lib.METHOD_HNSW)
+    s.close()
+    full = VectorSearcher.open(cfg, [(seg(merged.vectors, "m"), 1)])
+    full.build_hnsw(0)
+    r_full = recall_at(full, q, 3, _lib.METHOD_HNSW)
+    full.close()
+    assert r >= r_full - 0.03, (r, r_full)                        # as good as a graph built from scratch on the same rows
+    # a deletion in the LARGEST operand forbids reuse: the merged segment carries no graph (full rebuild)
+    alive_big = np.ones(len(big), bool)
+    alive_big[5] = False
+    rebuilt = segment_merge([(big_seg, alive_big), (seg(small[1], "s1"), None)], cfg)
+    assert rebuilt.graph is None and rebuilt.records == len(big) - 1 + 800
+    s2 = VectorSearcher.open(cfg, [(rebuilt, 1)])
+    t0 = time.time()
+    s2.build_hnsw(0)
+    t_full = time.time() - t0
+    s2.close()
+    assert t_full >= 1.5 * t_reuse, (t_full, t_reuse)             # segment/tests.rs:473-474

@@ -35,7 +35,7 @@ def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_d
     cfg = _lib.VectorConfigC(d, sim, 0, 0)
     g = np.frombuffer(graph, np.uint8) if graph is not None else None
     seg = _lib.VectorSegmentC(x.ctypes.data, d * 4, n, None, n, g.ctypes.data if g is not None else None,
-                              len(graph) if graph is not None else 0, alive.ctypes.data if alive is not None else None, None)
+                              len(graph) if graph is not None else 0, 0, None, 0, alive.ctypes.data if alive is not None else None, None)
     h = C.c_void_p()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)))
     try:
