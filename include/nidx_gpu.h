@@ -68,7 +68,9 @@ typedef struct {
     int32_t similarity;          /* NIDX_SIMILARITY_* */
     int32_t normalize_vectors;   /* normalise the QUERY at search time (searcher.rs:246-252) */
     int32_t vector_cardinality;  /* NIDX_CARDINALITY_*; only SINGLE is implemented */
+    uint32_t flags;              /* NIDX_CONFIG_* (VectorConfig::flags, config.rs:25-30) */
 } nidx_gpu_vector_config_t;
+#define NIDX_CONFIG_DISABLE_RABITQ_SEARCH 1u /* flags::DISABLE_RABITQ_SEARCH (config.rs:29) */
 
 /* One open segment as the reference has it after segment::open + apply_deletions
  * (nidx_vector/src/segment.rs:39-90, 428-445): the caller passes the mmap'd files as they lie. */
@@ -98,6 +100,13 @@ typedef struct {
     /* 64-bit identity of each paragraph key (equal key string <=> equal id) used by the
      * cross-segment merge Fssc (searcher.rs:67-96,175-198); NULL => ids unique per segment */
     const uint64_t *paragraph_key_ids;
+    /* vectors.quant (data_store/v2/quant_vector_store.rs:29-64): n_vectors RaBitQ records of
+     * dimension/8 + 8 bytes (rabitq.rs:38-106).  NULL => the segment has no quantized store
+     * (has_quantized() == false) until nidx_gpu_vector_quantize is called.  When present — and unless the
+     * config carries NIDX_CONFIG_DISABLE_RABITQ_SEARCH — NIDX_METHOD_AUTO takes the reference's RaBitQ
+     * branches (segment.rs:506-513). */
+    const uint8_t *quantized;
+    uint64_t quantized_len;
 } nidx_gpu_vector_segment_t;
 
 typedef struct nidx_gpu_vector_index nidx_gpu_vector_index_t;
@@ -124,9 +133,12 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
  * NIDX_METHOD_BRUTE_FORCE_BF16: the batched fallback on the bf16 matrix cores (k <= 32): candidates are
  * ranked with bf16 operands, the 32 best per query are re-scored from the f32 rows in
  * NIDX_ORDER_WAVE64 — returned scores are exact, the id set is the exact top-k up to bf16 ranking
- * error (recall measured in DESIGN.md).  Explicit only. */
+ * error (recall measured in DESIGN.md).  Explicit only.
+ * NIDX_METHOD_RABITQ_HNSW / NIDX_METHOD_RABITQ_BRUTE_FORCE: the two RaBitQ arms (hnsw/search.rs:333-366,
+ * segment.rs:602-611): estimates from the 1-bit codes, error-bounded re-rank with the raw vectors.  AUTO
+ * picks them, like the reference, whenever the segment has a quantized store. */
 enum { NIDX_METHOD_AUTO = 0, NIDX_METHOD_HNSW = 1, NIDX_METHOD_BRUTE_FORCE = 2, NIDX_METHOD_BRUTE_FORCE_MFMA = 3,
-       NIDX_METHOD_BRUTE_FORCE_BF16 = 4 };
+       NIDX_METHOD_BRUTE_FORCE_BF16 = 4, NIDX_METHOD_RABITQ_HNSW = 5, NIDX_METHOD_RABITQ_BRUTE_FORCE = 6 };
 
 /* The request fields the hot path reads (nidx_vector/src/request_types.rs:19-35). */
 typedef struct {
@@ -219,6 +231,15 @@ int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *
                                    uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
 /* Launches and queries served through nidx_gpu_vector_search_one so far. */
 int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out);
+
+/* DataStoreV2::create's quantized writer (data_store/v2.rs:57-76) for one segment of an open index:
+ * EncodedVector::encode (rabitq.rs:75-106) of every vector, on the device; the segment then has a
+ * quantized store.  NIDX_ERR_INVALID_CONFIGURATION unless the config is quantizable (Dot similarity and
+ * dimension % 64 == 0, config.rs:170-173). */
+int32_t nidx_gpu_vector_quantize(nidx_gpu_vector_index_t *index, uint32_t segment);
+/* The bytes of vectors.quant.  Call with out == NULL to get the length. */
+int32_t nidx_gpu_vector_serialize_quantized(nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *out,
+                                            uint64_t out_cap, uint64_t *len_out);
 
 /* use_hnsw (segment.rs:626-660) — exposed so callers can route exactly like the reference. */
 int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq);

@@ -25,6 +25,8 @@ NIDX_ERR_INEXACT = -9
 
 SIMILARITY_DOT, SIMILARITY_COSINE = 0, 1
 METHOD_AUTO, METHOD_HNSW, METHOD_BRUTE_FORCE, METHOD_BRUTE_FORCE_MFMA, METHOD_BRUTE_FORCE_BF16 = 0, 1, 2, 3, 4
+METHOD_RABITQ_HNSW, METHOD_RABITQ_BRUTE_FORCE = 5, 6
+CONFIG_DISABLE_RABITQ_SEARCH = 1
 ORDER_WAVE64, ORDER_SERIAL_FMA = 3, 1
 OCCUR_SHOULD, OCCUR_MUST, OCCUR_MUST_NOT, OCCUR_SHOULD_GROUP = 0, 1, 2, 3
 TF_FREQ, TF_BASIC, CONST_SCORE = 0, 1, 2
@@ -45,6 +47,7 @@ class VectorConfigC(C.Structure):
         ("similarity", C.c_int32),
         ("normalize_vectors", C.c_int32),
         ("vector_cardinality", C.c_int32),
+        ("flags", C.c_uint32),
     ]
 
 
@@ -62,6 +65,8 @@ class VectorSegmentC(C.Structure):
         ("n_hnsw_edges", C.c_uint64),
         ("alive_bitset", C.c_void_p),
         ("paragraph_key_ids", C.c_void_p),
+        ("quantized", C.c_void_p),
+        ("quantized_len", C.c_uint64),
     ]
 
 
@@ -141,6 +146,8 @@ SIGNATURES = {
     "nidx_gpu_normalize": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_vector_build_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "nidx_gpu_vector_extend_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "nidx_gpu_vector_quantize": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "nidx_gpu_vector_serialize_quantized": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nidx_gpu_vector_serialize_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_open": (C.c_int32, [C.POINTER(Bm25SegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
         sh.ctrl[2] = 1;
     }
     __syncthreads();
-    for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
+    const bool entry_mode = a.entry_vec != nullptr;
+    for (int layer = entry_mode ? 0 : (int)a.g.ep_layer; layer >= 1; layer--) {
         layer_search_block<NJ, EFL, EVR>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             uint64_t key = res.l[0].key;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     }
     // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
     const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
-    layer_search_block<NJ, EFL, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
+    if (!entry_mode) layer_search_block<NJ, EFL, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
 
     // ---- closest_up_nodes (search.rs:188-240) ----
     // candidates = the ef neighbours; visited = exactly those; pop best, accept if it passes the
@@ -77,7 +78,17 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     int pool_len = 0, n_res = 0;
     uint32_t vis_count = 0;
     uint64_t dropped_best = NIDX_EMPTY_KEY;
-    if (ctl) {
+    if (ctl && entry_mode) {
+        // RaBitQ arm: the candidates are the re-ranked neighbours, scored with the raw vectors
+        const int n_entry = (int)a.entry_count[qi];
+        for (int i = lane; i < n_entry; i += 64) {
+            const uint32_t addr = a.entry_vec[(size_t)qi * k + i];
+            vis_insert(vis, a.vis_log2, addr);
+            sh.pool[i] = rank_key(a.entry_score[(size_t)qi * k + i], addr);
+        }
+        pool_len = n_entry;
+        vis_count = n_entry;
+    } else if (ctl) {
 #pragma unroll
         for (int i = 0; i < EFL; i++) {
             uint64_t key = res.mine(i);
@@ -208,7 +219,10 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
         }
         if (lane == 0) {
             a.out_count[qi] = (uint32_t)n_res;
-            if (a.stats) {
+            if (a.stats && entry_mode) {
+                // the RaBitQ kernel's counters stay; only overflow flags are added
+                a.stats[(size_t)qi * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS] |= st.flags;
+            } else if (a.stats) {
                 uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
                 o[NIDX_STAT_EVALS] = st.evals;
                 o[NIDX_STAT_EXPANSIONS] = st.expansions;

@@ -141,8 +141,48 @@ struct HnswSearchArgs {
     uint32_t *stats;        // nullptr or [n_queries][NIDX_STAT_STRIDE]
     int eval_rows;          // rows in flight per wave in the distance phase: 2 or 4
     int min_waves;          // register budget: 2 (<=256 VGPR) or 4 (<=128 VGPR) waves per SIMD
+    // entry mode (RaBitQ arm): skip the descent and the layer-0 search, run closest_up_nodes from these
+    // re-ranked entry points (search.rs:354-375).  nullptr = the normal search.
+    const uint32_t *entry_vec;    // [n_queries][k]
+    const float *entry_score;     // [n_queries][k]
+    const uint32_t *entry_count;  // [n_queries]
 };
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
+
+// ---- RaBitQ (rabitq.hip) ----
+struct RabitqQueryDev {   // QueryVector (rabitq.rs:109-122) with the similarity() constants folded
+    float c_dot;          // 2.0 * delta / root_dim
+    float two_low;        // 2.0 * low
+    float c_sumq;         // delta * sum_quantized / root_dim
+    float c_low;          // low * root_dim
+    float root_dim, low, delta;
+    uint32_t sum_quantized;
+};
+struct RabitqSearchArgs {
+    SegDev seg;
+    GraphDev g;               // hnsw only
+    const uint8_t *quant;     // [n][rec_len] vectors.quant records
+    uint32_t rec_len;         // dim / 8 + 8
+    const float *queries;     // [n_queries][dp] raw queries (re-rank)
+    const RabitqQueryDev *qd; // [n_queries]
+    const uint64_t *planes;   // [n_queries][4][dim / 64]
+    uint32_t n_queries;
+    const uint64_t *filter;   // brute force only (the HNSW arm filters in closest_up_nodes)
+    uint32_t k;               // <= 256
+    uint32_t ef;              // hnsw: min(k * 100, 2000) (search.rs:333-340)
+    float min_score;
+    uint32_t *visited;        // hnsw: [n_queries][vis_words] zeroed bitsets over vector addrs
+    uint32_t vis_words;
+    uint32_t *out_vec;        // [n_queries][k]   brute force: the hits; hnsw: the re-ranked entry points
+    float *out_score;
+    uint32_t *out_count;
+    uint32_t *stats;          // nullptr or [n_queries][NIDX_STAT_STRIDE]: estimates, expansions, rows re-ranked, flags
+};
+hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s);
+hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,
+                               uint64_t *planes, hipStream_t s);
+hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s);
+hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s);
 
 // ---- HNSW build (hnsw_build.hip): one batch of concurrent inserts ----
 #define NIDX_BUILD_FOUND_STRIDE 128

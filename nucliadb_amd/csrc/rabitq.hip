@@ -1,0 +1,590 @@
+// rabitq.hip — RaBitQ on gfx950: 1-bit stored codes, 4-bit query codes, popcount estimates and the
+// error-bounded re-rank with the raw f32 rows.
+//
+// Replaces, for quantizable indexes (Dot similarity, dimension % 64 == 0, config.rs:170-173):
+//   EncodedVector::encode            nidx_vector/src/vector_types/rabitq.rs:75-106   rabitq_encode_kernel
+//   QueryVector::from_vector         rabitq.rs:124-157                               rabitq_query_kernel
+//   QueryVector::similarity          rabitq.rs:163-218                               rabitq_estimate()
+//   rerank_top                       rabitq.rs:221-244                               Reranker
+//   brute_force_search, RaBitQ arm   nidx_vector/src/segment.rs:569-623              rabitq_bf_kernel
+//   HnswSearcher::search, RaBitQ arm nidx_vector/src/hnsw/search.rs:306-366          rabitq_hnsw_kernel
+//     (closest_up_nodes then runs in hnsw_search_kernel's entry mode on the re-ranked entry points)
+//
+// All of it is integer popcounts and plain f32 arithmetic in the reference's operation order (the
+// file is compiled with -ffp-contract=off; f32 division and sqrt are correctly rounded), so estimates,
+// error bounds and therefore every admission / re-rank decision are bit-identical to the CPU path.
+// The only f32 sums are dot_quant_original (encode) and the re-rank's raw dot products: both in the
+// canonical WAVE64 order of device_common.h.
+//
+// Work shape: one WAVE per query.  The traversal and the re-rank are sequential decision chains
+// (ef = min(100 k, 2000) results, candidates visited best-first; re-rank thresholds move with
+// every accepted row), so the 64 lanes are spent on the 60 neighbours of one expansion (one
+// 8+D/8-byte code per lane — no cross-lane reduction at all) and on the 64-wide raw dot products.
+// Bound: HBM latency/bytes (D/8+8 bytes per estimate, 4 D per re-ranked row, 256 B per expansion).
+#include "hnsw_device.h"
+
+namespace nidx {
+
+#define RABITQ_EPSILON 1.9f /* rabitq.rs:30 */
+
+// ------------------------------------------------------------------------------------------------
+// bit plumbing: lane l of chunk j owns elements 256 j + 4 l .. + 3; ballots b[c] hold component c of
+// every lane.  Word s (0..3) of the chunk = elements 64 s .. 64 s + 63 = lanes 16 s .. 16 s + 15.
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint64_t spread4(uint64_t x) {  // bit i of a 16-bit value -> bit 4 i
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+__device__ inline uint64_t chunk_word(const unsigned long long (&b)[4], int s) {
+    uint64_t w = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) w |= spread4((b[c] >> (16 * s)) & 0xffffull) << c;
+    return w;
+}
+
+// ---- EncodedVector::encode: one wave per row ------------------------------------------------------
+__global__ __launch_bounds__(256) void rabitq_encode_kernel(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim,
+                                                            uint8_t *out, uint32_t rec_len) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *x = vectors + (size_t)row * dp;
+    uint8_t *rec = out + (size_t)row * rec_len;
+    const float root_dim = sqrtf((float)dim);
+    const float pos = 1.0f / root_dim, neg = -1.0f / root_dim;
+    const int nj = (int)((dim + 255u) / 256u);
+    float acc = 0.f;
+    uint32_t sum_bits = 0;
+    for (int j = 0; j < nj; j++) {
+        const uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+        const bool in = e < dim;
+        float4 v = in ? *reinterpret_cast<const float4 *>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            acc = fmaf(v.x, v.x > 0.0f ? pos : neg, acc);
+            acc = fmaf(v.y, v.y > 0.0f ? pos : neg, acc);
+            acc = fmaf(v.z, v.z > 0.0f ? pos : neg, acc);
+            acc = fmaf(v.w, v.w > 0.0f ? pos : neg, acc);
+        }
+        unsigned long long b[4];
+        b[0] = __ballot(in && v.x > 0.0f);
+        b[1] = __ballot(in && v.y > 0.0f);
+        b[2] = __ballot(in && v.z > 0.0f);
+        b[3] = __ballot(in && v.w > 0.0f);
+        sum_bits += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+        if (lane < 4) {
+            uint32_t w = (uint32_t)j * 4u + (uint32_t)lane;
+            if (w < dim / 64u) *reinterpret_cast<uint64_t *>(rec + 8 + (size_t)w * 8) = chunk_word(b, lane);
+        }
+    }
+    float dot = wave_butterfly_sum(acc);
+    if (lane == 0) {
+        *reinterpret_cast<float *>(rec) = dot;
+        *reinterpret_cast<uint32_t *>(rec + 4) = sum_bits;
+    }
+}
+
+// ---- QueryVector::from_vector: one wave per query ---------------------------------------------------
+__device__ inline unsigned long long f32_as_u64(float x) {  // Rust `as u64`: saturating, NaN -> 0
+    if (!(x > 0.0f)) return 0ull;
+    if (x >= 18446744073709551616.0f) return ~0ull;
+    return (unsigned long long)x;
+}
+
+__global__ __launch_bounds__(256) void rabitq_query_kernel(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim,
+                                                           RabitqQueryDev *qd, uint64_t *planes) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const float *x = queries + (size_t)qi * dp;
+    const uint32_t nw = dim / 64u;
+    uint64_t *pl = planes + (size_t)qi * 4u * nw;
+    const int nj = (int)((dim + 255u) / 256u);
+    // fold (min, max) — order independent
+    float lo = x[0], hi = x[0];
+    for (int j = 0; j < nj; j++) {
+        const uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+        if (e < dim) {
+            float4 v = *reinterpret_cast<const float4 *>(x + e);
+            float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (c[i] < lo) lo = c[i];
+                if (c[i] > hi) hi = c[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        if (ol < lo) lo = ol;
+        if (oh > hi) hi = oh;
+    }
+    hi += 0.00001f;
+    const float delta = (hi - lo) / 16.0f;
+    unsigned long long sumq = 0;
+    for (int j = 0; j < nj; j++) {
+        const uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+        const bool in = e < dim;
+        float4 v = in ? *reinterpret_cast<const float4 *>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long wq[4] = {0, 0, 0, 0};
+        if (in) {
+            wq[0] = f32_as_u64((v.x - lo) / delta);
+            wq[1] = f32_as_u64((v.y - lo) / delta);
+            wq[2] = f32_as_u64((v.z - lo) / delta);
+            wq[3] = f32_as_u64((v.w - lo) / delta);
+            sumq += wq[0] + wq[1] + wq[2] + wq[3];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            unsigned long long b[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) b[c] = __ballot(in && ((wq[c] >> p) & 1ull));
+            if (lane < 4) {
+                uint32_t w = (uint32_t)j * 4u + (uint32_t)lane;
+                if (w < nw) pl[(size_t)p * nw + w] = chunk_word(b, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t l = __shfl_xor((uint32_t)sumq, off, 64), h = __shfl_xor((uint32_t)(sumq >> 32), off, 64);
+        sumq += ((unsigned long long)h << 32) | l;
+    }
+    if (lane == 0) {
+        const float root_dim = sqrtf((float)dim);
+        const float sum_quantized = (float)(uint32_t)sumq;  // `sum_quantized as u32`, then `as f32` (rabitq.rs:152,207)
+        RabitqQueryDev o;
+        o.c_dot = 2.0f * delta / root_dim;               // 2.0 * delta / root_dim   (* dot)
+        o.two_low = 2.0f * lo;                           // 2.0 * low                (* sum_bits / root_dim)
+        o.c_sumq = delta * sum_quantized / root_dim;     // delta * sum_quantized / root_dim
+        o.c_low = lo * root_dim;                         // low * root_dim
+        o.root_dim = root_dim;
+        o.low = lo;
+        o.delta = delta;
+        o.sum_quantized = (uint32_t)sumq;
+        qd[qi] = o;
+    }
+}
+
+// ---- QueryVector::similarity for one stored code (per lane) -------------------------------------------
+// qp: this query's four bit planes in LDS ([4][nw]); every lane reads the same words (broadcast).
+__device__ inline void rabitq_estimate(const uint8_t *rec, const uint64_t *qp, uint32_t nw, const RabitqQueryDev &c,
+                                       float &est, float &err) {
+    const float dqo = *reinterpret_cast<const float *>(rec);
+    const uint32_t sum_bits = *reinterpret_cast<const uint32_t *>(rec + 4);
+    const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + 8);
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint64_t sw = s[w];
+        d0 += (uint32_t)__popcll(qp[w] & sw);
+        d1 += (uint32_t)__popcll(qp[nw + w] & sw);
+        d2 += (uint32_t)__popcll(qp[2 * nw + w] & sw);
+        d3 += (uint32_t)__popcll(qp[3 * nw + w] & sw);
+    }
+    const float dot = (float)(d0 + d1 * 2u + d2 * 4u + d3 * 8u);
+    const float dqq = c.c_dot * dot + c.two_low * (float)sum_bits / c.root_dim - c.c_sumq - c.c_low;
+    est = dqq / dqo;
+    const float dd = dqo * dqo;
+    err = sqrtf((1.0f - dd) / dd) * RABITQ_EPSILON / c.root_dim;
+}
+__device__ inline float rabitq_error(const uint8_t *rec, const RabitqQueryDev &c) {
+    const float dqo = *reinterpret_cast<const float *>(rec);
+    const float dd = dqo * dqo;
+    return sqrtf((1.0f - dd) / dd) * RABITQ_EPSILON / c.root_dim;
+}
+
+// ---- sorted key array in LDS (best first), one wave -----------------------------------------------------
+// Keys: score bits << 32 | (~addr & 0x7fffffff) << 1 | unexpanded flag — ordered like rank_key()
+// (higher score first, then lower address; the flag never decides: addresses are unique in a list).
+__device__ inline uint64_t rq_key(float score, uint32_t addr, uint32_t flag) {
+    uint32_t k = (uint32_t)total_key(score) ^ 0x80000000u;
+    return ((uint64_t)k << 32) | ((uint64_t)((~addr) & 0x7fffffffu) << 1) | flag;
+}
+__device__ inline uint32_t rq_addr(uint64_t key) { return (~(uint32_t)(key >> 1)) & 0x7fffffffu; }
+
+// Inserts nk keeping at most `cap` keys; returns the evicted key (0 if none) and the position of nk
+// (== cap when nk itself did not fit).  keys must have room for cap + 1 entries.
+__device__ inline uint64_t sorted_insert(uint64_t *keys, int &len, int cap, uint64_t nk, int lane, int &pos_out) {
+    int after = 0;  // entries ranking after nk (they move down by one)
+    for (int base = ((len - 1) >> 6) << 6; base >= 0 && len > 0; base -= 64) {
+        const int i = base + lane;
+        const uint64_t v = i < len ? keys[i] : ~0ull;
+        const bool mv = i < len && v < nk;
+        if (mv) keys[i + 1] = v;
+        const int c = __popcll(__ballot(mv));
+        after += c;
+        if (c < 64 && c < len - base) break;  // this chunk held an entry ranking before nk: everything above does too
+    }
+    const int pos = len - after;
+    if (lane == 0) keys[pos] = nk;
+    pos_out = pos;
+    len++;
+    uint64_t evicted = 0;
+    if (len > cap) {
+        evicted = keys[cap];
+        len = cap;
+    }
+    return evicted;
+}
+
+// ---- rerank_top ---------------------------------------------------------------------------------------
+// `best` (LDS, k + 1 keys) holds the k best real scores so far.  feed() takes up to 64 candidates in
+// the reference's iteration order (lane order) and replays `if best.len() < top_k || best_k < upper_bound`
+// / `if real_score >= min_score && (best.len() < top_k || best_k < real_score)` one by one; raw dot products
+// are computed four rows at a time (speculatively — a row evaluated but skipped by the replay costs bytes only).
+struct Reranker {
+    uint64_t *best;
+    int len, k;
+    float best_k, min_score;
+    uint32_t n_eval;
+    const float *vectors;
+    uint32_t dp;
+    const float *q;  // LDS copy of the raw query, [dp]
+
+    __device__ inline void init(uint64_t *best_, int k_, float min_score_, const float *vectors_, uint32_t dp_, const float *q_) {
+        best = best_;
+        len = 0;
+        k = k_;
+        best_k = 0.0f;
+        min_score = min_score_;
+        n_eval = 0;
+        vectors = vectors_;
+        dp = dp_;
+        q = q_;
+    }
+    __device__ inline void feed(bool cand, uint32_t addr, float ub, int lane) {
+        unsigned long long todo = __ballot(cand && (len < k || best_k < ub));
+        const int nj = (int)((dp + 255u) / 256u);
+        while (todo) {
+            int idx[4];
+            int cnt = 0;
+            unsigned long long t = todo;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                idx[i] = t ? __ffsll((long long)t) - 1 : -1;
+                if (t) {
+                    t &= t - 1;
+                    cnt++;
+                }
+            }
+            uint32_t ra[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) ra[i] = __shfl(addr, idx[i] < 0 ? 0 : idx[i], 64);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < nj; j++) {
+                const uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
+                if (e < dp) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(q + e);
+                    float4 x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        x[i] = i < cnt ? *reinterpret_cast<const float4 *>(vectors + (size_t)ra[i] * dp + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i] = fma4(x[i], qv, acc[i]);
+                }
+            }
+            const float red = QReduce<4>::run(acc, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i >= cnt) break;
+                const float real = __shfl(red, (i >> 1) * 32 + (i & 1) * 16, 64);
+                const float ubi = __shfl(ub, idx[i], 64);
+                if (len < k || best_k < ubi) {
+                    n_eval++;
+                    if (real >= min_score && (len < k || best_k < real)) {
+                        int pos;
+                        sorted_insert(best, len, k, rq_key(real, ra[i], 0), lane, pos);
+                        best_k = rank_key_score(best[len - 1]);
+                    }
+                }
+            }
+            todo = t;
+            // thresholds only rise: drop the lanes that can no longer pass
+            if (len >= k) todo &= __ballot(best_k < ub);
+        }
+    }
+    __device__ inline void write(uint32_t *out_vec, float *out_score, uint32_t *out_count, int lane) const {
+        for (int i = lane; i < k; i += 64) {
+            out_vec[i] = i < len ? rq_addr(best[i]) : 0xffffffffu;
+            out_score[i] = i < len ? rank_key_score(best[i]) : 0.f;
+        }
+        if (lane == 0) *out_count = (uint32_t)len;
+    }
+};
+
+// dynamic LDS carve-up shared by the two search kernels
+struct RqShared {
+    uint64_t *planes;  // [4][nw]
+    float *q;          // [dp]
+    uint64_t *best;    // [k + 1]
+    uint64_t *res;     // [ef + 1]            (hnsw only)
+    uint64_t *ties;    // [RABITQ_TIE_CAP]    (hnsw only)
+    uint32_t *vis;     // [1 << RABITQ_UPPER_VIS_LOG2] (hnsw only)
+};
+#define RABITQ_TIE_CAP 64
+#define RABITQ_UPPER_VIS_LOG2 11
+
+__device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
+    RqShared s;
+    size_t off = 0;
+    s.planes = reinterpret_cast<uint64_t *>(smem + off);
+    off += (size_t)4 * nw * 8;
+    s.best = reinterpret_cast<uint64_t *>(smem + off);
+    off += (size_t)(k + 1) * 8;
+    s.res = reinterpret_cast<uint64_t *>(smem + off);
+    off += (size_t)(ef + 1) * 8;
+    s.ties = reinterpret_cast<uint64_t *>(smem + off);
+    off += (size_t)RABITQ_TIE_CAP * 8;
+    off = (off + 15) & ~(size_t)15;
+    s.q = reinterpret_cast<float *>(smem + off);
+    off += (size_t)dp * 4;
+    s.vis = reinterpret_cast<uint32_t *>(smem + off);
+    return s;
+}
+static size_t rq_smem_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool hnsw) {
+    size_t off = (size_t)4 * nw * 8 + (size_t)(k + 1) * 8 + (size_t)(ef + 1) * 8 + (size_t)RABITQ_TIE_CAP * 8;
+    off = (off + 15) & ~(size_t)15;
+    off += (size_t)dp * 4;
+    if (hnsw) off += (size_t)4 << RABITQ_UPPER_VIS_LOG2;
+    return off;
+}
+
+__device__ inline void rq_load_query(const RqShared &sh, const RabitqSearchArgs &a, uint32_t qi, uint32_t nw, int lane) {
+    const uint64_t *gp = a.planes + (size_t)qi * 4u * nw;
+    for (uint32_t i = lane; i < 4u * nw; i += 64) sh.planes[i] = gp[i];
+    const float *gq = a.queries + (size_t)qi * a.seg.dp;
+    for (uint32_t i = lane; i < a.seg.dp; i += 64) sh.q[i] = gq[i];
+}
+
+// ---- brute force, RaBitQ arm (segment.rs:569-623): one wave per query -------------------------------
+// Rows are visited in address order (= the bitset iteration order); every passing row's estimate gives
+// an upper bound, `upper_bound >= min_score` admits it to the candidate list, and rerank_top consumes
+// that list in the same order.
+__global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t nw = a.seg.dim / 64u;
+    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, 0);
+    rq_load_query(sh, a, qi, nw, lane);
+    const RabitqQueryDev qc = a.qd[qi];
+    Reranker rr;
+    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
+    uint32_t n_est = 0;
+    for (uint32_t base = 0; base < a.seg.n; base += 64) {
+        const uint32_t r = base + (uint32_t)lane;
+        bool ok = r < a.seg.n;
+        if (ok) {
+            const uint32_t p = a.seg.para_of_vec ? a.seg.para_of_vec[r] : r;
+            if (a.seg.alive && !bit_test(a.seg.alive, p)) ok = false;
+            if (ok && a.filter && !bit_test(a.filter, p)) ok = false;
+        }
+        if (!__any(ok)) continue;
+        float est = 0.f, err = 0.f;
+        if (ok) rabitq_estimate(a.quant + (size_t)r * a.rec_len, sh.planes, nw, qc, est, err);
+        n_est += (uint32_t)__popcll(__ballot(ok));
+        const float ub = est + err;
+        rr.feed(ok && ub >= a.min_score, r, ub, lane);
+    }
+    rr.write(a.out_vec + (size_t)qi * a.k, a.out_score + (size_t)qi * a.k, a.out_count + qi, lane);
+    if (a.stats && lane == 0) {
+        uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
+        o[NIDX_STAT_EVALS] = n_est;
+        o[NIDX_STAT_EXPANSIONS] = 0;
+        o[NIDX_STAT_VISITED] = rr.n_eval;  // raw rows re-ranked
+        o[NIDX_STAT_FLAGS] = 0;
+    }
+}
+
+// ---- HNSW, RaBitQ arm (hnsw/search.rs:242-366): one wave per query ------------------------------------
+// layer_search on estimates.  `res` is the result set, sorted, each key carrying an "unexpanded" flag:
+// the candidate heap of the reference is exactly the unexpanded part of the result set, plus entries
+// evicted from it whose score still EQUALS the worst result's (`cs < ws` does not stop on those) — kept
+// in `ties`.  An entry evicted with a lower score than ws can only ever terminate the search when it is
+// popped, and by then nothing better is left, so it is dropped on the spot.
+struct RqLayer {
+    uint64_t *res, *ties;
+    int len, n_ties, cur;  // cur: every entry before it is expanded
+};
+
+__device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, int lane, uint32_t &flags) {
+    int pos;
+    const uint64_t ev = sorted_insert(L.res, L.len, kk, rq_key(est, addr, 1u), lane, pos);
+    if (pos < L.cur) L.cur = pos;
+    if (ev != 0 && (ev & 1ull) && L.len > 0) {
+        // still a candidate only while its score is not below the worst result's
+        const float ws = rank_key_score(L.res[L.len - 1]);
+        if (!(rank_key_score(ev) < ws)) {
+            if (L.n_ties < RABITQ_TIE_CAP) {
+                if (lane == 0) L.ties[L.n_ties] = ev;
+                L.n_ties++;
+            } else {
+                flags |= NIDX_FLAG_POOL_INEXACT;
+            }
+        }
+    }
+}
+
+// pops the best candidate; returns false when the search is over
+__device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node) {
+    while (L.cur < L.len) {
+        const int i = L.cur + lane;
+        const bool un = i < L.len && (L.res[i] & 1ull);
+        const unsigned long long m = __ballot(un);
+        if (m) {
+            const int idx = L.cur + __ffsll((long long)m) - 1;
+            const uint64_t key = L.res[idx];
+            if (lane == 0) L.res[idx] = key & ~1ull;
+            L.cur = idx + 1;
+            node = rq_addr(key);
+            return true;  // a member of the result set never scores below its worst entry
+        }
+        L.cur += 64;
+    }
+    if (L.cur > L.len) L.cur = L.len;
+    if (L.n_ties == 0) return false;
+    // best of the evicted ties
+    uint64_t b = lane < L.n_ties ? L.ties[lane] : 0ull;
+    const uint64_t best = wave_max_u64(b);
+    const unsigned long long m = __ballot(b == best);
+    const int idx = __ffsll((long long)m) - 1;
+    const uint64_t last = L.ties[L.n_ties - 1];
+    if (lane == 0) L.ties[idx] = last;
+    L.n_ties--;
+    const float ws = rank_key_score(L.res[L.len - 1]);
+    if (rank_key_score(best) < ws) return false;  // `cs < ws => break` (search.rs:271-277)
+    node = rq_addr(best);
+    return true;
+}
+
+__global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t nw = a.seg.dim / 64u;
+    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef);
+    rq_load_query(sh, a, qi, nw, lane);
+    const RabitqQueryDev qc = a.qd[qi];
+    uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
+    uint32_t n_est = 0, n_exp = 0, flags = 0;
+
+    uint32_t ep = a.g.ep_node;
+    RqLayer L;
+    L.res = sh.res;
+    L.ties = sh.ties;
+    for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
+        const int kk = layer == 0 ? (int)a.ef : 1;
+        L.len = 0;
+        L.n_ties = 0;
+        L.cur = 0;
+        uint32_t vis_count = 0;
+        if (layer > 0) {
+            for (uint32_t i = lane; i < (1u << RABITQ_UPPER_VIS_LOG2); i += 64) sh.vis[i] = NIDX_VIS_EMPTY;
+            if (lane == 0) vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, ep);
+            vis_count = 1;
+        } else if (lane == 0) {
+            atomicOr(&gvis[ep >> 5], 1u << (ep & 31));
+        }
+        {  // the entry point is admitted unconditionally (search.rs:256-261)
+            float est, err;
+            rabitq_estimate(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
+            n_est++;
+            rq_admit(L, kk, est, ep, lane, flags);
+        }
+        uint32_t node;
+        while (rq_pop(L, lane, node)) {
+            uint32_t deg;
+            const uint32_t w = load_edge_word(a.g, node, layer, lane, deg);
+            const bool is_edge = lane >= 1 && lane <= (int)deg;
+            bool fresh = false;
+            if (is_edge) {
+                if (layer > 0) fresh = vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, w);
+                else fresh = (atomicOr(&gvis[w >> 5], 1u << (w & 31)) & (1u << (w & 31))) == 0;
+            }
+            n_exp++;
+            const unsigned long long fm = __ballot(fresh);
+            if (layer > 0) {
+                vis_count += (uint32_t)__popcll(fm);
+                if (vis_count > (3u << RABITQ_UPPER_VIS_LOG2) / 4u) {
+                    flags |= NIDX_FLAG_VISITED_OVERFLOW;
+                    break;
+                }
+            }
+            float est = 0.f, err = 0.f;
+            if (fresh) rabitq_estimate(a.quant + (size_t)w * a.rec_len, sh.planes, nw, qc, est, err);
+            n_est += (uint32_t)__popcll(fm);
+            // `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295)
+            unsigned long long todo = fm;
+            while (todo) {
+                const float ws = rank_key_score(L.res[L.len - 1]);
+                if (L.len >= kk) {
+                    todo &= __ballot(fresh && est > ws);
+                    if (!todo) break;
+                }
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= ~(1ull << j);
+                const float sj = __shfl(est, j, 64);
+                if (sj > ws || L.len < kk) rq_admit(L, kk, sj, __shfl(w, j, 64), lane, flags);
+            }
+        }
+        ep = rq_addr(L.res[0]);  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
+    }
+
+    // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
+    Reranker rr;
+    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
+    for (int base = 0; base < L.len; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < L.len;
+        uint32_t addr = 0;
+        float ub = 0.f;
+        if (ok) {
+            const uint64_t key = L.res[i];
+            addr = rq_addr(key);
+            ub = rank_key_score(key) + rabitq_error(a.quant + (size_t)addr * a.rec_len, qc);
+        }
+        rr.feed(ok, addr, ub, lane);
+    }
+    rr.write(a.out_vec + (size_t)qi * a.k, a.out_score + (size_t)qi * a.k, a.out_count + qi, lane);
+    if (a.stats && lane == 0) {
+        uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
+        o[NIDX_STAT_EVALS] = n_est;
+        o[NIDX_STAT_EXPANSIONS] = n_exp;
+        o[NIDX_STAT_VISITED] = rr.n_eval;
+        o[NIDX_STAT_FLAGS] = flags;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------
+hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rabitq_encode_kernel, dim3((n + 3) / 4), dim3(256), 0, s, vectors, n, dp, dim, out, dim / 8 + 8);
+    return hipGetLastError();
+}
+hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,
+                               uint64_t *planes, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(rabitq_query_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, queries, nq, dp, dim, qd, planes);
+    return hipGetLastError();
+}
+hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s) {
+    if (a.n_queries == 0) return hipSuccess;
+    size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, 0, false);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_bf_kernel, dim3(a.n_queries), dim3(64), smem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
+    if (a.n_queries == 0) return hipSuccess;
+    size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw_kernel, dim3(a.n_queries), dim3(64), smem, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace nidx

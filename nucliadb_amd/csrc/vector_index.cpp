@@ -135,7 +135,7 @@ SegDev VectorSegment::seg_dev(int similarity) const {
 
 uint64_t VectorSegment::bytes() const {
     return vectors.bytes + norm2.bytes + norm2_serial.bytes + vectors16.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
-           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes + f_offsets.bytes + f_ids.bytes;
+           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes + f_offsets.bytes + f_ids.bytes + quant.bytes;
 }
 
 static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_vector_segment_t &in, VectorSegment &seg,
@@ -202,6 +202,19 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
         NIDX_HIP(hipMemcpy(seg.alive.p, seg.alive_host.data(), (size_t)words * 8, hipMemcpyHostToDevice));
     }
     if (in.paragraph_key_ids) seg.key_ids.assign(in.paragraph_key_ids, in.paragraph_key_ids + in.n_paragraphs);
+    // vectors.quant
+    seg.has_quant = false;
+    if (in.quantized && in.n_vectors > 0) {
+        if (cfg.similarity != NIDX_SIMILARITY_DOT || (d % 64u) != 0)
+            return fail(NIDX_ERR_INVALID_CONFIGURATION, "a quantized store needs Dot similarity and dimension %% 64 == 0");
+        const uint64_t need = (uint64_t)in.n_vectors * (d / 8 + 8);
+        if (in.quantized_len != need)
+            return fail(NIDX_ERR_INVALID_ARGUMENT, "vectors.quant holds %llu bytes, expected %llu", (unsigned long long)in.quantized_len,
+                        (unsigned long long)need);
+        NIDX_HIP(seg.quant.alloc(need));
+        NIDX_HIP(hipMemcpy(seg.quant.p, in.quantized, need, hipMemcpyHostToDevice));
+        seg.has_quant = true;
+    }
     // graph
     seg.has_graph = false;
     if (in.hnsw_graph && in.hnsw_graph_len > 0 && in.n_vectors > 0) {
@@ -251,6 +264,86 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.stats = d_stats;
         a.eval_rows = eval_rows;
         a.min_waves = min_waves;
+        a.entry_vec = nullptr;
+        a.entry_score = nullptr;
+        a.entry_count = nullptr;
+        NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
+        return NIDX_OK;
+    }
+    if (method == NIDX_METHOD_RABITQ_HNSW || method == NIDX_METHOD_RABITQ_BRUTE_FORCE) {
+        if (!seg.has_quant) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no quantized store", s);
+        const bool hnsw = method == NIDX_METHOD_RABITQ_HNSW;
+        const uint32_t nw = seg.dim / 64u;
+        NIDX_HIP(scratch_rq.reserve((size_t)nq * sizeof(RabitqQueryDev)));
+        NIDX_HIP(scratch_planes.reserve((size_t)nq * 4 * nw * 8));
+        NIDX_HIP(launch_rabitq_query(d_queries, nq, seg.dp, seg.dim, scratch_rq.as<RabitqQueryDev>(), scratch_planes.as<uint64_t>(), st));
+        RabitqSearchArgs r;
+        r.seg = seg.seg_dev(cfg.similarity);
+        r.g = seg.graph_dev();
+        r.quant = seg.quant.as<uint8_t>();
+        r.rec_len = seg.dim / 8 + 8;
+        r.queries = d_queries;
+        r.qd = scratch_rq.as<RabitqQueryDev>();
+        r.planes = scratch_planes.as<uint64_t>();
+        r.filter = d_filter;
+        r.k = k;
+        r.ef = 0;
+        r.min_score = min_score;
+        r.visited = nullptr;
+        r.vis_words = 0;
+        r.stats = d_stats;
+        if (!hnsw) {
+            r.n_queries = nq;
+            r.out_vec = d_out_vec;
+            r.out_score = d_out_score;
+            r.out_count = d_out_count;
+            NIDX_HIP(launch_rabitq_bf(r, st));
+            return NIDX_OK;
+        }
+        // last_layer_k = min(k * RERANKING_FACTOR, RERANKING_LIMIT) (hnsw/search.rs:333-340)
+        r.ef = std::min<uint32_t>(k * 100u, 2000u);
+        r.vis_words = (seg.n + 31u) / 32u;
+        NIDX_HIP(scratch_entry_vec.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_entry_score.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_entry_count.reserve((size_t)nq * 4));
+        // the visited bitsets of one launch are capped at 1 GiB: larger batches go in slices
+        const uint32_t slice = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / ((uint64_t)r.vis_words * 4)));
+        NIDX_HIP(scratch_vis.reserve((size_t)slice * r.vis_words * 4));
+        r.visited = scratch_vis.as<uint32_t>();
+        for (uint32_t q0 = 0; q0 < nq; q0 += slice) {
+            const uint32_t cnt = std::min(slice, nq - q0);
+            NIDX_HIP(hipMemsetAsync(scratch_vis.p, 0, (size_t)cnt * r.vis_words * 4, st));
+            RabitqSearchArgs rs = r;
+            rs.n_queries = cnt;
+            rs.queries = d_queries + (size_t)q0 * seg.dp;
+            rs.qd = r.qd + q0;
+            rs.planes = r.planes + (size_t)q0 * 4 * nw;
+            rs.out_vec = scratch_entry_vec.as<uint32_t>() + (size_t)q0 * k;
+            rs.out_score = scratch_entry_score.as<float>() + (size_t)q0 * k;
+            rs.out_count = scratch_entry_count.as<uint32_t>() + q0;
+            rs.stats = d_stats ? d_stats + (size_t)q0 * NIDX_STAT_STRIDE : nullptr;
+            NIDX_HIP(launch_rabitq_hnsw(rs, st));
+        }
+        // closest_up_nodes from the re-ranked entry points, on the raw query (search.rs:369-375)
+        HnswSearchArgs a;
+        a.seg = seg.seg_dev(cfg.similarity);
+        a.g = seg.graph_dev();
+        a.queries = d_queries;
+        a.n_queries = nq;
+        a.filter = d_filter;
+        a.k = k;
+        a.min_score = min_score;
+        a.with_duplicates = with_duplicates ? 1 : 0;
+        a.vis_log2 = vis_log2;
+        a.out_vec = d_out_vec;
+        a.out_score = d_out_score;
+        a.out_count = d_out_count;
+        a.stats = d_stats;  // entry mode only ORs its overflow flags into the RaBitQ counters
+        a.eval_rows = eval_rows;
+        a.min_waves = min_waves;
+        a.entry_vec = scratch_entry_vec.as<uint32_t>();
+        a.entry_score = scratch_entry_score.as<float>();
+        a.entry_count = scratch_entry_count.as<uint32_t>();
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -446,6 +539,22 @@ int32_t VectorIndex::eval_filter_program(uint32_t si, const nidx_gpu_filter_prog
     return NIDX_OK;
 }
 
+int32_t VectorIndex::quantize(uint32_t si) {
+    std::lock_guard<std::mutex> lock(mu);
+    NIDX_HIP(hipSetDevice(device));
+    VectorSegment &seg = segs[si];
+    // VectorConfig::quantizable_vectors (config.rs:170-173)
+    if (cfg.similarity != NIDX_SIMILARITY_DOT || (cfg.dimension % 64u) != 0)
+        return fail(NIDX_ERR_INVALID_CONFIGURATION, "vectors are quantizable only with Dot similarity and dimension %% 64 == 0");
+    seg.has_quant = false;
+    if (seg.n == 0) return NIDX_OK;
+    NIDX_HIP(seg.quant.alloc((size_t)seg.n * (seg.dim / 8 + 8)));
+    NIDX_HIP(launch_rabitq_encode(seg.vectors.as<float>(), seg.n, seg.dp, seg.dim, seg.quant.as<uint8_t>(), stream));
+    NIDX_HIP(hipStreamSynchronize(stream));
+    seg.has_quant = true;
+    return NIDX_OK;
+}
+
 int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
                                  const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
                                  uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
@@ -459,7 +568,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
     if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
     if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 256 is not supported (got %u)", k);
-    if (p.method < 0 || p.method > 4) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
+    if (p.method < 0 || p.method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
     // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
     const uint32_t dp = (d + 3u) & ~3u;
@@ -492,10 +601,14 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         hc[s].assign(nq, 0);
         if (matching == 0 || seg.n == 0) continue;
         int method = p.method;
-        if (method == NIDX_METHOD_AUTO)
-            method = (seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, false)) ? NIDX_METHOD_HNSW
-                                                                                      : NIDX_METHOD_BRUTE_FORCE;
-        if (method == NIDX_METHOD_HNSW && !seg.has_graph)
+        if (method == NIDX_METHOD_AUTO) {
+            // OpenSegment::_search (segment.rs:506-513,535-555): RaBitQ whenever the store has quantized vectors
+            const bool rabitq = rabitq_enabled(seg);
+            const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, rabitq);
+            method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
+                            : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);
+        }
+        if ((method == NIDX_METHOD_HNSW || method == NIDX_METHOD_RABITQ_HNSW) && !seg.has_graph)
             return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %zu has no HNSW graph", s);
         if (out_method) out_method[s] = method;
         const uint64_t *d_filter = nullptr;
@@ -514,7 +627,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
                                                scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
                                                scratch_stats.as<uint32_t>(), vis_log2, stream);
             if (rc != NIDX_OK) return rc;
-            if (method != NIDX_METHOD_HNSW) break;
+            if (method != NIDX_METHOD_HNSW && method != NIDX_METHOD_RABITQ_HNSW) break;
             std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
             NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, stream));
             NIDX_HIP(hipStreamSynchronize(stream));
@@ -611,7 +724,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len) {
     return (int32_t)g_last_error.size();
 }
 
-int32_t nidx_gpu_abi_version(void) { return 2; }
+int32_t nidx_gpu_abi_version(void) { return 3; }
 
 int32_t nidx_gpu_device_count(int32_t *count_out) {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");
@@ -706,6 +819,27 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
     const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
     if (!idx || !n_out || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
     *n_out = idx->segs[segment].n_paragraphs;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_vector_quantize(nidx_gpu_vector_index_t *index, uint32_t segment) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
+    return idx->quantize(segment);
+}
+
+int32_t nidx_gpu_vector_serialize_quantized(nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *out, uint64_t out_cap,
+                                            uint64_t *len_out) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size() || !len_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    VectorSegment &seg = idx->segs[segment];
+    if (!seg.has_quant) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no quantized store", segment);
+    *len_out = seg.quant.bytes;
+    if (!out) return NIDX_OK;
+    if (out_cap < seg.quant.bytes) return fail(NIDX_ERR_INVALID_ARGUMENT, "output buffer too small");
+    NIDX_HIP(hipSetDevice(idx->device));
+    NIDX_HIP(hipMemcpy(out, seg.quant.p, seg.quant.bytes, hipMemcpyDeviceToHost));
     return NIDX_OK;
 }
 

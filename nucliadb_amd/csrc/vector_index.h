@@ -38,6 +38,9 @@ struct VectorSegment {
     DevBuf g_l0_w, g_upper_w;            // edge weights (built graphs only)
     uint32_t ep_node = 0, ep_layer = 0;
     std::vector<uint8_t> top_layer;
+    // vectors.quant: RaBitQ records [n][dim/8 + 8] (absent => has_quantized() == false)
+    DevBuf quant;
+    bool has_quant = false;
     // merge with graph reuse: the graph of the first base_nodes vectors, waiting for extend_hnsw
     uint32_t base_nodes = 0;
     std::unique_ptr<HostGraph> base_graph;
@@ -65,7 +68,9 @@ struct VectorIndex {
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
-        scratch_stats;
+        scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count;
+    bool rabitq_enabled(const VectorSegment &seg) const { return seg.has_quant && !(cfg.flags & NIDX_CONFIG_DISABLE_RABITQ_SEARCH); }
+    int32_t quantize(uint32_t segment);
 
     int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                   bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,

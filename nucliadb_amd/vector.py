@@ -45,13 +45,21 @@ class VectorConfig:
     similarity: Similarity = Similarity.Dot
     normalize_vectors: bool = False
     vector_cardinality: VectorCardinality = VectorCardinality.Single
+    flags: List[str] = field(default_factory=list)  # config.rs:25-30; "disable_rabitq_search" is the one the search path reads
+
+    DISABLE_RABITQ_SEARCH = "disable_rabitq_search"
 
     @classmethod
     def for_paragraphs(cls, dimension: int) -> "VectorConfig":
         return cls(dimension=dimension)
 
+    def quantizable_vectors(self) -> bool:
+        """config.rs:170-173"""
+        return self.similarity == Similarity.Dot and self.dimension % 64 == 0
+
     def to_c(self) -> _lib.VectorConfigC:
-        return _lib.VectorConfigC(self.dimension, self.similarity.value, int(self.normalize_vectors), self.vector_cardinality.value)
+        flags = _lib.CONFIG_DISABLE_RABITQ_SEARCH if self.DISABLE_RABITQ_SEARCH in self.flags else 0
+        return _lib.VectorConfigC(self.dimension, self.similarity.value, int(self.normalize_vectors), self.vector_cardinality.value, flags)
 
 
 @dataclass
@@ -167,7 +175,9 @@ class VectorSegment:
 
     def __init__(self, keys: List[str], vectors: np.ndarray, labels: List[List[str]], metadata: List[bytes],
                  tags: Optional[set] = None, graph: Optional[bytes] = None, graph_edges: Optional[np.ndarray] = None,
-                 graph_nodes: int = 0):
+                 graph_nodes: int = 0, quantized: Optional[np.ndarray] = None):
+        # vectors.quant: [records][dimension/8 + 8] RaBitQ records (None = the store has no quantized vectors)
+        self.quantized = None if quantized is None else np.ascontiguousarray(quantized, dtype=np.uint8)
         self.graph_edges = None if graph_edges is None else np.ascontiguousarray(graph_edges, dtype=np.float32)
         self.graph_nodes = graph_nodes  # 0 = the image covers every vector; else only the first graph_nodes (merge reuse)
         self.keys = keys
@@ -316,14 +326,20 @@ def segment_merge(operants: Sequence[Tuple[VectorSegment, Optional[np.ndarray]]]
             metadata.append(seg.metadata[i])
         rows.append(seg.vectors if alive is None else seg.vectors[np.asarray(alive, dtype=bool)])
     vectors = np.vstack(rows) if rows else np.zeros((0, config.dimension), np.float32)
+    # quantized vectors are copied when every operand has them (data_store/v2.rs:104-113); otherwise the caller
+    # re-encodes the merged segment with VectorSearcher.quantize()
+    quantized = None
+    if config.quantizable_vectors() and all(seg.quantized is not None for seg, _ in ops):
+        quantized = np.vstack([seg.quantized if alive is None else seg.quantized[np.asarray(alive, dtype=bool)] for seg, alive in ops])
     first, first_alive = ops[0]
     reuse = first.graph is not None and not first.graph_nodes and (first_alive is None or bool(np.all(first_alive)))
     if reuse and first.records < len(keys):
         return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges,
-                             graph_nodes=first.records)
+                             graph_nodes=first.records, quantized=quantized)
     if reuse:
-        return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges)
-    return VectorSegment(keys, vectors, labels, metadata, tags)
+        return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges,
+                             quantized=quantized)
+    return VectorSegment(keys, vectors, labels, metadata, tags, quantized=quantized)
 
 
 def _bitset(mask: np.ndarray) -> np.ndarray:
@@ -401,6 +417,9 @@ class VectorSearcher:
             c_segs[i].n_hnsw_edges = len(seg.graph_edges) if has_edges else 0
             c_segs[i].alive_bitset = bits.ctypes.data
             c_segs[i].paragraph_key_ids = key_ids.ctypes.data if seg.records else None
+            if seg.quantized is not None and seg.records:
+                c_segs[i].quantized = seg.quantized.ctypes.data
+                c_segs[i].quantized_len = seg.quantized.size
             self._segments.append(seg)
         cfg = config.to_c()
         _lib.check(_lib.lib().nidx_gpu_vector_open(C.byref(cfg), c_segs, len(ordered), C.byref(self._handle)))
@@ -434,6 +453,18 @@ class VectorSearcher:
     def extend_hnsw(self, segment: int = 0, level_seed: int = 2):
         """The graph-reuse half of segment::merge (segment.rs:137-167): insert the vectors after the reused graph."""
         _lib.check(_lib.lib().nidx_gpu_vector_extend_hnsw(self._handle, segment, level_seed))
+
+    def quantize(self, segment: int = 0):
+        """DataStoreV2::create's quantized writer (data_store/v2.rs:57-76), on the device."""
+        _lib.check(_lib.lib().nidx_gpu_vector_quantize(self._handle, segment))
+
+    def serialize_quantized(self, segment: int = 0) -> np.ndarray:
+        """The records of vectors.quant, [records][dimension/8 + 8] u8."""
+        n = C.c_uint64()
+        _lib.check(_lib.lib().nidx_gpu_vector_serialize_quantized(self._handle, segment, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        _lib.check(_lib.lib().nidx_gpu_vector_serialize_quantized(self._handle, segment, out.ctypes.data, out.size, C.byref(n)))
+        return out.reshape(-1, self.config.dimension // 8 + 8)
 
     def serialize_hnsw(self, segment: int = 0) -> Tuple[bytes, np.ndarray]:
         glen, nedges = C.c_uint64(0), C.c_uint64(0)

@@ -193,6 +193,97 @@ int orc_total_cmp(float a, float b) {
     return (ka > kb) - (ka < kb);
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * RaBitQ (nidx_vector/src/vector_types/rabitq.rs).  Integer popcounts and plain f32 arithmetic in
+ * the reference's operation order (this file is compiled with -ffp-contract=off), so every value
+ * below except dot_quant_original (a SimSIMD dot: summation order = `order`) is exactly the
+ * reference's.
+ * ------------------------------------------------------------------------------------------ */
+#define RABITQ_EPSILON 1.9f /* rabitq.rs:30 */
+
+size_t orc_rabitq_encoded_len(size_t dim) { return dim / 8 + 8; }
+
+void orc_rabitq_encode(const float *v, size_t dim, int order, uint8_t *out) {
+    float root_dim = sqrtf((float)dim);
+    size_t n_words = dim / 64;
+    uint64_t *quantized = (uint64_t *)calloc(n_words ? n_words : 1, 8);
+    float *v_repr = (float *)malloc((dim ? dim : 1) * sizeof(float));
+    uint32_t sum_bits = 0;
+    for (size_t i = 0; i < dim; i++) {
+        if (v[i] > 0.0f) {
+            quantized[i / 64] += (uint64_t)1 << (i % 64);
+            sum_bits++;
+            v_repr[i] = 1.0f / root_dim;
+        } else {
+            v_repr[i] = -1.0f / root_dim;
+        }
+    }
+    float dot_quant_original = orc_dot(v, v_repr, dim, order);
+    memcpy(out, &dot_quant_original, 4);
+    memcpy(out + 4, &sum_bits, 4);
+    memcpy(out + 8, quantized, n_words * 8);
+    free(quantized);
+    free(v_repr);
+}
+
+/* Rust `f32 as u64`: saturating, NaN -> 0 */
+static inline uint64_t f32_as_u64(float x) {
+    if (!(x > 0.0f)) return 0;
+    if (x >= 18446744073709551616.0f) return UINT64_MAX;
+    return (uint64_t)x;
+}
+
+void orc_rabitq_query_init(orc_rabitq_query *q, const float *v, size_t dim) {
+    float low = v[0], hi = v[0];
+    for (size_t i = 0; i < dim; i++) {
+        if (v[i] < low) low = v[i];
+        if (v[i] > hi) hi = v[i];
+    }
+    hi += 0.00001f;
+    float delta = (hi - low) / 16.0f;
+    size_t n_words = dim / 64;
+    q->planes = (uint64_t *)calloc(4 * (n_words ? n_words : 1), 8);
+    uint64_t sum_quantized = 0;
+    for (size_t i = 0; i < dim; i++) {
+        uint64_t wq = f32_as_u64((v[i] - low) / delta);
+        sum_quantized += wq;
+        q->planes[0 * n_words + i / 64] += (wq % 2) << (i % 64);
+        q->planes[1 * n_words + i / 64] += ((wq / 2) % 2) << (i % 64);
+        q->planes[2 * n_words + i / 64] += ((wq / 4) % 2) << (i % 64);
+        q->planes[3 * n_words + i / 64] += ((wq / 8) % 2) << (i % 64);
+    }
+    q->low = low;
+    q->delta = delta;
+    q->root_dim = sqrtf((float)dim);
+    q->sum_quantized = (uint32_t)sum_quantized;
+    q->n_words = (uint32_t)n_words;
+}
+
+void orc_rabitq_query_free(orc_rabitq_query *q) { free(q->planes); q->planes = NULL; }
+
+void orc_rabitq_similarity(const orc_rabitq_query *q, const uint8_t *encoded, float *estimate, float *error) {
+    float dot_quant_original;
+    uint32_t sum_bits;
+    memcpy(&dot_quant_original, encoded, 4);
+    memcpy(&sum_bits, encoded + 4, 4);
+    uint32_t d[4] = {0, 0, 0, 0};
+    for (int p = 0; p < 4; p++)
+        for (uint32_t w = 0; w < q->n_words; w++) {
+            uint64_t s;
+            memcpy(&s, encoded + 8 + (size_t)w * 8, 8);
+            d[p] += (uint32_t)__builtin_popcountll(q->planes[(size_t)p * q->n_words + w] & s);
+        }
+    float dot = (float)(d[0] + d[1] * 2 + d[2] * 4 + d[3] * 8);
+    float dot_quant_query_vector = 2.0f * q->delta / q->root_dim * dot
+                                   + 2.0f * q->low * (float)sum_bits / q->root_dim
+                                   - q->delta * (float)q->sum_quantized / q->root_dim
+                                   - q->low * q->root_dim;
+    *estimate = dot_quant_query_vector / dot_quant_original;
+    float d2 = dot_quant_original * dot_quant_original;
+    *error = sqrtf((1.0f - d2) / d2) * RABITQ_EPSILON / q->root_dim;
+}
+
 /* ------------------------------------------------------------------------------------------
  * small containers
  * ------------------------------------------------------------------------------------------ */
@@ -430,6 +521,7 @@ typedef struct {
     const float *query;      /* SearchVector::Query, or stored vector for SearchVector::Stored */
     float min_score;
     orc_stats *stats;
+    const orc_rabitq_query *rq; /* SearchVector::RabitQ when set: similarity() = the estimate (segment.rs:331-335) */
 } retr_t;
 
 static inline const float *seg_vec(const orc_segment *seg, uint32_t a) { return seg->vectors + (size_t)a * seg->dim; }
@@ -437,6 +529,11 @@ static inline uint32_t seg_paragraph(const orc_segment *seg, uint32_t a) { retur
 
 static inline float retr_sim(const retr_t *r, uint32_t a) {
     if (r->stats) r->stats->distance_evals++;
+    if (r->rq) {
+        float est, err;
+        orc_rabitq_similarity(r->rq, r->seg->quantized + (size_t)a * orc_rabitq_encoded_len(r->seg->dim), &est, &err);
+        return est;
+    }
     return orc_similarity(seg_vec(r->seg, a), r->query, r->seg->dim, r->seg->similarity, r->seg->order);
 }
 
@@ -577,7 +674,52 @@ static void stable_sort_desc(cnx_t *a, size_t n) {
     }
 }
 
-/* a4. HnswSearcher::search (hnsw/search.rs:306-383), non-RaBitQ branch */
+/* rerank_top (rabitq.rs:221-244).  `best` is a min-heap on the real score; where BinaryHeap leaves ties to its
+ * internals the `better` order decides (the evicted one of two equal scores is the higher address). */
+static size_t rerank_top(const retr_t *exact, const cnx_t *cand, const float *upper_bound, size_t n_cand, size_t k,
+                         cnx_t *out, uint64_t *n_evaluated) {
+    heap_t best;
+    heap_init(&best, 0);
+    float best_k = 0.0f;
+    for (size_t i = 0; i < n_cand; i++) {
+        if (best.len < k || best_k < upper_bound[i]) {
+            float real = retr_sim(exact, cand[i].addr);
+            if (n_evaluated) (*n_evaluated)++;
+            if (real >= exact->min_score && (best.len < k || best_k < real)) {
+                cnx_t c = {cand[i].addr, real};
+                heap_push(&best, c);
+                if (best.len > k) heap_pop(&best);
+                best_k = best.d[0].score;
+            }
+        }
+    }
+    size_t n = best.len;
+    for (size_t i = n; i-- > 0;) out[i] = heap_pop(&best);
+    heap_free(&best);
+    return n;
+}
+
+size_t orc_rabitq_rerank_top(const orc_segment *seg, const float *query, float min_score, const uint32_t *cand,
+                             const float *cand_upper_bound, size_t n_cand, size_t k, uint32_t *out_vec, float *out_score,
+                             uint64_t *n_evaluated) {
+    retr_t exact = {seg, query, min_score, NULL, NULL};
+    cnx_t *c = (cnx_t *)malloc((n_cand ? n_cand : 1) * sizeof(cnx_t));
+    cnx_t *o = (cnx_t *)malloc((k ? k : 1) * sizeof(cnx_t));
+    for (size_t i = 0; i < n_cand; i++) { c[i].addr = cand[i]; c[i].score = 0.0f; }
+    if (n_evaluated) *n_evaluated = 0;
+    size_t n = k ? rerank_top(&exact, c, cand_upper_bound, n_cand, k, o, n_evaluated) : 0;
+    for (size_t i = 0; i < n; i++) { out_vec[i] = o[i].addr; out_score[i] = o[i].score; }
+    free(c); free(o);
+    return n;
+}
+
+static float rabitq_upper_bound(const retr_t *r, uint32_t a) {
+    float est, err;
+    orc_rabitq_similarity(r->rq, r->seg->quantized + (size_t)a * orc_rabitq_encoded_len(r->seg->dim), &est, &err);
+    return est + err; /* EstimatedScore::new_with_error (hnsw/search.rs:69-75) */
+}
+
+/* a4. HnswSearcher::search (hnsw/search.rs:306-383), both branches */
 static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const uint64_t *filter_bits,
                           int with_duplicates, int multi, cnx_t *results) {
     if (k == 0 || g->n_layers == 0) return 0;
@@ -595,9 +737,26 @@ static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const ui
         layer--;
     }
     size_t last_k = k > EF_SEARCH ? k : EF_SEARCH;
+    if (r->rq) { /* RaBitQ: over-fetch, rerank later (:333-340) */
+        last_k = k * ORC_RABITQ_RERANKING_FACTOR;
+        if (last_k > ORC_RABITQ_RERANKING_LIMIT) last_k = ORC_RABITQ_RERANKING_LIMIT;
+    }
     cnx_t *neigh;
     size_t n = layer_search(r, g, 0, last_k, eps, n_ep, &neigh);
     free(eps);
+    retr_t exact = *r;
+    exact.rq = NULL;
+    if (r->rq) { /* rerank with the original vectors (:354-363) */
+        float *ub = (float *)malloc((n ? n : 1) * sizeof(float));
+        for (size_t i = 0; i < n; i++) ub[i] = rabitq_upper_bound(r, neigh[i].addr);
+        cnx_t *rr = (cnx_t *)malloc((k ? k : 1) * sizeof(cnx_t));
+        size_t nr = rerank_top(&exact, neigh, ub, n, k, rr, NULL);
+        free(ub);
+        free(neigh);
+        neigh = rr;
+        n = nr;
+    }
+    r = &exact; /* closest_up_nodes runs on the original query (:369-375) */
     nodefilter_t nf;
     nf.seg = r->seg; nf.filter = filter_bits; nf.dedupe = !with_duplicates; nf.multi = multi;
     nf.results = NULL; nf.n_results = 0;
@@ -612,7 +771,7 @@ static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const ui
 int orc_layer_search(const orc_segment *seg, const float *query, int query_is_stored, uint32_t stored_addr,
                      int layer, size_t k, const uint32_t *entry_points, size_t n_ep,
                      uint32_t *out_vec, float *out_score, orc_stats *stats) {
-    retr_t r = {seg, query_is_stored ? seg_vec(seg, stored_addr) : query, -1.0f, stats};
+    retr_t r = {seg, query_is_stored ? seg_vec(seg, stored_addr) : query, -1.0f, stats, NULL};
     cnx_t *o;
     size_t n = layer_search(&r, seg->graph, (uint32_t)layer, k, entry_points, n_ep, &o);
     for (size_t i = 0; i < n; i++) { out_vec[i] = o[i].addr; out_score[i] = o[i].score; }
@@ -623,10 +782,13 @@ int orc_layer_search(const orc_segment *seg, const float *query, int query_is_st
 int orc_hnsw_search(const orc_segment *seg, const float *query, const uint64_t *filter,
                     size_t k, float min_score, int with_duplicates, int multi_vector,
                     uint32_t *out_vec, float *out_score, orc_stats *stats) {
-    retr_t r = {seg, query, min_score, stats};
+    retr_t r = {seg, query, min_score, stats, NULL};
+    orc_rabitq_query rq;
+    if (seg->quantized) { orc_rabitq_query_init(&rq, query, seg->dim); r.rq = &rq; }
     const uint64_t *bits = filter ? filter : seg->alive;
     cnx_t *res = (cnx_t *)malloc((k ? k : 1) * sizeof(cnx_t));
     size_t n = hnsw_search(&r, seg->graph, k, bits, with_duplicates, multi_vector, res);
+    if (seg->quantized) orc_rabitq_query_free(&rq);
     for (size_t i = 0; i < n; i++) { out_vec[i] = res[i].addr; out_score[i] = res[i].score; }
     free(res);
     return (int)n;
@@ -652,14 +814,16 @@ int orc_use_hnsw(size_t total_nodes, size_t matching_nodes, size_t top_k, int ha
     return hnsw_cost < bf_cost;
 }
 
-/* a7. OpenSegment::brute_force_search (segment.rs:569-623), non-RaBitQ branch.
+/* a7. OpenSegment::brute_force_search (segment.rs:569-623), both branches.
  * sort_unstable_by leaves ties unspecified -> `better` order (score desc, addr asc). */
 static int cmp_cnx_better_first(const void *pa, const void *pb) { return -cmp_cnx_asc(pa, pb); }
 
 int orc_brute_force_search(const orc_segment *seg, const float *query, const uint64_t *filter,
                            size_t k, float min_score, uint32_t *out_vec, float *out_score) {
     const uint64_t *bits = filter ? filter : seg->alive;
-    retr_t r = {seg, query, min_score, NULL};
+    retr_t r = {seg, query, min_score, NULL, NULL};
+    orc_rabitq_query rq;
+    if (seg->quantized) { orc_rabitq_query_init(&rq, query, seg->dim); r.rq = &rq; }
     size_t cap = 1024, len = 0;
     cnx_t *scored = (cnx_t *)malloc(cap * sizeof(cnx_t));
     for (uint32_t p = 0; p < seg->n_paragraphs; p++) {
@@ -673,10 +837,24 @@ int orc_brute_force_search(const orc_segment *seg, const float *query, const uin
             /* Iterator::max_by returns the LAST maximum */
             if (orc_total_cmp(s, best.score) >= 0) { best.addr = v; best.score = s; }
         }
-        if (best.score >= min_score) {
+        /* `upper_bound >= min_score` (:596): the upper bound is the score itself without RaBitQ */
+        float bound = r.rq ? rabitq_upper_bound(&r, best.addr) : best.score;
+        if (bound >= min_score) {
             if (len == cap) { cap *= 2; scored = (cnx_t *)realloc(scored, cap * sizeof(cnx_t)); }
             scored[len++] = best;
         }
+    }
+    if (r.rq) { /* rerank the candidates, in bitset order, with the raw vectors (:604-611) */
+        float *ub = (float *)malloc((len ? len : 1) * sizeof(float));
+        for (size_t i = 0; i < len; i++) ub[i] = rabitq_upper_bound(&r, scored[i].addr);
+        retr_t exact = r;
+        exact.rq = NULL;
+        cnx_t *rr = (cnx_t *)malloc((k ? k : 1) * sizeof(cnx_t));
+        size_t nr = k ? rerank_top(&exact, scored, ub, len, k, rr, NULL) : 0;
+        for (size_t i = 0; i < nr; i++) { out_vec[i] = rr[i].addr; out_score[i] = rr[i].score; }
+        free(ub); free(rr); free(scored);
+        orc_rabitq_query_free(&rq);
+        return (int)nr;
     }
     qsort(scored, len, sizeof(cnx_t), cmp_cnx_better_first);
     size_t n = len < k ? len : k;
@@ -694,7 +872,7 @@ int orc_segment_search(const orc_segment *seg, const float *query, const uint64_
     for (uint32_t p = 0; p < seg->n_paragraphs; p++) matching += bits ? (size_t)bit_get(bits, p) : 1;
     if (method_out) *method_out = 0;
     if (matching == 0) return 0;
-    if (seg->graph && orc_use_hnsw(seg->n_paragraphs, matching, k, 0)) {
+    if (seg->graph && orc_use_hnsw(seg->n_paragraphs, matching, k, seg->quantized != NULL)) {
         if (method_out) *method_out = 1;
         int n = orc_hnsw_search(seg, query, bits, k, min_score, with_duplicates, 0, out_vec, out_score, NULL);
         return n > (int)k ? (int)k : n;
@@ -803,7 +981,7 @@ static void layer_insert(const orc_segment *seg, layer_t *layer, uint32_t x, con
 
 /* insert (build.rs:121-166) */
 static void hnsw_insert(const orc_segment *seg, orc_hnsw *g, uint32_t node) {
-    retr_t r = {seg, seg_vec(seg, node), -1.0f, NULL};
+    retr_t r = {seg, seg_vec(seg, node), -1.0f, NULL, NULL};
     uint32_t *eps = (uint32_t *)malloc(sizeof(uint32_t));
     size_t n_ep = 1;
     eps[0] = g->ep_node;

@@ -67,6 +67,9 @@ typedef struct {
     const uint32_t *para_num_vec;    /* [n_paragraphs] */
     const uint64_t *alive;     /* bitset over paragraph addrs, NULL => all alive */
     const orc_hnsw *graph;     /* may be NULL (brute force only) */
+    const uint8_t *quantized;  /* vectors.quant: [n_vectors][dim/8 + 8] RaBitQ records, or NULL.  When set,
+                                * searches take the RaBitQ branches (has_quantized && !DISABLE_RABITQ_SEARCH,
+                                * segment.rs:506-513) */
 } orc_segment;
 
 typedef struct {
@@ -92,6 +95,29 @@ int orc_segment_search(const orc_segment *seg, const float *query, const uint64_
 int orc_layer_search(const orc_segment *seg, const float *query, int query_is_stored, uint32_t stored_addr,
                      int layer, size_t k, const uint32_t *entry_points, size_t n_ep,
                      uint32_t *out_vec, float *out_score, orc_stats *stats);
+
+/* ---- RaBitQ (nidx_vector/src/vector_types/rabitq.rs) ---- */
+#define ORC_RABITQ_RERANKING_FACTOR 100 /* rabitq.rs:34 */
+#define ORC_RABITQ_RERANKING_LIMIT 2000 /* rabitq.rs:36 */
+size_t orc_rabitq_encoded_len(size_t dim);                     /* EncodedVector::encoded_len (:70-73) */
+/* EncodedVector::encode (:75-106): [f32 dot_quant_original][u32 sum_bits][dim/64 x u64 sign bits].
+ * `order` = summation order of the SimSIMD dot inside (ORC_ORDER_*). */
+void orc_rabitq_encode(const float *v, size_t dim, int order, uint8_t *out);
+typedef struct {
+    float low, delta, root_dim;
+    uint32_t sum_quantized;
+    uint32_t n_words;          /* dim / 64 */
+    uint64_t *planes;          /* [4][n_words]: bit p of every 4-bit code */
+} orc_rabitq_query;
+/* QueryVector::from_vector (:124-157).  Free with orc_rabitq_query_free. */
+void orc_rabitq_query_init(orc_rabitq_query *q, const float *v, size_t dim);
+void orc_rabitq_query_free(orc_rabitq_query *q);
+/* QueryVector::similarity (:202-218) -> (estimate, error) */
+void orc_rabitq_similarity(const orc_rabitq_query *q, const uint8_t *encoded, float *estimate, float *error);
+/* rerank_top (:221-244): candidates in the given order; returns count (<= k), sorted score desc */
+size_t orc_rabitq_rerank_top(const orc_segment *seg, const float *query, float min_score, const uint32_t *cand,
+                             const float *cand_upper_bound, size_t n_cand, size_t k, uint32_t *out_vec, float *out_score,
+                             uint64_t *n_evaluated);
 
 /* ---- HNSW graph ---- */
 orc_hnsw *orc_hnsw_new(void);

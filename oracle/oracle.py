@@ -45,7 +45,13 @@ class _Segment(C.Structure):
         ("para_num_vec", C.c_void_p),
         ("alive", C.c_void_p),
         ("graph", C.c_void_p),
+        ("quantized", C.c_void_p),
     ]
+
+
+class _RabitqQuery(C.Structure):
+    _fields_ = [("low", C.c_float), ("delta", C.c_float), ("root_dim", C.c_float), ("sum_quantized", C.c_uint32),
+                ("n_words", C.c_uint32), ("planes", C.c_void_p)]
 
 
 class _Stats(C.Structure):
@@ -118,6 +124,19 @@ def lib():
     L.orc_total_cmp.argtypes = [C.c_float, C.c_float]
     L.orc_use_hnsw.restype = C.c_int
     L.orc_use_hnsw.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_rabitq_encoded_len.restype = C.c_size_t
+    L.orc_rabitq_encoded_len.argtypes = [C.c_size_t]
+    L.orc_rabitq_encode.restype = None
+    L.orc_rabitq_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.orc_rabitq_query_init.restype = None
+    L.orc_rabitq_query_init.argtypes = [C.POINTER(_RabitqQuery), C.c_void_p, C.c_size_t]
+    L.orc_rabitq_query_free.restype = None
+    L.orc_rabitq_query_free.argtypes = [C.POINTER(_RabitqQuery)]
+    L.orc_rabitq_similarity.restype = None
+    L.orc_rabitq_similarity.argtypes = [C.POINTER(_RabitqQuery), C.c_void_p, f32p, f32p]
+    L.orc_rabitq_rerank_top.restype = C.c_size_t
+    L.orc_rabitq_rerank_top.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.orc_brute_force_search.restype = C.c_int
     L.orc_brute_force_search.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]
     L.orc_hnsw_search.restype = C.c_int
@@ -337,6 +356,61 @@ def disk_v2_entry_point(graph: np.ndarray):
     return n.value, l.value
 
 
+# ---------------------------------------------------------------- RaBitQ
+def rabitq_encoded_len(dim: int) -> int:
+    return int(lib().orc_rabitq_encoded_len(dim))
+
+
+def rabitq_encode(vectors, order=ORDER_WAVE64) -> np.ndarray:
+    """EncodedVector::encode for every row -> [n][dim/8 + 8] u8."""
+    x = _f32(vectors)
+    x = x.reshape(1, -1) if x.ndim == 1 else x
+    out = np.zeros((x.shape[0], rabitq_encoded_len(x.shape[1])), np.uint8)
+    L = lib()
+    for i in range(x.shape[0]):
+        L.orc_rabitq_encode(x[i].ctypes.data, x.shape[1], order, out[i].ctypes.data)
+    return out
+
+
+class RabitqQuery:
+    """QueryVector::from_vector."""
+
+    def __init__(self, query):
+        self.q = _f32(query)
+        self.c = _RabitqQuery()
+        lib().orc_rabitq_query_init(C.byref(self.c), _ptr(self.q), self.q.size)
+
+    def __del__(self):
+        try:
+            lib().orc_rabitq_query_free(C.byref(self.c))
+        except Exception:
+            pass
+
+    @property
+    def planes(self) -> np.ndarray:
+        n = self.c.n_words
+        return np.ctypeslib.as_array(C.cast(self.c.planes, C.POINTER(C.c_uint64)), shape=(4, n)).copy()
+
+    def similarity(self, encoded) -> tuple:
+        e = np.ascontiguousarray(encoded, dtype=np.uint8)
+        est, err = C.c_float(), C.c_float()
+        lib().orc_rabitq_similarity(C.byref(self.c), e.ctypes.data, C.byref(est), C.byref(err))
+        return est.value, err.value
+
+
+def rabitq_rerank_top(segment, query, candidates, upper_bounds, k, min_score=-1.0):
+    """rerank_top over `candidates` in the given order. -> (vec addrs, real scores, raw rows evaluated)"""
+    q = _f32(query)
+    cand = np.ascontiguousarray(candidates, dtype=np.uint32)
+    ub = np.ascontiguousarray(upper_bounds, dtype=np.float32)
+    ov, os_ = np.empty(max(k, 1), np.uint32), np.empty(max(k, 1), np.float32)
+    cs = segment.c()
+    n_eval = C.c_uint64()
+    n = lib().orc_rabitq_rerank_top(C.byref(cs), _ptr(q), min_score, _ptr(cand), _ptr(ub), cand.size, k, _ptr(ov), _ptr(os_),
+                                    C.byref(n_eval))
+    return ov[:n].copy(), os_[:n].copy(), n_eval.value
+
+
 # ---------------------------------------------------------------- segment
 @dataclass
 class Stats:
@@ -349,7 +423,7 @@ class Segment:
     """One vector segment as the reference's OpenSegment sees it (segment.rs:39-90)."""
 
     def __init__(self, vectors, similarity=SIM_COSINE, order=ORDER_WAVE64, vec_paragraph=None, para_first_vec=None,
-                 para_num_vec=None, alive=None, graph: Hnsw | None = None, n_paragraphs=None):
+                 para_num_vec=None, alive=None, graph: Hnsw | None = None, n_paragraphs=None, quantized=None):
         self.vectors = _f32(vectors)
         assert self.vectors.ndim == 2
         self.n, self.dim = self.vectors.shape
@@ -360,6 +434,13 @@ class Segment:
         self.n_paragraphs = self.n if n_paragraphs is None else n_paragraphs
         self.alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint64)
         self.graph = graph
+        # vectors.quant (RaBitQ records); when set every search takes the reference's RaBitQ branch
+        self.quantized = None if quantized is None else np.ascontiguousarray(quantized, dtype=np.uint8)
+
+    def quantize(self):
+        """DataStoreV2::create's quantized writer (data_store/v2.rs:57-76): encode every vector."""
+        self.quantized = rabitq_encode(self.vectors, self.order)
+        return self.quantized
 
     def c(self) -> _Segment:
         s = _Segment()
@@ -372,6 +453,7 @@ class Segment:
         s.para_num_vec = None if self.para_num_vec is None else self.para_num_vec.ctypes.data
         s.alive = None if self.alive is None else self.alive.ctypes.data
         s.graph = None if self.graph is None else self.graph.h
+        s.quantized = None if self.quantized is None else self.quantized.ctypes.data
         return s
 
     def build_graph(self, seed: int = 2) -> Hnsw:

@@ -1,0 +1,231 @@
+"""GPU parity tests of the RaBitQ arms: device encode / query codes / popcount estimates /
+error-bounded re-rank / RaBitQ HNSW + brute force through the C ABI vs the CPU oracle on the same seeded inputs.
+Bar: bit-exact record bytes, vector addresses, ranks and score bit patterns."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import Similarity, VectorConfig, VectorSearcher, VectorSearchRequest, VectorSegment
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_rows(rng, n, d):
+    x = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    return x
+
+
+def clustered(rng, n, d, clusters=40, spread=0.05):
+    centers = unit_rows(rng, clusters, d)
+    x = centers[rng.integers(0, clusters, n)] + rng.normal(size=(n, d)).astype(np.float32) * np.float32(spread / np.sqrt(d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    return x.astype(np.float32)
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+class Index:
+    """One Dot segment through the C ABI, optionally with vectors.quant / hnsw.graph handed in."""
+
+    def __init__(self, x, graph=None, quantized=None, alive=None, flags=0):
+        L = _lib.lib()
+        n, d = x.shape
+        self.x, self.n, self.d = x, n, d
+        cfg = _lib.VectorConfigC(d, 0, 0, 0, flags)
+        self._keep = [x, graph, quantized, alive]
+        g = np.frombuffer(graph, np.uint8) if graph is not None else None
+        self._keep.append(g)
+        seg = _lib.VectorSegmentC(x.ctypes.data, d * 4, n, None, n, g.ctypes.data if g is not None else None,
+                                  len(graph) if graph is not None else 0, 0, None, 0,
+                                  alive.ctypes.data if alive is not None else None, None,
+                                  quantized.ctypes.data if quantized is not None else None,
+                                  quantized.size if quantized is not None else 0)
+        self.h = C.c_void_p()
+        _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(self.h)))
+
+    def close(self):
+        _lib.lib().nidx_gpu_vector_close(self.h)
+
+    def quantize(self):
+        _lib.check(_lib.lib().nidx_gpu_vector_quantize(self.h, 0))
+        n = C.c_uint64()
+        _lib.check(_lib.lib().nidx_gpu_vector_serialize_quantized(self.h, 0, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        _lib.check(_lib.lib().nidx_gpu_vector_serialize_quantized(self.h, 0, out.ctypes.data, out.size, C.byref(n)))
+        return out.reshape(self.n, self.d // 8 + 8)
+
+    def build(self):
+        L = _lib.lib()
+        _lib.check(L.nidx_gpu_vector_build_hnsw(self.h, 0, 2))
+        glen, elen = C.c_uint64(), C.c_uint64()
+        _lib.check(L.nidx_gpu_vector_serialize_hnsw(self.h, 0, None, 0, C.byref(glen), None, 0, C.byref(elen)))
+        g, e = np.zeros(glen.value, np.uint8), np.zeros(elen.value, np.float32)
+        _lib.check(L.nidx_gpu_vector_serialize_hnsw(self.h, 0, g.ctypes.data, g.size, C.byref(glen), e.ctypes.data, e.size, C.byref(elen)))
+        return g, e
+
+    def search(self, q, k, method, min_score=-1.0, with_duplicates=True, filter_bits=None):
+        L = _lib.lib()
+        q = np.ascontiguousarray(q, np.float32)
+        B = q.shape[0]
+        ov, osc, oc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
+        om = np.zeros(1, np.int32)
+        params = _lib.VectorSearchParamsC(k, min_score, int(with_duplicates), method)
+        fp = (C.c_void_p * 1)(filter_bits.ctypes.data) if filter_bits is not None else None
+        _lib.check(L.nidx_gpu_vector_search(self.h, q.ctypes.data, B, C.byref(params), fp, None, None, ov.ctypes.data,
+                                            osc.ctypes.data, oc.ctypes.data, om.ctypes.data))
+        return ov, osc, oc, int(om[0])
+
+
+def same_hits(got, want, i):
+    ov, osc, oc = got
+    wv, ws = want
+    assert oc[i] == len(wv), (i, oc[i], len(wv), ov[i], wv)
+    assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i, : oc[i]], wv)
+    assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws)), (i, osc[i, : oc[i]], ws)
+
+
+# ---- EncodedVector::encode ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [64, 128, 192, 448, 768, 1024, 1536, 2048])
+def test_encode_bytes_match_oracle(orc, d):
+    rng = np.random.default_rng(d)
+    x = unit_rows(rng, 301, d)
+    x[3, 5] = 0.0
+    x[4, :9] = -0.0
+    x[5] = np.abs(x[5])
+    x[6] = -np.abs(x[6])
+    idx = Index(x)
+    try:
+        got = idx.quantize()
+    finally:
+        idx.close()
+    want = orc.rabitq_encode(x, orc.ORDER_WAVE64)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:10]
+
+
+def test_quantize_needs_a_quantizable_config():
+    x = unit_rows(np.random.default_rng(1), 10, 100)  # 100 % 64 != 0 (config.rs:170-173)
+    idx = Index(x)
+    try:
+        with pytest.raises(_lib.NidxGpuError) as e:
+            idx.quantize()
+        assert e.value.code == _lib.NIDX_ERR_INVALID_CONFIGURATION
+    finally:
+        idx.close()
+
+
+# ---- brute force, RaBitQ arm --------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,nq,k", [(1, 64, 1, 3), (70, 64, 3, 100), (5000, 128, 9, 10), (20000, 768, 12, 10),
+                                      (6000, 1024, 5, 1), (3000, 192, 4, 64), (2000, 2048, 3, 7), (4000, 256, 3, 256)])
+def test_rabitq_brute_force_matches_oracle(orc, n, d, nq, k):
+    rng = np.random.default_rng(n + d)
+    x = clustered(rng, n, d) if n > 100 else unit_rows(rng, n, d)
+    q = np.vstack([x[rng.integers(n)] + rng.normal(size=d).astype(np.float32) * np.float32(0.3 / np.sqrt(d)) for _ in range(nq)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = q.astype(np.float32)
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT)
+    quant = oseg.quantize()
+    idx = Index(x, quantized=quant)
+    try:
+        got = idx.search(q, k, _lib.METHOD_RABITQ_BRUTE_FORCE)[:3]
+    finally:
+        idx.close()
+    for i in range(nq):
+        same_hits(got, oseg.brute_force(q[i], k), i)
+
+
+def test_rabitq_brute_force_filters_min_score_ties(orc):
+    rng = np.random.default_rng(77)
+    n, d, k = 7000, 128, 10
+    x = clustered(rng, n, d)
+    x[200:230] = x[9]  # identical rows: identical codes, estimates and real scores
+    q = np.vstack([x[9][None, :], unit_rows(rng, 4, d)]).astype(np.float32)
+    alive = orc.bitset(n, fill=True)
+    for dead in (9, 200, 201, 6999):
+        alive[dead >> 6] &= ~np.uint64(1 << (dead & 63))
+    filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.2)[0].tolist() + list(range(200, 230)))
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT, alive=alive)
+    quant = oseg.quantize()
+    idx = Index(x, quantized=quant, alive=alive)
+    try:
+        for fb, ob in ((None, alive), (filt, alive & filt)):
+            for ms in (-1.0, 0.3, 0.95, 0.9999):
+                got = idx.search(q, k, _lib.METHOD_RABITQ_BRUTE_FORCE, min_score=ms, filter_bits=fb)[:3]
+                for i in range(q.shape[0]):
+                    same_hits(got, oseg.brute_force(q[i], k, min_score=ms, filter_bits=ob), i)
+    finally:
+        idx.close()
+
+
+# ---- HNSW, RaBitQ arm ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5)])
+def test_rabitq_hnsw_matches_oracle(orc, n, d, k):
+    rng = np.random.default_rng(n * 7 + d + k)
+    x = clustered(rng, n, d, clusters=60, spread=0.3)
+    nq = 12
+    q = np.vstack([x[rng.integers(n)] + rng.normal(size=d).astype(np.float32) * np.float32(0.2 / np.sqrt(d)) for _ in range(nq)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = q.astype(np.float32)
+    idx = Index(x)
+    try:
+        graph, edges = idx.build()
+        quant = idx.quantize()
+        got = idx.search(q, k, _lib.METHOD_RABITQ_HNSW)[:3]
+        alive = orc.bitset(n, fill=True)
+        filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.5)[0].tolist())
+        got_f = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, min_score=0.2, with_duplicates=False, filter_bits=filt)[:3]
+    finally:
+        idx.close()
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT, graph=orc.Hnsw.deserialize_v2(graph, edges), quantized=quant)
+    for i in range(nq):
+        same_hits(got, oseg.hnsw_search(q[i], k), i)
+        same_hits(got_f, oseg.hnsw_search(q[i], k, min_score=0.2, with_duplicates=False, filter_bits=alive & filt), i)
+
+
+def test_auto_routes_like_the_reference_and_recall(orc):
+    """OpenSegment::_search (segment.rs:506-555): with a quantized store AUTO takes the RaBitQ arm the cost model picks;
+    DISABLE_RABITQ_SEARCH turns it off; a store handed in (any summation order) is used as it is."""
+    rng = np.random.default_rng(2024)
+    n, d, k = 60000, 128, 10
+    x = clustered(rng, n, d, clusters=200, spread=0.4)
+    nq = 64
+    q = np.vstack([x[rng.integers(n)] + rng.normal(size=d).astype(np.float32) * np.float32(0.2 / np.sqrt(d)) for _ in range(nq)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = q.astype(np.float32)
+    quant = orc.rabitq_encode(x, orc.ORDER_HASWELL)  # as a CPU writer would have produced it
+    plain = Index(x)
+    try:
+        graph, edges = plain.build()
+        exact = plain.search(q, k, _lib.METHOD_BRUTE_FORCE)
+    finally:
+        plain.close()
+    assert orc.use_hnsw(n, n, k, True)
+    idx = Index(x, graph=graph.tobytes(), quantized=quant)
+    try:
+        ov, osc, oc, method = idx.search(q, k, _lib.METHOD_AUTO)
+        assert method == _lib.METHOD_RABITQ_HNSW
+        sparse = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.02)[0].tolist())
+        fv, fs, fc, fmethod = idx.search(q, k, _lib.METHOD_AUTO, filter_bits=sparse)
+        assert fmethod == _lib.METHOD_RABITQ_BRUTE_FORCE
+    finally:
+        idx.close()
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT, graph=orc.Hnsw.deserialize_v2(graph, edges), quantized=quant)
+    hit = 0
+    for i in range(nq):
+        wv, ws, m = oseg.search(q[i], k)
+        assert m == "hnsw"
+        same_hits((ov, osc, oc), (wv, ws), i)
+        wv, ws, m = oseg.search(q[i], k, filter_bits=sparse)
+        assert m == "brute force"
+        same_hits((fv, fs, fc), (wv, ws), i)
+        hit += len(set(ov[i, : oc[i]].tolist()) & set(exact[0][i, : exact[2][i]].tolist()))
+    assert hit / (nq * k) >= 0.95, hit / (nq * k)  # ef = 1000 estimates + raw re-rank: recall vs the exact scan
+    off = Index(x, graph=graph.tobytes(), quantized=quant, flags=_lib.CONFIG_DISABLE_RABITQ_SEARCH)
+    try:
+        assert off.search(q[:2], k, _lib.METHOD_AUTO)[3] == _lib.METHOD_HNSW
+    finally:
+        off.close()
