@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25"], default="hnsw")
+    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25", "rabitq"], default="hnsw")
     p.add_argument("--n-docs", type=int, default=10_000_000, help="bm25: documents per shard")
     p.add_argument("--vocab", type=int, default=1_000_000)
     p.add_argument("--recall-queries", type=int, default=256)
@@ -88,6 +88,12 @@ def main():
     _lib.check(L.nidx_gpu_set_device(local_rank))
     if a.workload == "bm25":
         bench_bm25(a, L, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if a.workload == "rabitq":
+        bench_rabitq(a, L, dev, rank, world)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -401,6 +407,153 @@ def bench_bm25(a, L, dev, rank, world):
                        "note": "value is end to end through the host-buffer entry point (clauses in, hits out over PCIe); the corpus is resident in HBM"},
             "roofline": {"kernel": "bm25_search_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+            "cpu_baseline": cpu}))
+
+
+def bench_rabitq(a, L, dev, rank, world):
+    """The RaBitQ arm of a Dot index: 1-bit codes + popcount estimates drive the HNSW walk with
+    ef = min(100 k, 2000), the ef neighbours are re-ranked with the raw rows under the error bound, closest_up_nodes
+    finishes on the raw query.  Clustered unit vectors (the reference's recall recipe), so recall means something."""
+    from nucliadb_amd import _lib
+
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234567890 + rank)
+
+    def unit(*shape):
+        v = torch.rand(shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        return v / v.norm(dim=-1, keepdim=True)
+
+    per = 160
+    n_centres = (n + per - 1) // per
+    centres = unit(n_centres, d)
+    radius = torch.where(torch.arange(per, device=dev) < per // 2, 0.1, 0.3).repeat(n_centres)[:n]
+    x = centres.repeat_interleave(per, dim=0)[:n] + radius[:, None] * unit(n, d)
+    x = x / x.norm(dim=1, keepdim=True)
+    x = x[torch.randperm(n, generator=g, device=dev)]
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2)
+    n_pool = 4
+    base = x[torch.randint(0, n, (n_pool * B,), generator=gq, device=dev)]
+    noise = torch.rand((n_pool * B, d), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
+    q = base + 0.2 * noise / noise.norm(dim=1, keepdim=True)
+    qpool = (q / q.norm(dim=1, keepdim=True)).reshape(n_pool, B, d).contiguous()
+    xh = x.cpu().numpy()
+    del x, base, noise, q
+    torch.cuda.empty_cache()
+    cfg = _lib.VectorConfigC(d, 0, 0, 0, 0)
+    cseg = _lib.VectorSegmentC(xh.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
+    build_s = time.time() - t0
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_quantize(h, 0))
+    quant_s = time.time() - t0
+    ov = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    os_ = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    st = torch.zeros((B, 8), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def search(qb, m, with_stats=False):
+        p = _lib.VectorSearchParamsC(k, -1.0, 1, m)
+        _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, qb.data_ptr(), B, C.byref(p), None, ov.data_ptr(), os_.data_ptr(),
+                                                           oc.data_ptr(), st.data_ptr() if with_stats else None, stream))
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(m):
+        for i in range(a.warmup):
+            search(qpool[i % n_pool], m)
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            ev0[i].record()
+            search(qpool[i % n_pool], m)
+            ev1[i].record()
+        barrier()
+        el = time.perf_counter() - t0
+        return el, float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
+
+    elapsed, k_ms = timed(_lib.METHOD_RABITQ_HNSW)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    _, exact_hnsw_ms = timed(_lib.METHOD_HNSW)
+    # counters + recall
+    search(qpool[0], _lib.METHOD_RABITQ_HNSW, with_stats=True)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy().astype(np.int64)
+    got = ov.cpu().numpy().copy()
+    flags = int(np.bitwise_or.reduce(s[:, 3]))
+    rec_len = d // 8 + 8
+    alg = float((s[:, 0] * rec_len + s[:, 1] * 256 + s[:, 2] * 4 * d).sum())
+    search(qpool[0], _lib.METHOD_HNSW)
+    torch.cuda.synchronize()
+    got_exact_hnsw = ov.cpu().numpy().copy()
+    search(qpool[0], _lib.METHOD_BRUTE_FORCE)
+    torch.cuda.synchronize()
+    exact = ov.cpu().numpy().copy()
+    rq = min(a.recall_queries or B, B)
+    recall = float(np.mean([len(set(got[i]) & set(exact[i])) / k for i in range(rq)]))
+    recall_exact_hnsw = float(np.mean([len(set(got_exact_hnsw[i]) & set(exact[i])) / k for i in range(rq)]))
+    cpu = None
+    if rank == 0 and a.cpu_queries > 0:
+        from concurrent.futures import ThreadPoolExecutor
+
+        from oracle import oracle as orc
+
+        orc.build()
+        glen, nedges, qlen = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.nidx_gpu_vector_serialize_hnsw(h, 0, None, 0, C.byref(glen), None, 0, C.byref(nedges))
+        graph = np.zeros(glen.value, np.uint8)
+        edges = np.zeros(max(1, nedges.value), np.float32)
+        L.nidx_gpu_vector_serialize_hnsw(h, 0, graph.ctypes.data, glen.value, C.byref(glen), edges.ctypes.data, nedges.value, C.byref(nedges))
+        L.nidx_gpu_vector_serialize_quantized(h, 0, None, 0, C.byref(qlen))
+        quant = np.zeros(qlen.value, np.uint8)
+        L.nidx_gpu_vector_serialize_quantized(h, 0, quant.ctypes.data, quant.size, C.byref(qlen))
+        oseg = orc.Segment(xh, similarity=orc.SIM_DOT, order=orc.ORDER_HASWELL, graph=orc.Hnsw.deserialize_v2(graph, edges[: nedges.value]),
+                           quantized=quant.reshape(n, rec_len))
+        qs = qpool[0].cpu().numpy()
+        threads = a.cpu_threads or min(64, os.cpu_count() or 1)
+        nq = min(a.cpu_queries, B)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: oseg.hnsw_search(qs[i], k), range(min(threads, nq))))
+            t0 = time.perf_counter()
+            res = list(ex.map(lambda i: oseg.hnsw_search(qs[i], k), range(nq)))
+            dt = time.perf_counter() - t0
+        same = int(sum(np.array_equal(res[i][0], got[i][: len(res[i][0])]) for i in range(nq)))
+        cpu = {"value": nq / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": "%d queries of the same batch, oracle RaBitQ HNSW over the device-built graph and codes, one query per thread; "
+                         "%d/%d id lists identical to the device's" % (nq, same, nq)}
+    L.nidx_gpu_vector_close(h)
+    if rank == 0:
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "queries/sec (%d-dim dot k-NN, RaBitQ HNSW: ef=min(100k,2000) on 1-bit codes + raw re-rank, k=%d)" % (d, k),
+            "value": world * B * a.steps / elapsed, "unit": "queries/s (each against one %d-vector shard)" % n, "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 popcount + f32", "data": "synthetic",
+            "config": {"workload": "rabitq: %d x %d-dim dot (clustered unit vectors), k=%d, batch=%d queries, 1 shard per GPU" % (n, d, k, B),
+                       "recall_at_%d" % k: recall, "recall_at_%d_exact_hnsw_ef30" % k: recall_exact_hnsw,
+                       "exact_hnsw_ms_per_batch": exact_hnsw_ms, "estimates_per_query": float(s[:, 0].mean()),
+                       "expansions_per_query": float(s[:, 1].mean()), "rows_reranked_per_query": float(s[:, 2].mean()),
+                       "kernel_flags": flags, "hnsw_build_s": build_s, "quantize_s": quant_s,
+                       "cycles_per_query": {"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
+                                            "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())}},
+            "roofline": {"kernel": "rabitq_hnsw_kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
             "cpu_baseline": cpu}))
 
 

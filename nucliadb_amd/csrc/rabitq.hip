@@ -170,31 +170,92 @@ __global__ __launch_bounds__(256) void rabitq_query_kernel(const float *queries,
 }
 
 // ---- QueryVector::similarity for one stored code (per lane) -------------------------------------------
-// qp: this query's four bit planes in LDS ([4][nw]); every lane reads the same words (broadcast).
-__device__ inline void rabitq_estimate(const uint8_t *rec, const uint64_t *qp, uint32_t nw, const RabitqQueryDev &c,
-                                       float &est, float &err) {
-    const float dqo = *reinterpret_cast<const float *>(rec);
-    const uint32_t sum_bits = *reinterpret_cast<const uint32_t *>(rec + 4);
-    const uint64_t *s = reinterpret_cast<const uint64_t *>(rec + 8);
-    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-    for (uint32_t w = 0; w < nw; w++) {
-        const uint64_t sw = s[w];
-        d0 += (uint32_t)__popcll(qp[w] & sw);
-        d1 += (uint32_t)__popcll(qp[nw + w] & sw);
-        d2 += (uint32_t)__popcll(qp[2 * nw + w] & sw);
-        d3 += (uint32_t)__popcll(qp[3 * nw + w] & sw);
+// A code is fetched with all of its 8-byte loads in flight at once (NW of them when the word count is a
+// template constant, groups of four otherwise) and scored against this query's four bit planes in LDS
+// ([4][nw]; every lane reads the same words: broadcast).
+template <int NW>
+struct RqCode {
+    uint64_t s[NW > 0 ? NW : 1];
+    float dqo;
+    uint32_t sum_bits;
+};
+template <int NW>
+__device__ inline void rq_load_code(const uint8_t *rec, RqCode<NW> &c) {
+    const uint2 hdr = *reinterpret_cast<const uint2 *>(rec);
+    if (NW > 0) {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(rec + 8);
+#pragma unroll
+        for (int w = 0; w < (NW > 0 ? NW : 1); w++) c.s[w] = src[w];
     }
+    c.dqo = __builtin_bit_cast(float, hdr.x);
+    c.sum_bits = hdr.y;
+}
+__device__ inline void rq_finish(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, float dqo, uint32_t sum_bits,
+                                 const RabitqQueryDev &c, float &est, float &err) {
     const float dot = (float)(d0 + d1 * 2u + d2 * 4u + d3 * 8u);
     const float dqq = c.c_dot * dot + c.two_low * (float)sum_bits / c.root_dim - c.c_sumq - c.c_low;
     est = dqq / dqo;
     const float dd = dqo * dqo;
     err = sqrtf((1.0f - dd) / dd) * RABITQ_EPSILON / c.root_dim;
 }
+template <int NW>
+__device__ inline void rq_score_code(const RqCode<NW> &code, const uint8_t *rec, const uint64_t *qp, uint32_t nw,
+                                     const RabitqQueryDev &c, float &est, float &err) {
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    if (NW > 0) {
+#pragma unroll
+        for (int w = 0; w < (NW > 0 ? NW : 1); w++) {
+            const uint64_t sw = code.s[w];
+            d0 += (uint32_t)__popcll(qp[w] & sw);
+            d1 += (uint32_t)__popcll(qp[NW + w] & sw);
+            d2 += (uint32_t)__popcll(qp[2 * NW + w] & sw);
+            d3 += (uint32_t)__popcll(qp[3 * NW + w] & sw);
+        }
+    } else {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(rec + 8);
+        for (uint32_t w0 = 0; w0 < nw; w0 += 4) {
+            uint64_t sw[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) sw[u] = w0 + u < nw ? src[w0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (w0 + u < nw) {
+                    d0 += (uint32_t)__popcll(qp[w0 + u] & sw[u]);
+                    d1 += (uint32_t)__popcll(qp[nw + w0 + u] & sw[u]);
+                    d2 += (uint32_t)__popcll(qp[2 * nw + w0 + u] & sw[u]);
+                    d3 += (uint32_t)__popcll(qp[3 * nw + w0 + u] & sw[u]);
+                }
+            }
+        }
+    }
+    rq_finish(d0, d1, d2, d3, code.dqo, code.sum_bits, c, est, err);
+}
+template <int NW>
+__device__ inline void rabitq_estimate(const uint8_t *rec, const uint64_t *qp, uint32_t nw, const RabitqQueryDev &c,
+                                       float &est, float &err) {
+    RqCode<NW> code;
+    rq_load_code<NW>(rec, code);
+    rq_score_code<NW>(code, rec, qp, nw, c, est, err);
+}
 __device__ inline float rabitq_error(const uint8_t *rec, const RabitqQueryDev &c) {
     const float dqo = *reinterpret_cast<const float *>(rec);
     const float dd = dqo * dqo;
     return sqrtf((1.0f - dd) / dd) * RABITQ_EPSILON / c.root_dim;
 }
+
+// Wave-uniform reads of one lane's value.  Unlike __shfl they return SGPRs, so the sequential replay
+// loops below (whose every decision is wave-uniform) compile to scalar branches instead of exec-masked
+// vector code.
+__device__ inline uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ inline float lane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ inline uint64_t lane_u64(uint64_t v, int l) {
+    return ((uint64_t)lane_u32((uint32_t)(v >> 32), l) << 32) | lane_u32((uint32_t)v, l);
+}
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint64_t uni64(uint64_t v) {
+    return ((uint64_t)(uint32_t)uni((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)v);
+}
+__device__ inline float unif(float v) { return __builtin_bit_cast(float, uni(__builtin_bit_cast(int, v))); }
 
 // ---- sorted key array in LDS (best first), one wave -----------------------------------------------------
 // Keys: score bits << 32 | (~addr & 0x7fffffff) << 1 | unexpanded flag — ordered like rank_key()
@@ -205,27 +266,55 @@ __device__ inline uint64_t rq_key(float score, uint32_t addr, uint32_t flag) {
 }
 __device__ inline uint32_t rq_addr(uint64_t key) { return (~(uint32_t)(key >> 1)) & 0x7fffffffu; }
 
-// Inserts nk keeping at most `cap` keys; returns the evicted key (0 if none) and the position of nk
-// (== cap when nk itself did not fit).  keys must have room for cap + 1 entries.
-__device__ inline uint64_t sorted_insert(uint64_t *keys, int &len, int cap, uint64_t nk, int lane, int &pos_out) {
+// Inserts nk — which must rank before the current worst key when the list is full — keeping at most `cap`
+// keys.  Returns the evicted key (0 if none); `worst` is the list's last key and is kept up to date (both
+// come out of registers: no dependent LDS read).  `keys` must be readable up to the next multiple of 64
+// past cap + 1.  The list is walked from its end in blocks of eight 64-key chunks whose LDS reads are all
+// in flight together.  (A variant that located the landing chunk through per-chunk pivots held in
+// registers and moved the chunks behind it wholesale was measured 12 % SLOWER: the walk is bound by
+// taken scalar branches and LDS round trips of a lone wave, not by compares.)
+__device__ inline uint64_t sorted_insert(uint64_t *keys, int &len_io, int cap, uint64_t nk, int lane, int &pos_out,
+                                        uint64_t &worst) {
+    const int len = uni(len_io);
     int after = 0;  // entries ranking after nk (they move down by one)
-    for (int base = ((len - 1) >> 6) << 6; base >= 0 && len > 0; base -= 64) {
-        const int i = base + lane;
-        const uint64_t v = i < len ? keys[i] : ~0ull;
-        const bool mv = i < len && v < nk;
-        if (mv) keys[i + 1] = v;
-        const int c = __popcll(__ballot(mv));
-        after += c;
-        if (c < 64 && c < len - base) break;  // this chunk held an entry ranking before nk: everything above does too
+    bool done = len == 0;
+    uint64_t old_prev = 0;  // keys[len - 2] before the insert
+    const int top = (len - 1) >> 6;
+    for (int cb = top; cb >= 0 && !done; cb -= 8) {
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = cb - u < 0 ? 0 : cb - u;
+            v[u] = keys[c * 64 + lane];
+        }
+        if (cb == top && len >= 2) {
+            const uint64_t a = lane_u64(v[0], (len - 2) & 63), b = lane_u64(v[1], (len - 2) & 63);
+            old_prev = ((len - 2) >> 6) == top ? a : b;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = cb - u;
+            if (!done && c >= 0) {
+                const int i = c * 64 + lane;
+                const bool mv = i < len && v[u] < nk;
+                if (mv) keys[i + 1] = v[u];
+                const int cnt = __popcll(__ballot(mv));
+                after += cnt;
+                const int n_in = len - c * 64 < 64 ? len - c * 64 : 64;
+                if (cnt < n_in) done = true;  // an entry of this chunk ranks before nk: so does everything above
+            }
+        }
     }
     const int pos = len - after;
     if (lane == 0) keys[pos] = nk;
     pos_out = pos;
-    len++;
     uint64_t evicted = 0;
-    if (len > cap) {
-        evicted = keys[cap];
-        len = cap;
+    if (len == cap) {
+        evicted = worst;                       // the old last key moved to keys[cap]
+        worst = after >= 2 ? old_prev : nk;    // new last = the old keys[cap - 2], or nk when it landed at the end
+    } else {
+        if (after == 0) worst = nk;
+        len_io = len + 1;
     }
     return evicted;
 }
@@ -237,6 +326,7 @@ __device__ inline uint64_t sorted_insert(uint64_t *keys, int &len, int cap, uint
 // are computed four rows at a time (speculatively — a row evaluated but skipped by the replay costs bytes only).
 struct Reranker {
     uint64_t *best;
+    uint64_t worst;
     int len, k;
     float best_k, min_score;
     uint32_t n_eval;
@@ -246,6 +336,7 @@ struct Reranker {
 
     __device__ inline void init(uint64_t *best_, int k_, float min_score_, const float *vectors_, uint32_t dp_, const float *q_) {
         best = best_;
+        worst = 0;
         len = 0;
         k = k_;
         best_k = 0.0f;
@@ -256,9 +347,15 @@ struct Reranker {
         q = q_;
     }
     __device__ inline void feed(bool cand, uint32_t addr, float ub, int lane) {
+        len = uni(len);
+        best_k = unif(best_k);
         unsigned long long todo = __ballot(cand && (len < k || best_k < ub));
         const int nj = (int)((dp + 255u) / 256u);
         while (todo) {
+            todo = uni64(todo);
+            len = uni(len);
+            worst = uni64(worst);
+            best_k = unif(best_k);
             int idx[4];
             int cnt = 0;
             unsigned long long t = todo;
@@ -272,7 +369,7 @@ struct Reranker {
             }
             uint32_t ra[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) ra[i] = __shfl(addr, idx[i] < 0 ? 0 : idx[i], 64);
+            for (int i = 0; i < 4; i++) ra[i] = lane_u32(addr, idx[i] < 0 ? 0 : idx[i]);
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < nj; j++) {
                 const uint32_t e = (uint32_t)j * 256u + (uint32_t)lane * 4u;
@@ -290,14 +387,14 @@ struct Reranker {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (i >= cnt) break;
-                const float real = __shfl(red, (i >> 1) * 32 + (i & 1) * 16, 64);
-                const float ubi = __shfl(ub, idx[i], 64);
+                const float real = lane_f32(red, (i >> 1) * 32 + (i & 1) * 16);
+                const float ubi = lane_f32(ub, idx[i]);
                 if (len < k || best_k < ubi) {
                     n_eval++;
                     if (real >= min_score && (len < k || best_k < real)) {
                         int pos;
-                        sorted_insert(best, len, k, rq_key(real, ra[i], 0), lane, pos);
-                        best_k = rank_key_score(best[len - 1]);
+                        sorted_insert(best, len, k, rq_key(real, ra[i], 0), lane, pos, worst);
+                        best_k = rank_key_score(worst);
                     }
                 }
             }
@@ -327,15 +424,18 @@ struct RqShared {
 #define RABITQ_TIE_CAP 64
 #define RABITQ_UPPER_VIS_LOG2 11
 
+// a sorted list of `cap` keys: cap + 1 slots, readable in whole 64-key chunks
+__host__ __device__ inline size_t rq_list_bytes(uint32_t cap) { return (size_t)(((cap + 1 + 63) / 64) * 64) * 8; }
+
 __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
     RqShared s;
     size_t off = 0;
     s.planes = reinterpret_cast<uint64_t *>(smem + off);
     off += (size_t)4 * nw * 8;
     s.best = reinterpret_cast<uint64_t *>(smem + off);
-    off += (size_t)(k + 1) * 8;
+    off += rq_list_bytes(k);
     s.res = reinterpret_cast<uint64_t *>(smem + off);
-    off += (size_t)(ef + 1) * 8;
+    off += rq_list_bytes(ef);
     s.ties = reinterpret_cast<uint64_t *>(smem + off);
     off += (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
@@ -345,7 +445,7 @@ __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t d
     return s;
 }
 static size_t rq_smem_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool hnsw) {
-    size_t off = (size_t)4 * nw * 8 + (size_t)(k + 1) * 8 + (size_t)(ef + 1) * 8 + (size_t)RABITQ_TIE_CAP * 8;
+    size_t off = (size_t)4 * nw * 8 + rq_list_bytes(k) + rq_list_bytes(ef) + (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
     off += (size_t)dp * 4;
     if (hnsw) off += (size_t)4 << RABITQ_UPPER_VIS_LOG2;
@@ -363,6 +463,7 @@ __device__ inline void rq_load_query(const RqShared &sh, const RabitqSearchArgs 
 // Rows are visited in address order (= the bitset iteration order); every passing row's estimate gives
 // an upper bound, `upper_bound >= min_score` admits it to the candidate list, and rerank_top consumes
 // that list in the same order.
+template <int NW>
 __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -384,7 +485,7 @@ __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
         }
         if (!__any(ok)) continue;
         float est = 0.f, err = 0.f;
-        if (ok) rabitq_estimate(a.quant + (size_t)r * a.rec_len, sh.planes, nw, qc, est, err);
+        if (ok) rabitq_estimate<NW>(a.quant + (size_t)r * a.rec_len, sh.planes, nw, qc, est, err);
         n_est += (uint32_t)__popcll(__ballot(ok));
         const float ub = est + err;
         rr.feed(ok && ub >= a.min_score, r, ub, lane);
@@ -407,16 +508,20 @@ __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
 // popped, and by then nothing better is left, so it is dropped on the spot.
 struct RqLayer {
     uint64_t *res, *ties;
+    uint64_t worst;        // res[len - 1]
     int len, n_ties, cur;  // cur: every entry before it is expanded
 };
 
 __device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, int lane, uint32_t &flags) {
     int pos;
-    const uint64_t ev = sorted_insert(L.res, L.len, kk, rq_key(est, addr, 1u), lane, pos);
+    L.worst = uni64(L.worst);
+    L.cur = uni(L.cur);
+    L.n_ties = uni(L.n_ties);
+    const uint64_t ev = sorted_insert(L.res, L.len, kk, rq_key(est, addr, 1u), lane, pos, L.worst);
     if (pos < L.cur) L.cur = pos;
-    if (ev != 0 && (ev & 1ull) && L.len > 0) {
-        // still a candidate only while its score is not below the worst result's
-        const float ws = rank_key_score(L.res[L.len - 1]);
+    if (ev != 0 && (ev & 1ull)) {
+        // the evicted entry is still a candidate only while its score is not below the worst result's
+        const float ws = rank_key_score(L.worst);
         if (!(rank_key_score(ev) < ws)) {
             if (L.n_ties < RABITQ_TIE_CAP) {
                 if (lane == 0) L.ties[L.n_ties] = ev;
@@ -428,17 +533,31 @@ __device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, in
     }
 }
 
-// pops the best candidate; returns false when the search is over
-__device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node) {
+// lane i's word of the edge record of `node` (no cross-lane use: the load stays in flight)
+__device__ inline uint32_t load_edge_raw(const GraphDev &g, uint32_t node, int layer, int lane) {
+    if (layer == 0) return g.l0[(size_t)node * NIDX_L0_STRIDE + lane];
+    const uint32_t base = g.upper_base[node];
+    if (base != 0xffffffffu && lane < NIDX_UP_STRIDE) return g.upper[((size_t)base + (layer - 1)) * NIDX_UP_STRIDE + lane];
+    return 0u;
+}
+
+// pops the best candidate; returns false when the search is over.  `next` = the runner-up when it sits in
+// the same 64-key window (0xffffffff otherwise): its edge record is prefetched by the caller.
+__device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node, uint32_t &next) {
+    next = 0xffffffffu;
+    L.cur = uni(L.cur);
+    L.len = uni(L.len);
     while (L.cur < L.len) {
         const int i = L.cur + lane;
-        const bool un = i < L.len && (L.res[i] & 1ull);
-        const unsigned long long m = __ballot(un);
+        const uint64_t mine = i < L.len ? L.res[i] : 0ull;
+        unsigned long long m = __ballot((mine & 1ull) != 0);
         if (m) {
-            const int idx = L.cur + __ffsll((long long)m) - 1;
-            const uint64_t key = L.res[idx];
-            if (lane == 0) L.res[idx] = key & ~1ull;
-            L.cur = idx + 1;
+            const int j = __ffsll((long long)m) - 1;
+            const uint64_t key = lane_u64(mine, j);
+            if (lane == j) L.res[i] = mine & ~1ull;
+            m &= m - 1;
+            if (m) next = rq_addr(lane_u64(mine, __ffsll((long long)m) - 1));
+            L.cur += j + 1;
             node = rq_addr(key);
             return true;  // a member of the result set never scores below its worst entry
         }
@@ -454,12 +573,13 @@ __device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node) {
     const uint64_t last = L.ties[L.n_ties - 1];
     if (lane == 0) L.ties[idx] = last;
     L.n_ties--;
-    const float ws = rank_key_score(L.res[L.len - 1]);
+    const float ws = rank_key_score(L.worst);
     if (rank_key_score(best) < ws) return false;  // `cs < ws => break` (search.rs:271-277)
     node = rq_addr(best);
     return true;
 }
 
+template <int NW>
 __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -470,6 +590,8 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     const RabitqQueryDev qc = a.qd[qi];
     uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
     uint32_t n_est = 0, n_exp = 0, flags = 0;
+    uint64_t cyc_pop = 0, cyc_vis = 0, cyc_est = 0, cyc_ins = 0;
+    const uint64_t t_start = clock64();
 
     uint32_t ep = a.g.ep_node;
     RqLayer L;
@@ -478,6 +600,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const int kk = layer == 0 ? (int)a.ef : 1;
         L.len = 0;
+        L.worst = 0;
         L.n_ties = 0;
         L.cur = 0;
         uint32_t vis_count = 0;
@@ -490,15 +613,28 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         }
         {  // the entry point is admitted unconditionally (search.rs:256-261)
             float est, err;
-            rabitq_estimate(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
+            rabitq_estimate<NW>(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
             n_est++;
             rq_admit(L, kk, est, ep, lane, flags);
         }
-        uint32_t node;
-        while (rq_pop(L, lane, node)) {
-            uint32_t deg;
-            const uint32_t w = load_edge_word(a.g, node, layer, lane, deg);
+        uint32_t node, next, pf_node = 0xffffffffu, pf_word = 0;
+        for (;;) {
+            const uint64_t t0 = clock64();
+            if (!rq_pop(L, lane, node, next)) break;
+            // edge record: one coalesced 256 B (128 B above layer 0) load, usually already here — the runner-up's
+            // record is requested one expansion ahead
+            uint32_t w = node == pf_node ? pf_word : load_edge_raw(a.g, node, layer, lane);
+            pf_node = next;
+            if (next != 0xffffffffu) pf_word = load_edge_raw(a.g, next, layer, lane);
+            const uint32_t deg = lane_u32(w, 0);
             const bool is_edge = lane >= 1 && lane <= (int)deg;
+            const uint64_t t1 = clock64();
+            cyc_pop += t1 - t0;
+            // the code of every neighbour is requested together with the visited test (one round trip instead of
+            // two); codes of already-visited neighbours are dropped
+            RqCode<NW> code;
+            const uint8_t *rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
+            if (is_edge) rq_load_code<NW>(rec, code);
             bool fresh = false;
             if (is_edge) {
                 if (layer > 0) fresh = vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, w);
@@ -506,6 +642,8 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
             }
             n_exp++;
             const unsigned long long fm = __ballot(fresh);
+            const uint64_t t2 = clock64();
+            cyc_vis += t2 - t1;
             if (layer > 0) {
                 vis_count += (uint32_t)__popcll(fm);
                 if (vis_count > (3u << RABITQ_UPPER_VIS_LOG2) / 4u) {
@@ -514,26 +652,33 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
                 }
             }
             float est = 0.f, err = 0.f;
-            if (fresh) rabitq_estimate(a.quant + (size_t)w * a.rec_len, sh.planes, nw, qc, est, err);
+            if (fresh) rq_score_code<NW>(code, rec, sh.planes, nw, qc, est, err);
             n_est += (uint32_t)__popcll(fm);
+            const uint64_t t3 = clock64();
+            cyc_est += t3 - t2;
             // `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295)
             unsigned long long todo = fm;
             while (todo) {
-                const float ws = rank_key_score(L.res[L.len - 1]);
+                todo = uni64(todo);
+                L.len = uni(L.len);
+                L.worst = uni64(L.worst);
+                const float ws = rank_key_score(L.worst);
                 if (L.len >= kk) {
                     todo &= __ballot(fresh && est > ws);
                     if (!todo) break;
                 }
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= ~(1ull << j);
-                const float sj = __shfl(est, j, 64);
-                if (sj > ws || L.len < kk) rq_admit(L, kk, sj, __shfl(w, j, 64), lane, flags);
+                const float sj = lane_f32(est, j);
+                if (sj > ws || L.len < kk) rq_admit(L, kk, sj, lane_u32(w, j), lane, flags);
             }
+            cyc_ins += clock64() - t3;
         }
         ep = rq_addr(L.res[0]);  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
     }
 
     // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
+    const uint64_t t_rr = clock64();
     Reranker rr;
     rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
     for (int base = 0; base < L.len; base += 64) {
@@ -555,6 +700,12 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         o[NIDX_STAT_EXPANSIONS] = n_exp;
         o[NIDX_STAT_VISITED] = rr.n_eval;
         o[NIDX_STAT_FLAGS] = flags;
+        // cycle split of the walk: pop + edge record / visited test / estimates / admission; [7] = total incl. re-rank
+        o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_pop + cyc_vis);
+        o[NIDX_STAT_CYC_EVAL] = (uint32_t)cyc_est;
+        o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
+        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
+        (void)t_rr;
     }
 }
 
@@ -570,21 +721,42 @@ hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, u
     hipLaunchKernelGGL(rabitq_query_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, queries, nq, dp, dim, qd, planes);
     return hipGetLastError();
 }
+template <int NW>
+static hipError_t launch_bf_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_bf_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_bf_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
+    return hipGetLastError();
+}
+template <int NW>
+static hipError_t launch_hnsw_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
+    return hipGetLastError();
+}
+// word counts with a fully unrolled code fetch: 128 .. 2048 dimensions of the usual embedding models
+#define RQ_DISPATCH(fn, nw, ...)                     \
+    switch (nw) {                                    \
+        case 2: return fn<2>(__VA_ARGS__);           \
+        case 4: return fn<4>(__VA_ARGS__);           \
+        case 6: return fn<6>(__VA_ARGS__);           \
+        case 8: return fn<8>(__VA_ARGS__);           \
+        case 12: return fn<12>(__VA_ARGS__);         \
+        case 16: return fn<16>(__VA_ARGS__);         \
+        case 24: return fn<24>(__VA_ARGS__);         \
+        case 32: return fn<32>(__VA_ARGS__);         \
+        default: return fn<0>(__VA_ARGS__);          \
+    }
 hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, 0, false);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rabitq_bf_kernel, dim3(a.n_queries), dim3(64), smem, s, a);
-    return hipGetLastError();
+    const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, 0, false);
+    RQ_DISPATCH(launch_bf_nw, a.seg.dim / 64u, a, smem, s)
 }
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rabitq_hnsw_kernel, dim3(a.n_queries), dim3(64), smem, s, a);
-    return hipGetLastError();
+    const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
+    RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
 }
 
 }  // namespace nidx
