@@ -330,6 +330,50 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
                              float *out_score, uint32_t *out_count, uint64_t *out_total,
                              uint64_t *out_postings);
 
+/* ---- the collectors and query shapes around the scorer ---- */
+
+/* A clause whose `term` is NIDX_BM25_TERM_SET | j matches the UNION of the posting lists of term set j
+ * (options.term_set_terms[term_set_offsets[j] .. term_set_offsets[j+1])), each document once, scored
+ * ConstScorer(boost): FuzzyTermQuery / AutomatonWeight (nidx_paragraph/src/fuzzy_query.rs:55-125). */
+#define NIDX_BM25_TERM_SET 0x80000000u
+
+typedef struct {
+    uint32_t k;                                  /* TopDocs limit (0 with facets = only_faceted) */
+    const nidx_gpu_bm25_search_after_t *after;   /* NULL or [n_queries] (order by score only) */
+    const uint32_t *term_set_terms;              /* term ids of every set, concatenated */
+    const uint64_t *term_set_offsets;            /* [n_term_sets + 1] */
+    uint32_t n_term_sets;
+    /* TopDocs::order_by_fast_field (nidx_text/src/reader.rs:210-224, custom_order_collector): -1 = by score,
+     * else the fast field registered with nidx_gpu_bm25_set_fast_field (0 = created, 1 = modified) */
+    int32_t order_field;
+    int32_t order_desc;
+    /* FacetCollector (nidx_text/src/reader.rs:391-398): query q wants the number of matching documents that
+     * carry each of facet_terms[facet_offsets[q] .. facet_offsets[q+1]) (the term ids of the children of the
+     * requested facets); NULL = no facets */
+    const uint32_t *facet_terms;
+    const uint64_t *facet_offsets;               /* [n_queries + 1] */
+    uint64_t *out_facet_counts;                  /* [facet_offsets[n_queries]], summed over segments */
+    int64_t *out_order_value;                    /* NULL or [n_queries][k]: the fast value of every hit (order_field >= 0) */
+} nidx_gpu_bm25_search_options_t;
+
+/* nidx_gpu_bm25_search with the collectors above; out_score is the BM25 score when ordering by score and 0
+ * when ordering by a fast field (the reference returns the sort value instead, reader.rs:262-270). */
+int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses,
+                                const uint64_t *clause_offsets, uint32_t n_queries,
+                                const nidx_gpu_bm25_search_options_t *options, uint64_t *out_docaddr,
+                                float *out_score, uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings);
+
+/* The `created` / `modified` fast fields of one segment (nidx_text/src/schema.rs:59-115): values[doc]. */
+int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values);
+
+/* The term dictionary of the scored text field: term id t = bytes[offsets[t] .. offsets[t+1]) (UTF-8). */
+int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t *bytes, const uint64_t *offsets);
+/* FuzzyTermQuery's automaton over the dictionary (fuzzy_query.rs:127-251; Levenshtein distance 1, a
+ * transposition costs one, fuzzy_parser.rs:38-74; prefix != 0 = build_prefix_dfa): the ids of the accepted
+ * terms, ascending.  n_out receives the full count even when it exceeds cap. */
+int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *query_utf8, uint32_t query_len,
+                                  int32_t prefix, uint32_t *out_terms, uint32_t cap, uint32_t *n_out);
+
 /* Device time (HIP events on the handle's stream) spent in the scoring kernel(s) of the last
  * nidx_gpu_bm25_search call, summed over segments. */
 int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out);

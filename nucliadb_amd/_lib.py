@@ -70,6 +70,25 @@ class VectorSegmentC(C.Structure):
     ]
 
 
+class Bm25SearchOptionsC(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32),
+        ("after", C.c_void_p),
+        ("term_set_terms", C.c_void_p),
+        ("term_set_offsets", C.c_void_p),
+        ("n_term_sets", C.c_uint32),
+        ("order_field", C.c_int32),
+        ("order_desc", C.c_int32),
+        ("facet_terms", C.c_void_p),
+        ("facet_offsets", C.c_void_p),
+        ("out_facet_counts", C.c_void_p),
+        ("out_order_value", C.c_void_p),
+    ]
+
+
+BM25_TERM_SET = 0x80000000
+
+
 class FilterIndexC(C.Structure):
     _fields_ = [("n_lists", C.c_uint32), ("list_offsets", C.c_void_p), ("paragraph_ids", C.c_void_p)]
 
@@ -155,6 +174,11 @@ SIGNATURES = {
     "nidx_gpu_bm25_space_usage": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_search_ex": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Bm25SearchOptionsC), C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_set_fast_field": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nidx_gpu_bm25_set_dictionary": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_fuzzy_terms": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_bm25_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "nidx_gpu_bm25_idf": (C.c_float, [C.c_uint64, C.c_uint64]),
     "nidx_gpu_fieldnorm_from_id": (C.c_uint32, [C.c_uint8]),

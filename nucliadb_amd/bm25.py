@@ -26,6 +26,9 @@ class Clause:
     occur: int = _lib.OCCUR_SHOULD
     mode: int = _lib.TF_FREQ
     boost: float = 1.0
+    # FuzzyTermQuery (fuzzy_query.rs:55-125): the clause is the UNION of these terms' documents, each scored
+    # ConstScorer(boost) once; `term` and `mode` are ignored
+    term_set: Optional[Sequence[int]] = None
 
 
 @dataclass
@@ -122,8 +125,98 @@ class Bm25Searcher:
         _lib.check(_lib.lib().nidx_gpu_bm25_space_usage(self._handle, C.byref(out)))
         return out.value
 
+    def set_fast_field(self, segment: int, field: int, values) -> None:
+        """`created` (0) / `modified` (1) fast field of one segment: int64 per document."""
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        assert v.size == self.segments[segment].n_docs
+        _lib.check(_lib.lib().nidx_gpu_bm25_set_fast_field(self._handle, segment, field, v.ctypes.data))
+
+    def set_dictionary(self, terms: Sequence[str]) -> None:
+        """The term dictionary of the scored field, term id = position."""
+        enc = [t.encode("utf-8") for t in terms]
+        offs = np.zeros(len(enc) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(e) for e in enc])
+        blob = np.frombuffer(b"".join(enc) or b"\0", np.uint8)
+        _lib.check(_lib.lib().nidx_gpu_bm25_set_dictionary(self._handle, blob.ctypes.data, offs.ctypes.data))
+
+    def fuzzy_terms(self, word: str, prefix: bool = False) -> np.ndarray:
+        """Ids of the dictionary terms FuzzyTermQuery's automaton accepts (distance 1, transposition = one edit)."""
+        q = word.encode("utf-8")
+        n = C.c_uint32(0)
+        cap = 1024
+        while True:
+            out = np.zeros(cap, np.uint32)
+            _lib.check(_lib.lib().nidx_gpu_bm25_fuzzy_terms(self._handle, q, len(q), int(prefix), out.ctypes.data, cap, C.byref(n)))
+            if n.value <= cap:
+                return out[: n.value].copy()
+            cap = n.value
+
+    def search_batch_ex(self, queries: Sequence[Sequence[Clause]], k: int, after: Optional[Sequence[Optional[SearchAfter]]] = None,
+                        order_field: int = -1, order_desc: bool = True, facets: Optional[Sequence[Sequence[int]]] = None):
+        """The collectors around the scoring (nidx_text/src/reader.rs:367-451): term-set clauses, TopDocs ordered by a
+        fast field, facet counts (facets[q] = term ids to count among query q's matching documents).
+        -> dict(docaddr, score, count, total, postings, order_value, facet_counts[q] = counts aligned with facets[q])"""
+        B = len(queries)
+        offsets = np.zeros(B + 1, dtype=np.uint64)
+        flat = []
+        for i, q in enumerate(queries):
+            flat.extend(q)
+            offsets[i + 1] = len(flat)
+        cl = (_lib.Bm25ClauseC * max(1, len(flat)))()
+        set_terms: List[int] = []
+        set_offsets = [0]
+        for i, c in enumerate(flat):
+            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
+            if c.term_set is not None:
+                cl[i].term = _lib.BM25_TERM_SET | (len(set_offsets) - 1)
+                cl[i].mode = _lib.CONST_SCORE
+                set_terms.extend(int(t) for t in c.term_set)
+                set_offsets.append(len(set_terms))
+        af = None
+        if after is not None:
+            af = (_lib.Bm25SearchAfterC * max(1, B))()
+            for i, a in enumerate(after):
+                if a is not None:
+                    af[i].has_after, af[i].score, af[i].tie_break, af[i].docaddr = 1, a.score, a.tie_break, a.docaddr
+        kk = max(1, k)
+        docaddr = np.zeros((B, kk), dtype=np.uint64)
+        score = np.zeros((B, kk), dtype=np.float32)
+        order_value = np.zeros((B, kk), dtype=np.int64)
+        count = np.zeros(B, dtype=np.uint32)
+        total = np.zeros(B, dtype=np.uint64)
+        postings = np.zeros(B, dtype=np.uint64)
+        st = np.ascontiguousarray(set_terms, dtype=np.uint32)
+        so = np.ascontiguousarray(set_offsets, dtype=np.uint64)
+        opt = _lib.Bm25SearchOptionsC()
+        opt.k = k
+        opt.after = C.cast(af, C.c_void_p) if af is not None else None
+        opt.term_set_terms = st.ctypes.data if st.size else None
+        opt.term_set_offsets = so.ctypes.data
+        opt.n_term_sets = len(set_offsets) - 1
+        opt.order_field, opt.order_desc = order_field, int(order_desc)
+        fo = ft = fc = None
+        if facets is not None:
+            fo = np.zeros(B + 1, np.uint64)
+            fo[1:] = np.cumsum([len(f) for f in facets])
+            ft = np.ascontiguousarray([t for f in facets for t in f], dtype=np.uint32)
+            fc = np.zeros(max(int(fo[-1]), 1), np.uint64)
+            opt.facet_terms = ft.ctypes.data if ft.size else None
+            opt.facet_offsets = fo.ctypes.data
+            opt.out_facet_counts = fc.ctypes.data
+        opt.out_order_value = order_value.ctypes.data
+        _lib.check(_lib.lib().nidx_gpu_bm25_search_ex(self._handle, cl, offsets.ctypes.data, B, C.byref(opt), docaddr.ctypes.data,
+                                                      score.ctypes.data, count.ctypes.data, total.ctypes.data, postings.ctypes.data))
+        facet_counts = None
+        if facets is not None:
+            facet_counts = [fc[int(fo[q]): int(fo[q + 1])].astype(np.int64) for q in range(B)]
+        return {"docaddr": docaddr, "score": score, "count": count, "total": total, "postings": postings,
+                "order_value": order_value, "facet_counts": facet_counts}
+
     def search_batch(self, queries: Sequence[Sequence[Clause]], k: int, after: Optional[Sequence[Optional[SearchAfter]]] = None):
         """-> (docaddr [B][k] u64, score [B][k] f32, count [B], total [B], postings [B])"""
+        if any(c.term_set is not None for q in queries for c in q):
+            r = self.search_batch_ex(queries, k, after)
+            return r["docaddr"], r["score"], r["count"], r["total"], r["postings"]
         B = len(queries)
         offsets = np.zeros(B + 1, dtype=np.uint64)
         flat = []

@@ -33,6 +33,7 @@ struct Bm25Shared {
     float tf_cache[256];
     unsigned long long cursor[BM25_MAX_CLAUSES];
     unsigned long long end[BM25_MAX_CLAUSES];
+    const uint32_t *base[BM25_MAX_CLAUSES];  // doc-id array the clause's cursor indexes (postings, or a materialised term set)
     uint32_t hi;
     uint32_t taken_c[BM25_MAX_CLAUSES];
     unsigned long long total;
@@ -62,17 +63,25 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         n_must += cl[c].occur == 1 ? 1 : 0;
         n_group += cl[c].occur == 3 ? 1 : 0;
     }
+    if (tid < C) sh.base[tid] = (cl[tid].term & BM25_AUX_TERM) ? a.aux_doc_ids : a.doc_ids;
     if (work.n_slices <= 1) {
         if (tid < C) {
-            sh.cursor[tid] = a.term_offsets[cl[tid].term];
-            sh.end[tid] = a.term_offsets[cl[tid].term + 1];
+            const uint32_t t = cl[tid].term;
+            const bool aux = (t & BM25_AUX_TERM) != 0;  // aux lists: [begin, end) pairs
+            const uint32_t ti = t & ~BM25_AUX_TERM;
+            sh.cursor[tid] = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
+            sh.end[tid] = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
         }
     } else {
         // doc range of this slice; per clause a wave finds the first posting >= lo and >= hi
         const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
         const uint32_t hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
         for (int c = wib; c < C; c += 4) {
-            const unsigned long long b = a.term_offsets[cl[c].term], e = a.term_offsets[cl[c].term + 1];
+            const uint32_t t = cl[c].term;
+            const bool aux = (t & BM25_AUX_TERM) != 0;
+            const uint32_t ti = t & ~BM25_AUX_TERM;
+            const uint32_t *ids = aux ? a.aux_doc_ids : a.doc_ids;
+            const unsigned long long b = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti], e = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
             unsigned long long res[2];
 #pragma unroll
             for (int w = 0; w < 2; w++) {
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                 while (right - left > 64) {
                     unsigned long long step = (right - left + 63) / 64;
                     unsigned long long probe = left + step * (unsigned long long)lane;
-                    bool ge = probe < right ? a.doc_ids[probe] >= target : true;
+                    bool ge = probe < right ? ids[probe] >= target : true;
                     unsigned long long m = __ballot(ge);
                     int first = m ? __ffsll((long long)m) - 1 : 64;
                     unsigned long long nl = first == 0 ? left : left + step * (unsigned long long)(first - 1);
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                     right = nr < right ? nr : right;
                 }
                 unsigned long long probe = left + (unsigned long long)lane;
-                bool ge = probe < right ? a.doc_ids[probe] >= target : true;
+                bool ge = probe < right ? ids[probe] >= target : true;
                 unsigned long long m = __ballot(ge);
                 int first = m ? __ffsll((long long)m) - 1 : 64;
                 res[w] = left + (unsigned long long)first < right ? left + (unsigned long long)first : right;
@@ -118,6 +127,8 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     const int32_t after_key = has_after ? total_key(a.after[q].score) : 0;
     const int after_tie = has_after ? a.after[q].tie_break : 0;
     const uint64_t after_addr = has_after ? a.after[q].docaddr : 0;
+    const int mslot = a.match_slot ? a.match_slot[q] : -1;
+    uint32_t *mbits = mslot >= 0 ? a.match_bits + (size_t)mslot * a.match_words : nullptr;
 
     for (;;) {
         // ---- window end: smallest doc id that some clause could not fit ----
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         if (!any_left) break;
         if (tid < C) {
             unsigned long long cur = sh.cursor[tid], e = sh.end[tid];
-            if (cur + per < e) atomicMin(&sh.hi, a.doc_ids[cur + per]);
+            if (cur + per < e) atomicMin(&sh.hi, sh.base[tid][cur + per]);
         }
         __syncthreads();
         const uint32_t hi = sh.hi;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             if (c < C) {
                 const unsigned long long i = sh.cursor[c] + (g - (uint32_t)c * per);
                 if (i < sh.end[c]) {
-                    const uint32_t d = a.doc_ids[i];
+                    const uint32_t d = sh.base[c][i];
                     if (d < hi) {  // hi == 0xffffffff: every clause's remainder fits
                         p_clause[m] = c;
                         p_doc[m] = d;
@@ -212,7 +223,12 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
                 uint16_t f = sh.flags[i];
                 ok = !(f & 2) && (int)(f >> 8) == n_must && (n_group == 0 || (f & 4)) && (n_must > 0 || n_group > 0 || (f & 1));
                 if (ok && a.alive) ok = bit_test(a.alive, d);
-                if (ok) {
+                if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
+                if (ok && a.order_key) {
+                    // order_by_fast_field: the fast value's dense rank decides, then the lower doc id
+                    const uint32_t r = a.order_key[d];
+                    ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
+                } else if (ok) {
                     float s = sh.acc[i];
                     if (has_after) {
                         // tweak_score: -inf for docs not after the cursor

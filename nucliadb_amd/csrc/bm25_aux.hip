@@ -1,0 +1,170 @@
+// bm25_aux.hip — the pieces around the BM25 scorer, gfx950.
+//
+//   fuzzy_match_kernel    FuzzyTermQuery's Levenshtein automaton (nidx_paragraph/src/fuzzy_query.rs:127-251,
+//                         query_parser/fuzzy_parser.rs:35-93: distance 1, transposition_cost_one, prefix DFA for the
+//                         last literal) evaluated against EVERY term of the dictionary in parallel — tantivy walks
+//                         its FST with the DFA; here the dictionary is a byte blob in HBM and each thread decides one
+//                         term with the closed form of "edit distance <= 1".  HBM-bound: one pass over the blob.
+//   bitset_compact_kernel AutomatonWeight::scorer (fuzzy_query.rs:90-125) inserts every posting of every accepted term
+//                         into a doc BitSet and scores it with ConstScorer: the union is scattered into a bitset
+//                         (filter.hip: launch_bitset_scatter) and compacted here into an ascending doc-id list that the
+//                         scoring kernel consumes like any posting list (bm25.hip: BM25_AUX_TERM).
+//   facet_count_kernel    FacetCollector (nidx_text/src/reader.rs:43-62,391-398; nidx_paragraph/src/reader.rs:244-348):
+//                         a facet's count = |postings(facet term) ∩ matching documents|; the scoring kernel leaves the
+//                         matching documents of a query as a bitset.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+#define FUZZY_MAX_CP 48  /* tantivy's RemoveLongFilter drops tokens over 40 bytes: no term is longer */
+
+// first `cap` unicode scalar values of a UTF-8 string; returns how many were decoded, *more = bytes were left
+__device__ inline int utf8_head(const uint8_t *s, uint32_t len, uint32_t *out, int cap, bool *more) {
+    int n = 0;
+    uint32_t i = 0;
+    while (i < len && n < cap) {
+        uint32_t c = s[i];
+        const int extra = c < 0x80 ? 0 : (c >> 5) == 6 ? 1 : (c >> 4) == 14 ? 2 : (c >> 3) == 30 ? 3 : 0;
+        if (extra == 1) c &= 0x1f;
+        else if (extra == 2) c &= 0x0f;
+        else if (extra == 3) c &= 0x07;
+        i++;
+        for (int e = 0; e < extra && i < len; e++, i++) c = (c << 6) | (s[i] & 0x3f);
+        out[n++] = c;
+    }
+    *more = i < len;
+    return n;
+}
+
+// q[a .. a + len) == t[b .. b + len) ?
+__device__ inline bool cp_equal(const uint32_t *q, int a, const uint32_t *t, int b, int len) {
+    for (int i = 0; i < len; i++)
+        if (q[a + i] != t[b + i]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void fuzzy_match_kernel(const uint8_t *dict_bytes, const unsigned long long *dict_offsets,
+                                                          uint32_t n_terms, const uint32_t *query_cp, uint32_t n_query_cp, int prefix,
+                                                          uint8_t *flags) {
+    __shared__ uint32_t q[FUZZY_MAX_CP];
+    if (threadIdx.x < n_query_cp) q[threadIdx.x] = query_cp[threadIdx.x];
+    __syncthreads();
+    const uint32_t term = blockIdx.x * blockDim.x + threadIdx.x;
+    if (term >= n_terms) return;
+    const int n = (int)n_query_cp;
+    const unsigned long long b = dict_offsets[term], e = dict_offsets[term + 1];
+    uint32_t t[FUZZY_MAX_CP + 2];
+    bool more;
+    // only the first n + 2 characters can matter: one more and the term is too long (exact), or past every
+    // prefix that could be within one edit of the query (prefix)
+    const int m = utf8_head(dict_bytes + b, (uint32_t)(e - b), t, n + 2, &more);
+    const bool t_longer_than_n1 = m == n + 2;  // the term has at least n + 2 characters
+    int i = 0;
+    const int lim = n < m ? n : m;
+    while (i < lim && q[i] == t[i]) i++;
+    bool ok = false;
+    if (!prefix) {
+        if (!t_longer_than_n1 && m + 1 >= n) {         // |n - m| <= 1
+            if (i == lim) ok = true;                   // one is a prefix of the other (or they are equal)
+            else if (n == m) ok = cp_equal(q, i + 1, t, i + 1, n - i - 1) ||                                    // substitution
+                                  (i + 1 < n && q[i] == t[i + 1] && q[i + 1] == t[i] && cp_equal(q, i + 2, t, i + 2, n - i - 2));  // transposition
+            else if (n == m + 1) ok = cp_equal(q, i + 1, t, i, n - i - 1);                                     // the query has one extra
+            else ok = cp_equal(q, i, t, i + 1, n - i);                                                           // the term has one extra
+        }
+    } else {
+        if (i == n) ok = true;                         // the query itself is a prefix of the term
+        else if (i == m) ok = n - m <= 1;              // the term is the query minus its last character
+        else {
+            if (m >= n) ok = cp_equal(q, i + 1, t, i + 1, n - i - 1) ||                                          // substitution, prefix of length n
+                             (i + 1 < n && q[i] == t[i + 1] && q[i + 1] == t[i] && cp_equal(q, i + 2, t, i + 2, n - i - 2));
+            if (!ok && m >= n - 1) ok = cp_equal(q, i + 1, t, i, n - i - 1);                                    // prefix of length n - 1
+            if (!ok && m >= n + 1) ok = cp_equal(q, i, t, i + 1, n - i);                                        // prefix of length n + 1
+        }
+    }
+    flags[term] = ok ? 1 : 0;
+}
+
+hipError_t launch_fuzzy_match(const uint8_t *dict_bytes, const unsigned long long *dict_offsets, uint32_t n_terms,
+                              const uint32_t *query_cp, uint32_t n_query_cp, int prefix, uint8_t *flags, hipStream_t s) {
+    if (n_terms == 0) return hipSuccess;
+    if (n_query_cp == 0 || n_query_cp > FUZZY_MAX_CP) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fuzzy_match_kernel, dim3((n_terms + 255) / 256), dim3(256), 0, s, dict_bytes, dict_offsets, n_terms, query_cp,
+                       n_query_cp, prefix, flags);
+    return hipGetLastError();
+}
+
+// ---- bitset -> ascending id list, one block per bitset -------------------------------------------------------
+__global__ __launch_bounds__(256) void bitset_compact_kernel(const uint64_t *bits, uint32_t n_words, const unsigned long long *out_offsets,
+                                                             uint32_t *out, uint32_t *counts) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const uint64_t *b = bits + (size_t)blockIdx.x * n_words;
+    uint32_t *o = out + out_offsets[blockIdx.x];
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < n_words; w0 += 256) {
+        const uint32_t w = w0 + (uint32_t)tid;
+        uint64_t x = w < n_words ? b[w] : 0ull;
+        const uint32_t c = (uint32_t)__popcll(x);
+        // exclusive scan of c over the block: wave scan, then the four wave totals
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wib] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int i = 0; i < wib; i++) before += wave_sum[i];
+        uint32_t pos = before + incl - c;
+        while (x) {
+            const int bit = __ffsll((long long)x) - 1;
+            x &= x - 1;
+            o[pos++] = w * 64u + (uint32_t)bit;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+    if (tid == 0) counts[blockIdx.x] = base_s;
+}
+
+hipError_t launch_bitset_compact(const uint64_t *bits, uint32_t n_words, uint32_t n_sets, const unsigned long long *out_offsets,
+                                 uint32_t *out, uint32_t *counts, hipStream_t s) {
+    if (n_sets == 0) return hipSuccess;
+    hipLaunchKernelGGL(bitset_compact_kernel, dim3(n_sets), dim3(256), 0, s, bits, n_words, out_offsets, out, counts);
+    return hipGetLastError();
+}
+
+// ---- facet counts -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void facet_count_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids,
+                                                          const uint32_t *pair_term, const int *pair_slot, const uint32_t *match_bits,
+                                                          uint32_t match_words, unsigned long long *counts) {
+    const uint32_t p = blockIdx.x;
+    const int slot = pair_slot[p];
+    if (slot < 0) return;
+    const uint32_t *mb = match_bits + (size_t)slot * match_words;
+    const unsigned long long b = term_offsets[pair_term[p]], e = term_offsets[pair_term[p] + 1];
+    uint32_t c = 0;
+    for (unsigned long long i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const uint32_t d = doc_ids[i];
+        c += (mb[d >> 5] >> (d & 31)) & 1u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[p], (unsigned long long)c);
+}
+
+hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *pair_term,
+                              const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,
+                              unsigned long long *counts, hipStream_t s) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(facet_count_kernel, dim3(n_pairs), dim3(256), 0, s, term_offsets, doc_ids, pair_term, pair_slot, match_bits,
+                       match_words, counts);
+    return hipGetLastError();
+}
+
+}  // namespace nidx

@@ -50,7 +50,12 @@ struct Bm25Segment {
     std::vector<uint64_t> term_offsets_host;
     DevBuf term_offsets, doc_ids, tfs, fieldnorm_ids, alive;
     bool all_alive = true;
-    uint64_t bytes() const { return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes; }
+    // fast fields (created, modified): host values + their dense ranks in HBM (the kernel orders by rank)
+    std::vector<int64_t> fast_host[2];
+    DevBuf order_key[2];
+    uint64_t bytes() const {
+        return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes + order_key[0].bytes + order_key[1].bytes;
+    }
 };
 
 struct Bm25Index {
@@ -62,6 +67,11 @@ struct Bm25Index {
     uint32_t n_terms = 0;
     DevBuf tf_cache;
     DevBuf s_clauses, s_offsets, s_after, s_work, s_doc, s_score, s_count, s_total, s_postings;
+    // term dictionary (fuzzy expansion) and the scratch of the collectors
+    DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
+    bool has_dict = false;
+    DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
+        s_facet_counts;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
 };
@@ -157,21 +167,111 @@ int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *
     return NIDX_OK;
 }
 
-int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses,
-                             const uint64_t *clause_offsets, uint32_t nq, uint32_t k,
-                             const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr, float *out_score,
-                             uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values) {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
-    if (!idx || !clause_offsets || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!idx || segment >= idx->segs.size() || field > 1 || !values) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad fast field");
     std::lock_guard<std::mutex> lock(idx->mu);
     NIDX_HIP(hipSetDevice(idx->device));
+    Bm25Segment &seg = idx->segs[segment];
+    seg.fast_host[field].assign(values, values + seg.n_docs);
+    // dense ranks: equal values <=> equal ranks, order preserved
+    std::vector<int64_t> uniq(seg.fast_host[field]);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    std::vector<uint32_t> rank(seg.n_docs);
+    for (uint32_t d = 0; d < seg.n_docs; d++)
+        rank[d] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), values[d]) - uniq.begin()) + 1u;
+    NIDX_HIP(seg.order_key[field].alloc(std::max<size_t>(seg.n_docs, 1) * 4));
+    if (seg.n_docs) NIDX_HIP(hipMemcpy(seg.order_key[field].p, rank.data(), (size_t)seg.n_docs * 4, hipMemcpyHostToDevice));
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t *bytes, const uint64_t *offsets) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !offsets) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    const uint64_t total = offsets[idx->n_terms];
+    if (total && !bytes) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL dictionary bytes");
+    NIDX_HIP(idx->dict_bytes.alloc(std::max<uint64_t>(total, 1)));
+    NIDX_HIP(idx->dict_offsets.alloc((size_t)(idx->n_terms + 1) * 8));
+    if (total) NIDX_HIP(hipMemcpy(idx->dict_bytes.p, bytes, total, hipMemcpyHostToDevice));
+    NIDX_HIP(hipMemcpy(idx->dict_offsets.p, offsets, (size_t)(idx->n_terms + 1) * 8, hipMemcpyHostToDevice));
+    idx->has_dict = true;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *query, uint32_t query_len, int32_t prefix,
+                                  uint32_t *out_terms, uint32_t cap, uint32_t *n_out) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !n_out || (query_len && !query)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    *n_out = 0;
+    if (!idx->has_dict) return fail(NIDX_ERR_INVALID_ARGUMENT, "no term dictionary: call nidx_gpu_bm25_set_dictionary first");
+    // unicode scalar values of the query
+    std::vector<uint32_t> cp;
+    for (uint32_t i = 0; i < query_len;) {
+        uint32_t c = query[i];
+        int extra = c < 0x80 ? 0 : (c >> 5) == 6 ? 1 : (c >> 4) == 14 ? 2 : (c >> 3) == 30 ? 3 : 0;
+        if (extra == 1) c &= 0x1f;
+        else if (extra == 2) c &= 0x0f;
+        else if (extra == 3) c &= 0x07;
+        i++;
+        for (int e = 0; e < extra && i < query_len; e++, i++) c = (c << 6) | (query[i] & 0x3f);
+        cp.push_back(c);
+    }
+    if (cp.empty() || cp.size() > 48) return NIDX_OK;  // nothing within one edit of an indexed token (<= 40 bytes)
+    if (idx->n_terms == 0) return NIDX_OK;
+    NIDX_HIP(idx->s_fuzzy_q.reserve(cp.size() * 4));
+    NIDX_HIP(idx->s_fuzzy_flags.reserve(idx->n_terms));
+    NIDX_HIP(hipMemcpyAsync(idx->s_fuzzy_q.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice, idx->stream));
+    NIDX_HIP(launch_fuzzy_match(idx->dict_bytes.as<uint8_t>(), idx->dict_offsets.as<unsigned long long>(), idx->n_terms,
+                                idx->s_fuzzy_q.as<uint32_t>(), (uint32_t)cp.size(), prefix ? 1 : 0, idx->s_fuzzy_flags.as<uint8_t>(), idx->stream));
+    std::vector<uint8_t> flags(idx->n_terms);
+    NIDX_HIP(hipMemcpyAsync(flags.data(), idx->s_fuzzy_flags.p, idx->n_terms, hipMemcpyDeviceToHost, idx->stream));
+    NIDX_HIP(hipStreamSynchronize(idx->stream));
+    uint32_t n = 0;
+    for (uint32_t t = 0; t < idx->n_terms; t++)
+        if (flags[t]) {
+            if (out_terms && n < cap) out_terms[n] = t;
+            n++;
+        }
+    *n_out = n;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                                uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
+                                uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !clause_offsets || !out_count || !opt) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    const uint32_t k = opt->k;
+    const nidx_gpu_bm25_search_after_t *after = opt->after;
     for (uint32_t q = 0; q < nq; q++) {
         out_count[q] = 0;
         if (out_total) out_total[q] = 0;
         if (out_postings) out_postings[q] = 0;
     }
+    const uint64_t n_pairs = opt->facet_offsets ? opt->facet_offsets[nq] : 0;
+    for (uint64_t p = 0; p < n_pairs && opt->out_facet_counts; p++) opt->out_facet_counts[p] = 0;
     if (nq == 0) return NIDX_OK;
     if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > 256 is not supported (got %u)", k);
+    const int order_field = opt->order_field;
+    if (order_field > 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown fast field %d", order_field);
+    if (order_field >= 0) {
+        if (after) return fail(NIDX_ERR_UNSUPPORTED, "search-after applies to the score order only");
+        for (const Bm25Segment &sg : idx->segs)
+            if (sg.n_docs && !sg.order_key[order_field].p) return fail(NIDX_ERR_INVALID_ARGUMENT, "fast field %d was not registered for every segment", order_field);
+    }
+    if (n_pairs && (!opt->facet_terms || !opt->out_facet_counts)) return fail(NIDX_ERR_INVALID_ARGUMENT, "facets without terms / output");
+    const uint32_t n_sets = opt->n_term_sets;
+    if (n_sets && (!opt->term_set_offsets || (opt->term_set_offsets[n_sets] && !opt->term_set_terms)))
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "term sets without terms");
+    for (uint64_t i = 0; n_sets && i < opt->term_set_offsets[n_sets]; i++)
+        if (opt->term_set_terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term set: term id %u out of range", opt->term_set_terms[i]);
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
@@ -183,8 +283,13 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
     }
     for (uint64_t c = 0; c < n_clauses; c++) {
         const nidx_gpu_bm25_clause_t &cl = clauses[c];
-        if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
         if (cl.occur < 0 || cl.occur > 3 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        if (cl.term & NIDX_BM25_TERM_SET) {
+            if ((cl.term & ~NIDX_BM25_TERM_SET) >= n_sets) return fail(NIDX_ERR_INVALID_ARGUMENT, "term set %u out of range", cl.term & ~NIDX_BM25_TERM_SET);
+            dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, NIDX_CONST_SCORE, cl.boost};  // ConstScorer(boost)
+            continue;
+        }
+        if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
         uint64_t df = 0;
         for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
         float w = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
@@ -201,8 +306,38 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         NIDX_HIP(idx->s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
         NIDX_HIP(hipMemcpyAsync(idx->s_after.p, after, (size_t)nq * sizeof(Bm25AfterDev), hipMemcpyHostToDevice, idx->stream));
     }
+    // facets: one matching-document bitset per query that asks for counts
+    std::vector<int> match_slot(nq, -1);
+    std::vector<uint32_t> pair_term(n_pairs);
+    std::vector<int> pair_slot(n_pairs, -1);
+    uint32_t n_slots = 0;
+    for (uint32_t q = 0; q < nq && n_pairs; q++) {
+        if (opt->facet_offsets[q + 1] < opt->facet_offsets[q]) return fail(NIDX_ERR_INVALID_ARGUMENT, "facet_offsets not monotone");
+        if (opt->facet_offsets[q + 1] == opt->facet_offsets[q]) continue;
+        match_slot[q] = (int)n_slots++;
+        for (uint64_t p = opt->facet_offsets[q]; p < opt->facet_offsets[q + 1]; p++) {
+            if (opt->facet_terms[p] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "facet term id %u out of range", opt->facet_terms[p]);
+            pair_term[p] = opt->facet_terms[p];
+            pair_slot[p] = match_slot[q];
+        }
+    }
+    if (n_slots) {
+        NIDX_HIP(idx->s_match_slot.reserve((size_t)nq * 4));
+        NIDX_HIP(idx->s_pair_term.reserve(n_pairs * 4));
+        NIDX_HIP(idx->s_pair_slot.reserve(n_pairs * 4));
+        NIDX_HIP(idx->s_facet_counts.reserve(n_pairs * 8));
+        NIDX_HIP(hipMemcpyAsync(idx->s_match_slot.p, match_slot.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(idx->s_pair_term.p, pair_term.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(idx->s_pair_slot.p, pair_slot.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
+        NIDX_HIP(hipMemsetAsync(idx->s_facet_counts.p, 0, n_pairs * 8, idx->stream));
+    }
+    if (n_sets) {
+        const uint64_t n_set_terms = opt->term_set_offsets[n_sets];
+        NIDX_HIP(idx->s_set_terms.reserve(std::max<uint64_t>(n_set_terms, 1) * 4));
+        if (n_set_terms) NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, opt->term_set_terms, n_set_terms * 4, hipMemcpyHostToDevice, idx->stream));
+    }
     idx->last_kernel_ms = 0.f;
-    struct Hit { float score; uint64_t docaddr; };
+    struct Hit { float score; uint64_t docaddr; int64_t value; };
     std::vector<std::vector<Hit>> merged(nq);
     std::vector<Bm25Work> work;
     std::vector<uint32_t> h_doc, h_count;
@@ -210,12 +345,53 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
     std::vector<unsigned long long> h_total, h_post;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
+        // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
+        std::vector<unsigned long long> aux_pairs(2 * (size_t)n_sets + 2, 0);  // [begin, end) per set into s_aux_ids
+        std::vector<uint32_t> set_counts(n_sets, 0);
+        if (n_sets) {
+            const uint32_t words = (seg.n_docs + 63) / 64;
+            std::vector<unsigned long long> out_off(n_sets + 1, 0);
+            for (uint32_t j = 0; j < n_sets; j++) {
+                uint64_t df = 0;
+                for (uint64_t i = opt->term_set_offsets[j]; i < opt->term_set_offsets[j + 1]; i++)
+                    df += seg.term_offsets_host[opt->term_set_terms[i] + 1] - seg.term_offsets_host[opt->term_set_terms[i]];
+                out_off[j + 1] = out_off[j] + std::min<uint64_t>(df, seg.n_docs);
+            }
+            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
+            NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_sets + 1) * 8));
+            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_sets], 1) * 4));
+            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_sets * 4));
+            NIDX_HIP(hipMemcpyAsync(idx->s_aux_out_off.p, out_off.data(), (size_t)(n_sets + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+            if (words) {
+                NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, idx->stream));
+                for (uint32_t j = 0; j < n_sets; j++) {
+                    const uint32_t nl = (uint32_t)(opt->term_set_offsets[j + 1] - opt->term_set_offsets[j]);
+                    if (nl)
+                        NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
+                                                       idx->s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
+                                                       idx->s_set_bits.as<uint64_t>() + (size_t)j * words, idx->stream));
+                }
+                NIDX_HIP(launch_bitset_compact(idx->s_set_bits.as<uint64_t>(), words, n_sets, idx->s_aux_out_off.as<unsigned long long>(),
+                                               idx->s_aux_ids.as<uint32_t>(), idx->s_set_counts.as<uint32_t>(), idx->stream));
+                NIDX_HIP(hipMemcpyAsync(set_counts.data(), idx->s_set_counts.p, (size_t)n_sets * 4, hipMemcpyDeviceToHost, idx->stream));
+                NIDX_HIP(hipStreamSynchronize(idx->stream));
+            }
+            for (uint32_t j = 0; j < n_sets; j++) {
+                aux_pairs[2 * j] = out_off[j];
+                aux_pairs[2 * j + 1] = out_off[j] + set_counts[j];
+            }
+            NIDX_HIP(idx->s_aux_off.reserve(aux_pairs.size() * 8));
+            NIDX_HIP(hipMemcpyAsync(idx->s_aux_off.p, aux_pairs.data(), aux_pairs.size() * 8, hipMemcpyHostToDevice, idx->stream));
+        }
+        auto postings_of = [&](const nidx_gpu_bm25_clause_t &cl) -> uint64_t {
+            if (cl.term & NIDX_BM25_TERM_SET) return set_counts[cl.term & ~NIDX_BM25_TERM_SET];
+            return seg.term_offsets_host[cl.term + 1] - seg.term_offsets_host[cl.term];
+        };
         // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
         work.clear();
         for (uint32_t q = 0; q < nq; q++) {
             uint64_t p = 0;
-            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++)
-                p += seg.term_offsets_host[clauses[c].term + 1] - seg.term_offsets_host[clauses[c].term];
+            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) p += postings_of(clauses[c]);
             uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + BM25_SLICE_POSTINGS - 1) / BM25_SLICE_POSTINGS));
             for (uint32_t sl = 0; sl < slices; sl++) work.push_back(Bm25Work{q, sl, slices});
         }
@@ -227,6 +403,15 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         NIDX_HIP(idx->s_total.reserve(nw * 8));
         NIDX_HIP(idx->s_postings.reserve(nw * 8));
         NIDX_HIP(hipMemcpyAsync(idx->s_work.p, work.data(), nw * sizeof(Bm25Work), hipMemcpyHostToDevice, idx->stream));
+        const uint32_t match_words = (seg.n_docs + 31) / 32;
+        if (n_slots) {
+            const uint64_t bytes = (uint64_t)n_slots * std::max<uint32_t>(match_words, 1) * 4;
+            if (bytes > (1ull << 30))
+                return fail(NIDX_ERR_UNSUPPORTED, "%u faceted queries over a %u-document segment need %llu bytes of match bitsets (limit 1 GiB): split the batch",
+                            n_slots, seg.n_docs, (unsigned long long)bytes);
+            NIDX_HIP(idx->s_match_bits.reserve(bytes));
+            NIDX_HIP(hipMemsetAsync(idx->s_match_bits.p, 0, bytes, idx->stream));
+        }
         Bm25Args a;
         a.work = idx->s_work.as<Bm25Work>();
         a.n_docs = seg.n_docs;
@@ -246,6 +431,13 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         a.out_count = idx->s_count.as<uint32_t>();
         a.out_total = idx->s_total.as<unsigned long long>();
         a.out_postings = idx->s_postings.as<unsigned long long>();
+        a.aux_offsets = n_sets ? idx->s_aux_off.as<unsigned long long>() : nullptr;
+        a.aux_doc_ids = n_sets ? idx->s_aux_ids.as<uint32_t>() : nullptr;
+        a.order_key = order_field >= 0 ? seg.order_key[order_field].as<uint32_t>() : nullptr;
+        a.order_desc = opt->order_desc ? 1 : 0;
+        a.match_bits = n_slots ? idx->s_match_bits.as<uint32_t>() : nullptr;
+        a.match_slot = n_slots ? idx->s_match_slot.as<int>() : nullptr;
+        a.match_words = match_words;
         a.dbg = nullptr;
         DevBuf dbgbuf;
         if (getenv("NIDX_GPU_BM25_DEBUG")) {
@@ -256,6 +448,10 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
         NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
+        if (n_slots)
+            NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_pair_term.as<uint32_t>(),
+                                        idx->s_pair_slot.as<int>(), (uint32_t)n_pairs, idx->s_match_bits.as<uint32_t>(), match_words,
+                                        idx->s_facet_counts.as<unsigned long long>(), idx->stream));
         h_doc.resize(nw * kk);
         h_score.resize(nw * kk);
         h_count.resize(nw);
@@ -281,26 +477,55 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
             if (out_total) out_total[q] += h_total[w];
             if (out_postings) out_postings[q] += h_post[w];
             if (k == 0) continue;
-            for (uint32_t i = 0; i < h_count[w]; i++)
-                merged[q].push_back(Hit{h_score[w * kk + i], ((uint64_t)s << 32) | h_doc[w * kk + i]});
+            for (uint32_t i = 0; i < h_count[w]; i++) {
+                const uint32_t d = h_doc[w * kk + i];
+                if (order_field >= 0) merged[q].push_back(Hit{0.f, ((uint64_t)s << 32) | d, seg.fast_host[order_field][d]});
+                else merged[q].push_back(Hit{h_score[w * kk + i], ((uint64_t)s << 32) | d, 0});
+            }
         }
     }
+    if (n_slots) {
+        std::vector<unsigned long long> fc(n_pairs);
+        NIDX_HIP(hipMemcpy(fc.data(), idx->s_facet_counts.p, n_pairs * 8, hipMemcpyDeviceToHost));
+        for (uint64_t p = 0; p < n_pairs; p++) opt->out_facet_counts[p] = fc[p];
+    }
+    const bool desc = opt->order_desc != 0;
     for (uint32_t q = 0; q < nq && k > 0; q++) {
         std::vector<Hit> &m = merged[q];
-        // TopDocs order across segments: score desc (total order), DocAddress asc
-        std::sort(m.begin(), m.end(), [](const Hit &x, const Hit &y) {
-            int32_t kx = total_key(x.score), ky = total_key(y.score);
-            if (kx != ky) return kx > ky;
-            return x.docaddr < y.docaddr;
-        });
+        if (order_field >= 0) {
+            // order_by_fast_field across segments: the fast value, then DocAddress asc
+            std::sort(m.begin(), m.end(), [desc](const Hit &x, const Hit &y) {
+                if (x.value != y.value) return desc ? x.value > y.value : x.value < y.value;
+                return x.docaddr < y.docaddr;
+            });
+        } else {
+            // TopDocs order across segments: score desc (total order), DocAddress asc
+            std::sort(m.begin(), m.end(), [](const Hit &x, const Hit &y) {
+                int32_t kx = total_key(x.score), ky = total_key(y.score);
+                if (kx != ky) return kx > ky;
+                return x.docaddr < y.docaddr;
+            });
+        }
         uint32_t n = (uint32_t)std::min<size_t>(m.size(), k);
         out_count[q] = n;
         for (uint32_t i = 0; i < n; i++) {
             if (out_docaddr) out_docaddr[(size_t)q * k + i] = m[i].docaddr;
             if (out_score) out_score[(size_t)q * k + i] = m[i].score;
+            if (opt->out_order_value) opt->out_order_value[(size_t)q * k + i] = m[i].value;
         }
     }
     return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                             uint32_t nq, uint32_t k, const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr, float *out_score,
+                             uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+    nidx_gpu_bm25_search_options_t opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.k = k;
+    opt.after = after;
+    opt.order_field = -1;
+    return nidx_gpu_bm25_search_ex(index, clauses, clause_offsets, nq, &opt, out_docaddr, out_score, out_count, out_total, out_postings);
 }
 
 }  // extern "C"

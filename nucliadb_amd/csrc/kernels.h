@@ -256,7 +256,31 @@ struct Bm25Args {
     unsigned long long *out_total;
     unsigned long long *out_postings;
     unsigned long long *dbg;  // nullptr, or 6 counters: cycles load/apply/fold/total, windows, work items
+    // term sets (FuzzyTermQuery): clause.term = BM25_AUX_TERM | j reads the materialised union list j
+    const unsigned long long *aux_offsets;  // [n_sets][2]: begin, end into aux_doc_ids
+    const uint32_t *aux_doc_ids;            // ascending doc ids of each union
+    // TopDocs::order_by_fast_field: per-doc dense rank of the fast value (nullptr = order by score)
+    const uint32_t *order_key;
+    int order_desc;
+    // matching-document bitsets for the FacetCollector: query q writes slot match_slot[q] (-1 = none)
+    uint32_t *match_bits;                   // [n_slots][match_words]
+    const int *match_slot;                  // [n_queries] or nullptr
+    uint32_t match_words;
 };
+#define BM25_AUX_TERM 0x80000000u
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s);
+
+// ---- BM25 surroundings (bm25_aux.hip) ----
+// FuzzyTermQuery's automaton over the whole term dictionary: flags[t] = 1 when term t is accepted
+// (distance <= 1 in unicode scalar values, transposition = 1 edit; prefix: some prefix of the term)
+hipError_t launch_fuzzy_match(const uint8_t *dict_bytes, const unsigned long long *dict_offsets, uint32_t n_terms,
+                              const uint32_t *query_cp, uint32_t n_query_cp, int prefix, uint8_t *flags, hipStream_t s);
+// set bits -> ascending ids (one block per bitset): out[out_offsets[b] ..), counts[b] = number written
+hipError_t launch_bitset_compact(const uint64_t *bits, uint32_t n_words, uint32_t n_sets, const unsigned long long *out_offsets,
+                                 uint32_t *out, uint32_t *counts, hipStream_t s);
+// FacetCollector: counts[p] += |postings(term[p]) ∩ match bitset slot[p]|
+hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *pair_term,
+                              const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,
+                              unsigned long long *counts, hipStream_t s);
 
 }  // namespace nidx

@@ -1251,45 +1251,64 @@ static int is_after(const orc_search_after *after, float score, uint64_t docaddr
     return 0;
 }
 
-int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
-                    size_t k, const orc_search_after *after, uint32_t segment_ord,
-                    uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+typedef struct { float score; uint64_t docaddr; int64_t value; } bm_ohit_t;
+/* order_by_fast_field: the fast value decides (desc or asc), then the lower DocAddress */
+static inline int bm_obetter(bm_ohit_t a, bm_ohit_t b, int desc) {
+    if (a.value != b.value) return desc ? a.value > b.value : a.value < b.value;
+    return a.docaddr < b.docaddr;
+}
+
+int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                       size_t k, const orc_search_after *after, uint32_t segment_ord,
+                       const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
+                       uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out) {
     uint32_t n = idx->n_docs;
     float *acc = (float *)calloc(n ? n : 1, sizeof(float));
     uint8_t *should_hit = (uint8_t *)calloc(n ? n : 1, 1);
     uint16_t *must_cnt = (uint16_t *)calloc(n ? n : 1, sizeof(uint16_t));
     uint8_t *excluded = (uint8_t *)calloc(n ? n : 1, 1);
     uint8_t *group_hit = (uint8_t *)calloc(n ? n : 1, 1);
+    uint32_t *last_clause = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t)); /* term sets: a doc counts once per clause */
     size_t n_group = 0;
     float cache[256];
     float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
     orc_bm25_tf_cache(avg, cache);
     size_t n_must = 0, n_should = 0;
+    if (match_bits_out) memset(match_bits_out, 0, (size_t)((n + 63) / 64) * 8);
     /* term-at-a-time in clause order: per-doc f32 sums accumulate in clause order */
     for (size_t c = 0; c < n_clauses; c++) {
         const orc_bm25_clause *cl = &clauses[c];
-        uint64_t b = idx->term_offsets[cl->term], e = idx->term_offsets[cl->term + 1];
-        float weight = 0.0f;
-        if (cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(e - b, idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+        const int is_set = cl->n_set_terms > 0;
+        const size_t n_lists = is_set ? cl->n_set_terms : 1;
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
         if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
-        for (uint64_t i = b; i < e; i++) {
-            uint32_t d = idx->doc_ids[i];
-            if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
-            float s;
-            if (cl->mode == ORC_CONST_SCORE) s = cl->boost;
-            else {
-                float tf = cl->mode == ORC_TF_BASIC ? 1.0f : (float)idx->tfs[i];
-                s = weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
+        for (size_t t = 0; t < n_lists; t++) {
+            uint32_t term = is_set ? cl->set_terms[t] : cl->term;
+            uint64_t b = idx->term_offsets[term], e = idx->term_offsets[term + 1];
+            float weight = 0.0f;
+            if (!is_set && cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(e - b, idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+            for (uint64_t i = b; i < e; i++) {
+                uint32_t d = idx->doc_ids[i];
+                if (is_set) {
+                    if (last_clause[d] == (uint32_t)c + 1) continue; /* BitSet insert: already in this clause's doc set */
+                    last_clause[d] = (uint32_t)c + 1;
+                }
+                if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
+                float s;
+                if (is_set || cl->mode == ORC_CONST_SCORE) s = cl->boost;
+                else {
+                    float tf = cl->mode == ORC_TF_BASIC ? 1.0f : (float)idx->tfs[i];
+                    s = weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
+                }
+                acc[d] = acc[d] + s;
+                if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
+                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else should_hit[d] = 1;
             }
-            acc[d] = acc[d] + s;
-            if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
-            else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
-            else should_hit[d] = 1;
         }
     }
-    bm_hit_t *top = (bm_hit_t *)malloc((k + 1) * sizeof(bm_hit_t));
+    bm_ohit_t *top = (bm_ohit_t *)malloc((k + 1) * sizeof(bm_ohit_t));
     size_t n_top = 0;
     uint64_t total = 0;
     for (uint32_t d = 0; d < n; d++) {
@@ -1299,21 +1318,91 @@ int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, s
         if (n_must == 0 && n_group == 0 && !should_hit[d]) continue;
         if (idx->alive && !bit_get(idx->alive, d)) continue;
         total++;
+        if (match_bits_out) match_bits_out[d >> 6] |= (uint64_t)1 << (d & 63);
         uint64_t docaddr = ((uint64_t)segment_ord << 32) | d;
         float s = acc[d];
-        if (!is_after(after, s, docaddr)) s = -INFINITY; /* tweak_score (reader.rs:350-376) */
-        bm_hit_t h = {s, docaddr};
+        if (!order_values && !is_after(after, s, docaddr)) s = -INFINITY; /* tweak_score (reader.rs:350-376) */
+        bm_ohit_t h = {s, docaddr, order_values ? order_values[d] : 0};
         if (k == 0) continue;
-        if (n_top == k && !bm_better(h, top[n_top - 1])) continue;
+        int better_than_last = 1;
+        if (n_top == k) {
+            if (order_values) better_than_last = bm_obetter(h, top[n_top - 1], order_desc);
+            else { bm_hit_t a = {h.score, h.docaddr}, b = {top[n_top - 1].score, top[n_top - 1].docaddr}; better_than_last = bm_better(a, b); }
+        }
+        if (!better_than_last) continue;
         size_t j = n_top < k ? n_top++ : k - 1;
-        while (j > 0 && bm_better(h, top[j - 1])) { top[j] = top[j - 1]; j--; }
+        while (j > 0) {
+            int bt;
+            if (order_values) bt = bm_obetter(h, top[j - 1], order_desc);
+            else { bm_hit_t a = {h.score, h.docaddr}, b = {top[j - 1].score, top[j - 1].docaddr}; bt = bm_better(a, b); }
+            if (!bt) break;
+            top[j] = top[j - 1];
+            j--;
+        }
         top[j] = h;
     }
     (void)n_should;
-    for (size_t i = 0; i < n_top; i++) { out_docaddr[i] = top[i].docaddr; out_score[i] = top[i].score; }
+    for (size_t i = 0; i < n_top; i++) {
+        out_docaddr[i] = top[i].docaddr;
+        out_score[i] = top[i].score;
+        if (out_order_value) out_order_value[i] = top[i].value;
+    }
     if (total_out) *total_out = total;
-    free(top); free(acc); free(should_hit); free(must_cnt); free(excluded); free(group_hit);
+    free(top); free(acc); free(should_hit); free(must_cnt); free(excluded); free(group_hit); free(last_clause);
     return (int)n_top;
+}
+
+int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                    size_t k, const orc_search_after *after, uint32_t segment_ord,
+                    uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+    return orc_bm25_search_ex(idx, clauses, n_clauses, k, after, segment_ord, NULL, 0, NULL, out_docaddr, out_score, NULL, total_out);
+}
+
+/* ---- FuzzyTermQuery's automaton, restated as a dynamic program over unicode scalar values ---- */
+static size_t utf8_decode(const uint8_t *s, size_t len, uint32_t *out, size_t cap) {
+    size_t n = 0, i = 0;
+    while (i < len && n < cap) {
+        uint32_t c = s[i];
+        size_t extra = c < 0x80 ? 0 : (c >> 5) == 6 ? 1 : (c >> 4) == 14 ? 2 : (c >> 3) == 30 ? 3 : 0;
+        if (extra == 1) c &= 0x1f; else if (extra == 2) c &= 0x0f; else if (extra == 3) c &= 0x07;
+        i++;
+        for (size_t e = 0; e < extra && i < len; e++, i++) c = (c << 6) | (s[i] & 0x3f);
+        out[n++] = c;
+    }
+    return n;
+}
+
+int orc_fuzzy_match(const uint8_t *query, size_t qlen, const uint8_t *term, size_t tlen, int distance, int prefix) {
+    uint32_t q[256], t[256];
+    size_t nq = utf8_decode(query, qlen, q, 256), nt = utf8_decode(term, tlen, t, 256);
+    /* d[i][j] = restricted Damerau-Levenshtein distance between q[0..i) and t[0..j) */
+    static __thread int d[257][257];
+    for (size_t i = 0; i <= nq; i++) d[i][0] = (int)i;
+    for (size_t j = 0; j <= nt; j++) d[0][j] = (int)j;
+    for (size_t i = 1; i <= nq; i++)
+        for (size_t j = 1; j <= nt; j++) {
+            int cost = q[i - 1] == t[j - 1] ? 0 : 1;
+            int v = d[i - 1][j] + 1;
+            if (d[i][j - 1] + 1 < v) v = d[i][j - 1] + 1;
+            if (d[i - 1][j - 1] + cost < v) v = d[i - 1][j - 1] + cost;
+            if (i > 1 && j > 1 && q[i - 1] == t[j - 2] && q[i - 2] == t[j - 1] && d[i - 2][j - 2] + 1 < v) v = d[i - 2][j - 2] + 1;
+            d[i][j] = v;
+        }
+    if (!prefix) return d[nq][nt] <= distance;
+    for (size_t j = 0; j <= nt; j++)
+        if (d[nq][j] <= distance) return 1;
+    return 0;
+}
+
+size_t orc_fuzzy_terms(const uint8_t *bytes, const uint64_t *offsets, size_t n_terms, const uint8_t *query, size_t qlen,
+                       int distance, int prefix, uint32_t *out, size_t cap) {
+    size_t n = 0;
+    for (size_t i = 0; i < n_terms; i++)
+        if (orc_fuzzy_match(query, qlen, bytes + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), distance, prefix)) {
+            if (n < cap) out[n] = (uint32_t)i;
+            n++;
+        }
+    return n;
 }
 
 /* Document-at-a-time form of orc_bm25_search (what tantivy's union/intersection scorers do): the clause

@@ -187,6 +187,11 @@ typedef struct {
     int occur;         /* ORC_OCCUR_* */
     int mode;          /* ORC_TF_FREQ: BM25 with stored tf; ORC_TF_BASIC: tf == 1; ORC_CONST_SCORE: score = boost */
     float boost;
+    /* term set (FuzzyTermQuery / AutomatonWeight, nidx_paragraph/src/fuzzy_query.rs:55-125): when n_set_terms > 0
+     * the clause matches the UNION of these terms' posting lists, each document once, ConstScorer(boost);
+     * `term` and `mode` are ignored */
+    const uint32_t *set_terms;
+    uint32_t n_set_terms;
 } orc_bm25_clause;
 
 typedef struct {
@@ -200,6 +205,24 @@ typedef struct {
 int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
                     size_t k, const orc_search_after *after, uint32_t segment_ord,
                     uint64_t *out_docaddr, float *out_score, uint64_t *total_out);
+
+/* The collectors around the same scoring (nidx_text/src/reader.rs:367-451): TopDocs ordered by a fast field
+ * (order_values[doc], TopDocs::order_by_fast_field; NULL = by score), and the set of matching alive documents as a
+ * bitset (match_bits_out, NULL = not wanted) from which FacetCollector counts are taken.  out_order_value: NULL
+ * or [k]. */
+int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                       size_t k, const orc_search_after *after, uint32_t segment_ord,
+                       const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
+                       uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out);
+
+/* Levenshtein automaton of FuzzyTermQuery (levenshtein_automata 0.2.1, nidx/Cargo.lock:2313; restated):
+ * distance in unicode scalar values with a transposition of two adjacent characters costing one
+ * (`transposition_cost_one = true`, fuzzy_parser.rs:73); prefix = build_prefix_dfa: SOME prefix of `term` is
+ * within `distance` of `query`.  Returns 1 when `term` is accepted. */
+int orc_fuzzy_match(const uint8_t *query, size_t qlen, const uint8_t *term, size_t tlen, int distance, int prefix);
+/* every accepted term of a dictionary (term i = bytes[offsets[i] .. offsets[i+1])); returns the count */
+size_t orc_fuzzy_terms(const uint8_t *bytes, const uint64_t *offsets, size_t n_terms, const uint8_t *query, size_t qlen,
+                       int distance, int prefix, uint32_t *out, size_t cap);
 
 /* Same results, document-at-a-time (no dense accumulator): the CPU baseline of bench.py. */
 int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,

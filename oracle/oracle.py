@@ -76,7 +76,8 @@ class _Bm25Index(C.Structure):
 
 
 class _Bm25Clause(C.Structure):
-    _fields_ = [("term", C.c_uint32), ("occur", C.c_int), ("mode", C.c_int), ("boost", C.c_float)]
+    _fields_ = [("term", C.c_uint32), ("occur", C.c_int), ("mode", C.c_int), ("boost", C.c_float),
+                ("set_terms", C.c_void_p), ("n_set_terms", C.c_uint32)]
 
 
 class _SearchAfter(C.Structure):
@@ -188,6 +189,14 @@ def lib():
     L.orc_bm25_search.restype = C.c_int
     L.orc_bm25_search.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t,
                                   C.POINTER(_SearchAfter), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_bm25_search_ex.restype = C.c_int
+    L.orc_bm25_search_ex.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t, C.POINTER(_SearchAfter),
+                                     C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_uint64)]
+    L.orc_fuzzy_match.restype = C.c_int
+    L.orc_fuzzy_match.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_fuzzy_terms.restype = C.c_size_t
+    L.orc_fuzzy_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.orc_bm25_search_daat.restype = C.c_int
     L.orc_bm25_search_daat.argtypes = L.orc_bm25_search.argtypes
     L.orc_merge_vector.restype = C.c_size_t
@@ -556,12 +565,40 @@ class Bm25Index:
         s.alive = None if self.alive is None else self.alive.ctypes.data
         return s
 
+    def _clauses(self, clauses):
+        cl = (_Bm25Clause * max(len(clauses), 1))()
+        keep = []
+        for i, c in enumerate(clauses):
+            t, o, m, b = c[:4]
+            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = t, o, m, b
+            if len(c) > 4 and c[4] is not None:  # term set: the union of these terms, ConstScorer(boost)
+                ts = np.ascontiguousarray(c[4], dtype=np.uint32)
+                keep.append(ts)
+                cl[i].set_terms, cl[i].n_set_terms = ts.ctypes.data, ts.size
+                if ts.size == 0:  # an empty expansion matches nothing: an always-empty list stands for it
+                    raise ValueError("empty term set: map it to an empty term")
+        return cl, keep
+
+    def search_ex(self, clauses, k, after=None, segment_ord=0, order_values=None, order_desc=True, want_match_bits=False):
+        """The collectors around the scoring: clauses = (term, occur, mode, boost[, term_set]); order_values: int64 per doc
+        (TopDocs::order_by_fast_field) or None.  -> (docaddr, score, order values, total, match bitset or None)"""
+        cl, keep = self._clauses(clauses)
+        sa = _SearchAfter()
+        if after is not None:
+            sa.has_after, sa.score, sa.tie_break, sa.docaddr = 1, after[0], after[1], after[2]
+        od, os_, ov = np.empty(max(k, 1), np.uint64), np.empty(max(k, 1), np.float32), np.zeros(max(k, 1), np.int64)
+        total = C.c_uint64()
+        ci = self.c()
+        vals = None if order_values is None else np.ascontiguousarray(order_values, dtype=np.int64)
+        mb = np.zeros((ci.n_docs + 63) // 64, np.uint64) if want_match_bits else None
+        n = lib().orc_bm25_search_ex(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(vals), int(order_desc), _ptr(mb),
+                                     _ptr(od), _ptr(os_), _ptr(ov), C.byref(total))
+        return od[:n].copy(), os_[:n].copy(), ov[:n].copy(), total.value, mb
+
     def search(self, clauses, k, after=None, segment_ord=0, daat=False):
         """clauses: list of (term, occur, mode, boost). -> (docaddr u64[], score f32[], total).
         daat=True runs the document-at-a-time form (same results, no dense accumulator)."""
-        cl = (_Bm25Clause * max(len(clauses), 1))()
-        for i, (t, o, m, b) in enumerate(clauses):
-            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = t, o, m, b
+        cl, _keep = self._clauses(clauses)
         sa = _SearchAfter()
         if after is not None:
             sa.has_after, sa.score, sa.tie_break, sa.docaddr = 1, after[0], after[1], after[2]
@@ -571,6 +608,23 @@ class Bm25Index:
         fn = lib().orc_bm25_search_daat if daat else lib().orc_bm25_search
         n = fn(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(od), _ptr(os_), C.byref(total))
         return od[:n].copy(), os_[:n].copy(), total.value
+
+
+def fuzzy_match(query: str, term: str, distance: int = 1, prefix: bool = False) -> bool:
+    q, t = query.encode(), term.encode()
+    return bool(lib().orc_fuzzy_match(q, len(q), t, len(t), distance, int(prefix)))
+
+
+def fuzzy_terms(terms, query: str, distance: int = 1, prefix: bool = False) -> np.ndarray:
+    """Term ids (positions in `terms`) the FuzzyTermQuery automaton accepts."""
+    enc = [t.encode() for t in terms]
+    offs = np.zeros(len(enc) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    blob = np.frombuffer(b"".join(enc) or b"\0", np.uint8)
+    out = np.zeros(max(len(enc), 1), np.uint32)
+    q = query.encode()
+    n = lib().orc_fuzzy_terms(blob.ctypes.data, offs.ctypes.data, len(enc), q, len(q), distance, int(prefix), out.ctypes.data, out.size)
+    return out[:n].copy()
 
 
 # ---------------------------------------------------------------- shard merge

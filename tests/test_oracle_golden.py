@@ -428,3 +428,36 @@ def test_bm25_daat_equals_term_at_a_time(orc):
         a = idx.search(q, 15, after=after, segment_ord=2)
         b = idx.search(q, 15, after=after, segment_ord=2, daat=True)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and a[2] == b[2]
+
+
+# ---- FuzzyTermQuery's automaton (levenshtein_automata 0.2.1, restated) ----------------------------------------------
+def _osa(a, b):
+    d = [[0] * (len(b) + 1) for _ in range(len(a) + 1)]
+    for i in range(len(a) + 1):
+        d[i][0] = i
+    for j in range(len(b) + 1):
+        d[0][j] = j
+    for i in range(1, len(a) + 1):
+        for j in range(1, len(b) + 1):
+            d[i][j] = min(d[i - 1][j] + 1, d[i][j - 1] + 1, d[i - 1][j - 1] + (a[i - 1] != b[j - 1]))
+            if i > 1 and j > 1 and a[i - 1] == b[j - 2] and a[i - 2] == b[j - 1]:
+                d[i][j] = min(d[i][j], d[i - 2][j - 2] + 1)
+    return d
+
+
+def test_fuzzy_automaton_reference_cases(orc):
+    """nidx_paragraph/tests/reader.rs:262-300: a typo of distance 1 (a transposition counts one) still matches, distance 2
+    does not; fuzzy_parser.rs:35-42: distance 1, prefix DFA for the last literal."""
+    assert orc.fuzzy_match("shoupd", "should") and orc.fuzzy_match("enaugh", "enough")
+    assert not orc.fuzzy_match("sJoupd", "should") and not orc.fuzzy_match("enaugJ", "enough")
+    assert orc.fuzzy_match("enoguh", "enough") and not orc.fuzzy_match("eonguh", "enough")
+    assert orc.fuzzy_match("shoul", "shoulder", prefix=True) and not orc.fuzzy_match("shoul", "shoulder")
+    import random
+
+    rnd = random.Random(5)
+    for _ in range(3000):
+        a = "".join(rnd.choice("abcñ道") for _ in range(rnd.randint(1, 7)))
+        b = "".join(rnd.choice("abcñ道") for _ in range(rnd.randint(0, 9)))
+        d = _osa(a, b)
+        assert orc.fuzzy_match(a, b) == (d[len(a)][len(b)] <= 1), (a, b)
+        assert orc.fuzzy_match(a, b, prefix=True) == (min(d[len(a)]) <= 1), (a, b)
