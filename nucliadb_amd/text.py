@@ -12,17 +12,21 @@ What runs where:
   * every posting read, BM25 score, boolean combination, top-k and count: in the HIP kernel behind
     `nidx_gpu_bm25_search`.
 
-Supported query shapes are the term-clause ones (the overwhelmingly common path): text index =
-conjunction of the body's tokens (tantivy QueryParser with `set_conjunction_by_default`); paragraph
-index = Should(term, IndexRecordOption::Basic) per literal token, wrapped with the Must clauses
-`repeated_in_field:0` (unless with_duplicates) and label filters.  Quoted phrases, `-excluded`
-terms, the fuzzy fallback and facets are not term clauses and raise NotImplementedError (SURVEY §8f
-row 4, "next").
+Supported query shapes: text index = conjunction of the body's tokens (tantivy QueryParser with
+`set_conjunction_by_default`); paragraph index = the nidx query grammar (query_parser/tokenizer.rs:49-135):
+literals -> Should(term, IndexRecordOption::Basic), one-word quotes -> the same term query, wrapped with the
+Must clauses `repeated_in_field:0` (unless with_duplicates) and label filters; the FUZZY FALLBACK
+(reader.rs:128-133, fuzzy_parser.rs:35-93, search_query.rs:200-240): every literal of >= 3 characters becomes
+a FuzzyTermQuery (Levenshtein 1, the last literal as a prefix when >= 4 characters) expanded against the term
+dictionary on the device and scored ConstScorer(0.5).  Both searchers collect FACETS (FacetCollector, top 50
+children per requested facet) and can ORDER by the created / modified fast fields.  Multi-word quoted phrases
+(positions) and `-excluded` terms (a Should of "everything but") are not posting-list clauses and raise
+NotImplementedError.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
 
@@ -46,6 +50,8 @@ class TextDocument:
     text: str
     labels: List[str] = field(default_factory=list)
     repeated_in_field: bool = False  # paragraph index only
+    created: int = 0                 # fast fields (schema.rs:59-115), seconds
+    modified: int = 0
 
 
 class Vocabulary:
@@ -73,7 +79,8 @@ class TextSegment:
             self.streams.append(toks)
             vocab.id(ALL_DOCS), vocab.id(NOT_REPEATED)
             for lab in d.labels:
-                vocab.id("\x00label:" + lab)
+                for anc in facet_ancestors(lab):  # tantivy's FacetTokenizer indexes every ancestor path
+                    vocab.id("\x00label:" + anc)
 
     def to_bm25(self, n_terms: int, alive=None) -> Bm25Segment:
         """Postings of the text field, plus constant-frequency pseudo terms for AllQuery / labels /
@@ -86,7 +93,7 @@ class TextSegment:
             terms.extend(s)
             docs.extend([i] * len(s))
             extra = [self.vocab.ids[ALL_DOCS]] + ([] if d.repeated_in_field else [self.vocab.ids[NOT_REPEATED]])
-            extra += [self.vocab.ids["\x00label:" + lab] for lab in d.labels]
+            extra += sorted({self.vocab.ids["\x00label:" + anc] for lab in d.labels for anc in facet_ancestors(lab)})
             terms.extend(extra)
             docs.extend([i] * len(extra))
         terms = np.array(terms, dtype=np.int64)
@@ -99,6 +106,30 @@ class TextSegment:
         table = np.array([L.nidx_gpu_fieldnorm_from_id(i) for i in range(256)], dtype=np.int64)
         ids = (np.searchsorted(table, lens, side="right") - 1).astype(np.uint8)
         return Bm25Segment(term_offsets, dd.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive)
+
+
+def facet_ancestors(label: str) -> List[str]:
+    """/a/b/c -> [/a, /a/b, /a/b/c]"""
+    parts = [p for p in label.split("/") if p]
+    return ["/" + "/".join(parts[: i + 1]) for i in range(len(parts))]
+
+
+def is_valid_facet(facet: str) -> bool:
+    """Facet::from_text(..).is_ok(): an absolute path (the root "" / "/" is skipped by the callers' tests)"""
+    return facet.startswith("/") and len(facet) > 1
+
+
+@dataclass
+class OrderBy:
+    """nodereader.proto OrderBy: sort_by Created (0) / Modified (1), desc unless type says asc."""
+    field: int = 0
+    desc: bool = True
+
+
+@dataclass
+class FacetResult:
+    tag: str
+    total: int
 
 
 def _bitset(mask: np.ndarray) -> np.ndarray:
@@ -124,6 +155,47 @@ class _Index:
                 alive = _bitset(m)
             bsegs.append(seg.to_bm25(n_terms, alive))
         self.searcher = Bm25Searcher.open(bsegs)
+        # the term dictionary of the text field (pseudo terms excluded from fuzzy expansion by their \x00 prefix)
+        self.terms = [None] * n_terms
+        for t, i in self.vocab.ids.items():
+            self.terms[i] = t
+        self.terms[self.empty_term] = "\x00empty"
+        self.searcher.set_dictionary(self.terms)
+        for i, seg in enumerate(self.segments):
+            if seg.docs:
+                self.searcher.set_fast_field(i, 0, [d.created for d in seg.docs])
+                self.searcher.set_fast_field(i, 1, [d.modified for d in seg.docs])
+
+    def fuzzy_terms(self, word: str, prefix: bool) -> List[int]:
+        """FuzzyTermQuery's automaton over the text field's dictionary, evaluated on the device."""
+        return [int(t) for t in self.searcher.fuzzy_terms(word, prefix) if not self.terms[int(t)].startswith("\x00")]
+
+    def facet_children(self, facet: str) -> List[Tuple[str, int]]:
+        """(child path, term id) of every direct child of `facet` present in the index"""
+        pre = "\x00label:" + facet.rstrip("/") + "/"
+        out = []
+        for t, i in self.vocab.ids.items():
+            if t.startswith(pre) and "/" not in t[len(pre):]:
+                out.append((t[len("\x00label:"):], i))
+        return sorted(out)
+
+    def facet_request(self, faceted: Optional[Sequence[str]]):
+        """-> (requested valid facets, [(facet, child path, term id)])"""
+        facets = [f for f in (faceted or []) if is_valid_facet(f)]
+        pairs = [(f, child, tid) for f in facets for child, tid in self.facet_children(f)]
+        return facets, pairs
+
+    @staticmethod
+    def produce_facets(facets, pairs, counts) -> Dict[str, List[FacetResult]]:
+        """produce_facets / facet_count (nidx_text/src/reader.rs:43-62): the 50 most frequent children per facet,
+        facets without any hit dropped."""
+        out: Dict[str, List[FacetResult]] = {}
+        for f in facets:
+            rows = [(int(c), child) for (ff, child, _), c in zip(pairs, counts) if ff == f and int(c) > 0]
+            rows.sort(key=lambda r: (-r[0], r[1]))
+            if rows:
+                out[f] = [FacetResult(child, c) for c, child in rows[:50]]
+        return out
 
     def term(self, word: str) -> int:
         t = self.vocab.lookup(word)
@@ -143,14 +215,18 @@ class DocumentSearchRequest:
     result_per_page: int = 0
     min_score: float = 0.0
     label_filter: Optional[List[str]] = None  # a conjunction of labels (filter_expression subset)
+    faceted: Optional[List[str]] = None
+    order: Optional[OrderBy] = None
+    only_faceted: bool = False
 
 
 @dataclass
 class DocumentResult:
     uuid: str
     field: str
-    score: ResultScore
+    score: Optional[ResultScore]
     labels: List[str]
+    sort_value: Optional[int] = None  # SortValue::Date when ordered by a fast field
 
 
 @dataclass
@@ -159,6 +235,7 @@ class DocumentSearchResponse:
     results: List[DocumentResult]
     next_page: bool
     query: str
+    facets: Dict[str, List[FacetResult]] = field(default_factory=dict)
 
 
 class TextSearcher:
@@ -190,17 +267,31 @@ class TextSearcher:
 
     def search(self, request: DocumentSearchRequest) -> DocumentSearchResponse:
         k = max(0, int(request.result_per_page))
-        # TopDocs::with_limit(results + 1) (reader.rs:380,433)
-        docaddr, score, count, total, _ = self._index.searcher.search_batch([self._clauses(request)], k + 1)
+        facets, pairs = self._index.facet_request(request.faceted)
+        fterms = [[tid for _, _, tid in pairs]] if pairs else None
+        clauses = self._clauses(request)
+        if request.only_faceted:  # "Just a facet search" (reader.rs:403-410)
+            r = self._index.searcher.search_batch_ex([clauses], 0, facets=fterms)
+            return DocumentSearchResponse(0, [], False, "", self._index.produce_facets(facets, pairs, r["facet_counts"][0] if pairs else []))
+        order = request.order
+        # TopDocs::with_limit(results + 1) (reader.rs:380,433), by score or by a fast field
+        r = self._index.searcher.search_batch_ex([clauses], k + 1, order_field=-1 if order is None else order.field,
+                                                order_desc=True if order is None else order.desc, facets=fterms)
+        docaddr, score, count, total = r["docaddr"], r["score"], r["count"], r["total"]
         total_ = int(total[0])
         results = []
         for i in range(min(int(count[0]), k)):  # .take(results_per_page), drop `score < min_score` (reader.rs:299-305)
+            d = self._index.doc(int(docaddr[0, i]))
+            labels = [l for l in d.labels if l.startswith("/l/")]
+            if order is not None:  # convert_int_order: no min_score cut, the sort value instead of a score
+                results.append(DocumentResult(d.uuid, d.field, None, labels, sort_value=int(r["order_value"][0, i])))
+                continue
             s = float(score[0, i])
             if s < request.min_score:
                 continue
-            d = self._index.doc(int(docaddr[0, i]))
-            results.append(DocumentResult(d.uuid, d.field, ResultScore(s, int(docaddr[0, i])), [l for l in d.labels if l.startswith("/l/")]))
-        return DocumentSearchResponse(total_, results, total_ > k, request.body)
+            results.append(DocumentResult(d.uuid, d.field, ResultScore(s, int(docaddr[0, i])), labels))
+        fc = self._index.produce_facets(facets, pairs, r["facet_counts"][0]) if pairs else {}
+        return DocumentSearchResponse(total_, results, total_ > k, request.body, fc)
 
 
 # =============================================================================== nidx_paragraph
@@ -215,6 +306,9 @@ class ParagraphSearchRequest:
     min_score: float = 0.0
     label_filter: Optional[List[str]] = None
     search_after: Optional[SearchAfter] = None
+    faceted: Optional[List[str]] = None
+    order: Optional[OrderBy] = None
+    only_faceted: bool = False
 
 
 @dataclass
@@ -222,8 +316,9 @@ class ParagraphResult:
     uuid: str
     field: str
     paragraph: str
-    score: ResultScore
+    score: Optional[ResultScore]
     labels: List[str]
+    sort_value: Optional[int] = None
 
 
 @dataclass
@@ -232,52 +327,165 @@ class ParagraphSearchResponse:
     results: List[ParagraphResult]
     next_page: bool
     query: str
+    facets: Dict[str, List[FacetResult]] = field(default_factory=dict)
+    fuzzy: bool = False  # the hits come from the fuzzy fallback query
+
+
+def parse_query(body: str, stop_words: Optional[Set[str]] = None) -> List[Tuple[str, str]]:
+    """tokenize_query_infallible + remove_stop_words (query_parser/tokenizer.rs:49-188, query_parser.rs:60-62):
+    [(kind, text)] with kind in literal / quoted / excluded.  Grammar: "quoted text", -excluded, literals are runs of
+    non-space, non-control, non-quote characters; an unclosed quote is dropped.  Every token then goes through the
+    index's tokenizer (punctuation splits, lower case); a quoted run keeps its words joined by one space."""
+    raw: List[Tuple[str, str]] = []
+    i, n = 0, len(body)
+
+    def literal_char(c: str) -> bool:
+        return c.isalnum() or (not c.isspace() and c != '"' and c.isprintable())
+
+    while i < n:
+        c = body[i]
+        if c.isspace():
+            i += 1
+        elif c == '"':
+            j = body.find('"', i + 1)
+            if j > i + 1:  # "xxx"
+                if body[i + 1:j].strip():
+                    raw.append(("quoted", body[i + 1:j]))
+                i = j + 1
+            else:  # unclosed quote(s), or an empty pair: dropped
+                while i < n and body[i] == '"':
+                    i += 1
+        elif c == "-" and i + 1 < n and literal_char(body[i + 1]):
+            j = i + 1
+            while j < n and literal_char(body[j]):
+                j += 1
+            raw.append(("excluded", body[i + 1:j]))
+            i = j
+        elif literal_char(c):
+            j = i
+            while j < n and literal_char(body[j]):
+                j += 1
+            raw.append(("literal", body[i:j]))
+            i = j
+        else:
+            i += 1
+    tokens: List[Tuple[str, str]] = []
+    for kind, text in raw:
+        words = tokenize(text)
+        if kind == "quoted":
+            if words:
+                tokens.append((kind, " ".join(words)))
+        else:
+            tokens.extend((kind, w) for w in words)
+    if stop_words:
+        # remove_stop_words (stop_words.rs): literals that are stop words go, except the last token of the query
+        kept = [t for i, t in enumerate(tokens) if t[0] != "literal" or t[1] not in stop_words or i == len(tokens) - 1]
+        tokens = kept
+    return tokens
+
+
+MIN_FUZZY_LEN = 3          # fuzzy_parser.rs:35
+MIN_FUZZY_PREFIX_LEN = 4   # fuzzy_parser.rs:39
+FUZZY_BOOST = 0.5          # search_query.rs:235-239
 
 
 class ParagraphSearcher:
-    """nidx_paragraph::ParagraphSearcher (lib.rs:117-169) — keyword `search` only."""
+    """nidx_paragraph::ParagraphSearcher (lib.rs:117-169) — `search`: keyword query, fuzzy fallback, facets, order."""
 
-    def __init__(self, index: _Index):
+    def __init__(self, index: _Index, stop_words: Optional[Set[str]] = None):
         self._index = index
+        # the reference removes the stop words of eight languages (query_parser/stop_words/*.json, data files that
+        # are not copied here): pass the union of those lists to get the same query
+        self.stop_words = stop_words
 
     @classmethod
-    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = ()) -> "ParagraphSearcher":
-        return cls(_Index(segments, deleted))
+    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = (), stop_words: Optional[Set[str]] = None) -> "ParagraphSearcher":
+        return cls(_Index(segments, deleted), stop_words)
 
     def close(self):
         self._index.close()
 
-    def _clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
-        if '"' in request.body or any(w.startswith("-") for w in request.body.split()):
-            raise NotImplementedError("quoted phrases and -excluded terms are not term clauses")
-        words = tokenize(request.body)
-        clauses = []
-        if not words:  # parse_keyword_query: no subqueries => AllQuery
-            clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
-        # TermQuery(text, IndexRecordOption::Basic) per literal, Occur::Should (keyword_parser.rs:36-67)
-        # as a required group: the keyword BooleanQuery sits under Occur::Must next to the filters
-        # (search_query.rs:191-228), so a paragraph has to match at least one of its words
-        should = [Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0) for w in words]
+    def _filters(self, request: ParagraphSearchRequest, boost: float) -> List[Clause]:
         musts = []
         for lab in request.label_filter or []:
-            musts.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0))
+            musts.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, boost))
         if not request.with_duplicates:  # Must TermQuery(repeated_in_field = 0, Basic) (search_query.rs:218-223)
-            musts.append(Clause(self._index.term(NOT_REPEATED), _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0))
-        return clauses + should + musts
+            musts.append(Clause(self._index.term(NOT_REPEATED), _lib.OCCUR_MUST, _lib.TF_BASIC, boost))
+        return musts
 
-    def search(self, request: ParagraphSearchRequest) -> ParagraphSearchResponse:
+    def _tokens(self, request: ParagraphSearchRequest) -> List[Tuple[str, str]]:
+        tokens = parse_query(request.body, self.stop_words)
+        for kind, text in tokens:
+            if kind == "excluded":
+                raise NotImplementedError("-excluded terms are a Should of (everything but the term): not a posting-list clause")
+            if kind == "quoted" and " " in text:
+                raise NotImplementedError("multi-word quoted phrases need positions (PhraseQuery)")
+        return tokens
+
+    def _clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
+        """The keyword query (keyword_parser.rs:27-105 under search_query.rs:185-243)."""
+        tokens = self._tokens(request)
+        clauses = []
+        if not tokens:  # parse_keyword_query: no subqueries => AllQuery
+            clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
+        # TermQuery(text, IndexRecordOption::Basic) per literal / one-word quote, Occur::Should, as a required group: the
+        # keyword BooleanQuery sits under Occur::Must next to the filters, so a paragraph has to match one of its words
+        should = [Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0) for _, w in tokens]
+        return clauses + should + self._filters(request, 1.0)
+
+    def _fuzzy_clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
+        """The fuzzy query (fuzzy_parser.rs:52-123 under search_query.rs:200-240)."""
+        tokens = self._tokens(request)
+        filters_present = bool(request.label_filter) or not request.with_duplicates
+        boost = FUZZY_BOOST if filters_present else 1.0  # BoostQuery(0.5) only wraps a multi-clause Boolean (:229-240)
+        last_literal = max((i for i, t in enumerate(tokens) if t[0] == "literal"), default=None)
+        clauses = []
+        if not tokens:
+            clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
+        for i, (kind, w) in enumerate(tokens):
+            if kind == "quoted" or len(w.encode("utf-8")) < MIN_FUZZY_LEN:  # too short to be fuzzy: the exact term
+                clauses.append(Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, boost))
+                continue
+            prefix = i == last_literal and len(w.encode("utf-8")) >= MIN_FUZZY_PREFIX_LEN
+            members = self._index.fuzzy_terms(w, prefix) or [self._index.empty_term]
+            clauses.append(Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.CONST_SCORE, boost, term_set=members))
+        return clauses + self._filters(request, boost)
+
+    def _run(self, request: ParagraphSearchRequest, clauses: List[Clause], fuzzy: bool) -> ParagraphSearchResponse:
+        """Searcher::do_search (reader.rs:244-348) + the response assembly (search_response.rs:218-311)."""
         k = max(0, int(request.result_per_page))
-        clauses = self._clauses(request)
-        after = [request.search_after] if request.search_after is not None else None
-        docaddr, score, count, total, _ = self._index.searcher.search_batch([clauses], k + 1, after)
-        obtained = int(count[0])
+        facets, pairs = self._index.facet_request(request.faceted)
+        fterms = [[tid for _, _, tid in pairs]] if pairs else None
+        if request.only_faceted:
+            r = self._index.searcher.search_batch_ex([clauses], 0, facets=fterms)
+            return ParagraphSearchResponse(0, [], False, "", self._index.produce_facets(facets, pairs, r["facet_counts"][0] if pairs else []), fuzzy)
+        order = request.order
+        after = [request.search_after] if request.search_after is not None and order is None else None
+        r = self._index.searcher.search_batch_ex([clauses], k + 1, after, order_field=-1 if order is None else order.field,
+                                                order_desc=True if order is None else order.desc, facets=fterms)
+        docaddr, score, total = r["docaddr"], r["score"], r["total"]
+        obtained = int(r["count"][0])
+        fc = self._index.produce_facets(facets, pairs, r["facet_counts"][0]) if pairs else {}
+        results = []
+        if order is not None:  # SearchIntResponse: no min_score, next_page = total > requested
+            for i in range(min(obtained, k)):
+                d = self._index.doc(int(docaddr[0, i]))
+                results.append(ParagraphResult(d.uuid, d.field, d.text, None, list(d.labels), sort_value=int(r["order_value"][0, i])))
+            return ParagraphSearchResponse(int(total[0]), results, int(total[0]) > k, request.body, fc, fuzzy)
         scores = [float(score[0, i]) for i in range(obtained)]
         # search_response.rs:218-311: next_page counts scores above min_score, results stop at the first below it
         next_page = sum(1 for s in scores if s > request.min_score) > k
-        results = []
         for i in range(min(obtained, k)):
             if scores[i] < request.min_score:
                 break
             d = self._index.doc(int(docaddr[0, i]))
             results.append(ParagraphResult(d.uuid, d.field, d.text, ResultScore(scores[i], int(docaddr[0, i])), list(d.labels)))
-        return ParagraphSearchResponse(int(total[0]), results, next_page, request.body)
+        return ParagraphSearchResponse(int(total[0]), results, next_page, request.body, fc, fuzzy)
+
+    def search(self, request: ParagraphSearchRequest) -> ParagraphSearchResponse:
+        """ParagraphReaderService::search (reader.rs:104-139): the keyword query first; when it finds nothing (and results
+        were asked for, with min_score == 0) the fuzzy query is run instead."""
+        response = self._run(request, self._clauses(request), False)
+        if not response.results and request.result_per_page > 0 and request.min_score == 0.0 and not request.only_faceted:
+            response = self._run(request, self._fuzzy_clauses(request), True)
+        return response

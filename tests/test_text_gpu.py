@@ -143,3 +143,82 @@ def test_should_group_matches_oracle(orc):
         assert np.array_equal(docaddr[i, : count[i]], wd)
         assert np.array_equal(score[i, : count[i]].view(np.uint32), ws.view(np.uint32))
     s.close()
+
+
+def test_keyword_and_fuzzy_queries():
+    """nidx_paragraph/tests/reader.rs:248-300 (test_keyword_and_fuzzy_queries), the same ladder of typos on this corpus:
+    exact words, one typo each (fuzzy fallback), two typos (nothing), one-word quotes (never fuzzy), leniency."""
+    from nucliadb_amd.text import OrderBy
+
+    vocab = Vocabulary()
+    s = ParagraphSearcher.open([TextSegment(docs(), vocab)])
+
+    def n(query, **kw):
+        r = s.search(ParagraphSearchRequest(body=query, result_per_page=20, with_duplicates=True, **kw))
+        return len(r.results), r.fuzzy
+
+    assert n("") == (6, False)                       # empty query matches everything
+    assert n("should enough") == (4, False)          # Should semantics: either word (r1, r2, r3, r5)
+    assert n("shoulx") == (1, True)                  # distance 1 -> "should" (r1) through the fallback
+    assert n("shoupd")[1] is False                   # "shoupd" is itself indexed (r2): the keyword query answers
+    assert n("sJoulx") == (0, True)                  # distance 2: nothing, even fuzzily
+    assert n("enoguh") == (4, True)                  # a transposition costs one edit
+    assert n("eonguh") == (0, True)
+    assert n('"should"') == (1, False)               # one-word quote = exact term
+    assert n('"shoudl"') == (0, True)                # quotes never go fuzzy
+    assert n('"shoudl" enough') == (4, False)        # the literal still matches
+    assert n('"shoudl" enoguh') == (4, True)
+    assert n('"shoudl" eonguh') == (0, True)
+    assert n('shoulx + enaugh"') == (4, True)        # lenient grammar: stray symbols and quotes are dropped
+    # prefix DFA for the last literal of >= 4 characters (fuzzy_parser.rs:38-42,74-83): "enou" reaches "enough"
+    assert n("enou") == (4, True)
+    assert n("eno") == (0, True)                     # 3 characters: fuzzy but not a prefix
+    assert n("xy") == (0, True)                      # shorter than MIN_FUZZY_LEN: exact term only
+    # the fallback runs only when results were asked for and min_score == 0 (reader.rs:128)
+    r = s.search(ParagraphSearchRequest(body="shoulx", result_per_page=20, with_duplicates=True, min_score=0.1))
+    assert not r.results and not r.fuzzy
+    # scores of the fallback: ConstScorer per fuzzy literal, no BoostQuery without filters, 0.5 with them (:229-240)
+    r = s.search(ParagraphSearchRequest(body="shoulx", result_per_page=20, with_duplicates=True))
+    assert [x.score.bm25 for x in r.results] == [1.0]
+    r = s.search(ParagraphSearchRequest(body="shoulx", result_per_page=20))  # + Must(repeated = 0) => boosted by 0.5
+    assert len(r.results) == 1 and 0.5 < r.results[0].score.bm25 < 1.0
+    s.close()
+
+
+def test_faceted_search_and_order_by():
+    """nidx_paragraph/tests/reader.rs:345-401 (test_faceted_search, test_order_by) and nidx_text's facet path
+    (reader.rs:43-62): the root and unknown facets are dropped, children are counted among the matching documents."""
+    from nucliadb_amd.text import OrderBy
+
+    vocab = Vocabulary()
+    d = docs()
+    for i, x in enumerate(d):
+        x.labels = ["/l/set/a" if i < 4 else "/l/set/b", "/e/PERSON/p%d" % (i % 2), "/c/ool"] if i != 3 else ["/l/other/z"]
+        x.created = 1000 + (i % 3)
+        x.modified = 2000 - i
+    for searcher_cls, req_cls in ((ParagraphSearcher, ParagraphSearchRequest), (TextSearcher, DocumentSearchRequest)):
+        s = searcher_cls.open([TextSegment(d, vocab)])
+        kw = {"with_duplicates": True} if req_cls is ParagraphSearchRequest else {}
+        r = s.search(req_cls(body="", result_per_page=20, faceted=["", "/l", "/e", "/c", "/x", "/l/set"], **kw))
+        assert set(r.facets) == {"/l", "/e", "/c", "/l/set"}
+        assert [(f.tag, f.total) for f in r.facets["/l"]] == [("/l/set", 5), ("/l/other", 1)]
+        assert [(f.tag, f.total) for f in r.facets["/l/set"]] == [("/l/set/a", 3), ("/l/set/b", 2)]
+        assert [(f.tag, f.total) for f in r.facets["/e"]] == [("/e/PERSON", 5)]
+        assert [(f.tag, f.total) for f in r.facets["/c"]] == [("/c/ool", 5)]
+        # counted among the MATCHING documents only
+        r = s.search(req_cls(body="enough", result_per_page=20, faceted=["/l/set"], **kw))
+        want = {"/l/set/a": 0, "/l/set/b": 0}
+        for i, x in enumerate(d):
+            if "enough" in TEXTS[i].lower().split() and i != 3:
+                want[x.labels[0]] += 1
+        assert {f.tag: f.total for f in r.facets["/l/set"]} == {k: v for k, v in want.items() if v}
+        # only_faceted: no hits, just facets
+        r = s.search(req_cls(body="", result_per_page=20, faceted=["/c"], only_faceted=True, **kw))
+        assert not r.results and [(f.tag, f.total) for f in r.facets["/c"]] == [("/c/ool", 5)]
+        # order by a fast field: created asc with ties broken by document address, modified desc
+        r = s.search(req_cls(body="", result_per_page=20, order=OrderBy(0, desc=False), **kw))
+        assert [x.uuid for x in r.results] == ["r0", "r3", "r1", "r4", "r2", "r5"] and r.total == 6
+        assert [x.sort_value for x in r.results] == [1000, 1000, 1001, 1001, 1002, 1002]
+        r = s.search(req_cls(body="", result_per_page=3, order=OrderBy(1, desc=True), **kw))
+        assert [x.uuid for x in r.results] == ["r0", "r1", "r2"] and r.next_page
+        s.close()
