@@ -22,28 +22,36 @@
 
 namespace nidx {
 
-#define BM25_TABLE 4096
-#define BM25_MAX_DISTINCT 2048
 #define BM25_EMPTY 0xffffffffu
 
+// NT threads per work item: a window holds 8 postings per thread, the hash table is twice that.
+template <int NT>
 struct Bm25Shared {
-    uint32_t key[BM25_TABLE];
-    float acc[BM25_TABLE];
-    uint16_t flags[BM25_TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
+    static constexpr int TABLE = NT * 16, DISTINCT = NT * 8, NW = NT / 64;
+    uint32_t key[TABLE];
+    float acc[TABLE];
+    uint16_t flags[TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
     float tf_cache[256];
     unsigned long long cursor[BM25_MAX_CLAUSES];
     unsigned long long end[BM25_MAX_CLAUSES];
-    const uint32_t *base[BM25_MAX_CLAUSES];  // doc-id array the clause's cursor indexes (postings, or a materialised term set)
+    uint8_t c_aux[BM25_MAX_CLAUSES];    // the clause's cursor indexes a materialised term set (aux_doc_ids), not the postings
+    uint8_t c_occur[BM25_MAX_CLAUSES];
+    uint8_t c_mode[BM25_MAX_CLAUSES];
+    float c_weight[BM25_MAX_CLAUSES];
     uint32_t hi;
+    uint32_t slot_start[BM25_MAX_CLAUSES + 1];  // this window's slots [slot_start[c], slot_start[c + 1]) belong to clause c
+    uint64_t kth[NW];  // every wave's current k-th key: the best of them is the block's admission threshold
     uint32_t taken_c[BM25_MAX_CLAUSES];
     unsigned long long total;
     unsigned long long postings;
 };
 
-template <int KL>
-__global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
-    __shared__ Bm25Shared sh;
-    __shared__ uint64_t merge[3][64 * KL];
+template <int KL, int NT>
+__global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
+    constexpr int BM25_TABLE = Bm25Shared<NT>::TABLE, BM25_MAX_DISTINCT = Bm25Shared<NT>::DISTINCT, NW = NT / 64;
+    constexpr int HASH_SHIFT = NT == 256 ? 20 : (NT == 128 ? 21 : 22);  // 32 - log2(TABLE)
+    __shared__ Bm25Shared<NT> sh;
+    __shared__ uint64_t merge[NW > 1 ? NW - 1 : 1][64 * KL];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const Bm25Work work = a.work[blockIdx.x];
     const uint32_t q = work.query;
@@ -52,18 +60,23 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     const Bm25ClauseDev *cl = a.clauses + c0;
     const int k = (int)a.k;
 
-    for (int i = tid; i < BM25_TABLE; i += 256) {
+    for (int i = tid; i < BM25_TABLE; i += NT) {
         sh.key[i] = BM25_EMPTY;
         sh.acc[i] = 0.f;
         sh.flags[i] = 0;
     }
-    if (tid < 256) sh.tf_cache[tid] = a.tf_cache[tid];
+    for (int i = tid; i < 256; i += NT) sh.tf_cache[i] = a.tf_cache[i];
     int n_must = 0, n_group = 0;
     for (int c = 0; c < C; c++) {
         n_must += cl[c].occur == 1 ? 1 : 0;
         n_group += cl[c].occur == 3 ? 1 : 0;
     }
-    if (tid < C) sh.base[tid] = (cl[tid].term & BM25_AUX_TERM) ? a.aux_doc_ids : a.doc_ids;
+    for (int c = tid; c < C; c += NT) {
+        sh.c_aux[c] = (cl[c].term & BM25_AUX_TERM) ? 1 : 0;
+        sh.c_occur[c] = (uint8_t)cl[c].occur;
+        sh.c_mode[c] = (uint8_t)cl[c].mode;
+        sh.c_weight[c] = cl[c].weight;
+    }
     if (work.n_slices <= 1) {
         if (tid < C) {
             const uint32_t t = cl[tid].term;
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         // doc range of this slice; per clause a wave finds the first posting >= lo and >= hi
         const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
         const uint32_t hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
-        for (int c = wib; c < C; c += 4) {
+        for (int c = wib; c < C; c += NW) {
             const uint32_t t = cl[c].term;
             const bool aux = (t & BM25_AUX_TERM) != 0;
             const uint32_t ti = t & ~BM25_AUX_TERM;
@@ -114,8 +127,8 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
         sh.total = 0;
         sh.postings = 0;
     }
+    if (tid < NW) sh.kth[tid] = NIDX_EMPTY_KEY;
     __syncthreads();
-    const uint32_t per = C > 0 ? (uint32_t)(BM25_MAX_DISTINCT / C) : 1u;
     unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0;
     const unsigned long long cy_t0 = clock64();
 
@@ -131,70 +144,111 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     uint32_t *mbits = mslot >= 0 ? a.match_bits + (size_t)mslot * a.match_words : nullptr;
 
     for (;;) {
-        // ---- window end: smallest doc id that some clause could not fit ----
+        // ---- window: the slots are shared out in proportion to what is left of every clause's list in this slice
+        //      (doc ids of one slice are spread alike, so the lists then run out at about the same doc id);
+        //      the window ends at the smallest doc id that some clause could not fit ----
         if (tid == 0) sh.hi = 0xffffffffu;
         __syncthreads();
-        bool any_left = false;
-        for (int c = 0; c < C; c++) any_left = any_left || sh.cursor[c] < sh.end[c];
-        if (!any_left) break;
+        unsigned long long total_left = 0;
+        for (int c = 0; c < C; c++) total_left += sh.end[c] - sh.cursor[c];
+        if (total_left == 0) break;
+        if (tid == 0) {
+            uint32_t at = 0;
+            for (int c = 0; c < C; c++) {
+                const unsigned long long left = sh.end[c] - sh.cursor[c];
+                unsigned long long share = total_left <= (unsigned long long)BM25_MAX_DISTINCT
+                                               ? left
+                                               : (left * (unsigned long long)(BM25_MAX_DISTINCT - C)) / total_left + (left ? 1 : 0);
+                sh.slot_start[c] = at;
+                at += (uint32_t)share;
+            }
+            sh.slot_start[C] = at;
+        }
+        __syncthreads();
         if (tid < C) {
             unsigned long long cur = sh.cursor[tid], e = sh.end[tid];
-            if (cur + per < e) atomicMin(&sh.hi, sh.base[tid][cur + per]);
+            const uint32_t per_c = sh.slot_start[tid + 1] - sh.slot_start[tid];
+            if (cur + per_c < e) atomicMin(&sh.hi, (sh.c_aux[tid] ? a.aux_doc_ids : a.doc_ids)[cur + per_c]);
         }
         __syncthreads();
         const uint32_t hi = sh.hi;
         const unsigned long long cy_a = clock64();
-        // ---- load phase: the window holds <= 2048 posting slots (slot g belongs to clause g / per);
-        //      every thread fetches its 8 slots for ALL clauses up front, so a window costs three
-        //      dependent memory round trips (doc id -> tf + fieldnorm gather) instead of three per clause
+        // ---- load phase: the window holds <= 2048 posting slots (slot g belongs to clause g / per); every
+        //      thread fetches its 8 slots for ALL clauses, each of the three dependent steps (index -> doc id ->
+        //      tf + fieldnorm) issued for all 8 slots before the first use: three memory round trips per window
         uint32_t p_doc[8];
         float p_score[8];
         int p_clause[8];
+        unsigned long long p_idx[8];
+        uint32_t p_attr[8];   // occur | mode << 8 | aux << 16
+        float p_weight[8];
         if (tid < BM25_MAX_CLAUSES) sh.taken_c[tid] = 0;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const uint32_t g = (uint32_t)tid + 256u * m;
-            const int c = (int)(g / per);
-            p_clause[m] = -1;
-            p_doc[m] = 0;
+            const uint32_t g = (uint32_t)tid + (uint32_t)NT * m;
+            int c = 0;
+            while (c < C && g >= sh.slot_start[c + 1]) c++;
+            const int cc = c < C ? c : 0;
+            const unsigned long long i = sh.cursor[cc] + (g - sh.slot_start[cc]);
+            const bool valid = c < C && i < sh.end[cc];
+            p_clause[m] = valid ? c : -1;
+            p_idx[m] = valid ? i : 0;
+            p_attr[m] = (uint32_t)sh.c_occur[cc] | ((uint32_t)sh.c_mode[cc] << 8) | ((uint32_t)sh.c_aux[cc] << 16);
+            p_weight[m] = sh.c_weight[cc];
+        }
+        // unconditional loads (index 0 stands in for an unused slot), so that all eight are in flight together
+#pragma unroll
+        for (int m = 0; m < 8; m++) p_doc[m] = ((p_attr[m] >> 16) && p_clause[m] >= 0 ? a.aux_doc_ids : a.doc_ids)[p_idx[m]];
+        uint32_t p_tf[8], p_fn[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            if (p_clause[m] >= 0 && p_doc[m] >= hi) p_clause[m] = -1;  // hi == 0xffffffff: every clause's remainder fits
+            const bool scored = p_clause[m] >= 0 && (p_attr[m] & 0xff) != 2 && ((p_attr[m] >> 8) & 0xff) != 2;
+            p_tf[m] = a.tfs[scored && ((p_attr[m] >> 8) & 0xff) == 0 ? p_idx[m] : 0];
+            p_fn[m] = (uint32_t)a.fieldnorm_ids[scored ? p_doc[m] : 0];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
             p_score[m] = 0.f;
-            if (c < C) {
-                const unsigned long long i = sh.cursor[c] + (g - (uint32_t)c * per);
-                if (i < sh.end[c]) {
-                    const uint32_t d = sh.base[c][i];
-                    if (d < hi) {  // hi == 0xffffffff: every clause's remainder fits
-                        p_clause[m] = c;
-                        p_doc[m] = d;
-                        const int mode = cl[c].mode;
-                        if (cl[c].occur != 2) {
-                            if (mode == 2) p_score[m] = cl[c].weight;  // ConstScorer(boost)
-                            else {
-                                const float tf = mode == 1 ? 1.0f : (float)a.tfs[i];
-                                const float norm = sh.tf_cache[a.fieldnorm_ids[d]];
-                                p_score[m] = cl[c].weight * (tf / (tf + norm));
-                            }
-                        }
-                    }
+            if (p_clause[m] >= 0 && (p_attr[m] & 0xff) != 2) {
+                const uint32_t mode = (p_attr[m] >> 8) & 0xff;
+                if (mode == 2) p_score[m] = p_weight[m];  // ConstScorer(boost)
+                else {
+                    const float tf = mode == 1 ? 1.0f : (float)p_tf[m];
+                    p_score[m] = p_weight[m] * (tf / (tf + sh.tf_cache[p_fn[m]]));
                 }
             }
         }
-        __syncthreads();  // taken_c zeroed
         const unsigned long long cy_b = clock64();
-        // ---- apply phase: clause by clause (barrier in between) so every doc's f32 sum is built in clause order
+        // ---- probe phase: every posting finds (or claims) its document's slot; which posting claims a slot does
+        //      not matter, so all clauses probe together.  The claimer OWNS the document for the fold.
+        uint32_t p_slot[8];
+        uint32_t owned = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            p_slot[m] = 0;
+            if (p_clause[m] < 0) continue;
+            const uint32_t d = p_doc[m];
+            uint32_t h = (d * 2654435761u) >> HASH_SHIFT;
+            for (;;) {
+                uint32_t old = atomicCAS(&sh.key[h], BM25_EMPTY, d);
+                if (old == BM25_EMPTY) { owned |= 1u << m; break; }
+                if (old == d) break;
+                h = (h + 1) & (BM25_TABLE - 1);
+            }
+            p_slot[m] = h;
+        }
+        __syncthreads();  // taken_c zeroed, every key placed
+        // ---- apply phase: clause by clause (barrier in between) so every doc's f32 sum is built in clause order;
+        //      within a clause every posting is a different document, so the read-modify-writes do not collide
         for (int c = 0; c < C; c++) {
-            const int occur = cl[c].occur;
+            const int occur = sh.c_occur[c];
             uint32_t mine = 0;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 if (p_clause[m] != c) continue;
                 mine++;
-                const uint32_t d = p_doc[m];
-                uint32_t h = (d * 2654435761u) >> 20;
-                for (;;) {
-                    uint32_t old = atomicCAS(&sh.key[h], BM25_EMPTY, d);
-                    if (old == BM25_EMPTY || old == d) break;
-                    h = (h + 1) & (BM25_TABLE - 1);
-                }
+                const uint32_t h = p_slot[m];
                 if (occur == 2) {
                     sh.flags[h] |= 2;  // MustNot
                 } else {
@@ -212,15 +266,20 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             atomicAdd(&sh.postings, (unsigned long long)sh.taken_c[tid]);
         }
         const unsigned long long cy_c = clock64();
-        // ---- fold the window into the top-k, count matches, clear the table ----
+        // ---- fold the window into the top-k, count matches, clear the table: each thread folds the documents it
+        //      owns.  The admission threshold is shared by the four waves (any wave's k-th key bounds the block's).
         uint32_t matched_here = 0;
-        for (int base = wib * 64; base < BM25_TABLE; base += 256) {
-            int i = base + lane;
-            uint32_t d = sh.key[i];
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            if (sh.kth[w] > kth) kth = sh.kth[w];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
             bool ok = false;
             uint64_t ck = NIDX_EMPTY_KEY;
-            if (d != BM25_EMPTY) {
-                uint16_t f = sh.flags[i];
+            if (owned & (1u << m)) {
+                const uint32_t i = p_slot[m];
+                const uint32_t d = p_doc[m];
+                const uint16_t f = sh.flags[i];
                 ok = !(f & 2) && (int)(f >> 8) == n_must && (n_group == 0 || (f & 4)) && (n_must > 0 || n_group > 0 || (f & 1));
                 if (ok && a.alive) ok = bit_test(a.alive, d);
                 if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
@@ -245,14 +304,15 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             }
             unsigned long long okm = __ballot(ok);
             matched_here += (uint32_t)__popcll(okm);
-            unsigned long long m = __ballot(ok && ck > kth);
-            while (m) {
-                int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
+            unsigned long long mm = __ballot(ok && ck > kth);
+            while (mm) {
+                int src = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
                 uint64_t nk = shfl_u64(ck, src);
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }
+        if (lane == 0) sh.kth[wib] = kth;
         if (lane == 0 && matched_here) atomicAdd(&sh.total, (unsigned long long)matched_here);
         __syncthreads();
         cy_load += cy_b - cy_a;
@@ -276,7 +336,8 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     }
     __syncthreads();
     if (wib == 0) {
-        for (int w = 0; w < 3; w++)
+        kth = top.at(k - 1);  // this wave's own k-th key (the running threshold may have been another wave's)
+        for (int w = 0; w < NW - 1; w++)
             for (int i = 0; i < k; i++) {
                 uint64_t nk = merge[w][i];
                 if (nk == NIDX_EMPTY_KEY) break;
@@ -290,10 +351,7 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
             const uint64_t key = top.mine(i);
             const bool valid = key != NIDX_EMPTY_KEY && e < k;
             cnt += (uint32_t)__popcll(__ballot(valid));
-            if (e < k) {
-                a.out_doc[(size_t)blockIdx.x * k + e] = valid ? rank_key_addr(key) : 0xffffffffu;
-                a.out_score[(size_t)blockIdx.x * k + e] = valid ? rank_key_score(key) : 0.f;
-            }
+            if (e < k) a.out_key[(size_t)blockIdx.x * k + e] = valid ? key : NIDX_EMPTY_KEY;
         }
         if (lane == 0) {
             a.out_count[blockIdx.x] = cnt;
@@ -303,10 +361,68 @@ __global__ __launch_bounds__(256) void bm25_search_kernel(Bm25Args a) {
     }
 }
 
+// ---- per-query merge of the slices' lists (TopDocs merges its per-segment collectors the same way): one wave per
+//      query walks its work items' sorted key lists, stopping in a list at the first key below the running k-th ----
+template <int KL>
+__global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t w0 = m.item_first[q], w1 = m.item_first[q + 1];
+    const int k = (int)m.k;
+    WaveTopK<KL> top;
+    top.init();
+    uint64_t kth = NIDX_EMPTY_KEY;
+    unsigned long long total = 0, postings = 0;
+    for (uint32_t w = w0; w < w1; w++) {
+        const uint32_t cnt = m.item_count[w];
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const uint64_t key = i < cnt ? m.item_key[(size_t)w * k + i] : NIDX_EMPTY_KEY;
+            unsigned long long mm = __ballot(key > kth);
+            if (!mm) break;  // sorted: nothing further down this list can enter
+            while (mm) {
+                const int src = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const uint64_t nk = shfl_u64(key, src);
+                if (nk > kth) kth = top.insert_kth(nk, k, lane);
+            }
+        }
+        if (lane == 0) {
+            total += m.item_total[w];
+            postings += m.item_postings[w];
+        }
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KL; i++) {
+        const int e = 64 * i + lane;
+        const uint64_t key = top.mine(i);
+        const bool valid = key != NIDX_EMPTY_KEY && e < k;
+        cnt += (uint32_t)__popcll(__ballot(valid));
+        if (e < k) {
+            m.out_doc[(size_t)q * k + e] = valid ? rank_key_addr(key) : 0xffffffffu;
+            m.out_score[(size_t)q * k + e] = valid ? rank_key_score(key) : 0.f;
+        }
+    }
+    if (lane == 0) {
+        m.out_count[q] = cnt;
+        m.out_total[q] = total;
+        m.out_postings[q] = postings;
+    }
+}
+
+hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s) {
+    if (n_queries == 0) return hipSuccess;
+    if (m.k > 64) hipLaunchKernelGGL(bm25_merge_kernel<4>, dim3(n_queries), dim3(64), 0, s, m);
+    else hipLaunchKernelGGL(bm25_merge_kernel<1>, dim3(n_queries), dim3(64), 0, s, m);
+    return hipGetLastError();
+}
+
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s) {
     if (n_work == 0) return hipSuccess;
-    if (a.k > 64) hipLaunchKernelGGL(bm25_search_kernel<4>, dim3(n_work), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bm25_search_kernel<1>, dim3(n_work), dim3(256), 0, s, a);
+    // one WAVE per work item: no block barrier anywhere on the path, four times as many independent items per CU
+    if (a.k > 64) hipLaunchKernelGGL((bm25_search_kernel<4, BM25_ITEM_THREADS>), dim3(n_work), dim3(BM25_ITEM_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((bm25_search_kernel<1, BM25_ITEM_THREADS>), dim3(n_work), dim3(BM25_ITEM_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <mutex>
 
@@ -66,7 +67,7 @@ struct Bm25Index {
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
     DevBuf tf_cache;
-    DevBuf s_clauses, s_offsets, s_after, s_work, s_doc, s_score, s_count, s_total, s_postings;
+    DevBuf s_clauses, s_offsets, s_after, s_work, s_doc, s_score, s_count, s_total, s_postings, s_key, s_item_first, s_qcount, s_qtotal, s_qpostings;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
@@ -337,6 +338,10 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         if (n_set_terms) NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, opt->term_set_terms, n_set_terms * 4, hipMemcpyHostToDevice, idx->stream));
     }
     idx->last_kernel_ms = 0.f;
+    const bool host_dbg = getenv("NIDX_GPU_BM25_DEBUG") != nullptr;
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_us();
+    double t_work = 0, t_sync = 0, t_collect = 0;
     struct Hit { float score; uint64_t docaddr; int64_t value; };
     std::vector<std::vector<Hit>> merged(nq);
     std::vector<Bm25Work> work;
@@ -388,17 +393,28 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             return seg.term_offsets_host[cl.term + 1] - seg.term_offsets_host[cl.term];
         };
         // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
+        const double t_w0 = now_us();
         work.clear();
+        std::vector<uint32_t> item_first(nq + 1, 0);
         for (uint32_t q = 0; q < nq; q++) {
+            item_first[q] = (uint32_t)work.size();
             uint64_t p = 0;
             for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) p += postings_of(clauses[c]);
             uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + BM25_SLICE_POSTINGS - 1) / BM25_SLICE_POSTINGS));
             for (uint32_t sl = 0; sl < slices; sl++) work.push_back(Bm25Work{q, sl, slices});
         }
         const size_t nw = work.size();
+        item_first[nq] = (uint32_t)nw;
+        t_work += now_us() - t_w0;
         NIDX_HIP(idx->s_work.reserve(nw * sizeof(Bm25Work)));
-        NIDX_HIP(idx->s_doc.reserve(nw * kk * 4));
-        NIDX_HIP(idx->s_score.reserve(nw * kk * 4));
+        NIDX_HIP(idx->s_key.reserve(nw * kk * 8));
+        NIDX_HIP(idx->s_item_first.reserve((size_t)(nq + 1) * 4));
+        NIDX_HIP(idx->s_doc.reserve((size_t)nq * kk * 4));
+        NIDX_HIP(idx->s_score.reserve((size_t)nq * kk * 4));
+        NIDX_HIP(idx->s_qcount.reserve((size_t)nq * 4));
+        NIDX_HIP(idx->s_qtotal.reserve((size_t)nq * 8));
+        NIDX_HIP(idx->s_qpostings.reserve((size_t)nq * 8));
+        NIDX_HIP(hipMemcpyAsync(idx->s_item_first.p, item_first.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, idx->stream));
         NIDX_HIP(idx->s_count.reserve(nw * 4));
         NIDX_HIP(idx->s_total.reserve(nw * 8));
         NIDX_HIP(idx->s_postings.reserve(nw * 8));
@@ -426,8 +442,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         a.after = after ? idx->s_after.as<Bm25AfterDev>() : nullptr;
         a.k = kk;
         a.segment_ord = (uint32_t)s;
-        a.out_doc = idx->s_doc.as<uint32_t>();
-        a.out_score = idx->s_score.as<float>();
+        a.out_key = idx->s_key.as<unsigned long long>();
         a.out_count = idx->s_count.as<uint32_t>();
         a.out_total = idx->s_total.as<unsigned long long>();
         a.out_postings = idx->s_postings.as<unsigned long long>();
@@ -448,21 +463,37 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
         NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
+        Bm25MergeArgs mg;
+        mg.item_first = idx->s_item_first.as<uint32_t>();
+        mg.item_key = idx->s_key.as<unsigned long long>();
+        mg.item_count = idx->s_count.as<uint32_t>();
+        mg.item_total = idx->s_total.as<unsigned long long>();
+        mg.item_postings = idx->s_postings.as<unsigned long long>();
+        mg.k = kk;
+        mg.out_doc = idx->s_doc.as<uint32_t>();
+        mg.out_score = idx->s_score.as<float>();
+        mg.out_count = idx->s_qcount.as<uint32_t>();
+        mg.out_total = idx->s_qtotal.as<unsigned long long>();
+        mg.out_postings = idx->s_qpostings.as<unsigned long long>();
+        NIDX_HIP(launch_bm25_merge(mg, nq, idx->stream));
         if (n_slots)
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_pair_term.as<uint32_t>(),
                                         idx->s_pair_slot.as<int>(), (uint32_t)n_pairs, idx->s_match_bits.as<uint32_t>(), match_words,
                                         idx->s_facet_counts.as<unsigned long long>(), idx->stream));
-        h_doc.resize(nw * kk);
-        h_score.resize(nw * kk);
-        h_count.resize(nw);
-        h_total.resize(nw);
-        h_post.resize(nw);
-        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, nw * kk * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, nw * kk * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_count.p, nw * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_total.p, nw * 8, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_postings.p, nw * 8, hipMemcpyDeviceToHost, idx->stream));
+        h_doc.resize((size_t)nq * kk);
+        h_score.resize((size_t)nq * kk);
+        h_count.resize(nq);
+        h_total.resize(nq);
+        h_post.resize(nq);
+        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_qcount.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_qtotal.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_qpostings.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        const double t_s0 = now_us();
         NIDX_HIP(hipStreamSynchronize(idx->stream));
+        t_sync += now_us() - t_s0;
+        const double t_c0 = now_us();
         float ms = 0.f;
         NIDX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
         idx->last_kernel_ms += ms;
@@ -472,27 +503,31 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu cycles/item: load=%llu apply=%llu fold=%llu total=%llu kernel_ms=%.3f\n", d[5], d[4],
                     d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), ms);
         }
-        for (size_t w = 0; w < nw; w++) {
-            const uint32_t q = work[w].query;
-            if (out_total) out_total[q] += h_total[w];
-            if (out_postings) out_postings[q] += h_post[w];
+        for (uint32_t q = 0; q < nq; q++) {  // per segment the device already merged the slices
+            if (out_total) out_total[q] += h_total[q];
+            if (out_postings) out_postings[q] += h_post[q];
             if (k == 0) continue;
-            for (uint32_t i = 0; i < h_count[w]; i++) {
-                const uint32_t d = h_doc[w * kk + i];
+            for (uint32_t i = 0; i < h_count[q]; i++) {
+                const uint32_t d = h_doc[(size_t)q * kk + i];
                 if (order_field >= 0) merged[q].push_back(Hit{0.f, ((uint64_t)s << 32) | d, seg.fast_host[order_field][d]});
-                else merged[q].push_back(Hit{h_score[w * kk + i], ((uint64_t)s << 32) | d, 0});
+                else merged[q].push_back(Hit{h_score[(size_t)q * kk + i], ((uint64_t)s << 32) | d, 0});
             }
         }
+        t_collect += now_us() - t_c0;
     }
+    const double t_merge0 = now_us();
     if (n_slots) {
         std::vector<unsigned long long> fc(n_pairs);
         NIDX_HIP(hipMemcpy(fc.data(), idx->s_facet_counts.p, n_pairs * 8, hipMemcpyDeviceToHost));
         for (uint64_t p = 0; p < n_pairs; p++) opt->out_facet_counts[p] = fc[p];
     }
     const bool desc = opt->order_desc != 0;
+    const bool single_segment = idx->segs.size() == 1;
     for (uint32_t q = 0; q < nq && k > 0; q++) {
         std::vector<Hit> &m = merged[q];
-        if (order_field >= 0) {
+        if (single_segment) {
+            // one segment: the device list is already in TopDocs order
+        } else if (order_field >= 0) {
             // order_by_fast_field across segments: the fast value, then DocAddress asc
             std::sort(m.begin(), m.end(), [desc](const Hit &x, const Hit &y) {
                 if (x.value != y.value) return desc ? x.value > y.value : x.value < y.value;
@@ -514,6 +549,9 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             if (opt->out_order_value) opt->out_order_value[(size_t)q * k + i] = m[i].value;
         }
     }
+    if (host_dbg)
+        fprintf(stderr, "[bm25 host] total=%.0f us: work list=%.0f sync wait=%.0f collect=%.0f merge=%.0f\n", now_us() - t_begin, t_work, t_sync,
+                t_collect, now_us() - t_merge0);
     return NIDX_OK;
 }
 

@@ -234,7 +234,8 @@ struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
 struct Bm25Work {  // one workgroup: query `query`, doc-id slice `slice` of `n_slices`
     uint32_t query, slice, n_slices;
 };
-#define BM25_SLICE_POSTINGS 8192  /* target postings per work item */
+#define BM25_ITEM_THREADS 64      /* threads per work item (64 = one wave: no block barriers) */
+#define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
 #define BM25_MAX_SLICES 256
 struct Bm25Args {
     const Bm25Work *work;
@@ -250,8 +251,7 @@ struct Bm25Args {
     const Bm25AfterDev *after;  // nullptr or [n_queries]
     uint32_t k;                 // <= 256
     uint32_t segment_ord;
-    uint32_t *out_doc;          // [n_work][k]
-    float *out_score;           // [n_work][k]
+    unsigned long long *out_key;  // [n_work][k] rank keys, best first (score bits or order rank << 32 | ~doc)
     uint32_t *out_count;        // [n_work]
     unsigned long long *out_total;
     unsigned long long *out_postings;
@@ -268,6 +268,18 @@ struct Bm25Args {
     uint32_t match_words;
 };
 #define BM25_AUX_TERM 0x80000000u
+struct Bm25MergeArgs {  // per query: merge the key lists of its work items [item_first[q], item_first[q + 1])
+    const uint32_t *item_first;             // [n_queries + 1]
+    const unsigned long long *item_key;     // [n_work][k]
+    const uint32_t *item_count;             // [n_work]
+    const unsigned long long *item_total, *item_postings;  // [n_work]
+    uint32_t k;
+    uint32_t *out_doc;                      // [n_queries][k]
+    float *out_score;                       // [n_queries][k] (meaningless when ordering by a fast field)
+    uint32_t *out_count;
+    unsigned long long *out_total, *out_postings;  // [n_queries]
+};
+hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s);
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s);
 
 // ---- BM25 surroundings (bm25_aux.hip) ----
