@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25", "rabitq"], default="hnsw")
+    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25", "rabitq", "hybrid"], default="hnsw")
     p.add_argument("--n-docs", type=int, default=10_000_000, help="bm25: documents per shard")
     p.add_argument("--vocab", type=int, default=1_000_000)
     p.add_argument("--recall-queries", type=int, default=256)
@@ -88,6 +88,12 @@ def main():
     _lib.check(L.nidx_gpu_set_device(local_rank))
     if a.workload == "bm25":
         bench_bm25(a, L, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if a.workload == "hybrid":
+        bench_hybrid(a, L, dev, rank, world)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -294,17 +300,10 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_bm25(a, L, dev, rank, world):
-    """BASELINE.json's second metric: BM25 postings ("docs") scored per second.  T-zipf corpus of
-    SURVEY §8d: vocabulary 1M, term ids ~ Zipf(1.0), doc length ~ lognormal(ln 48, 0.6) in [4, 2000];
-    1024 queries x 3 Should terms drawn uniformly from the rank band [100, 100k], k = 20."""
-    from nucliadb_amd import _lib
-    from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment, Clause
-
-    n_docs, vocab, B, k = a.n_docs, a.vocab, a.batch, 20
+def zipf_corpus_on_device(L, dev, n_docs, vocab, rank):
+    """T-zipf of SURVEY §8d generated with torch on the device -> host CSR postings."""
     g = torch.Generator(device=dev)
     g.manual_seed(1234567890 + rank)
-    t0 = time.time()
     lens = torch.exp(torch.randn(n_docs, generator=g, device=dev) * 0.6 + np.log(48.0)).round().clamp(4, 2000).to(torch.int64)
     total_tokens = int(lens.sum().item())
     cdf = torch.cumsum(1.0 / torch.arange(1, vocab + 1, device=dev, dtype=torch.float64), 0)
@@ -329,6 +328,138 @@ def bench_bm25(a, L, dev, rank, world):
     fieldnorm_ids = (torch.searchsorted(table, lens, right=True) - 1).to(torch.uint8).cpu().numpy()
     del uniq, counts, term, df
     torch.cuda.empty_cache()
+    return term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens
+
+
+def rrf_batch(vec_ids, vec_cnt, bm_ids, bm_cnt, k_out, k_rrf=60.0):
+    """ReciprocalRankFusion (nucliadb rank_fusion.py:106-181) for a whole batch with numpy: both lists arrive ranked;
+    score(d) = sum 1 / (k + rank); returns the k_out best fused ids per query."""
+    B = vec_ids.shape[0]
+    ids = np.concatenate([vec_ids, bm_ids], axis=1).astype(np.int64)
+    w = np.concatenate([1.0 / (k_rrf + np.arange(vec_ids.shape[1])), 1.0 / (k_rrf + np.arange(bm_ids.shape[1]))])
+    w = np.broadcast_to(w, ids.shape).copy()
+    valid = np.concatenate([np.arange(vec_ids.shape[1])[None, :] < vec_cnt[:, None], np.arange(bm_ids.shape[1])[None, :] < bm_cnt[:, None]], axis=1)
+    w[~valid] = 0.0
+    ids[~valid] = -1
+    order = np.argsort(ids, axis=1, kind="stable")
+    ids_s = np.take_along_axis(ids, order, axis=1)
+    w_s = np.take_along_axis(w, order, axis=1)
+    same = np.zeros_like(ids_s, dtype=bool)
+    same[:, 1:] = ids_s[:, 1:] == ids_s[:, :-1]
+    # a document appears at most once per list: fold the second occurrence into the first
+    w_s[:, :-1] += np.where(same[:, 1:], w_s[:, 1:], 0.0)
+    w_s[same] = 0.0
+    top = np.argsort(-w_s, axis=1, kind="stable")[:, :k_out]
+    return np.take_along_axis(ids_s, top, axis=1), np.take_along_axis(w_s, top, axis=1)
+
+
+def bench_hybrid(a, L, dev, rank, world):
+    """BASELINE.json configs[2]: cosine HNSW over N x 768 vectors + BM25 over N synthetic documents (document i owns
+    vector i), a batch of 1024 hybrid queries (one vector + 3 keyword terms), fused with reciprocal rank fusion.
+    The vector search is launched on the torch stream, the BM25 search runs on the library's own stream: they overlap
+    on the device; the fusion is nucliadb's Python-side step (vectorised with numpy here)."""
+    from nucliadb_amd import _lib
+    from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
+
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    n_docs, vocab, kb = n, a.vocab, 20
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234567890 + rank)
+    x = torch.rand((n, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    x /= x.norm(dim=1, keepdim=True)
+    x_host = x.cpu().numpy()
+    del x
+    torch.cuda.empty_cache()
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    cseg = _lib.VectorSegmentC(x_host.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
+    del x_host
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
+    build_s = time.time() - t0
+    t0 = time.time()
+    term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens = zipf_corpus_on_device(L, dev, n_docs, vocab, rank)
+    gen_s = time.time() - t0
+    searcher = Bm25Searcher.open([Bm25Segment(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)])
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2)
+    n_pool = 4
+    qpool = torch.rand((n_pool, B, d), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
+    qpool /= qpool.norm(dim=2, keepdim=True)
+    rng = np.random.default_rng(2)
+    prepared = []
+    for _ in range(n_pool):
+        cl = (_lib.Bm25ClauseC * (3 * B))()
+        terms = rng.integers(99, 100_000, (B, 3))
+        for i in range(B):
+            for j in range(3):
+                cl[3 * i + j].term, cl[3 * i + j].occur, cl[3 * i + j].mode, cl[3 * i + j].boost = int(terms[i, j]), 0, 0, 1.0
+        prepared.append(cl)
+    offsets = (np.arange(B + 1, dtype=np.uint64) * 3).copy()
+    out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    docaddr, score = np.zeros((B, kb), np.uint64), np.zeros((B, kb), np.float32)
+    count, total, post = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
+    params = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+    stream = torch.cuda.current_stream().cuda_stream
+    t_parts = {"vector_launch+bm25": 0.0, "sync+copy": 0.0, "fusion": 0.0}
+
+    def step(i, timed=False):
+        t0 = time.perf_counter()
+        _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, qpool[i % n_pool].data_ptr(), B, C.byref(params), None, out_vec.data_ptr(),
+                                                           out_score.data_ptr(), out_count.data_ptr(), None, stream))
+        _lib.check(L.nidx_gpu_bm25_search(searcher._handle, prepared[i % n_pool], offsets.ctypes.data, B, kb, None, docaddr.ctypes.data,
+                                          score.ctypes.data, count.ctypes.data, total.ctypes.data, post.ctypes.data))
+        t1 = time.perf_counter()
+        vi = out_vec.cpu().numpy()
+        vc = out_count.cpu().numpy()
+        t2 = time.perf_counter()
+        fused = rrf_batch(vi, vc, (docaddr & 0xFFFFFFFF).astype(np.int64), count, k)
+        t3 = time.perf_counter()
+        if timed:
+            t_parts["vector_launch+bm25"] += t1 - t0
+            t_parts["sync+copy"] += t2 - t1
+            t_parts["fusion"] += t3 - t2
+        return fused
+
+    for i in range(max(1, a.warmup)):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, timed=True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = C.c_float()
+    L.nidx_gpu_bm25_last_kernel_ms(searcher._handle, C.byref(ms))
+    searcher.close()
+    L.nidx_gpu_vector_close(h)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "hybrid queries/sec (768-dim cosine HNSW k=%d + BM25 k=%d over the same %d documents, reciprocal rank fusion)" % (k, kb, n),
+            "value": world * B * a.steps / elapsed, "unit": "hybrid queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "hybrid: %d x %d-dim cosine HNSW + BM25 over %d docs (vocab %d), batch=%d, RRF k=60" % (n, d, n_docs, vocab, B),
+                       "hnsw_build_s": build_s, "corpus_gen_s": gen_s, "bm25_kernel_ms": ms.value,
+                       "ms_per_step_parts": {kk_: v / a.steps * 1e3 for kk_, v in t_parts.items()},
+                       "note": "end to end per batch: vector search on device buffers + BM25 through the host-buffer entry point, both device "
+                               "results copied to the host, fused by numpy"},
+            "roofline": None, "cpu_baseline": None}))
+
+
+def bench_bm25(a, L, dev, rank, world):
+    """BASELINE.json's second metric: BM25 postings ("docs") scored per second.  T-zipf corpus of
+    SURVEY §8d: vocabulary 1M, term ids ~ Zipf(1.0), doc length ~ lognormal(ln 48, 0.6) in [4, 2000];
+    1024 queries x 3 Should terms drawn uniformly from the rank band [100, 100k], k = 20."""
+    from nucliadb_amd import _lib
+    from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment, Clause
+
+    n_docs, vocab, B, k = a.n_docs, a.vocab, a.batch, 20
+    t0 = time.time()
+    term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens = zipf_corpus_on_device(L, dev, n_docs, vocab, rank)
     gen_s = time.time() - t0
     seg = Bm25Segment(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)
     t0 = time.time()
