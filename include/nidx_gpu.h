@@ -67,7 +67,8 @@ typedef struct {
     uint32_t dimension;          /* VectorType::DenseF32 { dimension } */
     int32_t similarity;          /* NIDX_SIMILARITY_* */
     int32_t normalize_vectors;   /* normalise the QUERY at search time (searcher.rs:246-252) */
-    int32_t vector_cardinality;  /* NIDX_CARDINALITY_*; only SINGLE is implemented */
+    int32_t vector_cardinality;  /* NIDX_CARDINALITY_*; MULTI: a paragraph may own several (contiguous) vectors — one hit per
+                                  * paragraph, its best vector (segment.rs:582-593, hnsw/search.rs:159-164) */
     uint32_t flags;              /* NIDX_CONFIG_* (VectorConfig::flags, config.rs:25-30) */
 } nidx_gpu_vector_config_t;
 #define NIDX_CONFIG_DISABLE_RABITQ_SEARCH 1u /* flags::DISABLE_RABITQ_SEARCH (config.rs:29) */

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
     __shared__ uint32_t res_addr[64 * EFL];
     __shared__ float res_score[64 * EFL];
+    __shared__ uint32_t res_para[64 * EFL];
 
     const int lane = threadIdx.x & 63;
     const bool ctl = (threadIdx.x >> 6) == 0;
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
                 if (dropped_best > ck) st.flags |= NIDX_FLAG_POOL_INEXACT;
                 if (!(cs < a.min_score)) {
                     bool accept = !(cs != cs);
+                    const uint32_t p = a.seg.para_of_vec ? a.seg.para_of_vec[c] : c;
                     if (accept) {
-                        uint32_t p = a.seg.para_of_vec ? a.seg.para_of_vec[c] : c;
                         if (a.seg.alive && !bit_test(a.seg.alive, p)) accept = false;
                         if (accept && a.filter && !bit_test(a.filter, p)) accept = false;
                     }
@@ -123,10 +124,16 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
                                 accept = false;
                         }
                     }
+                    if (accept && a.multi) {
+                        // one hit per paragraph (checked after the duplicate test, like NodeFilter::passes)
+                        for (int base = 0; base < n_res && accept; base += 64)
+                            if (__ballot(base + lane < n_res && res_para[base + lane] == p)) accept = false;
+                    }
                     if (accept) {
                         if (lane == 0) {
                             res_addr[n_res] = c;
                             res_score[n_res] = cs;
+                            res_para[n_res] = p;
                         }
                         n_res++;
                     }

@@ -26,6 +26,9 @@ uint32_t scan_num_blocks(uint32_t n);
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s);
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s);
+hipError_t launch_para_best(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count, uint32_t n_queries, uint32_t k_in,
+                            const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec, float *out_score, uint32_t *out_count,
+                            hipStream_t s);
 hipError_t launch_row_norms(const float *vectors, uint32_t n, uint32_t dp, float *norm2, hipStream_t s);
 hipError_t launch_pair_similarity(const float *x, const float *y, uint32_t n, uint32_t dp, int similarity, float *out,
                                   hipStream_t s);
@@ -139,6 +142,7 @@ struct HnswSearchArgs {
     float *out_score;       // [n_queries][k]
     uint32_t *out_count;    // [n_queries]
     uint32_t *stats;        // nullptr or [n_queries][NIDX_STAT_STRIDE]
+    int multi;              // VectorCardinality::Multi: one hit per paragraph (NodeFilter::paragraphs, search.rs:159-164)
     int eval_rows;          // rows in flight per wave in the distance phase: 2 or 4
     int min_waves;          // register budget: 2 (<=256 VGPR) or 4 (<=128 VGPR) waves per SIMD
     // entry mode (RaBitQ arm): skip the descent and the layer-0 search, run closest_up_nodes from these
@@ -168,6 +172,8 @@ struct RabitqSearchArgs {
     const uint64_t *planes;   // [n_queries][4][dim / 64]
     uint32_t n_queries;
     const uint64_t *filter;   // brute force only (the HNSW arm filters in closest_up_nodes)
+    const uint32_t *para_first, *para_num;  // brute force, multi-vector paragraphs: the vectors of paragraph p (nullptr = one each)
+    uint32_t n_paragraphs;
     uint32_t k;               // <= 256
     uint32_t ef;              // hnsw: min(k * 100, 2000) (search.rs:333-340)
     float min_score;

@@ -475,18 +475,35 @@ __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
     Reranker rr;
     rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
     uint32_t n_est = 0;
-    for (uint32_t base = 0; base < a.seg.n; base += 64) {
-        const uint32_t r = base + (uint32_t)lane;
-        bool ok = r < a.seg.n;
+    // one lane per PARAGRAPH: its best vector by estimate (Iterator::max_by keeps the last of equal maxima,
+    // segment.rs:586-593); single-vector stores have paragraph p = vector p
+    const uint32_t n_para = a.para_first ? a.n_paragraphs : a.seg.n;
+    for (uint32_t base = 0; base < n_para; base += 64) {
+        const uint32_t p = base + (uint32_t)lane;
+        bool ok = p < n_para;
         if (ok) {
-            const uint32_t p = a.seg.para_of_vec ? a.seg.para_of_vec[r] : r;
             if (a.seg.alive && !bit_test(a.seg.alive, p)) ok = false;
             if (ok && a.filter && !bit_test(a.filter, p)) ok = false;
         }
+        const uint32_t first = ok ? (a.para_first ? a.para_first[p] : p) : 0u;
+        const uint32_t num = ok ? (a.para_first ? a.para_num[p] : 1u) : 0u;
+        if (num == 0) ok = false;
         if (!__any(ok)) continue;
         float est = 0.f, err = 0.f;
-        if (ok) rabitq_estimate<NW>(a.quant + (size_t)r * a.rec_len, sh.planes, nw, qc, est, err);
-        n_est += (uint32_t)__popcll(__ballot(ok));
+        uint32_t r = first;
+        if (ok) {
+            rabitq_estimate<NW>(a.quant + (size_t)first * a.rec_len, sh.planes, nw, qc, est, err);
+            for (uint32_t v = first + 1; v < first + num; v++) {
+                float e2, r2;
+                rabitq_estimate<NW>(a.quant + (size_t)v * a.rec_len, sh.planes, nw, qc, e2, r2);
+                if (total_key(e2) >= total_key(est)) {
+                    est = e2;
+                    err = r2;
+                    r = v;
+                }
+            }
+        }
+        n_est += (uint32_t)__popcll(__ballot(ok)) ;
         const float ub = est + err;
         rr.feed(ok && ub >= a.min_score, r, ub, lane);
     }

@@ -165,12 +165,28 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
         if (pov[i] != i) { seg.identity_para = false; break; }
     if (pov.empty() && in.n_paragraphs != in.n_vectors)
         return fail(NIDX_ERR_INVALID_ARGUMENT, "packed vectors need n_paragraphs == n_vectors or paragraph_of_vector");
+    seg.vmax = 1;
     if (!pov.empty()) {
-        std::vector<uint8_t> seen(in.n_paragraphs, 0);
+        // StoredParagraph { first_vector, num_vectors } (data_store/v2/paragraph_store.rs:36-64): a paragraph's vectors are
+        // one contiguous run; more than one only with VectorCardinality::Multi
+        std::vector<uint32_t> first(in.n_paragraphs, 0), num(in.n_paragraphs, 0);
         for (uint32_t i = 0; i < in.n_vectors; i++) {
-            if (pov[i] >= in.n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "paragraph address out of range");
-            if (seen[pov[i]]) return fail(NIDX_ERR_UNSUPPORTED, "paragraphs with more than one vector are not supported yet");
-            seen[pov[i]] = 1;
+            const uint32_t p = pov[i];
+            if (p >= in.n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "paragraph address out of range");
+            if (num[p] == 0) first[p] = i;
+            else if (pov[i - 1] != p) return fail(NIDX_ERR_INVALID_ARGUMENT, "the vectors of paragraph %u are not contiguous", p);
+            num[p]++;
+            if (num[p] > 1 && cfg.vector_cardinality != NIDX_CARDINALITY_MULTI)
+                return fail(NIDX_ERR_INVALID_CONFIGURATION, "paragraph %u owns %u vectors but the index is VectorCardinality::Single", p, num[p]);
+            seg.vmax = std::max(seg.vmax, num[p]);
+        }
+        if (!seg.identity_para) {
+            NIDX_HIP(seg.para_first.alloc(std::max<size_t>(in.n_paragraphs, 1) * 4));
+            NIDX_HIP(seg.para_num.alloc(std::max<size_t>(in.n_paragraphs, 1) * 4));
+            if (in.n_paragraphs) {
+                NIDX_HIP(hipMemcpy(seg.para_first.p, first.data(), (size_t)in.n_paragraphs * 4, hipMemcpyHostToDevice));
+                NIDX_HIP(hipMemcpy(seg.para_num.p, num.data(), (size_t)in.n_paragraphs * 4, hipMemcpyHostToDevice));
+            }
         }
     }
     seg.para_host = pov;
@@ -262,6 +278,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.out_score = d_out_score;
         a.out_count = d_out_count;
         a.stats = d_stats;
+        a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
         a.eval_rows = eval_rows;
         a.min_waves = min_waves;
         a.entry_vec = nullptr;
@@ -286,6 +303,9 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         r.qd = scratch_rq.as<RabitqQueryDev>();
         r.planes = scratch_planes.as<uint64_t>();
         r.filter = d_filter;
+        r.para_first = seg.identity_para ? nullptr : seg.para_first.as<uint32_t>();
+        r.para_num = seg.identity_para ? nullptr : seg.para_num.as<uint32_t>();
+        r.n_paragraphs = seg.n_paragraphs;
         r.k = k;
         r.ef = 0;
         r.min_score = min_score;
@@ -339,6 +359,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.out_score = d_out_score;
         a.out_count = d_out_count;
         a.stats = d_stats;  // entry mode only ORs its overflow flags into the RaBitQ counters
+        a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
         a.eval_rows = eval_rows;
         a.min_waves = min_waves;
         a.entry_vec = scratch_entry_vec.as<uint32_t>();
@@ -347,6 +368,9 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
+    const bool multi = seg.vmax > 1;
+    if (multi && (method == NIDX_METHOD_BRUTE_FORCE_MFMA || method == NIDX_METHOD_BRUTE_FORCE_BF16))
+        return fail(NIDX_ERR_UNSUPPORTED, "the matrix-core scans do not reduce multi-vector paragraphs: use NIDX_METHOD_BRUTE_FORCE");
     if (method == NIDX_METHOD_BRUTE_FORCE_MFMA) {
         if (k > NIDX_MFMA_KMAX) return fail(NIDX_ERR_UNSUPPORTED, "the MFMA scan keeps at most %d hits per query (got k=%u)", NIDX_MFMA_KMAX, k);
         if (cfg.similarity == NIDX_SIMILARITY_COSINE && !seg.norm2_serial.p) {
@@ -427,6 +451,17 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     }
     // brute force
     uint32_t nblk = scan_num_blocks(seg.n);
+    // multi-vector paragraphs: the k best paragraphs are covered by the k * vmax best vectors (each better paragraph
+    // contributes at most vmax of them); they are reduced to one hit per paragraph afterwards
+    const uint32_t k_out = k;
+    if (multi) {
+        if ((uint64_t)k * seg.vmax > 256)
+            return fail(NIDX_ERR_UNSUPPORTED, "result_per_page %u x %u vectors per paragraph exceeds the 256-hit scan", k, seg.vmax);
+        k = k * seg.vmax;
+        NIDX_HIP(scratch_cand_vec.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_cand_score.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_cand_count.reserve((size_t)nq * 4));
+    }
     size_t need = (size_t)nq * nblk * k * 8;
     NIDX_HIP(scratch_partial.reserve(need));
     ScanArgs a;
@@ -445,7 +480,14 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     a.qt = 0;
     a.partial = scratch_partial.as<uint64_t>();
     NIDX_HIP(launch_scan(a, nblk, st));
-    NIDX_HIP(launch_merge_topk(a.partial, nq, nblk, k, d_out_vec, d_out_score, d_out_count, st));
+    if (!multi) {
+        NIDX_HIP(launch_merge_topk(a.partial, nq, nblk, k, d_out_vec, d_out_score, d_out_count, st));
+        return NIDX_OK;
+    }
+    NIDX_HIP(launch_merge_topk(a.partial, nq, nblk, k, scratch_cand_vec.as<uint32_t>(), scratch_cand_score.as<float>(),
+                               scratch_cand_count.as<uint32_t>(), st));
+    NIDX_HIP(launch_para_best(scratch_cand_vec.as<uint32_t>(), scratch_cand_score.as<float>(), scratch_cand_count.as<uint32_t>(), nq, k,
+                              seg.para_of_vec.as<uint32_t>(), k_out, d_out_vec, d_out_score, d_out_count, st));
     return NIDX_OK;
 }
 
@@ -750,8 +792,8 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     if (config->dimension == 0) return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: Vector dimension cannot be 0");
     if (config->similarity != NIDX_SIMILARITY_DOT && config->similarity != NIDX_SIMILARITY_COSINE)
         return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: unknown similarity %d", config->similarity);
-    if (config->vector_cardinality != NIDX_CARDINALITY_SINGLE)
-        return fail(NIDX_ERR_UNSUPPORTED, "multi-vector cardinality is not supported yet");
+    if (config->vector_cardinality != NIDX_CARDINALITY_SINGLE && config->vector_cardinality != NIDX_CARDINALITY_MULTI)
+        return fail(NIDX_ERR_INVALID_CONFIGURATION, "unknown vector cardinality %d", config->vector_cardinality);
     if (config->dimension > 3072) return fail(NIDX_ERR_UNSUPPORTED, "dimension > 3072 is not supported yet");
     std::unique_ptr<VectorIndex> idx(new VectorIndex());
     idx->cfg = *config;

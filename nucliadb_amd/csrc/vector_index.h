@@ -22,6 +22,8 @@ struct VectorSegment {
     DevBuf vectors16;    // [n][dp16] bf16 copy (filled on the first bf16 scan)
     uint32_t dp16 = 0;
     DevBuf para_of_vec;  // [n] u32 (absent when identity)
+    DevBuf para_first, para_num;  // [n_paragraphs] u32: the contiguous vectors of every paragraph (absent when identity)
+    uint32_t vmax = 1;   // most vectors owned by one paragraph (> 1 only with VectorCardinality::Multi)
     DevBuf alive;        // bitset over paragraph addrs (absent when all alive)
     bool identity_para = true, all_alive = true;
     std::vector<uint32_t> para_host;   // empty when identity

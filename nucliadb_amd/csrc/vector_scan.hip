@@ -322,6 +322,70 @@ hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32
     return hipGetLastError();
 }
 
+// ---- multi-vector paragraphs (VectorCardinality::Multi): "only return the best vector match per paragraph"
+//      (segment.rs:582-593).  Input: each query's k_in best VECTORS (score desc, addr asc); output: the k best
+//      paragraphs, each represented by its best vector — on equal scores the LAST one of the paragraph, like
+//      Iterator::max_by — ordered by (score desc, representative addr asc).  One wave per query. ----
+__global__ __launch_bounds__(64) void para_best_kernel(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count,
+                                                       uint32_t k_in, const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec,
+                                                       float *out_score, uint32_t *out_count) {
+    __shared__ uint32_t a_para[256], a_vec[256];
+    __shared__ float a_score[256];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t cnt = in_count[q];
+    int na = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t v = in_vec[(size_t)q * k_in + i];
+        const float s = in_score[(size_t)q * k_in + i];
+        const uint32_t p = para_of_vec[v];
+        int found = -1;
+        for (int base = 0; base < na; base += 64) {
+            const int j = base + lane;
+            const unsigned long long m = __ballot(j < na && a_para[j] == p);
+            if (m) {
+                found = base + __ffsll((long long)m) - 1;
+                break;
+            }
+        }
+        if (found >= 0) {
+            // a later vector of an accepted paragraph: it replaces the representative only on an exactly equal score
+            if (lane == 0 && __builtin_bit_cast(uint32_t, a_score[found]) == __builtin_bit_cast(uint32_t, s)) a_vec[found] = v;
+        } else if (na < (int)k) {
+            if (lane == 0) {
+                a_para[na] = p;
+                a_vec[na] = v;
+                a_score[na] = s;
+            }
+            na++;
+        }
+    }
+    // order by (score desc, representative addr asc): rank of every entry among the na accepted
+    for (int base = 0; base < (int)k; base += 64) {
+        const int e = base + lane;
+        if (e < na) {
+            const uint64_t key = rank_key(a_score[e], a_vec[e]);
+            int rank = 0;
+            for (int j = 0; j < na; j++) rank += rank_key(a_score[j], a_vec[j]) > key ? 1 : 0;
+            out_vec[(size_t)q * k + rank] = a_vec[e];
+            out_score[(size_t)q * k + rank] = a_score[e];
+        } else if (e < (int)k) {
+            out_vec[(size_t)q * k + e] = 0xffffffffu;
+            out_score[(size_t)q * k + e] = 0.f;
+        }
+    }
+    if (lane == 0) out_count[q] = (uint32_t)na;
+}
+
+hipError_t launch_para_best(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count, uint32_t n_queries, uint32_t k_in,
+                            const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec, float *out_score, uint32_t *out_count,
+                            hipStream_t s) {
+    if (n_queries == 0) return hipSuccess;
+    hipLaunchKernelGGL(para_best_kernel, dim3(n_queries), dim3(64), 0, s, in_vec, in_score, in_count, k_in, para_of_vec, k, out_vec, out_score,
+                       out_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_norms(const float *vectors, uint32_t n, uint32_t dp, float *norm2, hipStream_t s) {
     uint32_t blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;
