@@ -344,6 +344,9 @@ typedef struct {
     const uint32_t *term_set_terms;              /* term ids of every set, concatenated */
     const uint64_t *term_set_offsets;            /* [n_term_sets + 1] */
     uint32_t n_term_sets;
+    /* NULL or [n_term_sets]: != 0 = the clause matches every document OUTSIDE the union — parse_excluded's
+     * BooleanQuery[Must AllQuery, MustNot term] (nidx_paragraph/src/query_parser/keyword_parser.rs:93-105) */
+    const uint8_t *term_set_complement;
     /* TopDocs::order_by_fast_field (nidx_text/src/reader.rs:210-224, custom_order_collector): -1 = by score,
      * else the fast field registered with nidx_gpu_bm25_set_fast_field (0 = created, 1 = modified) */
     int32_t order_field;

@@ -77,6 +77,7 @@ class Bm25SearchOptionsC(C.Structure):
         ("term_set_terms", C.c_void_p),
         ("term_set_offsets", C.c_void_p),
         ("n_term_sets", C.c_uint32),
+        ("term_set_complement", C.c_void_p),
         ("order_field", C.c_int32),
         ("order_desc", C.c_int32),
         ("facet_terms", C.c_void_p),

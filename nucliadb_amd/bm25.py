@@ -29,6 +29,8 @@ class Clause:
     # FuzzyTermQuery (fuzzy_query.rs:55-125): the clause is the UNION of these terms' documents, each scored
     # ConstScorer(boost) once; `term` and `mode` are ignored
     term_set: Optional[Sequence[int]] = None
+    # parse_excluded (keyword_parser.rs:93-105): every document OUTSIDE the union, AllQuery's 1.0 * boost
+    complement: bool = False
 
 
 @dataclass
@@ -165,6 +167,7 @@ class Bm25Searcher:
         cl = (_lib.Bm25ClauseC * max(1, len(flat)))()
         set_terms: List[int] = []
         set_offsets = [0]
+        set_comp: List[int] = []
         for i, c in enumerate(flat):
             cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
             if c.term_set is not None:
@@ -172,6 +175,7 @@ class Bm25Searcher:
                 cl[i].mode = _lib.CONST_SCORE
                 set_terms.extend(int(t) for t in c.term_set)
                 set_offsets.append(len(set_terms))
+                set_comp.append(int(c.complement))
         af = None
         if after is not None:
             af = (_lib.Bm25SearchAfterC * max(1, B))()
@@ -193,6 +197,8 @@ class Bm25Searcher:
         opt.term_set_terms = st.ctypes.data if st.size else None
         opt.term_set_offsets = so.ctypes.data
         opt.n_term_sets = len(set_offsets) - 1
+        sc = np.ascontiguousarray(set_comp, dtype=np.uint8)
+        opt.term_set_complement = sc.ctypes.data if sc.size else None
         opt.order_field, opt.order_desc = order_field, int(order_desc)
         fo = ft = fc = None
         if facets is not None:

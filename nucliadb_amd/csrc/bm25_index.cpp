@@ -360,7 +360,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                 uint64_t df = 0;
                 for (uint64_t i = opt->term_set_offsets[j]; i < opt->term_set_offsets[j + 1]; i++)
                     df += seg.term_offsets_host[opt->term_set_terms[i] + 1] - seg.term_offsets_host[opt->term_set_terms[i]];
-                out_off[j + 1] = out_off[j] + std::min<uint64_t>(df, seg.n_docs);
+                const bool comp = opt->term_set_complement && opt->term_set_complement[j];
+                out_off[j + 1] = out_off[j] + (comp ? (uint64_t)seg.n_docs : std::min<uint64_t>(df, seg.n_docs));
             }
             NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
             NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_sets + 1) * 8));
@@ -375,6 +376,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                         NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
                                                        idx->s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
                                                        idx->s_set_bits.as<uint64_t>() + (size_t)j * words, idx->stream));
+                    if (opt->term_set_complement && opt->term_set_complement[j])
+                        NIDX_HIP(launch_bitset_not(idx->s_set_bits.as<uint64_t>() + (size_t)j * words, words, seg.n_docs, idx->stream));
                 }
                 NIDX_HIP(launch_bitset_compact(idx->s_set_bits.as<uint64_t>(), words, n_sets, idx->s_aux_out_off.as<unsigned long long>(),
                                                idx->s_aux_ids.as<uint32_t>(), idx->s_set_counts.as<uint32_t>(), idx->stream));

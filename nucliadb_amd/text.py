@@ -19,9 +19,9 @@ Must clauses `repeated_in_field:0` (unless with_duplicates) and label filters; t
 (reader.rs:128-133, fuzzy_parser.rs:35-93, search_query.rs:200-240): every literal of >= 3 characters becomes
 a FuzzyTermQuery (Levenshtein 1, the last literal as a prefix when >= 4 characters) expanded against the term
 dictionary on the device and scored ConstScorer(0.5).  Both searchers collect FACETS (FacetCollector, top 50
-children per requested facet) and can ORDER by the created / modified fast fields.  Multi-word quoted phrases
-(positions) and `-excluded` terms (a Should of "everything but") are not posting-list clauses and raise
-NotImplementedError.
+children per requested facet) and can ORDER by the created / modified fast fields.  `-excluded` words are
+Should(everything but the word): the complement of the posting list, built on the device.  Multi-word quoted
+phrases need positions (PhraseQuery) and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -416,8 +416,6 @@ class ParagraphSearcher:
     def _tokens(self, request: ParagraphSearchRequest) -> List[Tuple[str, str]]:
         tokens = parse_query(request.body, self.stop_words)
         for kind, text in tokens:
-            if kind == "excluded":
-                raise NotImplementedError("-excluded terms are a Should of (everything but the term): not a posting-list clause")
             if kind == "quoted" and " " in text:
                 raise NotImplementedError("multi-word quoted phrases need positions (PhraseQuery)")
         return tokens
@@ -430,8 +428,14 @@ class ParagraphSearcher:
             clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
         # TermQuery(text, IndexRecordOption::Basic) per literal / one-word quote, Occur::Should, as a required group: the
         # keyword BooleanQuery sits under Occur::Must next to the filters, so a paragraph has to match one of its words
-        should = [Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0) for _, w in tokens]
+        should = [self._excluded(w, 1.0) if kind == "excluded" else Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0)
+                  for kind, w in tokens]
         return clauses + should + self._filters(request, 1.0)
+
+    def _excluded(self, word: str, boost: float) -> Clause:
+        """parse_excluded (keyword_parser.rs:93-105): Should(BooleanQuery[Must AllQuery, MustNot term]) = every paragraph
+        that does not contain the word, scored AllQuery's 1.0: the complement of the term's posting list, on the device."""
+        return Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.CONST_SCORE, boost, term_set=[self._index.term(word)], complement=True)
 
     def _fuzzy_clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
         """The fuzzy query (fuzzy_parser.rs:52-123 under search_query.rs:200-240)."""
@@ -443,6 +447,9 @@ class ParagraphSearcher:
         if not tokens:
             clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
         for i, (kind, w) in enumerate(tokens):
+            if kind == "excluded":
+                clauses.append(self._excluded(w, boost))
+                continue
             if kind == "quoted" or len(w.encode("utf-8")) < MIN_FUZZY_LEN:  # too short to be fuzzy: the exact term
                 clauses.append(Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, boost))
                 continue

@@ -1283,6 +1283,22 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
         if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
+        if (is_set && cl->set_complement) {
+            /* every document outside the union, once */
+            for (size_t t = 0; t < n_lists; t++) {
+                uint64_t b = idx->term_offsets[cl->set_terms[t]], e = idx->term_offsets[cl->set_terms[t] + 1];
+                for (uint64_t i = b; i < e; i++) last_clause[idx->doc_ids[i]] = (uint32_t)c + 1;
+            }
+            for (uint32_t d = 0; d < n; d++) {
+                if (last_clause[d] == (uint32_t)c + 1) continue;
+                if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
+                acc[d] = acc[d] + cl->boost;
+                if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
+                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else should_hit[d] = 1;
+            }
+            continue;
+        }
         for (size_t t = 0; t < n_lists; t++) {
             uint32_t term = is_set ? cl->set_terms[t] : cl->term;
             uint64_t b = idx->term_offsets[term], e = idx->term_offsets[term + 1];

@@ -192,6 +192,9 @@ typedef struct {
      * `term` and `mode` are ignored */
     const uint32_t *set_terms;
     uint32_t n_set_terms;
+    /* set_complement != 0: the clause matches every document NOT in the union — parse_excluded's
+     * BooleanQuery[Must AllQuery, MustNot term] (query_parser/keyword_parser.rs:93-105), scored AllQuery's 1.0 * boost */
+    int set_complement;
 } orc_bm25_clause;
 
 typedef struct {

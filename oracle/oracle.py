@@ -77,7 +77,7 @@ class _Bm25Index(C.Structure):
 
 class _Bm25Clause(C.Structure):
     _fields_ = [("term", C.c_uint32), ("occur", C.c_int), ("mode", C.c_int), ("boost", C.c_float),
-                ("set_terms", C.c_void_p), ("n_set_terms", C.c_uint32)]
+                ("set_terms", C.c_void_p), ("n_set_terms", C.c_uint32), ("set_complement", C.c_int)]
 
 
 class _SearchAfter(C.Structure):
@@ -575,6 +575,7 @@ class Bm25Index:
                 ts = np.ascontiguousarray(c[4], dtype=np.uint32)
                 keep.append(ts)
                 cl[i].set_terms, cl[i].n_set_terms = ts.ctypes.data, ts.size
+                cl[i].set_complement = int(len(c) > 5 and bool(c[5]))
                 if ts.size == 0:  # an empty expansion matches nothing: an always-empty list stands for it
                     raise ValueError("empty term set: map it to an empty term")
         return cl, keep

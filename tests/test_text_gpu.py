@@ -222,3 +222,36 @@ def test_faceted_search_and_order_by():
         r = s.search(req_cls(body="", result_per_page=3, order=OrderBy(1, desc=True), **kw))
         assert [x.uuid for x in r.results] == ["r0", "r1", "r2"] and r.next_page
         s.close()
+
+
+def test_excluded_words(orc):
+    """parse_excluded (keyword_parser.rs:93-105): `-word` is a Should of (everything but the word): alone it returns every
+    paragraph without it; next to literals it adds 1.0 to those paragraphs' scores."""
+    from nucliadb_amd.bm25 import Bm25Segment
+
+    vocab = Vocabulary()
+    s = ParagraphSearcher.open([TextSegment(docs(), vocab)])
+    r = s.search(ParagraphSearchRequest(body="-enough", result_per_page=20, with_duplicates=True))
+    assert sorted(x.uuid for x in r.results) == ["r0", "r4"] and r.total == 2
+    assert all(x.score.bm25 == 1.0 for x in r.results)
+    r = s.search(ParagraphSearchRequest(body="test -enough", result_per_page=20, with_duplicates=True))
+    got = {x.uuid: x.score.bm25 for x in r.results}
+    assert set(got) == {"r0", "r2", "r3", "r4"}          # has "test", or lacks "enough"
+    assert got["r0"] > got["r2"] and got["r4"] == 1.0    # r0: BM25(test) + 1.0; r4: only the exclusion clause
+    s.close()
+    # kernel vs oracle on a complemented term set
+    rng = np.random.default_rng(4)
+    seg = Bm25Segment.from_term_docs([rng.integers(0, 50, int(rng.integers(3, 20))) for _ in range(3000)], 50)
+    from nucliadb_amd.bm25 import Bm25Searcher
+
+    bs = Bm25Searcher.open([seg])
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive)
+    qs = [[Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.CONST_SCORE, 1.0, term_set=[int(t)], complement=True),
+           Clause(int(u), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0)] for t, u in rng.integers(0, 50, (12, 2))]
+    r = bs.search_batch_ex(qs, 25)
+    for i, q in enumerate(qs):
+        wd, ws, _, wt, _ = oidx.search_ex([(c.term, c.occur, c.mode, c.boost, None if c.term_set is None else list(c.term_set), c.complement) for c in q], 25)
+        n = int(r["count"][i])
+        assert r["total"][i] == wt and n == len(wd)
+        assert np.array_equal(r["docaddr"][i, :n], wd) and np.array_equal(r["score"][i, :n].view(np.uint32), ws.view(np.uint32))
+    bs.close()
