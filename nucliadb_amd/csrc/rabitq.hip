@@ -426,6 +426,8 @@ struct RqShared {
 
 // a sorted list of `cap` keys: cap + 1 slots, readable in whole 64-key chunks
 __host__ __device__ inline size_t rq_list_bytes(uint32_t cap) { return (size_t)(((cap + 1 + 63) / 64) * 64) * 8; }
+// physical 64-key chunks of a two-level list of `cap` keys: every chunk but the last holds >= 32 keys
+__host__ __device__ inline uint32_t rq_chunks(uint32_t cap) { return cap / 32u + 2u < 64u ? cap / 32u + 2u : 64u; }
 
 __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
     RqShared s;
@@ -435,7 +437,7 @@ __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t d
     s.best = reinterpret_cast<uint64_t *>(smem + off);
     off += rq_list_bytes(k);
     s.res = reinterpret_cast<uint64_t *>(smem + off);
-    off += rq_list_bytes(ef);
+    off += (size_t)rq_chunks(ef) * 512;
     s.ties = reinterpret_cast<uint64_t *>(smem + off);
     off += (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
@@ -445,7 +447,7 @@ __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t d
     return s;
 }
 static size_t rq_smem_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool hnsw) {
-    size_t off = (size_t)4 * nw * 8 + rq_list_bytes(k) + rq_list_bytes(ef) + (size_t)RABITQ_TIE_CAP * 8;
+    size_t off = (size_t)4 * nw * 8 + rq_list_bytes(k) + (size_t)rq_chunks(ef) * 512 + (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
     off += (size_t)dp * 4;
     if (hnsw) off += (size_t)4 << RABITQ_UPPER_VIS_LOG2;
@@ -523,20 +525,127 @@ __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
 // evicted from it whose score still EQUALS the worst result's (`cs < ws` does not stop on those) — kept
 // in `ties`.  An entry evicted with a lower score than ws can only ever terminate the search when it is
 // popped, and by then nothing better is left, so it is dropped on the spot.
+// The result set is a two-level sorted list: 64-key chunks in LDS (each sorted, best first) and a directory held
+// one entry per lane in registers — lane d: the first key of the d-th chunk, its physical slot and fill.  An
+// admission touches ONE chunk: a ballot over the directory finds it, the chunk is read, split at the key's
+// position and written back; a full chunk is first halved into a free slot.  Evictions only ever shorten the last
+// chunk, so every other chunk holds >= 32 keys and the directory never needs more than cap / 32 + 2 <= 64 lanes.
 struct RqLayer {
     uint64_t *res, *ties;
-    uint64_t worst;        // res[len - 1]
-    int len, n_ties, cur;  // cur: every entry before it is expanded
+    uint64_t dir_first;      // lane d: first (best) key of chunk d
+    uint32_t dir_meta;       // lane d: physical slot | fill << 8
+    uint64_t free_mask;      // physical slots not in use
+    uint64_t worst;          // the last key of the last chunk
+    int n_dir, len, n_ties;
+    int dcur;                // every chunk before it holds expanded keys only
+
+    __device__ inline void init(int n_phys) {
+        dir_first = 0;
+        dir_meta = 0;
+        free_mask = n_phys >= 64 ? ~0ull : ((1ull << n_phys) - 1ull);
+        worst = 0;
+        n_dir = 0;
+        len = 0;
+        n_ties = 0;
+        dcur = 0;
+    }
+    __device__ inline uint64_t *chunk(uint32_t phys) const { return res + (size_t)phys * 64; }
 };
 
+// chunk d is full: its upper half moves to a free physical slot which becomes chunk d + 1
+__device__ inline void rq_split(RqLayer &L, int d, int lane) {
+    const uint32_t meta = lane_u32(L.dir_meta, d);
+    const uint32_t p = meta & 0xffu;
+    const int q = __ffsll((long long)L.free_mask) - 1;
+    L.free_mask &= ~(1ull << q);
+    const uint64_t row = L.chunk(p)[lane];
+    if (lane >= 32) L.chunk((uint32_t)q)[lane - 32] = row;
+    const uint64_t up_first = shfl_up_u64(L.dir_first, 1);
+    const uint32_t up_meta = (uint32_t)__shfl_up((int)L.dir_meta, 1, 64);
+    if (lane > d + 1) {
+        L.dir_first = up_first;
+        L.dir_meta = up_meta;
+    }
+    const uint64_t mid = lane_u64(row, 32);
+    if (lane == d + 1) {
+        L.dir_first = mid;
+        L.dir_meta = (uint32_t)q | (32u << 8);
+    }
+    if (lane == d) L.dir_meta = p | (32u << 8);
+    L.n_dir++;
+    if (L.dcur > d) L.dcur++;
+}
+
 __device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, int lane, uint32_t &flags) {
-    int pos;
     L.worst = uni64(L.worst);
-    L.cur = uni(L.cur);
+    L.free_mask = uni64(L.free_mask);
+    L.n_dir = uni(L.n_dir);
+    L.len = uni(L.len);
     L.n_ties = uni(L.n_ties);
-    const uint64_t ev = sorted_insert(L.res, L.len, kk, rq_key(est, addr, 1u), lane, pos, L.worst);
-    if (pos < L.cur) L.cur = pos;
-    if (ev != 0 && (ev & 1ull)) {
+    L.dcur = uni(L.dcur);
+    const uint64_t nk = rq_key(est, addr, 1u);
+    if (L.n_dir == 0) {  // first key of the layer
+        const int q = __ffsll((long long)L.free_mask) - 1;
+        L.free_mask &= ~(1ull << q);
+        if (lane == 0) {
+            L.chunk((uint32_t)q)[0] = nk;
+            L.dir_first = nk;
+            L.dir_meta = (uint32_t)q | (1u << 8);
+        }
+        L.n_dir = 1;
+        L.len = 1;
+        L.worst = nk;
+        L.dcur = 0;
+        return;
+    }
+    int d = __popcll(__ballot(lane < L.n_dir && L.dir_first > nk));
+    d = d > 0 ? d - 1 : 0;
+    if ((lane_u32(L.dir_meta, d) >> 8) == 64u) {
+        rq_split(L, d, lane);
+        if (lane_u64(L.dir_first, d + 1) > nk) d++;
+    }
+    const uint32_t meta = lane_u32(L.dir_meta, d);
+    const uint32_t phys = meta & 0xffu;
+    const int cnt = (int)(meta >> 8);
+    const int dl = L.n_dir - 1;
+    const uint32_t meta_l = lane_u32(L.dir_meta, dl);
+    // the landing chunk and the last chunk are read together (one LDS round trip)
+    const uint64_t row = L.chunk(phys)[lane];
+    const uint64_t tail = L.chunk(meta_l & 0xffu)[lane];
+    const bool valid = lane < cnt;
+    const int pos = __popcll(__ballot(valid && row > nk));
+    if (valid && lane >= pos) L.chunk(phys)[lane + 1] = row;
+    if (lane == 0) L.chunk(phys)[pos] = nk;
+    if (lane == d) {
+        L.dir_meta = phys | ((uint32_t)(cnt + 1) << 8);
+        if (pos == 0) L.dir_first = nk;
+    }
+    if (d < L.dcur) L.dcur = d;
+    const bool at_end = d == dl && pos == cnt;  // nk is the new last key of the list
+    if (L.len < kk) {
+        L.len++;
+        if (at_end) L.worst = nk;
+        return;
+    }
+    // full: the last key of the last chunk leaves (nk ranks before it, so it is never nk)
+    const uint64_t ev = L.worst;
+    const int cnt_l = (int)(meta_l >> 8) + (d == dl ? 1 : 0);  // fill of the last chunk after the insert
+    if (cnt_l >= 2) {
+        uint64_t nw;
+        if (d == dl) nw = pos == cnt - 1 ? nk : lane_u64(row, cnt - 2);  // arrangement after the insert, minus its last key
+        else nw = lane_u64(tail, cnt_l - 2);
+        L.worst = nw;
+        if (lane == dl) L.dir_meta = (meta_l & 0xffu) | ((uint32_t)(cnt_l - 1) << 8);
+    } else {
+        // the last chunk held only the evicted key: free it, the previous chunk's last key is the new worst
+        L.free_mask |= 1ull << (meta_l & 0xffu);
+        L.n_dir--;
+        const uint32_t meta_p = lane_u32(L.dir_meta, dl - 1);
+        const int cnt_p = (int)(meta_p >> 8) + (d == dl - 1 ? 0 : 0);
+        L.worst = L.chunk(meta_p & 0xffu)[cnt_p - 1];
+        if (L.dcur > L.n_dir) L.dcur = L.n_dir;
+    }
+    if (ev & 1ull) {
         // the evicted entry is still a candidate only while its score is not below the worst result's
         const float ws = rank_key_score(L.worst);
         if (!(rank_key_score(ev) < ws)) {
@@ -559,28 +668,26 @@ __device__ inline uint32_t load_edge_raw(const GraphDev &g, uint32_t node, int l
 }
 
 // pops the best candidate; returns false when the search is over.  `next` = the runner-up when it sits in
-// the same 64-key window (0xffffffff otherwise): its edge record is prefetched by the caller.
+// the same chunk (0xffffffff otherwise): its edge record is prefetched by the caller.
 __device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node, uint32_t &next) {
     next = 0xffffffffu;
-    L.cur = uni(L.cur);
-    L.len = uni(L.len);
-    while (L.cur < L.len) {
-        const int i = L.cur + lane;
-        const uint64_t mine = i < L.len ? L.res[i] : 0ull;
+    L.dcur = uni(L.dcur);
+    L.n_dir = uni(L.n_dir);
+    while (L.dcur < L.n_dir) {
+        const uint32_t meta = lane_u32(L.dir_meta, L.dcur);
+        const uint64_t mine = lane < (int)(meta >> 8) ? L.chunk(meta & 0xffu)[lane] : 0ull;
         unsigned long long m = __ballot((mine & 1ull) != 0);
         if (m) {
             const int j = __ffsll((long long)m) - 1;
             const uint64_t key = lane_u64(mine, j);
-            if (lane == j) L.res[i] = mine & ~1ull;
+            if (lane == j) L.chunk(meta & 0xffu)[lane] = mine & ~1ull;
             m &= m - 1;
             if (m) next = rq_addr(lane_u64(mine, __ffsll((long long)m) - 1));
-            L.cur += j + 1;
             node = rq_addr(key);
             return true;  // a member of the result set never scores below its worst entry
         }
-        L.cur += 64;
+        L.dcur++;
     }
-    if (L.cur > L.len) L.cur = L.len;
     if (L.n_ties == 0) return false;
     // best of the evicted ties
     uint64_t b = lane < L.n_ties ? L.ties[lane] : 0ull;
@@ -616,10 +723,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     L.ties = sh.ties;
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const int kk = layer == 0 ? (int)a.ef : 1;
-        L.len = 0;
-        L.worst = 0;
-        L.n_ties = 0;
-        L.cur = 0;
+        L.init((int)rq_chunks((uint32_t)kk));
         uint32_t vis_count = 0;
         if (layer > 0) {
             for (uint32_t i = lane; i < (1u << RABITQ_UPPER_VIS_LOG2); i += 64) sh.vis[i] = NIDX_VIS_EMPTY;
@@ -691,20 +795,20 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
             }
             cyc_ins += clock64() - t3;
         }
-        ep = rq_addr(L.res[0]);  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
+        ep = rq_addr(lane_u64(L.dir_first, 0));  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
     }
 
     // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
     const uint64_t t_rr = clock64();
     Reranker rr;
     rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
-    for (int base = 0; base < L.len; base += 64) {
-        const int i = base + lane;
-        const bool ok = i < L.len;
+    for (int dch = 0; dch < uni(L.n_dir); dch++) {  // the chunks in rank order = the neighbours best first
+        const uint32_t meta = lane_u32(L.dir_meta, dch);
+        const bool ok = lane < (int)(meta >> 8);
         uint32_t addr = 0;
         float ub = 0.f;
         if (ok) {
-            const uint64_t key = L.res[i];
+            const uint64_t key = L.chunk(meta & 0xffu)[lane];
             addr = rq_addr(key);
             ub = rank_key_score(key) + rabitq_error(a.quant + (size_t)addr * a.rec_len, qc);
         }
