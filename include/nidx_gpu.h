@@ -200,6 +200,18 @@ typedef struct {
     uint32_t n_lists;
 } nidx_gpu_filter_program_t;
 
+/* Searcher::search_multi_vector (searcher.rs:345-394) for VectorCardinality::Multi indexes: query q is the
+ * query_vec_offsets[q+1] - query_vec_offsets[q] vectors starting at queries[query_vec_offsets[q] * dimension].  Every
+ * query vector is searched on its own (max(k, 10) hits, duplicates kept, no min_score), the paragraphs found are
+ * scored with maxsim_similarity (multivector.rs:33-46: sum over the query vectors of the best similarity among the
+ * paragraph's vectors), those with score > min_score are ranked (score desc; ties by segment, paragraph) and cut to
+ * k.  Paragraphs are de-duplicated by their address alone, like the reference (searcher.rs:375-377).
+ * out_segment / out_paragraph / out_score: [n_queries][k]. */
+int32_t nidx_gpu_vector_search_maxsim(nidx_gpu_vector_index_t *index, const float *queries, const uint64_t *query_vec_offsets,
+                                      uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
+                                      const uint64_t *const *segment_filters, uint32_t *out_segment, uint32_t *out_paragraph,
+                                      float *out_score, uint32_t *out_count);
+
 /* nidx_gpu_vector_search_dim with the filter of every segment given as a program (segment_programs:
  * NULL or [n_segments]).  out_matching: NULL or [n_segments] = |filter ∩ alive| per segment. */
 int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,

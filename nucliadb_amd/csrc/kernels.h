@@ -26,6 +26,9 @@ uint32_t scan_num_blocks(uint32_t n);
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s);
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s);
+hipError_t launch_maxsim(const float *vectors, const float *norm2, uint32_t dp, int similarity, const float *queries,
+                         const uint32_t *cand_qfirst, const uint32_t *cand_qnum, const uint32_t *cand_first, const uint32_t *cand_num,
+                         uint32_t n_cand, float *out, hipStream_t s);
 hipError_t launch_para_best(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count, uint32_t n_queries, uint32_t k_in,
                             const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec, float *out_score, uint32_t *out_count,
                             hipStream_t s);

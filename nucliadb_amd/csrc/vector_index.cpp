@@ -929,6 +929,104 @@ int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_
     return NIDX_OK;
 }
 
+int32_t nidx_gpu_vector_search_maxsim(nidx_gpu_vector_index_t *index, const float *queries, const uint64_t *qoff, uint32_t nq,
+                                      const nidx_gpu_vector_search_params_t *params, const uint64_t *const *segment_filters,
+                                      uint32_t *out_segment, uint32_t *out_paragraph, float *out_score, uint32_t *out_count) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !params || !out_count || !qoff || (nq && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    const uint32_t k = params->k, d = idx->cfg.dimension;
+    for (uint32_t q = 0; q < nq; q++) out_count[q] = 0;
+    if (nq == 0 || k == 0) return NIDX_OK;
+    const uint64_t T = qoff[nq];
+    if (T == 0) return NIDX_OK;
+    // first pass: every query vector on its own (searcher.rs:352-372)
+    nidx_gpu_vector_search_params_t p1 = *params;
+    p1.k = std::max<uint32_t>(k, 10);
+    p1.min_score = -3.40282347e38f;  // f32::MIN
+    p1.with_duplicates = 1;
+    const uint32_t k1 = p1.k;
+    std::vector<uint32_t> s1((size_t)T * k1), pa1((size_t)T * k1), c1(T);
+    int32_t rc = idx->search_host(queries, (uint32_t)T, p1, segment_filters, nullptr, s1.data(), pa1.data(), nullptr, nullptr, c1.data(),
+                                  nullptr, nullptr);
+    if (rc != NIDX_OK) return rc;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    // candidates: the paragraphs found by any of the query's vectors, once per ADDRESS (searcher.rs:375-377)
+    struct Cand { uint32_t q, seg, para; };
+    std::vector<Cand> cands;
+    for (uint32_t q = 0; q < nq; q++) {
+        std::vector<std::pair<uint32_t, uint32_t>> found;  // (paragraph address, segment)
+        for (uint64_t t = qoff[q]; t < qoff[q + 1]; t++)
+            for (uint32_t i = 0; i < c1[t]; i++) found.emplace_back(pa1[t * k1 + i], s1[t * k1 + i]);
+        std::sort(found.begin(), found.end());
+        for (size_t i = 0; i < found.size(); i++)
+            if (i == 0 || found[i].first != found[i - 1].first) cands.push_back(Cand{q, found[i].second, found[i].first});
+    }
+    // raw query vectors on the device (maxsim uses the vectors as given, searcher.rs:346-350,384)
+    const uint32_t dp = (d + 3u) & ~3u;
+    std::vector<float> qpad((size_t)T * dp, 0.f);
+    for (uint64_t t = 0; t < T; t++) memcpy(&qpad[t * dp], queries + t * d, (size_t)d * 4);
+    NIDX_HIP(idx->scratch_queries.reserve(qpad.size() * 4));
+    NIDX_HIP(hipMemcpyAsync(idx->scratch_queries.p, qpad.data(), qpad.size() * 4, hipMemcpyHostToDevice, idx->stream));
+    std::vector<float> score(cands.size(), 0.f);
+    for (size_t sgi = 0; sgi < idx->segs.size(); sgi++) {
+        VectorSegment &seg = idx->segs[sgi];
+        std::vector<uint32_t> meta;  // qfirst, qnum, first, num per candidate of this segment
+        std::vector<size_t> where;
+        std::vector<uint32_t> first, num;
+        if (!seg.identity_para) {
+            first.assign(seg.n_paragraphs, 0);
+            num.assign(seg.n_paragraphs, 0);
+            for (uint32_t v = 0; v < seg.n; v++) {
+                if (num[seg.para_host[v]] == 0) first[seg.para_host[v]] = v;
+                num[seg.para_host[v]]++;
+            }
+        }
+        for (size_t i = 0; i < cands.size(); i++)
+            if (cands[i].seg == sgi) where.push_back(i);
+        if (where.empty()) continue;
+        const size_t n = where.size();
+        meta.resize(4 * n);
+        for (size_t j = 0; j < n; j++) {
+            const Cand &c = cands[where[j]];
+            meta[j] = (uint32_t)qoff[c.q];
+            meta[n + j] = (uint32_t)(qoff[c.q + 1] - qoff[c.q]);
+            meta[2 * n + j] = seg.identity_para ? c.para : first[c.para];
+            meta[3 * n + j] = seg.identity_para ? 1u : num[c.para];
+        }
+        NIDX_HIP(idx->scratch_cand_vec.reserve(meta.size() * 4));
+        NIDX_HIP(idx->scratch_cand_score.reserve(n * 4));
+        NIDX_HIP(hipMemcpyAsync(idx->scratch_cand_vec.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, idx->stream));
+        const uint32_t *dm = idx->scratch_cand_vec.as<uint32_t>();
+        NIDX_HIP(launch_maxsim(seg.vectors.as<float>(), seg.norm2.as<float>(), seg.dp, idx->cfg.similarity, idx->scratch_queries.as<float>(), dm,
+                               dm + n, dm + 2 * n, dm + 3 * n, (uint32_t)n, idx->scratch_cand_score.as<float>(), idx->stream));
+        std::vector<float> sc(n);
+        NIDX_HIP(hipMemcpyAsync(sc.data(), idx->scratch_cand_score.p, n * 4, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipStreamSynchronize(idx->stream));
+        for (size_t j = 0; j < n; j++) score[where[j]] = sc[j];
+    }
+    // `sp.score() > min_score`, sort by score desc, truncate (searcher.rs:381-391)
+    size_t i = 0;
+    for (uint32_t q = 0; q < nq; q++) {
+        std::vector<size_t> mine;
+        for (; i < cands.size() && cands[i].q == q; i++)
+            if (score[i] > params->min_score) mine.push_back(i);
+        std::sort(mine.begin(), mine.end(), [&](size_t a, size_t b) {
+            if (score[a] != score[b]) return score[a] > score[b];
+            if (cands[a].seg != cands[b].seg) return cands[a].seg < cands[b].seg;
+            return cands[a].para < cands[b].para;
+        });
+        const uint32_t n = (uint32_t)std::min<size_t>(mine.size(), k);
+        out_count[q] = n;
+        for (uint32_t j = 0; j < n; j++) {
+            if (out_segment) out_segment[(size_t)q * k + j] = cands[mine[j]].seg;
+            if (out_paragraph) out_paragraph[(size_t)q * k + j] = cands[mine[j]].para;
+            if (out_score) out_score[(size_t)q * k + j] = score[mine[j]];
+        }
+    }
+    return NIDX_OK;
+}
+
 int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
                                         uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
                                         const nidx_gpu_filter_program_t *segment_programs, uint32_t *out_segment,

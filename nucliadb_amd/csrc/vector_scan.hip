@@ -377,6 +377,51 @@ __global__ __launch_bounds__(64) void para_best_kernel(const uint32_t *in_vec, c
     if (lane == 0) out_count[q] = (uint32_t)na;
 }
 
+// ---- maxsim_similarity (nidx_vector/src/multivector.rs:33-46): score of one paragraph for one multi-vector query =
+//      sum over the query's vectors of the best similarity among the paragraph's vectors (0.0 when none is positive).
+//      One wave per (query, paragraph) candidate; every similarity in the WAVE64 order. ----
+__global__ __launch_bounds__(64) void maxsim_kernel(const float *vectors, const float *norm2, uint32_t dp, int similarity,
+                                                    const float *queries, const uint32_t *cand_qfirst, const uint32_t *cand_qnum,
+                                                    const uint32_t *cand_first, const uint32_t *cand_num, float *out) {
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    const uint32_t q0 = cand_qfirst[c], qn = cand_qnum[c], v0 = cand_first[c], vn = cand_num[c];
+    const int nj = (int)((dp + 255u) / 256u);
+    float summaxsim = 0.0f;
+    for (uint32_t qi = 0; qi < qn; qi++) {
+        const float *qrow = queries + (size_t)(q0 + qi) * dp;
+        float qq = 0.f;
+        if (similarity == 1) {
+            float acc = 0.f;
+            for (int j = 0; j < nj; j++) {
+                const float4 qv = load_row_chunk(qrow, dp, j, lane);
+                acc = fma4(qv, qv, acc);
+            }
+            qq = wave_butterfly_sum(acc);
+        }
+        float maxsim = 0.0f;
+        for (uint32_t vi = 0; vi < vn; vi++) {
+            const float *row = vectors + (size_t)(v0 + vi) * dp;
+            float acc = 0.f;
+            for (int j = 0; j < nj; j++) acc = fma4(load_row_chunk(row, dp, j, lane), load_row_chunk(qrow, dp, j, lane), acc);
+            const float ab = wave_butterfly_sum(acc);
+            const float sim = similarity == 1 ? cosine_from_sums(ab, norm2[v0 + vi], qq) : ab;
+            if (sim > maxsim) maxsim = sim;
+        }
+        summaxsim = summaxsim + maxsim;
+    }
+    if (lane == 0) out[c] = summaxsim;
+}
+
+hipError_t launch_maxsim(const float *vectors, const float *norm2, uint32_t dp, int similarity, const float *queries,
+                         const uint32_t *cand_qfirst, const uint32_t *cand_qnum, const uint32_t *cand_first, const uint32_t *cand_num,
+                         uint32_t n_cand, float *out, hipStream_t s) {
+    if (n_cand == 0) return hipSuccess;
+    hipLaunchKernelGGL(maxsim_kernel, dim3(n_cand), dim3(64), 0, s, vectors, norm2, dp, similarity, queries, cand_qfirst, cand_qnum, cand_first,
+                       cand_num, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_para_best(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count, uint32_t n_queries, uint32_t k_in,
                             const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec, float *out_score, uint32_t *out_count,
                             hipStream_t s) {

@@ -175,7 +175,9 @@ class VectorSegment:
 
     def __init__(self, keys: List[str], vectors: np.ndarray, labels: List[List[str]], metadata: List[bytes],
                  tags: Optional[set] = None, graph: Optional[bytes] = None, graph_edges: Optional[np.ndarray] = None,
-                 graph_nodes: int = 0, quantized: Optional[np.ndarray] = None):
+                 graph_nodes: int = 0, quantized: Optional[np.ndarray] = None, para_of_vec: Optional[np.ndarray] = None):
+        # VectorCardinality::Multi: paragraph (= key index) of every vector row, non-decreasing; None = one vector per key
+        self.para_of_vec = None if para_of_vec is None else np.ascontiguousarray(para_of_vec, dtype=np.uint32)
         # vectors.quant: [records][dimension/8 + 8] RaBitQ records (None = the store has no quantized vectors)
         self.quantized = None if quantized is None else np.ascontiguousarray(quantized, dtype=np.uint8)
         self.graph_edges = None if graph_edges is None else np.ascontiguousarray(graph_edges, dtype=np.float32)
@@ -297,6 +299,19 @@ def segment_create(elems: Iterable[Elem], config: VectorConfig, tags: Optional[s
     indexer's job (indexer.rs:107-111).  The HNSW graph is built later on the device
     (VectorSearcher.build_hnsw) or supplied as an hnsw.graph image."""
     elems = list(elems)
+    if config.vector_cardinality == VectorCardinality.Multi:
+        # indexer.rs:116-125: the sentence's vector is the concatenation of the paragraph's vectors
+        rows, pov = [], []
+        for i, e in enumerate(elems):
+            if len(e.vector) == 0 or len(e.vector) % config.dimension:
+                raise NidxGpuError(_lib.NIDX_ERR_INCONSISTENT_DIMENSIONS,
+                                   f"Inconsistent dimensions. Index={config.dimension} Vector={len(e.vector)}")
+            m = np.asarray(e.vector, dtype=np.float32).reshape(-1, config.dimension)
+            rows.append(m)
+            pov += [i] * m.shape[0]
+        vectors = np.vstack(rows) if rows else np.zeros((0, config.dimension), np.float32)
+        return VectorSegment([e.key for e in elems], vectors, [list(e.labels) for e in elems], [e.metadata for e in elems], tags,
+                             para_of_vec=np.asarray(pov, dtype=np.uint32))
     for e in elems:
         if len(e.vector) != config.dimension:
             raise NidxGpuError(_lib.NIDX_ERR_INCONSISTENT_DIMENSIONS,
@@ -375,7 +390,7 @@ class VectorSearcher:
 
     @classmethod
     def open(cls, config: VectorConfig, segments: Sequence[Tuple[VectorSegment, int]],
-             deletions: Sequence[Tuple[str, int]] = ()) -> "VectorSearcher":
+             deletions: Sequence[Tuple[str, int]] = (), quantize: bool = True) -> "VectorSearcher":
         """VectorSearcher::open(config, impl OpenIndexMetadata) (lib.rs:126-200): segments sorted by
         seq, walked newest -> oldest accumulating the deletions with seq > segment seq."""
         self = cls()
@@ -406,8 +421,8 @@ class VectorSearcher:
             self._keep += [bits, graph, seg.vectors, key_ids]
             c_segs[i].vectors = seg.vectors.ctypes.data
             c_segs[i].row_stride_bytes = config.dimension * 4
-            c_segs[i].n_vectors = seg.records
-            c_segs[i].paragraph_of_vector = None
+            c_segs[i].n_vectors = seg.vectors.shape[0]
+            c_segs[i].paragraph_of_vector = None if seg.para_of_vec is None else seg.para_of_vec.ctypes.data
             c_segs[i].n_paragraphs = seg.records
             c_segs[i].hnsw_graph = graph.ctypes.data if graph is not None else None
             c_segs[i].hnsw_graph_len = len(seg.graph) if seg.graph else 0
@@ -423,6 +438,12 @@ class VectorSearcher:
             self._segments.append(seg)
         cfg = config.to_c()
         _lib.check(_lib.lib().nidx_gpu_vector_open(C.byref(cfg), c_segs, len(ordered), C.byref(self._handle)))
+        # DataStoreV2::create writes vectors.quant for every quantizable index (data_store/v2.rs:57-76): a segment that
+        # arrives without its codes gets them encoded on the device, so AUTO routes like OpenSegment::_search
+        if quantize and config.quantizable_vectors():
+            for i, (seg, _alive) in enumerate(ordered):
+                if seg.quantized is None and seg.records:
+                    self.quantize(i)
         for i, seg in enumerate(self._segments):
             if len(seg.list_keys):
                 fi = _lib.FilterIndexC(len(seg.list_keys), seg.list_offsets.ctypes.data, seg.list_ids.ctypes.data if len(seg.list_ids) else None)
@@ -490,6 +511,39 @@ class VectorSearcher:
             return None
         return Or(clauses) if request.filter_operator == FilterOperator.Or else And(clauses)
 
+    def _search_multi_vector(self, request: VectorSearchRequest, prefilter: PrefilterResult, method: int) -> "VectorSearchResponse":
+        """Searcher::search_multi_vector (searcher.rs:345-394): the query is the concatenation of its vectors; every one is
+        searched on its own, the paragraphs found are re-scored with maxsim_similarity and cut at min_score / top k."""
+        d = self.config.dimension
+        flat = np.ascontiguousarray(request.vector, dtype=np.float32).reshape(-1)
+        if flat.size == 0 or flat.size % d:
+            raise NidxGpuError(_lib.NIDX_ERR_INCONSISTENT_DIMENSIONS, f"Inconsistent dimensions. Index={d} Vector={flat.size}")
+        k = max(0, int(request.result_per_page))
+        S = len(self._segments)
+        formula = self._formula(request, prefilter)
+        filt_arrays, filt_ptrs = [], (C.c_void_p * max(1, S))()
+        for s_, seg in enumerate(self._segments):
+            skip = request.segment_filtering_formula is not None and not _segment_matches(request.segment_filtering_formula, seg.tags)
+            bits = _bitset(np.zeros(seg.records, dtype=bool)) if skip else (_bitset(seg._eval(formula)) if formula is not None else None)
+            filt_arrays.append(bits)
+            filt_ptrs[s_] = bits.ctypes.data if bits is not None else None
+        kk = max(1, k)
+        out_seg, out_par = np.zeros((1, kk), np.uint32), np.zeros((1, kk), np.uint32)
+        out_score, out_count = np.zeros((1, kk), np.float32), np.zeros(1, np.uint32)
+        qoff = np.array([0, flat.size // d], dtype=np.uint64)
+        params = _lib.VectorSearchParamsC(k, float(request.min_score), 1, method)
+        _lib.check(_lib.lib().nidx_gpu_vector_search_maxsim(
+            self._handle, flat.ctypes.data, qoff.ctypes.data, 1, C.byref(params),
+            filt_ptrs if any(b is not None for b in filt_arrays) else None, out_seg.ctypes.data, out_par.ctypes.data,
+            out_score.ctypes.data, out_count.ctypes.data))
+        docs = []
+        for i in range(int(out_count[0])):
+            sg = self._segments[int(out_seg[0, i])]
+            p = int(out_par[0, i])
+            md = sg.metadata[p]
+            docs.append(DocumentScored(sg.keys[p], float(out_score[0, i]), md if md else None, list(sg.labels[p])))
+        return VectorSearchResponse(docs)
+
     def search_batch(self, request: VectorSearchRequest, queries: np.ndarray, prefilter: PrefilterResult = None,
                      method: int = _lib.METHOD_AUTO, device_filter: bool = True):
         """Batched form of search(): `queries` [B][D].  Returns (segment, paragraph, vector, score, count).
@@ -556,6 +610,8 @@ class VectorSearcher:
     def search(self, request: VectorSearchRequest, prefilter: PrefilterResult = None,
                method: int = _lib.METHOD_AUTO, device_filter: bool = True) -> VectorSearchResponse:
         prefilter = prefilter or PrefilterResult.all()
+        if self.config.vector_cardinality == VectorCardinality.Multi:
+            return self._search_multi_vector(request, prefilter, method)
         q = np.asarray(request.vector, dtype=np.float32).reshape(1, -1)
         seg, par, _vec, score, count = self.search_batch(request, q, prefilter, method, device_filter)
         docs = []

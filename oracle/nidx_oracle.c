@@ -863,6 +863,20 @@ int orc_brute_force_search(const orc_segment *seg, const float *query, const uin
     return (int)n;
 }
 
+/* maxsim_similarity (multivector.rs:33-46) */
+float orc_maxsim(const float *query_vectors, size_t n_query, const float *doc_vectors, size_t n_doc, size_t dim, int similarity, int order) {
+    float summaxsim = 0.0f;
+    for (size_t q = 0; q < n_query; q++) {
+        float maxsim = 0.0f;
+        for (size_t v = 0; v < n_doc; v++) {
+            float sim = orc_similarity(doc_vectors + v * dim, query_vectors + q * dim, dim, similarity, order);
+            if (sim > maxsim) maxsim = sim;
+        }
+        summaxsim = summaxsim + maxsim;
+    }
+    return summaxsim;
+}
+
 /* OpenSegment::_search (segment.rs:496-567) */
 int orc_segment_search(const orc_segment *seg, const float *query, const uint64_t *filter,
                        size_t k, float min_score, int with_duplicates,
@@ -874,7 +888,7 @@ int orc_segment_search(const orc_segment *seg, const float *query, const uint64_
     if (matching == 0) return 0;
     if (seg->graph && orc_use_hnsw(seg->n_paragraphs, matching, k, seg->quantized != NULL)) {
         if (method_out) *method_out = 1;
-        int n = orc_hnsw_search(seg, query, bits, k, min_score, with_duplicates, 0, out_vec, out_score, NULL);
+        int n = orc_hnsw_search(seg, query, bits, k, min_score, with_duplicates, seg->para_num_vec != NULL, out_vec, out_score, NULL);
         return n > (int)k ? (int)k : n;
     }
     if (method_out) *method_out = 2;

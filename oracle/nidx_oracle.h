@@ -91,6 +91,10 @@ int orc_segment_search(const orc_segment *seg, const float *query, const uint64_
                        size_t k, float min_score, int with_duplicates,
                        uint32_t *out_vec, float *out_score, int *method_out);
 
+/* maxsim_similarity (nidx_vector/src/multivector.rs:33-46): sum over the query vectors of the best similarity among the
+ * document's vectors, 0.0 when none is positive */
+float orc_maxsim(const float *query_vectors, size_t n_query, const float *doc_vectors, size_t n_doc, size_t dim, int similarity, int order);
+
 /* layer_search exposed for unit tests: returns count, results sorted (score desc, addr asc) */
 int orc_layer_search(const orc_segment *seg, const float *query, int query_is_stored, uint32_t stored_addr,
                      int layer, size_t k, const uint32_t *entry_points, size_t n_ep,

@@ -123,6 +123,8 @@ def lib():
     L.orc_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.orc_total_cmp.restype = C.c_int
     L.orc_total_cmp.argtypes = [C.c_float, C.c_float]
+    L.orc_maxsim.restype = C.c_float
+    L.orc_maxsim.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
     L.orc_use_hnsw.restype = C.c_int
     L.orc_use_hnsw.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
     L.orc_rabitq_encoded_len.restype = C.c_size_t
@@ -247,6 +249,11 @@ def normalize(x) -> np.ndarray:
 
 def total_cmp(a: float, b: float) -> int:
     return lib().orc_total_cmp(a, b)
+
+
+def maxsim(query_vectors, doc_vectors, sim, order=ORDER_WAVE64) -> float:
+    q, d = _f32(query_vectors), _f32(doc_vectors)
+    return float(lib().orc_maxsim(_ptr(q), q.shape[0], _ptr(d), d.shape[0], q.shape[1], sim, order))
 
 
 def use_hnsw(total: int, matching: int, k: int, rabitq: bool = False) -> bool:

@@ -130,3 +130,73 @@ def test_single_cardinality_rejects_multi_vector_paragraphs():
     with pytest.raises(_lib.NidxGpuError) as e:
         Index(x, pov, 3, 0, cardinality=0)
     assert e.value.code == _lib.NIDX_ERR_INVALID_CONFIGURATION
+
+
+def test_maxsim_reference_case():
+    """nidx_vector/tests/test_maxsim.rs:23-140: three paragraphs of three one-hot vectors, a two-vector query; the score is
+    the number of query vectors a paragraph contains, and min_score applies to the maxsim score, not to single vectors."""
+    import uuid
+
+    from nucliadb_amd.vector import Elem, PrefilterResult, VectorCardinality, VectorConfig, VectorSearcher, VectorSearchRequest, segment_create
+
+    def onehots(*idx):
+        m = np.zeros((len(idx), 5), np.float32)
+        for r, i in enumerate(idx):
+            m[r, i] = 1.0
+        return m.reshape(-1).tolist()
+
+    config = VectorConfig.for_paragraphs(5)
+    config.vector_cardinality = VectorCardinality.Multi
+    rid = uuid.uuid4().hex
+    seg = segment_create([Elem(f"{rid}/f/d0/0-123", onehots(1, 2, 4)), Elem(f"{rid}/f/d1/0-123", onehots(0, 1, 2)),
+                          Elem(f"{rid}/f/d2/0-123", onehots(0, 2, 3))], config)
+    s = VectorSearcher.open(config, [(seg, 1)])
+    query = onehots(0, 3)
+    r = s.search(VectorSearchRequest(vector=query, result_per_page=1, min_score=-10.0), PrefilterResult.All)
+    assert [d.doc_id for d in r.documents] == [f"{rid}/f/d2/0-123"] and r.documents[0].score == 2.0
+    r = s.search(VectorSearchRequest(vector=query, result_per_page=10, min_score=1.5), PrefilterResult.All)
+    assert [(d.doc_id, d.score) for d in r.documents] == [(f"{rid}/f/d2/0-123", 2.0)]
+    r = s.search(VectorSearchRequest(vector=query, result_per_page=10, min_score=0.5), PrefilterResult.All)
+    assert [(d.doc_id, d.score) for d in r.documents] == [(f"{rid}/f/d2/0-123", 2.0), (f"{rid}/f/d1/0-123", 1.0)]
+    r = s.search(VectorSearchRequest(vector=query, result_per_page=10, min_score=-10.0), PrefilterResult.All)
+    assert [(d.doc_id, d.score) for d in r.documents] == [(f"{rid}/f/d2/0-123", 2.0), (f"{rid}/f/d1/0-123", 1.0), (f"{rid}/f/d0/0-123", 0.0)]
+    s.close()
+
+
+@pytest.mark.parametrize("sim", [0, 1])
+def test_maxsim_matches_oracle(orc, sim):
+    """search_multi_vector (searcher.rs:345-394) composed from oracle pieces: per query vector the oracle's segment search
+    (max(k, 10) hits, one per paragraph), the union of the paragraphs, orc_maxsim, `> min_score`, top k."""
+    rng = np.random.default_rng(31 + sim)
+    n_para, d, vmax, k = 1500, 32, 4, 5
+    x, pov, first, num = make(rng, n_para, d, vmax)
+    idx = Index(x, pov, n_para, sim)
+    oseg = orc.Segment(x, similarity=sim, vec_paragraph=pov, para_first_vec=first, para_num_vec=num, n_paragraphs=n_para)
+    L = _lib.lib()
+    try:
+        for trial in range(6):
+            nqv = int(rng.integers(1, 5))
+            qv = (x[rng.integers(0, x.shape[0], nqv)] + rng.normal(size=(nqv, d)).astype(np.float32) * np.float32(0.2)).astype(np.float32)
+            min_score = float(rng.choice([-10.0, 0.5, 1.2]))
+            qoff = np.array([0, nqv], np.uint64)
+            oseg_, opar, osc, ocnt = np.zeros((1, k), np.uint32), np.zeros((1, k), np.uint32), np.zeros((1, k), np.float32), np.zeros(1, np.uint32)
+            params = _lib.VectorSearchParamsC(k, min_score, 0, _lib.METHOD_AUTO)
+            _lib.check(L.nidx_gpu_vector_search_maxsim(idx.h, qv.ctypes.data, qoff.ctypes.data, 1, C.byref(params), None, oseg_.ctypes.data,
+                                                       opar.ctypes.data, osc.ctypes.data, ocnt.ctypes.data))
+            paras = set()
+            for v in qv:
+                wv, _, _ = oseg.search(v, max(k, 10), min_score=-3.0e38, with_duplicates=True)
+                paras |= {int(pov[a]) for a in wv}
+            scored = []
+            for p in sorted(paras):
+                sc = orc.maxsim(qv, x[first[p]: first[p] + num[p]], sim)
+                if sc > min_score:
+                    scored.append((-sc, p))
+            scored.sort()
+            want = scored[:k]
+            n = int(ocnt[0])
+            assert n == len(want)
+            assert opar[0, :n].tolist() == [p for _, p in want]
+            assert np.array_equal(bits(osc[0, :n]), bits([-s for s, _ in want]))
+    finally:
+        idx.close()

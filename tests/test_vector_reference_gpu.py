@@ -123,6 +123,24 @@ def test_min_score():
         assert len(searcher.search(req, PrefilterResult.All, method=_lib.METHOD_HNSW).documents) == n
 
 
+def test_min_score_respected_with_rabitq_brute_force():
+    """test_min_score.rs:61-164 as written: DIMENSION = 64 and Dot make the index quantizable, five one-hot vectors keep the
+    segment on the RaBitQ brute-force arm; the huge error bound of a one-hot code lets every candidate through to the
+    re-rank, which must re-apply min_score (the bug the reference test pins)."""
+    config = VectorConfig.for_paragraphs(64)
+    assert config.similarity == Similarity.Dot and config.quantizable_vectors()
+    rid = str(uuid.uuid4())
+    segment = segment_create([Elem(f"{rid}/a/title/0-{i}", sentence(i, 64)) for i in range(5)], config)
+    searcher = VectorSearcher.open(config, [(segment, 1)])
+    results = searcher.search(VectorSearchRequest(vector=sentence(0, 64), result_per_page=5, min_score=0.5), PrefilterResult.All)
+    assert searcher.last_methods == [_lib.METHOD_RABITQ_BRUTE_FORCE]
+    assert len(results.documents) == 1
+    assert results.documents[0].score > 0.99
+    results = searcher.search(VectorSearchRequest(vector=sentence(0, 64), result_per_page=5, min_score=-1.0), PrefilterResult.All)
+    assert len(results.documents) == 5
+    searcher.close()
+
+
 def test_vector_normalization():
     """nidx/tests/integration/vector_normalization.rs:31-91: normalised index, Dot, 20 colinear vectors."""
     config = VectorConfig(dimension=10, similarity=Similarity.Dot, normalize_vectors=True)
