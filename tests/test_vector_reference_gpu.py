@@ -262,3 +262,21 @@ def test_single_query_callers_are_coalesced():
     oc = C.c_uint32()
     assert L.nidx_gpu_vector_search_one(s._handle, q[0].ctypes.data, d - 1, C.byref(params), None, None, None, None, C.byref(oc)) == _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS
     s.close()
+
+
+def test_hidden_search():
+    """test_hidden.rs:25-78: segment tags (the resource labels the indexer extracts, indexer.rs:27) and
+    segment_filtering_formula: Not("/q/h") skips the segment of the hidden resource."""
+    config = VectorConfig.for_paragraphs(4)
+    hid, hidden = _resource(4)
+    vid, visible = _resource(4)
+    hidden_segment = segment_create(hidden, config, tags={"/q/h"})
+    visible_segment = segment_create(visible, config)
+    searcher = VectorSearcher.open(config, [(hidden_segment, 1), (visible_segment, 2)])
+    request = VectorSearchRequest(vector=[0.5, 0.5, 0.5, 0.5], min_score=-1.0, result_per_page=10)
+    everything = searcher.search(request, PrefilterResult.All)
+    assert {d.doc_id for d in everything.documents} == {f"{hid}/a/title/0-5", f"{vid}/a/title/0-5"}
+    request.segment_filtering_formula = Not(Literal("/q/h"))
+    seen = searcher.search(request, PrefilterResult.All)
+    assert [d.doc_id for d in seen.documents] == [f"{vid}/a/title/0-5"]
+    searcher.close()
