@@ -7,15 +7,14 @@
 //   TopDocs::with_limit(k) ordered (score desc, DocAddress asc), Count, the search-after score tweak
 //   (reader.rs:350-390), deletions as an alive bitset (nidx_tantivy/src/index_reader.rs:39-74).
 //
-// One workgroup per work item = (query, doc-id slice of the segment): the host cuts every query into
-// slices of roughly equal posting count so that a query with a 400 k-posting term does not become the
-// tail of the launch; a slice's cursors are found with a wave-wide 64-ary search.  Inside a work item
-// the postings of the query's clauses are consumed in lockstep
-// doc-id windows [lo, hi): hi is chosen so that every clause contributes at most PER postings, all
-// of a window's (doc -> partial score) pairs live in an LDS hash table, clauses are applied one
-// after the other with a barrier in between — so each doc's f32 sum is built in clause order,
-// exactly like the oracle's term-at-a-time loop — and the finished window is folded into per-wave
-// top-k lists.  Postings are read once, coalesced (doc ids and tfs are separate arrays).
+// One WAVE per work item = (query, doc-id slice of the segment): the host cuts every query into slices of roughly
+// equal posting count so that a query with a 400 k-posting term does not become the tail of the launch; a slice's
+// cursors are found with a wave-wide 64-ary search.  Inside a work item the postings of the query's clauses are
+// consumed in lockstep doc-id windows [lo, hi) of <= 512 postings, shared out in proportion to what is left of every
+// clause's list; all of a window's (doc -> partial score) pairs live in an LDS hash table, clauses are applied one
+// after the other — so each doc's f32 sum is built in clause order, exactly like the oracle's term-at-a-time loop —
+// and the finished window is folded into the wave's top-k list.  Postings are read once (doc ids and tfs are
+// separate arrays).  bm25_merge_kernel then merges the slices of a query.
 // Bound: HBM; algorithmic bytes per posting scored = 9 (u32 doc + u32 tf + u8 fieldnorm id).
 #include "device_common.h"
 #include "kernels.h"
@@ -24,77 +23,78 @@ namespace nidx {
 
 #define BM25_EMPTY 0xffffffffu
 
-// NT threads per work item: a window holds 8 postings per thread, the hash table is twice that.
-template <int NT>
-struct Bm25Shared {
-    static constexpr int TABLE = NT * 16, DISTINCT = NT * 8, NW = NT / 64;
-    uint32_t key[TABLE];
-    float acc[TABLE];
-    uint16_t flags[TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
-    float tf_cache[256];
-    unsigned long long cursor[BM25_MAX_CLAUSES];
-    unsigned long long end[BM25_MAX_CLAUSES];
-    uint8_t c_aux[BM25_MAX_CLAUSES];    // the clause's cursor indexes a materialised term set (aux_doc_ids), not the postings
-    uint8_t c_occur[BM25_MAX_CLAUSES];
-    uint8_t c_mode[BM25_MAX_CLAUSES];
-    float c_weight[BM25_MAX_CLAUSES];
-    uint32_t hi;
-    uint32_t slot_start[BM25_MAX_CLAUSES + 1];  // this window's slots [slot_start[c], slot_start[c + 1]) belong to clause c
-    uint64_t kth[NW];  // every wave's current k-th key: the best of them is the block's admission threshold
-    uint32_t taken_c[BM25_MAX_CLAUSES];
-    unsigned long long total;
-    unsigned long long postings;
-};
+// =====================================================================================================
+// One WAVE per work item, clause state in lane registers (lane c = clause c): no block barrier, no LDS traffic for
+// cursors / shares / clause attributes; the window's hash table, the 1 KiB tf cache and 64 counters are all the
+// LDS it uses (~11 KiB => up to 14 items per CU).
+// =====================================================================================================
+#define BW_TABLE 1024      /* hash slots */
+#define BW_WINDOW 512      /* postings per window: 8 per lane */
+#define BW_SHIFT 22        /* 32 - log2(BW_TABLE) */
 
-template <int KL, int NT>
-__global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
-    constexpr int BM25_TABLE = Bm25Shared<NT>::TABLE, BM25_MAX_DISTINCT = Bm25Shared<NT>::DISTINCT, NW = NT / 64;
-    constexpr int HASH_SHIFT = NT == 256 ? 20 : (NT == 128 ? 21 : 22);  // 32 - log2(TABLE)
-    __shared__ Bm25Shared<NT> sh;
-    __shared__ uint64_t merge[NW > 1 ? NW - 1 : 1][64 * KL];
-    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ inline uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+template <int KL>
+__global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
+    __shared__ uint32_t t_key[BW_TABLE];
+    __shared__ float t_acc[BW_TABLE];
+    __shared__ uint16_t t_flags[BW_TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
+    __shared__ float tf_cache[256];
+    __shared__ uint32_t taken[BM25_MAX_CLAUSES];
+    const int lane = threadIdx.x;
     const Bm25Work work = a.work[blockIdx.x];
     const uint32_t q = work.query;
     const uint64_t c0 = a.clause_offsets[q], c1 = a.clause_offsets[q + 1];
     const int C = (int)(c1 - c0);
-    const Bm25ClauseDev *cl = a.clauses + c0;
     const int k = (int)a.k;
 
-    for (int i = tid; i < BM25_TABLE; i += NT) {
-        sh.key[i] = BM25_EMPTY;
-        sh.acc[i] = 0.f;
-        sh.flags[i] = 0;
+    for (int i = lane; i < BW_TABLE; i += 64) {
+        t_key[i] = BM25_EMPTY;
+        t_acc[i] = 0.f;
+        t_flags[i] = 0;
     }
-    for (int i = tid; i < 256; i += NT) sh.tf_cache[i] = a.tf_cache[i];
-    int n_must = 0, n_group = 0;
-    for (int c = 0; c < C; c++) {
-        n_must += cl[c].occur == 1 ? 1 : 0;
-        n_group += cl[c].occur == 3 ? 1 : 0;
+    for (int i = lane; i < 256; i += 64) tf_cache[i] = a.tf_cache[i];
+    taken[lane] = 0;
+
+    // ---- lane c holds clause c ----
+    uint32_t attr_l = 0;  // occur | mode << 8 | aux << 16
+    float weight_l = 0.f;
+    unsigned long long cur_l = 0, end_l = 0;
+    if (lane < C) {
+        const Bm25ClauseDev cd = a.clauses[c0 + lane];
+        const bool aux = (cd.term & BM25_AUX_TERM) != 0;
+        const uint32_t ti = cd.term & ~BM25_AUX_TERM;
+        attr_l = (uint32_t)cd.occur | ((uint32_t)cd.mode << 8) | (aux ? 1u << 16 : 0u);
+        weight_l = cd.weight;
+        cur_l = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
+        end_l = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
     }
-    for (int c = tid; c < C; c += NT) {
-        sh.c_aux[c] = (cl[c].term & BM25_AUX_TERM) ? 1 : 0;
-        sh.c_occur[c] = (uint8_t)cl[c].occur;
-        sh.c_mode[c] = (uint8_t)cl[c].mode;
-        sh.c_weight[c] = cl[c].weight;
-    }
-    if (work.n_slices <= 1) {
-        if (tid < C) {
-            const uint32_t t = cl[tid].term;
-            const bool aux = (t & BM25_AUX_TERM) != 0;  // aux lists: [begin, end) pairs
-            const uint32_t ti = t & ~BM25_AUX_TERM;
-            sh.cursor[tid] = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
-            sh.end[tid] = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
-        }
-    } else {
-        // doc range of this slice; per clause a wave finds the first posting >= lo and >= hi
+    const int n_must = __popcll(__ballot(lane < C && (attr_l & 0xff) == 1));
+    const int n_group = __popcll(__ballot(lane < C && (attr_l & 0xff) == 3));
+    if (work.n_slices > 1) {
+        // doc range of this slice: the wave finds, clause by clause, the first posting >= lo and >= hi (64-ary search)
         const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
         const uint32_t hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
-        for (int c = wib; c < C; c += NW) {
-            const uint32_t t = cl[c].term;
-            const bool aux = (t & BM25_AUX_TERM) != 0;
-            const uint32_t ti = t & ~BM25_AUX_TERM;
+        for (int c = 0; c < C; c++) {
+            const bool aux = (rl_u32(attr_l, c) >> 16) != 0;
             const uint32_t *ids = aux ? a.aux_doc_ids : a.doc_ids;
-            const unsigned long long b = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti], e = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
+            const unsigned long long b = shfl_u64(cur_l, c), e = shfl_u64(end_l, c);
             unsigned long long res[2];
 #pragma unroll
             for (int w = 0; w < 2; w++) {
@@ -117,19 +117,13 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
                 int first = m ? __ffsll((long long)m) - 1 : 64;
                 res[w] = left + (unsigned long long)first < right ? left + (unsigned long long)first : right;
             }
-            if (lane == 0) {
-                sh.cursor[c] = res[0];
-                sh.end[c] = res[1];
+            if (lane == c) {
+                cur_l = res[0];
+                end_l = res[1];
             }
         }
     }
-    if (tid == 0) {
-        sh.total = 0;
-        sh.postings = 0;
-    }
-    if (tid < NW) sh.kth[tid] = NIDX_EMPTY_KEY;
-    __syncthreads();
-    unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0;
+    unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0, postings = 0, total = 0;
     const unsigned long long cy_t0 = clock64();
 
     WaveTopK<KL> top;  // k <= 64*KL
@@ -147,54 +141,45 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
         // ---- window: the slots are shared out in proportion to what is left of every clause's list in this slice
         //      (doc ids of one slice are spread alike, so the lists then run out at about the same doc id);
         //      the window ends at the smallest doc id that some clause could not fit ----
-        if (tid == 0) sh.hi = 0xffffffffu;
-        __syncthreads();
-        unsigned long long total_left = 0;
-        for (int c = 0; c < C; c++) total_left += sh.end[c] - sh.cursor[c];
+        const unsigned long long left_l = lane < C ? end_l - cur_l : 0ull;
+        const unsigned long long total_left = wave_sum_u64(left_l);
         if (total_left == 0) break;
-        if (tid == 0) {
-            uint32_t at = 0;
-            for (int c = 0; c < C; c++) {
-                const unsigned long long left = sh.end[c] - sh.cursor[c];
-                unsigned long long share = total_left <= (unsigned long long)BM25_MAX_DISTINCT
-                                               ? left
-                                               : (left * (unsigned long long)(BM25_MAX_DISTINCT - C)) / total_left + (left ? 1 : 0);
-                sh.slot_start[c] = at;
-                at += (uint32_t)share;
-            }
-            sh.slot_start[C] = at;
+        uint32_t share_l = 0;
+        if (lane < C)
+            share_l = total_left <= (unsigned long long)BW_WINDOW ? (uint32_t)left_l
+                                                                  : (uint32_t)((left_l * (unsigned long long)(BW_WINDOW - C)) / total_left) + (left_l ? 1u : 0u);
+        uint32_t start_l = share_l;  // inclusive scan, then made exclusive
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(start_l, off, 64);
+            if (lane >= off) start_l += v;
         }
-        __syncthreads();
-        if (tid < C) {
-            unsigned long long cur = sh.cursor[tid], e = sh.end[tid];
-            const uint32_t per_c = sh.slot_start[tid + 1] - sh.slot_start[tid];
-            if (cur + per_c < e) atomicMin(&sh.hi, (sh.c_aux[tid] ? a.aux_doc_ids : a.doc_ids)[cur + per_c]);
-        }
-        __syncthreads();
-        const uint32_t hi = sh.hi;
+        const uint32_t n_slots = rl_u32(start_l, 63);
+        start_l -= share_l;
+        uint32_t hi_c = 0xffffffffu;
+        if (lane < C && cur_l + share_l < end_l) hi_c = ((attr_l >> 16) ? a.aux_doc_ids : a.doc_ids)[cur_l + share_l];
+        const uint32_t hi = wave_min_u32(hi_c);
         const unsigned long long cy_a = clock64();
-        // ---- load phase: the window holds <= 2048 posting slots (slot g belongs to clause g / per); every
-        //      thread fetches its 8 slots for ALL clauses, each of the three dependent steps (index -> doc id ->
-        //      tf + fieldnorm) issued for all 8 slots before the first use: three memory round trips per window
-        uint32_t p_doc[8];
-        float p_score[8];
+        // ---- load phase: 8 postings per lane; the clause of slot g is found against the C share boundaries, its
+        //      cursor and attributes come from that clause's lane; then the three dependent steps (index -> doc id ->
+        //      tf + fieldnorm) are each issued for all 8 slots before the first use ----
+        uint32_t p_doc[8], p_attr[8];
+        float p_score[8], p_weight[8];
         int p_clause[8];
         unsigned long long p_idx[8];
-        uint32_t p_attr[8];   // occur | mode << 8 | aux << 16
-        float p_weight[8];
-        if (tid < BM25_MAX_CLAUSES) sh.taken_c[tid] = 0;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const uint32_t g = (uint32_t)tid + (uint32_t)NT * m;
+            const uint32_t g = (uint32_t)lane + 64u * m;
             int c = 0;
-            while (c < C && g >= sh.slot_start[c + 1]) c++;
-            const int cc = c < C ? c : 0;
-            const unsigned long long i = sh.cursor[cc] + (g - sh.slot_start[cc]);
-            const bool valid = c < C && i < sh.end[cc];
+            for (int j = 1; j < C; j++) c += g >= rl_u32(start_l, j) ? 1 : 0;
+            const unsigned long long cur_c = shfl_u64(cur_l, c), end_c = shfl_u64(end_l, c);
+            const uint32_t start_c = __shfl(start_l, c, 64);
+            p_attr[m] = __shfl(attr_l, c, 64);
+            p_weight[m] = __shfl(weight_l, c, 64);
+            const unsigned long long i = cur_c + (g - start_c);
+            const bool valid = g < n_slots && i < end_c;
             p_clause[m] = valid ? c : -1;
             p_idx[m] = valid ? i : 0;
-            p_attr[m] = (uint32_t)sh.c_occur[cc] | ((uint32_t)sh.c_mode[cc] << 8) | ((uint32_t)sh.c_aux[cc] << 16);
-            p_weight[m] = sh.c_weight[cc];
         }
         // unconditional loads (index 0 stands in for an unused slot), so that all eight are in flight together
 #pragma unroll
@@ -215,63 +200,58 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
                 if (mode == 2) p_score[m] = p_weight[m];  // ConstScorer(boost)
                 else {
                     const float tf = mode == 1 ? 1.0f : (float)p_tf[m];
-                    p_score[m] = p_weight[m] * (tf / (tf + sh.tf_cache[p_fn[m]]));
+                    p_score[m] = p_weight[m] * (tf / (tf + tf_cache[p_fn[m]]));
                 }
             }
         }
         const unsigned long long cy_b = clock64();
         // ---- probe phase: every posting finds (or claims) its document's slot; which posting claims a slot does
-        //      not matter, so all clauses probe together.  The claimer OWNS the document for the fold.
+        //      not matter, so all clauses probe together.  The claimer OWNS the document for the fold. ----
         uint32_t p_slot[8];
         uint32_t owned = 0;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             p_slot[m] = 0;
             if (p_clause[m] < 0) continue;
+            atomicAdd(&taken[p_clause[m]], 1u);
             const uint32_t d = p_doc[m];
-            uint32_t h = (d * 2654435761u) >> HASH_SHIFT;
+            uint32_t h = (d * 2654435761u) >> BW_SHIFT;
             for (;;) {
-                uint32_t old = atomicCAS(&sh.key[h], BM25_EMPTY, d);
+                uint32_t old = atomicCAS(&t_key[h], BM25_EMPTY, d);
                 if (old == BM25_EMPTY) { owned |= 1u << m; break; }
                 if (old == d) break;
-                h = (h + 1) & (BM25_TABLE - 1);
+                h = (h + 1) & (BW_TABLE - 1);
             }
             p_slot[m] = h;
         }
-        __syncthreads();  // taken_c zeroed, every key placed
-        // ---- apply phase: clause by clause (barrier in between) so every doc's f32 sum is built in clause order;
-        //      within a clause every posting is a different document, so the read-modify-writes do not collide
+        // cursors advance by what was taken (lane c reads clause c's counter and clears it)
+        {
+            const uint32_t t = taken[lane];
+            taken[lane] = 0;
+            if (lane < C) cur_l += t;
+            postings += t;
+        }
+        // ---- apply phase: clause by clause, so every doc's f32 sum is built in clause order; within a clause every
+        //      posting is a different document and one wave's LDS operations execute in order ----
         for (int c = 0; c < C; c++) {
-            const int occur = sh.c_occur[c];
-            uint32_t mine = 0;
+            const int occur = (int)(rl_u32(attr_l, c) & 0xff);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 if (p_clause[m] != c) continue;
-                mine++;
                 const uint32_t h = p_slot[m];
                 if (occur == 2) {
-                    sh.flags[h] |= 2;  // MustNot
+                    t_flags[h] |= 2;  // MustNot
                 } else {
-                    sh.acc[h] = sh.acc[h] + p_score[m];
-                    if (occur == 1) sh.flags[h] += 0x100;
-                    else if (occur == 3) sh.flags[h] |= 4;
-                    else sh.flags[h] |= 1;
+                    t_acc[h] = t_acc[h] + p_score[m];
+                    if (occur == 1) t_flags[h] += 0x100;
+                    else if (occur == 3) t_flags[h] |= 4;
+                    else t_flags[h] |= 1;
                 }
             }
-            if (mine) atomicAdd(&sh.taken_c[c], mine);
-            __syncthreads();
-        }
-        if (tid < C) {
-            sh.cursor[tid] += sh.taken_c[tid];
-            atomicAdd(&sh.postings, (unsigned long long)sh.taken_c[tid]);
         }
         const unsigned long long cy_c = clock64();
-        // ---- fold the window into the top-k, count matches, clear the table: each thread folds the documents it
-        //      owns.  The admission threshold is shared by the four waves (any wave's k-th key bounds the block's).
+        // ---- fold the window into the top-k, count matches, clear the table: each lane folds the documents it owns ----
         uint32_t matched_here = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-            if (sh.kth[w] > kth) kth = sh.kth[w];
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             bool ok = false;
@@ -279,7 +259,7 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
             if (owned & (1u << m)) {
                 const uint32_t i = p_slot[m];
                 const uint32_t d = p_doc[m];
-                const uint16_t f = sh.flags[i];
+                const uint16_t f = t_flags[i];
                 ok = !(f & 2) && (int)(f >> 8) == n_must && (n_group == 0 || (f & 4)) && (n_must > 0 || n_group > 0 || (f & 1));
                 if (ok && a.alive) ok = bit_test(a.alive, d);
                 if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
@@ -288,7 +268,7 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
                     const uint32_t r = a.order_key[d];
                     ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
                 } else if (ok) {
-                    float s = sh.acc[i];
+                    float s = t_acc[i];
                     if (has_after) {
                         // tweak_score: -inf for docs not after the cursor
                         uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
@@ -298,9 +278,9 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
                     }
                     ck = rank_key(s, d);
                 }
-                sh.key[i] = BM25_EMPTY;
-                sh.acc[i] = 0.f;
-                sh.flags[i] = 0;
+                t_key[i] = BM25_EMPTY;
+                t_acc[i] = 0.f;
+                t_flags[i] = 0;
             }
             unsigned long long okm = __ballot(ok);
             matched_here += (uint32_t)__popcll(okm);
@@ -312,15 +292,13 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }
-        if (lane == 0) sh.kth[wib] = kth;
-        if (lane == 0 && matched_here) atomicAdd(&sh.total, (unsigned long long)matched_here);
-        __syncthreads();
+        total += matched_here;
         cy_load += cy_b - cy_a;
         cy_apply += cy_c - cy_b;
         cy_fold += clock64() - cy_c;
         n_win++;
     }
-    if (a.dbg && tid == 0) {
+    if (a.dbg && lane == 0) {
         atomicAdd(&a.dbg[0], cy_load);
         atomicAdd(&a.dbg[1], cy_apply);
         atomicAdd(&a.dbg[2], cy_fold);
@@ -328,36 +306,20 @@ __global__ __launch_bounds__(NT) void bm25_search_kernel(Bm25Args a) {
         atomicAdd(&a.dbg[4], n_win);
         atomicAdd(&a.dbg[5], 1ull);
     }
-
-    // ---- merge the four waves' lists ----
-    if (wib > 0) {
+    uint32_t cnt = 0;
 #pragma unroll
-        for (int i = 0; i < KL; i++) merge[wib - 1][64 * i + lane] = top.mine(i);
+    for (int i = 0; i < KL; i++) {
+        const int e = 64 * i + lane;
+        const uint64_t key = top.mine(i);
+        const bool valid = key != NIDX_EMPTY_KEY && e < k;
+        cnt += (uint32_t)__popcll(__ballot(valid));
+        if (e < k) a.out_key[(size_t)blockIdx.x * k + e] = valid ? key : NIDX_EMPTY_KEY;
     }
-    __syncthreads();
-    if (wib == 0) {
-        kth = top.at(k - 1);  // this wave's own k-th key (the running threshold may have been another wave's)
-        for (int w = 0; w < NW - 1; w++)
-            for (int i = 0; i < k; i++) {
-                uint64_t nk = merge[w][i];
-                if (nk == NIDX_EMPTY_KEY) break;
-                if (nk > kth) kth = top.insert_kth(nk, k, lane);
-                else break;
-            }
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int i = 0; i < KL; i++) {
-            const int e = 64 * i + lane;
-            const uint64_t key = top.mine(i);
-            const bool valid = key != NIDX_EMPTY_KEY && e < k;
-            cnt += (uint32_t)__popcll(__ballot(valid));
-            if (e < k) a.out_key[(size_t)blockIdx.x * k + e] = valid ? key : NIDX_EMPTY_KEY;
-        }
-        if (lane == 0) {
-            a.out_count[blockIdx.x] = cnt;
-            a.out_total[blockIdx.x] = sh.total;
-            a.out_postings[blockIdx.x] = sh.postings;
-        }
+    postings = wave_sum_u64(postings);  // lane c counted clause c's postings
+    if (lane == 0) {
+        a.out_count[blockIdx.x] = cnt;
+        a.out_total[blockIdx.x] = total;
+        a.out_postings[blockIdx.x] = postings;
     }
 }
 
@@ -421,8 +383,8 @@ hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStre
 hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s) {
     if (n_work == 0) return hipSuccess;
     // one WAVE per work item: no block barrier anywhere on the path, four times as many independent items per CU
-    if (a.k > 64) hipLaunchKernelGGL((bm25_search_kernel<4, BM25_ITEM_THREADS>), dim3(n_work), dim3(BM25_ITEM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((bm25_search_kernel<1, BM25_ITEM_THREADS>), dim3(n_work), dim3(BM25_ITEM_THREADS), 0, s, a);
+    if (a.k > 64) hipLaunchKernelGGL(bm25_wave_kernel<4>, dim3(n_work), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(bm25_wave_kernel<1>, dim3(n_work), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
