@@ -73,6 +73,12 @@ __host__ __device__ inline float cosine_from_sums(float ab, float xx, float yy) 
     return 1.0f - (float)dist;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it also waits for every
+// GLOBAL load in flight (s_waitcnt vmcnt(0)), which serialises a software pipeline whose prefetched rows are meant to stay
+// in flight across the barrier.  Here only the LDS queue is drained; the compiler still waits for a register's own load
+// before its first use.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline bool bit_test(const uint64_t *bits, uint32_t i) { return (bits[i >> 6] >> (i & 63)) & 1ull; }
 
 // A sorted (best first) list of up to 64 (score, addr) entries held one per lane as rank keys.
