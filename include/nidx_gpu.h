@@ -296,6 +296,10 @@ typedef struct {
     const uint32_t *tfs;          /* term frequency per posting */
     const uint8_t *fieldnorm_ids; /* [n_docs] 1-byte fieldnorm ids */
     const uint64_t *alive_bitset; /* open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74); NULL = all */
+    /* positions of every posting (the text field is indexed WithFreqsAndPositions, schema.rs:59-115): posting i owns
+     * positions[pos_offsets[i] .. pos_offsets[i+1]), ascending.  NULL = no positions: phrase clauses are refused */
+    const uint64_t *pos_offsets;  /* [n_postings + 1] */
+    const uint32_t *positions;
 } nidx_gpu_bm25_segment_t;
 
 typedef struct nidx_gpu_bm25_index nidx_gpu_bm25_index_t;
@@ -349,6 +353,11 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
  * (options.term_set_terms[term_set_offsets[j] .. term_set_offsets[j+1])), each document once, scored
  * ConstScorer(boost): FuzzyTermQuery / AutomatonWeight (nidx_paragraph/src/fuzzy_query.rs:55-125). */
 #define NIDX_BM25_TERM_SET 0x80000000u
+/* A clause whose `term` is NIDX_BM25_PHRASE | j is PhraseQuery(options.phrase_terms[phrase_offsets[j] ..
+ * phrase_offsets[j+1])) with slop 0 (keyword_parser.rs:69-91 for multi-word quotes; tantivy's QueryParser for
+ * nidx_text): the terms at consecutive positions, tf = number of occurrences, Bm25Weight::for_terms (idf summed
+ * over the terms).  `mode` is ignored. */
+#define NIDX_BM25_PHRASE 0x40000000u
 
 typedef struct {
     uint32_t k;                                  /* TopDocs limit (0 with facets = only_faceted) */
@@ -359,6 +368,9 @@ typedef struct {
     /* NULL or [n_term_sets]: != 0 = the clause matches every document OUTSIDE the union — parse_excluded's
      * BooleanQuery[Must AllQuery, MustNot term] (nidx_paragraph/src/query_parser/keyword_parser.rs:93-105) */
     const uint8_t *term_set_complement;
+    const uint32_t *phrase_terms;                /* term ids of every phrase, concatenated */
+    const uint64_t *phrase_offsets;              /* [n_phrases + 1] */
+    uint32_t n_phrases;
     /* TopDocs::order_by_fast_field (nidx_text/src/reader.rs:210-224, custom_order_collector): -1 = by score,
      * else the fast field registered with nidx_gpu_bm25_set_fast_field (0 = created, 1 = modified) */
     int32_t order_field;

@@ -78,6 +78,9 @@ class Bm25SearchOptionsC(C.Structure):
         ("term_set_offsets", C.c_void_p),
         ("n_term_sets", C.c_uint32),
         ("term_set_complement", C.c_void_p),
+        ("phrase_terms", C.c_void_p),
+        ("phrase_offsets", C.c_void_p),
+        ("n_phrases", C.c_uint32),
         ("order_field", C.c_int32),
         ("order_desc", C.c_int32),
         ("facet_terms", C.c_void_p),
@@ -88,6 +91,7 @@ class Bm25SearchOptionsC(C.Structure):
 
 
 BM25_TERM_SET = 0x80000000
+BM25_PHRASE = 0x40000000
 
 
 class FilterIndexC(C.Structure):
@@ -124,6 +128,8 @@ class Bm25SegmentC(C.Structure):
         ("tfs", C.c_void_p),
         ("fieldnorm_ids", C.c_void_p),
         ("alive_bitset", C.c_void_p),
+        ("pos_offsets", C.c_void_p),
+        ("positions", C.c_void_p),
     ]
 
 

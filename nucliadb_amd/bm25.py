@@ -31,6 +31,9 @@ class Clause:
     term_set: Optional[Sequence[int]] = None
     # parse_excluded (keyword_parser.rs:93-105): every document OUTSIDE the union, AllQuery's 1.0 * boost
     complement: bool = False
+    # PhraseQuery(term_set) with slop 0: the terms at consecutive positions in this order, tf = occurrences,
+    # Bm25Weight::for_terms (the index must have been opened with positions)
+    phrase: bool = False
 
 
 @dataclass
@@ -59,7 +62,10 @@ def tokenize(text: str) -> List[str]:
 class Bm25Segment:
     """One tantivy segment's postings for the scored field, term-id resolved (CSR)."""
 
-    def __init__(self, term_offsets, doc_ids, tfs, fieldnorm_ids, total_num_tokens, alive=None):
+    def __init__(self, term_offsets, doc_ids, tfs, fieldnorm_ids, total_num_tokens, alive=None, pos_offsets=None, positions=None):
+        # positions of every posting (WithFreqsAndPositions): posting i owns positions[pos_offsets[i] .. pos_offsets[i+1])
+        self.pos_offsets = None if pos_offsets is None else np.ascontiguousarray(pos_offsets, dtype=np.uint64)
+        self.positions = None if positions is None else np.ascontiguousarray(positions, dtype=np.uint32)
         self.term_offsets = np.ascontiguousarray(term_offsets, dtype=np.uint64)
         self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.uint32)
         self.tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
@@ -72,9 +78,9 @@ class Bm25Segment:
         return int(self.fieldnorm_ids.size)
 
     @classmethod
-    def from_term_docs(cls, docs: Sequence[np.ndarray], n_terms: int, alive=None) -> "Bm25Segment":
+    def from_term_docs(cls, docs: Sequence[np.ndarray], n_terms: int, alive=None, with_positions: bool = False) -> "Bm25Segment":
         """docs[i] = array of term ids (with repeats) of document i — what the single-segment tantivy
-        writer (nidx_tantivy/src/lib.rs:39-78) would index."""
+        writer (nidx_tantivy/src/lib.rs:39-78) would index.  with_positions: token index of every occurrence."""
         L = _lib.lib()
         lens = np.array([len(d) for d in docs], dtype=np.int64)
         doc_of = np.repeat(np.arange(len(docs), dtype=np.int64), lens)
@@ -88,12 +94,20 @@ class Bm25Segment:
         term_offsets = np.cumsum(term_offsets).astype(np.uint64)
         table = np.array([L.nidx_gpu_fieldnorm_from_id(i) for i in range(256)], dtype=np.int64)
         ids = (np.searchsorted(table, lens, side="right") - 1).astype(np.uint8)
-        return cls(term_offsets, d.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive)
+        pos_offsets = positions = None
+        if with_positions:
+            pos_in_doc = np.concatenate([np.arange(len(x), dtype=np.int64) for x in docs]) if len(docs) else np.zeros(0, np.int64)
+            order = np.lexsort((pos_in_doc, key))  # by (term, doc), then position
+            positions = pos_in_doc[order].astype(np.uint32)
+            pos_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        return cls(term_offsets, d.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive, pos_offsets, positions)
 
     def to_c(self) -> _lib.Bm25SegmentC:
         return _lib.Bm25SegmentC(self.n_docs, self.total_num_tokens, self.term_offsets.size - 1, self.term_offsets.ctypes.data,
                                  self.doc_ids.ctypes.data, self.tfs.ctypes.data, self.fieldnorm_ids.ctypes.data,
-                                 None if self.alive is None else self.alive.ctypes.data)
+                                 None if self.alive is None else self.alive.ctypes.data,
+                                 None if self.pos_offsets is None else self.pos_offsets.ctypes.data,
+                                 None if self.positions is None else self.positions.ctypes.data)
 
 
 class Bm25Searcher:
@@ -168,9 +182,15 @@ class Bm25Searcher:
         set_terms: List[int] = []
         set_offsets = [0]
         set_comp: List[int] = []
+        phrase_terms: List[int] = []
+        phrase_offsets = [0]
         for i, c in enumerate(flat):
             cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
-            if c.term_set is not None:
+            if c.term_set is not None and c.phrase:
+                cl[i].term = _lib.BM25_PHRASE | (len(phrase_offsets) - 1)
+                phrase_terms.extend(int(t) for t in c.term_set)
+                phrase_offsets.append(len(phrase_terms))
+            elif c.term_set is not None:
                 cl[i].term = _lib.BM25_TERM_SET | (len(set_offsets) - 1)
                 cl[i].mode = _lib.CONST_SCORE
                 set_terms.extend(int(t) for t in c.term_set)
@@ -199,6 +219,11 @@ class Bm25Searcher:
         opt.n_term_sets = len(set_offsets) - 1
         sc = np.ascontiguousarray(set_comp, dtype=np.uint8)
         opt.term_set_complement = sc.ctypes.data if sc.size else None
+        pt = np.ascontiguousarray(phrase_terms, dtype=np.uint32)
+        po = np.ascontiguousarray(phrase_offsets, dtype=np.uint64)
+        opt.phrase_terms = pt.ctypes.data if pt.size else None
+        opt.phrase_offsets = po.ctypes.data
+        opt.n_phrases = len(phrase_offsets) - 1
         opt.order_field, opt.order_desc = order_field, int(order_desc)
         fo = ft = fc = None
         if facets is not None:

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
         for (int m = 0; m < 8; m++) {
             if (p_clause[m] >= 0 && p_doc[m] >= hi) p_clause[m] = -1;  // hi == 0xffffffff: every clause's remainder fits
             const bool scored = p_clause[m] >= 0 && (p_attr[m] & 0xff) != 2 && ((p_attr[m] >> 8) & 0xff) != 2;
-            p_tf[m] = a.tfs[scored && ((p_attr[m] >> 8) & 0xff) == 0 ? p_idx[m] : 0];
+            p_tf[m] = ((p_attr[m] >> 16) && scored ? a.aux_tfs : a.tfs)[scored && ((p_attr[m] >> 8) & 0xff) == 0 ? p_idx[m] : 0];
             p_fn[m] = (uint32_t)a.fieldnorm_ids[scored ? p_doc[m] : 0];
         }
 #pragma unroll

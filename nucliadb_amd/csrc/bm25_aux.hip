@@ -139,6 +139,107 @@ hipError_t launch_bitset_compact(const uint64_t *bits, uint32_t n_words, uint32_
     return hipGetLastError();
 }
 
+// ---- PhraseQuery ---------------------------------------------------------------------------------------------------
+// first index in [b, e) whose doc id is >= d
+__device__ inline unsigned long long lower_bound_doc(const uint32_t *doc_ids, unsigned long long b, unsigned long long e, uint32_t d) {
+    while (b < e) {
+        const unsigned long long mid = b + (e - b) / 2;
+        if (doc_ids[mid] < d) b = mid + 1;
+        else e = mid;
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(256) void phrase_match_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids,
+                                                           const unsigned long long *pos_offsets, const uint32_t *positions, PhraseDev ph,
+                                                           uint32_t *tmp_tf) {
+    const unsigned long long b0 = term_offsets[ph.terms[ph.driver]], e0 = term_offsets[ph.terms[ph.driver] + 1];
+    const unsigned long long i0 = b0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= e0) return;
+    const uint32_t d = doc_ids[i0];
+    // the document's posting in every other term's list
+    unsigned long long at[BM25_MAX_PHRASE_TERMS];
+    bool all = true;
+    for (uint32_t t = 0; t < ph.n_terms && all; t++) {
+        if (t == ph.driver) { at[t] = i0; continue; }
+        const unsigned long long b = term_offsets[ph.terms[t]], e = term_offsets[ph.terms[t] + 1];
+        const unsigned long long i = lower_bound_doc(doc_ids, b, e, d);
+        all = i < e && doc_ids[i] == d;
+        at[t] = i;
+    }
+    uint32_t count = 0;
+    if (all) {
+        for (unsigned long long pi = pos_offsets[i0]; pi < pos_offsets[i0 + 1]; pi++) {
+            const uint32_t p = positions[pi];
+            if (p < ph.driver) continue;  // the phrase would start before position 0
+            const uint32_t start = p - ph.driver;
+            bool ok = true;
+            for (uint32_t t = 0; t < ph.n_terms && ok; t++) {
+                if (t == ph.driver) continue;
+                const uint32_t want = start + t;
+                unsigned long long lo = pos_offsets[at[t]], hi = pos_offsets[at[t] + 1];
+                while (lo < hi) {  // positions ascend
+                    const unsigned long long mid = lo + (hi - lo) / 2;
+                    if (positions[mid] < want) lo = mid + 1;
+                    else hi = mid;
+                }
+                ok = lo < pos_offsets[at[t] + 1] && positions[lo] == want;
+            }
+            count += ok ? 1u : 0u;
+        }
+    }
+    tmp_tf[i0 - b0] = count;
+}
+
+hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const unsigned long long *pos_offsets,
+                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, hipStream_t s) {
+    if (n_driver == 0) return hipSuccess;
+    hipLaunchKernelGGL(phrase_match_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, pos_offsets, positions, ph, tmp_tf);
+    return hipGetLastError();
+}
+
+// matches (tmp_tf > 0) -> ascending (doc, tf) list; one block, running offset
+__global__ __launch_bounds__(256) void phrase_compact_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph,
+                                                             const uint32_t *tmp_tf, unsigned long long out_begin, uint32_t *out_ids,
+                                                             uint32_t *out_tfs, uint32_t *out_count) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const unsigned long long b0 = term_offsets[ph.terms[ph.driver]], e0 = term_offsets[ph.terms[ph.driver] + 1];
+    const uint32_t n = (uint32_t)(e0 - b0);
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        const uint32_t tf = i < n ? tmp_tf[i] : 0u;
+        const uint32_t c = tf ? 1u : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wib] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int w = 0; w < wib; w++) before += wave_sum[w];
+        if (c) {
+            out_ids[out_begin + before + incl - 1] = doc_ids[b0 + i];
+            out_tfs[out_begin + before + incl - 1] = tf;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = base_s;
+}
+
+hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
+                                 unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs, uint32_t *out_count, hipStream_t s) {
+    hipLaunchKernelGGL(phrase_compact_kernel, dim3(1), dim3(256), 0, s, term_offsets, doc_ids, ph, tmp_tf, out_begin, out_ids, out_tfs, out_count);
+    return hipGetLastError();
+}
+
 // ---- facet counts -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void facet_count_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids,
                                                           const uint32_t *pair_term, const int *pair_slot, const uint32_t *match_bits,

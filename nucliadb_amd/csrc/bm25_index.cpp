@@ -50,12 +50,14 @@ struct Bm25Segment {
     uint32_t n_docs = 0, n_terms = 0;
     std::vector<uint64_t> term_offsets_host;
     DevBuf term_offsets, doc_ids, tfs, fieldnorm_ids, alive;
+    DevBuf pos_offsets, positions;  // positions of every posting (phrase queries); absent when the caller gave none
     bool all_alive = true;
     // fast fields (created, modified): host values + their dense ranks in HBM (the kernel orders by rank)
     std::vector<int64_t> fast_host[2];
     DevBuf order_key[2];
     uint64_t bytes() const {
-        return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes + order_key[0].bytes + order_key[1].bytes;
+        return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes + order_key[0].bytes + order_key[1].bytes +
+               pos_offsets.bytes + positions.bytes;
     }
 };
 
@@ -71,6 +73,7 @@ struct Bm25Index {
     // term dictionary (fuzzy expansion) and the scratch of the collectors
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
+    DevBuf s_phrase_tf, s_aux_tfs;
     DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
         s_facet_counts;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
@@ -123,6 +126,14 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
             size_t words = ((size_t)in.n_docs + 63) / 64;
             NIDX_HIP(seg.alive.alloc(std::max<size_t>(words, 1) * 8));
             if (words) NIDX_HIP(hipMemcpy(seg.alive.p, in.alive_bitset, words * 8, hipMemcpyHostToDevice));
+        }
+        if (in.pos_offsets && n_post) {
+            const uint64_t n_pos = in.pos_offsets[n_post];
+            if (n_pos && !in.positions) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: pos_offsets without positions", s);
+            NIDX_HIP(seg.pos_offsets.alloc((size_t)(n_post + 1) * 8));
+            NIDX_HIP(hipMemcpy(seg.pos_offsets.p, in.pos_offsets, (size_t)(n_post + 1) * 8, hipMemcpyHostToDevice));
+            NIDX_HIP(seg.positions.alloc(std::max<uint64_t>(n_pos, 1) * 4));
+            if (n_pos) NIDX_HIP(hipMemcpy(seg.positions.p, in.positions, n_pos * 4, hipMemcpyHostToDevice));
         }
         idx->total_docs += in.n_docs;
         idx->total_tokens += in.total_num_tokens;
@@ -273,6 +284,18 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         return fail(NIDX_ERR_INVALID_ARGUMENT, "term sets without terms");
     for (uint64_t i = 0; n_sets && i < opt->term_set_offsets[n_sets]; i++)
         if (opt->term_set_terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term set: term id %u out of range", opt->term_set_terms[i]);
+    const uint32_t n_phrases = opt->n_phrases;
+    if (n_phrases && (!opt->phrase_offsets || !opt->phrase_terms)) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrases without terms");
+    for (uint32_t j = 0; j < n_phrases; j++) {
+        const uint64_t m = opt->phrase_offsets[j + 1] - opt->phrase_offsets[j];
+        if (m == 0 || m > BM25_MAX_PHRASE_TERMS)
+            return fail(NIDX_ERR_UNSUPPORTED, "a phrase has 1..%d terms (got %llu)", BM25_MAX_PHRASE_TERMS, (unsigned long long)m);
+        for (uint64_t i = opt->phrase_offsets[j]; i < opt->phrase_offsets[j + 1]; i++)
+            if (opt->phrase_terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase: term id %u out of range", opt->phrase_terms[i]);
+    }
+    if (n_phrases)
+        for (const Bm25Segment &sg : idx->segs)
+            if (sg.term_offsets_host[idx->n_terms] && !sg.pos_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase clause on an index opened without positions");
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
@@ -285,6 +308,20 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     for (uint64_t c = 0; c < n_clauses; c++) {
         const nidx_gpu_bm25_clause_t &cl = clauses[c];
         if (cl.occur < 0 || cl.occur > 3 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        if (!(cl.term & NIDX_BM25_TERM_SET) && (cl.term & NIDX_BM25_PHRASE)) {
+            const uint32_t j = cl.term & ~NIDX_BM25_PHRASE;
+            if (j >= n_phrases) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase %u out of range", j);
+            // Bm25Weight::for_terms: the idf of every term, summed in order
+            float idf_sum = 0.0f;
+            for (uint64_t i = opt->phrase_offsets[j]; i < opt->phrase_offsets[j + 1]; i++) {
+                uint64_t df = 0;
+                for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[opt->phrase_terms[i] + 1] - sg.term_offsets_host[opt->phrase_terms[i]];
+                idf_sum += bm25_idf(df, idx->total_docs);
+            }
+            // the phrase's matches are materialised per segment as aux list n_sets + j, with their frequencies
+            dev_clauses[c] = Bm25ClauseDev{BM25_AUX_TERM | (n_sets + j), cl.occur, NIDX_TF_FREQ, idf_sum * (1.0f + kK1) * cl.boost};
+            continue;
+        }
         if (cl.term & NIDX_BM25_TERM_SET) {
             if ((cl.term & ~NIDX_BM25_TERM_SET) >= n_sets) return fail(NIDX_ERR_INVALID_ARGUMENT, "term set %u out of range", cl.term & ~NIDX_BM25_TERM_SET);
             dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, NIDX_CONST_SCORE, cl.boost};  // ConstScorer(boost)
@@ -351,22 +388,54 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
         // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
-        std::vector<unsigned long long> aux_pairs(2 * (size_t)n_sets + 2, 0);  // [begin, end) per set into s_aux_ids
-        std::vector<uint32_t> set_counts(n_sets, 0);
+        const uint32_t n_aux = n_sets + n_phrases;
+        std::vector<unsigned long long> aux_pairs(2 * (size_t)n_aux + 2, 0);  // [begin, end) per aux list into s_aux_ids
+        std::vector<uint32_t> set_counts(n_aux, 0);
+        // layout of the aux arrays: the term sets first (upper bounds), then one region per phrase (driver term's df)
+        std::vector<unsigned long long> out_off(n_aux + 1, 0);
+        std::vector<PhraseDev> phrases(n_phrases);
+        for (uint32_t j = 0; j < n_sets; j++) {
+            uint64_t df = 0;
+            for (uint64_t i = opt->term_set_offsets[j]; i < opt->term_set_offsets[j + 1]; i++)
+                df += seg.term_offsets_host[opt->term_set_terms[i] + 1] - seg.term_offsets_host[opt->term_set_terms[i]];
+            const bool comp = opt->term_set_complement && opt->term_set_complement[j];
+            out_off[j + 1] = out_off[j] + (comp ? (uint64_t)seg.n_docs : std::min<uint64_t>(df, seg.n_docs));
+        }
+        for (uint32_t j = 0; j < n_phrases; j++) {
+            PhraseDev &ph = phrases[j];
+            ph.n_terms = (uint32_t)(opt->phrase_offsets[j + 1] - opt->phrase_offsets[j]);
+            uint64_t best = ~0ull;
+            for (uint32_t t = 0; t < ph.n_terms; t++) {
+                ph.terms[t] = opt->phrase_terms[opt->phrase_offsets[j] + t];
+                const uint64_t df = seg.term_offsets_host[ph.terms[t] + 1] - seg.term_offsets_host[ph.terms[t]];
+                if (df < best) { best = df; ph.driver = t; }
+            }
+            out_off[n_sets + j + 1] = out_off[n_sets + j] + best;
+        }
+        if (n_aux) {
+            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4));
+            NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4));
+            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_aux * 4));
+            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, (size_t)n_aux * 4, idx->stream));
+        }
+        for (uint32_t j = 0; j < n_phrases; j++) {
+            const uint64_t n_driver = out_off[n_sets + j + 1] - out_off[n_sets + j];
+            if (n_driver == 0) continue;
+            NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 4));
+            NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.pos_offsets.as<unsigned long long>(),
+                                         seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, idx->s_phrase_tf.as<uint32_t>(), idx->stream));
+            NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], idx->s_phrase_tf.as<uint32_t>(),
+                                           out_off[n_sets + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
+                                           idx->s_set_counts.as<uint32_t>() + n_sets + j, idx->stream));
+        }
+        if (n_phrases) {
+            NIDX_HIP(hipMemcpyAsync(set_counts.data() + n_sets, idx->s_set_counts.as<uint32_t>() + n_sets, (size_t)n_phrases * 4, hipMemcpyDeviceToHost, idx->stream));
+            NIDX_HIP(hipStreamSynchronize(idx->stream));
+        }
         if (n_sets) {
             const uint32_t words = (seg.n_docs + 63) / 64;
-            std::vector<unsigned long long> out_off(n_sets + 1, 0);
-            for (uint32_t j = 0; j < n_sets; j++) {
-                uint64_t df = 0;
-                for (uint64_t i = opt->term_set_offsets[j]; i < opt->term_set_offsets[j + 1]; i++)
-                    df += seg.term_offsets_host[opt->term_set_terms[i] + 1] - seg.term_offsets_host[opt->term_set_terms[i]];
-                const bool comp = opt->term_set_complement && opt->term_set_complement[j];
-                out_off[j + 1] = out_off[j] + (comp ? (uint64_t)seg.n_docs : std::min<uint64_t>(df, seg.n_docs));
-            }
             NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
             NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_sets + 1) * 8));
-            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_sets], 1) * 4));
-            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_sets * 4));
             NIDX_HIP(hipMemcpyAsync(idx->s_aux_out_off.p, out_off.data(), (size_t)(n_sets + 1) * 8, hipMemcpyHostToDevice, idx->stream));
             if (words) {
                 NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, idx->stream));
@@ -384,7 +453,9 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                 NIDX_HIP(hipMemcpyAsync(set_counts.data(), idx->s_set_counts.p, (size_t)n_sets * 4, hipMemcpyDeviceToHost, idx->stream));
                 NIDX_HIP(hipStreamSynchronize(idx->stream));
             }
-            for (uint32_t j = 0; j < n_sets; j++) {
+        }
+        if (n_aux) {
+            for (uint32_t j = 0; j < n_aux; j++) {
                 aux_pairs[2 * j] = out_off[j];
                 aux_pairs[2 * j + 1] = out_off[j] + set_counts[j];
             }
@@ -393,6 +464,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         }
         auto postings_of = [&](const nidx_gpu_bm25_clause_t &cl) -> uint64_t {
             if (cl.term & NIDX_BM25_TERM_SET) return set_counts[cl.term & ~NIDX_BM25_TERM_SET];
+            if (cl.term & NIDX_BM25_PHRASE) return set_counts[n_sets + (cl.term & ~NIDX_BM25_PHRASE)];
             return seg.term_offsets_host[cl.term + 1] - seg.term_offsets_host[cl.term];
         };
         // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
@@ -449,8 +521,9 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         a.out_count = idx->s_count.as<uint32_t>();
         a.out_total = idx->s_total.as<unsigned long long>();
         a.out_postings = idx->s_postings.as<unsigned long long>();
-        a.aux_offsets = n_sets ? idx->s_aux_off.as<unsigned long long>() : nullptr;
-        a.aux_doc_ids = n_sets ? idx->s_aux_ids.as<uint32_t>() : nullptr;
+        a.aux_offsets = n_aux ? idx->s_aux_off.as<unsigned long long>() : nullptr;
+        a.aux_doc_ids = n_aux ? idx->s_aux_ids.as<uint32_t>() : nullptr;
+        a.aux_tfs = n_aux ? idx->s_aux_tfs.as<uint32_t>() : nullptr;
         a.order_key = order_field >= 0 ? seg.order_key[order_field].as<uint32_t>() : nullptr;
         a.order_desc = opt->order_desc ? 1 : 0;
         a.match_bits = n_slots ? idx->s_match_bits.as<uint32_t>() : nullptr;

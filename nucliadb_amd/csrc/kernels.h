@@ -267,7 +267,8 @@ struct Bm25Args {
     unsigned long long *dbg;  // nullptr, or 6 counters: cycles load/apply/fold/total, windows, work items
     // term sets (FuzzyTermQuery): clause.term = BM25_AUX_TERM | j reads the materialised union list j
     const unsigned long long *aux_offsets;  // [n_sets][2]: begin, end into aux_doc_ids
-    const uint32_t *aux_doc_ids;            // ascending doc ids of each union
+    const uint32_t *aux_doc_ids;            // ascending doc ids of each union / phrase
+    const uint32_t *aux_tfs;                // phrase frequencies (parallel to aux_doc_ids; read for phrase lists only)
     // TopDocs::order_by_fast_field: per-doc dense rank of the fast value (nullptr = order by score)
     const uint32_t *order_key;
     int order_desc;
@@ -299,6 +300,19 @@ hipError_t launch_fuzzy_match(const uint8_t *dict_bytes, const unsigned long lon
 // set bits -> ascending ids (one block per bitset): out[out_offsets[b] ..), counts[b] = number written
 hipError_t launch_bitset_compact(const uint64_t *bits, uint32_t n_words, uint32_t n_sets, const unsigned long long *out_offsets,
                                  uint32_t *out, uint32_t *counts, hipStream_t s);
+// PhraseQuery (slop 0): for every posting i of the driver term (the rarest of the phrase) tmp_tf[i] = number of start
+// positions at which all terms follow each other in order (0 = the document does not match); then the matches are
+// compacted in document order into (out_ids, out_tfs)[out_begin ..) and *out_count is set.
+struct PhraseDev {
+    uint32_t terms[8];     // phrase terms in order
+    uint32_t n_terms;      // <= 8
+    uint32_t driver;       // index into terms[] of the term whose postings are walked
+};
+#define BM25_MAX_PHRASE_TERMS 8
+hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const unsigned long long *pos_offsets,
+                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, hipStream_t s);
+hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
+                                 unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs, uint32_t *out_count, hipStream_t s);
 // FacetCollector: counts[p] += |postings(term[p]) ∩ match bitset slot[p]|
 hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *pair_term,
                               const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,

@@ -1297,6 +1297,43 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
         if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
+        if (is_set && cl->set_phrase) {
+            /* PhraseQuery: walk the first term's postings, look the document up in the others', count the start positions */
+            float idf_sum = 0.0f;
+            for (size_t t = 0; t < n_lists; t++) {
+                uint64_t b = idx->term_offsets[cl->set_terms[t]], e = idx->term_offsets[cl->set_terms[t] + 1];
+                idf_sum += orc_bm25_idf(e - b, idx->n_docs);
+            }
+            float weight = idf_sum * (1.0f + BM25_K1) * cl->boost;
+            uint64_t b0 = idx->term_offsets[cl->set_terms[0]], e0 = idx->term_offsets[cl->set_terms[0] + 1];
+            for (uint64_t i0 = b0; i0 < e0 && idx->pos_offsets; i0++) {
+                uint32_t d = idx->doc_ids[i0];
+                uint32_t count = 0;
+                for (uint64_t pi = idx->pos_offsets[i0]; pi < idx->pos_offsets[i0 + 1]; pi++) {
+                    uint32_t p = idx->positions[pi];
+                    int all = 1;
+                    for (size_t t = 1; t < n_lists && all; t++) {
+                        uint64_t b = idx->term_offsets[cl->set_terms[t]], e = idx->term_offsets[cl->set_terms[t] + 1];
+                        int found = 0;
+                        for (uint64_t i = b; i < e && !found; i++) {
+                            if (idx->doc_ids[i] != d) continue;
+                            for (uint64_t pj = idx->pos_offsets[i]; pj < idx->pos_offsets[i + 1]; pj++)
+                                if (idx->positions[pj] == p + (uint32_t)t) { found = 1; break; }
+                        }
+                        all = found;
+                    }
+                    count += (uint32_t)all;
+                }
+                if (count == 0) continue;
+                if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
+                float tf = (float)count;
+                acc[d] = acc[d] + weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
+                if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
+                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else should_hit[d] = 1;
+            }
+            continue;
+        }
         if (is_set && cl->set_complement) {
             /* every document outside the union, once */
             for (size_t t = 0; t < n_lists; t++) {

@@ -178,6 +178,10 @@ typedef struct {
     const uint32_t *tfs;
     const uint8_t *fieldnorm_ids;  /* [n_docs] */
     const uint64_t *alive;         /* bitset or NULL */
+    /* positions of every posting (IndexRecordOption::WithFreqsAndPositions): posting i owns
+     * positions[pos_offsets[i] .. pos_offsets[i+1]) ascending; NULL = no positions (no phrase clauses) */
+    const uint64_t *pos_offsets;
+    const uint32_t *positions;
 } orc_bm25_index;
 
 /* ORC_OCCUR_SHOULD_GROUP: a Should clause of a nested Must(BooleanQuery[Should..]) — the shape of
@@ -199,6 +203,10 @@ typedef struct {
     /* set_complement != 0: the clause matches every document NOT in the union — parse_excluded's
      * BooleanQuery[Must AllQuery, MustNot term] (query_parser/keyword_parser.rs:93-105), scored AllQuery's 1.0 * boost */
     int set_complement;
+    /* set_phrase != 0: PhraseQuery(set_terms) with slop 0 (tantivy PhraseWeight / PhraseScorer restated): a document
+     * matches when the terms occur at consecutive positions in this order; tf = the number of such occurrences,
+     * weight = (sum of the terms' idf, in term order) * (1 + K1) * boost (Bm25Weight::for_terms) */
+    int set_phrase;
 } orc_bm25_clause;
 
 typedef struct {

@@ -72,12 +72,14 @@ class _Bm25Index(C.Structure):
         ("tfs", C.c_void_p),
         ("fieldnorm_ids", C.c_void_p),
         ("alive", C.c_void_p),
+        ("pos_offsets", C.c_void_p),
+        ("positions", C.c_void_p),
     ]
 
 
 class _Bm25Clause(C.Structure):
     _fields_ = [("term", C.c_uint32), ("occur", C.c_int), ("mode", C.c_int), ("boost", C.c_float),
-                ("set_terms", C.c_void_p), ("n_set_terms", C.c_uint32), ("set_complement", C.c_int)]
+                ("set_terms", C.c_void_p), ("n_set_terms", C.c_uint32), ("set_complement", C.c_int), ("set_phrase", C.c_int)]
 
 
 class _SearchAfter(C.Structure):
@@ -552,7 +554,9 @@ def bm25_tf_cache(avg: float) -> np.ndarray:
 
 
 class Bm25Index:
-    def __init__(self, term_offsets, doc_ids, tfs, fieldnorm_ids, total_num_tokens, alive=None):
+    def __init__(self, term_offsets, doc_ids, tfs, fieldnorm_ids, total_num_tokens, alive=None, pos_offsets=None, positions=None):
+        self.pos_offsets = None if pos_offsets is None else np.ascontiguousarray(pos_offsets, dtype=np.uint64)
+        self.positions = None if positions is None else np.ascontiguousarray(positions, dtype=np.uint32)
         self.term_offsets = np.ascontiguousarray(term_offsets, dtype=np.uint64)
         self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.uint32)
         self.tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
@@ -570,6 +574,8 @@ class Bm25Index:
         s.tfs = self.tfs.ctypes.data
         s.fieldnorm_ids = self.fieldnorm_ids.ctypes.data
         s.alive = None if self.alive is None else self.alive.ctypes.data
+        s.pos_offsets = None if self.pos_offsets is None else self.pos_offsets.ctypes.data
+        s.positions = None if self.positions is None else self.positions.ctypes.data
         return s
 
     def _clauses(self, clauses):
@@ -583,6 +589,7 @@ class Bm25Index:
                 keep.append(ts)
                 cl[i].set_terms, cl[i].n_set_terms = ts.ctypes.data, ts.size
                 cl[i].set_complement = int(len(c) > 5 and bool(c[5]))
+                cl[i].set_phrase = int(len(c) > 6 and bool(c[6]))
                 if ts.size == 0:  # an empty expansion matches nothing: an always-empty list stands for it
                     raise ValueError("empty term set: map it to an empty term")
         return cl, keep

@@ -179,3 +179,40 @@ def test_two_segments_merge_by_fast_field(orc):
             assert r["order_value"][qi, :cnt].tolist() == [-h[0] for h in hits[:cnt]]
     finally:
         s.close()
+
+
+def test_phrase_clauses_match_oracle(orc):
+    """PhraseQuery with slop 0 (tantivy PhraseWeight / PhraseScorer restated; nidx_paragraph keyword_parser.rs:69-91, nidx_text's
+    QueryParser): consecutive positions in order, tf = occurrences, Bm25Weight::for_terms (idf summed over the terms)."""
+    rng = np.random.default_rng(41)
+    vocab = 40                     # small vocabulary: phrases of 2-4 terms really occur
+    docs = [rng.integers(0, vocab, int(rng.integers(3, 40))) for _ in range(6000)]
+    docs[10] = np.array([1, 2, 3, 1, 2, 3, 1, 2], np.int64)    # repeated phrase: tf 2 / 3
+    docs[11] = np.array([5, 5, 5, 5], np.int64)                # the same term at consecutive positions
+    seg = Bm25Segment.from_term_docs(docs, vocab, with_positions=True)
+    s = Bm25Searcher.open([seg])
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive, seg.pos_offsets, seg.positions)
+    queries = []
+    for _ in range(40):
+        m = int(rng.integers(2, 5))
+        q = [Clause(0, int(rng.choice([S, M, G])), FREQ, float(rng.choice([1.0, 0.5])), term_set=rng.integers(0, vocab, m).tolist(), phrase=True)]
+        if rng.random() < 0.5:
+            q.append(Clause(int(rng.integers(0, vocab)), S, BASIC))
+        if rng.random() < 0.3:
+            q.append(Clause(0, N, FREQ, 1.0, term_set=rng.integers(0, vocab, 2).tolist(), phrase=True))
+        queries.append(q)
+    queries.append([Clause(0, M, FREQ, 1.0, term_set=[1, 2, 3], phrase=True)])
+    queries.append([Clause(0, M, FREQ, 1.0, term_set=[5, 5], phrase=True)])
+    queries.append([Clause(0, M, FREQ, 1.0, term_set=[1, 2, 3, 1, 2, 3, 1, 2], phrase=True)])   # 8 terms: the maximum
+    try:
+        r = s.search_batch_ex(queries, 20)
+        for i, q in enumerate(queries):
+            oc = [(c.term, c.occur, c.mode, c.boost, None if c.term_set is None else list(c.term_set), False, c.phrase) for c in q]
+            wd, ws, _, wt, _ = oidx.search_ex(oc, 20)
+            n = int(r["count"][i])
+            assert r["total"][i] == wt, (i, r["total"][i], wt)
+            assert n == len(wd) and np.array_equal(r["docaddr"][i, :n], wd), (i, r["docaddr"][i, :n], wd)
+            assert np.array_equal(bits(r["score"][i, :n]), bits(ws)), (i, r["score"][i, :n], ws)
+        assert r["total"][-3] >= 1 and 10 in (r["docaddr"][-3, : r["count"][-3]] & 0xFFFFFFFF).tolist()
+    finally:
+        s.close()
