@@ -20,8 +20,8 @@ Must clauses `repeated_in_field:0` (unless with_duplicates) and label filters; t
 a FuzzyTermQuery (Levenshtein 1, the last literal as a prefix when >= 4 characters) expanded against the term
 dictionary on the device and scored ConstScorer(0.5).  Both searchers collect FACETS (FacetCollector, top 50
 children per requested facet) and can ORDER by the created / modified fast fields.  `-excluded` words are
-Should(everything but the word): the complement of the posting list, built on the device.  Multi-word quoted
-phrases need positions (PhraseQuery) and raise NotImplementedError.
+Should(everything but the word): the complement of the posting list, built on the device.  Multi-word quotes are
+PhraseQuery's (positions in HBM, phrase lists materialised on the device).
 """
 from __future__ import annotations
 
@@ -98,14 +98,25 @@ class TextSegment:
             docs.extend([i] * len(extra))
         terms = np.array(terms, dtype=np.int64)
         docs = np.array(docs, dtype=np.int64)
-        uniq, counts = np.unique(terms * (n + 1) + docs, return_counts=True)
+        # positions: token index inside the text field; pseudo terms (all / labels / repeated) sit at position 0
+        pos = []
+        for i, (d, st) in enumerate(zip(self.docs, self.streams)):
+            pos.extend(range(len(st)))
+            n_extra = 1 + (0 if d.repeated_in_field else 1) + len({anc for lab in d.labels for anc in facet_ancestors(lab)})
+            pos.extend([0] * n_extra)
+        pos = np.array(pos, dtype=np.int64)
+        key = terms * (n + 1) + docs
+        uniq, counts = np.unique(key, return_counts=True)
+        order = np.lexsort((pos, key))
+        positions = pos[order].astype(np.uint32)
+        pos_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
         t, dd = uniq // (n + 1), uniq % (n + 1)
         term_offsets = np.zeros(n_terms + 1, dtype=np.uint64)
         np.add.at(term_offsets, t + 1, 1)
         term_offsets = np.cumsum(term_offsets).astype(np.uint64)
         table = np.array([L.nidx_gpu_fieldnorm_from_id(i) for i in range(256)], dtype=np.int64)
         ids = (np.searchsorted(table, lens, side="right") - 1).astype(np.uint8)
-        return Bm25Segment(term_offsets, dd.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive)
+        return Bm25Segment(term_offsets, dd.astype(np.uint32), counts.astype(np.uint32), ids, int(lens.sum()), alive, pos_offsets, positions)
 
 
 def facet_ancestors(label: str) -> List[str]:
@@ -252,14 +263,24 @@ class TextSearcher:
         self._index.close()
 
     def _clauses(self, request: DocumentSearchRequest) -> List[Clause]:
-        words = tokenize(request.body)
-        if any(ch in request.body for ch in '"-+():^~*'):
-            raise NotImplementedError("only plain conjunctive term queries are term-clause shaped")
-        clauses = []
-        if not words:  # create_query: empty text => AllQuery (search_query.rs:100-104)
+        body = request.body
+        if any(ch in body for ch in '+():^~*') or body.count('"') % 2:
+            raise NotImplementedError("tantivy's query grammar beyond words and \"phrases\" is not mirrored")
+        # QueryParser with set_conjunction_by_default (reader.rs:372-377): every word is a Must TermQuery with frequencies,
+        # every "quoted run" a Must PhraseQuery (one word: a TermQuery)
+        parts = body.split('"')
+        clauses, any_token = [], False
+        for i, part in enumerate(parts):
+            words = tokenize(part)
+            if not words:
+                continue
+            any_token = True
+            if i % 2 == 1 and len(words) > 1:
+                clauses.append(Clause(0, _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0, term_set=[self._index.term(w) for w in words], phrase=True))
+            else:
+                clauses += [Clause(self._index.term(w), _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0) for w in words]
+        if not any_token:  # create_query: empty text => AllQuery (search_query.rs:100-104)
             clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
-        for w in words:  # set_conjunction_by_default: every term is a Must TermQuery with frequencies
-            clauses.append(Clause(self._index.term(w), _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0))
         for lab in request.label_filter or []:
             # filter clauses score too in tantivy's BooleanQuery; facet TermQuerys carry no frequencies
             clauses.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0))
@@ -414,11 +435,15 @@ class ParagraphSearcher:
         return musts
 
     def _tokens(self, request: ParagraphSearchRequest) -> List[Tuple[str, str]]:
-        tokens = parse_query(request.body, self.stop_words)
-        for kind, text in tokens:
-            if kind == "quoted" and " " in text:
-                raise NotImplementedError("multi-word quoted phrases need positions (PhraseQuery)")
-        return tokens
+        return parse_query(request.body, self.stop_words)
+
+    def _word_or_phrase(self, kind: str, text: str, boost: float) -> Clause:
+        """parse_literal / parse_quoted (keyword_parser.rs:62-91): a word is TermQuery(Basic); a quote of several words is
+        PhraseQuery(words)"""
+        words = text.split(" ")
+        if kind == "quoted" and len(words) > 1:
+            return Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.TF_FREQ, boost, term_set=[self._index.term(w) for w in words], phrase=True)
+        return Clause(self._index.term(text), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, boost)
 
     def _clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
         """The keyword query (keyword_parser.rs:27-105 under search_query.rs:185-243)."""
@@ -428,8 +453,7 @@ class ParagraphSearcher:
             clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
         # TermQuery(text, IndexRecordOption::Basic) per literal / one-word quote, Occur::Should, as a required group: the
         # keyword BooleanQuery sits under Occur::Must next to the filters, so a paragraph has to match one of its words
-        should = [self._excluded(w, 1.0) if kind == "excluded" else Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, 1.0)
-                  for kind, w in tokens]
+        should = [self._excluded(w, 1.0) if kind == "excluded" else self._word_or_phrase(kind, w, 1.0) for kind, w in tokens]
         return clauses + should + self._filters(request, 1.0)
 
     def _excluded(self, word: str, boost: float) -> Clause:
@@ -450,8 +474,8 @@ class ParagraphSearcher:
             if kind == "excluded":
                 clauses.append(self._excluded(w, boost))
                 continue
-            if kind == "quoted" or len(w.encode("utf-8")) < MIN_FUZZY_LEN:  # too short to be fuzzy: the exact term
-                clauses.append(Clause(self._index.term(w), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, boost))
+            if kind == "quoted" or len(w.encode("utf-8")) < MIN_FUZZY_LEN:  # quotes stay exact; too short to be fuzzy
+                clauses.append(self._word_or_phrase(kind, w, boost))
                 continue
             prefix = i == last_literal and len(w.encode("utf-8")) >= MIN_FUZZY_PREFIX_LEN
             members = self._index.fuzzy_terms(w, prefix) or [self._index.empty_term]

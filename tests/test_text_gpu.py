@@ -255,3 +255,37 @@ def test_excluded_words(orc):
         assert r["total"][i] == wt and n == len(wd)
         assert np.array_equal(r["docaddr"][i, :n], wd) and np.array_equal(r["score"][i, :n].view(np.uint32), ws.view(np.uint32))
     bs.close()
+
+
+def test_quoted_phrases():
+    """nidx_text/tests/test_search.rs:32-73 (test_search_queries): a quoted run is a PhraseQuery — the words have to follow each
+    other — while unquoted words are a conjunction; nidx_paragraph parse_quoted (keyword_parser.rs:69-91) likewise."""
+    vocab = Vocabulary()
+    s = TextSearcher.open([TextSegment(docs(), vocab)])
+
+    def total(q):
+        return s.search(DocumentSearchRequest(body=q, result_per_page=20)).total
+
+    assert total("") == 6
+    assert total("enough test for") == 1           # exact words, any order / distance (conjunction)
+    assert total('"enough test for"') == 1         # the exact run of r3
+    assert total("enough test") == 2 and total('"enough test"') == 2   # r2 "shoupd enough test", r3 "enough test for ..."
+    assert total("test enough") == 2 and total('"test enough"') == 0   # both words, but never in this order
+    assert total('"enough to"') == 0               # both words occur in r3, not next to each other
+    assert total('"should enough" test') == 0 and total('"should enough"') == 1
+    assert total("enough mischievous test") == 0   # a word nobody has
+    s.close()
+    p = ParagraphSearcher.open([TextSegment(docs(), vocab)])
+
+    def n(q):
+        r = p.search(ParagraphSearchRequest(body=q, result_per_page=20, with_duplicates=True))
+        return sorted(x.uuid for x in r.results), r.fuzzy
+
+    assert n('"enough test"') == (["r2", "r3"], False)
+    assert n('"test enough"') == ([], True)                     # quotes never go fuzzy: the fallback finds nothing either
+    assert n('"test enough" should') == (["r1"], False)         # Should semantics: the literal still matches
+    assert n('"for it to be"')[0] == ["r3"]
+    # the phrase is BM25-scored with its frequency: r3 has "test" twice but the phrase "a test" once
+    r = p.search(ParagraphSearchRequest(body='"a test"', result_per_page=20, with_duplicates=True))
+    assert [x.uuid for x in r.results] == ["r3"] and r.results[0].score.bm25 > 0
+    p.close()
