@@ -402,6 +402,41 @@ int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t
 int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *query_utf8, uint32_t query_len,
                                   int32_t prefix, uint32_t *out_terms, uint32_t cap, uint32_t *n_out);
 
+/* TextReaderService::prefilter (nidx_text/src/reader.rs:148-180): the documents (fields) that satisfy a boolean
+ * filter expression, evaluated as bitset algebra on the device.  The expression is what filter_to_query
+ * (nidx_text/src/search_query.rs:156-223) and security_query (ibid. 66-90) build, flattened by the caller to a
+ * postfix nidx_gpu_filter_program_t whose posting lists are TERM IDS of this index (facet, field, uuid, group and
+ * text terms alike live in one term-id space here):
+ *   Facet / Field / Resource / single-token Keyword / security groups -> PUSH_LISTS over the term(s)
+ *   BoolAnd / BoolOr / BoolNot                                        -> AND / OR / NOT (NOT = AllQuery minus operand)
+ *   Date {field, since, until}                                        -> NIDX_FILTER_PUSH_RANGE a = index into `ranges`
+ *                                                                        (both bounds INCLUSIVE, search_query.rs:30-49;
+ *                                                                        neither present = AllQuery)
+ *   multi-token Keyword (query_io.rs:22-42, a PhraseQuery)            -> NIDX_FILTER_PUSH_PHRASE a = index into phrases
+ * Deleted documents never match.  out_docaddr receives the matches as (segment << 32) | doc, ascending, at most
+ * `capacity` of them; *n_matching is the full count (call again with a larger buffer when it exceeds capacity) and
+ * *num_docs the live documents of the index (searcher.num_docs()), so the caller derives PrefilterResult::
+ * None (0) / All (== num_docs) / Some exactly as reader.rs:166-179 does. */
+#define NIDX_FILTER_PUSH_RANGE 6
+#define NIDX_FILTER_PUSH_PHRASE 7
+typedef struct {
+    uint32_t field;      /* 0 = created, 1 = modified (nidx_gpu_bm25_set_fast_field) */
+    int32_t has_since;   /* value >= since */
+    int32_t has_until;   /* value <= until */
+    int32_t reserved;
+    int64_t since, until;
+} nidx_gpu_bm25_date_range_t;
+typedef struct {
+    nidx_gpu_filter_program_t program;
+    const nidx_gpu_bm25_date_range_t *ranges;
+    uint32_t n_ranges;
+    uint32_t n_phrases;
+    const uint32_t *phrase_terms;   /* term ids of phrase j: phrase_terms[phrase_offsets[j] .. phrase_offsets[j+1]) */
+    const uint64_t *phrase_offsets; /* [n_phrases + 1] */
+} nidx_gpu_bm25_prefilter_t;
+int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_prefilter_t *request,
+                                uint64_t *out_docaddr, uint64_t capacity, uint64_t *n_matching, uint64_t *num_docs);
+
 /* Device time (HIP events on the handle's stream) spent in the scoring kernel(s) of the last
  * nidx_gpu_bm25_search call, summed over segments. */
 int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out);

@@ -107,6 +107,17 @@ class FilterProgramC(C.Structure):
 
 
 FILTER_PUSH_LISTS, FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PUSH_ALL, FILTER_PUSH_NONE = 0, 1, 2, 3, 4, 5
+FILTER_PUSH_RANGE, FILTER_PUSH_PHRASE = 6, 7  # text-index prefilter only
+
+
+class Bm25DateRangeC(C.Structure):
+    _fields_ = [("field", C.c_uint32), ("has_since", C.c_int32), ("has_until", C.c_int32), ("reserved", C.c_int32),
+                ("since", C.c_int64), ("until", C.c_int64)]
+
+
+class Bm25PrefilterC(C.Structure):
+    _fields_ = [("program", FilterProgramC), ("ranges", C.c_void_p), ("n_ranges", C.c_uint32), ("n_phrases", C.c_uint32),
+                ("phrase_terms", C.c_void_p), ("phrase_offsets", C.c_void_p)]
 
 
 class VectorSearchParamsC(C.Structure):
@@ -187,6 +198,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_bm25_set_fast_field": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_bm25_set_dictionary": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_prefilter": (C.c_int32, [C.c_void_p, C.POINTER(Bm25PrefilterC), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_fuzzy_terms": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_bm25_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "nidx_gpu_bm25_idf": (C.c_float, [C.c_uint64, C.c_uint64]),

@@ -167,6 +167,31 @@ class Bm25Searcher:
                 return out[: n.value].copy()
             cap = n.value
 
+    def prefilter(self, ops: Sequence[Tuple[int, int, int]], lists: Sequence[int] = (), ranges: Sequence[Tuple[int, Optional[int], Optional[int]]] = (),
+                  phrases: Sequence[Sequence[int]] = ()) -> Tuple[np.ndarray, int]:
+        """TextReaderService::prefilter (nidx_text/src/reader.rs:148-180) on the device: `ops` is a postfix filter program
+        [(op, a, b)] over term ids `lists`, inclusive fast-field `ranges` [(field, since | None, until | None)] and
+        `phrases` (term-id tuples).  Returns (ascending docaddrs of the live matching documents, live documents of the index)."""
+        c_ops = (_lib.FilterOpC * max(1, len(ops)))(*[_lib.FilterOpC(*o) for o in ops])
+        c_lists = np.ascontiguousarray(lists, dtype=np.uint32)
+        c_ranges = (_lib.Bm25DateRangeC * max(1, len(ranges)))(
+            *[_lib.Bm25DateRangeC(f, int(lo is not None), int(hi is not None), 0, int(lo or 0), int(hi or 0)) for f, lo, hi in ranges])
+        p_terms = np.ascontiguousarray([t for ph in phrases for t in ph], dtype=np.uint32)
+        p_offs = np.zeros(len(phrases) + 1, np.uint64)
+        p_offs[1:] = np.cumsum([len(ph) for ph in phrases])
+        req = _lib.Bm25PrefilterC(
+            _lib.FilterProgramC(C.addressof(c_ops) if len(ops) else None, len(ops), c_lists.ctypes.data if c_lists.size else None, c_lists.size),
+            C.addressof(c_ranges) if len(ranges) else None, len(ranges), len(phrases),
+            p_terms.ctypes.data if p_terms.size else None, p_offs.ctypes.data)
+        n, live = C.c_uint64(0), C.c_uint64(0)
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, np.uint64)
+            _lib.check(_lib.lib().nidx_gpu_bm25_prefilter(self._handle, C.byref(req), out.ctypes.data, cap, C.byref(n), C.byref(live)))
+            if n.value <= cap:
+                return out[: n.value].copy(), live.value
+            cap = n.value
+
     def search_batch_ex(self, queries: Sequence[Sequence[Clause]], k: int, after: Optional[Sequence[Optional[SearchAfter]]] = None,
                         order_field: int = -1, order_desc: bool = True, facets: Optional[Sequence[Sequence[int]]] = None):
         """The collectors around the scoring (nidx_text/src/reader.rs:367-451): term-set clauses, TopDocs ordered by a

@@ -268,4 +268,120 @@ hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint
     return hipGetLastError();
 }
 
+
+// ---- prefilter (TextReaderService::prefilter, nidx_text/src/reader.rs:148-180) --------------------------------------
+// RangeQuery over a fast field, on its dense ranks: bit d = rank_lo <= order_key[d] <= rank_hi.  One lane per document, the
+// wave's ballot is the output word.
+__global__ __launch_bounds__(256) void rank_range_bits_kernel(const uint32_t *order_key, uint32_t n_docs, uint32_t rank_lo,
+                                                              uint32_t rank_hi, uint64_t *out) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = d < n_docs ? order_key[d] : 0u;  // ranks start at 1
+    const unsigned long long m = __ballot(r >= rank_lo && r <= rank_hi);
+    if ((threadIdx.x & 63) == 0 && (d >> 6) < ((n_docs + 63) >> 6)) out[d >> 6] = m;
+}
+
+hipError_t launch_rank_range_bits(const uint32_t *order_key, uint32_t n_docs, uint32_t rank_lo, uint32_t rank_hi, uint64_t *out,
+                                  hipStream_t s) {
+    if (n_docs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_range_bits_kernel, dim3((n_docs + 255) / 256), dim3(256), 0, s, order_key, n_docs, rank_lo, rank_hi, out);
+    return hipGetLastError();
+}
+
+// PhraseQuery as a filter: the driver term's documents whose phrase frequency (phrase_match_kernel) is non-zero.
+__global__ __launch_bounds__(256) void phrase_bits_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph,
+                                                          const uint32_t *tmp_tf, unsigned int *bits) {
+    const unsigned long long b0 = term_offsets[ph.terms[ph.driver]], e0 = term_offsets[ph.terms[ph.driver] + 1];
+    const unsigned long long i = b0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e0 || tmp_tf[i - b0] == 0) return;
+    const uint32_t d = doc_ids[i];
+    atomicOr(&bits[d >> 5], 1u << (d & 31));
+}
+
+hipError_t launch_phrase_bits(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, uint32_t n_driver,
+                              const uint32_t *tmp_tf, uint64_t *bits, hipStream_t s) {
+    if (n_driver == 0) return hipSuccess;
+    hipLaunchKernelGGL(phrase_bits_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, ph, tmp_tf,
+                       reinterpret_cast<unsigned int *>(bits));
+    return hipGetLastError();
+}
+
+// bitset -> ascending DocAddress list (segment << 32 | doc) in three small launches: per-block popcounts, one block scanning
+// them, then every block emits its slice at its base.  A block owns 256 words = 16384 documents.
+__global__ __launch_bounds__(256) void docaddr_count_kernel(const uint64_t *bits, uint32_t n_words, uint32_t *block_counts) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    uint32_t c = w < n_words ? (uint32_t)__popcll(bits[w]) : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// exclusive scan of block_counts in place (one block); total -> *total
+__global__ __launch_bounds__(256) void docaddr_scan_kernel(uint32_t *block_counts, uint32_t n_blocks, unsigned long long *total) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_blocks; i0 += 256) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        const uint32_t c = i < n_blocks ? block_counts[i] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wib] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int w = 0; w < wib; w++) before += wave_sum[w];
+        if (i < n_blocks) block_counts[i] = before + incl - c;
+        __syncthreads();
+        if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+    if (tid == 0) *total = base_s;
+}
+
+__global__ __launch_bounds__(256) void docaddr_emit_kernel(const uint64_t *bits, uint32_t n_words, const uint32_t *block_base,
+                                                           uint64_t segment_hi, unsigned long long out_begin, unsigned long long out_cap,
+                                                           uint64_t *out) {
+    __shared__ uint32_t wave_sum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const uint32_t w = blockIdx.x * 256u + (uint32_t)tid;
+    uint64_t x = w < n_words ? bits[w] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(x);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_sum[wib] = incl;
+    __syncthreads();
+    unsigned long long at = out_begin + block_base[blockIdx.x] + incl - c;
+    for (int i = 0; i < wib; i++) at += wave_sum[i];
+    while (x) {
+        const int b = __ffsll((long long)x) - 1;
+        x &= x - 1;
+        if (at < out_cap) out[at] = segment_hi | (uint64_t)(w * 64u + (uint32_t)b);
+        at++;
+    }
+}
+
+hipError_t launch_bitset_to_docaddr(const uint64_t *bits, uint32_t n_words, uint32_t segment, uint32_t *block_scratch,
+                                    unsigned long long *total, unsigned long long out_begin, unsigned long long out_cap, uint64_t *out,
+                                    hipStream_t s) {
+    if (n_words == 0) return hipMemsetAsync(total, 0, 8, s);
+    const uint32_t n_blocks = (n_words + 255) / 256;
+    hipLaunchKernelGGL(docaddr_count_kernel, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_scratch);
+    hipLaunchKernelGGL(docaddr_scan_kernel, dim3(1), dim3(256), 0, s, block_scratch, n_blocks, total);
+    hipLaunchKernelGGL(docaddr_emit_kernel, dim3(n_blocks), dim3(256), 0, s, bits, n_words, block_scratch, (uint64_t)segment << 32, out_begin,
+                       out_cap, out);
+    return hipGetLastError();
+}
+
 }  // namespace nidx

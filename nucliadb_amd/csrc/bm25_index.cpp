@@ -54,7 +54,9 @@ struct Bm25Segment {
     bool all_alive = true;
     // fast fields (created, modified): host values + their dense ranks in HBM (the kernel orders by rank)
     std::vector<int64_t> fast_host[2];
+    std::vector<int64_t> fast_uniq[2];  // the distinct values, ascending: value -> rank for range filters
     DevBuf order_key[2];
+    int64_t n_alive = -1;  // live documents, counted on first use
     uint64_t bytes() const {
         return term_offsets.bytes + doc_ids.bytes + tfs.bytes + fieldnorm_ids.bytes + alive.bytes + order_key[0].bytes + order_key[1].bytes +
                pos_offsets.bytes + positions.bytes;
@@ -76,6 +78,7 @@ struct Bm25Index {
     DevBuf s_phrase_tf, s_aux_tfs;
     DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
         s_facet_counts;
+    DevBuf s_pf_stack, s_pf_lists, s_pf_result, s_pf_blocks, s_pf_total, s_pf_out;  // prefilter
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
 };
@@ -195,6 +198,7 @@ int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segm
         rank[d] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), values[d]) - uniq.begin()) + 1u;
     NIDX_HIP(seg.order_key[field].alloc(std::max<size_t>(seg.n_docs, 1) * 4));
     if (seg.n_docs) NIDX_HIP(hipMemcpy(seg.order_key[field].p, rank.data(), (size_t)seg.n_docs * 4, hipMemcpyHostToDevice));
+    seg.fast_uniq[field] = std::move(uniq);
     return NIDX_OK;
 }
 
@@ -250,6 +254,172 @@ int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *q
             n++;
         }
     *n_out = n;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_prefilter_t *req, uint64_t *out_docaddr, uint64_t capacity,
+                                uint64_t *n_matching, uint64_t *num_docs) {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !req || !n_matching || (capacity && !out_docaddr)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    *n_matching = 0;
+    if (num_docs) *num_docs = 0;
+    const nidx_gpu_filter_program_t &prog = req->program;
+    if (prog.n_ops && !prog.ops) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program without ops");
+    // validate once (the term-id space is shared by the segments) and find the stack depth
+    int depth = 0, max_depth = 1;
+    for (uint32_t i = 0; i < prog.n_ops; i++) {
+        const nidx_gpu_filter_op_t &op = prog.ops[i];
+        switch (op.op) {
+            case NIDX_FILTER_PUSH_LISTS:
+                if (op.a > op.b || op.b > prog.n_lists || (op.b > op.a && !prog.lists))
+                    return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: list range out of bounds");
+                for (uint32_t l = op.a; l < op.b; l++)
+                    if (prog.lists[l] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: term id %u out of range", prog.lists[l]);
+                depth++;
+                break;
+            case NIDX_FILTER_PUSH_RANGE:
+                if (op.a >= req->n_ranges || !req->ranges) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: range %u out of bounds", op.a);
+                if (req->ranges[op.a].field > 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "range %u: unknown fast field %u", op.a, req->ranges[op.a].field);
+                depth++;
+                break;
+            case NIDX_FILTER_PUSH_PHRASE: {
+                if (op.a >= req->n_phrases || !req->phrase_offsets || !req->phrase_terms)
+                    return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: phrase %u out of bounds", op.a);
+                const uint64_t m = req->phrase_offsets[op.a + 1] - req->phrase_offsets[op.a];
+                if (m == 0 || m > BM25_MAX_PHRASE_TERMS)
+                    return fail(NIDX_ERR_UNSUPPORTED, "a phrase has 1..%d terms (got %llu)", BM25_MAX_PHRASE_TERMS, (unsigned long long)m);
+                for (uint64_t t = req->phrase_offsets[op.a]; t < req->phrase_offsets[op.a + 1]; t++)
+                    if (req->phrase_terms[t] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase: term id %u out of range", req->phrase_terms[t]);
+                depth++;
+                break;
+            }
+            case NIDX_FILTER_PUSH_ALL:
+            case NIDX_FILTER_PUSH_NONE: depth++; break;
+            case NIDX_FILTER_AND:
+            case NIDX_FILTER_OR:
+                if (depth < 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: stack underflow");
+                depth--;
+                break;
+            case NIDX_FILTER_NOT:
+                if (depth < 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: stack underflow");
+                break;
+            default: return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program: unknown op %d", op.op);
+        }
+        max_depth = std::max(max_depth, depth);
+    }
+    if (prog.n_ops && depth != 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program must leave exactly one bitset (leaves %d)", depth);
+    hipStream_t st = idx->stream;
+    if (prog.n_lists) {
+        NIDX_HIP(idx->s_pf_lists.reserve((size_t)prog.n_lists * 4));
+        NIDX_HIP(hipMemcpyAsync(idx->s_pf_lists.p, prog.lists, (size_t)prog.n_lists * 4, hipMemcpyHostToDevice, st));
+    }
+    NIDX_HIP(idx->s_pf_total.reserve(16));
+    NIDX_HIP(idx->s_pf_out.reserve(std::max<uint64_t>(capacity, 1) * 8));
+    uint64_t matched = 0, live = 0;
+    for (size_t si = 0; si < idx->segs.size(); si++) {
+        Bm25Segment &seg = idx->segs[si];
+        const uint32_t n_bits = seg.n_docs, words = (n_bits + 63) / 64;
+        if (words == 0) continue;
+        NIDX_HIP(idx->s_pf_stack.reserve((size_t)max_depth * words * 8));
+        NIDX_HIP(idx->s_pf_result.reserve((size_t)words * 8));
+        NIDX_HIP(idx->s_pf_blocks.reserve((size_t)((words + 255) / 256) * 4));
+        uint64_t *stack = idx->s_pf_stack.as<uint64_t>();
+        auto slot = [&](int d) { return stack + (size_t)d * words; };
+        unsigned long long *d_total = idx->s_pf_total.as<unsigned long long>();
+        if (seg.n_alive < 0) {  // searcher.num_docs(): documents not deleted
+            if (seg.all_alive) {
+                seg.n_alive = seg.n_docs;
+            } else {
+                NIDX_HIP(hipMemsetAsync(d_total, 0, 8, st));
+                NIDX_HIP(launch_bitset_fill(slot(0), words, n_bits, 1, st));
+                NIDX_HIP(launch_bitset_and_count(slot(0), seg.alive.as<uint64_t>(), idx->s_pf_result.as<uint64_t>(), words, d_total, st));
+                unsigned long long c = 0;
+                NIDX_HIP(hipMemcpyAsync(&c, d_total, 8, hipMemcpyDeviceToHost, st));
+                NIDX_HIP(hipStreamSynchronize(st));
+                seg.n_alive = (int64_t)c;
+            }
+        }
+        live += (uint64_t)seg.n_alive;
+        depth = 0;
+        if (prog.n_ops == 0) NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 1, st));
+        for (uint32_t i = 0; i < prog.n_ops; i++) {
+            const nidx_gpu_filter_op_t &op = prog.ops[i];
+            switch (op.op) {
+                case NIDX_FILTER_PUSH_LISTS:
+                    NIDX_HIP(launch_bitset_fill(slot(depth), words, n_bits, 0, st));
+                    NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
+                                                   idx->s_pf_lists.as<uint32_t>() + op.a, op.b - op.a, n_bits, slot(depth), st));
+                    depth++;
+                    break;
+                case NIDX_FILTER_PUSH_RANGE: {
+                    const nidx_gpu_bm25_date_range_t &r = req->ranges[op.a];
+                    if (!r.has_since && !r.has_until) {  // produce_date_range_query returns None -> AllQuery
+                        NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 1, st));
+                        break;
+                    }
+                    if (!seg.order_key[r.field].p) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %zu has no fast field %u (nidx_gpu_bm25_set_fast_field)", si, r.field);
+                    const std::vector<int64_t> &u = seg.fast_uniq[r.field];
+                    // ranks are 1-based positions in the distinct values: first value >= since .. last value <= until
+                    const uint32_t lo = r.has_since ? (uint32_t)(std::lower_bound(u.begin(), u.end(), r.since) - u.begin()) + 1u : 1u;
+                    const uint32_t hi = r.has_until ? (uint32_t)(std::upper_bound(u.begin(), u.end(), r.until) - u.begin()) : (uint32_t)u.size();
+                    if (lo > hi) NIDX_HIP(launch_bitset_fill(slot(depth), words, n_bits, 0, st));
+                    else NIDX_HIP(launch_rank_range_bits(seg.order_key[r.field].as<uint32_t>(), n_bits, lo, hi, slot(depth), st));
+                    depth++;
+                    break;
+                }
+                case NIDX_FILTER_PUSH_PHRASE: {
+                    PhraseDev ph;
+                    ph.n_terms = (uint32_t)(req->phrase_offsets[op.a + 1] - req->phrase_offsets[op.a]);
+                    uint64_t best = ~0ull;
+                    ph.driver = 0;
+                    for (uint32_t t = 0; t < ph.n_terms; t++) {
+                        ph.terms[t] = req->phrase_terms[req->phrase_offsets[op.a] + t];
+                        const uint64_t df = seg.term_offsets_host[ph.terms[t] + 1] - seg.term_offsets_host[ph.terms[t]];
+                        if (df < best) { best = df; ph.driver = t; }
+                    }
+                    NIDX_HIP(launch_bitset_fill(slot(depth), words, n_bits, 0, st));
+                    if (best) {
+                        if (!seg.pos_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase filter on an index opened without positions");
+                        NIDX_HIP(idx->s_phrase_tf.reserve(best * 4));
+                        NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
+                                                     seg.pos_offsets.as<unsigned long long>(), seg.positions.as<uint32_t>(), ph, (uint32_t)best,
+                                                     idx->s_phrase_tf.as<uint32_t>(), st));
+                        NIDX_HIP(launch_phrase_bits(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), ph, (uint32_t)best,
+                                                    idx->s_phrase_tf.as<uint32_t>(), slot(depth), st));
+                    }
+                    depth++;
+                    break;
+                }
+                case NIDX_FILTER_PUSH_ALL: NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 1, st)); break;
+                case NIDX_FILTER_PUSH_NONE: NIDX_HIP(launch_bitset_fill(slot(depth++), words, n_bits, 0, st)); break;
+                case NIDX_FILTER_AND:
+                case NIDX_FILTER_OR:
+                    NIDX_HIP(launch_bitset_binop(slot(depth - 2), slot(depth - 1), words, op.op == NIDX_FILTER_AND ? 0 : 1, st));
+                    depth--;
+                    break;
+                case NIDX_FILTER_NOT: NIDX_HIP(launch_bitset_not(slot(depth - 1), words, n_bits, st)); break;
+            }
+        }
+        NIDX_HIP(hipMemsetAsync(d_total, 0, 16, st));
+        NIDX_HIP(launch_bitset_and_count(slot(0), seg.all_alive ? nullptr : seg.alive.as<uint64_t>(), idx->s_pf_result.as<uint64_t>(), words,
+                                         d_total, st));
+        NIDX_HIP(launch_bitset_to_docaddr(idx->s_pf_result.as<uint64_t>(), words, (uint32_t)si, idx->s_pf_blocks.as<uint32_t>(), d_total + 1,
+                                          matched, capacity, idx->s_pf_out.as<uint64_t>(), st));
+        unsigned long long c[2] = {0, 0};
+        NIDX_HIP(hipMemcpyAsync(c, d_total, 16, hipMemcpyDeviceToHost, st));
+        NIDX_HIP(hipStreamSynchronize(st));
+        if (c[0] != c[1]) return fail(NIDX_ERR_DEVICE, "prefilter: count mismatch (%llu vs %llu)", c[0], c[1]);
+        matched += c[0];
+    }
+    const uint64_t n_copy = std::min<uint64_t>(matched, capacity);
+    if (n_copy) {
+        NIDX_HIP(hipMemcpyAsync(out_docaddr, idx->s_pf_out.p, n_copy * 8, hipMemcpyDeviceToHost, st));
+        NIDX_HIP(hipStreamSynchronize(st));
+    }
+    *n_matching = matched;
+    if (num_docs) *num_docs = live;
     return NIDX_OK;
 }
 

@@ -318,4 +318,15 @@ hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint
                               const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,
                               unsigned long long *counts, hipStream_t s);
 
+// Prefilter (nidx_text reader.rs:148-180): range over a fast field's dense ranks, phrase matches as a bitset, and the
+// bitset -> ascending DocAddress list (block_scratch: ceil(n_words / 256) u32; *total = number of set bits; entries beyond
+// out_cap are counted but not written).
+hipError_t launch_rank_range_bits(const uint32_t *order_key, uint32_t n_docs, uint32_t rank_lo, uint32_t rank_hi, uint64_t *out,
+                                  hipStream_t s);
+hipError_t launch_phrase_bits(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, uint32_t n_driver,
+                              const uint32_t *tmp_tf, uint64_t *bits, hipStream_t s);
+hipError_t launch_bitset_to_docaddr(const uint64_t *bits, uint32_t n_words, uint32_t segment, uint32_t *block_scratch,
+                                    unsigned long long *total, unsigned long long out_begin, unsigned long long out_cap, uint64_t *out,
+                                    hipStream_t s);
+
 }  // namespace nidx

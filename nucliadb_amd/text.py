@@ -35,6 +35,7 @@ from .bm25 import Bm25Searcher, Bm25Segment, Clause, SearchAfter, tokenize
 
 ALL_DOCS = "\x00all"            # pseudo term: every document (AllQuery, scored by ConstScorer)
 NOT_REPEATED = "\x00repeated:0"  # pseudo term: paragraphs with repeated_in_field == 0
+PUBLIC = "\x00public"            # pseudo term: groups_public == 1
 
 
 @dataclass
@@ -52,6 +53,7 @@ class TextDocument:
     repeated_in_field: bool = False  # paragraph index only
     created: int = 0                 # fast fields (schema.rs:59-115), seconds
     modified: int = 0
+    access_groups: Optional[List[str]] = None  # resource security; None / empty = public (resource_indexer.rs:49-63)
 
 
 class Vocabulary:
@@ -78,9 +80,28 @@ class TextSegment:
             toks = [vocab.id(t) for t in tokenize(d.text)]
             self.streams.append(toks)
             vocab.id(ALL_DOCS), vocab.id(NOT_REPEATED)
-            for lab in d.labels:
-                for anc in facet_ancestors(lab):  # tantivy's FacetTokenizer indexes every ancestor path
-                    vocab.id("\x00label:" + anc)
+            for t in self._pseudo_terms(d):
+                vocab.id(t)
+
+    @staticmethod
+    def _pseudo_terms(d: TextDocument) -> List[str]:
+        """The non-text indexed fields of one document (nidx_text/src/resource_indexer.rs:34-110) as pseudo terms of the one
+        term-id space: AllQuery, repeated_in_field, facets (every ancestor path, tantivy's FacetTokenizer), the resource
+        uuid, the field facet, the encoded field id, and the security groups."""
+        out = {ALL_DOCS}
+        if not d.repeated_in_field:
+            out.add(NOT_REPEATED)
+        for lab in d.labels:
+            out.update("\x00label:" + anc for anc in facet_ancestors(lab))
+        out.add("\x00uuid:" + d.uuid)
+        out.update("\x00field:" + anc for anc in facet_ancestors(d.field))
+        out.add("\x00fid:" + d.uuid + "/" + d.field.lstrip("/"))
+        if d.access_groups:
+            for g in d.access_groups:
+                out.update("\x00group:" + anc for anc in facet_ancestors(g if g.startswith("/") else "/" + g))
+        else:
+            out.add(PUBLIC)
+        return sorted(out)
 
     def to_bm25(self, n_terms: int, alive=None) -> Bm25Segment:
         """Postings of the text field, plus constant-frequency pseudo terms for AllQuery / labels /
@@ -92,8 +113,7 @@ class TextSegment:
         for i, (d, s) in enumerate(zip(self.docs, self.streams)):
             terms.extend(s)
             docs.extend([i] * len(s))
-            extra = [self.vocab.ids[ALL_DOCS]] + ([] if d.repeated_in_field else [self.vocab.ids[NOT_REPEATED]])
-            extra += sorted({self.vocab.ids["\x00label:" + anc] for lab in d.labels for anc in facet_ancestors(lab)})
+            extra = [self.vocab.ids[t] for t in self._pseudo_terms(d)]
             terms.extend(extra)
             docs.extend([i] * len(extra))
         terms = np.array(terms, dtype=np.int64)
@@ -102,8 +122,7 @@ class TextSegment:
         pos = []
         for i, (d, st) in enumerate(zip(self.docs, self.streams)):
             pos.extend(range(len(st)))
-            n_extra = 1 + (0 if d.repeated_in_field else 1) + len({anc for lab in d.labels for anc in facet_ancestors(lab)})
-            pos.extend([0] * n_extra)
+            pos.extend([0] * len(self._pseudo_terms(d)))
         pos = np.array(pos, dtype=np.int64)
         key = terms * (n + 1) + docs
         uniq, counts = np.unique(key, return_counts=True)
@@ -249,6 +268,78 @@ class DocumentSearchResponse:
     facets: Dict[str, List[FacetResult]] = field(default_factory=dict)
 
 
+# ---- filter expressions (nidx_protos FilterExpression; nidx_text/src/search_query.rs:156-223) -----------------------
+@dataclass
+class BoolAnd:
+    operands: List["FilterExpression"]
+
+
+@dataclass
+class BoolOr:
+    operands: List["FilterExpression"]
+
+
+@dataclass
+class BoolNot:
+    operand: "FilterExpression"
+
+
+@dataclass
+class ResourceFilter:
+    resource_id: str
+
+
+@dataclass
+class FieldFilter:
+    field_type: str
+    field_id: Optional[str] = None
+
+
+@dataclass
+class ResourceFieldPrefixFilter:
+    resource_id: str
+    field_type: str
+    field_id_prefix: str
+
+
+@dataclass
+class KeywordFilter:
+    keyword: str
+
+
+@dataclass
+class DateRangeFilter:
+    field: int                    # OrderBy.CREATED / OrderBy.MODIFIED
+    since: Optional[int] = None   # inclusive
+    until: Optional[int] = None   # inclusive
+
+
+@dataclass
+class FacetFilter:
+    facet: str
+
+
+FilterExpression = object  # any of the classes above
+
+
+@dataclass
+class Security:
+    access_groups: List[str] = field(default_factory=list)
+
+
+@dataclass
+class PreFilterRequest:
+    security: Optional[Security] = None
+    filter_expression: Optional[FilterExpression] = None
+
+
+@dataclass
+class PrefilterResult:
+    """PrefilterResult::{All, None, Some(fields)} (nidx_types/src/prefilter.rs)"""
+    kind: str                                            # "All" | "None" | "Some"
+    fields: List[Tuple[str, str]] = field(default_factory=list)  # (resource uuid, field id) of every matching document
+
+
 class TextSearcher:
     """nidx_text::TextSearcher (lib.rs:178-237) — `search` only."""
 
@@ -285,6 +376,75 @@ class TextSearcher:
             # filter clauses score too in tantivy's BooleanQuery; facet TermQuerys carry no frequencies
             clauses.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0))
         return clauses
+
+    # ---- prefilter ------------------------------------------------------------------------------------------------
+    def _filter_program(self, expr, ops, lists, ranges, phrases) -> None:
+        """filter_to_query (search_query.rs:156-223) flattened to the postfix program of nidx_gpu_bm25_prefilter."""
+        ix = self._index
+
+        def push_terms(terms: Sequence[int]) -> None:
+            ops.append((_lib.FILTER_PUSH_LISTS, len(lists), len(lists) + len(terms)))
+            lists.extend(terms)
+
+        if isinstance(expr, (BoolAnd, BoolOr)):
+            if not expr.operands:  # BooleanQuery::intersection / union of nothing matches nothing
+                ops.append((_lib.FILTER_PUSH_NONE, 0, 0))
+                return
+            for i, e in enumerate(expr.operands):
+                self._filter_program(e, ops, lists, ranges, phrases)
+                if i:
+                    ops.append((_lib.FILTER_AND if isinstance(expr, BoolAnd) else _lib.FILTER_OR, 0, 0))
+        elif isinstance(expr, BoolNot):
+            self._filter_program(expr.operand, ops, lists, ranges, phrases)
+            ops.append((_lib.FILTER_NOT, 0, 0))
+        elif isinstance(expr, ResourceFilter):
+            push_terms([ix.term("\x00uuid:" + expr.resource_id)])
+        elif isinstance(expr, FieldFilter):  # field_key (search_query.rs:148-154)
+            key = f"/{expr.field_type}/{expr.field_id}" if expr.field_id is not None else f"/{expr.field_type}"
+            push_terms([ix.term("\x00field:" + key)])
+        elif isinstance(expr, ResourceFieldPrefixFilter):
+            # RangeQuery [prefix, prefix with its last byte + 1) over encoded_field_id_bytes: every indexed id with the prefix
+            prefix = "\x00fid:" + expr.resource_id + "/" + expr.field_type + "/" + expr.field_id_prefix
+            push_terms([i for t, i in ix.vocab.ids.items() if t.startswith(prefix)])
+        elif isinstance(expr, KeywordFilter):  # translate_keyword_to_text_query (query_io.rs:22-42)
+            words = tokenize(expr.keyword)
+            if len(words) <= 1:
+                push_terms([ix.term(words[0] if words else expr.keyword)])
+            else:
+                ops.append((_lib.FILTER_PUSH_PHRASE, len(phrases), 0))
+                phrases.append([ix.term(w) for w in words])
+        elif isinstance(expr, DateRangeFilter):
+            ops.append((_lib.FILTER_PUSH_RANGE, len(ranges), 0))
+            ranges.append((expr.field, expr.since, expr.until))
+        elif isinstance(expr, FacetFilter):
+            push_terms([ix.term("\x00label:" + expr.facet)])
+        else:
+            raise TypeError(f"not a filter expression: {expr!r}")
+
+    def prefilter(self, request: PreFilterRequest) -> PrefilterResult:
+        """TextReaderService::prefilter (reader.rs:148-180): which fields pass the security + filter expression."""
+        ops, lists, ranges, phrases = [], [], [], []
+        n_sub = 0
+        if request.security is not None:  # security_query (search_query.rs:66-90): public OR any of the groups
+            groups = [g if g.startswith("/") else "/" + g for g in request.security.access_groups]
+            terms = [self._index.term(PUBLIC)] + [self._index.term("\x00group:" + g) for g in groups]
+            ops.append((_lib.FILTER_PUSH_LISTS, len(lists), len(lists) + len(terms)))
+            lists.extend(terms)
+            n_sub += 1
+        if request.filter_expression is not None:
+            self._filter_program(request.filter_expression, ops, lists, ranges, phrases)
+            n_sub += 1
+            if n_sub == 2:
+                ops.append((_lib.FILTER_AND, 0, 0))
+        if n_sub == 0:
+            return PrefilterResult("All")
+        docaddr, live = self._index.searcher.prefilter(ops, lists, ranges, phrases)
+        if docaddr.size == 0:
+            return PrefilterResult("None")
+        if docaddr.size == live:
+            return PrefilterResult("All")
+        docs = [self._index.doc(int(a)) for a in docaddr]
+        return PrefilterResult("Some", [(d.uuid, d.field) for d in docs])
 
     def search(self, request: DocumentSearchRequest) -> DocumentSearchResponse:
         k = max(0, int(request.result_per_page))

@@ -1472,6 +1472,100 @@ size_t orc_fuzzy_terms(const uint8_t *bytes, const uint64_t *offsets, size_t n_t
     return n;
 }
 
+/* ---- prefilter ------------------------------------------------------------------------------------------------- */
+/* index of document d in the posting list [b, e), or e when absent */
+static uint64_t posting_of(const orc_bm25_index *idx, uint64_t b, uint64_t e, uint32_t d) {
+    uint64_t lo = b, hi = e;
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (idx->doc_ids[mid] < d) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < e && idx->doc_ids[lo] == d) ? lo : e;
+}
+
+/* does document d hold terms[0..n) at consecutive positions? */
+static int doc_has_phrase(const orc_bm25_index *idx, const uint32_t *terms, size_t n, uint32_t d) {
+    if (!idx->pos_offsets || n == 0) return 0;
+    uint64_t at[16];
+    if (n > 16) return 0;
+    for (size_t t = 0; t < n; t++) {
+        uint64_t b = idx->term_offsets[terms[t]], e = idx->term_offsets[terms[t] + 1];
+        at[t] = posting_of(idx, b, e, d);
+        if (at[t] == e) return 0;
+    }
+    for (uint64_t pi = idx->pos_offsets[at[0]]; pi < idx->pos_offsets[at[0] + 1]; pi++) {
+        uint32_t p = idx->positions[pi];
+        int all = 1;
+        for (size_t t = 1; t < n && all; t++) {
+            int found = 0;
+            for (uint64_t pj = idx->pos_offsets[at[t]]; pj < idx->pos_offsets[at[t] + 1] && !found; pj++)
+                found = idx->positions[pj] == p + (uint32_t)t;
+            all = found;
+        }
+        if (all) return 1;
+    }
+    return 0;
+}
+
+size_t orc_bm25_prefilter(const orc_bm25_index *idx, const orc_filter_op *ops, size_t n_ops, const uint32_t *lists,
+                          const orc_date_range *ranges, const int64_t *created, const int64_t *modified,
+                          const uint32_t *phrase_terms, const uint64_t *phrase_offsets, uint32_t *out_docs, size_t cap,
+                          uint64_t *live_out) {
+    size_t n_out = 0;
+    uint64_t live = 0;
+    int *stack = (int *)malloc((n_ops + 1) * sizeof(int));
+    for (uint32_t d = 0; d < idx->n_docs; d++) {
+        if (idx->alive && !((idx->alive[d >> 6] >> (d & 63)) & 1)) continue; /* deleted documents are not searched */
+        live++;
+        int sp = 0;
+        if (n_ops == 0) stack[sp++] = 1;
+        for (size_t i = 0; i < n_ops; i++) {
+            const orc_filter_op *op = &ops[i];
+            switch (op->op) {
+                case ORC_FILTER_TERMS: {
+                    int hit = 0;
+                    for (uint32_t l = op->a; l < op->b && !hit; l++) {
+                        uint64_t b = idx->term_offsets[lists[l]], e = idx->term_offsets[lists[l] + 1];
+                        hit = posting_of(idx, b, e, d) != e;
+                    }
+                    stack[sp++] = hit;
+                    break;
+                }
+                case ORC_FILTER_RANGE: {
+                    const orc_date_range *r = &ranges[op->a];
+                    const int64_t *vals = r->field == 0 ? created : modified;
+                    int hit = 1;
+                    if (r->has_since || r->has_until) {
+                        int64_t v = vals[d];
+                        if (r->has_since && v < r->since) hit = 0;
+                        if (r->has_until && v > r->until) hit = 0;
+                    }
+                    stack[sp++] = hit;
+                    break;
+                }
+                case ORC_FILTER_PHRASE:
+                    stack[sp++] = doc_has_phrase(idx, phrase_terms + phrase_offsets[op->a],
+                                                 (size_t)(phrase_offsets[op->a + 1] - phrase_offsets[op->a]), d);
+                    break;
+                case ORC_FILTER_ALL: stack[sp++] = 1; break;
+                case ORC_FILTER_NONE: stack[sp++] = 0; break;
+                case ORC_FILTER_AND: sp--; stack[sp - 1] = stack[sp - 1] && stack[sp]; break;
+                case ORC_FILTER_OR: sp--; stack[sp - 1] = stack[sp - 1] || stack[sp]; break;
+                case ORC_FILTER_NOT: stack[sp - 1] = !stack[sp - 1]; break;
+                default: break;
+            }
+        }
+        if (sp == 1 && stack[0]) {
+            if (n_out < cap) out_docs[n_out] = d;
+            n_out++;
+        }
+    }
+    free(stack);
+    if (live_out) *live_out = live;
+    return n_out;
+}
+
 /* Document-at-a-time form of orc_bm25_search (what tantivy's union/intersection scorers do): the clause
  * cursors advance together over ascending doc ids and every doc's clause scores are summed in clause
  * order — the same f32 arithmetic as the term-at-a-time loop above, without the dense accumulator.  Used

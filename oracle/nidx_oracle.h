@@ -239,6 +239,22 @@ int orc_fuzzy_match(const uint8_t *query, size_t qlen, const uint8_t *term, size
 size_t orc_fuzzy_terms(const uint8_t *bytes, const uint64_t *offsets, size_t n_terms, const uint8_t *query, size_t qlen,
                        int distance, int prefix, uint32_t *out, size_t cap);
 
+/* TextReaderService::prefilter (nidx_text/src/reader.rs:148-180) restated document-at-a-time: the boolean expression
+ * of filter_to_query (nidx_text/src/search_query.rs:156-223) in postfix form, evaluated per live document.  Leaves:
+ * ORC_FILTER_TERMS a..b (the document is in the posting list of ANY of lists[a..b), a TermQuery / union of TermQuery),
+ * ORC_FILTER_RANGE a (RangeQuery with INCLUSIVE bounds on a date fast field, search_query.rs:30-49; no bound at all
+ * = AllQuery), ORC_FILTER_PHRASE a (PhraseQuery of a tokenised keyword, query_io.rs:22-42), ALL and NONE; NOT is
+ * BooleanQuery[Must AllQuery, MustNot e].  out_docs: matching live doc ids ascending (at most cap written); returns
+ * the full count; *live_out = searcher.num_docs(). */
+enum { ORC_FILTER_TERMS = 0, ORC_FILTER_AND = 1, ORC_FILTER_OR = 2, ORC_FILTER_NOT = 3, ORC_FILTER_ALL = 4, ORC_FILTER_NONE = 5,
+       ORC_FILTER_RANGE = 6, ORC_FILTER_PHRASE = 7 };
+typedef struct { int op; uint32_t a, b; } orc_filter_op;
+typedef struct { uint32_t field; int has_since, has_until; int64_t since, until; } orc_date_range;
+size_t orc_bm25_prefilter(const orc_bm25_index *idx, const orc_filter_op *ops, size_t n_ops, const uint32_t *lists,
+                          const orc_date_range *ranges, const int64_t *created, const int64_t *modified,
+                          const uint32_t *phrase_terms, const uint64_t *phrase_offsets, uint32_t *out_docs, size_t cap,
+                          uint64_t *live_out);
+
 /* Same results, document-at-a-time (no dense accumulator): the CPU baseline of bench.py. */
 int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
                          size_t k, const orc_search_after *after, uint32_t segment_ord,

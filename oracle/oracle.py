@@ -199,6 +199,9 @@ def lib():
                                      C.POINTER(C.c_uint64)]
     L.orc_fuzzy_match.restype = C.c_int
     L.orc_fuzzy_match.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_bm25_prefilter.restype = C.c_size_t
+    L.orc_bm25_prefilter.argtypes = [C.POINTER(_Bm25Index), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.orc_fuzzy_terms.restype = C.c_size_t
     L.orc_fuzzy_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.orc_bm25_search_daat.restype = C.c_int
@@ -609,6 +612,29 @@ class Bm25Index:
         n = lib().orc_bm25_search_ex(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(vals), int(order_desc), _ptr(mb),
                                      _ptr(od), _ptr(os_), _ptr(ov), C.byref(total))
         return od[:n].copy(), os_[:n].copy(), ov[:n].copy(), total.value, mb
+
+    def prefilter(self, ops, lists=(), ranges=(), created=None, modified=None, phrases=()):
+        """TextReaderService::prefilter on this segment: ops = postfix [(op, a, b)] (ORC_FILTER_* numbering), lists = term ids,
+        ranges = [(field, since | None, until | None)], phrases = term-id tuples.  -> (matching live doc ids, live docs)"""
+        c_ops = np.ascontiguousarray([(o, a, b) for o, a, b in ops], dtype=np.uint32).reshape(-1, 3)
+        c_lists = np.ascontiguousarray(lists, dtype=np.uint32)
+
+        class _Range(C.Structure):
+            _fields_ = [("field", C.c_uint32), ("has_since", C.c_int), ("has_until", C.c_int), ("since", C.c_int64), ("until", C.c_int64)]
+
+        c_ranges = (_Range * max(1, len(ranges)))(*[_Range(f, int(lo is not None), int(hi is not None), int(lo or 0), int(hi or 0)) for f, lo, hi in ranges])
+        p_terms = np.ascontiguousarray([t for ph in phrases for t in ph], dtype=np.uint32)
+        p_offs = np.zeros(len(phrases) + 1, np.uint64)
+        p_offs[1:] = np.cumsum([len(ph) for ph in phrases])
+        cr = None if created is None else np.ascontiguousarray(created, dtype=np.int64)
+        mo = None if modified is None else np.ascontiguousarray(modified, dtype=np.int64)
+        ci = self.c()
+        out = np.zeros(max(ci.n_docs, 1), np.uint32)
+        live = C.c_uint64()
+        n = lib().orc_bm25_prefilter(C.byref(ci), _ptr(c_ops) if len(ops) else None, len(ops), _ptr(c_lists) if c_lists.size else None,
+                                     C.addressof(c_ranges), _ptr(cr), _ptr(mo), _ptr(p_terms) if p_terms.size else None, _ptr(p_offs),
+                                     _ptr(out), out.size, C.byref(live))
+        return out[:n].copy(), live.value
 
     def search(self, clauses, k, after=None, segment_ord=0, daat=False):
         """clauses: list of (term, occur, mode, boost). -> (docaddr u64[], score f32[], total).

@@ -216,3 +216,94 @@ def test_phrase_clauses_match_oracle(orc):
         assert r["total"][-3] >= 1 and 10 in (r["docaddr"][-3, : r["count"][-3]] & 0xFFFFFFFF).tolist()
     finally:
         s.close()
+
+
+def random_filter_program(rng, vocab, n_ranges, n_phrases, depth=0):
+    """A random boolean expression in postfix form: ([(op, a, b)], [term ids])."""
+    ops, lists = [], []
+
+    def leaf():
+        kind = rng.random()
+        if kind < 0.55:
+            m = int(rng.integers(0, 4))  # 0 terms: the empty union
+            ops.append((_lib.FILTER_PUSH_LISTS, len(lists), len(lists) + m))
+            lists.extend(int(t) for t in rng.integers(0, vocab, m))
+        elif kind < 0.75 and n_ranges:
+            ops.append((_lib.FILTER_PUSH_RANGE, int(rng.integers(0, n_ranges)), 0))
+        elif kind < 0.9 and n_phrases:
+            ops.append((_lib.FILTER_PUSH_PHRASE, int(rng.integers(0, n_phrases)), 0))
+        else:
+            ops.append((_lib.FILTER_PUSH_ALL if rng.random() < 0.5 else _lib.FILTER_PUSH_NONE, 0, 0))
+
+    def expr(d):
+        if d >= 3 or rng.random() < 0.3:
+            leaf()
+        else:
+            r = rng.random()
+            if r < 0.25:
+                expr(d + 1)
+                ops.append((_lib.FILTER_NOT, 0, 0))
+            else:
+                n = int(rng.integers(2, 4))
+                for i in range(n):
+                    expr(d + 1)
+                    if i:
+                        ops.append((_lib.FILTER_AND if r < 0.65 else _lib.FILTER_OR, 0, 0))
+
+    expr(depth)
+    return ops, lists
+
+
+def test_prefilter_matches_oracle(orc):
+    """TextReaderService::prefilter (nidx_text/src/reader.rs:148-180): nested And / Or / Not over term, date-range and phrase
+    leaves, two segments with deletions — the device's bitset algebra vs the oracle's document-at-a-time evaluation."""
+    rng = np.random.default_rng(2024)
+    vocab = 60
+    segs, oidx, fast = [], [], []
+    for n_docs in (20011, 777):
+        docs = [rng.integers(0, vocab, int(rng.integers(1, 30))) for _ in range(n_docs)]
+        alive = rng.random(n_docs) > 0.1
+        words = np.zeros((n_docs + 63) // 64, np.uint64)
+        for d in np.flatnonzero(alive):
+            words[d >> 6] |= np.uint64(1) << np.uint64(d & 63)
+        seg = Bm25Segment.from_term_docs(docs, vocab, alive=words, with_positions=True)
+        segs.append(seg)
+        oidx.append(orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive, seg.pos_offsets, seg.positions))
+        fast.append((rng.integers(1000, 1200, n_docs), rng.integers(-50, 50, n_docs)))
+    s = Bm25Searcher.open(segs)
+    try:
+        for i, (cr, mo) in enumerate(fast):
+            s.set_fast_field(i, 0, cr)
+            s.set_fast_field(i, 1, mo)
+        ranges = [(0, 1050, 1100), (0, 1100, None), (1, None, 0), (1, 10, 10), (0, 5000, None), (1, None, None), (0, 1100, 1050), (1, -50, 49)]
+        phrases = [rng.integers(0, vocab, int(rng.integers(2, 4))).tolist() for _ in range(6)] + [[3, 3]]
+        live_want = None
+        for trial in range(60):
+            ops, lists = random_filter_program(rng, vocab, len(ranges), len(phrases))
+            got, live = s.prefilter(ops, lists, ranges, phrases)
+            want, lw = [], 0
+            for i, oi in enumerate(oidx):
+                d, l = oi.prefilter(ops, lists, ranges, fast[i][0], fast[i][1], phrases)
+                want.append((np.uint64(i) << np.uint64(32)) | d.astype(np.uint64))
+                lw += l
+            want = np.concatenate(want)
+            assert live == lw
+            assert np.array_equal(got, want), (trial, ops, got.size, want.size)
+            live_want = lw
+        # no expression at all: every live document; a capacity smaller than the result still reports the full count
+        got, live = s.prefilter([], [])
+        assert got.size == live == live_want
+        import ctypes as C
+        req = _lib.Bm25PrefilterC()
+        out = np.zeros(10, np.uint64)
+        n, lv = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.lib().nidx_gpu_bm25_prefilter(s._handle, C.byref(req), out.ctypes.data, 10, C.byref(n), C.byref(lv)))
+        assert n.value == live_want and np.array_equal(out, got[:10])
+        # errors: stack underflow, unknown range, out-of-range term
+        for bad in ([(_lib.FILTER_AND, 0, 0)], [(_lib.FILTER_PUSH_RANGE, 99, 0)], [(_lib.FILTER_PUSH_ALL, 0, 0), (_lib.FILTER_PUSH_ALL, 0, 0)]):
+            with pytest.raises(_lib.NidxGpuError):
+                s.prefilter(bad, [], ranges, phrases)
+        with pytest.raises(_lib.NidxGpuError):
+            s.prefilter([(_lib.FILTER_PUSH_LISTS, 0, 1)], [vocab + 5])
+    finally:
+        s.close()

@@ -461,3 +461,90 @@ def test_fuzzy_automaton_reference_cases(orc):
         d = _osa(a, b)
         assert orc.fuzzy_match(a, b) == (d[len(a)][len(b)] <= 1), (a, b)
         assert orc.fuzzy_match(a, b, prefix=True) == (min(d[len(a)]) <= 1), (a, b)
+
+
+def test_prefilter_reference_cases(orc):
+    """nidx_text/tests/test_search.rs:75-128,355-443 on the reference's test resource (tests/common/mod.rs:60-111: two fields,
+    labels /l/mylabel + /e/myentity on the title, /f/body + /l/mylabel2 on the body, created = modified = now): the
+    counts those tests assert, and a pure-Python evaluation of random expressions."""
+    T, AND, OR, NOT, ALL, NONE, RANGE, PHRASE = range(8)
+    # terms: 0 /l/mylabel 1 /e/myentity 2 /f/body 3 /l/mylabel2 4 /l 5 uuid 6 first 7 document 8 tantivy 9 this
+    docs = [np.array([9, 6, 7, 0, 1, 4, 5]), np.array([9, 8, 2, 3, 4, 5])]
+    now = 1_700_000_000
+    created = modified = np.array([now, now], np.int64)
+
+    def build(docs, alive=None):
+        n_terms = 10
+        post = [[] for _ in range(n_terms)]
+        pos = [[] for _ in range(n_terms)]
+        for d, toks in enumerate(docs):
+            for t in sorted(set(toks.tolist())):
+                post[t].append(d)
+                pos[t].append([i for i, x in enumerate(toks) if x == t])
+        offs = np.cumsum([0] + [len(p) for p in post]).astype(np.uint64)
+        ids = np.array([d for p in post for d in p], np.uint32)
+        tfs = np.array([len(q) for p in pos for q in p], np.uint32)
+        po = np.cumsum([0] + [len(q) for p in pos for q in p]).astype(np.uint64)
+        pp = np.array([x for p in pos for q in p for x in q], np.uint32)
+        return orc.Bm25Index(offs, ids, tfs, np.zeros(len(docs), np.uint8), sum(len(d) for d in docs), alive, po, pp)
+
+    idx = build(docs)
+    run = lambda ops, lists=(), ranges=(), phrases=(): idx.prefilter(ops, lists, ranges, created, modified, phrases)
+    assert run([])[0].tolist() == [0, 1] and run([])[1] == 2
+    assert run([(T, 0, 1), (NOT, 0, 0)], [0])[0].tolist() == [1]                      # test_prefilter_not_search: 1 field
+    assert run([(T, 0, 1)], [0])[0].tolist() == [0]                                   # test_labels_prefilter_search: 1 field
+    assert run([(RANGE, 0, 0)], ranges=[(0, now - 100, now + 100)])[0].size == 2      # test_timestamp_filtering
+    assert run([(RANGE, 0, 0)], ranges=[(1, now + 100, None)])[0].size == 0
+    assert run([(RANGE, 0, 0)], ranges=[(1, now, now)])[0].size == 2                  # inclusive on both sides
+    assert run([(RANGE, 0, 0)], ranges=[(0, None, None)])[0].size == 2                # no bound = AllQuery
+    assert run([(T, 0, 1)], [5])[0].size == 2                                         # test_key_filtering: 2 fields
+    assert run([(PHRASE, 0, 0)], phrases=[[6, 7]])[0].tolist() == [0]                 # "first document"
+    assert run([(PHRASE, 0, 0)], phrases=[[7, 6]])[0].size == 0
+    assert run([(T, 0, 2), (T, 2, 3), (AND, 0, 0)], [0, 3, 8])[0].tolist() == [1]     # (mylabel | mylabel2) & tantivy
+    # deleted documents never match and do not count as live
+    dead = build(docs, np.array([0b10], np.uint64))
+    got, live = dead.prefilter([(ALL, 0, 0)], (), (), created, modified, ())
+    assert got.tolist() == [1] and live == 1
+    # random expressions vs a set-based evaluation
+    rng = np.random.default_rng(3)
+    rdocs = [rng.integers(0, 10, int(rng.integers(1, 12))) for _ in range(300)]
+    ridx = build(rdocs)
+    cr, mo = rng.integers(0, 50, 300), rng.integers(0, 50, 300)
+    universe = set(range(300))
+    for _ in range(200):
+        ops, lists, ranges, phrases, stack = [], [], [], [], []
+        for _ in range(int(rng.integers(1, 8))):
+            r = rng.random()
+            if r < 0.4 or len(stack) == 0:
+                kind = rng.random()
+                if kind < 0.5:
+                    ts = rng.integers(0, 10, int(rng.integers(0, 3))).tolist()
+                    ops.append((T, len(lists), len(lists) + len(ts)))
+                    lists += ts
+                    stack.append({d for d in universe if any(t in rdocs[d] for t in ts)})
+                elif kind < 0.8:
+                    lo, hi = (int(x) if rng.random() < 0.7 else None for x in rng.integers(0, 50, 2))
+                    f = int(rng.integers(0, 2))
+                    ops.append((RANGE, len(ranges), 0))
+                    ranges.append((f, lo, hi))
+                    v = cr if f == 0 else mo
+                    stack.append({d for d in universe if (lo is None or v[d] >= lo) and (hi is None or v[d] <= hi)})
+                else:
+                    ph = rng.integers(0, 10, 2).tolist()
+                    ops.append((PHRASE, len(phrases), 0))
+                    phrases.append(ph)
+                    stack.append({d for d in universe if any(rdocs[d][i] == ph[0] and rdocs[d][i + 1] == ph[1] for i in range(len(rdocs[d]) - 1))})
+            elif r < 0.55:
+                ops.append((NOT, 0, 0))
+                stack.append(universe - stack.pop())
+            elif len(stack) >= 2:
+                b, a = stack.pop(), stack.pop()
+                if rng.random() < 0.5:
+                    ops.append((AND, 0, 0)); stack.append(a & b)
+                else:
+                    ops.append((OR, 0, 0)); stack.append(a | b)
+        while len(stack) > 1:
+            b, a = stack.pop(), stack.pop()
+            ops.append((AND, 0, 0)); stack.append(a & b)
+        got, live = ridx.prefilter(ops, lists, ranges, cr, mo, phrases)
+        assert live == 300 and got.tolist() == sorted(stack[0]), ops

@@ -289,3 +289,68 @@ def test_quoted_phrases():
     r = p.search(ParagraphSearchRequest(body='"a test"', result_per_page=20, with_duplicates=True))
     assert [x.uuid for x in r.results] == ["r3"] and r.results[0].score.bm25 > 0
     p.close()
+
+
+def test_prefilter_mirrors_the_reference_cases():
+    """nidx_text/tests/test_search.rs:75-128 (prefilter all / not / labels), :355-402 (timestamps), :404-443 (resource key) on
+    the reference's own test resource (tests/common/mod.rs: one resource, fields a/title and a/body), plus the other leaves
+    of filter_to_query (search_query.rs:156-223) and the security query (ibid. 66-90)."""
+    from nucliadb_amd.text import (BoolAnd, BoolNot, BoolOr, DateRangeFilter, FacetFilter, FieldFilter, KeywordFilter,
+                                   PreFilterRequest, ResourceFieldPrefixFilter, ResourceFilter, Security)
+    now = 1_700_000_000
+    rid = "f56c58acb4f94d61a077ffccaadd0001"
+    p = ["This is the text of the second paragraph.", "This should be enough to test the tantivy.", "But I wanted to make it three anyway."]
+    d = [TextDocument(rid, "/a/title", "This is the first document", labels=["/l/mylabel", "/e/myentity"], created=now, modified=now),
+         TextDocument(rid, "/a/body", "".join(p), labels=["/f/body", "/l/mylabel2"], created=now, modified=now)]
+    s = TextSearcher.open([TextSegment(d, Vocabulary())])
+    try:
+        pf = lambda e, sec=None: s.prefilter(PreFilterRequest(sec, e))
+        assert pf(None).kind == "All"                                            # test_prefilter_all_search
+        r = pf(BoolNot(FacetFilter("/l/mylabel")))                               # test_prefilter_not_search
+        assert r.kind == "Some" and r.fields == [(rid, "/a/body")]
+        r = pf(FacetFilter("/l/mylabel"))                                        # test_labels_prefilter_search
+        assert r.kind == "Some" and r.fields == [(rid, "/a/title")]
+        assert pf(FacetFilter("/l")).kind == "All"                               # ancestor facets are indexed
+        assert pf(FacetFilter("/l/nothing")).kind == "None"
+        # test_timestamp_filtering: [before, after] holds both fields, [after, -) none; both date fields
+        for f in (0, 1):  # created, modified
+            assert pf(DateRangeFilter(f, now - 100, now + 100)).kind == "All"
+            assert pf(DateRangeFilter(f, now + 100, None)).kind == "None"
+            assert pf(DateRangeFilter(f, now, now)).kind == "All"                # both bounds inclusive
+            assert pf(DateRangeFilter(f, None, now - 1)).kind == "None"
+            assert pf(DateRangeFilter(f, None, None)).kind == "All"              # no bound: AllQuery
+        # test_key_filtering
+        assert pf(ResourceFilter(rid)).kind == "All" and pf(ResourceFilter("fake")).kind == "None"
+        # field filters: by type, by type + name
+        assert pf(FieldFilter("a")).kind == "All" and pf(FieldFilter("t")).kind == "None"
+        assert pf(FieldFilter("a", "title")).fields == [(rid, "/a/title")]
+        assert pf(ResourceFieldPrefixFilter(rid, "a", "bo")).fields == [(rid, "/a/body")]
+        assert pf(ResourceFieldPrefixFilter(rid, "a", "")).kind == "All"
+        assert pf(ResourceFieldPrefixFilter("0" * 32, "a", "")).kind == "None"
+        # keywords: one token = TermQuery, several = PhraseQuery on the text field
+        assert pf(KeywordFilter("tantivy")).fields == [(rid, "/a/body")]
+        assert pf(KeywordFilter("first document")).fields == [(rid, "/a/title")]
+        assert pf(KeywordFilter("document first")).kind == "None"
+        assert pf(KeywordFilter("this is the")).kind == "All"
+        # boolean combinations
+        assert pf(BoolAnd([FacetFilter("/l/mylabel"), KeywordFilter("tantivy")])).kind == "None"
+        assert pf(BoolOr([FacetFilter("/l/mylabel"), KeywordFilter("tantivy")])).kind == "All"
+        assert pf(BoolAnd([FacetFilter("/l"), BoolNot(FacetFilter("/f/body"))])).fields == [(rid, "/a/title")]
+        # security: a public resource passes any group list
+        assert pf(None, Security(["/g1"])).kind == "All"
+        assert pf(FacetFilter("/e/myentity"), Security([])).fields == [(rid, "/a/title")]
+    finally:
+        s.close()
+    # security groups (nidx_text/tests/test_security.rs shape): a resource restricted to group1 and group2, one public
+    d2 = [TextDocument("r1", "/a/title", "secret", access_groups=["group1", "group2"]), TextDocument("r2", "/a/title", "public"),
+          TextDocument("r3", "/a/title", "other", access_groups=["/group3"])]
+    s = TextSearcher.open([TextSegment(d2[:2], v := Vocabulary()), TextSegment(d2[2:], v)], deleted=[set(), set()])
+    try:
+        pf = lambda e, sec=None: s.prefilter(PreFilterRequest(sec, e))
+        assert pf(None, Security([])).fields == [("r2", "/a/title")]
+        assert pf(None, Security(["group1"])).fields == [("r1", "/a/title"), ("r2", "/a/title")]
+        assert pf(None, Security(["unknown"])).fields == [("r2", "/a/title")]
+        assert pf(None, Security(["group3", "group2"])).kind == "All"
+        assert pf(BoolNot(KeywordFilter("public")), Security(["group3"])).fields == [("r3", "/a/title")]
+    finally:
+        s.close()
