@@ -244,6 +244,10 @@ int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *
                                    uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
 /* Launches and queries served through nidx_gpu_vector_search_one so far. */
 int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out);
+/* Queries whose closest_up_nodes walk (hnsw/search.rs:188-240) outgrew the on-chip candidate pool / visited table
+ * and were re-run by the exact HBM-resident fallback (the reference's heap and visited set are unbounded), since
+ * open.  Results are the same either way; the counter tells how often the slow path ran. */
+int32_t nidx_gpu_vector_spill_stats(nidx_gpu_vector_index_t *index, uint64_t *queries_out);
 
 /* DataStoreV2::create's quantized writer (data_store/v2.rs:57-76) for one segment of an open index:
  * EncodedVector::encode (rabitq.rs:75-106) of every vector, on the device; the segment then has a
@@ -279,6 +283,72 @@ int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t seg
 int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *graph_out,
                                        uint64_t graph_cap, uint64_t *graph_len_out, float *edges_out,
                                        uint64_t edges_cap, uint64_t *n_edges_out);
+
+/* ---- segment directories -------------------------------------------------------------
+ * A vector segment as the reference lays it out on disk: vectors.bin (data_store/v2/vector_store.rs:30-40,
+ * 131-147), paragraphs.bin / paragraphs.pos (data_store/v2/paragraph_store.rs:37-44,100-106,132-150; the
+ * StoredParagraph records in the bincode-2 "standard" layout of utils.rs:25-28), vectors.quant
+ * (data_store/v2/quant_vector_store.rs:29-64), hnsw.graph / hnsw.edges (hnsw/disk/v2.rs).  Host side only (no
+ * device call): the files are mmap'd and the views below feed nidx_gpu_vector_open and
+ * nidx_gpu_vector_set_filter_index without a copy; everything stays valid until _close.
+ * field.fst / label.fst / index.map are not read: like segment::open when they are missing (segment.rs:49-67),
+ * the posting lists are rebuilt from the paragraph store (ParagraphInvertedIndexes::build,
+ * inverted_index/paragraph.rs:68-103).  A directory written by nidx_gpu_segment_dir_write is opened by the
+ * reference the same way.  DataStoreV1 directories (nodes.kv) are refused with NIDX_ERR_UNSUPPORTED. */
+typedef struct nidx_gpu_segment_dir nidx_gpu_segment_dir_t;
+int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out);
+void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir);
+/* The nidx_gpu_vector_segment_t of the directory (alive_bitset NULL: apply_deletions is the caller's,
+ * segment.rs:428-445; paragraph_key_ids = a 64-bit hash of every key). */
+int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *segment_out);
+/* The rebuilt inverted indexes as posting lists, the field-key lists first, then the label lists, each group in
+ * key order. */
+int32_t nidx_gpu_segment_dir_filter_index(const nidx_gpu_segment_dir_t *dir, nidx_gpu_filter_index_t *lists_out);
+/* The lookups the FSTs serve: the ids [first, first + count) of the posting lists selected by
+ *   NIDX_LIST_LABEL  a label such as "/l/set/label": label_index.get_prefix(labels_key(label)) — the label and
+ *                    its children (inverted_index/paragraph.rs:63-66,144-146); `prefix` is ignored;
+ *   NIDX_LIST_FIELD  a field id "uuid/type/name" (or a bare "uuid"), keyed as FieldKey::from_field_id does
+ *                    (utils.rs:84-115): prefix == 0 is field_index.get (AtomClause::KeyPrefixSet,
+ *                    paragraph.rs:147-151), prefix != 0 is field_index.get_prefix (ids_for_deletion_key, :118-120).
+ * An id FieldKey::from_field_id rejects selects nothing (count 0). */
+enum { NIDX_LIST_LABEL = 0, NIDX_LIST_FIELD = 1 };
+int32_t nidx_gpu_segment_dir_lists(const nidx_gpu_segment_dir_t *dir, int32_t kind, const uint8_t *key, uint32_t key_len,
+                                   int32_t prefix, uint32_t *first_out, uint32_t *count_out);
+/* StoredParagraph of one address (DataStore::get_paragraph): what try_to_document_scored (searcher.rs:126-146)
+ * reads to assemble a hit.  Pointers into the mapped paragraphs.bin, not NUL terminated. */
+typedef struct {
+    const char *key;
+    uint32_t key_len;
+    const uint8_t *metadata;
+    uint32_t metadata_len;
+    uint32_t n_labels;
+    uint32_t first_vector, num_vectors;
+} nidx_gpu_paragraph_t;
+int32_t nidx_gpu_segment_dir_paragraph(const nidx_gpu_segment_dir_t *dir, uint32_t addr, nidx_gpu_paragraph_t *out);
+int32_t nidx_gpu_segment_dir_paragraph_label(const nidx_gpu_segment_dir_t *dir, uint32_t addr, uint32_t i,
+                                             const char **label_out, uint32_t *len_out);
+/* segment::create's file output (segment.rs:199-239) for a segment built or merged on the device: vectors and
+ * paragraphs in address order; the graph image / edge weights as nidx_gpu_vector_serialize_hnsw returns them, the
+ * quantized store as nidx_gpu_vector_serialize_quantized does (NULL = file not written). */
+typedef struct {
+    uint32_t dimension, n_vectors, n_paragraphs;
+    const float *vectors;                    /* [n_vectors][dimension] */
+    const uint32_t *paragraph_of_vector;     /* NULL = one vector per paragraph, in order */
+    const uint8_t *keys;
+    const uint64_t *key_offsets;             /* [n_paragraphs + 1] */
+    const uint8_t *labels;
+    const uint64_t *label_offsets;           /* [n_labels_total + 1] */
+    const uint64_t *paragraph_label_offsets; /* [n_paragraphs + 1] into the label table; NULL = no labels */
+    const uint8_t *metadata;
+    const uint64_t *metadata_offsets;        /* [n_paragraphs + 1]; NULL = no metadata */
+    const uint8_t *hnsw_graph;
+    uint64_t hnsw_graph_len;
+    const float *hnsw_edges;
+    uint64_t n_hnsw_edges;
+    const uint8_t *quantized;
+    uint64_t quantized_len;
+} nidx_gpu_segment_dir_contents_t;
+int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *contents);
 
 /* =====================================================================================
  * BM25 index — replaces the tantivy scoring under TextSearcher::search

@@ -98,6 +98,22 @@ class FilterIndexC(C.Structure):
     _fields_ = [("n_lists", C.c_uint32), ("list_offsets", C.c_void_p), ("paragraph_ids", C.c_void_p)]
 
 
+class ParagraphC(C.Structure):
+    _fields_ = [("key", C.c_void_p), ("key_len", C.c_uint32), ("metadata", C.c_void_p), ("metadata_len", C.c_uint32),
+                ("n_labels", C.c_uint32), ("first_vector", C.c_uint32), ("num_vectors", C.c_uint32)]
+
+
+class SegmentDirContentsC(C.Structure):
+    _fields_ = [("dimension", C.c_uint32), ("n_vectors", C.c_uint32), ("n_paragraphs", C.c_uint32), ("vectors", C.c_void_p),
+                ("paragraph_of_vector", C.c_void_p), ("keys", C.c_void_p), ("key_offsets", C.c_void_p), ("labels", C.c_void_p),
+                ("label_offsets", C.c_void_p), ("paragraph_label_offsets", C.c_void_p), ("metadata", C.c_void_p),
+                ("metadata_offsets", C.c_void_p), ("hnsw_graph", C.c_void_p), ("hnsw_graph_len", C.c_uint64),
+                ("hnsw_edges", C.c_void_p), ("n_hnsw_edges", C.c_uint64), ("quantized", C.c_void_p), ("quantized_len", C.c_uint64)]
+
+
+LIST_LABEL, LIST_FIELD = 0, 1
+
+
 class FilterOpC(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_uint32), ("b", C.c_uint32)]
 
@@ -177,6 +193,7 @@ SIGNATURES = {
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_vector_search_one": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_spill_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nidx_gpu_vector_coalescer_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_use_hnsw": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
     "nidx_gpu_similarity": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -198,6 +215,14 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_bm25_set_fast_field": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_bm25_set_dictionary": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_segment_dir_open": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "nidx_gpu_segment_dir_close": (None, [C.c_void_p]),
+    "nidx_gpu_segment_dir_segment": (C.c_int32, [C.c_void_p, C.POINTER(VectorSegmentC)]),
+    "nidx_gpu_segment_dir_filter_index": (C.c_int32, [C.c_void_p, C.POINTER(FilterIndexC)]),
+    "nidx_gpu_segment_dir_lists": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "nidx_gpu_segment_dir_paragraph": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(ParagraphC)]),
+    "nidx_gpu_segment_dir_paragraph_label": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+    "nidx_gpu_segment_dir_write": (C.c_int32, [C.c_char_p, C.POINTER(SegmentDirContentsC)]),
     "nidx_gpu_bm25_prefilter": (C.c_int32, [C.c_void_p, C.POINTER(Bm25PrefilterC), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_fuzzy_terms": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_bm25_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),

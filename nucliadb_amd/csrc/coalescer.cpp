@@ -154,4 +154,12 @@ int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t
     return NIDX_OK;
 }
 
+int32_t nidx_gpu_vector_spill_stats(nidx_gpu_vector_index_t *index, uint64_t *queries_out) {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !queries_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *queries_out = idx->spill_queries;
+    return NIDX_OK;
+}
+
 }  // extern "C"

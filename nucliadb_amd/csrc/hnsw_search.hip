@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
     const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
     if (!entry_mode) layer_search_block<NJ, EFL, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
+    if (a.dump_vec) {
+        // spill path: the walk below runs in hnsw_closest_spill_kernel, from these candidates
+        if (ctl) {
+#pragma unroll
+            for (int i = 0; i < EFL; i++) {
+                const uint64_t key = res.mine(i);
+                const int e = 64 * i + lane;
+                if (e < res.len) {
+                    a.dump_vec[(size_t)qi * NIDX_DUMP_STRIDE + e] = rank_key_addr(key);
+                    a.dump_score[(size_t)qi * NIDX_DUMP_STRIDE + e] = rank_key_score(key);
+                }
+            }
+            if (lane == 0) {
+                a.dump_count[qi] = (uint32_t)res.len;
+                if (a.stats) a.stats[(size_t)qi * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS] = st.flags;
+            }
+        }
+        return;
+    }
 
     // ---- closest_up_nodes (search.rs:188-240) ----
     // candidates = the ef neighbours; visited = exactly those; pop best, accept if it passes the

@@ -153,8 +153,41 @@ struct HnswSearchArgs {
     const uint32_t *entry_vec;    // [n_queries][k]
     const float *entry_score;     // [n_queries][k]
     const uint32_t *entry_count;  // [n_queries]
+    // dump mode (spill path): stop after the layer-0 search and hand its ef results over as entry points for
+    // hnsw_closest_spill_kernel; nullptr = the normal search.  Rows of NIDX_DUMP_STRIDE entries.
+    uint32_t *dump_vec;
+    float *dump_score;
+    uint32_t *dump_count;
 };
+#define NIDX_DUMP_STRIDE 256
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
+
+// closest_up_nodes with the candidate pool and the visited set in HBM (hnsw_spill.hip): the exact fallback for the
+// queries whose walk outgrew the LDS structures of hnsw_search_kernel.
+struct HnswSpillArgs {
+    SegDev seg;
+    GraphDev g;
+    const float *queries;        // [*][dp], indexed by query id
+    const uint32_t *query_ids;   // [n_queries] ids of the queries to run; outputs / entries are indexed by id
+    uint32_t n_queries;
+    const uint64_t *filter;
+    uint32_t k;
+    float min_score;
+    int with_duplicates;
+    int multi;
+    const uint32_t *entry_vec;   // [*][entry_stride]
+    const float *entry_score;
+    const uint32_t *entry_count; // [*]
+    uint32_t entry_stride;
+    uint64_t *pool;              // [n_queries][pool_chunks * 64]
+    uint64_t *chunk_max;         // [n_queries][pool_chunks], zeroed
+    uint32_t *vis;               // [n_queries][vis_words], zeroed
+    uint32_t pool_chunks, vis_words;
+    uint32_t *out_vec;           // [*][k]
+    float *out_score;
+    uint32_t *out_count;
+};
+hipError_t launch_hnsw_closest_spill(const HnswSpillArgs &a, hipStream_t s);
 
 // ---- RaBitQ (rabitq.hip) ----
 struct RabitqQueryDev {   // QueryVector (rabitq.rs:109-122) with the similarity() constants folded

@@ -1,0 +1,401 @@
+// segment_dir.cpp — a vector segment directory as the reference writes it, host side only.
+//
+//   vectors.bin      data_store/v2/vector_store.rs:30-40,131-147   record = dimension f32 LE + u32 LE paragraph address
+//   paragraphs.bin   data_store/v2/paragraph_store.rs:37-44,132-150 StoredParagraph records, bincode-2 "standard" layout
+//   paragraphs.pos   ibid. :100-106,141                             u32 LE start of every record in paragraphs.bin
+//   vectors.quant    data_store/v2/quant_vector_store.rs:29-64      dimension/8 + 8 bytes per vector (rabitq.rs:38-106)
+//   hnsw.graph/.edges hnsw/disk/v2.rs:16-49,214-252                 opaque here: handed to nidx_gpu_vector_open as they lie
+//
+// The files are mmap'd and handed to nidx_gpu_vector_open without a copy.  field.fst / label.fst / index.map (third
+// party `fst` containers) are neither read nor written: the reference rebuilds them from the paragraph store when they
+// are missing (segment.rs:49-67, ParagraphInvertedIndexes::build, inverted_index/paragraph.rs:68-103), and this file
+// rebuilds the same posting lists in memory from the same records, keyed the same way (labels_key / FieldKey).
+//
+// StoredParagraph is serialised with wincode configured to match bincode::config::standard() (utils.rs:25-28): little
+// endian, variable-length integers (u < 251: one byte; 251 + u16; 252 + u32; 253 + u64), a sequence or string = its
+// length as such an integer followed by the elements / UTF-8 bytes; struct fields in declaration order:
+// key, labels, metadata, first_vector, num_vectors.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/nidx_gpu.h"
+#include "host_common.h"
+
+namespace nidx {
+namespace {
+
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t len = 0;
+    bool present = false;
+    ~MappedFile() {
+        if (p && len) munmap(const_cast<uint8_t *>(p), len);
+    }
+    // 0 = ok, 1 = missing, -1 = error
+    int open(const std::string &path) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return errno == ENOENT ? 1 : -1;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return -1; }
+        len = (size_t)st.st_size;
+        present = true;
+        if (len) {
+            void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); p = nullptr; len = 0; return -1; }
+            p = static_cast<const uint8_t *>(m);
+        }
+        ::close(fd);
+        return 0;
+    }
+};
+
+// bincode-2 varint
+bool read_varint(const uint8_t *d, size_t len, size_t &at, uint64_t &out) {
+    if (at >= len) return false;
+    const uint8_t b = d[at++];
+    int n;
+    if (b < 251) { out = b; return true; }
+    if (b == 251) n = 2;
+    else if (b == 252) n = 4;
+    else if (b == 253) n = 8;
+    else return false;  // u128 never occurs in these records
+    if (at + (size_t)n > len) return false;
+    out = 0;
+    for (int i = 0; i < n; i++) out |= (uint64_t)d[at + i] << (8 * i);
+    at += (size_t)n;
+    return true;
+}
+
+void write_varint(std::vector<uint8_t> &o, uint64_t v) {
+    int n;
+    if (v < 251) { o.push_back((uint8_t)v); return; }
+    if (v <= 0xffffu) { o.push_back(251); n = 2; }
+    else if (v <= 0xffffffffu) { o.push_back(252); n = 4; }
+    else { o.push_back(253); n = 8; }
+    for (int i = 0; i < n; i++) o.push_back((uint8_t)(v >> (8 * i)));
+}
+
+struct Span { uint64_t off; uint32_t len; };
+
+struct Paragraph {
+    Span key, metadata;
+    uint32_t first_label, n_labels;  // into SegmentDir::labels
+    uint32_t first_vector, num_vectors;
+};
+
+// 64-bit identity of a key string (FNV-1a folded through a finaliser); equal strings <=> equal ids up to 2^-64
+uint64_t key_id(const uint8_t *s, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= s[i]; h *= 1099511628211ull; }
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+    return h;
+}
+
+int hex_val(uint8_t c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; }
+
+// uuid::Uuid::parse_str on the simple (32 hex) and hyphenated (8-4-4-4-12) forms -> 16 bytes
+bool parse_uuid(const uint8_t *s, size_t n, uint8_t out[16]) {
+    if (n == 36) {
+        if (s[8] != '-' || s[13] != '-' || s[18] != '-' || s[23] != '-') return false;
+    } else if (n != 32) {
+        return false;
+    }
+    int k = 0;
+    for (size_t i = 0; i < n;) {
+        if (n == 36 && (i == 8 || i == 13 || i == 18 || i == 23)) { i++; continue; }
+        const int hi = hex_val(s[i]), lo = hex_val(s[i + 1]);
+        if (hi < 0 || lo < 0) return false;
+        out[k++] = (uint8_t)(hi * 16 + lo);
+        i += 2;
+    }
+    return k == 16;
+}
+
+// FieldKey::from_field_id (utils.rs:84-115): uuid bytes, then "type/name" when both are present; a lone uuid is the
+// resource key; "uuid/type" alone is rejected.
+bool field_key(const uint8_t *s, size_t n, std::string &out) {
+    size_t cut[3], nc = 0;
+    for (size_t i = 0; i < n && nc < 3; i++)
+        if (s[i] == '/') cut[nc++] = i;
+    const size_t uuid_end = nc >= 1 ? cut[0] : n;
+    uint8_t rid[16];
+    if (!parse_uuid(s, uuid_end, rid)) return false;
+    out.assign(reinterpret_cast<const char *>(rid), 16);
+    if (nc == 0) return true;
+    if (nc == 1) return false;  // a field type without a name
+    const size_t name_end = nc >= 3 ? cut[2] : n;
+    out.append(reinterpret_cast<const char *>(s + cut[0] + 1), cut[1] - cut[0] - 1);
+    out.push_back('/');
+    out.append(reinterpret_cast<const char *>(s + cut[1] + 1), name_end - cut[1] - 1);
+    return true;
+}
+
+}  // namespace
+
+struct SegmentDir {
+    uint32_t dimension = 0;
+    MappedFile vectors, para_data, para_pos, quant, graph, edges;
+    uint32_t n_vectors = 0, n_paragraphs = 0;
+    uint64_t row_stride = 0;
+    std::vector<Paragraph> paragraphs;
+    std::vector<Span> labels;
+    std::vector<uint64_t> key_ids;
+    std::vector<uint32_t> para_of_vec;  // only when the trailers disagree with nothing: kept for the Multi case
+    // the inverted indexes: sorted keys ("L" + labels_key | "F" + FieldKey bytes) -> ascending paragraph lists
+    std::vector<std::string> list_keys;
+    std::vector<uint64_t> list_offsets;
+    std::vector<uint32_t> list_ids;
+    uint32_t n_label_lists = 0;  // the "F" lists come first ('F' < 'L')
+};
+
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" {
+
+int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out) {
+    if (!path || !dir_out || dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *dir_out = nullptr;
+    std::unique_ptr<SegmentDir> d(new SegmentDir());
+    d->dimension = dimension;
+    const std::string base = std::string(path) + "/";
+    {   // DataStoreV1 (nodes.kv, data_store/v1.rs:89-93) is the pre-migration format: not read here
+        MappedFile v1;
+        if (v1.open(base + "nodes.kv") == 0) return fail(NIDX_ERR_UNSUPPORTED, "%s holds a DataStoreV1 segment (nodes.kv)", path);
+    }
+    if (d->vectors.open(base + "vectors.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %svectors.bin", base.c_str());
+    if (d->para_data.open(base + "paragraphs.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.bin", base.c_str());
+    if (d->para_pos.open(base + "paragraphs.pos") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.pos", base.c_str());
+    if (d->quant.open(base + "vectors.quant") < 0) return fail(NIDX_ERR_IO, "cannot read %svectors.quant", base.c_str());
+    if (d->graph.open(base + "hnsw.graph") < 0) return fail(NIDX_ERR_IO, "cannot read %shnsw.graph", base.c_str());
+    if (d->edges.open(base + "hnsw.edges") < 0) return fail(NIDX_ERR_IO, "cannot read %shnsw.edges", base.c_str());
+    // vector_alignment(DenseF32) == 4 == U32_LEN: no padding after the trailer (vector_store.rs:35-41)
+    d->row_stride = (uint64_t)dimension * 4 + 4;
+    if (d->vectors.len % d->row_stride) return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "vectors.bin (%zu bytes) is not a multiple of %llu-byte records", d->vectors.len, (unsigned long long)d->row_stride);
+    if (d->vectors.len / d->row_stride > 0xffffffffull || d->para_pos.len % 4) return fail(NIDX_ERR_IO, "malformed segment files");
+    d->n_vectors = (uint32_t)(d->vectors.len / d->row_stride);
+    d->n_paragraphs = (uint32_t)(d->para_pos.len / 4);
+    if (d->quant.present && d->quant.len != (uint64_t)d->n_vectors * (dimension / 8 + 8))
+        return fail(NIDX_ERR_IO, "vectors.quant holds %zu bytes, expected %llu", d->quant.len, (unsigned long long)d->n_vectors * (dimension / 8 + 8));
+    if (d->edges.len % 4) return fail(NIDX_ERR_IO, "hnsw.edges is not a whole number of f32");
+    // decode every StoredParagraph
+    d->paragraphs.resize(d->n_paragraphs);
+    d->key_ids.resize(d->n_paragraphs);
+    const uint8_t *data = d->para_data.p;
+    const size_t dlen = d->para_data.len;
+    std::map<std::string, std::vector<uint32_t>> lists;
+    std::string fk;
+    for (uint32_t a = 0; a < d->n_paragraphs; a++) {
+        uint32_t start;
+        memcpy(&start, d->para_pos.p + (size_t)a * 4, 4);
+        size_t at = start;
+        uint64_t v, n;
+        Paragraph &pg = d->paragraphs[a];
+        auto bad = [&]() { return fail(NIDX_ERR_IO, "paragraphs.bin: truncated record %u", a); };
+        if (!read_varint(data, dlen, at, n) || at + n > dlen) return bad();
+        pg.key = {at, (uint32_t)n};
+        at += n;
+        if (!read_varint(data, dlen, at, n)) return bad();
+        pg.first_label = (uint32_t)d->labels.size();
+        pg.n_labels = (uint32_t)n;
+        for (uint64_t i = 0; i < n; i++) {
+            if (!read_varint(data, dlen, at, v) || at + v > dlen) return bad();
+            d->labels.push_back({at, (uint32_t)v});
+            at += v;
+        }
+        if (!read_varint(data, dlen, at, n) || at + n > dlen) return bad();
+        pg.metadata = {at, (uint32_t)n};
+        at += n;
+        if (!read_varint(data, dlen, at, v)) return bad();
+        pg.first_vector = (uint32_t)v;
+        if (!read_varint(data, dlen, at, v)) return bad();
+        pg.num_vectors = (uint32_t)v;
+        if ((uint64_t)pg.first_vector + pg.num_vectors > d->n_vectors) return fail(NIDX_ERR_IO, "paragraph %u owns vectors beyond vectors.bin", a);
+        d->key_ids[a] = key_id(data + pg.key.off, pg.key.len);
+        // ParagraphInvertedIndexes::build (inverted_index/paragraph.rs:72-85)
+        if (field_key(data + pg.key.off, pg.key.len, fk)) lists["F" + fk].push_back(a);
+        for (uint32_t i = 0; i < pg.n_labels; i++) {
+            const Span &l = d->labels[pg.first_label + i];
+            if (l.len == 0) continue;
+            // labels_key: the label without its leading '/', plus a trailing '/'
+            std::string k = "L" + std::string(reinterpret_cast<const char *>(data + l.off + 1), l.len - 1) + "/";
+            std::vector<uint32_t> &pl = lists[k];
+            if (pl.empty() || pl.back() != a) pl.push_back(a);
+        }
+    }
+    d->list_offsets.push_back(0);
+    for (auto &kv : lists) {
+        d->list_keys.push_back(kv.first);
+        d->list_ids.insert(d->list_ids.end(), kv.second.begin(), kv.second.end());
+        d->list_offsets.push_back(d->list_ids.size());
+        if (kv.first[0] == 'L') d->n_label_lists++;
+    }
+    *dir_out = reinterpret_cast<nidx_gpu_segment_dir_t *>(d.release());
+    return NIDX_OK;
+}
+
+void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir) { delete reinterpret_cast<SegmentDir *>(dir); }
+
+int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *out) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->vectors = d->vectors.p;
+    out->row_stride_bytes = d->row_stride;
+    out->n_vectors = d->n_vectors;
+    out->paragraph_of_vector = nullptr;  // the row trailers
+    out->n_paragraphs = d->n_paragraphs;
+    out->hnsw_graph = d->graph.len ? d->graph.p : nullptr;
+    out->hnsw_graph_len = d->graph.len;
+    out->hnsw_edges = d->edges.len ? reinterpret_cast<const float *>(d->edges.p) : nullptr;
+    out->n_hnsw_edges = d->edges.len / 4;
+    out->paragraph_key_ids = d->n_paragraphs ? d->key_ids.data() : nullptr;
+    out->quantized = d->quant.len ? d->quant.p : nullptr;
+    out->quantized_len = d->quant.len;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_segment_dir_filter_index(const nidx_gpu_segment_dir_t *dir, nidx_gpu_filter_index_t *out) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    out->n_lists = (uint32_t)d->list_keys.size();
+    out->list_offsets = d->list_offsets.data();
+    out->paragraph_ids = d->list_ids.data();
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_segment_dir_lists(const nidx_gpu_segment_dir_t *dir, int32_t kind, const uint8_t *key, uint32_t key_len, int32_t prefix,
+                                   uint32_t *first_out, uint32_t *count_out) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !first_out || !count_out || (key_len && !key)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *first_out = *count_out = 0;
+    std::string k;
+    if (kind == NIDX_LIST_LABEL) {
+        // labels_key (inverted_index/paragraph.rs:63-66); the lookup is always a prefix search (:144-146)
+        if (key_len == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "empty label");
+        k = "L" + std::string(reinterpret_cast<const char *>(key) + 1, key_len - 1) + "/";
+        prefix = 1;
+    } else if (kind == NIDX_LIST_FIELD) {
+        std::string fk;
+        if (!field_key(key, key_len, fk)) return NIDX_OK;  // from_field_id -> None: the id selects nothing
+        k = "F" + fk;
+    } else {
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown list kind %d", kind);
+    }
+    auto lo = std::lower_bound(d->list_keys.begin(), d->list_keys.end(), k);
+    auto hi = lo;
+    if (prefix) {
+        while (hi != d->list_keys.end() && hi->compare(0, k.size(), k) == 0) ++hi;
+    } else if (hi != d->list_keys.end() && *hi == k) {
+        ++hi;
+    }
+    *first_out = (uint32_t)(lo - d->list_keys.begin());
+    *count_out = (uint32_t)(hi - lo);
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_segment_dir_paragraph(const nidx_gpu_segment_dir_t *dir, uint32_t addr, nidx_gpu_paragraph_t *out) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (addr >= d->n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "paragraph %u out of range (%u stored)", addr, d->n_paragraphs);
+    const Paragraph &pg = d->paragraphs[addr];
+    out->key = reinterpret_cast<const char *>(d->para_data.p + pg.key.off);
+    out->key_len = pg.key.len;
+    out->metadata = d->para_data.p + pg.metadata.off;
+    out->metadata_len = pg.metadata.len;
+    out->n_labels = pg.n_labels;
+    out->first_vector = pg.first_vector;
+    out->num_vectors = pg.num_vectors;
+    return NIDX_OK;
+}
+
+int32_t nidx_gpu_segment_dir_paragraph_label(const nidx_gpu_segment_dir_t *dir, uint32_t addr, uint32_t i, const char **label_out,
+                                             uint32_t *len_out) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !label_out || !len_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (addr >= d->n_paragraphs || i >= d->paragraphs[addr].n_labels) return fail(NIDX_ERR_INVALID_ARGUMENT, "label %u of paragraph %u out of range", i, addr);
+    const Span &l = d->labels[d->paragraphs[addr].first_label + i];
+    *label_out = reinterpret_cast<const char *>(d->para_data.p + l.off);
+    *len_out = l.len;
+    return NIDX_OK;
+}
+
+static int write_file(const std::string &path, const void *p, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return -1;
+    const bool ok = n == 0 || fwrite(p, 1, n, f) == n;
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
+int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *c) {
+    if (!path || !c || c->dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (c->n_vectors && !c->vectors) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL vectors");
+    if (c->n_paragraphs && (!c->key_offsets || !c->keys)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL keys");
+    const std::string base = std::string(path) + "/";
+    const uint32_t D = c->dimension;
+    // first vector / count of every paragraph: vectors of one paragraph are contiguous (segment.rs:216-229)
+    std::vector<uint32_t> first(c->n_paragraphs, 0), num(c->n_paragraphs, 0);
+    for (uint32_t v = 0; v < c->n_vectors; v++) {
+        const uint32_t p = c->paragraph_of_vector ? c->paragraph_of_vector[v] : v;
+        if (p >= c->n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "vector %u belongs to paragraph %u of %u", v, p, c->n_paragraphs);
+        if (num[p] == 0) first[p] = v;
+        else if (first[p] + num[p] != v) return fail(NIDX_ERR_INVALID_ARGUMENT, "the vectors of paragraph %u are not contiguous", p);
+        num[p]++;
+    }
+    {   // vectors.bin
+        const size_t stride = (size_t)D * 4 + 4;
+        std::vector<uint8_t> rows((size_t)c->n_vectors * stride);
+        for (uint32_t v = 0; v < c->n_vectors; v++) {
+            const uint32_t p = c->paragraph_of_vector ? c->paragraph_of_vector[v] : v;
+            memcpy(rows.data() + (size_t)v * stride, c->vectors + (size_t)v * D, (size_t)D * 4);
+            memcpy(rows.data() + (size_t)v * stride + (size_t)D * 4, &p, 4);
+        }
+        if (write_file(base + "vectors.bin", rows.data(), rows.size())) return fail(NIDX_ERR_IO, "cannot write %svectors.bin", base.c_str());
+    }
+    {   // paragraphs.bin + paragraphs.pos
+        std::vector<uint8_t> data;
+        std::vector<uint32_t> pos(c->n_paragraphs);
+        for (uint32_t a = 0; a < c->n_paragraphs; a++) {
+            if (data.size() > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "paragraphs.bin would exceed the 4 GiB its u32 offsets address");
+            pos[a] = (uint32_t)data.size();
+            const uint64_t kb = c->key_offsets[a], ke = c->key_offsets[a + 1];
+            write_varint(data, ke - kb);
+            data.insert(data.end(), c->keys + kb, c->keys + ke);
+            const uint64_t lb = c->paragraph_label_offsets ? c->paragraph_label_offsets[a] : 0, le = c->paragraph_label_offsets ? c->paragraph_label_offsets[a + 1] : 0;
+            write_varint(data, le - lb);
+            for (uint64_t l = lb; l < le; l++) {
+                write_varint(data, c->label_offsets[l + 1] - c->label_offsets[l]);
+                data.insert(data.end(), c->labels + c->label_offsets[l], c->labels + c->label_offsets[l + 1]);
+            }
+            const uint64_t mb = c->metadata_offsets ? c->metadata_offsets[a] : 0, me = c->metadata_offsets ? c->metadata_offsets[a + 1] : 0;
+            write_varint(data, me - mb);
+            if (me > mb) data.insert(data.end(), c->metadata + mb, c->metadata + me);
+            write_varint(data, first[a]);
+            write_varint(data, num[a]);
+        }
+        if (write_file(base + "paragraphs.bin", data.data(), data.size())) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.bin", base.c_str());
+        if (write_file(base + "paragraphs.pos", pos.data(), pos.size() * 4)) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.pos", base.c_str());
+    }
+    if (c->quantized && c->quantized_len) {
+        if (c->quantized_len != (uint64_t)c->n_vectors * (D / 8 + 8)) return fail(NIDX_ERR_INVALID_ARGUMENT, "quantized store has the wrong size");
+        if (write_file(base + "vectors.quant", c->quantized, c->quantized_len)) return fail(NIDX_ERR_IO, "cannot write %svectors.quant", base.c_str());
+    }
+    if (c->hnsw_graph && c->hnsw_graph_len) {
+        if (write_file(base + "hnsw.graph", c->hnsw_graph, c->hnsw_graph_len)) return fail(NIDX_ERR_IO, "cannot write %shnsw.graph", base.c_str());
+        if (write_file(base + "hnsw.edges", c->hnsw_edges, (size_t)c->n_hnsw_edges * 4)) return fail(NIDX_ERR_IO, "cannot write %shnsw.edges", base.c_str());
+    }
+    return NIDX_OK;
+}
+
+}  // extern "C"

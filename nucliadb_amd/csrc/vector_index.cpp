@@ -256,6 +256,97 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
     return NIDX_OK;
 }
 
+// ---- exact fallback: closest_up_nodes with the pool and the visited set in HBM ---------------------------------------
+int32_t VectorIndex::segment_spill_search(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, bool with_duplicates,
+                                          int method, const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score,
+                                          uint32_t *d_out_count, const std::vector<uint32_t> &flagged, hipStream_t st) {
+    VectorSegment &seg = segs[s];
+    if (flagged.empty()) return NIDX_OK;
+    HnswSpillArgs sp;
+    sp.seg = seg.seg_dev(cfg.similarity);
+    sp.g = seg.graph_dev();
+    sp.queries = d_queries;
+    sp.filter = d_filter;
+    sp.k = k;
+    sp.min_score = min_score;
+    sp.with_duplicates = with_duplicates ? 1 : 0;
+    sp.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
+    sp.out_vec = d_out_vec;
+    sp.out_score = d_out_score;
+    sp.out_count = d_out_count;
+    if (method == NIDX_METHOD_RABITQ_HNSW) {
+        // the re-ranked entry points of the RaBitQ arm are still in the scratch of the call that flagged
+        sp.entry_vec = scratch_entry_vec.as<uint32_t>();
+        sp.entry_score = scratch_entry_score.as<float>();
+        sp.entry_count = scratch_entry_count.as<uint32_t>();
+        sp.entry_stride = k;
+    } else {
+        // descent + layer-0 search again (bounded by ef), stopping before the walk
+        NIDX_HIP(scratch_dump_vec.reserve((size_t)nq * NIDX_DUMP_STRIDE * 4));
+        NIDX_HIP(scratch_dump_score.reserve((size_t)nq * NIDX_DUMP_STRIDE * 4));
+        NIDX_HIP(scratch_dump_count.reserve((size_t)nq * 4));
+        HnswSearchArgs a;
+        a.seg = sp.seg;
+        a.g = sp.g;
+        a.queries = d_queries;
+        a.n_queries = nq;
+        a.filter = d_filter;
+        a.k = k;
+        a.min_score = min_score;
+        a.with_duplicates = sp.with_duplicates;
+        a.vis_log2 = 15;
+        a.out_vec = d_out_vec;
+        a.out_score = d_out_score;
+        a.out_count = d_out_count;
+        a.stats = scratch_stats.as<uint32_t>();
+        a.multi = sp.multi;
+        a.eval_rows = eval_rows;
+        a.min_waves = min_waves;
+        a.entry_vec = nullptr;
+        a.entry_score = nullptr;
+        a.entry_count = nullptr;
+        a.dump_vec = scratch_dump_vec.as<uint32_t>();
+        a.dump_score = scratch_dump_score.as<float>();
+        a.dump_count = scratch_dump_count.as<uint32_t>();
+        NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
+        std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
+        NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, st));
+        NIDX_HIP(hipStreamSynchronize(st));
+        for (uint32_t q : flagged)
+            if (stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS])
+                return fail(NIDX_ERR_INEXACT, "HNSW layer search overflowed the 2^15-entry visited table (query %u, k=%u)", q, k);
+        sp.entry_vec = a.dump_vec;
+        sp.entry_score = a.dump_score;
+        sp.entry_count = a.dump_count;
+        sp.entry_stride = NIDX_DUMP_STRIDE;
+    }
+    // a node enters the pool at most once: n slots (+ one chunk of slack) and n visited bits per query
+    sp.pool_chunks = seg.n / 64 + 2;
+    sp.vis_words = (seg.n + 31) / 32;
+    const uint64_t per_query = (uint64_t)sp.pool_chunks * 64 * 8 + (uint64_t)sp.pool_chunks * 8 + (uint64_t)sp.vis_words * 4;
+    const uint64_t budget = 2ull << 30;
+    const size_t chunk = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(flagged.size(), budget / per_query));
+    NIDX_HIP(scratch_spill_pool.reserve(chunk * sp.pool_chunks * 64 * 8));
+    NIDX_HIP(scratch_spill_cmax.reserve(chunk * sp.pool_chunks * 8));
+    NIDX_HIP(scratch_spill_vis.reserve(chunk * sp.vis_words * 4));
+    NIDX_HIP(scratch_spill_ids.reserve(flagged.size() * 4));
+    NIDX_HIP(hipMemcpyAsync(scratch_spill_ids.p, flagged.data(), flagged.size() * 4, hipMemcpyHostToDevice, st));
+    sp.pool = scratch_spill_pool.as<uint64_t>();
+    sp.chunk_max = scratch_spill_cmax.as<uint64_t>();
+    sp.vis = scratch_spill_vis.as<uint32_t>();
+    for (size_t f0 = 0; f0 < flagged.size(); f0 += chunk) {
+        const size_t n = std::min(chunk, flagged.size() - f0);
+        NIDX_HIP(hipMemsetAsync(scratch_spill_cmax.p, 0, n * sp.pool_chunks * 8, st));
+        NIDX_HIP(hipMemsetAsync(scratch_spill_vis.p, 0, n * sp.vis_words * 4, st));
+        sp.query_ids = scratch_spill_ids.as<uint32_t>() + f0;
+        sp.n_queries = (uint32_t)n;
+        NIDX_HIP(launch_hnsw_closest_spill(sp, st));
+    }
+    NIDX_HIP(hipStreamSynchronize(st));  // `flagged` is read by the copy above
+    spill_queries += flagged.size();
+    return NIDX_OK;
+}
+
 // ---- one segment, device resident -------------------------------------------------------------------
 int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                            bool with_duplicates, int method, const uint64_t *d_filter,
@@ -284,6 +375,9 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.entry_vec = nullptr;
         a.entry_score = nullptr;
         a.entry_count = nullptr;
+        a.dump_vec = nullptr;
+        a.dump_score = nullptr;
+        a.dump_count = nullptr;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -365,6 +459,9 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.entry_vec = scratch_entry_vec.as<uint32_t>();
         a.entry_score = scratch_entry_score.as<float>();
         a.entry_count = scratch_entry_count.as<uint32_t>();
+        a.dump_vec = nullptr;
+        a.dump_score = nullptr;
+        a.dump_count = nullptr;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -676,9 +773,17 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
             uint32_t flags = 0;
             for (uint32_t q = 0; q < nq; q++) flags |= stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS];
             if (flags == 0) break;
-            if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15)
-                return fail(NIDX_ERR_INEXACT, "HNSW search overflowed an on-chip structure (flags=%u, visited table 2^%u)",
-                            flags, vis_log2);
+            if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15) {
+                // the walk of these queries outgrew the on-chip pool / visited table: re-run them with both in HBM
+                std::vector<uint32_t> flagged;
+                for (uint32_t q = 0; q < nq; q++)
+                    if (stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS]) flagged.push_back(q);
+                rc = segment_spill_search((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score, p.with_duplicates != 0, method, d_filter,
+                                          scratch_out_vec.as<uint32_t>(), scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
+                                          flagged, stream);
+                if (rc != NIDX_OK) return rc;
+                break;
+            }
             vis_log2 = 15;  // visited table was too small: retry once with the largest one (128 KiB of LDS)
         }
         hv[s].resize((size_t)nq * k);

@@ -70,7 +70,9 @@ struct VectorIndex {
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
-        scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count;
+        scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count,
+        scratch_dump_vec, scratch_dump_score, scratch_dump_count, scratch_spill_pool, scratch_spill_cmax, scratch_spill_vis, scratch_spill_ids;
+    uint64_t spill_queries = 0;  // queries re-run by the exact fallback since open (tunable "spill_queries" reads it)
     bool rabitq_enabled(const VectorSegment &seg) const { return seg.has_quant && !(cfg.flags & NIDX_CONFIG_DISABLE_RABITQ_SEARCH); }
     int32_t quantize(uint32_t segment);
 
@@ -78,6 +80,10 @@ struct VectorIndex {
                                   bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
                                   float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
                                   hipStream_t st);
+    // exact fallback for the queries whose closest_up_nodes walk outgrew the LDS pool / visited table (hnsw_spill.hip)
+    int32_t segment_spill_search(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, bool with_duplicates,
+                                 int method, const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,
+                                 const std::vector<uint32_t> &flagged, hipStream_t st);
     int32_t rows_equal_host(uint32_t sa, uint32_t va, uint32_t sb, uint32_t vb, bool &eq);
     int32_t search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
                         const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,

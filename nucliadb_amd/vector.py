@@ -169,6 +169,21 @@ def _key_norm(key: str) -> str:
     return head + sep + rest
 
 
+def _field_key(key: str) -> Optional[str]:
+    """FieldKey::from_field_id (utils.rs:84-115) in text form: `uuidhex/type/name`, a bare `uuidhex` for a key that is only
+    a resource id, None when the uuid does not parse or a type comes without a name."""
+    parts = key.split("/")
+    try:
+        rid = _uuid.UUID(parts[0]).hex
+    except ValueError:
+        return None
+    if len(parts) == 1:
+        return rid
+    if len(parts) == 2:
+        return None
+    return f"{rid}/{parts[1]}/{parts[2]}"
+
+
 class VectorSegment:
     """An in-memory vector segment: what segment::create writes to disk (segment.rs:199-239) minus
     the files.  `graph` is an hnsw.graph image (DiskHnswV2) or None."""
@@ -201,10 +216,10 @@ class VectorSegment:
         for i, ls in enumerate(labels):
             for lab in ls:
                 lists.setdefault("L:" + lab[1:] + "/", []).append(i)
-        for i, k in enumerate(self._norm_keys):
-            parts = k.split("/")
-            if len(parts) >= 3:
-                lists.setdefault("F:" + "/".join(parts[:3]), []).append(i)
+        self._field_keys = [_field_key(k) for k in keys]
+        for i, fk in enumerate(self._field_keys):
+            if fk is not None:
+                lists.setdefault("F:" + fk, []).append(i)
         self.list_keys = sorted(lists)
         self.list_id = {k: j for j, k in enumerate(self.list_keys)}
         self.list_offsets = np.zeros(len(self.list_keys) + 1, dtype=np.uint64)
@@ -274,7 +289,9 @@ class VectorSegment:
         raise TypeError(f"unknown expression {expr!r}")
 
     def ids_for_deletion_key(self, key: str) -> List[int]:
-        """apply_deletions' lookup (segment.rs:428-445): a resource uuid or `uuid/type/name`."""
+        """apply_deletions' lookup (segment.rs:428-445): a resource uuid or `uuid/type/name`, as
+        field_index.get_prefix(FieldKey::from_field_id(key)) (inverted_index/paragraph.rs:118-120) — a BYTE prefix of the
+        indexed `uuid type/name` keys, so deleting `uuid/t/title` also reaches a field named `title2` of that resource."""
         parts = key.split("/")
         try:
             rid = _uuid.UUID(parts[0]).hex
@@ -283,10 +300,128 @@ class VectorSegment:
         if len(parts) == 1:
             prefix = rid + "/"
         elif len(parts) >= 3:
-            prefix = f"{rid}/{parts[1]}/{parts[2]}/"
+            prefix = f"{rid}/{parts[1]}/{parts[2]}"
         else:
             return []
-        return [i for i, k in enumerate(self._norm_keys) if k.startswith(prefix) or k == prefix[:-1]]
+        return [i for i, fk in enumerate(self._field_keys) if fk is not None and (fk + "/").startswith(prefix)]
+
+    # ---- segment directories (data_store/v2, hnsw/disk/v2) ----------------------------------------------------------
+    def save(self, path: str, dimension: Optional[int] = None) -> None:
+        """segment::create's file output (segment.rs:199-239): vectors.bin, paragraphs.bin/.pos, and — when present —
+        vectors.quant and hnsw.graph/.edges, through nidx_gpu_segment_dir_write."""
+        if self.graph is not None and self.graph_nodes:
+            raise NidxGpuError(_lib.NIDX_ERR_INVALID_ARGUMENT, "the graph covers only part of the segment: extend it before saving")
+        D = int(dimension or self.vectors.shape[1])
+
+        def table(items: List[bytes]):
+            offs = np.zeros(len(items) + 1, np.uint64)
+            offs[1:] = np.cumsum([len(b) for b in items])
+            return np.frombuffer(b"".join(items) or b"\0", np.uint8), offs
+
+        keys, key_offs = table([k.encode() for k in self.keys])
+        labs, lab_offs = table([l.encode() for ls in self.labels for l in ls])
+        pl_offs = np.zeros(self.records + 1, np.uint64)
+        pl_offs[1:] = np.cumsum([len(ls) for ls in self.labels])
+        meta, meta_offs = table([bytes(m or b"") for m in self.metadata])
+        c = _lib.SegmentDirContentsC()
+        c.dimension, c.n_vectors, c.n_paragraphs = D, self.vectors.shape[0], self.records
+        c.vectors = self.vectors.ctypes.data if self.vectors.size else None
+        c.paragraph_of_vector = None if self.para_of_vec is None else self.para_of_vec.ctypes.data
+        c.keys, c.key_offsets = keys.ctypes.data, key_offs.ctypes.data
+        c.labels, c.label_offsets, c.paragraph_label_offsets = labs.ctypes.data, lab_offs.ctypes.data, pl_offs.ctypes.data
+        c.metadata, c.metadata_offsets = meta.ctypes.data, meta_offs.ctypes.data
+        graph = np.frombuffer(self.graph, np.uint8) if self.graph else None
+        if graph is not None:
+            edges = self.graph_edges if self.graph_edges is not None else np.zeros(0, np.float32)
+            c.hnsw_graph, c.hnsw_graph_len = graph.ctypes.data, graph.size
+            c.hnsw_edges, c.n_hnsw_edges = (edges.ctypes.data if edges.size else None), edges.size
+        if self.quantized is not None and self.quantized.size:
+            c.quantized, c.quantized_len = self.quantized.ctypes.data, self.quantized.size
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_write(path.encode(), C.byref(c)))
+
+    @classmethod
+    def load(cls, path: str, dimension: int, tags: Optional[set] = None) -> "VectorSegment":
+        """segment::open's file side (segment.rs:39-90) through nidx_gpu_segment_dir_open, materialised as host arrays."""
+        with SegmentDir(path, dimension) as d:
+            return d.to_segment(tags)
+
+
+class SegmentDir:
+    """A mapped segment directory (nidx_gpu_segment_dir_*): the zero-copy views nidx_gpu_vector_open consumes, the rebuilt
+    inverted indexes and the paragraph records."""
+
+    def __init__(self, path: str, dimension: int):
+        self.dimension = dimension
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_open(path.encode(), dimension, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.lib().nidx_gpu_segment_dir_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def segment_c(self) -> "_lib.VectorSegmentC":
+        s = _lib.VectorSegmentC()
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_segment(self._h, C.byref(s)))
+        return s
+
+    def filter_index_c(self) -> "_lib.FilterIndexC":
+        fi = _lib.FilterIndexC()
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_filter_index(self._h, C.byref(fi)))
+        return fi
+
+    def lists(self, kind: int, key: str, prefix: bool = False) -> range:
+        """Posting-list ids the FST lookup selects (label prefix search / field get / field get_prefix)."""
+        k = key.encode()
+        first, count = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_lists(self._h, kind, k, len(k), int(prefix), C.byref(first), C.byref(count)))
+        return range(first.value, first.value + count.value)
+
+    def posting_list(self, list_id: int) -> np.ndarray:
+        fi = self.filter_index_c()
+        offs = np.ctypeslib.as_array(C.cast(fi.list_offsets, C.POINTER(C.c_uint64)), (fi.n_lists + 1,))
+        b, e = int(offs[list_id]), int(offs[list_id + 1])
+        if e == b:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(C.cast(fi.paragraph_ids, C.POINTER(C.c_uint32)), (int(offs[-1]),))[b:e].copy()
+
+    def paragraph(self, addr: int) -> Tuple[str, List[str], bytes, int, int]:
+        """(key, labels, metadata, first_vector, num_vectors) of one StoredParagraph."""
+        p = _lib.ParagraphC()
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_paragraph(self._h, addr, C.byref(p)))
+        labels = []
+        for i in range(p.n_labels):
+            ptr, n = C.c_void_p(), C.c_uint32(0)
+            _lib.check(_lib.lib().nidx_gpu_segment_dir_paragraph_label(self._h, addr, i, C.byref(ptr), C.byref(n)))
+            labels.append(C.string_at(ptr, n.value).decode())
+        return (C.string_at(p.key, p.key_len).decode(), labels, C.string_at(p.metadata, p.metadata_len) if p.metadata_len else b"",
+                p.first_vector, p.num_vectors)
+
+    def to_segment(self, tags: Optional[set] = None) -> VectorSegment:
+        s = self.segment_c()
+        D = self.dimension
+        n, npar = s.n_vectors, s.n_paragraphs
+        if n:
+            raw = np.ctypeslib.as_array(C.cast(s.vectors, C.POINTER(C.c_uint8)), (n * s.row_stride_bytes,)).reshape(n, s.row_stride_bytes)
+            vectors = raw[:, : D * 4].copy().view(np.float32).reshape(n, D)
+            pov = raw[:, D * 4: D * 4 + 4].copy().view(np.uint32).reshape(n)
+        else:
+            vectors, pov = np.zeros((0, D), np.float32), np.zeros(0, np.uint32)
+        paras = [self.paragraph(a) for a in range(npar)]
+        single = n == npar and bool(np.array_equal(pov, np.arange(n, dtype=np.uint32)))
+        graph = C.string_at(s.hnsw_graph, s.hnsw_graph_len) if s.hnsw_graph_len else None
+        edges = np.ctypeslib.as_array(C.cast(s.hnsw_edges, C.POINTER(C.c_float)), (s.n_hnsw_edges,)).copy() if s.n_hnsw_edges else None
+        quant = None
+        if s.quantized_len:
+            quant = np.ctypeslib.as_array(C.cast(s.quantized, C.POINTER(C.c_uint8)), (s.quantized_len,)).copy().reshape(n, -1)
+        return VectorSegment([p[0] for p in paras], vectors, [p[1] for p in paras], [p[2] for p in paras], tags, graph=graph,
+                             graph_edges=edges, quantized=quant, para_of_vec=None if single else pov)
 
 
 @dataclass
@@ -465,6 +600,12 @@ class VectorSearcher:
     def space_usage(self) -> int:
         out = C.c_uint64(0)
         _lib.check(_lib.lib().nidx_gpu_vector_space_usage(self._handle, C.byref(out)))
+        return out.value
+
+    def spill_queries(self) -> int:
+        """Queries re-run by the exact HBM-resident closest_up_nodes fallback since open."""
+        out = C.c_uint64(0)
+        _lib.check(_lib.lib().nidx_gpu_vector_spill_stats(self._handle, C.byref(out)))
         return out.value
 
     def build_hnsw(self, segment: int = 0, level_seed: int = 2):

@@ -701,3 +701,68 @@ def merge_bm25(lists, limit):
         sid = C.string_at(out[i].shard_id, out[i].shard_id_len) if out[i].shard_id_len else b""
         res.append((float(np.float32(out[i].bm25)), out[i].docaddr, sid, out[i].payload))
     return res
+
+
+# ---------------------------------------------------------------- segment directory formats (pure Python restatement)
+def _varint(v: int) -> bytes:
+    """bincode-2 `standard()` integer (what wincode's with_varint_encoding matches, nidx_vector/src/utils.rs:25-28):
+    < 251 one byte; else a marker 251 / 252 / 253 and the value as u16 / u32 / u64 little endian."""
+    if v < 251:
+        return bytes([v])
+    if v <= 0xFFFF:
+        return b"\xfb" + v.to_bytes(2, "little")
+    if v <= 0xFFFFFFFF:
+        return b"\xfc" + v.to_bytes(4, "little")
+    return b"\xfd" + v.to_bytes(8, "little")
+
+
+def _read_varint(b: bytes, at: int):
+    m = b[at]
+    if m < 251:
+        return m, at + 1
+    n = {251: 2, 252: 4, 253: 8}[m]
+    return int.from_bytes(b[at + 1: at + 1 + n], "little"), at + 1 + n
+
+
+def segment_dir_files(dimension, vectors, para_of_vec, keys, labels, metadata):
+    """The data-store files of one segment as the reference writes them: vectors.bin = per vector `dimension` f32 LE +
+    u32 LE paragraph address (data_store/v2/vector_store.rs:131-147; DenseF32 alignment 4 => no padding, :35-41);
+    paragraphs.bin = StoredParagraph {key: str, labels: Vec<str>, metadata: bytes, first_vector: u32, num_vectors: u32}
+    in field order (paragraph_store.rs:37-44), paragraphs.pos = u32 LE offset of each record (:132-150)."""
+    vectors = np.ascontiguousarray(vectors, dtype="<f4").reshape(-1, dimension)
+    pov = np.arange(len(vectors), dtype=np.uint32) if para_of_vec is None else np.asarray(para_of_vec, dtype=np.uint32)
+    vb = b"".join(vectors[i].tobytes() + int(pov[i]).to_bytes(4, "little") for i in range(len(vectors)))
+    data, pos = b"", b""
+    for a, key in enumerate(keys):
+        own = np.flatnonzero(pov == a)
+        first, num = (int(own[0]), len(own)) if len(own) else (0, 0)
+        rec = _varint(len(key.encode())) + key.encode() + _varint(len(labels[a]))
+        for lab in labels[a]:
+            rec += _varint(len(lab.encode())) + lab.encode()
+        rec += _varint(len(metadata[a])) + bytes(metadata[a]) + _varint(first) + _varint(num)
+        pos += len(data).to_bytes(4, "little")
+        data += rec
+    return {"vectors.bin": vb, "paragraphs.bin": data, "paragraphs.pos": pos}
+
+
+def parse_paragraphs(data: bytes, pos: bytes):
+    """-> [(key, labels, metadata, first_vector, num_vectors)] (ParagraphStore::get_paragraph, paragraph_store.rs:100-106)"""
+    out = []
+    for a in range(len(pos) // 4):
+        at = int.from_bytes(pos[4 * a: 4 * a + 4], "little")
+        n, at = _read_varint(data, at)
+        key = data[at: at + n].decode()
+        at += n
+        nl, at = _read_varint(data, at)
+        labs = []
+        for _ in range(nl):
+            n, at = _read_varint(data, at)
+            labs.append(data[at: at + n].decode())
+            at += n
+        n, at = _read_varint(data, at)
+        meta = data[at: at + n]
+        at += n
+        first, at = _read_varint(data, at)
+        num, at = _read_varint(data, at)
+        out.append((key, labs, meta, first, num))
+    return out

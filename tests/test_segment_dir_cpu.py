@@ -1,0 +1,153 @@
+"""Segment directories: the C-ABI reader / writer of vectors.bin, paragraphs.bin/.pos, vectors.quant and
+hnsw.graph/.edges against the pure-Python restatement of the formats in oracle/oracle.py.  Host code only: no GPU."""
+import os
+import uuid
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import SegmentDir, VectorSegment
+
+RID = [uuid.UUID(int=0x1000 + i) for i in range(4)]
+
+
+def corpus(rng, dimension=8):
+    keys, labels, metadata = [], [], []
+    fields = ["t/title", "t/title2", "a/body", "f/file/extra"]
+    for r, rid in enumerate(RID):
+        for f in fields[: 2 + r % 3]:
+            for p in range(2):
+                keys.append(f"{rid}/{f}/{p * 10}-{p * 10 + 9}")
+                labels.append([f"/l/set/label_{(r + p) % 3}"] + (["/l/set"] if p else []) + (["/e/entity/x"] if r == 1 else []))
+                metadata.append(bytes(rng.integers(0, 256, int(rng.integers(0, 12)), dtype=np.uint8)))
+    # varint boundaries: key lengths 250 / 251, a 70 000-byte metadata blob, many labels, no labels, a key without field
+    keys += [f"{RID[0]}/t/" + "k" * (250 - 39), f"{RID[0]}/t/" + "k" * (251 - 39), "not-a-uuid/t/x/0-1", str(RID[3])]
+    labels += [[], [f"/l/many/{i}" for i in range(300)], ["/l/set/label_0"], ["/l/set/label_1"]]
+    metadata += [b"", bytes(70000), b"\x00\xff", b"m"]
+    assert len(keys[-4]) == 250 and len(keys[-3]) == 251
+    vectors = rng.standard_normal((len(keys), dimension)).astype(np.float32)
+    return keys, labels, metadata, vectors
+
+
+def read(path, name):
+    with open(os.path.join(path, name), "rb") as f:
+        return f.read()
+
+
+def test_writer_bytes_equal_the_format_restatement(orc, tmp_path):
+    rng = np.random.default_rng(5)
+    keys, labels, metadata, vectors = corpus(rng)
+    seg = VectorSegment(keys, vectors, labels, metadata)
+    seg.save(str(tmp_path))
+    want = orc.segment_dir_files(8, vectors, None, keys, labels, metadata)
+    for name, data in want.items():
+        assert read(tmp_path, name) == data, name
+    assert sorted(os.listdir(tmp_path)) == ["paragraphs.bin", "paragraphs.pos", "vectors.bin"]
+    # the record layout, spelled out once: key "ab", labels ["/l/x"], metadata 01 02, first_vector 0, num_vectors 1
+    one = orc.segment_dir_files(2, [[1.0, 2.0]], None, ["ab"], [["/l/x"]], [b"\x01\x02"])
+    assert one["paragraphs.bin"] == b"\x02ab" + b"\x01\x04/l/x" + b"\x02\x01\x02" + b"\x00" + b"\x01"
+    assert one["vectors.bin"] == np.array([1.0, 2.0], "<f4").tobytes() + b"\x00\x00\x00\x00" and one["paragraphs.pos"] == b"\x00\x00\x00\x00"
+    assert orc._varint(250) == b"\xfa" and orc._varint(251) == b"\xfb\xfb\x00" and orc._varint(65536) == b"\xfc\x00\x00\x01\x00"
+
+
+def test_reader_decodes_reference_layout_and_rebuilds_the_inverted_indexes(orc, tmp_path):
+    rng = np.random.default_rng(6)
+    keys, labels, metadata, vectors = corpus(rng)
+    # multi-vector paragraphs: paragraph a owns 1 + a % 3 contiguous rows
+    pov = np.repeat(np.arange(len(keys), dtype=np.uint32), [1 + a % 3 for a in range(len(keys))])
+    rows = rng.standard_normal((len(pov), 8)).astype(np.float32)
+    for name, data in orc.segment_dir_files(8, rows, pov, keys, labels, metadata).items():
+        with open(tmp_path / name, "wb") as f:
+            f.write(data)
+    with SegmentDir(str(tmp_path), 8) as d:
+        s = d.segment_c()
+        assert s.n_vectors == len(pov) and s.n_paragraphs == len(keys) and s.row_stride_bytes == 36
+        assert not s.hnsw_graph_len and not s.quantized_len and not s.alive_bitset
+        want = orc.parse_paragraphs(read(tmp_path, "paragraphs.bin"), read(tmp_path, "paragraphs.pos"))
+        for a in range(len(keys)):
+            assert d.paragraph(a) == want[a] == (keys[a], labels[a], metadata[a], int(np.flatnonzero(pov == a)[0]), 1 + a % 3)
+        key_ids = np.ctypeslib.as_array(_lib.C.cast(s.paragraph_key_ids, _lib.C.POINTER(_lib.C.c_uint64)), (len(keys),))
+        assert len(set(key_ids.tolist())) == len(set(keys))
+        seg = d.to_segment()
+        assert np.array_equal(seg.vectors, rows) and np.array_equal(seg.para_of_vec, pov) and seg.keys == keys and seg.labels == labels
+        # label lookups = prefix search on labels_key (inverted_index/paragraph.rs:63-66,144-146)
+        def label_paragraphs(label):
+            ids = set()
+            for l in d.lists(_lib.LIST_LABEL, label):
+                ids.update(d.posting_list(l).tolist())
+            return sorted(ids)
+        for label in ["/l/set/label_0", "/l/set", "/l", "/e/entity", "/l/many/7", "/l/se", "/zzz"]:
+            want_ids = [a for a in range(len(keys)) if any((l[1:] + "/").startswith(label[1:] + "/") for l in labels[a])]
+            assert label_paragraphs(label) == want_ids, label
+        # field lookups: exact get for KeyPrefixSet, byte-prefix get_prefix for deletions (title also reaches title2)
+        def field_paragraphs(key, prefix):
+            ids = set()
+            for l in d.lists(_lib.LIST_FIELD, key, prefix):
+                ids.update(d.posting_list(l).tolist())
+            return sorted(ids)
+        r0 = str(RID[0])
+        title = [a for a, k in enumerate(keys) if k.startswith(f"{r0}/t/title/")]
+        title2 = [a for a, k in enumerate(keys) if k.startswith(f"{r0}/t/title2/")]
+        assert title and title2
+        assert field_paragraphs(f"{r0}/t/title", False) == title
+        assert field_paragraphs(f"{RID[0].hex}/t/title", False) == title          # simple form of the uuid
+        assert field_paragraphs(f"{r0}/t/title", True) == sorted(title + title2)
+        assert field_paragraphs(r0, True) == [a for a, k in enumerate(keys) if k.startswith(r0 + "/")]
+        assert field_paragraphs(r0, False) == []                                   # a bare resource key is not stored
+        assert field_paragraphs(f"{r0}/t", True) == [] and field_paragraphs("garbage/t/x", True) == []
+        # the Python mirror's deletion lookup agrees
+        for key in [f"{r0}/t/title", r0, f"{RID[2]}/a/body", "garbage", f"{r0}/t"]:
+            assert seg.ids_for_deletion_key(key) == field_paragraphs(key, True), key
+        # "not-a-uuid/…" is in no field list; a key that is a bare uuid is stored under the 16-byte resource key
+        # (FieldKey::from_field_id accepts it, utils.rs:109-113)
+        fi = d.filter_index_c()
+        all_field = set()
+        for l in range(fi.n_lists):
+            if l not in set(d.lists(_lib.LIST_LABEL, "/l")) | set(d.lists(_lib.LIST_LABEL, "/e")):
+                all_field.update(d.posting_list(l).tolist())
+        assert keys.index("not-a-uuid/t/x/0-1") not in all_field and keys.index(str(RID[3])) in all_field
+        assert field_paragraphs(str(RID[3]), False) == [keys.index(str(RID[3]))]
+
+
+def test_round_trip_with_graph_and_quantized_store(tmp_path):
+    rng = np.random.default_rng(8)
+    n, D = 37, 64
+    vectors = rng.standard_normal((n, D)).astype(np.float32)
+    keys = [f"{RID[i % 4]}/a/body/{i}-{i + 1}" for i in range(n)]
+    graph = bytes(rng.integers(0, 256, 997, dtype=np.uint8))   # opaque here
+    edges = rng.random(211).astype(np.float32)
+    quant = rng.integers(0, 256, (n, D // 8 + 8), dtype=np.uint8)
+    seg = VectorSegment(keys, vectors, [[] for _ in keys], [b"" for _ in keys], graph=graph, graph_edges=edges, quantized=quant)
+    seg.save(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["hnsw.edges", "hnsw.graph", "paragraphs.bin", "paragraphs.pos", "vectors.bin", "vectors.quant"]
+    assert read(tmp_path, "hnsw.graph") == graph and read(tmp_path, "hnsw.edges") == edges.tobytes() and read(tmp_path, "vectors.quant") == quant.tobytes()
+    back = VectorSegment.load(str(tmp_path), D)
+    assert back.keys == keys and np.array_equal(back.vectors, vectors) and back.graph == graph and back.para_of_vec is None
+    assert np.array_equal(back.graph_edges, edges) and np.array_equal(back.quantized, quant)
+
+
+def test_errors(tmp_path):
+    with pytest.raises(_lib.NidxGpuError) as e:
+        SegmentDir(str(tmp_path / "missing"), 8)
+    assert e.value.code == _lib.NIDX_ERR_IO
+    seg = VectorSegment(["k"], np.ones((1, 8), np.float32), [["/l/a"]], [b"meta"])
+    seg.save(str(tmp_path))
+    with pytest.raises(_lib.NidxGpuError) as e:      # dimension mismatch: the file is not a whole number of records
+        SegmentDir(str(tmp_path), 7)
+    assert e.value.code == _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS
+    data = read(tmp_path, "paragraphs.bin")
+    with open(tmp_path / "paragraphs.bin", "wb") as f:
+        f.write(data[:-3])
+    with pytest.raises(_lib.NidxGpuError) as e:
+        SegmentDir(str(tmp_path), 8)
+    assert e.value.code == _lib.NIDX_ERR_IO and "truncated" in str(e.value)
+    with open(tmp_path / "nodes.kv", "wb") as f:     # DataStoreV1
+        f.write(b"x")
+    with pytest.raises(_lib.NidxGpuError) as e:
+        SegmentDir(str(tmp_path), 8)
+    assert e.value.code == _lib.NIDX_ERR_UNSUPPORTED
+    # vectors of one paragraph must be contiguous
+    bad = VectorSegment(["a", "b"], np.ones((3, 8), np.float32), [[], []], [b"", b""], para_of_vec=np.array([0, 1, 0], np.uint32))
+    with pytest.raises(_lib.NidxGpuError):
+        bad.save(str(tmp_path))

@@ -1,0 +1,102 @@
+"""Segment directories end to end: a segment built, quantized and graphed on the device is written as
+the reference's files, read back and searched — through the host mirror, and zero-copy through the C ABI (the mapped files
+go straight into nidx_gpu_vector_open / nidx_gpu_vector_set_filter_index)."""
+import ctypes as C
+import uuid
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.vector import (And, Elem, FieldId, Literal, Not, PrefilterResult, SegmentDir, Similarity, VectorConfig, VectorSearcher,
+                                 VectorSearchRequest, VectorSegment, segment_create)
+
+pytestmark = pytest.mark.gpu
+
+
+def build(tmp_path, n=3000, D=64):
+    rng = np.random.default_rng(17)
+    config = VectorConfig.for_paragraphs(D)
+    config.similarity = Similarity.Dot          # quantizable: vectors.quant is written too
+    rids = [str(uuid.UUID(int=0x5000 + i)) for i in range(40)]
+    v = rng.standard_normal((n, D)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    elems = [Elem(f"{rids[i % 40]}/{'a/title' if i % 3 else 't/body'}/{i}-{i + 5}", v[i].tolist(), labels=[f"/l/set/label_{i % 7}"] + (["/l/other/x"] if i % 5 == 0 else []),
+                  metadata=bytes([i % 251, 1, 2]) if i % 2 else b"") for i in range(n)]
+    seg = segment_create(elems, config)
+    s = VectorSearcher.open(config, [(seg, 1)])
+    s.build_hnsw(0)
+    seg.graph, seg.graph_edges = s.serialize_hnsw(0)
+    seg.quantized = s.serialize_quantized(0)
+    seg.save(str(tmp_path))
+    return config, seg, s, rids, rng
+
+
+def test_saved_segment_searches_identically(tmp_path):
+    config, seg, s, rids, rng = build(tmp_path)
+    back = VectorSegment.load(str(tmp_path), config.dimension)
+    assert back.keys == seg.keys and back.labels == seg.labels and back.metadata == seg.metadata
+    assert np.array_equal(back.vectors, seg.vectors) and back.graph == seg.graph and np.array_equal(back.quantized, seg.quantized)
+    s2 = VectorSearcher.open(config, [(back, 1)])
+    q = rng.standard_normal((64, config.dimension)).astype(np.float32)
+    some = PrefilterResult.some([FieldId(uuid.UUID(rids[3]), "/a/title"), FieldId(uuid.UUID(rids[4]), "/t/body")])
+    cases = [(None, None), (Literal("/l/set/label_3"), None), (And([Literal("/l/set"), Not(Literal("/l/other"))]), None), (None, some)]
+    for method in (_lib.METHOD_HNSW, _lib.METHOD_BRUTE_FORCE, _lib.METHOD_AUTO):
+        for formula, pre in cases:
+            req = VectorSearchRequest(vector=[], result_per_page=10, min_score=-1.0, filtering_formula=formula)
+            a = s.search_batch(req, q, pre, method)
+            b = s2.search_batch(req, q, pre, method)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (method, formula)
+            assert s.last_methods == s2.last_methods and s.last_matching == s2.last_matching
+    s.close()
+    s2.close()
+
+
+def test_mapped_directory_feeds_the_c_abi_without_copies(tmp_path):
+    config, seg, s, rids, rng = build(tmp_path)
+    L = _lib.lib()
+    q = rng.standard_normal((32, config.dimension)).astype(np.float32)
+    k = 10
+    with SegmentDir(str(tmp_path), config.dimension) as d:
+        c_seg = (_lib.VectorSegmentC * 1)(d.segment_c())
+        assert c_seg[0].hnsw_graph_len == len(seg.graph) and c_seg[0].quantized_len == seg.quantized.size
+        cfg = config.to_c()
+        h = C.c_void_p()
+        _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), c_seg, 1, C.byref(h)))
+        try:
+            fi = d.filter_index_c()
+            _lib.check(L.nidx_gpu_vector_set_filter_index(h, 0, C.byref(fi)))
+            # formula: label_2 AND NOT field (rids[5], a/title)  — list ids come from the directory's lookups
+            lab = list(d.lists(_lib.LIST_LABEL, "/l/set/label_2"))
+            fld = list(d.lists(_lib.LIST_FIELD, f"{rids[5]}/a/title"))
+            assert len(lab) == 1 and len(fld) == 1
+            lists = np.array(lab + fld, np.uint32)
+            ops = (_lib.FilterOpC * 4)(_lib.FilterOpC(_lib.FILTER_PUSH_LISTS, 0, 1), _lib.FilterOpC(_lib.FILTER_PUSH_LISTS, 1, 2),
+                                       _lib.FilterOpC(_lib.FILTER_NOT, 0, 0), _lib.FilterOpC(_lib.FILTER_AND, 0, 0))
+            prog = (_lib.FilterProgramC * 1)(_lib.FilterProgramC(C.addressof(ops), 4, lists.ctypes.data, 2))
+            out = [np.zeros((32, k), np.uint32) for _ in range(3)] + [np.zeros((32, k), np.float32), np.zeros(32, np.uint32)]
+            method, matching = np.zeros(1, np.int32), np.zeros(1, np.uint64)
+            params = _lib.VectorSearchParamsC(k, -1.0, 0, _lib.METHOD_AUTO)
+            _lib.check(L.nidx_gpu_vector_search_filtered(h, q.ctypes.data, 32, config.dimension, C.byref(params), prog, out[0].ctypes.data,
+                                                         out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, out[4].ctypes.data,
+                                                         method.ctypes.data, matching.ctypes.data))
+        finally:
+            L.nidx_gpu_vector_close(h)
+        # the same request through the in-memory mirror
+        formula = And([Literal("/l/set/label_2"), Not(_field(rids[5], "/a/title"))])
+        req = VectorSearchRequest(vector=[], result_per_page=k, min_score=-1.0, filtering_formula=formula)
+        want = s.search_batch(req, q, None, _lib.METHOD_AUTO)
+        for x, y in zip(out, want):
+            assert np.array_equal(x, y)
+        assert int(matching[0]) == s.last_matching[0] and int(method[0]) == s.last_methods[0]
+        # hits resolve to the stored paragraph records
+        key, labels, meta, first, num = d.paragraph(int(out[1][0, 0]))
+        p = int(out[1][0, 0])
+        assert key == seg.keys[p] and labels == seg.labels[p] and meta == seg.metadata[p] and (first, num) == (p, 1)
+    s.close()
+
+
+def _field(rid, field_id):
+    from nucliadb_amd.vector import _KeyPrefixSet
+    return _KeyPrefixSet([uuid.UUID(rid).hex + field_id])

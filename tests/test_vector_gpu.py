@@ -28,7 +28,7 @@ def make_segment(x, graph=None):
     return VectorSegment([f"k{i}" for i in range(n)], x, [[] for _ in range(n)], [b""] * n, graph=graph)
 
 
-def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_duplicates=True, filter_bits=None, alive=None):
+def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_duplicates=True, filter_bits=None, alive=None, info=None):
     """Single segment straight through the C ABI (no Python filter logic in between)."""
     L = _lib.lib()
     n, d = x.shape
@@ -48,6 +48,10 @@ def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_d
             fp = (C.c_void_p * 1)(filter_bits.ctypes.data)
         _lib.check(L.nidx_gpu_vector_search(h, q.ctypes.data, B, C.byref(params), fp, None, None, ov.ctypes.data,
                                             osc.ctypes.data, oc.ctypes.data, None))
+        if info is not None:
+            n_spill = C.c_uint64(0)
+            _lib.check(L.nidx_gpu_vector_spill_stats(h, C.byref(n_spill)))
+            info["spill_queries"] = n_spill.value
         return ov, osc, oc
     finally:
         L.nidx_gpu_vector_close(h)
@@ -160,6 +164,32 @@ def test_hnsw_search_filter_and_min_score(orc, hnsw_case):
                 assert oc[i] == len(wv), (sel, ms, i, oc[i], len(wv))
                 assert np.array_equal(ov[i, : oc[i]], wv)
                 assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_hnsw_walk_larger_than_the_on_chip_pool_matches_oracle(orc, hnsw_case):
+    """closest_up_nodes (search.rs:188-240) keeps an unbounded heap and visited set: under a filter that lets one row in
+    a hundred (or a thousand) through, the walk pops far more nodes than the kernel's LDS pool holds.  Those queries are
+    re-run by the HBM-resident fallback (hnsw_spill.hip) and must still equal the oracle bit for bit."""
+    x, oseg, gbytes = hnsw_case
+    n = x.shape[0]
+    rng = np.random.default_rng(31)
+    q = np.vstack([x[49][None, :], unit_rows(rng, 23, x.shape[1])])
+    spilled = 0
+    for sel, k, with_dup, ms in ((0.01, 10, True, -1.0), (0.003, 10, False, -1.0), (0.02, 40, True, -1.0), (0.01, 10, True, 0.05), (0.0, 5, True, -1.0)):
+        ones = np.nonzero(rng.random(n) < sel)[0].tolist() if sel else [7]      # sel 0: a single admissible row
+        if sel == 0.003:
+            ones = sorted(set(ones) | set(range(49, 58)))                        # the duplicated rows: RepCounter in the fallback
+        filt = orc.bitset(n, ones=ones)
+        info = {}
+        ov, osc, oc = gpu_search(x, 1, q, k, method=_lib.METHOD_HNSW, graph=gbytes, filter_bits=filt, min_score=ms, with_duplicates=with_dup,
+                                 info=info)
+        spilled += info["spill_queries"]
+        for i in range(q.shape[0]):
+            wv, ws = oseg.hnsw_search(q[i], k, min_score=ms, filter_bits=filt, with_duplicates=with_dup)
+            assert oc[i] == len(wv), (sel, k, i, oc[i], len(wv))
+            assert np.array_equal(ov[i, : oc[i]], wv), (sel, k, i)
+            assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+    assert spilled > 0  # the fallback really ran
 
 
 def test_auto_routing_follows_use_hnsw(orc, hnsw_case):
