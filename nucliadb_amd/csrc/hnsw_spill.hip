@@ -17,9 +17,10 @@ namespace nidx {
 
 namespace {
 
-// device-scope accesses: the wave re-reads slots other lanes wrote a few instructions earlier
-__device__ inline uint64_t ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void st64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the controller wave re-reads slots its other lanes wrote a few instructions earlier: workgroup-scope accesses keep that
+// coherent through the CU's L1 (agent scope would bypass the per-XCD L2 on every access)
+__device__ inline uint64_t ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void st64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int NJ>
 __device__ inline bool spill_rows_equal(const SegDev &seg, uint32_t a, uint32_t b, int lane) {

@@ -59,16 +59,14 @@ hipError_t launch_mfma_scan(const MfmaScanArgs &a, uint32_t stripes, hipStream_t
 // ---- bf16-MFMA brute-force fallback with exact re-scoring (vector_bf16.hip) ----
 #define NIDX_BF16_CAND 32  /* approximate candidates kept per query before the exact re-score */
 struct Bf16ScanArgs {
-    const unsigned short *vectors16;  // [n][dp16] bf16
-    const float *norm2;               // [n] |x|^2 (cosine) or nullptr
+    const unsigned short *vectors16;  // tiled bf16 blocks [ceil(n / 256)][dp16 / 16][256][16] (vector_bf16.hip "Operand layout")
     uint32_t n, dp16;
-    const unsigned short *queries16;  // [n_queries][dp16] bf16
-    const float *q_norm2;             // [n_queries]
+    const unsigned short *queries16;  // tiled the same way, [ceil(n_queries / 256)][dp16 / 16][256][16]
     uint32_t n_queries;
-    const uint64_t *alive, *filter;
-    const uint32_t *para_of_vec;
-    int similarity;
+    const uint64_t *row_mask;         // [ceil(n / 256) * 4] bit r = row r is scanned (launch_bf16_row_mask)
     uint64_t *partial;                // [n_queries][stripes][NIDX_BF16_CAND]
+    int debug;                        // diagnostics (env NIDX_GPU_BF16_DEBUG): 1 = no candidate admitted (GEMM time only)
+    const float *floor_score;         // nullptr or [n_queries]: a score at least NIDX_BF16_CAND rows are known to reach (sample pass)
 };
 struct RescoreArgs {
     const float *vectors;   // [n][dp] f32
@@ -84,7 +82,12 @@ struct RescoreArgs {
     float *out_score;
     uint32_t *out_count;
 };
-hipError_t launch_to_bf16(const float *in, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s);
+// rows -> the tiled bf16 operand layout; norm2 != nullptr scales every row by 1 / sqrt(norm2[row]) (cosine)
+hipError_t launch_to_bf16_tiled(const float *in, const float *norm2, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s);
+// floor[q] = the NIDX_BF16_CAND-th best score of query q's merged sample candidates (count < NIDX_BF16_CAND: -inf)
+hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, float *floor, hipStream_t s);
+hipError_t launch_bf16_row_mask(uint32_t n, const uint32_t *para_of_vec, const uint64_t *alive, const uint64_t *filter, uint64_t *out,
+                                hipStream_t s);
 uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries);
 hipError_t launch_bf16_scan(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s);
 hipError_t launch_rescore_select(const RescoreArgs &a, hipStream_t s);

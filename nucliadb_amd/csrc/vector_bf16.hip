@@ -13,6 +13,9 @@
 // measured, not assumed (tests/test_vector_gpu.py).  This method is explicit
 // (NIDX_METHOD_BRUTE_FORCE_BF16), never chosen by the cost model.
 #include "device_common.h"
+#include <algorithm>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace nidx {
@@ -20,21 +23,39 @@ namespace nidx {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define BF_BM 128
-#define BF_BN 128
-#define BF_BK 32                 /* bf16 elements per chunk = 64 B per row */
-#define BF_PITCH_B 80            /* bytes per LDS row: 64 + 16 pad => b128 reads hit 16 distinct slots (5i mod 16) */
-#define BF_KP NIDX_BF16_CAND     /* candidates kept per query */
+#define BF_BM 256                /* queries per workgroup */
+#define BF_BN 256                /* corpus rows per tile */
+#define BF_BK 16                 /* bf16 elements per K step = one 32-byte LDS row */
+#define BF_BLOCK_BYTES (256 * BF_BK * 2)     /* one operand block: 256 rows x 32 B = 8 KiB */
+#define BF_STAGE_BYTES (2 * BF_BLOCK_BYTES)  /* [Q block][X block] */
+#define BF_STAGES 5
+#define BF_KP NIDX_BF16_CAND     /* candidates kept per query and list */
+#define BF_THREADS 512
 
+// Operand layout.  Both bf16 operands are stored TILED in HBM: for a tile of 256 rows and K step kc (16 elements) the 8-KiB
+// block [256 rows][2 chunks of 16 B], blocks ordered [tile][kc].  A block is exactly the LDS image of that K step, bank swizzle
+// included (chunk position p of row r holds K chunk p ^ ((r >> 3) & 1): the 16 lanes of a ds_read_b128 phase then hit 16
+// distinct 16-byte bank groups), so staging is a linear copy: global_load_lds_dwordx4, 1 KiB per wave instruction, every
+// 128-byte line of the stream used in full.  Cosine indexes store x / |x| (and q / |q|), so the accumulator IS the approximate
+// score; rows outside the filter / alive set / past n are masked by a per-call bitset (bf16_row_mask_kernel).
+//
+// Tiling.  One workgroup of 8 waves per CU owns 256 queries and walks its stripe of 256-row corpus tiles; wave w holds the
+// 32 x 256 block of scores of queries 32 w.. against the whole tile as 8 accumulators of v_mfma_f32_32x32x16_bf16 (128
+// VGPRs): a K step costs 1 + 8 fragment reads (ds_read_b128) for 8 MFMAs, and — the point of giving a wave its own queries —
+// the candidate lists of a query are touched by exactly one wave, so they stay in LDS without locks.
+//
+// Pipeline.  The K steps of all the tiles of a stripe form one stream; step g lives in stage g % 5 and its two 8-KiB blocks
+// are requested FOUR steps ahead (2 DMA pieces per wave and step).  Per step: s_waitcnt vmcnt(6) — this wave's pieces of step g
+// have landed, three later steps stay in flight — then one raw s_barrier (everybody's pieces landed; everybody is done reading
+// step g - 1), then the request for step g + 4 into the stage step g - 1 used, then the fragment reads and MFMAs.  Nothing in
+// the loop waits for vmcnt(0), so HBM / L2 latency is covered by four steps of MFMA work; the epilogue between two tiles uses
+// LDS and scalar loads only and leaves the DMA queue alone.
+// LDS: 80 KiB stages + 64 KiB lists + 3 KiB thresholds.
 struct Bf16Shared {
-    unsigned char q[2][BF_BM][BF_PITCH_B];
-    unsigned char x[2][BF_BN][BF_PITCH_B];
+    __attribute__((aligned(16))) unsigned char stage[BF_STAGES][BF_STAGE_BYTES];
     uint64_t lists[BF_BM][BF_KP];
     uint64_t thr_key[BF_BM];
     float thr_score[BF_BM];
-    float q_rinv[BF_BM];
-    float row_rinv[BF_BN];
-    uint32_t row_ok[BF_BN];
 };
 
 __device__ inline unsigned short f32_to_bf16_rne(float f) {
@@ -44,166 +65,270 @@ __device__ inline unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 
-// rows [n][dp] f32 -> [n][dp16] bf16 (dp16 = dp rounded up to 64, zero padded)
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ in, uint32_t n, uint32_t dp, uint32_t dp16,
-                                                      unsigned short *__restrict__ out) {
-    const size_t total = (size_t)n * dp16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t r = (uint32_t)(i / dp16), c = (uint32_t)(i % dp16);
-        out[i] = c < dp ? f32_to_bf16_rne(in[(size_t)r * dp + c]) : (unsigned short)0;
+// rows [n][dp] f32 -> tiled bf16 blocks [ceil(n / 256)][dp16 / 16][256][16] (see "Operand layout"); rows past n and columns past
+// dp are zero; norm2 != nullptr: rows are scaled by 1 / sqrt(norm2[row]) (cosine).  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void to_bf16_tiled_kernel(const float *__restrict__ in, const float *__restrict__ norm2, uint32_t n, uint32_t dp,
+                                                            uint32_t dp16, unsigned short *__restrict__ out) {
+    const uint32_t nk = dp16 / BF_BK;
+    const size_t n_chunks = (size_t)((n + 255u) / 256u) * nk * 512u;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(c & 1u), rr = (uint32_t)((c >> 1) & 255u);
+        const size_t blk = c >> 9;
+        const uint32_t kc = (uint32_t)(blk % nk);
+        const uint32_t row = (uint32_t)(blk / nk) * 256u + rr;
+        const uint32_t k0 = kc * BF_BK + 8u * (p ^ ((rr >> 3) & 1u));
+        unsigned short v[8];
+        float scale = 1.0f;
+        if (row < n && norm2) {
+            const float nn = norm2[row];
+            scale = nn > 0.f ? 1.0f / sqrtf(nn) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (row < n && k0 + e < dp) ? f32_to_bf16_rne(in[(size_t)row * dp + k0 + e] * scale) : (unsigned short)0;
+        uint4 o;
+        o.x = v[0] | ((uint32_t)v[1] << 16);
+        o.y = v[2] | ((uint32_t)v[3] << 16);
+        o.z = v[4] | ((uint32_t)v[5] << 16);
+        o.w = v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<uint4 *>(out + c * 8) = o;
     }
 }
 
-__device__ inline void bf_stage_load(const unsigned short *base, uint32_t n_rows, uint32_t row0, uint32_t dp16, uint32_t k0,
-                                     int tid, uint4 (&regs)[2]) {
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        uint32_t row = row0 + (uint32_t)(tid >> 2) + 64u * it;
-        uint32_t k = k0 + 8u * (uint32_t)(tid & 3);
-        if (row < n_rows && k < dp16) regs[it] = *reinterpret_cast<const uint4 *>(base + (size_t)row * dp16 + k);
-        else regs[it] = make_uint4(0, 0, 0, 0);
+// bit r of the mask = row r takes part: r < n, its paragraph alive and inside the filter
+__global__ __launch_bounds__(256) void bf16_row_mask_kernel(uint32_t n, uint32_t n_pad, const uint32_t *__restrict__ para_of_vec,
+                                                            const uint64_t *__restrict__ alive, const uint64_t *__restrict__ filter,
+                                                            uint64_t *__restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = r < n;
+    if (ok) {
+        const uint32_t p = para_of_vec ? para_of_vec[r] : r;
+        if (alive && !bit_test(alive, p)) ok = false;
+        if (ok && filter && !bit_test(filter, p)) ok = false;
     }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && r < n_pad) out[r >> 6] = m;
 }
-__device__ inline void bf_stage_store(unsigned char (&tile)[BF_BM][BF_PITCH_B], int tid, const uint4 (&regs)[2]) {
+
+template <int AUX>
+__device__ inline void bf_glds16(const unsigned char *src, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, AUX);
+}
+
+// One 32 x 32 accumulator (the wave's 32 queries qb.., tile rows jb..) -> the candidate lists of its queries.  A lane holds
+// tile row jb + li against the 16 queries qb + (r & 3) + 8 (r >> 2) + 4 half.  ok_word: the 32 row-mask bits of jb.. .
+__device__ __forceinline__ void bf_epilogue_tile(const floatx16 &acc, float (&thr)[16], Bf16Shared &sh, uint32_t ok_word, uint32_t r0, int qb, int jb,
+                                                 int lane) {
+    const int li = lane & 31, half = lane >> 5;
+    const uint32_t row = r0 + (uint32_t)(jb + li);
+    const bool row_ok = (ok_word >> li) & 1u;
+    // thr[r]: this lane's copy of the threshold of query qb + (r & 3) + 8 (r >> 2) + 4 half, loaded once per tile; a stale value
+    // only lets a few extra candidates through to the exact key test below; padding queries carry +inf
+    uint32_t mask = 0;
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-        int row = (tid >> 2) + 64 * it;
-        *reinterpret_cast<uint4 *>(&tile[row][16 * (tid & 3)]) = regs[it];
+    for (int r = 0; r < 16; r++) mask |= (row_ok && acc[r] > thr[r]) ? (1u << r) : 0u;
+    if (!__ballot(mask != 0)) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const unsigned long long m = __ballot((mask >> r) & 1u);
+        if (!m) continue;
+        const uint64_t key = rank_key(acc[r], row);
+        // the lanes of one half share the query: its list is loaded once, takes every candidate of the group in registers, and
+        // goes back once
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned long long mh = m & (h ? 0xffffffff00000000ull : 0x00000000ffffffffull);
+            if (!mh) continue;
+            const int sq = qb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            WaveSortedList l;
+            l.key = lane < BF_KP ? sh.lists[sq][lane] : NIDX_EMPTY_KEY;
+            uint64_t kth = sh.thr_key[sq];
+            bool changed = false;
+            while (mh) {
+                const int src_lane = __ffsll((long long)mh) - 1;
+                mh &= mh - 1;
+                const uint64_t nk_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src_lane) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src_lane);
+                if (!(nk_ > kth)) continue;
+                l.insert(nk_, lane);
+                const uint64_t last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(l.key >> 32), BF_KP - 1) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)l.key, BF_KP - 1);
+                if (last != NIDX_EMPTY_KEY) kth = last;
+                changed = true;
+            }
+            if (changed) {
+                if (lane < BF_KP) sh.lists[sq][lane] = l.key;
+                if (lane == 0 && kth != NIDX_EMPTY_KEY) {
+                    sh.thr_key[sq] = kth;
+                    sh.thr_score[sq] = fmaxf(sh.thr_score[sq], rank_key_score(kth));   // never below the sample floor
+                }
+            }
+        }
+        thr[r] = sh.thr_score[qb + (r & 3) + 8 * (r >> 2) + 4 * half];   // what this group may just have raised
     }
 }
 
-__global__ __launch_bounds__(256, 2) void bf16_scan_kernel(Bf16ScanArgs a) {
-    __shared__ Bf16Shared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(BF_THREADS, 1) void bf16_scan_kernel(Bf16ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
+    Bf16Shared &sh = *reinterpret_cast<Bf16Shared *>(bf_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, half = lane >> 5;
     const uint32_t q0 = blockIdx.y * BF_BM;
-    const bool cosine = a.similarity == 1;
     const uint32_t n_tiles = (a.n + BF_BN - 1) / BF_BN;
     const uint32_t nk = a.dp16 / BF_BK;
 
     if (tid < BF_BM) {
-        uint32_t qi = q0 + tid < a.n_queries ? q0 + tid : a.n_queries - 1;
-        sh.q_rinv[tid] = cosine ? 1.0f / sqrtf(a.q_norm2[qi]) : 1.0f;
-        sh.thr_key[tid] = NIDX_EMPTY_KEY;
-        sh.thr_score[tid] = -INFINITY;
-    }
-    for (int i = tid; i < BF_BM * BF_KP; i += 256) (&sh.lists[0][0])[i] = NIDX_EMPTY_KEY;
-
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t r0 = tile * BF_BN;
-        __syncthreads();
-        if (tid < BF_BN) {
-            uint32_t r = r0 + tid;
-            bool ok = r < a.n;
-            float rinv = 1.0f;
-            if (ok) {
-                uint32_t p = a.para_of_vec ? a.para_of_vec[r] : r;
-                if (a.alive && !bit_test(a.alive, p)) ok = false;
-                if (ok && a.filter && !bit_test(a.filter, p)) ok = false;
-                if (cosine) rinv = 1.0f / sqrtf(a.norm2[r]);
+        const bool real = q0 + tid < a.n_queries && !(a.debug & 1);
+        sh.thr_key[tid] = real ? NIDX_EMPTY_KEY : ~0ull;     // padding queries admit nothing
+        // sample pass: BF_KP rows reach floor_score, so a row strictly below it is not among the query's BF_KP best; the test
+        // below is `>`, hence the largest float under the floor
+        float t0 = -INFINITY;
+        if (real && a.floor_score) {
+            const float f = a.floor_score[q0 + tid];
+            if (f > -INFINITY) {
+                const int32_t k = total_key(f) - 1;                                               // the float just below f in total order
+                t0 = __builtin_bit_cast(float, k ^ (int32_t)(((uint32_t)(k >> 31)) >> 1));   // total_key is its own inverse
             }
-            sh.row_ok[tid] = ok ? 1u : 0u;
-            sh.row_rinv[tid] = rinv;
         }
-        floatx16 acc[4];
+        sh.thr_score[tid] = real ? t0 : INFINITY;
+    }
+    for (int i = tid; i < BF_BM * BF_KP; i += BF_THREADS) (&sh.lists[0][0])[i] = NIDX_EMPTY_KEY;
+
+    // the stream of K steps of this workgroup's tiles: tile ordinal i -> tile blockIdx.x + i * gridDim.x
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t G = my_tiles * nk;
+    // DMA role of this wave: waves 0-3 copy the query block, 4-7 the corpus block; two 1-KiB pieces each.  The wave keeps one
+    // running source pointer: + 8 KiB per step; when a tile's last step has been requested the query waves rewind to the first
+    // block, the corpus waves jump to the stripe's next tile (or rewind on the last one: the requests run ahead of the work and
+    // simply re-read valid blocks into stages nobody looks at again — that keeps "four steps in flight" true to the very end, so
+    // the loop needs a single s_waitcnt vmcnt(6) and no tail cases).
+    const bool q_role = wave < 4;
+    const long long blk_tile = (long long)nk * BF_BLOCK_BYTES;                 // bytes of one tile's blocks
+    const long long wrap_back = -blk_tile;
+    const long long wrap_fwd = q_role ? -blk_tile : (long long)(gridDim.x - 1) * blk_tile;
+    const unsigned char *ptr = (q_role ? reinterpret_cast<const unsigned char *>(a.queries16) + (size_t)blockIdx.y * blk_tile
+                                       : reinterpret_cast<const unsigned char *>(a.vectors16) + (size_t)blockIdx.x * blk_tile) +
+                               (uint32_t)((wave & 3) * 2) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t dst_wave = (q_role ? 0u : (uint32_t)BF_BLOCK_BYTES) + (uint32_t)(wave & 3) * 2048u;
+    uint32_t is_kc = 0, is_tile = blockIdx.x;   // the next step to request
+    uint32_t wr_stage = 0, rd_stage = 0;        // byte offsets of the stage written next / read next
+    auto issue = [&]() __attribute__((always_inline)) {
+        unsigned char *dst = &sh.stage[0][0] + wr_stage + dst_wave;
+        bf_glds16<0>(ptr, dst);   // (the non-temporal hint, aux = 2, on the corpus stream measured 9 % slower)
+        bf_glds16<0>(ptr + 1024, dst + 1024);
+        ptr += BF_BLOCK_BYTES;
+        wr_stage = wr_stage + BF_STAGE_BYTES == BF_STAGES * BF_STAGE_BYTES ? 0 : wr_stage + BF_STAGE_BYTES;
+        if (++is_kc == nk) {
+            is_kc = 0;
+            if (is_tile + gridDim.x < n_tiles) {
+                is_tile += gridDim.x;
+                ptr += wrap_fwd;
+            } else {
+                ptr += wrap_back;
+            }
+        }
+    };
+    __syncthreads();  // lists / thresholds initialised
+    if (G)
+        for (int i = 0; i < BF_STAGES - 1; i++) issue();
+
+    // fragment addresses inside a stage: row r = 32 B, chunk position = half ^ ((r >> 3) & 1)
+    const int frag = (half ^ ((li >> 3) & 1)) * 16;
+    const int a_off = (32 * wave + li) * 32 + frag, b_off = BF_BLOCK_BYTES + li * 32 + frag;
+
+    // Next step: wait until its blocks are in LDS for everybody, request the step four ahead, read its nine fragments.  The
+    // fragment reads of the previous step (issued one call earlier, into the other register set) are drained first: the request
+    // below reuses the stage they came from.
+    floatx16 acc[8];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    auto mma = [&](const bf16x8 &av, const bf16x8 (&bv)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[t], acc[t], 0, 0, 0);
+    };
+    // The two waves of a SIMD (w and w + 4) take the two halves of a step in opposite order, so that one of them feeds the
+    // matrix core while the other one is busy with the barrier, the DMA requests and its LDS reads: waves 0-3 run the previous
+    // step's MFMAs first and read afterwards, waves 4-7 read first.
+    auto step = [&](auto mma_first_tag, bf16x8 &av, bf16x8 (&bv)[8], bf16x8 &pav, bf16x8 (&pbv)[8], bool with_mma) __attribute__((always_inline)) {
+        constexpr bool mma_first = decltype(mma_first_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);  // the MFMAs issued before this call stay before it
+        // s_waitcnt vmcnt(6) lgkmcnt(0) — this wave's two pieces of the step have landed, three later steps stay in flight — as
+        // the builtin (gfx9 encoding: vmcnt [3:0], expcnt [6:4] = 7 "no wait", lgkmcnt [11:8]), so that the compiler's own
+        // wait-count bookkeeping knows the LDS queue is empty here
+        __builtin_amdgcn_s_waitcnt(0x0076);
+        // the previous step's fragments (the other register set) are complete now; re-defining them through an empty asm keeps
+        // the compiler from waiting for them again — with the new reads already queued behind — in front of their MFMAs
+        asm volatile("" : "+v"(pav), "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]), "+v"(pbv[4]), "+v"(pbv[5]), "+v"(pbv[6]), "+v"(pbv[7]));
+        __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody is done with the stage of the previous step
+        issue();                       // four steps ahead -> the stage the previous step used
+        const unsigned char *base = &sh.stage[0][0] + rd_stage;
+        rd_stage = rd_stage + BF_STAGE_BYTES == BF_STAGES * BF_STAGE_BYTES ? 0 : rd_stage + BF_STAGE_BYTES;
+        if constexpr (mma_first) {
+            if (with_mma) mma(pav, pbv);
+            __builtin_amdgcn_sched_barrier(0);
+            av = *reinterpret_cast<const bf16x8 *>(base + a_off);
+#pragma unroll
+            for (int t = 0; t < 8; t++) bv[t] = *reinterpret_cast<const bf16x8 *>(base + b_off + 32 * t * 32);
+        } else {
+            av = *reinterpret_cast<const bf16x8 *>(base + a_off);
+#pragma unroll
+            for (int t = 0; t < 8; t++) bv[t] = *reinterpret_cast<const bf16x8 *>(base + b_off + 32 * t * 32);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (they belong to the other register set)
+            if (with_mma) mma(pav, pbv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    bf16x8 av0 = {}, bv0[8] = {}, av1 = {}, bv1[8] = {};
+    // approximate scores of a finished tile -> per-query candidate lists (one accumulator at a time); LDS + scalar loads only
+    auto epilogue = [&](uint32_t tile) __attribute__((always_inline)) {
+        const uint32_t r0 = tile * BF_BN;
+        // the tile's 256 row-mask bits through the scalar cache (a vector load here would make the compiler drain the DMA queue)
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        u32x8 okw;
+        const uint64_t *mp = a.row_mask + (r0 >> 6);
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(okw) : "s"(mp) : "memory");
+        float thr[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) thr[r] = sh.thr_score[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half];
+#define BF_EPI(T) bf_epilogue_tile(acc[T], thr, sh, okw[T], r0, 32 * wave, 32 * (T), lane)
+        BF_EPI(0); BF_EPI(1); BF_EPI(2); BF_EPI(3); BF_EPI(4); BF_EPI(5); BF_EPI(6); BF_EPI(7);
+#undef BF_EPI
+#pragma unroll
+        for (int t = 0; t < 8; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    };
 
-        uint4 gq[2], gx[2], nq_[2], nx_[2];
-        bf_stage_load(a.queries16, a.n_queries, q0, a.dp16, 0, tid, gq);
-        bf_stage_load(a.vectors16, a.n, r0, a.dp16, 0, tid, gx);
-        bf_stage_store(sh.q[0], tid, gq);
-        bf_stage_store(sh.x[0], tid, gx);
-        if (nk > 1) {
-            bf_stage_load(a.queries16, a.n_queries, q0, a.dp16, BF_BK, tid, gq);
-            bf_stage_load(a.vectors16, a.n, r0, a.dp16, BF_BK, tid, gx);
-        }
-        __syncthreads();
-        for (uint32_t kc = 0; kc < nk; kc++) {
-            const int st = (int)(kc & 1);
-            if (kc + 2 < nk) {
-                bf_stage_load(a.queries16, a.n_queries, q0, a.dp16, (kc + 2) * BF_BK, tid, nq_);
-                bf_stage_load(a.vectors16, a.n, r0, a.dp16, (kc + 2) * BF_BK, tid, nx_);
-            }
-            // BF_BK/16 k-steps of 16: lane (li, half) supplies k = 16*s + 8*half .. +7 of its row
-            bf16x8 av[BF_BK / 16];
-#pragma unroll
-            for (int s = 0; s < BF_BK / 16; s++)
-                av[s] = *reinterpret_cast<const bf16x8 *>(&sh.q[st][32 * wave + li][32 * s + 16 * half]);
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-#pragma unroll
-                for (int s = 0; s < BF_BK / 16; s++) {
-                    bf16x8 bv = *reinterpret_cast<const bf16x8 *>(&sh.x[st][32 * t + li][32 * s + 16 * half]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s], bv, acc[t], 0, 0, 0);
-                }
-            }
-            if (kc + 1 < nk) {
-                bf_stage_store(sh.q[st ^ 1], tid, gq);
-                bf_stage_store(sh.x[st ^ 1], tid, gx);
-            }
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-                gq[it] = nq_[it];
-                gx[it] = nx_[it];
-            }
-            __syncthreads();
-        }
-
-        // ---- epilogue: approximate scores -> per-query candidate lists ----
-        // per-lane copies of the 16 queries' 1/|q| and current thresholds (a stale threshold only lets a
-        // few extra candidates through to the exact key test below)
-        float qinv[16], thr[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int qi = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
-            qinv[r] = sh.q_rinv[qi];
-            thr[r] = sh.thr_score[qi];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = 32 * t + li;
-            const uint32_t row = r0 + (uint32_t)j;
-            const bool row_ok = sh.row_ok[j] != 0;
-            const float rinv = sh.row_rinv[j];
-            uint32_t mask = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float approx = acc[t][r] * rinv * qinv[r];
-                mask |= (row_ok && approx > thr[r]) ? (1u << r) : 0u;
-            }
-            if (!__ballot(mask != 0)) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                unsigned long long m = __ballot((mask >> r) & 1u);
-                if (!m) continue;
-                const int qi = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const uint64_t key = rank_key(acc[t][r] * rinv * qinv[r], row);
-                while (m) {
-                    int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int sq = __shfl(qi, src, 64);
-                    const uint64_t nk_ = shfl_u64(key, src);
-                    if (!(nk_ > sh.thr_key[sq])) continue;
-                    WaveSortedList l;
-                    l.key = lane < BF_KP ? sh.lists[sq][lane] : NIDX_EMPTY_KEY;
-                    l.insert(nk_, lane);
-                    if (lane < BF_KP) sh.lists[sq][lane] = l.key;
-                    uint64_t kth = l.at(BF_KP - 1);
-                    if (lane == 0 && kth != NIDX_EMPTY_KEY) {
-                        sh.thr_key[sq] = kth;
-                        sh.thr_score[sq] = rank_key_score(kth);
-                    }
-                }
-                // refresh this lane's view of the thresholds it just may have raised
-                thr[r] = sh.thr_score[qi];
+    // Two K steps per iteration (nk and therefore G are even): the fragments of the next step are on their way from LDS while the
+    // matrix cores work on the current one.  The last pair is peeled so that the loop body has no conditional fetch.
+    auto run = [&](auto tag) __attribute__((always_inline)) {
+        uint32_t tile = blockIdx.x, kc = 0, g = 0;
+        step(tag, av0, bv0, av1, bv1, false);
+        for (; g + 2 < G; g += 2) {
+            step(tag, av1, bv1, av0, bv0, true);
+            step(tag, av0, bv0, av1, bv1, true);
+            kc += 2;
+            if (kc == nk) {
+                epilogue(tile);
+                kc = 0;
+                tile += gridDim.x;
             }
         }
+        step(tag, av1, bv1, av0, bv0, true);
+        __builtin_amdgcn_s_waitcnt(0x0070);  // the last fragments, and the requests that ran ahead of the last step
+        mma(av1, bv1);
+        epilogue(tile);
+    };
+    if (G) {
+        if (wave < 4) run(std::true_type{});
+        else run(std::false_type{});
     }
     __syncthreads();
-    for (int i = tid; i < BF_BM * BF_KP; i += 256) {
+    for (int i = tid; i < BF_BM * BF_KP; i += BF_THREADS) {
         int q = i / BF_KP, e = i % BF_KP;
         if (q0 + q < a.n_queries) a.partial[((size_t)(q0 + q) * gridDim.x + blockIdx.x) * BF_KP + e] = sh.lists[q][e];
     }
@@ -255,17 +380,37 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
     if (lane == 0) a.out_count[q] = (uint32_t)__popcll(vm);
 }
 
-hipError_t launch_to_bf16(const float *in, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s) {
+hipError_t launch_to_bf16_tiled(const float *in, const float *norm2, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    size_t total = (size_t)n * dp16;
-    uint32_t blocks = (uint32_t)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks), dim3(256), 0, s, in, n, dp, dp16, out);
+    const size_t chunks = (size_t)((n + 255u) / 256u) * (dp16 / BF_BK) * 512u;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((chunks + 255) / 256, 16384);
+    hipLaunchKernelGGL(to_bf16_tiled_kernel, dim3(blocks), dim3(256), 0, s, in, norm2, n, dp, dp16, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bf16_floor_kernel(const float *__restrict__ cand_score, const uint32_t *__restrict__ cand_count, uint32_t n_queries,
+                                                         float *__restrict__ floor) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_queries) floor[q] = cand_count[q] >= BF_KP ? cand_score[(size_t)q * BF_KP + BF_KP - 1] : -INFINITY;
+}
+
+hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, float *floor, hipStream_t s) {
+    if (n_queries == 0) return hipSuccess;
+    hipLaunchKernelGGL(bf16_floor_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, cand_score, cand_count, n_queries, floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_row_mask(uint32_t n, const uint32_t *para_of_vec, const uint64_t *alive, const uint64_t *filter, uint64_t *out,
+                                hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t n_pad = (n + 255u) & ~255u;
+    hipLaunchKernelGGL(bf16_row_mask_kernel, dim3(n_pad / 256), dim3(256), 0, s, n, n_pad, para_of_vec, alive, filter, out);
     return hipGetLastError();
 }
 
 uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries) {
     uint32_t tiles = (n + BF_BN - 1) / BF_BN, qb = (n_queries + BF_BM - 1) / BF_BM;
-    uint32_t s = 512 / (qb ? qb : 1);  // two workgroups per CU
+    uint32_t s = 256 / (qb ? qb : 1);  // one 8-wave workgroup per CU
     if (s < 1) s = 1;
     if (s > tiles) s = tiles;
     return s ? s : 1;
@@ -273,7 +418,11 @@ uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries) {
 
 hipError_t launch_bf16_scan(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    hipLaunchKernelGGL(bf16_scan_kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(256), 0, s, a);
+    if (a.n == 0 || (a.dp16 % 64u)) return hipErrorInvalidValue;
+    const size_t smem = sizeof(Bf16Shared);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf16_scan_kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(BF_THREADS), smem, s, a);
     return hipGetLastError();
 }
 

@@ -499,15 +499,20 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     }
     if (method == NIDX_METHOD_BRUTE_FORCE_BF16) {
         if (k > NIDX_BF16_CAND) return fail(NIDX_ERR_UNSUPPORTED, "the bf16 fallback re-scores %d candidates per query (got k=%u)", NIDX_BF16_CAND, k);
+        const bool cos = cfg.similarity == NIDX_SIMILARITY_COSINE;
         if (!seg.vectors16.p) {
             seg.dp16 = (seg.dp + 63u) & ~63u;
-            NIDX_HIP(seg.vectors16.alloc((size_t)seg.n * seg.dp16 * 2));
-            NIDX_HIP(launch_to_bf16(seg.vectors.as<float>(), seg.n, seg.dp, seg.dp16, seg.vectors16.as<unsigned short>(), st));
+            NIDX_HIP(seg.vectors16.alloc((size_t)((seg.n + 255u) & ~255u) * seg.dp16 * 2));
+            NIDX_HIP(launch_to_bf16_tiled(seg.vectors.as<float>(), cos ? seg.norm2.as<float>() : nullptr, seg.n, seg.dp, seg.dp16,
+                                          seg.vectors16.as<unsigned short>(), st));
         }
-        NIDX_HIP(scratch_q16.reserve((size_t)nq * seg.dp16 * 2));
-        NIDX_HIP(launch_to_bf16(d_queries, nq, seg.dp, seg.dp16, scratch_q16.as<unsigned short>(), st));
         NIDX_HIP(scratch_qnorm.reserve((size_t)nq * 4));
         NIDX_HIP(launch_row_norms(d_queries, nq, seg.dp, scratch_qnorm.as<float>(), st));
+        NIDX_HIP(scratch_q16.reserve((size_t)((nq + 255u) & ~255u) * seg.dp16 * 2));
+        NIDX_HIP(launch_to_bf16_tiled(d_queries, cos ? scratch_qnorm.as<float>() : nullptr, nq, seg.dp, seg.dp16, scratch_q16.as<unsigned short>(), st));
+        NIDX_HIP(scratch_rowmask.reserve((size_t)((seg.n + 255u) / 256u) * 32));
+        NIDX_HIP(launch_bf16_row_mask(seg.n, seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>(),
+                                      seg.all_alive ? nullptr : seg.alive.as<uint64_t>(), d_filter, scratch_rowmask.as<uint64_t>(), st));
         const uint32_t stripes = bf16_scan_stripes(seg.n, nq);
         NIDX_HIP(scratch_partial.reserve((size_t)nq * stripes * NIDX_BF16_CAND * 8));
         NIDX_HIP(scratch_cand_vec.reserve((size_t)nq * NIDX_BF16_CAND * 4));
@@ -515,17 +520,33 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         NIDX_HIP(scratch_cand_count.reserve((size_t)nq * 4));
         Bf16ScanArgs b;
         b.vectors16 = seg.vectors16.as<unsigned short>();
-        b.norm2 = seg.norm2.as<float>();
         b.n = seg.n;
         b.dp16 = seg.dp16;
         b.queries16 = scratch_q16.as<unsigned short>();
-        b.q_norm2 = scratch_qnorm.as<float>();
         b.n_queries = nq;
-        b.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
-        b.filter = d_filter;
-        b.para_of_vec = seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>();
-        b.similarity = cfg.similarity;
+        b.row_mask = scratch_rowmask.as<uint64_t>();
         b.partial = scratch_partial.as<uint64_t>();
+        b.floor_score = nullptr;
+        {
+            const char *dbg = getenv("NIDX_GPU_BF16_DEBUG");
+            b.debug = dbg ? atoi(dbg) : 0;
+        }
+        // Sample pass: the first 1/16 of the rows (at most 256 tiles) are scanned on their own; the 32nd best score each query
+        // reaches there is a floor for its final 32nd best, and the full pass starts every candidate list at that floor instead
+        // of at -inf — it skips the record-breaking insertions every stripe would otherwise pay while its list warms up.
+        const uint32_t n_tiles = (seg.n + 255u) / 256u;
+        const uint32_t sample_tiles = std::min<uint32_t>(256u, n_tiles / 16u);
+        if (sample_tiles >= 8 && !(b.debug & 4)) {
+            Bf16ScanArgs sm = b;
+            sm.n = std::min<uint32_t>(seg.n, sample_tiles * 256u);
+            const uint32_t s_stripes = bf16_scan_stripes(sm.n, nq);
+            NIDX_HIP(launch_bf16_scan(sm, s_stripes, st));
+            NIDX_HIP(launch_merge_topk(sm.partial, nq, s_stripes, NIDX_BF16_CAND, scratch_cand_vec.as<uint32_t>(), scratch_cand_score.as<float>(),
+                                       scratch_cand_count.as<uint32_t>(), st));
+            NIDX_HIP(scratch_floor.reserve((size_t)nq * 4));
+            NIDX_HIP(launch_bf16_floor(scratch_cand_score.as<float>(), scratch_cand_count.as<uint32_t>(), nq, scratch_floor.as<float>(), st));
+            b.floor_score = scratch_floor.as<float>();
+        }
         NIDX_HIP(launch_bf16_scan(b, stripes, st));
         NIDX_HIP(launch_merge_topk(b.partial, nq, stripes, NIDX_BF16_CAND, scratch_cand_vec.as<uint32_t>(),
                                    scratch_cand_score.as<float>(), scratch_cand_count.as<uint32_t>(), st));

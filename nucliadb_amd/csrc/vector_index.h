@@ -19,7 +19,7 @@ struct VectorSegment {
     DevBuf vectors;      // [n][dp] f32, zero padded
     DevBuf norm2;        // [n] f32, WAVE64-order |x|^2
     DevBuf norm2_serial; // [n] f32, SERIAL_FMA-order |x|^2 (filled on the first MFMA scan)
-    DevBuf vectors16;    // [n][dp16] bf16 copy (filled on the first bf16 scan)
+    DevBuf vectors16;    // tiled bf16 copy (vector_bf16.hip "Operand layout"), filled on the first bf16 scan
     uint32_t dp16 = 0;
     DevBuf para_of_vec;  // [n] u32 (absent when identity)
     DevBuf para_first, para_num;  // [n_paragraphs] u32: the contiguous vectors of every paragraph (absent when identity)
@@ -71,7 +71,7 @@ struct VectorIndex {
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count,
-        scratch_dump_vec, scratch_dump_score, scratch_dump_count, scratch_spill_pool, scratch_spill_cmax, scratch_spill_vis, scratch_spill_ids;
+        scratch_dump_vec, scratch_dump_score, scratch_dump_count, scratch_spill_pool, scratch_spill_cmax, scratch_spill_vis, scratch_spill_ids, scratch_rowmask, scratch_floor;
     uint64_t spill_queries = 0;  // queries re-run by the exact fallback since open (tunable "spill_queries" reads it)
     bool rabitq_enabled(const VectorSegment &seg) const { return seg.has_quant && !(cfg.flags & NIDX_CONFIG_DISABLE_RABITQ_SEARCH); }
     int32_t quantize(uint32_t segment);
