@@ -161,7 +161,22 @@ struct QReduce<1> {
 
 template <int QT>
 struct QReduce {
-    // Halving levels: at offset `off` lanes with (lane & off) keep the upper half of the query set.
+    // Halving levels: at offset `off` lanes with (lane & off) keep the upper half of the query set.  The first two levels are
+    // gfx950's v_permlane32_swap / v_permlane16_swap: swap(x, y) leaves [x.lower, y.lower] in x and [x.upper, y.upper] in y
+    // (halves of 32 lanes, resp. 16-lane rows), so x + y is "x[l] + x[l ^ off]" in the lanes that keep x and "y[l] + y[l ^ off]"
+    // in the lanes that keep y — the same operand pairs as the xor butterfly, one swap + one add per PAIR of values, no selects
+    // and no LDS crossbar.  (A generic "keep / send / shuffle" formulation compiled to ~40 compare + select instructions per
+    // value.)
+    // (inline asm: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane32_swap / 16_swap builtins use the first result for both
+    // elements of the returned pair, i.e. x + x; the s_nop's stand in for the hazard slots the compiler cannot see around asm)
+    static __device__ inline float swap_add32(float x, float y) {
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        return x + y;
+    }
+    static __device__ inline float swap_add16(float x, float y) {
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        return x + y;
+    }
     static __device__ inline float run(float (&a)[QT], int lane) {
         float v[QT];
 #pragma unroll
@@ -169,12 +184,21 @@ struct QReduce {
         int off = 32;
 #pragma unroll
         for (int n = QT; n > 1; n >>= 1, off >>= 1) {
-            const bool up = (lane & off) != 0;
+            if (off == 32) {
 #pragma unroll
-            for (int i = 0; i < n / 2; i++) {
-                float keep = up ? v[i + n / 2] : v[i];
-                float send = up ? v[i] : v[i + n / 2];
-                v[i] = keep + __shfl_xor(send, off, 64);
+                for (int i = 0; i < n / 2; i++) v[i] = swap_add32(v[i], v[i + n / 2]);
+            } else if (off == 16) {
+#pragma unroll
+                for (int i = 0; i < n / 2; i++) v[i] = swap_add16(v[i], v[i + n / 2]);
+            } else {
+                const bool up = (lane & off) != 0;
+#pragma unroll
+                for (int i = 0; i < n / 2; i++) {
+                    // both full butterflies of the level, then the lane's own one (x[l] + x[l ^ off] is the same value in l and l ^ off)
+                    const float lo = v[i] + __shfl_xor(v[i], off, 64);
+                    const float hi = v[i + n / 2] + __shfl_xor(v[i + n / 2], off, 64);
+                    v[i] = up ? hi : lo;
+                }
             }
         }
         float r = v[0];

@@ -20,10 +20,15 @@ struct ScanArgs {
     uint32_t k;                   // <= 256
     uint32_t qt;                  // query tile (filled by launch_scan)
     uint64_t *partial;            // [n_queries][nblk][k] rank keys
+    const uint64_t *row_mask;     // shared-row scan only: bit r = row r is scanned (launch_bf16_row_mask); nullptr otherwise
 };
 uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp, uint32_t k);
 uint32_t scan_num_blocks(uint32_t n);
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s);
+// the same scan for large batches (vector_scan_shared.hip): row stripes to use, 0 = not applicable (use launch_scan);
+// `matching` = rows passing the filter.  Needs a.row_mask and norm2 padded to a multiple of 8 rows.
+uint32_t scan_shared_stripes(uint32_t n, uint32_t n_queries, uint32_t dp, uint32_t k, uint64_t matching);
+hipError_t launch_scan_shared(const ScanArgs &a, uint32_t stripes, hipStream_t s);
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s);
 hipError_t launch_maxsim(const float *vectors, const float *norm2, uint32_t dp, int similarity, const float *queries,

@@ -200,7 +200,7 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
         if (seg.dp != d) NIDX_HIP(hipMemset(seg.vectors.p, 0, seg.vectors.bytes));
         NIDX_HIP(hipMemcpy2D(seg.vectors.p, (size_t)seg.dp * 4, in.vectors, in.row_stride_bytes, packed, in.n_vectors,
                              hipMemcpyHostToDevice));
-        NIDX_HIP(seg.norm2.alloc((size_t)in.n_vectors * 4));
+        NIDX_HIP(seg.norm2.alloc((size_t)((in.n_vectors + 7u) & ~7u) * 4));  // padded: the shared-row scan copies 8 norms per tile
         NIDX_HIP(launch_row_norms(seg.vectors.as<float>(), seg.n, seg.dp, seg.norm2.as<float>(), stream));
     }
     // alive bitset
@@ -569,6 +569,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     }
     // brute force
     uint32_t nblk = scan_num_blocks(seg.n);
+    uint32_t shared_stripes = 0;  // > 0: the shared-row scan (large batches) with that many row stripes
     // multi-vector paragraphs: the k best paragraphs are covered by the k * vmax best vectors (each better paragraph
     // contributes at most vmax of them); they are reduced to one hit per paragraph afterwards
     const uint32_t k_out = k;
@@ -579,6 +580,16 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         NIDX_HIP(scratch_cand_vec.reserve((size_t)nq * k * 4));
         NIDX_HIP(scratch_cand_score.reserve((size_t)nq * k * 4));
         NIDX_HIP(scratch_cand_count.reserve((size_t)nq * 4));
+    }
+    {
+        // rows the filter lets through decide which scan streams less (the register-tile scan never loads a filtered row)
+        uint64_t matching = seg.n;
+        if (scan_matching_hint != ~0ull) matching = scan_matching_hint;
+        else if (d_filter) matching = 0;          // unknown selectivity: the scan that skips filtered rows
+        else if (!seg.all_alive) matching = seg.alive_count;
+        shared_stripes = scan_shared_stripes(seg.n, nq, seg.dp, k, matching);
+        if (const char *e = getenv("NIDX_GPU_SCAN_SHARED")) shared_stripes = atoi(e) ? shared_stripes : 0;
+        if (shared_stripes) nblk = shared_stripes;
     }
     size_t need = (size_t)nq * nblk * k * 8;
     NIDX_HIP(scratch_partial.reserve(need));
@@ -597,7 +608,15 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     a.k = k;
     a.qt = 0;
     a.partial = scratch_partial.as<uint64_t>();
-    NIDX_HIP(launch_scan(a, nblk, st));
+    a.row_mask = nullptr;
+    if (shared_stripes) {
+        NIDX_HIP(scratch_rowmask.reserve((size_t)((seg.n + 255u) / 256u) * 32));
+        NIDX_HIP(launch_bf16_row_mask(seg.n, a.para_of_vec, a.alive, a.filter, scratch_rowmask.as<uint64_t>(), st));
+        a.row_mask = scratch_rowmask.as<uint64_t>();
+        NIDX_HIP(launch_scan_shared(a, nblk, st));
+    } else {
+        NIDX_HIP(launch_scan(a, nblk, st));
+    }
     if (!multi) {
         NIDX_HIP(launch_merge_topk(a.partial, nq, nblk, k, d_out_vec, d_out_score, d_out_count, st));
         return NIDX_OK;
@@ -781,11 +800,13 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
             d_filter = scratch_filter.as<uint64_t>();
         }
         uint32_t vis_log2 = default_vis_log2;
+        scan_matching_hint = matching;
         for (;;) {
             int32_t rc = segment_search_device((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score,
                                                p.with_duplicates != 0, method, d_filter, scratch_out_vec.as<uint32_t>(),
                                                scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
                                                scratch_stats.as<uint32_t>(), vis_log2, stream);
+            scan_matching_hint = ~0ull;
             if (rc != NIDX_OK) return rc;
             if (method != NIDX_METHOD_HNSW && method != NIDX_METHOD_RABITQ_HNSW) break;
             std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);

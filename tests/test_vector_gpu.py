@@ -100,6 +100,36 @@ def test_brute_force_matches_oracle(orc, sim, n, d, nq, k):
         assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
 
 
+@pytest.mark.parametrize("sim", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [(20003, 768, 200, 10), (5001, 256, 64, 64), (9000, 1024, 130, 7), (4100, 512, 65, 33)])
+def test_shared_row_scan_matches_oracle_and_register_tile_scan(orc, monkeypatch, sim, n, d, nq, k):
+    """Large batches take the shared-row form of the exact scan (vector_scan_shared.hip: rows staged once per 64 queries through
+    LDS): same arithmetic, so ids, ranks and score bits equal the oracle's and the register-tile scan's — with dead rows, a
+    filter, a min_score cut, identical rows (address-ordered ties) and n not a multiple of the 8-row tile."""
+    rng = np.random.default_rng(n + d + sim)
+    x = unit_rows(rng, n, d)
+    x[200:230] = x[11]                     # exact ties
+    q = rng.normal(size=(nq, d)).astype(np.float32)
+    q[0] = x[11]
+    alive = orc.bitset(n, fill=True)
+    for dead in (11, 200, n - 1, 4097):
+        alive[dead >> 6] &= ~np.uint64(1 << (dead & 63))
+    filt = orc.bitset(n, ones=np.nonzero(rng.random(n) < 0.6)[0].tolist() + list(range(200, 230)))
+    oseg = orc.Segment(x, similarity=sim, alive=alive)
+    for kwargs, obits, ms in (({}, None, -1.0), ({"alive": alive, "filter_bits": filt}, alive & filt, 0.02)):
+        monkeypatch.setenv("NIDX_GPU_SCAN_SHARED", "1")
+        ov, osc, oc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE, min_score=ms, **kwargs)
+        monkeypatch.setenv("NIDX_GPU_SCAN_SHARED", "0")
+        rv, rsc, rc = gpu_search(x, sim, q, k, method=_lib.METHOD_BRUTE_FORCE, min_score=ms, **kwargs)
+        assert np.array_equal(oc, rc) and np.array_equal(ov, rv) and np.array_equal(bits(osc), bits(rsc))
+        oref = oseg if obits is not None else orc.Segment(x, similarity=sim)
+        for i in sorted({0, 1, 2, 3, 4, 5, 63, min(64, nq - 1), nq - 1}):
+            wv, ws = oref.brute_force(q[i], k, min_score=ms, filter_bits=obits)
+            assert oc[i] == len(wv), (i, oc[i], len(wv))
+            assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i, : oc[i]], wv)
+            assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
 def test_brute_force_filters_min_score_and_ties(orc):
     rng = np.random.default_rng(99)
     n, d, k = 6000, 128, 10
