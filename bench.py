@@ -357,9 +357,10 @@ def bench_hybrid(a, L, dev, rank, world):
     """BASELINE.json configs[2]: cosine HNSW over N x 768 vectors + BM25 over N synthetic documents (document i owns
     vector i), a batch of 1024 hybrid queries (one vector + 3 keyword terms), fused with reciprocal rank fusion.
     The vector search is launched on the torch stream, the BM25 search runs on the library's own stream: they overlap
-    on the device; the fusion is nucliadb's Python-side step (vectorised with numpy here)."""
+    on the device; the fusion is nucliadb's Python-side step (batched in host C++ here: nidx_gpu_rank_fusion_rrf)."""
     from nucliadb_amd import _lib
     from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
+    from nucliadb_amd.rank_fusion import rrf_fuse_batch
 
     n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
     n_docs, vocab, kb = n, a.vocab, 20
@@ -416,7 +417,9 @@ def bench_hybrid(a, L, dev, rank, world):
         vi = out_vec.cpu().numpy()
         vc = out_count.cpu().numpy()
         t2 = time.perf_counter()
-        fused = rrf_batch(vi, vc, (docaddr & 0xFFFFFFFF).astype(np.int64), count, k)
+        # keyword list first, like nucliadb's fuse({"keyword": .., "semantic": ..}); ids = document numbers
+        fused = rrf_fuse_batch([(docaddr & np.uint64(0xFFFFFFFF), count, 1.0, score), (vi.astype(np.uint64), vc.astype(np.uint32), 1.0, None)],
+                               k=60.0, window=k)
         t3 = time.perf_counter()
         if timed:
             t_parts["vector_launch+bm25"] += t1 - t0
@@ -446,7 +449,7 @@ def bench_hybrid(a, L, dev, rank, world):
                        "hnsw_build_s": build_s, "corpus_gen_s": gen_s, "bm25_kernel_ms": ms.value,
                        "ms_per_step_parts": {kk_: v / a.steps * 1e3 for kk_, v in t_parts.items()},
                        "note": "end to end per batch: vector search on device buffers + BM25 through the host-buffer entry point, both device "
-                               "results copied to the host, fused by numpy"},
+                               "results copied to the host, fused by nidx_gpu_rank_fusion_rrf (host C++)"},
             "roofline": None, "cpu_baseline": None}))
 
 

@@ -539,6 +539,24 @@ int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *d
                             uint32_t limit, float *out_score, uint64_t *out_docaddr, uint32_t *out_list,
                             uint32_t *n_out);
 
+/* Rank fusion of the ranked lists a hybrid request gets back (nucliadb/src/nucliadb/search/search/rank_fusion.py; the
+ * reference does this per request in Python).  Batched host code, no device work.
+ * ReciprocalRankFusion._fuse + RankFusionAlgorithm.fuse (:60-181): for every query, walk the lists in the order given
+ * (list 0 first), hit by hit in rank order; a hit's id is first seen => it enters the result with score
+ * weight / (k + rank) — evaluated as (1.0 / (k + rank)) * weight in f64, like the Python expression — else the term is
+ * added to its score; then a stable sort by score descending (ties keep first-seen order) and the first `window` hits.
+ * A query with exactly one non-empty list returns that list unchanged with its own scores (fuse(): "one non-empty
+ * source => its hits unchanged"), which is why lists may carry scores. */
+typedef struct {
+    const uint64_t *ids;     /* [n_queries][stride], ranked best first */
+    const float *scores;     /* [n_queries][stride] or NULL (only read for the single-source case; NULL => 0) */
+    const uint32_t *counts;  /* [n_queries] valid entries per row */
+    uint32_t stride;
+    double weight;           /* ReciprocalRankFusion.weights[source] (default_weight when absent) */
+} nidx_gpu_ranked_list_t;
+int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k,
+                                 uint32_t window, uint64_t *out_ids, double *out_scores, uint32_t *out_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,10 @@ class SegmentDirContentsC(C.Structure):
 LIST_LABEL, LIST_FIELD = 0, 1
 
 
+class RankedListC(C.Structure):
+    _fields_ = [("ids", C.c_void_p), ("scores", C.c_void_p), ("counts", C.c_void_p), ("stride", C.c_uint32), ("weight", C.c_double)]
+
+
 class FilterOpC(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_uint32), ("b", C.c_uint32)]
 
@@ -233,6 +237,7 @@ SIGNATURES = {
                                           C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_merge_vector_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_rank_fusion_rrf": (C.c_int32, [C.POINTER(RankedListC), C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
 }

@@ -7,6 +7,7 @@
 // what each GPU produced; with one shard per GPU they arrive through an RCCL all-gather.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "device_common.h"
@@ -105,6 +106,56 @@ int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *d
         if (out_list) out_list[i] = order[i].list;
     }
     *n_out = n;
+    return NIDX_OK;
+}
+
+// ---- rank fusion (nucliadb rank_fusion.py:60-181), batched on the host -----------------------------------------------------------
+int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window,
+                                 uint64_t *out_ids, double *out_scores, uint32_t *out_counts) {
+    if ((n_lists && !lists) || !out_ids || !out_scores || !out_counts) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (uint32_t l = 0; l < n_lists; l++)
+        if (!lists[l].counts || (lists[l].stride && !lists[l].ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: NULL arrays", l);
+    struct Item { uint64_t id; double score; };
+    std::vector<Item> acc;
+    std::vector<uint32_t> order;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        uint32_t non_empty = 0, only = 0;
+        for (uint32_t l = 0; l < n_lists; l++) {
+            const uint32_t c = std::min(lists[l].counts[q], lists[l].stride);
+            if (c) { non_empty++; only = l; }
+        }
+        acc.clear();
+        if (non_empty == 1) {
+            // fuse(): the single source's hits, unchanged (then the same stable sort by their own scores)
+            const nidx_gpu_ranked_list_t &L = lists[only];
+            const uint32_t c = std::min(L.counts[q], L.stride);
+            for (uint32_t r = 0; r < c; r++)
+                acc.push_back({L.ids[(size_t)q * L.stride + r], L.scores ? (double)L.scores[(size_t)q * L.stride + r] : 0.0});
+        } else {
+            for (uint32_t l = 0; l < n_lists; l++) {
+                const nidx_gpu_ranked_list_t &L = lists[l];
+                const uint32_t c = std::min(L.counts[q], L.stride);
+                for (uint32_t r = 0; r < c; r++) {
+                    const uint64_t id = L.ids[(size_t)q * L.stride + r];
+                    const double term = (1.0 / (k + (double)r)) * L.weight;
+                    // windows are a few tens of hits: a linear probe of the first-seen order beats a hash table
+                    size_t at = 0;
+                    while (at < acc.size() && acc[at].id != id) at++;
+                    if (at == acc.size()) acc.push_back({id, term});
+                    else acc[at].score += term;
+                }
+            }
+        }
+        order.resize(acc.size());
+        for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return acc[a].score > acc[b].score; });
+        const uint32_t n = (uint32_t)std::min<size_t>(order.size(), window);
+        for (uint32_t i = 0; i < n; i++) {
+            out_ids[(size_t)q * window + i] = acc[order[i]].id;
+            out_scores[(size_t)q * window + i] = acc[order[i]].score;
+        }
+        out_counts[q] = n;
+    }
     return NIDX_OK;
 }
 

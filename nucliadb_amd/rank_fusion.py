@@ -99,3 +99,29 @@ class WeightedCombSum(RankFusionAlgorithm):
             item.score, item.score_type = total[pid], kind[pid]
             out.append(item)
         return out
+
+
+def rrf_fuse_batch(lists, k: float = 60.0, window: int = 20):
+    """ReciprocalRankFusion for a whole batch through the native host routine (nidx_gpu_rank_fusion_rrf): `lists` =
+    [(ids u64 [B][stride], counts u32 [B], weight, scores f32 [B][stride] | None), ...] in source order.
+    -> (ids u64 [B][window], scores f64 [B][window], counts u32 [B])"""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    B = len(lists[0][1]) if lists else 0
+    arr = (_lib.RankedListC * max(1, len(lists)))()
+    keep = []
+    for i, (ids, counts, weight, scores) in enumerate(lists):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        sc = None if scores is None else np.ascontiguousarray(scores, dtype=np.float32)
+        keep += [ids, counts, sc]
+        arr[i] = _lib.RankedListC(ids.ctypes.data, None if sc is None else sc.ctypes.data, counts.ctypes.data, ids.shape[1] if ids.ndim == 2 else 0, float(weight))
+    out_ids = np.zeros((B, window), np.uint64)
+    out_scores = np.zeros((B, window), np.float64)
+    out_counts = np.zeros(B, np.uint32)
+    _lib.check(_lib.lib().nidx_gpu_rank_fusion_rrf(arr, len(lists), B, float(k), window, out_ids.ctypes.data, out_scores.ctypes.data, out_counts.ctypes.data))
+    return out_ids, out_scores, out_counts

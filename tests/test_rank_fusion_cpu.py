@@ -74,3 +74,41 @@ def test_weighted_comb_sum():
     assert got == [("r-4", round(0.3 * 2.0 + 6 * 0.5, 6), BOTH), ("r-5", round(6 * 0.5, 6), VECTOR),
                    ("r-1", round(0.1 * 2.0 + 2 * 0.5 + 1.0 * 1.5, 6), BOTH), ("r-3", round(3 * 0.5, 6), VECTOR),
                    ("r-6", round(1.0 * 1.5, 6), RELATION_RELEVANCE), ("r-2", round(0.5 * 2.0, 6), BM25)]
+
+
+def test_native_batched_rrf_equals_the_mirror():
+    """nidx_gpu_rank_fusion_rrf (host C++, batched) against ReciprocalRankFusion on random ranked lists: overlapping ids, weights,
+    empty lists (single-source rule), windows shorter than the union — same ids, same f64 scores, same order."""
+    import numpy as np
+
+    from nucliadb_amd.rank_fusion import rrf_fuse_batch
+
+    rng = np.random.default_rng(12)
+    B, sa, sb, sc, window = 300, 20, 10, 4, 12
+    def make(stride, lo):
+        ids = np.zeros((B, stride), np.uint64)
+        scores = np.zeros((B, stride), np.float32)
+        counts = rng.integers(lo, stride + 1, B).astype(np.uint32)
+        for q in range(B):
+            ids[q, : counts[q]] = rng.choice(40, counts[q], replace=False)          # small id space: lists overlap
+            scores[q, : counts[q]] = np.sort(rng.random(counts[q]).astype(np.float32))[::-1]
+        return ids, counts, scores
+    a, b, c = make(sa, 0), make(sb, 0), make(sc, 0)
+    b[1][:40] = 0                                                                     # many single-source queries
+    c[1][:200] = 0
+    weights = {"keyword": 1.0, "semantic": 2.5, "graph": 0.5}
+    got_ids, got_scores, got_counts = rrf_fuse_batch([(a[0], a[1], weights["keyword"], a[2]), (b[0], b[1], weights["semantic"], b[2]),
+                                                      (c[0], c[1], weights["graph"], c[2])], k=K, window=window)
+    algo = ReciprocalRankFusion(k=K, window=window, weights=weights)
+    for q in range(B):
+        src = {"keyword": [ScoredItem(str(int(i)), float(s), BM25) for i, s in zip(a[0][q, : a[1][q]], a[2][q])],
+               "semantic": [ScoredItem(str(int(i)), float(s), VECTOR) for i, s in zip(b[0][q, : b[1][q]], b[2][q])],
+               "graph": [ScoredItem(str(int(i)), float(s), RELATION_RELEVANCE) for i, s in zip(c[0][q, : c[1][q]], c[2][q])]}
+        if not any(src.values()):
+            assert got_counts[q] == 0
+            continue
+        want = algo.fuse(src)[:window]
+        n = int(got_counts[q])
+        assert n == len(want), q
+        assert [int(x) for x in got_ids[q, :n]] == [int(w.paragraph_id) for w in want], q
+        assert [float(x) for x in got_scores[q, :n]] == [float(w.score) for w in want], q
