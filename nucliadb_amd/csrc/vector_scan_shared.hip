@@ -65,10 +65,19 @@ __global__ __launch_bounds__(64 * SS_WAVES, 1) void scan_shared_kernel(ScanArgs 
     // the queries are in registers before the first DMA request: the compiler must not find a pending vector load behind the
     // requests later (it would wait vmcnt(0) for it inside the loop and drain the queue)
     __builtin_amdgcn_s_waitcnt(0x0070);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 qp[SS_QT / 2][NJ][4];  // [query pair][chunk][component] = (element of query 2h, element of query 2h + 1)
 #pragma unroll
-    for (int q = 0; q < SS_QT; q++)
+    for (int h = 0; h < SS_QT / 2; h++)
 #pragma unroll
-        for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(qv[q][j].x), "+v"(qv[q][j].y), "+v"(qv[q][j].z), "+v"(qv[q][j].w));
+        for (int j = 0; j < NJ; j++) {
+            qp[h][j][0] = f32x2{qv[2 * h][j].x, qv[2 * h + 1][j].x};
+            qp[h][j][1] = f32x2{qv[2 * h][j].y, qv[2 * h + 1][j].y};
+            qp[h][j][2] = f32x2{qv[2 * h][j].z, qv[2 * h + 1][j].z};
+            qp[h][j][3] = f32x2{qv[2 * h][j].w, qv[2 * h + 1][j].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) asm volatile("" : "+v"(qp[h][j][c]));
+        }
     asm volatile("" : "+v"(qq_mine));
     WaveTopK<1> top[SS_QT];
 #pragma unroll
@@ -126,57 +135,44 @@ __global__ __launch_bounds__(64 * SS_WAVES, 1) void scan_shared_kernel(ScanArgs 
             // early-clobber outputs: the first result must not land in the address register the second read still needs
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(n_lo), "=&v"(n_hi) : "v"(naddr) : "memory");
         }
-#pragma unroll 1
-        for (uint32_t rr = 0; rr < SS_ROWS; rr++) {
-            const uint32_t r = r0 + rr;
-            if (!((tile_mask >> rr) & 1u)) continue;
-            // The row's chunks of this lane, read with explicit ds_read_b128: behind a C++ load the compiler's wait-count pass sees
-            // an LDS read that may alias the DMA requests in flight and puts s_waitcnt vmcnt(0) in front of it — which would
-            // drain the queue every row.  The stage being read was waited for above; the ones being written are other stages.
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4 raw[NJ];
+        // SEVERAL rows per iteration: a wave's work on one row is a single dependent chain (reads -> fma chains -> 6 reduction levels
+        // -> f64 cosine -> key -> ballot) and only two waves share a SIMD, so the other rows' chains are what fills the
+        // latency of the first.  A row the mask excludes is computed along and dropped at the admission test.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        auto read_row = [&](uint32_t rr, f32x4 (&raw)[NJ]) __attribute__((always_inline)) {
+            // explicit ds_read_b128: behind a C++ load the compiler's wait-count pass sees an LDS read that may alias the DMA
+            // requests in flight and puts s_waitcnt vmcnt(0) in front of it — which would drain the queue every row.  The stage
+            // being read was waited for above; the ones being written are other stages.
             const uint32_t addr = (uint32_t)(uintptr_t)(stage + rr * row_bytes + lane * 16);
             asm volatile("ds_read_b128 %0, %1" : "=v"(raw[0]) : "v"(addr) : "memory");
             if constexpr (NJ > 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(raw[1]) : "v"(addr) : "memory");
             if constexpr (NJ > 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(raw[2]) : "v"(addr) : "memory");
             if constexpr (NJ > 3) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(raw[3]) : "v"(addr) : "memory");
-            if constexpr (NJ == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0])::"memory");
-            if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
-            if constexpr (NJ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2])::"memory");
-            if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])::"memory");
-            float4 cur[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; j++) cur[j] = make_float4(raw[j].x, raw[j].y, raw[j].z, raw[j].w);
-            float acc[SS_QT];
-#pragma unroll
-            for (int q = 0; q < SS_QT; q++) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) s = fma4(cur[j], qv[q][j], s);
-                acc[q] = s;
-            }
+        };
+        auto wait_row = [&](f32x4 (&ra)[NJ]) __attribute__((always_inline)) {   // after the LAST read: every row of the group is in
+            if constexpr (NJ == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0])::"memory");
+            if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1])::"memory");
+            if constexpr (NJ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2])::"memory");
+            if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])::"memory");
+        };
+        // score of the row against this lane's query, from the per-lane partial sums of the wave's 8 queries
+        auto finish = [&](float (&acc)[SS_QT], float xx) __attribute__((always_inline)) -> float {
             const float ab = QReduce<SS_QT>::run(acc, lane);
-            float score;
-            if (cosine) {
-                const float xs[8] = {n_lo.x, n_lo.y, n_lo.z, n_lo.w, n_hi.x, n_hi.y, n_hi.z, n_hi.w};
-                float xx = xs[0];
-#pragma unroll
-                for (int i = 1; i < 8; i++) xx = rr == (uint32_t)i ? xs[i] : xx;
-                // cosine_from_sums with sqrt(|q|^2) hoisted (same f64 operations, same order)
-                const double dab = (double)ab, dxx = (double)xx;
-                double dist;
-                if (dxx == 0.0 && (double)qq_mine == 0.0) dist = 0.0;
-                else if (dab == 0.0) dist = 1.0;
-                else {
-                    const double d = 1.0 - dab / (sqrt(dxx) * sqrt_qq);
-                    dist = d > 0.0 ? d : 0.0;
-                }
-                score = 1.0f - (float)dist;
-            } else {
-                score = ab;
+            if (!cosine) return ab;
+            // cosine_from_sums with sqrt(|q|^2) hoisted (same f64 operations, same order)
+            const double dab = (double)ab, dxx = (double)xx;
+            double dist;
+            if (dxx == 0.0 && (double)qq_mine == 0.0) dist = 0.0;
+            else if (dab == 0.0) dist = 1.0;
+            else {
+                const double d = 1.0 - dab / (sqrt(dxx) * sqrt_qq);
+                dist = d > 0.0 ? d : 0.0;
             }
+            return 1.0f - (float)dist;
+        };
+        auto admit = [&](float score, uint32_t r, bool row_ok) __attribute__((always_inline)) {
             const uint64_t ck = rank_key(score, r);
-            const bool ok = (score >= a.min_score) && (ck > thr) && ((lane & QReduce<SS_QT>::group_mask()) == 0);
+            const bool ok = row_ok && (score >= a.min_score) && (ck > thr) && ((lane & QReduce<SS_QT>::group_mask()) == 0);
             unsigned long long m = __ballot(ok);
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
@@ -191,6 +187,48 @@ __global__ __launch_bounds__(64 * SS_WAVES, 1) void scan_shared_kernel(ScanArgs 
                     }
                 }
             }
+        };
+        const float xs[8] = {n_lo.x, n_lo.y, n_lo.z, n_lo.w, n_hi.x, n_hi.y, n_hi.z, n_hi.w};
+        constexpr int RG = NJ <= 3 ? 4 : 2;   // rows per group: what the register file holds next to the 8 x NJ x 4 query registers
+#pragma unroll
+        for (uint32_t rr = 0; rr < SS_ROWS; rr += RG) {
+            const uint32_t bits = (tile_mask >> rr) & ((1u << RG) - 1u);
+            if (!bits) continue;
+            f32x4 raw[RG][NJ];
+#pragma unroll
+            for (int g = 0; g < RG; g++) read_row(rr + g, raw[g]);
+#pragma unroll
+            for (int g = 0; g < RG; g++) wait_row(raw[g]);   // one real wait (the first), the rest only tie the registers to it
+            // two queries per v_pk_fma_f32: the row element is broadcast to both halves, the pair of query elements sits in one
+            // 64-bit register pair (qp[]), each half is its query's own fmaf chain in the usual (chunk, component) order
+            f32x2 acc2[RG][SS_QT / 2];
+#pragma unroll
+            for (int g = 0; g < RG; g++)
+#pragma unroll
+                for (int h = 0; h < SS_QT / 2; h++) acc2[g][h] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int g = 0; g < RG; g++) {
+                        const float x = c == 0 ? raw[g][j].x : c == 1 ? raw[g][j].y : c == 2 ? raw[g][j].z : raw[g][j].w;
+#pragma unroll
+                        for (int h = 0; h < SS_QT / 2; h++) acc2[g][h] = __builtin_elementwise_fma(f32x2{x, x}, qp[h][j][c], acc2[g][h]);
+                    }
+            float score[RG];
+#pragma unroll
+            for (int g = 0; g < RG; g++) {
+                float acc[SS_QT];
+#pragma unroll
+                for (int h = 0; h < SS_QT / 2; h++) {
+                    acc[2 * h] = acc2[g][h].x;
+                    acc[2 * h + 1] = acc2[g][h].y;
+                }
+                score[g] = finish(acc, xs[rr + g]);
+            }
+#pragma unroll
+            for (int g = 0; g < RG; g++) admit(score[g], r0 + rr + g, (bits >> g) & 1u);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);  // the requests that ran ahead of the last tile
