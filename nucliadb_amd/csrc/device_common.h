@@ -37,12 +37,48 @@ __host__ __device__ inline uint32_t rank_key_addr(uint64_t key) { return ~(uint3
 // The empty slot: ranks after every real entry (real keys have addr != 0xffffffff or score bits > 0).
 #define NIDX_EMPTY_KEY 0ull
 
-// xor butterfly: every lane ends with the same value, pairing a[l] + a[l^off] at each level.
-__device__ inline float wave_butterfly_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
+// ---- x[l] + x[l ^ OFF] without the LDS crossbar -------------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (an address register, an LDS-pipe round trip of ~100 cycles, six of them in a row for
+// one wave sum).  gfx950 can do every level of the xor butterfly in the VALU: 32 and 16 with v_permlane32_swap /
+// v_permlane16_swap (swap(x, y) leaves [x.lower, y.lower] in x and [x.upper, y.upper] in y — halves of 32 lanes, resp. 16-lane
+// rows), 8 with the DPP row rotation by 8, 4 with row_half_mirror followed by the quad reversal (l ^ 7 ^ 3 = l ^ 4), 2 and 1 with
+// quad permutations.  The operand pairs are exactly those of the shuffle form (float add is commutative), so results are
+// bit-identical.
+// (inline asm for the swaps: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane32_swap / 16_swap builtins use the first result
+// for both elements of the returned pair, i.e. x + x; the s_nop 1 is the two wait states hipcc itself puts between a VALU write
+// of an operand and the swap — it cannot see inside the asm; results may be read right away.)
+__device__ inline float swap_add32(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
 }
+__device__ inline float swap_add16(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+template <int CTRL>
+__device__ inline float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int OFF>
+__device__ inline float xor_add(float x) {
+    static_assert(OFF == 32 || OFF == 16 || OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "xor_add: power of two below 64");
+    if constexpr (OFF == 32) return swap_add32(x, x);
+    else if constexpr (OFF == 16) return swap_add16(x, x);
+    else if constexpr (OFF == 8) return x + dpp_move<0x128>(x);                   // row_ror:8
+    else if constexpr (OFF == 4) return x + dpp_move<0x1B>(dpp_move<0x141>(x));   // row_half_mirror, then quad_perm:[3,2,1,0]
+    else if constexpr (OFF == 2) return x + dpp_move<0x4E>(x);                    // quad_perm:[2,3,0,1]
+    else return x + dpp_move<0xB1>(x);                                            // quad_perm:[1,0,3,2]
+}
+// levels OFF, OFF / 2, .., 1 of the butterfly
+template <int OFF>
+__device__ inline float xor_tail(float x) {
+    x = xor_add<OFF>(x);
+    if constexpr (OFF > 1) return xor_tail<OFF / 2>(x);
+    else return x;
+}
+
+// xor butterfly: every lane ends with the same value, pairing a[l] + a[l^off] at each level.
+__device__ inline float wave_butterfly_sum(float v) { return xor_tail<32>(v); }
 
 __device__ inline uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -161,49 +197,38 @@ struct QReduce<1> {
 
 template <int QT>
 struct QReduce {
-    // Halving levels: at offset `off` lanes with (lane & off) keep the upper half of the query set.  The first two levels are
-    // gfx950's v_permlane32_swap / v_permlane16_swap: swap(x, y) leaves [x.lower, y.lower] in x and [x.upper, y.upper] in y
-    // (halves of 32 lanes, resp. 16-lane rows), so x + y is "x[l] + x[l ^ off]" in the lanes that keep x and "y[l] + y[l ^ off]"
-    // in the lanes that keep y — the same operand pairs as the xor butterfly, one swap + one add per PAIR of values, no selects
-    // and no LDS crossbar.  (A generic "keep / send / shuffle" formulation compiled to ~40 compare + select instructions per
-    // value.)
-    // (inline asm: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane32_swap / 16_swap builtins use the first result for both
-    // elements of the returned pair, i.e. x + x; the s_nop's stand in for the hazard slots the compiler cannot see around asm)
-    static __device__ inline float swap_add32(float x, float y) {
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-        return x + y;
-    }
-    static __device__ inline float swap_add16(float x, float y) {
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-        return x + y;
+    // Halving levels: at offset `off` lanes with (lane & off) keep the upper half of the query set.  Levels 32 and 16: one
+    // swap_add per PAIR of values — x + y after the swap is "x[l] + x[l ^ off]" in the lanes that keep x and "y[l] + y[l ^ off]"
+    // in the lanes that keep y: no selects at all.  Below that: both butterflies in the VALU (xor_add) and one select.  (A
+    // generic "keep / send / shuffle" formulation compiled to ~40 compare + select instructions per value.)
+    template <int N, int OFF>
+    static __device__ inline void level(float (&v)[QT], int lane) {
+        if constexpr (N > 1) {
+            if constexpr (OFF == 32) {
+#pragma unroll
+                for (int i = 0; i < N / 2; i++) v[i] = swap_add32(v[i], v[i + N / 2]);
+            } else if constexpr (OFF == 16) {
+#pragma unroll
+                for (int i = 0; i < N / 2; i++) v[i] = swap_add16(v[i], v[i + N / 2]);
+            } else {
+                const bool up = (lane & OFF) != 0;
+#pragma unroll
+                for (int i = 0; i < N / 2; i++) {
+                    const float lo = xor_add<OFF>(v[i]), hi = xor_add<OFF>(v[i + N / 2]);
+                    v[i] = up ? hi : lo;   // x[l] + x[l ^ off] is the same value in l and l ^ off
+                }
+            }
+            level<N / 2, OFF / 2>(v, lane);
+        } else {
+            if constexpr (OFF >= 1) v[0] = xor_tail<OFF>(v[0]);
+        }
     }
     static __device__ inline float run(float (&a)[QT], int lane) {
         float v[QT];
 #pragma unroll
         for (int i = 0; i < QT; i++) v[i] = a[i];
-        int off = 32;
-#pragma unroll
-        for (int n = QT; n > 1; n >>= 1, off >>= 1) {
-            if (off == 32) {
-#pragma unroll
-                for (int i = 0; i < n / 2; i++) v[i] = swap_add32(v[i], v[i + n / 2]);
-            } else if (off == 16) {
-#pragma unroll
-                for (int i = 0; i < n / 2; i++) v[i] = swap_add16(v[i], v[i + n / 2]);
-            } else {
-                const bool up = (lane & off) != 0;
-#pragma unroll
-                for (int i = 0; i < n / 2; i++) {
-                    // both full butterflies of the level, then the lane's own one (x[l] + x[l ^ off] is the same value in l and l ^ off)
-                    const float lo = v[i] + __shfl_xor(v[i], off, 64);
-                    const float hi = v[i + n / 2] + __shfl_xor(v[i + n / 2], off, 64);
-                    v[i] = up ? hi : lo;
-                }
-            }
-        }
-        float r = v[0];
-        for (; off >= 1; off >>= 1) r = r + __shfl_xor(r, off, 64);
-        return r;
+        level<QT, 32>(v, lane);
+        return v[0];
     }
     static __device__ inline int query_of_lane(int lane) {
         int q = 0, off = 32;
