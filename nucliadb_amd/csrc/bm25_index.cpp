@@ -79,6 +79,9 @@ struct Bm25Index {
     DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
         s_facet_counts;
     DevBuf s_pf_stack, s_pf_lists, s_pf_result, s_pf_blocks, s_pf_total, s_pf_out;  // prefilter
+    // packed staging: [clauses | clause offsets], [item_first | work list] in; [doc | score | count | total | postings] out
+    DevBuf s_in_q, s_in_w, s_outpack;
+    PinBuf h_in_q, h_in_w, h_outpack;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
 };
@@ -504,11 +507,16 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, cl.mode, w};
     }
     const uint32_t kk = std::max<uint32_t>(k, 1);
-    NIDX_HIP(idx->s_clauses.reserve(std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev)));
-    NIDX_HIP(idx->s_offsets.reserve((size_t)(nq + 1) * 8));
-    if (n_clauses)
-        NIDX_HIP(hipMemcpyAsync(idx->s_clauses.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev), hipMemcpyHostToDevice, idx->stream));
-    NIDX_HIP(hipMemcpyAsync(idx->s_offsets.p, clause_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+    // clauses and clause offsets travel as one pinned block
+    const size_t cl_bytes = (std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev) + 7) & ~(size_t)7;
+    const size_t inq_bytes = cl_bytes + (size_t)(nq + 1) * 8;
+    NIDX_HIP(idx->s_in_q.reserve(inq_bytes));
+    NIDX_HIP(idx->h_in_q.reserve(inq_bytes));
+    if (n_clauses) memcpy(idx->h_in_q.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
+    memcpy(idx->h_in_q.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
+    NIDX_HIP(hipMemcpyAsync(idx->s_in_q.p, idx->h_in_q.p, inq_bytes, hipMemcpyHostToDevice, idx->stream));
+    const Bm25ClauseDev *d_clauses = idx->s_in_q.as<Bm25ClauseDev>();
+    const unsigned long long *d_clause_offsets = reinterpret_cast<const unsigned long long *>(idx->s_in_q.as<unsigned char>() + cl_bytes);
     static_assert(sizeof(Bm25AfterDev) == sizeof(nidx_gpu_bm25_search_after_t), "search-after layout");
     if (after) {
         NIDX_HIP(idx->s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
@@ -550,11 +558,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     const double t_begin = now_us();
     double t_work = 0, t_sync = 0, t_collect = 0;
     struct Hit { float score; uint64_t docaddr; int64_t value; };
-    std::vector<std::vector<Hit>> merged(nq);
+    std::vector<std::vector<Hit>> merged(idx->segs.size() == 1 ? 0 : nq);
     std::vector<Bm25Work> work;
-    std::vector<uint32_t> h_doc, h_count;
-    std::vector<float> h_score;
-    std::vector<unsigned long long> h_total, h_post;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
         // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
@@ -651,19 +656,25 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
         t_work += now_us() - t_w0;
-        NIDX_HIP(idx->s_work.reserve(nw * sizeof(Bm25Work)));
         NIDX_HIP(idx->s_key.reserve(nw * kk * 8));
-        NIDX_HIP(idx->s_item_first.reserve((size_t)(nq + 1) * 4));
-        NIDX_HIP(idx->s_doc.reserve((size_t)nq * kk * 4));
-        NIDX_HIP(idx->s_score.reserve((size_t)nq * kk * 4));
-        NIDX_HIP(idx->s_qcount.reserve((size_t)nq * 4));
-        NIDX_HIP(idx->s_qtotal.reserve((size_t)nq * 8));
-        NIDX_HIP(idx->s_qpostings.reserve((size_t)nq * 8));
-        NIDX_HIP(hipMemcpyAsync(idx->s_item_first.p, item_first.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, idx->stream));
+        const size_t if_bytes = ((size_t)(nq + 1) * 4 + 7) & ~(size_t)7;
+        const size_t inw_bytes = if_bytes + nw * sizeof(Bm25Work);
+        NIDX_HIP(idx->s_in_w.reserve(inw_bytes));
+        NIDX_HIP(idx->h_in_w.reserve(inw_bytes));
+        memcpy(idx->h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
+        memcpy(idx->h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
+        NIDX_HIP(hipMemcpyAsync(idx->s_in_w.p, idx->h_in_w.p, inw_bytes, hipMemcpyHostToDevice, idx->stream));
+        const uint32_t *d_item_first = idx->s_in_w.as<uint32_t>();
+        const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(idx->s_in_w.as<unsigned char>() + if_bytes);
+        // per-query outputs of the merge kernel, one block: doc u32 [nq][kk] | score f32 [nq][kk] | count u32 [nq] | total u64 [nq] | postings u64 [nq]
+        const size_t o_doc = 0, o_score = (size_t)nq * kk * 4, o_count = o_score + (size_t)nq * kk * 4;
+        const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, out_bytes = o_post + (size_t)nq * 8;
+        NIDX_HIP(idx->s_outpack.reserve(out_bytes));
+        NIDX_HIP(idx->h_outpack.reserve(out_bytes));
+        unsigned char *d_out = idx->s_outpack.as<unsigned char>();
         NIDX_HIP(idx->s_count.reserve(nw * 4));
         NIDX_HIP(idx->s_total.reserve(nw * 8));
         NIDX_HIP(idx->s_postings.reserve(nw * 8));
-        NIDX_HIP(hipMemcpyAsync(idx->s_work.p, work.data(), nw * sizeof(Bm25Work), hipMemcpyHostToDevice, idx->stream));
         const uint32_t match_words = (seg.n_docs + 31) / 32;
         if (n_slots) {
             const uint64_t bytes = (uint64_t)n_slots * std::max<uint32_t>(match_words, 1) * 4;
@@ -674,7 +685,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             NIDX_HIP(hipMemsetAsync(idx->s_match_bits.p, 0, bytes, idx->stream));
         }
         Bm25Args a;
-        a.work = idx->s_work.as<Bm25Work>();
+        a.work = d_work;
         a.n_docs = seg.n_docs;
         a.term_offsets = seg.term_offsets.as<unsigned long long>();
         a.doc_ids = seg.doc_ids.as<uint32_t>();
@@ -682,8 +693,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         a.fieldnorm_ids = seg.fieldnorm_ids.as<uint8_t>();
         a.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
         a.tf_cache = idx->tf_cache.as<float>();
-        a.clauses = idx->s_clauses.as<Bm25ClauseDev>();
-        a.clause_offsets = idx->s_offsets.as<unsigned long long>();
+        a.clauses = d_clauses;
+        a.clause_offsets = d_clause_offsets;
         a.after = after ? idx->s_after.as<Bm25AfterDev>() : nullptr;
         a.k = kk;
         a.segment_ord = (uint32_t)s;
@@ -710,32 +721,29 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
         Bm25MergeArgs mg;
-        mg.item_first = idx->s_item_first.as<uint32_t>();
+        mg.item_first = d_item_first;
         mg.item_key = idx->s_key.as<unsigned long long>();
         mg.item_count = idx->s_count.as<uint32_t>();
         mg.item_total = idx->s_total.as<unsigned long long>();
         mg.item_postings = idx->s_postings.as<unsigned long long>();
         mg.k = kk;
-        mg.out_doc = idx->s_doc.as<uint32_t>();
-        mg.out_score = idx->s_score.as<float>();
-        mg.out_count = idx->s_qcount.as<uint32_t>();
-        mg.out_total = idx->s_qtotal.as<unsigned long long>();
-        mg.out_postings = idx->s_qpostings.as<unsigned long long>();
+        mg.out_doc = reinterpret_cast<uint32_t *>(d_out + o_doc);
+        mg.out_score = reinterpret_cast<float *>(d_out + o_score);
+        mg.out_count = reinterpret_cast<uint32_t *>(d_out + o_count);
+        mg.out_total = reinterpret_cast<unsigned long long *>(d_out + o_total);
+        mg.out_postings = reinterpret_cast<unsigned long long *>(d_out + o_post);
         NIDX_HIP(launch_bm25_merge(mg, nq, idx->stream));
         if (n_slots)
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_pair_term.as<uint32_t>(),
                                         idx->s_pair_slot.as<int>(), (uint32_t)n_pairs, idx->s_match_bits.as<uint32_t>(), match_words,
                                         idx->s_facet_counts.as<unsigned long long>(), idx->stream));
-        h_doc.resize((size_t)nq * kk);
-        h_score.resize((size_t)nq * kk);
-        h_count.resize(nq);
-        h_total.resize(nq);
-        h_post.resize(nq);
-        NIDX_HIP(hipMemcpyAsync(h_doc.data(), idx->s_doc.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_score.data(), idx->s_score.p, (size_t)nq * kk * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_count.data(), idx->s_qcount.p, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_total.data(), idx->s_qtotal.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(h_post.data(), idx->s_qpostings.p, (size_t)nq * 8, hipMemcpyDeviceToHost, idx->stream));
+        NIDX_HIP(hipMemcpyAsync(idx->h_outpack.p, idx->s_outpack.p, out_bytes, hipMemcpyDeviceToHost, idx->stream));
+        const unsigned char *h_out = idx->h_outpack.as<unsigned char>();
+        const uint32_t *h_doc = reinterpret_cast<const uint32_t *>(h_out + o_doc);
+        const float *h_score = reinterpret_cast<const float *>(h_out + o_score);
+        const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + o_count);
+        const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + o_total);
+        const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + o_post);
         const double t_s0 = now_us();
         NIDX_HIP(hipStreamSynchronize(idx->stream));
         t_sync += now_us() - t_s0;
@@ -749,10 +757,22 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu cycles/item: load=%llu apply=%llu fold=%llu total=%llu kernel_ms=%.3f\n", d[5], d[4],
                     d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), ms);
         }
+        const bool direct = idx->segs.size() == 1;   // one segment: the device list is the answer, no host merge
         for (uint32_t q = 0; q < nq; q++) {  // per segment the device already merged the slices
             if (out_total) out_total[q] += h_total[q];
             if (out_postings) out_postings[q] += h_post[q];
             if (k == 0) continue;
+            if (direct) {
+                const uint32_t n = std::min<uint32_t>(h_count[q], k);
+                out_count[q] = n;
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t d = h_doc[(size_t)q * kk + i];
+                    if (out_docaddr) out_docaddr[(size_t)q * k + i] = ((uint64_t)s << 32) | d;
+                    if (out_score) out_score[(size_t)q * k + i] = order_field >= 0 ? 0.f : h_score[(size_t)q * kk + i];
+                    if (opt->out_order_value) opt->out_order_value[(size_t)q * k + i] = order_field >= 0 ? seg.fast_host[order_field][d] : 0;
+                }
+                continue;
+            }
             for (uint32_t i = 0; i < h_count[q]; i++) {
                 const uint32_t d = h_doc[(size_t)q * kk + i];
                 if (order_field >= 0) merged[q].push_back(Hit{0.f, ((uint64_t)s << 32) | d, seg.fast_host[order_field][d]});
@@ -769,7 +789,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     }
     const bool desc = opt->order_desc != 0;
     const bool single_segment = idx->segs.size() == 1;
-    for (uint32_t q = 0; q < nq && k > 0; q++) {
+    for (uint32_t q = 0; q < nq && k > 0 && !single_segment; q++) {
         std::vector<Hit> &m = merged[q];
         if (single_segment) {
             // one segment: the device list is already in TopDocs order

@@ -53,4 +53,28 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// grow-only pinned host staging buffer: one hipMemcpyAsync moves a whole call's inputs (or outputs) without the runtime's own
+// bounce through pageable memory
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 }  // namespace nidx
