@@ -71,7 +71,7 @@ struct Bm25Index {
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
     DevBuf tf_cache;
-    DevBuf s_clauses, s_offsets, s_after, s_work, s_doc, s_score, s_count, s_total, s_postings, s_key, s_item_first, s_qcount, s_qtotal, s_qpostings;
+    DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
