@@ -141,40 +141,82 @@ def main():
     params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def search(qb, with_stats=False, m=None):
+    def search(qb, with_stats=False, m=None, out=None):
         p = params if m is None else _lib.VectorSearchParamsC(k, -1.0, 1, m)
+        ov, osc, oc = out if out is not None else (out_vec, out_score, out_count)
         _lib.check(L.nidx_gpu_vector_segment_search_device(
-            h, 0, qb.data_ptr(), B, C.byref(p), None, out_vec.data_ptr(), out_score.data_ptr(), out_count.data_ptr(),
+            h, 0, qb.data_ptr(), B, C.byref(p), None, ov.data_ptr(), osc.data_ptr(), oc.data_ptr(),
             stats.data_ptr() if with_stats else None, stream))
 
-    def exchange():
+    def exchange(out):
         # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
         from nucliadb_amd.shard_merge import exchange_and_merge_vector
 
-        ids = (out_vec.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
-        return exchange_and_merge_vector(out_score, ids, out_count, k)
+        ov, osc, oc = out
+        ids = (ov.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
+        return exchange_and_merge_vector(osc, ids, oc, k)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # With more than one rank a step is search + exchange.  The exchange (three small all-gathers over xGMI + the merge kernel) is
+    # latency-bound and needs none of the compute units, so it runs on a side stream from one of two result-buffer sets while
+    # the main stream already searches the next batch into the other set: search i + 1 overlaps exchange i; a buffer set is
+    # searched into again only after its exchange has finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
+    do_exchange = world > 1 or os.environ.get("NIDX_BENCH_FORCE_EXCHANGE") == "1"
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream() if do_exchange else None
+    out_sets = [(out_vec, out_score, out_count),
+                (torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count))] if do_exchange else None
+    ev_searched = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_exchanged = [torch.cuda.Event(), torch.cuda.Event()]
+    last_merged = [None]
+
+    def step(i, e0=None, e1=None):
+        if not do_exchange:
+            if e0 is not None:
+                e0.record()
+            search(qpool[i % n_pool])
+            if e1 is not None:
+                e1.record()
+            return
+        b = i & 1
+        main_stream.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
+        if e0 is not None:
+            e0.record(main_stream)
+        search(qpool[i % n_pool], out=out_sets[b])
+        if e1 is not None:
+            e1.record(main_stream)
+        ev_searched[b].record(main_stream)
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(ev_searched[b])
+            last_merged[0] = exchange(out_sets[b])
+            ev_exchanged[b].record(side_stream)
+
     for i in range(a.warmup):
-        search(qpool[i % n_pool])
-        if world > 1:
-            exchange()
+        step(i)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ev0[i].record()
-        search(qpool[i % n_pool])
-        ev1[i].record()
-        if world > 1:
-            exchange()
+        step(a.warmup + i, ev0[i], ev1[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    if do_exchange and a.steps > 0:
+        # the overlapped pipeline must give what a plain search -> exchange of the same batch gives
+        i_last = a.warmup + a.steps - 1
+        got = [t.clone() for t in last_merged[0]]
+        search(qpool[i_last % n_pool], out=out_sets[0])
+        torch.cuda.synchronize()
+        want = exchange(out_sets[0])
+        torch.cuda.synchronize()
+        for g_, w_ in zip(got, want):
+            if not torch.equal(g_, w_):
+                raise RuntimeError("overlapped exchange diverged from the sequential one")
+        barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
