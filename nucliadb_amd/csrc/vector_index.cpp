@@ -300,8 +300,8 @@ int32_t VectorIndex::segment_spill_search(uint32_t s, const float *d_queries, ui
         a.out_count = d_out_count;
         a.stats = scratch_stats.as<uint32_t>();
         a.multi = sp.multi;
-        a.eval_rows = eval_rows;
-        a.min_waves = min_waves;
+        a.eval_rows = rows_for(nq);
+        a.min_waves = waves_for(nq);
         a.entry_vec = nullptr;
         a.entry_score = nullptr;
         a.entry_count = nullptr;
@@ -370,8 +370,8 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.out_count = d_out_count;
         a.stats = d_stats;
         a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
-        a.eval_rows = eval_rows;
-        a.min_waves = min_waves;
+        a.eval_rows = rows_for(nq);
+        a.min_waves = waves_for(nq);
         a.entry_vec = nullptr;
         a.entry_score = nullptr;
         a.entry_count = nullptr;
@@ -454,8 +454,8 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.out_count = d_out_count;
         a.stats = d_stats;  // entry mode only ORs its overflow flags into the RaBitQ counters
         a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
-        a.eval_rows = eval_rows;
-        a.min_waves = min_waves;
+        a.eval_rows = rows_for(nq);
+        a.min_waves = waves_for(nq);
         a.entry_vec = scratch_entry_vec.as<uint32_t>();
         a.entry_score = scratch_entry_score.as<float>();
         a.entry_count = scratch_entry_count.as<uint32_t>();
@@ -946,8 +946,8 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     idx->cfg = *config;
     // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels
     if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
-    if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) idx->eval_rows = std::max(2, std::min(4, atoi(e)));
-    if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) idx->min_waves = atoi(e) >= 4 ? 4 : 2;
+    if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) { idx->eval_rows = std::max(2, std::min(4, atoi(e))); idx->shape_pinned = true; }
+    if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) { idx->min_waves = atoi(e) >= 4 ? 4 : 2; idx->shape_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     NIDX_HIP(hipGetDevice(&idx->device));
@@ -978,8 +978,8 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     std::lock_guard<std::mutex> lock(idx->mu);
     std::string n(name);
     if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
-    else if (n == "eval_rows") idx->eval_rows = std::max(2, std::min(4, (int)value));
-    else if (n == "min_waves") idx->min_waves = value >= 4 ? 4 : 2;
+    else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
+    else if (n == "min_waves") { idx->min_waves = value >= 4 ? 4 : 2; idx->shape_pinned = true; }
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else if (n == "coalesce_window_us") { idx->mu.unlock(); idx->coalescer_config(value, -1); idx->mu.lock(); }
     else if (n == "coalesce_max_batch") { idx->mu.unlock(); idx->coalescer_config(-1, value); idx->mu.lock(); }

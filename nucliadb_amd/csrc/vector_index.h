@@ -65,6 +65,12 @@ struct VectorIndex {
     int waves_per_query = 4;
     int eval_rows = 2;   // rows in flight per wave (HNSW distance phase); tuned on MI355X, profiles/r01_tune_hnsw.txt
     int min_waves = 4;   // register budget class of the HNSW kernel (4 => <=128 VGPR, 16 waves per CU)
+    bool shape_pinned = false;  // eval_rows / min_waves were set by the caller (tunable or environment): no per-batch choice
+    // launch shape of the HNSW kernels for a batch: a batch that leaves most CUs with at most one workgroup (<= 256 queries) is
+    // latency-bound, not occupancy-bound — four rows in flight per wave and the 256-VGPR budget measured 10-11 % faster there
+    // (batch 1: 0.48 -> 0.43 ms, batch 64: 0.65 -> 0.57 ms at 1 M x 768); large batches keep 2 rows / 128 VGPRs (16 waves per CU)
+    int rows_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 4 : eval_rows; }
+    int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : min_waves; }
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
