@@ -92,6 +92,14 @@ __device__ inline uint64_t shfl_up_u64(uint64_t v, int delta) {
     hi = __shfl_up(hi, delta, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+// lane l gets lane l - 1's value (lane 0 keeps its own): the wavefront shift of the gfx9 DPP unit (wave_shr:1) instead of two
+// ds_bpermute_b32 round trips — the move every sorted-list insertion makes
+__device__ inline uint64_t wave_shr1_u64(uint64_t v) {
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return ((uint64_t)h2 << 32) | l2;
+}
 
 // dense_f32::cosine_similarity (vector_types/dense_f32.rs:29-34) on pre-summed f32 terms:
 // SimSIMD distance semantics (zero-norm cases, clamp >= 0) evaluated in f64, then `1.0 - (d as f32)`.
@@ -126,8 +134,10 @@ struct WaveSortedList {
         // position = number of entries ranking before nk
         unsigned long long before = __ballot(key > nk);
         int pos = __popcll(before);
-        uint64_t dropped = shfl_u64(key, 63);
-        uint64_t up = shfl_up_u64(key, 1);
+        // lane 63's key through the scalar unit (v_readlane) rather than the LDS crossbar
+        uint64_t dropped = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63);
+        uint64_t up = wave_shr1_u64(key);
         if (lane > pos) key = up;
         if (lane == pos) key = nk;
         return pos >= 64 ? nk : dropped;
