@@ -80,6 +80,58 @@ __device__ inline float xor_tail(float x) {
 // xor butterfly: every lane ends with the same value, pairing a[l] + a[l^off] at each level.
 __device__ inline float wave_butterfly_sum(float v) { return xor_tail<32>(v); }
 
+// The same VALU-only butterfly for order statistics.  combine(x[l], x[l ^ OFF]) for a commutative combine: levels 32 and 16 hand
+// both operands over as the two results of a permlane swap of the value with itself, the levels below as a DPP move.
+__device__ inline void swap_pair32(uint32_t &x, uint32_t &y) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+__device__ inline void swap_pair16(uint32_t &x, uint32_t &y) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+template <int CTRL>
+__device__ inline uint32_t dpp_move_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false); }
+template <int OFF>
+__device__ inline uint32_t xor_partner_dpp(uint32_t x) {   // x[l ^ OFF] for OFF in {8, 4, 2, 1}
+    if constexpr (OFF == 8) return dpp_move_u32<0x128>(x);
+    else if constexpr (OFF == 4) return dpp_move_u32<0x1B>(dpp_move_u32<0x141>(x));
+    else if constexpr (OFF == 2) return dpp_move_u32<0x4E>(x);
+    else return dpp_move_u32<0xB1>(x);
+}
+template <bool MAX>
+__device__ inline uint64_t wave_extreme_u64(uint64_t v) {
+    auto pick = [](uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    {
+        uint32_t a0 = (uint32_t)v, a1 = a0, b0 = (uint32_t)(v >> 32), b1 = b0;
+        swap_pair32(a0, a1);
+        swap_pair32(b0, b1);
+        v = pick(((uint64_t)b0 << 32) | a0, ((uint64_t)b1 << 32) | a1);
+    }
+    {
+        uint32_t a0 = (uint32_t)v, a1 = a0, b0 = (uint32_t)(v >> 32), b1 = b0;
+        swap_pair16(a0, a1);
+        swap_pair16(b0, b1);
+        v = pick(((uint64_t)b0 << 32) | a0, ((uint64_t)b1 << 32) | a1);
+    }
+    v = pick(v, ((uint64_t)xor_partner_dpp<8>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<8>((uint32_t)v));
+    v = pick(v, ((uint64_t)xor_partner_dpp<4>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<4>((uint32_t)v));
+    v = pick(v, ((uint64_t)xor_partner_dpp<2>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<2>((uint32_t)v));
+    v = pick(v, ((uint64_t)xor_partner_dpp<1>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<1>((uint32_t)v));
+    return v;
+}
+__device__ inline int wave_min_i32(int x) {
+    uint32_t a0 = (uint32_t)x, a1 = a0;
+    swap_pair32(a0, a1);
+    x = (int)a0 < (int)a1 ? (int)a0 : (int)a1;
+    a0 = a1 = (uint32_t)x;
+    swap_pair16(a0, a1);
+    x = (int)a0 < (int)a1 ? (int)a0 : (int)a1;
+    int o;
+    o = (int)xor_partner_dpp<8>((uint32_t)x); x = o < x ? o : x;
+    o = (int)xor_partner_dpp<4>((uint32_t)x); x = o < x ? o : x;
+    o = (int)xor_partner_dpp<2>((uint32_t)x); x = o < x ? o : x;
+    o = (int)xor_partner_dpp<1>((uint32_t)x); x = o < x ? o : x;
+    return x;
+}
+// value of lane `src` (wave-uniform index) through the scalar unit
+__device__ inline uint32_t lane_bcast_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ inline float lane_bcast_f32(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+
 __device__ inline uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl(lo, src, 64);

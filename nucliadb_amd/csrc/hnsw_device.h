@@ -81,24 +81,8 @@ __device__ inline bool vis_insert(uint32_t *vis, uint32_t log2cap, uint32_t v) {
 }
 
 // ---- candidate pool: unsorted array in LDS, arg-max pop --------------------------------------
-__device__ inline uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-        uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ inline uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-        uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
-}
+__device__ inline uint64_t wave_max_u64(uint64_t v) { return wave_extreme_u64<true>(v); }
+__device__ inline uint64_t wave_min_u64(uint64_t v) { return wave_extreme_u64<false>(v); }
 // Pops the best key (EMPTY if none).  Wave-0 only; pool_len is wave-uniform.
 __device__ inline uint64_t pool_pop(uint64_t *pool, int &pool_len, int lane) {
     if (pool_len == 0) return NIDX_EMPTY_KEY;
@@ -112,11 +96,7 @@ __device__ inline uint64_t pool_pop(uint64_t *pool, int &pool_len, int lane) {
     int idx = 0x7fffffff;
     for (int i = lane; i < pool_len; i += 64)
         if (pool[i] == best && i < idx) idx = i;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(idx, off, 64);
-        idx = o < idx ? o : idx;
-    }
+    idx = wave_min_i32(idx);
     uint64_t last = pool[pool_len - 1];
     if (lane == 0) pool[idx] = last;
     pool_len--;
@@ -220,7 +200,7 @@ __device__ inline uint32_t load_edge_word(const GraphDev &g, uint32_t node, int 
         uint32_t base = g.upper_base[node];
         if (base != 0xffffffffu && lane < NIDX_UP_STRIDE) w = g.upper[((size_t)base + (layer - 1)) * NIDX_UP_STRIDE + lane];
     }
-    deg = __shfl(w, 0, 64);
+    deg = lane_bcast_u32(w, 0);
     return w;
 }
 
@@ -266,7 +246,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
             float s = lane < chunk ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
             uint32_t addr = sh.nb_addr[lane];
             for (int j = 0; j < chunk; j++) {
-                uint64_t nk = rank_key(__shfl(s, j, 64), __shfl(addr, j, 64));
+                uint64_t nk = rank_key(lane_bcast_f32(s, j), lane_bcast_u32(addr, j));
                 if (lane == 0) sh.pool[pool_len] = nk;
                 pool_len++;
                 res.insert(nk, 64 * EFL, lane);
@@ -333,9 +313,9 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
                 }
                 int j = __ffsll((long long)todo) - 1;
                 todo &= ~(1ull << j);
-                float sj = __shfl(s, j, 64);
+                float sj = lane_bcast_f32(s, j);
                 if (sj > ws || res.len < k) {
-                    uint64_t nk = rank_key(sj, __shfl(addr, j, 64));
+                    uint64_t nk = rank_key(sj, lane_bcast_u32(addr, j));
                     if (pool_len == NIDX_POOL_CAP) {
                         if (res.len >= k) pool_prune(sh.pool, pool_len, ws, lane);
                         if (pool_len == NIDX_POOL_CAP) {  // more than CAP live ties: cannot stay exact

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
             while (todo) {
                 int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                uint64_t nk = rank_key(__shfl(s, j, 64), __shfl(addr, j, 64));
+                uint64_t nk = rank_key(lane_bcast_f32(s, j), lane_bcast_u32(addr, j));
                 if (pool_len == NIDX_POOL_CAP) {
                     // evict the worst candidate; remember the best one ever evicted so that popping
                     // past it is reported instead of silently diverging from the reference
@@ -208,11 +208,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
                     int idx = 0x7fffffff;
                     for (int i = lane; i < pool_len; i += 64)
                         if (sh.pool[i] == worst && i < idx) idx = i;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        int o = __shfl_xor(idx, off, 64);
-                        idx = o < idx ? o : idx;
-                    }
+                    idx = wave_min_i32(idx);
                     if (lane == 0) sh.pool[idx] = nk;
                 } else {
                     if (lane == 0) sh.pool[pool_len] = nk;
