@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
         for (int c = 0; c < C; c++) {
             const bool aux = (rl_u32(attr_l, c) >> 16) != 0;
             const uint32_t *ids = aux ? a.aux_doc_ids : a.doc_ids;
-            const unsigned long long b = shfl_u64(cur_l, c), e = shfl_u64(end_l, c);
+            const unsigned long long b = lane_bcast_u64(cur_l, c), e = lane_bcast_u64(end_l, c);
             unsigned long long res[2];
 #pragma unroll
             for (int w = 0; w < 2; w++) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
             while (mm) {
                 int src = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
-                uint64_t nk = shfl_u64(ck, src);
+                uint64_t nk = lane_bcast_u64(ck, src);
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
             while (mm) {
                 const int src = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
-                const uint64_t nk = shfl_u64(key, src);
+                const uint64_t nk = lane_bcast_u64(key, src);
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }

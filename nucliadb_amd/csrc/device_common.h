@@ -130,6 +130,9 @@ __device__ inline int wave_min_i32(int x) {
 }
 // value of lane `src` (wave-uniform index) through the scalar unit
 __device__ inline uint32_t lane_bcast_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ inline uint64_t lane_bcast_u64(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
 __device__ inline float lane_bcast_f32(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
 __device__ inline uint64_t shfl_u64(uint64_t v, int src) {
@@ -194,7 +197,7 @@ struct WaveSortedList {
         if (lane == pos) key = nk;
         return pos >= 64 ? nk : dropped;
     }
-    __device__ inline uint64_t at(int rank) const { return shfl_u64(key, rank); }
+    __device__ inline uint64_t at(int rank) const { return lane_bcast_u64(key, rank); }  // rank is wave-uniform at every call site
 };
 
 // Up to 64*NL best entries: NL sorted lists chained (what falls off list i is inserted into list i+1).

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void mfma_scan_kernel(MfmaScanArgs a) {
                 while (m) {
                     int src = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const int sq = __shfl(qi, src, 64);
-                    const uint64_t nk_ = shfl_u64(key, src);
+                    const int sq = (int)lane_bcast_u32((uint32_t)qi, src);
+                    const uint64_t nk_ = lane_bcast_u64(key, src);
                     if (!(nk_ > sh.thr_key[sq])) continue;  // an earlier insert of this round raised the bar
                     WaveSortedList l;
                     l.key = lane < MF_KMAX ? sh.lists[sq][lane] : NIDX_EMPTY_KEY;

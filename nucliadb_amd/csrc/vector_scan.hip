@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         while (m) {
             int src = __ffsll((long long)m) - 1;
             m &= m - 1;
-            uint64_t nk = shfl_u64(ck, src);
+            uint64_t nk = lane_bcast_u64(ck, src);
             int q = QReduce<QT>::query_of_lane(src);
 #pragma unroll
             for (int qq = 0; qq < QT; qq++) {

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * SS_WAVES, 1) void scan_shared_kernel(ScanArgs 
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint64_t nk = shfl_u64(ck, src);
+                const uint64_t nk = lane_bcast_u64(ck, src);
                 const int q = QReduce<SS_QT>::query_of_lane(src);
 #pragma unroll
                 for (int qq = 0; qq < SS_QT; qq++) {
