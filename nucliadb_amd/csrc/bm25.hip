@@ -32,21 +32,12 @@ namespace nidx {
 #define BW_WINDOW 512      /* postings per window: 8 per lane */
 #define BW_SHIFT 22        /* 32 - log2(BW_TABLE) */
 
+// wave reductions on the swap + DPP levels of device_common.h (no ds_bpermute round trips)
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-        v += ((unsigned long long)hi << 32) | lo;
-    }
-    return v;
+    return wave_reduce_u64((uint64_t)v, [](uint64_t a, uint64_t b) { return a + b; });
 }
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
 }
 __device__ inline uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 

@@ -93,9 +93,9 @@ __device__ inline uint32_t xor_partner_dpp(uint32_t x) {   // x[l ^ OFF] for OFF
     else if constexpr (OFF == 2) return dpp_move_u32<0x4E>(x);
     else return dpp_move_u32<0xB1>(x);
 }
-template <bool MAX>
-__device__ inline uint64_t wave_extreme_u64(uint64_t v) {
-    auto pick = [](uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+// all-lanes reduction of a 64-bit value with a commutative, associative combine
+template <typename F>
+__device__ inline uint64_t wave_reduce_u64(uint64_t v, F pick) {
     {
         uint32_t a0 = (uint32_t)v, a1 = a0, b0 = (uint32_t)(v >> 32), b1 = b0;
         swap_pair32(a0, a1);
@@ -113,6 +113,24 @@ __device__ inline uint64_t wave_extreme_u64(uint64_t v) {
     v = pick(v, ((uint64_t)xor_partner_dpp<2>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<2>((uint32_t)v));
     v = pick(v, ((uint64_t)xor_partner_dpp<1>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<1>((uint32_t)v));
     return v;
+}
+template <bool MAX>
+__device__ inline uint64_t wave_extreme_u64(uint64_t v) {
+    return wave_reduce_u64(v, [](uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); });
+}
+template <typename F>
+__device__ inline uint32_t wave_reduce_u32(uint32_t x, F pick) {
+    uint32_t a0 = x, a1 = x;
+    swap_pair32(a0, a1);
+    x = pick(a0, a1);
+    a0 = a1 = x;
+    swap_pair16(a0, a1);
+    x = pick(a0, a1);
+    x = pick(x, xor_partner_dpp<8>(x));
+    x = pick(x, xor_partner_dpp<4>(x));
+    x = pick(x, xor_partner_dpp<2>(x));
+    x = pick(x, xor_partner_dpp<1>(x));
+    return x;
 }
 __device__ inline int wave_min_i32(int x) {
     uint32_t a0 = (uint32_t)x, a1 = a0;
