@@ -38,6 +38,8 @@ extern "C" {
 #define NIDX_ERR_DEVICE (-7)                  /* HIP runtime error, or no gfx950 device present */
 #define NIDX_ERR_INVALID_GRAPH (-8)           /* malformed hnsw.graph image */
 #define NIDX_ERR_INEXACT (-9)                 /* a bounded on-chip pool overflowed: result would differ from the reference */
+#define NIDX_ERR_OUT_OF_MEMORY (-10)          /* a host allocation failed inside the library */
+#define NIDX_ERR_INTERNAL (-11)               /* any other C++ exception, caught at the boundary */
 
 /* Copies the calling thread's last error message (NUL terminated) and returns its length. */
 int32_t nidx_gpu_last_error(char *buf, size_t len);

@@ -22,6 +22,8 @@ NIDX_ERR_UNSUPPORTED = -6
 NIDX_ERR_DEVICE = -7
 NIDX_ERR_INVALID_GRAPH = -8
 NIDX_ERR_INEXACT = -9
+NIDX_ERR_OUT_OF_MEMORY = -10
+NIDX_ERR_INTERNAL = -11
 
 SIMILARITY_DOT, SIMILARITY_COSINE = 0, 1
 METHOD_AUTO, METHOD_HNSW, METHOD_BRUTE_FORCE, METHOD_BRUTE_FORCE_MFMA, METHOD_BRUTE_FORCE_BF16 = 0, 1, 2, 3, 4

@@ -84,6 +84,17 @@ struct Bm25Index {
     PinBuf h_in_q, h_in_w, h_outpack;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
+    Bm25Index() = default;
+    Bm25Index(const Bm25Index &) = delete;
+    // also the clean-up of an open that failed half way
+    ~Bm25Index() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
 };
 
 }  // namespace nidx
@@ -96,7 +107,7 @@ float nidx_gpu_bm25_idf(uint64_t doc_freq, uint64_t doc_count) { return bm25_idf
 uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id) { return fieldnorm_from_id(id); }
 uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm) { return fieldnorm_to_id(fieldnorm); }
 
-int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments, nidx_gpu_bm25_index_t **index_out) {
+int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments, nidx_gpu_bm25_index_t **index_out) try {
     if (!index_out || (n_segments && !segments)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *index_out = nullptr;
     std::unique_ptr<Bm25Index> idx(new Bm25Index());
@@ -117,6 +128,15 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
         seg.term_offsets_host.assign(in.term_offsets, in.term_offsets + in.n_terms + 1);
         const uint64_t n_post = seg.term_offsets_host[in.n_terms];
         if (n_post && (!in.doc_ids || !in.tfs)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL postings", s);
+        // the kernels index fieldnorm_ids / the alive bitset with these without a bounds check
+        if (seg.term_offsets_host[0] != 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets[0] != 0", s);
+        for (uint32_t t = 0; t < in.n_terms; t++)
+            if (seg.term_offsets_host[t + 1] < seg.term_offsets_host[t])
+                return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets decrease at term %u", s, t);
+        uint32_t max_doc = 0;
+        for (uint64_t i = 0; i < n_post; i++) max_doc = std::max(max_doc, in.doc_ids[i]);
+        if (n_post && max_doc >= in.n_docs)
+            return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: posting doc id %u >= n_docs %u", s, max_doc, in.n_docs);
         NIDX_HIP(seg.term_offsets.alloc((size_t)(in.n_terms + 1) * 8));
         NIDX_HIP(hipMemcpy(seg.term_offsets.p, in.term_offsets, (size_t)(in.n_terms + 1) * 8, hipMemcpyHostToDevice));
         NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4));
@@ -154,38 +174,32 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     NIDX_HIP(hipMemcpy(idx->tf_cache.p, cache, sizeof(cache), hipMemcpyHostToDevice));
     *index_out = reinterpret_cast<nidx_gpu_bm25_index_t *>(idx.release());
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index) {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    if (idx->stream) {
-        (void)hipStreamSynchronize(idx->stream);
-        (void)hipStreamDestroy(idx->stream);
-    }
-    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
-    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     delete idx;
 }
 
-int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out) {
+int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out) try {
     const Bm25Index *idx = reinterpret_cast<const Bm25Index *>(index);
     if (!idx || !ms_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *ms_out = idx->last_kernel_ms;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *bytes_out) {
+int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *bytes_out) try {
     const Bm25Index *idx = reinterpret_cast<const Bm25Index *>(index);
     if (!idx || !bytes_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     uint64_t b = idx->tf_cache.bytes;
     for (const Bm25Segment &s : idx->segs) b += s.bytes();
     *bytes_out = b;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values) {
+int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || segment >= idx->segs.size() || field > 1 || !values) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad fast field");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -203,9 +217,9 @@ int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segm
     if (seg.n_docs) NIDX_HIP(hipMemcpy(seg.order_key[field].p, rank.data(), (size_t)seg.n_docs * 4, hipMemcpyHostToDevice));
     seg.fast_uniq[field] = std::move(uniq);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t *bytes, const uint64_t *offsets) {
+int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t *bytes, const uint64_t *offsets) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !offsets) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -218,10 +232,10 @@ int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t
     NIDX_HIP(hipMemcpy(idx->dict_offsets.p, offsets, (size_t)(idx->n_terms + 1) * 8, hipMemcpyHostToDevice));
     idx->has_dict = true;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *query, uint32_t query_len, int32_t prefix,
-                                  uint32_t *out_terms, uint32_t cap, uint32_t *n_out) {
+                                  uint32_t *out_terms, uint32_t cap, uint32_t *n_out) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !n_out || (query_len && !query)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -258,10 +272,10 @@ int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *q
         }
     *n_out = n;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_prefilter_t *req, uint64_t *out_docaddr, uint64_t capacity,
-                                uint64_t *n_matching, uint64_t *num_docs) {
+                                uint64_t *n_matching, uint64_t *num_docs) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !req || !n_matching || (capacity && !out_docaddr)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -424,11 +438,11 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     *n_matching = matched;
     if (num_docs) *num_docs = live;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                 uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
-                                uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+                                uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !clause_offsets || !out_count || !opt) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -819,17 +833,17 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         fprintf(stderr, "[bm25 host] total=%.0f us: work list=%.0f sync wait=%.0f collect=%.0f merge=%.0f\n", now_us() - t_begin, t_work, t_sync,
                 t_collect, now_us() - t_merge0);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                              uint32_t nq, uint32_t k, const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr, float *out_score,
-                             uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+                             uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) try {
     nidx_gpu_bm25_search_options_t opt;
     memset(&opt, 0, sizeof(opt));
     opt.k = k;
     opt.after = after;
     opt.order_field = -1;
     return nidx_gpu_bm25_search_ex(index, clauses, clause_offsets, nq, &opt, out_docaddr, out_score, out_count, out_total, out_postings);
-}
+} NIDX_ABI_CATCH
 
 }  // extern "C"

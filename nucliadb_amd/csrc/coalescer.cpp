@@ -25,7 +25,7 @@ struct OneRequest {
     float *out_score;
     uint32_t *out_count;
     int32_t rc = NIDX_OK;
-    std::string error;
+    char error[512] = {0};
     bool done = false;
 };
 
@@ -45,13 +45,13 @@ static bool same_params(const nidx_gpu_vector_search_params_t &a, const nidx_gpu
 
 int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
                                 uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
-    if (!coalescer) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!coalescer) coalescer = std::make_shared<Coalescer>();
-    }
-    Coalescer &c = *coalescer;
+    Coalescer &c = *coalescer;  // created with the handle (nidx_gpu_vector_open)
     OneRequest req{query, p, out_segment, out_paragraph, out_vector, out_score, out_count};
     std::unique_lock<std::mutex> lk(c.mu);
+    // everything that can fail for lack of memory happens before the request is visible to other callers: `req` lives on this
+    // stack frame, and a leader that unwinds would strand its followers
+    std::vector<OneRequest *> batch;
+    batch.reserve(c.max_batch);
     c.pending.push_back(&req);
     c.cv.notify_all();
     while (!req.done) {
@@ -64,9 +64,10 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c.window_us);
         while (c.pending.size() < c.max_batch && c.cv.wait_until(lk, deadline) != std::cv_status::timeout) {
         }
-        std::vector<OneRequest *> batch;
         const nidx_gpu_vector_search_params_t lead = c.pending.front()->params;
-        for (auto it = c.pending.begin(); it != c.pending.end() && batch.size() < c.max_batch;) {
+        const size_t room = std::min<size_t>(c.max_batch, batch.capacity());
+        batch.clear();
+        for (auto it = c.pending.begin(); it != c.pending.end() && batch.size() < room;) {
             if (same_params((*it)->params, lead)) {
                 batch.push_back(*it);
                 it = c.pending.erase(it);
@@ -76,20 +77,27 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         }
         lk.unlock();
         const uint32_t B = (uint32_t)batch.size(), k = lead.k, d = cfg.dimension;
-        std::vector<float> q((size_t)B * d);
-        for (uint32_t i = 0; i < B; i++) std::memcpy(&q[(size_t)i * d], batch[i]->query, (size_t)d * 4);
         const size_t kk = std::max<uint32_t>(k, 1);
-        std::vector<uint32_t> seg(B * kk), par(B * kk), vec(B * kk), cnt(B);
-        std::vector<float> sc(B * kk);
-        int32_t rc = search_host(q.data(), B, lead, nullptr, nullptr, seg.data(), par.data(), vec.data(), sc.data(), cnt.data(),
-                                 nullptr, nullptr);
+        std::vector<uint32_t> seg, par, vec, cnt;
+        std::vector<float> q, sc;
+        int32_t rc;
+        // the followers of this batch are parked on the condition variable: whatever happens here, they must be released
+        try {
+            q.resize((size_t)B * d);
+            for (uint32_t i = 0; i < B; i++) std::memcpy(&q[(size_t)i * d], batch[i]->query, (size_t)d * 4);
+            seg.resize(B * kk), par.resize(B * kk), vec.resize(B * kk), cnt.resize(B), sc.resize(B * kk);
+            rc = search_host(q.data(), B, lead, nullptr, nullptr, seg.data(), par.data(), vec.data(), sc.data(), cnt.data(), nullptr,
+                             nullptr);
+        } catch (...) {
+            rc = abi_exception();
+        }
         char err[512] = {0};
         if (rc != NIDX_OK) nidx_gpu_last_error(err, sizeof(err));
         lk.lock();
         for (uint32_t i = 0; i < B; i++) {
             OneRequest *r = batch[i];
             r->rc = rc;
-            if (rc != NIDX_OK) r->error = err;
+            if (rc != NIDX_OK) std::memcpy(r->error, err, sizeof(err));
             else {
                 *r->out_count = cnt[i];
                 for (uint32_t j = 0; j < cnt[i]; j++) {
@@ -106,7 +114,7 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         c.leader_active = false;
         c.cv.notify_all();
     }
-    if (req.rc != NIDX_OK) set_error("%s", req.error.c_str());
+    if (req.rc != NIDX_OK) set_error("%s", req.error);
     return req.rc;
 }
 
@@ -118,11 +126,9 @@ void VectorIndex::coalescer_stats(uint64_t &batches, uint64_t &queries) {
     queries = coalescer->n_queries;
 }
 
+std::shared_ptr<Coalescer> make_coalescer() { return std::make_shared<Coalescer>(); }
+
 void VectorIndex::coalescer_config(int32_t window_us, int32_t max_batch) {
-    if (!coalescer) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!coalescer) coalescer = std::make_shared<Coalescer>();
-    }
     std::lock_guard<std::mutex> lk(coalescer->mu);
     if (window_us >= 0) coalescer->window_us = (uint32_t)window_us;
     if (max_batch > 0) coalescer->max_batch = (uint32_t)max_batch;
@@ -136,7 +142,7 @@ extern "C" {
 
 int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *query, uint32_t query_dimension,
                                    const nidx_gpu_vector_search_params_t *params, uint32_t *out_segment,
-                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
+                                   uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !query || !params || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (query_dimension != idx->cfg.dimension)
@@ -145,21 +151,21 @@ int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *
     *out_count = 0;
     if (params->k == 0) return NIDX_OK;
     return idx->search_one(query, *params, out_segment, out_paragraph, out_vector, out_score, out_count);
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out) {
+int32_t nidx_gpu_vector_coalescer_stats(nidx_gpu_vector_index_t *index, uint64_t *batches_out, uint64_t *queries_out) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !batches_out || !queries_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     idx->coalescer_stats(*batches_out, *queries_out);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_spill_stats(nidx_gpu_vector_index_t *index, uint64_t *queries_out) {
+int32_t nidx_gpu_vector_spill_stats(nidx_gpu_vector_index_t *index, uint64_t *queries_out) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !queries_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     *queries_out = idx->spill_queries;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 }  // extern "C"

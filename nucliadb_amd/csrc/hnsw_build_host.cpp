@@ -194,14 +194,14 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
 
 using namespace nidx;
 
-extern "C" int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) {
+extern "C" int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     return idx->build_hnsw(segment, level_seed, false);
-}
+} NIDX_ABI_CATCH
 
-extern "C" int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) {
+extern "C" int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     return idx->build_hnsw(segment, level_seed, true);
-}
+} NIDX_ABI_CATCH

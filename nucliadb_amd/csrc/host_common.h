@@ -15,6 +15,11 @@ namespace nidx {
 void set_error(const char *fmt, ...);
 int32_t fail(int32_t code, const char *fmt, ...);
 int32_t hip_fail(hipError_t e, const char *what);
+int32_t abi_exception() noexcept;
+
+// Every extern "C" entry point is a function-try-block closed by this handler: no C++ exception crosses the ABI.
+#define NIDX_ABI_CATCH \
+    catch (...) { return ::nidx::abi_exception(); }
 
 #define NIDX_HIP(expr)                                         \
     do {                                                       \

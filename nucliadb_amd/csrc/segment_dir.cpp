@@ -164,7 +164,7 @@ using namespace nidx;
 
 extern "C" {
 
-int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out) {
+int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out) try {
     if (!path || !dir_out || dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *dir_out = nullptr;
     std::unique_ptr<SegmentDir> d(new SegmentDir());
@@ -203,25 +203,25 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
         uint64_t v, n;
         Paragraph &pg = d->paragraphs[a];
         auto bad = [&]() { return fail(NIDX_ERR_IO, "paragraphs.bin: truncated record %u", a); };
-        if (!read_varint(data, dlen, at, n) || at + n > dlen) return bad();
+        if (!read_varint(data, dlen, at, n) || n > dlen - at || n > 0xffffffffull) return bad();
         pg.key = {at, (uint32_t)n};
         at += n;
-        if (!read_varint(data, dlen, at, n)) return bad();
+        if (!read_varint(data, dlen, at, n) || n > dlen - at) return bad();  // every label takes at least its length byte
         pg.first_label = (uint32_t)d->labels.size();
         pg.n_labels = (uint32_t)n;
         for (uint64_t i = 0; i < n; i++) {
-            if (!read_varint(data, dlen, at, v) || at + v > dlen) return bad();
+            if (!read_varint(data, dlen, at, v) || v > dlen - at || v > 0xffffffffull) return bad();
             d->labels.push_back({at, (uint32_t)v});
             at += v;
         }
-        if (!read_varint(data, dlen, at, n) || at + n > dlen) return bad();
+        if (!read_varint(data, dlen, at, n) || n > dlen - at || n > 0xffffffffull) return bad();
         pg.metadata = {at, (uint32_t)n};
         at += n;
-        if (!read_varint(data, dlen, at, v)) return bad();
-        pg.first_vector = (uint32_t)v;
-        if (!read_varint(data, dlen, at, v)) return bad();
-        pg.num_vectors = (uint32_t)v;
-        if ((uint64_t)pg.first_vector + pg.num_vectors > d->n_vectors) return fail(NIDX_ERR_IO, "paragraph %u owns vectors beyond vectors.bin", a);
+        uint64_t fv, nv;
+        if (!read_varint(data, dlen, at, fv) || !read_varint(data, dlen, at, nv)) return bad();
+        pg.first_vector = (uint32_t)fv;
+        pg.num_vectors = (uint32_t)nv;
+        if (fv > d->n_vectors || nv > d->n_vectors - fv) return fail(NIDX_ERR_IO, "paragraph %u owns vectors beyond vectors.bin", a);
         d->key_ids[a] = key_id(data + pg.key.off, pg.key.len);
         // ParagraphInvertedIndexes::build (inverted_index/paragraph.rs:72-85)
         if (field_key(data + pg.key.off, pg.key.len, fk)) lists["F" + fk].push_back(a);
@@ -243,11 +243,11 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
     }
     *dir_out = reinterpret_cast<nidx_gpu_segment_dir_t *>(d.release());
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir) { delete reinterpret_cast<SegmentDir *>(dir); }
 
-int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *out) {
+int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
     if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     memset(out, 0, sizeof(*out));
@@ -264,19 +264,19 @@ int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu
     out->quantized = d->quant.len ? d->quant.p : nullptr;
     out->quantized_len = d->quant.len;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_segment_dir_filter_index(const nidx_gpu_segment_dir_t *dir, nidx_gpu_filter_index_t *out) {
+int32_t nidx_gpu_segment_dir_filter_index(const nidx_gpu_segment_dir_t *dir, nidx_gpu_filter_index_t *out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
     if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     out->n_lists = (uint32_t)d->list_keys.size();
     out->list_offsets = d->list_offsets.data();
     out->paragraph_ids = d->list_ids.data();
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_segment_dir_lists(const nidx_gpu_segment_dir_t *dir, int32_t kind, const uint8_t *key, uint32_t key_len, int32_t prefix,
-                                   uint32_t *first_out, uint32_t *count_out) {
+                                   uint32_t *first_out, uint32_t *count_out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
     if (!d || !first_out || !count_out || (key_len && !key)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *first_out = *count_out = 0;
@@ -303,9 +303,9 @@ int32_t nidx_gpu_segment_dir_lists(const nidx_gpu_segment_dir_t *dir, int32_t ki
     *first_out = (uint32_t)(lo - d->list_keys.begin());
     *count_out = (uint32_t)(hi - lo);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_segment_dir_paragraph(const nidx_gpu_segment_dir_t *dir, uint32_t addr, nidx_gpu_paragraph_t *out) {
+int32_t nidx_gpu_segment_dir_paragraph(const nidx_gpu_segment_dir_t *dir, uint32_t addr, nidx_gpu_paragraph_t *out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
     if (!d || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (addr >= d->n_paragraphs) return fail(NIDX_ERR_INVALID_ARGUMENT, "paragraph %u out of range (%u stored)", addr, d->n_paragraphs);
@@ -318,10 +318,10 @@ int32_t nidx_gpu_segment_dir_paragraph(const nidx_gpu_segment_dir_t *dir, uint32
     out->first_vector = pg.first_vector;
     out->num_vectors = pg.num_vectors;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_segment_dir_paragraph_label(const nidx_gpu_segment_dir_t *dir, uint32_t addr, uint32_t i, const char **label_out,
-                                             uint32_t *len_out) {
+                                             uint32_t *len_out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
     if (!d || !label_out || !len_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (addr >= d->n_paragraphs || i >= d->paragraphs[addr].n_labels) return fail(NIDX_ERR_INVALID_ARGUMENT, "label %u of paragraph %u out of range", i, addr);
@@ -329,7 +329,7 @@ int32_t nidx_gpu_segment_dir_paragraph_label(const nidx_gpu_segment_dir_t *dir, 
     *label_out = reinterpret_cast<const char *>(d->para_data.p + l.off);
     *len_out = l.len;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 static int write_file(const std::string &path, const void *p, size_t n) {
     FILE *f = fopen(path.c_str(), "wb");
@@ -338,7 +338,7 @@ static int write_file(const std::string &path, const void *p, size_t n) {
     return (fclose(f) == 0 && ok) ? 0 : -1;
 }
 
-int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *c) {
+int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *c) try {
     if (!path || !c || c->dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (c->n_vectors && !c->vectors) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL vectors");
     if (c->n_paragraphs && (!c->key_offsets || !c->keys)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL keys");
@@ -353,15 +353,23 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
         else if (first[p] + num[p] != v) return fail(NIDX_ERR_INVALID_ARGUMENT, "the vectors of paragraph %u are not contiguous", p);
         num[p]++;
     }
-    {   // vectors.bin
+    {   // vectors.bin, streamed a few MiB at a time (a 10 M x 768 segment is 30 GB: no second copy in host memory)
         const size_t stride = (size_t)D * 4 + 4;
-        std::vector<uint8_t> rows((size_t)c->n_vectors * stride);
-        for (uint32_t v = 0; v < c->n_vectors; v++) {
-            const uint32_t p = c->paragraph_of_vector ? c->paragraph_of_vector[v] : v;
-            memcpy(rows.data() + (size_t)v * stride, c->vectors + (size_t)v * D, (size_t)D * 4);
-            memcpy(rows.data() + (size_t)v * stride + (size_t)D * 4, &p, 4);
+        const uint32_t chunk = (uint32_t)std::max<size_t>(1, (4u << 20) / stride);
+        std::vector<uint8_t> rows((size_t)std::min(chunk, std::max(c->n_vectors, 1u)) * stride);
+        FILE *f = fopen((base + "vectors.bin").c_str(), "wb");
+        bool ok = f != nullptr;
+        for (uint32_t v0 = 0; ok && v0 < c->n_vectors; v0 += chunk) {
+            const uint32_t nv = std::min(chunk, c->n_vectors - v0);
+            for (uint32_t i = 0; i < nv; i++) {
+                const uint32_t v = v0 + i, p = c->paragraph_of_vector ? c->paragraph_of_vector[v] : v;
+                memcpy(rows.data() + (size_t)i * stride, c->vectors + (size_t)v * D, (size_t)D * 4);
+                memcpy(rows.data() + (size_t)i * stride + (size_t)D * 4, &p, 4);
+            }
+            ok = fwrite(rows.data(), stride, nv, f) == nv;
         }
-        if (write_file(base + "vectors.bin", rows.data(), rows.size())) return fail(NIDX_ERR_IO, "cannot write %svectors.bin", base.c_str());
+        if (f && fclose(f) != 0) ok = false;
+        if (!ok) return fail(NIDX_ERR_IO, "cannot write %svectors.bin", base.c_str());
     }
     {   // paragraphs.bin + paragraphs.pos
         std::vector<uint8_t> data;
@@ -396,6 +404,6 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
         if (write_file(base + "hnsw.edges", c->hnsw_edges, (size_t)c->n_hnsw_edges * 4)) return fail(NIDX_ERR_IO, "cannot write %shnsw.edges", base.c_str());
     }
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 }  // extern "C"

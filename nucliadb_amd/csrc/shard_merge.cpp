@@ -69,7 +69,7 @@ extern "C" {
 
 int32_t nidx_gpu_merge_vector(const float *const *scores, const uint64_t *const *ids, const uint32_t *lens,
                               uint32_t n_lists, uint32_t limit, float *out_score, uint64_t *out_id, uint32_t *out_list,
-                              uint32_t *n_out) {
+                              uint32_t *n_out) try {
     if (!n_out || (n_lists && (!scores || !lens))) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::vector<Head> order;
     // kmerge_by(|a, b| a.score >= b.score)
@@ -82,12 +82,12 @@ int32_t nidx_gpu_merge_vector(const float *const *scores, const uint64_t *const 
     }
     *n_out = n;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *docaddrs, const uint32_t *lens,
                             const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists,
                             uint32_t limit, float *out_score, uint64_t *out_docaddr, uint32_t *out_list,
-                            uint32_t *n_out) {
+                            uint32_t *n_out) try {
     if (!n_out || (n_lists && (!scores || !docaddrs || !lens || !shard_ids || !shard_id_lens)))
         return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::vector<Head> order;
@@ -107,11 +107,11 @@ int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *d
     }
     *n_out = n;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 // ---- rank fusion (nucliadb rank_fusion.py:60-181), batched on the host -----------------------------------------------------------
 int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window,
-                                 uint64_t *out_ids, double *out_scores, uint32_t *out_counts) {
+                                 uint64_t *out_ids, double *out_scores, uint32_t *out_counts) try {
     if ((n_lists && !lists) || !out_ids || !out_scores || !out_counts) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     for (uint32_t l = 0; l < n_lists; l++)
         if (!lists[l].counts || (lists[l].stride && !lists[l].ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: NULL arrays", l);
@@ -157,6 +157,6 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
         out_counts[q] = n;
     }
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 }  // extern "C"

@@ -22,24 +22,38 @@
 namespace nidx {
 
 // ---- errors -----------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
+// Fixed storage: recording an error never allocates, so it also works from the out-of-memory handler below.
+static thread_local char g_last_error[512];
+
+static void record_error(const char *fmt, va_list ap) { vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap); }
 
 void set_error(const char *fmt, ...) {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    record_error(fmt, ap);
     va_end(ap);
-    g_last_error = buf;
 }
 int32_t fail(int32_t code, const char *fmt, ...) {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    record_error(fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
+}
+// The catch handler of every entry point (NIDX_ABI_CATCH): the callers are Rust / cgo / ctypes frames that cannot unwind, so
+// what the host containers throw (allocation failure, a length derived from a corrupt input) leaves as an error code.
+int32_t abi_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(NIDX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    } catch (const std::length_error &e) {
+        return fail(NIDX_ERR_OUT_OF_MEMORY, "host allocation failed: %s", e.what());
+    } catch (const std::exception &e) {
+        return fail(NIDX_ERR_INTERNAL, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(NIDX_ERR_INTERNAL, "unexpected exception");
+    }
 }
 int32_t hip_fail(hipError_t e, const char *what) {
     return fail(NIDX_ERR_DEVICE, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
@@ -904,18 +918,19 @@ using namespace nidx;
 
 extern "C" {
 
-int32_t nidx_gpu_last_error(char *buf, size_t len) {
+int32_t nidx_gpu_last_error(char *buf, size_t len) try {
+    const size_t have = strlen(g_last_error);
     if (buf && len) {
-        size_t n = g_last_error.size() < len - 1 ? g_last_error.size() : len - 1;
-        memcpy(buf, g_last_error.data(), n);
+        size_t n = have < len - 1 ? have : len - 1;
+        memcpy(buf, g_last_error, n);
         buf[n] = 0;
     }
-    return (int32_t)g_last_error.size();
-}
+    return (int32_t)have;
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_abi_version(void) { return 3; }
 
-int32_t nidx_gpu_device_count(int32_t *count_out) {
+int32_t nidx_gpu_device_count(int32_t *count_out) try {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -925,15 +940,15 @@ int32_t nidx_gpu_device_count(int32_t *count_out) {
     }
     *count_out = n;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_set_device(int32_t device) {
+int32_t nidx_gpu_set_device(int32_t device) try {
     NIDX_HIP(hipSetDevice(device));
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_gpu_vector_segment_t *segments,
-                             uint32_t n_segments, nidx_gpu_vector_index_t **index_out) {
+                             uint32_t n_segments, nidx_gpu_vector_index_t **index_out) try {
     if (!config || !index_out || (n_segments && !segments)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *index_out = nullptr;
     if (config->dimension == 0) return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: Vector dimension cannot be 0");
@@ -959,20 +974,16 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     }
     *index_out = reinterpret_cast<nidx_gpu_vector_index_t *>(idx.release());
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 void nidx_gpu_vector_close(nidx_gpu_vector_index_t *index) {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    if (idx->stream) {
-        (void)hipStreamSynchronize(idx->stream);
-        (void)hipStreamDestroy(idx->stream);
-    }
     delete idx;
 }
 
-int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value) {
+int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !name) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -981,44 +992,44 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
     else if (n == "min_waves") { idx->min_waves = value >= 4 ? 4 : 2; idx->shape_pinned = true; }
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
-    else if (n == "coalesce_window_us") { idx->mu.unlock(); idx->coalescer_config(value, -1); idx->mu.lock(); }
-    else if (n == "coalesce_max_batch") { idx->mu.unlock(); idx->coalescer_config(-1, value); idx->mu.lock(); }
+    else if (n == "coalesce_window_us") idx->coalescer_config(value, -1);
+    else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value);
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown tunable %s", name);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64_t *bytes_out) {
+int32_t nidx_gpu_vector_space_usage(const nidx_gpu_vector_index_t *index, uint64_t *bytes_out) try {
     const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
     if (!idx || !bytes_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     uint64_t b = 0;
     for (const VectorSegment &s : idx->segs) b += s.bytes();
     *bytes_out = b;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint32_t *n_out) {
+int32_t nidx_gpu_vector_num_segments(const nidx_gpu_vector_index_t *index, uint32_t *n_out) try {
     const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
     if (!idx || !n_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *n_out = (uint32_t)idx->segs.size();
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out) {
+int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, uint32_t segment, uint32_t *n_out) try {
     const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
     if (!idx || !n_out || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
     *n_out = idx->segs[segment].n_paragraphs;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_quantize(nidx_gpu_vector_index_t *index, uint32_t segment) {
+int32_t nidx_gpu_vector_quantize(nidx_gpu_vector_index_t *index, uint32_t segment) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
     return idx->quantize(segment);
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_serialize_quantized(nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *out, uint64_t out_cap,
-                                            uint64_t *len_out) {
+                                            uint64_t *len_out) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size() || !len_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad segment");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -1030,23 +1041,23 @@ int32_t nidx_gpu_vector_serialize_quantized(nidx_gpu_vector_index_t *index, uint
     NIDX_HIP(hipSetDevice(idx->device));
     NIDX_HIP(hipMemcpy(out, seg.quant.p, seg.quant.bytes, hipMemcpyDeviceToHost));
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_search(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
                                const nidx_gpu_vector_search_params_t *params, const uint64_t *const *segment_filters,
                                uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
-                               uint32_t *out_count, int32_t *out_method) {
+                               uint32_t *out_count, int32_t *out_method) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     return idx->search_host(queries, n_queries, *params, segment_filters, nullptr, out_segment, out_paragraph, out_vector,
                             out_score, out_count, out_method, nullptr);
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
                                    uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
                                    const uint64_t *const *segment_filters, uint32_t *out_segment,
                                    uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count,
-                                   int32_t *out_method) {
+                                   int32_t *out_method) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL index");
     if (query_dimension != idx->cfg.dimension)
@@ -1054,9 +1065,9 @@ int32_t nidx_gpu_vector_search_dim(nidx_gpu_vector_index_t *index, const float *
                     query_dimension);
     return nidx_gpu_vector_search(index, queries, n_queries, params, segment_filters, out_segment, out_paragraph,
                                   out_vector, out_score, out_count, out_method);
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_t segment, const nidx_gpu_filter_index_t *lists) {
+int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_t segment, const nidx_gpu_filter_index_t *lists) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !lists || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     if (lists->n_lists && !lists->list_offsets) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL list_offsets");
@@ -1074,11 +1085,11 @@ int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_
     seg.f_n_lists = lists->n_lists;
     seg.f_n_ids = n_ids;
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_search_maxsim(nidx_gpu_vector_index_t *index, const float *queries, const uint64_t *qoff, uint32_t nq,
                                       const nidx_gpu_vector_search_params_t *params, const uint64_t *const *segment_filters,
-                                      uint32_t *out_segment, uint32_t *out_paragraph, float *out_score, uint32_t *out_count) {
+                                      uint32_t *out_segment, uint32_t *out_paragraph, float *out_score, uint32_t *out_count) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || !out_count || !qoff || (nq && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     const uint32_t k = params->k, d = idx->cfg.dimension;
@@ -1172,13 +1183,13 @@ int32_t nidx_gpu_vector_search_maxsim(nidx_gpu_vector_index_t *index, const floa
         }
     }
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries,
                                         uint32_t query_dimension, const nidx_gpu_vector_search_params_t *params,
                                         const nidx_gpu_filter_program_t *segment_programs, uint32_t *out_segment,
                                         uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count,
-                                        int32_t *out_method, uint64_t *out_matching) {
+                                        int32_t *out_method, uint64_t *out_matching) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (query_dimension != idx->cfg.dimension)
@@ -1186,12 +1197,12 @@ int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const fl
                     query_dimension);
     return idx->search_host(queries, n_queries, *params, nullptr, segment_programs, out_segment, out_paragraph, out_vector,
                             out_score, out_count, out_method, out_matching);
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,
                                               uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
                                               const uint64_t *d_filter, uint32_t *d_out_vector, float *d_out_score,
-                                              uint32_t *d_out_count, uint32_t *d_stats, void *stream) {
+                                              uint32_t *d_out_count, uint32_t *d_stats, void *stream) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     if (params->k == 0 || params->k > 256) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..256 (got %u)", params->k);
@@ -1209,14 +1220,14 @@ int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, ui
     return idx->segment_search_device(segment, d_queries, n_queries, params->k, params->min_score,
                                       params->with_duplicates != 0, method, d_filter, d_out_vector, d_out_score,
                                       d_out_count, d_stats, idx->default_vis_log2, (hipStream_t)stream);
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq) {
+int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq) try {
     return use_hnsw(total_nodes, matching_nodes, top_k, has_rabitq != 0) ? 1 : 0;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_similarity(const float *x, const float *y, uint32_t n_pairs, uint32_t dimension, int32_t similarity,
-                            int32_t order, float *out) {
+                            int32_t order, float *out) try {
     if (!x || !y || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     if (order != NIDX_ORDER_WAVE64) return fail(NIDX_ERR_UNSUPPORTED, "only NIDX_ORDER_WAVE64 is implemented here");
     if (n_pairs == 0) return NIDX_OK;
@@ -1234,17 +1245,17 @@ int32_t nidx_gpu_similarity(const float *x, const float *y, uint32_t n_pairs, ui
     NIDX_HIP(launch_pair_similarity(dx.as<float>(), dy.as<float>(), n_pairs, dp, similarity, dout.as<float>(), nullptr));
     NIDX_HIP(hipMemcpy(out, dout.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
-int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, float *out) {
+int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, float *out) try {
     if (!in || !out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     for (uint32_t i = 0; i < n; i++) normalize_row(in + (size_t)i * dimension, out + (size_t)i * dimension, dimension);
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uint32_t segment, uint8_t *graph_out,
                                        uint64_t graph_cap, uint64_t *graph_len_out, float *edges_out, uint64_t edges_cap,
-                                       uint64_t *n_edges_out) {
+                                       uint64_t *n_edges_out) try {
     const VectorIndex *idx = reinterpret_cast<const VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     const VectorSegment &seg = idx->segs[segment];
@@ -1283,6 +1294,6 @@ int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uin
         memcpy(edges_out, edges.data(), edges.size() * 4);
     }
     return NIDX_OK;
-}
+} NIDX_ABI_CATCH
 
 }  // extern "C"

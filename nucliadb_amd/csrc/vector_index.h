@@ -54,11 +54,21 @@ struct VectorSegment {
 };
 
 struct Coalescer;
+std::shared_ptr<Coalescer> make_coalescer();  // coalescer.cpp
 
 struct VectorIndex {
     nidx_gpu_vector_config_t cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    VectorIndex() = default;
+    VectorIndex(const VectorIndex &) = delete;
+    // also the clean-up of an open that failed half way
+    ~VectorIndex() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+    }
     std::mutex mu;
     std::vector<VectorSegment> segs;
     // tunables
@@ -100,7 +110,7 @@ struct VectorIndex {
     int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed, bool extend = false);
     // request coalescing for single-query callers (coalescer.cpp)
-    std::shared_ptr<Coalescer> coalescer;
+    std::shared_ptr<Coalescer> coalescer = make_coalescer();
     int32_t search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
     void coalescer_stats(uint64_t &batches, uint64_t &queries);

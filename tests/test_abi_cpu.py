@@ -46,6 +46,35 @@ def test_no_cpu_fallback_when_device_missing(L):
     assert rc == _lib.NIDX_ERR_DEVICE
 
 
+_OOM_CHILD = r"""
+import ctypes as C, mmap, resource, sys
+import numpy as np
+from nucliadb_amd import _lib
+L = _lib.lib()
+n = 1 << 28
+scores = mmap.mmap(-1, 4 * n)                       # untouched anonymous zero pages: address space, no RAM
+base = C.addressof(C.c_char.from_buffer(scores))
+scp, lens, cnt = (C.c_void_p * 1)(base), np.array([n], np.uint32), C.c_uint32()
+vm = int(open('/proc/self/statm').read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (vm + (256 << 20), resource.RLIM_INFINITY))
+rc = L.nidx_gpu_merge_vector(scp, None, lens.ctypes.data, 1, n, None, None, None, C.byref(cnt))
+resource.setrlimit(resource.RLIMIT_AS, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+print(rc, _lib.last_error())
+"""
+
+
+def test_host_allocation_failure_is_an_error_code_not_an_unwind(L):
+    # the 2 GiB merge order cannot be allocated under the address-space limit: std::bad_alloc is caught at the boundary
+    # (a Rust / cgo caller cannot unwind a C++ exception; before the function-try-blocks this aborted the process)
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", _OOM_CHILD], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[0] == str(_lib.NIDX_ERR_OUT_OF_MEMORY), r.stdout
+    assert "host allocation failed" in r.stdout
+
+
 def test_config_errors(L):
     h = C.c_void_p()
     cfg = _lib.VectorConfigC(0, 0, 0, 0)

@@ -151,3 +151,49 @@ def test_errors(tmp_path):
     bad = VectorSegment(["a", "b"], np.ones((3, 8), np.float32), [[], []], [b"", b""], para_of_vec=np.array([0, 1, 0], np.uint32))
     with pytest.raises(_lib.NidxGpuError):
         bad.save(str(tmp_path))
+
+
+def test_corrupt_records_are_io_errors_never_reads_past_the_file(tmp_path):
+    seg = VectorSegment(["k" * 20, "j" * 20], np.ones((2, 8), np.float32), [["/l/a", "/l/b"], []], [b"meta", b""])
+    seg.save(str(tmp_path))
+    good = read(tmp_path, "paragraphs.bin")
+    SegmentDir(str(tmp_path), 8).close()
+    # a length of 2^64 - 1 in front of the key / the label count / a label / the metadata (would wrap `at + n`)
+    huge = b"\xfd" + b"\xff" * 8
+    for cut in (0, 21, 22, 27, 32):
+        with open(tmp_path / "paragraphs.bin", "wb") as f:
+            f.write(good[:cut] + huge + good[cut + 1:])
+        with pytest.raises(_lib.NidxGpuError) as e:
+            SegmentDir(str(tmp_path), 8)
+        assert e.value.code == _lib.NIDX_ERR_IO, cut
+    # every single-byte corruption either still parses or is reported; nothing crashes
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        b = bytearray(good)
+        b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        with open(tmp_path / "paragraphs.bin", "wb") as f:
+            f.write(bytes(b))
+        try:
+            SegmentDir(str(tmp_path), 8).close()
+        except _lib.NidxGpuError as e:
+            assert e.code == _lib.NIDX_ERR_IO
+    # a record start beyond the file
+    with open(tmp_path / "paragraphs.bin", "wb") as f:
+        f.write(good)
+    with open(tmp_path / "paragraphs.pos", "wb") as f:
+        f.write(np.array([0, 1 << 31], "<u4").tobytes())
+    with pytest.raises(_lib.NidxGpuError):
+        SegmentDir(str(tmp_path), 8)
+
+
+def test_writer_streams_vectors_bin_in_chunks(orc, tmp_path):
+    # more rows than one 4 MiB write chunk holds (stride 36 B -> 116 508 rows per chunk)
+    rng = np.random.default_rng(12)
+    n = 250_000
+    vectors = rng.standard_normal((n, 8)).astype(np.float32)
+    pov = np.repeat(np.arange(n // 2, dtype=np.uint32), 2)
+    keys = ["k%d" % i for i in range(n // 2)]
+    VectorSegment(keys, vectors, [[] for _ in keys], [b"" for _ in keys], para_of_vec=pov).save(str(tmp_path))
+    got = np.frombuffer(read(tmp_path, "vectors.bin"), np.uint8).reshape(n, 36)
+    assert np.array_equal(got[:, :32].copy().view("<f4"), vectors)
+    assert np.array_equal(got[:, 32:].copy().view("<u4")[:, 0], pov)
