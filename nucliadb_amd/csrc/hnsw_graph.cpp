@@ -39,7 +39,7 @@ int parse_disk_v2(const uint8_t *buf, uint64_t len, uint32_t n_nodes, HostGraph 
 
     // pass 1: find each node's top layer to lay out the upper records
     std::vector<uint32_t> node_end(n_nodes);
-    uint32_t n_upper = 0;
+    uint64_t n_upper = 0;
     for (uint32_t i = 0; i < n_nodes; i++) {
         uint64_t pos = indexing_end - ((uint64_t)i + 1) * 4;
         uint32_t end = rd32(buf + pos);
@@ -61,8 +61,9 @@ int parse_disk_v2(const uint8_t *buf, uint64_t len, uint32_t n_nodes, HostGraph 
         if (i == g.ep_node && top < g.ep_layer) top = g.ep_layer;
         g.top_layer[i] = (uint8_t)top;
         if (top > 0) {
-            g.upper_base[i] = n_upper;
+            g.upper_base[i] = (uint32_t)n_upper;
             n_upper += top;
+            if (n_upper >= 0xffffffffull) { err = "hnsw.graph holds more upper-layer records than a u32 indexes"; return NIDX_ERR_INVALID_GRAPH; }
         }
     }
     g.upper.assign((size_t)n_upper * NIDX_UP_STRIDE, 0u);
