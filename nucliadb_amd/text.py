@@ -353,9 +353,18 @@ class TextSearcher:
     def close(self):
         self._index.close()
 
+    @staticmethod
+    def adapt_text(text: str) -> str:
+        """TextReaderService::adapt_text (reader.rs:357-365): a body tantivy's QueryParser rejects is searched as one phrase,
+        its quotes dropped.  Of the grammar's syntax errors the unbalanced quote is the one mirrored here (the reference's
+        test_quote_fixing cases); the operators (+ - ( ) : ^ ~ *) are refused by _clauses instead of guessed at."""
+        if text and text.count('"') % 2:
+            return '"' + text.replace('"', "") + '"'
+        return text
+
     def _clauses(self, request: DocumentSearchRequest) -> List[Clause]:
-        body = request.body
-        if any(ch in body for ch in '+():^~*') or body.count('"') % 2:
+        body = self.adapt_text(request.body)
+        if any(ch in body for ch in '+():^~*'):
             raise NotImplementedError("tantivy's query grammar beyond words and \"phrases\" is not mirrored")
         # QueryParser with set_conjunction_by_default (reader.rs:372-377): every word is a Must TermQuery with frequencies,
         # every "quoted run" a Must PhraseQuery (one word: a TermQuery)
@@ -472,7 +481,7 @@ class TextSearcher:
                 continue
             results.append(DocumentResult(d.uuid, d.field, ResultScore(s, int(docaddr[0, i])), labels))
         fc = self._index.produce_facets(facets, pairs, r["facet_counts"][0]) if pairs else {}
-        return DocumentSearchResponse(total_, results, total_ > k, request.body, fc)
+        return DocumentSearchResponse(total_, results, total_ > k, self.adapt_text(request.body), fc)
 
 
 # =============================================================================== nidx_paragraph

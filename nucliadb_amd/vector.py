@@ -467,29 +467,141 @@ def segment_merge(operants: Sequence[Tuple[VectorSegment, Optional[np.ndarray]]]
     for seg, _ in ops:
         if seg.tags != tags:
             raise NidxGpuError(_lib.NIDX_ERR_INVALID_ARGUMENT, "Not all of the merged segments have the same tags")
-    keys, labels, metadata, rows = [], [], [], []
+    keys, labels, metadata, rows, povs = [], [], [], [], []
+    multi = any(seg.para_of_vec is not None for seg, _ in ops)
+
+    def vector_mask(seg, alive):
+        # a paragraph's vectors live and die together (data_store/v2.rs:89-103 copies alive paragraphs with their vectors)
+        if alive is None:
+            return None
+        alive = np.asarray(alive, dtype=bool)
+        return alive if seg.para_of_vec is None else alive[seg.para_of_vec]
+
     for seg, alive in ops:
         idx = range(seg.records) if alive is None else np.nonzero(alive)[0].tolist()
+        if multi:
+            pov = seg.para_of_vec if seg.para_of_vec is not None else np.arange(seg.records, dtype=np.uint32)
+            renumber = np.full(seg.records, -1, np.int64)
+            renumber[list(idx)] = len(keys) + np.arange(len(idx))
+            vm = vector_mask(seg, alive)
+            povs.append(renumber[pov if vm is None else pov[vm]].astype(np.uint32))
         for i in idx:
             keys.append(seg.keys[i])
             labels.append(list(seg.labels[i]))
             metadata.append(seg.metadata[i])
-        rows.append(seg.vectors if alive is None else seg.vectors[np.asarray(alive, dtype=bool)])
+        vm = vector_mask(seg, alive)
+        rows.append(seg.vectors if vm is None else seg.vectors[vm])
     vectors = np.vstack(rows) if rows else np.zeros((0, config.dimension), np.float32)
+    para_of_vec = np.concatenate(povs) if multi else None
     # quantized vectors are copied when every operand has them (data_store/v2.rs:104-113); otherwise the caller
     # re-encodes the merged segment with VectorSearcher.quantize()
     quantized = None
     if config.quantizable_vectors() and all(seg.quantized is not None for seg, _ in ops):
-        quantized = np.vstack([seg.quantized if alive is None else seg.quantized[np.asarray(alive, dtype=bool)] for seg, alive in ops])
+        quantized = np.vstack([seg.quantized if alive is None else seg.quantized[vector_mask(seg, alive)] for seg, alive in ops])
     first, first_alive = ops[0]
     reuse = first.graph is not None and not first.graph_nodes and (first_alive is None or bool(np.all(first_alive)))
     if reuse and first.records < len(keys):
         return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges,
-                             graph_nodes=first.records, quantized=quantized)
+                             graph_nodes=first.vectors.shape[0], quantized=quantized, para_of_vec=para_of_vec)
     if reuse:
         return VectorSegment(keys, vectors, labels, metadata, tags, graph=first.graph, graph_edges=first.graph_edges,
-                             quantized=quantized)
-    return VectorSegment(keys, vectors, labels, metadata, tags, quantized=quantized)
+                             quantized=quantized, para_of_vec=para_of_vec)
+    return VectorSegment(keys, vectors, labels, metadata, tags, quantized=quantized, para_of_vec=para_of_vec)
+
+
+def _segments_with_deletions(segments: Sequence[Tuple[VectorSegment, int]],
+                             deletions: Sequence[Tuple[str, int]]) -> List[Tuple[VectorSegment, np.ndarray]]:
+    """segment_deletions + apply_deletions (lib.rs:169-200, segment.rs:428-445): segments and deletions sorted by seq, walked
+    newest -> oldest; a segment loses the paragraphs of every deletion with seq > its own seq.  Returns [(segment, alive
+    mask)] newest first — the order open_segments / VectorIndexer::merge push them in."""
+    segs = sorted(segments, key=lambda t: t[1])
+    dels = sorted(deletions, key=lambda t: t[1])
+    ordered: List[Tuple[VectorSegment, np.ndarray]] = []
+    so_far: List[str] = []
+    di = len(dels) - 1
+    for seg, seq in reversed(segs):
+        while di >= 0 and dels[di][1] > seq:
+            so_far.append(dels[di][0])
+            di -= 1
+        alive = np.ones(seg.records, dtype=bool)
+        for key in so_far:
+            alive[seg.ids_for_deletion_key(key)] = False
+        ordered.append((seg, alive))
+    return ordered
+
+
+# ---- the indexer side (nidx_vector::VectorIndexer, lib.rs:65-118; indexer.rs:28-145) ------------------------------------------
+SEGMENT_TAGS = ("/q/h",)  # indexer.rs:26
+
+
+@dataclass
+class VectorSentence:
+    """noderesources.VectorSentence: the vector (a Multi index holds the paragraph's vectors concatenated) + metadata bytes."""
+
+    vector: Sequence[float]
+    metadata: Optional[bytes] = None
+
+
+@dataclass
+class IndexParagraph:
+    """noderesources.IndexParagraph, the fields the vector indexer reads."""
+
+    start: int = 0
+    end: int = 0
+    sentences: dict = field(default_factory=dict)             # sentence key -> VectorSentence (the default vectorset)
+    vectorsets_sentences: dict = field(default_factory=dict)  # vectorset -> {sentence key -> VectorSentence}
+    labels: List[str] = field(default_factory=list)
+
+
+@dataclass
+class Resource:
+    """noderesources.Resource, the fields the vector indexer reads."""
+
+    uuid: str
+    labels: List[str] = field(default_factory=list)
+    paragraphs: dict = field(default_factory=dict)            # field id -> {paragraph key -> IndexParagraph}
+    vector_prefixes_to_delete: dict = field(default_factory=dict)
+    vectors_to_delete_in_all_vectorsets: List[str] = field(default_factory=list)
+
+
+class VectorIndexer:
+    """nidx_vector::VectorIndexer for paragraph indexes (lib.rs:65-118).  Segments are VectorSegment objects (save() writes
+    the directory the reference's index_resource / merge leave in `output_dir`)."""
+
+    def index_resource(self, config: VectorConfig, resource: Resource, index_name: str = "default",
+                       use_default_vectorset: bool = True) -> Optional[VectorSegment]:
+        """indexer.rs:94-145 over ResourceWrapper::fields (:59-86): one Elem per sentence of the vectorset (falling back to
+        the default sentences when asked to), normalised when the index says so; None when the resource has no vectors."""
+        elems = []
+        for _field_id, paragraphs in resource.paragraphs.items():
+            for paragraph in paragraphs.values():
+                sentences = paragraph.vectorsets_sentences.get(index_name)
+                if sentences is None:
+                    if not use_default_vectorset:
+                        continue
+                    sentences = paragraph.sentences
+                for key, sentence in sentences.items():
+                    v = np.ascontiguousarray(sentence.vector, dtype=np.float32)
+                    if config.normalize_vectors and v.size:
+                        out = np.empty_like(v)
+                        _lib.check(_lib.lib().nidx_gpu_normalize(v.ctypes.data, 1, v.size, out.ctypes.data))
+                        v = out
+                    elems.append(Elem(key, v, list(paragraph.labels), sentence.metadata or b""))
+        if not elems:
+            return None
+        tags = {t for t in resource.labels if t in SEGMENT_TAGS}
+        return segment_create(elems, config, tags)
+
+    def deletions_for_resource(self, resource: Resource, index_name: str) -> List[str]:
+        """lib.rs:90-96"""
+        if index_name in resource.vector_prefixes_to_delete:
+            return list(resource.vector_prefixes_to_delete[index_name])
+        return list(resource.vectors_to_delete_in_all_vectorsets)
+
+    def merge(self, config: VectorConfig, segments: Sequence[Tuple[VectorSegment, int]],
+              deletions: Sequence[Tuple[str, int]] = ()) -> VectorSegment:
+        """lib.rs:98-118: every segment opened with the deletions newer than itself applied, then segment::merge."""
+        return segment_merge(_segments_with_deletions(segments, deletions), config)
 
 
 def _bitset(mask: np.ndarray) -> np.ndarray:
@@ -530,19 +642,7 @@ class VectorSearcher:
         seq, walked newest -> oldest accumulating the deletions with seq > segment seq."""
         self = cls()
         self.config = config
-        segs = sorted(segments, key=lambda t: t[1])
-        dels = sorted(deletions, key=lambda t: t[1])
-        ordered: List[Tuple[VectorSegment, np.ndarray]] = []
-        so_far: List[str] = []
-        di = len(dels) - 1
-        for seg, seq in reversed(segs):
-            while di >= 0 and dels[di][1] > seq:
-                so_far.append(dels[di][0])
-                di -= 1
-            alive = np.ones(seg.records, dtype=bool)
-            for key in so_far:
-                alive[seg.ids_for_deletion_key(key)] = False
-            ordered.append((seg, alive))
+        ordered = _segments_with_deletions(segments, deletions)
         # open_segments pushes in that (newest first) order and _search walks them in it
         c_segs = (_lib.VectorSegmentC * max(1, len(ordered)))()
         key_table: dict = {}  # Fssc equates hits by paragraph id string (searcher.rs:67-96): intern the keys

@@ -37,3 +37,13 @@ def test_stop_words_keep_the_last_token():
 def test_facet_paths():
     assert facet_ancestors("/l/labelset/label") == ["/l", "/l/labelset", "/l/labelset/label"]
     assert is_valid_facet("/l") and is_valid_facet("/e/PERSON") and not is_valid_facet("") and not is_valid_facet("l/x")
+
+
+def test_adapt_text_quote_fixing():
+    """nidx_text/tests/test_search.rs:291-310 (test_quote_fixing) on TextReaderService::adapt_text (reader.rs:357-365)."""
+    from nucliadb_amd.text import TextSearcher
+
+    for body in ('"enough test"', 'enough test"', '"enough test'):
+        assert TextSearcher.adapt_text(body) == '"enough test"'
+    assert TextSearcher.adapt_text("") == "" and TextSearcher.adapt_text("enough test") == "enough test"
+    assert TextSearcher.adapt_text('a "b c" d "e') == '"a b c d e"'

@@ -274,6 +274,19 @@ def test_quoted_phrases():
     assert total('"enough to"') == 0               # both words occur in r3, not next to each other
     assert total('"should enough" test') == 0 and total('"should enough"') == 1
     assert total("enough mischievous test") == 0   # a word nobody has
+    # test_quote_fixing (test_search.rs:291-310): an unbalanced quote is searched as the phrase of the whole body
+    for body in ('"enough test"', 'enough test"', '"enough test'):
+        r = s.search(DocumentSearchRequest(body=body, result_per_page=20))
+        assert r.query == '"enough test"' and r.total == 2
+    # test_search_with_min_score (:312-333) and test_int_order_pagination (:335-353)
+    r = s.search(DocumentSearchRequest(body="should", result_per_page=20, min_score=0.0))
+    assert len(r.results) == 1 and not r.next_page
+    r = s.search(DocumentSearchRequest(body="should", result_per_page=20, min_score=100.0))
+    assert len(r.results) == 0 and not r.next_page
+    from nucliadb_amd.text import OrderBy
+
+    r = s.search(DocumentSearchRequest(body="", result_per_page=1, order=OrderBy(0, True), min_score=-3.4e38))
+    assert len(r.results) == 1 and r.next_page
     s.close()
     p = ParagraphSearcher.open([TextSegment(docs(), vocab)])
 

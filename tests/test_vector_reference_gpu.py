@@ -280,3 +280,28 @@ def test_hidden_search():
     seen = searcher.search(request, PrefilterResult.All)
     assert [d.doc_id for d in seen.documents] == [f"{vid}/a/title/0-5"]
     searcher.close()
+
+
+def test_paragraph_merge_with_deletions():
+    """tests/test_paragraph_merge.rs:69-173: two single-resource segments (seq 2 and 4) merged under deletions that share
+    their seq; the merged segment holds all four vectors and every one of them is its own top hit."""
+    from test_vector_indexer_cpu import UUID1, UUID2, make_vector, two_segments
+    from nucliadb_amd.vector import VectorIndexer
+
+    config, s1, s2 = two_segments()
+    deletions = [(f"{UUID1}/a/title", 2), (f"{UUID1}/t/body", 2), (f"{UUID2}/a/title", 4), (f"{UUID2}/t/body", 4)]
+    merged = VectorIndexer().merge(config, [(s1, 2), (s2, 4)], deletions)
+    assert merged.records == 4
+    searcher = VectorSearcher.open(config, [(merged, 5)])
+    owner = {0: f"{UUID1}/a/title/0-10", 1: f"{UUID1}/t/body/0-10", 2: f"{UUID2}/a/title/0-10", 3: f"{UUID2}/t/body/0-10"}
+    for axis in (0, 2, 3):
+        results = searcher.search(VectorSearchRequest(vector=make_vector(axis), result_per_page=10, with_duplicates=True),
+                                  PrefilterResult.All)
+        assert len(results.documents) == 4
+        assert results.documents[0].score > 0.9999 and results.documents[0].doc_id == owner[axis]
+    searcher.close()
+    # the same index searched unmerged, with a deletion that IS newer than segment 1
+    searcher = VectorSearcher.open(config, [(s1, 2), (s2, 4)], deletions + [(f"{UUID1}/a/title", 3)])
+    results = searcher.search(VectorSearchRequest(vector=make_vector(0), result_per_page=10, with_duplicates=True), PrefilterResult.All)
+    assert len(results.documents) == 3 and owner[0] not in {d.doc_id for d in results.documents}
+    searcher.close()
