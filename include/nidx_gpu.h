@@ -352,6 +352,22 @@ typedef struct {
 } nidx_gpu_segment_dir_contents_t;
 int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *contents);
 
+/* The file side of segment::merge (segment.rs:92-135) / DataStoreV2::merge (data_store/v2.rs:82-128): the operands sorted
+ * largest first (stored paragraphs, stable), the alive paragraphs of each copied in address order with their vectors (new
+ * trailers), their StoredParagraph records (new first_vector) and — when every operand has a vectors.quant — their RaBitQ
+ * records.  Writes vectors.bin, paragraphs.bin/.pos, vectors.quant under `path` (an existing directory).  When no paragraph
+ * of the largest operand is deleted and it has a graph, hnsw.graph / hnsw.edges are copied and *graph_nodes_out = its vector
+ * count (merge_indexes, segment.rs:143-158): open the result with hnsw_graph_nodes = that value and finish the graph with
+ * nidx_gpu_vector_extend_hnsw; otherwise *graph_nodes_out = 0 and the graph is built from scratch.  *has_quantized_out = 0 on
+ * a quantizable index means some operand had no codes: nidx_gpu_vector_quantize re-encodes the merged segment on the device. */
+typedef struct {
+    const nidx_gpu_segment_dir_t *dir;
+    const uint64_t *alive_bitset; /* one bit per stored paragraph (apply_deletions, segment.rs:428-445); NULL = all alive */
+} nidx_gpu_merge_operand_t;
+int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const nidx_gpu_merge_operand_t *operands,
+                                   uint32_t n_operands, uint32_t *records_out, uint32_t *vectors_out, uint32_t *graph_nodes_out,
+                                   int32_t *has_quantized_out);
+
 /* =====================================================================================
  * BM25 index — replaces the tantivy scoring under TextSearcher::search
  * (nidx_text/src/reader.rs:367-451) and ParagraphSearcher::search

@@ -105,6 +105,10 @@ class ParagraphC(C.Structure):
                 ("n_labels", C.c_uint32), ("first_vector", C.c_uint32), ("num_vectors", C.c_uint32)]
 
 
+class MergeOperandC(C.Structure):
+    _fields_ = [("dir", C.c_void_p), ("alive_bitset", C.c_void_p)]
+
+
 class SegmentDirContentsC(C.Structure):
     _fields_ = [("dimension", C.c_uint32), ("n_vectors", C.c_uint32), ("n_paragraphs", C.c_uint32), ("vectors", C.c_void_p),
                 ("paragraph_of_vector", C.c_void_p), ("keys", C.c_void_p), ("key_offsets", C.c_void_p), ("labels", C.c_void_p),
@@ -229,6 +233,8 @@ SIGNATURES = {
     "nidx_gpu_segment_dir_paragraph": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(ParagraphC)]),
     "nidx_gpu_segment_dir_paragraph_label": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "nidx_gpu_segment_dir_write": (C.c_int32, [C.c_char_p, C.POINTER(SegmentDirContentsC)]),
+    "nidx_gpu_segment_dir_merge": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(MergeOperandC), C.c_uint32, C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "nidx_gpu_bm25_prefilter": (C.c_int32, [C.c_void_p, C.POINTER(Bm25PrefilterC), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_bm25_fuzzy_terms": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_bm25_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),

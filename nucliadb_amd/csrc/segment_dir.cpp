@@ -406,4 +406,104 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
+namespace {
+struct OutFile {
+    FILE *f = nullptr;
+    bool ok = true;
+    explicit OutFile(const std::string &path) : f(fopen(path.c_str(), "wb")) { ok = f != nullptr; }
+    OutFile(const OutFile &) = delete;
+    ~OutFile() { if (f) fclose(f); }
+    void put(const void *p, size_t n) { if (ok && n) ok = fwrite(p, 1, n, f) == n; }
+    bool finish() {
+        if (f && fclose(f) != 0) ok = false;
+        f = nullptr;
+        return ok;
+    }
+};
+}  // namespace
+
+int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const nidx_gpu_merge_operand_t *operands, uint32_t n_operands,
+                                   uint32_t *records_out, uint32_t *vectors_out, uint32_t *graph_nodes_out, int32_t *has_quantized_out) try {
+    if (!path || !operands || dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_operands == 0) return fail(NIDX_ERR_EMPTY_MERGE, "Can not merge zero segments");
+    // segment::merge (segment.rs:92-94): largest operand first, so that as much of its graph as possible is reused
+    std::vector<uint32_t> order(n_operands);
+    for (uint32_t i = 0; i < n_operands; i++) {
+        if (!operands[i].dir) return fail(NIDX_ERR_INVALID_ARGUMENT, "operand %u: NULL directory", i);
+        if (reinterpret_cast<const SegmentDir *>(operands[i].dir)->dimension != dimension)
+            return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "operand %u was opened with another dimension", i);
+        order[i] = i;
+    }
+    auto dir_of = [&](uint32_t i) { return reinterpret_cast<const SegmentDir *>(operands[i].dir); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dir_of(a)->n_paragraphs > dir_of(b)->n_paragraphs; });
+    auto alive = [&](uint32_t i, uint32_t a) {
+        const uint64_t *w = operands[i].alive_bitset;
+        return !w || ((w[a >> 6] >> (a & 63)) & 1);
+    };
+    bool all_quant = true;
+    for (uint32_t i = 0; i < n_operands; i++) all_quant = all_quant && (dir_of(i)->quant.present || dir_of(i)->n_vectors == 0);
+    const bool quantizable = dimension % 64 == 0;  // the caller only passes stores with codes for Dot indexes (config.rs:170-173)
+    const bool write_quant = quantizable && all_quant && [&] { for (uint32_t i = 0; i < n_operands; i++) if (dir_of(i)->quant.present) return true; return false; }();
+    const std::string base = std::string(path) + "/";
+    const size_t row_bytes = (size_t)dimension * 4, qrec = (size_t)dimension / 8 + 8;
+    OutFile vec(base + "vectors.bin"), pdata(base + "paragraphs.bin"), ppos(base + "paragraphs.pos");
+    std::unique_ptr<OutFile> quant;
+    if (write_quant) quant.reset(new OutFile(base + "vectors.quant"));
+    // DataStoreV2::merge (data_store/v2.rs:82-128): the alive paragraphs of every operand in address order, each with its
+    // vectors (their trailer = the paragraph's new address) and, when stored, their RaBitQ records
+    uint64_t p_idx = 0, v_idx = 0, data_len = 0;
+    std::vector<uint8_t> rec;
+    for (uint32_t oi : order) {
+        const SegmentDir *d = dir_of(oi);
+        const uint8_t *data = d->para_data.p;
+        for (uint32_t a = 0; a < d->n_paragraphs; a++) {
+            if (!alive(oi, a)) continue;
+            const Paragraph &pg = d->paragraphs[a];
+            if (p_idx > 0xfffffffeull || v_idx + pg.num_vectors > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "merged segment exceeds 2^32 records");
+            if (data_len > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "paragraphs.bin would exceed the 4 GiB its u32 offsets address");
+            const uint32_t trailer = (uint32_t)p_idx, pos = (uint32_t)data_len;
+            for (uint32_t v = 0; v < pg.num_vectors; v++) {
+                vec.put(d->vectors.p + (size_t)(pg.first_vector + v) * d->row_stride, row_bytes);
+                vec.put(&trailer, 4);
+                if (quant) quant->put(d->quant.p + (size_t)(pg.first_vector + v) * qrec, qrec);
+            }
+            rec.clear();
+            write_varint(rec, pg.key.len);
+            rec.insert(rec.end(), data + pg.key.off, data + pg.key.off + pg.key.len);
+            write_varint(rec, pg.n_labels);
+            for (uint32_t l = 0; l < pg.n_labels; l++) {
+                const Span &sp = d->labels[pg.first_label + l];
+                write_varint(rec, sp.len);
+                rec.insert(rec.end(), data + sp.off, data + sp.off + sp.len);
+            }
+            write_varint(rec, pg.metadata.len);
+            rec.insert(rec.end(), data + pg.metadata.off, data + pg.metadata.off + pg.metadata.len);
+            write_varint(rec, v_idx);
+            write_varint(rec, pg.num_vectors);
+            pdata.put(rec.data(), rec.size());
+            ppos.put(&pos, 4);
+            data_len += rec.size();
+            v_idx += pg.num_vectors;
+            p_idx++;
+        }
+    }
+    if (!vec.finish() || !pdata.finish() || !ppos.finish() || (quant && !quant->finish())) return fail(NIDX_ERR_IO, "cannot write the merged segment under %s", base.c_str());
+    // merge_indexes (segment.rs:137-167): the largest operand's graph is reused when none of its paragraphs is deleted — its
+    // vectors are then the first rows of the merged store; the caller extends it (nidx_gpu_vector_extend_hnsw)
+    const SegmentDir *first = dir_of(order[0]);
+    uint32_t first_alive = 0;
+    for (uint32_t a = 0; a < first->n_paragraphs; a++) first_alive += alive(order[0], a) ? 1 : 0;
+    uint32_t graph_nodes = 0;
+    if (first_alive == first->n_paragraphs && first->graph.len) {
+        if (write_file(base + "hnsw.graph", first->graph.p, first->graph.len) || write_file(base + "hnsw.edges", first->edges.p, first->edges.len))
+            return fail(NIDX_ERR_IO, "cannot write %shnsw.graph", base.c_str());
+        graph_nodes = first->n_vectors;
+    }
+    if (records_out) *records_out = (uint32_t)p_idx;
+    if (vectors_out) *vectors_out = (uint32_t)v_idx;
+    if (graph_nodes_out) *graph_nodes_out = graph_nodes;
+    if (has_quantized_out) *has_quantized_out = write_quant ? 1 : 0;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
 }  // extern "C"

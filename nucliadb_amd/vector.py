@@ -424,6 +424,24 @@ class SegmentDir:
                              graph_edges=edges, quantized=quant, para_of_vec=None if single else pov)
 
 
+def segment_dir_merge(path: str, dimension: int, operands: Sequence[Tuple["SegmentDir", Optional[np.ndarray]]]):
+    """segment::merge's file output through nidx_gpu_segment_dir_merge: `operands` = [(open SegmentDir, alive mask or None)].
+    Returns (records, vectors, graph_nodes, has_quantized); graph_nodes > 0 = the largest operand's hnsw.graph was carried
+    over and covers the first graph_nodes vectors (open with hnsw_graph_nodes, then VectorSearcher.extend_hnsw)."""
+    ops = (_lib.MergeOperandC * max(1, len(operands)))()
+    keep = []
+    for i, (d, alive) in enumerate(operands):
+        ops[i].dir = d._h
+        if alive is not None:
+            bits = _bitset(np.asarray(alive, dtype=bool))
+            keep.append(bits)
+            ops[i].alive_bitset = bits.ctypes.data
+    rec, vec, gn, hq = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32()
+    _lib.check(_lib.lib().nidx_gpu_segment_dir_merge(path.encode(), dimension, ops, len(operands), C.byref(rec), C.byref(vec),
+                                                   C.byref(gn), C.byref(hq)))
+    return rec.value, vec.value, gn.value, bool(hq.value)
+
+
 @dataclass
 class _KeyPrefixSet:
     prefixes: List[str]

@@ -197,3 +197,72 @@ def test_writer_streams_vectors_bin_in_chunks(orc, tmp_path):
     got = np.frombuffer(read(tmp_path, "vectors.bin"), np.uint8).reshape(n, 36)
     assert np.array_equal(got[:, :32].copy().view("<f4"), vectors)
     assert np.array_equal(got[:, 32:].copy().view("<u4")[:, 0], pov)
+
+
+def test_native_directory_merge_equals_the_mirror_merge(tmp_path):
+    """nidx_gpu_segment_dir_merge (segment::merge / DataStoreV2::merge file output) against segment_merge + save of the host
+    mirror: same bytes in every file, same graph-reuse decision."""
+    from nucliadb_amd.vector import VectorConfig, segment_dir_merge, segment_merge
+
+    rng = np.random.default_rng(21)
+    cfg = VectorConfig(dimension=64)
+
+    def make(n, tag, quant=True, graph=False, multi=False):
+        keys = [f"{RID[i % 4]}/t/{tag}{i}/0-{i}" for i in range(n)]
+        labels = [[f"/l/{tag}/{i % 3}"] * (i % 2) + ["/e/x"] * (i % 5 == 0) for i in range(n)]
+        metadata = [bytes(rng.integers(0, 256, i % 7, dtype=np.uint8)) for i in range(n)]
+        pov = np.repeat(np.arange(n, dtype=np.uint32), 1 + (np.arange(n) % 3 == 0)) if multi else None
+        nv = n if pov is None else len(pov)
+        vectors = rng.standard_normal((nv, 64)).astype(np.float32)
+        q = rng.integers(0, 256, (nv, 64 // 8 + 8), dtype=np.uint8) if quant else None
+        g = (bytes(rng.integers(0, 256, 40, dtype=np.uint8)), rng.standard_normal(6).astype(np.float32)) if graph else (None, None)
+        return VectorSegment(keys, vectors, labels, metadata, quantized=q, graph=g[0], graph_edges=g[1], para_of_vec=pov)
+
+    def check(segs_alive, name):
+        dirs = []
+        for i, (seg, _) in enumerate(segs_alive):
+            d = tmp_path / f"{name}_op{i}"
+            d.mkdir()
+            seg.save(str(d))
+            dirs.append(SegmentDir(str(d), 64))
+        want_dir, got_dir = tmp_path / f"{name}_want", tmp_path / f"{name}_got"
+        want_dir.mkdir(), got_dir.mkdir()
+        want = segment_merge(segs_alive, cfg)
+        covered, want.graph_nodes = want.graph_nodes, 0   # the mirror refuses to save a partial graph; the files are the same
+        want.save(str(want_dir))
+        want.graph_nodes = covered
+        rec, vec, gn, hq = segment_dir_merge(str(got_dir), 64, [(d, alive) for d, (_, alive) in zip(dirs, segs_alive)])
+        assert rec == want.records and vec == want.vectors.shape[0]
+        assert hq == (want.quantized is not None)
+        # the mirror says "graph covers the first graph_nodes vectors (0 = all of them)"; the ABI reports the covered count
+        assert gn == (0 if want.graph is None else (want.graph_nodes or want.vectors.shape[0]))
+        assert sorted(os.listdir(got_dir)) == sorted(os.listdir(want_dir))
+        for f in os.listdir(want_dir):
+            assert read(got_dir, f) == read(want_dir, f), (name, f)
+        for d in dirs:
+            d.close()
+        return want
+
+    small, big, mid = make(5, "s"), make(9, "b", graph=True), make(7, "m")
+    dead = np.ones(5, bool)
+    dead[[1, 3]] = False
+    # largest operand intact: its graph is carried over; a smaller operand loses two paragraphs
+    w = check([(small, dead), (big, None), (mid, None)], "reuse")
+    assert w.graph is not None and w.records == 3 + 9 + 7
+    # the largest operand has a deletion: no graph
+    hole = np.ones(9, bool)
+    hole[0] = False
+    w = check([(big, hole), (mid, None)], "rebuild")
+    assert w.graph is None
+    # one operand without codes: the merged directory has no vectors.quant (re-encoded on the device afterwards)
+    w = check([(make(4, "q", quant=False), None), (mid, None)], "noquant")
+    assert w.quantized is None
+    # equal sizes keep their order; an operand that is entirely deleted; multi-vector paragraphs
+    check([(make(6, "x"), None), (make(6, "y"), np.zeros(6, bool)), (make(6, "z"), None)], "ties")
+    mdead = np.ones(8, bool)
+    mdead[[0, 5]] = False
+    check([(make(8, "u", multi=True), mdead), (make(10, "v", multi=True, graph=True), None)], "multi")
+    # zero operands
+    with pytest.raises(_lib.NidxGpuError) as e:
+        segment_dir_merge(str(tmp_path), 64, [])
+    assert e.value.code == _lib.NIDX_ERR_EMPTY_MERGE
