@@ -100,3 +100,76 @@ def test_mapped_directory_feeds_the_c_abi_without_copies(tmp_path):
 def _field(rid, field_id):
     from nucliadb_amd.vector import _KeyPrefixSet
     return _KeyPrefixSet([uuid.UUID(rid).hex + field_id])
+
+
+def test_native_directory_merge_then_extend_on_the_device(tmp_path):
+    """VectorIndexer::merge end to end without the mirror's in-memory segments: two directories -> nidx_gpu_segment_dir_merge
+    (the largest operand's graph carried over) -> nidx_gpu_vector_open on the mapped result -> nidx_gpu_vector_extend_hnsw ->
+    search.  The exact scan must equal the in-memory merge's, the extended graph must find what the scan finds."""
+    from nucliadb_amd.vector import segment_dir_merge, segment_merge
+
+    a_dir, b_dir, m_dir = tmp_path / "a", tmp_path / "b", tmp_path / "m"
+    for d in (a_dir, b_dir, m_dir):
+        d.mkdir()
+    config, seg_a, s, rids, rng = build(a_dir)
+    s.close()
+    D = config.dimension
+    vb = rng.standard_normal((700, D)).astype(np.float32)
+    vb /= np.linalg.norm(vb, axis=1, keepdims=True)
+    seg_b = segment_create([Elem(f"{rids[i % 40]}/t/extra/{i}-{i + 1}", vb[i].tolist(), labels=["/l/set/label_1"]) for i in range(700)], config)
+    sb = VectorSearcher.open(config, [(seg_b, 1)])
+    seg_b.quantized = sb.serialize_quantized(0)
+    sb.close()
+    seg_b.save(str(b_dir))
+    alive_b = np.ones(700, bool)
+    alive_b[::9] = False
+    with SegmentDir(str(a_dir), D) as da, SegmentDir(str(b_dir), D) as db:
+        rec, vec, covered, has_q = segment_dir_merge(str(m_dir), D, [(db, alive_b), (da, None)])
+    n = seg_a.records + int(alive_b.sum())
+    assert (rec, vec, covered, has_q) == (n, n, seg_a.records, True)
+    want_seg = segment_merge([(seg_b, alive_b), (seg_a, None)], config)
+    L = _lib.lib()
+    q = rng.standard_normal((64, D)).astype(np.float32)
+    k = 10
+    with SegmentDir(str(m_dir), D) as dm:
+        c_seg = (_lib.VectorSegmentC * 1)(dm.segment_c())
+        c_seg[0].hnsw_graph_nodes = covered
+        cfg = config.to_c()
+        h = C.c_void_p()
+        _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), c_seg, 1, C.byref(h)))
+        try:
+            _lib.check(L.nidx_gpu_vector_extend_hnsw(h, 0, 2))
+            res = {}
+            for method in (_lib.METHOD_BRUTE_FORCE, _lib.METHOD_HNSW):
+                out = [np.zeros((64, k), np.uint32) for _ in range(3)] + [np.zeros((64, k), np.float32), np.zeros(64, np.uint32)]
+                params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
+                _lib.check(L.nidx_gpu_vector_search_dim(h, q.ctypes.data, 64, D, C.byref(params), None, out[0].ctypes.data, out[1].ctypes.data,
+                                                        out[2].ctypes.data, out[3].ctypes.data, out[4].ctypes.data, None))
+                res[method] = out
+        finally:
+            L.nidx_gpu_vector_close(h)
+        # the hit addresses resolve to the merged store's records
+        p = int(res[_lib.METHOD_BRUTE_FORCE][1][0, 0])
+        assert dm.paragraph(p)[0] == want_seg.keys[p]
+    sw = VectorSearcher.open(config, [(want_seg, 1)], quantize=False)
+    req = VectorSearchRequest(vector=[], result_per_page=k, min_score=-1.0, with_duplicates=True)
+    want = sw.search_batch(req, q, None, _lib.METHOD_BRUTE_FORCE)
+    sw.close()
+    for x, y in zip(res[_lib.METHOD_BRUTE_FORCE], want):
+        assert np.array_equal(x, y)
+    exact, walk = res[_lib.METHOD_BRUTE_FORCE][2], res[_lib.METHOD_HNSW][2]
+    recall = np.mean([len(set(exact[i]) & set(walk[i])) / k for i in range(64)])
+    # the same merge through the in-memory mirror (segment_merge -> extend_hnsw): the graph the directory route ends with is as good
+    sm = VectorSearcher.open(config, [(want_seg, 1)], quantize=False)
+    sm.extend_hnsw(0)
+    req_walk = VectorSearchRequest(vector=[], result_per_page=k, min_score=-1.0, with_duplicates=True)
+    mirror_walk = sm.search_batch(req_walk, q, None, _lib.METHOD_HNSW)[2]
+    # every appended row finds itself through the extended graph (segment/tests.rs:379-477)
+    own = sm.search_batch(VectorSearchRequest(vector=[], result_per_page=1, min_score=-1.0, with_duplicates=True),
+                          want_seg.vectors[covered:], None, _lib.METHOD_HNSW)
+    sm.close()
+    recall_mirror = np.mean([len(set(exact[i]) & set(mirror_walk[i])) / k for i in range(64)])
+    assert recall >= 0.8 and recall >= recall_mirror - 0.03, (recall, recall_mirror)   # uniform-random 64-d rows at ef = 30
+    assert (own[3][:, 0] >= 0.999).mean() >= 0.97
+    # the appended rows are reachable in the directory route too: some hits come from beyond the carried-over graph
+    assert (walk >= covered).any()
