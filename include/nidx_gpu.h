@@ -360,6 +360,13 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
  * count (merge_indexes, segment.rs:143-158): open the result with hnsw_graph_nodes = that value and finish the graph with
  * nidx_gpu_vector_extend_hnsw; otherwise *graph_nodes_out = 0 and the graph is built from scratch.  *has_quantized_out = 0 on
  * a quantizable index means some operand had no codes: nidx_gpu_vector_quantize re-encodes the merged segment on the device. */
+/* OpenSegment::apply_deletions (segment.rs:428-445): clears in `alive_bitset` (one bit per stored paragraph, initialised by
+ * the caller) the paragraphs of every deletion key — a resource uuid or `uuid/type/name` — found by
+ * field_index.get_prefix(FieldKey::from_field_id(key)) (inverted_index/paragraph.rs:118-120; a BYTE prefix: `…/t/title` also
+ * reaches `…/t/title2`).  Keys that are no field id delete nothing.  *n_cleared_out = paragraphs that were alive. */
+int32_t nidx_gpu_segment_dir_apply_deletions(const nidx_gpu_segment_dir_t *dir, const char *const *keys, const uint32_t *key_lens,
+                                             uint32_t n_keys, uint64_t *alive_bitset, uint32_t *n_cleared_out);
+
 typedef struct {
     const nidx_gpu_segment_dir_t *dir;
     const uint64_t *alive_bitset; /* one bit per stored paragraph (apply_deletions, segment.rs:428-445); NULL = all alive */

@@ -506,4 +506,29 @@ int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const n
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
+int32_t nidx_gpu_segment_dir_apply_deletions(const nidx_gpu_segment_dir_t *dir, const char *const *keys, const uint32_t *key_lens, uint32_t n_keys,
+                                             uint64_t *alive_bitset, uint32_t *n_cleared_out) try {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    if (!d || !alive_bitset || (n_keys && (!keys || !key_lens))) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    uint32_t cleared = 0;
+    std::string fk;
+    for (uint32_t i = 0; i < n_keys; i++) {
+        if (!keys[i] && key_lens[i]) return fail(NIDX_ERR_INVALID_ARGUMENT, "key %u is NULL", i);
+        // FieldKey::from_field_id -> None: not a field id, nothing to delete (lib.rs:193-195)
+        if (!field_key(reinterpret_cast<const uint8_t *>(keys[i]), key_lens[i], fk)) continue;
+        const std::string k = "F" + fk;
+        // field_index.get_prefix (inverted_index/paragraph.rs:118-120): every indexed key the FieldKey bytes are a prefix of
+        for (auto it = std::lower_bound(d->list_keys.begin(), d->list_keys.end(), k); it != d->list_keys.end() && it->compare(0, k.size(), k) == 0; ++it) {
+            const size_t l = (size_t)(it - d->list_keys.begin());
+            for (uint64_t j = d->list_offsets[l]; j < d->list_offsets[l + 1]; j++) {
+                const uint32_t a = d->list_ids[j];
+                const uint64_t bit = 1ull << (a & 63);
+                if (alive_bitset[a >> 6] & bit) { alive_bitset[a >> 6] &= ~bit; cleared++; }
+            }
+        }
+    }
+    if (n_cleared_out) *n_cleared_out = cleared;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
 }  // extern "C"

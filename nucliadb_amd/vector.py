@@ -383,6 +383,22 @@ class SegmentDir:
         _lib.check(_lib.lib().nidx_gpu_segment_dir_lists(self._h, kind, k, len(k), int(prefix), C.byref(first), C.byref(count)))
         return range(first.value, first.value + count.value)
 
+    def apply_deletions(self, keys: Sequence[str], alive: Optional[np.ndarray] = None) -> np.ndarray:
+        """OpenSegment::apply_deletions through nidx_gpu_segment_dir_apply_deletions: the alive mask (bool per stored
+        paragraph) after deleting `keys` (resource uuids or uuid/type/name field ids)."""
+        n = self.segment_c().n_paragraphs
+        bits = _bitset(np.ones(n, bool) if alive is None else np.asarray(alive, dtype=bool))
+        if len(bits) == 0:
+            return np.zeros(0, bool)
+        enc = [k.encode() for k in keys]
+        arr = (C.c_char_p * max(1, len(enc)))(*enc)
+        lens = (C.c_uint32 * max(1, len(enc)))(*[len(e) for e in enc])
+        cleared = C.c_uint32()
+        _lib.check(_lib.lib().nidx_gpu_segment_dir_apply_deletions(self._h, arr, lens, len(enc), bits.ctypes.data, C.byref(cleared)))
+        mask = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert int(cleared.value) == int((np.ones(n, bool) if alive is None else np.asarray(alive, dtype=bool)).sum() - mask.sum())
+        return mask
+
     def posting_list(self, list_id: int) -> np.ndarray:
         fi = self.filter_index_c()
         offs = np.ctypeslib.as_array(C.cast(fi.list_offsets, C.POINTER(C.c_uint64)), (fi.n_lists + 1,))

@@ -266,3 +266,29 @@ def test_native_directory_merge_equals_the_mirror_merge(tmp_path):
     with pytest.raises(_lib.NidxGpuError) as e:
         segment_dir_merge(str(tmp_path), 64, [])
     assert e.value.code == _lib.NIDX_ERR_EMPTY_MERGE
+
+
+def test_apply_deletions_equals_the_mirror(tmp_path):
+    """nidx_gpu_segment_dir_apply_deletions (OpenSegment::apply_deletions, segment.rs:428-445) against
+    VectorSegment.ids_for_deletion_key: resource keys, field keys, the byte-prefix reach (title -> title2), non-keys."""
+    rng = np.random.default_rng(31)
+    keys, labels, metadata, vectors = corpus(rng)
+    seg = VectorSegment(keys, vectors, labels, metadata)
+    seg.save(str(tmp_path))
+    cases = [[str(RID[0])], [RID[1].hex], [f"{RID[2]}/t/title"], [f"{RID[2]}/t/title2"], [f"{RID[1]}/a/body", f"{RID[3]}/t/title"],
+             [f"{RID[0]}/t"], ["not-a-uuid/t/title"], [f"{RID[3]}/f/file"], [f"{RID[3]}/f/file/extra"], [], [str(RID[0]), str(RID[0])]]
+    with SegmentDir(str(tmp_path), 8) as d:
+        for dels in cases:
+            want = np.ones(seg.records, bool)
+            for k in dels:
+                want[seg.ids_for_deletion_key(k)] = False
+            got = d.apply_deletions(dels)
+            assert np.array_equal(got, want), dels
+        # something was actually deleted in the interesting cases, and title reaches title2
+        assert not d.apply_deletions([str(RID[0])]).all() and d.apply_deletions(["not-a-uuid/t/title"]).all()
+        t1, t2 = d.apply_deletions([f"{RID[2]}/t/title"]), d.apply_deletions([f"{RID[2]}/t/title2"])
+        assert (~t1).sum() > (~t2).sum() > 0 and not (t1 & ~t2).any()
+        # an already-dead paragraph stays dead and is not counted twice
+        start = np.ones(seg.records, bool)
+        start[:5] = False
+        assert not d.apply_deletions([str(RID[0])], start)[:5].any()
