@@ -150,7 +150,6 @@ struct SegmentDir {
     std::vector<Paragraph> paragraphs;
     std::vector<Span> labels;
     std::vector<uint64_t> key_ids;
-    std::vector<uint32_t> para_of_vec;  // only when the trailers disagree with nothing: kept for the Multi case
     // the inverted indexes: sorted keys ("L" + labels_key | "F" + FieldKey bytes) -> ascending paragraph lists
     std::vector<std::string> list_keys;
     std::vector<uint64_t> list_offsets;
