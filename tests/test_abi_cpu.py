@@ -159,3 +159,55 @@ def test_merge_bm25_matches_oracle(L, orc):
                                      od.ctypes.data, ol.ctypes.data, C.byref(cnt)) == 0
         got = [(float(os_[i]), int(od[i]), shard_ids[int(ol[i])]) for i in range(cnt.value)]
         assert got == [(w[0], w[1], w[2]) for w in want], (got, want)
+
+
+_STRUCTS = {
+    "nidx_gpu_vector_config_t": "VectorConfigC", "nidx_gpu_vector_segment_t": "VectorSegmentC",
+    "nidx_gpu_vector_search_params_t": "VectorSearchParamsC", "nidx_gpu_filter_index_t": "FilterIndexC",
+    "nidx_gpu_filter_op_t": "FilterOpC", "nidx_gpu_filter_program_t": "FilterProgramC", "nidx_gpu_paragraph_t": "ParagraphC",
+    "nidx_gpu_segment_dir_contents_t": "SegmentDirContentsC", "nidx_gpu_merge_operand_t": "MergeOperandC",
+    "nidx_gpu_bm25_segment_t": "Bm25SegmentC", "nidx_gpu_bm25_clause_t": "Bm25ClauseC",
+    "nidx_gpu_bm25_search_after_t": "Bm25SearchAfterC", "nidx_gpu_bm25_search_options_t": "Bm25SearchOptionsC",
+    "nidx_gpu_bm25_date_range_t": "Bm25DateRangeC", "nidx_gpu_bm25_prefilter_t": "Bm25PrefilterC",
+    "nidx_gpu_ranked_list_t": "RankedListC",
+}
+
+
+def _header_structs():
+    h = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nidx_gpu.h")).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct\s*\{(.*?)\}\s*(nidx_gpu_\w+_t)\s*;", h, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            for part in decl.strip().split(","):
+                if part.strip():
+                    fields.append(re.findall(r"(\w+)\s*(?:\[\d+\])?$", part.strip())[0])
+        out[m.group(2)] = fields
+    return out
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """Every struct of include/nidx_gpu.h has a ctypes mirror with the same fields in the same order, the same size and the
+    same field offsets as the C compiler gives them (a binding that drifts from the header corrupts arguments silently)."""
+    import subprocess
+
+    structs = _header_structs()
+    assert set(structs) == set(_STRUCTS), set(structs) ^ set(_STRUCTS)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nidx_gpu.h"', "int main(void) {"]
+    for cname, fields in structs.items():
+        cls = getattr(_lib, _STRUCTS[cname])
+        assert [f[0] for f in cls._fields_] == fields, cname
+        lines.append(f'    printf("{cname} %zu", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'    printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('    printf("\\n");')
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, size, *offsets = line.split()
+        cls = getattr(_lib, _STRUCTS[cname])
+        assert C.sizeof(cls) == int(size), cname
+        assert [getattr(cls, f[0]).offset for f in cls._fields_] == [int(o) for o in offsets], cname
