@@ -270,6 +270,15 @@ int32_t nidx_gpu_similarity(const float *x, const float *y, uint32_t n_pairs, ui
 /* utils::normalize_vector (utils.rs:20-23) for n rows, host in/out. */
 int32_t nidx_gpu_normalize(const float *in, uint32_t n, uint32_t dimension, float *out);
 
+/* Host-only check of an hnsw.graph image (and, when given, its hnsw.edges weights) for `n_nodes` vectors — the validation
+ * nidx_gpu_vector_open applies before the graph goes to HBM (node offsets, layer offsets, degrees <= M_max, edge targets,
+ * entry point; hnsw/disk/v2.rs:16-49), without a device.  NIDX_ERR_INVALID_GRAPH + message when malformed.  Outputs (each may be
+ * NULL): the entry point (node, layer), the number of edges, and the number of links fix_broken_graph would drop
+ * (ram_hnsw.rs:109-143: links into a layer the target does not live on). */
+int32_t nidx_gpu_hnsw_graph_check(const uint8_t *graph, uint64_t graph_len, const float *edges, uint64_t n_edges, uint32_t n_nodes,
+                                  uint32_t *entry_node_out, uint32_t *entry_layer_out, uint64_t *n_links_out,
+                                  uint64_t *n_broken_links_out);
+
 /* HnswBuilder (hnsw/build.rs:28-167) on the device for one segment of an open index: level
  * draw from SmallRng::seed_from_u64(level_seed) (build.rs:36-55; the reference uses 2), batched
  * concurrent inserts with M=30/M0=60/efC=100 (hnsw/params.rs:20-46).  Replaces any graph the

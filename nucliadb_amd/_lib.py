@@ -233,6 +233,8 @@ SIGNATURES = {
     "nidx_gpu_segment_dir_paragraph": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(ParagraphC)]),
     "nidx_gpu_segment_dir_paragraph_label": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "nidx_gpu_segment_dir_write": (C.c_int32, [C.c_char_p, C.POINTER(SegmentDirContentsC)]),
+    "nidx_gpu_hnsw_graph_check": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_segment_dir_apply_deletions": (C.c_int32, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
                                                          C.POINTER(C.c_uint32)]),
     "nidx_gpu_segment_dir_merge": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(MergeOperandC), C.c_uint32, C.POINTER(C.c_uint32),

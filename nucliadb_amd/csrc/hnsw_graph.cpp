@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../include/nidx_gpu.h"
+#include "host_common.h"
 
 namespace nidx {
 
@@ -226,3 +227,32 @@ void draw_levels(uint64_t seed, uint32_t n, std::vector<uint8_t> &levels) {
 }
 
 }  // namespace nidx
+
+extern "C" int32_t nidx_gpu_hnsw_graph_check(const uint8_t *graph, uint64_t graph_len, const float *edges, uint64_t n_edges, uint32_t n_nodes,
+                                             uint32_t *entry_node_out, uint32_t *entry_layer_out, uint64_t *n_links_out,
+                                             uint64_t *n_broken_links_out) try {
+    using namespace nidx;
+    if (graph_len && !graph) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL graph");
+    HostGraph g;
+    std::string err;
+    int rc = parse_disk_v2(graph, graph_len, n_nodes, g, err);
+    if (rc == NIDX_OK) rc = attach_edge_weights(g, graph, graph_len, edges, n_edges, err);
+    if (rc != NIDX_OK) return fail(rc, "%s", err.c_str());
+    auto links = [&]() {
+        uint64_t n = 0;
+        for (uint32_t i = 0; i < g.n; i++) {
+            n += g.l0[(size_t)i * NIDX_L0_STRIDE];
+            for (uint32_t l = 1; l <= g.top_layer[i] && g.upper_base[i] != 0xffffffffu; l++) n += g.upper[((size_t)g.upper_base[i] + (l - 1)) * NIDX_UP_STRIDE];
+        }
+        return n;
+    };
+    const uint64_t before = links();
+    if (entry_node_out) *entry_node_out = g.ep_node;
+    if (entry_layer_out) *entry_layer_out = g.ep_layer;
+    if (n_links_out) *n_links_out = before;
+    if (n_broken_links_out) {
+        fix_broken_graph(g);
+        *n_broken_links_out = before - links();
+    }
+    return NIDX_OK;
+} NIDX_ABI_CATCH
