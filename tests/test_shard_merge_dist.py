@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exchange per-shard top-k lists with the same
+"""The N>1 path on CPU: world_size-2 (and -4) gloo processes exchange per-shard top-k lists with the same
 all-gather + merge code bench.py runs over RCCL, and both ranks must end with the oracle's
 merge_vector_responses / sort_documents_fn result (shard_merge.rs:211-234,332-348)."""
 import os
@@ -32,6 +32,10 @@ def _shard_lists(rank, B, k, seed):
     return score, ident, count
 
 
+# compared as bytes, descending (shard_merge.rs:211-234): not in rank order, one a prefix of another
+SHARD_IDS = [b"shard-b", b"shard-a", b"shard", b"shard-c"]
+
+
 def _worker(rank, world, port, B, k, limit, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,28 +46,30 @@ def _worker(rank, world, port, B, k, limit, out):
     # BM25 lists: docaddr ascending inside equal scores, shard ids compared as bytes
     bs, ba, bc = _shard_lists(rank, B, k, 200)
     ba = np.sort(np.abs(ba) & 0xFFFF, axis=1)
-    shard_ids = [b"shard-b", b"shard-a"][:world]
+    shard_ids = SHARD_IDS[:world]
     os_, oa, osh, oc = exchange_and_merge_bm25(torch.from_numpy(bs), torch.from_numpy(ba), torch.from_numpy(bc), shard_ids, limit)
     out[rank] = (ms.numpy().copy(), mi.numpy().copy(), mc.numpy().copy(), os_, oa, osh, oc)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_gloo_exchange_matches_oracle(orc):
+@pytest.mark.parametrize("world", [2, 4])
+def test_world2_gloo_exchange_matches_oracle(orc, world):
     import __graft_entry__ as g
 
     g.build()
-    world, B, k, limit = 2, 33, 10, 10
+    B, k, limit = 33, 10, 10
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), B, k, limit, out), nprocs=world, join=True)
-    assert set(out.keys()) == {0, 1}
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b), "ranks disagree after the exchange"
+    assert set(out.keys()) == set(range(world))
+    for r in range(1, world):
+        for a, b in zip(out[0], out[r]):
+            assert np.array_equal(a, b), "ranks disagree after the exchange"
     ms, mi, mc, bs, ba, bsh, bc = out[0]
     shards = [_shard_lists(r, B, k, 100) for r in range(world)]
     bshards = [_shard_lists(r, B, k, 200) for r in range(world)]
-    shard_ids = [b"shard-b", b"shard-a"]
+    shard_ids = SHARD_IDS[:world]
     for q in range(B):
         lists = [[(float(s[q, i]), int(d[q, i])) for i in range(c[q])] for s, d, c in shards]
         want = orc.merge_vector(lists, limit)
