@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py — the nidx vector hot path on MI355X: batched 768-d cosine HNSW k-NN (BASELINE.json configs[1]).
+"""bench.py — the nidx vector hot path on MI355X: batched 768-d cosine HNSW k-NN over 10 M vectors
+(the configuration BASELINE.json's metric is quoted on: configs[2]'s vector half; configs[3] = 12.5 M per GPU with --gpus 8).
 
 One process per GPU.  Every rank owns one index shard (n_vectors x dim, synthetic, resident in HBM,
 HNSW graph built on the device before the timed region), receives the full query batch, searches
 its shard with the hand-written HIP kernel through the C ABI (device pointers, torch's current
 stream), and — when world_size > 1 — all-gathers the per-shard top-k over RCCL and merges them
 with merge_vector_responses' rule on the device.  A "step" = one batch of `--batch` queries.
+
+The timed corpus is the reference's clustered recall recipe (nidx_vector/src/segment.rs:841-905) scaled to the shard
+size, so recall@10 is measured on the corpus the throughput is quoted on; the uniform-random corpus of the reference's
+other tests is a second, labelled figure (config.uniform_corpus).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), extended with
   roofline      dominant kernel (hnsw_search_kernel): algorithmic bytes per launch / HIP-event time vs 8 TB/s
@@ -35,17 +40,25 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n-vectors", type=int, default=1_000_000, help="vectors per shard (per GPU)")
+    p.add_argument("--n-vectors", type=int, default=0,
+                   help="vectors per shard (per GPU); 0 = BASELINE.json: 10 M on one GPU (configs[2]), 12.5 M per GPU otherwise (configs[3]: 100 M over 8)")
+    p.add_argument("--corpus", choices=["clustered", "uniform", "both"], default="both",
+                   help="hnsw workload: the timed corpus is the clustered one; 'both' adds the uniform corpus as a second figure")
+    p.add_argument("--parity-queries", type=int, default=256, help="hnsw: queries of the timed batch checked bit for bit against the oracle (0 = skip)")
+    p.add_argument("--scan-check-queries", type=int, default=4, help="hnsw: queries whose exact-scan ground truth is checked against the oracle's brute force")
+    p.add_argument("--segment-regime", type=int, default=200_000,
+                   help="cpu_baseline: also time the oracle over segments of this many records + Fssc (the reference's own regime, src/settings.rs:258-278); 0 = skip")
+    p.add_argument("--ref-build-n", type=int, default=50_000,
+                   help="recall of the oracle's sequential HnswBuilder vs the device build on a clustered segment of this size (0 = skip)")
+    p.add_argument("--single-query-calls", type=int, default=2048, help="hnsw: nidx_gpu_vector_search_one calls for the p50/p99 figure (0 = skip)")
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25", "rabitq", "hybrid"], default="hnsw")
+    p.add_argument("--workload", choices=["hnsw", "scan", "mfma", "bf16", "bm25", "rabitq", "hybrid", "gather"], default="hnsw")
     p.add_argument("--n-docs", type=int, default=10_000_000, help="bm25: documents per shard")
     p.add_argument("--vocab", type=int, default=1_000_000)
     p.add_argument("--recall-queries", type=int, default=256)
-    p.add_argument("--clustered-n", type=int, default=200_000,
-                   help="size of the extra clustered shard used for the recall figure (0 = skip)")
-    p.add_argument("--cpu-queries", type=int, default=2048, help="bounded sample for the cpu_baseline leg (0 = skip)")
+    p.add_argument("--cpu-queries", type=int, default=4096, help="bounded sample for the cpu_baseline leg (0 = skip)")
     p.add_argument("--cpu-threads", type=int, default=0)
     p.add_argument("--waves-per-query", type=int, default=0, help="tuning: workgroup waves per query (env NIDX_GPU_WAVES_PER_QUERY)")
     return p.parse_args()
@@ -86,6 +99,17 @@ def main():
             dist.barrier()
     L = _lib.lib()
     _lib.check(L.nidx_gpu_set_device(local_rank))
+    if a.n_vectors <= 0:
+        a.n_vectors = 10_000_000 if world == 1 else 12_500_000
+    if a.workload == "hnsw":
+        bench_hnsw(a, L, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if a.workload == "gather":
+        bench_gather(a, L, dev, rank)
+        return
     if a.workload == "bm25":
         bench_bm25(a, L, dev, rank, world)
         if world > 1:
@@ -121,10 +145,6 @@ def main():
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
     open_s = time.time() - t0
     build_s = 0.0
-    if a.workload == "hnsw":
-        t0 = time.time()
-        _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
-        build_s = time.time() - t0
 
     # ---- query batches (seed 2, identical on every rank)
     gq = torch.Generator(device=dev)
@@ -136,8 +156,7 @@ def main():
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
     out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
     stats = torch.zeros((B, 8), dtype=torch.int32, device=dev)
-    method = {"hnsw": _lib.METHOD_HNSW, "scan": _lib.METHOD_BRUTE_FORCE, "mfma": _lib.METHOD_BRUTE_FORCE_MFMA,
-              "bf16": _lib.METHOD_BRUTE_FORCE_BF16}[a.workload]
+    method = {"scan": _lib.METHOD_BRUTE_FORCE, "mfma": _lib.METHOD_BRUTE_FORCE_MFMA, "bf16": _lib.METHOD_BRUTE_FORCE_BF16}[a.workload]
     params = _lib.VectorSearchParamsC(k, -1.0, 1, method)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -224,54 +243,16 @@ def main():
         elapsed = float(t.item())
     kernel_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
 
-    # ---- algorithmic bytes per launch: evals*4D + expansions*256 B, counted by the kernel
-    bytes_per_launch, evals_q, exp_q, flags = [], [], [], 0
-    if a.workload == "hnsw":
-        for i in range(min(n_pool, a.steps)):
-            search(qpool[i], with_stats=True)
-            torch.cuda.synchronize()
-            s = stats.cpu().numpy().astype(np.int64)
-            bytes_per_launch.append(float((s[:, 0] * 4 * d + s[:, 1] * 256).sum()))
-            evals_q.append(float(s[:, 0].mean()))
-            exp_q.append(float(s[:, 1].mean()))
-            flags |= int(np.bitwise_or.reduce(s[:, 3]))
-        alg_bytes = float(np.mean(bytes_per_launch))
-    else:
-        alg_bytes = float(n) * d * 4  # the shard is read once per batch algorithmically
-        evals_q, exp_q = [float(n)], [0.0]
+    alg_bytes = float(n) * d * 4  # the shard is read once per batch algorithmically
+    evals_q, exp_q, flags = [float(n)], [0.0], 0
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     alg_flops = 2.0 * n * d * B
     achieved_tf = alg_flops / (kernel_ms * 1e-3) / 1e12
-    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the committed
-    # rocprofv3 --pmc passes of this same command are quoted when the workload is the profiled one.
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        w = pmc["workload"]
-        if a.workload == "hnsw" and (w["n_vectors"], w["dim"], w["batch"], w["k"]) == (n, d, B, k):
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], pmc["source"]
-    except (OSError, KeyError, ValueError):
-        pass
-
-    # ---- the same batch through the host-buffer entry point (queries in / hits out over PCIe): reported
-    # beside `value`, never as `value`
-    host_qps = None
-    if a.workload == "hnsw":
-        qh = qpool[0].cpu().numpy()
-        hv, hs_, hc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
-        hp = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
-        reps = 5
-        for i in range(reps + 1):
-            if i == 1:
-                t1 = time.perf_counter()
-            _lib.check(L.nidx_gpu_vector_search(h, qh.ctypes.data, B, C.byref(hp), None, None, None, hv.ctypes.data,
-                                                hs_.ctypes.data, hc.ctypes.data, None))
-        host_qps = B * reps / (time.perf_counter() - t1)
+    traffic, traffic_src, host_qps = None, None, None
 
     # ---- recall@k against the exact scan (oracle-verified kernel) on the same shard
     recall = None
-    if a.workload in ("hnsw", "bf16") and a.recall_queries > 0:
+    if a.workload == "bf16" and a.recall_queries > 0:
         rq = min(a.recall_queries, B)
         search(qpool[0])
         torch.cuda.synchronize()
@@ -280,14 +261,6 @@ def main():
         torch.cuda.synchronize()
         exact = out_vec[:rq].cpu().numpy()
         recall = float(np.mean([len(set(got[i]) & set(exact[i])) / k for i in range(rq)]))
-
-    # ---- recall@k on clustered data: the reference's recall recipe (segment.rs:849-883) scaled up —
-    # chained centres c' = norm(c + 0.1u), 160 points per centre (half at radius 0.01, half at 0.03),
-    # queries = norm(stored + 0.05u).  Uniform random 768-d vectors have no neighbourhood structure,
-    # so this is the data the recall claim is made on.
-    recall_clustered, clustered_build_s = None, None
-    if a.workload == "hnsw" and a.clustered_n > 0 and rank == 0:
-        recall_clustered, clustered_build_s = clustered_recall(a, L, dev)
 
     # ---- CPU baseline: the oracle (restated reference algorithm, AVX2-shaped sums) on the host cores
     cpu = None
@@ -302,7 +275,7 @@ def main():
     if rank == 0:
         total_q = world * B * a.steps
         line = {
-            "metric": "queries/sec (768-dim cosine k-NN, HNSW M=30 ef=30, k=10)" if a.workload == "hnsw" else "queries/sec (exact cosine k-NN, %s)" % a.workload,
+            "metric": "queries/sec (exact cosine k-NN, %s)" % a.workload,
             "value": total_q / elapsed,
             "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
             "n_gpus": world,
@@ -318,9 +291,7 @@ def main():
                 "workload": "%s: %d x %d-dim cosine, k=%d, batch=%d queries, 1 shard per GPU" % (a.workload, n, d, k, B),
                 "vectors_per_shard": n, "dim": d, "batch": B, "k": k, "shards": world,
                 "corpus_vectors": n * world, "merged_queries_per_s": B * a.steps / elapsed,
-                "recall_at_%d" % k: recall, "recall_at_%d_clustered" % k: recall_clustered,
-                "clustered_vectors": a.clustered_n if recall_clustered is not None else None,
-                "clustered_build_s": clustered_build_s, "hnsw_build_s": build_s, "open_s": open_s,
+                "recall_at_%d" % k: recall, "open_s": open_s,
                 "distance_evals_per_query": float(np.mean(evals_q)), "expansions_per_query": float(np.mean(exp_q)),
                 "kernel_flags": flags, "host_buffer_queries_per_s": host_qps, "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": exchange_check,
             },
@@ -334,7 +305,7 @@ def main():
                 "algorithmic_flops_per_launch": alg_flops, "hbm_GBps_algorithmic_bf16": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9,
                 "hbm_frac": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kernel_ms,
             } if a.workload == "bf16" else {
-                "kernel": "hnsw_search_kernel<3,2,4>" if a.workload == "hnsw" else "scan_shared_kernel / scan_topk_kernel (+ merge_topk_kernel)",
+                "kernel": "scan_shared_kernel / scan_topk_kernel (+ merge_topk_kernel)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
@@ -345,6 +316,620 @@ def main():
     if world > 1:
         dist.barrier()  # rank 0 runs the CPU baseline; keep the group alive until it is done
         dist.destroy_process_group()
+
+
+# =====================================================================================================================
+# The headline workload: batched cosine HNSW k-NN over one shard per GPU
+# =====================================================================================================================
+PER_CLUSTER = 160  # segment.rs:849-863: 80 vectors at radius 0.01 + 80 at 0.03 around each centre
+
+
+def _unit_rows(shape, g, dev):
+    v = torch.rand(shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    return v / v.norm(dim=-1, keepdim=True)
+
+
+def clustered_centres(n, d, seed):
+    """The chained cluster centres of the reference's recall recipe (segment.rs:849-865: `center =
+    random_nearby_vector(center, 0.1)` after every cluster) — sequential by construction, so drawn on the host."""
+    rng = np.random.default_rng(seed)
+
+    def unit(*shape):
+        v = rng.uniform(-1.0, 1.0, shape).astype(np.float32)
+        return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+    n_centres = (n + PER_CLUSTER - 1) // PER_CLUSTER
+    steps = unit(n_centres, d)
+    centres = np.empty((n_centres, d), np.float32)
+    c = unit(d)
+    for j in range(n_centres):
+        centres[j] = c
+        c = c + np.float32(0.1) * steps[j]
+        c = c / np.linalg.norm(c)
+    return centres
+
+
+def gen_corpus(kind, n, d, dev, seed):
+    """-> x [n][d] f32 unit rows on the device.
+    uniform:   the generator of the reference's unit tests (segment.rs:682-695): uniform(-1, 1), normalised.
+    clustered: the reference's recall recipe (segment.rs:841-905) scaled to n: chained centres 0.1 apart, 160 vectors per
+               centre (half at radius 0.01, half at 0.03), rows in random order (the reference inserts in BTreeMap order of
+               random keys)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.empty((n, d), device=dev, dtype=torch.float32)
+    chunk = 1 << 20
+    if kind == "uniform":
+        for i0 in range(0, n, chunk):
+            i1 = min(n, i0 + chunk)
+            x[i0:i1] = _unit_rows((i1 - i0, d), g, dev)
+        return x
+    centres = torch.from_numpy(clustered_centres(n, d, seed)).to(dev)
+    radius = torch.where(torch.arange(PER_CLUSTER, device=dev) < PER_CLUSTER // 2, 0.01, 0.03).to(torch.float32)
+    perm = torch.randperm(n, generator=g, device=dev)  # row r of the shard is point perm[r] of the recipe
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        src = perm[i0:i1]
+        rows = centres[src // PER_CLUSTER] + radius[src % PER_CLUSTER][:, None] * _unit_rows((i1 - i0, d), g, dev)
+        x[i0:i1] = rows / rows.norm(dim=1, keepdim=True)
+    return x
+
+
+def gen_queries(kind, x, n_pool, B, d, dev, seed):
+    """uniform: random unit vectors; clustered: `random_nearby_vector(stored, 0.05)` of random stored vectors (segment.rs:879-882)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    if kind == "uniform":
+        return _unit_rows((n_pool, B, d), g, dev)
+    base = x[torch.randint(0, x.shape[0], (n_pool * B,), generator=g, device=dev)]
+    q = base + 0.05 * _unit_rows((n_pool * B, d), g, dev)
+    return (q / q.norm(dim=1, keepdim=True)).reshape(n_pool, B, d).contiguous()
+
+
+def serialize_graph(L, h, seg=0):
+    glen, nedges = C.c_uint64(0), C.c_uint64(0)
+    from nucliadb_amd import _lib
+    _lib.check(L.nidx_gpu_vector_serialize_hnsw(h, seg, None, 0, C.byref(glen), None, 0, C.byref(nedges)))
+    graph = np.zeros(glen.value, np.uint8)
+    edges = np.zeros(max(1, nedges.value), np.float32)
+    _lib.check(L.nidx_gpu_vector_serialize_hnsw(h, seg, graph.ctypes.data, glen.value, C.byref(glen), edges.ctypes.data, nedges.value,
+                                                C.byref(nedges)))
+    return graph, edges[: nedges.value]
+
+
+def pmc_traffic(kind, n, d, B, k):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r02_pmc_traffic.json, written by scripts/refresh_profiles.sh; counters cannot be read from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                w = e["workload"]
+                if (w["corpus"], w["n_vectors"], w["dim"], w["batch"], w["k"]) == (kind, n, d, B, k):
+                    return e["hbm_bytes_per_launch"], e["source"]
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None, None
+
+
+def hnsw_leg(a, L, dev, rank, world, kind, headline):
+    """One corpus: generate, open, build, time, count, check.  Returns the figures of this corpus (rank 0) or None."""
+    from nucliadb_amd import _lib
+    if world > 1:
+        import torch.distributed as dist
+
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    n_pool = 8
+    t0 = time.time()
+    x = gen_corpus(kind, n, d, dev, 1234567890 + rank)
+    qpool = gen_queries(kind, x, n_pool, B, d, dev, 2)
+    if world > 1:
+        dist.broadcast(qpool, src=0)  # every shard answers the same batch (the clustered queries sit near rank 0's vectors)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    cseg = _lib.VectorSegmentC(x.data_ptr(), d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))  # packed device matrix: copied device to device
+    open_s = time.time() - t0
+    # the host copy feeds the oracle legs (rank 0 of the headline corpus only): the product never reads it
+    need_host = rank == 0 and headline and (a.parity_queries > 0 or a.cpu_queries > 0 or a.scan_check_queries > 0)
+    x_host = x.cpu().numpy() if need_host else None
+    del x
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
+    build_s = time.time() - t0
+
+    out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((B, 8), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def search(qb, with_stats=False, m=_lib.METHOD_HNSW, out=None, nq=B):
+        p = _lib.VectorSearchParamsC(k, -1.0, 1, m)
+        ov, osc, oc = out if out is not None else (out_vec, out_score, out_count)
+        _lib.check(L.nidx_gpu_vector_segment_search_device(
+            h, 0, qb.data_ptr(), nq, C.byref(p), None, ov.data_ptr(), osc.data_ptr(), oc.data_ptr(),
+            stats.data_ptr() if with_stats else None, stream))
+
+    def device_flags():
+        f = C.c_uint32(0)
+        _lib.check(L.nidx_gpu_vector_device_flags(h, stream, C.byref(f)))
+        return int(f.value)
+
+    def exchange(out):
+        # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
+        from nucliadb_amd.shard_merge import exchange_and_merge_vector
+
+        ov, osc, oc = out
+        ids = (ov.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
+        return exchange_and_merge_vector(osc, ids, oc, k)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # With more than one rank a step is search + exchange.  The exchange (three small all-gathers over xGMI + the merge kernel) is
+    # latency-bound and needs none of the compute units, so it runs on a side stream from one of two result-buffer sets while
+    # the main stream already searches the next batch into the other set: search i + 1 overlaps exchange i; a buffer set is
+    # searched into again only after its exchange has finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
+    do_exchange = world > 1 or os.environ.get("NIDX_BENCH_FORCE_EXCHANGE") == "1"
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream() if do_exchange else None
+    out_sets = [(out_vec, out_score, out_count),
+                (torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count))] if do_exchange else None
+    ev_searched = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_exchanged = [torch.cuda.Event(), torch.cuda.Event()]
+    last_merged = [None]
+
+    def step(i, e0=None, e1=None):
+        if not do_exchange:
+            if e0 is not None:
+                e0.record()
+            search(qpool[i % n_pool])
+            if e1 is not None:
+                e1.record()
+            return
+        b = i & 1
+        main_stream.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
+        if e0 is not None:
+            e0.record(main_stream)
+        search(qpool[i % n_pool], out=out_sets[b])
+        if e1 is not None:
+            e1.record(main_stream)
+        ev_searched[b].record(main_stream)
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(ev_searched[b])
+            last_merged[0] = exchange(out_sets[b])
+            ev_exchanged[b].record(side_stream)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    device_flags()  # clear: the word below covers exactly the timed launches
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, ev0[i], ev1[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # every timed launch ORs the overflow flags of its queries into one device word: 0 = each launch already delivered the final,
+    # exact hits (no query would have been re-run by nidx_gpu_vector_segment_search_device_exact)
+    timed_flags = device_flags()
+    exchange_check = None
+    if do_exchange and a.steps > 0:
+        # the overlapped pipeline must give what a plain search -> exchange of the same batch gives
+        i_last = a.warmup + a.steps - 1
+        got = [t.clone() for t in last_merged[0]]
+        search(qpool[i_last % n_pool], out=out_sets[0])
+        torch.cuda.synchronize()
+        want = exchange(out_sets[0])
+        torch.cuda.synchronize()
+        exchange_check = "ok" if all(torch.equal(g_, w_) for g_, w_ in zip(got, want)) else "MISMATCH"
+        if exchange_check != "ok":
+            print("WARNING: overlapped exchange diverged from the sequential one", file=sys.stderr)
+        barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
+
+    # ---- algorithmic bytes per launch (SURVEY §8d): evals*4D + expansions*256 B, counted by the kernel
+    bytes_per_launch, evals_q, exp_q, flags = [], [], [], 0
+    for i in range(min(n_pool, max(1, a.steps))):
+        search(qpool[i], with_stats=True)
+        torch.cuda.synchronize()
+        st = stats.cpu().numpy().astype(np.int64)
+        bytes_per_launch.append(float((st[:, 0] * 4 * d + st[:, 1] * 256).sum()))
+        evals_q.append(float(st[:, 0].mean()))
+        exp_q.append(float(st[:, 1].mean()))
+        flags |= int(np.bitwise_or.reduce(st[:, 3]))
+    alg_bytes = float(np.mean(bytes_per_launch))
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(kind, n, d, B, k)
+
+    # ---- recall@k of the timed configuration against the exact scan of the same shard (merged over the shards when N > 1)
+    recall, got0, exact0 = None, None, None
+    if a.recall_queries > 0:
+        rq = min(a.recall_queries, B)
+        search(qpool[0])
+        torch.cuda.synchronize()
+        got0 = (out_vec.cpu().numpy().copy(), out_score.cpu().numpy().copy(), out_count.cpu().numpy().copy())
+        if world > 1:
+            mg = exchange((out_vec, out_score, out_count))
+            torch.cuda.synchronize()
+            got_ids = mg[1].cpu().numpy()
+        else:
+            got_ids = got0[0].astype(np.int64)
+        # exact scan (oracle-verified kernel): the first rq queries only, the rest of the buffers keep the HNSW rows
+        ev_, es_, ec_ = torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count)
+        search(qpool[0], m=_lib.METHOD_BRUTE_FORCE, out=(ev_, es_, ec_), nq=rq)
+        torch.cuda.synchronize()
+        exact0 = (ev_.cpu().numpy().copy(), es_.cpu().numpy().copy(), ec_.cpu().numpy().copy())
+        if world > 1:
+            ec_[rq:] = 0
+            me = exchange((ev_, es_, ec_))
+            torch.cuda.synchronize()
+            exact_ids = me[1].cpu().numpy()
+        else:
+            exact_ids = exact0[0].astype(np.int64)
+        recall = float(np.mean([len(set(got_ids[i][:k].tolist()) & set(exact_ids[i][:k].tolist())) / k for i in range(rq)]))
+
+    res = None
+    if rank == 0:
+        res = {
+            "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alg_bytes": alg_bytes, "achieved": achieved,
+            "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "evals": float(np.mean(evals_q)),
+            "expansions": float(np.mean(exp_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
+            "build_s": build_s, "exchange_check": exchange_check,
+        }
+    if not headline:
+        L.nidx_gpu_vector_close(h)
+        return res
+
+    # ---- serving shapes of the same batch (reported beside `value`, never as `value`) -----------------------------------------
+    extra = {}
+    if rank == 0:
+        # (1) the complete device entry: launch + one D2H of the result block + flag check (+ fallback when flagged)
+        words = B * k * 2 + B + 1
+        d_block = torch.zeros((words,), dtype=torch.int32, device=dev)
+        h_block = torch.zeros((words,), dtype=torch.int32).pin_memory()
+        p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+        retried = C.c_uint32(0)
+        reps = 10
+        for i in range(reps + 2):
+            if i == 2:
+                t1 = time.perf_counter()
+            _lib.check(L.nidx_gpu_vector_segment_search_device_exact(h, 0, qpool[i % n_pool].data_ptr(), B, C.byref(p), None, d_block.data_ptr(),
+                                                                     h_block.data_ptr(), stream, C.byref(retried)))
+        extra["exact_entry_queries_per_s"] = B * reps / (time.perf_counter() - t1)
+        # (2) host buffers in and out (queries over PCIe, Fssc on the host): nidx_gpu_vector_search
+        qh = qpool[0].cpu().numpy()
+        hv, hs_, hc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
+        for i in range(reps + 2):
+            if i == 2:
+                t1 = time.perf_counter()
+            _lib.check(L.nidx_gpu_vector_search(h, qh.ctypes.data, B, C.byref(p), None, None, None, hv.ctypes.data,
+                                                hs_.ctypes.data, hc.ctypes.data, None))
+        extra["host_buffer_queries_per_s"] = B * reps / (time.perf_counter() - t1)
+        if got0 is not None:
+            extra["host_buffer_equals_device_entry"] = bool(np.array_equal(hv, got0[0].view(np.uint32)) and np.array_equal(hs_.view(np.uint32), got0[1].view(np.uint32)))
+        # (3) the reference's request shape: one query per call from many blocking threads (shard_search.rs:139-153),
+        # coalesced into batched launches by csrc/coalescer.cpp
+        if a.single_query_calls > 0:
+            extra["single_query"] = single_query_latency(a, L, h, qpool.reshape(-1, d).cpu().numpy())
+
+    # ---- oracle legs (rank 0): bit parity at this scale, then the CPU baseline ------------------------------------------------
+    parity, cpu = None, None
+    if rank == 0 and x_host is not None:
+        try:
+            parity, cpu = oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind)
+        except Exception as e:  # side legs: their failure must not cost the measured line
+            print("WARNING: oracle legs failed: %r" % (e,), file=sys.stderr)
+            parity = {"status": "failed: %r" % (e,)}
+    L.nidx_gpu_vector_close(h)
+    if res is not None:
+        res.update({"extra": extra, "parity": parity, "cpu": cpu})
+    return res
+
+
+def single_query_latency(a, L, h, queries):
+    """nidx_gpu_vector_search_one from 64 blocking threads (ctypes releases the GIL during the call)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nucliadb_amd import _lib
+
+    d, k = a.dim, a.k
+    threads = 64
+    calls = min(a.single_query_calls, queries.shape[0])
+    p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+
+    def one(i):
+        ov, os_, oseg, opar = np.zeros(k, np.uint32), np.zeros(k, np.float32), np.zeros(k, np.uint32), np.zeros(k, np.uint32)
+        cnt = C.c_uint32(0)
+        t = time.perf_counter()
+        _lib.check(L.nidx_gpu_vector_search_one(h, queries[i].ctypes.data, d, C.byref(p), oseg.ctypes.data, opar.ctypes.data,
+                                                ov.ctypes.data, os_.ctypes.data, C.byref(cnt)))
+        return time.perf_counter() - t
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(min(threads, calls))))
+        t0 = time.perf_counter()
+        lat = np.array(list(ex.map(one, range(calls))))
+        dt = time.perf_counter() - t0
+    b, q = C.c_uint64(0), C.c_uint64(0)
+    L.nidx_gpu_vector_coalescer_stats(h, C.byref(b), C.byref(q))
+    return {"threads": threads, "calls": calls, "p50_ms": float(np.percentile(lat, 50) * 1e3), "p99_ms": float(np.percentile(lat, 99) * 1e3),
+            "queries_per_s": calls / dt, "queries_per_launch": (q.value / b.value) if b.value else None,
+            "note": "callers are Python threads: the figure includes ctypes + GIL hand-over per call"}
+
+
+def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
+    """(parity, cpu_baseline) for the headline corpus.  Test infrastructure on the host cores; nothing here is timed as `value`."""
+    from nucliadb_amd import _lib
+    from oracle import oracle as orc
+
+    orc.build()
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    threads = a.cpu_threads or min(64, os.cpu_count() or 1)
+    t0 = time.time()
+    graph, edges = serialize_graph(L, h)
+    og = orc.Hnsw.deserialize_v2(graph, edges)
+    del graph, edges
+    graph_s = time.time() - t0
+    q0 = qpool[0].cpu().numpy()
+    parity = {"graph_roundtrip_s": graph_s}
+    # ---- (1) the timed kernel against the oracle on the same device-built graph: ids, ranks and score BITS, WAVE64 order
+    if a.parity_queries > 0 and got0 is not None:
+        nq = min(a.parity_queries, B)
+        oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_WAVE64, graph=og)
+        ov, os_, oc = oseg.hnsw_search_batch(q0[:nq], k, threads=threads)
+        gv, gs, gc = got0
+        same = [bool(oc[i] == gc[i] and np.array_equal(ov[i, : oc[i]], gv[i, : oc[i]].view(np.uint32)) and
+                     np.array_equal(os_[i, : oc[i]].view(np.uint32), gs[i, : oc[i]].view(np.uint32))) for i in range(nq)]
+        parity["hnsw_vs_oracle"] = {"queries": nq, "identical_ids_ranks_score_bits": int(sum(same)),
+                                    "status": "ok" if all(same) else "MISMATCH", "oracle_order": "WAVE64",
+                                    "reference": "nidx_vector/src/hnsw/search.rs:242-383"}
+        if not all(same):
+            print("WARNING: device HNSW results differ from the oracle's on %d of %d queries" % (nq - sum(same), nq), file=sys.stderr)
+    # ---- (2) the recall ground truth (exact scan kernel) against orc_brute_force_search
+    if a.scan_check_queries > 0 and exact0 is not None:
+        nq = min(a.scan_check_queries, a.recall_queries, B)
+        oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_WAVE64)
+        ov, os_, oc = oseg.brute_force_batch(q0[:nq], k, threads=min(threads, nq))
+        ev, es, ec = exact0
+        same = [bool(oc[i] == ec[i] and np.array_equal(ov[i, : oc[i]], ev[i, : oc[i]].view(np.uint32)) and
+                     np.array_equal(os_[i, : oc[i]].view(np.uint32), es[i, : oc[i]].view(np.uint32))) for i in range(nq)]
+        parity["exact_scan_vs_oracle"] = {"queries": nq, "identical_ids_ranks_score_bits": int(sum(same)),
+                                          "status": "ok" if all(same) else "MISMATCH", "reference": "nidx_vector/src/segment.rs:569-623"}
+    # ---- (3) CPU baseline, flat: the oracle's HNSW search over the same (device-built) graph, AVX2-shaped sums,
+    # one query per POSIX thread (the reference serves one request per blocking thread, shard_search.rs:139-153)
+    cpu = None
+    if a.cpu_queries > 0:
+        qs = qpool.reshape(-1, d)[: a.cpu_queries].cpu().numpy()
+        oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL, graph=og)
+        oseg.hnsw_search_batch(qs[:threads], k, threads=threads)  # warm
+        t0 = time.perf_counter()
+        cv, cs, cc, cst = oseg.hnsw_search_batch(qs, k, threads=threads, want_stats=True)
+        dt = time.perf_counter() - t0
+        cpu = {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": "%d queries of the timed pool over the same %d x %d %s shard and device-built graph, oracle (C restatement of the "
+                         "reference algorithm, AVX2-shaped f32 sums), one query per POSIX thread; flat = ONE segment" % (qs.shape[0], n, d, kind),
+               "distance_evals_per_query": float(cst[:, 0].mean())}
+        if got0 is not None:
+            m = min(B, qs.shape[0])
+            cpu["recall_vs_device_ids"] = float(np.mean([len(set(cv[i, : cc[i]].tolist()) & set(got0[0][i, : got0[2][i]].view(np.uint32).tolist())) / k for i in range(m)]))
+    del og
+    # ---- (4) CPU baseline in the reference's own regime: segments of <= 200 k records searched one after the other and merged
+    # by Fssc (searcher.rs:270-287; the cap: src/settings.rs:258-278).  Graphs of the segments: device-built, like the flat one.
+    if a.cpu_queries > 0 and a.segment_regime > 0 and n > a.segment_regime:
+        try:
+            cpu["segment_regime"] = segment_regime_leg(a, L, x_host, qpool, kind, threads)
+        except Exception as e:
+            cpu["segment_regime"] = {"status": "failed: %r" % (e,)}
+    # ---- (5) recall of the reference's sequential HnswBuilder vs the device's batch-synchronous build, same data and queries
+    if a.ref_build_n > 0:
+        try:
+            parity["build_recall"] = build_recall_leg(a, L, threads)
+        except Exception as e:
+            parity["build_recall"] = {"status": "failed: %r" % (e,)}
+    return parity, cpu
+
+
+def segment_regime_leg(a, L, x_host, qpool, kind, threads):
+    from nucliadb_amd import _lib
+    from oracle import oracle as orc
+
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    cap = a.segment_regime
+    bounds = list(range(0, n, cap)) + [n]
+    S = len(bounds) - 1
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    csegs = (_lib.VectorSegmentC * S)()
+    for s in range(S):
+        rows = x_host[bounds[s]: bounds[s + 1]]
+        csegs[s] = _lib.VectorSegmentC(rows.ctypes.data, d * 4, rows.shape[0], None, rows.shape[0], None, 0, 0, None, 0, None, None)
+    hs = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), csegs, S, C.byref(hs)))
+    t0 = time.time()
+    osegs = []
+    for s in range(S):
+        _lib.check(L.nidx_gpu_vector_build_hnsw(hs, s, 2))
+        g, e = serialize_graph(L, hs, s)
+        osegs.append(orc.Segment(x_host[bounds[s]: bounds[s + 1]], similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL,
+                                 graph=orc.Hnsw.deserialize_v2(g, e)))
+    build_s = time.time() - t0
+    # the device on the same segmented index through the host-buffer API (sequential segments + Fssc on the host)
+    qh = qpool[0].cpu().numpy()
+    p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+    hv, hsc, hc, hsg = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32), np.zeros((B, k), np.uint32)
+    for i in range(3):
+        if i == 1:
+            t1 = time.perf_counter()
+        _lib.check(L.nidx_gpu_vector_search(hs, qh.ctypes.data, B, C.byref(p), None, hsg.ctypes.data, None, hv.ctypes.data, hsc.ctypes.data,
+                                            hc.ctypes.data, None))
+    gpu_qps = B * 2 / (time.perf_counter() - t1)
+    L.nidx_gpu_vector_close(hs)
+    nq = min(a.cpu_queries, max(threads * 4, 512))
+    qs = qpool.reshape(-1, d)[:nq].cpu().numpy()
+    orc.searcher_search_batch(osegs, qs[:threads], k, threads=threads)
+    t0 = time.perf_counter()
+    sg, sv, ss, sc = orc.searcher_search_batch(osegs, qs, k, with_duplicates=True, threads=threads)
+    dt = time.perf_counter() - t0
+    m = min(B, nq)
+    same = int(sum(bool(sc[i] == hc[i] and np.array_equal(sg[i, : sc[i]], hsg[i, : sc[i]]) and np.array_equal(sv[i, : sc[i]], hv[i, : sc[i]]))
+                   for i in range(m)))
+    return {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
+            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
+            "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
+            "device_ids_identical_to_oracle": "%d/%d (the timed baseline sums in AVX2 order, the device in WAVE64 order: near-ties may flip)" % (same, m)}
+
+
+def build_recall_leg(a, L, threads):
+    """HnswBuilder parity is recall (the reference's rayon build is not deterministic): the oracle's sequential build
+    (hnsw/build.rs:57-166 restated) and the device's batch-synchronous build of the same clustered segment, both searched
+    by the oracle with the same queries, against the oracle's brute force."""
+    from nucliadb_amd import _lib
+    from oracle import oracle as orc
+
+    n, d, k = a.ref_build_n, a.dim, a.k
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = gen_corpus("clustered", n, d, dev, 99)
+    nq = 256
+    q = gen_queries("clustered", x, 1, nq, d, dev, 3)[0].cpu().numpy()
+    xh = x.cpu().numpy()
+    del x
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    cseg = _lib.VectorSegmentC(xh.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
+    dev_build_s = time.time() - t0
+    g, e = serialize_graph(L, h)
+    L.nidx_gpu_vector_close(h)
+    oseg = orc.Segment(xh, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL)
+    ev, _, ec = oseg.brute_force_batch(q, k, threads=threads)
+    oseg.graph = orc.Hnsw.deserialize_v2(g, e)
+    dv, _, dc = oseg.hnsw_search_batch(q, k, threads=threads)
+    t0 = time.time()
+    oseg.build_graph(2)
+    ref_build_s = time.time() - t0
+    rv, _, rc = oseg.hnsw_search_batch(q, k, threads=threads)
+
+    def rec(v, c):
+        return float(np.mean([len(set(v[i, : c[i]].tolist()) & set(ev[i, : ec[i]].tolist())) / k for i in range(nq)]))
+
+    return {"vectors": n, "queries": nq, "recall_at_%d_device_build" % k: rec(dv, dc), "recall_at_%d_reference_sequential_build" % k: rec(rv, rc),
+            "device_build_s": dev_build_s, "reference_sequential_build_s": ref_build_s,
+            "note": "clustered recipe; both graphs searched by the oracle (ef = 30) against the oracle's brute force"}
+
+
+def bench_hnsw(a, L, dev, rank, world):
+    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
+    kinds = ["clustered", "uniform"] if a.corpus == "both" else [a.corpus]
+    head = hnsw_leg(a, L, dev, rank, world, kinds[0], True)
+    second = hnsw_leg(a, L, dev, rank, world, kinds[1], False) if len(kinds) > 1 else None
+    if rank != 0:
+        return
+    total_q = world * B * a.steps
+    extra = head.get("extra") or {}
+    cfgd = {
+        "workload": "hnsw: %d x %d-dim cosine (%s corpus), k=%d, batch=%d queries, 1 shard per GPU" % (n, d, head["corpus"], k, B),
+        "corpus": head["corpus"] + (": the reference's recall recipe (nidx_vector/src/segment.rs:841-905) scaled to the shard: chained centres 0.1 apart, "
+                                    "160 vectors per centre at radius 0.01 / 0.03, queries = stored vector + 0.05 noise" if head["corpus"] == "clustered" else
+                                    ": uniform(-1,1) normalised (segment.rs:682-695)"),
+        "vectors_per_shard": n, "dim": d, "batch": B, "k": k, "shards": world, "corpus_vectors": n * world,
+        "merged_queries_per_s": B * a.steps / head["elapsed"],
+        "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B),
+        "distance_evals_per_query": head["evals"], "expansions_per_query": head["expansions"],
+        "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"],
+        "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"],
+        "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],
+        "parity": head.get("parity"),
+    }
+    cfgd.update(extra)
+    if second is not None:
+        cfgd["uniform_corpus" if second["corpus"] == "uniform" else "second_corpus"] = {
+            "workload": "hnsw: %d x %d-dim cosine (%s corpus), k=%d, batch=%d queries" % (n, d, second["corpus"], k, B),
+            "queries_per_s": total_q / second["elapsed"], "ms_per_step": second["elapsed"] / a.steps * 1e3,
+            "recall_at_%d" % k: second["recall"], "distance_evals_per_query": second["evals"], "expansions_per_query": second["expansions"],
+            "kernel_flags": second["flags"], "timed_launch_flags": second["timed_flags"], "hnsw_build_s": second["build_s"],
+            "roofline": {"achieved": second["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": second["achieved"] / HBM_PEAK_GBS,
+                         "traffic": second["traffic"], "algorithmic_bytes_per_launch": second["alg_bytes"], "kernel_ms": second["kernel_ms"]},
+            "note": "uniform random 768-d unit vectors have no neighbourhood structure (all pairwise cosines within +-0.1): ef = 30 cannot "
+                    "find the exact top-10 among near-ties, for the reference either; it is the worst-case access pattern (every neighbour unvisited)",
+        }
+    line = {
+        "metric": "queries/sec + recall@%d (768-dim cosine k-NN, HNSW M=30 ef=30, k=%d)" % (k, k),
+        "value": total_q / head["elapsed"],
+        "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["elapsed"] / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": cfgd,
+        "roofline": {"kernel": "hnsw_search_kernel<3,2,4,1>", "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": head["achieved"] / HBM_PEAK_GBS, "traffic": head["traffic"], "traffic_source": head["traffic_src"],
+                     "algorithmic_bytes_per_launch": head["alg_bytes"], "kernel_ms": head["kernel_ms"],
+                     "gather_ceiling": gather_ceiling()},
+        "cpu_baseline": head.get("cpu"),
+    }
+    print(json.dumps(line))
+
+
+def gather_ceiling():
+    """The measured ceiling this kernel's access pattern has on the box: random 3-KiB-row gathers, read only
+    (profiles/r02_gather_ceiling.json, written by bench.py --workload gather)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_gather_ceiling.json")) as f:
+            j = json.load(f)
+        return {"GBps": j["best_GBps"], "source": "profiles/r02_gather_ceiling.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+
+def bench_gather(a, L, dev, rank):
+    """Calibration of the HBM roofline claim: read-only random gathers of 4*dim-byte rows over an n_vectors x dim matrix (no
+    traversal, no arithmetic beyond a fold), swept over wavefronts in flight and rows in flight per wave.  The best rate is
+    the gather ceiling of this box; copy it to profiles/r02_gather_ceiling.json."""
+    from nucliadb_amd import _lib
+
+    n, d = a.n_vectors, a.dim
+    x = torch.empty((n, d), device=dev, dtype=torch.float32)
+    chunk = 1 << 20
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    for i0 in range(0, n, chunk):
+        x[i0:i0 + chunk] = torch.rand((min(chunk, n - i0), d), generator=g, device=dev, dtype=torch.float32)
+    torch.cuda.synchronize()
+    sweep = []
+    for waves in (4096, 8192, 16384, 32768):
+        for rif in (1, 2, 4, 8):
+            gpw = max(64, (1 << 22) // waves)  # ~4 M row gathers (12.9 GB at 768 dims) per launch
+            ms = C.c_float(0)
+            _lib.check(L.nidx_gpu_diag_gather(x.data_ptr(), n, d, waves, gpw, rif, 5, C.byref(ms)))
+            gbps = waves * gpw * d * 4 / (ms.value * 1e-3) / 1e9
+            sweep.append({"waves": waves, "rows_in_flight": rif, "gathers_per_wave": gpw, "ms": ms.value, "GBps": gbps,
+                          "rows_per_s": waves * gpw / (ms.value * 1e-3)})
+    # the same sweep confined to a 256 MiB window (what the L2 / MALL can hold): the cached ceiling
+    m = min(n, (256 << 20) // (d * 4))
+    cached = []
+    for rif in (2, 4, 8):
+        ms = C.c_float(0)
+        _lib.check(L.nidx_gpu_diag_gather(x.data_ptr(), m, d, 16384, 256, rif, 5, C.byref(ms)))
+        cached.append({"rows_in_flight": rif, "GBps": 16384 * 256 * d * 4 / (ms.value * 1e-3) / 1e9})
+    best = max(sweep, key=lambda r: r["GBps"])
+    if rank == 0:
+        print(json.dumps({"metric": "random row-gather rate (read only)", "value": best["GBps"], "unit": "GB/s", "n_gpus": 1,
+                          "config": {"workload": "gather: %d x %d f32 rows (%.1f GB), %d-byte rows, uniform random row numbers" % (n, d, n * d * 4 / 1e9, d * 4)},
+                          "best_GBps": best["GBps"], "best": best, "frac_of_8TBps": best["GBps"] / HBM_PEAK_GBS, "sweep": sweep,
+                          "cached_256MiB_window": cached}))
 
 
 def zipf_corpus_on_device(L, dev, n_docs, vocab, rank):
@@ -739,99 +1324,22 @@ def bench_rabitq(a, L, dev, rank, world):
             "cpu_baseline": cpu}))
 
 
-def clustered_recall(a, L, dev):
-    from nucliadb_amd import _lib
-
-    n, d, k = a.clustered_n, a.dim, a.k
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234567890)
-
-    def unit(*shape):
-        v = torch.rand(shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1
-        return v / v.norm(dim=-1, keepdim=True)
-
-    per = 160
-    n_centres = (n + per - 1) // per
-    steps = unit(n_centres, d)
-    centres = torch.empty((n_centres, d), device=dev)
-    c = unit(d)
-    for j in range(n_centres):
-        centres[j] = c
-        c = c + 0.1 * steps[j]
-        c = c / c.norm()
-    radius = torch.where(torch.arange(per, device=dev) < per // 2, 0.01, 0.03).repeat(n_centres)[:n]
-    x = centres.repeat_interleave(per, dim=0)[:n] + radius[:, None] * unit(n, d)
-    x = x / x.norm(dim=1, keepdim=True)
-    x = x[torch.randperm(n, generator=g, device=dev)]
-    nq = min(1024, a.batch)
-    base = x[torch.randint(0, n, (nq,), generator=g, device=dev)]
-    q = base + 0.05 * unit(nq, d)
-    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
-    xh = x.cpu().numpy()
-    del x
-    cfg = _lib.VectorConfigC(d, 1, 0, 0)
-    cseg = _lib.VectorSegmentC(xh.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
-    h = C.c_void_p()
-    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
-    t0 = time.time()
-    _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
-    build_s = time.time() - t0
-    ov = torch.zeros((nq, k), dtype=torch.int32, device=dev)
-    os_ = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-    oc = torch.zeros((nq,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    res = {}
-    st = torch.zeros((nq, 8), dtype=torch.int32, device=dev)
-    for name, m in (("hnsw", _lib.METHOD_HNSW), ("exact", _lib.METHOD_BRUTE_FORCE)):
-        p = _lib.VectorSearchParamsC(k, -1.0, 1, m)
-        _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, q.data_ptr(), nq, C.byref(p), None, ov.data_ptr(), os_.data_ptr(),
-                                                           oc.data_ptr(), st.data_ptr(), stream))
-        torch.cuda.synchronize()
-        res[name] = ov.cpu().numpy().copy()
-        if name == "hnsw" and int(st[:, 3].max().item()) != 0:
-            raise RuntimeError("HNSW kernel raised overflow flags on the clustered shard: %d" % int(st[:, 3].max().item()))
-    L.nidx_gpu_vector_close(h)
-    rec = float(np.mean([len(set(res["hnsw"][i]) & set(res["exact"][i])) / k for i in range(nq)]))
-    return rec, build_s
-
-
 def cpu_baseline(a, L, h, x_host, q0, q1):
-    """The oracle's HNSW search (oracle/nidx_oracle.c, reference constants) over the SAME graph the
-    device built, one query per thread (the reference serves one request per blocking thread,
-    shard_search.rs:139-153), on a bounded sample."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    """Exact-scan workloads: the oracle's brute_force_search (segment.rs:569-623 restated, AVX2-shaped sums) over the same
+    shard, one query per POSIX thread, on a bounded sample (one query per thread)."""
     from oracle import oracle as orc
 
     orc.build()
     n, d, k = a.n_vectors, a.dim, a.k
     threads = a.cpu_threads or min(64, os.cpu_count() or 1)
-    if a.workload == "hnsw":
-        glen, nedges = C.c_uint64(0), C.c_uint64(0)
-        L.nidx_gpu_vector_serialize_hnsw(h, 0, None, 0, C.byref(glen), None, 0, C.byref(nedges))
-        graph = np.zeros(glen.value, np.uint8)
-        edges = np.zeros(max(1, nedges.value), np.float32)
-        L.nidx_gpu_vector_serialize_hnsw(h, 0, graph.ctypes.data, glen.value, C.byref(glen), edges.ctypes.data, nedges.value, C.byref(nedges))
-        og = orc.Hnsw.deserialize_v2(graph, edges[: nedges.value])
-    else:
-        og = None
-    oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL, graph=og)
-    qs = np.vstack([q0, q1])
-    nq = min(a.cpu_queries if a.workload == "hnsw" else threads, qs.shape[0])
-
-    def one(i):
-        if a.workload == "hnsw":
-            return oseg.hnsw_search(qs[i], k)
-        return oseg.brute_force(qs[i], k)
-
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, range(min(threads, nq))))  # warm the page cache / thread pool
-        t0 = time.perf_counter()
-        list(ex.map(one, range(nq)))
-        dt = time.perf_counter() - t0
-    return {"value": nq / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": "%d queries of the same batch over the same %d x %d shard%s, oracle (C restatement of the reference "
-                      "algorithm, AVX2-shaped f32 sums), one query per thread" % (nq, n, d, " and device-built graph" if og else "")}
+    oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL)
+    qs = np.vstack([q0, q1])[:threads]
+    t0 = time.perf_counter()
+    oseg.brute_force_batch(qs, k, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": "%d queries of the same batch over the same %d x %d shard, oracle brute force (C restatement of the reference "
+                      "algorithm, AVX2-shaped f32 sums), one query per thread" % (qs.shape[0], n, d)}
 
 
 if __name__ == "__main__":

@@ -80,7 +80,8 @@ typedef struct {
 typedef struct {
     /* vectors.bin (data_store/v2/vector_store.rs:30-40,131-147): n_vectors rows, each
      * `dimension` f32 LE followed — when row_stride_bytes == 4*dimension+4 — by the u32
-     * paragraph address.  A packed [n][dimension] f32 matrix is row_stride_bytes == 4*dimension. */
+     * paragraph address.  A packed [n][dimension] f32 matrix is row_stride_bytes == 4*dimension; a packed matrix
+     * may also be a DEVICE pointer (the copy into the index is then device to device). */
     const void *vectors;
     uint64_t row_stride_bytes;
     uint32_t n_vectors;
@@ -235,6 +236,32 @@ int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, ui
                                               const uint64_t *d_filter, uint32_t *d_out_vector,
                                               float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats,
                                               void *stream);
+
+/* Every launch made through nidx_gpu_vector_segment_search_device ORs the NIDX_FLAG_* its queries raised (a bounded on-chip
+ * structure overflowed: the answer of that query needs the exact fallback) into one device word.  This call reads and clears it
+ * (it synchronises `stream`): 0 = every launch since the previous call already produced the final, exact hits, which is what a
+ * serving loop polls once per delivery instead of reading n_queries x 8 counters back.  Flagged launches are repeated through
+ * nidx_gpu_vector_segment_search_device_exact. */
+int32_t nidx_gpu_vector_device_flags(nidx_gpu_vector_index_t *index, void *stream, uint32_t *flags_out);
+
+/* OpenSegment::search on one segment, device-resident queries, complete: the launch, ONE device-to-host transfer of the result
+ * block, and — only when the block's flag word is set — the re-run of the flagged queries with the 2^15 visited table /
+ * the HBM-resident closest_up_nodes walk (the reference's heap and visited set are unbounded, hnsw/search.rs:188-304).
+ *   d_out_block     device, n_queries*k u32 vectors | n_queries*k f32 scores | n_queries u32 counts | 1 u32 flag word
+ *   host_out_block  NULL or pinned host memory of the same size: receives the block (the call returns with it filled)
+ *   n_retried_out   NULL or the number of queries that took the fallback
+ * Synchronous on `stream`. */
+int32_t nidx_gpu_vector_segment_search_device_exact(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,
+                                                    uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
+                                                    const uint64_t *d_filter, uint32_t *d_out_block, uint32_t *host_out_block,
+                                                    void *stream, uint32_t *n_retried_out);
+
+/* Measurement probe (no reference counterpart): read-only random gathers of whole `dimension`-float rows from a device matrix —
+ * the row access of the HNSW kernels without any traversal — `waves` wavefronts x `gathers_per_wave` rows, `rows_in_flight`
+ * (1, 2, 4, 8) rows requested per wave before the first is consumed.  ms_out = average launch time over `repeats` launches after
+ * one warm-up; rows x 4*dimension / time is the measured gather ceiling bench.py quotes beside the roofline fraction. */
+int32_t nidx_gpu_diag_gather(const float *d_rows, uint32_t n_rows, uint32_t dimension, uint32_t waves, uint32_t gathers_per_wave,
+                             int32_t rows_in_flight, uint32_t repeats, float *ms_out);
 
 /* One query per call, the shape of the reference's request path (one blocking thread per Search request,
  * src/searcher/shard_search.rs:139-153; one vector per request, nodereader.proto:402).  Thread safe:

@@ -201,6 +201,12 @@ SIGNATURES = {
     "nidx_gpu_vector_segment_search_device": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                                           C.POINTER(VectorSearchParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_diag_gather": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32,
+                                         C.POINTER(C.c_float)]),
+    "nidx_gpu_vector_device_flags": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_segment_search_device_exact": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                                C.POINTER(VectorSearchParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_vector_search_one": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_vector_spill_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -1,0 +1,91 @@
+// diag.hip — measurement probes (no reference counterpart): what the box can do on the access pattern of the HNSW kernels.
+//
+// gather_probe_kernel: read-only random gathers of whole rows (NJ x 1 KiB, 16 B per lane — the row access of eval_neighbours,
+// hnsw_device.h) from a matrix in HBM, independent of any traversal: every wave draws its row numbers from a counter hash, keeps
+// R rows in flight, folds what it read into one word so the loads cannot be dropped.  rows/s x row bytes is the ceiling the
+// HBM-bound roofline fraction of hnsw_search_kernel should be read against (a float4 COPY reaches 6.3 TB/s on this
+// part because half of its traffic is writes; a pure gather has no write stream).
+#include "device_common.h"
+#include "host_common.h"
+#include "kernels.h"
+
+namespace nidx {
+
+__device__ inline uint32_t probe_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <int NJ, int R>
+__global__ __launch_bounds__(256) void gather_probe_kernel(const float *rows, uint32_t n, uint32_t dp, uint32_t gathers_per_wave,
+                                                           uint32_t seed, float *sink) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float acc = 0.f;
+    for (uint32_t g = 0; g < gathers_per_wave; g += R) {
+        float4 v[R][NJ];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            // wave-uniform row number (readfirstlane keeps the address arithmetic scalar, as in the search kernel)
+            const uint32_t id = __builtin_amdgcn_readfirstlane(probe_hash(seed ^ (wave * 0x9e3779b9u + g + (uint32_t)r)) % n);
+            const float *row = rows + (size_t)id * dp;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) v[r][j] = load_row_chunk(row, dp, j, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc += v[r][j].x + v[r][j].y + v[r][j].z + v[r][j].w;
+    }
+    if (acc == 12345.678f) sink[wave] = acc;  // never true for the probe's data; keeps the loads alive
+}
+
+template <int NJ>
+static hipError_t launch_probe(const float *rows, uint32_t n, uint32_t dp, uint32_t waves, uint32_t gathers_per_wave, int in_flight,
+                               uint32_t seed, float *sink, hipStream_t s) {
+    const dim3 grid((waves + 3) / 4), block(256);
+    switch (in_flight) {
+        case 1: hipLaunchKernelGGL((gather_probe_kernel<NJ, 1>), grid, block, 0, s, rows, n, dp, gathers_per_wave, seed, sink); break;
+        case 2: hipLaunchKernelGGL((gather_probe_kernel<NJ, 2>), grid, block, 0, s, rows, n, dp, gathers_per_wave, seed, sink); break;
+        case 4: hipLaunchKernelGGL((gather_probe_kernel<NJ, 4>), grid, block, 0, s, rows, n, dp, gathers_per_wave, seed, sink); break;
+        default: hipLaunchKernelGGL((gather_probe_kernel<NJ, 8>), grid, block, 0, s, rows, n, dp, gathers_per_wave, seed, sink); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nidx
+
+using namespace nidx;
+
+extern "C" int32_t nidx_gpu_diag_gather(const float *d_rows, uint32_t n_rows, uint32_t dimension, uint32_t waves, uint32_t gathers_per_wave,
+                                        int32_t rows_in_flight, uint32_t repeats, float *ms_out) try {
+    if (!d_rows || !ms_out || n_rows == 0 || waves == 0 || gathers_per_wave == 0 || repeats == 0)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "bad probe arguments");
+    if (dimension & 3u) return fail(NIDX_ERR_UNSUPPORTED, "the probe reads 16 B per lane: dimension must be a multiple of 4");
+    if (rows_in_flight != 1 && rows_in_flight != 2 && rows_in_flight != 4 && rows_in_flight != 8)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "rows_in_flight must be 1, 2, 4 or 8");
+    const uint32_t nj = (dimension + 255u) / 256u;
+    if (nj != 3 && nj != 4) return fail(NIDX_ERR_UNSUPPORTED, "the probe is built for 513..1024-dimensional rows");
+    gathers_per_wave = (gathers_per_wave + 7u) & ~7u;
+    DevBuf sink;
+    NIDX_HIP(sink.alloc((size_t)((waves + 3) / 4) * 4 * 4));
+    hipEvent_t e0, e1;
+    NIDX_HIP(hipEventCreate(&e0));
+    NIDX_HIP(hipEventCreate(&e1));
+    hipError_t err = hipSuccess;
+    for (uint32_t r = 0; r < repeats + 1 && err == hipSuccess; r++) {
+        if (r == 1) err = hipEventRecord(e0, nullptr);  // first launch = warm-up
+        if (err == hipSuccess)
+            err = nj == 3 ? launch_probe<3>(d_rows, n_rows, dimension, waves, gathers_per_wave, rows_in_flight, 1000u + r, sink.as<float>(), nullptr)
+                          : launch_probe<4>(d_rows, n_rows, dimension, waves, gathers_per_wave, rows_in_flight, 1000u + r, sink.as<float>(), nullptr);
+    }
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    NIDX_HIP(err);
+    *ms_out = ms / (float)repeats;
+    return NIDX_OK;
+} NIDX_ABI_CATCH

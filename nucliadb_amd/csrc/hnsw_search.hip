@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
             if (lane == 0) {
                 a.dump_count[qi] = (uint32_t)res.len;
                 if (a.stats) a.stats[(size_t)qi * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS] = st.flags;
+                if (st.flags && a.flag_word) atomicOr(a.flag_word, st.flags);
             }
         }
         return;
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
         }
         if (lane == 0) {
             a.out_count[qi] = (uint32_t)n_res;
+            if (st.flags && a.flag_word) atomicOr(a.flag_word, st.flags);
             if (a.stats && entry_mode) {
                 // the RaBitQ kernel's counters stay; only overflow flags are added
                 a.stats[(size_t)qi * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS] |= st.flags;

@@ -166,6 +166,9 @@ struct HnswSearchArgs {
     uint32_t *dump_vec;
     float *dump_score;
     uint32_t *dump_count;
+    // nullptr or [1]: every query that raises a NIDX_FLAG_* ORs it in here too (one atomic, only when a flag was raised), so
+    // a caller that did not ask for per-query counters can tell with one word whether the launch needs the exact fallback
+    uint32_t *flag_word = nullptr;
 };
 #define NIDX_DUMP_STRIDE 256
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
@@ -227,6 +230,7 @@ struct RabitqSearchArgs {
     float *out_score;
     uint32_t *out_count;
     uint32_t *stats;          // nullptr or [n_queries][NIDX_STAT_STRIDE]: estimates, expansions, rows re-ranked, flags
+    uint32_t *flag_word = nullptr;  // nullptr or [1]: OR of the flags any query raised (see HnswSearchArgs)
 };
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s);
 hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,

@@ -815,6 +815,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         rr.feed(ok, addr, ub, lane);
     }
     rr.write(a.out_vec + (size_t)qi * a.k, a.out_score + (size_t)qi * a.k, a.out_count + qi, lane);
+    if (flags && a.flag_word && lane == 0) atomicOr(a.flag_word, flags);
     if (a.stats && lane == 0) {
         uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
         o[NIDX_STAT_EVALS] = n_est;

@@ -212,8 +212,10 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
     if (in.n_vectors > 0) {
         NIDX_HIP(seg.vectors.alloc((size_t)in.n_vectors * seg.dp * 4));
         if (seg.dp != d) NIDX_HIP(hipMemset(seg.vectors.p, 0, seg.vectors.bytes));
+        // hipMemcpyDefault: a packed matrix may already live in device memory (a shard produced on the GPU); rows with the
+        // 4-byte trailer are the mmap'd vectors.bin and are read by the host above
         NIDX_HIP(hipMemcpy2D(seg.vectors.p, (size_t)seg.dp * 4, in.vectors, in.row_stride_bytes, packed, in.n_vectors,
-                             hipMemcpyHostToDevice));
+                             hipMemcpyDefault));
         NIDX_HIP(seg.norm2.alloc((size_t)((in.n_vectors + 7u) & ~7u) * 4));  // padded: the shared-row scan copies 8 norms per tile
         NIDX_HIP(launch_row_norms(seg.vectors.as<float>(), seg.n, seg.dp, seg.norm2.as<float>(), stream));
     }
@@ -365,9 +367,40 @@ int32_t VectorIndex::segment_spill_search(uint32_t s, const float *d_queries, ui
 int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                            bool with_duplicates, int method, const uint64_t *d_filter,
                                            uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,
-                                           uint32_t *d_stats, uint32_t vis_log2, hipStream_t st) {
+                                           uint32_t *d_stats, uint32_t vis_log2, hipStream_t st, uint32_t *d_flag_word) {
     VectorSegment &seg = segs[s];
     if (nq == 0) return NIDX_OK;
+    if ((method == NIDX_METHOD_HNSW || method == NIDX_METHOD_RABITQ_HNSW) && !seg.has_graph)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no HNSW graph", s);
+    if (method != NIDX_METHOD_HNSW) {
+        // every other method stages through index-owned scratch: order this call behind the previous user's work
+        int32_t rc = scratch_acquire(st);
+        if (rc != NIDX_OK) return rc;
+        rc = segment_search_device_scratch(s, d_queries, nq, k, min_score, with_duplicates, method, d_filter, d_out_vec, d_out_score,
+                                           d_out_count, d_stats, vis_log2, st, d_flag_word);
+        const int32_t rc2 = scratch_release(st);
+        return rc != NIDX_OK ? rc : rc2;
+    }
+    return segment_search_device_scratch(s, d_queries, nq, k, min_score, with_duplicates, method, d_filter, d_out_vec, d_out_score,
+                                         d_out_count, d_stats, vis_log2, st, d_flag_word);
+}
+
+int32_t VectorIndex::scratch_acquire(hipStream_t st) {
+    if (scratch_event_recorded) NIDX_HIP(hipStreamWaitEvent(st, scratch_event, 0));
+    return NIDX_OK;
+}
+int32_t VectorIndex::scratch_release(hipStream_t st) {
+    if (!scratch_event) NIDX_HIP(hipEventCreateWithFlags(&scratch_event, hipEventDisableTiming));
+    NIDX_HIP(hipEventRecord(scratch_event, st));
+    scratch_event_recorded = true;
+    return NIDX_OK;
+}
+
+int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
+                                                   bool with_duplicates, int method, const uint64_t *d_filter,
+                                                   uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,
+                                                   uint32_t *d_stats, uint32_t vis_log2, hipStream_t st, uint32_t *d_flag_word) {
+    VectorSegment &seg = segs[s];
     if (method == NIDX_METHOD_HNSW) {
         HnswSearchArgs a;
         a.seg = seg.seg_dev(cfg.similarity);
@@ -392,6 +425,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.dump_vec = nullptr;
         a.dump_score = nullptr;
         a.dump_count = nullptr;
+        a.flag_word = d_flag_word;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -420,6 +454,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         r.visited = nullptr;
         r.vis_words = 0;
         r.stats = d_stats;
+        r.flag_word = d_flag_word;
         if (!hnsw) {
             r.n_queries = nq;
             r.out_vec = d_out_vec;
@@ -476,6 +511,7 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
         a.dump_vec = nullptr;
         a.dump_score = nullptr;
         a.dump_count = nullptr;
+        a.flag_word = d_flag_word;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -642,6 +678,49 @@ int32_t VectorIndex::segment_search_device(uint32_t s, const float *d_queries, u
     return NIDX_OK;
 }
 
+// ---- one segment, exactly: launch -> (only if the flag word is set) larger visited table / HBM-resident walk ----------
+int32_t VectorIndex::segment_search_exact(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
+                                          bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_block,
+                                          uint32_t *host_block, hipStream_t st, uint32_t *n_retried) {
+    uint32_t *d_vec = d_out_block;
+    float *d_score = reinterpret_cast<float *>(d_out_block + (size_t)nq * k);
+    uint32_t *d_count = d_out_block + (size_t)nq * k * 2;
+    uint32_t *d_flag = d_count + nq;
+    const size_t block_bytes = out_block_words(nq, k) * 4;
+    const bool walks = method == NIDX_METHOD_HNSW || method == NIDX_METHOD_RABITQ_HNSW;
+    if (n_retried) *n_retried = 0;
+    if (walks) NIDX_HIP(scratch_stats.reserve((size_t)nq * NIDX_STAT_STRIDE * 4));
+    uint32_t vis_log2 = default_vis_log2;
+    for (;;) {
+        NIDX_HIP(hipMemsetAsync(d_flag, 0, 4, st));
+        int32_t rc = segment_search_device(s, d_queries, nq, k, min_score, with_duplicates, method, d_filter, d_vec, d_score, d_count,
+                                           walks ? scratch_stats.as<uint32_t>() : nullptr, vis_log2, st, d_flag);
+        if (rc != NIDX_OK) return rc;
+        NIDX_HIP(hipMemcpyAsync(host_block, d_out_block, block_bytes, hipMemcpyDeviceToHost, st));
+        NIDX_HIP(hipStreamSynchronize(st));
+        const uint32_t flags = host_block[block_bytes / 4 - 1];
+        if (!walks || flags == 0) return NIDX_OK;
+        // a bounded on-chip structure overflowed for some query: find which (the per-query counters) and re-run
+        std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
+        NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, st));
+        NIDX_HIP(hipStreamSynchronize(st));
+        if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15) {
+            // the walk of these queries outgrew the on-chip pool / visited table: re-run them with both in HBM
+            std::vector<uint32_t> flagged;
+            for (uint32_t q = 0; q < nq; q++)
+                if (stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS]) flagged.push_back(q);
+            if (n_retried) *n_retried = (uint32_t)flagged.size();
+            rc = segment_spill_search(s, d_queries, nq, k, min_score, with_duplicates, method, d_filter, d_vec, d_score, d_count, flagged, st);
+            if (rc != NIDX_OK) return rc;
+            NIDX_HIP(hipMemcpyAsync(host_block, d_out_block, block_bytes, hipMemcpyDeviceToHost, st));
+            NIDX_HIP(hipStreamSynchronize(st));
+            return NIDX_OK;
+        }
+        if (n_retried) *n_retried = nq;
+        vis_log2 = 15;  // visited table was too small: retry once with the largest one (128 KiB of LDS)
+    }
+}
+
 // ---- Fssc (searcher.rs:149-199) -----------------------------------------------------------------------
 namespace {
 struct Cand {
@@ -763,19 +842,22 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 256 is not supported (got %u)", k);
     if (p.method < 0 || p.method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
-    // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252)
+    // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252), staged in pinned memory: one
+    // transfer in, and per segment one transfer out (hits + counts + the launch's flag word)
     const uint32_t dp = (d + 3u) & ~3u;
-    std::vector<float> qpad((size_t)nq * dp, 0.f);
+    NIDX_HIP(pin_in.reserve((size_t)nq * dp * 4));
+    float *qpad = pin_in.as<float>();
     for (uint32_t q = 0; q < nq; q++) {
-        if (cfg.normalize_vectors) normalize_row(queries + (size_t)q * d, &qpad[(size_t)q * dp], d);
-        else memcpy(&qpad[(size_t)q * dp], queries + (size_t)q * d, (size_t)d * 4);
+        float *row = qpad + (size_t)q * dp;
+        if (cfg.normalize_vectors) normalize_row(queries + (size_t)q * d, row, d);
+        else memcpy(row, queries + (size_t)q * d, (size_t)d * 4);
+        for (uint32_t i = d; i < dp; i++) row[i] = 0.f;
     }
-    NIDX_HIP(scratch_queries.reserve(qpad.size() * 4));
-    NIDX_HIP(hipMemcpyAsync(scratch_queries.p, qpad.data(), qpad.size() * 4, hipMemcpyHostToDevice, stream));
-    NIDX_HIP(scratch_out_vec.reserve((size_t)nq * k * 4));
-    NIDX_HIP(scratch_out_score.reserve((size_t)nq * k * 4));
-    NIDX_HIP(scratch_out_count.reserve((size_t)nq * 4));
-    NIDX_HIP(scratch_stats.reserve((size_t)nq * NIDX_STAT_STRIDE * 4));
+    NIDX_HIP(scratch_queries.reserve((size_t)nq * dp * 4));
+    NIDX_HIP(hipMemcpyAsync(scratch_queries.p, qpad, (size_t)nq * dp * 4, hipMemcpyHostToDevice, stream));
+    const size_t block_words = out_block_words(nq, k);
+    NIDX_HIP(scratch_out_block.reserve(block_words * 4));
+    NIDX_HIP(pin_out.reserve(block_words * 4));
 
     const size_t S = segs.size();
     std::vector<std::vector<uint32_t>> hv(S), hc(S);
@@ -813,41 +895,16 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
             NIDX_HIP(hipMemcpyAsync(scratch_filter.p, filt, bytes, hipMemcpyHostToDevice, stream));
             d_filter = scratch_filter.as<uint64_t>();
         }
-        uint32_t vis_log2 = default_vis_log2;
         scan_matching_hint = matching;
-        for (;;) {
-            int32_t rc = segment_search_device((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score,
-                                               p.with_duplicates != 0, method, d_filter, scratch_out_vec.as<uint32_t>(),
-                                               scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
-                                               scratch_stats.as<uint32_t>(), vis_log2, stream);
-            scan_matching_hint = ~0ull;
-            if (rc != NIDX_OK) return rc;
-            if (method != NIDX_METHOD_HNSW && method != NIDX_METHOD_RABITQ_HNSW) break;
-            std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
-            NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, stream));
-            NIDX_HIP(hipStreamSynchronize(stream));
-            uint32_t flags = 0;
-            for (uint32_t q = 0; q < nq; q++) flags |= stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS];
-            if (flags == 0) break;
-            if ((flags & NIDX_FLAG_POOL_INEXACT) || vis_log2 >= 15) {
-                // the walk of these queries outgrew the on-chip pool / visited table: re-run them with both in HBM
-                std::vector<uint32_t> flagged;
-                for (uint32_t q = 0; q < nq; q++)
-                    if (stats[(size_t)q * NIDX_STAT_STRIDE + NIDX_STAT_FLAGS]) flagged.push_back(q);
-                rc = segment_spill_search((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score, p.with_duplicates != 0, method, d_filter,
-                                          scratch_out_vec.as<uint32_t>(), scratch_out_score.as<float>(), scratch_out_count.as<uint32_t>(),
-                                          flagged, stream);
-                if (rc != NIDX_OK) return rc;
-                break;
-            }
-            vis_log2 = 15;  // visited table was too small: retry once with the largest one (128 KiB of LDS)
-        }
-        hv[s].resize((size_t)nq * k);
+        const int32_t rc = segment_search_exact((uint32_t)s, scratch_queries.as<float>(), nq, k, p.min_score, p.with_duplicates != 0, method,
+                                                d_filter, scratch_out_block.as<uint32_t>(), pin_out.as<uint32_t>(), stream, nullptr);
+        scan_matching_hint = ~0ull;
+        if (rc != NIDX_OK) return rc;
+        const uint32_t *blk = pin_out.as<uint32_t>();
+        hv[s].assign(blk, blk + (size_t)nq * k);
         hs[s].resize((size_t)nq * k);
-        NIDX_HIP(hipMemcpyAsync(hv[s].data(), scratch_out_vec.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
-        NIDX_HIP(hipMemcpyAsync(hs[s].data(), scratch_out_score.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
-        NIDX_HIP(hipMemcpyAsync(hc[s].data(), scratch_out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
-        NIDX_HIP(hipStreamSynchronize(stream));
+        memcpy(hs[s].data(), blk + (size_t)nq * k, (size_t)nq * k * 4);
+        hc[s].assign(blk + (size_t)nq * k * 2, blk + (size_t)nq * k * 2 + nq);
     }
 
     // Fssc per query
@@ -967,6 +1024,9 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     NIDX_HIP(hipGetDevice(&idx->device));
     NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    NIDX_HIP(idx->flag_word.alloc(64));
+    NIDX_HIP(hipMemset(idx->flag_word.p, 0, 64));
+    NIDX_HIP(idx->pin_flag.reserve(64));
     idx->segs.resize(n_segments);
     for (uint32_t s = 0; s < n_segments; s++) {
         int32_t rc = open_segment(*config, segments[s], idx->segs[s], idx->stream);
@@ -1199,27 +1259,72 @@ int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const fl
                             out_score, out_count, out_method, out_matching);
 } NIDX_ABI_CATCH
 
+static int32_t device_entry_method(VectorIndex *idx, uint32_t segment, const nidx_gpu_vector_search_params_t *params,
+                                   const uint64_t *d_filter, int &method) {
+    if (params->k == 0 || params->k > 256) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..256 (got %u)", params->k);
+    if (idx->cfg.dimension & 3u)
+        return fail(NIDX_ERR_UNSUPPORTED, "device-resident queries need a dimension that is a multiple of 4");
+    if (params->method < 0 || params->method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", params->method);
+    VectorSegment &seg = idx->segs[segment];
+    method = params->method;
+    if (method == NIDX_METHOD_AUTO) {
+        if (d_filter) return fail(NIDX_ERR_INVALID_ARGUMENT, "NIDX_METHOD_AUTO with a device filter: pick the method explicitly");
+        // OpenSegment::_search (segment.rs:506-513,535-555), like search_host
+        const bool rabitq = idx->rabitq_enabled(seg);
+        const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, seg.alive_count, params->k, rabitq);
+        method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
+                        : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);
+    }
+    if ((method == NIDX_METHOD_HNSW || method == NIDX_METHOD_RABITQ_HNSW) && !seg.has_graph)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "segment has no HNSW graph");
+    return NIDX_OK;
+}
+
 int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,
                                               uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
                                               const uint64_t *d_filter, uint32_t *d_out_vector, float *d_out_score,
                                               uint32_t *d_out_count, uint32_t *d_stats, void *stream) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
-    if (params->k == 0 || params->k > 256) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..256 (got %u)", params->k);
-    if (idx->cfg.dimension & 3u)
-        return fail(NIDX_ERR_UNSUPPORTED, "device-resident queries need a dimension that is a multiple of 4");
     std::lock_guard<std::mutex> lock(idx->mu);
-    VectorSegment &seg = idx->segs[segment];
-    int method = params->method;
-    if (method == NIDX_METHOD_AUTO) {
-        if (d_filter) return fail(NIDX_ERR_INVALID_ARGUMENT, "NIDX_METHOD_AUTO with a device filter: pick the method explicitly");
-        method = (seg.has_graph && use_hnsw(seg.n_paragraphs, seg.alive_count, params->k, false)) ? NIDX_METHOD_HNSW
-                                                                                                   : NIDX_METHOD_BRUTE_FORCE;
-    }
-    if (method == NIDX_METHOD_HNSW && !seg.has_graph) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment has no HNSW graph");
+    int method = 0;
+    int32_t rc = device_entry_method(idx, segment, params, d_filter, method);
+    if (rc != NIDX_OK) return rc;
     return idx->segment_search_device(segment, d_queries, n_queries, params->k, params->min_score,
                                       params->with_duplicates != 0, method, d_filter, d_out_vector, d_out_score,
-                                      d_out_count, d_stats, idx->default_vis_log2, (hipStream_t)stream);
+                                      d_out_count, d_stats, idx->default_vis_log2, (hipStream_t)stream, idx->flag_word.as<uint32_t>());
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_vector_device_flags(nidx_gpu_vector_index_t *index, void *stream, uint32_t *flags_out) try {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !flags_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    hipStream_t st = (hipStream_t)stream;
+    NIDX_HIP(hipMemcpyAsync(idx->pin_flag.p, idx->flag_word.p, 4, hipMemcpyDeviceToHost, st));
+    NIDX_HIP(hipMemsetAsync(idx->flag_word.p, 0, 4, st));
+    NIDX_HIP(hipStreamSynchronize(st));
+    *flags_out = *idx->pin_flag.as<uint32_t>();
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_vector_segment_search_device_exact(nidx_gpu_vector_index_t *index, uint32_t segment, const float *d_queries,
+                                                    uint32_t n_queries, const nidx_gpu_vector_search_params_t *params,
+                                                    const uint64_t *d_filter, uint32_t *d_out_block, uint32_t *host_out_block,
+                                                    void *stream, uint32_t *n_retried_out) try {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !params || segment >= idx->segs.size() || !d_out_block) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    if (n_queries == 0) return NIDX_OK;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    int method = 0;
+    int32_t rc = device_entry_method(idx, segment, params, d_filter, method);
+    if (rc != NIDX_OK) return rc;
+    uint32_t *host = host_out_block;
+    if (!host) {
+        NIDX_HIP(idx->pin_out.reserve(VectorIndex::out_block_words(n_queries, params->k) * 4));
+        host = idx->pin_out.as<uint32_t>();
+    }
+    return idx->segment_search_exact(segment, d_queries, n_queries, params->k, params->min_score, params->with_duplicates != 0, method,
+                                     d_filter, d_out_block, host, (hipStream_t)stream, n_retried_out);
 } NIDX_ABI_CATCH
 
 int32_t nidx_gpu_use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, int32_t has_rabitq) try {

@@ -68,6 +68,7 @@ struct VectorIndex {
             (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
         }
+        if (scratch_event) (void)hipEventDestroy(scratch_event);
     }
     std::mutex mu;
     std::vector<VectorSegment> segs;
@@ -96,7 +97,27 @@ struct VectorIndex {
     int32_t segment_search_device(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                   bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
                                   float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
-                                  hipStream_t st);
+                                  hipStream_t st, uint32_t *d_flag_word = nullptr);
+    int32_t segment_search_device_scratch(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
+                                          bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
+                                          float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
+                                          hipStream_t st, uint32_t *d_flag_word);
+    // The whole OpenSegment::search of one segment: launch, then — only when the launch's flag word says a bounded on-chip
+    // structure overflowed — the 2^15 visited table and the HBM-resident closest_up_nodes for exactly the flagged queries.
+    // d_out_block = [nq*k vec][nq*k score][nq count][1 flag word]; it is copied to `host_block` (pinned) in ONE transfer.
+    int32_t segment_search_exact(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, bool with_duplicates,
+                                 int method, const uint64_t *d_filter, uint32_t *d_out_block, uint32_t *host_block, hipStream_t st,
+                                 uint32_t *n_retried);
+    static size_t out_block_words(uint32_t nq, uint32_t k) { return (size_t)nq * k * 2 + nq + 1; }
+    // scratch buffers are index-owned but the device entry point runs on the caller's stream and returns with the work in
+    // flight: the next user of the scratch (any stream) first waits for this event
+    hipEvent_t scratch_event = nullptr;
+    bool scratch_event_recorded = false;
+    int32_t scratch_acquire(hipStream_t st);
+    int32_t scratch_release(hipStream_t st);
+    DevBuf flag_word;        // [16] u32: [0] = flags raised by device-entry launches since the last nidx_gpu_vector_device_flags
+    DevBuf scratch_out_block;
+    PinBuf pin_in, pin_out, pin_flag;
     // exact fallback for the queries whose closest_up_nodes walk outgrew the LDS pool / visited table (hnsw_spill.hip)
     int32_t segment_spill_search(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, bool with_duplicates,
                                  int method, const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,

@@ -1709,3 +1709,123 @@ size_t orc_merge_bm25(const orc_bm25_hit *const *lists, const size_t *lens, size
     free(order);
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Batch runners (bench.py's cpu_baseline leg and the benchmark-scale parity checks): the per-query
+ * functions above, one query per work item, on `threads` POSIX threads pulling items from a shared
+ * counter — the reference serves one request per blocking thread (src/searcher/shard_search.rs:139-153).
+ * Nothing here changes a result: every item calls exactly the single-query function.
+ * ------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+
+typedef struct batch_job batch_job;
+typedef void (*batch_fn)(const batch_job *job, size_t i);
+struct batch_job {
+    batch_fn fn;
+    size_t n;
+    size_t next;          /* atomic work counter */
+    /* vector searches */
+    const orc_segment *segs;
+    const uint64_t *const *para_keys;
+    size_t n_segs;
+    const float *queries;
+    size_t k;
+    float min_score;
+    int with_duplicates;
+    uint32_t *out_vec;
+    float *out_score;
+    uint32_t *out_count;
+    orc_scored_paragraph *out_sp;
+    orc_stats *stats;     /* [n] or NULL */
+    /* bm25 */
+    const orc_bm25_index *bm;
+    const orc_bm25_clause *clauses;
+    const uint64_t *clause_offsets;
+    uint64_t *out_docaddr;
+    uint64_t *out_total;
+};
+
+static void *batch_worker(void *p) {
+    batch_job *job = (batch_job *)p;
+    for (;;) {
+        size_t i = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+        if (i >= job->n) break;
+        job->fn(job, i);
+    }
+    return NULL;
+}
+
+static void batch_run(batch_job *job, unsigned threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    if ((size_t)threads > job->n) threads = (unsigned)(job->n ? job->n : 1);
+    job->next = 0;
+    pthread_t *t = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    unsigned started = 0;
+    for (unsigned i = 1; i < threads; i++)
+        if (pthread_create(&t[started], NULL, batch_worker, job) == 0) started++;
+    batch_worker(job);
+    for (unsigned i = 0; i < started; i++) pthread_join(t[i], NULL);
+    free(t);
+}
+
+static void job_hnsw(const batch_job *j, size_t i) {
+    const orc_segment *seg = j->segs;
+    j->out_count[i] = (uint32_t)orc_hnsw_search(seg, j->queries + i * seg->dim, NULL, j->k, j->min_score, j->with_duplicates, 0,
+                                                j->out_vec + i * j->k, j->out_score + i * j->k, j->stats ? &j->stats[i] : NULL);
+}
+static void job_brute(const batch_job *j, size_t i) {
+    const orc_segment *seg = j->segs;
+    j->out_count[i] = (uint32_t)orc_brute_force_search(seg, j->queries + i * seg->dim, NULL, j->k, j->min_score,
+                                                       j->out_vec + i * j->k, j->out_score + i * j->k);
+}
+static void job_searcher(const batch_job *j, size_t i) {
+    j->out_count[i] = (uint32_t)orc_searcher_search(j->segs, j->para_keys, j->n_segs, j->queries + i * j->segs[0].dim, NULL, j->k,
+                                                    j->min_score, j->with_duplicates, 0, j->out_sp + i * j->k);
+}
+static void job_bm25(const batch_job *j, size_t i) {
+    const uint64_t b = j->clause_offsets[i], e = j->clause_offsets[i + 1];
+    j->out_count[i] = (uint32_t)orc_bm25_search_daat(j->bm, j->clauses + b, (size_t)(e - b), j->k, NULL, 0, j->out_docaddr + i * j->k,
+                                                     j->out_score + i * j->k, &j->out_total[i]);
+}
+
+void orc_hnsw_search_batch(const orc_segment *seg, const float *queries, size_t n_queries, size_t k, float min_score,
+                           int with_duplicates, unsigned threads, uint32_t *out_vec, float *out_score, uint32_t *out_count,
+                           orc_stats *stats) {
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    j.fn = job_hnsw; j.n = n_queries; j.segs = seg; j.queries = queries; j.k = k; j.min_score = min_score;
+    j.with_duplicates = with_duplicates; j.out_vec = out_vec; j.out_score = out_score; j.out_count = out_count; j.stats = stats;
+    if (stats) memset(stats, 0, n_queries * sizeof(orc_stats));
+    batch_run(&j, threads);
+}
+
+void orc_brute_force_batch(const orc_segment *seg, const float *queries, size_t n_queries, size_t k, float min_score,
+                           unsigned threads, uint32_t *out_vec, float *out_score, uint32_t *out_count) {
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    j.fn = job_brute; j.n = n_queries; j.segs = seg; j.queries = queries; j.k = k; j.min_score = min_score;
+    j.out_vec = out_vec; j.out_score = out_score; j.out_count = out_count;
+    batch_run(&j, threads);
+}
+
+void orc_searcher_search_batch(const orc_segment *segs, const uint64_t *const *para_keys, size_t n_segs, const float *queries,
+                               size_t n_queries, size_t k, float min_score, int with_duplicates, unsigned threads,
+                               orc_scored_paragraph *out, uint32_t *out_count) {
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    if (n_segs == 0) { for (size_t i = 0; i < n_queries; i++) out_count[i] = 0; return; }
+    j.fn = job_searcher; j.n = n_queries; j.segs = segs; j.para_keys = para_keys; j.n_segs = n_segs; j.queries = queries; j.k = k;
+    j.min_score = min_score; j.with_duplicates = with_duplicates; j.out_sp = out; j.out_count = out_count;
+    batch_run(&j, threads);
+}
+
+void orc_bm25_search_daat_batch(const orc_bm25_index *idx, const orc_bm25_clause *clauses, const uint64_t *clause_offsets,
+                                size_t n_queries, size_t k, unsigned threads, uint64_t *out_docaddr, float *out_score,
+                                uint32_t *out_count, uint64_t *out_total) {
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    j.fn = job_bm25; j.n = n_queries; j.bm = idx; j.clauses = clauses; j.clause_offsets = clause_offsets; j.k = k;
+    j.out_docaddr = out_docaddr; j.out_score = out_score; j.out_count = out_count; j.out_total = out_total;
+    batch_run(&j, threads);
+}

@@ -276,6 +276,21 @@ typedef struct {
 } orc_bm25_hit;
 size_t orc_merge_bm25(const orc_bm25_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_bm25_hit *out);
 
+/* ---- batch runners (cpu_baseline leg of bench.py, benchmark-scale parity checks): the single-query functions above,
+ * one query per work item on `threads` POSIX threads (one blocking thread per request, src/searcher/shard_search.rs:139-153).
+ * out_* are [n_queries][k]; stats NULL or [n_queries]. */
+void orc_hnsw_search_batch(const orc_segment *seg, const float *queries, size_t n_queries, size_t k, float min_score,
+                           int with_duplicates, unsigned threads, uint32_t *out_vec, float *out_score, uint32_t *out_count,
+                           orc_stats *stats);
+void orc_brute_force_batch(const orc_segment *seg, const float *queries, size_t n_queries, size_t k, float min_score,
+                           unsigned threads, uint32_t *out_vec, float *out_score, uint32_t *out_count);
+void orc_searcher_search_batch(const orc_segment *segs, const uint64_t *const *para_keys, size_t n_segs, const float *queries,
+                               size_t n_queries, size_t k, float min_score, int with_duplicates, unsigned threads,
+                               orc_scored_paragraph *out, uint32_t *out_count);
+void orc_bm25_search_daat_batch(const orc_bm25_index *idx, const orc_bm25_clause *clauses, const uint64_t *clause_offsets,
+                                size_t n_queries, size_t k, unsigned threads, uint64_t *out_docaddr, float *out_score,
+                                uint32_t *out_count, uint64_t *out_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,6 +210,18 @@ def lib():
     L.orc_merge_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     L.orc_merge_bm25.restype = C.c_size_t
     L.orc_merge_bm25.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.orc_hnsw_search_batch.restype = None
+    L.orc_hnsw_search_batch.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_uint,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_brute_force_batch.restype = None
+    L.orc_brute_force_batch.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_uint, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    L.orc_searcher_search_batch.restype = None
+    L.orc_searcher_search_batch.argtypes = [C.POINTER(_Segment), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                            C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+    L.orc_bm25_search_daat_batch.restype = None
+    L.orc_bm25_search_daat_batch.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -502,6 +514,26 @@ class Segment:
             stats.edges_read += st.edges_read
         return ov[:n].copy(), os_[:n].copy()
 
+    def hnsw_search_batch(self, queries, k, min_score=-1.0, with_duplicates=True, threads=1, want_stats=False):
+        """orc_hnsw_search for every row of `queries`, one query per work item on `threads` POSIX threads.
+        -> (vec [nq][k] u32, score [nq][k] f32, count [nq] u32[, stats (nq, 3) u64])"""
+        q = _f32(queries)
+        nq = q.shape[0]
+        ov, os_, oc = np.zeros((nq, max(k, 1)), np.uint32), np.zeros((nq, max(k, 1)), np.float32), np.zeros(nq, np.uint32)
+        st = np.zeros((nq, 3), np.uint64) if want_stats else None
+        cs = self.c()
+        lib().orc_hnsw_search_batch(C.byref(cs), _ptr(q), nq, k, min_score, int(with_duplicates), int(threads), _ptr(ov), _ptr(os_),
+                                    _ptr(oc), _ptr(st))
+        return (ov, os_, oc, st) if want_stats else (ov, os_, oc)
+
+    def brute_force_batch(self, queries, k, min_score=-1.0, threads=1):
+        q = _f32(queries)
+        nq = q.shape[0]
+        ov, os_, oc = np.zeros((nq, max(k, 1)), np.uint32), np.zeros((nq, max(k, 1)), np.float32), np.zeros(nq, np.uint32)
+        cs = self.c()
+        lib().orc_brute_force_batch(C.byref(cs), _ptr(q), nq, k, min_score, int(threads), _ptr(ov), _ptr(os_), _ptr(oc))
+        return ov, os_, oc
+
     def search(self, query, k, min_score=-1.0, with_duplicates=True, filter_bits=None):
         """OpenSegment::_search: cost-model routed. -> (vec addrs, scores, method)"""
         q = _f32(query)
@@ -535,6 +567,24 @@ def searcher_search(segments, para_keys, query, k, min_score=-1.0, with_duplicat
     out = (_ScoredParagraph * max(k, 1))()
     m = lib().orc_searcher_search(segs, key_ptrs, n, _ptr(q), fl, k, min_score, int(with_duplicates), int(normalize_query), out)
     return [(out[i].paragraph_key, float(np.float32(out[i].score)), out[i].segment, out[i].vector) for i in range(m)]
+
+
+def searcher_search_batch(segments, queries, k, min_score=-1.0, with_duplicates=True, threads=1, para_keys=None):
+    """Searcher::_search (sequential segments + Fssc) for every row of `queries` on `threads` POSIX threads.
+    -> (segment [nq][k] u32, vector [nq][k] u32, score [nq][k] f32, count [nq] u32)"""
+    n = len(segments)
+    segs = (_Segment * n)(*[s.c() for s in segments])
+    key_ptrs = None
+    if para_keys is not None:
+        keys = [np.ascontiguousarray(k_, dtype=np.uint64) for k_ in para_keys]
+        key_ptrs = (C.c_void_p * n)(*[k_.ctypes.data for k_ in keys])
+    q = _f32(queries)
+    nq = q.shape[0]
+    out = np.zeros((nq, max(k, 1)), dtype=np.dtype([("key", np.uint64), ("score", np.float32), ("segment", np.uint32), ("vector", np.uint32)], align=True))
+    assert out.dtype.itemsize == C.sizeof(_ScoredParagraph)
+    oc = np.zeros(nq, np.uint32)
+    lib().orc_searcher_search_batch(segs, key_ptrs, n, _ptr(q), nq, k, min_score, int(with_duplicates), int(threads), out.ctypes.data, _ptr(oc))
+    return out["segment"].copy(), out["vector"].copy(), out["score"].copy(), oc
 
 
 # ---------------------------------------------------------------- BM25
@@ -649,6 +699,21 @@ class Bm25Index:
         fn = lib().orc_bm25_search_daat if daat else lib().orc_bm25_search
         n = fn(C.byref(ci), cl, len(clauses), k, C.byref(sa), segment_ord, _ptr(od), _ptr(os_), C.byref(total))
         return od[:n].copy(), os_[:n].copy(), total.value
+
+
+def bm25_search_daat_batch(index: "Bm25Index", queries, k, threads=1):
+    """orc_bm25_search_daat for every query (a list of (term, occur, mode, boost) clause lists) on `threads` POSIX threads.
+    -> (docaddr [nq][k] u64, score [nq][k] f32, count [nq] u32, total [nq] u64)"""
+    nq = len(queries)
+    offs = np.zeros(nq + 1, np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    flat = [c for q in queries for c in q]
+    cl, _keep = index._clauses(flat)
+    od, os_ = np.zeros((nq, max(k, 1)), np.uint64), np.zeros((nq, max(k, 1)), np.float32)
+    oc, tot = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+    ci = index.c()
+    lib().orc_bm25_search_daat_batch(C.byref(ci), cl, _ptr(offs), nq, k, int(threads), _ptr(od), _ptr(os_), _ptr(oc), _ptr(tot))
+    return od, os_, oc, tot
 
 
 def fuzzy_match(query: str, term: str, distance: int = 1, prefix: bool = False) -> bool:
