@@ -216,6 +216,9 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
         // 4-byte trailer are the mmap'd vectors.bin and are read by the host above
         NIDX_HIP(hipMemcpy2D(seg.vectors.p, (size_t)seg.dp * 4, in.vectors, in.row_stride_bytes, packed, in.n_vectors,
                              hipMemcpyDefault));
+        // a device-to-device copy returns before it has run, and `stream` (non-blocking) does not order itself behind the null
+        // stream: the norms below must not read the rows before they have landed
+        NIDX_HIP(hipStreamSynchronize(nullptr));
         NIDX_HIP(seg.norm2.alloc((size_t)((in.n_vectors + 7u) & ~7u) * 4));  // padded: the shared-row scan copies 8 norms per tile
         NIDX_HIP(launch_row_norms(seg.vectors.as<float>(), seg.n, seg.dp, seg.norm2.as<float>(), stream));
     }
