@@ -22,13 +22,18 @@ namespace nidx {
 #define NIDX_POOL_CAP 512
 #define NIDX_VIS_EMPTY 0xffffffffu
 
+// The neighbours of one expansion: their addresses and, after the distance phase, the two sums of each.
+struct NbBuf {
+    uint32_t addr[64];
+    float ab[64];   // <x, q>
+    float xx[64];   // |x|^2
+};
 struct SearchShared {
     uint64_t pool[NIDX_POOL_CAP];  // unexpanded candidates (rank keys), unsorted
-    uint32_t nb_addr[64];          // neighbours to evaluate
-    float nb_ab[64];               // <x, q>
-    float nb_xx[64];               // |x|^2
+    NbBuf nb[2];                   // two expansions: the one being admitted and the one being evaluated (layer_search_block)
     uint32_t eps[256];             // entry points for the next layer search
-    int ctrl[8];                   // [0] continue, [1] n_new, [2] n_eps
+    int ctrl[12];                  // [0] continue, [1] n_new (single-buffer loops), [2] n_eps, [3] next row to evaluate,
+                                   // [4] redo, [5] the speculated expansion exists, [6..7] n_new of nb[0], nb[1]
 };
 
 template <int NJ>
@@ -80,9 +85,30 @@ __device__ inline bool vis_insert(uint32_t *vis, uint32_t log2cap, uint32_t v) {
     }
 }
 
+// read-only membership test (the table is not being written while this runs)
+__device__ inline bool vis_contains(const uint32_t *vis, uint32_t log2cap, uint32_t v) {
+    const uint32_t mask = (1u << log2cap) - 1u;
+    uint32_t h = (v * 2654435761u) >> (32 - log2cap);
+    for (;;) {
+        const uint32_t cur = vis[h];
+        if (cur == NIDX_VIS_EMPTY) return false;
+        if (cur == v) return true;
+        h = (h + 1) & mask;
+    }
+}
+
 // ---- candidate pool: unsorted array in LDS, arg-max pop --------------------------------------
 __device__ inline uint64_t wave_max_u64(uint64_t v) { return wave_extreme_u64<true>(v); }
 __device__ inline uint64_t wave_min_u64(uint64_t v) { return wave_extreme_u64<false>(v); }
+// The best key without removing it (EMPTY if none).  Wave-0 only.
+__device__ inline uint64_t pool_peek(const uint64_t *pool, int pool_len, int lane) {
+    uint64_t best = NIDX_EMPTY_KEY;
+    for (int i = lane; i < pool_len; i += 64) {
+        uint64_t v = pool[i];
+        best = v > best ? v : best;
+    }
+    return wave_max_u64(best);
+}
 // Pops the best key (EMPTY if none).  Wave-0 only; pool_len is wave-uniform.
 __device__ inline uint64_t pool_pop(uint64_t *pool, int &pool_len, int lane) {
     if (pool_len == 0) return NIDX_EMPTY_KEY;
@@ -120,74 +146,166 @@ __device__ inline void pool_prune(uint64_t *pool, int &pool_len, float ws, int l
     pool_len = out;
 }
 
+// ---- the result set of a layer search + which of its entries are still unexpanded --------------------------------------------
+// HnswSearcher::layer_search keeps two heaps: `ms_neighbours` (the k best so far) and `candidates` (everything ever admitted,
+// popped best first until the best one is worse than the worst result).  Every candidate was admitted into the result set too,
+// and one that has since been evicted scores below the worst result for good — except one that left while TYING with it
+// (`cs < ws` does not stop on equal scores).  So the live candidates are exactly the unexpanded entries of the result set plus
+// those tied evictions: the set below is the sorted result list with one "unexpanded" bit per rank (wave-uniform masks that
+// move with the insertions as scalar shifts), and the LDS pool only holds the tied evictions.  Pop = the lowest set bit — no
+// LDS scan, no wave reduction on the controller's critical path.
+template <int NL>
+struct CandSet {
+    uint64_t unexp[NL];
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < NL; i++) unexp[i] = 0;
+    }
+    // Inserts an unexpanded entry, keeping the `cap` best.  out_key / out_unexp: the entry that left the set (EMPTY: none).
+    __device__ inline void insert(WaveTopK<NL> &res, uint64_t nk, int cap, int lane, uint64_t &out_key, bool &out_unexp) {
+        uint64_t d = nk, dflag = 1;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            if (d != NIDX_EMPTY_KEY) {
+                const int pos = __popcll(__ballot(res.l[i].key > d));  // 0..64: entries of this list ranking before d
+                if (pos < 64) {
+                    const uint64_t last = lane_bcast_u64(res.l[i].key, 63);
+                    const uint64_t lastflag = unexp[i] >> 63;
+                    const uint64_t up = wave_shr1_u64(res.l[i].key);
+                    if (lane > pos) res.l[i].key = up;
+                    if (lane == pos) res.l[i].key = d;
+                    const uint64_t low = unexp[i] & ((1ull << pos) - 1ull);
+                    const uint64_t high = pos < 63 ? ((unexp[i] >> pos) << (pos + 1)) : 0ull;
+                    unexp[i] = low | (dflag << pos) | high;
+                    d = last;
+                    dflag = lastflag;
+                }
+            }
+        }
+        res.len++;
+        out_key = NIDX_EMPTY_KEY;
+        out_unexp = false;
+        if (res.len > cap) {
+            if (cap >= 64 * NL) {  // the list itself is the bound: what fell off its end left the set
+                out_key = d;
+                out_unexp = dflag != 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                if ((cap >> 6) == i) {
+                    out_key = lane_bcast_u64(res.l[i].key, cap & 63);
+                    out_unexp = ((unexp[i] >> (cap & 63)) & 1ull) != 0;
+                    if (lane == (cap & 63)) res.l[i].key = NIDX_EMPTY_KEY;
+                    unexp[i] &= ~(1ull << (cap & 63));
+                }
+            res.len = cap;
+        }
+    }
+    // best unexpanded entry (EMPTY if none); pop marks it expanded
+    __device__ inline uint64_t peek(const WaveTopK<NL> &res) const {
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+            if (unexp[i]) return lane_bcast_u64(res.l[i].key, __builtin_ctzll(unexp[i]));
+        return NIDX_EMPTY_KEY;
+    }
+    __device__ inline uint64_t pop(const WaveTopK<NL> &res) {
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+            if (unexp[i]) {
+                const int r = __builtin_ctzll(unexp[i]);
+                unexp[i] &= unexp[i] - 1ull;
+                return lane_bcast_u64(res.l[i].key, r);
+            }
+        return NIDX_EMPTY_KEY;
+    }
+};
+
 struct SearchCounters {
     uint32_t evals, expansions, visited, flags;
     // wave-0 cycle accounting (s_memtime): controller pop/edge/visited, distance phase, admission
     uint64_t cyc_ctl, cyc_eval, cyc_ins;
 };
 
-// ---- distances of sh.nb_addr[0..n) -> sh.nb_ab / sh.nb_xx (all waves) ------------------------
-// EVR rows are in flight per wave at a time (EVR * NJ 16-byte loads per lane).
+// ---- distances of nb.addr[base .. base + EVR) -> nb.ab / nb.xx (one wave) --------------------------------------------
+// EVR rows are in flight at a time (EVR * NJ 16-byte loads per lane).
 template <int NJ, int EVR>
-__device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q, SearchShared &sh, int n, bool cosine) {
+__device__ inline void eval_row_group(const SegDev &seg, const QueryRegs<NJ> &q, NbBuf &nb, int base, int n, bool cosine, int lane) {
+    float4 row[EVR][NJ];
+#pragma unroll
+    for (int i = 0; i < EVR; i++) {
+        if (base + i < n) {
+            const float *r = seg.vectors + (size_t)nb.addr[base + i] * seg.dp;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) row[i][j] = load_row_chunk(r, seg.dp, j, lane);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) row[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // reduce width: next power of two >= the number of per-lane partial sums
+    constexpr int NV_COS = 2 * EVR <= 2 ? 2 : (2 * EVR <= 4 ? 4 : 8);
+    constexpr int NV_DOT = EVR <= 1 ? 1 : (EVR <= 2 ? 2 : 4);
+    if (cosine) {
+        float v[NV_COS];
+#pragma unroll
+        for (int i = 0; i < NV_COS; i++) v[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EVR; i++) {
+            float ab = 0.f, xx = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                ab = fma4(row[i][j], q.qv[j], ab);
+                xx = fma4(row[i][j], row[i][j], xx);
+            }
+            v[2 * i] = ab;
+            v[2 * i + 1] = xx;
+        }
+        float r = QReduce<NV_COS>::run(v, lane);
+        int which = QReduce<NV_COS>::query_of_lane(lane);
+        if ((lane & QReduce<NV_COS>::group_mask()) == 0) {
+            int i = which >> 1;
+            if (i < EVR && base + i < n) {
+                if ((which & 1) == 0) nb.ab[base + i] = r;
+                else nb.xx[base + i] = r;
+            }
+        }
+    } else {
+        float v[NV_DOT];
+#pragma unroll
+        for (int i = 0; i < NV_DOT; i++) v[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EVR; i++) {
+            float ab = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) ab = fma4(row[i][j], q.qv[j], ab);
+            v[i] = ab;
+        }
+        float r = QReduce<NV_DOT>::run(v, lane);
+        int which = QReduce<NV_DOT>::query_of_lane(lane);
+        if ((lane & QReduce<NV_DOT>::group_mask()) == 0 && which < EVR && base + which < n) nb.ab[base + which] = r;
+    }
+}
+
+// all waves, rows dealt out statically (wave w takes groups w, w + nwaves, ..)
+template <int NJ, int EVR>
+__device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q, NbBuf &nb, int n, bool cosine) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
-    for (int base = wave * EVR; base < n; base += nwaves * EVR) {
-        float4 row[EVR][NJ];
-#pragma unroll
-        for (int i = 0; i < EVR; i++) {
-            if (base + i < n) {
-                const float *r = seg.vectors + (size_t)sh.nb_addr[base + i] * seg.dp;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) row[i][j] = load_row_chunk(r, seg.dp, j, lane);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NJ; j++) row[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        // reduce width: next power of two >= the number of per-lane partial sums
-        constexpr int NV_COS = 2 * EVR <= 2 ? 2 : (2 * EVR <= 4 ? 4 : 8);
-        constexpr int NV_DOT = EVR <= 1 ? 1 : (EVR <= 2 ? 2 : 4);
-        if (cosine) {
-            float v[NV_COS];
-#pragma unroll
-            for (int i = 0; i < NV_COS; i++) v[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < EVR; i++) {
-                float ab = 0.f, xx = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    ab = fma4(row[i][j], q.qv[j], ab);
-                    xx = fma4(row[i][j], row[i][j], xx);
-                }
-                v[2 * i] = ab;
-                v[2 * i + 1] = xx;
-            }
-            float r = QReduce<NV_COS>::run(v, lane);
-            int which = QReduce<NV_COS>::query_of_lane(lane);
-            if ((lane & QReduce<NV_COS>::group_mask()) == 0) {
-                int i = which >> 1;
-                if (i < EVR && base + i < n) {
-                    if ((which & 1) == 0) sh.nb_ab[base + i] = r;
-                    else sh.nb_xx[base + i] = r;
-                }
-            }
-        } else {
-            float v[NV_DOT];
-#pragma unroll
-            for (int i = 0; i < NV_DOT; i++) v[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < EVR; i++) {
-                float ab = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) ab = fma4(row[i][j], q.qv[j], ab);
-                v[i] = ab;
-            }
-            float r = QReduce<NV_DOT>::run(v, lane);
-            int which = QReduce<NV_DOT>::query_of_lane(lane);
-            if ((lane & QReduce<NV_DOT>::group_mask()) == 0 && which < EVR && base + which < n) sh.nb_ab[base + which] = r;
-        }
+    for (int base = wave * EVR; base < n; base += nwaves * EVR) eval_row_group<NJ, EVR>(seg, q, nb, base, n, cosine, lane);
+}
+
+// any subset of the waves, at any time: every caller claims the next EVR rows from the shared counter until none are left
+// (which wave scores a row does not change the score: same loads, same fma chain, same butterfly)
+template <int NJ, int EVR>
+__device__ inline void eval_neighbours_dynamic(const SegDev &seg, const QueryRegs<NJ> &q, NbBuf &nb, int n, bool cosine, int *next_row) {
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(next_row, EVR);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        eval_row_group<NJ, EVR>(seg, q, nb, base, n, cosine, lane);
     }
 }
 
@@ -220,12 +338,14 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
     vis_clear(vis, vis_cap);
     __syncthreads();
     int n_new = sh.ctrl[2];
+    CandSet<EFL> cand;
+    cand.init();
     if (ctl) {
         res.init();
         if (lane < n_new) {
             uint32_t ep = sh.eps[lane];
             vis_insert(vis, vis_log2, ep);
-            sh.nb_addr[lane] = ep;
+            sh.nb[0].addr[lane] = ep;
         }
         // entry points beyond 64 (only the ef=100 build path) are handled in a second round below
     }
@@ -237,19 +357,18 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
         if (ctl && ep_done > 0 && lane < chunk) {
             uint32_t ep = sh.eps[ep_done + lane];
             vis_insert(vis, vis_log2, ep);
-            sh.nb_addr[lane] = ep;
+            sh.nb[0].addr[lane] = ep;
         }
         __syncthreads();
-        eval_neighbours<NJ, EVR>(seg, q, sh, chunk, cosine);
+        eval_neighbours<NJ, EVR>(seg, q, sh.nb[0], chunk, cosine);
         __syncthreads();
         if (ctl) {
-            float s = lane < chunk ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
-            uint32_t addr = sh.nb_addr[lane];
+            float s = lane < chunk ? score_from_sums(sh.nb[0].ab[lane], sh.nb[0].xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
+            uint32_t addr = sh.nb[0].addr[lane];
             for (int j = 0; j < chunk; j++) {
-                uint64_t nk = rank_key(lane_bcast_f32(s, j), lane_bcast_u32(addr, j));
-                if (lane == 0) sh.pool[pool_len] = nk;
-                pool_len++;
-                res.insert(nk, 64 * EFL, lane);
+                uint64_t ek;
+                bool eu;
+                cand.insert(res, rank_key(lane_bcast_f32(s, j), lane_bcast_u32(addr, j)), 64 * EFL, lane, ek, eu);
             }
             st.evals += chunk;
             vis_count += chunk;
@@ -257,81 +376,175 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
         ep_done += chunk;
     }
 
-    for (;;) {
-        uint64_t t_a = clock64();
-        if (ctl) {
-            int cont = 0;
-            n_new = 0;
-            uint64_t ck = pool_pop(sh.pool, pool_len, lane);
-            if (ck != NIDX_EMPTY_KEY) {
-                float cs = rank_key_score(ck);
-                float ws = res.worst_score();
-                if (!(cs < ws)) {
-                    cont = 1;
-                    uint32_t deg;
-                    uint32_t w = load_edge_word(g, rank_key_addr(ck), layer, lane, deg);
-                    bool is_edge = lane >= 1 && lane <= (int)deg;
-                    bool fresh = is_edge && vis_insert(vis, vis_log2, w);
-                    unsigned long long m = __ballot(fresh);
-                    int pos = __popcll(m & ((1ull << lane) - 1ull));
-                    if (fresh) sh.nb_addr[pos] = w;
-                    n_new = __popcll(m);
-                    st.expansions++;
-                    vis_count += n_new;
-                    if (vis_count > vis_cap - vis_cap / 4) {  // table too full: give up exactly here
-                        st.flags |= NIDX_FLAG_VISITED_OVERFLOW;
-                        cont = 0;
+    // ---- the expansion loop, software-pipelined ---------------------------------------------------------------------------
+    // The reference's loop is: pop the best candidate c, stop if it is worse than the worst result, score c's unvisited
+    // neighbours, admit them in edge order.  One expansion is two dependent memory round trips (edge record, then rows) plus
+    // the controller's serial admission — and with one query per workgroup nothing else hides them.  Here the NEXT candidate is
+    // determined before the current expansion is admitted: it is max(best of the pool, best admissible new neighbour) — the best
+    // new neighbour that beats the current worst result is always admitted, and nothing admitted can rank above it — so its
+    // edge record is fetched, its unvisited neighbours are listed (read-only test) and the other waves start on their rows while
+    // wave 0 runs the admission of the current expansion.  Nothing of the speculated expansion is committed (visited marks,
+    // counters) before the real pop confirms it; a mismatch (possible only with exactly tied scores or a pool overflow) throws
+    // it away and expands the popped candidate the plain way.
+    auto prepare = [&](uint64_t ck, NbBuf &dst) -> int {   // wave 0: the neighbours of ck that are not visited -> dst.addr
+        uint32_t deg;
+        const uint32_t w = load_edge_word(g, rank_key_addr(ck), layer, lane, deg);
+        const bool fresh = lane >= 1 && lane <= (int)deg && !vis_contains(vis, vis_log2, w);
+        const unsigned long long m = __ballot(fresh);
+        if (fresh) dst.addr[__popcll(m & ((1ull << lane) - 1ull))] = w;
+        return __popcll(m);
+    };
+    int p = 0;
+    uint64_t cur = NIDX_EMPTY_KEY;
+    uint32_t pf0 = 0, pf1 = 0, pf_sink = 0;
+    if (ctl) {
+        const uint64_t t_a = clock64();
+        int cont = 0, n0 = 0;
+        cur = cand.pop(res);
+        if (cur != NIDX_EMPTY_KEY && !(rank_key_score(cur) < res.worst_score())) {
+            cont = 1;
+            n0 = prepare(cur, sh.nb[0]);
+        }
+        if (lane == 0) {
+            sh.ctrl[0] = cont;
+            sh.ctrl[6] = n0;
+            sh.ctrl[3] = 0;
+        }
+        st.cyc_ctl += clock64() - t_a;
+    }
+    lds_barrier();
+    if (sh.ctrl[0]) {
+        eval_neighbours_dynamic<NJ, EVR>(seg, q, sh.nb[0], sh.ctrl[6], cosine, &sh.ctrl[3]);
+        lds_barrier();
+        for (;;) {
+            NbBuf &nb_cur = sh.nb[p], &nb_next = sh.nb[p ^ 1];
+            const int n_cur = sh.ctrl[6 + p];
+            // ---- wave 0: commit the expansion whose sums are in nb_cur, pick the next candidate, list its neighbours ----
+            float s = 0.f;
+            uint32_t addr = 0;
+            unsigned long long todo = 0;
+            uint64_t nxt = NIDX_EMPTY_KEY;
+            bool overflow = false;
+            const uint64_t t_a = clock64();
+            if (ctl) {
+                const bool mine = lane < n_cur;
+                addr = nb_cur.addr[lane];
+                bool ins = mine && vis_insert(vis, vis_log2, addr);
+                // an edge record that names a node twice (the reference can write one): the first occurrence counts
+                unsigned long long failed = __ballot(mine && !ins);
+                while (failed) {
+                    const int f = __ffsll((long long)failed) - 1;
+                    failed &= failed - 1;
+                    const unsigned long long same = __ballot(mine && addr == lane_bcast_u32(addr, f));
+                    if ((same >> lane) & 1ull) ins = lane == __ffsll((long long)same) - 1;
+                }
+                todo = __ballot(ins);
+                const int n_valid = __popcll(todo);
+                st.expansions++;
+                st.evals += n_valid;
+                vis_count += n_valid;
+                overflow = vis_count > vis_cap - vis_cap / 4;  // table too full: give up exactly here
+                s = ins ? score_from_sums(nb_cur.ab[lane], nb_cur.xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
+                int n_next = 0;
+                if (!overflow) {
+                    const float ws = res.worst_score();
+                    const bool adm = ins && (s > ws || res.len < k);
+                    const uint64_t bn = wave_max_u64(adm ? rank_key(s, addr) : NIDX_EMPTY_KEY);
+                    const uint64_t pm = cand.peek(res);
+                    nxt = pm > bn ? pm : bn;
+                    if (nxt == NIDX_EMPTY_KEY && pool_len > 0) nxt = pool_peek(sh.pool, pool_len, lane);  // tied evictions (rare)
+                    if (nxt != NIDX_EMPTY_KEY) n_next = prepare(nxt, nb_next);
+                    // Warm the L2 with the layer-0 edge records of the neighbours that can be admitted: whichever of them is
+                    // popped later finds its 256-byte record there instead of paying a second HBM round trip in front of its
+                    // rows.  Issued after this expansion's own edge load (vector loads return in order) and consumed one
+                    // expansion later, when they have long landed.
+                    pf_sink ^= pf0 ^ pf1;
+                    pf0 = pf1 = 0;
+                    if (layer == 0 && adm) {
+                        pf0 = g.l0[(size_t)addr * NIDX_L0_STRIDE];
+                        pf1 = g.l0[(size_t)addr * NIDX_L0_STRIDE + 32];
                     }
                 }
-            }
-            if (lane == 0) {
-                sh.ctrl[0] = cont;
-                sh.ctrl[1] = n_new;
-            }
-        }
-        __syncthreads();
-        uint64_t t_b = clock64();
-        st.cyc_ctl += t_b - t_a;
-        if (!sh.ctrl[0]) break;
-        n_new = sh.ctrl[1];
-        eval_neighbours<NJ, EVR>(seg, q, sh, n_new, cosine);
-        __syncthreads();
-        uint64_t t_c = clock64();
-        st.cyc_eval += t_c - t_b;
-        if (ctl && n_new > 0) {
-            float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
-            uint32_t addr = sh.nb_addr[lane];
-            st.evals += n_new;
-            // `if similarity > ws || len < k` replayed in edge order (search.rs:287-295).  Once the
-            // set is full ws only grows, so lanes failing against the current ws can be skipped.
-            unsigned long long todo = __ballot(lane < n_new);
-            while (todo) {
-                float ws = res.worst_score();
-                if (res.len >= k) {
-                    todo &= __ballot(lane < n_new && s > ws);
-                    if (!todo) break;
+                if (lane == 0) {
+                    sh.ctrl[5] = nxt != NIDX_EMPTY_KEY;
+                    sh.ctrl[6 + (p ^ 1)] = n_next;
+                    sh.ctrl[3] = 0;
                 }
-                int j = __ffsll((long long)todo) - 1;
-                todo &= ~(1ull << j);
-                float sj = lane_bcast_f32(s, j);
-                if (sj > ws || res.len < k) {
-                    uint64_t nk = rank_key(sj, lane_bcast_u32(addr, j));
-                    if (pool_len == NIDX_POOL_CAP) {
-                        if (res.len >= k) pool_prune(sh.pool, pool_len, ws, lane);
-                        if (pool_len == NIDX_POOL_CAP) {  // more than CAP live ties: cannot stay exact
-                            st.flags |= NIDX_FLAG_POOL_INEXACT;
-                            pool_len--;
+            }
+            lds_barrier();
+            const uint64_t t_b = clock64();
+            st.cyc_ctl += t_b - t_a;
+            const bool has_next = sh.ctrl[5] != 0;
+            const int n_next = sh.ctrl[6 + (p ^ 1)];
+            if (!ctl && has_next) eval_neighbours_dynamic<NJ, EVR>(seg, q, nb_next, n_next, cosine, &sh.ctrl[3]);
+            if (ctl) {
+                // `if similarity > ws || len < k` replayed in edge order (search.rs:287-295).  Once the
+                // set is full ws only grows, so lanes failing against the current ws can be skipped.
+                while (todo) {
+                    float ws = res.worst_score();
+                    if (res.len >= k) {
+                        todo &= __ballot(s > ws);
+                        if (!todo) break;
+                    }
+                    int j = __ffsll((long long)todo) - 1;
+                    todo &= ~(1ull << j);
+                    float sj = lane_bcast_f32(s, j);
+                    if (sj > ws || res.len < k) {
+                        uint64_t ek;
+                        bool eu;
+                        cand.insert(res, rank_key(sj, lane_bcast_u32(addr, j)), k, lane, ek, eu);
+                        // an unexpanded entry evicted while tying with the new worst result is still a live candidate
+                        if (eu && ek != NIDX_EMPTY_KEY && !(rank_key_score(ek) < res.worst_score())) {
+                            if (pool_len == NIDX_POOL_CAP) {
+                                pool_prune(sh.pool, pool_len, res.worst_score(), lane);
+                                if (pool_len == NIDX_POOL_CAP) {  // more than CAP live ties: cannot stay exact
+                                    st.flags |= NIDX_FLAG_POOL_INEXACT;
+                                    pool_len--;
+                                }
+                            }
+                            if (lane == 0) sh.pool[pool_len] = ek;
+                            pool_len++;
                         }
                     }
-                    if (lane == 0) sh.pool[pool_len] = nk;
-                    pool_len++;
-                    res.insert(nk, k, lane);
                 }
+                int cont = 0, redo = 0;
+                if (overflow) {
+                    st.flags |= NIDX_FLAG_VISITED_OVERFLOW;
+                } else {
+                    cur = cand.pop(res);
+                    if (cur == NIDX_EMPTY_KEY && pool_len > 0) cur = pool_pop(sh.pool, pool_len, lane);
+                    cont = cur != NIDX_EMPTY_KEY && !(rank_key_score(cur) < res.worst_score());
+                    redo = cont && cur != nxt;
+                }
+                if (lane == 0) {
+                    sh.ctrl[0] = cont;
+                    sh.ctrl[4] = redo;
+                }
+                const uint64_t t_c = clock64();
+                st.cyc_ins += t_c - t_b;
+                if (has_next) eval_neighbours_dynamic<NJ, EVR>(seg, q, nb_next, n_next, cosine, &sh.ctrl[3]);
+                st.cyc_eval += clock64() - t_c;
             }
+            lds_barrier();
+            if (!sh.ctrl[0]) break;
+            if (sh.ctrl[4]) {
+                // the pop did not return the speculated candidate: expand the real one (nothing of the other was committed)
+                if (ctl) {
+                    const int n1 = prepare(cur, nb_next);
+                    if (lane == 0) {
+                        sh.ctrl[6 + (p ^ 1)] = n1;
+                        sh.ctrl[3] = 0;
+                    }
+                }
+                lds_barrier();
+                eval_neighbours_dynamic<NJ, EVR>(seg, q, nb_next, sh.ctrl[6 + (p ^ 1)], cosine, &sh.ctrl[3]);
+                lds_barrier();
+            }
+            p ^= 1;
         }
-        // the controller's LDS reads of nb_* above complete before it rewrites them: same wave
-        st.cyc_ins += clock64() - t_c;
     }
+    pf_sink ^= pf0 ^ pf1;
+    asm volatile("" ::"v"(pf_sink));
     st.visited = st.visited > vis_count ? st.visited : vis_count;
 }
 

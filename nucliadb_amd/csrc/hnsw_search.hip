@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
                         bool fresh = is_edge && vis_insert(vis, a.vis_log2, w);
                         unsigned long long m = __ballot(fresh);
                         int pos = __popcll(m & ((1ull << lane) - 1ull));
-                        if (fresh) sh.nb_addr[pos] = w;
+                        if (fresh) sh.nb[0].addr[pos] = w;
                         n_new = __popcll(m);
                         st.expansions++;
                         vis_count += n_new;
@@ -184,11 +184,11 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
         __syncthreads();
         if (!sh.ctrl[0]) break;
         int n_new = sh.ctrl[1];
-        eval_neighbours<NJ, EVR>(a.seg, q, sh, n_new, cosine);
+        eval_neighbours<NJ, EVR>(a.seg, q, sh.nb[0], n_new, cosine);
         __syncthreads();
         if (ctl && n_new > 0) {
-            float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
-            uint32_t addr = sh.nb_addr[lane];
+            float s = lane < n_new ? score_from_sums(sh.nb[0].ab[lane], sh.nb[0].xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
+            uint32_t addr = sh.nb[0].addr[lane];
             st.evals += n_new;
             unsigned long long todo = __ballot(lane < n_new && s >= a.min_score);
             while (todo) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void hnsw_closest_spill_kernel(HnswSpillArgs a
                         }
                         const unsigned long long m = __ballot(fresh);
                         const int pos = __popcll(m & ((1ull << lane) - 1ull));
-                        if (fresh) sh.nb_addr[pos] = w;
+                        if (fresh) sh.nb[0].addr[pos] = w;
                         n_new = __popcll(m);
                     }
                 }
@@ -187,11 +187,11 @@ __global__ __launch_bounds__(256) void hnsw_closest_spill_kernel(HnswSpillArgs a
         __syncthreads();
         if (!sh.ctrl[0]) break;
         const int n_new = sh.ctrl[1];
-        eval_neighbours<NJ, 2>(a.seg, q, sh, n_new, cosine);
+        eval_neighbours<NJ, 2>(a.seg, q, sh.nb[0], n_new, cosine);
         __syncthreads();
         if (ctl && n_new > 0) {
-            const float s = lane < n_new ? score_from_sums(sh.nb_ab[lane], sh.nb_xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
-            const uint32_t addr = sh.nb_addr[lane];
+            const float s = lane < n_new ? score_from_sums(sh.nb[0].ab[lane], sh.nb[0].xx[lane], q.qq, q.sqrt_qq, cosine) : 0.f;
+            const uint32_t addr = sh.nb[0].addr[lane];
             pool.push(lane < n_new && s >= a.min_score, rank_key(s, addr), lane);
         }
     }

@@ -74,7 +74,7 @@ struct VectorIndex {
     std::vector<VectorSegment> segs;
     // tunables
     int waves_per_query = 4;
-    int eval_rows = 2;   // rows in flight per wave (HNSW distance phase); tuned on MI355X, profiles/r01_tune_hnsw.txt
+    int eval_rows = 4;   // rows in flight per wave (HNSW distance phase); tuned on MI355X (profiles/r02_tune_hnsw.txt: 4 rows fit the 128-VGPR budget since the pipelined loop)
     int min_waves = 4;   // register budget class of the HNSW kernel (4 => <=128 VGPR, 16 waves per CU)
     bool shape_pinned = false;  // eval_rows / min_waves were set by the caller (tunable or environment): no per-batch choice
     // launch shape of the HNSW kernels for a batch: a batch that leaves most CUs with at most one workgroup (<= 256 queries) is

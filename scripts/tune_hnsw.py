@@ -12,22 +12,20 @@ p.add_argument("--d", type=int, default=768)
 p.add_argument("--batch", type=int, default=1024)
 p.add_argument("--k", type=int, default=10)
 p.add_argument("--reps", type=int, default=8)
+p.add_argument("--corpus", default="uniform")
 p.add_argument("--grid", default="waves_per_query=4,2;eval_rows=4,2;min_waves=2,4;vis_log2=13,12")
 a = p.parse_args()
 L = _lib.lib()
 dev = torch.device("cuda", 0)
-g = torch.Generator(device=dev); g.manual_seed(1234567890)
-x = torch.rand((a.n, a.d), generator=g, device=dev) * 2 - 1
-x /= x.norm(dim=1, keepdim=True)
-xh = x.cpu().numpy(); del x
+import bench
+x = bench.gen_corpus(a.corpus, a.n, a.d, dev, 1234567890)
+q = bench.gen_queries(a.corpus, x, 4, a.batch, a.d, dev, 2)
 cfg = _lib.VectorConfigC(a.d, 1, 0, 0)
-seg = _lib.VectorSegmentC(xh.ctypes.data, a.d * 4, a.n, None, a.n, None, 0, 0, None, 0, None, None)
+seg = _lib.VectorSegmentC(x.data_ptr(), a.d * 4, a.n, None, a.n, None, 0, 0, None, 0, None, None)
 h = C.c_void_p()
 _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)))
+del x
 t0 = time.time(); _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2)); print("build_s", time.time() - t0, flush=True)
-gq = torch.Generator(device=dev); gq.manual_seed(2)
-q = torch.rand((4, a.batch, a.d), generator=gq, device=dev) * 2 - 1
-q /= q.norm(dim=2, keepdim=True)
 B, k = a.batch, a.k
 ov = torch.zeros((B, k), dtype=torch.int32, device=dev); os_ = torch.zeros((B, k), device=dev); oc = torch.zeros(B, dtype=torch.int32, device=dev)
 st = torch.zeros((B, 8), dtype=torch.int32, device=dev)
@@ -54,4 +52,8 @@ for combo in itertools.product(*vals):
     print(dict(zip(names, combo)), "ms=%.3f qps=%.0f GB/s=%.0f frac=%.3f evals=%.0f exp=%.1f flags=%d cyc(ctl,eval,ins,total)=%s us_total=%.0f" % (
         ms, B / ms * 1e3, byt / ms / 1e6, byt / ms / 1e6 / 8000, s[:, 0].mean(), s[:, 1].mean(), int(np.bitwise_or.reduce(s[:, 3])),
         np.round(cyc).astype(int).tolist(), cyc[3] / 100.0), flush=True)
+    tot = s[:, 7].astype(np.float64)
+    print("   total cycles per query: min %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f ; evals p50 %.0f p99 %.0f max %.0f ; exp p50 %.0f max %.0f" % (
+        tot.min(), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), np.percentile(s[:, 0], 50),
+        np.percentile(s[:, 0], 99), s[:, 0].max(), np.percentile(s[:, 1], 50), s[:, 1].max()), flush=True)
 L.nidx_gpu_vector_close(h)
