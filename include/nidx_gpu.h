@@ -443,6 +443,9 @@ int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *
 /* NIDX_OCCUR_SHOULD_GROUP: a Should clause of a nested Must(BooleanQuery[Should ...]) — the paragraph
  * keyword query under its Must filters (nidx_paragraph/src/search_query.rs:185-243): it scores like a
  * Should, and a document has to match at least one clause of the group. */
+/* NIDX_OCCUR_SHOULD_GROUP + g, g < 8: further required Should groups (a document needs a clause of EVERY group): the
+ * prefilter's BooleanQuery[Should SetQuery(field_uuid), Should SetQuery(uuid)] and an Or formula beside the keyword group
+ * (nidx_paragraph/src/search_query.rs:88-143). */
 enum { NIDX_OCCUR_SHOULD = 0, NIDX_OCCUR_MUST = 1, NIDX_OCCUR_MUST_NOT = 2, NIDX_OCCUR_SHOULD_GROUP = 3 };
 /* NIDX_TF_FREQ: BM25 with the stored tf (nidx_text, IndexRecordOption::WithFreqs);
  * NIDX_TF_BASIC: tf == 1 (nidx_paragraph keyword terms, query_parser/keyword_parser.rs:62-67);

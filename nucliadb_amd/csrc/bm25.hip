@@ -16,6 +16,8 @@
 // and the finished window is folded into the wave's top-k list.  Postings are read once (doc ids and tfs are
 // separate arrays).  bm25_merge_kernel then merges the slices of a query.
 // Bound: HBM; algorithmic bytes per posting scored = 9 (u32 doc + u32 tf + u8 fieldnorm id).
+#include <type_traits>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -24,13 +26,24 @@ namespace nidx {
 #define BM25_EMPTY 0xffffffffu
 
 // =====================================================================================================
-// One WAVE per work item, clause state in lane registers (lane c = clause c): no block barrier, no LDS traffic for
-// cursors / shares / clause attributes; the window's hash table, the 1 KiB tf cache and 64 counters are all the
-// LDS it uses (~11 KiB => up to 14 items per CU).
+// One WAVE per work item, four items per workgroup (they share nothing but the 1 KiB tf cache and never meet at a barrier
+// after the start).  Clause state lives in lane registers (lane c = clause c).  A window is R ROWS of 64 postings; a row
+// belongs to ONE clause, so everything a posting needs from its clause (list base, attributes, weight, hit bit) is
+// wave-uniform — scalar registers, no cross-lane shuffles.  Rows are shared out in proportion to what is left of every
+// clause's list; the window ends at the smallest doc id some clause could not fit (or at the slice's upper doc bound).
+// Per window:
+//   1. ONE round trip for the R rows' doc ids and the per-clause "first doc not loaded";
+//   2. ONE round trip for tf + fieldnorm of the postings inside the window;
+//   3. every posting finds or claims its document's slot in the wave's LDS hash table (all CAS issued, then the rare collisions);
+//   4. scores are added with LDS float atomics and the clause's hit bit is ORed in, row by row: one wave's LDS operations
+//      execute in order and rows are in clause order, so a document's f32 sum is built in clause order like the oracle's
+//      term-at-a-time loop, without a read-modify-write round trip per clause;
+//   5. the lane that claimed a document folds it: the boolean structure of the query is a test on the hit mask
+//      (all Must bits, no MustNot bit, one bit of every required Should group), then alive / facets / order key / cursor,
+//      and the rank key goes to the wave's top-k list if it beats the k-th.
+// LDS: 128 R slots x 12 B per wave (R = 4: 6 KiB; 25 KiB per workgroup => 6 workgroups = 24 waves per CU).
 // =====================================================================================================
-#define BW_TABLE 1024      /* hash slots */
-#define BW_WINDOW 512      /* postings per window: 8 per lane */
-#define BW_SHIFT 22        /* 32 - log2(BW_TABLE) */
+#define BW_MAX_GROUPS 8
 
 // wave reductions on the swap + DPP levels of device_common.h (no ds_bpermute round trips)
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
@@ -39,29 +52,45 @@ __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
     return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
 }
+__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+    return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a + b; });
+}
 __device__ inline uint32_t rl_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ inline float rl_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
-template <int KL>
-__global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
-    __shared__ uint32_t t_key[BW_TABLE];
-    __shared__ float t_acc[BW_TABLE];
-    __shared__ uint16_t t_flags[BW_TABLE];  // bit0 should-hit, bit1 excluded, bit2 group-hit, bits 8.. must count
+template <typename M>
+struct BwSlot {   // one document of the current window
+    float acc;    // clause-ordered f32 sum of the clause scores
+    M mask;       // bit c: clause c has a posting for the document
+};
+
+template <int KL, int R, typename M>
+__global__ __launch_bounds__(256) void bm25_rows_kernel(Bm25Args a, const uint32_t *items, uint32_t n_work) {
+    constexpr int T = 128 * R;              // slots per wave: the window's <= 64 R postings at load factor <= 0.5
+    constexpr int TSHIFT = 32 - (R == 4 ? 9 : R == 8 ? 10 : 8);
+    static_assert(R == 2 || R == 4 || R == 8, "rows per window");
     __shared__ float tf_cache[256];
-    __shared__ uint32_t taken[BM25_MAX_CLAUSES];
-    const int lane = threadIdx.x;
-    const Bm25Work work = a.work[blockIdx.x];
+    __shared__ uint32_t t_key_all[4][T];
+    __shared__ BwSlot<M> t_val_all[4][T];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *t_key = t_key_all[wave];
+    BwSlot<M> *t_val = t_val_all[wave];
+    tf_cache[threadIdx.x] = a.tf_cache[threadIdx.x];
+    for (int i = lane; i < T; i += 64) {
+        t_key[i] = BM25_EMPTY;
+        t_val[i].acc = 0.f;
+        t_val[i].mask = 0;
+    }
+    __syncthreads();   // the only workgroup barrier: the tf cache
+    const uint32_t slot_in_grid = blockIdx.x * 4u + (uint32_t)wave;
+    if (slot_in_grid >= n_work) return;
+    const uint32_t item = items[slot_in_grid];
+    const Bm25Work work = a.work[item];
     const uint32_t q = work.query;
     const uint64_t c0 = a.clause_offsets[q], c1 = a.clause_offsets[q + 1];
     const int C = (int)(c1 - c0);
     const int k = (int)a.k;
-
-    for (int i = lane; i < BW_TABLE; i += 64) {
-        t_key[i] = BM25_EMPTY;
-        t_acc[i] = 0.f;
-        t_flags[i] = 0;
-    }
-    for (int i = lane; i < 256; i += 64) tf_cache[i] = a.tf_cache[i];
-    taken[lane] = 0;
 
     // ---- lane c holds clause c ----
     uint32_t attr_l = 0;  // occur | mode << 8 | aux << 16
@@ -76,44 +105,54 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
         cur_l = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
         end_l = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
     }
-    const int n_must = __popcll(__ballot(lane < C && (attr_l & 0xff) == 1));
-    const int n_group = __popcll(__ballot(lane < C && (attr_l & 0xff) == 3));
-    if (work.n_slices > 1) {
-        // doc range of this slice: the wave finds, clause by clause, the first posting >= lo and >= hi (64-ary search)
-        const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
-        const uint32_t hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
-        for (int c = 0; c < C; c++) {
-            const bool aux = (rl_u32(attr_l, c) >> 16) != 0;
-            const uint32_t *ids = aux ? a.aux_doc_ids : a.doc_ids;
-            const unsigned long long b = lane_bcast_u64(cur_l, c), e = lane_bcast_u64(end_l, c);
-            unsigned long long res[2];
+    const uint32_t occur_l = attr_l & 0xff;
+    // the query's boolean structure as masks over the clause bits (BooleanQuery: every Must, no MustNot, at least one clause
+    // of every required Should group; plain Shoulds are required only when nothing else is)
+    const M must_m = (M)__ballot(lane < C && occur_l == 1);
+    const M not_m = (M)__ballot(lane < C && occur_l == 2);
+    const M should_m = (M)__ballot(lane < C && occur_l == 0);
+    M group_m[BW_MAX_GROUPS];
+    int n_groups = 0;
 #pragma unroll
-            for (int w = 0; w < 2; w++) {
-                const uint32_t target = w == 0 ? lo_doc : hi_doc;
-                unsigned long long left = b, right = e;  // first index in [left, right] whose doc >= target
+    for (int g = 0; g < BW_MAX_GROUPS; g++) {
+        group_m[g] = (M)__ballot(lane < C && occur_l == 3u + (uint32_t)g);
+        if (group_m[g]) n_groups = g + 1;
+    }
+    const bool any_required = must_m != 0 || n_groups > 0;
+    const uint32_t *ids_l = (attr_l >> 16) ? a.aux_doc_ids : a.doc_ids;   // this lane's clause's doc-id array
+    // doc range of this slice [lo_doc, hi_doc); the wave finds, clause by clause, the first posting >= lo_doc (64-ary search)
+    uint32_t hi_doc = 0xffffffffu;
+    if (work.n_slices > 1) {
+        const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
+        if (work.slice + 1 < work.n_slices) hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
+        if (work.slice > 0) {
+            for (int c = 0; c < C; c++) {
+                const bool aux = (rl_u32(attr_l, c) >> 16) != 0;
+                const uint32_t *ids = aux ? a.aux_doc_ids : a.doc_ids;
+                unsigned long long left = lane_bcast_u64(cur_l, c), right = lane_bcast_u64(end_l, c);  // first index in [left, right] whose doc >= lo_doc
                 while (right - left > 64) {
-                    unsigned long long step = (right - left + 63) / 64;
-                    unsigned long long probe = left + step * (unsigned long long)lane;
-                    bool ge = probe < right ? ids[probe] >= target : true;
-                    unsigned long long m = __ballot(ge);
-                    int first = m ? __ffsll((long long)m) - 1 : 64;
-                    unsigned long long nl = first == 0 ? left : left + step * (unsigned long long)(first - 1);
-                    unsigned long long nr = left + step * (unsigned long long)first;
+                    const unsigned long long step = (right - left + 63) / 64;
+                    const unsigned long long probe = left + step * (unsigned long long)lane;
+                    const bool ge = probe < right ? ids[probe] >= lo_doc : true;
+                    const unsigned long long m = __ballot(ge);
+                    const int first = m ? __ffsll((long long)m) - 1 : 64;
+                    const unsigned long long nl = first == 0 ? left : left + step * (unsigned long long)(first - 1);
+                    const unsigned long long nr = left + step * (unsigned long long)first;
                     left = nl;
                     right = nr < right ? nr : right;
                 }
-                unsigned long long probe = left + (unsigned long long)lane;
-                bool ge = probe < right ? ids[probe] >= target : true;
-                unsigned long long m = __ballot(ge);
-                int first = m ? __ffsll((long long)m) - 1 : 64;
-                res[w] = left + (unsigned long long)first < right ? left + (unsigned long long)first : right;
-            }
-            if (lane == c) {
-                cur_l = res[0];
-                end_l = res[1];
+                const unsigned long long probe = left + (unsigned long long)lane;
+                const bool ge = probe < right ? ids[probe] >= lo_doc : true;
+                const unsigned long long m = __ballot(ge);
+                const int first = m ? __ffsll((long long)m) - 1 : 64;
+                const unsigned long long res = left + (unsigned long long)first < right ? left + (unsigned long long)first : right;
+                if (lane == c) cur_l = res;
             }
         }
     }
+    // first doc of every clause inside the slice (0xffffffff: none)
+    uint32_t cdoc_l = 0xffffffffu;
+    if (lane < C && cur_l < end_l) cdoc_l = ids_l[cur_l];
     unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0, postings = 0, total = 0;
     const unsigned long long cy_t0 = clock64();
 
@@ -128,130 +167,188 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
     const int mslot = a.match_slot ? a.match_slot[q] : -1;
     uint32_t *mbits = mslot >= 0 ? a.match_bits + (size_t)mslot * a.match_words : nullptr;
 
-    for (;;) {
-        // ---- window: the slots are shared out in proportion to what is left of every clause's list in this slice
-        //      (doc ids of one slice are spread alike, so the lists then run out at about the same doc id);
-        //      the window ends at the smallest doc id that some clause could not fit ----
-        const unsigned long long left_l = lane < C ? end_l - cur_l : 0ull;
-        const unsigned long long total_left = wave_sum_u64(left_l);
-        if (total_left == 0) break;
-        uint32_t share_l = 0;
-        if (lane < C)
-            share_l = total_left <= (unsigned long long)BW_WINDOW ? (uint32_t)left_l
-                                                                  : (uint32_t)((left_l * (unsigned long long)(BW_WINDOW - C)) / total_left) + (left_l ? 1u : 0u);
-        uint32_t start_l = share_l;  // inclusive scan, then made exclusive
+    // One window.  FAST (at most R live clauses): whole rows per clause, everything per-clause is wave-uniform.  Otherwise the
+    // PACKED form: the 64 R slots are shared out posting by posting (every live clause gets at least one — clauses tied on the
+    // smallest doc id must all be inside the window), a lane's slots may belong to different clauses, their attributes travel
+    // by cross-lane reads, and the apply phase walks the clauses one by one to keep the clause order of the sums.
+    auto window = [&](auto fast_tag, unsigned long long act_m, int n_act) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const bool active = (act_m >> lane) & 1ull;
+        const float left_f = active ? (float)(end_l - cur_l) : 0.f;
+        const float tot = wave_butterfly_sum(left_f);   // only used for the shares: any rounding is fine
+        const uint32_t units = FAST ? (uint32_t)R : 64u * R;       // rows, or posting slots
+        uint32_t share_l = active ? 1u + (uint32_t)((float)(units - (uint32_t)n_act) * (left_f / tot)) : 0u;
+        uint32_t end_u = share_l;  // inclusive scan over the clause lanes
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(start_l, off, 64);
-            if (lane >= off) start_l += v;
+            const uint32_t v = __shfl_up(end_u, off, 64);
+            if (lane >= off) end_u += v;
         }
-        const uint32_t n_slots = rl_u32(start_l, 63);
-        start_l -= share_l;
-        uint32_t hi_c = 0xffffffffu;
-        if (lane < C && cur_l + share_l < end_l) hi_c = ((attr_l >> 16) ? a.aux_doc_ids : a.doc_ids)[cur_l + share_l];
-        const uint32_t hi = wave_min_u32(hi_c);
+        if (rl_u32(end_u, 63) > units) {   // float rounding pushed the shares past the window: one unit each
+            share_l = active ? 1u : 0u;
+            end_u = share_l;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(end_u, off, 64);
+                if (lane >= off) end_u += v;
+            }
+        }
+        const uint32_t start_u = end_u - share_l;
+        const uint32_t n_units = rl_u32(end_u, 63);
         const unsigned long long cy_a = clock64();
-        // ---- load phase: 8 postings per lane; the clause of slot g is found against the C share boundaries, its
-        //      cursor and attributes come from that clause's lane; then the three dependent steps (index -> doc id ->
-        //      tf + fieldnorm) are each issued for all 8 slots before the first use ----
-        uint32_t p_doc[8], p_attr[8];
-        float p_score[8], p_weight[8];
-        int p_clause[8];
-        unsigned long long p_idx[8];
+        // ---- round trip 1: the window's doc ids + every live clause's first doc beyond its share ----
+        const unsigned long long next_l = cur_l + (FAST ? 64ull : 1ull) * share_l;
+        uint32_t p_doc[R], p_at[R];
+        unsigned long long p_idx[R];
+        float p_w[R];
+        int p_c[R];          // the clause of slot (m, lane); FAST: wave-uniform per row
+        bool p_in[R];        // the posting exists (inside the clause's list)
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const uint32_t g = (uint32_t)lane + 64u * m;
-            int c = 0;
-            for (int j = 1; j < C; j++) c += g >= rl_u32(start_l, j) ? 1 : 0;
-            const unsigned long long cur_c = shfl_u64(cur_l, c), end_c = shfl_u64(end_l, c);
-            const uint32_t start_c = __shfl(start_l, c, 64);
-            p_attr[m] = __shfl(attr_l, c, 64);
-            p_weight[m] = __shfl(weight_l, c, 64);
-            const unsigned long long i = cur_c + (g - start_c);
-            const bool valid = g < n_slots && i < end_c;
-            p_clause[m] = valid ? c : -1;
-            p_idx[m] = valid ? i : 0;
+        for (int m = 0; m < R; m++) {
+            if constexpr (FAST) {
+                const int rc = __popcll(__ballot(lane < C && end_u <= (uint32_t)m));   // clauses that end before row m
+                const int c = rc < C ? rc : 0;
+                p_c[m] = c;
+                const unsigned long long cur_c = lane_bcast_u64(cur_l, c), end_c = lane_bcast_u64(end_l, c);
+                p_at[m] = rl_u32(attr_l, c);
+                p_w[m] = rl_f32(weight_l, c);
+                p_idx[m] = cur_c + 64ull * ((uint32_t)m - rl_u32(start_u, c)) + (unsigned long long)lane;
+                p_in[m] = (uint32_t)m < n_units && p_idx[m] < end_c;
+            } else {
+                const uint32_t g = (uint32_t)lane + 64u * m;
+                int c = 0;
+                for (int j = 1; j < C; j++) c += g >= rl_u32(start_u, j) ? 1 : 0;
+                p_c[m] = c;
+                const unsigned long long cur_c = shfl_u64(cur_l, c), end_c = shfl_u64(end_l, c);
+                p_at[m] = __shfl(attr_l, c, 64);
+                p_w[m] = __shfl(weight_l, c, 64);
+                p_idx[m] = cur_c + (g - __shfl(start_u, c, 64));
+                p_in[m] = g < n_units && p_idx[m] < end_c;
+            }
+            // unconditional loads (posting 0 of the main list stands in for a slot that does not exist): a load under a branch
+            // is waited for at the end of that branch, which would turn the window's one round trip into R of them
+            p_doc[m] = ((p_at[m] >> 16) && p_in[m] ? a.aux_doc_ids : a.doc_ids)[p_in[m] ? p_idx[m] : 0ull];
         }
-        // unconditional loads (index 0 stands in for an unused slot), so that all eight are in flight together
+        const bool more_l = active && next_l < end_l;
+        uint32_t hi_c = (more_l ? ids_l : a.doc_ids)[more_l ? next_l : 0ull];
 #pragma unroll
-        for (int m = 0; m < 8; m++) p_doc[m] = ((p_attr[m] >> 16) && p_clause[m] >= 0 ? a.aux_doc_ids : a.doc_ids)[p_idx[m]];
-        uint32_t p_tf[8], p_fn[8];
+        for (int m = 0; m < R; m++) p_doc[m] = p_in[m] ? p_doc[m] : 0xffffffffu;
+        hi_c = more_l ? hi_c : 0xffffffffu;
+        const uint32_t hi_w = wave_min_u32(hi_c);
+        const uint32_t hi = hi_w < hi_doc ? hi_w : hi_doc;
+        // ---- inside the window?  cursors advance by what was taken; a clause's next doc is its first posting that was not ----
+        bool p_ok[R];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            if (p_clause[m] >= 0 && p_doc[m] >= hi) p_clause[m] = -1;  // hi == 0xffffffff: every clause's remainder fits
-            const bool scored = p_clause[m] >= 0 && (p_attr[m] & 0xff) != 2 && ((p_attr[m] >> 8) & 0xff) != 2;
-            p_tf[m] = ((p_attr[m] >> 16) && scored ? a.aux_tfs : a.tfs)[scored && ((p_attr[m] >> 8) & 0xff) == 0 ? p_idx[m] : 0];
-            p_fn[m] = (uint32_t)a.fieldnorm_ids[scored ? p_doc[m] : 0];
-        }
+        for (int m = 0; m < R; m++) p_ok[m] = p_in[m] && p_doc[m] < hi;
+        if constexpr (FAST) {
+            bool upd_l = false;
+            uint32_t ndoc_l = hi_c;   // every loaded row taken: the next doc is the one behind them
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            p_score[m] = 0.f;
-            if (p_clause[m] >= 0 && (p_attr[m] & 0xff) != 2) {
-                const uint32_t mode = (p_attr[m] >> 8) & 0xff;
-                if (mode == 2) p_score[m] = p_weight[m];  // ConstScorer(boost)
-                else {
-                    const float tf = mode == 1 ? 1.0f : (float)p_tf[m];
-                    p_score[m] = p_weight[m] * (tf / (tf + tf_cache[p_fn[m]]));
+            for (int m = 0; m < R; m++) {
+                const unsigned long long okm = __ballot(p_ok[m]);
+                const unsigned long long overm = __ballot(p_in[m] && !p_ok[m]);
+                const uint32_t cnt = (uint32_t)__popcll(okm);
+                const uint32_t first_over = overm ? rl_u32(p_doc[m], __ffsll((long long)overm) - 1) : 0xffffffffu;
+                if (lane == p_c[m]) {
+                    cur_l += cnt;
+                    if (overm && !upd_l) {
+                        ndoc_l = first_over;
+                        upd_l = true;
+                    }
                 }
+                postings += lane == 0 ? cnt : 0u;
+            }
+            if (active) cdoc_l = ndoc_l;
+        } else {
+            for (int c = 0; c < C; c++) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int m = 0; m < R; m++) cnt += (uint32_t)__popcll(__ballot(p_ok[m] && p_c[m] == c));
+                if (lane == c) cur_l += cnt;
+                postings += lane == 0 ? cnt : 0u;
+            }
+            const bool left_some = active && cur_l < end_l;
+            const uint32_t nd = (left_some ? ids_l : a.doc_ids)[left_some ? cur_l : 0ull];
+            if (active) cdoc_l = left_some ? nd : 0xffffffffu;
+        }
+        // ---- round trip 2: tf + fieldnorm of the postings that are scored ----
+        uint32_t p_tf[R], p_fn[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const uint32_t occur = p_at[m] & 0xff, mode = (p_at[m] >> 8) & 0xff;
+            const bool scored = p_ok[m] && occur != 2 && mode != 2;
+            const bool want_tf = scored && mode == 0;
+            p_tf[m] = ((p_at[m] >> 16) && want_tf ? a.aux_tfs : a.tfs)[want_tf ? p_idx[m] : 0ull];
+            p_fn[m] = (uint32_t)a.fieldnorm_ids[scored ? p_doc[m] : 0u];
+            p_tf[m] = want_tf ? p_tf[m] : 1u;
+        }
+        float p_score[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const uint32_t mode = (p_at[m] >> 8) & 0xff;
+            if (mode == 2) p_score[m] = p_w[m];  // ConstScorer(boost)
+            else {
+                const float tf = (float)p_tf[m];   // mode 1: tf == 1
+                p_score[m] = p_w[m] * (tf / (tf + tf_cache[p_fn[m]]));
             }
         }
         const unsigned long long cy_b = clock64();
-        // ---- probe phase: every posting finds (or claims) its document's slot; which posting claims a slot does
-        //      not matter, so all clauses probe together.  The claimer OWNS the document for the fold. ----
-        uint32_t p_slot[8];
+        // ---- probe: every posting finds (or claims) its document's slot; the claimer OWNS the document for the fold ----
+        uint32_t p_slot[R];
         uint32_t owned = 0;
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            p_slot[m] = 0;
-            if (p_clause[m] < 0) continue;
-            atomicAdd(&taken[p_clause[m]], 1u);
-            const uint32_t d = p_doc[m];
-            uint32_t h = (d * 2654435761u) >> BW_SHIFT;
-            for (;;) {
-                uint32_t old = atomicCAS(&t_key[h], BM25_EMPTY, d);
-                if (old == BM25_EMPTY) { owned |= 1u << m; break; }
-                if (old == d) break;
-                h = (h + 1) & (BW_TABLE - 1);
-            }
-            p_slot[m] = h;
-        }
-        // cursors advance by what was taken (lane c reads clause c's counter and clears it)
         {
-            const uint32_t t = taken[lane];
-            taken[lane] = 0;
-            if (lane < C) cur_l += t;
-            postings += t;
-        }
-        // ---- apply phase: clause by clause, so every doc's f32 sum is built in clause order; within a clause every
-        //      posting is a different document and one wave's LDS operations execute in order ----
-        for (int c = 0; c < C; c++) {
-            const int occur = (int)(rl_u32(attr_l, c) & 0xff);
+            uint32_t old[R];
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                if (p_clause[m] != c) continue;
-                const uint32_t h = p_slot[m];
-                if (occur == 2) {
-                    t_flags[h] |= 2;  // MustNot
-                } else {
-                    t_acc[h] = t_acc[h] + p_score[m];
-                    if (occur == 1) t_flags[h] += 0x100;
-                    else if (occur == 3) t_flags[h] |= 4;
-                    else t_flags[h] |= 1;
+            for (int m = 0; m < R; m++) {
+                p_slot[m] = (p_doc[m] * 2654435761u) >> TSHIFT;
+                old[m] = p_ok[m] ? atomicCAS(&t_key[p_slot[m]], BM25_EMPTY, p_doc[m]) : BM25_EMPTY;
+            }
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if (!p_ok[m]) continue;
+                if (old[m] == BM25_EMPTY) { owned |= 1u << m; continue; }
+                uint32_t o = old[m], h = p_slot[m];
+                while (o != p_doc[m]) {   // another document's slot: linear probing (the table is at most half full)
+                    h = (h + 1) & (T - 1);
+                    o = atomicCAS(&t_key[h], BM25_EMPTY, p_doc[m]);
+                    if (o == BM25_EMPTY) { owned |= 1u << m; break; }
                 }
+                p_slot[m] = h;
+            }
+        }
+        // ---- apply in clause order (LDS operations of one wave execute in order): FAST rows are in clause order already ----
+        if constexpr (FAST) {
+#pragma unroll
+            for (int m = 0; m < R; m++)
+                if (p_ok[m]) {
+                    if ((p_at[m] & 0xff) != 2) __hip_atomic_fetch_add(&t_val[p_slot[m]].acc, p_score[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&t_val[p_slot[m]].mask, (M)1 << p_c[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+        } else {
+            for (int c = 0; c < C; c++) {
+#pragma unroll
+                for (int m = 0; m < R; m++)
+                    if (p_ok[m] && p_c[m] == c) {
+                        if ((p_at[m] & 0xff) != 2) __hip_atomic_fetch_add(&t_val[p_slot[m]].acc, p_score[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&t_val[p_slot[m]].mask, (M)1 << c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
             }
         }
         const unsigned long long cy_c = clock64();
         // ---- fold the window into the top-k, count matches, clear the table: each lane folds the documents it owns ----
         uint32_t matched_here = 0;
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
+        for (int m = 0; m < R; m++) {
             bool ok = false;
             uint64_t ck = NIDX_EMPTY_KEY;
             if (owned & (1u << m)) {
                 const uint32_t i = p_slot[m];
                 const uint32_t d = p_doc[m];
-                const uint16_t f = t_flags[i];
-                ok = !(f & 2) && (int)(f >> 8) == n_must && (n_group == 0 || (f & 4)) && (n_must > 0 || n_group > 0 || (f & 1));
+                const BwSlot<M> v = t_val[i];
+                ok = (v.mask & must_m) == must_m && (v.mask & not_m) == 0 && (any_required || (v.mask & should_m) != 0);
+#pragma unroll
+                for (int g = 0; g < BW_MAX_GROUPS; g++)
+                    if (g < n_groups && group_m[g] != 0 && (v.mask & group_m[g]) == 0) ok = false;   // (group ids need not be dense)
                 if (ok && a.alive) ok = bit_test(a.alive, d);
                 if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
                 if (ok && a.order_key) {
@@ -259,7 +356,7 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
                     const uint32_t r = a.order_key[d];
                     ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
                 } else if (ok) {
-                    float s = t_acc[i];
+                    float s = v.acc;
                     if (has_after) {
                         // tweak_score: -inf for docs not after the cursor
                         uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
@@ -270,20 +367,332 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
                     ck = rank_key(s, d);
                 }
                 t_key[i] = BM25_EMPTY;
-                t_acc[i] = 0.f;
-                t_flags[i] = 0;
+                t_val[i].acc = 0.f;
+                t_val[i].mask = 0;
             }
-            unsigned long long okm = __ballot(ok);
+            const unsigned long long okm = __ballot(ok);
             matched_here += (uint32_t)__popcll(okm);
             unsigned long long mm = __ballot(ok && ck > kth);
             while (mm) {
-                int src = __ffsll((long long)mm) - 1;
+                const int src = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
-                uint64_t nk = lane_bcast_u64(ck, src);
+                const uint64_t nk = lane_bcast_u64(ck, src);
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
         }
         total += matched_here;
+        cy_load += cy_b - cy_a;
+        cy_apply += cy_c - cy_b;
+        cy_fold += clock64() - cy_c;
+        n_win++;
+    };
+    for (;;) {
+        // live clauses: those whose next doc is still inside the slice
+        const unsigned long long act_m = __ballot(lane < C && cdoc_l < hi_doc);
+        if (!act_m) break;
+        const int n_act = __popcll(act_m);
+        if (n_act <= R) window(std::true_type{}, act_m, n_act);
+        else window(std::false_type{}, act_m, n_act);
+    }
+    if (a.dbg && lane == 0) {
+        atomicAdd(&a.dbg[0], cy_load);
+        atomicAdd(&a.dbg[1], cy_apply);
+        atomicAdd(&a.dbg[2], cy_fold);
+        atomicAdd(&a.dbg[3], clock64() - cy_t0);
+        atomicAdd(&a.dbg[4], n_win);
+        atomicAdd(&a.dbg[5], 1ull);
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KL; i++) {
+        const int e = 64 * i + lane;
+        const uint64_t key = top.mine(i);
+        const bool valid = key != NIDX_EMPTY_KEY && e < k;
+        cnt += (uint32_t)__popcll(__ballot(valid));
+        if (e < k) a.out_key[(size_t)item * k + e] = valid ? key : NIDX_EMPTY_KEY;
+    }
+    postings = lane_bcast_u64(postings, 0);
+    if (lane == 0) {
+        a.out_count[item] = cnt;
+        a.out_total[item] = total;
+        a.out_postings[item] = postings;
+    }
+}
+
+// =====================================================================================================
+// The lean form for queries of at most R clauses (the usual request: a few keywords plus a few filters).  Same
+// arithmetic, same window rule and same results as bm25_rows_kernel's FAST window; what differs is the instruction count:
+// a clause's list is a wave-uniform base pointer + a 32-bit position (global loads with a scalar base), the row -> clause
+// table and the cursor bookkeeping run on the scalar unit, in-window tests are mask arithmetic on ballots, and the table is
+// 80 R slots (load factor <= 0.8, ~0.5 typical) so that five workgroups of four items fit a CU.
+// =====================================================================================================
+template <int KL, int R>
+__global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
+    constexpr uint32_t T = 80 * R;
+    __shared__ float tf_cache[256];
+    __shared__ uint32_t t_key_all[4][T];
+    __shared__ uint2 t_val_all[4][T];    // x: the f32 sum's bits, y: hit mask (bit c = clause c)
+    __shared__ uint32_t s_group_all[4][BW_MAX_GROUPS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *t_key = t_key_all[wave];
+    uint2 *t_val = t_val_all[wave];
+    uint32_t *s_group = s_group_all[wave];
+    tf_cache[threadIdx.x] = a.tf_cache[threadIdx.x];
+    for (uint32_t i = lane; i < T; i += 64) {
+        t_key[i] = BM25_EMPTY;
+        t_val[i] = make_uint2(0u, 0u);
+    }
+    __syncthreads();   // the only workgroup barrier: the tf cache
+    const uint32_t slot_in_grid = blockIdx.x * 4u + (uint32_t)wave;
+    if (slot_in_grid >= n_items) return;
+    const uint32_t item = items[slot_in_grid];
+    const Bm25Work work = a.work[item];
+    const uint32_t q = work.query;
+    const uint64_t c0 = a.clause_offsets[q];
+    const int C = (int)(a.clause_offsets[q + 1] - c0);   // <= R
+    const int k = (int)a.k;
+
+    // ---- lane c holds clause c: list = base pointers + [pos, len) ----
+    uint32_t attr_l = 0, pos_l = 0, len_l = 0;
+    float weight_l = 0.f;
+    const uint32_t *ids_l = a.doc_ids, *tfs_l = a.tfs;
+    if (lane < C) {
+        const Bm25ClauseDev cd = a.clauses[c0 + lane];
+        const bool aux = (cd.term & BM25_AUX_TERM) != 0;
+        const uint32_t ti = cd.term & ~BM25_AUX_TERM;
+        attr_l = (uint32_t)cd.occur | ((uint32_t)cd.mode << 8);
+        weight_l = cd.weight;
+        const unsigned long long b = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
+        const unsigned long long e = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
+        ids_l = (aux ? a.aux_doc_ids : a.doc_ids) + b;
+        if (cd.mode == 0) tfs_l = (aux ? a.aux_tfs : a.tfs) + b;   // other modes never use a stored tf: any valid address
+        len_l = (uint32_t)(e - b);
+    }
+    const uint32_t occur_l = attr_l & 0xff;
+    const uint32_t must_m = (uint32_t)__ballot(lane < C && occur_l == 1);
+    const uint32_t not_m = (uint32_t)__ballot(lane < C && occur_l == 2);
+    const uint32_t should_m = (uint32_t)__ballot(lane < C && occur_l == 0);
+    int n_groups = 0;
+#pragma unroll
+    for (int g = 0; g < BW_MAX_GROUPS; g++) {
+        const uint32_t gm = (uint32_t)__ballot(lane < C && occur_l == 3u + (uint32_t)g);
+        if (gm) {   // dense list of the non-empty groups
+            if (lane == 0) s_group[n_groups] = gm;
+            n_groups++;
+        }
+    }
+    const bool any_required = must_m != 0 || n_groups > 0;
+    uint32_t hi_doc = 0xffffffffu;
+    if (work.n_slices > 1) {
+        const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
+        if (work.slice + 1 < work.n_slices) hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
+        if (work.slice > 0) {
+            // first posting >= lo_doc of every clause: 64-ary search, clause by clause
+            for (int c = 0; c < C; c++) {
+                const uint32_t *ids = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)ids_l, c));
+                uint32_t left = 0, right = rl_u32(len_l, c);
+                while (right - left > 64) {
+                    const uint32_t step = (right - left + 63) / 64;
+                    const uint32_t probe = left + step * (uint32_t)lane;
+                    const bool ge = probe < right ? ids[probe] >= lo_doc : true;
+                    const unsigned long long m = __ballot(ge);
+                    const int first = m ? __ffsll((long long)m) - 1 : 64;
+                    const uint32_t nl = first == 0 ? left : left + step * (uint32_t)(first - 1);
+                    const uint32_t nr = left + step * (uint32_t)first;
+                    left = nl;
+                    right = nr < right ? nr : right;
+                }
+                const uint32_t probe = left + (uint32_t)lane;
+                const bool ge = probe < right ? ids[probe] >= lo_doc : true;
+                const unsigned long long m = __ballot(ge);
+                const int first = m ? __ffsll((long long)m) - 1 : 64;
+                const uint32_t res = left + (uint32_t)first < right ? left + (uint32_t)first : right;
+                if (lane == c) pos_l = res;
+            }
+        }
+    }
+    uint32_t cdoc_l = 0xffffffffu;   // the clause's next doc inside the slice
+    if (lane < C && pos_l < len_l) cdoc_l = ids_l[pos_l];
+    unsigned long long cy_load = 0, cy_apply = 0, cy_fold = 0, n_win = 0, postings = 0, total = 0;
+    const unsigned long long cy_t0 = clock64();
+
+    WaveTopK<KL> top;
+    top.init();
+    uint64_t kth = NIDX_EMPTY_KEY;
+    const bool has_after = a.after != nullptr && a.after[q].has_after != 0;
+    const int32_t after_key = has_after ? total_key(a.after[q].score) : 0;
+    const int after_tie = has_after ? a.after[q].tie_break : 0;
+    const uint64_t after_addr = has_after ? a.after[q].docaddr : 0;
+    const int mslot = a.match_slot ? a.match_slot[q] : -1;
+    uint32_t *mbits = mslot >= 0 ? a.match_bits + (size_t)mslot * a.match_words : nullptr;
+
+    for (;;) {
+        const unsigned long long act_m = __ballot(lane < C && cdoc_l < hi_doc);
+        if (!act_m) break;
+        const bool active = (act_m >> lane) & 1ull;
+        const int n_act = __popcll(act_m);
+        // rows: one per live clause, the rest in proportion to the list remainders
+        const float left_f = active ? (float)(len_l - pos_l) : 0.f;
+        const float tot = wave_butterfly_sum(left_f);
+        uint32_t rows_l = active ? 1u + (uint32_t)((float)(R - n_act) * (left_f / tot)) : 0u;
+        // wave-uniform maps, one nibble per row / clause: the clause of row m, and the first row of clause j
+        uint32_t run = 0, row_map = 0, start_map = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const uint32_t rj = rl_u32(rows_l, j);
+            start_map |= run << (4 * j);
+            if (rj) row_map |= ((uint32_t)j * 0x11111111u) & (((rj >= 8 ? 0u : (1u << (4 * rj))) - 1u) << (4 * run));
+            run += rj;
+        }
+        if (run > (uint32_t)R) {   // float rounding pushed the shares past R: one row each
+            rows_l = active ? 1u : 0u;
+            run = 0, row_map = 0, start_map = 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const uint32_t rj = rl_u32(rows_l, j);
+                start_map |= run << (4 * j);
+                if (rj) row_map |= ((uint32_t)j * 0x11111111u) & (0xfu << (4 * run));
+                run += rj;
+            }
+        }
+        const uint32_t n_rows = run;
+        const unsigned long long cy_a = clock64();
+        // ---- round trip 1 ----
+        uint32_t p_doc[R], p_idx[R];
+        int row_c[R];
+        unsigned long long in_m[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int c = (int)((row_map >> (4 * m)) & 15u);   // rows past n_rows map to clause 0 and are masked out
+            row_c[m] = c;
+            const uint32_t first_row = (start_map >> (4 * c)) & 15u;
+            const uint32_t *ids = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)ids_l, c));
+            p_idx[m] = rl_u32(pos_l, c) + 64u * ((uint32_t)m - first_row) + (uint32_t)lane;
+            in_m[m] = (uint32_t)m < n_rows ? __ballot(p_idx[m] < rl_u32(len_l, c)) : 0ull;
+            p_doc[m] = ids[p_idx[m]];   // unconditional (the arrays are padded): every row's load is in flight before the first wait
+        }
+        const uint32_t next_l = pos_l + 64u * rows_l;
+        const bool more_l = active && next_l < len_l;
+        uint32_t hi_c = ids_l[more_l ? next_l : 0u];
+        hi_c = more_l ? hi_c : 0xffffffffu;
+        const uint32_t hi_w = wave_min_u32(hi_c);
+        const uint32_t hi = hi_w < hi_doc ? hi_w : hi_doc;
+        // ---- in-window masks, cursors, next docs ----
+        unsigned long long ok_m[R];
+        bool upd_l = false;
+        uint32_t ndoc_l = hi_c;
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            ok_m[m] = in_m[m] & __ballot(p_doc[m] < hi);
+            const unsigned long long over = in_m[m] & ~ok_m[m];
+            const uint32_t cnt = (uint32_t)__popcll(ok_m[m]);
+            const uint32_t first_over = over ? rl_u32(p_doc[m], __ffsll((long long)over) - 1) : 0xffffffffu;
+            if (lane == row_c[m]) {
+                pos_l += cnt;
+                if (over && !upd_l) {
+                    ndoc_l = first_over;
+                    upd_l = true;
+                }
+            }
+            postings += cnt;
+        }
+        if (active) cdoc_l = ndoc_l;
+        // ---- round trip 2: tf + fieldnorm ----
+        uint32_t p_tf[R], p_fn[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const uint32_t *tfs = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)tfs_l, row_c[m]));
+            const bool ok = (ok_m[m] >> lane) & 1ull;
+            p_tf[m] = tfs[(rl_u32(attr_l, row_c[m]) >> 8) == 0 ? p_idx[m] : 0u];
+            p_fn[m] = (uint32_t)a.fieldnorm_ids[ok ? p_doc[m] : 0u];
+        }
+        float p_score[R];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const uint32_t mode = rl_u32(attr_l, row_c[m]) >> 8;
+            const float w = rl_f32(weight_l, row_c[m]);
+            const float tf = mode == 0 ? (float)p_tf[m] : 1.0f;
+            const float bm = w * (tf / (tf + tf_cache[p_fn[m]]));
+            p_score[m] = mode == 2 ? w : bm;   // ConstScorer(boost)
+        }
+        const unsigned long long cy_b = clock64();
+        // ---- probe ----
+        uint32_t p_slot[R];
+        uint32_t owned = 0;
+        {
+            uint32_t old[R];
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                p_slot[m] = __umulhi(p_doc[m] * 2654435761u, T);
+                const bool ok = (ok_m[m] >> lane) & 1ull;
+                old[m] = ok ? atomicCAS(&t_key[p_slot[m]], BM25_EMPTY, p_doc[m]) : BM25_EMPTY;
+            }
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const bool ok = (ok_m[m] >> lane) & 1ull;
+                if (!ok) continue;
+                if (old[m] == BM25_EMPTY) { owned |= 1u << m; continue; }
+                uint32_t o = old[m], h = p_slot[m];
+                while (o != p_doc[m]) {
+                    h = h + 1 == T ? 0 : h + 1;
+                    o = atomicCAS(&t_key[h], BM25_EMPTY, p_doc[m]);
+                    if (o == BM25_EMPTY) { owned |= 1u << m; break; }
+                }
+                p_slot[m] = h;
+            }
+        }
+        // ---- apply: rows are in clause order, one wave's LDS operations execute in order ----
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const bool ok = (ok_m[m] >> lane) & 1ull;
+            const uint32_t occur = rl_u32(attr_l, row_c[m]) & 0xff;
+            if (ok) {
+                if (occur != 2) __hip_atomic_fetch_add(reinterpret_cast<float *>(&t_val[p_slot[m]].x), p_score[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&t_val[p_slot[m]].y, 1u << row_c[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        const unsigned long long cy_c = clock64();
+        // ---- fold ----
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            bool ok = false;
+            uint64_t ck = NIDX_EMPTY_KEY;
+            if (owned & (1u << m)) {
+                const uint32_t i = p_slot[m];
+                const uint32_t d = p_doc[m];
+                const uint2 v = t_val[i];
+                ok = (v.y & must_m) == must_m && (v.y & not_m) == 0 && (any_required || (v.y & should_m) != 0);
+                for (int g = 0; g < n_groups; g++)
+                    if ((v.y & s_group[g]) == 0) ok = false;
+                if (ok && a.alive) ok = bit_test(a.alive, d);
+                if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
+                if (ok && a.order_key) {
+                    const uint32_t r = a.order_key[d];
+                    ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
+                } else if (ok) {
+                    float s = __builtin_bit_cast(float, v.x);
+                    if (has_after) {
+                        uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
+                        int32_t sk = total_key(s);
+                        bool after = sk < after_key || (sk == after_key && (after_tie == 0 || (after_tie == 1 && addr > after_addr)));
+                        if (!after) s = -INFINITY;
+                    }
+                    ck = rank_key(s, d);
+                }
+                t_key[i] = BM25_EMPTY;
+                t_val[i] = make_uint2(0u, 0u);
+            }
+            const unsigned long long okm = __ballot(ok);
+            total += (uint32_t)__popcll(okm);
+            unsigned long long mm = __ballot(ok && ck > kth);
+            while (mm) {
+                const int src = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const uint64_t nk = lane_bcast_u64(ck, src);
+                if (nk > kth) kth = top.insert_kth(nk, k, lane);
+            }
+        }
         cy_load += cy_b - cy_a;
         cy_apply += cy_c - cy_b;
         cy_fold += clock64() - cy_c;
@@ -304,13 +713,12 @@ __global__ __launch_bounds__(64) void bm25_wave_kernel(Bm25Args a) {
         const uint64_t key = top.mine(i);
         const bool valid = key != NIDX_EMPTY_KEY && e < k;
         cnt += (uint32_t)__popcll(__ballot(valid));
-        if (e < k) a.out_key[(size_t)blockIdx.x * k + e] = valid ? key : NIDX_EMPTY_KEY;
+        if (e < k) a.out_key[(size_t)item * k + e] = valid ? key : NIDX_EMPTY_KEY;
     }
-    postings = wave_sum_u64(postings);  // lane c counted clause c's postings
     if (lane == 0) {
-        a.out_count[blockIdx.x] = cnt;
-        a.out_total[blockIdx.x] = total;
-        a.out_postings[blockIdx.x] = postings;
+        a.out_count[item] = cnt;
+        a.out_total[item] = total;
+        a.out_postings[item] = postings;
     }
 }
 
@@ -322,27 +730,41 @@ __global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
     const uint32_t q = blockIdx.x;
     const uint32_t w0 = m.item_first[q], w1 = m.item_first[q + 1];
     const int k = (int)m.k;
+    const uint32_t n_items = w1 - w0;
+    // Count / postings: every lane sums its share of the items
+    unsigned long long total = 0, postings = 0;
+    for (uint32_t w = w0 + (uint32_t)lane; w < w1; w += 64) {
+        total += m.item_total[w];
+        postings += m.item_postings[w];
+    }
+    total = wave_sum_u64(total);
+    postings = wave_sum_u64(postings);
     WaveTopK<KL> top;
     top.init();
-    uint64_t kth = NIDX_EMPTY_KEY;
-    unsigned long long total = 0, postings = 0;
-    for (uint32_t w = w0; w < w1; w++) {
-        const uint32_t cnt = m.item_count[w];
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            const uint32_t i = base + (uint32_t)lane;
-            const uint64_t key = i < cnt ? m.item_key[(size_t)w * k + i] : NIDX_EMPTY_KEY;
+    if (n_items == 1) {
+        // one slice: its list is the answer
+        const uint32_t cnt = m.item_count[w0];
+#pragma unroll
+        for (int i = 0; i < KL; i++) {
+            const int e = 64 * i + lane;
+            top.l[i].key = e < (int)cnt && e < k ? m.item_key[(size_t)w0 * k + e] : NIDX_EMPTY_KEY;
+        }
+    } else {
+        // all the slices' keys side by side, 64 at a time: the loads of a chunk do not wait for any other list
+        uint64_t kth = NIDX_EMPTY_KEY;
+        const uint32_t slots = n_items * (uint32_t)k;
+        for (uint32_t base = 0; base < slots; base += 64) {
+            const uint32_t idx = base + (uint32_t)lane;
+            const uint32_t it = idx / (uint32_t)k, pos = idx - it * (uint32_t)k;
+            const bool have = idx < slots && pos < m.item_count[w0 + (idx < slots ? it : 0u)];
+            const uint64_t key = have ? m.item_key[(size_t)(w0 + it) * k + pos] : NIDX_EMPTY_KEY;
             unsigned long long mm = __ballot(key > kth);
-            if (!mm) break;  // sorted: nothing further down this list can enter
             while (mm) {
                 const int src = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
                 const uint64_t nk = lane_bcast_u64(key, src);
                 if (nk > kth) kth = top.insert_kth(nk, k, lane);
             }
-        }
-        if (lane == 0) {
-            total += m.item_total[w];
-            postings += m.item_postings[w];
         }
     }
     uint32_t cnt = 0;
@@ -371,11 +793,29 @@ hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s) {
-    if (n_work == 0) return hipSuccess;
-    // one WAVE per work item: no block barrier anywhere on the path, four times as many independent items per CU
-    if (a.k > 64) hipLaunchKernelGGL(bm25_wave_kernel<4>, dim3(n_work), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(bm25_wave_kernel<1>, dim3(n_work), dim3(64), 0, s, a);
+template <int KL, typename M>
+static void launch_rows(const Bm25Args &a, const uint32_t *items, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL((bm25_rows_kernel<KL, 4, M>), dim3((n + 3) / 4), dim3(256), 0, s, a, items, n);
+}
+
+// Two launches over disjoint item lists (device arrays of indices into a.work): `fast` = the items of queries with at most
+// BM25_FAST_CLAUSES clauses, `wide` = the rest (max_clauses: the most clauses any of them has; <= 32: 32-bit hit masks).
+hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uint32_t n_fast, const uint32_t *wide_items, uint32_t n_wide,
+                              uint32_t max_clauses, hipStream_t s) {
+    if (n_fast) {
+        const dim3 grid((n_fast + 3) / 4), block(256);
+        if (a.k > 64) hipLaunchKernelGGL((bm25_fast_kernel<4, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
+        else hipLaunchKernelGGL((bm25_fast_kernel<1, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
+    }
+    if (n_wide) {
+        if (max_clauses > 32) {
+            if (a.k > 64) launch_rows<4, unsigned long long>(a, wide_items, n_wide, s);
+            else launch_rows<1, unsigned long long>(a, wide_items, n_wide, s);
+        } else {
+            if (a.k > 64) launch_rows<4, uint32_t>(a, wide_items, n_wide, s);
+            else launch_rows<1, uint32_t>(a, wide_items, n_wide, s);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -139,8 +139,8 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
             return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: posting doc id %u >= n_docs %u", s, max_doc, in.n_docs);
         NIDX_HIP(seg.term_offsets.alloc((size_t)(in.n_terms + 1) * 8));
         NIDX_HIP(hipMemcpy(seg.term_offsets.p, in.term_offsets, (size_t)(in.n_terms + 1) * 8, hipMemcpyHostToDevice));
-        NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4));
-        NIDX_HIP(seg.tfs.alloc(std::max<size_t>(n_post, 1) * 4));
+        NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
+        NIDX_HIP(seg.tfs.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
         if (n_post) {
             NIDX_HIP(hipMemcpy(seg.doc_ids.p, in.doc_ids, n_post * 4, hipMemcpyHostToDevice));
             NIDX_HIP(hipMemcpy(seg.tfs.p, in.tfs, n_post * 4, hipMemcpyHostToDevice));
@@ -487,14 +487,21 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
     std::vector<Bm25ClauseDev> dev_clauses(n_clauses);
+    uint32_t max_clauses = 0;
     for (uint32_t q = 0; q < nq; q++) {
         if (clause_offsets[q + 1] < clause_offsets[q]) return fail(NIDX_ERR_INVALID_ARGUMENT, "clause_offsets not monotone");
         if (clause_offsets[q + 1] - clause_offsets[q] > BM25_MAX_CLAUSES)
             return fail(NIDX_ERR_UNSUPPORTED, "more than %d clauses in one query", BM25_MAX_CLAUSES);
+        max_clauses = std::max<uint32_t>(max_clauses, (uint32_t)(clause_offsets[q + 1] - clause_offsets[q]));
     }
+    // launch shape knobs (no effect on results): postings rows per window and postings per work item
+    uint64_t slice_postings = BM25_SLICE_POSTINGS;
+    const bool force_wide = getenv("NIDX_GPU_BM25_WIDE") != nullptr;   // every query through the general kernel (tests)
+    (void)max_clauses;
+    if (const char *e = getenv("NIDX_GPU_BM25_SLICE")) slice_postings = (uint64_t)std::max(256, atoi(e));
     for (uint64_t c = 0; c < n_clauses; c++) {
         const nidx_gpu_bm25_clause_t &cl = clauses[c];
-        if (cl.occur < 0 || cl.occur > 3 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        if (cl.occur < 0 || cl.occur > NIDX_OCCUR_SHOULD_GROUP + 7 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
         if (!(cl.term & NIDX_BM25_TERM_SET) && (cl.term & NIDX_BM25_PHRASE)) {
             const uint32_t j = cl.term & ~NIDX_BM25_PHRASE;
             if (j >= n_phrases) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase %u out of range", j);
@@ -602,8 +609,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             out_off[n_sets + j + 1] = out_off[n_sets + j] + best;
         }
         if (n_aux) {
-            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4));
-            NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4));
+            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
+            NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
             NIDX_HIP(idx->s_set_counts.reserve((size_t)n_aux * 4));
             NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, (size_t)n_aux * 4, idx->stream));
         }
@@ -664,22 +671,39 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             item_first[q] = (uint32_t)work.size();
             uint64_t p = 0;
             for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) p += postings_of(clauses[c]);
-            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + BM25_SLICE_POSTINGS - 1) / BM25_SLICE_POSTINGS));
+            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
             for (uint32_t sl = 0; sl < slices; sl++) work.push_back(Bm25Work{q, sl, slices});
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
+        // the items of narrow queries go to the lean kernel, the rest to the general one
+        std::vector<uint32_t> item_list(nw);
+        uint32_t n_fast = 0, n_wide = 0, wide_max_clauses = 0;
+        for (size_t w = 0; w < nw; w++) {
+            const uint32_t nc = (uint32_t)(clause_offsets[work[w].query + 1] - clause_offsets[work[w].query]);
+            if (nc <= BM25_FAST_CLAUSES && !force_wide) item_list[n_fast++] = (uint32_t)w;
+        }
+        for (size_t w = 0; w < nw; w++) {
+            const uint32_t nc = (uint32_t)(clause_offsets[work[w].query + 1] - clause_offsets[work[w].query]);
+            if (!(nc <= BM25_FAST_CLAUSES && !force_wide)) {
+                item_list[n_fast + n_wide++] = (uint32_t)w;
+                wide_max_clauses = std::max(wide_max_clauses, nc);
+            }
+        }
         t_work += now_us() - t_w0;
         NIDX_HIP(idx->s_key.reserve(nw * kk * 8));
         const size_t if_bytes = ((size_t)(nq + 1) * 4 + 7) & ~(size_t)7;
-        const size_t inw_bytes = if_bytes + nw * sizeof(Bm25Work);
+        const size_t work_bytes = (nw * sizeof(Bm25Work) + 7) & ~(size_t)7;
+        const size_t inw_bytes = if_bytes + work_bytes + nw * 4;
         NIDX_HIP(idx->s_in_w.reserve(inw_bytes));
         NIDX_HIP(idx->h_in_w.reserve(inw_bytes));
         memcpy(idx->h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
         memcpy(idx->h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
+        memcpy(idx->h_in_w.as<unsigned char>() + if_bytes + work_bytes, item_list.data(), nw * 4);
         NIDX_HIP(hipMemcpyAsync(idx->s_in_w.p, idx->h_in_w.p, inw_bytes, hipMemcpyHostToDevice, idx->stream));
         const uint32_t *d_item_first = idx->s_in_w.as<uint32_t>();
         const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(idx->s_in_w.as<unsigned char>() + if_bytes);
+        const uint32_t *d_items = reinterpret_cast<const uint32_t *>(idx->s_in_w.as<unsigned char>() + if_bytes + work_bytes);
         // per-query outputs of the merge kernel, one block: doc u32 [nq][kk] | score f32 [nq][kk] | count u32 [nq] | total u64 [nq] | postings u64 [nq]
         const size_t o_doc = 0, o_score = (size_t)nq * kk * 4, o_count = o_score + (size_t)nq * kk * 4;
         const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, out_bytes = o_post + (size_t)nq * 8;
@@ -732,7 +756,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             a.dbg = dbgbuf.as<unsigned long long>();
         }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
-        NIDX_HIP(launch_bm25_search(a, (uint32_t)nw, idx->stream));
+        NIDX_HIP(launch_bm25_search(a, d_items, n_fast, d_items + n_fast, n_wide, wide_max_clauses, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
         Bm25MergeArgs mg;
         mg.item_first = d_item_first;

@@ -275,7 +275,7 @@ hipError_t launch_bitset_and_count(const uint64_t *a, const uint64_t *alive, uin
 #define BM25_MAX_CLAUSES 64
 struct Bm25ClauseDev {
     uint32_t term;
-    int occur;     // 0 should, 1 must, 2 must-not, 3 should of a required group
+    int occur;     // 0 should, 1 must, 2 must-not, 3 + g: should of required group g (g < 8)
     int mode;      // 0 stored tf, 1 tf == 1, 2 constant score
     float weight;  // idf * (1 + K1) * boost, or the constant score
 };
@@ -335,7 +335,10 @@ struct Bm25MergeArgs {  // per query: merge the key lists of its work items [ite
     unsigned long long *out_total, *out_postings;  // [n_queries]
 };
 hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s);
-hipError_t launch_bm25_search(const Bm25Args &a, uint32_t n_work, hipStream_t s);
+#define BM25_FAST_CLAUSES 8   /* queries of at most this many clauses take bm25_fast_kernel */
+#define BM25_LIST_PAD_BYTES 8192  /* slack behind the posting arrays: the kernels load whole 64-posting rows unconditionally */
+hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uint32_t n_fast, const uint32_t *wide_items, uint32_t n_wide,
+                              uint32_t max_clauses, hipStream_t s);
 
 // ---- BM25 surroundings (bm25_aux.hip) ----
 // FuzzyTermQuery's automaton over the whole term dictionary: flags[t] = 1 when term t is accepted

@@ -1283,7 +1283,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
     uint8_t *excluded = (uint8_t *)calloc(n ? n : 1, 1);
     uint8_t *group_hit = (uint8_t *)calloc(n ? n : 1, 1);
     uint32_t *last_clause = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t)); /* term sets: a doc counts once per clause */
-    size_t n_group = 0;
+    uint8_t groups_present = 0;   /* required Should groups g = occur - ORC_OCCUR_SHOULD_GROUP (g < 8) that have clauses */
     float cache[256];
     float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
     orc_bm25_tf_cache(avg, cache);
@@ -1296,7 +1296,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
         const size_t n_lists = is_set ? cl->n_set_terms : 1;
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur == ORC_OCCUR_SHOULD) n_should++;
-        if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
+        if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) groups_present |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
         if (is_set && cl->set_phrase) {
             /* PhraseQuery: walk the first term's postings, look the document up in the others', count the start positions */
             float idf_sum = 0.0f;
@@ -1329,7 +1329,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
                 float tf = (float)count;
                 acc[d] = acc[d] + weight * (tf / (tf + cache[idx->fieldnorm_ids[d]]));
                 if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
-                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) group_hit[d] |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
                 else should_hit[d] = 1;
             }
             continue;
@@ -1345,7 +1345,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
                 if (cl->occur == ORC_OCCUR_MUST_NOT) { excluded[d] = 1; continue; }
                 acc[d] = acc[d] + cl->boost;
                 if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
-                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) group_hit[d] |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
                 else should_hit[d] = 1;
             }
             continue;
@@ -1370,7 +1370,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
                 }
                 acc[d] = acc[d] + s;
                 if (cl->occur == ORC_OCCUR_MUST) must_cnt[d]++;
-                else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group_hit[d] = 1;
+                else if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) group_hit[d] |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
                 else should_hit[d] = 1;
             }
         }
@@ -1381,8 +1381,8 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
     for (uint32_t d = 0; d < n; d++) {
         if (excluded[d]) continue;
         if (must_cnt[d] != n_must) continue;
-        if (n_group > 0 && !group_hit[d]) continue;
-        if (n_must == 0 && n_group == 0 && !should_hit[d]) continue;
+        if ((group_hit[d] & groups_present) != groups_present) continue;   /* a clause of EVERY required group */
+        if (n_must == 0 && groups_present == 0 && !should_hit[d]) continue;
         if (idx->alive && !bit_get(idx->alive, d)) continue;
         total++;
         if (match_bits_out) match_bits_out[d >> 6] |= (uint64_t)1 << (d & 63);
@@ -1579,14 +1579,15 @@ int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *claus
     uint64_t *cur = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
     uint64_t *end = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
     float *weight = (float *)malloc((n_clauses ? n_clauses : 1) * sizeof(float));
-    size_t n_must = 0, n_group = 0;
+    size_t n_must = 0;
+    uint8_t groups_present = 0;
     for (size_t c = 0; c < n_clauses; c++) {
         const orc_bm25_clause *cl = &clauses[c];
         cur[c] = idx->term_offsets[cl->term];
         end[c] = idx->term_offsets[cl->term + 1];
         weight[c] = cl->mode == ORC_CONST_SCORE ? cl->boost : orc_bm25_idf(end[c] - cur[c], idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
-        if (cl->occur == ORC_OCCUR_SHOULD_GROUP) n_group++;
+        if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) groups_present |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
     }
     bm_hit_t *top = (bm_hit_t *)malloc((k + 1) * sizeof(bm_hit_t));
     size_t n_top = 0;
@@ -1598,7 +1599,8 @@ int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *claus
         if (d == 0xffffffffu) break;
         float acc = 0.0f;
         size_t must = 0;
-        int should = 0, group = 0, excluded = 0;
+        int should = 0, excluded = 0;
+        uint8_t group = 0;
         for (size_t c = 0; c < n_clauses; c++) {
             if (cur[c] >= end[c] || idx->doc_ids[cur[c]] != d) continue;
             const orc_bm25_clause *cl = &clauses[c];
@@ -1612,12 +1614,12 @@ int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *claus
             }
             acc = acc + s;
             if (cl->occur == ORC_OCCUR_MUST) must++;
-            else if (cl->occur == ORC_OCCUR_SHOULD_GROUP) group = 1;
+            else if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) group |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
             else should = 1;
         }
         if (excluded || must != n_must) continue;
-        if (n_group > 0 && !group) continue;
-        if (n_must == 0 && n_group == 0 && !should) continue;
+        if ((group & groups_present) != groups_present) continue;
+        if (n_must == 0 && groups_present == 0 && !should) continue;
         if (idx->alive && !bit_get(idx->alive, d)) continue;
         total++;
         uint64_t docaddr = ((uint64_t)segment_ord << 32) | d;

@@ -187,6 +187,8 @@ typedef struct {
 /* ORC_OCCUR_SHOULD_GROUP: a Should clause of a nested Must(BooleanQuery[Should..]) — the shape of
  * nidx_paragraph's keyword query under its Must filters (search_query.rs:185-243): scored like Should,
  * and a document must match at least one clause of the group. */
+/* ORC_OCCUR_SHOULD_GROUP + g (g < 8): the same for a g-th nested group — the prefilter's BooleanQuery[Should SetQuery(field_uuid),
+ * Should SetQuery(uuid)] and an Or formula are further required groups beside the keyword group (search_query.rs:88-143,218-223). */
 enum { ORC_OCCUR_SHOULD = 0, ORC_OCCUR_MUST = 1, ORC_OCCUR_MUST_NOT = 2, ORC_OCCUR_SHOULD_GROUP = 3 };
 enum { ORC_TF_FREQ = 0, ORC_TF_BASIC = 1, ORC_CONST_SCORE = 2 };
 

@@ -145,3 +145,47 @@ def test_reference_min_score_counts():
     assert count[1] == 4 and total[1] == 4 and (score[1, :4] < 30).all() and (score[1, :4] > 0).all()
     assert sum(1 for x in score[1, :4] if x >= 30) == 0
     s.close()
+
+
+def test_required_should_groups_and_wide_queries(orc, corpus):
+    """Several required Should groups (occur = OCCUR_SHOULD_GROUP + g: the keyword group, an Or formula, the prefilter's
+    SetQuery pair — nidx_paragraph/src/search_query.rs:88-143), queries with more clauses than a window has rows, and
+    queries with more than 32 clauses (64-bit hit masks)."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(7)
+    s = Bm25Searcher.open([seg])
+    G = _lib.OCCUR_SHOULD_GROUP
+    queries = []
+    for _ in range(60):
+        q = []
+        for g in range(int(rng.integers(1, 4))):           # 1..3 groups of 1..3 clauses over dense terms
+            for _ in range(int(rng.integers(1, 4))):
+                q.append(Clause(int(rng.integers(0, 120)), G + g, int(rng.choice([FREQ, BASIC, CONST])), float(rng.choice([1.0, 0.5]))))
+        if rng.random() < 0.5:
+            q.append(Clause(int(rng.integers(0, 40)), M, BASIC))
+        if rng.random() < 0.3:
+            q.append(Clause(int(rng.integers(0, 200)), N))
+        if rng.random() < 0.3:
+            q.append(Clause(int(rng.integers(0, 500)), S))
+        order = rng.permutation(len(q))
+        queries.append([q[i] for i in order])              # groups interleaved with the other clauses
+    queries.append([Clause(3, G), Clause(4, G + 1), Clause(5, G + 7)])   # the highest group id
+    compare(orc, seg, s, queries, 20)
+    wide = [[Clause(int(t), int(rng.choice([S, S, S, M])) if t < 30 else S) for t in rng.permutation(400)[: int(n)]] for n in (5, 9, 12, 20, 33, 40, 64)]
+    compare(orc, seg, s, wide, 20)
+    compare(orc, seg, s, wide + queries[:8], 10)            # one launch mixing 64-bit-mask and narrow queries
+    s.close()
+
+
+def test_general_kernel_on_narrow_queries(orc, corpus, monkeypatch):
+    """Narrow queries normally take bm25_fast_kernel; NIDX_GPU_BM25_WIDE routes them through the general kernel
+    (bm25_rows_kernel, FAST and PACKED windows): both must give the oracle's answer."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("NIDX_GPU_BM25_WIDE", "1")
+    s = Bm25Searcher.open([seg])
+    queries = [[Clause(int(t), int(rng.choice([S, S, M, N])), int(rng.choice([FREQ, BASIC, CONST]))) for t in rng.integers(0, 400, int(rng.integers(1, 8)))]
+               for _ in range(64)]
+    compare(orc, seg, s, queries, 20)
+    compare(orc, seg, s, queries, 100)
+    s.close()
