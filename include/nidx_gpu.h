@@ -571,6 +571,14 @@ typedef struct {
 int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_prefilter_t *request,
                                 uint64_t *out_docaddr, uint64_t capacity, uint64_t *n_matching, uint64_t *num_docs);
 
+/* open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74), the device half: the caller maps the deletion keys that
+ * are newer than the segment (`Seq(segment) < del_seq`) to term ids the way the DeletionQueryBuilders do (a key longer than 32
+ * bytes is a field id, else a resource uuid: nidx_text/src/lib.rs:95-128, nidx_paragraph/src/lib.rs:50-71); every document in
+ * any of those posting lists leaves the segment's alive bitset (union of the lists scattered into a bitset, and-not).
+ * n_alive_out: NULL or the segment's live documents afterwards. */
+int32_t nidx_gpu_bm25_apply_deletions(nidx_gpu_bm25_index_t *index, uint32_t segment, const uint32_t *terms, uint32_t n_terms,
+                                      uint64_t *n_alive_out);
+
 /* Device time (HIP events on the handle's stream) spent in the scoring kernel(s) of the last
  * nidx_gpu_bm25_search call, summed over segments. */
 int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out);

@@ -147,6 +147,14 @@ class Bm25Searcher:
         assert v.size == self.segments[segment].n_docs
         _lib.check(_lib.lib().nidx_gpu_bm25_set_fast_field(self._handle, segment, field, v.ctypes.data))
 
+    def apply_deletions(self, segment: int, terms: Sequence[int]) -> int:
+        """open_index_with_deletions' device half: the documents of these posting lists leave the segment's alive bitset.
+        -> live documents of the segment afterwards."""
+        t = np.ascontiguousarray(terms, dtype=np.uint32)
+        n_alive = C.c_uint64(0)
+        _lib.check(_lib.lib().nidx_gpu_bm25_apply_deletions(self._handle, segment, t.ctypes.data if t.size else None, t.size, C.byref(n_alive)))
+        return int(n_alive.value)
+
     def set_dictionary(self, terms: Sequence[str]) -> None:
         """The term dictionary of the scored field, term id = position."""
         enc = [t.encode("utf-8") for t in terms]

@@ -859,6 +859,53 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
+// open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74): the documents of every posting list in `terms` (the
+// TermSetQuery the DeletionQueryBuilder makes of the deletion keys newer than the segment) leave the segment's alive bitset.
+int32_t nidx_gpu_bm25_apply_deletions(nidx_gpu_bm25_index_t *index, uint32_t segment, const uint32_t *terms, uint32_t n_terms,
+                                      uint64_t *n_alive_out) try {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || segment >= idx->segs.size() || (n_terms && !terms)) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    Bm25Segment &seg = idx->segs[segment];
+    for (uint32_t i = 0; i < n_terms; i++)
+        if (terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "deletion term id %u out of range", terms[i]);
+    const uint32_t words = (seg.n_docs + 63) / 64;
+    hipStream_t st = idx->stream;
+    if (n_terms && words) {
+        if (seg.all_alive) {
+            NIDX_HIP(seg.alive.alloc((size_t)words * 8));
+            NIDX_HIP(launch_bitset_fill(seg.alive.as<uint64_t>(), words, seg.n_docs, 1, st));
+            seg.all_alive = false;
+        }
+        NIDX_HIP(idx->s_set_terms.reserve((size_t)n_terms * 4));
+        NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, terms, (size_t)n_terms * 4, hipMemcpyHostToDevice, st));
+        NIDX_HIP(idx->s_set_bits.reserve((size_t)words * 8));
+        NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), words, seg.n_docs, 0, st));
+        NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_set_terms.as<uint32_t>(),
+                                       n_terms, seg.n_docs, idx->s_set_bits.as<uint64_t>(), st));
+        NIDX_HIP(launch_bitset_binop(seg.alive.as<uint64_t>(), idx->s_set_bits.as<uint64_t>(), words, 2, st));
+        seg.n_alive = -1;
+    }
+    if (n_alive_out) {
+        if (seg.all_alive) *n_alive_out = seg.n_docs;
+        else {
+            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>(words, 1) * 8 + 8));
+            NIDX_HIP(idx->s_set_counts.reserve(8));
+            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, 8, st));
+            NIDX_HIP(launch_bitset_and_count(seg.alive.as<uint64_t>(), nullptr, idx->s_set_bits.as<uint64_t>(), words,
+                                             idx->s_set_counts.as<unsigned long long>(), st));
+            unsigned long long c = 0;
+            NIDX_HIP(hipMemcpyAsync(&c, idx->s_set_counts.p, 8, hipMemcpyDeviceToHost, st));
+            NIDX_HIP(hipStreamSynchronize(st));
+            *n_alive_out = c;
+            seg.n_alive = (int64_t)c;
+        }
+    }
+    NIDX_HIP(hipStreamSynchronize(st));
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
 int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                              uint32_t nq, uint32_t k, const nidx_gpu_bm25_search_after_t *after, uint64_t *out_docaddr, float *out_score,
                              uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) try {

@@ -34,11 +34,11 @@ __global__ void bitset_scatter_kernel(const unsigned long long *__restrict__ lis
     }
 }
 
-// op: 0 and, 1 or
+// op: 0 and, 1 or, 2 and-not (a &= ~b)
 __global__ void bitset_binop_kernel(uint64_t *a, const uint64_t *b, uint32_t n_words, int op) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
-    a[w] = op == 0 ? (a[w] & b[w]) : (a[w] | b[w]);
+    a[w] = op == 0 ? (a[w] & b[w]) : op == 1 ? (a[w] | b[w]) : (a[w] & ~b[w]);
 }
 
 __global__ void bitset_not_kernel(uint64_t *a, uint32_t n_words, uint32_t n_bits) {

@@ -170,8 +170,24 @@ def _bitset(mask: np.ndarray) -> np.ndarray:
     return np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words).copy()
 
 
+def deletion_terms(vocab: "Vocabulary", segment_seq: int, deletions: Sequence[Tuple[str, int]]) -> List[int]:
+    """The TermSetQuery of the DeletionQueryBuilders (nidx_text/src/lib.rs:95-128, nidx_paragraph/src/lib.rs:50-71) for one
+    segment: of the (key, seq) deletions those NEWER than the segment (index_reader.rs:47-50: `Seq(segment) < del_seq`); a
+    key longer than 32 bytes is a field id (`<32 hex>/<type>/<name>`), else a resource uuid; keys the dictionary does not
+    know delete nothing."""
+    terms = []
+    for key, del_seq in deletions:
+        if not segment_seq < del_seq:
+            continue
+        t = vocab.lookup(("\x00fid:" if len(key) > 32 else "\x00uuid:") + key)
+        if t is not None:
+            terms.append(t)
+    return sorted(set(terms))
+
+
 class _Index:
-    def __init__(self, segments: Sequence[TextSegment], deleted: Sequence[set] = ()):
+    def __init__(self, segments: Sequence[TextSegment], deleted: Sequence[set] = (), seqs: Optional[Sequence[int]] = None,
+                 deletions: Sequence[Tuple[str, int]] = ()):
         self.segments = list(segments)
         self.vocab = segments[0].vocab if segments else Vocabulary()
         n_terms = len(self.vocab.ids) + 1  # + one always-empty term for words missing from the dictionary
@@ -191,6 +207,12 @@ class _Index:
             self.terms[i] = t
         self.terms[self.empty_term] = "\x00empty"
         self.searcher.set_dictionary(self.terms)
+        # open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74): deletions by key, resolved on the device
+        self.live = [len(seg.docs) for seg in self.segments]
+        if deletions:
+            for i in range(len(self.segments)):
+                terms = deletion_terms(self.vocab, seqs[i] if seqs is not None else 0, deletions)
+                self.live[i] = self.searcher.apply_deletions(i, terms)
         for i, seg in enumerate(self.segments):
             if seg.docs:
                 self.searcher.set_fast_field(i, 0, [d.created for d in seg.docs])
@@ -340,6 +362,181 @@ class PrefilterResult:
     fields: List[Tuple[str, str]] = field(default_factory=list)  # (resource uuid, field id) of every matching document
 
 
+# ---- tantivy's query grammar (tantivy-query-grammar 0.26, restated for the shapes nidx_text sends) --------------------------
+class QuerySyntaxError(ValueError):
+    """QueryParserError::SyntaxError: the body is then searched as one phrase (adapt_text)."""
+
+
+@dataclass
+class QLeaf:
+    text: str = ""
+    boost: float = 1.0
+    all: bool = False      # `*`
+
+
+@dataclass
+class QNode:
+    op: str                # "and" | "or" | "not"
+    children: list
+
+
+_SPECIAL = set(' \t\n\r()"\':^{}[]')
+
+
+def parse_text_query(body: str):
+    """-> QLeaf | QNode.  Grammar: clause := ['+' | '-'] (word | "phrase" | '(' query ')' | '*') ['^' number], words may
+    carry a `text:` field prefix; clauses are joined by AND / OR / NOT or by juxtaposition (= AND: conjunction by default);
+    AND binds tighter than OR.  Raises QuerySyntaxError on what tantivy's parser rejects (unbalanced quotes / parentheses,
+    a dangling operator, an unknown field, slop / range syntax is refused as NotImplementedError)."""
+    pos, n = 0, len(body)
+
+    def skip_ws():
+        nonlocal pos
+        while pos < n and body[pos].isspace():
+            pos += 1
+
+    def parse_boost() -> float:
+        nonlocal pos
+        if pos < n and body[pos] == "^":
+            j = pos + 1
+            while j < n and (body[j].isdigit() or body[j] == "."):
+                j += 1
+            if j == pos + 1:
+                raise QuerySyntaxError("boost without a number")
+            b = float(body[pos + 1:j])
+            pos = j
+            return b
+        return 1.0
+
+    def parse_atom():
+        nonlocal pos
+        skip_ws()
+        if pos >= n:
+            raise QuerySyntaxError("unexpected end")
+        c = body[pos]
+        if c == "(":
+            pos += 1
+            node = parse_or()
+            skip_ws()
+            if pos >= n or body[pos] != ")":
+                raise QuerySyntaxError("unbalanced parenthesis")
+            pos += 1
+            b = parse_boost()
+            if b != 1.0:
+                raise NotImplementedError("boost on a parenthesised group")
+            return node
+        if c == '"':
+            j = body.find('"', pos + 1)
+            if j < 0:
+                raise QuerySyntaxError("unbalanced quote")
+            text = body[pos + 1:j]
+            pos = j + 1
+            if pos < n and body[pos] == "~":
+                raise NotImplementedError("phrase slop")
+            return QLeaf(text, parse_boost())
+        if c == "*":
+            pos += 1
+            return QLeaf("", parse_boost(), all=True)
+        if c in "[{":
+            raise NotImplementedError("range queries")
+        if c in _SPECIAL or c in "+-":
+            raise QuerySyntaxError(f"unexpected {c!r}")
+        j = pos
+        while j < n and body[j] not in _SPECIAL:
+            j += 1
+        word = body[pos:j]
+        pos = j
+        if pos < n and body[pos] == ":":  # field prefix
+            if word != "text":
+                raise QuerySyntaxError(f"field {word!r} does not exist")
+            pos += 1
+            return parse_atom()
+        return QLeaf(word, parse_boost())
+
+    def parse_clause():
+        nonlocal pos
+        skip_ws()
+        if pos < n and body[pos] in "+-" and pos + 1 < n and not body[pos + 1].isspace():
+            neg = body[pos] == "-"
+            pos += 1
+            atom = parse_atom()
+            return QNode("not", [atom]) if neg else atom
+        if body.startswith("NOT", pos) and pos + 3 < n and body[pos + 3].isspace():
+            pos += 3
+            return QNode("not", [parse_clause()])
+        return parse_atom()
+
+    def at_operator(word: str) -> bool:
+        return body.startswith(word, pos) and (pos + len(word) == n or body[pos + len(word)].isspace() or body[pos + len(word)] == "(")
+
+    def parse_and():
+        nonlocal pos
+        items = [parse_clause()]
+        while True:
+            skip_ws()
+            if pos >= n or body[pos] == ")" or at_operator("OR"):
+                break
+            if at_operator("AND"):
+                pos += 3
+                skip_ws()
+                if pos >= n:
+                    raise QuerySyntaxError("dangling AND")
+            items.append(parse_clause())
+        return items[0] if len(items) == 1 else QNode("and", items)
+
+    def parse_or():
+        nonlocal pos
+        items = [parse_and()]
+        while True:
+            skip_ws()
+            if at_operator("OR"):
+                pos += 2
+                skip_ws()
+                if pos >= n:
+                    raise QuerySyntaxError("dangling OR")
+                items.append(parse_and())
+            else:
+                break
+        return items[0] if len(items) == 1 else QNode("or", items)
+
+    skip_ws()
+    if pos >= n:
+        return None
+    node = parse_or()
+    skip_ws()
+    if pos < n:
+        raise QuerySyntaxError(f"unexpected {body[pos]!r}")
+    return node
+
+
+def flatten_conjunction(node):
+    """The boolean tree as (Must leaves, MustNot leaves, [required OR groups of leaves]); shapes outside that family
+    (an AND inside an OR, a negation inside an OR) are refused."""
+    musts, nots, groups = [], [], []
+
+    def walk(nd):
+        if isinstance(nd, QLeaf):
+            musts.append(nd)
+        elif nd.op == "and":
+            for ch in nd.children:
+                walk(ch)
+        elif nd.op == "not":
+            inner = nd.children[0]
+            if isinstance(inner, QLeaf):
+                nots.append(inner)
+            elif inner.op == "or" and all(isinstance(c, QLeaf) for c in inner.children):
+                nots.extend(inner.children)   # NOT (a OR b) = NOT a AND NOT b
+            else:
+                raise NotImplementedError("negation of a nested boolean expression")
+        elif nd.op == "or":
+            if not all(isinstance(c, QLeaf) for c in nd.children):
+                raise NotImplementedError("nested boolean expression inside OR")
+            groups.append(list(nd.children))
+
+    walk(node)
+    return musts, nots, groups
+
+
 class TextSearcher:
     """nidx_text::TextSearcher (lib.rs:178-237) — `search` only."""
 
@@ -347,40 +544,78 @@ class TextSearcher:
         self._index = index
 
     @classmethod
-    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = ()) -> "TextSearcher":
-        return cls(_Index(segments, deleted))
+    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = (), seqs: Optional[Sequence[int]] = None,
+             deletions: Sequence[Tuple[str, int]] = ()) -> "TextSearcher":
+        """segments + either explicit deleted doc sets, or the index's (key, seq) deletions with every segment's seq."""
+        return cls(_Index(segments, deleted, seqs, deletions))
 
     def close(self):
         self._index.close()
 
     @staticmethod
     def adapt_text(text: str) -> str:
-        """TextReaderService::adapt_text (reader.rs:357-365): a body tantivy's QueryParser rejects is searched as one phrase,
-        its quotes dropped.  Of the grammar's syntax errors the unbalanced quote is the one mirrored here (the reference's
-        test_quote_fixing cases); the operators (+ - ( ) : ^ ~ *) are refused by _clauses instead of guessed at."""
-        if text and text.count('"') % 2:
+        """TextReaderService::adapt_text (reader.rs:357-365): a body the QueryParser rejects is searched as ONE phrase, its
+        quotes dropped."""
+        if text == "":
+            return text
+        try:
+            parse_text_query(text)
+            return text
+        except QuerySyntaxError:
             return '"' + text.replace('"', "") + '"'
-        return text
+
+    def _leaf(self, leaf: "QLeaf", occur: int) -> Optional[Clause]:
+        """One literal of the grammar through the text field's tokenizer: no token -> no clause, one -> TermQuery with
+        frequencies, several -> PhraseQuery (QueryParser::compute_logical_ast_for_leaf)."""
+        words = tokenize(leaf.text)
+        if not words:
+            return None
+        if len(words) > 1:
+            return Clause(0, occur, _lib.TF_FREQ, leaf.boost, term_set=[self._index.term(w) for w in words], phrase=True)
+        return Clause(self._index.term(words[0]), occur, _lib.TF_FREQ, leaf.boost)
 
     def _clauses(self, request: DocumentSearchRequest) -> List[Clause]:
+        """create_query (search_query.rs:92-126): Must(main query) + Must(filters).  The main query is the body through
+        tantivy's QueryParser with set_conjunction_by_default (reader.rs:372-377): juxtaposed literals are Must, `+` / `-`
+        prefixes, AND / OR / NOT, parentheses, "phrases", `text:` field prefixes and `^boost`; the boolean tree is
+        flattened to Must / MustNot clauses and required Should groups (one per OR)."""
         body = self.adapt_text(request.body)
-        if any(ch in body for ch in '+():^~*'):
-            raise NotImplementedError("tantivy's query grammar beyond words and \"phrases\" is not mirrored")
-        # QueryParser with set_conjunction_by_default (reader.rs:372-377): every word is a Must TermQuery with frequencies,
-        # every "quoted run" a Must PhraseQuery (one word: a TermQuery)
-        parts = body.split('"')
-        clauses, any_token = [], False
-        for i, part in enumerate(parts):
-            words = tokenize(part)
-            if not words:
-                continue
-            any_token = True
-            if i % 2 == 1 and len(words) > 1:
-                clauses.append(Clause(0, _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0, term_set=[self._index.term(w) for w in words], phrase=True))
+        clauses: List[Clause] = []
+        if body == "":
+            clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))  # AllQuery
+        else:
+            try:
+                ast = parse_text_query(body)
+            except QuerySyntaxError:  # `parse_query(text).unwrap_or_else(|_| AllQuery)`: cannot happen after adapt_text
+                ast = None
+            if ast is None:
+                clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
             else:
-                clauses += [Clause(self._index.term(w), _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0) for w in words]
-        if not any_token:  # create_query: empty text => AllQuery (search_query.rs:100-104)
-            clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
+                musts, nots, groups = flatten_conjunction(ast)
+                positive = False
+                for leaf in musts:
+                    if leaf.all:
+                        clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, leaf.boost))
+                        positive = True
+                        continue
+                    c = self._leaf(leaf, _lib.OCCUR_MUST)
+                    if c is not None:
+                        clauses.append(c)
+                        positive = True
+                for g, leaves in enumerate(groups):
+                    if g >= 8:
+                        raise NotImplementedError("more than 8 OR groups in one query")
+                    members = [self._leaf(l, _lib.OCCUR_SHOULD_GROUP + g) for l in leaves]
+                    members = [m for m in members if m is not None]
+                    if members:
+                        clauses += members
+                        positive = True
+                for leaf in nots:
+                    c = self._leaf(leaf, _lib.OCCUR_MUST_NOT)
+                    if c is not None:
+                        clauses.append(c)
+                if not positive:  # only exclusions (or nothing survived the tokenizer): a BooleanQuery without a positive clause matches nothing
+                    clauses.append(Clause(self._index.empty_term, _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0))
         for lab in request.label_filter or []:
             # filter clauses score too in tantivy's BooleanQuery; facet TermQuerys carry no frequencies
             clauses.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0))
@@ -499,6 +734,25 @@ class ParagraphSearchRequest:
     faceted: Optional[List[str]] = None
     order: Optional[OrderBy] = None
     only_faceted: bool = False
+    # BooleanExpression<String> over label facets (nidx_types/src/query_language.rs): FormulaLiteral / FormulaNot / FormulaOp
+    filtering_formula: Optional[object] = None
+    filter_or: bool = False   # FilterOperator::Or: the formula and the prefilter are alternatives (search_query.rs:94-98)
+
+
+@dataclass
+class FormulaLiteral:
+    label: str
+
+
+@dataclass
+class FormulaNot:
+    operand: object
+
+
+@dataclass
+class FormulaOp:
+    operator: str              # "and" | "or"
+    operands: List[object]
 
 
 @dataclass
@@ -584,19 +838,89 @@ class ParagraphSearcher:
 
     def __init__(self, index: _Index, stop_words: Optional[Set[str]] = None):
         self._index = index
+        self._prefilter: Optional[PrefilterResult] = None
         # the reference removes the stop words of eight languages (query_parser/stop_words/*.json, data files that
         # are not copied here): pass the union of those lists to get the same query
         self.stop_words = stop_words
 
     @classmethod
-    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = (), stop_words: Optional[Set[str]] = None) -> "ParagraphSearcher":
-        return cls(_Index(segments, deleted), stop_words)
+    def open(cls, segments: Sequence[TextSegment], deleted: Sequence[set] = (), stop_words: Optional[Set[str]] = None,
+             seqs: Optional[Sequence[int]] = None, deletions: Sequence[Tuple[str, int]] = ()) -> "ParagraphSearcher":
+        return cls(_Index(segments, deleted, seqs, deletions), stop_words)
 
     def close(self):
         self._index.close()
 
+    def _label(self, label: str, occur: int, boost: float) -> Clause:
+        return Clause(self._index.term("\x00label:" + label), occur, _lib.TF_BASIC, boost)   # translate_literal (query_io.rs:22-26)
+
+    def _filter_query(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult], boost: float) -> List[Clause]:
+        """filter_query (search_query.rs:88-143): BooleanQuery[(occur, translate_expression(formula)), (occur,
+        BooleanQuery[Should SetQuery(field_uuid), Should SetQuery(uuid)])] under Occur::Must, occur = Must (And) / Should (Or).
+        Flattened to the kernel's clause family: And of literals -> Must each; Or of literals -> one required Should group;
+        Not(literal) -> Must AllQuery + MustNot literal (query_io.rs:28-41); the prefilter's two SetQuerys -> one required
+        group of constant-score term sets.  With FilterOperator::Or everything is ONE required group."""
+        groups: List[List[Clause]] = []
+        out: List[Clause] = []
+        G = _lib.OCCUR_SHOULD_GROUP
+        next_group = [1]   # group 0 is the keyword group
+
+        def new_group() -> int:
+            g = next_group[0]
+            next_group[0] += 1
+            if g >= 8:
+                raise NotImplementedError("more than 8 required Should groups")
+            return G + g
+
+        def conj(expr):   # expr under Occur::Must
+            if isinstance(expr, FormulaLiteral):
+                out.append(self._label(expr.label, _lib.OCCUR_MUST, boost))
+            elif isinstance(expr, FormulaNot):
+                if not isinstance(expr.operand, FormulaLiteral):
+                    raise NotImplementedError("negation of a nested formula")
+                out.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
+                out.append(self._label(expr.operand.label, _lib.OCCUR_MUST_NOT, boost))
+            elif isinstance(expr, FormulaOp) and expr.operator == "and":
+                for e in expr.operands:
+                    conj(e)
+            elif isinstance(expr, FormulaOp) and expr.operator == "or":
+                disj(expr, new_group())
+            else:
+                raise TypeError(f"not a formula: {expr!r}")
+
+        def disj(expr, occur: int):   # expr as members of one required group
+            if isinstance(expr, FormulaLiteral):
+                out.append(self._label(expr.label, occur, boost))
+            elif isinstance(expr, FormulaOp) and expr.operator == "or":
+                for e in expr.operands:
+                    disj(e, occur)
+            else:
+                raise NotImplementedError("a conjunction or negation inside an Or formula")
+
+        def prefilter_sets(occur: int):
+            fields = sorted({"\x00fid:" + rid + "/" + fid.lstrip("/") for rid, fid in prefilter.fields if fid is not None})
+            resources = sorted({"\x00uuid:" + rid for rid, fid in prefilter.fields if fid is None})
+            for keys in (fields, resources):   # SetQuery = TermSetQuery: ConstScorer over the union of the terms
+                if keys:
+                    terms = [self._index.term(t) for t in keys]
+                    out.append(Clause(0, occur, _lib.CONST_SCORE, boost, term_set=terms))
+
+        some = prefilter is not None and prefilter.kind == "Some" and prefilter.fields
+        if request.filter_or and (request.filtering_formula is not None or some):
+            g = new_group()
+            if request.filtering_formula is not None:
+                disj(request.filtering_formula, g)
+            if some:
+                prefilter_sets(g)
+        else:
+            if request.filtering_formula is not None:
+                conj(request.filtering_formula)
+            if some:
+                prefilter_sets(new_group())
+        return out
+
     def _filters(self, request: ParagraphSearchRequest, boost: float) -> List[Clause]:
-        musts = []
+        musts = self._filter_query(request, self._prefilter, boost)
         for lab in request.label_filter or []:
             musts.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, boost))
         if not request.with_duplicates:  # Must TermQuery(repeated_in_field = 0, Basic) (search_query.rs:218-223)
@@ -633,7 +957,8 @@ class ParagraphSearcher:
     def _fuzzy_clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
         """The fuzzy query (fuzzy_parser.rs:52-123 under search_query.rs:200-240)."""
         tokens = self._tokens(request)
-        filters_present = bool(request.label_filter) or not request.with_duplicates
+        some = self._prefilter is not None and self._prefilter.kind == "Some" and self._prefilter.fields
+        filters_present = bool(request.label_filter) or not request.with_duplicates or request.filtering_formula is not None or bool(some)
         boost = FUZZY_BOOST if filters_present else 1.0  # BoostQuery(0.5) only wraps a multi-clause Boolean (:229-240)
         last_literal = max((i for i, t in enumerate(tokens) if t[0] == "literal"), default=None)
         clauses = []
@@ -682,9 +1007,13 @@ class ParagraphSearcher:
             results.append(ParagraphResult(d.uuid, d.field, d.text, ResultScore(scores[i], int(docaddr[0, i])), list(d.labels)))
         return ParagraphSearchResponse(int(total[0]), results, next_page, request.body, fc, fuzzy)
 
-    def search(self, request: ParagraphSearchRequest) -> ParagraphSearchResponse:
+    def search(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult] = None) -> ParagraphSearchResponse:
         """ParagraphReaderService::search (reader.rs:104-139): the keyword query first; when it finds nothing (and results
-        were asked for, with min_score == 0) the fuzzy query is run instead."""
+        were asked for, with min_score == 0) the fuzzy query is run instead.  `prefilter` = the text index's verdict on the
+        request's field filters (PrefilterResult::{All, None, Some}); None finds nothing by construction."""
+        if prefilter is not None and prefilter.kind == "None":
+            return ParagraphSearchResponse(0, [], False, request.body, {}, False)
+        self._prefilter = prefilter
         response = self._run(request, self._clauses(request), False)
         if not response.results and request.result_per_page > 0 and request.min_score == 0.0 and not request.only_faceted:
             response = self._run(request, self._fuzzy_clauses(request), True)

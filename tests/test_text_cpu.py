@@ -1,6 +1,8 @@
 """Host logic of the paragraph query grammar (no GPU): the cases of nidx_paragraph/src/query_parser/tokenizer.rs's own
 tests (test_empty_query, test_simple_query, quotes / exclusions / unclosed quotes) and query_parser.rs's stop-word test
 shape."""
+import pytest
+
 from nucliadb_amd.text import facet_ancestors, is_valid_facet, parse_query
 
 
@@ -47,3 +49,39 @@ def test_adapt_text_quote_fixing():
         assert TextSearcher.adapt_text(body) == '"enough test"'
     assert TextSearcher.adapt_text("") == "" and TextSearcher.adapt_text("enough test") == "enough test"
     assert TextSearcher.adapt_text('a "b c" d "e') == '"a b c d e"'
+
+
+def test_tantivy_grammar_subset_parses_like_the_query_parser():
+    from nucliadb_amd.text import QuerySyntaxError, flatten_conjunction, parse_text_query
+
+    def shape(q):
+        m, n, g = flatten_conjunction(parse_text_query(q))
+        return [l.text for l in m], [l.text for l in n], [[l.text for l in grp] for grp in g]
+
+    assert shape("enough to test") == (["enough", "to", "test"], [], [])
+    assert shape('"enough to test" more') == (["enough to test", "more"], [], [])
+    assert shape("+a -b c") == (["a", "c"], ["b"], [])
+    assert shape("(a OR b) AND NOT c") == ([], ["c"], [["a", "b"]])
+    assert shape("a AND b OR c AND d".replace(" OR ", " AND ")) == (["a", "b", "c", "d"], [], [])
+    assert shape("x (a OR b) (c OR d)") == (["x"], [], [["a", "b"], ["c", "d"]])
+    assert shape("NOT (a OR b) z") == (["z"], ["a", "b"], [])
+    m, _, _ = flatten_conjunction(parse_text_query("text:foo^2.5 *"))
+    assert (m[0].text, m[0].boost, m[1].all) == ("foo", 2.5, True)
+    for bad in ['"enough test', "enough test\"", "a AND", "a OR", "(a b", "a b)", "enough - test", "title:x", "a^"]:
+        with pytest.raises(QuerySyntaxError):
+            parse_text_query(bad)
+    for refused in ['"a b"~2', "[a TO b]", "a OR b c", "NOT (a AND b)"]:
+        with pytest.raises(NotImplementedError):
+            flatten_conjunction(parse_text_query(refused))
+
+
+def test_deletion_terms_respect_seq_and_key_kind():
+    from nucliadb_amd.text import Vocabulary, deletion_terms
+
+    v = Vocabulary()
+    rid = "%032x" % 7
+    a, b = v.id("\x00uuid:" + rid), v.id("\x00fid:" + rid + "/a/body")
+    dele = [(rid, 5), (rid + "/a/body", 3), ("%032x" % 9, 9)]
+    assert deletion_terms(v, 2, dele) == sorted([a, b])
+    assert deletion_terms(v, 3, dele) == [a]          # `Seq(segment) < del_seq` is strict
+    assert deletion_terms(v, 5, dele) == []

@@ -367,3 +367,118 @@ def test_prefilter_mirrors_the_reference_cases():
         assert pf(BoolNot(KeywordFilter("public")), Security(["group3"])).fields == [("r3", "/a/title")]
     finally:
         s.close()
+
+
+# ---- round 2: filtered paragraph search, deletions by key, the nidx_text grammar ------------------------------------------
+def _hex(i: int) -> str:
+    return "%032x" % i
+
+
+def labelled_docs():
+    """The shape of nidx_paragraph/tests/reader.rs::create_resource: paragraphs of one resource with different labels."""
+    rid = _hex(1)
+    return rid, [
+        TextDocument(rid, "/a/title", "the untitled title", labels=["/l/mylabel", "/e/myentity"]),
+        TextDocument(rid, "/a/body", "a paragraph about tantivy search", labels=["/l/mylabel", "/tantivy"]),
+        TextDocument(rid, "/a/body", "another paragraph with label two", labels=["/l/mylabel", "/label2"]),
+        TextDocument(rid, "/a/summary", "short summary", labels=["/l/mylabel"]),
+        TextDocument(_hex(2), "/a/body", "tantivy paragraph of a second resource", labels=["/tantivy", "/label2"]),
+    ]
+
+
+def test_paragraph_filtering_formula_reference_cases():
+    """nidx_paragraph/tests/reader.rs:194-246 (test_filtering_formula): a literal, an Or, an And of label facets."""
+    from nucliadb_amd.text import FormulaLiteral, FormulaNot, FormulaOp
+
+    rid, d = labelled_docs()
+    s = ParagraphSearcher.open([TextSegment(d, Vocabulary())])
+    req = lambda f, **kw: ParagraphSearchRequest(body="", result_per_page=20, filtering_formula=f, **kw)
+    assert s.search(req(FormulaLiteral("/tantivy"))).total == 2
+    assert s.search(req(FormulaOp("or", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")]))).total == 3
+    assert s.search(req(FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")]))).total == 1
+    assert s.search(req(FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/e/myentity")]))).total == 0
+    assert s.search(req(FormulaNot(FormulaLiteral("/l/mylabel")))).total == 1
+    # nested: And(Or(a, b), Not(c)) -> a required group + exclusion
+    f = FormulaOp("and", [FormulaOp("or", [FormulaLiteral("/tantivy"), FormulaLiteral("/e/myentity")]), FormulaNot(FormulaLiteral("/label2"))])
+    r = s.search(req(f))
+    assert r.total == 2 and sorted(x.field for x in r.results) == ["/a/body", "/a/title"]
+    # with keywords: the keyword group AND the formula group
+    r = s.search(ParagraphSearchRequest(body="paragraph summary", result_per_page=20,
+                                       filtering_formula=FormulaOp("or", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")])))
+    assert r.total == 3
+    with pytest.raises(NotImplementedError):
+        s.search(req(FormulaOp("or", [FormulaOp("and", [FormulaLiteral("/a"), FormulaLiteral("/b")]), FormulaLiteral("/c")])))
+    s.close()
+
+
+def test_paragraph_prefilter_some_and_operator(orc):
+    """PrefilterResult::Some (search_query.rs:105-139): field-granular and resource-granular entries as a second required
+    group (FilterOperator::And) or as alternatives of the formula (FilterOperator::Or); PrefilterResult::None finds nothing."""
+    from nucliadb_amd.text import FormulaLiteral, PrefilterResult
+
+    rid, d = labelled_docs()
+    s = ParagraphSearcher.open([TextSegment(d, Vocabulary())])
+    some_field = PrefilterResult("Some", [(rid, "/a/body")])
+    some_res = PrefilterResult("Some", [(_hex(2), None)])
+    both = PrefilterResult("Some", [(rid, "/a/summary"), (_hex(2), None)])
+    req = ParagraphSearchRequest(body="", result_per_page=20)
+    assert s.search(req, some_field).total == 2
+    assert s.search(req, some_res).total == 1
+    assert s.search(req, both).total == 2
+    assert s.search(req, PrefilterResult("None")).total == 0
+    assert s.search(req, PrefilterResult("All")).total == 5
+    # And: formula AND prefilter; Or: formula OR prefilter
+    f = FormulaLiteral("/tantivy")
+    assert s.search(ParagraphSearchRequest(body="", result_per_page=20, filtering_formula=f), some_field).total == 1
+    assert s.search(ParagraphSearchRequest(body="", result_per_page=20, filtering_formula=f, filter_or=True), some_field).total == 3
+    # keywords + prefilter: three groups/clauses in one query, scores against the oracle's clause-level answer
+    r = s.search(ParagraphSearchRequest(body="paragraph tantivy", result_per_page=20, filtering_formula=f), both)
+    assert r.total == 1 and r.results[0].uuid == _hex(2)
+    s.close()
+
+
+def test_deletions_by_key_follow_the_segment_seq():
+    """open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74): a deletion applies to the segments OLDER than
+    it; a key longer than 32 bytes deletes one field of a resource, a 32-byte key the whole resource."""
+    rid, d = labelled_docs()
+    vocab = Vocabulary()
+    segs = [TextSegment(d, vocab), TextSegment([TextDocument(rid, "/a/body", "the rewritten paragraph about tantivy", labels=["/tantivy"])], vocab)]
+    # the resource's body field was re-indexed at seq 5 (second segment): its old paragraphs (segment seq 2) go away
+    dele = [(rid + "/a/body", 5)]
+    s = ParagraphSearcher.open(segs, seqs=[2, 5], deletions=dele)
+    r = s.search(ParagraphSearchRequest(body="tantivy", result_per_page=20))
+    assert sorted((x.uuid, x.paragraph) for x in r.results) == sorted([(rid, "the rewritten paragraph about tantivy"), (_hex(2), "tantivy paragraph of a second resource")])
+    assert s.search(ParagraphSearchRequest(body="", result_per_page=20)).total == 4
+    s.close()
+    # a resource key deletes every field of it, in the older segment only
+    s = ParagraphSearcher.open(segs, seqs=[2, 5], deletions=[(rid, 4), (_hex(2), 1)])
+    r = s.search(ParagraphSearchRequest(body="", result_per_page=20))
+    assert r.total == 2 and sorted(x.uuid for x in r.results) == sorted([rid, _hex(2)])   # seq 1 < 2: too old to touch segment 0
+    s.close()
+    t = TextSearcher.open(segs, seqs=[2, 5], deletions=dele)
+    assert t.search(DocumentSearchRequest(body="", result_per_page=20)).total == 4
+    t.close()
+
+
+def test_text_query_grammar_reference_cases():
+    """nidx_text/tests/test_search.rs:31-73 (test_search_queries) and :285-305 (test_quote_fixing)."""
+    d = [TextDocument(_hex(1), "/a/title", "The little prince"), TextDocument(_hex(1), "/a/body", "This is enough to test"),]
+    s = TextSearcher.open([TextSegment(d, Vocabulary())])
+    q = lambda body: s.search(DocumentSearchRequest(body=body, result_per_page=20))
+    for body, expected in [("", 2), ("enough to test", 1), ('"enough to test"', 1), ("enough test", 1), ('"enough test"', 0), ('"enough test', 0),
+                           ("enough mischievous test", 0), ("enough - test", 0)]:
+        r = q(body)
+        assert r.total == expected == len(r.results), body
+    for body in ['"enough test"', 'enough test"', '"enough test']:
+        assert q(body).query == '"enough test"'
+    # the operator grammar: OR groups, exclusions, required prefixes, field prefix, boosts
+    assert q("prince OR enough").total == 2
+    assert q("(prince OR enough) AND test").total == 1
+    assert q("enough -test").total == 0 and q("enough -prince").total == 1 and q("-prince").total == 0
+    assert q("+enough +test").total == 1 and q("text:enough").total == 1 and q("NOT enough little").total == 1
+    one, two = q("enough").results[0].score.bm25, q("enough^2").results[0].score.bm25
+    assert np.float32(two) == np.float32(one) * np.float32(2.0)
+    assert q("title:enough").total == 0     # unknown field: a syntax error, searched as the phrase "title:enough" -> tokens title, enough
+    with pytest.raises(NotImplementedError):
+        q("a OR (b AND c)")
+    s.close()
