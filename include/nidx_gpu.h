@@ -187,6 +187,18 @@ typedef struct {
 int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_t segment,
                                          const nidx_gpu_filter_index_t *lists);
 
+/* The string -> posting-list lookups label.fst / field.fst serve (inverted_index/fst_index.rs:70-83, map.rs:78-86), on the
+ * device for batches: the keys of the segment's posting lists — key j names list j of nidx_gpu_vector_set_filter_index — as
+ * bytewise-sorted strings in HBM (labels_key / FieldKey bytes, inverted_index/paragraph.rs:63-103, however the caller encodes
+ * them), and a batched lookup: for every query string the range [first, last) of lists whose key EQUALS it (query_is_prefix[q]
+ * == 0: FstIndexReader::get) or STARTS WITH it (!= 0: get_prefix).  A PrefilterResult::Some of thousands of field ids
+ * (searcher.rs:300-313) is one call. */
+int32_t nidx_gpu_vector_set_filter_keys(nidx_gpu_vector_index_t *index, uint32_t segment, const uint8_t *key_bytes, const uint64_t *key_offsets,
+                                        uint32_t n_keys);
+int32_t nidx_gpu_vector_lookup_filter_keys(nidx_gpu_vector_index_t *index, uint32_t segment, const uint8_t *query_bytes,
+                                           const uint64_t *query_offsets, const uint8_t *query_is_prefix, uint32_t n_queries,
+                                           uint32_t *out_first, uint32_t *out_last);
+
 enum {
     NIDX_FILTER_PUSH_LISTS = 0, /* push the union of posting lists lists[a .. b) (an AtomClause) */
     NIDX_FILTER_AND = 1,        /* pop 2, push their intersection */

@@ -97,4 +97,56 @@ hipError_t launch_bitset_and_count(const uint64_t *a, const uint64_t *alive, uin
     return hipGetLastError();
 }
 
+
+// ---- the posting lists' KEY TABLE (what label.fst / field.fst resolve): sorted byte strings, key j names posting list j.
+// One thread per query: [first, last) = the table entries equal to the query (exact) or starting with it (prefix): two
+// binary searches over byte strings in HBM.  A prefilter hands over thousands of field ids at once; their lookups run side
+// by side here instead of one FST walk after the other on the host.
+__device__ inline int key_cmp(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {   // bytewise, shorter first on a tie
+    const uint32_t n = la < lb ? la : lb;
+    for (uint32_t i = 0; i < n; i++)
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return la == lb ? 0 : (la < lb ? -1 : 1);
+}
+__device__ inline bool key_starts_with(const uint8_t *k, uint32_t lk, const uint8_t *p, uint32_t lp) {
+    if (lk < lp) return false;
+    for (uint32_t i = 0; i < lp; i++)
+        if (k[i] != p[i]) return false;
+    return true;
+}
+__global__ void key_range_kernel(const uint8_t *tbl, const unsigned long long *tbl_off, uint32_t n_keys, const uint8_t *qb,
+                                 const unsigned long long *q_off, const uint8_t *q_prefix, uint32_t n_q, uint32_t *first, uint32_t *last) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    const uint8_t *p = qb + q_off[q];
+    const uint32_t lp = (uint32_t)(q_off[q + 1] - q_off[q]);
+    uint32_t lo = 0, hi = n_keys;
+    while (lo < hi) {   // lower bound: first key >= query
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (key_cmp(tbl + tbl_off[mid], (uint32_t)(tbl_off[mid + 1] - tbl_off[mid]), p, lp) < 0) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint32_t f = lo;
+    uint32_t l = f;
+    if (q_prefix[q]) {
+        hi = n_keys;      // keys with the prefix are contiguous from f: first key beyond them
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (key_starts_with(tbl + tbl_off[mid], (uint32_t)(tbl_off[mid + 1] - tbl_off[mid]), p, lp)) lo = mid + 1;
+            else hi = mid;
+        }
+        l = lo;
+    } else if (f < n_keys && key_cmp(tbl + tbl_off[f], (uint32_t)(tbl_off[f + 1] - tbl_off[f]), p, lp) == 0) {
+        l = f + 1;
+    }
+    first[q] = f;
+    last[q] = l;
+}
+hipError_t launch_key_range(const uint8_t *tbl, const unsigned long long *tbl_off, uint32_t n_keys, const uint8_t *qb, const unsigned long long *q_off,
+                            const uint8_t *q_prefix, uint32_t n_q, uint32_t *first, uint32_t *last, hipStream_t s) {
+    if (!n_q) return hipSuccess;
+    hipLaunchKernelGGL(key_range_kernel, dim3((n_q + 127) / 128), dim3(128), 0, s, tbl, tbl_off, n_keys, qb, q_off, q_prefix, n_q, first, last);
+    return hipGetLastError();
+}
+
 }  // namespace nidx

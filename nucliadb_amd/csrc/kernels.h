@@ -268,6 +268,9 @@ hipError_t launch_bitset_scatter(const unsigned long long *list_offsets, const u
                                  uint32_t n_lists, uint32_t n_bits, uint64_t *out, hipStream_t s);
 hipError_t launch_bitset_binop(uint64_t *a, const uint64_t *b, uint32_t n_words, int op, hipStream_t s);
 hipError_t launch_bitset_not(uint64_t *a, uint32_t n_words, uint32_t n_bits, hipStream_t s);
+// sorted key table -> [first, last) of the entries equal to / prefixed by each query (filter.hip)
+hipError_t launch_key_range(const uint8_t *tbl, const unsigned long long *tbl_off, uint32_t n_keys, const uint8_t *qb, const unsigned long long *q_off,
+                            const uint8_t *q_prefix, uint32_t n_q, uint32_t *first, uint32_t *last, hipStream_t s);
 hipError_t launch_bitset_and_count(const uint64_t *a, const uint64_t *alive, uint64_t *out, uint32_t n_words,
                                    unsigned long long *count, hipStream_t s);
 

@@ -149,7 +149,7 @@ SegDev VectorSegment::seg_dev(int similarity) const {
 
 uint64_t VectorSegment::bytes() const {
     return vectors.bytes + norm2.bytes + norm2_serial.bytes + vectors16.bytes + para_of_vec.bytes + alive.bytes + g_l0.bytes + g_upper_base.bytes +
-           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes + f_offsets.bytes + f_ids.bytes + quant.bytes;
+           g_upper.bytes + g_l0_w.bytes + g_upper_w.bytes + f_offsets.bytes + f_ids.bytes + f_key_bytes.bytes + f_key_offsets.bytes + quant.bytes;
 }
 
 static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_vector_segment_t &in, VectorSegment &seg,
@@ -1147,6 +1147,65 @@ int32_t nidx_gpu_vector_set_filter_index(nidx_gpu_vector_index_t *index, uint32_
     if (n_ids) NIDX_HIP(hipMemcpy(seg.f_ids.p, lists->paragraph_ids, n_ids * 4, hipMemcpyHostToDevice));
     seg.f_n_lists = lists->n_lists;
     seg.f_n_ids = n_ids;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_vector_set_filter_keys(nidx_gpu_vector_index_t *index, uint32_t segment, const uint8_t *key_bytes, const uint64_t *key_offsets,
+                                        uint32_t n_keys) try {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size() || (n_keys && (!key_offsets || (key_offsets[n_keys] && !key_bytes))))
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment/keys");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    VectorSegment &seg = idx->segs[segment];
+    if (n_keys != seg.f_n_lists) return fail(NIDX_ERR_INVALID_ARGUMENT, "%u keys for %u posting lists", n_keys, seg.f_n_lists);
+    // sorted, strictly: the lookups are binary searches
+    for (uint32_t j = 1; j < n_keys; j++) {
+        const uint64_t la = key_offsets[j] - key_offsets[j - 1], lb = key_offsets[j + 1] - key_offsets[j];
+        const int c = memcmp(key_bytes + key_offsets[j - 1], key_bytes + key_offsets[j], (size_t)std::min(la, lb));
+        if (c > 0 || (c == 0 && la >= lb)) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter keys are not sorted (key %u)", j);
+    }
+    const uint64_t n_bytes = n_keys ? key_offsets[n_keys] : 0;
+    NIDX_HIP(seg.f_key_bytes.alloc(std::max<uint64_t>(n_bytes, 1)));
+    NIDX_HIP(seg.f_key_offsets.alloc((size_t)(n_keys + 1) * 8));
+    if (n_bytes) NIDX_HIP(hipMemcpy(seg.f_key_bytes.p, key_bytes, n_bytes, hipMemcpyHostToDevice));
+    if (n_keys) NIDX_HIP(hipMemcpy(seg.f_key_offsets.p, key_offsets, (size_t)(n_keys + 1) * 8, hipMemcpyHostToDevice));
+    else NIDX_HIP(hipMemset(seg.f_key_offsets.p, 0, 8));
+    seg.f_n_keys = n_keys;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_vector_lookup_filter_keys(nidx_gpu_vector_index_t *index, uint32_t segment, const uint8_t *query_bytes,
+                                           const uint64_t *query_offsets, const uint8_t *query_is_prefix, uint32_t n_queries,
+                                           uint32_t *out_first, uint32_t *out_last) try {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    if (n_queries == 0) return NIDX_OK;
+    if (!query_offsets || !query_is_prefix || !out_first || !out_last || (query_offsets[n_queries] && !query_bytes))
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    VectorSegment &seg = idx->segs[segment];
+    if (seg.f_n_lists && !seg.f_key_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no filter key table", segment);
+    const uint64_t qb = query_offsets[n_queries];
+    const size_t off_bytes = (size_t)(n_queries + 1) * 8, total = off_bytes + n_queries + (size_t)qb;
+    NIDX_HIP(idx->pin_in.reserve(total));
+    unsigned char *h = idx->pin_in.as<unsigned char>();
+    memcpy(h, query_offsets, off_bytes);
+    memcpy(h + off_bytes, query_is_prefix, n_queries);
+    if (qb) memcpy(h + off_bytes + n_queries, query_bytes, (size_t)qb);
+    NIDX_HIP(idx->scratch_flists.reserve(total + 8));
+    NIDX_HIP(idx->scratch_out_block.reserve((size_t)n_queries * 8));
+    NIDX_HIP(idx->pin_out.reserve((size_t)n_queries * 8));
+    NIDX_HIP(hipMemcpyAsync(idx->scratch_flists.p, h, total, hipMemcpyHostToDevice, idx->stream));
+    const unsigned char *d = idx->scratch_flists.as<unsigned char>();
+    uint32_t *d_first = idx->scratch_out_block.as<uint32_t>(), *d_last = d_first + n_queries;
+    NIDX_HIP(launch_key_range(seg.f_key_bytes.as<uint8_t>(), seg.f_key_offsets.as<unsigned long long>(), seg.f_n_keys, d + off_bytes + n_queries,
+                              reinterpret_cast<const unsigned long long *>(d), d + off_bytes, n_queries, d_first, d_last, idx->stream));
+    NIDX_HIP(hipMemcpyAsync(idx->pin_out.p, d_first, (size_t)n_queries * 8, hipMemcpyDeviceToHost, idx->stream));
+    NIDX_HIP(hipStreamSynchronize(idx->stream));
+    memcpy(out_first, idx->pin_out.p, (size_t)n_queries * 4);
+    memcpy(out_last, idx->pin_out.as<unsigned char>() + (size_t)n_queries * 4, (size_t)n_queries * 4);
     return NIDX_OK;
 } NIDX_ABI_CATCH
 

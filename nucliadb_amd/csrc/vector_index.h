@@ -32,6 +32,8 @@ struct VectorSegment {
     std::vector<uint64_t> key_ids;     // Fssc identity of each paragraph (optional)
     // label / field-key posting lists for device-side filter formulas (optional)
     DevBuf f_offsets, f_ids;
+    DevBuf f_key_bytes, f_key_offsets;   // the posting lists' keys, sorted bytewise (what label.fst / field.fst resolve)
+    uint32_t f_n_keys = 0;
     uint32_t f_n_lists = 0;
     uint64_t f_n_ids = 0;
     // HNSW graph

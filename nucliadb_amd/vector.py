@@ -238,13 +238,47 @@ class VectorSegment:
             out += [self.list_id[k] for k in self.list_keys if k == key or k.startswith(key + "/")]
         return sorted(set(out))
 
-    def compile(self, expr):
-        """BooleanExpression -> postfix program for nidx_gpu_vector_search_filtered."""
+    @staticmethod
+    def atom_queries(e) -> List[Tuple[bytes, int]]:
+        """The key-table lookups of one atom: (query bytes, is_prefix)."""
+        if isinstance(e, Literal):
+            return [(("L:" + e.label[1:] + "/").encode("utf-8"), 1)]
+        out = []
+        for pre in e.prefixes:  # "{uuid_simple}{field_id}": that field; "{uuid_simple}": every field of the resource
+            out.append((("F:" + pre).encode("utf-8"), 0))
+            out.append((("F:" + pre + "/").encode("utf-8"), 1))
+        return out
+
+    def compile(self, expr, lookup=None):
+        """BooleanExpression -> postfix program for nidx_gpu_vector_search_filtered.  lookup: a function resolving a batch of
+        (query bytes, is_prefix) against this segment's key table on the device (VectorSearcher._lookup); None = the host dict."""
         ops, lists = [], []
+        resolved = {}
+        if lookup is not None:
+            atoms = []
+
+            def collect(e):
+                if isinstance(e, (Literal, _KeyPrefixSet)):
+                    atoms.append(e)
+                elif isinstance(e, Not):
+                    collect(e.operand)
+                elif isinstance(e, (And, Or)):
+                    for o in e.operands:
+                        collect(o)
+
+            collect(expr)
+            queries = [q for a in atoms for q in self.atom_queries(a)]
+            ranges = lookup(queries)   # ONE device call for every atom of the formula
+            at = 0
+            for a in atoms:
+                nq = len(self.atom_queries(a))
+                ids = sorted({j for f, l in ranges[at: at + nq] for j in range(f, l)})
+                at += nq
+                resolved[id(a)] = ids
 
         def emit(e):
             if isinstance(e, (Literal, _KeyPrefixSet)):
-                ids = self.lists_for(e)
+                ids = resolved[id(e)] if lookup is not None else self.lists_for(e)
                 ops.append((_lib.FILTER_PUSH_LISTS, len(lists), len(lists) + len(ids)))
                 lists.extend(ids)
             elif isinstance(e, Not):
@@ -717,6 +751,13 @@ class VectorSearcher:
             if len(seg.list_keys):
                 fi = _lib.FilterIndexC(len(seg.list_keys), seg.list_offsets.ctypes.data, seg.list_ids.ctypes.data if len(seg.list_ids) else None)
                 _lib.check(_lib.lib().nidx_gpu_vector_set_filter_index(self._handle, i, C.byref(fi)))
+                # the lists' keys as a sorted table in HBM: label-prefix and field-key lookups of a request run on the device
+                enc = [k.encode("utf-8") for k in seg.list_keys]
+                assert enc == sorted(enc)
+                offs = np.zeros(len(enc) + 1, np.uint64)
+                offs[1:] = np.cumsum([len(e) for e in enc])
+                blob = np.frombuffer(b"".join(enc) + b"\0", np.uint8)
+                _lib.check(_lib.lib().nidx_gpu_vector_set_filter_keys(self._handle, i, blob.ctypes.data, offs.ctypes.data, len(enc)))
         self._keep = []  # everything was copied to HBM / host vectors by open
         return self
 
@@ -730,6 +771,19 @@ class VectorSearcher:
             self.close()
         except Exception:
             pass
+
+    def _lookup(self, segment: int, queries) -> List[Tuple[int, int]]:
+        """label.fst / field.fst lookups of one segment, batched on the device: [(first list, last list)] per query."""
+        if not queries:
+            return []
+        blob = np.frombuffer(b"".join(q for q, _ in queries) + b"\0", np.uint8)
+        offs = np.zeros(len(queries) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(q) for q, _ in queries])
+        flags = np.array([p for _, p in queries], dtype=np.uint8)
+        first, last = np.zeros(len(queries), np.uint32), np.zeros(len(queries), np.uint32)
+        _lib.check(_lib.lib().nidx_gpu_vector_lookup_filter_keys(self._handle, segment, blob.ctypes.data, offs.ctypes.data, flags.ctypes.data,
+                                                                 len(queries), first.ctypes.data, last.ctypes.data))
+        return list(zip(first.tolist(), last.tolist()))
 
     def space_usage(self) -> int:
         out = C.c_uint64(0)
@@ -850,7 +904,7 @@ class VectorSearcher:
                 if skips[s]:
                     ops, lists = [(_lib.FILTER_PUSH_NONE, 0, 0)], []
                 elif formula is not None:
-                    ops, lists = seg.compile(formula)
+                    ops, lists = seg.compile(formula, lookup=lambda queries, s=s: self._lookup(s, queries))
                 else:
                     continue
                 c_ops = (_lib.FilterOpC * len(ops))(*[_lib.FilterOpC(*o) for o in ops])

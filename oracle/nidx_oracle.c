@@ -1831,3 +1831,123 @@ void orc_bm25_search_daat_batch(const orc_bm25_index *idx, const orc_bm25_clause
     j.out_docaddr = out_docaddr; j.out_score = out_score; j.out_count = out_count; j.out_total = out_total;
     batch_run(&j, threads);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a8 / f1. ParagraphInvertedIndexes::filter (nidx_vector/src/inverted_index/paragraph.rs:124-184) restated
+ * DOCUMENT AT A TIME over the paragraph store — no posting lists, no FST: for every paragraph the formula is
+ * evaluated on the paragraph's own key and labels, which is what the inverted indexes are an index OF
+ * (ParagraphInvertedIndexes::build, :68-103: field_index keyed by FieldKey::from_field_id(paragraph id),
+ * label_index keyed by labels_key(label) = label[1..] + "/", searched by prefix).
+ * ------------------------------------------------------------------------------------------ */
+static int hexval(int c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+/* FieldKey::from_field_id (utils.rs:80-111): "<uuid>[/<type>/<name>[/...]]" -> 16 uuid bytes [+ type + "/" + name].
+ * Returns the key length, or -1 when the id does not parse (invalid uuid; a type without a name). */
+int orc_field_key(const uint8_t *id, size_t len, uint8_t *out, size_t cap) {
+    size_t p = 0, n_hex = 0;
+    uint8_t uuid[16];
+    memset(uuid, 0, sizeof(uuid));
+    while (p < len && id[p] != '/') {   /* uuid::Uuid::parse_str: 32 hex digits, simple or hyphenated */
+        if (id[p] == '-') { p++; continue; }
+        int h = hexval(id[p]);
+        if (h < 0 || n_hex >= 32) return -1;
+        uuid[n_hex / 2] = (uint8_t)(n_hex % 2 ? (uuid[n_hex / 2] | h) : (h << 4));
+        n_hex++;
+        p++;
+    }
+    if (n_hex != 32) return -1;
+    if (cap < 16) return -1;
+    memcpy(out, uuid, 16);
+    if (p >= len) return 16;
+    size_t t0 = ++p;
+    while (p < len && id[p] != '/') p++;
+    size_t t1 = p;
+    if (p >= len) return -1;            /* has a field type but no name */
+    size_t n0 = ++p;
+    while (p < len && id[p] != '/') p++;
+    size_t n1 = p;
+    size_t need = 16 + (t1 - t0) + 1 + (n1 - n0);
+    if (cap < need) return -1;
+    memcpy(out + 16, id + t0, t1 - t0);
+    out[16 + (t1 - t0)] = '/';
+    memcpy(out + 16 + (t1 - t0) + 1, id + n0, n1 - n0);
+    return (int)need;
+}
+
+/* strings: concatenated bytes + offsets.  para_keys: the paragraph ids ("<uuid>/<type>/<name>/<start>-<end>").
+ * para_label_offsets[p] .. [p+1]: the paragraph's labels, indices into `labels`.
+ * program: postfix ORC_FORMULA_* ops; LABEL a = atom string a of `atoms` (a label, "/l/x");
+ * KEYSET a, b = atoms a..b (field ids: "<uuid_simple><field_id>" or "<uuid_simple>") — AtomClause::KeyPrefixSet;
+ * AND / OR pop two; NOT complements the top (Clause::Compound with BooleanOperator::Not = complement of the AND
+ * of its operands: emit the ANDs first).
+ * resource_prefix != 0: a 16-byte key (resource-granular entry) matches every field of the resource — the intent
+ * documented at searcher.rs:300-313; 0: `field_index.get` as written (:147-151), an exact match that a bare resource
+ * key never satisfies.
+ * out: bitset over paragraph addresses.  Returns the number of set bits, or -1 on a malformed program. */
+enum { ORC_FORMULA_LABEL = 0, ORC_FORMULA_AND = 1, ORC_FORMULA_OR = 2, ORC_FORMULA_NOT = 3, ORC_FORMULA_ALL = 4, ORC_FORMULA_NONE = 5,
+       ORC_FORMULA_KEYSET = 6 };
+long orc_formula_filter(const uint8_t *key_bytes, const uint64_t *key_offsets, size_t n_paragraphs,
+                        const uint8_t *label_bytes, const uint64_t *label_offsets, const uint64_t *para_label_offsets, const uint32_t *para_labels,
+                        const uint8_t *atom_bytes, const uint64_t *atom_offsets, const orc_filter_op *ops, size_t n_ops, int resource_prefix,
+                        uint64_t *out) {
+    size_t words = (n_paragraphs + 63) / 64;
+    memset(out, 0, words * 8);
+    long count = 0;
+    uint8_t pk[512], ak[512];
+    int stack[64];
+    for (size_t p = 0; p < n_paragraphs; p++) {
+        int pklen = orc_field_key(key_bytes + key_offsets[p], (size_t)(key_offsets[p + 1] - key_offsets[p]), pk, sizeof(pk));
+        int sp = 0;
+        for (size_t i = 0; i < n_ops; i++) {
+            const orc_filter_op *op = &ops[i];
+            switch (op->op) {
+                case ORC_FORMULA_LABEL: {
+                    /* label_index.get_prefix(labels_key(atom)): some label l of the paragraph with
+                     * (l[1..] + "/") starting with (atom[1..] + "/") */
+                    const uint8_t *a = atom_bytes + atom_offsets[op->a];
+                    size_t alen = (size_t)(atom_offsets[op->a + 1] - atom_offsets[op->a]);
+                    int hit = 0;
+                    for (uint64_t j = para_label_offsets[p]; j < para_label_offsets[p + 1] && !hit; j++) {
+                        const uint8_t *l = label_bytes + label_offsets[para_labels[j]];
+                        size_t llen = (size_t)(label_offsets[para_labels[j] + 1] - label_offsets[para_labels[j]]);
+                        if (alen == 0 || llen == 0) continue;
+                        /* compare l[1..] + "/" against the prefix a[1..] + "/" */
+                        size_t need = alen - 1;
+                        if (llen - 1 < need) continue;
+                        if (memcmp(l + 1, a + 1, need) != 0) continue;
+                        if (llen - 1 == need || l[1 + need] == '/') hit = 1;
+                    }
+                    if (sp >= 64) return -1;
+                    stack[sp++] = hit;
+                    break;
+                }
+                case ORC_FORMULA_KEYSET: {
+                    int hit = 0;
+                    for (uint32_t a = op->a; a < op->b && !hit; a++) {
+                        int aklen = orc_field_key(atom_bytes + atom_offsets[a], (size_t)(atom_offsets[a + 1] - atom_offsets[a]), ak, sizeof(ak));
+                        if (aklen < 0 || pklen < 0) continue;   /* filter_map: ids that do not parse are skipped */
+                        if (aklen == pklen && memcmp(ak, pk, (size_t)aklen) == 0) hit = 1;
+                        else if (resource_prefix && aklen == 16 && pklen >= 16 && memcmp(ak, pk, 16) == 0) hit = 1;
+                    }
+                    if (sp >= 64) return -1;
+                    stack[sp++] = hit;
+                    break;
+                }
+                case ORC_FORMULA_ALL: if (sp >= 64) return -1; stack[sp++] = 1; break;
+                case ORC_FORMULA_NONE: if (sp >= 64) return -1; stack[sp++] = 0; break;
+                case ORC_FORMULA_AND: if (sp < 2) return -1; stack[sp - 2] = stack[sp - 2] && stack[sp - 1]; sp--; break;
+                case ORC_FORMULA_OR: if (sp < 2) return -1; stack[sp - 2] = stack[sp - 2] || stack[sp - 1]; sp--; break;
+                case ORC_FORMULA_NOT: if (sp < 1) return -1; stack[sp - 1] = !stack[sp - 1]; break;
+                default: return -1;
+            }
+        }
+        if (sp != 1) return -1;
+        if (stack[0]) { out[p >> 6] |= 1ull << (p & 63); count++; }
+    }
+    return count;
+}

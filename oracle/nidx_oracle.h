@@ -278,6 +278,14 @@ typedef struct {
 } orc_bm25_hit;
 size_t orc_merge_bm25(const orc_bm25_hit *const *lists, const size_t *lens, size_t n_lists, size_t limit, orc_bm25_hit *out);
 
+/* ---- vector-index filter formulas, document at a time (ParagraphInvertedIndexes::filter, inverted_index/paragraph.rs:124-184;
+ * see the definition for the program format) ---- */
+int orc_field_key(const uint8_t *id, size_t len, uint8_t *out, size_t cap);   /* FieldKey::from_field_id (utils.rs:80-111) */
+long orc_formula_filter(const uint8_t *key_bytes, const uint64_t *key_offsets, size_t n_paragraphs,
+                        const uint8_t *label_bytes, const uint64_t *label_offsets, const uint64_t *para_label_offsets, const uint32_t *para_labels,
+                        const uint8_t *atom_bytes, const uint64_t *atom_offsets, const orc_filter_op *ops, size_t n_ops, int resource_prefix,
+                        uint64_t *out);
+
 /* ---- batch runners (cpu_baseline leg of bench.py, benchmark-scale parity checks): the single-query functions above,
  * one query per work item on `threads` POSIX threads (one blocking thread per request, src/searcher/shard_search.rs:139-153).
  * out_* are [n_queries][k]; stats NULL or [n_queries]. */

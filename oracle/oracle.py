@@ -222,6 +222,10 @@ def lib():
     L.orc_bm25_search_daat_batch.restype = None
     L.orc_bm25_search_daat_batch.argtypes = [C.POINTER(_Bm25Index), C.POINTER(_Bm25Clause), C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_formula_filter.restype = C.c_long
+    L.orc_formula_filter.argtypes = [C.c_void_p] * 2 + [C.c_size_t] + [C.c_void_p] * 6 + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.orc_field_key.restype = C.c_int
+    L.orc_field_key.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -585,6 +589,48 @@ def searcher_search_batch(segments, queries, k, min_score=-1.0, with_duplicates=
     oc = np.zeros(nq, np.uint32)
     lib().orc_searcher_search_batch(segs, key_ptrs, n, _ptr(q), nq, k, min_score, int(with_duplicates), int(threads), out.ctypes.data, _ptr(oc))
     return out["segment"].copy(), out["vector"].copy(), out["score"].copy(), oc
+
+
+FORMULA_LABEL, FORMULA_AND, FORMULA_OR, FORMULA_NOT, FORMULA_ALL, FORMULA_NONE, FORMULA_KEYSET = 0, 1, 2, 3, 4, 5, 6
+
+
+def _strings(items):
+    enc = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+    offs = np.zeros(len(enc) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    return np.frombuffer(b"".join(enc) + b"\0", np.uint8).copy(), offs
+
+
+def field_key(field_id: str):
+    """FieldKey::from_field_id (utils.rs:80-111) -> bytes or None"""
+    out = np.zeros(512, np.uint8)
+    b = field_id.encode()
+    n = lib().orc_field_key(b, len(b), out.ctypes.data, out.size)
+    return None if n < 0 else bytes(out[:n])
+
+
+def formula_filter(para_keys, para_labels, ops, atoms, resource_prefix=False) -> np.ndarray:
+    """ParagraphInvertedIndexes::filter evaluated paragraph by paragraph.  para_keys: paragraph ids; para_labels: list of label
+    lists; ops: postfix [(FORMULA_*, a, b)] with atoms = the label / field-id strings the LABEL / KEYSET ops index.
+    -> bool mask over paragraph addresses."""
+    n = len(para_keys)
+    kb, ko = _strings(para_keys)
+    uniq = sorted({l for ls in para_labels for l in ls})
+    lid = {l: i for i, l in enumerate(uniq)}
+    lb, lo = _strings(uniq)
+    plo = np.zeros(n + 1, np.uint64)
+    plo[1:] = np.cumsum([len(ls) for ls in para_labels])
+    pl = np.array([lid[l] for ls in para_labels for l in ls] + [0], dtype=np.uint32)
+    ab, ao = _strings(atoms)
+    c_ops = np.ascontiguousarray([(o, a, b) for o, a, b in ops], dtype=np.uint32).reshape(-1, 3)
+    out = np.zeros((n + 63) // 64 or 1, np.uint64)
+    cnt = lib().orc_formula_filter(kb.ctypes.data, ko.ctypes.data, n, lb.ctypes.data, lo.ctypes.data, plo.ctypes.data, pl.ctypes.data,
+                                   ab.ctypes.data, ao.ctypes.data, c_ops.ctypes.data if len(ops) else None, len(ops), int(resource_prefix), out.ctypes.data)
+    if cnt < 0:
+        raise ValueError("malformed formula program")
+    mask = np.unpackbits(out.view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert int(mask.sum()) == cnt
+    return mask
 
 
 # ---------------------------------------------------------------- BM25

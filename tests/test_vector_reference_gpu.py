@@ -173,9 +173,45 @@ def test_metadata_and_labels_round_trip():
     assert searcher.space_usage() > 0
 
 
-def test_device_filter_programs_match_host_bitsets():
+def oracle_formula_mask(orc, seg, expr):
+    """The formula evaluated by the ORACLE (oracle/nidx_oracle.c: orc_formula_filter — ParagraphInvertedIndexes::filter restated
+    document at a time over the paragraph keys and labels; no posting lists, nothing from the product package).  The
+    translation below is the test's own: expression tree -> the oracle's postfix program over label / field-id strings."""
+    from nucliadb_amd.vector import _KeyPrefixSet
+
+    ops, atoms = [], []
+
+    def emit(e):
+        if isinstance(e, Literal):
+            ops.append((orc.FORMULA_LABEL, len(atoms), 0))
+            atoms.append(e.label)
+        elif isinstance(e, _KeyPrefixSet):
+            ops.append((orc.FORMULA_KEYSET, len(atoms), len(atoms) + len(e.prefixes)))
+            atoms.extend(e.prefixes)
+        elif isinstance(e, Not):
+            emit(e.operand)
+            ops.append((orc.FORMULA_NOT, 0, 0))
+        elif isinstance(e, (And, Or)):
+            if not e.operands:
+                ops.append((orc.FORMULA_ALL if isinstance(e, And) else orc.FORMULA_NONE, 0, 0))
+                return
+            emit(e.operands[0])
+            for o in e.operands[1:]:
+                emit(o)
+                ops.append((orc.FORMULA_AND if isinstance(e, And) else orc.FORMULA_OR, 0, 0))
+        else:
+            raise TypeError(e)
+
+    emit(expr)
+    # resource-granular prefilter entries: the product follows the intent documented at searcher.rs:300-313 (every field of
+    # the resource), DESIGN.md §4.9
+    return orc.formula_filter(seg.keys, seg.labels, ops, atoms, resource_prefix=True)
+
+
+def test_device_filter_programs_match_host_bitsets(orc):
     """Random label / key-prefix formulas: the postfix program evaluated on the GPU (filter.hip) and the
-    numpy bitset route must select the same paragraphs, report the same matching count and route alike."""
+    numpy bitset route must select the same paragraphs, report the same matching count and route alike — and that count
+    must be what the ORACLE's document-at-a-time evaluation of the same formula gives."""
     rng = np.random.default_rng(3)
     d, n = 16, 700
     config = VectorConfig.for_paragraphs(d)
@@ -216,8 +252,15 @@ def test_device_filter_programs_match_host_bitsets():
         for x, y in zip(a, b):
             assert np.array_equal(x, y), trial
         if formula is not None or pre.kind == "some":
-            want = [int((seg._eval(searcher._formula(req, pre))).sum()) for seg in searcher._segments]
+            want = [int(oracle_formula_mask(orc, seg, searcher._formula(req, pre)).sum()) for seg in searcher._segments]
             assert matching_dev == want, (trial, matching_dev, want)
+            # and paragraph by paragraph: a search that returns every matching paragraph returns exactly the oracle's set
+            big = VectorSearchRequest(result_per_page=200, min_score=-1e30, with_duplicates=True, filtering_formula=formula, filter_operator=op)
+            hits = searcher.search(VectorSearchRequest(**{**big.__dict__, "vector": q[0].tolist()}), pre).documents
+            if sum(want) <= 200:
+                got = sorted(h.doc_id for h in hits)
+                exp = sorted(seg.keys[i] for seg in searcher._segments for i in np.nonzero(oracle_formula_mask(orc, seg, searcher._formula(req, pre)))[0])
+                assert got == exp, trial
     searcher.close()
 
 
