@@ -788,7 +788,8 @@ __global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
 
 hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s) {
     if (n_queries == 0) return hipSuccess;
-    if (m.k > 64) hipLaunchKernelGGL(bm25_merge_kernel<4>, dim3(n_queries), dim3(64), 0, s, m);
+    if (m.k > 256) hipLaunchKernelGGL(bm25_merge_kernel<8>, dim3(n_queries), dim3(64), 0, s, m);
+    else if (m.k > 64) hipLaunchKernelGGL(bm25_merge_kernel<4>, dim3(n_queries), dim3(64), 0, s, m);
     else hipLaunchKernelGGL(bm25_merge_kernel<1>, dim3(n_queries), dim3(64), 0, s, m);
     return hipGetLastError();
 }
@@ -804,15 +805,18 @@ hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uin
                               uint32_t max_clauses, hipStream_t s) {
     if (n_fast) {
         const dim3 grid((n_fast + 3) / 4), block(256);
-        if (a.k > 64) hipLaunchKernelGGL((bm25_fast_kernel<4, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
+        if (a.k > 256) hipLaunchKernelGGL((bm25_fast_kernel<8, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
+        else if (a.k > 64) hipLaunchKernelGGL((bm25_fast_kernel<4, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
         else hipLaunchKernelGGL((bm25_fast_kernel<1, BM25_FAST_CLAUSES>), grid, block, 0, s, a, fast_items, n_fast);
     }
     if (n_wide) {
         if (max_clauses > 32) {
-            if (a.k > 64) launch_rows<4, unsigned long long>(a, wide_items, n_wide, s);
+            if (a.k > 256) launch_rows<8, unsigned long long>(a, wide_items, n_wide, s);
+            else if (a.k > 64) launch_rows<4, unsigned long long>(a, wide_items, n_wide, s);
             else launch_rows<1, unsigned long long>(a, wide_items, n_wide, s);
         } else {
-            if (a.k > 64) launch_rows<4, uint32_t>(a, wide_items, n_wide, s);
+            if (a.k > 256) launch_rows<8, uint32_t>(a, wide_items, n_wide, s);
+            else if (a.k > 64) launch_rows<4, uint32_t>(a, wide_items, n_wide, s);
             else launch_rows<1, uint32_t>(a, wide_items, n_wide, s);
         }
     }

@@ -457,7 +457,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     const uint64_t n_pairs = opt->facet_offsets ? opt->facet_offsets[nq] : 0;
     for (uint64_t p = 0; p < n_pairs && opt->out_facet_counts; p++) opt->out_facet_counts[p] = 0;
     if (nq == 0) return NIDX_OK;
-    if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > 256 is not supported (got %u)", k);
+    // the paragraph search asks for result_per_page + 1 with pages up to max(top_k, fusion / reranker window) = 500
+    if (k > NIDX_K_MAX) return fail(NIDX_ERR_UNSUPPORTED, "TopDocs limit > %d is not supported (got %u)", NIDX_K_MAX, k);
     const int order_field = opt->order_field;
     if (order_field > 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown fast field %d", order_field);
     if (order_field >= 0) {

@@ -32,7 +32,13 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     // initialize_graph(skip_nodes = n0, total = n): a fresh RNG draws the levels of the NEW nodes only
     std::vector<uint8_t> drawn, levels(n);
     draw_levels(level_seed, n - n0, drawn);
-    for (uint32_t i = 0; i < n0; i++) levels[i] = base->top_layer[i];
+    for (uint32_t i = 0; i < n0; i++) {
+        // the request keys of the build carry 4 bits of layer and the records of a node are sized from its level: a reused
+        // graph with a node above layer 15 (P ~ 30^-15 for a real one: a corrupt or crafted image) is refused, not clamped
+        if (base->top_layer[i] > 15)
+            return fail(NIDX_ERR_UNSUPPORTED, "hnsw.graph: node %u lives on layer %u; graphs above layer 15 cannot be extended", i, (unsigned)base->top_layer[i]);
+        levels[i] = base->top_layer[i];
+    }
     for (uint32_t i = n0; i < n; i++) levels[i] = drawn[i - n0];
     uint32_t max_level = 0;
     for (uint32_t i = 0; i < n; i++) {

@@ -275,6 +275,7 @@ template <int NJ>
 static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
     const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
     // large result pages (ef > 64) are the rare path: one shape each
+    if (ef > 256) return launch_v<NJ, 2, 2, 8>(a, waves, s);
     if (ef > 128) return launch_v<NJ, 2, 2, 4>(a, waves, s);
     if (ef > 64) return launch_v<NJ, 2, 2, 2>(a, waves, s);
     // rows in flight per wave / register budget: tuned on MI355X (profiles/r01_tune_hnsw.txt)
@@ -286,6 +287,7 @@ static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
 template <int NJ>
 static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s) {
     const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
+    if (ef > 256) return launch_v<NJ, 2, 1, 8>(a, waves, s);
     if (ef > 128) return launch_v<NJ, 2, 1, 4>(a, waves, s);
     if (ef > 64) return launch_v<NJ, 2, 1, 2>(a, waves, s);
     return launch_v<NJ, 2, 1, 1>(a, waves, s);
@@ -293,7 +295,7 @@ static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s)
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
+    if (a.k == 0 || a.k > NIDX_K_MAX) return hipErrorInvalidValue;
     int nj = (int)((a.seg.dp + 255u) / 256u);
     if (waves_per_query < 1) waves_per_query = 1;
     if (waves_per_query > 4) waves_per_query = 4;

@@ -92,9 +92,9 @@ struct SpillPool {
 template <int NJ>
 __global__ __launch_bounds__(256) void hnsw_closest_spill_kernel(HnswSpillArgs a) {
     __shared__ SearchShared sh;
-    __shared__ uint32_t res_addr[256];
-    __shared__ float res_score[256];
-    __shared__ uint32_t res_para[256];
+    __shared__ uint32_t res_addr[NIDX_K_MAX];
+    __shared__ float res_score[NIDX_K_MAX];
+    __shared__ uint32_t res_para[NIDX_K_MAX];
 
     const int lane = threadIdx.x & 63;
     const bool ctl = (threadIdx.x >> 6) == 0;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void hnsw_closest_spill_kernel(HnswSpillArgs a
 
     // filtered_result.sort_by(|a, b| b.1.total_cmp(&a.1)) — stable (search.rs:381)
     if (ctl) {
-        for (int e = lane; e < 256; e += 64) {
+        for (int e = lane; e < NIDX_K_MAX; e += 64) {
             if (e < n_res) {
                 const float s = res_score[e];
                 const int32_t key = total_key(s);
@@ -226,7 +226,7 @@ static hipError_t launch_spill_nj(const HnswSpillArgs &a, hipStream_t s) {
 
 hipError_t launch_hnsw_closest_spill(const HnswSpillArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
+    if (a.k == 0 || a.k > NIDX_K_MAX) return hipErrorInvalidValue;
     const int nj = (int)((a.seg.dp + 255u) / 256u);
     if (nj <= 1) return launch_spill_nj<1>(a, s);
     if (nj <= 2) return launch_spill_nj<2>(a, s);

@@ -1,5 +1,6 @@
 // kernels.h — host-visible launch interfaces of the gfx950 kernels (internal to libnidx_gpu).
 #pragma once
+#define NIDX_K_MAX 512   /* largest result page: nucliadb asks for max(top_k, rank-fusion window, reranker window) <= 500 */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -170,7 +171,7 @@ struct HnswSearchArgs {
     // a caller that did not ask for per-query counters can tell with one word whether the launch needs the exact fallback
     uint32_t *flag_word = nullptr;
 };
-#define NIDX_DUMP_STRIDE 256
+#define NIDX_DUMP_STRIDE 512
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
 
 // closest_up_nodes with the candidate pool and the visited set in HBM (hnsw_spill.hip): the exact fallback for the

@@ -118,6 +118,21 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     struct Item { uint64_t id; double score; };
     std::vector<Item> acc;
     std::vector<uint32_t> order;
+    // _fuse ranks every source by its OWN scores, descending (a stable sort; rank_fusion.py:139-147): callers hand the lists
+    // over ranked, and a list that carries scores is checked — an unsorted one would silently fuse with wrong ranks
+    for (uint32_t l = 0; l < n_lists; l++) {
+        const nidx_gpu_ranked_list_t &L = lists[l];
+        if (!L.scores) continue;
+        for (uint32_t q = 0; q < n_queries; q++) {
+            const uint32_t c = std::min(L.counts[q], L.stride);
+            for (uint32_t r = 1; r < c; r++)
+                if (L.scores[(size_t)q * L.stride + r] > L.scores[(size_t)q * L.stride + r - 1])
+                    return fail(NIDX_ERR_INVALID_ARGUMENT, "rank fusion: list %u of query %u is not sorted by score (rank %u)", l, q, r);
+        }
+    }
+    // first-seen position of every id of one query: open addressing, sized for the query's hits
+    std::vector<uint64_t> slot_id;
+    std::vector<uint32_t> slot_at;
     for (uint32_t q = 0; q < n_queries; q++) {
         uint32_t non_empty = 0, only = 0;
         for (uint32_t l = 0; l < n_lists; l++) {
@@ -132,17 +147,27 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
             for (uint32_t r = 0; r < c; r++)
                 acc.push_back({L.ids[(size_t)q * L.stride + r], L.scores ? (double)L.scores[(size_t)q * L.stride + r] : 0.0});
         } else {
+            size_t hits = 0;
+            for (uint32_t l = 0; l < n_lists; l++) hits += std::min(lists[l].counts[q], lists[l].stride);
+            size_t cap = 16;
+            while (cap < 2 * hits) cap <<= 1;
+            slot_at.assign(cap, 0xffffffffu);
+            slot_id.resize(cap);
             for (uint32_t l = 0; l < n_lists; l++) {
                 const nidx_gpu_ranked_list_t &L = lists[l];
                 const uint32_t c = std::min(L.counts[q], L.stride);
                 for (uint32_t r = 0; r < c; r++) {
                     const uint64_t id = L.ids[(size_t)q * L.stride + r];
                     const double term = (1.0 / (k + (double)r)) * L.weight;
-                    // windows are a few tens of hits: a linear probe of the first-seen order beats a hash table
-                    size_t at = 0;
-                    while (at < acc.size() && acc[at].id != id) at++;
-                    if (at == acc.size()) acc.push_back({id, term});
-                    else acc[at].score += term;
+                    size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 32) & (slot_at.size() - 1);
+                    while (slot_at[h] != 0xffffffffu && slot_id[h] != id) h = (h + 1) & (slot_at.size() - 1);
+                    if (slot_at[h] == 0xffffffffu) {
+                        slot_at[h] = (uint32_t)acc.size();
+                        slot_id[h] = id;
+                        acc.push_back({id, term});
+                    } else {
+                        acc[slot_at[h]].score += term;
+                    }
                 }
             }
         }

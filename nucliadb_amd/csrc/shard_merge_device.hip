@@ -43,8 +43,10 @@ __global__ void merge_vector_kernel(const float *__restrict__ scores,    // [P][
             heap[child] = t;
         }
     };
+    // a shard's count can never exceed the k slots its row has: an oversized value (a bad gather) must not read past the row
+    auto count_of = [&](uint32_t l) { const uint32_t c = counts[(size_t)l * B + q]; return c < k ? c : k; };
     for (uint32_t l = 0; l < P; l++)
-        if (counts[(size_t)l * B + q] > 0) heap[len++] = MergeHead{l, 0};
+        if (count_of(l) > 0) heap[len++] = MergeHead{l, 0};
     for (uint32_t i = len / 2; i-- > 0;) sift_down(i);
     uint32_t n = 0;
     while (len > 0 && n < limit) {
@@ -52,7 +54,7 @@ __global__ void merge_vector_kernel(const float *__restrict__ scores,    // [P][
         out_score[(size_t)q * limit + n] = score_of(h);
         out_id[(size_t)q * limit + n] = ids[((size_t)h.list * B + q) * k + h.pos];
         n++;
-        if (h.pos + 1 < counts[(size_t)h.list * B + q]) heap[0].pos++;
+        if (h.pos + 1 < count_of(h.list)) heap[0].pos++;
         else {
             heap[0] = heap[len - 1];
             len--;

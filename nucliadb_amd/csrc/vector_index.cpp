@@ -434,6 +434,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
     }
     if (method == NIDX_METHOD_RABITQ_HNSW || method == NIDX_METHOD_RABITQ_BRUTE_FORCE) {
         if (!seg.has_quant) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no quantized store", s);
+        if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "the RaBitQ arms keep at most 256 hits per query (got k=%u)", k);
         const bool hnsw = method == NIDX_METHOD_RABITQ_HNSW;
         const uint32_t nw = seg.dim / 64u;
         NIDX_HIP(scratch_rq.reserve((size_t)nq * sizeof(RabitqQueryDev)));
@@ -627,8 +628,8 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
     // contributes at most vmax of them); they are reduced to one hit per paragraph afterwards
     const uint32_t k_out = k;
     if (multi) {
-        if ((uint64_t)k * seg.vmax > 256)
-            return fail(NIDX_ERR_UNSUPPORTED, "result_per_page %u x %u vectors per paragraph exceeds the 256-hit scan", k, seg.vmax);
+        if ((uint64_t)k * seg.vmax > NIDX_K_MAX)
+            return fail(NIDX_ERR_UNSUPPORTED, "result_per_page %u x %u vectors per paragraph exceeds the %d-hit scan", k, seg.vmax, NIDX_K_MAX);
         k = k * seg.vmax;
         NIDX_HIP(scratch_cand_vec.reserve((size_t)nq * k * 4));
         NIDX_HIP(scratch_cand_score.reserve((size_t)nq * k * 4));
@@ -842,7 +843,8 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     if (out_method)
         for (size_t s = 0; s < segs.size(); s++) out_method[s] = 0;
     if (nq == 0 || k == 0 || segs.empty()) return NIDX_OK;
-    if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > 256 is not supported (got %u)", k);
+    // nucliadb asks for max(top_k, rank-fusion window, reranker window) results per page (unit_retrieval.py), windows <= 500
+    if (k > NIDX_K_MAX) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > %d is not supported (got %u)", NIDX_K_MAX, k);
     if (p.method < 0 || p.method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
 
     // query batch -> HBM (normalised first when the index says so, searcher.rs:246-252), staged in pinned memory: one
@@ -881,7 +883,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         int method = p.method;
         if (method == NIDX_METHOD_AUTO) {
             // OpenSegment::_search (segment.rs:506-513,535-555): RaBitQ whenever the store has quantized vectors
-            const bool rabitq = rabitq_enabled(seg);
+            const bool rabitq = rabitq_enabled(seg) && k <= 256;   // the RaBitQ kernels keep at most 256 hits: larger pages take the exact arms
             const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, rabitq);
             method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
                             : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);
@@ -1323,7 +1325,7 @@ int32_t nidx_gpu_vector_search_filtered(nidx_gpu_vector_index_t *index, const fl
 
 static int32_t device_entry_method(VectorIndex *idx, uint32_t segment, const nidx_gpu_vector_search_params_t *params,
                                    const uint64_t *d_filter, int &method) {
-    if (params->k == 0 || params->k > 256) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..256 (got %u)", params->k);
+    if (params->k == 0 || params->k > NIDX_K_MAX) return fail(NIDX_ERR_UNSUPPORTED, "k must be in 1..%d (got %u)", NIDX_K_MAX, params->k);
     if (idx->cfg.dimension & 3u)
         return fail(NIDX_ERR_UNSUPPORTED, "device-resident queries need a dimension that is a multiple of 4");
     if (params->method < 0 || params->method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", params->method);
@@ -1332,7 +1334,7 @@ static int32_t device_entry_method(VectorIndex *idx, uint32_t segment, const nid
     if (method == NIDX_METHOD_AUTO) {
         if (d_filter) return fail(NIDX_ERR_INVALID_ARGUMENT, "NIDX_METHOD_AUTO with a device filter: pick the method explicitly");
         // OpenSegment::_search (segment.rs:506-513,535-555), like search_host
-        const bool rabitq = idx->rabitq_enabled(seg);
+        const bool rabitq = idx->rabitq_enabled(seg) && params->k <= 256;
         const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, seg.alive_count, params->k, rabitq);
         method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
                         : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);

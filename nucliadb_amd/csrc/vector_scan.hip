@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
 // ---------------------------------------------------------------------------------------------
 template <int NJ, bool WIDE>
 static hipError_t launch_scan_nj(const ScanArgs &a, uint32_t nblk, hipStream_t s) {
-    if (a.k > 64) {  // large result pages: 4 chained lists per query, at most 4 queries per pass
+    if (a.k > 256) {  // k up to 512 (rank-fusion / reranker windows reach 500): 8 chained lists, one query per pass
+        hipLaunchKernelGGL((scan_topk_kernel<NJ, 1, 8>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
+    } else if (a.k > 64) {  // large result pages: 4 chained lists per query, at most 4 queries per pass
         if (a.qt == 1) hipLaunchKernelGGL((scan_topk_kernel<NJ, 1, 4>), dim3(nblk, a.n_queries), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((scan_topk_kernel<NJ, 4, 4>), dim3(nblk, (a.n_queries + 3) / 4), dim3(256), 0, s, a);
     } else if (a.qt == 1) {
@@ -285,7 +287,7 @@ static hipError_t launch_scan_nj(const ScanArgs &a, uint32_t nblk, hipStream_t s
 
 // queries per pass over the rows: 8 while the tile fits the register file (D <= 1024, k <= 64), else 4
 uint32_t scan_query_tile(uint32_t n_queries, uint32_t dp, uint32_t k) {
-    if (n_queries == 1) return 1;
+    if (n_queries == 1 || k > 256) return 1;
     if (n_queries <= 4 || dp > 1024 || k > 64) return 4;
     return 8;
 }
@@ -298,7 +300,7 @@ uint32_t scan_num_blocks(uint32_t n) {
 }
 
 hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
-    if (a.k == 0 || a.k > 256) return hipErrorInvalidValue;
+    if (a.k == 0 || a.k > NIDX_K_MAX) return hipErrorInvalidValue;
     a.qt = scan_query_tile(a.n_queries, a.dp, a.k);
     int nj = (int)((a.dp + 255u) / 256u);
     if (nj <= 1) return launch_scan_nj<1, true>(a, nblk, s);
@@ -313,7 +315,10 @@ hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
 
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s) {
-    if (k > 64)
+    if (k > 256)
+        hipLaunchKernelGGL(merge_topk_kernel<8>, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
+                           out_score, out_count);
+    else if (k > 64)
         hipLaunchKernelGGL(merge_topk_kernel<4>, dim3(n_queries), dim3(256), 0, s, partial, lists_per_query, k, out_vec,
                            out_score, out_count);
     else
@@ -329,8 +334,8 @@ hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32
 __global__ __launch_bounds__(64) void para_best_kernel(const uint32_t *in_vec, const float *in_score, const uint32_t *in_count,
                                                        uint32_t k_in, const uint32_t *para_of_vec, uint32_t k, uint32_t *out_vec,
                                                        float *out_score, uint32_t *out_count) {
-    __shared__ uint32_t a_para[256], a_vec[256];
-    __shared__ float a_score[256];
+    __shared__ uint32_t a_para[NIDX_K_MAX], a_vec[NIDX_K_MAX];
+    __shared__ float a_score[NIDX_K_MAX];
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint32_t cnt = in_count[q];

@@ -70,6 +70,7 @@ def test_or_queries_match_oracle(orc, corpus):
     compare(orc, seg, s, queries, 1)
     compare(orc, seg, s, queries, 64)
     compare(orc, seg, s, queries, 201)   # paragraph search asks for k+1 with result_per_page up to 200
+    compare(orc, seg, s, queries, 501)   # ... or max(top_k, rank-fusion window, reranker window) = 500
     s.close()
 
 

@@ -1,6 +1,9 @@
 """Rank fusion mirror vs the cases of the reference's own unit tests (nucliadb/tests/search/unit/test_rank_fusion.py:
 test_reciprocal_rank_fusion_algorithm :150-312, _boosting :315-404, test_weighted_comb_sum_rank_fusion :409-455; RRF_TEST_K = 2,
 FAKE_GRAPH_SCORE = 1.0): same inputs, same (id, rounded score, score type) sequences."""
+import numpy as np
+import pytest
+
 from nucliadb_amd.rank_fusion import BM25, BOTH, RELATION_RELEVANCE, VECTOR, ReciprocalRankFusion, ScoredItem, WeightedCombSum
 
 K = 2
@@ -112,3 +115,32 @@ def test_native_batched_rrf_equals_the_mirror():
         assert n == len(want), q
         assert [int(x) for x in got_ids[q, :n]] == [int(w.paragraph_id) for w in want], q
         assert [float(x) for x in got_scores[q, :n]] == [float(w.score) for w in want], q
+
+
+def test_rrf_refuses_unsorted_scored_lists_and_dedups_large_windows():
+    """ranks are positions, so a list that carries scores must arrive sorted by them (rank_fusion.py:139-147 sorts
+    every source first); windows of 500 hits per source are merged through a hash map."""
+    import ctypes as C
+
+    from nucliadb_amd import _lib
+    from nucliadb_amd.rank_fusion import rrf_fuse_batch
+
+    ids = np.array([[5, 6, 7]], np.uint64)
+    cnt = np.array([3], np.uint32)
+    bad = np.array([[1.0, 3.0, 2.0]], np.float32)
+    with pytest.raises(_lib.NidxGpuError):
+        rrf_fuse_batch([(ids, cnt, 1.0, bad), (ids, cnt, 1.0, None)], k=60.0, window=3)
+    rng = np.random.default_rng(5)
+    a = rng.permutation(2000)[:500].astype(np.uint64)[None, :]
+    b = rng.permutation(2000)[:500].astype(np.uint64)[None, :]
+    c500 = np.array([500], np.uint32)
+    fused_ids, fused_scores, n = rrf_fuse_batch([(a, c500, 1.0, None), (b, c500, 2.0, None)], k=60.0, window=1000)
+    want = {}
+    for r, i in enumerate(a[0]):
+        want[int(i)] = want.get(int(i), 0.0) + 1.0 / (60.0 + r)
+    for r, i in enumerate(b[0]):
+        want[int(i)] = want.get(int(i), 0.0) + 2.0 / (60.0 + r)
+    assert n[0] == len(want)
+    got = {int(i): float(s) for i, s in zip(fused_ids[0, : n[0]], fused_scores[0, : n[0]])}
+    assert got.keys() == want.keys() and all(abs(got[i] - want[i]) < 1e-12 for i in want)
+    assert list(fused_scores[0, : n[0]]) == sorted(fused_scores[0, : n[0]], reverse=True)

@@ -84,7 +84,7 @@ def test_similarity_bits_match_oracle(orc, d):
 
 # ---- a7: brute_force_search ----------------------------------------------------------------------------
 @pytest.mark.parametrize("sim", [0, 1])
-@pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 3), (5, 3, 2, 10), (4000, 64, 9, 10), (20000, 768, 17, 10), (3000, 758, 5, 7),
+@pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 3), (5, 3, 2, 10), (4000, 64, 9, 10), (20000, 768, 17, 10), (3000, 758, 5, 7), (6000, 128, 5, 500), (2500, 768, 3, 301),
                                       (2500, 1024, 8, 64), (1200, 1536, 3, 5), (4000, 64, 9, 200), (300, 32, 1, 256),
                                       (9000, 768, 6, 100)])
 def test_brute_force_matches_oracle(orc, sim, n, d, nq, k):
@@ -166,7 +166,7 @@ def hnsw_case(orc):
     return x, oseg, bytes(gbytes)
 
 
-@pytest.mark.parametrize("k", [1, 10, 30, 50, 64, 100, 200])
+@pytest.mark.parametrize("k", [1, 10, 30, 50, 64, 100, 200, 300, 500])   # 500: MAX_RANK_FUSION_WINDOW (result_per_page = max(top_k, windows))
 @pytest.mark.parametrize("with_dup", [True, False])
 def test_hnsw_search_matches_oracle(orc, hnsw_case, k, with_dup):
     x, oseg, gbytes = hnsw_case
