@@ -91,13 +91,15 @@ def test_multi_vector_brute_force_and_hnsw_match_oracle(orc, sim):
         bf_f = idx.search(q, k, _lib.METHOD_BRUTE_FORCE, min_score=0.3, filter_bits=filt)
         hn = idx.search(q, k, _lib.METHOD_HNSW)
         hn_f = idx.search(q, k, _lib.METHOD_HNSW, min_score=0.3, with_duplicates=False, filter_bits=filt)
+        bf100 = idx.search(q, 100, _lib.METHOD_BRUTE_FORCE)      # 100 x 4 vectors per paragraph = 400 candidate vectors (<= 512)
         with pytest.raises(_lib.NidxGpuError):
-            idx.search(q, 100, _lib.METHOD_BRUTE_FORCE)          # 100 x 4 vectors per paragraph > 256
+            idx.search(q, 200, _lib.METHOD_BRUTE_FORCE)          # 200 x 4 > 512
     finally:
         idx.close()
     oseg = orc.Segment(x, similarity=sim, vec_paragraph=pov, para_first_vec=first, para_num_vec=num, alive=alive, n_paragraphs=n_para,
                        graph=orc.Hnsw.deserialize_v2(graph, edges))
     for i in range(nq):
+        check(bf100, oseg.brute_force(q[i], 100), pov, i)
         check(bf, oseg.brute_force(q[i], k), pov, i)
         check(bf_f, oseg.brute_force(q[i], k, min_score=0.3, filter_bits=alive & filt), pov, i)
         check(hn, oseg.hnsw_search(q[i], k, multi=True), pov, i)
