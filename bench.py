@@ -907,8 +907,16 @@ def bench_hnsw(a, L, dev, rank, world):
             "queries_per_s": total_q / second["elapsed"], "ms_per_step": second["elapsed"] / a.steps * 1e3,
             "recall_at_%d" % k: second["recall"], "distance_evals_per_query": second["evals"], "expansions_per_query": second["expansions"],
             "kernel_flags": second["flags"], "timed_launch_flags": second["timed_flags"], "hnsw_build_s": second["build_s"],
-            "roofline": {"achieved": second["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": second["achieved"] / HBM_PEAK_GBS,
-                         "traffic": second["traffic"], "algorithmic_bytes_per_launch": second["alg_bytes"], "kernel_ms": second["kernel_ms"]},
+            "batches_in_flight": second["nfl"],
+            "roofline": {"kernel": "hnsw_search_kernel<3,4,4,1>", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "algorithmic_bytes_per_launch": second["alg_bytes"], "traffic": second["traffic"], "traffic_source": second["traffic_src"],
+                         # this corpus is bandwidth-bound: two launches in flight share the HBM, so each lasts about twice as long and
+                         # the per-launch figure halves without anything being slower; one launch at a time is the kernel's own rate
+                         "one_launch_at_a_time": {"kernel_ms": second["alone_ms"], "achieved": second["alg_bytes"] / (second["alone_ms"] * 1e-3) / 1e9,
+                                                  "frac": second["alg_bytes"] / (second["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "while_batches_overlap": {"kernel_ms": second["kernel_ms"], "achieved": second["achieved"], "frac": second["achieved"] / HBM_PEAK_GBS},
+                         "sustained": {"achieved": second["alg_bytes"] * a.steps / second["elapsed"] / 1e9,
+                                       "frac": second["alg_bytes"] * a.steps / second["elapsed"] / 1e9 / HBM_PEAK_GBS}},
             "note": "uniform random 768-d unit vectors have no neighbourhood structure (all pairwise cosines within +-0.1): ef = 30 cannot "
                     "find the exact top-10 among near-ties, for the reference either; it is the worst-case access pattern (every neighbour unvisited)",
         }

@@ -1,23 +1,25 @@
 #!/bin/bash
-# Re-measures the headline workload on the GPU box and writes everything under gpurun_out/final/:
-#   bench line (default bench.py), rocprofv3 --kernel-trace --stats summary, and the two PMC passes (FETCH_SIZE, WRITE_SIZE)
-# of the same command.  Usage (from the repo root on the GPU box): bash scripts/refresh_profiles.sh
+# Round 2: re-measures the headline workload (bench.py default: 10 M x 768 cosine HNSW, batch 1024) on the GPU box and writes under
+# gpurun_out/final/: the bench line, and per corpus (clustered = the timed one, uniform = the second figure) the rocprofv3
+# --kernel-trace --stats summary plus the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes, --kernel-trace only) of the same
+# command with the side legs switched off.  scripts/make_pmc_traffic.py turns the summaries into profiles/r02_pmc_traffic.json.
+# Usage (repo root, GPU box): bash scripts/refresh_profiles.sh [n_vectors]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+N=${1:-10000000}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
-cd $ROOT
-python bench.py > $OUT/bench_hnsw_1m.json 2> $OUT/bench_hnsw_1m.err
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --cpu-queries 0 --recall-queries 0 --clustered-n 0"
-rocprofv3 --kernel-trace --stats -d $OUT/prof_trace -- $BENCH > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch -- $BENCH > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write -- $BENCH > /dev/null 2>&1
-cd $ROOT
-for p in trace fetch write; do
-  db=$(ls $OUT/prof_$p/*/*.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python scripts/prof_summary.py $db "$p pass: $BENCH" > $OUT/summary_$p.txt 2>&1
+for corpus in clustered uniform; do
+  BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0"
+  PMCBENCH="$BENCH --batches-in-flight 1"   # counter collection serialises dispatches; concurrent streams crash rocprofv3 --pmc on this box
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace_$corpus -- $BENCH > $OUT/bench_${corpus}_profiled.json 2> /dev/null
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch_$corpus -- $PMCBENCH > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write_$corpus -- $PMCBENCH > /dev/null 2>&1
+  for p in trace fetch write; do
+    db=$(ls $OUT/prof_${p}_$corpus/*/*.db 2>/dev/null | head -1)
+    [ -n "$db" ] && python $ROOT/scripts/prof_summary.py $db "$corpus corpus, $p pass: $BENCH" > $OUT/summary_${p}_$corpus.txt 2>&1
+    rm -rf $OUT/prof_${p}_$corpus
+  done
 done
-rm -rf $OUT/prof_trace $OUT/prof_fetch $OUT/prof_write
-tail -c 600 $OUT/bench_hnsw_1m.json
-grep -h "hnsw_search_kernel" $OUT/summary_*.txt | cut -c1-200
+grep -h "hnsw_search_kernel" $OUT/summary_*.txt | cut -c1-220
