@@ -685,34 +685,29 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
 
 
 def single_query_latency(a, L, h, queries):
-    """nidx_gpu_vector_search_one from 64 blocking threads (ctypes releases the GIL during the call)."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    """nidx_gpu_vector_search_one from 64 native threads (nidx_gpu_diag_single_query_latency: the reference's one blocking
+    thread per request), coalesced into batched launches by csrc/coalescer.cpp."""
     from nucliadb_amd import _lib
 
     d, k = a.dim, a.k
     threads = 64
-    calls = min(a.single_query_calls, queries.shape[0])
+    calls = max(threads, a.single_query_calls)
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
-
-    def one(i):
-        ov, os_, oseg, opar = np.zeros(k, np.uint32), np.zeros(k, np.float32), np.zeros(k, np.uint32), np.zeros(k, np.uint32)
-        cnt = C.c_uint32(0)
-        t = time.perf_counter()
-        _lib.check(L.nidx_gpu_vector_search_one(h, queries[i].ctypes.data, d, C.byref(p), oseg.ctypes.data, opar.ctypes.data,
-                                                ov.ctypes.data, os_.ctypes.data, C.byref(cnt)))
-        return time.perf_counter() - t
-
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, range(min(threads, calls))))
-        t0 = time.perf_counter()
-        lat = np.array(list(ex.map(one, range(calls))))
-        dt = time.perf_counter() - t0
-    b, q = C.c_uint64(0), C.c_uint64(0)
-    L.nidx_gpu_vector_coalescer_stats(h, C.byref(b), C.byref(q))
-    return {"threads": threads, "calls": calls, "p50_ms": float(np.percentile(lat, 50) * 1e3), "p99_ms": float(np.percentile(lat, 99) * 1e3),
-            "queries_per_s": calls / dt, "queries_per_launch": (q.value / b.value) if b.value else None,
-            "note": "callers are Python threads: the figure includes ctypes + GIL hand-over per call"}
+    q = np.ascontiguousarray(queries, np.float32)
+    out = {}
+    for th in (1, threads):
+        n = calls if th > 1 else min(calls, 256)
+        lat = np.zeros(n, np.float32)
+        el = C.c_double(0)
+        b0, q0 = C.c_uint64(0), C.c_uint64(0)
+        L.nidx_gpu_vector_coalescer_stats(h, C.byref(b0), C.byref(q0))
+        _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, n, lat.ctypes.data, C.byref(el)))
+        b1, q1 = C.c_uint64(0), C.c_uint64(0)
+        L.nidx_gpu_vector_coalescer_stats(h, C.byref(b1), C.byref(q1))
+        out["threads_%d" % th] = {"calls": n, "p50_ms": float(np.percentile(lat, 50) / 1e3), "p99_ms": float(np.percentile(lat, 99) / 1e3),
+                                  "queries_per_s": n / el.value,
+                                  "queries_per_launch": (q1.value - q0.value) / max(1, b1.value - b0.value)}
+    return out
 
 
 def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
@@ -1057,18 +1052,16 @@ def bench_hybrid(a, L, dev, rank, world):
 
     n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
     n_docs, vocab, kb = n, a.vocab, 20
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234567890 + rank)
-    x = torch.rand((n, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
-    x /= x.norm(dim=1, keepdim=True)
-    x_host = x.cpu().numpy()
-    del x
-    torch.cuda.empty_cache()
+    kind = "uniform" if a.corpus == "uniform" else "clustered"
+    x = gen_corpus(kind, n, d, dev, 1234567890 + rank)
+    n_pool = 4
+    qpool = gen_queries(kind, x, n_pool, B, d, dev, 2)
     cfg = _lib.VectorConfigC(d, 1, 0, 0)
-    cseg = _lib.VectorSegmentC(x_host.ctypes.data, d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    cseg = _lib.VectorSegmentC(x.data_ptr(), d * 4, n, None, n, None, 0, 0, None, 0, None, None)
     h = C.c_void_p()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
-    del x_host
+    del x
+    torch.cuda.empty_cache()
     t0 = time.time()
     _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
     build_s = time.time() - t0
@@ -1076,11 +1069,6 @@ def bench_hybrid(a, L, dev, rank, world):
     term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens = zipf_corpus_on_device(L, dev, n_docs, vocab, rank)
     gen_s = time.time() - t0
     searcher = Bm25Searcher.open([Bm25Segment(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)])
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(2)
-    n_pool = 4
-    qpool = torch.rand((n_pool, B, d), generator=gq, device=dev, dtype=torch.float32) * 2 - 1
-    qpool /= qpool.norm(dim=2, keepdim=True)
     rng = np.random.default_rng(2)
     prepared = []
     for _ in range(n_pool):
@@ -1138,7 +1126,7 @@ def bench_hybrid(a, L, dev, rank, world):
             "value": world * B * a.steps / elapsed, "unit": "hybrid queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "hybrid: %d x %d-dim cosine HNSW + BM25 over %d docs (vocab %d), batch=%d, RRF k=60" % (n, d, n_docs, vocab, B),
+            "config": {"workload": "hybrid: %d x %d-dim cosine HNSW (%s corpus) + BM25 over %d docs (vocab %d), batch=%d, RRF k=60" % (n, d, kind, n_docs, vocab, B),
                        "hnsw_build_s": build_s, "corpus_gen_s": gen_s, "bm25_kernel_ms": ms.value,
                        "ms_per_step_parts": {kk_: v / a.steps * 1e3 for kk_, v in t_parts.items()},
                        "note": "end to end per batch: vector search on device buffers + BM25 through the host-buffer entry point, both device "

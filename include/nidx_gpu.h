@@ -276,6 +276,13 @@ int32_t nidx_gpu_vector_segment_search_device_exact(nidx_gpu_vector_index_t *ind
 int32_t nidx_gpu_diag_gather(const float *d_rows, uint32_t n_rows, uint32_t dimension, uint32_t waves, uint32_t gathers_per_wave,
                              int32_t rows_in_flight, uint32_t repeats, float *ms_out);
 
+/* Measurement probe: `threads` native threads issue `calls` nidx_gpu_vector_search_one requests in total, back to back (query c
+ * = queries[c % n_queries]); latencies_us_out[calls] = wall time of every call, *elapsed_s_out = the whole run.  The reference's
+ * serving shape (one blocking thread per request, src/searcher/shard_search.rs:139-153) without an interpreter in the way. */
+int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries, uint32_t dimension,
+                                           const nidx_gpu_vector_search_params_t *params, uint32_t threads, uint32_t calls,
+                                           float *latencies_us_out, double *elapsed_s_out);
+
 /* One query per call, the shape of the reference's request path (one blocking thread per Search request,
  * src/searcher/shard_search.rs:139-153; one vector per request, nodereader.proto:402).  Thread safe:
  * concurrent callers with equal params are coalesced into one batched launch (window and batch size via

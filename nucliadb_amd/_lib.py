@@ -204,6 +204,8 @@ SIGNATURES = {
     "nidx_gpu_bm25_apply_deletions": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "nidx_gpu_vector_set_filter_keys": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]),
     "nidx_gpu_vector_lookup_filter_keys": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_diag_single_query_latency": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_uint32,
+                                                       C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]),
     "nidx_gpu_diag_gather": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32,
                                          C.POINTER(C.c_float)]),
     "nidx_gpu_vector_device_flags": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),

@@ -5,6 +5,10 @@
 // R rows in flight, folds what it read into one word so the loads cannot be dropped.  rows/s x row bytes is the ceiling the
 // HBM-bound roofline fraction of hnsw_search_kernel should be read against (a float4 COPY reaches 6.3 TB/s on this
 // part because half of its traffic is writes; a pure gather has no write stream).
+#include <chrono>
+#include <thread>
+#include <vector>
+
 #include "device_common.h"
 #include "host_common.h"
 #include "kernels.h"
@@ -87,5 +91,40 @@ extern "C" int32_t nidx_gpu_diag_gather(const float *d_rows, uint32_t n_rows, ui
     (void)hipEventDestroy(e1);
     NIDX_HIP(err);
     *ms_out = ms / (float)repeats;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+// The reference's request shape measured without an interpreter in the way: `threads` native threads each issue
+// nidx_gpu_vector_search_one calls back to back (one blocking thread per Search request, src/searcher/shard_search.rs:139-153);
+// the coalescer (coalescer.cpp) merges concurrent callers into batched launches.  latencies_us_out[c] = wall time of call c.
+extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries, uint32_t dimension,
+                                                      const nidx_gpu_vector_search_params_t *params, uint32_t threads, uint32_t calls,
+                                                      float *latencies_us_out, double *elapsed_s_out) try {
+    if (!index || !queries || !params || !latencies_us_out || n_queries == 0 || threads == 0 || calls == 0 || params->k == 0)
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "bad latency probe arguments");
+    std::vector<int32_t> rc(threads, NIDX_OK);
+    int dev = 0;
+    NIDX_HIP(hipGetDevice(&dev));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < threads; t++)
+        pool.emplace_back([&, t]() {
+            (void)hipSetDevice(dev);
+            const uint32_t k = params->k;
+            std::vector<uint32_t> seg(k), par(k), vec(k);
+            std::vector<float> score(k);
+            for (uint32_t c = t; c < calls; c += threads) {
+                uint32_t count = 0;
+                const auto a = std::chrono::steady_clock::now();
+                const int32_t r = nidx_gpu_vector_search_one(index, queries + (size_t)(c % n_queries) * dimension, dimension, params, seg.data(), par.data(),
+                                                             vec.data(), score.data(), &count);
+                latencies_us_out[c] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
+                if (r != NIDX_OK) { rc[t] = r; return; }
+            }
+        });
+    for (auto &th : pool) th.join();
+    if (elapsed_s_out) *elapsed_s_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t t = 0; t < threads; t++)
+        if (rc[t] != NIDX_OK) return rc[t];
     return NIDX_OK;
 } NIDX_ABI_CATCH

@@ -1,16 +1,30 @@
 #!/bin/bash
-# Every bench line + profile quoted in DESIGN.md, re-measured in one go on the GPU box (writes gpurun_out/final/).
+# Round 2: every bench.py workload once on the GPU box, each under rocprofv3 --kernel-trace --stats, summaries under gpurun_out/final/.
+# Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | others | all
+set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+PART=${1:-all}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
-cd $ROOT
-bash scripts/refresh_profiles.sh > $OUT/refresh_profiles.log 2>&1
-python bench.py --n-vectors 10000000 > $OUT/bench_hnsw_10m.json 2> $OUT/bench_hnsw_10m.err
-python bench.py --workload hybrid --n-vectors 10000000 --cpu-queries 0 > $OUT/bench_hybrid_10m.json 2> $OUT/hybrid.err
-python bench.py --workload scan --cpu-queries 0 --clustered-n 0 --steps 5 --recall-queries 0 > $OUT/bench_scan_1m.json 2>/dev/null
-python bench.py --workload rabitq > $OUT/bench_rabitq_1m.json 2> $OUT/rabitq.err
-python bench.py --workload bf16 --n-vectors 12500000 --dim 1024 --clustered-n 0 --steps 10 --recall-queries 256 --cpu-queries 64 > $OUT/bench_bf16_12m5x1024.json 2> $OUT/bf16.err
-python bench.py --workload bf16 --clustered-n 0 --steps 10 --recall-queries 256 --cpu-queries 0 > $OUT/bench_bf16_1m.json 2>> $OUT/bf16.err
-python bench.py --workload bm25 > $OUT/bench_bm25_10m.json 2> $OUT/bm25.err
-for f in $OUT/bench_*.json; do echo "$(basename $f): $(tail -1 $f | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], (d.get("roofline") or {}).get("frac"))')"; done
-grep -h "hnsw_search_kernel" $OUT/summary_*.txt | cut -c1-160
+cd /tmp && export TMPDIR=/tmp
+prof() {  # name, bench args...
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$name -- python $ROOT/bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  local db=$(ls $OUT/prof_$name/*/*.db 2>/dev/null | head -1)
+  [ -n "$db" ] && python $ROOT/scripts/prof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py $*" > $OUT/kernel_stats_$name.txt 2>&1
+  rm -rf $OUT/prof_$name
+  tail -c 400 $OUT/bench_$name.json; echo
+}
+if [ "$PART" = headline ] || [ "$PART" = all ]; then
+  timeout 1500 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  tail -c 300 $OUT/bench_default.json; echo
+  bash $ROOT/scripts/refresh_profiles.sh
+fi
+if [ "$PART" = others ] || [ "$PART" = all ]; then
+  prof bm25 --workload bm25 --steps 10 --warmup 2
+  prof hybrid --workload hybrid --steps 10 --warmup 2
+  prof scan_1m --workload scan --n-vectors 1000000 --steps 3 --warmup 1
+  prof mfma_1m --workload mfma --n-vectors 1000000 --steps 5 --warmup 1
+  prof bf16_12m5x1024 --workload bf16 --n-vectors 12500000 --dim 1024 --steps 5 --warmup 1 --cpu-queries 0
+  prof rabitq_1m --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1
+fi
