@@ -14,6 +14,7 @@ for corpus in clustered uniform; do
   BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0"
   # the PMC passes load the graph the trace pass built (rocprofv3 --pmc segfaults over the thousands of dispatches of a 10 M build)
   BENCH="$BENCH --graph-cache /tmp/nidx_graphs"
+  [ $corpus = uniform ] && BENCH="$BENCH --batches-in-flight 1"   # the default run times this corpus one launch at a time
   PMCBENCH="$BENCH --batches-in-flight 1"   # counter collection serialises dispatches; concurrent streams crash rocprofv3 --pmc on this box
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace_$corpus -- $BENCH > $OUT/bench_${corpus}_profiled.json 2> /dev/null
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch_$corpus -- $PMCBENCH > /dev/null 2>&1
