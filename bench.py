@@ -205,7 +205,7 @@ def main():
     # launch of B queries; per-launch durations (kernel_ms, the roofline's denominator) are measured on the launch's own stream.
     # (the second corpus is bandwidth-bound: overlapping its launches buys ~10 % and doubles every launch's duration, so it runs
     # one launch at a time and its per-launch figures read directly)
-    nfl = max(1, a.batches_in_flight) if (headline and not do_exchange) else 1
+    nfl = 1   # (the exact-scan workloads are one launch at a time)
     fl_streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else None
     fl_out = [(torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count)) for _ in range(nfl)] if nfl > 1 else None
 
