@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Batches in flight live on separate HIP streams; with the runtime's default of 4 hardware queues two of them can land on one
+# queue and serialise (measured: 3 in flight = 2.2 M queries/s with 4 queues, 3.5 M with 8).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -50,7 +54,7 @@ def parse():
                    help="cpu_baseline: also time the oracle over segments of this many records + Fssc (the reference's own regime, src/settings.rs:258-278); 0 = skip")
     p.add_argument("--ref-build-n", type=int, default=50_000,
                    help="recall of the oracle's sequential HnswBuilder vs the device build on a clustered segment of this size (0 = skip)")
-    p.add_argument("--batches-in-flight", type=int, default=2,
+    p.add_argument("--batches-in-flight", type=int, default=3,
                    help="hnsw: consecutive batches are launched on this many streams in turn, so the walk-length tail of one batch (a launch "
                         "lasts as long as its longest walk) overlaps the body of the next; 1 = strictly one launch at a time")
     p.add_argument("--graph-cache", default="",
@@ -252,6 +256,7 @@ def main():
     if do_exchange and a.steps > 0:
         # the overlapped pipeline must give what a plain search -> exchange of the same batch gives
         i_last = a.warmup + a.steps - 1
+        torch.cuda.synchronize()
         got = [t.clone() for t in last_merged[0]]
         search(qpool[i_last % n_pool], out=out_sets[0])
         torch.cuda.synchronize()
@@ -508,57 +513,45 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # With more than one rank a step is search + exchange.  The exchange (three small all-gathers over xGMI + the merge kernel) is
-    # latency-bound and needs none of the compute units, so it runs on a side stream from one of two result-buffer sets while
-    # the main stream already searches the next batch into the other set: search i + 1 overlaps exchange i; a buffer set is
-    # searched into again only after its exchange has finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
-    do_exchange = world > 1 or os.environ.get("NIDX_BENCH_FORCE_EXCHANGE") == "1"
-    main_stream = torch.cuda.current_stream()
-    side_stream = torch.cuda.Stream() if do_exchange else None
-    out_sets = [(out_vec, out_score, out_count),
-                (torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count))] if do_exchange else None
-    ev_searched = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_exchanged = [torch.cuda.Event(), torch.cuda.Event()]
-    last_merged = [None]
-
     # One launch lasts as long as its longest walk, and on clustered data one query in a thousand walks three times the median:
-    # with a single stream the whole GPU waits for it.  Consecutive batches therefore go to `nfl` streams in turn (each with its
-    # own result buffers): the workgroups of batch i + 1 take the slots batch i's finished walks free.  Every batch is still one
+    # with a single stream the whole GPU waits for it.  Consecutive batches therefore go to `nfl` streams in turn, each batch into
+    # its own result buffers: the workgroups of batch i + 1 take the slots batch i's finished walks free.  Every batch is still one
     # launch of B queries; per-launch durations (kernel_ms, the roofline's denominator) are measured on the launch's own stream.
     # (the second corpus is bandwidth-bound: overlapping its launches buys ~10 % and doubles every launch's duration, so it runs
     # one launch at a time and its per-launch figures read directly)
-    nfl = max(1, a.batches_in_flight) if (headline and not do_exchange) else 1
-    fl_streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else None
-    fl_out = [(torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count)) for _ in range(nfl)] if nfl > 1 else None
+    # With more than one rank a step is search + exchange.  The exchange (three small all-gathers over xGMI + the merge kernel) is
+    # latency-bound and needs none of the compute units, so it runs on a side stream, in step order on every rank, while the
+    # search streams already work on the next batches; a result-buffer set is searched into again only after its exchange has
+    # finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
+    do_exchange = world > 1 or os.environ.get("NIDX_BENCH_FORCE_EXCHANGE") == "1"
+    nfl = max(1, a.batches_in_flight) if headline else 1
+    main_stream = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else [main_stream]
+    side_stream = torch.cuda.Stream() if do_exchange else None
+    n_sets = nfl + 1 if do_exchange else nfl
+    out_sets = [(out_vec, out_score, out_count)] + [(torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count))
+                                                    for _ in range(max(n_sets, 2) - 1)]
+    n_sets = len(out_sets)
+    ev_searched = [torch.cuda.Event() for _ in range(n_sets)]
+    ev_exchanged = [torch.cuda.Event() for _ in range(n_sets)]
+    last_merged = [None]
 
     def step(i, e0=None, e1=None):
-        if not do_exchange:
-            if nfl > 1:
-                st_ = fl_streams[i % nfl]
-                if e0 is not None:
-                    e0.record(st_)
-                search(qpool[i % n_pool], out=fl_out[i % nfl], on=st_.cuda_stream)
-                if e1 is not None:
-                    e1.record(st_)
-                return
-            if e0 is not None:
-                e0.record()
-            search(qpool[i % n_pool])
-            if e1 is not None:
-                e1.record()
-            return
-        b = i & 1
-        main_stream.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
+        b = i % n_sets
+        st_ = streams[i % nfl]
+        if do_exchange:
+            st_.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
         if e0 is not None:
-            e0.record(main_stream)
-        search(qpool[i % n_pool], out=out_sets[b])
+            e0.record(st_)
+        search(qpool[i % n_pool], out=out_sets[b], on=st_.cuda_stream)
         if e1 is not None:
-            e1.record(main_stream)
-        ev_searched[b].record(main_stream)
-        with torch.cuda.stream(side_stream):
-            side_stream.wait_event(ev_searched[b])
-            last_merged[0] = exchange(out_sets[b])
-            ev_exchanged[b].record(side_stream)
+            e1.record(st_)
+        if do_exchange:
+            ev_searched[b].record(st_)
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(ev_searched[b])
+                last_merged[0] = exchange(out_sets[b])
+                ev_exchanged[b].record(side_stream)
 
     for i in range(a.warmup):
         step(i)
@@ -579,6 +572,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     if do_exchange and a.steps > 0:
         # the overlapped pipeline must give what a plain search -> exchange of the same batch gives
         i_last = a.warmup + a.steps - 1
+        torch.cuda.synchronize()
         got = [t.clone() for t in last_merged[0]]
         search(qpool[i_last % n_pool], out=out_sets[0])
         torch.cuda.synchronize()
