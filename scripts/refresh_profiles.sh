@@ -16,7 +16,13 @@ for corpus in clustered uniform; do
   BENCH="$BENCH --graph-cache /tmp/nidx_graphs"
   [ $corpus = uniform ] && BENCH="$BENCH --batches-in-flight 1"   # the default run times this corpus one launch at a time
   PMCBENCH="$BENCH --batches-in-flight 1"   # counter collection serialises dispatches; concurrent streams crash rocprofv3 --pmc on this box
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace_$corpus -- $BENCH > $OUT/bench_${corpus}_profiled.json 2> /dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace_$corpus -- $PMCBENCH > $OUT/bench_${corpus}_profiled.json 2> /dev/null
+  if [ $corpus = clustered ]; then   # and with the default number of batches in flight (durations then overlap)
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace3_$corpus -- $BENCH > $OUT/bench_${corpus}_profiled_in_flight.json 2> /dev/null
+    db=$(ls $OUT/prof_trace3_$corpus/*/*.db 2>/dev/null | head -1)
+    [ -n "$db" ] && python $ROOT/scripts/prof_summary.py $db "$corpus corpus, trace pass with the default batches in flight: $BENCH" > $OUT/summary_trace_in_flight_$corpus.txt 2>&1
+    rm -rf $OUT/prof_trace3_$corpus
+  fi
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_fetch_$corpus -- $PMCBENCH > /dev/null 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write_$corpus -- $PMCBENCH > /dev/null 2>&1
   for p in trace fetch write; do
