@@ -468,7 +468,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     open_s = time.time() - t0
     del cached
     # the host copy feeds the oracle legs (rank 0 of the headline corpus only): the product never reads it
-    need_host = rank == 0 and headline and (a.parity_queries > 0 or a.cpu_queries > 0 or a.scan_check_queries > 0)
+    need_host = rank == 0 and headline and (a.parity_queries > 0 or a.cpu_queries > 0 or a.scan_check_queries > 0 or a.ref_build_n > 0)
     x_host = x.cpu().numpy() if need_host else None
     del x
     torch.cuda.empty_cache()
