@@ -46,6 +46,18 @@ static bool same_params(const nidx_gpu_vector_search_params_t &a, const nidx_gpu
 int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
                                 uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
     Coalescer &c = *coalescer;  // created with the handle (nidx_gpu_vector_open)
+    {
+        // staging for a full batch, once (not under the coalescer's lock: it takes the index's)
+        uint32_t mb;
+        {
+            std::lock_guard<std::mutex> g(c.mu);
+            mb = c.max_batch;
+        }
+        if (mb > reserved_nq || p.k > reserved_k) {
+            const int32_t rc = reserve_search(mb, p.k);
+            if (rc != NIDX_OK) return rc;
+        }
+    }
     OneRequest req{query, p, out_segment, out_paragraph, out_vector, out_score, out_count};
     std::unique_lock<std::mutex> lk(c.mu);
     // everything that can fail for lack of memory happens before the request is visible to other callers: `req` lives on this

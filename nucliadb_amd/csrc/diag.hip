@@ -5,6 +5,7 @@
 // R rows in flight, folds what it read into one word so the loads cannot be dropped.  rows/s x row bytes is the ceiling the
 // HBM-bound roofline fraction of hnsw_search_kernel should be read against (a float4 COPY reaches 6.3 TB/s on this
 // part because half of its traffic is writes; a pure gather has no write stream).
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -105,7 +106,10 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
     std::vector<int32_t> rc(threads, NIDX_OK);
     int dev = 0;
     NIDX_HIP(hipGetDevice(&dev));
-    const auto t0 = std::chrono::steady_clock::now();
+    // a serving thread lives long: its first HIP call (per-thread runtime state, tens of ms when 64 threads start at once) is not
+    // part of a request's latency — every thread makes one untimed call, then all start the timed calls together
+    std::atomic<uint32_t> ready{0};
+    std::chrono::steady_clock::time_point t0;
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < threads; t++)
         pool.emplace_back([&, t]() {
@@ -113,11 +117,16 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
             const uint32_t k = params->k;
             std::vector<uint32_t> seg(k), par(k), vec(k);
             std::vector<float> score(k);
+            uint32_t count = 0;
+            int32_t r = nidx_gpu_vector_search_one(index, queries + (size_t)(t % n_queries) * dimension, dimension, params, seg.data(), par.data(),
+                                                   vec.data(), score.data(), &count);
+            if (ready.fetch_add(1) + 1 == threads) t0 = std::chrono::steady_clock::now();
+            while (ready.load() < threads) std::this_thread::yield();
+            if (r != NIDX_OK) { rc[t] = r; return; }
             for (uint32_t c = t; c < calls; c += threads) {
-                uint32_t count = 0;
                 const auto a = std::chrono::steady_clock::now();
-                const int32_t r = nidx_gpu_vector_search_one(index, queries + (size_t)(c % n_queries) * dimension, dimension, params, seg.data(), par.data(),
-                                                             vec.data(), score.data(), &count);
+                r = nidx_gpu_vector_search_one(index, queries + (size_t)(c % n_queries) * dimension, dimension, params, seg.data(), par.data(),
+                                               vec.data(), score.data(), &count);
                 latencies_us_out[c] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
                 if (r != NIDX_OK) { rc[t] = r; return; }
             }

@@ -53,8 +53,15 @@ struct DevBuf {
         else p = nullptr;
         return e;
     }
-    // grow-only scratch
-    hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(n); }
+    // grow-only scratch; small requests are rounded up to a power of two so that a serving loop whose batch sizes wander (the
+    // coalescer's batches of 1..64 queries) reallocates a handful of times, not on every new maximum
+    static size_t grow_size(size_t n) {
+        if (n > ((size_t)256 << 20)) return n;
+        size_t p = 4096;
+        while (p < n) p <<= 1;
+        return p;
+    }
+    hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(grow_size(n)); }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -74,6 +81,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         bytes = 0;
+        n = DevBuf::grow_size(n);   // pinning is slow (tens of ms): grow in powers of two
         hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
         if (e == hipSuccess) bytes = n;
         else p = nullptr;

@@ -831,6 +831,23 @@ int32_t VectorIndex::quantize(uint32_t si) {
     return NIDX_OK;
 }
 
+int32_t VectorIndex::reserve_search(uint32_t nq_max, uint32_t k) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (nq_max <= reserved_nq && k <= reserved_k) return NIDX_OK;
+    NIDX_HIP(hipSetDevice(device));
+    nq_max = std::max(nq_max, reserved_nq);
+    k = std::max(k, reserved_k);
+    const uint32_t dp = (cfg.dimension + 3u) & ~3u;
+    NIDX_HIP(pin_in.reserve((size_t)nq_max * dp * 4));
+    NIDX_HIP(scratch_queries.reserve((size_t)nq_max * dp * 4));
+    NIDX_HIP(scratch_out_block.reserve(out_block_words(nq_max, k) * 4));
+    NIDX_HIP(pin_out.reserve(out_block_words(nq_max, k) * 4));
+    NIDX_HIP(scratch_stats.reserve((size_t)nq_max * NIDX_STAT_STRIDE * 4));
+    reserved_nq = nq_max;
+    reserved_k = k;
+    return NIDX_OK;
+}
+
 int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
                                  const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
                                  uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,

@@ -134,6 +134,10 @@ struct VectorIndex {
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed, bool extend = false);
     // request coalescing for single-query callers (coalescer.cpp)
     std::shared_ptr<Coalescer> coalescer = make_coalescer();
+    // staging for batches of up to nq_max queries with pages of k hits, taken once: pinning memory costs tens of ms, which a
+    // serving loop must not meet the first time a larger batch than any before comes together
+    int32_t reserve_search(uint32_t nq_max, uint32_t k);
+    uint32_t reserved_nq = 0, reserved_k = 0;
     int32_t search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
     void coalescer_stats(uint64_t &batches, uint64_t &queries);
