@@ -526,6 +526,8 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
     const uint64_t after_addr = has_after ? a.after[q].docaddr : 0;
     const int mslot = a.match_slot ? a.match_slot[q] : -1;
     uint32_t *mbits = mslot >= 0 ? a.match_bits + (size_t)mslot * a.match_words : nullptr;
+    const bool extras = a.alive != nullptr || mbits != nullptr || a.order_key != nullptr || has_after;
+    uint32_t matched_l = 0;   // documents this lane folded that matched (Count collector), summed once at the end
 
     for (;;) {
         const unsigned long long act_m = __ballot(lane < C && cdoc_l < hi_doc);
@@ -617,28 +619,35 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
             p_score[m] = mode == 2 ? w : bm;   // ConstScorer(boost)
         }
         const unsigned long long cy_b = clock64();
-        // ---- probe ----
+        // ---- probe: every row's first CAS is issued before any result is looked at; collisions (another document in the slot)
+        //      are the rare case and go through one loop afterwards ----
         uint32_t p_slot[R];
-        uint32_t owned = 0;
+        uint32_t owned = 0, pend = 0;
         {
             uint32_t old[R];
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 p_slot[m] = __umulhi(p_doc[m] * 2654435761u, T);
                 const bool ok = (ok_m[m] >> lane) & 1ull;
-                old[m] = ok ? atomicCAS(&t_key[p_slot[m]], BM25_EMPTY, p_doc[m]) : BM25_EMPTY;
+                old[m] = ok ? atomicCAS(&t_key[p_slot[m]], BM25_EMPTY, p_doc[m]) : p_doc[m];
             }
 #pragma unroll
             for (int m = 0; m < R; m++) {
                 const bool ok = (ok_m[m] >> lane) & 1ull;
-                if (!ok) continue;
-                if (old[m] == BM25_EMPTY) { owned |= 1u << m; continue; }
-                uint32_t o = old[m], h = p_slot[m];
-                while (o != p_doc[m]) {
+                owned |= (ok && old[m] == BM25_EMPTY) ? 1u << m : 0u;
+                pend |= (old[m] != BM25_EMPTY && old[m] != p_doc[m]) ? 1u << m : 0u;
+            }
+        }
+        if (__ballot(pend != 0)) {
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                if (!(pend & (1u << m))) continue;
+                uint32_t h = p_slot[m], o;
+                do {   // linear probing (the table is at most 0.8 full)
                     h = h + 1 == T ? 0 : h + 1;
                     o = atomicCAS(&t_key[h], BM25_EMPTY, p_doc[m]);
-                    if (o == BM25_EMPTY) { owned |= 1u << m; break; }
-                }
+                } while (o != BM25_EMPTY && o != p_doc[m]);
+                if (o == BM25_EMPTY) owned |= 1u << m;
                 p_slot[m] = h;
             }
         }
@@ -653,7 +662,11 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
             }
         }
         const unsigned long long cy_c = clock64();
-        // ---- fold ----
+        // ---- fold: every lane finishes the documents it owns (boolean structure on the hit mask, then the optional alive /
+        //      facet / order / cursor steps) and keeps its best key; matches are counted per lane and summed once per item; the
+        //      top-k list is only touched when some lane holds a key above the k-th (after the list has warmed up: rarely) ----
+        uint64_t p_ck[R];
+        uint64_t best_l = NIDX_EMPTY_KEY;
 #pragma unroll
         for (int m = 0; m < R; m++) {
             bool ok = false;
@@ -665,32 +678,42 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
                 ok = (v.y & must_m) == must_m && (v.y & not_m) == 0 && (any_required || (v.y & should_m) != 0);
                 for (int g = 0; g < n_groups; g++)
                     if ((v.y & s_group[g]) == 0) ok = false;
-                if (ok && a.alive) ok = bit_test(a.alive, d);
-                if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
-                if (ok && a.order_key) {
-                    const uint32_t r = a.order_key[d];
-                    ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
-                } else if (ok) {
-                    float s = __builtin_bit_cast(float, v.x);
-                    if (has_after) {
-                        uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
-                        int32_t sk = total_key(s);
-                        bool after = sk < after_key || (sk == after_key && (after_tie == 0 || (after_tie == 1 && addr > after_addr)));
-                        if (!after) s = -INFINITY;
+                if (extras) {   // wave-uniform: alive bitset, facet bitset, order by a fast field, search-after cursor
+                    if (ok && a.alive) ok = bit_test(a.alive, d);
+                    if (ok && mbits) atomicOr(&mbits[d >> 5], 1u << (d & 31));
+                }
+                if (ok) {
+                    if (extras && a.order_key) {
+                        const uint32_t r = a.order_key[d];
+                        ck = ((uint64_t)(a.order_desc ? r : ~r) << 32) | (uint64_t)(~d);
+                    } else {
+                        float s = __builtin_bit_cast(float, v.x);
+                        if (extras && has_after) {
+                            uint64_t addr = ((uint64_t)a.segment_ord << 32) | d;
+                            int32_t sk = total_key(s);
+                            bool after = sk < after_key || (sk == after_key && (after_tie == 0 || (after_tie == 1 && addr > after_addr)));
+                            if (!after) s = -INFINITY;
+                        }
+                        ck = rank_key(s, d);
                     }
-                    ck = rank_key(s, d);
                 }
                 t_key[i] = BM25_EMPTY;
                 t_val[i] = make_uint2(0u, 0u);
             }
-            const unsigned long long okm = __ballot(ok);
-            total += (uint32_t)__popcll(okm);
-            unsigned long long mm = __ballot(ok && ck > kth);
-            while (mm) {
-                const int src = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const uint64_t nk = lane_bcast_u64(ck, src);
-                if (nk > kth) kth = top.insert_kth(nk, k, lane);
+            matched_l += ok ? 1u : 0u;
+            p_ck[m] = ck;
+            best_l = ck > best_l ? ck : best_l;
+        }
+        if (__ballot(best_l > kth)) {
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                unsigned long long mm = __ballot(p_ck[m] > kth);
+                while (mm) {
+                    const int src = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const uint64_t nk = lane_bcast_u64(p_ck[m], src);
+                    if (nk > kth) kth = top.insert_kth(nk, k, lane);
+                }
             }
         }
         cy_load += cy_b - cy_a;
@@ -715,6 +738,7 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
         cnt += (uint32_t)__popcll(__ballot(valid));
         if (e < k) a.out_key[(size_t)item * k + e] = valid ? key : NIDX_EMPTY_KEY;
     }
+    total = wave_sum_u32(matched_l);
     if (lane == 0) {
         a.out_count[item] = cnt;
         a.out_total[item] = total;
