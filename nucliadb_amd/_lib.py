@@ -268,6 +268,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP/HSA runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and asks for them by
+    file name, so when libnidx_gpu.so (linked against /opt/rocm's libamdhip64.so.7) is loaded first, a later `import torch`
+    maps a second runtime whose hsa_init finds no device ("No HIP GPUs are available").  The other order shares one
+    runtime, because torch's copy carries the soname libnidx_gpu.so asks for.  So: when torch is installed (not necessarily
+    imported), map its runtime first.  Processes without PyTorch (the Rust host) are not affected."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Loads libnidx_gpu.so (once).  Raises ImportError when it has not been built."""
     global _lib
@@ -277,6 +296,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        _share_torch_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -8,6 +8,7 @@
 // calling nidx_gpu_vector_search with a batch of one (the kernels are per-query deterministic).
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -31,7 +32,11 @@ struct OneRequest {
 
 struct Coalescer {
     std::mutex mu;
-    std::condition_variable cv;
+    // Two condition variables, so that an arriving request wakes at most the leader.  With a single one every arrival woke every
+    // parked caller (each re-takes the mutex to find nothing to do): 64 callers arriving behind a running batch are ~4 000 mutex
+    // hand-overs, and the leader coming back from the GPU queued behind them for 25-75 ms (measured: the p99 of 64 callers).
+    std::condition_variable cv_leader;  // the gathering leader waits here for arrivals
+    std::condition_variable cv_done;    // everyone else waits here for a batch to be handed out
     std::deque<OneRequest *> pending;
     bool leader_active = false;
     uint64_t n_batches = 0, n_queries = 0;
@@ -59,22 +64,29 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         }
     }
     OneRequest req{query, p, out_segment, out_paragraph, out_vector, out_score, out_count};
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto t_in = std::chrono::steady_clock::now();
+    auto t_lead = t_in, t_gathered = t_in, t_searched = t_in, t_posted = t_in;
+    uint32_t led = 0;
     std::unique_lock<std::mutex> lk(c.mu);
     // everything that can fail for lack of memory happens before the request is visible to other callers: `req` lives on this
     // stack frame, and a leader that unwinds would strand its followers
     std::vector<OneRequest *> batch;
     batch.reserve(c.max_batch);
     c.pending.push_back(&req);
-    c.cv.notify_all();
+    if (c.leader_active) c.cv_leader.notify_one();
     while (!req.done) {
         if (c.leader_active) {
-            c.cv.wait(lk);
+            c.cv_done.wait(lk);
             continue;
         }
         // become the leader: gather a batch of requests that share this request's parameters
         c.leader_active = true;
+        t_lead = std::chrono::steady_clock::now();
         auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(c.window_us);
-        while (c.pending.size() < c.max_batch && c.cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        while (c.pending.size() < c.max_batch && c.cv_leader.wait_until(lk, deadline) != std::cv_status::timeout) {
         }
         const nidx_gpu_vector_search_params_t lead = c.pending.front()->params;
         const size_t room = std::min<size_t>(c.max_batch, batch.capacity());
@@ -88,7 +100,9 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
             }
         }
         lk.unlock();
+        t_gathered = std::chrono::steady_clock::now();
         const uint32_t B = (uint32_t)batch.size(), k = lead.k, d = cfg.dimension;
+        led = B;
         const size_t kk = std::max<uint32_t>(k, 1);
         std::vector<uint32_t> seg, par, vec, cnt;
         std::vector<float> q, sc;
@@ -105,6 +119,7 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         }
         char err[512] = {0};
         if (rc != NIDX_OK) nidx_gpu_last_error(err, sizeof(err));
+        t_searched = std::chrono::steady_clock::now();
         lk.lock();
         for (uint32_t i = 0; i < B; i++) {
             OneRequest *r = batch[i];
@@ -124,7 +139,14 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         c.n_batches++;
         c.n_queries += B;
         c.leader_active = false;
-        c.cv.notify_all();
+        c.cv_done.notify_all();
+        t_posted = std::chrono::steady_clock::now();
+    }
+    if (trace_slow_us() > 0) {
+        const auto t_out = std::chrono::steady_clock::now();
+        if (us(t_in, t_out) > trace_slow_us())
+            fprintf(stderr, "[nidx_gpu slow search_one] total %.0f us: led a batch of %u (0 = follower only); until leader %.0f, gather %.0f, search %.0f, hand-out %.0f, after %.0f\n",
+                    us(t_in, t_out), led, us(t_in, t_lead), us(t_lead, t_gathered), us(t_gathered, t_searched), us(t_searched, t_posted), us(t_posted, t_out));
     }
     if (req.rc != NIDX_OK) set_error("%s", req.error);
     return req.rc;

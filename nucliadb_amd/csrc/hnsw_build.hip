@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
     SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
     const int lane = threadIdx.x & 63;
-    const bool ctl = (threadIdx.x >> 6) == 0;
+    const bool ctl = (nidx_tid() >> 6) == 0;
     const uint32_t bi = blockIdx.x;
     const uint32_t x = a.batch_start + bi;
     const bool cosine = a.seg.similarity == 1;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
     SearchCounters st = {0, 0, 0, 0, 0, 0, 0};
     WaveTopK<2> res;
     res.init();
-    if (threadIdx.x == 0) {
+    if (nidx_tid() == 0) {
         sh.eps[0] = a.g.ep_node;
         sh.ctrl[2] = 1;
     }

@@ -69,9 +69,13 @@ __device__ inline float score_from_sums(float ab, float xx, float qq, double sqr
     return 1.0f - (float)dist;
 }
 
+// Virtual thread id: the wave roles rotate with the workgroup index so that the controller waves (virtual wave 0) of the
+// workgroups sharing a CU do not all sit on the same SIMD.  Lanes keep their position.
+__device__ inline uint32_t nidx_tid() { return (threadIdx.x + ((blockIdx.x & 3u) << 6)) & (blockDim.x - 1u); }
+
 // ---- visited set ------------------------------------------------------------------------------
 __device__ inline void vis_clear(uint32_t *vis, uint32_t cap) {
-    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) vis[i] = NIDX_VIS_EMPTY;
+    for (uint32_t i = nidx_tid(); i < cap; i += blockDim.x) vis[i] = NIDX_VIS_EMPTY;
 }
 // true when v was not present (and is now)
 __device__ inline bool vis_insert(uint32_t *vis, uint32_t log2cap, uint32_t v) {
@@ -290,7 +294,7 @@ __device__ inline void eval_row_group(const SegDev &seg, const QueryRegs<NJ> &q,
 template <int NJ, int EVR>
 __device__ inline void eval_neighbours(const SegDev &seg, const QueryRegs<NJ> &q, NbBuf &nb, int n, bool cosine) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = nidx_tid() >> 6;
     const int nwaves = blockDim.x >> 6;
     for (int base = wave * EVR; base < n; base += nwaves * EVR) eval_row_group<NJ, EVR>(seg, q, nb, base, n, cosine, lane);
 }
@@ -329,7 +333,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
                                           const QueryRegs<NJ> &q, SearchShared &sh, uint32_t *vis, uint32_t vis_log2,
                                           WaveTopK<EFL> &res, SearchCounters &st) {
     const int lane = threadIdx.x & 63;
-    const bool ctl = (threadIdx.x >> 6) == 0;
+    const bool ctl = (nidx_tid() >> 6) == 0;
     const bool cosine = seg.similarity == 1;
     const uint32_t vis_cap = 1u << vis_log2;
     int pool_len = 0;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     __shared__ uint32_t res_para[64 * EFL];
 
     const int lane = threadIdx.x & 63;
-    const bool ctl = (threadIdx.x >> 6) == 0;
+    const bool ctl = (nidx_tid() >> 6) == 0;
     const uint32_t qi = blockIdx.x;
     const bool cosine = a.seg.similarity == 1;
     const int k = (int)a.k;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     res.init();
 
     // ---- upper layers: k = 1 (search.rs:318-324) ----
-    if (threadIdx.x == 0) {
+    if (nidx_tid() == 0) {
         sh.eps[0] = a.g.ep_node;
         sh.ctrl[2] = 1;
     }
@@ -278,7 +278,10 @@ static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
     if (ef > 256) return launch_v<NJ, 2, 2, 8>(a, waves, s);
     if (ef > 128) return launch_v<NJ, 2, 2, 4>(a, waves, s);
     if (ef > 64) return launch_v<NJ, 2, 2, 2>(a, waves, s);
-    // rows in flight per wave / register budget: tuned on MI355X (profiles/r01_tune_hnsw.txt)
+    // rows in flight per wave / register budget: tuned on MI355X (profiles/r01_tune_hnsw.txt, r02_tune_hnsw.txt).
+    // min_waves 5 / 6: <= 96 / 80 VGPRs, two rows in flight per wave; with vis_log2 <= 12 a CU then holds 5 / 6 walks.
+    if (a.min_waves >= 6) return launch_v<NJ, 2, 6, 1>(a, waves, s);
+    if (a.min_waves == 5) return launch_v<NJ, 2, 5, 1>(a, waves, s);
     if (a.eval_rows == 3) return a.min_waves >= 4 ? launch_v<NJ, 3, 4, 1>(a, waves, s) : launch_v<NJ, 3, 2, 1>(a, waves, s);
     if (a.eval_rows == 2) return a.min_waves >= 4 ? launch_v<NJ, 2, 4, 1>(a, waves, s) : launch_v<NJ, 2, 2, 1>(a, waves, s);
     return a.min_waves >= 4 ? launch_v<NJ, 4, 4, 1>(a, waves, s) : launch_v<NJ, 4, 2, 1>(a, waves, s);

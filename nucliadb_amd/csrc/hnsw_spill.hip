@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void hnsw_closest_spill_kernel(HnswSpillArgs a
     __shared__ uint32_t res_para[NIDX_K_MAX];
 
     const int lane = threadIdx.x & 63;
-    const bool ctl = (threadIdx.x >> 6) == 0;
+    const bool ctl = (nidx_tid() >> 6) == 0;
     const uint32_t slot = blockIdx.x;
     const uint32_t qi = a.query_ids[slot];
     const bool cosine = a.seg.similarity == 1;

@@ -6,10 +6,12 @@
 //             OpenSegment::_search: filter ∩ alive, use_hnsw routing      (segment.rs:496-567,626-660)
 // All arithmetic on vectors happens in the kernels; this file only moves data, routes and merges.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <mutex>
 
@@ -683,6 +685,18 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
 }
 
 // ---- one segment, exactly: launch -> (only if the flag word is set) larger visited table / HBM-resident walk ----------
+namespace {
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// NIDX_GPU_TRACE_SLOW_US=N: a host search that takes longer than N microseconds prints where the time went (stderr)
+}  // namespace
+double trace_slow_us() {
+    static const double v = [] { const char *e = getenv("NIDX_GPU_TRACE_SLOW_US"); return e ? atof(e) : 0.0; }();
+    return v;
+}
+namespace {
+thread_local double t_launch_us = 0, t_sync_us = 0;
+}  // namespace
+
 int32_t VectorIndex::segment_search_exact(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                           bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_block,
                                           uint32_t *host_block, hipStream_t st, uint32_t *n_retried) {
@@ -696,12 +710,16 @@ int32_t VectorIndex::segment_search_exact(uint32_t s, const float *d_queries, ui
     if (walks) NIDX_HIP(scratch_stats.reserve((size_t)nq * NIDX_STAT_STRIDE * 4));
     uint32_t vis_log2 = default_vis_log2;
     for (;;) {
+        const double t0 = now_us();
         NIDX_HIP(hipMemsetAsync(d_flag, 0, 4, st));
         int32_t rc = segment_search_device(s, d_queries, nq, k, min_score, with_duplicates, method, d_filter, d_vec, d_score, d_count,
                                            walks ? scratch_stats.as<uint32_t>() : nullptr, vis_log2, st, d_flag);
         if (rc != NIDX_OK) return rc;
         NIDX_HIP(hipMemcpyAsync(host_block, d_out_block, block_bytes, hipMemcpyDeviceToHost, st));
+        const double t1 = now_us();
         NIDX_HIP(hipStreamSynchronize(st));
+        t_launch_us += t1 - t0;
+        t_sync_us += now_us() - t1;
         const uint32_t flags = host_block[block_bytes / 4 - 1];
         if (!walks || flags == 0) return NIDX_OK;
         // a bounded on-chip structure overflowed for some query: find which (the per-query counters) and re-run
@@ -852,7 +870,20 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
                                  const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
                                  uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
                                  uint32_t *out_count, int32_t *out_method, uint64_t *out_matching) {
+    const double t_enter = now_us();
     std::lock_guard<std::mutex> lock(mu);
+    const double t_locked = now_us();
+    t_launch_us = t_sync_us = 0;
+    struct SlowTrace {
+        double t_enter, t_locked, t_staged = 0, t_searched = 0;
+        uint32_t nq;
+        ~SlowTrace() {
+            const double lim = trace_slow_us(), t_end = now_us();
+            if (lim > 0 && t_end - t_enter > lim)
+                fprintf(stderr, "[nidx_gpu slow search] nq=%u total=%.0f us: lock %.0f, stage %.0f, segments %.0f (launch calls %.0f, sync %.0f), fssc %.0f\n", nq,
+                        t_end - t_enter, t_locked - t_enter, t_staged - t_locked, t_searched - t_staged, t_launch_us, t_sync_us, t_end - t_searched);
+        }
+    } trace{t_enter, t_locked, 0, 0, nq};
     NIDX_HIP(hipSetDevice(device));
     const uint32_t k = p.k;
     const uint32_t d = cfg.dimension;
@@ -881,6 +912,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     NIDX_HIP(scratch_out_block.reserve(block_words * 4));
     NIDX_HIP(pin_out.reserve(block_words * 4));
 
+    trace.t_staged = now_us();
     const size_t S = segs.size();
     std::vector<std::vector<uint32_t>> hv(S), hc(S);
     std::vector<std::vector<float>> hs(S);
@@ -929,6 +961,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         hc[s].assign(blk + (size_t)nq * k * 2, blk + (size_t)nq * k * 2 + nq);
     }
 
+    trace.t_searched = now_us();
     // Fssc per query
     std::vector<Cand> buff, offered;
     for (uint32_t q = 0; q < nq; q++) {
@@ -1041,7 +1074,7 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels
     if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) { idx->eval_rows = std::max(2, std::min(4, atoi(e))); idx->shape_pinned = true; }
-    if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) { idx->min_waves = atoi(e) >= 4 ? 4 : 2; idx->shape_pinned = true; }
+    if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) { idx->min_waves = atoi(e) >= 4 ? std::min(6, atoi(e)) : 2; idx->shape_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
     NIDX_HIP(hipGetDevice(&idx->device));
@@ -1072,7 +1105,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     std::string n(name);
     if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
     else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
-    else if (n == "min_waves") { idx->min_waves = value >= 4 ? 4 : 2; idx->shape_pinned = true; }
+    else if (n == "min_waves") { idx->min_waves = value >= 4 ? std::min(6, (int)value) : 2; idx->shape_pinned = true; }
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else if (n == "coalesce_window_us") idx->coalescer_config(value, -1);
     else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value);

@@ -56,7 +56,8 @@ struct VectorSegment {
 };
 
 struct Coalescer;
-std::shared_ptr<Coalescer> make_coalescer();  // coalescer.cpp
+std::shared_ptr<Coalescer> make_coalescer();
+double trace_slow_us();  // NIDX_GPU_TRACE_SLOW_US  // coalescer.cpp
 
 struct VectorIndex {
     nidx_gpu_vector_config_t cfg{};

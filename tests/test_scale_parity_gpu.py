@@ -26,6 +26,9 @@ def torch_dev():
     import torch
 
     if not torch.cuda.is_available():
+        if _lib.device_count() > 0:  # the HIP library sees a device: torch not seeing it is a failure, not a skip
+            torch.cuda.init()
+            pytest.fail("torch.cuda.is_available() is False although libnidx_gpu sees %d device(s)" % _lib.device_count())
         pytest.skip("needs a GPU")
     return torch.device("cuda", 0)
 
