@@ -27,3 +27,9 @@ run w5_vis12_f3 3 NIDX_GPU_MIN_WAVES=5 NIDX_GPU_VIS_LOG2=12
 run w5_vis12_f4 4 NIDX_GPU_MIN_WAVES=5 NIDX_GPU_VIS_LOG2=12
 run w6_vis12_f3 3 NIDX_GPU_MIN_WAVES=6 NIDX_GPU_VIS_LOG2=12
 run w6_vis12_f5 5 NIDX_GPU_MIN_WAVES=6 NIDX_GPU_VIS_LOG2=12
+run base_f2 2 A=1
+run base_f4 4 A=1
+run rows2_f3 3 NIDX_GPU_EVAL_ROWS=2
+run rows3_f3 3 NIDX_GPU_EVAL_ROWS=3
+run wpq2_f3 3 NIDX_GPU_WAVES_PER_QUERY=2
+run wpq2_f6 6 NIDX_GPU_WAVES_PER_QUERY=2

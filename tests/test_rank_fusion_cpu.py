@@ -144,3 +144,62 @@ def test_rrf_refuses_unsorted_scored_lists_and_dedups_large_windows():
     got = {int(i): float(s) for i, s in zip(fused_ids[0, : n[0]], fused_scores[0, : n[0]])}
     assert got.keys() == want.keys() and all(abs(got[i] - want[i]) < 1e-12 for i in want)
     assert list(fused_scores[0, : n[0]]) == sorted(fused_scores[0, : n[0]], reverse=True)
+
+
+def _reference_cases():
+    import gzip
+    import json
+    import os
+
+    with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "rank_fusion_reference.json.gz"), "rt", encoding="utf-8") as f:
+        return json.load(f)["cases"]
+
+
+def test_mirror_matches_outputs_of_the_reference_module():
+    """tests/golden/rank_fusion_reference.json.gz holds outputs of the REFERENCE's rank_fusion.py itself (imported from /root/reference by
+    scripts/make_reference_golden.py) on seeded random cases: three sources, overlapping ids, ties, weights, empty sources.  The
+    mirror must give the same order, the same f64 score bits, the same score types and the same score history per hit."""
+    from nucliadb_amd.rank_fusion import BM25, ReciprocalRankFusion, ScoredItem, WeightedCombSum
+
+    cases = _reference_cases()
+    assert len(cases) >= 90
+    seen = {"rrf": 0, "wcombsum": 0, "single": 0, "both": 0}
+    for n, c in enumerate(cases):
+        if c["algorithm"] == "rrf":
+            algo = ReciprocalRankFusion(k=c["k"], window=20, weights=c["weights"], default_weight=c["default_weight"])
+        else:
+            algo = WeightedCombSum(window=20, weights=c["weights"], default_weight=c["default_weight"])
+        src = {name: [ScoredItem(pid, float.fromhex(s), kind) for pid, s, kind in hits] for name, hits in c["sources"].items()}
+        got = algo.fuse(src)
+        assert [(g.paragraph_id, float(g.score).hex(), g.score_type, [float(h).hex() for h in g.history]) for g in got] == [
+            (pid, s, kind, hist) for pid, s, kind, hist in c["expected"]], n
+        seen[c["algorithm"]] += 1
+        seen["single"] += sum(1 for h in c["sources"].values() if h) == 1
+        seen["both"] += any(e[2] == "BOTH" for e in c["expected"])
+    assert min(seen.values()) > 0, seen
+
+
+def test_native_batched_rrf_matches_outputs_of_the_reference_module():
+    """The same reference outputs against nidx_gpu_rank_fusion_rrf: every source pre-sorted by score (stable, as
+    rank_fusion.py:139-147 does) and handed over as ranked id lists."""
+    from nucliadb_amd.rank_fusion import rrf_fuse_batch
+
+    n_checked = 0
+    for n, c in enumerate(_reference_cases()):
+        if c["algorithm"] != "rrf":
+            continue
+        ids_of, lists = {}, []
+        for name in ("keyword", "semantic", "graph"):
+            hits = sorted(c["sources"][name], key=lambda h: float.fromhex(h[1]), reverse=True)
+            row = np.zeros((1, 32), np.uint64)
+            for j, (pid, _, _) in enumerate(hits):
+                row[0, j] = ids_of.setdefault(pid, len(ids_of) + 1)
+            lists.append((row, np.array([len(hits)], np.uint32), c["weights"].get(name, c["default_weight"]), None))
+        if sum(1 for l in lists if l[1][0]) < 2:
+            continue   # a single source keeps its own scores: nothing to fuse
+        got_ids, got_scores, got_counts = rrf_fuse_batch(lists, k=c["k"], window=64)
+        name_of = {v: k for k, v in ids_of.items()}
+        m = int(got_counts[0])
+        assert [(name_of[int(i)], float(s).hex()) for i, s in zip(got_ids[0, :m], got_scores[0, :m])] == [(e[0], e[1]) for e in c["expected"]], n
+        n_checked += 1
+    assert n_checked >= 20
