@@ -1200,7 +1200,8 @@ def bench_bm25(a, L, dev, rank, world):
     elapsed = time.perf_counter() - t0
     postings = float(np.sum(post_per_batch))
     k_ms = float(np.mean(kernel_ms))
-    alg = float(np.mean(post_per_batch)) * 9.0
+    bm25_traffic, bm25_traffic_src = pmc_traffic("bm25", n_docs, vocab, B, k)
+    alg = float(np.mean(post_per_batch)) * 8.0   # doc id (4 B) + the resident posting word tf | fieldnorm id << 24 (4 B)
     achieved = alg / (k_ms * 1e-3) / 1e9
     cpu = None
     if rank == 0 and a.cpu_queries > 0:
@@ -1235,7 +1236,8 @@ def bench_bm25(a, L, dev, rank, world):
                        "corpus_gen_s": gen_s, "open_s": open_s,
                        "note": "value is end to end through the host-buffer entry point (clauses in, hits out over PCIe); the corpus is resident in HBM"},
             "roofline": {"kernel": "bm25_fast_kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": bm25_traffic, "traffic_source": bm25_traffic_src,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
             "cpu_baseline": cpu}))
 
 

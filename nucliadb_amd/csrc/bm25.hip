@@ -271,16 +271,15 @@ __global__ __launch_bounds__(256) void bm25_rows_kernel(Bm25Args a, const uint32
             const uint32_t nd = (left_some ? ids_l : a.doc_ids)[left_some ? cur_l : 0ull];
             if (active) cdoc_l = left_some ? nd : 0xffffffffu;
         }
-        // ---- round trip 2: tf + fieldnorm of the postings that are scored ----
+        // ---- round trip 2: the packed tf | fieldnorm id << 24 word of the postings that are scored (no gather by doc id) ----
         uint32_t p_tf[R], p_fn[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const uint32_t occur = p_at[m] & 0xff, mode = (p_at[m] >> 8) & 0xff;
             const bool scored = p_ok[m] && occur != 2 && mode != 2;
-            const bool want_tf = scored && mode == 0;
-            p_tf[m] = ((p_at[m] >> 16) && want_tf ? a.aux_tfs : a.tfs)[want_tf ? p_idx[m] : 0ull];
-            p_fn[m] = (uint32_t)a.fieldnorm_ids[scored ? p_doc[m] : 0u];
-            p_tf[m] = want_tf ? p_tf[m] : 1u;
+            const uint32_t word = ((p_at[m] >> 16) && scored ? a.aux_tfs : a.tfs)[scored ? p_idx[m] : 0ull];
+            p_fn[m] = word >> 24;
+            p_tf[m] = (scored && mode == 0) ? (word & 0xffffffu) : 1u;
         }
         float p_score[R];
 #pragma unroll
@@ -429,6 +428,7 @@ __global__ __launch_bounds__(256) void bm25_rows_kernel(Bm25Args a, const uint32
 template <int KL, int R>
 __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
     constexpr uint32_t T = 80 * R;
+    const unsigned long long cy_entry = clock64();
     __shared__ float tf_cache[256];
     __shared__ uint32_t t_key_all[4][T];
     __shared__ uint2 t_val_all[4][T];    // x: the f32 sum's bits, y: hit mask (bit c = clause c)
@@ -438,19 +438,22 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
     uint32_t *t_key = t_key_all[wave];
     uint2 *t_val = t_val_all[wave];
     uint32_t *s_group = s_group_all[wave];
+    // the item's header (item -> work record -> clause records) is a chain of dependent loads: start it before the table is cleared
+    const uint32_t slot_in_grid = blockIdx.x * 4u + (uint32_t)wave;
+    const bool has_item = slot_in_grid < n_items;
+    const uint32_t item = has_item ? items[slot_in_grid] : 0u;
+    Bm25Work work = {0u, 0u, 1u, 0u, 0u};
+    if (has_item) work = a.work[item];
     tf_cache[threadIdx.x] = a.tf_cache[threadIdx.x];
     for (uint32_t i = lane; i < T; i += 64) {
         t_key[i] = BM25_EMPTY;
         t_val[i] = make_uint2(0u, 0u);
     }
     __syncthreads();   // the only workgroup barrier: the tf cache
-    const uint32_t slot_in_grid = blockIdx.x * 4u + (uint32_t)wave;
-    if (slot_in_grid >= n_items) return;
-    const uint32_t item = items[slot_in_grid];
-    const Bm25Work work = a.work[item];
+    if (!has_item) return;
     const uint32_t q = work.query;
-    const uint64_t c0 = a.clause_offsets[q];
-    const int C = (int)(a.clause_offsets[q + 1] - c0);   // <= R
+    const uint64_t c0 = work.clause_first;
+    const int C = (int)work.n_clauses;   // <= R
     const int k = (int)a.k;
 
     // ---- lane c holds clause c: list = base pointers + [pos, len) ----
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
         const unsigned long long b = aux ? a.aux_offsets[2 * ti] : a.term_offsets[ti];
         const unsigned long long e = aux ? a.aux_offsets[2 * ti + 1] : a.term_offsets[ti + 1];
         ids_l = (aux ? a.aux_doc_ids : a.doc_ids) + b;
-        if (cd.mode == 0) tfs_l = (aux ? a.aux_tfs : a.tfs) + b;   // other modes never use a stored tf: any valid address
+        if (cd.mode != 2) tfs_l = (aux ? a.aux_tfs : a.tfs) + b;   // tf | fieldnorm id << 24 per posting; ConstScorer clauses read neither
         len_l = (uint32_t)(e - b);
     }
     const uint32_t occur_l = attr_l & 0xff;
@@ -488,27 +491,43 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
         const uint32_t lo_doc = (uint32_t)((unsigned long long)a.n_docs * work.slice / work.n_slices);
         if (work.slice + 1 < work.n_slices) hi_doc = (uint32_t)((unsigned long long)a.n_docs * (work.slice + 1) / work.n_slices);
         if (work.slice > 0) {
-            // first posting >= lo_doc of every clause: 64-ary search, clause by clause
-            for (int c = 0; c < C; c++) {
-                const uint32_t *ids = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)ids_l, c));
-                uint32_t left = 0, right = rl_u32(len_l, c);
-                while (right - left > 64) {
-                    const uint32_t step = (right - left + 63) / 64;
-                    const uint32_t probe = left + step * (uint32_t)lane;
-                    const bool ge = probe < right ? ids[probe] >= lo_doc : true;
-                    const unsigned long long m = __ballot(ge);
-                    const int first = m ? __ffsll((long long)m) - 1 : 64;
-                    const uint32_t nl = first == 0 ? left : left + step * (uint32_t)(first - 1);
-                    const uint32_t nr = left + step * (uint32_t)first;
+            // first posting >= lo_doc of every clause.  The clauses search side by side: the wave is cut into groups of G = 64 / 2^ceil(log2 C)
+            // lanes, group c runs a G-ary search over clause c's list (one probe per lane and step), so the number of dependent round
+            // trips is that of ONE search (log_G len) instead of C searches.
+            const int g_log = C <= 1 ? 6 : C <= 2 ? 5 : C <= 4 ? 4 : 3;
+            const uint32_t G = 1u << g_log;
+            const int grp = lane >> g_log;
+            const uint32_t li = (uint32_t)lane & (G - 1u);
+            const bool g_live = grp < C;
+            const uint32_t *ids = reinterpret_cast<const uint32_t *>(
+                ((uint64_t)(uint32_t)__shfl((int)((uint64_t)(uintptr_t)ids_l >> 32), grp) << 32) | (uint32_t)__shfl((int)(uint32_t)(uintptr_t)ids_l, grp));
+            uint32_t left = 0, right = g_live ? (uint32_t)__shfl((int)len_l, grp) : 0u;   // uniform inside a group
+            const unsigned long long g_mask = (G == 64u ? ~0ull : ((1ull << G) - 1ull));
+            for (;;) {
+                const bool wide = right - left > G;
+                if (!__ballot(wide)) break;
+                const uint32_t step = (right - left + G - 1u) / G;
+                const uint32_t probe = left + step * li;
+                const uint32_t v = ids[wide && probe < right ? probe : 0u];   // unconditional load (index 0 of a padded list is always readable)
+                const bool ge = (wide && probe < right) ? v >= lo_doc : true;
+                const unsigned long long m = (__ballot(ge) >> (grp << g_log)) & g_mask;
+                const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : G;
+                if (wide) {
+                    const uint32_t nl = first == 0u ? left : left + step * (first - 1u);
+                    const uint32_t nr = left + step * first;
                     left = nl;
                     right = nr < right ? nr : right;
                 }
-                const uint32_t probe = left + (uint32_t)lane;
-                const bool ge = probe < right ? ids[probe] >= lo_doc : true;
-                const unsigned long long m = __ballot(ge);
-                const int first = m ? __ffsll((long long)m) - 1 : 64;
-                const uint32_t res = left + (uint32_t)first < right ? left + (uint32_t)first : right;
-                if (lane == c) pos_l = res;
+            }
+            {
+                const uint32_t probe = left + li;
+                const uint32_t v = ids[probe < right ? probe : 0u];
+                const bool ge = probe < right ? v >= lo_doc : true;
+                const unsigned long long m = (__ballot(ge) >> (grp << g_log)) & g_mask;
+                const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : G;
+                const uint32_t res = left + first < right ? left + first : right;
+                const uint32_t mine = (uint32_t)__shfl((int)res, (lane << g_log) & 63);   // lane c takes group c's answer
+                if (lane < C) pos_l = mine;
             }
         }
     }
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
         const uint32_t n_rows = run;
         const unsigned long long cy_a = clock64();
         // ---- round trip 1 ----
-        uint32_t p_doc[R], p_idx[R];
+        uint32_t p_doc[R], p_idx[R], p_tf[R];
         int row_c[R];
         unsigned long long in_m[R];
 #pragma unroll
@@ -573,6 +592,8 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
             p_idx[m] = rl_u32(pos_l, c) + 64u * ((uint32_t)m - first_row) + (uint32_t)lane;
             in_m[m] = (uint32_t)m < n_rows ? __ballot(p_idx[m] < rl_u32(len_l, c)) : 0ull;
             p_doc[m] = ids[p_idx[m]];   // unconditional (the arrays are padded): every row's load is in flight before the first wait
+            const uint32_t *tfs = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)tfs_l, c));
+            p_tf[m] = tfs[(rl_u32(attr_l, c) >> 8) != 2u ? p_idx[m] : 0u];   // tf | fieldnorm id << 24: same round trip, no gather by doc id
         }
         const uint32_t next_l = pos_l + 64u * rows_l;
         const bool more_l = active && next_l < len_l;
@@ -600,22 +621,13 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
             postings += cnt;
         }
         if (active) cdoc_l = ndoc_l;
-        // ---- round trip 2: tf + fieldnorm ----
-        uint32_t p_tf[R], p_fn[R];
-#pragma unroll
-        for (int m = 0; m < R; m++) {
-            const uint32_t *tfs = reinterpret_cast<const uint32_t *>(lane_bcast_u64((uint64_t)(uintptr_t)tfs_l, row_c[m]));
-            const bool ok = (ok_m[m] >> lane) & 1ull;
-            p_tf[m] = tfs[(rl_u32(attr_l, row_c[m]) >> 8) == 0 ? p_idx[m] : 0u];
-            p_fn[m] = (uint32_t)a.fieldnorm_ids[ok ? p_doc[m] : 0u];
-        }
         float p_score[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const uint32_t mode = rl_u32(attr_l, row_c[m]) >> 8;
             const float w = rl_f32(weight_l, row_c[m]);
-            const float tf = mode == 0 ? (float)p_tf[m] : 1.0f;
-            const float bm = w * (tf / (tf + tf_cache[p_fn[m]]));
+            const float tf = mode == 0 ? (float)(p_tf[m] & 0xffffffu) : 1.0f;
+            const float bm = w * (tf / (tf + tf_cache[p_tf[m] >> 24]));
             p_score[m] = mode == 2 ? w : bm;   // ConstScorer(boost)
         }
         const unsigned long long cy_b = clock64();
@@ -728,6 +740,9 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
         atomicAdd(&a.dbg[3], clock64() - cy_t0);
         atomicAdd(&a.dbg[4], n_win);
         atomicAdd(&a.dbg[5], 1ull);
+        atomicAdd(&a.dbg[6], cy_t0 - cy_entry);
+        atomicMax(&a.dbg[7], clock64() - cy_entry);
+        atomicMax(&a.dbg[8], n_win);
     }
     uint32_t cnt = 0;
 #pragma unroll

@@ -200,8 +200,8 @@ hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uin
 
 // matches (tmp_tf > 0) -> ascending (doc, tf) list; one block, running offset
 __global__ __launch_bounds__(256) void phrase_compact_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph,
-                                                             const uint32_t *tmp_tf, unsigned long long out_begin, uint32_t *out_ids,
-                                                             uint32_t *out_tfs, uint32_t *out_count) {
+                                                             const uint32_t *tmp_tf, const uint8_t *fieldnorm_ids, unsigned long long out_begin,
+                                                             uint32_t *out_ids, uint32_t *out_tfs, uint32_t *out_count) {
     __shared__ uint32_t wave_sum[4];
     __shared__ uint32_t base_s;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -224,8 +224,9 @@ __global__ __launch_bounds__(256) void phrase_compact_kernel(const unsigned long
         uint32_t before = base_s;
         for (int w = 0; w < wib; w++) before += wave_sum[w];
         if (c) {
-            out_ids[out_begin + before + incl - 1] = doc_ids[b0 + i];
-            out_tfs[out_begin + before + incl - 1] = tf;
+            const uint32_t d = doc_ids[b0 + i];
+            out_ids[out_begin + before + incl - 1] = d;
+            out_tfs[out_begin + before + incl - 1] = (tf & 0xffffffu) | ((uint32_t)fieldnorm_ids[d] << 24);   // the scorer's posting word
         }
         __syncthreads();
         if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
@@ -235,8 +236,37 @@ __global__ __launch_bounds__(256) void phrase_compact_kernel(const unsigned long
 }
 
 hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
-                                 unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs, uint32_t *out_count, hipStream_t s) {
-    hipLaunchKernelGGL(phrase_compact_kernel, dim3(1), dim3(256), 0, s, term_offsets, doc_ids, ph, tmp_tf, out_begin, out_ids, out_tfs, out_count);
+                                 const uint8_t *fieldnorm_ids, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs,
+                                 uint32_t *out_count, hipStream_t s) {
+    hipLaunchKernelGGL(phrase_compact_kernel, dim3(1), dim3(256), 0, s, term_offsets, doc_ids, ph, tmp_tf, fieldnorm_ids, out_begin, out_ids, out_tfs,
+                       out_count);
+    return hipGetLastError();
+}
+
+// ---- posting words ---------------------------------------------------------------------------------------------------
+// The scorer needs a posting's term frequency and its document's fieldnorm id.  Fetching the fieldnorm by doc id is one random
+// cache line per posting (64-128 B moved for one byte); the resident copy therefore carries it in the posting itself:
+// word = tf | fieldnorm_id << 24, written once when the segment is opened.  *flag |= 1 when a frequency does not fit 24 bits.
+__global__ __launch_bounds__(256) void bm25_pack_fieldnorm_kernel(const uint32_t *__restrict__ doc_ids, uint32_t *__restrict__ tfs,
+                                                                  const uint8_t *__restrict__ fieldnorm_ids, unsigned long long n, uint32_t n_docs,
+                                                                  uint32_t *flag) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t tf = tfs[i], d = doc_ids[i];
+        if (tf >= (1u << 24)) atomicOr(flag, 1u);
+        if (d >= n_docs) {
+            atomicOr(flag, 2u);
+            continue;
+        }
+        tfs[i] = (tf & 0xffffffu) | ((uint32_t)fieldnorm_ids[d] << 24);
+    }
+}
+
+hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
+                                      uint32_t *flag, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned long long blocks = (n + 255ull) / 256ull;
+    hipLaunchKernelGGL(bm25_pack_fieldnorm_kernel, dim3((uint32_t)(blocks < 65536ull ? blocks : 65536ull)), dim3(256), 0, s, doc_ids, tfs, fieldnorm_ids, n,
+                       n_docs, flag);
     return hipGetLastError();
 }
 

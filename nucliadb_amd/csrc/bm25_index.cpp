@@ -147,6 +147,20 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
         }
         NIDX_HIP(seg.fieldnorm_ids.alloc(std::max<size_t>(in.n_docs, 1)));
         if (in.n_docs) NIDX_HIP(hipMemcpy(seg.fieldnorm_ids.p, in.fieldnorm_ids, in.n_docs, hipMemcpyHostToDevice));
+        if (n_post) {
+            // resident posting word = tf | fieldnorm id << 24: the scorer reads the fieldnorm with the posting instead of one random
+            // cache line per posting (bm25_aux.hip)
+            DevBuf flag;
+            NIDX_HIP(flag.alloc(4));
+            NIDX_HIP(hipMemsetAsync(flag.p, 0, 4, idx->stream));
+            NIDX_HIP(launch_bm25_pack_fieldnorm(seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(), n_post, in.n_docs,
+                                                flag.as<uint32_t>(), idx->stream));
+            uint32_t f = 0;
+            NIDX_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, idx->stream));
+            NIDX_HIP(hipStreamSynchronize(idx->stream));
+            if (f & 1u) return fail(NIDX_ERR_UNSUPPORTED, "segment %u: a term frequency >= 2^24 does not fit the resident posting word", s);
+            if (f & 2u) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: a posting's doc id is >= n_docs", s);
+        }
         seg.all_alive = in.alive_bitset == nullptr;
         if (in.alive_bitset) {
             size_t words = ((size_t)in.n_docs + 63) / 64;
@@ -621,7 +635,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 4));
             NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.pos_offsets.as<unsigned long long>(),
                                          seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, idx->s_phrase_tf.as<uint32_t>(), idx->stream));
-            NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], idx->s_phrase_tf.as<uint32_t>(),
+            NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], idx->s_phrase_tf.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(),
                                            out_off[n_sets + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
                                            idx->s_set_counts.as<uint32_t>() + n_sets + j, idx->stream));
         }
@@ -673,7 +687,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             uint64_t p = 0;
             for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) p += postings_of(clauses[c]);
             uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
-            for (uint32_t sl = 0; sl < slices; sl++) work.push_back(Bm25Work{q, sl, slices});
+            for (uint32_t sl = 0; sl < slices; sl++)
+                work.push_back(Bm25Work{q, sl, slices, (uint32_t)clause_offsets[q], (uint32_t)(clause_offsets[q + 1] - clause_offsets[q])});
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
@@ -752,8 +767,8 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         a.dbg = nullptr;
         DevBuf dbgbuf;
         if (getenv("NIDX_GPU_BM25_DEBUG")) {
-            NIDX_HIP(dbgbuf.alloc(6 * 8));
-            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, 48, idx->stream));
+            NIDX_HIP(dbgbuf.alloc(9 * 8));
+            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, 72, idx->stream));
             a.dbg = dbgbuf.as<unsigned long long>();
         }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
@@ -791,10 +806,10 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         NIDX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
         idx->last_kernel_ms += ms;
         if (a.dbg) {
-            unsigned long long d[6];
-            NIDX_HIP(hipMemcpy(d, a.dbg, 48, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu cycles/item: load=%llu apply=%llu fold=%llu total=%llu kernel_ms=%.3f\n", d[5], d[4],
-                    d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), ms);
+            unsigned long long d[9];
+            NIDX_HIP(hipMemcpy(d, a.dbg, 72, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu (max %llu per item) cycles/item: setup=%llu load=%llu apply=%llu fold=%llu windows total=%llu; longest item (entry to exit) %llu cycles; kernel_ms=%.3f\n",
+                    d[5], d[4], d[8], d[6] / (d[5] ? d[5] : 1), d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), d[7], ms);
         }
         const bool direct = idx->segs.size() == 1;   // one segment: the device list is the answer, no host merge
         for (uint32_t q = 0; q < nq; q++) {  // per segment the device already merged the slices

@@ -289,8 +289,8 @@ struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
     int tie_break;
     unsigned long long docaddr;
 };
-struct Bm25Work {  // one workgroup: query `query`, doc-id slice `slice` of `n_slices`
-    uint32_t query, slice, n_slices;
+struct Bm25Work {  // one work item: query `query`, doc-id slice `slice` of `n_slices`; its clause records [clause_first, + n_clauses)
+    uint32_t query, slice, n_slices, clause_first, n_clauses;
 };
 #define BM25_ITEM_THREADS 64      /* threads per work item (64 = one wave: no block barriers) */
 #define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
@@ -300,7 +300,7 @@ struct Bm25Args {
     uint32_t n_docs;
     const unsigned long long *term_offsets;
     const uint32_t *doc_ids;
-    const uint32_t *tfs;
+    const uint32_t *tfs;              // posting words: tf | fieldnorm id << 24 (packed at open)
     const uint8_t *fieldnorm_ids;
     const uint64_t *alive;   // nullptr = all
     const float *tf_cache;   // [256] K1*(1-B+B*fieldnorm/avg)
@@ -364,7 +364,11 @@ struct PhraseDev {
 hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const unsigned long long *pos_offsets,
                                const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, hipStream_t s);
 hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
-                                 unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs, uint32_t *out_count, hipStream_t s);
+                                 const uint8_t *fieldnorm_ids, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs,
+                                 uint32_t *out_count, hipStream_t s);
+// resident posting word: tfs[i] = tf | fieldnorm_ids[doc_ids[i]] << 24 (in place); *flag: bit 0 = a tf >= 2^24, bit 1 = a doc id >= n_docs
+hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
+                                      uint32_t *flag, hipStream_t s);
 // FacetCollector: counts[p] += |postings(term[p]) ∩ match bitset slot[p]|
 hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *pair_term,
                               const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,

@@ -1,0 +1,18 @@
+#!/bin/bash
+# BM25 scoring kernel vs batch size under rocprofv3 --kernel-trace --stats (GPU box).  Prints one line per batch.
+cd /tmp && export TMPDIR=/tmp
+for b in ${@:-256 1024 4096 16384}; do
+  rm -rf /tmp/prof_$b
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$b -- python $GRAFT_REPO_ROOT/bench.py --workload bm25 --batch $b --steps 4 --warmup 1 --cpu-queries 0 > /tmp/out_$b.json 2>/dev/null
+  python - $b <<'P'
+import json, sys, glob, subprocess, os
+b = sys.argv[1]
+d = json.load(open("/tmp/out_%s.json" % b))
+db = sorted(glob.glob("/tmp/prof_%s/*/*.db" % b))[0]
+out = subprocess.run([sys.executable, os.environ["GRAFT_REPO_ROOT"] + "/scripts/prof_summary.py", db, "x"], capture_output=True, text=True).stdout
+fast = [l for l in out.splitlines() if "bm25_fast_kernel" in l][0].split("|")
+merge = [l for l in out.splitlines() if "bm25_merge_kernel" in l][0].split("|")
+print("%-6s | postings/batch %.0f | fast avg us %s | event us %.1f | merge avg us %s | end-to-end %.1f G postings/s" % (
+    b, d["config"]["postings_per_batch"], fast[3].strip(), d["roofline"]["kernel_ms"] * 1000, merge[3].strip(), d["value"] / 1e9))
+P
+done
