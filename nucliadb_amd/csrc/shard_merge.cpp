@@ -8,6 +8,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "device_common.h"
@@ -15,6 +20,88 @@
 
 namespace nidx {
 namespace {
+
+// A few persistent host threads for per-query host work that is too small for a kernel launch and too large to leave serial
+// (rank fusion of a 1024-query batch).  run(n, grain, f) calls f(begin, end) over [0, n) in chunks claimed from an atomic
+// counter, on the workers and on the caller; it returns when every chunk is done.  One job at a time (callers queue on a mutex).
+class HostPool {
+  public:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned n = hw > 2 ? std::min(hw / 2, 8u) : 0u;
+        if (const char *e = getenv("NIDX_GPU_HOST_THREADS")) n = (unsigned)std::max(0, std::min(64, atoi(e) - 1));
+        for (unsigned i = 0; i < n; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void run(uint32_t n, uint32_t grain, const std::function<void(uint32_t, uint32_t)> &f) {
+        if (n == 0) return;
+        if (workers_.empty() || n <= grain) {
+            f(0, n);
+            return;
+        }
+        std::lock_guard<std::mutex> job_lock(job_mu_);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            f_ = &f;
+            n_ = n;
+            grain_ = grain;
+            next_.store(0);
+            pending_ = (n + grain - 1) / grain;
+            generation_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [this] { return pending_ == 0 && active_ == 0; });   // no worker is still inside work() when the next job is set up
+        f_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            const uint32_t b = next_.fetch_add(grain_);
+            if (b >= n_) return;
+            (*f_)(b, std::min(n_, b + grain_));
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                if (pending_ == 0) continue;   // the job finished before this worker woke up
+                active_++;
+            }
+            work();
+            std::lock_guard<std::mutex> g(mu_);
+            if (--active_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(uint32_t, uint32_t)> *f_ = nullptr;
+    std::atomic<uint32_t> next_{0};
+    uint32_t n_ = 0, grain_ = 1, pending_ = 0, active_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+HostPool &fuse_pool() {
+    static HostPool pool;
+    return pool;
+}
 
 struct Head {
     uint32_t list, pos;
@@ -116,8 +203,6 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     for (uint32_t l = 0; l < n_lists; l++)
         if (!lists[l].counts || (lists[l].stride && !lists[l].ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: NULL arrays", l);
     struct Item { uint64_t id; double score; };
-    std::vector<Item> acc;
-    std::vector<uint32_t> order;
     // _fuse ranks every source by its OWN scores, descending (a stable sort; rank_fusion.py:139-147): callers hand the lists
     // over ranked, and a list that carries scores is checked — an unsorted one would silently fuse with wrong ranks
     for (uint32_t l = 0; l < n_lists; l++) {
@@ -130,57 +215,76 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
                     return fail(NIDX_ERR_INVALID_ARGUMENT, "rank fusion: list %u of query %u is not sorted by score (rank %u)", l, q, r);
         }
     }
-    // first-seen position of every id of one query: open addressing, sized for the query's hits
-    std::vector<uint64_t> slot_id;
-    std::vector<uint32_t> slot_at;
-    for (uint32_t q = 0; q < n_queries; q++) {
-        uint32_t non_empty = 0, only = 0;
-        for (uint32_t l = 0; l < n_lists; l++) {
-            const uint32_t c = std::min(lists[l].counts[q], lists[l].stride);
-            if (c) { non_empty++; only = l; }
-        }
-        acc.clear();
-        if (non_empty == 1) {
-            // fuse(): the single source's hits, unchanged (then the same stable sort by their own scores)
-            const nidx_gpu_ranked_list_t &L = lists[only];
-            const uint32_t c = std::min(L.counts[q], L.stride);
-            for (uint32_t r = 0; r < c; r++)
-                acc.push_back({L.ids[(size_t)q * L.stride + r], L.scores ? (double)L.scores[(size_t)q * L.stride + r] : 0.0});
-        } else {
+    // Queries are independent: ranges of them go to worker threads (a batch of 1024 hybrid queries spends more time here than in
+    // either search kernel otherwise).  Inside a range: first-seen position of every id of one query by open addressing (sized for
+    // the query's hits), then a stable order by fused score — an insertion sort for the usual few dozen hits.
+    auto fuse_range = [&](uint32_t q_begin, uint32_t q_end) {
+        std::vector<Item> acc;
+        std::vector<uint32_t> order, slot_at;
+        std::vector<uint64_t> slot_id;
+        for (uint32_t q = q_begin; q < q_end; q++) {
+            uint32_t non_empty = 0, only = 0;
             size_t hits = 0;
-            for (uint32_t l = 0; l < n_lists; l++) hits += std::min(lists[l].counts[q], lists[l].stride);
-            size_t cap = 16;
-            while (cap < 2 * hits) cap <<= 1;
-            slot_at.assign(cap, 0xffffffffu);
-            slot_id.resize(cap);
             for (uint32_t l = 0; l < n_lists; l++) {
-                const nidx_gpu_ranked_list_t &L = lists[l];
+                const uint32_t c = std::min(lists[l].counts[q], lists[l].stride);
+                if (c) { non_empty++; only = l; }
+                hits += c;
+            }
+            acc.clear();
+            if (non_empty == 1) {
+                // fuse(): the single source's hits, unchanged (then the same stable sort by their own scores)
+                const nidx_gpu_ranked_list_t &L = lists[only];
                 const uint32_t c = std::min(L.counts[q], L.stride);
-                for (uint32_t r = 0; r < c; r++) {
-                    const uint64_t id = L.ids[(size_t)q * L.stride + r];
-                    const double term = (1.0 / (k + (double)r)) * L.weight;
-                    size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 32) & (slot_at.size() - 1);
-                    while (slot_at[h] != 0xffffffffu && slot_id[h] != id) h = (h + 1) & (slot_at.size() - 1);
-                    if (slot_at[h] == 0xffffffffu) {
-                        slot_at[h] = (uint32_t)acc.size();
-                        slot_id[h] = id;
-                        acc.push_back({id, term});
-                    } else {
-                        acc[slot_at[h]].score += term;
+                for (uint32_t r = 0; r < c; r++)
+                    acc.push_back({L.ids[(size_t)q * L.stride + r], L.scores ? (double)L.scores[(size_t)q * L.stride + r] : 0.0});
+            } else {
+                size_t cap = 16;
+                while (cap < 2 * hits) cap <<= 1;
+                slot_at.assign(cap, 0xffffffffu);
+                slot_id.resize(cap);
+                for (uint32_t l = 0; l < n_lists; l++) {
+                    const nidx_gpu_ranked_list_t &L = lists[l];
+                    const uint32_t c = std::min(L.counts[q], L.stride);
+                    for (uint32_t r = 0; r < c; r++) {
+                        const uint64_t id = L.ids[(size_t)q * L.stride + r];
+                        const double term = (1.0 / (k + (double)r)) * L.weight;
+                        size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 32) & (cap - 1);
+                        while (slot_at[h] != 0xffffffffu && slot_id[h] != id) h = (h + 1) & (cap - 1);
+                        if (slot_at[h] == 0xffffffffu) {
+                            slot_at[h] = (uint32_t)acc.size();
+                            slot_id[h] = id;
+                            acc.push_back({id, term});
+                        } else {
+                            acc[slot_at[h]].score += term;
+                        }
                     }
                 }
             }
+            const uint32_t m = (uint32_t)acc.size();
+            order.resize(m);
+            if (m <= 96) {   // stable insertion sort, descending by score
+                for (uint32_t i = 0; i < m; i++) {
+                    const double sc = acc[i].score;
+                    uint32_t j = i;
+                    while (j > 0 && acc[order[j - 1]].score < sc) {
+                        order[j] = order[j - 1];
+                        j--;
+                    }
+                    order[j] = i;
+                }
+            } else {
+                for (uint32_t i = 0; i < m; i++) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return acc[a].score > acc[b].score; });
+            }
+            const uint32_t n = std::min<uint32_t>(m, window);
+            for (uint32_t i = 0; i < n; i++) {
+                out_ids[(size_t)q * window + i] = acc[order[i]].id;
+                out_scores[(size_t)q * window + i] = acc[order[i]].score;
+            }
+            out_counts[q] = n;
         }
-        order.resize(acc.size());
-        for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return acc[a].score > acc[b].score; });
-        const uint32_t n = (uint32_t)std::min<size_t>(order.size(), window);
-        for (uint32_t i = 0; i < n; i++) {
-            out_ids[(size_t)q * window + i] = acc[order[i]].id;
-            out_scores[(size_t)q * window + i] = acc[order[i]].score;
-        }
-        out_counts[q] = n;
-    }
+    };
+    fuse_pool().run(n_queries, 64, fuse_range);
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
