@@ -203,3 +203,37 @@ def test_native_batched_rrf_matches_outputs_of_the_reference_module():
         assert [(name_of[int(i)], float(s).hex()) for i, s in zip(got_ids[0, :m], got_scores[0, :m])] == [(e[0], e[1]) for e in c["expected"]], n
         n_checked += 1
     assert n_checked >= 20
+
+
+def test_native_rrf_is_thread_safe_and_deterministic():
+    """The native routine spreads a batch over a persistent host-thread pool (one job at a time): concurrent callers with batches of
+    different sizes must each get exactly what a lone caller gets."""
+    import threading
+
+    from nucliadb_amd.rank_fusion import rrf_fuse_batch
+
+    rng = np.random.default_rng(77)
+
+    def make(B):
+        a = np.stack([rng.choice(500, 20, replace=False) for _ in range(B)]).astype(np.uint64)
+        b = np.stack([rng.choice(500, 10, replace=False) for _ in range(B)]).astype(np.uint64)
+        sa = np.sort(rng.random((B, 20)).astype(np.float32), axis=1)[:, ::-1].copy()
+        return [(a, np.full(B, 20, np.uint32), 1.0, sa), (b, np.full(B, 10, np.uint32), 2.0, None)]
+
+    jobs = [make(B) for B in (1, 63, 64, 65, 300, 1024, 2048, 130)]
+    want = [rrf_fuse_batch(j, k=60.0, window=16) for j in jobs]
+    errors = []
+
+    def worker(i):
+        for _ in range(40):
+            got = rrf_fuse_batch(jobs[i], k=60.0, window=16)
+            if not all(np.array_equal(g, w) for g, w in zip(got, want[i])):
+                errors.append(i)
+                return
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
