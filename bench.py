@@ -600,6 +600,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
 
     # ---- algorithmic bytes per launch: evals*4D + expansions*256 B, counted by the kernel
     bytes_per_launch, evals_q, exp_q, flags = [], [], [], 0
+    hits_q = []
     for i in range(min(n_pool, max(1, a.steps))):
         search(qpool[i], with_stats=True)
         torch.cuda.synchronize()
@@ -607,6 +608,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         bytes_per_launch.append(float((st[:, 0] * 4 * d + st[:, 1] * 256).sum()))
         evals_q.append(float(st[:, 0].mean()))
         exp_q.append(float(st[:, 1].mean()))
+        hits_q.append(float(st[:, 5].mean()))   # NIDX_STAT_EDGE_HITS
         flags |= int(np.bitwise_or.reduce(st[:, 3]))
     alg_bytes = float(np.mean(bytes_per_launch))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -644,7 +646,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         res = {
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
             "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "evals": float(np.mean(evals_q)),
-            "expansions": float(np.mean(exp_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
+            "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
             "build_s": build_s, "exchange_check": exchange_check,
         }
     if not headline:
@@ -904,6 +906,7 @@ def bench_hnsw(a, L, dev, rank, world):
         "merged_queries_per_s": B * a.steps / head["elapsed"],
         "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B),
         "distance_evals_per_query": head["evals"], "expansions_per_query": head["expansions"],
+        "expansions_with_edge_record_fetched_ahead_per_query": head["edge_hits"],
         "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"],
         "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"],
         "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],

@@ -212,6 +212,23 @@ struct CandSet {
             if (unexp[i]) return lane_bcast_u64(res.l[i].key, __builtin_ctzll(unexp[i]));
         return NIDX_EMPTY_KEY;
     }
+    // the two best unexpanded entries other than `skip` (EMPTY where there is none); nothing changes
+    __device__ inline void peek2_except(const WaveTopK<NL> &res, uint64_t skip, uint64_t &a, uint64_t &b) const {
+        a = b = NIDX_EMPTY_KEY;
+        int found = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            uint64_t m = unexp[i];
+            while (m && found < 2) {
+                const uint64_t key = lane_bcast_u64(res.l[i].key, __builtin_ctzll(m));
+                m &= m - 1ull;
+                if (key == skip) continue;
+                if (found == 0) a = key;
+                else b = key;
+                found++;
+            }
+        }
+    }
     __device__ inline uint64_t pop(const WaveTopK<NL> &res) {
 #pragma unroll
         for (int i = 0; i < NL; i++)
@@ -225,7 +242,7 @@ struct CandSet {
 };
 
 struct SearchCounters {
-    uint32_t evals, expansions, visited, flags;
+    uint32_t evals, expansions, visited, flags, edge_hits;
     // wave-0 cycle accounting (s_memtime): controller pop/edge/visited, distance phase, admission
     uint64_t cyc_ctl, cyc_eval, cyc_ins;
 };
@@ -390,9 +407,26 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
     // wave 0 runs the admission of the current expansion.  Nothing of the speculated expansion is committed (visited marks,
     // counters) before the real pop confirms it; a mismatch (possible only with exactly tied scores or a pool overflow) throws
     // it away and expands the popped candidate the plain way.
+    // Edge records fetched ahead (wave 0, layer 0): while an expansion's rows are in flight, the records of the two best unexpanded
+    // entries that were NOT chosen are loaded too — one of them is usually the next candidate but one, and its expansion then
+    // starts without the edge round trip in front of its rows.  pw*: the record (word `lane`), tg*: whose it is.
+    uint32_t pw0 = 0, pw1 = 0, tg0 = 0xffffffffu, tg1 = 0xffffffffu;
+    uint32_t edge_hits = 0;
     auto prepare = [&](uint64_t ck, NbBuf &dst) -> int {   // wave 0: the neighbours of ck that are not visited -> dst.addr
         uint32_t deg;
-        const uint32_t w = load_edge_word(g, rank_key_addr(ck), layer, lane, deg);
+        const uint32_t node = rank_key_addr(ck);
+        uint32_t w;
+        if (node == tg0) {
+            w = pw0;
+            deg = lane_bcast_u32(w, 0);
+            edge_hits++;
+        } else if (node == tg1) {
+            w = pw1;
+            deg = lane_bcast_u32(w, 0);
+            edge_hits++;
+        } else {
+            w = load_edge_word(g, node, layer, lane, deg);
+        }
         const bool fresh = lane >= 1 && lane <= (int)deg && !vis_contains(vis, vis_log2, w);
         const unsigned long long m = __ballot(fresh);
         if (fresh) dst.addr[__popcll(m & ((1ull << lane) - 1ull))] = w;
@@ -400,7 +434,6 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
     };
     int p = 0;
     uint64_t cur = NIDX_EMPTY_KEY;
-    uint32_t pf0 = 0, pf1 = 0, pf_sink = 0;
     if (ctl) {
         const uint64_t t_a = clock64();
         int cont = 0, n0 = 0;
@@ -458,15 +491,25 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
                     nxt = pm > bn ? pm : bn;
                     if (nxt == NIDX_EMPTY_KEY && pool_len > 0) nxt = pool_peek(sh.pool, pool_len, lane);  // tied evictions (rare)
                     if (nxt != NIDX_EMPTY_KEY) n_next = prepare(nxt, nb_next);
-                    // Warm the L2 with the layer-0 edge records of the neighbours that can be admitted: whichever of them is
-                    // popped later finds its 256-byte record there instead of paying a second HBM round trip in front of its
-                    // rows.  Issued after this expansion's own edge load (vector loads return in order) and consumed one
-                    // expansion later, when they have long landed.
-                    pf_sink ^= pf0 ^ pf1;
-                    pf0 = pf1 = 0;
-                    if (layer == 0 && adm) {
-                        pf0 = g.l0[(size_t)addr * NIDX_L0_STRIDE];
-                        pf1 = g.l0[(size_t)addr * NIDX_L0_STRIDE + 32];
+                    if (layer == 0) {
+                        // the candidates after `nxt` as far as they are known now: the best unexpanded entries of the list
+                        uint64_t ka, kb;
+                        cand.peek2_except(res, nxt, ka, kb);
+                        uint32_t wa = ka != NIDX_EMPTY_KEY ? rank_key_addr(ka) : 0xffffffffu;
+                        uint32_t wb = kb != NIDX_EMPTY_KEY ? rank_key_addr(kb) : 0xffffffffu;
+                        if (wa == tg1 || wb == tg0) {   // a record already held stays where it is
+                            const uint32_t t = wa;
+                            wa = wb;
+                            wb = t;
+                        }
+                        if (wa != tg0) {
+                            tg0 = wa;
+                            if (wa != 0xffffffffu) pw0 = g.l0[(size_t)wa * NIDX_L0_STRIDE + lane];
+                        }
+                        if (wb != tg1) {
+                            tg1 = wb;
+                            if (wb != 0xffffffffu) pw1 = g.l0[(size_t)wb * NIDX_L0_STRIDE + lane];
+                        }
                     }
                 }
                 if (lane == 0) {
@@ -547,8 +590,7 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
             p ^= 1;
         }
     }
-    pf_sink ^= pf0 ^ pf1;
-    asm volatile("" ::"v"(pf_sink));
+    st.edge_hits += edge_hits;
     st.visited = st.visited > vis_count ? st.visited : vis_count;
 }
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
                 o[NIDX_STAT_VISITED] = st.visited;
                 o[NIDX_STAT_FLAGS] = st.flags;
                 o[NIDX_STAT_CYC_CTL] = (uint32_t)st.cyc_ctl;
-                o[NIDX_STAT_CYC_EVAL] = (uint32_t)st.cyc_eval;
+                o[NIDX_STAT_EDGE_HITS] = st.edge_hits;
                 o[NIDX_STAT_CYC_INS] = (uint32_t)st.cyc_ins;
                 o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
             }

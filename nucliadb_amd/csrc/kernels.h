@@ -133,7 +133,7 @@ struct SegDev {
 #define NIDX_STAT_VISITED 2
 #define NIDX_STAT_FLAGS 3
 #define NIDX_STAT_CYC_CTL 4    /* wave-0 cycles: pop + edge record + visited test */
-#define NIDX_STAT_CYC_EVAL 5   /* cycles in the distance phase (all waves, incl. barriers) */
+#define NIDX_STAT_EDGE_HITS 5  /* expansions whose edge record had been fetched ahead (no round trip in front of the rows) */
 #define NIDX_STAT_CYC_INS 6    /* cycles replaying the admission rule */
 #define NIDX_STAT_CYC_TOTAL 7
 #define NIDX_STAT_STRIDE 8

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         o[NIDX_STAT_FLAGS] = flags;
         // cycle split of the walk: pop + edge record / visited test / estimates / admission; [7] = total incl. re-rank
         o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_pop + cyc_vis);
-        o[NIDX_STAT_CYC_EVAL] = (uint32_t)cyc_est;
+        o[NIDX_STAT_EDGE_HITS] = (uint32_t)cyc_est;   // this kernel: cycles in the estimate phase
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
         o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
         (void)t_rr;

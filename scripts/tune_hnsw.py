@@ -49,7 +49,7 @@ for combo in itertools.product(*vals):
     s = st.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     byt = float((s[:, 0] * 4 * a.d + s[:, 1] * 256).sum())
     cyc = s[:, 4:8].mean(0)
-    print(dict(zip(names, combo)), "ms=%.3f qps=%.0f GB/s=%.0f frac=%.3f evals=%.0f exp=%.1f flags=%d cyc(ctl,eval,ins,total)=%s us_total=%.0f" % (
+    print(dict(zip(names, combo)), "ms=%.3f qps=%.0f GB/s=%.0f frac=%.3f evals=%.0f exp=%.1f flags=%d cyc(ctl,EDGE_HITS,ins,total)=%s us_total=%.0f" % (
         ms, B / ms * 1e3, byt / ms / 1e6, byt / ms / 1e6 / 8000, s[:, 0].mean(), s[:, 1].mean(), int(np.bitwise_or.reduce(s[:, 3])),
         np.round(cyc).astype(int).tolist(), cyc[3] / 100.0), flush=True)
     tot = s[:, 7].astype(np.float64)

@@ -14,9 +14,9 @@ import json, sys
 try:
     d = json.load(open("gpurun_out/occ/%s.json" % sys.argv[1]))
     r, c = d["roofline"], d["config"]
-    print("%-16s value %.0f ms/step %.4f kernel_ms %.4f frac %.3f sustained %.3f recall %.3f evals %.0f flags %s/%s" % (
+    print("%-16s value %.0f ms/step %.4f kernel_ms %.4f frac %.3f sustained %.3f recall %.3f evals %.0f edge_hits %.1f flags %s/%s" % (
         sys.argv[1], d["value"], d["ms_per_step"], r["kernel_ms"], r["frac"], r["sustained"]["frac"], c["recall_at_10"],
-        c["distance_evals_per_query"], c["kernel_flags"], c["timed_launch_flags"]))
+        c["distance_evals_per_query"], c.get("expansions_with_edge_record_fetched_ahead_per_query", -1), c["kernel_flags"], c["timed_launch_flags"]))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 P
