@@ -71,7 +71,11 @@ __device__ inline float score_from_sums(float ab, float xx, float qq, double sqr
 
 // Virtual thread id: the wave roles rotate with the workgroup index so that the controller waves (virtual wave 0) of the
 // workgroups sharing a CU do not all sit on the same SIMD.  Lanes keep their position.
-__device__ inline uint32_t nidx_tid() { return (threadIdx.x + ((blockIdx.x & 3u) << 6)) & (blockDim.x - 1u); }
+__device__ inline uint32_t nidx_tid() {
+    const uint32_t nw = blockDim.x >> 6;   // 1, 2, 3 or 4 waves per workgroup
+    const uint32_t t = threadIdx.x + ((blockIdx.x % nw) << 6);
+    return t >= blockDim.x ? t - blockDim.x : t;
+}
 
 // ---- visited set ------------------------------------------------------------------------------
 __device__ inline void vis_clear(uint32_t *vis, uint32_t cap) {
