@@ -85,3 +85,44 @@ def test_deletion_terms_respect_seq_and_key_kind():
     assert deletion_terms(v, 2, dele) == sorted([a, b])
     assert deletion_terms(v, 3, dele) == [a]          # `Seq(segment) < del_seq` is strict
     assert deletion_terms(v, 5, dele) == []
+
+
+def test_tricky_resource_of_the_reference_at_the_host_level():
+    """nidx_paragraph/tests/reader.rs:71-91 (create_tricky_resource) and :452-500 (test_query_parsing_weird_stuff), :418-450
+    (test_query_parsing): what those cases pin on the host side — the document tokenizer ("default": split on non-alphanumerics,
+    lower-case), the keyword grammar and the stop-word rule (every stop word but the last token goes; the lists are the
+    reference's own data files, read from /root/reference when it is there)."""
+    import glob
+    import json
+    import os
+
+    from nucliadb_amd.bm25 import tokenize
+
+    paragraphs = ["That's a too *tricky* resource", "It's very important to do-stuff", "It's not that important to do-stuff",
+                  "W'h'a't a -w-e-i-r-d p\"ara\"gra\"ph"]
+    tokens = [tokenize(p) for p in paragraphs]
+    matching = lambda word: sum(word in t for t in tokens)   # noqa: E731
+    # `total` of the one-word queries of the reference's test
+    assert (matching("important"), matching("paragraph"), matching("ara"), matching("ph"), matching("to")) == (2, 0, 1, 1, 2)
+    assert tokens[3][-4:] == ["p", "ara", "gra", "ph"] and tokens[1][-2:] == ["do", "stuff"]
+
+    def contains_phrase(doc, words):
+        return any(doc[i:i + len(words)] == words for i in range(len(doc) - len(words) + 1))
+
+    quoted = parse_query('"It\'s very important to do-stuff"')
+    assert quoted == [("quoted", "it s very important to do stuff")]
+    assert sum(contains_phrase(t, quoted[0][1].split()) for t in tokens) == 1            # `total` == 1
+    assert parse_query("some ' document") == lit("some", "document")                      # the stray quote goes (PR 3216)
+
+    base = "/root/reference/nidx/nidx_paragraph/stop_words"
+    if not os.path.isdir(base):
+        pytest.skip("the reference's stop-word data files are not on this machine")
+    stop = set()
+    for code in ("fr", "it", "es", "en", "ca", "de", "nl", "pt"):   # LOADED_LANGUAGES, query_parser/stop_words.rs:84-93
+        with open(os.path.join(base, code + ".json")) as f:
+            stop |= set(json.load(f))
+    assert len(glob.glob(os.path.join(base, "*.json"))) >= 8
+    # "removes all stop words except the last and matches `to` exactly": ematches == ["to"]
+    assert parse_query("it's not that to", stop) == lit("to")
+    assert parse_query("some ' document", stop) == lit("document")
+    assert parse_query("important", stop) == lit("important")
