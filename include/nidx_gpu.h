@@ -444,7 +444,8 @@ typedef struct {
     uint32_t n_terms;
     const uint64_t *term_offsets; /* [n_terms+1] into doc_ids / tfs */
     const uint32_t *doc_ids;      /* ascending within a term */
-    const uint32_t *tfs;          /* term frequency per posting */
+    const uint32_t *tfs;          /* term frequency per posting; must be < 2^24 (the resident posting word is tf | fieldnorm id << 24:
+                                   * NIDX_ERR_UNSUPPORTED at open otherwise) */
     const uint8_t *fieldnorm_ids; /* [n_docs] 1-byte fieldnorm ids */
     const uint64_t *alive_bitset; /* open_index_with_deletions (nidx_tantivy/src/index_reader.rs:39-74); NULL = all */
     /* positions of every posting (the text field is indexed WithFreqsAndPositions, schema.rs:59-115): posting i owns
