@@ -6,6 +6,7 @@
 // rebuilt with sift_down after every pop (third-party algorithm, restated).  The per-shard lists are
 // what each GPU produced; with one shard per GPU they arrive through an RCCL all-gather.
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -42,7 +43,7 @@ class HostPool {
     }
     void run(uint32_t n, uint32_t grain, const std::function<void(uint32_t, uint32_t)> &f) {
         if (n == 0) return;
-        if (workers_.empty() || n <= grain) {
+        if (workers_.empty() || n <= grain || getpid() != pid_) {   // a forked child inherits the object but not the threads
             f(0, n);
             return;
         }
@@ -89,6 +90,7 @@ class HostPool {
             if (--active_ == 0) done_cv_.notify_all();
         }
     }
+    const pid_t pid_ = getpid();
     std::vector<std::thread> workers_;
     std::mutex mu_, job_mu_;
     std::condition_variable cv_, done_cv_;
@@ -99,8 +101,9 @@ class HostPool {
     bool stop_ = false;
 };
 HostPool &fuse_pool() {
-    static HostPool pool;
-    return pool;
+    // never destroyed: worker threads must not be joined from a static destructor (exit order; a forked child has no workers)
+    static HostPool *pool = new HostPool;
+    return *pool;
 }
 
 struct Head {
