@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -221,7 +222,10 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     // Queries are independent: ranges of them go to worker threads (a batch of 1024 hybrid queries spends more time here than in
     // either search kernel otherwise).  Inside a range: first-seen position of every id of one query by open addressing (sized for
     // the query's hits), then a stable order by fused score — an insertion sort for the usual few dozen hits.
+    // an exception must not leave a worker thread (that would be std::terminate, not an error code): remember it and report after the job
+    std::atomic<int> worker_failure{0};   // 0 none, 1 bad_alloc, 2 anything else
     auto fuse_range = [&](uint32_t q_begin, uint32_t q_end) {
+      try {
         std::vector<Item> acc;
         std::vector<uint32_t> order, slot_at;
         std::vector<uint64_t> slot_id;
@@ -286,8 +290,15 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
             }
             out_counts[q] = n;
         }
+      } catch (const std::bad_alloc &) {
+        worker_failure.store(1);
+      } catch (...) {
+        worker_failure.store(2);
+      }
     };
     fuse_pool().run(n_queries, 64, fuse_range);
+    if (worker_failure.load() == 1) return fail(NIDX_ERR_OUT_OF_MEMORY, "rank fusion: a host allocation failed");
+    if (worker_failure.load() == 2) return fail(NIDX_ERR_INTERNAL, "rank fusion: unexpected exception in a worker");
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
