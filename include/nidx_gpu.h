@@ -40,6 +40,7 @@ extern "C" {
 #define NIDX_ERR_INEXACT (-9)                 /* a bounded on-chip pool overflowed: result would differ from the reference */
 #define NIDX_ERR_OUT_OF_MEMORY (-10)          /* a host allocation failed inside the library */
 #define NIDX_ERR_INTERNAL (-11)               /* any other C++ exception, caught at the boundary */
+#define NIDX_ERR_BUSY (-12)                   /* nidx_gpu_vector_search_submit: every pipeline slot holds an unwaited ticket */
 
 /* Copies the calling thread's last error message (NUL terminated) and returns its length. */
 int32_t nidx_gpu_last_error(char *buf, size_t len);
@@ -127,8 +128,12 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
 
 /* Launch-shape knobs of the HNSW kernels (no effect on results): "waves_per_query" 1..4,
  * "eval_rows" 2..4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15, and the request coalescer's
- * "coalesce_window_us" / "coalesce_max_batch".  The kernel knobs are also read at
- * open from the environment as NIDX_GPU_<NAME>. */
+ * "coalesce_window_us" / "coalesce_max_batch" / "coalesce_in_flight" and the serving pipeline's "pipeline_depth".  The kernel knobs are also read at
+ * open from the environment as NIDX_GPU_<NAME>.
+ * One knob DOES change results: "ef_search" (0 = the reference's constant EF_SEARCH = 30, hnsw/params.rs:46; up to 512): the
+ * layer-0 search keeps max(k, ef_search) candidates.  The reference reaches its recall at 10 M vectors by searching 50 segments
+ * of <= 200 k records each at ef = 30 (searcher.rs:270-287); a flat graph over the same vectors matches that recall at a larger
+ * ef — bench.py reports both.  The RaBitQ arm keeps its own ef = min(100 k, 2000) (hnsw/search.rs:333-340). */
 int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value);
 
 /* NIDX_METHOD_BRUTE_FORCE_MFMA: the same exact scan as a dense GEMM on the f32 matrix cores (one
@@ -283,11 +288,38 @@ int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *index, const
                                            const nidx_gpu_vector_search_params_t *params, uint32_t threads, uint32_t calls,
                                            float *latencies_us_out, double *elapsed_s_out);
 
+/* ---- pipelined serving -----------------------------------------------------------------------------------
+ * Replaces the loop the reference runs around VectorSearcher::search (lib.rs:120-148; one call per request from
+ * src/searcher/shard_search.rs:139-153) for callers that have batches: the library owns "pipeline_depth" slots (tunable, default
+ * 4, at most 16) — a HIP stream, pinned staging and a device result block each — so that several batches are in flight and the
+ * walk-length tail of one launch overlaps the body of the next (a launch lasts as long as its longest walk).  The library sets
+ * GPU_MAX_HW_QUEUES=8 at load time unless the variable is already set (streams beyond the runtime's 4 hardware queues share a
+ * queue and serialise).
+ *
+ * submit: `queries` = [n_queries][dimension] f32 rows in host memory (copied before the call returns; normalised when the index
+ * says so) or in DEVICE memory (searched where they lie: dimension % 4 == 0, an index that does not normalise, rows complete —
+ * their producing stream synchronised — and untouched until the ticket has been waited for).  segment_filters as in
+ * nidx_gpu_vector_search (host bitsets, copied before the call returns).  Every segment's search is launched on the slot's
+ * stream and ONE device-to-host transfer of the result block is queued behind them; the call returns without waiting for
+ * either.  NIDX_ERR_BUSY when every slot holds a ticket that has not been waited for (nothing was launched).
+ *
+ * wait: blocks until the block of `ticket` has landed in pinned host memory, re-runs a segment whose flag word says a bounded
+ * on-chip structure overflowed through the exact fallback (as nidx_gpu_vector_segment_search_device_exact does; *n_retried_out
+ * = queries that took it), merges the segments with Fssc and fills the caller's [n_queries][k] arrays exactly as
+ * nidx_gpu_vector_search would have.  A ticket is waited for once; waits may come in any order and from any thread. */
+int32_t nidx_gpu_vector_search_submit(nidx_gpu_vector_index_t *index, const float *queries, uint32_t n_queries, uint32_t query_dimension,
+                                      const nidx_gpu_vector_search_params_t *params, const uint64_t *const *segment_filters,
+                                      uint64_t *ticket_out);
+int32_t nidx_gpu_vector_search_wait(nidx_gpu_vector_index_t *index, uint64_t ticket, uint32_t *out_segment, uint32_t *out_paragraph,
+                                    uint32_t *out_vector, float *out_score, uint32_t *out_count, uint32_t *n_retried_out);
+
 /* One query per call, the shape of the reference's request path (one blocking thread per Search request,
  * src/searcher/shard_search.rs:139-153; one vector per request, nodereader.proto:402).  Thread safe:
- * concurrent callers with equal params are coalesced into one batched launch (window and batch size via
- * the tunables "coalesce_window_us", default 100, and "coalesce_max_batch", default 1024).  Unfiltered;
- * outputs are [k] rows.  Blocks until this query's hits are ready. */
+ * concurrent callers with equal params are coalesced into batched launches that run through the pipeline above, up to
+ * "coalesce_in_flight" (default 4) of them at a time: while batches are running the next one gathers, and it is closed when its
+ * window ("coalesce_window_us", default 50, counted from the moment it starts gathering) has passed or it is full
+ * ("coalesce_max_batch", default 1024) AND a slot is free — so under load the batch size adapts to the arrival rate.
+ * Unfiltered; outputs are [k] rows.  Blocks until this query's hits are ready. */
 int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *query, uint32_t query_dimension,
                                    const nidx_gpu_vector_search_params_t *params, uint32_t *out_segment,
                                    uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
@@ -610,8 +642,8 @@ uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id);
 uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm);
 
 /* =====================================================================================
- * Shard merge — replaces src/searcher/shard_merge.rs:197-348 (host side; the multi-GPU
- * exchange that feeds it is an RCCL all-gather driven from the host language).
+ * Shard merge — replaces src/searcher/shard_merge.rs:197-414: host merges, device merges for whole batches, and the
+ * multi-GPU exchange (an RCCL all-gather inside the library) that feeds them.
  * ===================================================================================== */
 
 /* merge_vector_responses (shard_merge.rs:332-348): kmerge_by(a.score >= b.score).take(limit).
@@ -632,10 +664,68 @@ int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *d
                             uint32_t limit, float *out_score, uint64_t *out_docaddr, uint32_t *out_list,
                             uint32_t *n_out);
 
+/* The BM25 merges for a whole batch with everything in HBM: d_scores [n_lists][n_queries][k] f32, d_docaddrs [..] u64,
+ * d_order_values [..] i64 or NULL (the sort value of every hit when the request orders by a date field — seconds * 10^9 + nanos,
+ * or the fast value itself), d_counts [n_lists][n_queries].  `order`: NIDX_MERGE_ORDER_SCORE = sort_documents_fn /
+ * sort_paragraphs_fn with SortExpr::Score (bm25 greater by total_cmp, else shard id greater as bytes, else docaddr smaller);
+ * NIDX_MERGE_ORDER_VALUE_DESC / _ASC = SortExpr::Date descending / ascending (shard_merge.rs:236-250,314-329: strictly greater /
+ * smaller value first; ties keep kmerge's heap order, the same as nidx_gpu_merge_bm25's).  shard_ids (host): the id of every list's
+ * shard.  Outputs [n_queries][limit] (each may be NULL) / [n_queries]; d_out_list = the list every hit came from. */
+enum { NIDX_MERGE_ORDER_SCORE = 0, NIDX_MERGE_ORDER_VALUE_DESC = 1, NIDX_MERGE_ORDER_VALUE_ASC = 2 };
+int32_t nidx_gpu_merge_bm25_device(const float *d_scores, const uint64_t *d_docaddrs, const int64_t *d_order_values, const uint32_t *d_counts,
+                                   const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists, uint32_t n_queries,
+                                   uint32_t k, uint32_t limit, int32_t order, float *d_out_score, uint64_t *d_out_docaddr,
+                                   int64_t *d_out_order_value, uint32_t *d_out_list, uint32_t *d_out_count, void *stream);
+/* The two host merges for a whole batch (arrays laid out like the device forms, in host memory; order as above). */
+int32_t nidx_gpu_merge_vector_batch(const float *scores, const uint64_t *ids, const uint32_t *counts, uint32_t n_lists, uint32_t n_queries,
+                                    uint32_t k, uint32_t limit, float *out_score, uint64_t *out_id, uint32_t *out_count);
+int32_t nidx_gpu_merge_bm25_batch(const float *scores, const uint64_t *docaddrs, const int64_t *order_values, const uint32_t *counts,
+                                  const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists, uint32_t n_queries,
+                                  uint32_t k, uint32_t limit, int32_t order, float *out_score, uint64_t *out_docaddr,
+                                  int64_t *out_order_value, uint32_t *out_list, uint32_t *out_count);
+
+/* merge_facets (shard_merge.rs:380-414): the facet counts of several shards summed per (group, tag).  The reference returns a
+ * HashMap (iteration order unspecified); the output here is sorted by (group, tag) bytes.  Output entries point into the
+ * inputs' strings.  *n_out receives the number of distinct (group, tag) pairs even when it exceeds `capacity`. */
+typedef struct {
+    const uint8_t *group;   /* the facet root, e.g. "/l" */
+    uint32_t group_len;
+    const uint8_t *tag;     /* FacetResult.tag, e.g. "/l/mylabel" */
+    uint32_t tag_len;
+    int32_t total;          /* FacetResult.total */
+} nidx_gpu_facet_count_t;
+int32_t nidx_gpu_merge_facets(const nidx_gpu_facet_count_t *const *shard_facets, const uint32_t *shard_lens, uint32_t n_shards,
+                              nidx_gpu_facet_count_t *out, uint32_t capacity, uint32_t *n_out);
+
+/* ---- the multi-GPU exchange: one index shard per GPU, one process per GPU, RCCL over xGMI ------------------------------------
+ * Replaces the gRPC scatter / gather around merge_search (shard_merge.rs:54-99; src/searcher/shard_search.rs) inside one node:
+ * every rank searches its own shard, then ONE ncclAllGather moves every rank's per-query top-k (a packed block: scores | ids |
+ * [sort values] | counts — 120 KiB per rank at 1 024 queries x 10 hits) and every rank runs the reference's k-way merge on the
+ * device.  librccl is bound at the first call (dlopen); no torch, no host staging.
+ *   rank 0:    nidx_gpu_shard_comm_unique_id(id)            (ncclGetUniqueId; the host ships the 128 bytes to the other ranks)
+ *   all ranks: nidx_gpu_set_device(local gpu); nidx_gpu_shard_comm_init(id, rank, world, this shard's id, ..)   (collective)
+ *   per batch: nidx_gpu_shard_exchange_merge_vector / _bm25  (collective: same order on every rank; asynchronous on `stream`,
+ *              inputs and outputs are device arrays of this rank; the merged lists are identical on every rank)
+ * d_out_rank = the rank (= shard) every merged hit came from.  At most 64 ranks. */
+#define NIDX_SHARD_COMM_ID_BYTES 128
+typedef struct nidx_gpu_shard_comm nidx_gpu_shard_comm_t;
+int32_t nidx_gpu_shard_comm_unique_id(uint8_t *id_out /* [NIDX_SHARD_COMM_ID_BYTES] */);
+int32_t nidx_gpu_shard_comm_init(const uint8_t *unique_id, int32_t rank, int32_t world, const uint8_t *shard_id, uint32_t shard_id_len,
+                                 nidx_gpu_shard_comm_t **comm_out);
+void nidx_gpu_shard_comm_destroy(nidx_gpu_shard_comm_t *comm);
+int32_t nidx_gpu_shard_exchange_merge_vector(nidx_gpu_shard_comm_t *comm, const float *d_scores, const uint64_t *d_ids, const uint32_t *d_counts,
+                                             uint32_t n_queries, uint32_t k, uint32_t limit, float *d_out_score, uint64_t *d_out_id,
+                                             uint32_t *d_out_count, void *stream);
+int32_t nidx_gpu_shard_exchange_merge_bm25(nidx_gpu_shard_comm_t *comm, const float *d_scores, const uint64_t *d_docaddrs,
+                                           const int64_t *d_order_values, const uint32_t *d_counts, uint32_t n_queries, uint32_t k, uint32_t limit,
+                                           int32_t order, float *d_out_score, uint64_t *d_out_docaddr, int64_t *d_out_order_value,
+                                           uint32_t *d_out_rank, uint32_t *d_out_count, void *stream);
+
 /* Rank fusion of the ranked lists a hybrid request gets back (nucliadb/src/nucliadb/search/search/rank_fusion.py; the
  * reference does this per request in Python).  Batched host code, no device work.
  * ReciprocalRankFusion._fuse + RankFusionAlgorithm.fuse (:60-181): for every query, walk the lists in the order given
- * (list 0 first), hit by hit in rank order; a hit's id is first seen => it enters the result with score
+ * (list 0 first), hit by hit in rank order (a list that carries scores is first ranked by them, descending, with a stable sort,
+ * like _fuse's sorted(); a list without scores is taken as ranked); a hit's id is first seen => it enters the result with score
  * weight / (k + rank) — evaluated as (1.0 / (k + rank)) * weight in f64, like the Python expression — else the term is
  * added to its score; then a stable sort by score descending (ties keep first-seen order) and the first `window` hits.
  * A query with exactly one non-empty list returns that list unchanged with its own scores (fuse(): "one non-empty

@@ -24,6 +24,7 @@ NIDX_ERR_INVALID_GRAPH = -8
 NIDX_ERR_INEXACT = -9
 NIDX_ERR_OUT_OF_MEMORY = -10
 NIDX_ERR_INTERNAL = -11
+NIDX_ERR_BUSY = -12
 
 SIMILARITY_DOT, SIMILARITY_COSINE = 0, 1
 METHOD_AUTO, METHOD_HNSW, METHOD_BRUTE_FORCE, METHOD_BRUTE_FORCE_MFMA, METHOD_BRUTE_FORCE_BF16 = 0, 1, 2, 3, 4
@@ -124,6 +125,14 @@ class RankedListC(C.Structure):
     _fields_ = [("ids", C.c_void_p), ("scores", C.c_void_p), ("counts", C.c_void_p), ("stride", C.c_uint32), ("weight", C.c_double)]
 
 
+class FacetCountC(C.Structure):
+    _fields_ = [("group", C.c_void_p), ("group_len", C.c_uint32), ("tag", C.c_void_p), ("tag_len", C.c_uint32), ("total", C.c_int32)]
+
+
+MERGE_ORDER_SCORE, MERGE_ORDER_VALUE_DESC, MERGE_ORDER_VALUE_ASC = 0, 1, 2
+SHARD_COMM_ID_BYTES = 128
+
+
 class FilterOpC(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_uint32), ("b", C.c_uint32)]
 
@@ -214,6 +223,10 @@ SIGNATURES = {
                                                                 C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_vector_search_one": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_vector_search_submit": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
+                                                  C.POINTER(C.c_uint64)]),
+    "nidx_gpu_vector_search_wait": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.c_uint32)]),
     "nidx_gpu_vector_spill_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "nidx_gpu_vector_coalescer_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nidx_gpu_use_hnsw": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32]),
@@ -260,6 +273,22 @@ SIGNATURES = {
                                           C.c_void_p, C.POINTER(C.c_uint32)]),
     "nidx_gpu_merge_vector_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_merge_bm25_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]),
+    "nidx_gpu_merge_vector_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_merge_bm25_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_merge_facets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "nidx_gpu_shard_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "nidx_gpu_shard_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "nidx_gpu_shard_comm_destroy": (None, [C.c_void_p]),
+    "nidx_gpu_shard_exchange_merge_vector": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_shard_exchange_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                       C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p]),
     "nidx_gpu_rank_fusion_rrf": (C.c_int32, [C.POINTER(RankedListC), C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),

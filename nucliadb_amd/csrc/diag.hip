@@ -111,8 +111,13 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
     std::atomic<uint32_t> ready{0};
     std::chrono::steady_clock::time_point t0;
     std::vector<std::thread> pool;
-    for (uint32_t t = 0; t < threads; t++)
-        pool.emplace_back([&, t]() {
+    pool.reserve(threads);
+    // nothing may leave a worker thread as an exception (std::terminate, not an error code), and a thread that cannot be started
+    // must not strand the ones already spinning at the start line
+    std::atomic<uint32_t> started{0};
+    std::atomic<bool> abort_run{false};
+    auto worker = [&](uint32_t t) {
+        try {
             (void)hipSetDevice(dev);
             const uint32_t k = params->k;
             std::vector<uint32_t> seg(k), par(k), vec(k);
@@ -121,7 +126,8 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
             int32_t r = nidx_gpu_vector_search_one(index, queries + (size_t)(t % n_queries) * dimension, dimension, params, seg.data(), par.data(),
                                                    vec.data(), score.data(), &count);
             if (ready.fetch_add(1) + 1 == threads) t0 = std::chrono::steady_clock::now();
-            while (ready.load() < threads) std::this_thread::yield();
+            while (ready.load() < threads && !abort_run.load()) std::this_thread::yield();
+            if (abort_run.load()) return;
             if (r != NIDX_OK) { rc[t] = r; return; }
             for (uint32_t c = t; c < calls; c += threads) {
                 const auto a = std::chrono::steady_clock::now();
@@ -130,8 +136,27 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
                 latencies_us_out[c] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
                 if (r != NIDX_OK) { rc[t] = r; return; }
             }
-        });
+        } catch (const std::bad_alloc &) {
+            rc[t] = NIDX_ERR_OUT_OF_MEMORY;
+            ready.fetch_add(1);
+        } catch (...) {
+            rc[t] = NIDX_ERR_INTERNAL;
+            ready.fetch_add(1);
+        }
+    };
+    int32_t spawn_rc = NIDX_OK;
+    for (uint32_t t = 0; t < threads; t++) {
+        try {
+            pool.emplace_back(worker, t);
+            started.fetch_add(1);
+        } catch (...) {
+            spawn_rc = fail(NIDX_ERR_INTERNAL, "could not start probe thread %u of %u", t, threads);
+            abort_run.store(true);
+            break;
+        }
+    }
     for (auto &th : pool) th.join();
+    if (spawn_rc != NIDX_OK) return spawn_rc;
     if (elapsed_s_out) *elapsed_s_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t t = 0; t < threads; t++)
         if (rc[t] != NIDX_OK) return rc[t];

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
         __syncthreads();
     }
     // ---- layer 0 with ef = max(k, EF_SEARCH) (search.rs:333-349) ----
-    const int ef = k > NIDX_EF_SEARCH ? k : NIDX_EF_SEARCH;
+    const int efs = a.ef_search ? (int)a.ef_search : NIDX_EF_SEARCH;
+    const int ef = k > efs ? k : efs;
     if (!entry_mode) layer_search_block<NJ, EFL, EVR>(a.seg, a.g, 0, ef, q, sh, vis, a.vis_log2, res, st);
     if (a.dump_vec) {
         // spill path: the walk below runs in hnsw_closest_spill_kernel, from these candidates
@@ -271,9 +272,14 @@ static hipError_t launch_v(const HnswSearchArgs &a, int waves, hipStream_t s) {
     return hipGetLastError();
 }
 
+static uint32_t layer0_ef(const HnswSearchArgs &a) {
+    const uint32_t efs = a.ef_search ? a.ef_search : NIDX_EF_SEARCH;
+    return a.k > efs ? a.k : efs;
+}
+
 template <int NJ>
 static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
-    const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
+    const uint32_t ef = layer0_ef(a);
     // large result pages (ef > 64) are the rare path: one shape each
     if (ef > 256) return launch_v<NJ, 2, 2, 8>(a, waves, s);
     if (ef > 128) return launch_v<NJ, 2, 2, 4>(a, waves, s);
@@ -289,7 +295,7 @@ static hipError_t launch_nj(const HnswSearchArgs &a, int waves, hipStream_t s) {
 
 template <int NJ>
 static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s) {
-    const uint32_t ef = a.k > NIDX_EF_SEARCH ? a.k : NIDX_EF_SEARCH;
+    const uint32_t ef = layer0_ef(a);
     if (ef > 256) return launch_v<NJ, 2, 1, 8>(a, waves, s);
     if (ef > 128) return launch_v<NJ, 2, 1, 4>(a, waves, s);
     if (ef > 64) return launch_v<NJ, 2, 1, 2>(a, waves, s);
@@ -298,7 +304,7 @@ static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s)
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    if (a.k == 0 || a.k > NIDX_K_MAX) return hipErrorInvalidValue;
+    if (a.k == 0 || a.k > NIDX_K_MAX || a.ef_search > NIDX_K_MAX) return hipErrorInvalidValue;
     int nj = (int)((a.seg.dp + 255u) / 256u);
     if (waves_per_query < 1) waves_per_query = 1;
     if (waves_per_query > 4) waves_per_query = 4;

@@ -170,6 +170,9 @@ struct HnswSearchArgs {
     // nullptr or [1]: every query that raises a NIDX_FLAG_* ORs it in here too (one atomic, only when a flag was raised), so
     // a caller that did not ask for per-query counters can tell with one word whether the launch needs the exact fallback
     uint32_t *flag_word = nullptr;
+    // 0 = the reference's EF_SEARCH (hnsw/params.rs:46); the layer-0 search keeps ef = max(k, ef_search) results.  Only the
+    // "ef_search" tunable sets it: a flat 10 M graph trades ef against the recall the reference gets from merging 50 segments
+    uint32_t ef_search = 0;
 };
 #define NIDX_DUMP_STRIDE 512
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);

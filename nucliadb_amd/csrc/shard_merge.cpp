@@ -200,6 +200,86 @@ int32_t nidx_gpu_merge_bm25(const float *const *scores, const uint64_t *const *d
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
+// ---- the same merges for a whole batch in host memory (layout of the device forms: [n_lists][n_queries][k]) ---------------------
+int32_t nidx_gpu_merge_vector_batch(const float *scores, const uint64_t *ids, const uint32_t *counts, uint32_t n_lists, uint32_t n_queries,
+                                    uint32_t k, uint32_t limit, float *out_score, uint64_t *out_id, uint32_t *out_count) try {
+    if (!out_count || (n_lists && n_queries && (!scores || !ids || !counts))) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<Head> order;
+    std::vector<uint32_t> lens(n_lists);
+    for (uint32_t q = 0; q < n_queries; q++) {
+        for (uint32_t l = 0; l < n_lists; l++) lens[l] = std::min(counts[(size_t)l * n_queries + q], k);
+        auto at = [&](const Head &h) { return ((size_t)h.list * n_queries + q) * k + h.pos; };
+        auto first = [&](const Head &a, const Head &b) { return scores[at(a)] >= scores[at(b)]; };
+        const uint32_t n = kmerge(lens.data(), n_lists, limit, first, order);
+        for (uint32_t i = 0; i < n; i++) {
+            if (out_score) out_score[(size_t)q * limit + i] = scores[at(order[i])];
+            if (out_id) out_id[(size_t)q * limit + i] = ids[at(order[i])];
+        }
+        out_count[q] = n;
+    }
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_merge_bm25_batch(const float *scores, const uint64_t *docaddrs, const int64_t *order_values, const uint32_t *counts,
+                                  const uint8_t *const *shard_ids, const uint32_t *shard_id_lens, uint32_t n_lists, uint32_t n_queries,
+                                  uint32_t k, uint32_t limit, int32_t order_by, float *out_score, uint64_t *out_docaddr,
+                                  int64_t *out_order_value, uint32_t *out_list, uint32_t *out_count) try {
+    if (!out_count || (n_lists && (!shard_ids || !shard_id_lens)) || (n_lists && n_queries && (!scores || !docaddrs || !counts)))
+        return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (order_by < 0 || order_by > NIDX_MERGE_ORDER_VALUE_ASC) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown merge order %d", order_by);
+    if (order_by != NIDX_MERGE_ORDER_SCORE && !order_values) return fail(NIDX_ERR_INVALID_ARGUMENT, "ordering by value needs order_values");
+    std::vector<Head> order;
+    std::vector<uint32_t> lens(n_lists);
+    for (uint32_t q = 0; q < n_queries; q++) {
+        for (uint32_t l = 0; l < n_lists; l++) lens[l] = std::min(counts[(size_t)l * n_queries + q], k);
+        auto at = [&](const Head &h) { return ((size_t)h.list * n_queries + q) * k + h.pos; };
+        auto first = [&](const Head &a, const Head &b) {
+            if (order_by == NIDX_MERGE_ORDER_VALUE_DESC) return order_values[at(a)] > order_values[at(b)];
+            if (order_by == NIDX_MERGE_ORDER_VALUE_ASC) return order_values[at(a)] < order_values[at(b)];
+            const int32_t ka = total_key(scores[at(a)]), kb = total_key(scores[at(b)]);
+            if (ka != kb) return ka > kb;
+            const int c = cmp_bytes(shard_ids[a.list], shard_id_lens[a.list], shard_ids[b.list], shard_id_lens[b.list]);
+            if (c) return c > 0;
+            return docaddrs[at(a)] < docaddrs[at(b)];
+        };
+        const uint32_t n = kmerge(lens.data(), n_lists, limit, first, order);
+        for (uint32_t i = 0; i < n; i++) {
+            if (out_score) out_score[(size_t)q * limit + i] = scores[at(order[i])];
+            if (out_docaddr) out_docaddr[(size_t)q * limit + i] = docaddrs[at(order[i])];
+            if (out_order_value && order_values) out_order_value[(size_t)q * limit + i] = order_values[at(order[i])];
+            if (out_list) out_list[(size_t)q * limit + i] = order[i].list;
+        }
+        out_count[q] = n;
+    }
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+// ---- merge_facets (shard_merge.rs:380-414) ----------------------------------------------------------------------------------------
+int32_t nidx_gpu_merge_facets(const nidx_gpu_facet_count_t *const *shard_facets, const uint32_t *shard_lens, uint32_t n_shards,
+                              nidx_gpu_facet_count_t *out, uint32_t capacity, uint32_t *n_out) try {
+    if (!n_out || (n_shards && (!shard_facets || !shard_lens)) || (capacity && !out)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<nidx_gpu_facet_count_t> all;
+    for (uint32_t s = 0; s < n_shards; s++)
+        for (uint32_t i = 0; i < shard_lens[s]; i++) all.push_back(shard_facets[s][i]);
+    auto cmp = [](const nidx_gpu_facet_count_t &a, const nidx_gpu_facet_count_t &b) {
+        const int g = cmp_bytes(a.group, a.group_len, b.group, b.group_len);
+        return g ? g : cmp_bytes(a.tag, a.tag_len, b.tag, b.tag_len);
+    };
+    // counts.entry((group, tag)).and_modify(|total| *total += ..).or_insert(..): equal keys are summed (i32, wrapping like release Rust)
+    std::stable_sort(all.begin(), all.end(), [&](const nidx_gpu_facet_count_t &a, const nidx_gpu_facet_count_t &b) { return cmp(a, b) < 0; });
+    uint32_t n = 0;
+    for (size_t i = 0; i < all.size();) {
+        nidx_gpu_facet_count_t acc = all[i];
+        size_t j = i + 1;
+        for (; j < all.size() && cmp(all[j], acc) == 0; j++) acc.total = (int32_t)((uint32_t)acc.total + (uint32_t)all[j].total);
+        if (n < capacity) out[n] = acc;
+        n++;
+        i = j;
+    }
+    *n_out = n;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
 // ---- rank fusion (nucliadb rank_fusion.py:60-181), batched on the host -----------------------------------------------------------
 int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window,
                                  uint64_t *out_ids, double *out_scores, uint32_t *out_counts) try {
@@ -207,18 +287,9 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     for (uint32_t l = 0; l < n_lists; l++)
         if (!lists[l].counts || (lists[l].stride && !lists[l].ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: NULL arrays", l);
     struct Item { uint64_t id; double score; };
-    // _fuse ranks every source by its OWN scores, descending (a stable sort; rank_fusion.py:139-147): callers hand the lists
-    // over ranked, and a list that carries scores is checked — an unsorted one would silently fuse with wrong ranks
-    for (uint32_t l = 0; l < n_lists; l++) {
-        const nidx_gpu_ranked_list_t &L = lists[l];
-        if (!L.scores) continue;
-        for (uint32_t q = 0; q < n_queries; q++) {
-            const uint32_t c = std::min(L.counts[q], L.stride);
-            for (uint32_t r = 1; r < c; r++)
-                if (L.scores[(size_t)q * L.stride + r] > L.scores[(size_t)q * L.stride + r - 1])
-                    return fail(NIDX_ERR_INVALID_ARGUMENT, "rank fusion: list %u of query %u is not sorted by score (rank %u)", l, q, r);
-        }
-    }
+    // _fuse ranks every source by its OWN scores, descending, with a stable sort (rank_fusion.py:139-147): a list that carries
+    // scores and is not already in that order (BM25 hits ordered by a fast field, say) is ranked through a per-query
+    // permutation below; a list without scores is taken as ranked
     // Queries are independent: ranges of them go to worker threads (a batch of 1024 hybrid queries spends more time here than in
     // either search kernel otherwise).  Inside a range: first-seen position of every id of one query by open addressing (sized for
     // the query's hits), then a stable order by fused score — an insertion sort for the usual few dozen hits.
@@ -227,7 +298,7 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     auto fuse_range = [&](uint32_t q_begin, uint32_t q_end) {
       try {
         std::vector<Item> acc;
-        std::vector<uint32_t> order, slot_at;
+        std::vector<uint32_t> order, slot_at, perm;
         std::vector<uint64_t> slot_id;
         for (uint32_t q = q_begin; q < q_end; q++) {
             uint32_t non_empty = 0, only = 0;
@@ -252,8 +323,20 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
                 for (uint32_t l = 0; l < n_lists; l++) {
                     const nidx_gpu_ranked_list_t &L = lists[l];
                     const uint32_t c = std::min(L.counts[q], L.stride);
+                    // sorted(values, key=score, reverse=True): only when the list is not in that order already
+                    bool ranked = true;
+                    if (L.scores)
+                        for (uint32_t r = 1; r < c && ranked; r++)
+                            ranked = !(L.scores[(size_t)q * L.stride + r] > L.scores[(size_t)q * L.stride + r - 1]);
+                    if (!ranked) {
+                        perm.resize(c);
+                        for (uint32_t i = 0; i < c; i++) perm[i] = i;
+                        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+                            return L.scores[(size_t)q * L.stride + a] > L.scores[(size_t)q * L.stride + b];
+                        });
+                    }
                     for (uint32_t r = 0; r < c; r++) {
-                        const uint64_t id = L.ids[(size_t)q * L.stride + r];
+                        const uint64_t id = L.ids[(size_t)q * L.stride + (ranked ? r : perm[r])];
                         const double term = (1.0 / (k + (double)r)) * L.weight;
                         size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 32) & (cap - 1);
                         while (slot_at[h] != 0xffffffffu && slot_id[h] != id) h = (h + 1) & (cap - 1);

@@ -329,6 +329,7 @@ int32_t VectorIndex::segment_spill_search(uint32_t s, const float *d_queries, ui
         a.dump_vec = scratch_dump_vec.as<uint32_t>();
         a.dump_score = scratch_dump_score.as<float>();
         a.dump_count = scratch_dump_count.as<uint32_t>();
+        a.ef_search = ef_search;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
         NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, st));
@@ -431,6 +432,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         a.dump_score = nullptr;
         a.dump_count = nullptr;
         a.flag_word = d_flag_word;
+        a.ef_search = ef_search;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -962,17 +964,57 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     }
 
     trace.t_searched = now_us();
-    // Fssc per query
+    std::vector<const uint32_t *> pv(S), pc(S);
+    std::vector<const float *> ps(S);
+    for (size_t s = 0; s < S; s++) {
+        const bool any = !hv[s].empty();
+        pv[s] = any ? hv[s].data() : nullptr;
+        ps[s] = any ? hs[s].data() : nullptr;
+        pc[s] = any ? hc[s].data() : nullptr;
+    }
+    return fssc_merge(nq, p, pv.data(), ps.data(), pc.data(), out_segment, out_paragraph, out_vector, out_score, out_count);
+}
+
+// ---- Fssc (searcher.rs:149-199): the k best across segments, one hit per paragraph key --------------------------------
+// seg_vec / seg_score: [n_segments] pointers to [nq][k] rows (nullptr = the segment was not searched), seg_count: [nq].
+int32_t VectorIndex::fssc_merge(uint32_t nq, const nidx_gpu_vector_search_params_t &p, const uint32_t *const *seg_vec,
+                                const float *const *seg_score, const uint32_t *const *seg_count, uint32_t *out_segment,
+                                uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count) {
+    const uint32_t k = p.k;
+    const size_t S = segs.size();
+    // One segment whose paragraph identities are its addresses, a query whose scores fall strictly: every hit enters the buffer
+    // (<= k candidates with distinct keys: nothing is evicted or rejected, equal vector bytes would mean equal scores) and the
+    // final sort leaves the kernel's order — the general loop below would copy the row unchanged.
+    const bool one_plain_segment = S == 1 && seg_count[0] && segs[0].key_ids.empty();
     std::vector<Cand> buff, offered;
     for (uint32_t q = 0; q < nq; q++) {
+        if (one_plain_segment) {
+            const uint32_t cnt = seg_count[0][q];
+            const float *sc = seg_score[0] + (size_t)q * k;
+            bool falling = cnt <= k;
+            for (uint32_t i = 1; i < cnt && falling; i++) falling = sc[i - 1] > sc[i];
+            if (cnt == 1) falling = sc[0] == sc[0];
+            if (falling) {
+                const uint32_t *vv = seg_vec[0] + (size_t)q * k;
+                out_count[q] = cnt;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    if (out_segment) out_segment[(size_t)q * k + i] = 0;
+                    if (out_paragraph) out_paragraph[(size_t)q * k + i] = segs[0].para_host.empty() ? vv[i] : segs[0].para_host[vv[i]];
+                    if (out_vector) out_vector[(size_t)q * k + i] = vv[i];
+                    if (out_score) out_score[(size_t)q * k + i] = sc[i];
+                }
+                continue;
+            }
+        }
         buff.clear();
         offered.clear();
         for (size_t s = 0; s < S; s++) {
-            for (uint32_t i = 0; i < hc[s][q]; i++) {
+            if (!seg_count[s]) continue;
+            for (uint32_t i = 0; i < seg_count[s][q]; i++) {
                 Cand c;
-                c.score = hs[s][(size_t)q * k + i];
+                c.score = seg_score[s][(size_t)q * k + i];
                 c.seg = (uint32_t)s;
-                c.vec = hv[s][(size_t)q * k + i];
+                c.vec = seg_vec[s][(size_t)q * k + i];
                 c.para = segs[s].para_host.empty() ? c.vec : segs[s].para_host[c.vec];
                 c.key = segs[s].key_ids.empty() ? (((uint64_t)s << 32) | c.para) : segs[s].key_ids[c.para];
                 if (!p.with_duplicates) {
@@ -1021,6 +1063,10 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     return NIDX_OK;
 }
 
+uint64_t VectorIndex::popcount_filter(uint32_t s, const uint64_t *filt) const {
+    return popcount_and(segs[s].alive_host.data(), filt, segs[s].n_paragraphs);
+}
+
 }  // namespace nidx
 
 // =====================================================================================================
@@ -1040,7 +1086,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len) try {
     return (int32_t)have;
 } NIDX_ABI_CATCH
 
-int32_t nidx_gpu_abi_version(void) { return 3; }
+int32_t nidx_gpu_abi_version(void) { return 4; }
 
 int32_t nidx_gpu_device_count(int32_t *count_out) try {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");
@@ -1107,9 +1153,15 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
     else if (n == "min_waves") { idx->min_waves = value >= 4 ? std::min(6, (int)value) : 2; idx->shape_pinned = true; }
     else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
-    else if (n == "coalesce_window_us") idx->coalescer_config(value, -1);
-    else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value);
+    else if (n == "coalesce_window_us") idx->coalescer_config(value, -1, -1);
+    else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value, -1);
+    else if (n == "coalesce_in_flight") idx->coalescer_config(-1, -1, value);
+    else if (n == "pipeline_depth") idx->pipeline_config(value);
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else if (n == "ef_search") {   // 0 = the reference's EF_SEARCH (30)
+        if (value < 0 || value > NIDX_K_MAX) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_search must be in 0..%d", NIDX_K_MAX);
+        idx->ef_search = (uint32_t)value;
+    }
     else return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown tunable %s", name);
     return NIDX_OK;
 } NIDX_ABI_CATCH

@@ -57,6 +57,8 @@ struct VectorSegment {
 
 struct Coalescer;
 std::shared_ptr<Coalescer> make_coalescer();
+struct Pipeline;
+std::shared_ptr<Pipeline> make_pipeline();
 double trace_slow_us();  // NIDX_GPU_TRACE_SLOW_US  // coalescer.cpp
 
 struct VectorIndex {
@@ -72,6 +74,7 @@ struct VectorIndex {
             (void)hipStreamDestroy(stream);
         }
         if (scratch_event) (void)hipEventDestroy(scratch_event);
+        pipe.reset();   // synchronises and destroys the slot streams before the segments they read go away
     }
     std::mutex mu;
     std::vector<VectorSegment> segs;
@@ -85,6 +88,7 @@ struct VectorIndex {
     // (batch 1: 0.48 -> 0.43 ms, batch 64: 0.65 -> 0.57 ms at 1 M x 768); large batches keep 2 rows / 128 VGPRs (16 waves per CU)
     int rows_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 4 : eval_rows; }
     int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : min_waves; }
+    uint32_t ef_search = 0;   // 0 = EF_SEARCH (hnsw/params.rs:46); tunable "ef_search"
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
@@ -130,6 +134,18 @@ struct VectorIndex {
                         const uint64_t *const *segment_filters, const nidx_gpu_filter_program_t *programs,
                         uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
                         uint32_t *out_count, int32_t *out_method, uint64_t *out_matching);
+    // Fssc over per-segment result rows (nullptr = segment not searched); shared by search_host and the pipeline's wait
+    int32_t fssc_merge(uint32_t nq, const nidx_gpu_vector_search_params_t &p, const uint32_t *const *seg_vec, const float *const *seg_score,
+                       const uint32_t *const *seg_count, uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector,
+                       float *out_score, uint32_t *out_count);
+    uint64_t popcount_filter(uint32_t s, const uint64_t *filt) const;   // |filt ∩ alive| of segment s
+    // pipelined serving (serving.cpp): batches in flight on their own streams, results delivered to pinned host memory
+    std::shared_ptr<Pipeline> pipe = make_pipeline();
+    int32_t pipeline_submit(const float *queries, uint32_t nq, const nidx_gpu_vector_search_params_t &p,
+                            const uint64_t *const *segment_filters, bool blocking, uint64_t *ticket_out);
+    int32_t pipeline_wait(uint64_t ticket, uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
+                          uint32_t *out_count, uint32_t *n_retried_out);
+    void pipeline_config(int32_t depth);
     // evaluates `prog` for segment s into scratch_filter (already intersected with alive); returns |filter ∩ alive|
     int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed, bool extend = false);
@@ -142,7 +158,7 @@ struct VectorIndex {
     int32_t search_one(const float *query, const nidx_gpu_vector_search_params_t &p, uint32_t *out_segment,
                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
     void coalescer_stats(uint64_t &batches, uint64_t &queries);
-    void coalescer_config(int32_t window_us, int32_t max_batch);
+    void coalescer_config(int32_t window_us, int32_t max_batch, int32_t in_flight);
 };
 
 }  // namespace nidx

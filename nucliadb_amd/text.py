@@ -838,7 +838,6 @@ class ParagraphSearcher:
 
     def __init__(self, index: _Index, stop_words: Optional[Set[str]] = None):
         self._index = index
-        self._prefilter: Optional[PrefilterResult] = None
         # the reference removes the stop words of eight languages (query_parser/stop_words/*.json, data files that
         # are not copied here): pass the union of those lists to get the same query
         self.stop_words = stop_words
@@ -919,8 +918,10 @@ class ParagraphSearcher:
                 prefilter_sets(new_group())
         return out
 
-    def _filters(self, request: ParagraphSearchRequest, boost: float) -> List[Clause]:
-        musts = self._filter_query(request, self._prefilter, boost)
+    def _filters(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult], boost: float) -> List[Clause]:
+        # the prefilter is per request (it carries the field / security verdict): it travels as an argument, never through
+        # the searcher, which concurrent requests share
+        musts = self._filter_query(request, prefilter, boost)
         for lab in request.label_filter or []:
             musts.append(Clause(self._index.term("\x00label:" + lab), _lib.OCCUR_MUST, _lib.TF_BASIC, boost))
         if not request.with_duplicates:  # Must TermQuery(repeated_in_field = 0, Basic) (search_query.rs:218-223)
@@ -938,7 +939,7 @@ class ParagraphSearcher:
             return Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.TF_FREQ, boost, term_set=[self._index.term(w) for w in words], phrase=True)
         return Clause(self._index.term(text), _lib.OCCUR_SHOULD_GROUP, _lib.TF_BASIC, boost)
 
-    def _clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
+    def _clauses(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult] = None) -> List[Clause]:
         """The keyword query (keyword_parser.rs:27-105 under search_query.rs:185-243)."""
         tokens = self._tokens(request)
         clauses = []
@@ -947,17 +948,17 @@ class ParagraphSearcher:
         # TermQuery(text, IndexRecordOption::Basic) per literal / one-word quote, Occur::Should, as a required group: the
         # keyword BooleanQuery sits under Occur::Must next to the filters, so a paragraph has to match one of its words
         should = [self._excluded(w, 1.0) if kind == "excluded" else self._word_or_phrase(kind, w, 1.0) for kind, w in tokens]
-        return clauses + should + self._filters(request, 1.0)
+        return clauses + should + self._filters(request, prefilter, 1.0)
 
     def _excluded(self, word: str, boost: float) -> Clause:
         """parse_excluded (keyword_parser.rs:93-105): Should(BooleanQuery[Must AllQuery, MustNot term]) = every paragraph
         that does not contain the word, scored AllQuery's 1.0: the complement of the term's posting list, on the device."""
         return Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.CONST_SCORE, boost, term_set=[self._index.term(word)], complement=True)
 
-    def _fuzzy_clauses(self, request: ParagraphSearchRequest) -> List[Clause]:
+    def _fuzzy_clauses(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult] = None) -> List[Clause]:
         """The fuzzy query (fuzzy_parser.rs:52-123 under search_query.rs:200-240)."""
         tokens = self._tokens(request)
-        some = self._prefilter is not None and self._prefilter.kind == "Some" and self._prefilter.fields
+        some = prefilter is not None and prefilter.kind == "Some" and prefilter.fields
         filters_present = bool(request.label_filter) or not request.with_duplicates or request.filtering_formula is not None or bool(some)
         boost = FUZZY_BOOST if filters_present else 1.0  # BoostQuery(0.5) only wraps a multi-clause Boolean (:229-240)
         last_literal = max((i for i, t in enumerate(tokens) if t[0] == "literal"), default=None)
@@ -974,7 +975,7 @@ class ParagraphSearcher:
             prefix = i == last_literal and len(w.encode("utf-8")) >= MIN_FUZZY_PREFIX_LEN
             members = self._index.fuzzy_terms(w, prefix) or [self._index.empty_term]
             clauses.append(Clause(0, _lib.OCCUR_SHOULD_GROUP, _lib.CONST_SCORE, boost, term_set=members))
-        return clauses + self._filters(request, boost)
+        return clauses + self._filters(request, prefilter, boost)
 
     def _run(self, request: ParagraphSearchRequest, clauses: List[Clause], fuzzy: bool) -> ParagraphSearchResponse:
         """Searcher::do_search (reader.rs:244-348) + the response assembly (search_response.rs:218-311)."""
@@ -1013,8 +1014,7 @@ class ParagraphSearcher:
         request's field filters (PrefilterResult::{All, None, Some}); None finds nothing by construction."""
         if prefilter is not None and prefilter.kind == "None":
             return ParagraphSearchResponse(0, [], False, request.body, {}, False)
-        self._prefilter = prefilter
-        response = self._run(request, self._clauses(request), False)
+        response = self._run(request, self._clauses(request, prefilter), False)
         if not response.results and request.result_per_page > 0 and request.min_score == 0.0 and not request.only_faceted:
-            response = self._run(request, self._fuzzy_clauses(request), True)
+            response = self._run(request, self._fuzzy_clauses(request, prefilter), True)
         return response

@@ -736,7 +736,8 @@ static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const ui
         free(lr);
         layer--;
     }
-    size_t last_k = k > EF_SEARCH ? k : EF_SEARCH;
+    const size_t ef_search = r->seg->ef_search ? r->seg->ef_search : EF_SEARCH;
+    size_t last_k = k > ef_search ? k : ef_search;
     if (r->rq) { /* RaBitQ: over-fetch, rerank later (:333-340) */
         last_k = k * ORC_RABITQ_RERANKING_FACTOR;
         if (last_k > ORC_RABITQ_RERANKING_LIMIT) last_k = ORC_RABITQ_RERANKING_LIMIT;

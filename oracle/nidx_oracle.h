@@ -70,6 +70,8 @@ typedef struct {
     const uint8_t *quantized;  /* vectors.quant: [n_vectors][dim/8 + 8] RaBitQ records, or NULL.  When set,
                                 * searches take the RaBitQ branches (has_quantized && !DISABLE_RABITQ_SEARCH,
                                 * segment.rs:506-513) */
+    uint32_t ef_search;        /* 0 = the reference's constant EF_SEARCH = 30 (hnsw/params.rs:46); another value only for the
+                                * bench's iso-recall leg (the flat graph at the ef whose recall matches the segmented regime) */
 } orc_segment;
 
 typedef struct {

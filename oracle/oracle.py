@@ -46,6 +46,7 @@ class _Segment(C.Structure):
         ("alive", C.c_void_p),
         ("graph", C.c_void_p),
         ("quantized", C.c_void_p),
+        ("ef_search", C.c_uint32),
     ]
 
 
@@ -473,6 +474,7 @@ class Segment:
         self.graph = graph
         # vectors.quant (RaBitQ records); when set every search takes the reference's RaBitQ branch
         self.quantized = None if quantized is None else np.ascontiguousarray(quantized, dtype=np.uint8)
+        self.ef_search = 0   # 0 = the reference's EF_SEARCH (30)
 
     def quantize(self):
         """DataStoreV2::create's quantized writer (data_store/v2.rs:57-76): encode every vector."""
@@ -491,6 +493,7 @@ class Segment:
         s.alive = None if self.alive is None else self.alive.ctypes.data
         s.graph = None if self.graph is None else self.graph.h
         s.quantized = None if self.quantized is None else self.quantized.ctypes.data
+        s.ef_search = self.ef_search
         return s
 
     def build_graph(self, seed: int = 2) -> Hnsw:

@@ -23,12 +23,12 @@ def L():
 def test_exports_every_declared_symbol(L):
     header = open(os.path.join(ROOT, "include", "nidx_gpu.h")).read()
     declared = set(re.findall(r"\b(nidx_gpu_[a-z0-9_]+)\s*\(", header))
-    declared -= {"nidx_gpu_vector_index_t", "nidx_gpu_bm25_index_t"}
+    declared -= {"nidx_gpu_vector_index_t", "nidx_gpu_bm25_index_t", "nidx_gpu_shard_comm_t"}
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/nidx_gpu.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.nidx_gpu_abi_version() == 3
+    assert L.nidx_gpu_abi_version() == 4
 
 
 def test_no_cpu_fallback_when_device_missing(L):
@@ -169,7 +169,7 @@ _STRUCTS = {
     "nidx_gpu_bm25_segment_t": "Bm25SegmentC", "nidx_gpu_bm25_clause_t": "Bm25ClauseC",
     "nidx_gpu_bm25_search_after_t": "Bm25SearchAfterC", "nidx_gpu_bm25_search_options_t": "Bm25SearchOptionsC",
     "nidx_gpu_bm25_date_range_t": "Bm25DateRangeC", "nidx_gpu_bm25_prefilter_t": "Bm25PrefilterC",
-    "nidx_gpu_ranked_list_t": "RankedListC",
+    "nidx_gpu_ranked_list_t": "RankedListC", "nidx_gpu_facet_count_t": "FacetCountC",
 }
 
 

@@ -50,3 +50,150 @@ def test_host_merge_matches_oracle(orc):
 @pytest.mark.gpu
 def test_device_merge_matches_oracle(orc):
     _check(orc, torch.device("cuda", 0))
+
+
+# ---- BM25 merges: sort_documents_fn / sort_paragraphs_fn (shard_merge.rs:211-250,289-329) for a whole batch -----------------------
+SHARD_IDS = [b"shard-b", b"shard-a", b"shard", b"shard-c", b"", b"t", b"shard-b", b"zz"]   # a prefix, an empty id, two equal ids
+
+
+def _bm25_lists(P, B, k, seed):
+    rng = np.random.default_rng(seed)
+    score = np.zeros((P, B, k), np.float32)
+    addr = np.zeros((P, B, k), np.int64)
+    value = np.zeros((P, B, k), np.int64)
+    count = rng.integers(0, k + 1, (P, B)).astype(np.int32)
+    if B > 1:
+        count[:, 0] = 0
+        count[:, 1] = k
+    for p in range(P):
+        for q in range(B):
+            c = int(count[p, q])
+            score[p, q, :c] = np.sort(rng.integers(0, 5, c).astype(np.float32) / 2)[::-1]
+            addr[p, q, :c] = np.sort(rng.integers(0, 40, c))            # same docaddr in several shards: the shard id decides
+            value[p, q, :c] = np.sort(rng.integers(-3, 4, c))[::-1]     # dates, descending inside a shard
+    return score, addr, value, count
+
+
+def _check_bm25(orc, device):
+    import __graft_entry__ as g
+    from nucliadb_amd import _lib
+    from nucliadb_amd.shard_merge import merge_bm25_lists
+
+    g.build()
+    for P, B, k, limit in ((1, 4, 10, 10), (2, 130, 10, 10), (4, 64, 10, 25), (8, 70, 20, 7), (3, 1, 4, 50)):
+        score, addr, value, count = _bm25_lists(P, B, k, 2000 + P)
+        ids = SHARD_IDS[:P]
+        t = lambda a: torch.from_numpy(a).to(device)
+        ms, ma, ml, mc = [x.cpu().numpy() for x in merge_bm25_lists(t(score), t(addr), t(count), ids, limit)]
+        for q in range(B):
+            lists = [[(float(score[p, q, i]), int(addr[p, q, i]), ids[p], p) for i in range(count[p, q])] for p in range(P)]
+            want = orc.merge_bm25(lists, limit)
+            got = [(float(ms[q, i]), int(ma[q, i]), ids[int(ml[q, i])]) for i in range(mc[q])]
+            assert got == [(w[0], w[1], w[2]) for w in want], (P, B, k, limit, q)
+        # SortExpr::Date: strictly greater (descending) / smaller (ascending) value first, ties in kmerge's heap order —
+        # the expectation is the host per-query merge driven with the value as the only key (score = value, one shard id)
+        for order, sign in ((_lib.MERGE_ORDER_VALUE_DESC, 1), (_lib.MERGE_ORDER_VALUE_ASC, -1)):
+            v = value if sign == 1 else -value   # lists must arrive in the requested order
+            vs, va, vl, vc, vv = [x.cpu().numpy() for x in merge_bm25_lists(t(score), t(addr), t(count), ids, limit, g_value=t(np.ascontiguousarray(v)), order=order)]
+            for q in range(B):
+                # kmerge with first(a, b) = a.value > b.value (desc) == merge_vector's `>=` only without ties; build the expectation
+                # by a direct restatement of itertools' kmerge on the keys
+                heads = [[int(v[p, q, i]) for i in range(count[p, q])] for p in range(P)]
+                want = _kmerge_strict(heads, limit, desc=(sign == 1))
+                got = [(int(vl[q, i]), int(vv[q, i])) for i in range(vc[q])]
+                assert got == want, (order, P, B, q, got, want)
+
+
+def _kmerge_strict(lists, limit, desc):
+    """itertools::kmerge_by with first(a, b) = a > b (desc) / a < b (asc): heap of (list, pos) heads, sift_down after every pop."""
+    heap = [[l, 0] for l in range(len(lists)) if lists[l]]
+    val = lambda h: lists[h[0]][h[1]]
+    first = (lambda a, b: val(a) > val(b)) if desc else (lambda a, b: val(a) < val(b))
+
+    def sift_down(n, index):
+        pos, child = index, 2 * index + 1
+        while child + 1 < n:
+            if first(heap[child + 1], heap[child]):
+                child += 1
+            if not first(heap[child], heap[pos]):
+                return
+            heap[pos], heap[child] = heap[child], heap[pos]
+            pos, child = child, 2 * child + 1
+        if child + 1 == n and first(heap[child], heap[pos]):
+            heap[pos], heap[child] = heap[child], heap[pos]
+
+    n = len(heap)
+    for i in range(n // 2 - 1, -1, -1):
+        sift_down(n, i)
+    out = []
+    while n > 0 and len(out) < limit:
+        h = heap[0]
+        out.append((h[0], val(h)))
+        if h[1] + 1 < len(lists[h[0]]):
+            h[1] += 1
+        else:
+            heap[0] = heap[n - 1]
+            n -= 1
+        sift_down(n, 0)
+    return out
+
+
+def test_host_bm25_batch_merge_matches_oracle(orc):
+    _check_bm25(orc, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_device_bm25_merge_matches_oracle(orc):
+    _check_bm25(orc, torch.device("cuda", 0))
+
+
+def test_merge_facets_sums_per_group_and_tag():
+    """merge_facets (shard_merge.rs:380-414): totals of equal (group, tag) summed across shards; the reference's own case
+    (shard_merge.rs tests: two shards sharing one tag) plus disjoint tags, an empty shard, equal tags under different groups."""
+    import __graft_entry__ as g
+    from nucliadb_amd.shard_merge import merge_facets
+
+    g.build()
+    shards = [
+        [(b"/l", b"/l/a", 2), (b"/l", b"/l/b", 1), (b"/t", b"/t/x", 7)],
+        [],
+        [(b"/l", b"/l/a", 3), (b"/n", b"/l/a", 5), (b"/t", b"/t/x", 1), (b"/t", b"/t/y", 4)],
+    ]
+    want = {}
+    for s in shards:
+        for grp, tag, total in s:
+            want[(grp, tag)] = want.get((grp, tag), 0) + total
+    got = merge_facets(shards)
+    assert got == [(grp, tag, want[(grp, tag)]) for grp, tag in sorted(want)]
+    assert merge_facets([]) == [] and merge_facets([[], []]) == []
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_world_of_one(orc):
+    """The product's own RCCL path (csrc/shard_comm.cpp) on the one GPU a test box has: communicator of size 1, the packed
+    all-gather and the merge kernels on the gathered block.  A world of one must return every list cut to `limit`."""
+    import __graft_entry__ as g
+    from nucliadb_amd import _lib
+    from nucliadb_amd.shard_merge import ShardComm
+
+    g.build()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    _lib.check(_lib.lib().nidx_gpu_set_device(0))
+    comm = ShardComm(ShardComm.unique_id(), 0, 1, b"shard-0")
+    try:
+        for B, k, limit in ((5, 10, 10), (257, 10, 4), (64, 7, 20)):
+            score, ident, count = _lists(1, B, k, 77)
+            t = lambda a: torch.from_numpy(a[0]).to(dev)
+            ms, mi, mc = [x.cpu().numpy() for x in comm.exchange_merge_vector(t(score), t(ident), t(count), limit)]
+            for q in range(B):
+                n = min(int(count[0, q]), limit)
+                assert mc[q] == n and np.array_equal(ms[q, :n], score[0, q, :n]) and np.array_equal(mi[q, :n], ident[0, q, :n])
+            bs, ba, bv, bc = _bm25_lists(1, B, k, 78)
+            os_, oa, orank, oc, ov = [x.cpu().numpy() for x in comm.exchange_merge_bm25(t(bs), t(ba), t(bc), limit, value=t(bv),
+                                                                                        order=_lib.MERGE_ORDER_VALUE_DESC)]
+            for q in range(B):
+                n = min(int(bc[0, q]), limit)
+                assert oc[q] == n and np.array_equal(ov[q, :n], bv[0, q, :n]) and np.array_equal(oa[q, :n], ba[0, q, :n]) and not orank[q, :n].any()
+    finally:
+        comm.close()
