@@ -117,19 +117,26 @@ def test_native_batched_rrf_equals_the_mirror():
         assert [float(x) for x in got_scores[q, :n]] == [float(w.score) for w in want], q
 
 
-def test_rrf_refuses_unsorted_scored_lists_and_dedups_large_windows():
-    """ranks are positions, so a list that carries scores must arrive sorted by them (rank_fusion.py:139-147 sorts
-    every source first); windows of 500 hits per source are merged through a hash map."""
-    import ctypes as C
-
-    from nucliadb_amd import _lib
+def test_rrf_ranks_scored_lists_by_score_and_dedups_large_windows():
+    """Ranks are positions AFTER `sorted(values, key=score, reverse=True)` (rank_fusion.py:139-147: every source is sorted first,
+    stably): a list that carries scores in another order — BM25 hits ordered by a date field — is ranked by them, not refused
+    (ADVICE r02); windows of 500 hits per source are merged through a hash map."""
     from nucliadb_amd.rank_fusion import rrf_fuse_batch
 
-    ids = np.array([[5, 6, 7]], np.uint64)
-    cnt = np.array([3], np.uint32)
-    bad = np.array([[1.0, 3.0, 2.0]], np.float32)
-    with pytest.raises(_lib.NidxGpuError):
-        rrf_fuse_batch([(ids, cnt, 1.0, bad), (ids, cnt, 1.0, None)], k=60.0, window=3)
+    ids = np.array([[5, 6, 7, 8]], np.uint64)
+    cnt = np.array([4], np.uint32)
+    unsorted = np.array([[1.0, 3.0, 2.0, 3.0]], np.float32)    # ranks by score, stable: 6, 8, 7, 5
+    other = np.array([[9, 5, 6, 0]], np.uint64)
+    f_ids, f_scores, n = rrf_fuse_batch([(ids, cnt, 1.0, unsorted), (other, np.array([3], np.uint32), 2.0, None)], k=60.0, window=8)
+    want = {}
+    for r, i in enumerate([6, 8, 7, 5]):
+        want[i] = want.get(i, 0.0) + 1 / (60.0 + r) * 1.0
+    for r, i in enumerate([9, 5, 6]):
+        want[i] = want.get(i, 0.0) + 1 / (60.0 + r) * 2.0
+    first_seen = [6, 8, 7, 5, 9]
+    order = sorted(first_seen, key=lambda i: -want[i])          # stable: ties keep first-seen order
+    assert n[0] == 5 and [int(i) for i in f_ids[0, :5]] == order
+    assert [float(s) for s in f_scores[0, :5]] == [want[i] for i in order]
     rng = np.random.default_rng(5)
     a = rng.permutation(2000)[:500].astype(np.uint64)[None, :]
     b = rng.permutation(2000)[:500].astype(np.uint64)[None, :]
