@@ -30,13 +30,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Batches in flight live on separate HIP streams; with the runtime's default of 4 hardware queues two of them can land on one
-# queue and serialise (measured: 3 in flight = 2.2 M queries/s with 4 queues, 3.5 M with 8).  Must be set before HIP initialises.
+# queue and serialise (measured: 3 in flight = 2.2 M queries/s with 4 queues, 3.5 M with 8).  libnidx_gpu.so sets GPU_MAX_HW_QUEUES=8
+# itself when it is loaded (csrc/serving.cpp) — main() loads it before torch touches HIP; the line below only covers a fresh
+# checkout, where the library is built after HIP has been initialised.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FAILURES = []          # parity / consistency breaks found on the way: the line is still printed, the exit status is 1
 
 
 def parse():
@@ -61,6 +64,10 @@ def parse():
                    help="hnsw: directory; the device-built hnsw.graph of each corpus is written there and, when present, loaded instead "
                         "of rebuilt (profiling runs: rocprofv3 --pmc crashes over the thousands of dispatches of a 10 M build)")
     p.add_argument("--single-query-calls", type=int, default=2048, help="hnsw: nidx_gpu_vector_search_one calls for the p50/p99 figure (0 = skip)")
+    p.add_argument("--min-timed-s", type=float, default=1.0,
+                   help="the timed pass of --steps steps is repeated until the timed region is at least this long (ms_per_step = mean over all)")
+    p.add_argument("--iso-recall", type=int, default=1, help="hnsw: also time the flat graph at the ef_search whose recall reaches the reference regime's (0 = skip)")
+    p.add_argument("--bm25-block", type=int, default=1, help="hnsw: add the BM25 and hybrid blocks of BASELINE.json configs[2] to the default line (0 = skip)")
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
@@ -88,6 +95,10 @@ def main():
     same_device = os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1"
     if same_device:
         local_rank = 0
+    from nucliadb_amd import _lib as _early
+
+    if os.path.exists(_early.LIB_PATH):
+        _early.lib()   # before the first HIP call of the process: the library's load-time defaults (hardware queues) apply
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -500,13 +511,32 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         _lib.check(L.nidx_gpu_vector_device_flags(h, stream, C.byref(f)))
         return int(f.value)
 
-    def exchange(out):
-        # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
+    comm = None
+    if world > 1 and not os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1":
+        # the product's own exchange (csrc/shard_comm.cpp: RCCL inside the library); torch.distributed only ships the 128-byte id
+        from nucliadb_amd.shard_merge import ShardComm
+
+        idt = torch.zeros(_lib.SHARD_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ShardComm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm = ShardComm(bytes(idt.cpu().numpy().tobytes()), rank, world, b"shard-%02d" % rank)
+
+    def exchange_torch(out):
+        # the same exchange through torch.distributed (cross-check of the product path; the only path with NIDX_BENCH_SAME_DEVICE)
         from nucliadb_amd.shard_merge import exchange_and_merge_vector
 
         ov, osc, oc = out
         ids = (ov.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
         return exchange_and_merge_vector(osc, ids, oc, k)
+
+    def exchange(out, st=None):
+        # K10: all-gather of the per-shard top-k (12 B/hit) + merge_vector_responses on every rank
+        if comm is None:
+            return exchange_torch(out)
+        ov, osc, oc = out
+        ids = (ov.to(torch.int64) & 0xFFFFFFFF) | (rank << 32)
+        return comm.exchange_merge_vector(osc, ids, oc, k, stream=st)
 
     def barrier():
         if world > 1:
@@ -514,64 +544,102 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         torch.cuda.synchronize()
 
     # One launch lasts as long as its longest walk, and on clustered data one query in a thousand walks three times the median:
-    # with a single stream the whole GPU waits for it.  Consecutive batches therefore go to `nfl` streams in turn, each batch into
-    # its own result buffers: the workgroups of batch i + 1 take the slots batch i's finished walks free.  Every batch is still one
-    # launch of B queries; per-launch durations (kernel_ms, the roofline's denominator) are measured on the launch's own stream.
+    # with a single batch at a time the whole GPU waits for it.  `nfl` batches are therefore kept in flight; every batch is still one
+    # launch of B queries.
+    #   N = 1: through the PRODUCT's serving pipeline — nidx_gpu_vector_search_submit (device-resident queries, the library's own
+    #          streams) / nidx_gpu_vector_search_wait (hits in host arrays, flagged queries re-run exactly): the timed region is
+    #          what a host gets from the C ABI, results delivered;
+    #   N > 1: search into device buffers + the library's RCCL exchange (ShardComm) on a side stream, in step order on every rank,
+    #          while the search streams already work on the next batches; a result-buffer set is searched into again only after
+    #          its exchange has finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
     # (the second corpus is bandwidth-bound: overlapping its launches buys ~10 % and doubles every launch's duration, so it runs
     # one launch at a time and its per-launch figures read directly)
-    # With more than one rank a step is search + exchange.  The exchange (three small all-gathers over xGMI + the merge kernel) is
-    # latency-bound and needs none of the compute units, so it runs on a side stream, in step order on every rank, while the
-    # search streams already work on the next batches; a result-buffer set is searched into again only after its exchange has
-    # finished.  NIDX_BENCH_FORCE_EXCHANGE=1 runs this path at world size 1.
     do_exchange = world > 1 or os.environ.get("NIDX_BENCH_FORCE_EXCHANGE") == "1"
     nfl = max(1, a.batches_in_flight) if headline else 1
     main_stream = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else [main_stream]
+    streams = [torch.cuda.Stream() for _ in range(nfl)] if (nfl > 1 and do_exchange) else [main_stream]
     side_stream = torch.cuda.Stream() if do_exchange else None
-    n_sets = nfl + 1 if do_exchange else nfl
+    n_sets = nfl + 1 if do_exchange else 1
     out_sets = [(out_vec, out_score, out_count)] + [(torch.zeros_like(out_vec), torch.zeros_like(out_score), torch.zeros_like(out_count))
                                                     for _ in range(max(n_sets, 2) - 1)]
     n_sets = len(out_sets)
     ev_searched = [torch.cuda.Event() for _ in range(n_sets)]
     ev_exchanged = [torch.cuda.Event() for _ in range(n_sets)]
     last_merged = [None]
+    p_hnsw = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+    host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
+    in_flight = []   # (ticket, host_out index)
+    retried_total = [0]
 
-    def step(i, e0=None, e1=None):
+    def wait_oldest():
+        t, j = in_flight.pop(0)
+        hv_, hs2_, hc_ = host_out[j]
+        r_ = C.c_uint32(0)
+        _lib.check(L.nidx_gpu_vector_search_wait(h, t, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, C.byref(r_)))
+        retried_total[0] += r_.value
+        return j
+
+    def step(i):
+        if not do_exchange:
+            if len(in_flight) == nfl:
+                wait_oldest()
+            t = C.c_uint64(0)
+            _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[i % n_pool].data_ptr(), B, d, C.byref(p_hnsw), None, C.byref(t)))
+            in_flight.append((t.value, i % nfl))
+            return
         b = i % n_sets
-        st_ = streams[i % nfl]
-        if do_exchange:
-            st_.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
-        if e0 is not None:
-            e0.record(st_)
+        st_ = streams[i % len(streams)]
+        st_.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
         search(qpool[i % n_pool], out=out_sets[b], on=st_.cuda_stream)
-        if e1 is not None:
-            e1.record(st_)
-        if do_exchange:
-            ev_searched[b].record(st_)
-            with torch.cuda.stream(side_stream):
-                side_stream.wait_event(ev_searched[b])
-                last_merged[0] = exchange(out_sets[b])
-                ev_exchanged[b].record(side_stream)
+        ev_searched[b].record(st_)
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(ev_searched[b])
+            last_merged[0] = exchange(out_sets[b], st=side_stream.cuda_stream)
+            ev_exchanged[b].record(side_stream)
 
+    def drain():
+        while in_flight:
+            wait_oldest()
+
+    _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl, 4)))
     for i in range(a.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     device_flags()  # clear: the word below covers exactly the timed launches
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    retried_total[0] = 0
+    # EXACTLY `--steps` steps are timed per pass; the pass is repeated until the timed region is at least `--min-timed-s` long (20
+    # steps of this workload are 6 ms: too short to time honestly), and `ms_per_step` is the mean over every timed step
+    repeats, elapsed = 1, 0.0
+    if a.steps > 0:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        drain()
+        barrier()
+        probe = time.perf_counter() - t0
+        repeats = max(1, int(np.ceil(a.min_timed_s / max(probe, 1e-6))))
+        if world > 1:
+            t = torch.tensor([repeats], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, ev0[i], ev1[i])
+    for i in range(a.steps * repeats):
+        step(a.warmup + i)
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    # every timed launch ORs the overflow flags of its queries into one device word: 0 = each launch already delivered the final,
-    # exact hits (no query would have been re-run by nidx_gpu_vector_segment_search_device_exact)
-    timed_flags = device_flags()
+    # every timed launch ORs the overflow flags of its queries into one word: wait() re-runs flagged queries exactly and counts them
+    # (N = 1); the device-entry launches of the exchange path leave the word for the poll below
+    timed_flags = device_flags() if do_exchange else 0
+    timed_retried = retried_total[0]
     exchange_check = None
     if do_exchange and a.steps > 0:
-        # the overlapped pipeline must give what a plain search -> exchange of the same batch gives
-        i_last = a.warmup + a.steps - 1
+        # the overlapped pipeline must give what a plain search -> exchange of the same batch gives — and the library's RCCL
+        # exchange what the same exchange through torch.distributed gives
+        i_last = a.warmup + a.steps * repeats - 1
         torch.cuda.synchronize()
         got = [t.clone() for t in last_merged[0]]
         search(qpool[i_last % n_pool], out=out_sets[0])
@@ -579,25 +647,30 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         want = exchange(out_sets[0])
         torch.cuda.synchronize()
         exchange_check = "ok" if all(torch.equal(g_, w_) for g_, w_ in zip(got, want)) else "MISMATCH"
+        if comm is not None:
+            ref = exchange_torch(out_sets[0])
+            torch.cuda.synchronize()
+            if not all(torch.equal(g_, w_) for g_, w_ in zip(want, ref)):
+                exchange_check = "MISMATCH (library RCCL exchange vs torch.distributed)"
         if exchange_check != "ok":
-            print("WARNING: overlapped exchange diverged from the sequential one", file=sys.stderr)
+            FAILURES.append("exchange_check: " + exchange_check)
+            print("ERROR: " + exchange_check, file=sys.stderr)
         barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
-    # the same launches strictly one at a time (what a single batch costs from launch to last walk)
+    steps_timed = a.steps * repeats
+    # per-launch duration: HIP events on the launch's own stream around launches issued one at a time (the overlapped launches of
+    # the timed region also span their wait for workgroup slots, which no profiler counts as kernel time)
+    ea = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max(1, min(a.steps, 8)))]
+    for i in range(len(ea) // 2):
+        ea[2 * i].record()
+        search(qpool[i % n_pool])
+        ea[2 * i + 1].record()
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(len(ea) // 2)]))
     alone_ms = kernel_ms
-    if nfl > 1:
-        ea = [torch.cuda.Event(enable_timing=True) for _ in range(2 * min(a.steps, 8))]
-        for i in range(len(ea) // 2):
-            ea[2 * i].record()
-            search(qpool[i % n_pool])
-            ea[2 * i + 1].record()
-        torch.cuda.synchronize()
-        alone_ms = float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(len(ea) // 2)]))
-
     # ---- algorithmic bytes per launch: evals*4D + expansions*256 B, counted by the kernel
     bytes_per_launch, evals_q, exp_q, flags = [], [], [], 0
     hits_q = []
@@ -647,7 +720,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
             "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "evals": float(np.mean(evals_q)),
             "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
-            "build_s": build_s, "exchange_check": exchange_check,
+            "build_s": build_s, "exchange_check": exchange_check, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
         }
     if not headline:
         L.nidx_gpu_vector_close(h)
@@ -655,6 +728,17 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
 
     # ---- serving shapes of the same batch (reported beside `value`, never as `value`) -----------------------------------------
     extra = {}
+    if rank == 0 and not do_exchange and got0 is not None:
+        # what the timed entry points deliver to the host == what the launch-only entry leaves in HBM (the block the oracle checks)
+        t = C.c_uint64(0)
+        _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[0].data_ptr(), B, d, C.byref(p_hnsw), None, C.byref(t)))
+        hv_, hs2_, hc_ = host_out[0]
+        _lib.check(L.nidx_gpu_vector_search_wait(h, t.value, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
+        same_ = bool(np.array_equal(hc_, got0[2].view(np.uint32)) and np.array_equal(hv_, got0[0].view(np.uint32)) and
+                     np.array_equal(hs2_.view(np.uint32), got0[1].view(np.uint32)))
+        extra["submit_wait_equals_device_entry"] = same_
+        if not same_:
+            FAILURES.append("submit/wait delivered other hits than the device entry")
     if rank == 0:
         # (1) the complete device entry: launch + one D2H of the result block + flag check (+ fallback when flagged)
         words = B * k * 2 + B + 1
@@ -690,32 +774,114 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     if rank == 0 and x_host is not None:
         try:
             parity, cpu = oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind)
-        except Exception as e:  # side legs: their failure must not cost the measured line
-            print("WARNING: oracle legs failed: %r" % (e,), file=sys.stderr)
+        except Exception as e:  # side legs: the measured line is still printed, the run is marked failed
+            print("ERROR: oracle legs failed: %r" % (e,), file=sys.stderr)
             parity = {"status": "failed: %r" % (e,)}
+            FAILURES.append("oracle legs failed: %r" % (e,))
+        for name, leg in (parity or {}).items():
+            status = leg.get("status") if isinstance(leg, dict) else leg
+            if isinstance(status, str) and (status.startswith("MISMATCH") or status.startswith("BEYOND") or status.startswith("failed")):
+                FAILURES.append("parity.%s: %s" % (name, status))
+                print("ERROR: parity.%s: %s" % (name, status), file=sys.stderr)
+    del x_host
+
+    # ---- the flat graph at the reference regime's recall ------------------------------------------------------------------------
+    # The reference at this corpus size is 50 segments of <= 200 k records, EACH searched at ef = 30 and merged: that regime's
+    # recall@k (measured above against the exact scan) is the bar "recall >= reference".  One flat graph reaches it at a larger
+    # ef_search; the ladder below finds the smallest such ef and times the serving loop there.
+    iso = None
+    seg_reg = (cpu or {}).get("segment_regime") if isinstance(cpu, dict) else None
+    if rank == 0 and world == 1 and a.iso_recall and exact0 is not None and isinstance(seg_reg, dict) and ("recall_at_%d" % k) in seg_reg:
+        target = seg_reg["recall_at_%d" % k]
+        rq = min(a.recall_queries, B)
+        ev, _es, ec = exact0
+
+        def recall_now():
+            search(qpool[0])
+            torch.cuda.synchronize()
+            g_ = out_vec.cpu().numpy()
+            return float(np.mean([len(set(g_[i][:k].tolist()) & set(ev[i, : ec[i]].tolist())) / k for i in range(rq)]))
+
+        iso = {"target": "recall@%d of the reference regime (%d segments x ef = 30 + Fssc, oracle)" % (k, seg_reg.get("segments", 0)),
+               "target_recall": target, "ladder": []}
+        chosen = None
+        for ef in (30, 36, 42, 48, 56, 64, 80, 96, 128, 192, 256):
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", ef))
+            r_ = recall_now()
+            iso["ladder"].append({"ef_search": ef, "recall": r_})
+            if r_ >= target:
+                chosen = ef
+                break
+        if chosen is not None:
+            for i in range(max(2, a.warmup)):
+                step(i)
+            drain()
+            n_iso = max(a.steps, int(steps_timed * 0.6))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_iso):
+                step(i)
+            drain()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ea = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+            for i in range(4):
+                ea[2 * i].record()
+                search(qpool[i % n_pool])
+                ea[2 * i + 1].record()
+            torch.cuda.synchronize()
+            k_ms = float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(4)]))
+            search(qpool[0], with_stats=True)
+            torch.cuda.synchronize()
+            st = stats.cpu().numpy().astype(np.int64)
+            ab = float((st[:, 0] * 4 * d + st[:, 1] * 256).sum())
+            iso.update({"ef_search": chosen, "recall_at_%d" % k: iso["ladder"][-1]["recall"], "queries_per_s": B * n_iso / dt,
+                        "ms_per_step": dt / n_iso * 1e3, "steps": n_iso, "batches_in_flight": nfl,
+                        "distance_evals_per_query": float(st[:, 0].mean()), "expansions_per_query": float(st[:, 1].mean()),
+                        "kernel_flags": int(np.bitwise_or.reduce(st[:, 3])),
+                        "roofline": {"bound": "hbm", "achieved": ab / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab, "kernel_ms": k_ms,
+                                     "sustained_frac": ab * n_iso / dt / 1e9 / HBM_PEAK_GBS}})
+        else:
+            iso["note"] = "no ef_search of the ladder reaches the target"
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", 0))
+
+    # ---- the other half of BASELINE.json's metric on the same box: BM25 over as many synthetic documents, and the hybrid batch ---
+    bm25_blk, hybrid_blk = None, None
+    if a.bm25_block and world == 1:
+        try:
+            bm = Bm25Bench(a, L, dev, rank, n)
+            bm25_blk = bm.timed_block(rank)
+            cpu_v = cpu.get("value") if isinstance(cpu, dict) else None
+            cpu_b = (bm25_blk.get("cpu_baseline") or {}).get("queries_per_s")
+            hybrid_blk = hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_v, cpu_b)
+            bm.close()
+        except Exception as e:
+            print("ERROR: bm25 / hybrid block failed: %r" % (e,), file=sys.stderr)
+            FAILURES.append("bm25 / hybrid block failed: %r" % (e,))
     L.nidx_gpu_vector_close(h)
     if res is not None:
-        res.update({"extra": extra, "parity": parity, "cpu": cpu})
+        res.update({"extra": extra, "parity": parity, "cpu": cpu, "iso_recall": iso, "bm25": bm25_blk, "hybrid": hybrid_blk})
     return res
 
 
 def single_query_latency(a, L, h, queries):
-    """nidx_gpu_vector_search_one from 64 native threads (nidx_gpu_diag_single_query_latency: the reference's one blocking
-    thread per request), coalesced into batched launches by csrc/coalescer.cpp."""
+    """nidx_gpu_vector_search_one from 1 / 64 / 256 / 1024 native threads (nidx_gpu_diag_single_query_latency: the reference's one
+    blocking thread per request, shard_search.rs:139-153), coalesced by csrc/coalescer.cpp into batches that run through the serving
+    pipeline, several of them in flight."""
     from nucliadb_amd import _lib
 
     d, k = a.dim, a.k
-    threads = 64
-    calls = max(threads, a.single_query_calls)
+    calls = max(64, a.single_query_calls)
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     q = np.ascontiguousarray(queries, np.float32)
     out = {}
-    for th in (1, threads):
-        n = calls if th > 1 else min(calls, 256)
+    for th in (1, 64, 256, 1024):
+        n = min(calls, 256) if th == 1 else max(calls, 8 * th)
         lat = np.zeros(n, np.float32)
         el = C.c_double(0)
         # untimed warm-up: small batches take other launch shapes of the kernel, whose code objects load on first use
-        _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, 4 * th, lat.ctypes.data, C.byref(el)))
+        _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, 2 * th, lat.ctypes.data, C.byref(el)))
         b0, q0 = C.c_uint64(0), C.c_uint64(0)
         L.nidx_gpu_vector_coalescer_stats(h, C.byref(b0), C.byref(q0))
         _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, n, lat.ctypes.data, C.byref(el)))
@@ -724,7 +890,42 @@ def single_query_latency(a, L, h, queries):
         out["threads_%d" % th] = {"calls": n, "p50_ms": float(np.percentile(lat, 50) / 1e3), "p99_ms": float(np.percentile(lat, 99) / 1e3),
                                   "queries_per_s": n / el.value,
                                   "queries_per_launch": (q1.value - q0.value) / max(1, b1.value - b0.value)}
+    if os.environ.get("NIDX_BENCH_SQ_SWEEP") == "1":   # tuning aid: the coalescer's window / batches in flight at 256 callers
+        sweep = []
+        for window in (10, 25, 50, 100):
+            for inflight in (2, 4, 8):
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_window_us", window))
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_in_flight", inflight))
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(4, inflight)))
+                for th in (64, 256):
+                    n = 16 * th
+                    lat = np.zeros(n, np.float32)
+                    el = C.c_double(0)
+                    _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, n, lat.ctypes.data, C.byref(el)))
+                    sweep.append({"window_us": window, "in_flight": inflight, "threads": th, "queries_per_s": n / el.value,
+                                  "p50_ms": float(np.percentile(lat, 50) / 1e3), "p99_ms": float(np.percentile(lat, 99) / 1e3)})
+        out["sweep"] = sweep
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_window_us", 50))
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_in_flight", 4))
     return out
+
+
+def score_bound(cnt_a, score_a, cnt_b, score_b, same_ids, tol=1e-5):
+    """north_star: 'cosine scores within 1e-5'.  For the lists whose ids differ between two summation orders (AVX2-shaped oracle vs
+    WAVE64 device): the score vectors, rank by rank, must agree within `tol` — a near-tie flipped, nothing else happened."""
+    worst, beyond, differing = 0.0, 0, 0
+    for i in range(len(same_ids)):
+        if same_ids[i]:
+            continue
+        differing += 1
+        c = int(min(cnt_a[i], cnt_b[i]))
+        dmax = float(np.max(np.abs(score_a[i, :c].astype(np.float64) - score_b[i, :c].astype(np.float64)))) if c else 0.0
+        if cnt_a[i] != cnt_b[i]:
+            dmax = max(dmax, 1.0)
+        worst = max(worst, dmax)
+        beyond += int(dmax > tol)
+    return {"lists_with_other_ids": differing, "of": len(same_ids), "max_abs_score_difference_rank_by_rank": worst,
+            "lists_beyond_1e-5": beyond, "status": "ok" if beyond == 0 else "BEYOND_TOLERANCE"}
 
 
 def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
@@ -782,12 +983,19 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
         if got0 is not None:
             m = min(B, qs.shape[0])
             cpu["recall_vs_device_ids"] = float(np.mean([len(set(cv[i, : cc[i]].tolist()) & set(got0[0][i, : got0[2][i]].view(np.uint32).tolist())) / k for i in range(m)]))
+            same_ids = [bool(cc[i] == got0[2][i] and np.array_equal(cv[i, : cc[i]], got0[0][i, : cc[i]].view(np.uint32))) for i in range(m)]
+            cpu["avx2_vs_wave64"] = score_bound(cc[:m], cs[:m], got0[2][:m], got0[1][:m], same_ids)
+            cpu["avx2_vs_wave64"]["note"] = ("the timed baseline sums in AVX2 order, the device in WAVE64 order; where the id lists differ the "
+                                             "scores must still agree rank by rank within 1e-5 (a near-tie flipped)")
+            parity["avx2_vs_wave64_flat"] = cpu["avx2_vs_wave64"]["status"]
     del og
     # ---- (4) CPU baseline in the reference's own regime: segments of <= 200 k records searched one after the other and merged
     # by Fssc (searcher.rs:270-287; the cap: src/settings.rs:258-278).  Graphs of the segments: device-built, like the flat one.
     if a.cpu_queries > 0 and a.segment_regime > 0 and n > a.segment_regime:
         try:
-            cpu["segment_regime"] = segment_regime_leg(a, L, x_host, qpool, kind, threads)
+            cpu["segment_regime"] = segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0)
+            if cpu["segment_regime"].get("avx2_vs_wave64"):
+                parity["avx2_vs_wave64_segments"] = cpu["segment_regime"]["avx2_vs_wave64"]["status"]
         except Exception as e:
             cpu["segment_regime"] = {"status": "failed: %r" % (e,)}
     # ---- (5) recall of the reference's sequential HnswBuilder vs the device's batch-synchronous build, same data and queries
@@ -799,7 +1007,7 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
     return parity, cpu
 
 
-def segment_regime_leg(a, L, x_host, qpool, kind, threads):
+def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
     from nucliadb_amd import _lib
     from oracle import oracle as orc
 
@@ -840,12 +1048,31 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads):
     sg, sv, ss, sc = orc.searcher_search_batch(osegs, qs, k, with_duplicates=True, threads=threads)
     dt = time.perf_counter() - t0
     m = min(B, nq)
-    same = int(sum(bool(sc[i] == hc[i] and np.array_equal(sg[i, : sc[i]], hsg[i, : sc[i]]) and np.array_equal(sv[i, : sc[i]], hv[i, : sc[i]]))
-                   for i in range(m)))
-    return {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
-            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
-            "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
-            "device_ids_identical_to_oracle": "%d/%d (the timed baseline sums in AVX2 order, the device in WAVE64 order: near-ties may flip)" % (same, m)}
+    same_l = [bool(sc[i] == hc[i] and np.array_equal(sg[i, : sc[i]], hsg[i, : sc[i]]) and np.array_equal(sv[i, : sc[i]], hv[i, : sc[i]])) for i in range(m)]
+    same = int(sum(same_l))
+    out = {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
+           "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
+           "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
+           "device_ids_identical_to_oracle": "%d/%d (the timed baseline sums in AVX2 order, the device in WAVE64 order: near-ties may flip)" % (same, m),
+           "avx2_vs_wave64": score_bound(sc[:m], ss[:m], hc[:m], hsc[:m], same_l)}
+    # recall@k of the REFERENCE'S OWN REGIME (every segment searched at ef = 30, merged by Fssc) against the exact scan of the
+    # whole shard: the bar 'recall@10 >= reference' is this figure.  Flat row number = segment start + row in the segment.
+    if exact0 is not None:
+        ev, _es, ec = exact0
+        rq = min(a.recall_queries, m, ev.shape[0])
+        starts = np.asarray(bounds[:-1], np.int64)
+
+        def rec(seg_, vec_, cnt_):
+            r = []
+            for i in range(rq):
+                flat = (starts[seg_[i, : cnt_[i]].astype(np.int64)] + vec_[i, : cnt_[i]].astype(np.int64)).tolist()
+                r.append(len(set(flat) & set(ev[i, : ec[i]].view(np.uint32).astype(np.int64).tolist())) / k)
+            return float(np.mean(r))
+
+        out["recall_at_%d" % k] = rec(sg, sv, sc)
+        out["recall_at_%d_device_same_index" % k] = rec(hsg, hv, hc)
+        out["recall_queries"] = rq
+    return out
 
 
 def build_recall_leg(a, L, threads):
@@ -895,7 +1122,7 @@ def bench_hnsw(a, L, dev, rank, world):
     second = hnsw_leg(a, L, dev, rank, world, kinds[1], False) if len(kinds) > 1 else None
     if rank != 0:
         return
-    total_q = world * B * a.steps
+    total_q = world * B * head["steps_timed"]
     extra = head.get("extra") or {}
     cfgd = {
         "workload": "hnsw: %d x %d-dim cosine (%s corpus), k=%d, batch=%d queries, 1 shard per GPU" % (n, d, head["corpus"], k, B),
@@ -903,11 +1130,16 @@ def bench_hnsw(a, L, dev, rank, world):
                                     "160 vectors per centre at radius 0.01 / 0.03, queries = stored vector + 0.05 noise" if head["corpus"] == "clustered" else
                                     ": uniform(-1,1) normalised (segment.rs:682-695)"),
         "vectors_per_shard": n, "dim": d, "batch": B, "k": k, "shards": world, "corpus_vectors": n * world,
-        "merged_queries_per_s": B * a.steps / head["elapsed"],
+        "merged_queries_per_s": B * head["steps_timed"] / head["elapsed"],
         "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B),
+        "recall_at_%d_reference_regime" % k: ((head.get("cpu") or {}).get("segment_regime") or {}).get("recall_at_%d" % k),
+        "iso_recall": head.get("iso_recall"), "bm25": head.get("bm25"), "hybrid": head.get("hybrid"),
         "distance_evals_per_query": head["evals"], "expansions_per_query": head["expansions"],
         "expansions_with_edge_record_fetched_ahead_per_query": head["edge_hits"],
-        "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"],
+        "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"], "timed_queries_re_run_exactly": head["timed_retried"],
+        "timed_region": {"steps_per_pass": a.steps, "passes": head["repeats"], "steps_timed": head["steps_timed"], "seconds": head["elapsed"],
+                         "entry": "nidx_gpu_vector_search_submit / _wait: device-resident queries in, hits in host arrays out" if world == 1 else
+                                  "nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (RCCL inside the library)"},
         "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"],
         "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],
         "batches_in_flight": head["nfl"],
@@ -917,7 +1149,7 @@ def bench_hnsw(a, L, dev, rank, world):
     if second is not None:
         cfgd["uniform_corpus" if second["corpus"] == "uniform" else "second_corpus"] = {
             "workload": "hnsw: %d x %d-dim cosine (%s corpus), k=%d, batch=%d queries" % (n, d, second["corpus"], k, B),
-            "queries_per_s": total_q / second["elapsed"], "ms_per_step": second["elapsed"] / a.steps * 1e3,
+            "queries_per_s": world * B * second["steps_timed"] / second["elapsed"], "ms_per_step": second["elapsed"] / second["steps_timed"] * 1e3,
             "recall_at_%d" % k: second["recall"], "distance_evals_per_query": second["evals"], "expansions_per_query": second["expansions"],
             "kernel_flags": second["flags"], "timed_launch_flags": second["timed_flags"], "hnsw_build_s": second["build_s"],
             "batches_in_flight": second["nfl"],
@@ -931,7 +1163,7 @@ def bench_hnsw(a, L, dev, rank, world):
         "metric": "queries/sec + recall@%d (768-dim cosine k-NN, HNSW M=30 ef=30, k=%d)" % (k, k),
         "value": total_q / head["elapsed"],
         "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["elapsed"] / a.steps * 1e3,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["elapsed"] / head["steps_timed"] * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": cfgd,
         # Per-launch figures: the timed batches overlap (nfl in flight), and an event pair on a stream then also spans the time the
@@ -944,14 +1176,14 @@ def bench_hnsw(a, L, dev, rank, world):
                      "traffic": head["traffic"], "traffic_source": head["traffic_src"],
                      "algorithmic_bytes_per_launch": head["alg_bytes"], "kernel_ms": head["alone_ms"],
                      "note": "one launch at a time (a launch lasts as long as its longest walk); the timed region keeps %d batches in flight" % head["nfl"],
-                     "while_batches_overlap": {"kernel_ms_incl_queue_wait": head["kernel_ms"], "achieved": head["achieved"],
-                                               "frac": head["achieved"] / HBM_PEAK_GBS},
-                     "sustained": {"achieved": head["alg_bytes"] * a.steps / head["elapsed"] / 1e9,
-                                   "frac": head["alg_bytes"] * a.steps / head["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                     "sustained": {"achieved": head["alg_bytes"] * head["steps_timed"] / head["elapsed"] / 1e9,
+                                   "frac": head["alg_bytes"] * head["steps_timed"] / head["elapsed"] / 1e9 / HBM_PEAK_GBS,
                                    "note": "algorithmic bytes of all timed launches / elapsed time of the timed region"},
                      "gather_ceiling": gather_ceiling()},
         "cpu_baseline": head.get("cpu"),
     }
+    if FAILURES:
+        line["failures"] = FAILURES
     print(json.dumps(line))
 
 
@@ -1058,21 +1290,217 @@ def rrf_batch(vec_ids, vec_cnt, bm_ids, bm_cnt, k_out, k_rrf=60.0):
     return np.take_along_axis(ids_s, top, axis=1), np.take_along_axis(w_s, top, axis=1)
 
 
-def bench_hybrid(a, L, dev, rank, world):
-    """BASELINE.json configs[2]: cosine HNSW over N x 768 vectors + BM25 over N synthetic documents (document i owns
-    vector i), a batch of 1024 hybrid queries (one vector + 3 keyword terms), fused with reciprocal rank fusion.
-    The vector search is launched on the torch stream, the BM25 search runs on the library's own stream: they overlap
-    on the device; the fusion is nucliadb's Python-side step (batched in host C++ here: nidx_gpu_rank_fusion_rrf)."""
+class Bm25Bench:
+    """The BM25 half of BASELINE.json's metric: T-zipf corpus of SURVEY §8d (vocabulary 1 M, term ids ~ Zipf(1.0), doc length ~
+    lognormal(ln 48, 0.6) in [4, 2000]) resident in HBM; batches of `B` queries x 3 Should terms drawn uniformly from the rank band
+    [100, 100 k], k = 20."""
+
+    K = 20
+
+    def __init__(self, a, L, dev, rank, n_docs, n_pool=4):
+        from nucliadb_amd import _lib
+        from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
+
+        self.a, self.L, self.n_docs, self.vocab, self.B = a, L, n_docs, a.vocab, a.batch
+        t0 = time.time()
+        self.corpus = zipf_corpus_on_device(L, dev, n_docs, a.vocab, rank)
+        self.gen_s = time.time() - t0
+        t0 = time.time()
+        self.searcher = Bm25Searcher.open([Bm25Segment(*self.corpus)])
+        self.open_s = time.time() - t0
+        rng = np.random.default_rng(2)
+        B = self.B
+        self.terms = [rng.integers(99, 100_000, (B, 3)) for _ in range(n_pool)]
+        self.prepared = []
+        for terms in self.terms:   # clause arrays are prepared once: the timed region is the library call (clauses in, hits out)
+            cl = (_lib.Bm25ClauseC * (3 * B))()
+            for i in range(B):
+                for j in range(3):
+                    cl[3 * i + j].term, cl[3 * i + j].occur, cl[3 * i + j].mode, cl[3 * i + j].boost = int(terms[i, j]), 0, 0, 1.0
+            self.prepared.append(cl)
+        self.offsets = (np.arange(B + 1, dtype=np.uint64) * 3).copy()
+        k = self.K
+        self.docaddr, self.score = np.zeros((B, k), np.uint64), np.zeros((B, k), np.float32)
+        self.count, self.total, self.post = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
+
+    def search(self, i):
+        from nucliadb_amd import _lib
+
+        _lib.check(self.L.nidx_gpu_bm25_search(self.searcher._handle, self.prepared[i % len(self.prepared)], self.offsets.ctypes.data, self.B, self.K, None,
+                                               self.docaddr.ctypes.data, self.score.ctypes.data, self.count.ctypes.data, self.total.ctypes.data,
+                                               self.post.ctypes.data))
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        self.L.nidx_gpu_bm25_last_kernel_ms(self.searcher._handle, C.byref(ms))
+        return ms.value
+
+    def close(self):
+        self.searcher.close()
+
+    def oracle_index(self):
+        from oracle import oracle as orc
+
+        orc.build()
+        return orc.Bm25Index(*self.corpus)
+
+    def timed_block(self, rank):
+        """-> dict: value (postings/s end to end through the host-buffer entry point), roofline of the scoring kernel, cpu_baseline,
+        parity of a sample against the oracle."""
+        a, B, k = self.a, self.B, self.K
+        for i in range(max(1, a.warmup)):
+            self.search(i)
+        post_per_batch, kernel_ms = [], []
+        t0 = time.perf_counter()
+        n_steps = 0
+        while n_steps < a.steps or time.perf_counter() - t0 < min(a.min_timed_s, 1.0):
+            self.search(n_steps)
+            post_per_batch.append(float(self.post.sum()))
+            kernel_ms.append(self.kernel_ms())
+            n_steps += 1
+        elapsed = time.perf_counter() - t0
+        postings = float(np.sum(post_per_batch))
+        k_ms = float(np.mean(kernel_ms))
+        traffic, traffic_src = pmc_traffic("bm25", self.n_docs, self.vocab, B, k)
+        alg = float(np.mean(post_per_batch)) * 8.0   # doc id (4 B) + the resident posting word tf | fieldnorm id << 24 (4 B)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "BM25 docs (postings) scored/sec", "value": postings / elapsed, "unit": "postings/s", "queries_per_s": n_steps * B / elapsed,
+            "steps": n_steps, "ms_per_step": elapsed / n_steps * 1e3,
+            "workload": "bm25: %d docs, vocab %d Zipf(1.0), %d queries x 3 Should terms from rank band [100,100k], k=%d" % (self.n_docs, self.vocab, B, k),
+            "postings_in_index": int(self.corpus[0][-1]), "postings_per_batch": float(np.mean(post_per_batch)),
+            "corpus_gen_s": self.gen_s, "open_s": self.open_s,
+            "note": "value is end to end through the host-buffer entry point (clauses in, hits out over PCIe); the corpus is resident in HBM",
+            "roofline": {"kernel": "bm25 scoring kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+            "cpu_baseline": None,
+        }
+        if rank == 0 and a.cpu_queries > 0:
+            from oracle import oracle as orc
+
+            term_offsets = self.corpus[0]
+            oidx = self.oracle_index()
+            threads = a.cpu_threads or min(64, os.cpu_count() or 1)
+            nq = min(max(4 * threads, 256), B)
+            self.search(0)
+            got = (self.docaddr.copy(), self.score.copy(), self.count.copy(), self.total.copy())
+            queries = [[(int(t), 0, 0, 1.0) for t in self.terms[0][i]] for i in range(nq)]
+            done = int(sum(int(term_offsets[int(t) + 1] - term_offsets[int(t)]) for i in range(nq) for t in self.terms[0][i]))
+            orc.bm25_search_daat_batch(oidx, queries[:threads], k, threads=threads)   # warm
+            t1 = time.perf_counter()
+            od, os_, oc, ot = orc.bm25_search_daat_batch(oidx, queries, k, threads=threads)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": done / dt, "unit": "postings/s", "queries_per_s": nq / dt, "cores": threads, "kind": "port",
+                                   "sample": "%d queries of batch 0 over the same %d-doc index, oracle document-at-a-time BM25 (tantivy-style union of the clause cursors, no block-max pruning), one query per POSIX thread" % (nq, self.n_docs)}
+            # bit parity of the same sample: doc ids, ranks, score bits, Count
+            ok = 0
+            for i in range(nq):
+                c = int(got[2][i])
+                ok += int(c == oc[i] and ot[i] == got[3][i] and np.array_equal(got[0][i, :c], od[i, :c]) and
+                          np.array_equal(got[1][i, :c].view(np.uint32), os_[i, :c].view(np.uint32)))
+            out["parity"] = {"queries": nq, "identical_ids_ranks_score_bits": ok, "status": "ok" if ok == nq else "MISMATCH",
+                             "reference": "nidx_paragraph/src/reader.rs:244-348 (tantivy BM25, TopDocs)"}
+            if ok != nq:
+                FAILURES.append("bm25 block: device hits differ from the oracle's on %d of %d queries" % (nq - ok, nq))
+        return out
+
+
+def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qps):
+    """BASELINE.json configs[2]: cosine HNSW over N x 768 vectors + BM25 over N synthetic documents (document i owns vector i), a
+    batch of hybrid queries (one vector + 3 keyword terms), fused with reciprocal rank fusion.  The vector batches go through the
+    serving pipeline (`nfl` in flight, hits delivered to the host), the BM25 call runs on the library's own stream meanwhile, the
+    fusion is nucliadb's Python-side step (batched in host C++ here: nidx_gpu_rank_fusion_rrf)."""
     from nucliadb_amd import _lib
-    from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
     from nucliadb_amd.rank_fusion import rrf_fuse_batch
 
-    n, d, B, k = a.n_vectors, a.dim, a.batch, a.k
-    n_docs, vocab, kb = n, a.vocab, 20
+    B, k, d, kb = a.batch, a.k, a.dim, bm.K
+    n_pool = qpool.shape[0]
+    p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+    host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
+    in_flight = []
+    t_parts = {"vector_submit": 0.0, "bm25_call": 0.0, "vector_wait": 0.0, "fusion": 0.0}
+    kernel_ms = []
+
+    def submit(i):
+        t = C.c_uint64(0)
+        _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[i % n_pool].data_ptr(), B, d, C.byref(p), None, C.byref(t)))
+        in_flight.append((t.value, i % nfl))
+
+    def step(i, last):
+        # the vector batches run ahead of the keyword search of batch i; BM25 of batch i overlaps them on the device
+        t0 = time.perf_counter()
+        while len(in_flight) < nfl and (i + len(in_flight)) < last:
+            submit(i + len(in_flight))
+        t1 = time.perf_counter()
+        bm.search(i)
+        kernel_ms.append(bm.kernel_ms())
+        t2 = time.perf_counter()
+        tk, j = in_flight.pop(0)
+        hv_, hs_, hc_ = host_out[j]
+        _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, None))
+        t3 = time.perf_counter()
+        # keyword list first, like nucliadb's fuse({"keyword": .., "semantic": ..}); ids = document numbers
+        fused = rrf_fuse_batch([(bm.docaddr & np.uint64(0xFFFFFFFF), bm.count, 1.0, bm.score), (hv_.astype(np.uint64), hc_, 1.0, None)], k=60.0, window=k)
+        t4 = time.perf_counter()
+        t_parts["vector_submit"] += t1 - t0
+        t_parts["bm25_call"] += t2 - t1
+        t_parts["vector_wait"] += t3 - t2
+        t_parts["fusion"] += t4 - t3
+        return fused
+
+    for i in range(max(2, a.warmup)):
+        step(i, max(2, a.warmup))
+    torch.cuda.synchronize()
+    for k_ in t_parts:
+        t_parts[k_] = 0.0
+    kernel_ms.clear()
+    # probe, then a region of at least min_timed_s
+    n_steps = max(a.steps, 8)
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        step(i, n_steps)
+    probe = time.perf_counter() - t0
+    n_steps = max(n_steps, int(np.ceil(n_steps * min(a.min_timed_s, 1.0) / max(probe, 1e-6))))
+    for k_ in t_parts:
+        t_parts[k_] = 0.0
+    kernel_ms.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        step(i, n_steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": "hybrid queries/sec (768-dim cosine HNSW k=%d + BM25 k=%d over the same documents, reciprocal rank fusion)" % (k, kb),
+        "value": B * n_steps / elapsed, "unit": "hybrid queries/s", "steps": n_steps, "ms_per_step": elapsed / n_steps * 1e3,
+        "workload": "hybrid: HNSW over the timed shard + BM25 over %d docs (vocab %d), batch=%d, RRF k=60, results (fused ids + scores) on the host" % (bm.n_docs, bm.vocab, B),
+        "vector_batches_in_flight": nfl, "bm25_kernel_ms": float(np.mean(kernel_ms)),
+        "ms_per_step_parts": {kk_: v / n_steps * 1e3 for kk_, v in t_parts.items()},
+        "cpu_baseline": None,
+    }
+    if cpu_vector_qps and cpu_bm25_qps:
+        nq = min(B, 512)
+        t1 = time.perf_counter()
+        for _ in range(4):
+            rrf_fuse_batch([(bm.docaddr[:nq] & np.uint64(0xFFFFFFFF), bm.count[:nq], 1.0, bm.score[:nq]),
+                            (host_out[0][0][:nq].astype(np.uint64), host_out[0][2][:nq], 1.0, None)], k=60.0, window=k)
+        t_fuse = (time.perf_counter() - t1) / 4
+        out["cpu_baseline"] = {"value": nq / (nq / cpu_vector_qps + nq / cpu_bm25_qps + t_fuse), "unit": "hybrid queries/s", "kind": "port",
+                               "cores": a.cpu_threads or min(64, os.cpu_count() or 1),
+                               "sample": "composed on this box's cores: the oracle's flat HNSW leg (%.0f queries/s) then its document-at-a-time BM25 leg (%.0f queries/s), "
+                                         "both measured above on their bounded samples, then the rank fusion of %d queries timed here" % (cpu_vector_qps, cpu_bm25_qps, nq)}
+    return out
+
+
+def bench_hybrid(a, L, dev, rank, world):
+    """--workload hybrid: the hybrid block on its own (generates the shard, builds the graph, opens the BM25 index)."""
+    from nucliadb_amd import _lib
+
+    n, d, B = a.n_vectors, a.dim, a.batch
     kind = "uniform" if a.corpus == "uniform" else "clustered"
     x = gen_corpus(kind, n, d, dev, 1234567890 + rank)
-    n_pool = 4
-    qpool = gen_queries(kind, x, n_pool, B, d, dev, 2)
+    qpool = gen_queries(kind, x, 4, B, d, dev, 2)
     cfg = _lib.VectorConfigC(d, 1, 0, 0)
     cseg = _lib.VectorSegmentC(x.data_ptr(), d * 4, n, None, n, None, 0, 0, None, 0, None, None)
     h = C.c_void_p()
@@ -1082,166 +1510,30 @@ def bench_hybrid(a, L, dev, rank, world):
     t0 = time.time()
     _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
     build_s = time.time() - t0
-    t0 = time.time()
-    term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens = zipf_corpus_on_device(L, dev, n_docs, vocab, rank)
-    gen_s = time.time() - t0
-    searcher = Bm25Searcher.open([Bm25Segment(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)])
-    rng = np.random.default_rng(2)
-    prepared = []
-    for _ in range(n_pool):
-        cl = (_lib.Bm25ClauseC * (3 * B))()
-        terms = rng.integers(99, 100_000, (B, 3))
-        for i in range(B):
-            for j in range(3):
-                cl[3 * i + j].term, cl[3 * i + j].occur, cl[3 * i + j].mode, cl[3 * i + j].boost = int(terms[i, j]), 0, 0, 1.0
-        prepared.append(cl)
-    offsets = (np.arange(B + 1, dtype=np.uint64) * 3).copy()
-    out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
-    out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
-    out_count = torch.zeros((B,), dtype=torch.int32, device=dev)
-    docaddr, score = np.zeros((B, kb), np.uint64), np.zeros((B, kb), np.float32)
-    count, total, post = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
-    params = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
-    stream = torch.cuda.current_stream().cuda_stream
-    t_parts = {"vector_launch+bm25": 0.0, "sync+copy": 0.0, "fusion": 0.0}
-
-    def step(i, timed=False):
-        t0 = time.perf_counter()
-        _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, qpool[i % n_pool].data_ptr(), B, C.byref(params), None, out_vec.data_ptr(),
-                                                           out_score.data_ptr(), out_count.data_ptr(), None, stream))
-        _lib.check(L.nidx_gpu_bm25_search(searcher._handle, prepared[i % n_pool], offsets.ctypes.data, B, kb, None, docaddr.ctypes.data,
-                                          score.ctypes.data, count.ctypes.data, total.ctypes.data, post.ctypes.data))
-        t1 = time.perf_counter()
-        vi = out_vec.cpu().numpy()
-        vc = out_count.cpu().numpy()
-        t2 = time.perf_counter()
-        # keyword list first, like nucliadb's fuse({"keyword": .., "semantic": ..}); ids = document numbers
-        fused = rrf_fuse_batch([(docaddr & np.uint64(0xFFFFFFFF), count, 1.0, score), (vi.astype(np.uint64), vc.astype(np.uint32), 1.0, None)],
-                               k=60.0, window=k)
-        t3 = time.perf_counter()
-        if timed:
-            t_parts["vector_launch+bm25"] += t1 - t0
-            t_parts["sync+copy"] += t2 - t1
-            t_parts["fusion"] += t3 - t2
-        return fused
-
-    for i in range(max(1, a.warmup)):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, timed=True)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms = C.c_float()
-    L.nidx_gpu_bm25_last_kernel_ms(searcher._handle, C.byref(ms))
-    searcher.close()
+    bm = Bm25Bench(a, L, dev, rank, n)
+    blk = hybrid_block(a, L, dev, rank, h, qpool, bm, max(1, a.batches_in_flight), None, None)
+    bm.close()
     L.nidx_gpu_vector_close(h)
     if rank == 0:
         print(json.dumps({
-            "metric": "hybrid queries/sec (768-dim cosine HNSW k=%d + BM25 k=%d over the same %d documents, reciprocal rank fusion)" % (k, kb, n),
-            "value": world * B * a.steps / elapsed, "unit": "hybrid queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "hybrid: %d x %d-dim cosine HNSW (%s corpus) + BM25 over %d docs (vocab %d), batch=%d, RRF k=60" % (n, d, kind, n_docs, vocab, B),
-                       "hnsw_build_s": build_s, "corpus_gen_s": gen_s, "bm25_kernel_ms": ms.value,
-                       "ms_per_step_parts": {kk_: v / a.steps * 1e3 for kk_, v in t_parts.items()},
-                       "note": "end to end per batch: vector search on device buffers + BM25 through the host-buffer entry point, both device "
-                               "results copied to the host, fused by nidx_gpu_rank_fusion_rrf (host C++)"},
-            "roofline": None, "cpu_baseline": None}))
+            "metric": blk["metric"], "value": world * blk["value"], "unit": blk["unit"], "n_gpus": world, "steps": blk["steps"], "warmup": a.warmup,
+            "ms_per_step": blk["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict({kk_: v for kk_, v in blk.items() if kk_ not in ("metric", "value", "unit", "steps", "ms_per_step", "cpu_baseline")},
+                           hnsw_build_s=build_s),
+            "roofline": None, "cpu_baseline": blk["cpu_baseline"]}))
 
 
 def bench_bm25(a, L, dev, rank, world):
-    """BASELINE.json's second metric: BM25 postings ("docs") scored per second.  T-zipf corpus of
-    SURVEY §8d: vocabulary 1M, term ids ~ Zipf(1.0), doc length ~ lognormal(ln 48, 0.6) in [4, 2000];
-    1024 queries x 3 Should terms drawn uniformly from the rank band [100, 100k], k = 20."""
-    from nucliadb_amd import _lib
-    from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment, Clause
-
-    n_docs, vocab, B, k = a.n_docs, a.vocab, a.batch, 20
-    t0 = time.time()
-    term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens = zipf_corpus_on_device(L, dev, n_docs, vocab, rank)
-    gen_s = time.time() - t0
-    seg = Bm25Segment(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)
-    t0 = time.time()
-    searcher = Bm25Searcher.open([seg])
-    open_s = time.time() - t0
-    rng = np.random.default_rng(2)
-    n_pool = 4
-    pools = [[[Clause(int(t)) for t in rng.integers(99, 100_000, 3)] for _ in range(B)] for _ in range(n_pool)]
-    # clause arrays are prepared once: the timed region is the library call (clauses in, hits out)
-    prepared = []
-    for pool in pools:
-        cl = (_lib.Bm25ClauseC * (3 * B))()
-        for i, q in enumerate(pool):
-            for j, c in enumerate(q):
-                cl[3 * i + j].term, cl[3 * i + j].occur, cl[3 * i + j].mode, cl[3 * i + j].boost = c.term, c.occur, c.mode, c.boost
-        prepared.append(cl)
-    offsets = (np.arange(B + 1, dtype=np.uint64) * 3).copy()
-    docaddr = np.zeros((B, k), np.uint64)
-    score = np.zeros((B, k), np.float32)
-    count = np.zeros(B, np.uint32)
-    total = np.zeros(B, np.uint64)
-    post = np.zeros(B, np.uint64)
-
-    def step(i):
-        _lib.check(L.nidx_gpu_bm25_search(searcher._handle, prepared[i % n_pool], offsets.ctypes.data, B, k, None, docaddr.ctypes.data,
-                                          score.ctypes.data, count.ctypes.data, total.ctypes.data, post.ctypes.data))
-
-    post_per_batch = []
-    for i in range(max(1, a.warmup)):
-        step(i)
-    torch.cuda.synchronize()
-    kernel_ms = []
-    ms = C.c_float()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-        post_per_batch.append(float(post.sum()))
-        L.nidx_gpu_bm25_last_kernel_ms(searcher._handle, C.byref(ms))
-        kernel_ms.append(ms.value)
-    elapsed = time.perf_counter() - t0
-    postings = float(np.sum(post_per_batch))
-    k_ms = float(np.mean(kernel_ms))
-    bm25_traffic, bm25_traffic_src = pmc_traffic("bm25", n_docs, vocab, B, k)
-    alg = float(np.mean(post_per_batch)) * 8.0   # doc id (4 B) + the resident posting word tf | fieldnorm id << 24 (4 B)
-    achieved = alg / (k_ms * 1e-3) / 1e9
-    cpu = None
-    if rank == 0 and a.cpu_queries > 0:
-        from concurrent.futures import ThreadPoolExecutor
-
-        from oracle import oracle as orc
-
-        orc.build()
-        oidx = orc.Bm25Index(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)
-        threads = a.cpu_threads or min(64, os.cpu_count() or 1)
-        nq = min(max(4 * threads, 256), B)
-
-        def one(i):
-            q = pools[0][i]
-            oidx.search([(c.term, c.occur, c.mode, c.boost) for c in q], k, daat=True)
-            return sum(int(term_offsets[c.term + 1] - term_offsets[c.term]) for c in q)
-
-        with ThreadPoolExecutor(threads) as ex:
-            t1 = time.perf_counter()
-            done = sum(ex.map(one, range(nq)))
-            dt = time.perf_counter() - t1
-        cpu = {"value": done / dt, "unit": "postings/s", "cores": threads, "kind": "port",
-               "sample": "%d queries of batch 0 over the same %d-doc index, oracle document-at-a-time BM25 (tantivy-style union of the clause cursors, no block-max pruning), one query per thread" % (nq, n_docs)}
-    searcher.close()
+    """--workload bm25: BASELINE.json's second metric on its own line."""
+    bm = Bm25Bench(a, L, dev, rank, a.n_docs)
+    blk = bm.timed_block(rank)
+    bm.close()
     if rank == 0:
         print(json.dumps({
-            "metric": "BM25 docs (postings) scored/sec", "value": postings / elapsed, "unit": "postings/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "bm25: %d docs, vocab %d Zipf(1.0), %d queries x 3 Should terms from rank band [100,100k], k=20" % (n_docs, vocab, B),
-                       "postings_in_index": int(term_offsets[-1]), "postings_per_batch": float(np.mean(post_per_batch)),
-                       "corpus_gen_s": gen_s, "open_s": open_s,
-                       "note": "value is end to end through the host-buffer entry point (clauses in, hits out over PCIe); the corpus is resident in HBM"},
-            "roofline": {"kernel": "bm25_fast_kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": bm25_traffic, "traffic_source": bm25_traffic_src,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
-            "cpu_baseline": cpu}))
+            "metric": blk["metric"], "value": blk["value"], "unit": blk["unit"], "n_gpus": world, "steps": blk["steps"], "warmup": a.warmup,
+            "ms_per_step": blk["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {kk_: v for kk_, v in blk.items() if kk_ not in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "cpu_baseline")},
+            "roofline": blk["roofline"], "cpu_baseline": blk["cpu_baseline"]}))
 
 
 def bench_rabitq(a, L, dev, rank, world):
@@ -1412,3 +1704,6 @@ def cpu_baseline(a, L, h, x_host, q0, q1):
 
 if __name__ == "__main__":
     main()
+    if FAILURES:   # the line above was printed; a parity break must not look like a green run
+        sys.stdout.flush()
+        sys.exit(1)
