@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--single-query-calls", type=int, default=2048, help="hnsw: nidx_gpu_vector_search_one calls for the p50/p99 figure (0 = skip)")
     p.add_argument("--min-timed-s", type=float, default=1.0,
                    help="the timed pass of --steps steps is repeated until the timed region is at least this long (ms_per_step = mean over all)")
+    p.add_argument("--iso-target", type=float, default=0.0, help="hnsw: recall target of the iso-recall ladder when the segment-regime leg is off")
     p.add_argument("--iso-recall", type=int, default=1, help="hnsw: also time the flat graph at the ef_search whose recall reaches the reference regime's (0 = skip)")
     p.add_argument("--bm25-block", type=int, default=1, help="hnsw: add the BM25 and hybrid blocks of BASELINE.json configs[2] to the default line (0 = skip)")
     p.add_argument("--dim", type=int, default=768)
@@ -688,7 +689,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     traffic, traffic_src = pmc_traffic(kind, n, d, B, k)
 
     # ---- recall@k of the timed configuration against the exact scan of the same shard (merged over the shards when N > 1)
-    recall, got0, exact0 = None, None, None
+    recall, got0, exact0, recall_hist = None, None, None, None
     if a.recall_queries > 0:
         rq = min(a.recall_queries, B)
         search(qpool[0])
@@ -712,13 +713,15 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             exact_ids = me[1].cpu().numpy()
         else:
             exact_ids = exact0[0].astype(np.int64)
-        recall = float(np.mean([len(set(got_ids[i][:k].tolist()) & set(exact_ids[i][:k].tolist())) / k for i in range(rq)]))
+        found_q = [len(set(got_ids[i][:k].tolist()) & set(exact_ids[i][:k].tolist())) for i in range(rq)]
+        recall = float(np.mean(found_q)) / k
+        recall_hist = np.bincount(np.asarray(found_q, np.int64), minlength=k + 1).tolist()   # queries with 0, 1, ..., k of the exact top-k
 
     res = None
     if rank == 0:
         res = {
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
-            "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "evals": float(np.mean(evals_q)),
+            "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "recall_hist": recall_hist, "evals": float(np.mean(evals_q)),
             "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
             "build_s": build_s, "exchange_check": exchange_check, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
         }
@@ -791,8 +794,9 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     # ef_search; the ladder below finds the smallest such ef and times the serving loop there.
     iso = None
     seg_reg = (cpu or {}).get("segment_regime") if isinstance(cpu, dict) else None
-    if rank == 0 and world == 1 and a.iso_recall and exact0 is not None and isinstance(seg_reg, dict) and ("recall_at_%d" % k) in seg_reg:
-        target = seg_reg["recall_at_%d" % k]
+    iso_target = a.iso_target if a.iso_target > 0 else (seg_reg or {}).get("recall_at_%d" % k) if isinstance(seg_reg, dict) else None
+    if rank == 0 and world == 1 and a.iso_recall and exact0 is not None and iso_target is not None:
+        target = iso_target
         rq = min(a.recall_queries, B)
         ev, _es, ec = exact0
 
@@ -800,17 +804,23 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             search(qpool[0])
             torch.cuda.synchronize()
             g_ = out_vec.cpu().numpy()
-            return float(np.mean([len(set(g_[i][:k].tolist()) & set(ev[i, : ec[i]].tolist())) / k for i in range(rq)]))
+            f_ = [len(set(g_[i][:k].tolist()) & set(ev[i, : ec[i]].tolist())) for i in range(rq)]
+            return float(np.mean(f_)) / k, np.bincount(np.asarray(f_, np.int64), minlength=k + 1).tolist()
 
-        iso = {"target": "recall@%d of the reference regime (%d segments x ef = 30 + Fssc, oracle)" % (k, seg_reg.get("segments", 0)),
-               "target_recall": target, "ladder": []}
+        iso = {"target": ("recall@%d of the reference regime (%d segments x ef = 30 + Fssc, oracle)" % (k, seg_reg.get("segments", 0)))
+                         if a.iso_target <= 0 else "--iso-target",
+               "target_recall": target, "ladder": [],
+               "knobs": "ef_upper = results kept per upper layer of the descent (reference: 1, hnsw/search.rs:318-324), ef_search = results kept "
+                        "on layer 0 (reference: 30); both tunables, defaults = the reference's constants"}
         chosen = None
-        for ef in (30, 36, 42, 48, 56, 64, 80, 96, 128, 192, 256):
+        # the cheap knob first: a wider descent (the upper layers hold 1/30 of the nodes), then a wider layer-0 search
+        for efu, ef in ((1, 30), (4, 30), (8, 30), (16, 30), (32, 30), (64, 30), (16, 48), (32, 64), (64, 96), (64, 128), (64, 192), (64, 256)):
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", 0 if efu == 1 else efu))
             _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", ef))
-            r_ = recall_now()
-            iso["ladder"].append({"ef_search": ef, "recall": r_})
+            r_, hist_ = recall_now()
+            iso["ladder"].append({"ef_upper": efu, "ef_search": ef, "recall": r_, "queries_by_hits": hist_})
             if r_ >= target:
-                chosen = ef
+                chosen = (efu, ef)
                 break
         if chosen is not None:
             for i in range(max(2, a.warmup)):
@@ -835,7 +845,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             torch.cuda.synchronize()
             st = stats.cpu().numpy().astype(np.int64)
             ab = float((st[:, 0] * 4 * d + st[:, 1] * 256).sum())
-            iso.update({"ef_search": chosen, "recall_at_%d" % k: iso["ladder"][-1]["recall"], "queries_per_s": B * n_iso / dt,
+            iso.update({"ef_upper": chosen[0], "ef_search": chosen[1], "recall_at_%d" % k: iso["ladder"][-1]["recall"], "queries_per_s": B * n_iso / dt,
                         "ms_per_step": dt / n_iso * 1e3, "steps": n_iso, "batches_in_flight": nfl,
                         "distance_evals_per_query": float(st[:, 0].mean()), "expansions_per_query": float(st[:, 1].mean()),
                         "kernel_flags": int(np.bitwise_or.reduce(st[:, 3])),
@@ -843,8 +853,9 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
                                      "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab, "kernel_ms": k_ms,
                                      "sustained_frac": ab * n_iso / dt / 1e9 / HBM_PEAK_GBS}})
         else:
-            iso["note"] = "no ef_search of the ladder reaches the target"
+            iso["note"] = "no rung of the ladder reaches the target"
         _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", 0))
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", 0))
 
     # ---- the other half of BASELINE.json's metric on the same box: BM25 over as many synthetic documents, and the hybrid batch ---
     bm25_blk, hybrid_blk = None, None
@@ -1131,7 +1142,7 @@ def bench_hnsw(a, L, dev, rank, world):
                                     ": uniform(-1,1) normalised (segment.rs:682-695)"),
         "vectors_per_shard": n, "dim": d, "batch": B, "k": k, "shards": world, "corpus_vectors": n * world,
         "merged_queries_per_s": B * head["steps_timed"] / head["elapsed"],
-        "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B),
+        "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B), "recall_queries_by_hits": head.get("recall_hist"),
         "recall_at_%d_reference_regime" % k: ((head.get("cpu") or {}).get("segment_regime") or {}).get("recall_at_%d" % k),
         "iso_recall": head.get("iso_recall"), "bm25": head.get("bm25"), "hybrid": head.get("hybrid"),
         "distance_evals_per_query": head["evals"], "expansions_per_query": head["expansions"],

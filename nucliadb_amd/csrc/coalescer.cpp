@@ -2,18 +2,29 @@
 //
 // The reference serves every Search request on its own blocking thread with ONE query vector
 // (nidx/src/searcher/shard_search.rs:139-153, nodereader.proto:402); a GPU wants batches.  Concurrent
-// callers of nidx_gpu_vector_search_one are therefore merged: one caller at a time is the GATHERER — it waits until its
-// batch is due, takes the pending requests that share its parameters, hands the gatherer role to the next pending caller
-// and only then runs its batch through the serving pipeline (serving.cpp: its own stream and staging) — so the next batch
-// gathers, and up to `max_in_flight` batches run, while this one is on the device.  A batch is due when its window has passed
-// (or it is full) AND fewer than max_in_flight batches are running: under load a batch closes when an earlier launch finishes
-// and its size follows the arrival rate.  Results are identical to calling nidx_gpu_vector_search with a batch of one
-// (the kernels are per-query deterministic).
+// callers of nidx_gpu_vector_search_one are therefore merged into batches that run through the serving pipeline
+// (serving.cpp: a stream and staging per batch in flight):
+//
+//   * an arrival JOINS the open batch of its parameters (or opens one and becomes its gatherer): a slot index under the
+//     coalescer's mutex — nothing else happens under it — then it copies its own query row into the batch and counts itself ready;
+//   * the gatherer waits until the batch is due — its window has passed (or it is full) AND fewer than max_in_flight batches are
+//     running — closes it (later arrivals open the next batch, whose first arrival gathers it while this one is on the device),
+//     runs it (submit + wait) and publishes "done" with ONE futex wake for all members;
+//   * every member copies its own hits out of the batch.
+// Under load a batch closes when an earlier launch finishes, so its size follows the arrival rate.  The mutex is taken twice per
+// request for a few instructions; completion takes no lock at all (round 2's version distributed the results and woke every
+// member under the mutex: at 256 callers the convoy on that mutex, not the device, set the latency).
+// Results are identical to calling nidx_gpu_vector_search with a batch of one (the kernels are per-query deterministic).
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
+#include <climits>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
-#include <deque>
 #include <memory>
 #include <mutex>
 
@@ -22,25 +33,35 @@
 
 namespace nidx {
 
-struct OneRequest {
-    const float *query;
-    nidx_gpu_vector_search_params_t params;
-    uint32_t *out_segment, *out_paragraph, *out_vector;
-    float *out_score;
-    uint32_t *out_count;
+namespace {
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t> *w) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+}  // namespace
+
+struct CoBatch {
+    nidx_gpu_vector_search_params_t params{};
+    uint32_t cap = 0, d = 0;
+    uint32_t n = 0;                       // members (under Coalescer::mu while the batch is open, fixed afterwards)
+    bool open = false;
+    std::atomic<uint32_t> ready{0};       // members whose query row is in `q`
+    std::atomic<uint32_t> done{0};        // futex word: 0 = gathering / on the device, 1 = results (or rc) published
+    std::unique_ptr<float[]> q;           // [cap][d]
+    std::vector<uint32_t> seg, par, vec, cnt;
+    std::vector<float> sc;
     int32_t rc = NIDX_OK;
     char error[512] = {0};
-    bool done = false;
-    // every parked caller sleeps on its own condition variable: a finished batch wakes exactly its members, an arrival wakes at
-    // most the gatherer (one shared variable made 64 arrivals behind a running batch ~4 000 mutex hand-overs: 25-75 ms stalls)
-    std::condition_variable cv;
 };
 
 struct Coalescer {
     std::mutex mu;
-    std::condition_variable cv_gather;  // the gatherer waits here for arrivals, for its window and for a free slot
-    std::deque<OneRequest *> pending;
-    bool gatherer_active = false;
+    std::condition_variable cv_gather;    // gatherers: a batch filled up, or a batch in flight finished
+    std::vector<std::shared_ptr<CoBatch>> open;   // at most one per parameter set
+    std::vector<std::shared_ptr<CoBatch>> pool;   // batch objects are recycled (their query block is max_batch rows)
     uint32_t in_flight = 0;
     uint64_t n_batches = 0, n_queries = 0;
     uint32_t window_us = 50, max_batch = 1024, max_in_flight = 4;
@@ -56,111 +77,116 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
     Coalescer &c = *coalescer;  // created with the handle (nidx_gpu_vector_open)
     if (p.k > NIDX_K_MAX) return fail(NIDX_ERR_UNSUPPORTED, "result_per_page > %d is not supported (got %u)", NIDX_K_MAX, p.k);
     if (p.method < 0 || p.method > 6) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown search method %d", p.method);
-    OneRequest req{query, p, out_segment, out_paragraph, out_vector, out_score, out_count};
+    const uint32_t d = cfg.dimension;
     const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::micro>(b - a).count();
     };
     const auto t_in = std::chrono::steady_clock::now();
-    auto t_lead = t_in, t_gathered = t_in, t_searched = t_in, t_posted = t_in;
+    auto t_joined = t_in, t_gathered = t_in, t_searched = t_in;
+    std::shared_ptr<CoBatch> b;
+    uint32_t slot = 0;
+    bool gatherer = false;
+    {
+        // ---- join: everything that can fail for lack of memory happens before the batch is visible to other callers ----------------
+        std::unique_lock<std::mutex> lk(c.mu);
+        for (auto &ob : c.open)
+            if (ob->n < ob->cap && same_params(ob->params, p)) { b = ob; break; }
+        if (!b) {
+            for (auto it = c.pool.begin(); it != c.pool.end(); ++it)
+                if (it->use_count() == 1 && (*it)->cap == c.max_batch && (*it)->d == d) { b = *it; break; }
+            if (!b) {
+                b = std::make_shared<CoBatch>();
+                b->cap = c.max_batch;
+                b->d = d;
+                b->q.reset(new float[(size_t)b->cap * d]);
+                if (c.pool.size() < 32) c.pool.push_back(b);
+            }
+            b->params = p;
+            b->n = 0;
+            b->ready.store(0, std::memory_order_relaxed);
+            b->done.store(0, std::memory_order_relaxed);
+            b->rc = NIDX_OK;
+            b->open = true;
+            c.open.push_back(b);
+            gatherer = true;
+        }
+        slot = b->n++;
+        if (!gatherer && b->n == b->cap) c.cv_gather.notify_all();   // full: its gatherer need not sit out the window
+    }
+    std::memcpy(b->q.get() + (size_t)slot * d, query, (size_t)d * 4);
+    b->ready.fetch_add(1, std::memory_order_release);
+    t_joined = std::chrono::steady_clock::now();
     uint32_t led = 0;
-    std::unique_lock<std::mutex> lk(c.mu);
-    // everything that can fail for lack of memory happens before the request is visible to other callers (`req` lives on this
-    // stack frame: a caller that unwinds while others hold a pointer to it would strand them) or inside the try block below
-    std::vector<OneRequest *> batch;
-    batch.reserve(c.max_batch);
-    c.pending.push_back(&req);
-    if (c.gatherer_active) c.cv_gather.notify_one();
-    while (!req.done) {
-        if (c.gatherer_active) {   // parked until this request is done or this caller is asked to gather
-            req.cv.wait(lk);
-            continue;
-        }
-        // ---- gatherer: wait until the batch is due, take it, pass the role on -------------------------------------------
-        c.gatherer_active = true;
-        t_lead = std::chrono::steady_clock::now();
-        const auto deadline = t_lead + std::chrono::microseconds(c.window_us);
-        for (;;) {
-            const bool full = c.pending.size() >= c.max_batch;
-            const bool due = full || std::chrono::steady_clock::now() >= deadline;
-            if (due && c.in_flight < c.max_in_flight) break;
-            if (due) c.cv_gather.wait(lk);            // only a finishing batch can make it runnable
-            else c.cv_gather.wait_until(lk, deadline);
-        }
-        const nidx_gpu_vector_search_params_t lead = c.pending.front()->params;
-        const size_t room = std::min<size_t>(c.max_batch, batch.capacity());
-        batch.clear();
-        for (auto it = c.pending.begin(); it != c.pending.end() && batch.size() < room;) {
-            if (same_params((*it)->params, lead)) {
-                batch.push_back(*it);
-                it = c.pending.erase(it);
-            } else {
-                ++it;
+    if (gatherer) {
+        uint32_t B;
+        {
+            std::unique_lock<std::mutex> lk(c.mu);
+            const auto deadline = t_in + std::chrono::microseconds(c.window_us);
+            for (;;) {
+                const bool due = b->n >= b->cap || std::chrono::steady_clock::now() >= deadline;
+                if (due && c.in_flight < c.max_in_flight) break;
+                if (due) c.cv_gather.wait(lk);            // only a finishing batch can make it runnable
+                else c.cv_gather.wait_until(lk, deadline);
             }
+            // close: later arrivals open the next batch and gather it while this one is on the device
+            for (auto it = c.open.begin(); it != c.open.end(); ++it)
+                if (it->get() == b.get()) { c.open.erase(it); break; }
+            b->open = false;
+            B = b->n;
+            c.in_flight++;
         }
-        c.in_flight++;
-        c.gatherer_active = false;
-        // whoever is first in line (this caller runs its batch now) gathers the next one meanwhile; a woken caller that finds
-        // the role taken by a new arrival simply parks again
-        for (OneRequest *r : c.pending)
-            if (r != &req) {
-                r->cv.notify_one();
-                break;
-            }
-        lk.unlock();
+        while (b->ready.load(std::memory_order_acquire) < B) sched_yield();   // a member between its slot and the end of its row copy
         t_gathered = std::chrono::steady_clock::now();
-        const uint32_t B = (uint32_t)batch.size(), k = lead.k, d = cfg.dimension;
         led = B;
+        const uint32_t k = b->params.k;
         const size_t kk = std::max<uint32_t>(k, 1);
-        std::vector<uint32_t> seg, par, vec, cnt;
-        std::vector<float> q, sc;
         int32_t rc;
         // the members of this batch are parked: whatever happens here, they must be released
         try {
-            q.resize((size_t)B * d);
-            for (uint32_t i = 0; i < B; i++) std::memcpy(&q[(size_t)i * d], batch[i]->query, (size_t)d * 4);
-            seg.resize(B * kk), par.resize(B * kk), vec.resize(B * kk), cnt.resize(B), sc.resize(B * kk);
+            b->seg.resize(B * kk), b->par.resize(B * kk), b->vec.resize(B * kk), b->cnt.resize(B), b->sc.resize(B * kk);
             uint64_t ticket = 0;
-            rc = pipeline_submit(q.data(), B, lead, nullptr, /*blocking=*/true, &ticket);
-            if (rc == NIDX_OK) rc = pipeline_wait(ticket, seg.data(), par.data(), vec.data(), sc.data(), cnt.data(), nullptr);
+            rc = pipeline_submit(b->q.get(), B, b->params, nullptr, /*blocking=*/true, &ticket);
+            if (rc == NIDX_OK) rc = pipeline_wait(ticket, b->seg.data(), b->par.data(), b->vec.data(), b->sc.data(), b->cnt.data(), nullptr);
         } catch (...) {
             rc = abi_exception();
         }
-        char err[512] = {0};
-        if (rc != NIDX_OK) nidx_gpu_last_error(err, sizeof(err));
+        b->rc = rc;
+        if (rc != NIDX_OK) nidx_gpu_last_error(b->error, sizeof(b->error));
         t_searched = std::chrono::steady_clock::now();
-        lk.lock();
-        for (uint32_t i = 0; i < B; i++) {
-            OneRequest *r = batch[i];
-            r->rc = rc;
-            if (rc != NIDX_OK) std::memcpy(r->error, err, sizeof(err));
-            else {
-                *r->out_count = cnt[i];
-                for (uint32_t j = 0; j < cnt[i]; j++) {
-                    if (r->out_segment) r->out_segment[j] = seg[i * kk + j];
-                    if (r->out_paragraph) r->out_paragraph[j] = par[i * kk + j];
-                    if (r->out_vector) r->out_vector[j] = vec[i * kk + j];
-                    if (r->out_score) r->out_score[j] = sc[i * kk + j];
-                }
-            }
-            r->done = true;
-            if (r != &req) r->cv.notify_one();
+        b->done.store(1, std::memory_order_release);
+        futex_wake_all(&b->done);
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            c.n_batches++;
+            c.n_queries += B;
+            c.in_flight--;
         }
-        c.n_batches++;
-        c.n_queries += B;
-        c.in_flight--;
-        c.cv_gather.notify_one();   // a gatherer waiting for a free slot
-        // (this caller's own request may have had other parameters than the batch it led: it is still pending then, and the
-        // loop either parks it behind the current gatherer or makes it the gatherer again)
-        t_posted = std::chrono::steady_clock::now();
+        c.cv_gather.notify_all();   // gatherers waiting for a free slot
+    } else {
+        while (b->done.load(std::memory_order_acquire) == 0) futex_wait(&b->done, 0);
+    }
+    // ---- every member takes its own hits ------------------------------------------------------------------------------------------
+    const int32_t rc = b->rc;
+    if (rc == NIDX_OK) {
+        const size_t kk = std::max<uint32_t>(b->params.k, 1);
+        const uint32_t cnt = b->cnt[slot];
+        *out_count = cnt;
+        for (uint32_t j = 0; j < cnt; j++) {
+            if (out_segment) out_segment[j] = b->seg[slot * kk + j];
+            if (out_paragraph) out_paragraph[j] = b->par[slot * kk + j];
+            if (out_vector) out_vector[j] = b->vec[slot * kk + j];
+            if (out_score) out_score[j] = b->sc[slot * kk + j];
+        }
+    } else {
+        set_error("%s", b->error);
     }
     if (trace_slow_us() > 0) {
         const auto t_out = std::chrono::steady_clock::now();
         if (us(t_in, t_out) > trace_slow_us())
-            fprintf(stderr, "[nidx_gpu slow search_one] total %.0f us: led a batch of %u (0 = member only); until gatherer %.0f, gather %.0f, search %.0f, hand-out %.0f, after %.0f\n",
-                    us(t_in, t_out), led, us(t_in, t_lead), us(t_lead, t_gathered), us(t_gathered, t_searched), us(t_searched, t_posted), us(t_posted, t_out));
+            fprintf(stderr, "[nidx_gpu slow search_one] total %.0f us: led a batch of %u (0 = member only); join %.0f, gather %.0f, search %.0f, after %.0f\n",
+                    us(t_in, t_out), led, us(t_in, t_joined), us(t_joined, t_gathered), us(t_gathered, t_searched), us(t_searched, t_out));
     }
-    if (req.rc != NIDX_OK) set_error("%s", req.error);
-    return req.rc;
+    return rc;
 }
 
 void VectorIndex::coalescer_stats(uint64_t &batches, uint64_t &queries) {
@@ -176,7 +202,7 @@ std::shared_ptr<Coalescer> make_coalescer() { return std::make_shared<Coalescer>
 void VectorIndex::coalescer_config(int32_t window_us, int32_t max_batch, int32_t in_flight) {
     std::lock_guard<std::mutex> lk(coalescer->mu);
     if (window_us >= 0) coalescer->window_us = (uint32_t)window_us;
-    if (max_batch > 0) coalescer->max_batch = (uint32_t)max_batch;
+    if (max_batch > 0) coalescer->max_batch = (uint32_t)std::min(max_batch, 4096);   // batches already open keep their size
     if (in_flight > 0) coalescer->max_in_flight = (uint32_t)std::min(in_flight, 16);
 }
 

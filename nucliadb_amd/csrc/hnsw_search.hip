@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
     }
     __syncthreads();
     const bool entry_mode = a.entry_vec != nullptr;
+    const int efu = a.ef_upper ? (int)a.ef_upper : 1;
     for (int layer = entry_mode ? 0 : (int)a.g.ep_layer; layer >= 1; layer--) {
-        layer_search_block<NJ, EFL, EVR>(a.seg, a.g, layer, 1, q, sh, vis, a.vis_log2, res, st);
+        layer_search_block<NJ, EFL, EVR>(a.seg, a.g, layer, efu, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             uint64_t key = res.l[0].key;
             if (lane < res.len) sh.eps[lane] = rank_key_addr(key);
@@ -304,7 +305,7 @@ static hipError_t launch_wide(const HnswSearchArgs &a, int waves, hipStream_t s)
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    if (a.k == 0 || a.k > NIDX_K_MAX || a.ef_search > NIDX_K_MAX) return hipErrorInvalidValue;
+    if (a.k == 0 || a.k > NIDX_K_MAX || a.ef_search > NIDX_K_MAX || a.ef_upper > 64) return hipErrorInvalidValue;
     int nj = (int)((a.seg.dp + 255u) / 256u);
     if (waves_per_query < 1) waves_per_query = 1;
     if (waves_per_query > 4) waves_per_query = 4;

@@ -173,6 +173,9 @@ struct HnswSearchArgs {
     // 0 = the reference's EF_SEARCH (hnsw/params.rs:46); the layer-0 search keeps ef = max(k, ef_search) results.  Only the
     // "ef_search" tunable sets it: a flat 10 M graph trades ef against the recall the reference gets from merging 50 segments
     uint32_t ef_search = 0;
+    // 0 = 1, the reference's greedy descent (search.rs:318-324: k = 1 on the layers above 0).  Only the "ef_upper" tunable sets it: the
+    // descent then keeps ef_upper results per upper layer and hands all of them to the next layer as entry points (<= 64).
+    uint32_t ef_upper = 0;
 };
 #define NIDX_DUMP_STRIDE 512
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);

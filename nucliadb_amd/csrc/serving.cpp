@@ -110,10 +110,14 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
     {
         std::unique_lock<std::mutex> lk(P.mu);
         for (;;) {
-            for (auto &s : P.slots)
-                if (!s->busy) { slot = s.get(); break; }
+            // `depth` bounds the tickets outstanding, also after it was lowered below the number of slots that exist
+            uint32_t n_busy = 0;
+            for (auto &s : P.slots) n_busy += s->busy ? 1u : 0u;
+            if (n_busy < P.depth)
+                for (auto &s : P.slots)
+                    if (!s->busy) { slot = s.get(); break; }
             if (slot) break;
-            if (P.slots.size() < P.depth) {
+            if (n_busy < P.depth) {
                 std::unique_ptr<SearchSlot> ns(new SearchSlot());
                 NIDX_HIP(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
                 NIDX_HIP(hipEventCreateWithFlags(&ns->done, hipEventDisableTiming));

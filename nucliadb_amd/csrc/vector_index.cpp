@@ -330,6 +330,7 @@ int32_t VectorIndex::segment_spill_search(uint32_t s, const float *d_queries, ui
         a.dump_score = scratch_dump_score.as<float>();
         a.dump_count = scratch_dump_count.as<uint32_t>();
         a.ef_search = ef_search;
+        a.ef_upper = ef_upper;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         std::vector<uint32_t> stats((size_t)nq * NIDX_STAT_STRIDE);
         NIDX_HIP(hipMemcpyAsync(stats.data(), scratch_stats.p, stats.size() * 4, hipMemcpyDeviceToHost, st));
@@ -433,6 +434,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         a.dump_count = nullptr;
         a.flag_word = d_flag_word;
         a.ef_search = ef_search;
+        a.ef_upper = ef_upper;
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -1161,6 +1163,10 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "ef_search") {   // 0 = the reference's EF_SEARCH (30)
         if (value < 0 || value > NIDX_K_MAX) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_search must be in 0..%d", NIDX_K_MAX);
         idx->ef_search = (uint32_t)value;
+    }
+    else if (n == "ef_upper") {   // 0 = the reference's greedy descent (one result per upper layer)
+        if (value < 0 || value > 64) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_upper must be in 0..64");
+        idx->ef_upper = (uint32_t)value;
     }
     else return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown tunable %s", name);
     return NIDX_OK;

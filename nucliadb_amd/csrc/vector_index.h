@@ -89,6 +89,7 @@ struct VectorIndex {
     int rows_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 4 : eval_rows; }
     int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : min_waves; }
     uint32_t ef_search = 0;   // 0 = EF_SEARCH (hnsw/params.rs:46); tunable "ef_search"
+    uint32_t ef_upper = 0;    // 0 = 1: the greedy descent of hnsw/search.rs:318-324; tunable "ef_upper"
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
     uint32_t last_build_flags = 0;
