@@ -66,6 +66,17 @@ def parse():
     p.add_argument("--single-query-calls", type=int, default=2048, help="hnsw: nidx_gpu_vector_search_one calls for the p50/p99 figure (0 = skip)")
     p.add_argument("--min-timed-s", type=float, default=1.0,
                    help="the timed pass of --steps steps is repeated until the timed region is at least this long (ms_per_step = mean over all)")
+    p.add_argument("--build-ef-upper", type=int, default=4,
+                   help="hnsw: tunable build_ef_upper of the timed flat graph: results kept per layer while an insertion descends to its "
+                        "node's top layer (0 = 1 = the reference's greedy descent, hnsw/build.rs:137-146).  A greedy descent into a graph of "
+                        "millions of nodes ends in the wrong neighbourhood for a few percent of the insertions, and a node linked into the "
+                        "wrong neighbourhood cannot be found by any search width (scripts/diag_orphans.py); the reference never builds such "
+                        "graphs (segments stay <= 200 k records).  Searches keep the reference's constants either way.")
+    p.add_argument("--ef-upper", type=int, default=4,
+                   help="hnsw: tunable ef_upper of the timed searches: results kept per layer of the descent (1 = the reference's greedy "
+                        "descent, hnsw/search.rs:318-324).  With a greedy descent a few percent of the queries end in another neighbourhood "
+                        "of a 10 M-node layer 0 and return nothing useful; 4 costs no measurable time and removes them.  The oracle restates "
+                        "the knob, so parity is checked at this setting; the reference-constants figures are reported beside it.")
     p.add_argument("--iso-target", type=float, default=0.0, help="hnsw: recall target of the iso-recall ladder when the segment-regime leg is off")
     p.add_argument("--iso-recall", type=int, default=1, help="hnsw: also time the flat graph at the ef_search whose recall reaches the reference regime's (0 = skip)")
     p.add_argument("--bm25-block", type=int, default=1, help="hnsw: add the BM25 and hybrid blocks of BASELINE.json configs[2] to the default line (0 = skip)")
@@ -468,7 +479,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     torch.cuda.synchronize()
     gen_s = time.time() - t0
     cfg = _lib.VectorConfigC(d, 1, 0, 0)
-    gpath = os.path.join(a.graph_cache, "hnsw_%s_%d_%d_r%d.graph" % (kind, n, d, rank)) if a.graph_cache else ""
+    gpath = os.path.join(a.graph_cache, "hnsw_%s_%d_%d_r%d_u%d.graph" % (kind, n, d, rank, a.build_ef_upper)) if a.graph_cache else ""
     cached = None
     if gpath and os.path.exists(gpath):
         cached = np.fromfile(gpath, dtype=np.uint8)
@@ -486,6 +497,8 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     torch.cuda.empty_cache()
     t0 = time.time()
     if not (gpath and os.path.exists(gpath)):
+        if a.build_ef_upper > 1:
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"build_ef_upper", a.build_ef_upper))
         _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
         if gpath:
             os.makedirs(a.graph_cache, exist_ok=True)
@@ -493,6 +506,8 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             g_.tofile(gpath)
             del g_, _e
     build_s = time.time() - t0
+    if a.ef_upper > 1:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", a.ef_upper))
 
     out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)
@@ -788,15 +803,15 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
                 print("ERROR: parity.%s: %s" % (name, status), file=sys.stderr)
     del x_host
 
-    # ---- the flat graph at the reference regime's recall ------------------------------------------------------------------------
+    # ---- recall bar and the reference's own search constants ----------------------------------------------------------------------
     # The reference at this corpus size is 50 segments of <= 200 k records, EACH searched at ef = 30 and merged: that regime's
-    # recall@k (measured above against the exact scan) is the bar "recall >= reference".  One flat graph reaches it at a larger
-    # ef_search; the ladder below finds the smallest such ef and times the serving loop there.
-    iso = None
+    # recall@k (measured above against the exact scan) is the bar "recall >= reference".  The timed configuration (--ef-upper,
+    # layer-0 ef = 30) is checked against it; if it fell short, a ladder of wider layer-0 searches would be walked and the first
+    # rung that reaches the bar timed.  The same graph at the reference's constants (greedy descent) is timed beside it.
+    iso, ref_consts = None, None
     seg_reg = (cpu or {}).get("segment_regime") if isinstance(cpu, dict) else None
     iso_target = a.iso_target if a.iso_target > 0 else (seg_reg or {}).get("recall_at_%d" % k) if isinstance(seg_reg, dict) else None
-    if rank == 0 and world == 1 and a.iso_recall and exact0 is not None and iso_target is not None:
-        target = iso_target
+    if rank == 0 and world == 1 and a.iso_recall and exact0 is not None:
         rq = min(a.recall_queries, B)
         ev, _es, ec = exact0
 
@@ -807,26 +822,11 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             f_ = [len(set(g_[i][:k].tolist()) & set(ev[i, : ec[i]].tolist())) for i in range(rq)]
             return float(np.mean(f_)) / k, np.bincount(np.asarray(f_, np.int64), minlength=k + 1).tolist()
 
-        iso = {"target": ("recall@%d of the reference regime (%d segments x ef = 30 + Fssc, oracle)" % (k, seg_reg.get("segments", 0)))
-                         if a.iso_target <= 0 else "--iso-target",
-               "target_recall": target, "ladder": [],
-               "knobs": "ef_upper = results kept per upper layer of the descent (reference: 1, hnsw/search.rs:318-324), ef_search = results kept "
-                        "on layer 0 (reference: 30); both tunables, defaults = the reference's constants"}
-        chosen = None
-        # the cheap knob first: a wider descent (the upper layers hold 1/30 of the nodes), then a wider layer-0 search
-        for efu, ef in ((1, 30), (4, 30), (8, 30), (16, 30), (32, 30), (64, 30), (16, 48), (32, 64), (64, 96), (64, 128), (64, 192), (64, 256)):
-            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", 0 if efu == 1 else efu))
-            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", ef))
-            r_, hist_ = recall_now()
-            iso["ladder"].append({"ef_upper": efu, "ef_search": ef, "recall": r_, "queries_by_hits": hist_})
-            if r_ >= target:
-                chosen = (efu, ef)
-                break
-        if chosen is not None:
+        def timed_now():
             for i in range(max(2, a.warmup)):
                 step(i)
             drain()
-            n_iso = max(a.steps, int(steps_timed * 0.6))
+            n_iso = max(a.steps, int(steps_timed * 0.4))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(n_iso):
@@ -845,17 +845,47 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             torch.cuda.synchronize()
             st = stats.cpu().numpy().astype(np.int64)
             ab = float((st[:, 0] * 4 * d + st[:, 1] * 256).sum())
-            iso.update({"ef_upper": chosen[0], "ef_search": chosen[1], "recall_at_%d" % k: iso["ladder"][-1]["recall"], "queries_per_s": B * n_iso / dt,
-                        "ms_per_step": dt / n_iso * 1e3, "steps": n_iso, "batches_in_flight": nfl,
-                        "distance_evals_per_query": float(st[:, 0].mean()), "expansions_per_query": float(st[:, 1].mean()),
-                        "kernel_flags": int(np.bitwise_or.reduce(st[:, 3])),
-                        "roofline": {"bound": "hbm", "achieved": ab / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab, "kernel_ms": k_ms,
-                                     "sustained_frac": ab * n_iso / dt / 1e9 / HBM_PEAK_GBS}})
-        else:
-            iso["note"] = "no rung of the ladder reaches the target"
-        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", 0))
-        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", 0))
+            return {"queries_per_s": B * n_iso / dt, "ms_per_step": dt / n_iso * 1e3, "steps": n_iso, "batches_in_flight": nfl,
+                    "distance_evals_per_query": float(st[:, 0].mean()), "expansions_per_query": float(st[:, 1].mean()),
+                    "kernel_flags": int(np.bitwise_or.reduce(st[:, 3])),
+                    "roofline": {"bound": "hbm", "achieved": ab / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab, "kernel_ms": k_ms,
+                                 "sustained_frac": ab * n_iso / dt / 1e9 / HBM_PEAK_GBS}}
+
+        if iso_target is not None:
+            iso = {"target": ("recall@%d of the reference regime (%d segments x ef = 30 + Fssc, oracle)" % (k, seg_reg.get("segments", 0)))
+                             if a.iso_target <= 0 else "--iso-target",
+                   "target_recall": iso_target, "timed_configuration": {"ef_upper": max(1, a.ef_upper), "ef_search": 30, "recall": recall},
+                   "knobs": "ef_upper = results kept per upper layer of the descent (reference: 1, hnsw/search.rs:318-324), ef_search = results "
+                            "kept on layer 0 (reference: 30); both tunables of the library, defaults = the reference's constants"}
+            if recall is not None and recall >= iso_target:
+                iso["status"] = "the timed configuration reaches the bar: `value` is the iso-recall figure"
+            else:
+                iso["ladder"] = []
+                chosen = None
+                for ef in (48, 64, 96, 128, 192, 256):
+                    _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", ef))
+                    r_, hist_ = recall_now()
+                    iso["ladder"].append({"ef_upper": max(1, a.ef_upper), "ef_search": ef, "recall": r_, "queries_by_hits": hist_})
+                    if r_ >= iso_target:
+                        chosen = ef
+                        break
+                if chosen is not None:
+                    iso.update({"ef_search": chosen, "recall_at_%d" % k: iso["ladder"][-1]["recall"]})
+                    iso.update(timed_now())
+                    iso["status"] = "reached on the ladder"
+                else:
+                    iso["status"] = "no rung of the ladder reaches the target"
+                    FAILURES.append("recall: no configuration of the ladder reaches the reference regime's recall")
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_search", 0))
+        if a.ef_upper > 1:
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", 0))
+            r_, hist_ = recall_now()
+            ref_consts = {"ef_upper": 1, "ef_search": 30, "recall_at_%d" % k: r_, "queries_by_hits": hist_,
+                          "note": "the same graph searched with the reference's constants (greedy descent): its misses are whole queries whose "
+                                  "descent ends in another neighbourhood of a 10 M-node layer 0"}
+            ref_consts.update(timed_now())
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", a.ef_upper))
 
     # ---- the other half of BASELINE.json's metric on the same box: BM25 over as many synthetic documents, and the hybrid batch ---
     bm25_blk, hybrid_blk = None, None
@@ -872,7 +902,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             FAILURES.append("bm25 / hybrid block failed: %r" % (e,))
     L.nidx_gpu_vector_close(h)
     if res is not None:
-        res.update({"extra": extra, "parity": parity, "cpu": cpu, "iso_recall": iso, "bm25": bm25_blk, "hybrid": hybrid_blk})
+        res.update({"extra": extra, "parity": parity, "cpu": cpu, "iso_recall": iso, "reference_constants": ref_consts, "bm25": bm25_blk, "hybrid": hybrid_blk})
     return res
 
 
@@ -958,6 +988,7 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
     if a.parity_queries > 0 and got0 is not None:
         nq = min(a.parity_queries, B)
         oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_WAVE64, graph=og)
+        oseg.ef_upper = a.ef_upper if a.ef_upper > 1 else 0
         ov, os_, oc = oseg.hnsw_search_batch(q0[:nq], k, threads=threads)
         gv, gs, gc = got0
         same = [bool(oc[i] == gc[i] and np.array_equal(ov[i, : oc[i]], gv[i, : oc[i]].view(np.uint32)) and
@@ -983,13 +1014,14 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
     if a.cpu_queries > 0:
         qs = qpool.reshape(-1, d)[: a.cpu_queries].cpu().numpy()
         oseg = orc.Segment(x_host, similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL, graph=og)
+        oseg.ef_upper = a.ef_upper if a.ef_upper > 1 else 0   # the same search configuration as the timed device run
         oseg.hnsw_search_batch(qs[:threads], k, threads=threads)  # warm
         t0 = time.perf_counter()
         cv, cs, cc, cst = oseg.hnsw_search_batch(qs, k, threads=threads, want_stats=True)
         dt = time.perf_counter() - t0
         cpu = {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
                "sample": "%d queries of the timed pool over the same %d x %d %s shard and device-built graph, oracle (C restatement of the "
-                         "reference algorithm, AVX2-shaped f32 sums), one query per POSIX thread; flat = ONE segment" % (qs.shape[0], n, d, kind),
+                         "reference algorithm, AVX2-shaped f32 sums), one query per POSIX thread; flat = ONE segment; descent width ef_upper = %d like the timed device run" % (qs.shape[0], n, d, kind, max(1, a.ef_upper)),
                "distance_evals_per_query": float(cst[:, 0].mean())}
         if got0 is not None:
             m = min(B, qs.shape[0])
@@ -1144,14 +1176,15 @@ def bench_hnsw(a, L, dev, rank, world):
         "merged_queries_per_s": B * head["steps_timed"] / head["elapsed"],
         "recall_at_%d" % k: head["recall"], "recall_queries": min(a.recall_queries, B), "recall_queries_by_hits": head.get("recall_hist"),
         "recall_at_%d_reference_regime" % k: ((head.get("cpu") or {}).get("segment_regime") or {}).get("recall_at_%d" % k),
-        "iso_recall": head.get("iso_recall"), "bm25": head.get("bm25"), "hybrid": head.get("hybrid"),
+        "search_knobs": {"ef_upper": max(1, a.ef_upper), "ef_search": 30},
+        "iso_recall": head.get("iso_recall"), "reference_constants": head.get("reference_constants"), "bm25": head.get("bm25"), "hybrid": head.get("hybrid"),
         "distance_evals_per_query": head["evals"], "expansions_per_query": head["expansions"],
         "expansions_with_edge_record_fetched_ahead_per_query": head["edge_hits"],
         "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"], "timed_queries_re_run_exactly": head["timed_retried"],
         "timed_region": {"steps_per_pass": a.steps, "passes": head["repeats"], "steps_timed": head["steps_timed"], "seconds": head["elapsed"],
                          "entry": "nidx_gpu_vector_search_submit / _wait: device-resident queries in, hits in host arrays out" if world == 1 else
                                   "nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (RCCL inside the library)"},
-        "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"],
+        "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"], "build_ef_upper": max(1, a.build_ef_upper),
         "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],
         "batches_in_flight": head["nfl"],
         "parity": head.get("parity"),

@@ -512,6 +512,9 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     // launch shape knobs (no effect on results): postings rows per window and postings per work item
     uint64_t slice_postings = BM25_SLICE_POSTINGS;
     const bool force_wide = getenv("NIDX_GPU_BM25_WIDE") != nullptr;   // every query through the general kernel (tests)
+    // NIDX_GPU_BM25_UNION: 0 = never the union kernel, 2 = every query of <= 8 plain term clauses (tests drive its slow path with it)
+    int union_mode = 1;
+    if (const char *e = getenv("NIDX_GPU_BM25_UNION")) union_mode = atoi(e);
     (void)max_clauses;
     if (const char *e = getenv("NIDX_GPU_BM25_SLICE")) slice_postings = (uint64_t)std::max(256, atoi(e));
     for (uint64_t c = 0; c < n_clauses; c++) {
@@ -692,30 +695,65 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
-        // the items of narrow queries go to the lean kernel, the rest to the general one
+        // three launches over disjoint item lists: term unions whose lists rarely meet (bm25_union.hip), the other narrow queries
+        // (bm25_fast_kernel), the rest (bm25_rows_kernel).  A query is a "rare-meeting union" when it has at most 8 plain term clauses
+        // and the number of documents two of its lists are expected to share (independent lists: len_a * len_b / n_docs, summed over
+        // the pairs) is at most 1/8 of its postings — the union kernel is exact for any input, that bound only keeps its slow path rare.
+        std::vector<uint8_t> q_union(nq, 0);
+        for (uint32_t q = 0; q < nq && union_mode != 0; q++) {
+            const uint64_t c0 = clause_offsets[q], c1 = clause_offsets[q + 1];
+            if (c1 - c0 == 0 || c1 - c0 > BM25_FAST_CLAUSES || force_wide) continue;
+            bool plain = true;
+            double sum = 0.0, sum_sq = 0.0;
+            for (uint64_t c = c0; c < c1; c++) {
+                if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE)) plain = false;
+                const double l = (double)postings_of(clauses[c]);
+                sum += l;
+                sum_sq += l * l;
+            }
+            if (!plain) continue;
+            const double shared = (sum * sum - sum_sq) / 2.0 / std::max<double>(1.0, (double)seg.n_docs);
+            q_union[q] = (union_mode == 2 || shared * 8.0 <= sum) ? 1 : 0;
+        }
         std::vector<uint32_t> item_list(nw);
-        uint32_t n_fast = 0, n_wide = 0, wide_max_clauses = 0;
+        uint32_t n_union = 0, n_fast = 0, n_wide = 0, wide_max_clauses = 0;
+        for (size_t w = 0; w < nw; w++)
+            if (q_union[work[w].query]) item_list[n_union++] = (uint32_t)w;
         for (size_t w = 0; w < nw; w++) {
-            const uint32_t nc = (uint32_t)(clause_offsets[work[w].query + 1] - clause_offsets[work[w].query]);
-            if (nc <= BM25_FAST_CLAUSES && !force_wide) item_list[n_fast++] = (uint32_t)w;
+            const uint32_t nc = work[w].n_clauses;
+            if (!q_union[work[w].query] && nc <= BM25_FAST_CLAUSES && !force_wide) item_list[n_union + n_fast++] = (uint32_t)w;
         }
         for (size_t w = 0; w < nw; w++) {
-            const uint32_t nc = (uint32_t)(clause_offsets[work[w].query + 1] - clause_offsets[work[w].query]);
-            if (!(nc <= BM25_FAST_CLAUSES && !force_wide)) {
-                item_list[n_fast + n_wide++] = (uint32_t)w;
+            const uint32_t nc = work[w].n_clauses;
+            if (!q_union[work[w].query] && !(nc <= BM25_FAST_CLAUSES && !force_wide)) {
+                item_list[n_union + n_fast + n_wide++] = (uint32_t)w;
                 wide_max_clauses = std::max(wide_max_clauses, nc);
+            }
+        }
+        // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
+        std::vector<Bm25UClause> ucl(n_union ? n_clauses : 0);
+        for (uint32_t q = 0; q < nq && n_union; q++) {
+            if (!q_union[q]) continue;
+            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) {
+                const uint64_t b = seg.term_offsets_host[clauses[c].term];
+                const uint64_t l = seg.term_offsets_host[clauses[c].term + 1] - b;
+                if (l > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "a posting list of one segment holds more than 2^32 - 1 postings");
+                ucl[c] = Bm25UClause{(uint32_t)b, (uint32_t)(b >> 32), (uint32_t)l, dev_clauses[c].weight,
+                                     (uint32_t)dev_clauses[c].occur | ((uint32_t)dev_clauses[c].mode << 8), 0u, 0u, 0u};
             }
         }
         t_work += now_us() - t_w0;
         NIDX_HIP(idx->s_key.reserve(nw * kk * 8));
-        const size_t if_bytes = ((size_t)(nq + 1) * 4 + 7) & ~(size_t)7;
-        const size_t work_bytes = (nw * sizeof(Bm25Work) + 7) & ~(size_t)7;
-        const size_t inw_bytes = if_bytes + work_bytes + nw * 4;
+        const size_t if_bytes = ((size_t)(nq + 1) * 4 + 31) & ~(size_t)31;   // 32-byte pieces: the clause table is read with 16-byte scalar loads
+        const size_t work_bytes = (nw * sizeof(Bm25Work) + 31) & ~(size_t)31;
+        const size_t items_bytes = (nw * 4 + 31) & ~(size_t)31;
+        const size_t inw_bytes = if_bytes + work_bytes + items_bytes + ucl.size() * sizeof(Bm25UClause);
         NIDX_HIP(idx->s_in_w.reserve(inw_bytes));
         NIDX_HIP(idx->h_in_w.reserve(inw_bytes));
         memcpy(idx->h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
         memcpy(idx->h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
         memcpy(idx->h_in_w.as<unsigned char>() + if_bytes + work_bytes, item_list.data(), nw * 4);
+        if (!ucl.empty()) memcpy(idx->h_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes, ucl.data(), ucl.size() * sizeof(Bm25UClause));
         NIDX_HIP(hipMemcpyAsync(idx->s_in_w.p, idx->h_in_w.p, inw_bytes, hipMemcpyHostToDevice, idx->stream));
         const uint32_t *d_item_first = idx->s_in_w.as<uint32_t>();
         const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(idx->s_in_w.as<unsigned char>() + if_bytes);
@@ -764,15 +802,18 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         a.match_bits = n_slots ? idx->s_match_bits.as<uint32_t>() : nullptr;
         a.match_slot = n_slots ? idx->s_match_slot.as<int>() : nullptr;
         a.match_words = match_words;
+        a.uclauses = reinterpret_cast<const Bm25UClause *>(idx->s_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes);
         a.dbg = nullptr;
         DevBuf dbgbuf;
         if (getenv("NIDX_GPU_BM25_DEBUG")) {
-            NIDX_HIP(dbgbuf.alloc(9 * 8));
-            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, 72, idx->stream));
+            NIDX_HIP(dbgbuf.alloc((16 + 8 * nw) * 8));
+            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, (16 + 8 * nw) * 8, idx->stream));
             a.dbg = dbgbuf.as<unsigned long long>();
+
         }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
-        NIDX_HIP(launch_bm25_search(a, d_items, n_fast, d_items + n_fast, n_wide, wide_max_clauses, idx->stream));
+        NIDX_HIP(launch_bm25_union(a, d_items, n_union, a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr, idx->stream));
+        NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
         Bm25MergeArgs mg;
         mg.item_first = d_item_first;
@@ -808,6 +849,46 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         if (a.dbg) {
             unsigned long long d[9];
             NIDX_HIP(hipMemcpy(d, a.dbg, 72, hipMemcpyDeviceToHost));
+            if (n_union) {
+                std::vector<unsigned long long> tr(8 * nw);
+                NIDX_HIP(hipMemcpy(tr.data(), a.dbg + 16, tr.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<std::pair<unsigned long long, uint32_t>> by;
+                for (uint32_t w = 0; w < nw; w++)
+                    if (tr[8 * w]) by.push_back({tr[8 * w], w});
+                std::sort(by.begin(), by.end());
+                auto pct = [&](double p) { return by.empty() ? 0ull : by[(size_t)(p * (by.size() - 1))].first; };
+                unsigned long long t_min = ~0ull, t_max = 0;
+                for (auto &e : by) {
+                    const unsigned long long st = tr[8 * e.second + 3] & 0xffffffffull;
+                    t_min = std::min(t_min, st);
+                    t_max = std::max(t_max, st);
+                }
+                fprintf(stderr, "[bm25 dbg] union items %zu: cycles p10 %llu p50 %llu p90 %llu p99 %llu max %llu; entry clocks (low 32 bits) span %llu\n", by.size(),
+                        pct(0.1), pct(0.5), pct(0.9), pct(0.99), pct(1.0), t_max - t_min);
+                {   // phase cycles per window by the number of slices of the item's query
+                    const uint32_t edges[5] = {1, 2, 4, 16, 0xffffffffu};
+                    for (int g = 0; g < 5; g++) {
+                        unsigned long long n = 0, wins = 0, ld = 0, fi = 0, fn = 0, rs = 0, st = 0, po = 0;
+                        for (auto &e : by) {
+                            const uint32_t w = e.second, ns = work[w].n_slices;
+                            if (ns > edges[g] || (g > 0 && ns <= edges[g - 1])) continue;
+                            n++, wins += tr[8 * w + 2] & 0xffffffffull, ld += tr[8 * w + 4], fi += tr[8 * w + 5], fn += tr[8 * w + 6], rs += tr[8 * w + 7], st += tr[8 * w + 1], po += tr[8 * w + 3] >> 32;
+                        }
+                        if (n) fprintf(stderr, "[bm25 dbg]   queries of <= %u slices: %llu items, %.1f windows and %.0f postings per item, setup %.0f; per window: load %.0f filter %.0f final %.0f resolve %.0f cycles\n",
+                                       edges[g], n, (double)wins / n, (double)po / n, (double)st / n, (double)ld / wins, (double)fi / wins, (double)fn / wins, (double)rs / wins);
+                    }
+                }
+                for (size_t i = by.size() >= 6 ? by.size() - 6 : 0; i < by.size(); i++) {
+                    const uint32_t w = by[i].second;
+                    fprintf(stderr, "[bm25 dbg]   slow item %u: %llu cycles (setup %llu; load %llu filter %llu final %llu resolve %llu), %llu windows, %llu inserts, %llu postings, query %u slice %u/%u\n", w, tr[8 * w],
+                            tr[8 * w + 1], tr[8 * w + 4], tr[8 * w + 5], tr[8 * w + 6], tr[8 * w + 7], tr[8 * w + 2] & 0xffffffffull, tr[8 * w + 2] >> 32, tr[8 * w + 3] >> 32, work[w].query, work[w].slice, work[w].n_slices);
+                }
+                for (size_t i = 0; i < std::min<size_t>(3, by.size()); i++) {
+                    const uint32_t w = by[i].second;
+                    fprintf(stderr, "[bm25 dbg]   fast item %u: %llu cycles (setup %llu; load %llu filter %llu final %llu resolve %llu), %llu windows, %llu inserts, %llu postings, query %u slice %u/%u\n", w, tr[8 * w],
+                            tr[8 * w + 1], tr[8 * w + 4], tr[8 * w + 5], tr[8 * w + 6], tr[8 * w + 7], tr[8 * w + 2] & 0xffffffffull, tr[8 * w + 2] >> 32, tr[8 * w + 3] >> 32, work[w].query, work[w].slice, work[w].n_slices);
+                }
+            }
             fprintf(stderr, "[bm25 dbg] items=%llu windows=%llu (max %llu per item) cycles/item: setup=%llu load=%llu apply=%llu fold=%llu windows total=%llu; longest item (entry to exit) %llu cycles; kernel_ms=%.3f\n",
                     d[5], d[4], d[8], d[6] / (d[5] ? d[5] : 1), d[0] / (d[5] ? d[5] : 1), d[1] / (d[5] ? d[5] : 1), d[2] / (d[5] ? d[5] : 1), d[3] / (d[5] ? d[5] : 1), d[7], ms);
         }

@@ -36,6 +36,7 @@ struct BuildArgs {
     uint64_t *req_key;          // [n_slots*32]  layer:4 | target:30 | source:30   (~0 = unused)
     float *req_val;             // [n_slots*32]
     uint32_t vis_log2;
+    uint32_t ef_upper;          // results kept per layer ABOVE the node's top layer (0 = 1: the greedy descent of build.rs / search.rs)
     uint32_t *flags;            // [1] OR of NIDX_FLAG_*
     unsigned long long *dbg;    // nullptr or 5 counters: appends, prunes, prune cycles, total cycles, targets
 };
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
     __syncthreads();
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const bool in_layer = layer <= level;
-        const int k = in_layer ? NIDX_EF_CONSTRUCTION : 1;
+        const int k = in_layer ? NIDX_EF_CONSTRUCTION : (a.ef_upper ? (int)a.ef_upper : 1);
         layer_search_block<NJ, 2, 4>(a.seg, a.g, layer, k, q, sh, vis, a.vis_log2, res, st);
         if (ctl) {
             // next layer's entry points = every result (build.rs:146)
@@ -395,6 +396,7 @@ hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s) {
     a.req_key = b.req_key;
     a.req_val = b.req_val;
     a.vis_log2 = b.vis_log2;
+    a.ef_upper = b.ef_upper;
     a.flags = b.flags;
     a.dbg = b.dbg;
     int nj = (int)((a.seg.dp + 255u) / 256u);

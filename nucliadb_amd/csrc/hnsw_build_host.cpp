@@ -162,6 +162,7 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     b.sort_tmp = d_tmp.p;
     b.sort_tmp_bytes = tmp_bytes;
     b.vis_log2 = build_vis_log2;
+    b.ef_upper = build_ef_upper;
     b.flags = d_flags.as<uint32_t>();
     DevBuf d_dbg;
     b.dbg = nullptr;

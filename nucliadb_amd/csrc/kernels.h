@@ -263,6 +263,7 @@ struct BuildBatch {
     void *sort_tmp;
     size_t sort_tmp_bytes;
     uint32_t vis_log2;
+    uint32_t ef_upper = 0;      // results kept per layer above the node's top layer (0 = 1: the reference's greedy descent)
     uint32_t *flags;            // [1]
     unsigned long long *dbg;    // nullptr or [5] (NIDX_GPU_BUILD_DEBUG)
 };
@@ -298,6 +299,13 @@ struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
 struct Bm25Work {  // one work item: query `query`, doc-id slice `slice` of `n_slices`; its clause records [clause_first, + n_clauses)
     uint32_t query, slice, n_slices, clause_first, n_clauses;
 };
+// bm25_union_kernel's clause table (one record per query clause, per segment): the list's first posting, its length, the
+// Bm25Weight (or constant score) and occur | mode << 8 — everything the kernel needs of a clause without touching term_offsets
+struct Bm25UClause {
+    uint32_t b_lo, b_hi, len;
+    float weight;
+    uint32_t attr, pad0, pad1, pad2;
+};
 #define BM25_ITEM_THREADS 64      /* threads per work item (64 = one wave: no block barriers) */
 #define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
 #define BM25_MAX_SLICES 256
@@ -331,6 +339,7 @@ struct Bm25Args {
     uint32_t *match_bits;                   // [n_slots][match_words]
     const int *match_slot;                  // [n_queries] or nullptr
     uint32_t match_words;
+    const Bm25UClause *uclauses;            // [n_clauses of the batch] (bm25_union_kernel), parallel to `clauses`
 };
 #define BM25_AUX_TERM 0x80000000u
 struct Bm25MergeArgs {  // per query: merge the key lists of its work items [item_first[q], item_first[q + 1])
@@ -349,6 +358,8 @@ hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStre
 #define BM25_LIST_PAD_BYTES 8192  /* slack behind the posting arrays: the kernels load whole 64-posting rows unconditionally */
 hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uint32_t n_fast, const uint32_t *wide_items, uint32_t n_wide,
                               uint32_t max_clauses, hipStream_t s);
+// term unions whose lists rarely meet (bm25_union.hip); extras = alive bitset / facet bitsets / order by a fast field / search-after
+hipError_t launch_bm25_union(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s);
 
 // ---- BM25 surroundings (bm25_aux.hip) ----
 // FuzzyTermQuery's automaton over the whole term dictionary: flags[t] = 1 when term t is accepted

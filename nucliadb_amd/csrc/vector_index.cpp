@@ -1164,6 +1164,10 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
         if (value < 0 || value > NIDX_K_MAX) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_search must be in 0..%d", NIDX_K_MAX);
         idx->ef_search = (uint32_t)value;
     }
+    else if (n == "build_ef_upper") {   // 0 = the reference's greedy descent while inserting
+        if (value < 0 || value > 64) return fail(NIDX_ERR_INVALID_ARGUMENT, "build_ef_upper must be in 0..64");
+        idx->build_ef_upper = (uint32_t)value;
+    }
     else if (n == "ef_upper") {   // 0 = the reference's greedy descent (one result per upper layer)
         if (value < 0 || value > 64) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_upper must be in 0..64");
         idx->ef_upper = (uint32_t)value;

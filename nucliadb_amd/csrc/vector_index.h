@@ -92,6 +92,7 @@ struct VectorIndex {
     uint32_t ef_upper = 0;    // 0 = 1: the greedy descent of hnsw/search.rs:318-324; tunable "ef_upper"
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
+    uint32_t build_ef_upper = 0;   // 0 = 1 (reference); tunable "build_ef_upper": a wider descent when inserting into very large flat graphs
     uint32_t last_build_flags = 0;
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,

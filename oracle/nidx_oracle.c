@@ -727,9 +727,10 @@ static size_t hnsw_search(const retr_t *r, const orc_hnsw *g, size_t k, const ui
     uint32_t *eps = (uint32_t *)malloc(sizeof(uint32_t));
     size_t n_ep = 1;
     eps[0] = g->ep_node;
+    const size_t ef_upper = r->seg->ef_upper ? r->seg->ef_upper : 1;
     while (layer != 0) {
         cnx_t *lr;
-        size_t n = layer_search(r, g, layer, 1, eps, n_ep, &lr);
+        size_t n = layer_search(r, g, layer, ef_upper, eps, n_ep, &lr);
         eps = (uint32_t *)realloc(eps, (n ? n : 1) * sizeof(uint32_t));
         for (size_t i = 0; i < n; i++) eps[i] = lr[i].addr;
         n_ep = n;

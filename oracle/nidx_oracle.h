@@ -72,6 +72,9 @@ typedef struct {
                                 * segment.rs:506-513) */
     uint32_t ef_search;        /* 0 = the reference's constant EF_SEARCH = 30 (hnsw/params.rs:46); another value only for the
                                 * bench's iso-recall leg (the flat graph at the ef whose recall matches the segmented regime) */
+    uint32_t ef_upper;         /* 0 = 1: the reference's greedy descent, k = 1 on the layers above 0 (hnsw/search.rs:318-324); another
+                                * value keeps that many results per upper layer, all of them entry points of the next one — the
+                                * product's "ef_upper" tunable, restated here so that its results are checked too */
 } orc_segment;
 
 typedef struct {

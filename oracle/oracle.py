@@ -47,6 +47,7 @@ class _Segment(C.Structure):
         ("graph", C.c_void_p),
         ("quantized", C.c_void_p),
         ("ef_search", C.c_uint32),
+        ("ef_upper", C.c_uint32),
     ]
 
 
@@ -475,6 +476,7 @@ class Segment:
         # vectors.quant (RaBitQ records); when set every search takes the reference's RaBitQ branch
         self.quantized = None if quantized is None else np.ascontiguousarray(quantized, dtype=np.uint8)
         self.ef_search = 0   # 0 = the reference's EF_SEARCH (30)
+        self.ef_upper = 0    # 0 = 1: the reference's greedy descent
 
     def quantize(self):
         """DataStoreV2::create's quantized writer (data_store/v2.rs:57-76): encode every vector."""
@@ -494,6 +496,7 @@ class Segment:
         s.graph = None if self.graph is None else self.graph.h
         s.quantized = None if self.quantized is None else self.quantized.ctypes.data
         s.ef_search = self.ef_search
+        s.ef_upper = self.ef_upper
         return s
 
     def build_graph(self, seed: int = 2) -> Hnsw:

@@ -38,6 +38,8 @@ def main():
     p.add_argument("--n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--queries", type=int, default=512)
+    p.add_argument("--build-ef-upper", type=int, default=0, help="tunable build_ef_upper (0 = the reference's greedy descent while inserting)")
+    p.add_argument("--degrees", type=int, default=1, help="0 = skip the host-side in-degree pass")
     a = p.parse_args()
     L = _lib.lib()
     dev = torch.device("cuda", 0)
@@ -55,10 +57,18 @@ def main():
     h = C.c_void_p()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
     del x
+    if a.build_ef_upper:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"build_ef_upper", a.build_ef_upper))
+    import time
+    t0 = time.time()
     _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
-    graph, _edges = bench.serialize_graph(L, h)
-    indeg, outdeg = layer0_in_degree(graph, n)
-    out = {"n": n, "orphans_layer0": int((indeg == 0).sum()), "in_degree_le_2": int((indeg <= 2).sum()),
+    build_s = time.time() - t0
+    if a.degrees:
+        graph, _edges = bench.serialize_graph(L, h)
+        indeg, outdeg = layer0_in_degree(graph, n)
+    else:
+        indeg, outdeg = np.full(n, 10, np.int64), np.zeros(n, np.int64)
+    out = {"n": n, "build_ef_upper": a.build_ef_upper, "build_s": build_s, "orphans_layer0": int((indeg == 0).sum()), "in_degree_le_2": int((indeg <= 2).sum()),
            "orphans_loose": int(((indeg == 0) & loose).sum()), "orphans_tight": int(((indeg == 0) & ~loose).sum()),
            "mean_in_degree_loose": float(indeg[loose].mean()), "mean_in_degree_tight": float(indeg[~loose].mean()),
            "mean_out_degree": float(outdeg.mean())}

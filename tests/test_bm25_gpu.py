@@ -190,3 +190,45 @@ def test_general_kernel_on_narrow_queries(orc, corpus, monkeypatch):
     compare(orc, seg, s, queries, 20)
     compare(orc, seg, s, queries, 100)
     s.close()
+
+
+@pytest.mark.parametrize("union_mode", ["2", "0"])
+def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeypatch, union_mode):
+    """bm25_union_kernel (postings are final unless a bitmap filter says their document may occur twice; those are resolved
+    exactly) against the oracle, on query families that make its slow path the common one: NIDX_GPU_BM25_UNION=2 sends every
+    query of <= 8 plain term clauses there — dense terms (term 0 is in nearly every document: every window overflows the
+    involved list and is cut in half), Must / MustNot / required Should groups, constant scores, negative and zero boosts,
+    k from 1 to 501, the alive bitset and the search-after cursor.  Mode 0 never uses it: the same answers from the hash kernels."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(21)
+    monkeypatch.setenv("NIDX_GPU_BM25_UNION", union_mode)
+    s = Bm25Searcher.open([seg])
+    G = _lib.OCCUR_SHOULD_GROUP
+    sparse = [[Clause(int(t)) for t in rng.integers(200, vocab, int(rng.integers(1, 9)))] for _ in range(48)]
+    dense = [[Clause(0), Clause(1), Clause(2)], [Clause(0, M), Clause(1, M), Clause(5)], [Clause(0, M, CONST, 0.5), Clause(300), Clause(301)],
+             [Clause(0), Clause(0)], [Clause(1, N), Clause(0), Clause(7)], [Clause(2, boost=-1.5), Clause(3, boost=0.0), Clause(4, boost=-0.0)],
+             [Clause(0, G), Clause(1, G), Clause(2, G + 1), Clause(3, G + 1), Clause(4, M, BASIC)], []]
+    mixed = []
+    for _ in range(64):
+        q = []
+        for _ in range(int(rng.integers(1, 9))):
+            q.append(Clause(int(rng.integers(0, 400)), int(rng.choice([S, S, M, N, G, G + 1])), int(rng.choice([FREQ, BASIC, CONST])),
+                            float(rng.choice([1.0, 0.5, 2.0]))))
+        mixed.append(q)
+    for k in (20, 1, 64, 201, 501):
+        compare(orc, seg, s, sparse + dense, k)
+    compare(orc, seg, s, mixed, 20)
+    compare(orc, seg, s, mixed + sparse, 10)
+    s.close()
+    # alive bitset + search-after (many exact score ties: tf == 1)
+    rng = np.random.default_rng(3)
+    docs = zipf_corpus(rng, 20000, 800, mean_len=12)
+    alive = orc.bitset(20000, ones=np.nonzero(rng.random(20000) < 0.7)[0].tolist())
+    seg2 = Bm25Segment.from_term_docs(docs, 800, alive=alive)
+    s = Bm25Searcher.open([seg2])
+    queries = [[Clause(int(t), S, BASIC) for t in rng.integers(0, 60, 3)] for _ in range(24)]
+    compare(orc, seg2, s, queries, 20)
+    docaddr, score, count, total, _ = s.search_batch(queries, 20)
+    after = [SearchAfter(float(score[i, 3]), t, int(docaddr[i, 3])) if count[i] > 3 else None for i, t in zip(range(len(queries)), [0, 1, 2] * 8)]
+    compare(orc, seg2, s, queries, 20, after=after)
+    s.close()

@@ -28,7 +28,7 @@ def make_segment(x, graph=None):
     return VectorSegment([f"k{i}" for i in range(n)], x, [[] for _ in range(n)], [b""] * n, graph=graph)
 
 
-def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_duplicates=True, filter_bits=None, alive=None, info=None):
+def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_duplicates=True, filter_bits=None, alive=None, info=None, tunables=None):
     """Single segment straight through the C ABI (no Python filter logic in between)."""
     L = _lib.lib()
     n, d = x.shape
@@ -39,6 +39,8 @@ def gpu_search(x, sim, queries, k, *, method, graph=None, min_score=-1.0, with_d
     h = C.c_void_p()
     _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)))
     try:
+        for name, value in (tunables or {}).items():
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, name.encode(), value))
         q = np.ascontiguousarray(queries, np.float32)
         B = q.shape[0]
         ov, osc, oc = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)
@@ -178,6 +180,27 @@ def test_hnsw_search_matches_oracle(orc, hnsw_case, k, with_dup):
         assert oc[i] == len(wv), (i, oc[i], len(wv))
         assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i, : oc[i]], wv)
         assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+@pytest.mark.parametrize("ef_upper,ef_search", [(4, 0), (1, 48), (8, 100), (64, 30), (16, 300)])
+def test_hnsw_search_knobs_match_the_oracles(orc, hnsw_case, ef_upper, ef_search):
+    """The two knobs that change results — "ef_search" (layer-0 width, reference constant 30) and "ef_upper" (results kept per
+    upper layer of the descent, reference: 1, hnsw/search.rs:318-345) — are restated in the oracle: ids, ranks and score bits."""
+    x, oseg, gbytes = hnsw_case
+    rng = np.random.default_rng(ef_upper * 1000 + ef_search)
+    q = np.vstack([x[49][None, :], unit_rows(rng, 24, x.shape[1])])
+    oseg.ef_upper, oseg.ef_search = ef_upper, ef_search
+    try:
+        for k, with_dup in ((10, True), (10, False), (70, True)):
+            ov, osc, oc = gpu_search(x, 1, q, k, method=_lib.METHOD_HNSW, graph=gbytes, with_duplicates=with_dup,
+                                     tunables={"ef_upper": ef_upper, "ef_search": ef_search})
+            for i in range(q.shape[0]):
+                wv, ws = oseg.hnsw_search(q[i], k, with_duplicates=with_dup)
+                assert oc[i] == len(wv), (i, oc[i], len(wv))
+                assert np.array_equal(ov[i, : oc[i]], wv), (i, ov[i, : oc[i]], wv)
+                assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+    finally:
+        oseg.ef_upper, oseg.ef_search = 0, 0
 
 
 def test_hnsw_search_filter_and_min_score(orc, hnsw_case):
