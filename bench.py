@@ -918,7 +918,7 @@ def single_query_latency(a, L, h, queries):
     q = np.ascontiguousarray(queries, np.float32)
     out = {}
     for th in (1, 64, 256, 1024):
-        n = min(calls, 256) if th == 1 else max(calls, 8 * th)
+        n = min(calls, 256) if th == 1 else max(calls, 48 * th)   # dozens of calls per thread: the start of a run is not its steady state
         lat = np.zeros(n, np.float32)
         el = C.c_double(0)
         # untimed warm-up: small batches take other launch shapes of the kernel, whose code objects load on first use

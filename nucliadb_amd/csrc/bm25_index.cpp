@@ -112,7 +112,13 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     *index_out = nullptr;
     std::unique_ptr<Bm25Index> idx(new Bm25Index());
     NIDX_HIP(hipGetDevice(&idx->device));
-    NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+    {
+        // BM25 launches are short (~0.15 ms) and their callers wait for them; when they share the device with HNSW batches in flight
+        // (the hybrid request: serving.cpp keeps several on their own streams) they should not queue behind those: highest priority
+        int lo = 0, hi = 0;
+        NIDX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        NIDX_HIP(hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, hi));
+    }
     NIDX_HIP(hipEventCreate(&idx->ev0));
     NIDX_HIP(hipEventCreate(&idx->ev1));
     idx->segs.resize(n_segments);

@@ -6,9 +6,10 @@
 // (serving.cpp: a stream and staging per batch in flight):
 //
 //   * an arrival JOINS the open batch of its parameters (or opens one and becomes its gatherer): a slot index under the
-//     coalescer's mutex — nothing else happens under it — then it copies its own query row into the batch and counts itself ready;
-//   * the gatherer waits until the batch is due — its window has passed (or it is full) AND fewer than max_in_flight batches are
-//     running — closes it (later arrivals open the next batch, whose first arrival gathers it while this one is on the device),
+//     coalescer's mutex — nothing else happens under it — then it copies its own query row into the batch (the gatherer copies
+//     the rows of members that have not got that far when it closes the batch);
+//   * the gatherer waits until the batch is due — one window after its first request if it then holds its share of the requests
+//     in the system, at most six windows (or it is full), AND fewer than max_in_flight batches are running — closes it (later arrivals open the next batch, whose first arrival gathers it while this one is on the device),
 //     runs it (submit + wait) and publishes "done" with ONE futex wake for all members;
 //   * every member copies its own hits out of the batch.
 // Under load a batch closes when an earlier launch finishes, so its size follows the arrival rate.  The mutex is taken twice per
@@ -48,7 +49,11 @@ struct CoBatch {
     uint32_t cap = 0, d = 0;
     uint32_t n = 0;                       // members (under Coalescer::mu while the batch is open, fixed afterwards)
     bool open = false;
-    std::atomic<uint32_t> ready{0};       // members whose query row is in `q`
+    // per member: where its query lies and who copies it into `q` — the member itself as soon as it has joined, or the gatherer
+    // when it closes the batch first (with more callers than cores a member can lose its time slice between taking its slot and
+    // copying its row: the gatherer must never wait for a descheduled thread).  0 = not copied, 1 = being copied, 2 = in `q`.
+    std::unique_ptr<const float *[]> src;
+    std::unique_ptr<std::atomic<uint8_t>[]> row_state;
     std::atomic<uint32_t> done{0};        // futex word: 0 = gathering / on the device, 1 = results (or rc) published
     std::unique_ptr<float[]> q;           // [cap][d]
     std::vector<uint32_t> seg, par, vec, cnt;
@@ -63,6 +68,7 @@ struct Coalescer {
     std::vector<std::shared_ptr<CoBatch>> open;   // at most one per parameter set
     std::vector<std::shared_ptr<CoBatch>> pool;   // batch objects are recycled (their query block is max_batch rows)
     uint32_t in_flight = 0;
+    std::atomic<uint32_t> active{0};      // requests inside search_one (joined, on the device or collecting their hits)
     uint64_t n_batches = 0, n_queries = 0;
     uint32_t window_us = 50, max_batch = 1024, max_in_flight = 4;
 };
@@ -83,6 +89,11 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
     };
     const auto t_in = std::chrono::steady_clock::now();
     auto t_joined = t_in, t_gathered = t_in, t_searched = t_in;
+    struct ActiveCount {
+        std::atomic<uint32_t> &n;
+        explicit ActiveCount(std::atomic<uint32_t> &c_) : n(c_) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~ActiveCount() { n.fetch_sub(1, std::memory_order_relaxed); }
+    } active_count(c.active);
     std::shared_ptr<CoBatch> b;
     uint32_t slot = 0;
     bool gatherer = false;
@@ -99,11 +110,13 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
                 b->cap = c.max_batch;
                 b->d = d;
                 b->q.reset(new float[(size_t)b->cap * d]);
+                b->src.reset(new const float *[b->cap]);
+                b->row_state.reset(new std::atomic<uint8_t>[b->cap]);
                 if (c.pool.size() < 32) c.pool.push_back(b);
             }
             b->params = p;
             b->n = 0;
-            b->ready.store(0, std::memory_order_relaxed);
+            for (uint32_t i = 0; i < b->cap; i++) b->row_state[i].store(0, std::memory_order_relaxed);
             b->done.store(0, std::memory_order_relaxed);
             b->rc = NIDX_OK;
             b->open = true;
@@ -111,22 +124,39 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
             gatherer = true;
         }
         slot = b->n++;
+        b->src[slot] = query;
         if (!gatherer && b->n == b->cap) c.cv_gather.notify_all();   // full: its gatherer need not sit out the window
     }
-    std::memcpy(b->q.get() + (size_t)slot * d, query, (size_t)d * 4);
-    b->ready.fetch_add(1, std::memory_order_release);
+    {
+        uint8_t unclaimed = 0;
+        if (b->row_state[slot].compare_exchange_strong(unclaimed, 1, std::memory_order_acquire)) {
+            std::memcpy(b->q.get() + (size_t)slot * d, query, (size_t)d * 4);
+            b->row_state[slot].store(2, std::memory_order_release);
+        }
+    }
     t_joined = std::chrono::steady_clock::now();
     uint32_t led = 0;
     if (gatherer) {
         uint32_t B;
         {
             std::unique_lock<std::mutex> lk(c.mu);
-            const auto deadline = t_in + std::chrono::microseconds(c.window_us);
+            // The batch is due one window after its first request IF it then holds its share of the requests that are inside
+            // search_one right now (active / (max_in_flight + 1): with F batches on the device and one gathering, that share keeps
+            // every caller either in a launch or in the next one); a batch short of its share waits on, window by window, at most
+            // six.  A lone caller waits one window; 64 callers pipeline through batches of ~13; 1 024 through batches of ~200.
+            const auto w = std::chrono::microseconds(c.window_us);
+            auto deadline = t_in + w;
+            const auto latest = t_in + 6 * w;
             for (;;) {
-                const bool due = b->n >= b->cap || std::chrono::steady_clock::now() >= deadline;
+                const auto now = std::chrono::steady_clock::now();
+                const uint32_t share = std::max<uint32_t>(1u, c.active.load(std::memory_order_relaxed) / (c.max_in_flight + 1u));
+                const bool due = b->n >= b->cap || (now >= deadline && (b->n >= share || now >= latest));
                 if (due && c.in_flight < c.max_in_flight) break;
                 if (due) c.cv_gather.wait(lk);            // only a finishing batch can make it runnable
-                else c.cv_gather.wait_until(lk, deadline);
+                else {
+                    if (now >= deadline) deadline = std::min(latest, now + w);
+                    c.cv_gather.wait_until(lk, deadline);
+                }
             }
             // close: later arrivals open the next batch and gather it while this one is on the device
             for (auto it = c.open.begin(); it != c.open.end(); ++it)
@@ -135,7 +165,15 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
             B = b->n;
             c.in_flight++;
         }
-        while (b->ready.load(std::memory_order_acquire) < B) sched_yield();   // a member between its slot and the end of its row copy
+        for (uint32_t i = 0; i < B; i++) {   // rows their members have not copied yet
+            uint8_t unclaimed = 0;
+            if (b->row_state[i].compare_exchange_strong(unclaimed, 1, std::memory_order_acquire)) {
+                std::memcpy(b->q.get() + (size_t)i * d, b->src[i], (size_t)d * 4);
+                b->row_state[i].store(2, std::memory_order_release);
+            }
+        }
+        for (uint32_t i = 0; i < B; i++)     // (a member inside its 3 KiB copy right now)
+            while (b->row_state[i].load(std::memory_order_acquire) != 2) sched_yield();
         t_gathered = std::chrono::steady_clock::now();
         led = B;
         const uint32_t k = b->params.k;

@@ -6,6 +6,8 @@
 // HBM-bound roofline fraction of hnsw_search_kernel should be read against (a float4 COPY reaches 6.3 TB/s on this
 // part because half of its traffic is writes; a pure gather has no write stream).
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -116,6 +118,8 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
     // must not strand the ones already spinning at the start line
     std::atomic<uint32_t> started{0};
     std::atomic<bool> abort_run{false};
+    std::mutex start_mu;
+    std::condition_variable start_cv;
     auto worker = [&](uint32_t t) {
         try {
             (void)hipSetDevice(dev);
@@ -125,8 +129,15 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
             uint32_t count = 0;
             int32_t r = nidx_gpu_vector_search_one(index, queries + (size_t)(t % n_queries) * dimension, dimension, params, seg.data(), par.data(),
                                                    vec.data(), score.data(), &count);
-            if (ready.fetch_add(1) + 1 == threads) t0 = std::chrono::steady_clock::now();
-            while (ready.load() < threads && !abort_run.load()) std::this_thread::yield();
+            {   // the start line: parked, not spinning (1 024 yielding threads on 64 cores would be the first thing measured)
+                std::unique_lock<std::mutex> lk(start_mu);
+                if (ready.fetch_add(1) + 1 == threads) {
+                    t0 = std::chrono::steady_clock::now();
+                    start_cv.notify_all();
+                } else {
+                    start_cv.wait(lk, [&] { return ready.load() >= threads || abort_run.load(); });
+                }
+            }
             if (abort_run.load()) return;
             if (r != NIDX_OK) { rc[t] = r; return; }
             for (uint32_t c = t; c < calls; c += threads) {
@@ -138,10 +149,14 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
             }
         } catch (const std::bad_alloc &) {
             rc[t] = NIDX_ERR_OUT_OF_MEMORY;
+            std::lock_guard<std::mutex> lk(start_mu);
             ready.fetch_add(1);
+            start_cv.notify_all();
         } catch (...) {
             rc[t] = NIDX_ERR_INTERNAL;
+            std::lock_guard<std::mutex> lk(start_mu);
             ready.fetch_add(1);
+            start_cv.notify_all();
         }
     };
     int32_t spawn_rc = NIDX_OK;
@@ -151,7 +166,11 @@ extern "C" int32_t nidx_gpu_diag_single_query_latency(nidx_gpu_vector_index_t *i
             started.fetch_add(1);
         } catch (...) {
             spawn_rc = fail(NIDX_ERR_INTERNAL, "could not start probe thread %u of %u", t, threads);
-            abort_run.store(true);
+            {
+                std::lock_guard<std::mutex> lk(start_mu);
+                abort_run.store(true);
+            }
+            start_cv.notify_all();
             break;
         }
     }
