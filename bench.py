@@ -451,15 +451,17 @@ def serialize_graph(L, h, seg=0):
 
 def pmc_traffic(kind, n, d, B, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r02_pmc_traffic.json, written by scripts/refresh_profiles.sh; counters cannot be read from inside this process)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            for e in json.load(f)["entries"]:
-                w = e["workload"]
-                if (w["corpus"], w["n_vectors"], w["dim"], w["batch"], w["k"]) == (kind, n, d, B, k):
-                    return e["hbm_bytes_per_launch"], e["source"]
-    except (OSError, KeyError, ValueError, TypeError):
-        pass
+    (profiles/r03_pmc_traffic.json — or the previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
+    cannot be read from inside this process)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                for e in json.load(f)["entries"]:
+                    w = e["workload"]
+                    if (w["corpus"], w["n_vectors"], w["dim"], w["batch"], w["k"]) == (kind, n, d, B, k):
+                        return e["hbm_bytes_per_launch"], e["source"]
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
     return None, None
 
 

@@ -739,6 +739,12 @@ typedef struct {
 } nidx_gpu_ranked_list_t;
 int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k,
                                  uint32_t window, uint64_t *out_ids, double *out_scores, uint32_t *out_counts);
+/* WeightedCombSum._fuse + RankFusionAlgorithm.fuse (rank_fusion.py:184-254): the lists in the order given, their hits in the order
+ * given (no re-ranking); a hit's id is first seen => it enters with score (f64)score * weight, else the term is added; then the
+ * same stable sort by score descending, the first `window` hits, and the same single-source shortcut.  Every list carries scores;
+ * `weight` = WeightedCombSum.weights[source]. */
+int32_t nidx_gpu_rank_fusion_wcombsum(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, uint32_t window,
+                                      uint64_t *out_ids, double *out_scores, uint32_t *out_counts);
 
 #ifdef __cplusplus
 }

@@ -290,6 +290,7 @@ SIGNATURES = {
                                                        C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p]),
     "nidx_gpu_rank_fusion_rrf": (C.c_int32, [C.POINTER(RankedListC), C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_rank_fusion_wcombsum": (C.c_int32, [C.POINTER(RankedListC), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_merge_bm25": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
 }

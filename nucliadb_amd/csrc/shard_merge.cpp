@@ -280,12 +280,18 @@ int32_t nidx_gpu_merge_facets(const nidx_gpu_facet_count_t *const *shard_facets,
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
-// ---- rank fusion (nucliadb rank_fusion.py:60-181), batched on the host -----------------------------------------------------------
-int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window,
-                                 uint64_t *out_ids, double *out_scores, uint32_t *out_counts) try {
+}  // extern "C"
+
+// ---- rank fusion (nucliadb rank_fusion.py:60-254), batched on the host -----------------------------------------------------------
+// comb_sum = false: ReciprocalRankFusion._fuse (:139-181); true: WeightedCombSum._fuse (:216-252) — the hits in the order given, the
+// term is score * weight (f64, like the Python expression over the f32 scores), a hit's first occurrence is the one kept
+static int32_t rank_fusion(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window, bool comb_sum,
+                           uint64_t *out_ids, double *out_scores, uint32_t *out_counts) {
     if ((n_lists && !lists) || !out_ids || !out_scores || !out_counts) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
-    for (uint32_t l = 0; l < n_lists; l++)
+    for (uint32_t l = 0; l < n_lists; l++) {
         if (!lists[l].counts || (lists[l].stride && !lists[l].ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: NULL arrays", l);
+        if (comb_sum && lists[l].stride && !lists[l].scores) return fail(NIDX_ERR_INVALID_ARGUMENT, "list %u: wCombSUM needs the scores", l);
+    }
     struct Item { uint64_t id; double score; };
     // _fuse ranks every source by its OWN scores, descending, with a stable sort (rank_fusion.py:139-147): a list that carries
     // scores and is not already in that order (BM25 hits ordered by a fast field, say) is ranked through a per-query
@@ -325,7 +331,7 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
                     const uint32_t c = std::min(L.counts[q], L.stride);
                     // sorted(values, key=score, reverse=True): only when the list is not in that order already
                     bool ranked = true;
-                    if (L.scores)
+                    if (L.scores && !comb_sum)
                         for (uint32_t r = 1; r < c && ranked; r++)
                             ranked = !(L.scores[(size_t)q * L.stride + r] > L.scores[(size_t)q * L.stride + r - 1]);
                     if (!ranked) {
@@ -337,7 +343,7 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
                     }
                     for (uint32_t r = 0; r < c; r++) {
                         const uint64_t id = L.ids[(size_t)q * L.stride + (ranked ? r : perm[r])];
-                        const double term = (1.0 / (k + (double)r)) * L.weight;
+                        const double term = comb_sum ? (double)L.scores[(size_t)q * L.stride + r] * L.weight : (1.0 / (k + (double)r)) * L.weight;
                         size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 32) & (cap - 1);
                         while (slot_at[h] != 0xffffffffu && slot_id[h] != id) h = (h + 1) & (cap - 1);
                         if (slot_at[h] == 0xffffffffu) {
@@ -383,6 +389,18 @@ int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n
     if (worker_failure.load() == 1) return fail(NIDX_ERR_OUT_OF_MEMORY, "rank fusion: a host allocation failed");
     if (worker_failure.load() == 2) return fail(NIDX_ERR_INTERNAL, "rank fusion: unexpected exception in a worker");
     return NIDX_OK;
+}
+
+extern "C" {
+
+int32_t nidx_gpu_rank_fusion_rrf(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, double k, uint32_t window,
+                                 uint64_t *out_ids, double *out_scores, uint32_t *out_counts) try {
+    return rank_fusion(lists, n_lists, n_queries, k, window, false, out_ids, out_scores, out_counts);
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_rank_fusion_wcombsum(const nidx_gpu_ranked_list_t *lists, uint32_t n_lists, uint32_t n_queries, uint32_t window,
+                                      uint64_t *out_ids, double *out_scores, uint32_t *out_counts) try {
+    return rank_fusion(lists, n_lists, n_queries, 0.0, window, true, out_ids, out_scores, out_counts);
 } NIDX_ABI_CATCH
 
 }  // extern "C"

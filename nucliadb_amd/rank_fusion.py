@@ -1,6 +1,7 @@
 """Host mirror of nucliadb's rank fusion of the BM25 and vector lists:
-`nucliadb/src/nucliadb/search/search/rank_fusion.py:60-254` — plain Python over windows of a few hundred hits, so it
-stays on the host; the lists it fuses come from the HIP kernels (ParagraphSearcher / VectorSearcher).
+`nucliadb/src/nucliadb/search/search/rank_fusion.py:60-254` — windows of a few hundred hits, so it stays on the host; the lists
+it fuses come from the HIP kernels (ParagraphSearcher / VectorSearcher).  The classes below mirror the reference's objects (score
+types, per-hit score history); rrf_fuse_batch / wcombsum_fuse_batch run whole batches through the library's native routines.
 
   fuse()                 one non-empty source => its hits unchanged, else the algorithm; then sort by score desc (:74-91)
   ReciprocalRankFusion   score(d) = sum over retrievers of weight(r) / (k + rank_r(d)), ranks from each list sorted by score
@@ -101,7 +102,13 @@ class WeightedCombSum(RankFusionAlgorithm):
         return out
 
 
-def rrf_fuse_batch(lists, k: float = 60.0, window: int = 20):
+def wcombsum_fuse_batch(lists, window: int = 20):
+    """WeightedCombSum for a whole batch through the native host routine (nidx_gpu_rank_fusion_wcombsum): `lists` as for
+    rrf_fuse_batch, every one with its f32 scores, hits in the order the retriever returned them."""
+    return rrf_fuse_batch(lists, k=0.0, window=window, _comb_sum=True)
+
+
+def rrf_fuse_batch(lists, k: float = 60.0, window: int = 20, _comb_sum: bool = False):
     """ReciprocalRankFusion for a whole batch through the native host routine (nidx_gpu_rank_fusion_rrf): `lists` =
     [(ids u64 [B][stride], counts u32 [B], weight, scores f32 [B][stride] | None), ...] in source order.
     -> (ids u64 [B][window], scores f64 [B][window], counts u32 [B])"""
@@ -123,5 +130,8 @@ def rrf_fuse_batch(lists, k: float = 60.0, window: int = 20):
     out_ids = np.zeros((B, window), np.uint64)
     out_scores = np.zeros((B, window), np.float64)
     out_counts = np.zeros(B, np.uint32)
-    _lib.check(_lib.lib().nidx_gpu_rank_fusion_rrf(arr, len(lists), B, float(k), window, out_ids.ctypes.data, out_scores.ctypes.data, out_counts.ctypes.data))
+    if _comb_sum:
+        _lib.check(_lib.lib().nidx_gpu_rank_fusion_wcombsum(arr, len(lists), B, window, out_ids.ctypes.data, out_scores.ctypes.data, out_counts.ctypes.data))
+    else:
+        _lib.check(_lib.lib().nidx_gpu_rank_fusion_rrf(arr, len(lists), B, float(k), window, out_ids.ctypes.data, out_scores.ctypes.data, out_counts.ctypes.data))
     return out_ids, out_scores, out_counts

@@ -83,10 +83,18 @@ def main():
 
     kinds = {"keyword": (SCORE_TYPE.BM25, KeywordScore), "semantic": (SCORE_TYPE.VECTOR, SemanticScore),
              "graph": (SCORE_TYPE.RELATION_RELEVANCE, GraphScore)}
+    import struct
+
+    def f32(x):   # the product's lists carry f32 scores: cases 96.. use values an f32 holds exactly, so the native routine can replay them
+        return struct.unpack("f", struct.pack("f", x))[0]
+
     rng = random.Random(20260924)
     cases = []
-    for case in range(96):
-        algo = "rrf" if case % 2 == 0 else "wcombsum"
+    for case in range(144):
+        if case == 96:
+            rng = random.Random(20260925)   # (cases 0..95 stay what they were)
+        exact32 = case >= 96
+        algo = "rrf" if case % 2 == 0 and not exact32 else "wcombsum"
         n_ids = rng.choice([3, 8, 20, 60])
         pool = ["%032x/f/file%d/%d-%d" % (rng.randrange(1, 6), rng.randrange(3), 10 * i, 10 * i + 9) for i in range(n_ids)]
         sources = {}
@@ -102,6 +110,8 @@ def main():
                 scores = [float.fromhex((rng.uniform(0.1, 30.0)).hex()) for _ in range(n)]
             else:
                 scores = [rng.uniform(-0.2, 1.0) for _ in range(n)]
+            if exact32:
+                scores = [f32(x) for x in scores]
             sources[name] = [(i, s) for i, s in zip(ids, scores)]
         weights = {} if rng.random() < 0.4 else {n: rng.choice([0.5, 1.0, 2.0, 3.25]) for n in rng.sample(list(kinds), rng.randrange(1, 4))}
         k = rng.choice([60.0, 2.0, 1.0, 10.5])
@@ -114,7 +124,7 @@ def main():
                          for pid, s in hits] for name, hits in sources.items()}
         merged = fusion.fuse(inputs)
         cases.append({
-            "algorithm": algo, "k": k, "weights": weights, "default_weight": default_weight,
+            "algorithm": algo, "k": k, "weights": weights, "default_weight": default_weight, "f32_scores": exact32,
             "sources": {name: [[pid, s.hex(), kinds[name][0].value] for pid, s in hits] for name, hits in sources.items()},
             "expected": [[m.paragraph_id.full(), float(m.score).hex(), m.score_type.value, [float(s.score).hex() for s in m.scores]] for m in merged],
         })
