@@ -545,6 +545,14 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
  * nidx_text): the terms at consecutive positions, tf = number of occurrences, Bm25Weight::for_terms (idf summed
  * over the terms).  `mode` is ignored. */
 #define NIDX_BM25_PHRASE 0x40000000u
+/* A clause whose `term` is NIDX_BM25_SUBQUERY | j is a nested BooleanQuery: the leaves options.subquery_clauses[subquery_offsets[j]
+ * .. subquery_offsets[j+1]) — plain terms, at most 16, AT LEAST ONE of them Must; occur / mode / boost as for top-level clauses,
+ * required Should groups included.  It matches a document when its own boolean structure does, its score there is the f32 sum of its
+ * scoring leaves that hold the document (leaf order), and the outer clause contributes boost x that score (tantivy: BoostQuery over
+ * the nested BooleanQuery; `mode` of the outer clause is ignored).  This is what tantivy's QueryParser builds for an AND inside an
+ * OR, a negated conjunction or a boosted conjunction (nidx_text/src/reader.rs:357-376) and what a conjunction or a negation inside an
+ * `Or` filtering formula becomes (nidx_paragraph/src/search_query.rs:88-143). */
+#define NIDX_BM25_SUBQUERY 0x20000000u
 
 typedef struct {
     uint32_t k;                                  /* TopDocs limit (0 with facets = only_faceted) */
@@ -569,6 +577,9 @@ typedef struct {
     const uint64_t *facet_offsets;               /* [n_queries + 1] */
     uint64_t *out_facet_counts;                  /* [facet_offsets[n_queries]], summed over segments */
     int64_t *out_order_value;                    /* NULL or [n_queries][k]: the fast value of every hit (order_field >= 0) */
+    const nidx_gpu_bm25_clause_t *subquery_clauses;   /* leaves of every nested BooleanQuery, concatenated (NIDX_BM25_SUBQUERY) */
+    const uint64_t *subquery_offsets;                 /* [n_subqueries + 1] */
+    uint32_t n_subqueries;
 } nidx_gpu_bm25_search_options_t;
 
 /* nidx_gpu_bm25_search with the collectors above; out_score is the BM25 score when ordering by score and 0

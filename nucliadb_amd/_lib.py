@@ -90,11 +90,15 @@ class Bm25SearchOptionsC(C.Structure):
         ("facet_offsets", C.c_void_p),
         ("out_facet_counts", C.c_void_p),
         ("out_order_value", C.c_void_p),
+        ("subquery_clauses", C.c_void_p),
+        ("subquery_offsets", C.c_void_p),
+        ("n_subqueries", C.c_uint32),
     ]
 
 
 BM25_TERM_SET = 0x80000000
 BM25_PHRASE = 0x40000000
+BM25_SUBQUERY = 0x20000000
 
 
 class FilterIndexC(C.Structure):

@@ -34,6 +34,9 @@ class Clause:
     # PhraseQuery(term_set) with slop 0: the terms at consecutive positions in this order, tf = occurrences,
     # Bm25Weight::for_terms (the index must have been opened with positions)
     phrase: bool = False
+    # a nested BooleanQuery (NIDX_BM25_SUBQUERY): its leaves — plain term clauses, at least one of them Must; the outer clause
+    # contributes boost x the nested query's own score; `term` and `mode` are ignored
+    subquery: Optional[Sequence["Clause"]] = None
 
 
 @dataclass
@@ -217,9 +220,15 @@ class Bm25Searcher:
         set_comp: List[int] = []
         phrase_terms: List[int] = []
         phrase_offsets = [0]
+        sub_leaves: List[Clause] = []
+        sub_offsets = [0]
         for i, c in enumerate(flat):
             cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
-            if c.term_set is not None and c.phrase:
+            if c.subquery is not None:
+                cl[i].term = _lib.BM25_SUBQUERY | (len(sub_offsets) - 1)
+                sub_leaves.extend(c.subquery)
+                sub_offsets.append(len(sub_leaves))
+            elif c.term_set is not None and c.phrase:
                 cl[i].term = _lib.BM25_PHRASE | (len(phrase_offsets) - 1)
                 phrase_terms.extend(int(t) for t in c.term_set)
                 phrase_offsets.append(len(phrase_terms))
@@ -257,6 +266,13 @@ class Bm25Searcher:
         opt.phrase_terms = pt.ctypes.data if pt.size else None
         opt.phrase_offsets = po.ctypes.data
         opt.n_phrases = len(phrase_offsets) - 1
+        sub_cl = (_lib.Bm25ClauseC * max(1, len(sub_leaves)))()
+        for i, c in enumerate(sub_leaves):
+            sub_cl[i].term, sub_cl[i].occur, sub_cl[i].mode, sub_cl[i].boost = c.term, c.occur, c.mode, c.boost
+        sub_off = np.ascontiguousarray(sub_offsets, dtype=np.uint64)
+        opt.subquery_clauses = C.cast(sub_cl, C.c_void_p) if sub_leaves else None
+        opt.subquery_offsets = sub_off.ctypes.data
+        opt.n_subqueries = len(sub_offsets) - 1
         opt.order_field, opt.order_desc = order_field, int(order_desc)
         fo = ft = fc = None
         if facets is not None:
@@ -278,7 +294,7 @@ class Bm25Searcher:
 
     def search_batch(self, queries: Sequence[Sequence[Clause]], k: int, after: Optional[Sequence[Optional[SearchAfter]]] = None):
         """-> (docaddr [B][k] u64, score [B][k] f32, count [B], total [B], postings [B])"""
-        if any(c.term_set is not None for q in queries for c in q):
+        if any(c.term_set is not None or c.subquery is not None for q in queries for c in q):
             r = self.search_batch_ex(queries, k, after)
             return r["docaddr"], r["score"], r["count"], r["total"], r["postings"]
         B = len(queries)

@@ -272,12 +272,13 @@ __global__ __launch_bounds__(256) void bm25_rows_kernel(Bm25Args a, const uint32
             if (active) cdoc_l = left_some ? nd : 0xffffffffu;
         }
         // ---- round trip 2: the packed tf | fieldnorm id << 24 word of the postings that are scored (no gather by doc id) ----
-        uint32_t p_tf[R], p_fn[R];
+        uint32_t p_tf[R], p_fn[R], p_raw[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const uint32_t occur = p_at[m] & 0xff, mode = (p_at[m] >> 8) & 0xff;
             const bool scored = p_ok[m] && occur != 2 && mode != 2;
             const uint32_t word = ((p_at[m] >> 16) && scored ? a.aux_tfs : a.tfs)[scored ? p_idx[m] : 0ull];
+            p_raw[m] = word;
             p_fn[m] = word >> 24;
             p_tf[m] = (scored && mode == 0) ? (word & 0xffffffu) : 1u;
         }
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void bm25_rows_kernel(Bm25Args a, const uint32
         for (int m = 0; m < R; m++) {
             const uint32_t mode = (p_at[m] >> 8) & 0xff;
             if (mode == 2) p_score[m] = p_w[m];  // ConstScorer(boost)
+            else if (mode == 3) p_score[m] = p_w[m] * __uint_as_float(p_raw[m]);   // a materialised sub-query: boost x its own score
             else {
                 const float tf = (float)p_tf[m];   // mode 1: tf == 1
                 p_score[m] = p_w[m] * (tf / (tf + tf_cache[p_fn[m]]));
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
             const float w = rl_f32(weight_l, row_c[m]);
             const float tf = mode == 0 ? (float)(p_tf[m] & 0xffffffu) : 1.0f;
             const float bm = w * (tf / (tf + tf_cache[p_tf[m] >> 24]));
-            p_score[m] = mode == 2 ? w : bm;   // ConstScorer(boost)
+            p_score[m] = mode == 2 ? w : mode == 3 ? w * __uint_as_float(p_tf[m]) : bm;   // ConstScorer(boost); a materialised sub-query
         }
         const unsigned long long cy_b = clock64();
         // ---- probe: every row's first CAS is issued before any result is looked at; collisions (another document in the slot)

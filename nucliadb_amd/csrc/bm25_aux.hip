@@ -243,6 +243,97 @@ hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const u
     return hipGetLastError();
 }
 
+// ---- nested BooleanQuery -> pre-scored posting list -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subquery_match_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *words,
+                                                             const float *tf_cache, SubqueryDev sq, uint32_t *tmp_ok, uint32_t *tmp_score) {
+    const unsigned long long b0 = term_offsets[sq.term[sq.driver]], e0 = term_offsets[sq.term[sq.driver] + 1];
+    const unsigned long long i0 = b0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= e0) return;
+    const uint32_t d = doc_ids[i0];
+    uint32_t mask = 0, must_m = 0, not_m = 0;
+    uint32_t group_m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float acc = 0.f;   // the nested scorer's own sum, leaf by leaf
+    for (uint32_t t = 0; t < sq.n; t++) {
+        const uint32_t occur = sq.occur[t];
+        if (occur == 1) must_m |= 1u << t;
+        else if (occur == 2) not_m |= 1u << t;
+        else if (occur >= 3) group_m[(occur - 3) & 7] |= 1u << t;
+        unsigned long long i = i0;
+        bool here = true;
+        if (t != sq.driver) {
+            const unsigned long long b = term_offsets[sq.term[t]], e = term_offsets[sq.term[t] + 1];
+            i = lower_bound_doc(doc_ids, b, e, d);
+            here = i < e && doc_ids[i] == d;
+        }
+        if (!here) continue;
+        mask |= 1u << t;
+        if (occur == 2) continue;
+        const uint32_t mode = sq.mode[t];
+        if (mode == 2) acc += sq.weight[t];
+        else {
+            const uint32_t w = words[i];
+            const float tf = mode == 0 ? (float)(w & 0xffffffu) : 1.0f;
+            acc += sq.weight[t] * (tf / (tf + tf_cache[w >> 24]));
+        }
+    }
+    bool ok = (mask & must_m) == must_m && (mask & not_m) == 0;
+    for (int g = 0; g < 8; g++)
+        if (group_m[g] && (mask & group_m[g]) == 0) ok = false;
+    tmp_ok[i0 - b0] = ok ? 1u : 0u;
+    tmp_score[i0 - b0] = __float_as_uint(acc);
+}
+
+hipError_t launch_subquery_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *posting_words, const float *tf_cache,
+                                 const SubqueryDev &sq, uint32_t n_driver, uint32_t *tmp_ok, uint32_t *tmp_score, hipStream_t s) {
+    if (n_driver == 0) return hipSuccess;
+    hipLaunchKernelGGL(subquery_match_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, posting_words, tf_cache, sq, tmp_ok,
+                       tmp_score);
+    return hipGetLastError();
+}
+
+// matches -> ascending (doc, score bits) list; one block, running offset (the driver's postings are in doc order)
+__global__ __launch_bounds__(256) void subquery_compact_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, SubqueryDev sq,
+                                                               const uint32_t *tmp_ok, const uint32_t *tmp_score, unsigned long long out_begin,
+                                                               uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const unsigned long long b0 = term_offsets[sq.term[sq.driver]], e0 = term_offsets[sq.term[sq.driver] + 1];
+    const uint32_t n = (uint32_t)(e0 - b0);
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        const uint32_t c = i < n ? tmp_ok[i] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wib] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int w = 0; w < wib; w++) before += wave_sum[w];
+        if (c) {
+            out_ids[out_begin + before + incl - 1] = doc_ids[b0 + i];
+            out_words[out_begin + before + incl - 1] = tmp_score[i];
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = base_s;
+}
+
+hipError_t launch_subquery_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, const SubqueryDev &sq, const uint32_t *tmp_ok,
+                                   const uint32_t *tmp_score, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(subquery_compact_kernel, dim3(1), dim3(256), 0, s, term_offsets, doc_ids, sq, tmp_ok, tmp_score, out_begin, out_ids, out_words,
+                       out_count);
+    return hipGetLastError();
+}
+
 // ---- posting words ---------------------------------------------------------------------------------------------------
 // The scorer needs a posting's term frequency and its document's fieldnorm id.  Fetching the fieldnorm by doc id is one random
 // cache line per posting (64-128 B moved for one byte); the resident copy therefore carries it in the posting itself:

@@ -504,6 +504,34 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     if (n_phrases)
         for (const Bm25Segment &sg : idx->segs)
             if (sg.term_offsets_host[idx->n_terms] && !sg.pos_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase clause on an index opened without positions");
+    // nested BooleanQuerys (NIDX_BM25_SUBQUERY): plain term leaves, at most 16, at least one Must (the list that is walked)
+    const uint32_t n_sub = opt->n_subqueries;
+    if (n_sub && (!opt->subquery_offsets || !opt->subquery_clauses)) return fail(NIDX_ERR_INVALID_ARGUMENT, "sub-queries without clauses");
+    std::vector<SubqueryDev> subs(n_sub);
+    for (uint32_t j = 0; j < n_sub; j++) {
+        if (opt->subquery_offsets[j + 1] < opt->subquery_offsets[j]) return fail(NIDX_ERR_INVALID_ARGUMENT, "subquery_offsets not monotone");
+        const uint64_t m = opt->subquery_offsets[j + 1] - opt->subquery_offsets[j];
+        if (m == 0 || m > BM25_MAX_SUBQUERY_LEAVES)
+            return fail(NIDX_ERR_UNSUPPORTED, "a nested query has 1..%d leaves (got %llu)", BM25_MAX_SUBQUERY_LEAVES, (unsigned long long)m);
+        SubqueryDev &sq = subs[j];
+        sq.n = (uint32_t)m;
+        sq.driver = 0;
+        bool any_must = false;
+        for (uint32_t t = 0; t < sq.n; t++) {
+            const nidx_gpu_bm25_clause_t &cl = opt->subquery_clauses[opt->subquery_offsets[j] + t];
+            if (cl.term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY) || cl.term >= idx->n_terms)
+                return fail(NIDX_ERR_UNSUPPORTED, "the leaves of a nested query are plain terms of the dictionary");
+            if (cl.occur < 0 || cl.occur > NIDX_OCCUR_SHOULD_GROUP + 7 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause in a nested query");
+            any_must |= cl.occur == NIDX_OCCUR_MUST;
+            uint64_t df = 0;
+            for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[cl.term + 1] - sg.term_offsets_host[cl.term];
+            sq.term[t] = cl.term;
+            sq.occur[t] = (uint8_t)cl.occur;
+            sq.mode[t] = (uint8_t)cl.mode;
+            sq.weight[t] = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
+        }
+        if (!any_must) return fail(NIDX_ERR_UNSUPPORTED, "a nested query needs at least one Must leaf (a pure disjunction is a required Should group of the outer query)");
+    }
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
@@ -526,6 +554,13 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     for (uint64_t c = 0; c < n_clauses; c++) {
         const nidx_gpu_bm25_clause_t &cl = clauses[c];
         if (cl.occur < 0 || cl.occur > NIDX_OCCUR_SHOULD_GROUP + 7 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause");
+        if (!(cl.term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE)) && (cl.term & NIDX_BM25_SUBQUERY)) {
+            const uint32_t j = cl.term & ~NIDX_BM25_SUBQUERY;
+            if (j >= n_sub) return fail(NIDX_ERR_INVALID_ARGUMENT, "nested query %u out of range", j);
+            // materialised per segment as aux list n_sets + n_phrases + j; the clause contributes boost x the nested score (mode 3)
+            dev_clauses[c] = Bm25ClauseDev{BM25_AUX_TERM | (n_sets + n_phrases + j), cl.occur, 3, cl.boost};
+            continue;
+        }
         if (!(cl.term & NIDX_BM25_TERM_SET) && (cl.term & NIDX_BM25_PHRASE)) {
             const uint32_t j = cl.term & ~NIDX_BM25_PHRASE;
             if (j >= n_phrases) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase %u out of range", j);
@@ -608,7 +643,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
         // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
-        const uint32_t n_aux = n_sets + n_phrases;
+        const uint32_t n_aux = n_sets + n_phrases + n_sub;
         std::vector<unsigned long long> aux_pairs(2 * (size_t)n_aux + 2, 0);  // [begin, end) per aux list into s_aux_ids
         std::vector<uint32_t> set_counts(n_aux, 0);
         // layout of the aux arrays: the term sets first (upper bounds), then one region per phrase (driver term's df)
@@ -632,6 +667,16 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             }
             out_off[n_sets + j + 1] = out_off[n_sets + j] + best;
         }
+        for (uint32_t j = 0; j < n_sub; j++) {   // the shortest Must leaf of this segment is the one that is walked
+            SubqueryDev &sq = subs[j];
+            uint64_t best = ~0ull;
+            for (uint32_t t = 0; t < sq.n; t++) {
+                if (sq.occur[t] != NIDX_OCCUR_MUST) continue;
+                const uint64_t df = seg.term_offsets_host[sq.term[t] + 1] - seg.term_offsets_host[sq.term[t]];
+                if (df < best) { best = df; sq.driver = t; }
+            }
+            out_off[n_sets + n_phrases + j + 1] = out_off[n_sets + n_phrases + j] + best;
+        }
         if (n_aux) {
             NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
             NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
@@ -648,8 +693,19 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                                            out_off[n_sets + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
                                            idx->s_set_counts.as<uint32_t>() + n_sets + j, idx->stream));
         }
-        if (n_phrases) {
-            NIDX_HIP(hipMemcpyAsync(set_counts.data() + n_sets, idx->s_set_counts.as<uint32_t>() + n_sets, (size_t)n_phrases * 4, hipMemcpyDeviceToHost, idx->stream));
+        for (uint32_t j = 0; j < n_sub; j++) {
+            const uint64_t n_driver = out_off[n_sets + n_phrases + j + 1] - out_off[n_sets + n_phrases + j];
+            if (n_driver == 0) continue;
+            NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 8));   // [n_driver] match flags | [n_driver] score bits
+            uint32_t *tmp_ok = idx->s_phrase_tf.as<uint32_t>(), *tmp_score = tmp_ok + n_driver;
+            NIDX_HIP(launch_subquery_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), idx->tf_cache.as<float>(),
+                                           subs[j], (uint32_t)n_driver, tmp_ok, tmp_score, idx->stream));
+            NIDX_HIP(launch_subquery_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), subs[j], tmp_ok, tmp_score,
+                                             out_off[n_sets + n_phrases + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
+                                             idx->s_set_counts.as<uint32_t>() + n_sets + n_phrases + j, idx->stream));
+        }
+        if (n_phrases + n_sub) {
+            NIDX_HIP(hipMemcpyAsync(set_counts.data() + n_sets, idx->s_set_counts.as<uint32_t>() + n_sets, (size_t)(n_phrases + n_sub) * 4, hipMemcpyDeviceToHost, idx->stream));
             NIDX_HIP(hipStreamSynchronize(idx->stream));
         }
         if (n_sets) {
@@ -685,6 +741,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         auto postings_of = [&](const nidx_gpu_bm25_clause_t &cl) -> uint64_t {
             if (cl.term & NIDX_BM25_TERM_SET) return set_counts[cl.term & ~NIDX_BM25_TERM_SET];
             if (cl.term & NIDX_BM25_PHRASE) return set_counts[n_sets + (cl.term & ~NIDX_BM25_PHRASE)];
+            if (cl.term & NIDX_BM25_SUBQUERY) return set_counts[n_sets + n_phrases + (cl.term & ~NIDX_BM25_SUBQUERY)];
             return seg.term_offsets_host[cl.term + 1] - seg.term_offsets_host[cl.term];
         };
         // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
@@ -712,7 +769,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
             bool plain = true;
             double sum = 0.0, sum_sq = 0.0;
             for (uint64_t c = c0; c < c1; c++) {
-                if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE)) plain = false;
+                if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
                 const double l = (double)postings_of(clauses[c]);
                 sum += l;
                 sum_sq += l * l;

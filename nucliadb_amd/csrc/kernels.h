@@ -287,7 +287,7 @@ hipError_t launch_bitset_and_count(const uint64_t *a, const uint64_t *alive, uin
 struct Bm25ClauseDev {
     uint32_t term;
     int occur;     // 0 should, 1 must, 2 must-not, 3 + g: should of required group g (g < 8)
-    int mode;      // 0 stored tf, 1 tf == 1, 2 constant score
+    int mode;      // 0 stored tf, 1 tf == 1, 2 constant score, 3 pre-scored (the posting word is an f32: a materialised sub-query)
     float weight;  // idf * (1 + K1) * boost, or the constant score
 };
 struct Bm25AfterDev {  // same layout as nidx_gpu_bm25_search_after_t
@@ -383,6 +383,25 @@ hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uin
 hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
                                  const uint8_t *fieldnorm_ids, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs,
                                  uint32_t *out_count, hipStream_t s);
+// A nested BooleanQuery of plain term leaves with at least one Must leaf (tantivy: a BooleanQuery inside a BooleanQuery — an AND
+// inside an OR, a negated conjunction, a conjunction inside an `Or` formula): its matches are materialised as one more aux list whose
+// posting word is the sub-score's f32 bits (clause mode 3 = pre-scored).  The driver Must leaf's postings are walked, one lane each,
+// the other leaves are probed by binary search; a document matches when every Must leaf holds it, no MustNot leaf does and every
+// required Should group has one that does; its score is the f32 sum of the scoring leaves that hold it, in leaf order.
+#define BM25_MAX_SUBQUERY_LEAVES 16
+struct SubqueryDev {
+    uint32_t n;        // leaves
+    uint32_t driver;   // index of the Must leaf that is walked (the shortest in this segment)
+    uint32_t term[BM25_MAX_SUBQUERY_LEAVES];
+    uint8_t occur[BM25_MAX_SUBQUERY_LEAVES];   // 0 should, 1 must, 2 must-not, 3 + g required Should group g
+    uint8_t mode[BM25_MAX_SUBQUERY_LEAVES];    // 0 stored tf, 1 tf == 1, 2 constant score
+    float weight[BM25_MAX_SUBQUERY_LEAVES];
+};
+hipError_t launch_subquery_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *posting_words, const float *tf_cache,
+                                 const SubqueryDev &sq, uint32_t n_driver, uint32_t *tmp_ok, uint32_t *tmp_score, hipStream_t s);
+hipError_t launch_subquery_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, const SubqueryDev &sq, const uint32_t *tmp_ok,
+                                   const uint32_t *tmp_score, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count,
+                                   hipStream_t s);
 // resident posting word: tfs[i] = tf | fieldnorm_ids[doc_ids[i]] << 24 (in place); *flag: bit 0 = a tf >= 2^24, bit 1 = a doc id >= n_docs
 hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
                                       uint32_t *flag, hipStream_t s);

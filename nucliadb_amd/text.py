@@ -378,6 +378,7 @@ class QLeaf:
 class QNode:
     op: str                # "and" | "or" | "not"
     children: list
+    boost: float = 1.0     # `( ... )^boost`: BoostQuery over the group
 
 
 _SPECIAL = set(' \t\n\r()"\':^{}[]')
@@ -423,7 +424,10 @@ def parse_text_query(body: str):
             pos += 1
             b = parse_boost()
             if b != 1.0:
-                raise NotImplementedError("boost on a parenthesised group")
+                if isinstance(node, QLeaf):
+                    node = QLeaf(node.text, node.boost * b, node.all)
+                else:
+                    node = QNode(node.op, node.children, node.boost * b)
             return node
         if c == '"':
             j = body.find('"', pos + 1)
@@ -509,32 +513,60 @@ def parse_text_query(body: str):
     return node
 
 
-def flatten_conjunction(node):
-    """The boolean tree as (Must leaves, MustNot leaves, [required OR groups of leaves]); shapes outside that family
-    (an AND inside an OR, a negation inside an OR) are refused."""
-    musts, nots, groups = [], [], []
+def _scaled(leaf: "QLeaf", factor: float) -> "QLeaf":
+    return leaf if factor == 1.0 else QLeaf(leaf.text, leaf.boost * factor, leaf.all)
 
-    def walk(nd):
+
+def flatten_conjunction(node, nested: bool = True):
+    """The boolean tree as (Must leaves, MustNot leaves, [required OR groups], MustNot sub-trees, Must sub-trees).  A group
+    member is a leaf or — an AND inside an OR, `a OR (b AND c)` — a conjunction node that becomes a nested BooleanQuery
+    (NIDX_BM25_SUBQUERY); a negated conjunction `NOT (a AND b)` and a boosted one `(a b)^2` are sub-trees too.  A boost on an OR
+    group is carried by its members (tantivy multiplies the group's sum: equal for powers of two, else it may differ in the last
+    bit — the oracle follows the mirror).  nested = False: inside a nested query only leaves are left."""
+    musts, nots, groups, not_subs, must_subs = [], [], [], [], []
+
+    def conj_like(nd) -> bool:
+        return isinstance(nd, QNode) and nd.op in ("and", "not")
+
+    def walk(nd, factor=1.0):
         if isinstance(nd, QLeaf):
-            musts.append(nd)
+            musts.append(_scaled(nd, factor))
         elif nd.op == "and":
-            for ch in nd.children:
-                walk(ch)
+            if nd.boost * factor != 1.0 and nested:
+                must_subs.append((nd, nd.boost * factor))   # (a b)^2: BoostQuery over the conjunction's own sum
+            else:
+                if nd.boost * factor != 1.0:
+                    raise NotImplementedError("a boosted conjunction nested two levels deep")
+                for ch in nd.children:
+                    walk(ch)
         elif nd.op == "not":
             inner = nd.children[0]
             if isinstance(inner, QLeaf):
                 nots.append(inner)
             elif inner.op == "or" and all(isinstance(c, QLeaf) for c in inner.children):
                 nots.extend(inner.children)   # NOT (a OR b) = NOT a AND NOT b
+            elif inner.op == "and" and nested:
+                not_subs.append(inner)        # NOT (a AND b): a MustNot nested BooleanQuery
             else:
                 raise NotImplementedError("negation of a nested boolean expression")
         elif nd.op == "or":
-            if not all(isinstance(c, QLeaf) for c in nd.children):
-                raise NotImplementedError("nested boolean expression inside OR")
-            groups.append(list(nd.children))
+            members = []
+            for c in nd.children:
+                if isinstance(c, QLeaf):
+                    members.append(_scaled(c, nd.boost * factor))
+                elif conj_like(c) and nested:
+                    members.append((c, nd.boost * factor * (c.boost if c.op == "and" else 1.0)))   # a OR (b AND c), a OR (NOT b)
+                elif isinstance(c, QNode) and c.op == "or":
+                    for cc in c.children:   # an OR inside an OR is the same group
+                        if not isinstance(cc, QLeaf):
+                            raise NotImplementedError("nested boolean expression inside OR")
+                        members.append(_scaled(cc, nd.boost * factor * c.boost))
+                else:
+                    raise NotImplementedError("nested boolean expression inside OR")
+            groups.append(members)
 
     walk(node)
-    return musts, nots, groups
+    return musts, nots, groups, not_subs, must_subs
 
 
 class TextSearcher:
@@ -574,6 +606,43 @@ class TextSearcher:
             return Clause(0, occur, _lib.TF_FREQ, leaf.boost, term_set=[self._index.term(w) for w in words], phrase=True)
         return Clause(self._index.term(words[0]), occur, _lib.TF_FREQ, leaf.boost)
 
+    def _subquery(self, node, occur: int, boost: float) -> Optional[Clause]:
+        """A conjunction (or a negation) below the top level as a nested BooleanQuery: Must / MustNot leaves and required OR
+        groups of single words; the kernels walk its shortest Must list, so it needs one."""
+        inner = QNode(node.op, node.children) if isinstance(node, QNode) else node
+        musts, nots, groups, not_subs, must_subs = flatten_conjunction(inner, nested=False)
+        leaves: List[Clause] = []
+
+        def word(leaf, occ):
+            if leaf.all:
+                return Clause(self._index.term(ALL_DOCS), occ, _lib.CONST_SCORE, leaf.boost)
+            words = tokenize(leaf.text)
+            if not words:
+                return None
+            if len(words) > 1:
+                raise NotImplementedError("a phrase inside a nested boolean expression")
+            return Clause(self._index.term(words[0]), occ, _lib.TF_FREQ, leaf.boost)
+
+        for leaf in musts:
+            c = word(leaf, _lib.OCCUR_MUST)
+            if c is not None:
+                leaves.append(c)
+        for g, members in enumerate(groups):
+            if g >= 8:
+                raise NotImplementedError("more than 8 OR groups in one nested query")
+            leaves += [c for c in (word(m, _lib.OCCUR_SHOULD_GROUP + g) for m in members) if c is not None]
+        for leaf in nots:
+            c = word(leaf, _lib.OCCUR_MUST_NOT)
+            if c is not None:
+                leaves.append(c)
+        if not any(l.occur == _lib.OCCUR_MUST for l in leaves):
+            if isinstance(node, QNode) and node.op == "not":   # `a OR (NOT b)`: BooleanQuery[MustNot b] matches nothing in tantivy
+                return None
+            raise NotImplementedError("a nested boolean expression without a required word")
+        if len(leaves) > 16:
+            raise NotImplementedError("more than 16 leaves in a nested boolean expression")
+        return Clause(0, occur, _lib.TF_FREQ, boost, subquery=leaves)
+
     def _clauses(self, request: DocumentSearchRequest) -> List[Clause]:
         """create_query (search_query.rs:92-126): Must(main query) + Must(filters).  The main query is the body through
         tantivy's QueryParser with set_conjunction_by_default (reader.rs:372-377): juxtaposed literals are Must, `+` / `-`
@@ -591,8 +660,13 @@ class TextSearcher:
             if ast is None:
                 clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
             else:
-                musts, nots, groups = flatten_conjunction(ast)
+                musts, nots, groups, not_subs, must_subs = flatten_conjunction(ast)
                 positive = False
+                for nd, b in must_subs:   # a boosted conjunction: BoostQuery(BooleanQuery[Must ...])
+                    c = self._subquery(QNode("and", nd.children), _lib.OCCUR_MUST, b)
+                    if c is not None:
+                        clauses.append(c)
+                        positive = True
                 for leaf in musts:
                     if leaf.all:
                         clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, leaf.boost))
@@ -605,13 +679,18 @@ class TextSearcher:
                 for g, leaves in enumerate(groups):
                     if g >= 8:
                         raise NotImplementedError("more than 8 OR groups in one query")
-                    members = [self._leaf(l, _lib.OCCUR_SHOULD_GROUP + g) for l in leaves]
+                    members = [self._subquery(l[0], _lib.OCCUR_SHOULD_GROUP + g, l[1]) if isinstance(l, tuple) else self._leaf(l, _lib.OCCUR_SHOULD_GROUP + g)
+                               for l in leaves]
                     members = [m for m in members if m is not None]
                     if members:
                         clauses += members
                         positive = True
                 for leaf in nots:
                     c = self._leaf(leaf, _lib.OCCUR_MUST_NOT)
+                    if c is not None:
+                        clauses.append(c)
+                for nd in not_subs:   # NOT (a AND b)
+                    c = self._subquery(nd, _lib.OCCUR_MUST_NOT, 1.0)
                     if c is not None:
                         clauses.append(c)
                 if not positive:  # only exclusions (or nothing survived the tokenizer): a BooleanQuery without a positive clause matches nothing
@@ -875,10 +954,13 @@ class ParagraphSearcher:
             if isinstance(expr, FormulaLiteral):
                 out.append(self._label(expr.label, _lib.OCCUR_MUST, boost))
             elif isinstance(expr, FormulaNot):
-                if not isinstance(expr.operand, FormulaLiteral):
-                    raise NotImplementedError("negation of a nested formula")
                 out.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
-                out.append(self._label(expr.operand.label, _lib.OCCUR_MUST_NOT, boost))
+                if isinstance(expr.operand, FormulaLiteral):
+                    out.append(self._label(expr.operand.label, _lib.OCCUR_MUST_NOT, boost))
+                elif isinstance(expr.operand, FormulaOp) and expr.operand.operator == "or" and all(isinstance(e, FormulaLiteral) for e in expr.operand.operands):
+                    out.extend(self._label(e.label, _lib.OCCUR_MUST_NOT, boost) for e in expr.operand.operands)   # Not(Or(..)) = none of them
+                else:   # Not(And(..)): BooleanQuery[Must AllQuery, MustNot BooleanQuery[Must ...]]
+                    out.append(nested(expr.operand, _lib.OCCUR_MUST_NOT))
             elif isinstance(expr, FormulaOp) and expr.operator == "and":
                 for e in expr.operands:
                     conj(e)
@@ -887,14 +969,45 @@ class ParagraphSearcher:
             else:
                 raise TypeError(f"not a formula: {expr!r}")
 
+        def nested(expr, occur: int) -> Clause:
+            """A conjunction or a negation below an `Or` (or a negated conjunction) as a nested BooleanQuery of label leaves
+            (translate_expression, query_io.rs:28-41: Not(x) = BooleanQuery[Must AllQuery, MustNot x])."""
+            leaves: List[Clause] = []
+            groups_in = [0]
+
+            def inner(e):
+                if isinstance(e, FormulaLiteral):
+                    leaves.append(self._label(e.label, _lib.OCCUR_MUST, boost))
+                elif isinstance(e, FormulaNot) and isinstance(e.operand, FormulaLiteral):
+                    leaves.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
+                    leaves.append(self._label(e.operand.label, _lib.OCCUR_MUST_NOT, boost))
+                elif isinstance(e, FormulaOp) and e.operator == "and":
+                    for x in e.operands:
+                        inner(x)
+                elif isinstance(e, FormulaOp) and e.operator == "or" and all(isinstance(x, FormulaLiteral) for x in e.operands):
+                    g = groups_in[0]
+                    groups_in[0] += 1
+                    if g >= 8:
+                        raise NotImplementedError("more than 8 Or groups inside a nested formula")
+                    leaves.extend(self._label(x.label, G + g, boost) for x in e.operands)
+                else:
+                    raise NotImplementedError("a formula nested three levels deep")
+
+            inner(expr)
+            if not any(l.occur == _lib.OCCUR_MUST for l in leaves):   # And(Or(a, b), Or(c, d)) below an Or: nothing to walk
+                raise NotImplementedError("a nested formula without a required literal")
+            if len(leaves) > 16:
+                raise NotImplementedError("more than 16 literals in a nested formula")
+            return Clause(0, occur, _lib.TF_BASIC, 1.0, subquery=leaves)
+
         def disj(expr, occur: int):   # expr as members of one required group
             if isinstance(expr, FormulaLiteral):
                 out.append(self._label(expr.label, occur, boost))
             elif isinstance(expr, FormulaOp) and expr.operator == "or":
                 for e in expr.operands:
                     disj(e, occur)
-            else:
-                raise NotImplementedError("a conjunction or negation inside an Or formula")
+            else:   # And(..) / Not(..) below an Or
+                out.append(nested(expr, occur))
 
         def prefilter_sets(occur: int):
             fields = sorted({"\x00fid:" + rid + "/" + fid.lstrip("/") for rid, fid in prefilter.fields if fid is not None})

@@ -753,6 +753,78 @@ class Bm25Index:
         return od[:n].copy(), os_[:n].copy(), total.value
 
 
+def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
+    """BooleanQuerys nested inside the BooleanQuery (tantivy's QueryParser for `a OR (b AND c)`, `NOT (a AND b)`, `(a AND b)^2`; a
+    conjunction inside an `Or` filtering formula): clauses = (term, occur, mode, boost) leaves or ("sub", occur, boost, [leaves]).
+    Document at a time in f32 like orc_bm25_search: a nested query matches by its own boolean structure, its score is the f32
+    sum of its scoring leaves that hold the document (leaf order, from +0), the outer clause adds boost * that score at its
+    position; TopDocs order (score desc by total order, doc asc).  -> (docaddr u64[], score f32[], total)"""
+    f32 = np.float32
+    n_docs = int(index.fieldnorm_ids.size)
+    avg = f32(index.total_num_tokens) / f32(n_docs) if n_docs else f32(0)
+    cache = bm25_tf_cache(float(avg))
+    K1 = f32(1.2)
+
+    def leaf_scores(term, mode, boost):
+        b, e = int(index.term_offsets[term]), int(index.term_offsets[term + 1])
+        docs = index.doc_ids[b:e]
+        if mode == 2:   # ConstScorer(boost)
+            return docs, np.full(docs.size, f32(boost), f32)
+        w = f32(bm25_idf(e - b, n_docs)) * (f32(1.0) + K1) * f32(boost)
+        tf = index.tfs[b:e].astype(f32) if mode == 0 else np.ones(docs.size, f32)
+        fn = cache[index.fieldnorm_ids[docs]]
+        return docs, (w * (tf / (tf + fn))).astype(f32)
+
+    def boolean(cl):
+        """-> dict doc -> f32 score of one BooleanQuery level (leaves only, or leaves + evaluated sub-queries)"""
+        acc, mask, musts, nots, groups, plain = {}, {}, [], [], {}, []
+        for i, c in enumerate(cl):
+            if c[0] == "sub":
+                _, occur, boost, leaves = c
+                sub = boolean(leaves)
+                docs = np.fromiter(sorted(sub), np.uint32, len(sub))
+                sc = np.array([f32(boost) * sub[int(d)] for d in docs], f32)
+            else:
+                term, occur, mode, boost = c
+                docs, sc = leaf_scores(term, mode, boost)
+            if occur == 1:
+                musts.append(i)
+            elif occur == 2:
+                nots.append(i)
+            elif occur >= 3:
+                groups.setdefault(occur, []).append(i)
+            else:
+                plain.append(i)
+            for d, s_ in zip(docs.tolist(), sc):
+                mask[d] = mask.get(d, 0) | (1 << i)
+                if occur != 2:
+                    acc[d] = f32(acc.get(d, f32(0.0)) + s_)
+                else:
+                    acc.setdefault(d, f32(0.0))
+        out = {}
+        any_required = bool(musts) or bool(groups)
+        for d, m in mask.items():
+            if any(not (m >> i) & 1 for i in musts) or any((m >> i) & 1 for i in nots):
+                continue
+            if any(not any((m >> i) & 1 for i in g) for g in groups.values()):
+                continue
+            if not any_required and not any((m >> i) & 1 for i in plain):
+                continue
+            out[d] = acc[d]
+        return out
+
+    res = boolean(clauses)
+    if index.alive is not None:
+        res = {d: s_ for d, s_ in res.items() if (int(index.alive[d >> 6]) >> (d & 63)) & 1}
+    def key(item):
+        d, s_ = item
+        b = int(np.float32(s_).view(np.int32))
+        b ^= (b >> 31) & 0x7FFFFFFF
+        return (-b, d)
+    top = sorted(res.items(), key=key)[:k]
+    return (np.array([(segment_ord << 32) | d for d, _ in top], np.uint64), np.array([s_ for _, s_ in top], np.float32), len(res))
+
+
 def bm25_search_daat_batch(index: "Bm25Index", queries, k, threads=1):
     """orc_bm25_search_daat for every query (a list of (term, occur, mode, boost) clause lists) on `threads` POSIX threads.
     -> (docaddr [nq][k] u64, score [nq][k] f32, count [nq] u32, total [nq] u64)"""

@@ -232,3 +232,54 @@ def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeyp
     after = [SearchAfter(float(score[i, 3]), t, int(docaddr[i, 3])) if count[i] > 3 else None for i, t in zip(range(len(queries)), [0, 1, 2] * 8)]
     compare(orc, seg2, s, queries, 20, after=after)
     s.close()
+
+
+def _nested_to_oracle(q):
+    return [("sub", c.occur, c.boost, [(l.term, l.occur, l.mode, l.boost) for l in c.subquery]) if c.subquery is not None
+            else (c.term, c.occur, c.mode, c.boost) for c in q]
+
+
+def test_nested_boolean_queries_match_the_oracle(orc, corpus):
+    """BooleanQuerys inside the BooleanQuery (NIDX_BM25_SUBQUERY): an AND inside an OR, a negated conjunction, a boosted
+    conjunction, a conjunction with its own required Should group and optional Should leaves — what tantivy's QueryParser builds
+    for `a OR (b AND c)`, `x AND NOT (a AND b)`, `(a AND b)^2.5` (nidx_text/src/reader.rs:357-376) and what a conjunction or a
+    negation inside an `Or` filtering formula is (nidx_paragraph/src/search_query.rs:88-143).  The nested query is materialised on
+    the device as a pre-scored posting list; the oracle evaluates the tree document at a time (orc.bm25_nested_search, itself
+    pinned to the C oracle on flat queries in tests/test_oracle_golden.py)."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(31)
+    s = Bm25Searcher.open([seg])
+    G = _lib.OCCUR_SHOULD_GROUP
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive)
+
+    def leaf(lo, hi, occur, mode=None, boost=None):
+        return Clause(int(rng.integers(lo, hi)), occur, int(rng.choice([FREQ, BASIC, CONST])) if mode is None else mode,
+                      float(rng.choice([1.0, 0.5, 2.0])) if boost is None else boost)
+
+    queries = [
+        [Clause(300), Clause(0, S, subquery=[Clause(1, M), Clause(2, M)])],                                # a OR (b AND c)
+        [Clause(5, M), Clause(0, N, subquery=[Clause(1, M), Clause(2, M)])],                                # x AND NOT (a AND b)
+        [Clause(0, S, boost=2.5, subquery=[Clause(3, M), Clause(4, M, BASIC)]), Clause(900)],               # (a AND b)^2.5 OR c
+        [Clause(0, M, subquery=[Clause(0, M, CONST, 1.0), Clause(7, N)]), Clause(20, S)],                   # Not(l) inside a formula: AllQuery-like Must + MustNot
+        [Clause(0, G, subquery=[Clause(10, M), Clause(11, G), Clause(12, G), Clause(400, S)]), Clause(13, G), Clause(2, M, BASIC)],
+        [Clause(0, S, subquery=[Clause(4000, M), Clause(4001, M)])],                                         # a conjunction that matches (almost) nothing
+    ]
+    for _ in range(40):
+        q = []
+        for _ in range(int(rng.integers(1, 4))):
+            q.append(leaf(0, 500, int(rng.choice([S, S, M, N]))))
+        for _ in range(int(rng.integers(1, 3))):
+            sub = [leaf(0, 60, M)] + [leaf(0, 200, int(rng.choice([M, N, S, G, G + 1]))) for _ in range(int(rng.integers(1, 5)))]
+            order = rng.permutation(len(sub))
+            q.append(Clause(0, int(rng.choice([S, S, M, N, G])), boost=float(rng.choice([1.0, 0.5, 3.0])), subquery=[sub[i] for i in order]))
+        order = rng.permutation(len(q))
+        queries.append([q[i] for i in order])
+    for k in (20, 3, 120):
+        docaddr, score, count, total, _ = s.search_batch(queries, k)
+        for i, q in enumerate(queries):
+            wd, ws, wt = orc.bm25_nested_search(oidx, _nested_to_oracle(q), k)
+            assert total[i] == wt, (i, total[i], wt)
+            assert count[i] == len(wd), (i, count[i], len(wd))
+            assert np.array_equal(docaddr[i, : count[i]], wd), (i, docaddr[i, : count[i]], wd)
+            assert np.array_equal(bits(score[i, : count[i]]), bits(ws)), (i, score[i, : count[i]], ws)
+    s.close()

@@ -548,3 +548,36 @@ def test_prefilter_reference_cases(orc):
             ops.append((AND, 0, 0)); stack.append(a & b)
         got, live = ridx.prefilter(ops, lists, ranges, cr, mo, phrases)
         assert live == 300 and got.tolist() == sorted(stack[0]), ops
+
+
+def test_nested_query_evaluator_equals_the_c_oracle_on_flat_queries():
+    """oracle.bm25_nested_search (numpy, used to check nested BooleanQuerys on the device) evaluates flat queries exactly like
+    orc_bm25_search: same doc addresses, same f32 score bits, same Count — Must / MustNot / Should / required groups, the three
+    score modes, boosts."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    orc.build()
+    rng = np.random.default_rng(5)
+    n_docs, vocab = 4000, 300
+    lens = np.clip(np.round(rng.lognormal(np.log(20), 0.6, n_docs)), 2, 400).astype(np.int64)
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    flat = rng.choice(vocab, size=int(lens.sum()), p=p)
+    doc_of = np.repeat(np.arange(n_docs), lens)
+    key = flat.astype(np.int64) * (n_docs + 1) + doc_of
+    uniq, counts = np.unique(key, return_counts=True)
+    t, d = uniq // (n_docs + 1), uniq % (n_docs + 1)
+    term_offsets = np.zeros(vocab + 1, np.uint64)
+    np.add.at(term_offsets, t + 1, 1)
+    term_offsets = np.cumsum(term_offsets).astype(np.uint64)
+    table = orc.fieldnorm_table().astype(np.int64)
+    fn_ids = (np.searchsorted(table, lens, side="right") - 1).astype(np.uint8)
+    idx = orc.Bm25Index(term_offsets, d.astype(np.uint32), counts.astype(np.uint32), fn_ids, int(lens.sum()))
+    for _ in range(60):
+        q = [(int(rng.integers(0, 120)), int(rng.choice([0, 0, 1, 2, 3, 4])), int(rng.choice([0, 1, 2])), float(rng.choice([1.0, 0.5, 2.0])))
+             for _ in range(int(rng.integers(1, 6)))]
+        wd, ws, wt = idx.search(q, 25)
+        gd, gs, gt = orc.bm25_nested_search(idx, q, 25)
+        assert gt == wt and np.array_equal(gd, wd) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), q

@@ -55,7 +55,8 @@ def test_tantivy_grammar_subset_parses_like_the_query_parser():
     from nucliadb_amd.text import QuerySyntaxError, flatten_conjunction, parse_text_query
 
     def shape(q):
-        m, n, g = flatten_conjunction(parse_text_query(q))
+        m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query(q))
+        assert not not_subs and not must_subs
         return [l.text for l in m], [l.text for l in n], [[l.text for l in grp] for grp in g]
 
     assert shape("enough to test") == (["enough", "to", "test"], [], [])
@@ -65,12 +66,22 @@ def test_tantivy_grammar_subset_parses_like_the_query_parser():
     assert shape("a AND b OR c AND d".replace(" OR ", " AND ")) == (["a", "b", "c", "d"], [], [])
     assert shape("x (a OR b) (c OR d)") == (["x"], [], [["a", "b"], ["c", "d"]])
     assert shape("NOT (a OR b) z") == (["z"], ["a", "b"], [])
-    m, _, _ = flatten_conjunction(parse_text_query("text:foo^2.5 *"))
+    m = flatten_conjunction(parse_text_query("text:foo^2.5 *"))[0]
     assert (m[0].text, m[0].boost, m[1].all) == ("foo", 2.5, True)
+    # nested shapes (round 3): an AND inside an OR is a group member that is a conjunction node, a negated conjunction and a
+    # boosted conjunction are sub-trees; a boost on an OR group is carried by its members
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("a OR b c"))
+    assert (m, n, not_subs, must_subs) == ([], [], [], []) and g[0][0].text == "a" and g[0][1][0].op == "and" and [l.text for l in g[0][1][0].children] == ["b", "c"]
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("z NOT (a AND b)"))
+    assert [l.text for l in m] == ["z"] and [l.text for l in not_subs[0].children] == ["a", "b"]
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("(a b)^2.5 c"))
+    assert [l.text for l in m] == ["c"] and must_subs[0][1] == 2.5
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("(a OR b)^2 c"))
+    assert [(l.text, l.boost) for l in g[0]] == [("a", 2.0), ("b", 2.0)]
     for bad in ['"enough test', "enough test\"", "a AND", "a OR", "(a b", "a b)", "enough - test", "title:x", "a^"]:
         with pytest.raises(QuerySyntaxError):
             parse_text_query(bad)
-    for refused in ['"a b"~2', "[a TO b]", "a OR b c", "NOT (a AND b)"]:
+    for refused in ['"a b"~2', "[a TO b]"]:
         with pytest.raises(NotImplementedError):
             flatten_conjunction(parse_text_query(refused))
 

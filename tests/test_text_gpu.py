@@ -406,8 +406,18 @@ def test_paragraph_filtering_formula_reference_cases():
     r = s.search(ParagraphSearchRequest(body="paragraph summary", result_per_page=20,
                                        filtering_formula=FormulaOp("or", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")])))
     assert r.total == 3
-    with pytest.raises(NotImplementedError):
-        s.search(req(FormulaOp("or", [FormulaOp("and", [FormulaLiteral("/a"), FormulaLiteral("/b")]), FormulaLiteral("/c")])))
+    # a conjunction / a negation below an Or (round 3: nested BooleanQuerys, NIDX_BM25_SUBQUERY): /tantivy AND /label2 is one
+    # paragraph, /e/myentity another; Not(/label2) below an Or = everything but the two /label2 paragraphs
+    f = FormulaOp("or", [FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")]), FormulaLiteral("/e/myentity")])
+    assert s.search(req(f)).total == 2
+    f = FormulaOp("or", [FormulaNot(FormulaLiteral("/label2")), FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")])])
+    assert s.search(req(f)).total == 4
+    # a negated conjunction under And: everything but (/tantivy AND /label2)
+    f = FormulaOp("and", [FormulaNot(FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")]))])
+    assert s.search(req(f)).total == 4
+    with pytest.raises(NotImplementedError):   # no required literal to walk inside the nested query
+        s.search(req(FormulaOp("or", [FormulaOp("and", [FormulaOp("or", [FormulaLiteral("/a"), FormulaLiteral("/b")]),
+                                                          FormulaOp("or", [FormulaLiteral("/c"), FormulaLiteral("/d")])]), FormulaLiteral("/e")])))
     s.close()
 
 
@@ -479,6 +489,11 @@ def test_text_query_grammar_reference_cases():
     one, two = q("enough").results[0].score.bm25, q("enough^2").results[0].score.bm25
     assert np.float32(two) == np.float32(one) * np.float32(2.0)
     assert q("title:enough").total == 0     # unknown field: a syntax error, searched as the phrase "title:enough" -> tokens title, enough
+    # nested boolean expressions (round 3): an AND inside an OR, a negated conjunction, a boosted conjunction
+    assert q("prince OR (enough AND test)").total == 2 and q("prince OR (enough AND mischievous)").total == 1
+    assert q("little NOT (little AND enough)").total == 1 and q("enough NOT (enough AND test)").total == 0
+    one, boosted = q("enough test").results[0].score.bm25, q("(enough test)^2").results[0].score.bm25
+    assert np.float32(boosted) == np.float32(one) * np.float32(2.0)
     with pytest.raises(NotImplementedError):
-        q("a OR (b AND c)")
+        q("a OR (b (c OR (d e)))")   # three levels
     s.close()
