@@ -633,7 +633,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         if (n_set_terms) NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, opt->term_set_terms, n_set_terms * 4, hipMemcpyHostToDevice, idx->stream));
     }
     idx->last_kernel_ms = 0.f;
-    const bool host_dbg = getenv("NIDX_GPU_BM25_DEBUG") != nullptr;
+    const bool host_dbg = getenv("NIDX_GPU_BM25_DEBUG") != nullptr || getenv("NIDX_GPU_BM25_HOST_TRACE") != nullptr;
     auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_us();
     double t_work = 0, t_sync = 0, t_collect = 0;
