@@ -589,6 +589,20 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                                 const nidx_gpu_bm25_search_options_t *options, uint64_t *out_docaddr,
                                 float *out_score, uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings);
 
+/* The same search, pipelined (the loop the reference runs around TextSearcher / ParagraphSearcher::search, nidx_text/src/lib.rs:178-237,
+ * nidx_paragraph/src/lib.rs:117-169, one call per request from src/searcher/shard_search.rs:176-248, for a caller that has batches):
+ * submit prepares the batch (clause weights, work list, staging), queues the launches and ONE device-to-host transfer of the result
+ * block on a stream of its own and returns; wait blocks until that block has landed and fills the caller's arrays exactly as
+ * nidx_gpu_bm25_search_ex would have.  With two tickets outstanding the host side of batch i + 1 overlaps the kernels of batch i.  At most 4
+ * tickets may be outstanding (NIDX_ERR_BUSY otherwise); a ticket is waited for once, from any thread.  A request the pipeline does not
+ * cover — several segments, term sets, phrases, nested queries, facets, order by a fast field — runs to completion inside submit
+ * (options.out_facet_counts / out_order_value are filled there) and wait only hands its hits over.  clauses / clause_offsets / options
+ * need not outlive submit. */
+int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                                    uint32_t n_queries, const nidx_gpu_bm25_search_options_t *options, uint64_t *ticket_out);
+int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket, uint64_t *out_docaddr, float *out_score, uint32_t *out_count,
+                                  uint64_t *out_total, uint64_t *out_postings);
+
 /* The `created` / `modified` fast fields of one segment (nidx_text/src/schema.rs:59-115): values[doc]. */
 int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values);
 

@@ -251,6 +251,8 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_bm25_search_ex": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Bm25SearchOptionsC), C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nidx_gpu_bm25_search_submit": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Bm25SearchOptionsC), C.POINTER(C.c_uint64)]),
+    "nidx_gpu_bm25_search_wait": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_bm25_set_fast_field": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_bm25_set_dictionary": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_segment_dir_open": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -292,6 +292,42 @@ class Bm25Searcher:
         return {"docaddr": docaddr, "score": score, "count": count, "total": total, "postings": postings,
                 "order_value": order_value, "facet_counts": facet_counts}
 
+    def submit(self, queries: Sequence[Sequence[Clause]], k: int) -> int:
+        """nidx_gpu_bm25_search_submit for a batch of plain term clauses -> ticket; the host side of this batch overlaps the kernels of
+        the batches already in flight (at most 4 tickets outstanding)."""
+        B = len(queries)
+        offsets = np.zeros(B + 1, dtype=np.uint64)
+        flat = []
+        for i, q in enumerate(queries):
+            flat.extend(q)
+            offsets[i + 1] = len(flat)
+        cl = (_lib.Bm25ClauseC * max(1, len(flat)))()
+        for i, c in enumerate(flat):
+            if c.term_set is not None or c.subquery is not None:
+                raise ValueError("submit() takes plain term clauses; use search_batch_ex for the rest")
+            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
+        opt = _lib.Bm25SearchOptionsC()
+        opt.k = k
+        opt.order_field = -1
+        t = C.c_uint64(0)
+        _lib.check(_lib.lib().nidx_gpu_bm25_search_submit(self._handle, cl, offsets.ctypes.data, B, C.byref(opt), C.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = (B, k)
+        return t.value
+
+    def wait(self, ticket: int):
+        """-> (docaddr [B][k] u64, score [B][k] f32, count [B], total [B], postings [B]) of the batch submitted under `ticket`."""
+        B, k = self._tickets.pop(ticket)
+        kk = max(1, k)
+        docaddr = np.zeros((B, kk), dtype=np.uint64)
+        score = np.zeros((B, kk), dtype=np.float32)
+        count = np.zeros(B, dtype=np.uint32)
+        total = np.zeros(B, dtype=np.uint64)
+        postings = np.zeros(B, dtype=np.uint64)
+        _lib.check(_lib.lib().nidx_gpu_bm25_search_wait(self._handle, ticket, docaddr.ctypes.data, score.ctypes.data, count.ctypes.data, total.ctypes.data,
+                                                        postings.ctypes.data))
+        return docaddr, score, count, total, postings
+
     def search_batch(self, queries: Sequence[Sequence[Clause]], k: int, after: Optional[Sequence[Optional[SearchAfter]]] = None):
         """-> (docaddr [B][k] u64, score [B][k] f32, count [B], total [B], postings [B])"""
         if any(c.term_set is not None or c.subquery is not None for q in queries for c in q):

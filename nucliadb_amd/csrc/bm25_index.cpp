@@ -63,6 +63,33 @@ struct Bm25Segment {
     }
 };
 
+// One batch in flight of nidx_gpu_bm25_search_submit / _wait: its own stream, events and staging — the buffers of the synchronous
+// path's set are swapped with a slot's while its batch is prepared and launched, so the search code below has one form.
+struct Bm25Slot {
+    bool busy = false, launched = false;
+    uint64_t ticket = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf s_after, s_count, s_total, s_postings, s_key, s_in_q, s_in_w, s_outpack;
+    PinBuf h_in_q, h_in_w, h_outpack;
+    // layout of h_outpack for the collect step
+    uint32_t nq = 0, k = 0, kk = 0;
+    size_t o_doc = 0, o_score = 0, o_count = 0, o_total = 0, o_post = 0;
+    // a request the pipeline does not cover (several segments, term sets, phrases, nested queries, facets, order by a field) runs
+    // synchronously inside submit; its results wait here
+    std::vector<uint64_t> r_docaddr, r_total, r_postings;
+    std::vector<float> r_score;
+    std::vector<uint32_t> r_count;
+    ~Bm25Slot() {
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
 struct Bm25Index {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +111,15 @@ struct Bm25Index {
     PinBuf h_in_q, h_in_w, h_outpack;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
+    std::vector<std::unique_ptr<Bm25Slot>> slots;   // nidx_gpu_bm25_search_submit / _wait
+    uint64_t next_ticket = 1;
+    Bm25Slot *async_slot = nullptr;                 // set while a submit prepares its batch: launch, do not wait
+    void swap_slot(Bm25Slot &sl) {
+        std::swap(stream, sl.stream), std::swap(ev0, sl.ev0), std::swap(ev1, sl.ev1);
+        std::swap(s_after, sl.s_after), std::swap(s_count, sl.s_count), std::swap(s_total, sl.s_total), std::swap(s_postings, sl.s_postings);
+        std::swap(s_key, sl.s_key), std::swap(s_in_q, sl.s_in_q), std::swap(s_in_w, sl.s_in_w), std::swap(s_outpack, sl.s_outpack);
+        std::swap(h_in_q, sl.h_in_q), std::swap(h_in_w, sl.h_in_w), std::swap(h_outpack, sl.h_outpack);
+    }
     Bm25Index() = default;
     Bm25Index(const Bm25Index &) = delete;
     // also the clean-up of an open that failed half way
@@ -460,12 +496,13 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
-int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
-                                uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
-                                uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) try {
-    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
-    if (!idx || !clause_offsets || !out_count || !opt) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lock(idx->mu);
+}  // extern "C"
+
+// The search itself; the caller holds idx->mu.  With idx->async_slot set and a request the pipeline covers it returns after the
+// last asynchronous call (launches + the device-to-host transfer of the result block are queued on the slot's stream).
+static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                                  uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
+                                  uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
     NIDX_HIP(hipSetDevice(idx->device));
     const uint32_t k = opt->k;
     const nidx_gpu_bm25_search_after_t *after = opt->after;
@@ -902,6 +939,14 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + o_count);
         const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + o_total);
         const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + o_post);
+        if (idx->async_slot && idx->segs.size() == 1 && n_aux == 0 && n_slots == 0 && order_field < 0 && !a.dbg) {
+            // pipelined: the collect step runs in nidx_gpu_bm25_search_wait (the buffers are the slot's: swapped in by submit)
+            Bm25Slot &sl = *idx->async_slot;
+            sl.launched = true;
+            sl.nq = nq, sl.k = k, sl.kk = kk;
+            sl.o_doc = o_doc, sl.o_score = o_score, sl.o_count = o_count, sl.o_total = o_total, sl.o_post = o_post;
+            return NIDX_OK;
+        }
         const double t_s0 = now_us();
         NIDX_HIP(hipStreamSynchronize(idx->stream));
         t_sync += now_us() - t_s0;
@@ -1016,6 +1061,123 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     if (host_dbg)
         fprintf(stderr, "[bm25 host] total=%.0f us: work list=%.0f sync wait=%.0f collect=%.0f merge=%.0f\n", now_us() - t_begin, t_work, t_sync,
                 t_collect, now_us() - t_merge0);
+    return NIDX_OK;
+}
+
+extern "C" {
+
+int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                                uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
+                                uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) try {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !clause_offsets || !out_count || !opt) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    return bm25_search_locked(idx, clauses, clause_offsets, nq, opt, out_docaddr, out_score, out_count, out_total, out_postings);
+} NIDX_ABI_CATCH
+
+// ---- pipelined form: the host side of batch i + 1 (clause weights, work list, staging) overlaps the kernels of batch i ----------
+#define NIDX_BM25_PIPELINE_DEPTH 4
+
+int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+                                    uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *ticket_out) try {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !clause_offsets || !opt || !ticket_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *ticket_out = 0;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    NIDX_HIP(hipSetDevice(idx->device));
+    Bm25Slot *slot = nullptr;
+    for (auto &s : idx->slots)
+        if (!s->busy) { slot = s.get(); break; }
+    if (!slot) {
+        if (idx->slots.size() >= NIDX_BM25_PIPELINE_DEPTH)
+            return fail(NIDX_ERR_BUSY, "all %d BM25 pipeline slots hold a ticket that has not been waited for", NIDX_BM25_PIPELINE_DEPTH);
+        std::unique_ptr<Bm25Slot> ns(new Bm25Slot());
+        int lo = 0, hi = 0;
+        NIDX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        NIDX_HIP(hipStreamCreateWithPriority(&ns->stream, hipStreamNonBlocking, hi));
+        NIDX_HIP(hipEventCreate(&ns->ev0));
+        NIDX_HIP(hipEventCreate(&ns->ev1));
+        idx->slots.push_back(std::move(ns));
+        slot = idx->slots.back().get();
+    }
+    const uint32_t k = opt->k;
+    slot->launched = false;
+    slot->nq = nq, slot->k = k;
+    // outputs of a request that runs synchronously inside this call
+    const size_t kk1 = std::max<uint32_t>(k, 1);
+    slot->r_docaddr.assign((size_t)nq * kk1, 0), slot->r_score.assign((size_t)nq * kk1, 0.f);
+    slot->r_count.assign(nq, 0), slot->r_total.assign(nq, 0), slot->r_postings.assign(nq, 0);
+    idx->swap_slot(*slot);
+    idx->async_slot = slot;
+    const int32_t rc = bm25_search_locked(idx, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
+                                          slot->r_total.data(), slot->r_postings.data());
+    idx->async_slot = nullptr;
+    idx->swap_slot(*slot);
+    if (rc != NIDX_OK) return rc;
+    slot->busy = true;
+    slot->ticket = idx->next_ticket++;
+    *ticket_out = slot->ticket;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket, uint64_t *out_docaddr, float *out_score, uint32_t *out_count,
+                                  uint64_t *out_total, uint64_t *out_postings) try {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    Bm25Slot *slot = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(idx->mu);
+        for (auto &s : idx->slots)
+            if (s->busy && s->ticket == ticket && ticket != 0) { slot = s.get(); break; }
+        if (!slot) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown ticket %llu (a ticket is waited for once)", (unsigned long long)ticket);
+        slot->ticket = 0;   // nobody else finds it; it stays busy until its results are out
+    }
+    struct Release {
+        Bm25Index *idx;
+        Bm25Slot *slot;
+        ~Release() {
+            std::lock_guard<std::mutex> lock(idx->mu);
+            slot->busy = false;
+        }
+    } release{idx, slot};
+    const uint32_t nq = slot->nq, k = slot->k;
+    if (slot->launched) {
+        NIDX_HIP(hipSetDevice(idx->device));
+        NIDX_HIP(hipStreamSynchronize(slot->stream));
+        float ms = 0.f;
+        NIDX_HIP(hipEventElapsedTime(&ms, slot->ev0, slot->ev1));
+        {
+            std::lock_guard<std::mutex> lock(idx->mu);
+            idx->last_kernel_ms += ms;
+        }
+        const unsigned char *h_out = slot->h_outpack.as<unsigned char>();
+        const uint32_t *h_doc = reinterpret_cast<const uint32_t *>(h_out + slot->o_doc);
+        const float *h_score = reinterpret_cast<const float *>(h_out + slot->o_score);
+        const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + slot->o_count);
+        const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + slot->o_total);
+        const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + slot->o_post);
+        const uint32_t kk = slot->kk;
+        for (uint32_t q = 0; q < nq; q++) {   // one segment: the device list is the answer
+            if (out_total) out_total[q] = h_total[q];
+            if (out_postings) out_postings[q] = h_post[q];
+            const uint32_t n = k ? std::min<uint32_t>(h_count[q], k) : 0u;
+            out_count[q] = n;
+            for (uint32_t i = 0; i < n; i++) {
+                if (out_docaddr) out_docaddr[(size_t)q * k + i] = (uint64_t)h_doc[(size_t)q * kk + i];
+                if (out_score) out_score[(size_t)q * k + i] = h_score[(size_t)q * kk + i];
+            }
+        }
+        return NIDX_OK;
+    }
+    for (uint32_t q = 0; q < nq; q++) {
+        out_count[q] = slot->r_count[q];
+        if (out_total) out_total[q] = slot->r_total[q];
+        if (out_postings) out_postings[q] = slot->r_postings[q];
+        for (uint32_t i = 0; i < slot->r_count[q]; i++) {
+            if (out_docaddr) out_docaddr[(size_t)q * k + i] = slot->r_docaddr[(size_t)q * k + i];
+            if (out_score) out_score[(size_t)q * k + i] = slot->r_score[(size_t)q * k + i];
+        }
+    }
     return NIDX_OK;
 } NIDX_ABI_CATCH
 

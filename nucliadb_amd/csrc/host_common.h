@@ -73,6 +73,14 @@ struct PinBuf {
     PinBuf() = default;
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
+    PinBuf(PinBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    PinBuf &operator=(PinBuf &&o) noexcept {
+        if (this != &o) {
+            if (p) (void)hipHostFree(p);
+            p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+        }
+        return *this;
+    }
     ~PinBuf() {
         if (p) (void)hipHostFree(p);
     }

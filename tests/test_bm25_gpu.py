@@ -283,3 +283,47 @@ def test_nested_boolean_queries_match_the_oracle(orc, corpus):
             assert np.array_equal(docaddr[i, : count[i]], wd), (i, docaddr[i, : count[i]], wd)
             assert np.array_equal(bits(score[i, : count[i]]), bits(ws)), (i, score[i, : count[i]], ws)
     s.close()
+
+
+def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
+    """nidx_gpu_bm25_search_submit / _wait: several batches in flight, waited for out of order, give what nidx_gpu_bm25_search gives
+    for each; a fifth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term
+    sets) run inside submit and still come back through wait."""
+    import ctypes as C
+
+    seg, vocab = corpus
+    rng = np.random.default_rng(41)
+    s = Bm25Searcher.open([seg])
+    batches = [[[Clause(int(t), int(rng.choice([S, S, M, N]))) for t in rng.integers(0, vocab, int(rng.integers(1, 6)))] for _ in range(int(n))]
+               for n in (64, 1, 200, 33)]
+    want = [s.search_batch(b, 20) for b in batches]
+    for _ in range(3):
+        tickets = [s.submit(b, 20) for b in batches]
+        with pytest.raises(_lib.NidxGpuError) as e:
+            s.submit(batches[0], 20)
+        assert "not been waited" in str(e.value)
+        for i in (2, 0, 3, 1):
+            got = s.wait(tickets[i])
+            for g, w in zip(got, want[i]):
+                assert np.array_equal(g.view(np.uint32) if g.dtype == np.float32 else g, w.view(np.uint32) if w.dtype == np.float32 else w), i
+        out = np.zeros(1, np.uint32)
+        assert _lib.lib().nidx_gpu_bm25_search_wait(s._handle, tickets[0], None, None, out.ctypes.data, None, None) == _lib.NIDX_ERR_INVALID_ARGUMENT
+    # a term-set query through the pipeline entry points (runs inside submit)
+    q = [[Clause(0, S, CONST, 0.5, term_set=[3, 4, 5]), Clause(7)]]
+    ref = s.search_batch_ex(q, 10)
+    cl = (_lib.Bm25ClauseC * 2)()
+    cl[0].term, cl[0].occur, cl[0].mode, cl[0].boost = _lib.BM25_TERM_SET | 0, S, CONST, 0.5
+    cl[1].term, cl[1].occur, cl[1].mode, cl[1].boost = 7, S, FREQ, 1.0
+    st, so, offs = np.array([3, 4, 5], np.uint32), np.array([0, 3], np.uint64), np.array([0, 2], np.uint64)
+    po = np.zeros(1, np.uint64)
+    opt = _lib.Bm25SearchOptionsC()
+    opt.k, opt.order_field = 10, -1
+    opt.term_set_terms, opt.term_set_offsets, opt.n_term_sets = st.ctypes.data, so.ctypes.data, 1
+    opt.phrase_offsets = po.ctypes.data
+    opt.subquery_offsets = po.ctypes.data
+    t = C.c_uint64(0)
+    _lib.check(_lib.lib().nidx_gpu_bm25_search_submit(s._handle, cl, offs.ctypes.data, 1, C.byref(opt), C.byref(t)))
+    d, sc, cnt = np.zeros((1, 10), np.uint64), np.zeros((1, 10), np.float32), np.zeros(1, np.uint32)
+    _lib.check(_lib.lib().nidx_gpu_bm25_search_wait(s._handle, t.value, d.ctypes.data, sc.ctypes.data, cnt.ctypes.data, None, None))
+    assert cnt[0] == ref["count"][0] and np.array_equal(d[0, : cnt[0]], ref["docaddr"][0, : cnt[0]]) and np.array_equal(bits(sc[0, : cnt[0]]), bits(ref["score"][0, : cnt[0]]))
+    s.close()
