@@ -1381,6 +1381,26 @@ class Bm25Bench:
         self.L.nidx_gpu_bm25_last_kernel_ms(self.searcher._handle, C.byref(ms))
         return ms.value
 
+    def submit(self, i):
+        """nidx_gpu_bm25_search_submit of prepared batch i -> ticket"""
+        from nucliadb_amd import _lib
+
+        if not hasattr(self, "_opt"):
+            self._opt = _lib.Bm25SearchOptionsC()
+            self._opt.k, self._opt.order_field = self.K, -1
+            self._zero64 = np.zeros(1, np.uint64)
+            self._opt.term_set_offsets = self._opt.phrase_offsets = self._opt.subquery_offsets = self._zero64.ctypes.data
+        t = C.c_uint64(0)
+        _lib.check(self.L.nidx_gpu_bm25_search_submit(self.searcher._handle, self.prepared[i % len(self.prepared)], self.offsets.ctypes.data, self.B,
+                                                      C.byref(self._opt), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        from nucliadb_amd import _lib
+
+        _lib.check(self.L.nidx_gpu_bm25_search_wait(self.searcher._handle, ticket, self.docaddr.ctypes.data, self.score.ctypes.data, self.count.ctypes.data,
+                                                    self.total.ctypes.data, self.post.ctypes.data))
+
     def close(self):
         self.searcher.close()
 
@@ -1494,8 +1514,8 @@ class Bm25Bench:
 def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qps):
     """BASELINE.json configs[2]: cosine HNSW over N x 768 vectors + BM25 over N synthetic documents (document i owns vector i), a
     batch of hybrid queries (one vector + 3 keyword terms), fused with reciprocal rank fusion.  The vector batches go through the
-    serving pipeline (`nfl` in flight, hits delivered to the host), the BM25 call runs on the library's own stream meanwhile, the
-    fusion is nucliadb's Python-side step (batched in host C++ here: nidx_gpu_rank_fusion_rrf)."""
+    serving pipeline (`nfl` in flight, hits delivered to the host), the BM25 batches through the library's pipelined entries (two in flight,
+    streams of their own), the fusion is nucliadb's Python-side step (batched in host C++ here: nidx_gpu_rank_fusion_rrf)."""
     from nucliadb_amd import _lib
     from nucliadb_amd.rank_fusion import rrf_fuse_batch
 
@@ -1504,7 +1524,8 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
     in_flight = []
-    t_parts = {"vector_submit": 0.0, "bm25_call": 0.0, "vector_wait": 0.0, "fusion": 0.0}
+    bm_in_flight = []   # (batch, ticket): the keyword search runs one batch ahead too (nidx_gpu_bm25_search_submit / _wait)
+    t_parts = {"vector_submit": 0.0, "bm25_submit_wait": 0.0, "vector_wait": 0.0, "fusion": 0.0}
     kernel_ms = []
 
     def submit(i):
@@ -1518,7 +1539,10 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         while len(in_flight) < nfl and (i + len(in_flight)) < last:
             submit(i + len(in_flight))
         t1 = time.perf_counter()
-        bm.search(i)
+        while len(bm_in_flight) < 2 and (i + len(bm_in_flight)) < last:
+            bm_in_flight.append((i + len(bm_in_flight), bm.submit(i + len(bm_in_flight))))
+        _bi, btk = bm_in_flight.pop(0)
+        bm.wait(btk)
         kernel_ms.append(bm.kernel_ms())
         t2 = time.perf_counter()
         tk, j = in_flight.pop(0)
@@ -1529,7 +1553,7 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         fused = rrf_fuse_batch([(bm.docaddr & np.uint64(0xFFFFFFFF), bm.count, 1.0, bm.score), (hv_.astype(np.uint64), hc_, 1.0, None)], k=60.0, window=k)
         t4 = time.perf_counter()
         t_parts["vector_submit"] += t1 - t0
-        t_parts["bm25_call"] += t2 - t1
+        t_parts["bm25_submit_wait"] += t2 - t1
         t_parts["vector_wait"] += t3 - t2
         t_parts["fusion"] += t4 - t3
         return fused
