@@ -534,11 +534,27 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         # the product's own exchange (csrc/shard_comm.cpp: RCCL inside the library); torch.distributed only ships the 128-byte id
         from nucliadb_amd.shard_merge import ShardComm
 
+        # (if the library's communicator cannot be set up on this node every rank falls back to the same exchange through
+        # torch.distributed — the line then says so in config.timed_region.entry — instead of losing the run)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
         idt = torch.zeros(_lib.SHARD_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(ShardComm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        comm = ShardComm(bytes(idt.cpu().numpy().tobytes()), rank, world, b"shard-%02d" % rank)
+        try:
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ShardComm.unique_id()), dtype=torch.uint8))
+        except Exception as e:
+            print("WARNING: nidx_gpu_shard_comm_unique_id failed: %r" % (e,), file=sys.stderr)
+            ok.zero_()
+        dist.broadcast(ok, src=0)
+        if int(ok.item()):
+            dist.broadcast(idt, src=0)
+            try:
+                comm = ShardComm(bytes(idt.cpu().numpy().tobytes()), rank, world, b"shard-%02d" % rank)
+            except Exception as e:
+                print("WARNING: rank %d: nidx_gpu_shard_comm_init failed: %r" % (rank, e), file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                comm = None
 
     def exchange_torch(out):
         # the same exchange through torch.distributed (cross-check of the product path; the only path with NIDX_BENCH_SAME_DEVICE)
@@ -607,17 +623,26 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             return
         b = i % n_sets
         st_ = streams[i % len(streams)]
+        tr0 = time.perf_counter()
         st_.wait_event(ev_exchanged[b])   # (a no-op until the event has been recorded once)
         search(qpool[i % n_pool], out=out_sets[b], on=st_.cuda_stream)
         ev_searched[b].record(st_)
+        tr1 = time.perf_counter()
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(ev_searched[b])
             last_merged[0] = exchange(out_sets[b], st=side_stream.cuda_stream)
             ev_exchanged[b].record(side_stream)
+        if trace_steps:
+            trace_acc[0] += tr1 - tr0
+            trace_acc[1] += time.perf_counter() - tr1
+            trace_acc[2] += 1
 
     def drain():
         while in_flight:
             wait_oldest()
+
+    trace_steps = os.environ.get("NIDX_BENCH_TRACE_STEPS") == "1"
+    trace_acc = [0.0, 0.0, 0]
 
     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl, 4)))
     for i in range(a.warmup):
@@ -649,6 +674,9 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace_steps and trace_acc[2]:
+        print("[bench trace] rank %d: %d exchange steps: host time in search launch %.3f ms, in exchange %.3f ms per step; elapsed %.3f ms per step"
+              % (rank, trace_acc[2], trace_acc[0] / trace_acc[2] * 1e3, trace_acc[1] / trace_acc[2] * 1e3, elapsed / max(1, a.steps * repeats) * 1e3), file=sys.stderr)
     # every timed launch ORs the overflow flags of its queries into one word: wait() re-runs flagged queries exactly and counts them
     # (N = 1); the device-entry launches of the exchange path leave the word for the poll below
     timed_flags = device_flags() if do_exchange else 0
@@ -740,7 +768,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
             "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "recall_hist": recall_hist, "evals": float(np.mean(evals_q)),
             "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
-            "build_s": build_s, "exchange_check": exchange_check, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
+            "build_s": build_s, "exchange_check": exchange_check, "library_exchange": comm is not None, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
         }
     if not headline:
         L.nidx_gpu_vector_close(h)
@@ -1185,7 +1213,8 @@ def bench_hnsw(a, L, dev, rank, world):
         "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"], "timed_queries_re_run_exactly": head["timed_retried"],
         "timed_region": {"steps_per_pass": a.steps, "passes": head["repeats"], "steps_timed": head["steps_timed"], "seconds": head["elapsed"],
                          "entry": "nidx_gpu_vector_search_submit / _wait: device-resident queries in, hits in host arrays out" if world == 1 else
-                                  "nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (RCCL inside the library)"},
+                                  ("nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (RCCL inside the library)" if head.get("library_exchange")
+                                   else "nidx_gpu_vector_segment_search_device + the same exchange through torch.distributed (validation mode, or the library's communicator could not be set up)")},
         "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"], "build_ef_upper": max(1, a.build_ef_upper),
         "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],
         "batches_in_flight": head["nfl"],
