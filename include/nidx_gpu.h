@@ -381,13 +381,20 @@ int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uin
  * (data_store/v2/quant_vector_store.rs:29-64), hnsw.graph / hnsw.edges (hnsw/disk/v2.rs).  Host side only (no
  * device call): the files are mmap'd and the views below feed nidx_gpu_vector_open and
  * nidx_gpu_vector_set_filter_index without a copy; everything stays valid until _close.
- * field.fst / label.fst / index.map are not read: like segment::open when they are missing (segment.rs:49-67),
- * the posting lists are rebuilt from the paragraph store (ParagraphInvertedIndexes::build,
- * inverted_index/paragraph.rs:68-103).  A directory written by nidx_gpu_segment_dir_write is opened by the
- * reference the same way.  DataStoreV1 directories (nodes.kv) are refused with NIDX_ERR_UNSUPPORTED. */
+ * field.fst / label.fst / index.map (inverted_index/{fst_index.rs:26-87, map.rs:27-86, paragraph.rs:68-121}: two
+ * fst::Map images key -> offset into index.map, whose records are a u64 count + the stream-vbyte encoded paragraph
+ * addresses) are read when index.map exists (InvertedIndexes::exists, inverted_index.rs:57-60) and every list in
+ * them is a well-formed list of this paragraph store; otherwise — like segment::open when they are missing
+ * (segment.rs:49-67) — the posting lists are rebuilt from the paragraph store (ParagraphInvertedIndexes::build,
+ * paragraph.rs:68-103).  nidx_gpu_segment_dir_write / _merge write the three files (NIDX_GPU_SEGMENT_DIR_FST=0 in the
+ * environment: neither written nor read — the reference then regenerates them on open).  The two containers are
+ * third-party formats (fst 0.4.7, stream-vbyte 0.4.1) restated without the crates at hand: see fst_index.cpp.
+ * DataStoreV1 directories (nodes.kv) are refused with NIDX_ERR_UNSUPPORTED. */
 typedef struct nidx_gpu_segment_dir nidx_gpu_segment_dir_t;
 int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out);
 void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir);
+/* 1: the posting lists came from field.fst / label.fst / index.map; 0: rebuilt from the paragraph store; -1: NULL */
+int32_t nidx_gpu_segment_dir_index_source(const nidx_gpu_segment_dir_t *dir);
 /* The nidx_gpu_vector_segment_t of the directory (alive_bitset NULL: apply_deletions is the caller's,
  * segment.rs:428-445; paragraph_key_ids = a 64-bit hash of every key). */
 int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *segment_out);
@@ -462,6 +469,18 @@ typedef struct {
 int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const nidx_gpu_merge_operand_t *operands,
                                    uint32_t n_operands, uint32_t *records_out, uint32_t *vectors_out, uint32_t *graph_nodes_out,
                                    int32_t *has_quantized_out);
+
+/* The containers on their own (tooling and tests).  _fst_map_build: FstIndexWriter::write's fst::MapBuilder (fst_index.rs:
+ * 40-50) over n strictly ascending keys; call with out = NULL for the size.  _fst_map_get: FstIndexReader::get's lookup
+ * (:66-68).  _fst_map_entries: the stream of get_prefix (:76-86) with an empty prefix — every key in order (sizes first with
+ * NULL buffers).  _index_map_read: InvertedMapReader::get (map.rs:63-70). */
+int32_t nidx_gpu_fst_map_build(const uint8_t *keys, const uint64_t *key_offsets, const uint64_t *values, uint32_t n, uint8_t *out,
+                               uint64_t cap, uint64_t *len_out);
+int32_t nidx_gpu_fst_map_get(const uint8_t *image, uint64_t len, const uint8_t *key, uint32_t key_len, uint64_t *value_out,
+                             int32_t *found_out);
+int32_t nidx_gpu_fst_map_entries(const uint8_t *image, uint64_t len, uint8_t *keys_out, uint64_t keys_cap, uint64_t *key_offsets_out,
+                                 uint64_t *values_out, uint32_t cap, uint32_t *n_out, uint64_t *keys_len_out);
+int32_t nidx_gpu_index_map_read(const uint8_t *map, uint64_t len, uint64_t pos, uint32_t *ids_out, uint32_t cap, uint32_t *n_out);
 
 /* =====================================================================================
  * BM25 index — replaces the tantivy scoring under TextSearcher::search

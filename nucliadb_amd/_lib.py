@@ -257,6 +257,12 @@ SIGNATURES = {
     "nidx_gpu_bm25_set_dictionary": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_segment_dir_open": (C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "nidx_gpu_segment_dir_close": (None, [C.c_void_p]),
+    "nidx_gpu_segment_dir_index_source": (C.c_int32, [C.c_void_p]),
+    "nidx_gpu_fst_map_build": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nidx_gpu_fst_map_get": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "nidx_gpu_fst_map_entries": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "nidx_gpu_index_map_read": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_segment_dir_segment": (C.c_int32, [C.c_void_p, C.POINTER(VectorSegmentC)]),
     "nidx_gpu_segment_dir_filter_index": (C.c_int32, [C.c_void_p, C.POINTER(FilterIndexC)]),
     "nidx_gpu_segment_dir_lists": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -6,10 +6,14 @@
 //   vectors.quant    data_store/v2/quant_vector_store.rs:29-64      dimension/8 + 8 bytes per vector (rabitq.rs:38-106)
 //   hnsw.graph/.edges hnsw/disk/v2.rs:16-49,214-252                 opaque here: handed to nidx_gpu_vector_open as they lie
 //
-// The files are mmap'd and handed to nidx_gpu_vector_open without a copy.  field.fst / label.fst / index.map (third
-// party `fst` containers) are neither read nor written: the reference rebuilds them from the paragraph store when they
-// are missing (segment.rs:49-67, ParagraphInvertedIndexes::build, inverted_index/paragraph.rs:68-103), and this file
-// rebuilds the same posting lists in memory from the same records, keyed the same way (labels_key / FieldKey).
+//   field.fst / label.fst / index.map   inverted_index/{fst_index.rs,map.rs,paragraph.rs}   fst_index.cpp
+//
+// The files are mmap'd and handed to nidx_gpu_vector_open without a copy.  The inverted indexes are read from their three
+// files when index.map is there (InvertedIndexes::exists, inverted_index.rs:57-60) and every list they hold passes the
+// checks below; otherwise — like segment::open when they are missing (segment.rs:49-67) — the posting lists are rebuilt
+// from the paragraph store, keyed the same way (ParagraphInvertedIndexes::build, inverted_index/paragraph.rs:68-103:
+// labels_key / FieldKey).  Writers emit the three files next to the stores (NIDX_GPU_SEGMENT_DIR_FST=0: neither written
+// nor read).
 //
 // StoredParagraph is serialised with wincode configured to match bincode::config::standard() (utils.rs:25-28): little
 // endian, variable-length integers (u < 251: one byte; 251 + u16; 252 + u32; 253 + u64), a sequence or string = its
@@ -29,6 +33,7 @@
 #include <vector>
 
 #include "../../include/nidx_gpu.h"
+#include "fst_index.h"
 #include "host_common.h"
 
 namespace nidx {
@@ -140,6 +145,48 @@ bool field_key(const uint8_t *s, size_t n, std::string &out) {
     return true;
 }
 
+// ParagraphInvertedIndexes::build (inverted_index/paragraph.rs:72-85): "F" + FieldKey bytes | "L" + labels_key -> addresses
+struct ListBuilder {
+    std::map<std::string, std::vector<uint32_t>> lists;
+    std::string fk;
+    void key(const uint8_t *s, size_t n, uint32_t a) {
+        if (field_key(s, n, fk)) lists["F" + fk].push_back(a);
+    }
+    void label(const uint8_t *s, size_t n, uint32_t a) {
+        if (n == 0) return;
+        // labels_key: the label without its leading '/', plus a trailing '/'
+        std::vector<uint32_t> &pl = lists["L" + std::string(reinterpret_cast<const char *>(s + 1), n - 1) + "/"];
+        if (pl.empty() || pl.back() != a) pl.push_back(a);
+    }
+};
+
+bool fst_files_enabled() {
+    const char *e = getenv("NIDX_GPU_SEGMENT_DIR_FST");
+    return !(e && e[0] == '0');
+}
+
+int write_bytes(const std::string &path, const void *p, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return -1;
+    const bool ok = n == 0 || fwrite(p, 1, n, f) == n;
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
+// ParagraphInvertedIndexes::build's file output: the field index first, then the label index, both into one index.map
+// (paragraph.rs:87-100; IndexBuilder sorts every list, fst_index.rs:36-38 — they already ascend here).  index.map is written
+// last: it is the file whose presence says "the indexes exist".
+int write_index_files(const std::string &base, const std::map<std::string, std::vector<uint32_t>> &lists) {
+    std::vector<uint8_t> map_bytes, image;
+    for (const char kind : {'F', 'L'}) {
+        std::vector<std::pair<std::string, uint64_t>> entries;
+        for (const auto &kv : lists)
+            if (kv.first[0] == kind) entries.push_back({kv.first.substr(1), map_append(map_bytes, kv.second.data(), kv.second.size())});
+        if (!fst_build(entries, image)) return -1;
+        if (write_bytes(base + (kind == 'F' ? "field.fst" : "label.fst"), image.data(), image.size())) return -1;
+    }
+    return write_bytes(base + "index.map", map_bytes.data(), map_bytes.size());
+}
+
 }  // namespace
 
 struct SegmentDir {
@@ -155,7 +202,37 @@ struct SegmentDir {
     std::vector<uint64_t> list_offsets;
     std::vector<uint32_t> list_ids;
     uint32_t n_label_lists = 0;  // the "F" lists come first ('F' < 'L')
+    bool lists_from_files = false;
 };
+
+namespace {
+// The posting lists out of field.fst / label.fst / index.map.  false (nothing kept): a file is missing or anything in them
+// is not what a well-formed index of THIS paragraph store looks like — the caller rebuilds from the paragraphs instead.
+bool load_index_files(SegmentDir *d, const std::string &base) {
+    MappedFile map, fst[2];
+    if (map.open(base + "index.map") != 0 || fst[0].open(base + "field.fst") != 0 || fst[1].open(base + "label.fst") != 0) return false;
+    std::vector<std::string> keys;
+    std::vector<uint64_t> offsets(1, 0);
+    std::vector<uint32_t> ids, list;
+    std::vector<std::pair<std::string, uint64_t>> entries;
+    uint32_t n_label = 0;
+    for (int kind = 0; kind < 2; kind++) {
+        if (!fst_check_sum(fst[kind].p, fst[kind].len) || !fst_enumerate(fst[kind].p, fst[kind].len, entries, map.len / 9 + 1)) return false;   // (a record is >= 9 bytes)
+        for (const auto &e : entries) {
+            if (!map_read(map.p, map.len, e.second, list) || list.empty()) return false;
+            for (size_t i = 0; i < list.size(); i++)
+                if (list[i] >= d->n_paragraphs || (i && list[i] <= list[i - 1])) return false;
+            keys.push_back((kind == 0 ? "F" : "L") + e.first);
+            ids.insert(ids.end(), list.begin(), list.end());
+            offsets.push_back(ids.size());
+        }
+        if (kind == 1) n_label = (uint32_t)entries.size();
+    }
+    d->list_keys.swap(keys), d->list_offsets.swap(offsets), d->list_ids.swap(ids);
+    d->n_label_lists = n_label;
+    return true;
+}
+}  // namespace
 
 }  // namespace nidx
 
@@ -193,8 +270,9 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
     d->key_ids.resize(d->n_paragraphs);
     const uint8_t *data = d->para_data.p;
     const size_t dlen = d->para_data.len;
-    std::map<std::string, std::vector<uint32_t>> lists;
-    std::string fk;
+    d->lists_from_files = fst_files_enabled() && load_index_files(d.get(), base);
+    const bool rebuild = !d->lists_from_files;
+    ListBuilder lb;
     for (uint32_t a = 0; a < d->n_paragraphs; a++) {
         uint32_t start;
         memcpy(&start, d->para_pos.p + (size_t)a * 4, 4);
@@ -222,29 +300,29 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
         pg.num_vectors = (uint32_t)nv;
         if (fv > d->n_vectors || nv > d->n_vectors - fv) return fail(NIDX_ERR_IO, "paragraph %u owns vectors beyond vectors.bin", a);
         d->key_ids[a] = key_id(data + pg.key.off, pg.key.len);
-        // ParagraphInvertedIndexes::build (inverted_index/paragraph.rs:72-85)
-        if (field_key(data + pg.key.off, pg.key.len, fk)) lists["F" + fk].push_back(a);
-        for (uint32_t i = 0; i < pg.n_labels; i++) {
-            const Span &l = d->labels[pg.first_label + i];
-            if (l.len == 0) continue;
-            // labels_key: the label without its leading '/', plus a trailing '/'
-            std::string k = "L" + std::string(reinterpret_cast<const char *>(data + l.off + 1), l.len - 1) + "/";
-            std::vector<uint32_t> &pl = lists[k];
-            if (pl.empty() || pl.back() != a) pl.push_back(a);
-        }
+        if (!rebuild) continue;
+        lb.key(data + pg.key.off, pg.key.len, a);
+        for (uint32_t i = 0; i < pg.n_labels; i++) lb.label(data + d->labels[pg.first_label + i].off, d->labels[pg.first_label + i].len, a);
     }
-    d->list_offsets.push_back(0);
-    for (auto &kv : lists) {
-        d->list_keys.push_back(kv.first);
-        d->list_ids.insert(d->list_ids.end(), kv.second.begin(), kv.second.end());
-        d->list_offsets.push_back(d->list_ids.size());
-        if (kv.first[0] == 'L') d->n_label_lists++;
+    if (rebuild) {
+        d->list_offsets.push_back(0);
+        for (auto &kv : lb.lists) {
+            d->list_keys.push_back(kv.first);
+            d->list_ids.insert(d->list_ids.end(), kv.second.begin(), kv.second.end());
+            d->list_offsets.push_back(d->list_ids.size());
+            if (kv.first[0] == 'L') d->n_label_lists++;
+        }
     }
     *dir_out = reinterpret_cast<nidx_gpu_segment_dir_t *>(d.release());
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
 void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir) { delete reinterpret_cast<SegmentDir *>(dir); }
+
+int32_t nidx_gpu_segment_dir_index_source(const nidx_gpu_segment_dir_t *dir) {
+    const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
+    return d ? (d->lists_from_files ? 1 : 0) : -1;
+}
 
 int32_t nidx_gpu_segment_dir_segment(const nidx_gpu_segment_dir_t *dir, nidx_gpu_vector_segment_t *out) try {
     const SegmentDir *d = reinterpret_cast<const SegmentDir *>(dir);
@@ -330,12 +408,7 @@ int32_t nidx_gpu_segment_dir_paragraph_label(const nidx_gpu_segment_dir_t *dir, 
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
-static int write_file(const std::string &path, const void *p, size_t n) {
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) return -1;
-    const bool ok = n == 0 || fwrite(p, 1, n, f) == n;
-    return (fclose(f) == 0 && ok) ? 0 : -1;
-}
+static int write_file(const std::string &path, const void *p, size_t n) { return write_bytes(path, p, n); }
 
 int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_contents_t *c) try {
     if (!path || !c || c->dimension == 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -373,17 +446,20 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
     {   // paragraphs.bin + paragraphs.pos
         std::vector<uint8_t> data;
         std::vector<uint32_t> pos(c->n_paragraphs);
+        ListBuilder built;
         for (uint32_t a = 0; a < c->n_paragraphs; a++) {
             if (data.size() > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "paragraphs.bin would exceed the 4 GiB its u32 offsets address");
             pos[a] = (uint32_t)data.size();
             const uint64_t kb = c->key_offsets[a], ke = c->key_offsets[a + 1];
             write_varint(data, ke - kb);
             data.insert(data.end(), c->keys + kb, c->keys + ke);
+            built.key(c->keys + kb, ke - kb, a);
             const uint64_t lb = c->paragraph_label_offsets ? c->paragraph_label_offsets[a] : 0, le = c->paragraph_label_offsets ? c->paragraph_label_offsets[a + 1] : 0;
             write_varint(data, le - lb);
             for (uint64_t l = lb; l < le; l++) {
                 write_varint(data, c->label_offsets[l + 1] - c->label_offsets[l]);
                 data.insert(data.end(), c->labels + c->label_offsets[l], c->labels + c->label_offsets[l + 1]);
+                built.label(c->labels + c->label_offsets[l], c->label_offsets[l + 1] - c->label_offsets[l], a);
             }
             const uint64_t mb = c->metadata_offsets ? c->metadata_offsets[a] : 0, me = c->metadata_offsets ? c->metadata_offsets[a + 1] : 0;
             write_varint(data, me - mb);
@@ -393,6 +469,7 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
         }
         if (write_file(base + "paragraphs.bin", data.data(), data.size())) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.bin", base.c_str());
         if (write_file(base + "paragraphs.pos", pos.data(), pos.size() * 4)) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.pos", base.c_str());
+        if (fst_files_enabled() && write_index_files(base, built.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
     }
     if (c->quantized && c->quantized_len) {
         if (c->quantized_len != (uint64_t)c->n_vectors * (D / 8 + 8)) return fail(NIDX_ERR_INVALID_ARGUMENT, "quantized store has the wrong size");
@@ -452,6 +529,7 @@ int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const n
     // vectors (their trailer = the paragraph's new address) and, when stored, their RaBitQ records
     uint64_t p_idx = 0, v_idx = 0, data_len = 0;
     std::vector<uint8_t> rec;
+    ListBuilder lb;   // segment::create_indexes builds the inverted indexes of the merged store (segment.rs:231-236)
     for (uint32_t oi : order) {
         const SegmentDir *d = dir_of(oi);
         const uint8_t *data = d->para_data.p;
@@ -469,11 +547,13 @@ int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const n
             rec.clear();
             write_varint(rec, pg.key.len);
             rec.insert(rec.end(), data + pg.key.off, data + pg.key.off + pg.key.len);
+            lb.key(data + pg.key.off, pg.key.len, trailer);
             write_varint(rec, pg.n_labels);
             for (uint32_t l = 0; l < pg.n_labels; l++) {
                 const Span &sp = d->labels[pg.first_label + l];
                 write_varint(rec, sp.len);
                 rec.insert(rec.end(), data + sp.off, data + sp.off + sp.len);
+                lb.label(data + sp.off, sp.len, trailer);
             }
             write_varint(rec, pg.metadata.len);
             rec.insert(rec.end(), data + pg.metadata.off, data + pg.metadata.off + pg.metadata.len);
@@ -487,6 +567,7 @@ int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const n
         }
     }
     if (!vec.finish() || !pdata.finish() || !ppos.finish() || (quant && !quant->finish())) return fail(NIDX_ERR_IO, "cannot write the merged segment under %s", base.c_str());
+    if (fst_files_enabled() && write_index_files(base, lb.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
     // merge_indexes (segment.rs:137-167): the largest operand's graph is reused when none of its paragraphs is deleted — its
     // vectors are then the first rows of the merged store; the caller extends it (nidx_gpu_vector_extend_hnsw)
     const SegmentDir *first = dir_of(order[0]);
@@ -527,6 +608,55 @@ int32_t nidx_gpu_segment_dir_apply_deletions(const nidx_gpu_segment_dir_t *dir, 
         }
     }
     if (n_cleared_out) *n_cleared_out = cleared;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+// ---- the containers themselves (tooling / tests; fst_index.cpp) ----
+int32_t nidx_gpu_fst_map_build(const uint8_t *keys, const uint64_t *key_offsets, const uint64_t *values, uint32_t n, uint8_t *out, uint64_t cap, uint64_t *len_out) try {
+    if (!len_out || (n && (!keys || !key_offsets || !values))) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<std::pair<std::string, uint64_t>> entries(n);
+    for (uint32_t i = 0; i < n; i++) entries[i] = {std::string(reinterpret_cast<const char *>(keys + key_offsets[i]), key_offsets[i + 1] - key_offsets[i]), values[i]};
+    std::vector<uint8_t> image;
+    if (!fst_build(entries, image)) return fail(NIDX_ERR_INVALID_ARGUMENT, "keys must be strictly ascending");
+    *len_out = image.size();
+    if (out && cap >= image.size()) memcpy(out, image.data(), image.size());
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_fst_map_get(const uint8_t *image, uint64_t len, const uint8_t *key, uint32_t key_len, uint64_t *value_out, int32_t *found_out) try {
+    if (!image || !value_out || !found_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    *found_out = fst_get(image, len, key, key_len, value_out) ? 1 : 0;
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_fst_map_entries(const uint8_t *image, uint64_t len, uint8_t *keys_out, uint64_t keys_cap, uint64_t *key_offsets_out, uint64_t *values_out,
+                                 uint32_t cap, uint32_t *n_out, uint64_t *keys_len_out) try {
+    if (!image || !n_out || !keys_len_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<std::pair<std::string, uint64_t>> entries;
+    if (!fst_enumerate(image, len, entries)) return fail(NIDX_ERR_IO, "not a well-formed fst image");
+    uint64_t total = 0;
+    for (const auto &e : entries) total += e.first.size();
+    *n_out = (uint32_t)entries.size();
+    *keys_len_out = total;
+    if (keys_out && key_offsets_out && values_out && cap >= entries.size() && keys_cap >= total) {
+        uint64_t at = 0;
+        for (size_t i = 0; i < entries.size(); i++) {
+            key_offsets_out[i] = at;
+            memcpy(keys_out + at, entries[i].first.data(), entries[i].first.size());
+            at += entries[i].first.size();
+            values_out[i] = entries[i].second;
+        }
+        key_offsets_out[entries.size()] = at;
+    }
+    return NIDX_OK;
+} NIDX_ABI_CATCH
+
+int32_t nidx_gpu_index_map_read(const uint8_t *map, uint64_t len, uint64_t pos, uint32_t *ids_out, uint32_t cap, uint32_t *n_out) try {
+    if (!map || !n_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<uint32_t> ids;
+    if (!map_read(map, len, pos, ids)) return fail(NIDX_ERR_IO, "no record at offset %llu", (unsigned long long)pos);
+    *n_out = (uint32_t)ids.size();
+    if (ids_out && cap >= ids.size() && !ids.empty()) memcpy(ids_out, ids.data(), ids.size() * 4);
     return NIDX_OK;
 } NIDX_ABI_CATCH
 

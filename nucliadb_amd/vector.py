@@ -400,6 +400,11 @@ class SegmentDir:
     def __exit__(self, *exc):
         self.close()
 
+    @property
+    def indexes_from_files(self) -> bool:
+        """True: the posting lists were read from field.fst / label.fst / index.map; False: rebuilt from the paragraphs."""
+        return _lib.lib().nidx_gpu_segment_dir_index_source(self._h) == 1
+
     def segment_c(self) -> "_lib.VectorSegmentC":
         s = _lib.VectorSegmentC()
         _lib.check(_lib.lib().nidx_gpu_segment_dir_segment(self._h, C.byref(s)))
@@ -950,3 +955,48 @@ class VectorSearcher:
             md = sg.metadata[p]
             docs.append(DocumentScored(sg.keys[p], float(score[0, i]), md if md else None, list(sg.labels[p])))
         return VectorSearchResponse(docs)
+
+
+def fst_map_build(entries: Sequence[Tuple[bytes, int]]) -> bytes:
+    """fst::MapBuilder over strictly ascending (key, value) pairs (nidx_gpu_fst_map_build) -> the image."""
+    keys = b"".join(k for k, _ in entries)
+    offs = np.zeros(len(entries) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(k) for k, _ in entries], dtype=np.uint64)
+    vals = np.array([v for _, v in entries], np.uint64)
+    kb = np.frombuffer(keys, np.uint8) if keys else np.zeros(1, np.uint8)
+    n = C.c_uint64(0)
+    _lib.check(_lib.lib().nidx_gpu_fst_map_build(kb.ctypes.data, offs.ctypes.data, vals.ctypes.data, len(entries), None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.uint8)
+    _lib.check(_lib.lib().nidx_gpu_fst_map_build(kb.ctypes.data, offs.ctypes.data, vals.ctypes.data, len(entries), out.ctypes.data, out.size, C.byref(n)))
+    return out.tobytes()
+
+
+def fst_map_get(image: bytes, key: bytes) -> Optional[int]:
+    buf = np.frombuffer(image, np.uint8)
+    v, found = C.c_uint64(0), C.c_int32(0)
+    _lib.check(_lib.lib().nidx_gpu_fst_map_get(buf.ctypes.data, buf.size, key, len(key), C.byref(v), C.byref(found)))
+    return v.value if found.value else None
+
+
+def fst_map_entries(image: bytes) -> List[Tuple[bytes, int]]:
+    """Every (key, value) of an fst::Map image in key order (nidx_gpu_fst_map_entries); raises on a malformed image."""
+    buf = np.frombuffer(image, np.uint8)
+    n, klen = C.c_uint32(0), C.c_uint64(0)
+    _lib.check(_lib.lib().nidx_gpu_fst_map_entries(buf.ctypes.data, buf.size, None, 0, None, None, 0, C.byref(n), C.byref(klen)))
+    keys = np.zeros(max(klen.value, 1), np.uint8)
+    offs = np.zeros(n.value + 1, np.uint64)
+    vals = np.zeros(max(n.value, 1), np.uint64)
+    _lib.check(_lib.lib().nidx_gpu_fst_map_entries(buf.ctypes.data, buf.size, keys.ctypes.data, keys.size, offs.ctypes.data, vals.ctypes.data,
+                                                  n.value, C.byref(n), C.byref(klen)))
+    kb = keys.tobytes()
+    return [(kb[int(offs[i]):int(offs[i + 1])], int(vals[i])) for i in range(n.value)]
+
+
+def index_map_read(data: bytes, pos: int) -> np.ndarray:
+    """InvertedMapReader::get (inverted_index/map.rs:63-70) through nidx_gpu_index_map_read."""
+    buf = np.frombuffer(data, np.uint8)
+    n = C.c_uint32(0)
+    _lib.check(_lib.lib().nidx_gpu_index_map_read(buf.ctypes.data, buf.size, pos, None, 0, C.byref(n)))
+    out = np.zeros(max(n.value, 1), np.uint32)
+    _lib.check(_lib.lib().nidx_gpu_index_map_read(buf.ctypes.data, buf.size, pos, out.ctypes.data, out.size, C.byref(n)))
+    return out[: n.value]

@@ -89,7 +89,8 @@ int main(int argc, char **argv) {
     const std::string seed = argv[1], scratch = argv[2];
     const uint32_t dim = (uint32_t)atoi(argv[3]);
     const int iters = atoi(argv[4]);
-    const char *names[] = {"vectors.bin", "paragraphs.bin", "paragraphs.pos", "vectors.quant", "hnsw.graph", "hnsw.edges"};
+    const char *names[] = {"vectors.bin", "paragraphs.bin", "paragraphs.pos", "vectors.quant", "hnsw.graph", "hnsw.edges", "field.fst", "label.fst", "index.map"};
+    const size_t n_names = sizeof(names) / sizeof(names[0]);
     std::vector<std::vector<uint8_t>> good;
     for (const char *n : names) good.push_back(slurp(seed + "/" + n));
     const std::string mdir = scratch + "/mutant", odir = scratch + "/merged";
@@ -102,8 +103,9 @@ int main(int argc, char **argv) {
             const int n_mut = 1 + (int)(rng() % 3);
             for (int m = 0; m < n_mut; m++) mutate(files[1 + rng() % 2 + (rng() % 4 == 0 ? 2 : 0)]);  // mostly the paragraph store
             if (rng() % 8 == 0) mutate(files[0]);
+            if (rng() % 3 == 0) mutate(files[6 + rng() % 3]);   // the inverted-index files (an fst that fails its checksum => rebuild)
         }
-        for (size_t i = 0; i < 6; i++) spit(mdir + "/" + names[i], files[i]);
+        for (size_t i = 0; i < n_names; i++) spit(mdir + "/" + names[i], files[i]);
         nidx_gpu_segment_dir_t *d = nullptr;
         const int32_t rc = nidx_gpu_segment_dir_open(mdir.c_str(), dim, &d);
         if (rc == 0) { accepted++; acc += walk(d, odir, dim); nidx_gpu_segment_dir_close(d); }
@@ -119,6 +121,28 @@ int main(int argc, char **argv) {
         const int32_t grc = nidx_gpu_hnsw_graph_check(exact, g.size(), (const float *)good[5].data(), good[5].size() / 4, n_nodes, &en, &el, &nl, &nb);
         if (it == 0 && grc != 0) { fprintf(stderr, "the seed graph was refused (%d)\n", grc); return 1; }
         free(exact);
+        // the fst reader (no checksum gate here) and the index.map record reader on exact-size heap copies
+        std::vector<uint8_t> f = good[6 + it % 2];
+        if (it) { mutate(f); if (rng() % 2) mutate(f); }
+        uint8_t *fx = (uint8_t *)malloc(f.size() ? f.size() : 1);
+        memcpy(fx, f.data(), f.size());
+        uint32_t n_keys = 0;
+        uint64_t keys_len = 0;
+        const int32_t frc = nidx_gpu_fst_map_entries(fx, f.size(), nullptr, 0, nullptr, nullptr, 0, &n_keys, &keys_len);
+        if (it < 2 && (frc != 0 || n_keys == 0)) { fprintf(stderr, "the seed fst was refused (%d)\n", frc); return 1; }
+        uint64_t v = 0;
+        int32_t found = 0;
+        nidx_gpu_fst_map_get(fx, f.size(), (const uint8_t *)"set/1/", 6, &v, &found);
+        acc += n_keys + (uint64_t)found;
+        free(fx);
+        std::vector<uint8_t> m = good[8];
+        if (it) mutate(m);
+        uint8_t *mx = (uint8_t *)malloc(m.size() ? m.size() : 1);
+        memcpy(mx, m.data(), m.size());
+        uint32_t n_ids = 0;
+        std::vector<uint32_t> ids(64);
+        if (nidx_gpu_index_map_read(mx, m.size(), it ? rng() % (m.size() + 8) : 0, ids.data(), 64, &n_ids) == 0) acc += n_ids;
+        free(mx);
     }
     printf("iterations %d: directories accepted %llu refused %llu (checksum %llu)\n", iters, (unsigned long long)accepted, (unsigned long long)refused,
            (unsigned long long)acc);

@@ -7,7 +7,7 @@ WORK=$(mktemp -d /tmp/nidx_fuzz.XXXXXX)
 ITER=${1:-4000}
 CXXFLAGS="-std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/nucliadb_amd/csrc"
 g++ $CXXFLAGS "$ROOT/scripts/fuzz/fuzz_host_parsers.cpp" "$ROOT/scripts/fuzz/stub_errors.cpp" \
-    "$ROOT/nucliadb_amd/csrc/segment_dir.cpp" "$ROOT/nucliadb_amd/csrc/hnsw_graph.cpp" -o "$WORK/fuzz"
+    "$ROOT/nucliadb_amd/csrc/segment_dir.cpp" "$ROOT/nucliadb_amd/csrc/fst_index.cpp" "$ROOT/nucliadb_amd/csrc/hnsw_graph.cpp" -o "$WORK/fuzz"
 mkdir -p "$WORK/seed" "$WORK/scratch"
 cd "$ROOT"
 python - "$WORK/seed" <<'PY'

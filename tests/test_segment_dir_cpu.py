@@ -41,9 +41,10 @@ def test_writer_bytes_equal_the_format_restatement(orc, tmp_path):
     seg = VectorSegment(keys, vectors, labels, metadata)
     seg.save(str(tmp_path))
     want = orc.segment_dir_files(8, vectors, None, keys, labels, metadata)
+    want.update(orc.segment_dir_index_files(keys, labels))
     for name, data in want.items():
         assert read(tmp_path, name) == data, name
-    assert sorted(os.listdir(tmp_path)) == ["paragraphs.bin", "paragraphs.pos", "vectors.bin"]
+    assert sorted(os.listdir(tmp_path)) == ["field.fst", "index.map", "label.fst", "paragraphs.bin", "paragraphs.pos", "vectors.bin"]
     # the record layout, spelled out once: key "ab", labels ["/l/x"], metadata 01 02, first_vector 0, num_vectors 1
     one = orc.segment_dir_files(2, [[1.0, 2.0]], None, ["ab"], [["/l/x"]], [b"\x01\x02"])
     assert one["paragraphs.bin"] == b"\x02ab" + b"\x01\x04/l/x" + b"\x02\x01\x02" + b"\x00" + b"\x01"
@@ -61,6 +62,7 @@ def test_reader_decodes_reference_layout_and_rebuilds_the_inverted_indexes(orc, 
         with open(tmp_path / name, "wb") as f:
             f.write(data)
     with SegmentDir(str(tmp_path), 8) as d:
+        assert not d.indexes_from_files   # no index.map: ParagraphInvertedIndexes::build's rebuild (segment.rs:49-67)
         s = d.segment_c()
         assert s.n_vectors == len(pov) and s.n_paragraphs == len(keys) and s.row_stride_bytes == 36
         assert not s.hnsw_graph_len and not s.quantized_len and not s.alive_bitset
@@ -120,7 +122,8 @@ def test_round_trip_with_graph_and_quantized_store(tmp_path):
     quant = rng.integers(0, 256, (n, D // 8 + 8), dtype=np.uint8)
     seg = VectorSegment(keys, vectors, [[] for _ in keys], [b"" for _ in keys], graph=graph, graph_edges=edges, quantized=quant)
     seg.save(str(tmp_path))
-    assert sorted(os.listdir(tmp_path)) == ["hnsw.edges", "hnsw.graph", "paragraphs.bin", "paragraphs.pos", "vectors.bin", "vectors.quant"]
+    assert sorted(os.listdir(tmp_path)) == ["field.fst", "hnsw.edges", "hnsw.graph", "index.map", "label.fst", "paragraphs.bin", "paragraphs.pos",
+                                            "vectors.bin", "vectors.quant"]
     assert read(tmp_path, "hnsw.graph") == graph and read(tmp_path, "hnsw.edges") == edges.tobytes() and read(tmp_path, "vectors.quant") == quant.tobytes()
     back = VectorSegment.load(str(tmp_path), D)
     assert back.keys == keys and np.array_equal(back.vectors, vectors) and back.graph == graph and back.para_of_vec is None
@@ -292,3 +295,166 @@ def test_apply_deletions_equals_the_mirror(tmp_path):
         start = np.ones(seg.records, bool)
         start[:5] = False
         assert not d.apply_deletions([str(RID[0])], start)[:5].any()
+
+
+# ---- field.fst / label.fst / index.map ---------------------------------------------------------------------------------------
+def all_lists(d):
+    fi = d.filter_index_c()
+    return [d.posting_list(l).tolist() for l in range(fi.n_lists)]
+
+
+def lookups(d, keys):
+    out = []
+    for label in ["/l/set/label_0", "/l/set", "/l", "/e/entity", "/l/many/7", "/l/se", "/zzz"]:
+        out.append([d.posting_list(l).tolist() for l in d.lists(_lib.LIST_LABEL, label)])
+    for key in [f"{RID[0]}/t/title", str(RID[0]), f"{RID[2]}/a/body", "garbage", str(RID[3])]:
+        for prefix in (False, True):
+            out.append([d.posting_list(l).tolist() for l in d.lists(_lib.LIST_FIELD, key, prefix)])
+    return out
+
+
+def test_directory_opened_through_its_index_files_equals_the_rebuild(orc, tmp_path):
+    rng = np.random.default_rng(31)
+    keys, labels, metadata, vectors = corpus(rng)
+    VectorSegment(keys, vectors, labels, metadata).save(str(tmp_path))
+    with SegmentDir(str(tmp_path), 8) as d:
+        assert d.indexes_from_files
+        from_files = (all_lists(d), lookups(d, keys))
+        dead = d.apply_deletions([f"{RID[0]}/t/title", str(RID[2])])
+    # the same files through the independent restatement: every key -> its record in index.map
+    files = orc.segment_dir_index_files(keys, labels)
+    n_lists = 0
+    for name in ("field.fst", "label.fst"):
+        for key, pos in orc.fst_read(read(tmp_path, name)):
+            assert orc.index_map_read(read(tmp_path, "index.map"), pos) == orc.index_map_read(files["index.map"], dict(orc.fst_read(files[name]))[key])
+            n_lists += 1
+    assert n_lists == len(from_files[0])
+    os.remove(tmp_path / "index.map")   # InvertedIndexes::exists is false: rebuild
+    with SegmentDir(str(tmp_path), 8) as d:
+        assert not d.indexes_from_files
+        assert (all_lists(d), lookups(d, keys)) == from_files
+        assert np.array_equal(d.apply_deletions([f"{RID[0]}/t/title", str(RID[2])]), dead)
+
+
+def test_damaged_index_files_fall_back_to_the_rebuild(tmp_path, monkeypatch):
+    rng = np.random.default_rng(32)
+    keys, labels, metadata, vectors = corpus(rng)
+    VectorSegment(keys, vectors, labels, metadata).save(str(tmp_path))
+    with SegmentDir(str(tmp_path), 8) as d:
+        want = all_lists(d)
+    good = {name: read(tmp_path, name) for name in ("field.fst", "label.fst", "index.map")}
+
+    def reopen(exact=True):
+        with SegmentDir(str(tmp_path), 8) as d:
+            got = all_lists(d)
+            assert got == want or (not exact and d.indexes_from_files and len(got) == len(want))
+            return d.indexes_from_files
+
+    for name, data in good.items():
+        damaged = [data[: len(data) // 2], b"", data + b"\0"] if name != "index.map" else [data[: len(data) // 2], b""]
+        for _ in range(40):
+            b = bytearray(data)
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            damaged.append(bytes(b))
+        for bad in damaged:
+            with open(tmp_path / name, "wb") as f:
+                f.write(bad)
+            # whichever way it was opened, the lists are the right ones — except that index.map carries no checksum (in the
+            # reference neither): a flipped address bit that still decodes to an ascending list of stored paragraphs is read
+            reopen(exact=name != "index.map")
+            if name != "index.map" and bad != data:
+                assert not reopen(), name   # an fst image with any byte changed fails its checksum
+        with open(tmp_path / name, "wb") as f:
+            f.write(data)
+    assert reopen()
+    # index.map that decodes, but to lists that are not lists of this store: an address beyond the paragraphs
+    from nucliadb_amd.vector import fst_map_entries
+    first_key, pos = fst_map_entries(good["label.fst"])[0]
+    b = bytearray(good["index.map"])
+    b[pos + 8 + 1] = 0xFF   # (the list's first address byte, behind the u64 count and one control byte)
+    with open(tmp_path / "index.map", "wb") as f:
+        f.write(bytes(b))
+    assert not reopen()
+    with open(tmp_path / "index.map", "wb") as f:
+        f.write(good["index.map"])
+    monkeypatch.setenv("NIDX_GPU_SEGMENT_DIR_FST", "0")
+    assert not reopen()
+    other = tmp_path / "plain"
+    other.mkdir()
+    VectorSegment(keys, vectors, labels, metadata).save(str(other))
+    assert sorted(os.listdir(other)) == ["paragraphs.bin", "paragraphs.pos", "vectors.bin"]
+
+
+def test_fst_and_index_map_containers(orc):
+    from nucliadb_amd.vector import fst_map_build, fst_map_entries, fst_map_get, index_map_read
+
+    assert orc._crc32c(b"123456789") == 0xE3069283   # CRC-32C check value
+    # stream-vbyte: lengths 1,1,2,2 | 3,4,4,1 -> control bytes 0x50, 0x3e
+    ids = [0, 255, 256, 65535, 65536, 1 << 24, (1 << 32) - 1, 7]
+    rec = orc.index_map_record(ids)
+    assert rec == bytes.fromhex("0800000000000000" "503e" "00ff" "0001ffff" "000001" "00000001" "ffffffff" "07")
+    assert index_map_read(b"junk" + rec, 4).tolist() == ids == orc.index_map_read(b"junk" + rec, 4)
+    assert index_map_read(orc.index_map_record([]), 0).tolist() == []
+    with pytest.raises(_lib.NidxGpuError):
+        index_map_read(rec[:-1], 0)
+    # the writer's image of a small map, byte by byte (trie, general node encoding, value in the last node's final output)
+    entries = [(b"a", 0), (b"ab", 5), (b"abc", 70000), (b"b", 1 << 40), (b"zzz", 3)]
+    image = fst_map_build(entries)
+    body = bytes.fromhex(
+        "0300000000000000" "0000000000000000"      # version 3, type 0
+        "701101" "03" "00" "40"                    # @21 "abc": final output 70000 (3 bytes), sizes 0|3, 0 transitions, final
+        "05" "00" "01" "63" "11" "41"              # @27 "ab": final output 5, c -> delta 1 (out 0), sizes 1|1, final + 1
+        "01" "62" "10" "41"                        # @31 "a": b -> delta 1, sizes 1|0, final + 1 (final output 0)
+        "000000000001" "06" "00" "40"              # @40 "b": final output 2^40
+        "03" "01" "00" "40"                        # @44 "zzz"
+        "01" "7a" "10" "01" "01" "7a" "10" "01"    # @48 "zz", @52 "z"
+        "010d16" "7a6261" "10" "03"                # @60 root: z, b, a (last first) -> deltas 1, 13, 22
+        "0500000000000000" "3c00000000000000")     # 5 keys, root address 60
+    s = orc._crc32c(body)
+    assert image == body + ((((s >> 15) | (s << 17)) + 0xA282EAD8) & 0xFFFFFFFF).to_bytes(4, "little") == orc.fst_image(entries)
+    assert fst_map_entries(image) == entries == orc.fst_read(image)
+    assert [fst_map_get(image, k) for k in (b"ab", b"abc", b"b", b"", b"abd", b"zz", b"zzzz")] == [5, 70000, 1 << 40, None, None, None, None]
+    with pytest.raises(_lib.NidxGpuError):
+        fst_map_build([(b"b", 1), (b"a", 2)])
+    with pytest.raises(_lib.NidxGpuError):
+        fst_map_build([(b"a", 1), (b"a", 2)])
+    # images the crate's own builder would write use its two compact single-transition encodings and put outputs on the
+    # transitions (shared prefixes of the values); hand-assembled:
+    def finish(nodes, n_keys, root):
+        b = (3).to_bytes(8, "little") + bytes(8) + nodes + n_keys.to_bytes(8, "little") + root.to_bytes(8, "little")
+        c = orc._crc32c(b)
+        return b + ((((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF).to_bytes(4, "little")
+    #   "ab" -> 7, "ac" -> 300: the node behind 'a' has b (out 0) and c (out 293), both to the empty final node (address 0);
+    #   the root is a OneTrans node on the common input 'a' (index 5) with output 7
+    img = finish(bytes.fromhex("2501" "0000" "00" "00" "63" "62" "12" "02") + bytes.fromhex("07" "01" "11" "85"), 2, 29)
+    assert fst_map_entries(img) == [(b"ab", 7), (b"ac", 300)] == orc.fst_read(img)
+    assert fst_map_get(img, b"ac") == 300 and fst_map_get(img, b"a") is None
+    #   "xyz" -> 0: z = OneTrans to the empty final node, y and x = OneTransNext ("the node right below"), all common inputs
+    img = finish(bytes.fromhex("00" "10" "b6") + b"\xdd" + b"\xea", 1, 20)
+    assert fst_map_entries(img) == [(b"xyz", 0)] == orc.fst_read(img)
+    #   the same with inputs that are not in the common table (stored in the byte below the state byte, the pack sizes below it): 01 02 03 -> 9
+    img = finish(bytes.fromhex("09" "00" "11" "03" "80") + bytes.fromhex("02" "c0") + bytes.fromhex("01" "c0"), 1, 24)
+    assert fst_map_entries(img) == [(b"\x01\x02\x03", 9)] == orc.fst_read(img)
+    # random maps: both writers agree byte for byte, both readers read both; a root with all 256 first bytes (count stored as 1),
+    # nodes with more than 32 transitions (the 256-byte index), values of every width, a value of 0 on a leaf (empty node)
+    import random
+    rng = random.Random(2)
+    for trial in range(12):
+        alphabet = b"abc/xyz" if trial % 2 else bytes(range(256))
+        keys = sorted({bytes(rng.choice(alphabet) for _ in range(rng.randrange(1, 8))) for _ in range(rng.choice([0, 1, 5, 300, 3000]))})
+        ents = [(k, rng.randrange(1 << rng.randrange(1, 64)) if rng.random() < 0.9 else 0) for k in keys]
+        a, b = fst_map_build(ents), orc.fst_image(ents)
+        assert a == b and orc.fst_read(a) == ents and fst_map_entries(b) == ents
+        for k, v in ents[:50]:
+            assert fst_map_get(a, k) == v
+    # a damaged image is an error (or still a map), never a crash or an endless walk
+    good = fst_map_build([(b"key%03d" % i, i * 1000) for i in range(200)])
+    r = np.random.default_rng(5)
+    for _ in range(400):
+        b = bytearray(good)
+        for _ in range(int(r.integers(1, 4))):
+            b[int(r.integers(0, len(b)))] = int(r.integers(0, 256))
+        try:
+            fst_map_entries(bytes(b[: int(r.integers(0, len(b) + 1))] if r.random() < 0.2 else b))
+        except _lib.NidxGpuError as e:
+            assert e.code == _lib.NIDX_ERR_IO
