@@ -363,6 +363,9 @@ __device__ inline void layer_search_block(const SegDev &seg, const GraphDev &g, 
     vis_clear(vis, vis_cap);
     __syncthreads();
     int n_new = sh.ctrl[2];
+    // more entry points than k (a descent kept wider than this layer's k): every entry point is admitted and each later push
+    // pops ONE result (search.rs:256-261,289-292), so the set keeps the size the entry points gave it
+    if (n_new > k) k = n_new < 64 * EFL ? n_new : 64 * EFL;
     CandSet<EFL> cand;
     cand.init();
     if (ctl) {
