@@ -583,9 +583,13 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     // launch shape knobs (no effect on results): postings rows per window and postings per work item
     uint64_t slice_postings = BM25_SLICE_POSTINGS;
     const bool force_wide = getenv("NIDX_GPU_BM25_WIDE") != nullptr;   // every query through the general kernel (tests)
-    // NIDX_GPU_BM25_UNION: 0 = never the union kernel, 2 = every query of <= 8 plain term clauses (tests drive its slow path with it)
+    // NIDX_GPU_BM25_UNION: 0 = never a union kernel, 1 = rare-meeting unions through bm25_stream_kernel (default), 2 = every query of
+    // <= 8 plain term clauses through it (tests drive its slow paths with it); 3 / 4 = the same two with bm25_union_kernel (round 3's
+    // first union kernel, kept for comparison)
     int union_mode = 1;
     if (const char *e = getenv("NIDX_GPU_BM25_UNION")) union_mode = atoi(e);
+    const bool lockstep_union = union_mode >= 3;
+    if (lockstep_union) union_mode -= 2;
     (void)max_clauses;
     if (const char *e = getenv("NIDX_GPU_BM25_SLICE")) slice_postings = (uint64_t)std::max(256, atoi(e));
     for (uint64_t c = 0; c < n_clauses; c++) {
@@ -830,6 +834,13 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 wide_max_clauses = std::max(wide_max_clauses, nc);
             }
         }
+        if (const char *e = getenv("NIDX_GPU_BM25_SHUFFLE")) {   // (experiment: the union items in a pseudo-random order)
+            uint64_t x = 88172645463325252ull + (uint64_t)atoi(e);
+            for (uint32_t i = n_union; i > 1; i--) {
+                x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+                std::swap(item_list[i - 1], item_list[x % i]);
+            }
+        }
         // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
         std::vector<Bm25UClause> ucl(n_union ? n_clauses : 0);
         for (uint32_t q = 0; q < nq && n_union; q++) {
@@ -912,7 +923,10 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
 
         }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
-        NIDX_HIP(launch_bm25_union(a, d_items, n_union, a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr, idx->stream));
+        {
+            const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
+            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, idx->stream));
+        }
         NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, idx->stream));
         NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
         Bm25MergeArgs mg;

@@ -360,6 +360,8 @@ hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uin
                               uint32_t max_clauses, hipStream_t s);
 // term unions whose lists rarely meet (bm25_union.hip); extras = alive bitset / facet bitsets / order by a fast field / search-after
 hipError_t launch_bm25_union(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s);
+// the same queries term at a time (bm25_stream.hip): the default; launch_bm25_union stays selectable for comparison
+hipError_t launch_bm25_stream(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s);
 
 // ---- BM25 surroundings (bm25_aux.hip) ----
 // FuzzyTermQuery's automaton over the whole term dictionary: flags[t] = 1 when term t is accepted

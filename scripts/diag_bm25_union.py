@@ -16,9 +16,14 @@ vocab = 5000
 docs = zipf_corpus(rng, 60000, vocab)
 seg = Bm25Segment.from_term_docs(docs, vocab)
 rng = np.random.default_rng(1)
-queries = [[Clause(int(t)) for t in rng.integers(0, vocab, int(rng.integers(1, 6)))] for _ in range(64)]
+rng = np.random.default_rng(int(os.environ.get("DIAG_SEED", "21")))
+queries = [[Clause(int(t)) for t in rng.integers(int(os.environ.get("DIAG_LO", "200")), vocab, int(rng.integers(1, 9)))] for _ in range(48)]
+if os.environ.get("DIAG_N"):
+    queries = queries[: int(os.environ["DIAG_N"])]
+if os.environ.get("DIAG_ONE"):
+    queries = [queries[int(os.environ["DIAG_ONE"])]]
 s = Bm25Searcher.open([seg])
-k = 20
+k = int(os.environ.get("DIAG_K", "64"))
 os.environ["NIDX_GPU_BM25_UNION"] = "0"
 d0, s0, c0, t0, p0 = s.search_batch(queries, k)
 os.environ["NIDX_GPU_BM25_UNION"] = "2"
@@ -31,8 +36,8 @@ for i, q in enumerate(queries):
     nbad += 1
     if nbad > 3:
         continue
-    lists = {c.term: seg.doc_ids[seg.term_offsets[c.term]: seg.term_offsets[c.term + 1]] for c in q}
-    print("query", i, "terms", [(c.term, len(lists[c.term])) for c in q], "total", t0[i], t1[i], "postings", p0[i], p1[i])
+    lists = {j: seg.doc_ids[seg.term_offsets[c.term]: seg.term_offsets[c.term + 1]] for j, c in enumerate(q)}
+    print("query", i, "terms", [(c.term, len(lists[j])) for j, c in enumerate(q)], "total", t0[i], t1[i], "postings", p0[i], p1[i], "count", c0[i], c1[i])
     exp = {int(d): float(sc) for d, sc in zip(d0[i, : c0[i]], s0[i, : c0[i]])}
     got = {int(d): float(sc) for d, sc in zip(d1[i, : c1[i]], s1[i, : c1[i]])}
     for d in sorted(set(exp) | set(got)):

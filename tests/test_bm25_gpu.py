@@ -192,13 +192,14 @@ def test_general_kernel_on_narrow_queries(orc, corpus, monkeypatch):
     s.close()
 
 
-@pytest.mark.parametrize("union_mode", ["2", "0"])
+@pytest.mark.parametrize("union_mode", ["2", "4", "0"])
 def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeypatch, union_mode):
-    """bm25_union_kernel (postings are final unless a bitmap filter says their document may occur twice; those are resolved
-    exactly) against the oracle, on query families that make its slow path the common one: NIDX_GPU_BM25_UNION=2 sends every
-    query of <= 8 plain term clauses there — dense terms (term 0 is in nearly every document: every window overflows the
-    involved list and is cut in half), Must / MustNot / required Should groups, constant scores, negative and zero boosts,
-    k from 1 to 501, the alive bitset and the search-after cursor.  Mode 0 never uses it: the same answers from the hash kernels."""
+    """The union kernels (postings are final unless a bitmap filter says their document may occur twice; those are resolved
+    exactly) against the oracle, on query families that make their slow paths the common ones: NIDX_GPU_BM25_UNION=2 sends every
+    query of <= 8 plain term clauses through bm25_stream_kernel (4: through bm25_union_kernel) — dense terms (term 0 is in nearly
+    every document: the involved list overflows, the doc range is cut in half and retried), Must / MustNot / required Should
+    groups, constant scores, negative and zero boosts, k from 1 to 501, the alive bitset and the search-after cursor.  Mode 0 never
+    uses them: the same answers from the hash kernels."""
     seg, vocab = corpus
     rng = np.random.default_rng(21)
     monkeypatch.setenv("NIDX_GPU_BM25_UNION", union_mode)
