@@ -763,25 +763,40 @@ __global__ __launch_bounds__(256) void bm25_fast_kernel(Bm25Args a, const uint32
     }
 }
 
-// ---- per-query merge of the slices' lists (TopDocs merges its per-segment collectors the same way): one wave per
-//      query walks its work items' sorted key lists, stopping in a list at the first key below the running k-th ----
+// ---- per-query merge of the slices' lists (TopDocs merges its per-segment collectors the same way): one workgroup per query;
+//      its four waves walk the work items' sorted key lists side by side (every fourth chunk of 64 keys each, stopping short of
+//      nothing: a key below the wave's running k-th is dropped by one compare), then wave 0 folds the other three lists in ----
 template <int KL>
-__global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
+    __shared__ uint64_t part[3][64 * KL];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
     const uint32_t w0 = m.item_first[q], w1 = m.item_first[q + 1];
     const int k = (int)m.k;
     const uint32_t n_items = w1 - w0;
-    // Count / postings: every lane sums its share of the items
+    // Count / postings: every lane of wave 0 sums its share of the items
     unsigned long long total = 0, postings = 0;
-    for (uint32_t w = w0 + (uint32_t)lane; w < w1; w += 64) {
-        total += m.item_total[w];
-        postings += m.item_postings[w];
+    if (wave == 0) {
+        for (uint32_t w = w0 + (uint32_t)lane; w < w1; w += 64) {
+            total += m.item_total[w];
+            postings += m.item_postings[w];
+        }
+        total = wave_sum_u64(total);
+        postings = wave_sum_u64(postings);
     }
-    total = wave_sum_u64(total);
-    postings = wave_sum_u64(postings);
     WaveTopK<KL> top;
     top.init();
+    uint64_t kth = NIDX_EMPTY_KEY;
+    auto consume = [&](uint64_t key) {   // 64 keys, one per lane
+        unsigned long long mm = __ballot(key > kth);
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const uint64_t nk = lane_bcast_u64(key, src);
+            if (nk > kth) kth = top.insert_kth(nk, k, lane);
+        }
+    };
     if (n_items == 1) {
         // one slice: its list is the answer
         const uint32_t cnt = m.item_count[w0];
@@ -792,20 +807,24 @@ __global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
         }
     } else {
         // all the slices' keys side by side, 64 at a time: the loads of a chunk do not wait for any other list
-        uint64_t kth = NIDX_EMPTY_KEY;
         const uint32_t slots = n_items * (uint32_t)k;
-        for (uint32_t base = 0; base < slots; base += 64) {
+        for (uint32_t base = 64u * (uint32_t)wave; base < slots; base += 256) {
             const uint32_t idx = base + (uint32_t)lane;
             const uint32_t it = idx / (uint32_t)k, pos = idx - it * (uint32_t)k;
             const bool have = idx < slots && pos < m.item_count[w0 + (idx < slots ? it : 0u)];
-            const uint64_t key = have ? m.item_key[(size_t)(w0 + it) * k + pos] : NIDX_EMPTY_KEY;
-            unsigned long long mm = __ballot(key > kth);
-            while (mm) {
-                const int src = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const uint64_t nk = lane_bcast_u64(key, src);
-                if (nk > kth) kth = top.insert_kth(nk, k, lane);
-            }
+            consume(have ? m.item_key[(size_t)(w0 + it) * k + pos] : NIDX_EMPTY_KEY);
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < KL; i++) part[wave - 1][64 * i + lane] = top.l[i].key;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (n_items > 1) {
+        for (int w = 0; w < 3; w++) {
+#pragma unroll
+            for (int i = 0; i < KL; i++) consume(part[w][64 * i + lane]);
         }
     }
     uint32_t cnt = 0;
@@ -829,9 +848,9 @@ __global__ __launch_bounds__(64) void bm25_merge_kernel(Bm25MergeArgs m) {
 
 hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s) {
     if (n_queries == 0) return hipSuccess;
-    if (m.k > 256) hipLaunchKernelGGL(bm25_merge_kernel<8>, dim3(n_queries), dim3(64), 0, s, m);
-    else if (m.k > 64) hipLaunchKernelGGL(bm25_merge_kernel<4>, dim3(n_queries), dim3(64), 0, s, m);
-    else hipLaunchKernelGGL(bm25_merge_kernel<1>, dim3(n_queries), dim3(64), 0, s, m);
+    if (m.k > 256) hipLaunchKernelGGL(bm25_merge_kernel<8>, dim3(n_queries), dim3(256), 0, s, m);
+    else if (m.k > 64) hipLaunchKernelGGL(bm25_merge_kernel<4>, dim3(n_queries), dim3(256), 0, s, m);
+    else hipLaunchKernelGGL(bm25_merge_kernel<1>, dim3(n_queries), dim3(256), 0, s, m);
     return hipGetLastError();
 }
 
