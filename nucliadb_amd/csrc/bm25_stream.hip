@@ -102,7 +102,8 @@ __device__ inline uint64_t bs_merge64(uint64_t top, uint64_t v) {
     return bs_merge_steps<32>(m);
 }
 
-template <int KL, bool EXTRAS>
+// DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
+template <int KL, bool EXTRAS, bool DBG>
 __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
     __shared__ float tf_cache[256];          // K1 * (1 - B + B * fieldnorm / avg)
     __shared__ float inv1[256];              // 1 / (1 + tf_cache): the tf == 1 quotient, the same two f32 operations as the general form
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
     __shared__ uint64_t cand_all[4][BS_CAND];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long cy_entry = a.dbg ? clock64() : 0;
+    const unsigned long long cy_entry = DBG ? clock64() : 0;
     uint32_t *bm_a = bm_a_all[wave];
     uint32_t *bm_b = bm_b_all[wave];
     uint32_t *list_doc = list_doc_all[wave];
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
     uint32_t postings = 0, total = 0, n_ranges = 0;
     uint32_t cur_lo = lo_doc, cur_hi = hi_doc;
     uint32_t e_l = item_e_l;
-    const unsigned long long cy_t0 = a.dbg ? clock64() : 0;
+    const unsigned long long cy_t0 = DBG ? clock64() : 0;
     unsigned long long cy_p1 = 0, cy_p2 = 0, cy_p3 = 0, cy_p4 = 0;
     bool dirty = false;   // the bitmaps hold bits
     for (;;) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 bs_lds_order();
                 dirty = false;
             }
-            const unsigned long long cw0 = a.dbg ? clock64() : 0;
+            const unsigned long long cw0 = DBG ? clock64() : 0;
             // the longest clause (lowest index on ties)
             uint32_t best = n_l;
             best = wave_reduce_u32(best, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 const uint32_t s = bs_rl(s_l, L);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    dn[r] = (doc_ids + base)[s + 64u * r + (uint32_t)lane];
-                    wn[r] = (tfs + base)[s + 64u * r + (uint32_t)lane];
+                    dn[r] = (doc_ids + base + s)[64u * r + (uint32_t)lane];
+                    wn[r] = (tfs + base + s)[64u * r + (uint32_t)lane];
                 }
             }
             uint32_t matched = 0, posted = 0, n_short = 0, n_long = 0;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                     for (uint32_t p = s; p < e; p += 256u) {
                         uint32_t d[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) d[r] = ip[p + 64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
+                        for (int r = 0; r < 4; r++) d[r] = (ip + p)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             if (p + 64u * r >= e) break;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 }
                 bs_lds_order();
             }
-            const unsigned long long cw1 = a.dbg ? clock64() : 0;
+            const unsigned long long cw1 = DBG ? clock64() : 0;
             unsigned long long cw2 = cw1;
             // ---- phases 2 and 3: the longest clause, then the others in clause order ----
             uint32_t todo_m = probe ? (act_m & ~(1u << L)) : 0u;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                     c = __ffs((int)todo_m) - 1;
                     todo_m &= todo_m - 1u;
                 }
-                if (step == 1 && a.dbg) cw2 = clock64();
+                if (DBG && step == 1) cw2 = clock64();
                 const bool is_long = step == 0;
                 const unsigned long long base = ((unsigned long long)bs_rl((uint32_t)(b_l >> 32), c) << 32) | bs_rl((uint32_t)b_l, c);
                 const uint32_t s = bs_rl(s_l, c), e = bs_rl(e_l, c);
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 if (!is_long) {   // (L's first rows have been in flight since before phase 1)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        dn[r] = ip[s + 64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
-                        wn[r] = wp[s + 64u * r + (uint32_t)lane];
+                        dn[r] = (ip + s)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
+                        wn[r] = (wp + s)[64u * r + (uint32_t)lane];
                     }
                 }
                 for (uint32_t p = s; p < e && !overflow; p += 256u) {
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                     if (p + 256u < e) {   // the next four rows travel while these are scored
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            dn[r] = ip[p + 256u + 64u * r + (uint32_t)lane];
-                            wn[r] = wp[p + 256u + 64u * r + (uint32_t)lane];
+                            dn[r] = (ip + p)[256u + 64u * r + (uint32_t)lane];
+                            wn[r] = (wp + p)[256u + 64u * r + (uint32_t)lane];
                         }
                     }
 #pragma unroll
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 if (!is_long && lane == c) run_lo_l = run_lo, run_hi_l = n_short;
                 if (is_long) bs_lds_order();   // B is complete before phase 3 reads it
             }
-            const unsigned long long cw3 = a.dbg ? clock64() : 0;
+            const unsigned long long cw3 = DBG ? clock64() : 0;
             if (overflow) {
                 // halve the doc range (>= 1 document stays: one document has at most 8 postings) and retry it; the candidates offered so
                 // far are all final ones (the involved postings were not resolved yet), they will be offered again
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                 }
                 bs_lds_order();
             }
-            if (a.dbg) {
+            if constexpr (DBG) {
                 const unsigned long long cw4 = clock64();
                 cy_p1 += cw1 - cw0, cy_p2 += cw2 - cw1, cy_p3 += cw3 - cw2, cy_p4 += cw4 - cw3;
             }
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
     if (KL == 1) {
         while (n_cand) flush64();
     }
-    if (a.dbg && lane == 0) {
+    if (DBG && lane == 0) {
         // (no shared counters here: thousands of atomics on one cache line stall the memory channel that owns it for everyone)
         // per-item trace: cycles entry -> exit, cycles before the first range, ranges | flushes, postings, cycles of the four phases
         const unsigned long long t_exit = clock64();
@@ -601,15 +602,21 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
 hipError_t launch_bm25_stream(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s) {
     if (n_items == 0) return hipSuccess;
     const dim3 grid((n_items + 3) / 4), block(256);
-#define NIDX_BS_LAUNCH(KL)                                                                                      \
-    do {                                                                                                        \
-        if (extras) hipLaunchKernelGGL((bm25_stream_kernel<KL, true>), grid, block, 0, s, a, items, n_items);   \
-        else hipLaunchKernelGGL((bm25_stream_kernel<KL, false>), grid, block, 0, s, a, items, n_items);         \
+#define NIDX_BS_LAUNCH2(KL, EX)                                                                                        \
+    do {                                                                                                            \
+        if (a.dbg) hipLaunchKernelGGL((bm25_stream_kernel<KL, EX, true>), grid, block, 0, s, a, items, n_items);    \
+        else hipLaunchKernelGGL((bm25_stream_kernel<KL, EX, false>), grid, block, 0, s, a, items, n_items);         \
+    } while (0)
+#define NIDX_BS_LAUNCH(KL)                  \
+    do {                                    \
+        if (extras) NIDX_BS_LAUNCH2(KL, true); \
+        else NIDX_BS_LAUNCH2(KL, false);    \
     } while (0)
     if (a.k > 256) NIDX_BS_LAUNCH(8);
     else if (a.k > 64) NIDX_BS_LAUNCH(4);
     else NIDX_BS_LAUNCH(1);
 #undef NIDX_BS_LAUNCH
+#undef NIDX_BS_LAUNCH2
     return hipGetLastError();
 }
 
