@@ -463,7 +463,9 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                             offer(ck, ok);
                         } else {
                             matched += (uint32_t)__popcll(__ballot(ok));
-                            offer(rank_key(sc, d[r]), ok);
+                            // most rows hold nothing the list wants once it is full: one float compare before any key is built (the k-th
+                            // score is NaN while the list is not full: !(s < NaN) lets every score through to the exact test)
+                            if (__ballot(ok && !(sc < rank_key_score(kth)))) offer(rank_key(sc, d[r]), ok);
                         }
                         if (KL == 1 && r == 1) {   // the buffer holds what two rows can add on top of 63 left-overs
                             while (n_cand >= 64u) flush64();

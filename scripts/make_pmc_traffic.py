@@ -34,7 +34,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     f = os.path.join(ROOT, "gpurun_out", "pmc_bm25", "traffic_%s.txt" % counter)
     if os.path.exists(f):
         for line in open(f):
-            m = re.match(r"void nidx::(bm25_(?:union|fast)_kernel<[^>]*>).*\| %s \| (\d+) \| ([0-9.]+) \|" % counter, line)
+            m = re.match(r"void nidx::(bm25_(?:stream|union|fast)_kernel<[^>]*>).*\| %s \| (\d+) \| ([0-9.]+) \|" % counter, line)
             if m:
                 bvals[counter] = (float(m.group(3)), int(m.group(2)), m.group(1))
 if "FETCH_SIZE" in bvals:
