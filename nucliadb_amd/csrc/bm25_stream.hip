@@ -499,7 +499,43 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
             // ---- phase 4: the involved postings, clause by clause, through a hash table over the bitmaps' space ----
             bs_lds_order();
             const uint32_t n_inv = n_short + n_long;
-            if (n_inv) {
+            if (n_inv && n_inv <= 32u) {
+                // few involved postings (the usual case): one per lane, in clause order, compared through the scalar unit — lane i learns
+                // its document's sum (built in lane = clause order) and mask from lanes 0 .. n_inv-1; the first lane of a document owns it
+                uint32_t src = 0, my_c = 0, off = 0;
+                for (int c = 0; c < C; c++) {
+                    const bool is_l = c == L;
+                    const uint32_t lo = is_l ? 0u : bs_rl(run_lo_l, c), len = is_l ? n_long : bs_rl(run_hi_l, c) - lo;
+                    const uint32_t i = (uint32_t)lane - off;
+                    if ((uint32_t)lane >= off && i < len) {
+                        src = is_l ? BS_CAP - 1u - i : lo + i;
+                        my_c = (uint32_t)c;
+                    }
+                    off += len;
+                }
+                const bool live = (uint32_t)lane < n_inv;
+                const uint32_t my_doc = list_doc[live ? src : 0u];
+                const uint32_t my_sc = list_score[live ? src : 0u];
+                const uint32_t my_adds = (__builtin_amdgcn_ds_bpermute((int)(my_c << 2), (int)attr_l) & 0xff) != 2 ? 1u : 0u;   // a MustNot clause adds nothing
+                float acc = 0.f;
+                uint32_t mask = 0;
+                bool owner = live;
+                for (uint32_t j = 0; j < n_inv; j++) {
+                    const uint32_t dj = bs_rl(my_doc, (int)j), cj = bs_rl(my_c, (int)j);
+                    const float sj = __uint_as_float(bs_rl(my_sc, (int)j));
+                    const bool same = dj == my_doc;
+                    if (same && bs_rl(my_adds, (int)j)) acc += sj;
+                    if (same) mask |= 1u << cj;
+                    if (same && j < (uint32_t)lane) owner = false;
+                }
+                bool ok = owner && mask_ok(mask);
+                const uint64_t ck = finish(ok, my_doc, acc);
+                matched += (uint32_t)__popcll(__ballot(ok));
+                offer(ck, ok);
+                if (KL == 1) {
+                    while (n_cand >= 64u) flush64();
+                }
+            } else if (n_inv) {
                 uint32_t *t_doc = bm_a, *t_acc = bm_a + 512;
                 // the masks live in the top third of the candidate buffer: fewer than 128 candidates are buffered while this phase runs
                 uint8_t *t_mask = reinterpret_cast<uint8_t *>(cand + 128);
