@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -97,6 +98,7 @@ struct Bm25Index {
     std::vector<Bm25Segment> segs;
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
+    std::vector<float> idf_of_term;   // Bm25Weight's idf per term over all segments, filled on first use (NaN = not yet)
     DevBuf tf_cache;
     DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
@@ -503,6 +505,7 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
 static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                   uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
                                   uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
+    const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     NIDX_HIP(hipSetDevice(idx->device));
     const uint32_t k = opt->k;
     const nidx_gpu_bm25_search_after_t *after = opt->after;
@@ -622,9 +625,17 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             continue;
         }
         if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
-        uint64_t df = 0;
-        for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
-        float w = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
+        float w = cl.boost;
+        if (cl.mode != NIDX_CONST_SCORE) {
+            if (idx->idf_of_term.size() != idx->n_terms) idx->idf_of_term.assign(idx->n_terms, std::numeric_limits<float>::quiet_NaN());
+            float idf = idx->idf_of_term[cl.term];
+            if (idf != idf) {
+                uint64_t df = 0;
+                for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
+                idf = idx->idf_of_term[cl.term] = bm25_idf(df, idx->total_docs);
+            }
+            w = idf * (1.0f + kK1) * cl.boost;
+        }
         dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, cl.mode, w};
     }
     const uint32_t kk = std::max<uint32_t>(k, 1);
@@ -785,60 +796,55 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             if (cl.term & NIDX_BM25_SUBQUERY) return set_counts[n_sets + n_phrases + (cl.term & ~NIDX_BM25_SUBQUERY)];
             return seg.term_offsets_host[cl.term + 1] - seg.term_offsets_host[cl.term];
         };
-        // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings
+        // work list: every query cut into doc-id slices of ~BM25_SLICE_POSTINGS postings.  Three launches over disjoint item lists: term
+        // unions whose lists rarely meet (bm25_stream.hip), the other narrow queries (bm25_fast_kernel), the rest (bm25_rows_kernel).  A
+        // query is a "rare-meeting union" when it has at most 8 plain term clauses and the number of documents two of its lists are
+        // expected to share (independent lists: len_a * len_b / n_docs, summed over the pairs) is at most 1/8 of its postings — the union
+        // kernels are exact for any input, that bound only keeps their slow paths rare.
         const double t_w0 = now_us();
         work.clear();
         std::vector<uint32_t> item_first(nq + 1, 0);
+        std::vector<uint8_t> q_union(nq, 0);
+        const double inv_docs = 1.0 / std::max<double>(1.0, (double)seg.n_docs);
         for (uint32_t q = 0; q < nq; q++) {
             item_first[q] = (uint32_t)work.size();
+            const uint64_t c0 = clause_offsets[q], c1 = clause_offsets[q + 1];
             uint64_t p = 0;
-            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) p += postings_of(clauses[c]);
-            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
-            for (uint32_t sl = 0; sl < slices; sl++)
-                work.push_back(Bm25Work{q, sl, slices, (uint32_t)clause_offsets[q], (uint32_t)(clause_offsets[q + 1] - clause_offsets[q])});
+            bool plain = true;
+            double sum_sq = 0.0;
+            for (uint64_t c = c0; c < c1; c++) {
+                const uint64_t l = postings_of(clauses[c]);
+                p += l;
+                sum_sq += (double)l * (double)l;
+                if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
+            }
+            if (union_mode != 0 && plain && c1 > c0 && c1 - c0 <= BM25_FAST_CLAUSES && !force_wide) {
+                const double sum = (double)p, shared = (sum * sum - sum_sq) * 0.5 * inv_docs;
+                q_union[q] = (union_mode == 2 || shared * 8.0 <= sum) ? 1 : 0;
+            }
+            const uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
+            const Bm25Work w{q, 0, slices, (uint32_t)c0, (uint32_t)(c1 - c0)};
+            work.resize(work.size() + slices, w);
+            Bm25Work *wp = work.data() + work.size() - slices;
+            for (uint32_t sl = 1; sl < slices; sl++) wp[sl].slice = sl;
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
-        // three launches over disjoint item lists: term unions whose lists rarely meet (bm25_union.hip), the other narrow queries
-        // (bm25_fast_kernel), the rest (bm25_rows_kernel).  A query is a "rare-meeting union" when it has at most 8 plain term clauses
-        // and the number of documents two of its lists are expected to share (independent lists: len_a * len_b / n_docs, summed over
-        // the pairs) is at most 1/8 of its postings — the union kernel is exact for any input, that bound only keeps its slow path rare.
-        std::vector<uint8_t> q_union(nq, 0);
-        for (uint32_t q = 0; q < nq && union_mode != 0; q++) {
-            const uint64_t c0 = clause_offsets[q], c1 = clause_offsets[q + 1];
-            if (c1 - c0 == 0 || c1 - c0 > BM25_FAST_CLAUSES || force_wide) continue;
-            bool plain = true;
-            double sum = 0.0, sum_sq = 0.0;
-            for (uint64_t c = c0; c < c1; c++) {
-                if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
-                const double l = (double)postings_of(clauses[c]);
-                sum += l;
-                sum_sq += l * l;
-            }
-            if (!plain) continue;
-            const double shared = (sum * sum - sum_sq) / 2.0 / std::max<double>(1.0, (double)seg.n_docs);
-            q_union[q] = (union_mode == 2 || shared * 8.0 <= sum) ? 1 : 0;
-        }
         std::vector<uint32_t> item_list(nw);
         uint32_t n_union = 0, n_fast = 0, n_wide = 0, wide_max_clauses = 0;
         for (size_t w = 0; w < nw; w++)
             if (q_union[work[w].query]) item_list[n_union++] = (uint32_t)w;
-        for (size_t w = 0; w < nw; w++) {
-            const uint32_t nc = work[w].n_clauses;
-            if (!q_union[work[w].query] && nc <= BM25_FAST_CLAUSES && !force_wide) item_list[n_union + n_fast++] = (uint32_t)w;
-        }
-        for (size_t w = 0; w < nw; w++) {
-            const uint32_t nc = work[w].n_clauses;
-            if (!q_union[work[w].query] && !(nc <= BM25_FAST_CLAUSES && !force_wide)) {
-                item_list[n_union + n_fast + n_wide++] = (uint32_t)w;
-                wide_max_clauses = std::max(wide_max_clauses, nc);
+        if (n_union < nw) {
+            for (size_t w = 0; w < nw; w++) {
+                const uint32_t nc = work[w].n_clauses;
+                if (!q_union[work[w].query] && nc <= BM25_FAST_CLAUSES && !force_wide) item_list[n_union + n_fast++] = (uint32_t)w;
             }
-        }
-        if (const char *e = getenv("NIDX_GPU_BM25_SHUFFLE")) {   // (experiment: the union items in a pseudo-random order)
-            uint64_t x = 88172645463325252ull + (uint64_t)atoi(e);
-            for (uint32_t i = n_union; i > 1; i--) {
-                x ^= x << 13, x ^= x >> 7, x ^= x << 17;
-                std::swap(item_list[i - 1], item_list[x % i]);
+            for (size_t w = 0; w < nw; w++) {
+                const uint32_t nc = work[w].n_clauses;
+                if (!q_union[work[w].query] && !(nc <= BM25_FAST_CLAUSES && !force_wide)) {
+                    item_list[n_union + n_fast + n_wide++] = (uint32_t)w;
+                    wide_max_clauses = std::max(wide_max_clauses, nc);
+                }
             }
         }
         // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
@@ -1073,8 +1079,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         }
     }
     if (host_dbg)
-        fprintf(stderr, "[bm25 host] total=%.0f us: work list=%.0f sync wait=%.0f collect=%.0f merge=%.0f\n", now_us() - t_begin, t_work, t_sync,
-                t_collect, now_us() - t_merge0);
+        fprintf(stderr, "[bm25 host] total=%.0f us: clauses=%.0f work list=%.0f sync wait=%.0f collect=%.0f merge=%.0f\n", now_us() - t_entry, t_begin - t_entry,
+                t_work, t_sync, t_collect, now_us() - t_merge0);
     return NIDX_OK;
 }
 
