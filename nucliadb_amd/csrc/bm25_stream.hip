@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
             // ---- phase 4: the involved postings, clause by clause, through a hash table over the bitmaps' space ----
             bs_lds_order();
             const uint32_t n_inv = n_short + n_long;
-            if (n_inv && n_inv <= 32u) {
+            if (n_inv && n_inv <= 64u) {
                 // few involved postings (the usual case): one per lane, in clause order, compared through the scalar unit — lane i learns
                 // its document's sum (built in lane = clause order) and mask from lanes 0 .. n_inv-1; the first lane of a document owns it
                 uint32_t src = 0, my_c = 0, off = 0;
