@@ -99,6 +99,10 @@ struct Bm25Index {
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
     std::vector<float> idf_of_term;   // Bm25Weight's idf per term over all segments, filled on first use (NaN = not yet)
+    // host scratch of a search call (kept for their capacity)
+    std::vector<uint32_t> w_item_first, w_item_list;
+    std::vector<Bm25Work> w_work;
+    std::vector<uint8_t> w_q_union;
     DevBuf tf_cache;
     DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
@@ -691,7 +695,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     double t_work = 0, t_sync = 0, t_collect = 0;
     struct Hit { float score; uint64_t docaddr; int64_t value; };
     std::vector<std::vector<Hit>> merged(idx->segs.size() == 1 ? 0 : nq);
-    std::vector<Bm25Work> work;
+    std::vector<Bm25Work> &work = idx->w_work;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
         // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
@@ -803,8 +807,10 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         // kernels are exact for any input, that bound only keeps their slow paths rare.
         const double t_w0 = now_us();
         work.clear();
-        std::vector<uint32_t> item_first(nq + 1, 0);
-        std::vector<uint8_t> q_union(nq, 0);
+        std::vector<uint32_t> &item_first = idx->w_item_first;
+        std::vector<uint8_t> &q_union = idx->w_q_union;
+        item_first.assign(nq + 1, 0);
+        q_union.assign(nq, 0);
         const double inv_docs = 1.0 / std::max<double>(1.0, (double)seg.n_docs);
         for (uint32_t q = 0; q < nq; q++) {
             item_first[q] = (uint32_t)work.size();
@@ -820,7 +826,11 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             }
             if (union_mode != 0 && plain && c1 > c0 && c1 - c0 <= BM25_FAST_CLAUSES && !force_wide) {
                 const double sum = (double)p, shared = (sum * sum - sum_sq) * 0.5 * inv_docs;
-                q_union[q] = (union_mode == 2 || shared * 8.0 <= sum) ? 1 : 0;
+                bool repeated = false;   // the same term twice: its lists meet in every document (the estimate above assumes independent lists)
+                for (uint64_t c = c0; c < c1 && !repeated; c++)
+                    for (uint64_t e = c + 1; e < c1; e++)
+                        if (clauses[c].term == clauses[e].term) repeated = true;
+                q_union[q] = (union_mode == 2 || (shared * 8.0 <= sum && !repeated)) ? 1 : 0;
             }
             const uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
             const Bm25Work w{q, 0, slices, (uint32_t)c0, (uint32_t)(c1 - c0)};
@@ -830,7 +840,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
-        std::vector<uint32_t> item_list(nw);
+        std::vector<uint32_t> &item_list = idx->w_item_list;
+        item_list.resize(nw);
         uint32_t n_union = 0, n_fast = 0, n_wide = 0, wide_max_clauses = 0;
         for (size_t w = 0; w < nw; w++)
             if (q_union[work[w].query]) item_list[n_union++] = (uint32_t)w;
@@ -1125,8 +1136,9 @@ int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu
     slot->nq = nq, slot->k = k;
     // outputs of a request that runs synchronously inside this call
     const size_t kk1 = std::max<uint32_t>(k, 1);
-    slot->r_docaddr.assign((size_t)nq * kk1, 0), slot->r_score.assign((size_t)nq * kk1, 0.f);
-    slot->r_count.assign(nq, 0), slot->r_total.assign(nq, 0), slot->r_postings.assign(nq, 0);
+    // (resize, not assign: the search zeroes the counts itself and nothing is read beyond a query's count)
+    slot->r_docaddr.resize((size_t)nq * kk1), slot->r_score.resize((size_t)nq * kk1);
+    slot->r_count.resize(nq), slot->r_total.resize(nq), slot->r_postings.resize(nq);
     idx->swap_slot(*slot);
     idx->async_slot = slot;
     const int32_t rc = bm25_search_locked(idx, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
