@@ -824,15 +824,21 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 sum_sq += (double)l * (double)l;
                 if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
             }
+            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
             if (union_mode != 0 && plain && c1 > c0 && c1 - c0 <= BM25_FAST_CLAUSES && !force_wide) {
                 const double sum = (double)p, shared = (sum * sum - sum_sq) * 0.5 * inv_docs;
-                bool repeated = false;   // the same term twice: its lists meet in every document (the estimate above assumes independent lists)
-                for (uint64_t c = c0; c < c1 && !repeated; c++)
+                // the same term twice: those two lists meet in every document (the estimate above assumes independent lists)
+                double repeated = 0.0;
+                for (uint64_t c = c0; c < c1; c++)
                     for (uint64_t e = c + 1; e < c1; e++)
-                        if (clauses[c].term == clauses[e].term) repeated = true;
-                q_union[q] = (union_mode == 2 || (shared * 8.0 <= sum && !repeated)) ? 1 : 0;
+                        if (clauses[c].term == clauses[e].term) repeated += (double)postings_of(clauses[c]);
+                // the stream kernel resolves up to 192 involved postings per item without cutting its doc range: enough slices to keep
+                // the expected number (two postings per meeting) around 96
+                const double want = std::ceil((shared + repeated) * 2.0 / 96.0);
+                if (union_mode == 2) q_union[q] = 1;
+                else if (shared * 8.0 <= sum && want <= (double)BM25_MAX_SLICES) q_union[q] = 1;
+                if (q_union[q] && !lockstep_union) slices = (uint32_t)std::min<double>(BM25_MAX_SLICES, std::max<double>(slices, want));
             }
-            const uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
             const Bm25Work w{q, 0, slices, (uint32_t)c0, (uint32_t)(c1 - c0)};
             work.resize(work.size() + slices, w);
             Bm25Work *wp = work.data() + work.size() - slices;
