@@ -389,7 +389,11 @@ int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uin
  * paragraph.rs:68-103).  nidx_gpu_segment_dir_write / _merge write the three files (NIDX_GPU_SEGMENT_DIR_FST=0 in the
  * environment: neither written nor read — the reference then regenerates them on open).  The two containers are
  * third-party formats (fst 0.4.7, stream-vbyte 0.4.1) restated without the crates at hand: see fst_index.cpp.
- * DataStoreV1 directories (nodes.kv) are refused with NIDX_ERR_UNSUPPORTED. */
+ * A pre-migration directory — nodes.kv (DataStoreV1, data_store/v1.rs) and index.hnsw (DiskHnswV1, hnsw/disk/v1.rs), what
+ * segment::open takes first when nodes.kv exists (segment.rs:41-57) and open_disk_hnsw falls back to (hnsw/disk.rs:25-32) —
+ * is migrated in memory at open: its records and graph are re-laid out as the vectors.bin / paragraphs.bin / paragraphs.pos /
+ * hnsw.graph / hnsw.edges images of the same segment (one vector per paragraph), and everything below behaves as if those
+ * files had been mapped; nidx_gpu_segment_dir_merge therefore writes the current formats from it (segment.rs:117-128). */
 typedef struct nidx_gpu_segment_dir nidx_gpu_segment_dir_t;
 int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu_segment_dir_t **dir_out);
 void nidx_gpu_segment_dir_close(nidx_gpu_segment_dir_t *dir);

@@ -8,6 +8,8 @@
 //
 //   field.fst / label.fst / index.map   inverted_index/{fst_index.rs,map.rs,paragraph.rs}   fst_index.cpp
 //
+//   nodes.kv / index.hnsw   data_store/v1.rs, hnsw/disk/v1.rs (pre-migration segments)   segment_v1.cpp: migrated in memory at open
+//
 // The files are mmap'd and handed to nidx_gpu_vector_open without a copy.  The inverted indexes are read from their three
 // files when index.map is there (InvertedIndexes::exists, inverted_index.rs:57-60) and every list they hold passes the
 // checks below; otherwise — like segment::open when they are missing (segment.rs:49-67) — the posting lists are rebuilt
@@ -35,6 +37,7 @@
 #include "../../include/nidx_gpu.h"
 #include "fst_index.h"
 #include "host_common.h"
+#include "segment_v1.h"
 
 namespace nidx {
 namespace {
@@ -43,8 +46,16 @@ struct MappedFile {
     const uint8_t *p = nullptr;
     size_t len = 0;
     bool present = false;
+    std::vector<uint8_t> owned;   // an image produced in memory instead of a mapped file (segment_v1.cpp)
     ~MappedFile() {
-        if (p && len) munmap(const_cast<uint8_t *>(p), len);
+        if (p && len && owned.empty()) munmap(const_cast<uint8_t *>(p), len);
+    }
+    void adopt(std::vector<uint8_t> &&bytes) {
+        owned = std::move(bytes);
+        if (owned.empty()) owned.push_back(0), len = 0;   // (keeps `owned` non-empty: nothing to unmap)
+        else len = owned.size();
+        p = owned.data();
+        present = true;
     }
     // 0 = ok, 1 = missing, -1 = error
     int open(const std::string &path) {
@@ -203,6 +214,7 @@ struct SegmentDir {
     std::vector<uint32_t> list_ids;
     uint32_t n_label_lists = 0;  // the "F" lists come first ('F' < 'L')
     bool lists_from_files = false;
+    bool from_v1 = false;   // nodes.kv: the stores above are images made at open, not mapped files
 };
 
 namespace {
@@ -246,16 +258,42 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
     std::unique_ptr<SegmentDir> d(new SegmentDir());
     d->dimension = dimension;
     const std::string base = std::string(path) + "/";
-    {   // DataStoreV1 (nodes.kv, data_store/v1.rs:89-93) is the pre-migration format: not read here
-        MappedFile v1;
-        if (v1.open(base + "nodes.kv") == 0) return fail(NIDX_ERR_UNSUPPORTED, "%s holds a DataStoreV1 segment (nodes.kv)", path);
+    MappedFile v1_nodes;
+    const int v1_state = v1_nodes.open(base + "nodes.kv");
+    if (v1_state < 0) return fail(NIDX_ERR_IO, "cannot read %snodes.kv", base.c_str());
+    if (v1_state == 0) {
+        // DataStoreV1::exists (data_store/v1.rs:89-91, segment.rs:41-57): a pre-migration segment.  Its records are re-laid out in
+        // memory as vectors.bin / paragraphs.bin / paragraphs.pos (what segment::merge would write from it, segment.rs:117-128)
+        std::vector<uint8_t> vb, pb, pp;
+        std::string err;
+        if (migrate_nodes_kv(v1_nodes.p, v1_nodes.len, dimension, vb, pb, pp, err)) return fail(NIDX_ERR_IO, "%s%s", base.c_str(), err.c_str());
+        d->vectors.adopt(std::move(vb)), d->para_data.adopt(std::move(pb)), d->para_pos.adopt(std::move(pp));
+        d->from_v1 = true;
+    } else {
+        if (d->vectors.open(base + "vectors.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %svectors.bin", base.c_str());
+        if (d->para_data.open(base + "paragraphs.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.bin", base.c_str());
+        if (d->para_pos.open(base + "paragraphs.pos") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.pos", base.c_str());
+        if (d->quant.open(base + "vectors.quant") < 0) return fail(NIDX_ERR_IO, "cannot read %svectors.quant", base.c_str());
     }
-    if (d->vectors.open(base + "vectors.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %svectors.bin", base.c_str());
-    if (d->para_data.open(base + "paragraphs.bin") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.bin", base.c_str());
-    if (d->para_pos.open(base + "paragraphs.pos") != 0) return fail(NIDX_ERR_IO, "cannot open %sparagraphs.pos", base.c_str());
-    if (d->quant.open(base + "vectors.quant") < 0) return fail(NIDX_ERR_IO, "cannot read %svectors.quant", base.c_str());
+    // open_disk_hnsw (hnsw/disk.rs:25-32): the current format first, then DiskHnswV1's index.hnsw
     if (d->graph.open(base + "hnsw.graph") < 0) return fail(NIDX_ERR_IO, "cannot read %shnsw.graph", base.c_str());
     if (d->edges.open(base + "hnsw.edges") < 0) return fail(NIDX_ERR_IO, "cannot read %shnsw.edges", base.c_str());
+    if (!d->graph.present) {
+        MappedFile v1_graph;
+        const int gs = v1_graph.open(base + "index.hnsw");
+        if (gs < 0) return fail(NIDX_ERR_IO, "cannot read %sindex.hnsw", base.c_str());
+        if (gs == 0) {
+            const uint64_t stride = (uint64_t)dimension * 4 + 4;
+            if (d->vectors.len % stride) return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "vectors.bin (%zu bytes) is not a multiple of %llu-byte records", d->vectors.len, (unsigned long long)stride);
+            std::vector<uint8_t> gb;
+            std::vector<float> ew;
+            std::string err;
+            if (migrate_index_hnsw(v1_graph.p, v1_graph.len, (uint32_t)(d->vectors.len / stride), gb, ew, err)) return fail(NIDX_ERR_IO, "%s%s", base.c_str(), err.c_str());
+            std::vector<uint8_t> eb(ew.size() * 4);
+            if (!ew.empty()) memcpy(eb.data(), ew.data(), eb.size());
+            d->graph.adopt(std::move(gb)), d->edges.adopt(std::move(eb));
+        }
+    }
     // vector_alignment(DenseF32) == 4 == U32_LEN: no padding after the trailer (vector_store.rs:35-41)
     d->row_stride = (uint64_t)dimension * 4 + 4;
     if (d->vectors.len % d->row_stride) return fail(NIDX_ERR_INCONSISTENT_DIMENSIONS, "vectors.bin (%zu bytes) is not a multiple of %llu-byte records", d->vectors.len, (unsigned long long)d->row_stride);

@@ -1109,6 +1109,112 @@ def segment_dir_index_files(keys, labels):
     return {"field.fst": images[0], "label.fst": images[1], "index.map": index_map}
 
 
+# ---- pre-migration segment files: nodes.kv (DataStoreV1) and index.hnsw (DiskHnswV1) ------------------------------------------------
+# Restated from the reference's serialisers (test-only code there now): nidx_vector/src/data_store/v1/{store,node,trie,trie_ram}.rs and
+# hnsw/disk/v1.rs.  No bytes of either format exist in the reference tree: PARITY UNPINNED beyond the layouts.
+def label_trie_bytes(labels) -> bytes:
+    """trie_ram::create_trie over the SORTED labels (Elem::serialize_into sorts them, v1.rs:147-150) + trie::serialize_into (trie.rs:29-60):
+    [len u64] then per trie node [is_final u8][n_edges u64]{[byte u8][target u64]} and one u64 per node in reverse order = its record's offset."""
+    nodes = [[False, {}]]   # (is_final, {byte: node})
+    for lab in sorted(l.encode() if isinstance(l, str) else bytes(l) for l in labels):
+        at = 0
+        for b in lab:
+            nxt = nodes[at][1].get(b)
+            if nxt is None:
+                nxt = len(nodes)
+                nodes.append([False, {}])
+                nodes[at][1][b] = nxt
+            at = nxt
+        nodes[at][0] = True
+    body, offsets, off = b"", [], 8
+    for is_final, table in nodes:
+        offsets.append(off)
+        rec = bytes([1 if is_final else 0]) + len(table).to_bytes(8, "little")
+        for b, t in table.items():   # (the reference iterates a HashMap: any order is a valid file)
+            rec += bytes([b]) + t.to_bytes(8, "little")
+        body += rec
+        off += len(rec)
+    index = b"".join(o.to_bytes(8, "little") for o in reversed(offsets))
+    total = 8 + len(body) + len(index)
+    return total.to_bytes(8, "little") + body + index
+
+
+def node_v1_bytes(key, vector_bytes: bytes, labels, metadata: bytes, alignment: int = 4) -> bytes:
+    """Node::serialize_into (v1/node.rs:56-107)"""
+    k = key.encode() if isinstance(key, str) else bytes(key)
+    trie = label_trie_bytes(labels)
+    vector_start = 32 + len(metadata)
+    pad = (alignment - vector_start % alignment) % alignment
+    key_start = vector_start + len(vector_bytes) + 8 + pad
+    labels_start = key_start + len(k) + 8
+    total = 32 + pad + len(vector_bytes) + 8 + len(k) + 8 + len(trie) + len(metadata)
+    out = b"".join(v.to_bytes(8, "little") for v in (total, vector_start, key_start, labels_start)) + bytes(metadata)
+    out += len(vector_bytes).to_bytes(4, "little") + pad.to_bytes(4, "little") + bytes(pad) + vector_bytes
+    out += len(k).to_bytes(8, "little") + k + trie
+    assert len(out) == total
+    return out
+
+
+def nodes_kv_bytes(dimension, vectors, keys, labels, metadata, alignment: int = 4) -> bytes:
+    """store::create_key_value (v1/store.rs:103-141): [n u64][n slot addresses u64][slots, each at a multiple of the vector alignment]"""
+    vectors = np.ascontiguousarray(vectors, dtype="<f4").reshape(-1, dimension)
+    n = len(keys)
+    out = bytearray(n.to_bytes(8, "little") + bytes(8 * n))
+    for i in range(n):
+        if len(out) % alignment:
+            out.extend(bytes(alignment - len(out) % alignment))
+        out[8 + 8 * i: 16 + 8 * i] = len(out).to_bytes(8, "little")
+        out.extend(node_v1_bytes(keys[i], vectors[i].tobytes(), labels[i], bytes(metadata[i]), alignment))
+    return bytes(out)
+
+
+def disk_hnsw_v1_bytes(n_nodes: int, layers, entry) -> bytes:
+    """DiskHnswV1::serialize_into (hnsw/disk/v1.rs:128-200).  layers[l] = {node: [(to, weight), ...]}; entry = (node, layer).  Every node
+    writes a record for every layer of the graph; offsets are absolute."""
+    if n_nodes == 0:
+        return b""
+    out, ends = bytearray(), []
+    for node in range(n_nodes):
+        starts = []
+        for layer in layers:
+            starts.append(len(out))
+            edges = layer.get(node, [])
+            out.extend(len(edges).to_bytes(8, "little"))
+            for to, w in edges:
+                out.extend(int(to).to_bytes(8, "little") + np.float32(w).tobytes())
+        for st in reversed(starts):
+            out.extend(st.to_bytes(8, "little"))
+        ends.append(len(out))
+    for e in reversed(ends):
+        out.extend(e.to_bytes(8, "little"))
+    out.extend(int(entry[1]).to_bytes(8, "little") + int(entry[0]).to_bytes(8, "little"))
+    return bytes(out)
+
+
+def parse_hnsw_v2(graph: bytes, edges, n_nodes: int):
+    """An hnsw.graph image + hnsw.edges weights (DiskHnswV2, hnsw/disk/v2.rs:16-49) -> (layers, (entry node, entry layer)) with
+    layers[l] = {node: [(to, weight), ...]}: a node is in layer l > 0 when it has edges there, every node is in layer 0."""
+    if not graph:
+        return [], (0, 0)
+    u = lambda at: int.from_bytes(graph[at: at + 4], "little")
+    ep_layer, ep_node = u(len(graph) - 8), u(len(graph) - 4)
+    n_layers = ep_layer + 1
+    layers = [dict() for _ in range(n_layers)]
+    index_end = len(graph) - 8
+    ew, start = 0, 0
+    for node in range(n_nodes):
+        end = u(index_end - 4 * (node + 1))
+        for l in range(n_layers):
+            at = end - u(end - 4 * (l + 1))   # the layer's record starts that far in front of the node's end
+            deg = u(at)
+            es = [(u(at + 4 + 4 * e), float(edges[ew + e])) for e in range(deg)]
+            ew += deg
+            if l == 0 or deg:
+                layers[l][node] = es
+        start = end
+    return layers, (ep_node, ep_layer)
+
+
 def parse_paragraphs(data: bytes, pos: bytes):
     """-> [(key, labels, metadata, first_vector, num_vectors)] (ParagraphStore::get_paragraph, paragraph_store.rs:100-106)"""
     out = []

@@ -144,6 +144,28 @@ int main(int argc, char **argv) {
         if (nidx_gpu_index_map_read(mx, m.size(), it ? rng() % (m.size() + 8) : 0, ids.data(), 64, &n_ids) == 0) acc += n_ids;
         free(mx);
     }
+    // pre-migration directories: nodes.kv + index.hnsw mutants through the same entry point
+    uint64_t v1_accepted = 0, v1_refused = 0;
+    if (argc > 5) {
+        const std::string seed1 = argv[5], vdir = scratch + "/mutant_v1";
+        mkdir(vdir.c_str(), 0755);
+        const char *vnames[] = {"nodes.kv", "index.hnsw"};
+        std::vector<std::vector<uint8_t>> vgood;
+        for (const char *n : vnames) vgood.push_back(slurp(seed1 + "/" + n));
+        for (int it = 0; it < iters; it++) {
+            std::vector<std::vector<uint8_t>> files = vgood;
+            if (it) {
+                const int n_mut = 1 + (int)(rng() % 3);
+                for (int m = 0; m < n_mut; m++) mutate(files[rng() % 2]);
+            }
+            for (size_t i = 0; i < 2; i++) spit(vdir + "/" + vnames[i], files[i]);
+            nidx_gpu_segment_dir_t *d = nullptr;
+            const int32_t rc = nidx_gpu_segment_dir_open(vdir.c_str(), dim, &d);
+            if (rc == 0) { v1_accepted++; acc += walk(d, odir, dim); nidx_gpu_segment_dir_close(d); }
+            else { v1_refused++; if (it == 0) { fprintf(stderr, "the pre-migration seed directory was refused (%d)\n", rc); return 1; } }
+        }
+        printf("pre-migration directories: accepted %llu refused %llu\n", (unsigned long long)v1_accepted, (unsigned long long)v1_refused);
+    }
     printf("iterations %d: directories accepted %llu refused %llu (checksum %llu)\n", iters, (unsigned long long)accepted, (unsigned long long)refused,
            (unsigned long long)acc);
     return 0;

@@ -145,11 +145,12 @@ def test_errors(tmp_path):
     with pytest.raises(_lib.NidxGpuError) as e:
         SegmentDir(str(tmp_path), 8)
     assert e.value.code == _lib.NIDX_ERR_IO and "truncated" in str(e.value)
-    with open(tmp_path / "nodes.kv", "wb") as f:     # DataStoreV1
+    with open(tmp_path / "nodes.kv", "wb") as f:     # DataStoreV1 takes precedence (segment.rs:41); this one is not a store
         f.write(b"x")
     with pytest.raises(_lib.NidxGpuError) as e:
         SegmentDir(str(tmp_path), 8)
-    assert e.value.code == _lib.NIDX_ERR_UNSUPPORTED
+    assert e.value.code == _lib.NIDX_ERR_IO and "nodes.kv" in str(e.value)
+    os.remove(tmp_path / "nodes.kv")
     # vectors of one paragraph must be contiguous
     bad = VectorSegment(["a", "b"], np.ones((3, 8), np.float32), [[], []], [b"", b""], para_of_vec=np.array([0, 1, 0], np.uint32))
     with pytest.raises(_lib.NidxGpuError):
@@ -458,3 +459,129 @@ def test_fst_and_index_map_containers(orc):
             fst_map_entries(bytes(b[: int(r.integers(0, len(b) + 1))] if r.random() < 0.2 else b))
         except _lib.NidxGpuError as e:
             assert e.code == _lib.NIDX_ERR_IO
+
+
+# ---- pre-migration segments: nodes.kv (DataStoreV1) + index.hnsw (DiskHnswV1) ---------------------------------------------------
+def v1_corpus(orc, rng, n=260, d=16):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    keys = [f"{RID[i % 4]}/{'t/title' if i % 3 else 'a/body2'}/{i}-{i + 3}" for i in range(n)]
+    labels = [[f"/l/set/{i % 5}"] * (i % 3 != 0) + ["/e/x/y"] * (i % 11 == 0) + ["/l/set"] * (i % 7 == 0) for i in range(n)]
+    labels[5] = ["WORD1", "WORD2", "WORD3", "ORD1", "BAD", "GOOD"]   # the dictionary of the reference's own trie test (v1/trie.rs:113-134)
+    metadata = [bytes(rng.integers(0, 256, i % 9, dtype=np.uint8)) for i in range(n)]
+    g = orc.Segment(x, similarity=orc.SIM_DOT).build_graph(2)
+    gbytes, edges = g.serialize_v2(n)
+    return x, keys, labels, metadata, bytes(gbytes), np.asarray(edges, np.float32)
+
+
+def write_v1(orc, path, x, keys, labels, metadata, gbytes, edges):
+    with open(path / "nodes.kv", "wb") as f:
+        f.write(orc.nodes_kv_bytes(x.shape[1], x, keys, labels, metadata))
+    layers, entry = orc.parse_hnsw_v2(gbytes, edges, len(keys))
+    with open(path / "index.hnsw", "wb") as f:
+        f.write(orc.disk_hnsw_v1_bytes(len(keys), layers, entry))
+
+
+def test_pre_migration_directory_opens_as_the_same_segment(orc, tmp_path):
+    """A DataStoreV1 + DiskHnswV1 directory (segment::open's first branch, segment.rs:41-57; open_disk_hnsw's fallback, hnsw/disk.rs:25-32)
+    against the same segment in the current formats: records, vectors, inverted indexes, deletions and the graph image byte for byte."""
+    rng = np.random.default_rng(41)
+    x, keys, labels, metadata, gbytes, edges = v1_corpus(orc, rng)
+    v1, v2 = tmp_path / "v1", tmp_path / "v2"
+    v1.mkdir(), v2.mkdir()
+    write_v1(orc, v1, x, keys, labels, metadata, gbytes, edges)
+    VectorSegment(keys, x, labels, metadata, graph=gbytes, graph_edges=edges).save(str(v2))
+    # the layout, spelled out once: key "ab", labels ["L1"], metadata "M", one f32
+    one = orc.node_v1_bytes("ab", np.array([1.0], "<f4").tobytes(), ["L1"], b"M")
+    trie = orc.label_trie_bytes(["L1"])
+    assert trie == (8 + 3 * 9 + 2 * 9 + 3 * 8).to_bytes(8, "little") + b"\0" + (1).to_bytes(8, "little") + b"L" + (1).to_bytes(8, "little") \
+        + b"\0" + (1).to_bytes(8, "little") + b"1" + (2).to_bytes(8, "little") + b"\1" + bytes(8) \
+        + (44).to_bytes(8, "little") + (26).to_bytes(8, "little") + (8).to_bytes(8, "little")
+    assert one == b"".join(v.to_bytes(8, "little") for v in (32 + 1 + 3 + 8 + 4 + 8 + 2 + len(trie), 33, 33 + 3 + 12, 33 + 3 + 12 + 10)) + b"M" \
+        + (4).to_bytes(4, "little") + (3).to_bytes(4, "little") + bytes(3) + np.array([1.0], "<f4").tobytes() + (2).to_bytes(8, "little") + b"ab" + trie
+    with SegmentDir(str(v1), x.shape[1]) as a, SegmentDir(str(v2), x.shape[1]) as b:
+        sa, sb = a.to_segment(), b.to_segment()
+        assert sa.keys == sb.keys == keys and np.array_equal(sa.vectors, sb.vectors) and sa.para_of_vec is None
+        assert [sorted(l) for l in sa.labels] == [sorted(set(l)) for l in labels] and sa.metadata == sb.metadata == metadata
+        assert sorted(sa.labels[5]) == sorted(labels[5])
+        assert sa.graph == sb.graph == gbytes and np.array_equal(sa.graph_edges, sb.graph_edges)
+        assert not a.indexes_from_files and b.indexes_from_files   # (the V1 directory has no index files: rebuilt)
+        assert all_lists(a) == all_lists(b)
+        dead = [f"{RID[1]}/t/title", str(RID[2])]
+        assert np.array_equal(a.apply_deletions(dead), b.apply_deletions(dead))
+        for addr in (0, 5, len(keys) - 1):
+            pa, pb = a.paragraph(addr), b.paragraph(addr)
+            assert pa[0] == pb[0] and sorted(pa[1]) == sorted(set(pb[1])) and pa[2:] == pb[2:]
+    # the reference's own migration test (hnsw/disk.rs:52-108): three nodes, node 0 alone (and without edges) in layer 1, entry (0, 1)
+    layers = [{0: [(1, 0.5), (2, 0.2)], 1: [(0, 0.5), (1, 0.7)], 2: [(0, 0.2)]}, {0: []}]
+    tiny = tmp_path / "tiny"
+    tiny.mkdir()
+    with open(tiny / "nodes.kv", "wb") as f:
+        f.write(orc.nodes_kv_bytes(2, np.eye(3, 2, dtype=np.float32), ["a", "b", "c"], [[], [], []], [b"", b"", b""]))
+    with open(tiny / "index.hnsw", "wb") as f:
+        f.write(orc.disk_hnsw_v1_bytes(3, layers, (0, 1)))
+    with SegmentDir(str(tiny), 2) as t:
+        st = t.to_segment()
+        got, entry = orc.parse_hnsw_v2(st.graph, st.graph_edges, 3)
+        assert entry == (0, 1) and got[0] == {n: [(to, float(np.float32(w))) for to, w in es] for n, es in layers[0].items()} and got[1] == {}
+    # an empty graph is an empty index.hnsw; a directory with nodes.kv only has no graph
+    with open(tiny / "index.hnsw", "wb") as f:
+        f.write(b"")
+    with SegmentDir(str(tiny), 2) as t:
+        assert t.to_segment().graph is None
+
+
+def test_pre_migration_directory_merges_into_the_current_formats(orc, tmp_path):
+    from nucliadb_amd.vector import segment_dir_merge
+
+    rng = np.random.default_rng(42)
+    x, keys, labels, metadata, gbytes, edges = v1_corpus(orc, rng, n=90)
+    labels = [sorted(set(l)) for l in labels]   # (a V1 node stores its labels as a trie: a set, in trie order)
+    y = rng.standard_normal((40, 16)).astype(np.float32)
+    other = VectorSegment([f"{RID[3]}/f/file/{i}-{i + 1}" for i in range(40)], y, [["/l/other"]] * 40, [b"m"] * 40)
+    dirs = {}
+    for name in ("v1", "v2", "other", "out1", "out2"):
+        dirs[name] = tmp_path / name
+        dirs[name].mkdir()
+    write_v1(orc, dirs["v1"], x, keys, labels, metadata, gbytes, edges)
+    VectorSegment(keys, x, labels, metadata, graph=gbytes, graph_edges=edges).save(str(dirs["v2"]))
+    other.save(str(dirs["other"]))
+    alive = np.ones(90, bool)
+    alive[[3, 50]] = False
+    with SegmentDir(str(dirs["v1"]), 16) as a, SegmentDir(str(dirs["v2"]), 16) as b, SegmentDir(str(dirs["other"]), 16) as o:
+        r1 = segment_dir_merge(str(dirs["out1"]), 16, [(a, alive), (o, None)])
+        r2 = segment_dir_merge(str(dirs["out2"]), 16, [(b, alive), (o, None)])
+    assert r1 == r2 and sorted(os.listdir(dirs["out1"])) == sorted(os.listdir(dirs["out2"]))
+    with SegmentDir(str(dirs["out1"]), 16) as m1, SegmentDir(str(dirs["out2"]), 16) as m2:
+        s1, s2 = m1.to_segment(), m2.to_segment()
+        assert s1.keys == s2.keys and np.array_equal(s1.vectors, s2.vectors) and s1.metadata == s2.metadata
+        assert [sorted(l) for l in s1.labels] == [sorted(l) for l in s2.labels] and all_lists(m1) == all_lists(m2)
+
+
+def test_damaged_pre_migration_files_are_io_errors(orc, tmp_path):
+    rng = np.random.default_rng(43)
+    x, keys, labels, metadata, gbytes, edges = v1_corpus(orc, rng, n=60)
+    write_v1(orc, tmp_path, x, keys, labels, metadata, gbytes, edges)
+    SegmentDir(str(tmp_path), 16).close()
+    with pytest.raises(_lib.NidxGpuError) as e:   # the vectors of the store do not have the index's dimension
+        SegmentDir(str(tmp_path), 8)
+    assert e.value.code == _lib.NIDX_ERR_IO
+    for name in ("nodes.kv", "index.hnsw"):
+        good = read(tmp_path, name)
+        for trial in range(250):
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(0, len(b)))
+                if trial % 3 == 0:   # a whole u64 field
+                    b[at - at % 8: at - at % 8 + 8] = int(rng.integers(0, 1 << 62)).to_bytes(8, "little")
+                else:
+                    b[at] = int(rng.integers(0, 256))
+            cut = int(rng.integers(0, len(b) + 1)) if trial % 5 == 0 else len(b)
+            with open(tmp_path / name, "wb") as f:
+                f.write(bytes(b[:cut]))
+            try:
+                SegmentDir(str(tmp_path), 16).close()
+            except _lib.NidxGpuError as err:
+                assert err.code in (_lib.NIDX_ERR_IO, _lib.NIDX_ERR_INCONSISTENT_DIMENSIONS)
+        with open(tmp_path / name, "wb") as f:
+            f.write(good)
