@@ -170,6 +170,24 @@ def _bitset(mask: np.ndarray) -> np.ndarray:
     return np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words).copy()
 
 
+def terms_in_range(vocab: "Vocabulary", lo: Optional[str], lo_incl: bool, hi: Optional[str], hi_incl: bool) -> List[int]:
+    """The ids of the text field's terms inside a range of tantivy's RangeQuery (term bytes in lexicographic order; None = open end).
+    The pseudo terms of the other fields (their \x00 prefix) are not terms of the text field."""
+    lo_b = None if lo is None else lo.encode()
+    hi_b = None if hi is None else hi.encode()
+    out = []
+    for t, i in vocab.ids.items():
+        if t.startswith("\x00"):
+            continue
+        b = t.encode()
+        if lo_b is not None and (b < lo_b or (b == lo_b and not lo_incl)):
+            continue
+        if hi_b is not None and (b > hi_b or (b == hi_b and not hi_incl)):
+            continue
+        out.append(i)
+    return sorted(out)
+
+
 def deletion_terms(vocab: "Vocabulary", segment_seq: int, deletions: Sequence[Tuple[str, int]]) -> List[int]:
     """The TermSetQuery of the DeletionQueryBuilders (nidx_text/src/lib.rs:95-128, nidx_paragraph/src/lib.rs:50-71) for one
     segment: of the (key, seq) deletions those NEWER than the segment (index_reader.rs:47-50: `Seq(segment) < del_seq`); a
@@ -372,6 +390,9 @@ class QLeaf:
     text: str = ""
     boost: float = 1.0
     all: bool = False      # `*`
+    # `[a TO b]` / `{a TO b}` / `[a TO *]`: (lower token or None, inclusive, upper token or None, inclusive) — a RangeQuery over the
+    # text field's terms (byte order), scored ConstScorer(1.0)
+    term_range: Optional[Tuple[Optional[str], bool, Optional[str], bool]] = None
 
 
 @dataclass
@@ -388,7 +409,8 @@ def parse_text_query(body: str):
     """-> QLeaf | QNode.  Grammar: clause := ['+' | '-'] (word | "phrase" | '(' query ')' | '*') ['^' number], words may
     carry a `text:` field prefix; clauses are joined by AND / OR / NOT or by juxtaposition (= AND: conjunction by default);
     AND binds tighter than OR.  Raises QuerySyntaxError on what tantivy's parser rejects (unbalanced quotes / parentheses,
-    a dangling operator, an unknown field, slop / range syntax is refused as NotImplementedError)."""
+    a dangling operator, an unknown field, a range bound that is not one token; phrase slop is refused as NotImplementedError).
+    Ranges: `[a TO b]` inclusive, `{a TO b}` exclusive, mixed brackets, `*` for an open end."""
     pos, n = 0, len(body)
 
     def skip_ws():
@@ -442,7 +464,46 @@ def parse_text_query(body: str):
             pos += 1
             return QLeaf("", parse_boost(), all=True)
         if c in "[{":
-            raise NotImplementedError("range queries")
+            lo_incl = c == "["
+            pos += 1
+
+            def parse_bound():
+                nonlocal pos
+                skip_ws()
+                if pos >= n:
+                    raise QuerySyntaxError("unterminated range")
+                if body[pos] == "*":
+                    pos += 1
+                    return None
+                if body[pos] == '"':
+                    j = body.find('"', pos + 1)
+                    if j < 0:
+                        raise QuerySyntaxError("unbalanced quote")
+                    raw = body[pos + 1:j]
+                    pos = j + 1
+                else:
+                    j = pos
+                    while j < n and not body[j].isspace() and body[j] not in "]}":
+                        j += 1
+                    raw = body[pos:j]
+                    pos = j
+                toks = tokenize(raw)
+                if len(toks) != 1:   # QueryParserError::RangeMustNotHavePhrase (and an empty bound)
+                    raise QuerySyntaxError("a range bound must be exactly one token")
+                return toks[0]
+
+            lo = parse_bound()
+            skip_ws()
+            if not (body.startswith("TO", pos) and pos + 2 < n and body[pos + 2].isspace()):
+                raise QuerySyntaxError("range without TO")
+            pos += 2
+            hi = parse_bound()
+            skip_ws()
+            if pos >= n or body[pos] not in "]}":
+                raise QuerySyntaxError("unterminated range")
+            hi_incl = body[pos] == "]"
+            pos += 1
+            return QLeaf("", parse_boost(), term_range=(lo, lo_incl, hi, hi_incl))
         if c in _SPECIAL or c in "+-":
             raise QuerySyntaxError(f"unexpected {c!r}")
         j = pos
@@ -599,6 +660,12 @@ class TextSearcher:
     def _leaf(self, leaf: "QLeaf", occur: int) -> Optional[Clause]:
         """One literal of the grammar through the text field's tokenizer: no token -> no clause, one -> TermQuery with
         frequencies, several -> PhraseQuery (QueryParser::compute_logical_ast_for_leaf)."""
+        if leaf.term_range is not None:
+            # RangeQuery over the field's term dictionary: the union of the terms inside the bounds, ConstScorer(1.0) x boost
+            ids = terms_in_range(self._index.vocab, *leaf.term_range)
+            if not ids:
+                return Clause(self._index.empty_term, occur, _lib.TF_FREQ, 1.0)   # matches nothing
+            return Clause(0, occur, _lib.CONST_SCORE, leaf.boost, term_set=ids)
         words = tokenize(leaf.text)
         if not words:
             return None
@@ -614,6 +681,8 @@ class TextSearcher:
         leaves: List[Clause] = []
 
         def word(leaf, occ):
+            if leaf.term_range is not None:
+                raise NotImplementedError("a range inside a nested boolean expression")
             if leaf.all:
                 return Clause(self._index.term(ALL_DOCS), occ, _lib.CONST_SCORE, leaf.boost)
             words = tokenize(leaf.text)

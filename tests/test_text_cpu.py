@@ -81,9 +81,23 @@ def test_tantivy_grammar_subset_parses_like_the_query_parser():
     for bad in ['"enough test', "enough test\"", "a AND", "a OR", "(a b", "a b)", "enough - test", "title:x", "a^"]:
         with pytest.raises(QuerySyntaxError):
             parse_text_query(bad)
-    for refused in ['"a b"~2', "[a TO b]"]:
+    for refused in ['"a b"~2']:
         with pytest.raises(NotImplementedError):
             flatten_conjunction(parse_text_query(refused))
+    # ranges over the text field's terms: inclusive / exclusive / open ends, a field prefix, a boost; bounds are single tokens
+    from nucliadb_amd.text import Vocabulary, terms_in_range
+
+    leaf = flatten_conjunction(parse_text_query("x text:[Apple TO melon}^2"))[0][1]
+    assert leaf.term_range == ("apple", True, "melon", False) and leaf.boost == 2.0
+    assert parse_text_query("{a TO *]").term_range == ("a", False, None, True) and parse_text_query('["b" TO c]').term_range == ("b", True, "c", True)
+    for bad in ["[a b TO c]", "[a TO ]", "[a c]", "[a TO b", '["a b" TO c]']:
+        with pytest.raises(QuerySyntaxError):
+            parse_text_query(bad)
+    vocab = Vocabulary()
+    ids = {t: vocab.id(t) for t in ["apple", "banana", "cherry", "melon", "zebra", "\x00label:/l/x", "émile"]}
+    pick = lambda *r: [t for t in ids if ids[t] in terms_in_range(vocab, *r)]
+    assert pick("apple", True, "melon", False) == ["apple", "banana", "cherry"] and pick("apple", False, "melon", True) == ["banana", "cherry", "melon"]
+    assert pick(None, True, "b", True) == ["apple"] and pick("n", True, None, True) == ["zebra", "émile"] and pick("x", True, "a", True) == []
 
 
 def test_deletion_terms_respect_seq_and_key_kind():
