@@ -361,6 +361,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
+                # at batch >= ~64 the shared-row scan is bound by the f32 FMA pipe, not by HBM (every row is read once per launch and used by
+                # all queries): the fraction that says how good the kernel is there
+                "valu_f32": {"achieved": achieved_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved_tf / 157.3,
+                             "note": "2 n d B flops per launch on the VALU (packed f32 FMA), against the 157.3 TFLOP/s f32 peak"},
             }),
             "cpu_baseline": cpu,
         }
