@@ -10,12 +10,16 @@
 // and instruction issue is what bounds it.  Here every clause's part of the slice is STREAMED on its own — the
 // two bounds of the slice are found by the side-by-side search first, so a clause is a plain counted loop over rows with nothing to plan:
 //   phase 1  every clause but the longest: doc ids only; each posting sets its bit of bitmap A (32 Kibit, ds_or_rtn).  A bit that was
-//            already set marks a POSSIBLE second posting of the same document: that posting sets the document's bit in bitmap B.
-//   phase 2  the longest clause (it sets nothing — its documents are distinct): a posting whose A bit is set is "involved" (sets B,
-//            joins the involved list with its score); any other posting is FINAL: score -> rank key -> candidate.
+//            already set marks a POSSIBLE second posting of the same document: that posting sets the document's bit in bitmap B (2 Kibit).
+//   phase 2  the longest clause (it sets nothing — its documents are distinct; its first four rows have been in flight since before phase 1):
+//            a posting whose A bit is set is "involved" (sets B,
+//            joins the involved list with its score); any other posting is FINAL: score -> one float compare with the k-th score ->
+//            (rarely) rank key -> candidate.
 //   phase 3  the other clauses again, now with scores: B bit set = involved, otherwise final.
-//   phase 4  the involved postings (a few per cent: true meetings + hash collisions) are resolved exactly through a 512-slot LDS hash
-//            table (it reuses the bitmaps' space): clause by clause in clause order — inside one clause the documents are distinct, so
+//   phase 4  the involved postings (a few per cent: true meetings + hash collisions) are resolved exactly.  Up to 64 of them sit one
+//            per lane in clause order and are compared through the scalar unit (v_readlane): lane i learns its document's f32 sum, built
+//            in lane = clause order, and its clause mask; the first lane of a document owns it.  More go through a 512-slot LDS hash
+//            table (it reuses the bitmaps' space and the top of the candidate buffer): clause by clause in clause order — inside one clause the documents are distinct, so
 //            every lane owns its document's slot for that round — a posting claims or finds its document's slot (ds_cmpst) and adds its
 //            score to the slot's f32 sum, which is therefore built in clause order like the oracle's term-at-a-time loop, and ORs its
 //            clause into the slot's mask; one pass over the slots then tests every document against the query's boolean structure.
