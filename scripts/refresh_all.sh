@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: every bench.py workload once on the GPU box, each under rocprofv3 --kernel-trace --stats, summaries under gpurun_out/final/.
-# Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | others | all
+# Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | bm25 | others | all
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 PART=${1:-all}
@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench args...
   local name=$1; shift
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$name -- python $ROOT/bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$name -- python $ROOT/bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err < /dev/null
   local db=$(ls $OUT/prof_$name/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $ROOT/scripts/prof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py $*" > $OUT/kernel_stats_$name.txt 2>&1
   rm -rf $OUT/prof_$name
@@ -19,6 +19,14 @@ if [ "$PART" = headline ] || [ "$PART" = all ]; then
   timeout 1500 python $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
   tail -c 300 $OUT/bench_default.json; echo
   bash $ROOT/scripts/refresh_profiles.sh
+fi
+if [ "$PART" = bm25 ] || [ "$PART" = all ]; then
+  # the BM25 evidence of DESIGN 4.4: kernel stats one batch at a time (what the bench line's HIP events time), HBM traffic, the batch curve,
+  # SQ / instruction-cache counters of both union kernels  (every command bounded: a stalled step must not eat the GPU budget)
+  NIDX_BENCH_BM25_DEPTH=1 prof bm25_one_at_a_time --workload bm25 --cpu-queries 0 --steps 200
+  timeout 400 bash $ROOT/scripts/pmc_bm25_traffic.sh < /dev/null > $OUT/pmc_bm25_traffic.log 2>&1
+  timeout 500 bash $ROOT/scripts/bm25_batch_curve.sh 256 1024 4096 16384 < /dev/null > $OUT/bm25_batch_curve.txt 2>&1
+  timeout 500 bash $ROOT/scripts/pmc_bm25_icache.sh < /dev/null > $OUT/pmc_bm25_counters.txt 2>&1
 fi
 if [ "$PART" = others ] || [ "$PART" = all ]; then
   prof bm25 --workload bm25 --steps 10 --warmup 2
