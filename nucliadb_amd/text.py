@@ -447,7 +447,7 @@ def parse_text_query(body: str):
             b = parse_boost()
             if b != 1.0:
                 if isinstance(node, QLeaf):
-                    node = QLeaf(node.text, node.boost * b, node.all)
+                    node = QLeaf(node.text, node.boost * b, node.all, node.term_range)
                 else:
                     node = QNode(node.op, node.children, node.boost * b)
             return node
@@ -575,7 +575,7 @@ def parse_text_query(body: str):
 
 
 def _scaled(leaf: "QLeaf", factor: float) -> "QLeaf":
-    return leaf if factor == 1.0 else QLeaf(leaf.text, leaf.boost * factor, leaf.all)
+    return leaf if factor == 1.0 else QLeaf(leaf.text, leaf.boost * factor, leaf.all, leaf.term_range)
 
 
 def flatten_conjunction(node, nested: bool = True):

@@ -89,6 +89,8 @@ def test_tantivy_grammar_subset_parses_like_the_query_parser():
 
     leaf = flatten_conjunction(parse_text_query("x text:[Apple TO melon}^2"))[0][1]
     assert leaf.term_range == ("apple", True, "melon", False) and leaf.boost == 2.0
+    boosted = flatten_conjunction(parse_text_query("([a TO b])^3 OR (c [d TO e])^2"))
+    assert boosted[2][0][0].term_range == ("a", True, "b", True) and boosted[2][0][0].boost == 3.0
     assert parse_text_query("{a TO *]").term_range == ("a", False, None, True) and parse_text_query('["b" TO c]').term_range == ("b", True, "c", True)
     for bad in ["[a b TO c]", "[a TO ]", "[a c]", "[a TO b", '["a b" TO c]']:
         with pytest.raises(QuerySyntaxError):
