@@ -564,17 +564,22 @@ int32_t nidx_gpu_bm25_search(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_c
  * ConstScorer(boost): FuzzyTermQuery / AutomatonWeight (nidx_paragraph/src/fuzzy_query.rs:55-125). */
 #define NIDX_BM25_TERM_SET 0x80000000u
 /* A clause whose `term` is NIDX_BM25_PHRASE | j is PhraseQuery(options.phrase_terms[phrase_offsets[j] ..
- * phrase_offsets[j+1])) with slop 0 (keyword_parser.rs:69-91 for multi-word quotes; tantivy's QueryParser for
- * nidx_text): the terms at consecutive positions, tf = number of occurrences, Bm25Weight::for_terms (idf summed
- * over the terms).  `mode` is ignored. */
+ * phrase_offsets[j+1])) (keyword_parser.rs:69-91 for multi-word quotes; tantivy's QueryParser for nidx_text): with
+ * slop 0 the terms at consecutive positions, tf = number of occurrences, Bm25Weight::for_terms (idf summed over the
+ * terms).  options.phrase_slops[j] > 0 (`"a b"~2` in the QueryParser's grammar) = PhraseQuery::set_slop: tantivy's
+ * PhraseScorer with slop — each next term may trail the match so far by up to `slop` extra positions, in order.
+ * `mode` is ignored. */
 #define NIDX_BM25_PHRASE 0x40000000u
 /* A clause whose `term` is NIDX_BM25_SUBQUERY | j is a nested BooleanQuery: the leaves options.subquery_clauses[subquery_offsets[j]
- * .. subquery_offsets[j+1]) — plain terms, at most 16, AT LEAST ONE of them Must; occur / mode / boost as for top-level clauses,
- * required Should groups included.  It matches a document when its own boolean structure does, its score there is the f32 sum of its
- * scoring leaves that hold the document (leaf order), and the outer clause contributes boost x that score (tantivy: BoostQuery over
- * the nested BooleanQuery; `mode` of the outer clause is ignored).  This is what tantivy's QueryParser builds for an AND inside an
- * OR, a negated conjunction or a boosted conjunction (nidx_text/src/reader.rs:357-376) and what a conjunction or a negation inside an
- * `Or` filtering formula becomes (nidx_paragraph/src/search_query.rs:88-143). */
+ * .. subquery_offsets[j+1]), at most 32; occur / mode / boost as for top-level clauses, required Should groups included.  A leaf is
+ * a term of the dictionary, a term set (NIDX_BM25_TERM_SET | s), a phrase (NIDX_BM25_PHRASE | p) or ANOTHER nested query
+ * (NIDX_BM25_SUBQUERY | i with i < j: a tree's queries are listed children first), so boolean trees of any depth are expressible.
+ * It matches a document when its own boolean structure does — every Must leaf, no MustNot leaf, a member of every required Should
+ * group, and when it has neither Must leaves nor groups at least one Should leaf (a nested query with only MustNot leaves matches
+ * nothing, like tantivy's) — its score there is the f32 sum of its scoring leaves that hold the document (leaf order), and the outer
+ * clause contributes boost x that score (tantivy: BoostQuery over the nested BooleanQuery; `mode` of the outer clause is ignored).
+ * This is what tantivy's QueryParser builds for parenthesised boolean expressions (nidx_text/src/reader.rs:357-376) and what nested
+ * filtering formulas become (nidx_paragraph/src/search_query.rs:88-143). */
 #define NIDX_BM25_SUBQUERY 0x20000000u
 
 typedef struct {
@@ -603,6 +608,7 @@ typedef struct {
     const nidx_gpu_bm25_clause_t *subquery_clauses;   /* leaves of every nested BooleanQuery, concatenated (NIDX_BM25_SUBQUERY) */
     const uint64_t *subquery_offsets;                 /* [n_subqueries + 1] */
     uint32_t n_subqueries;
+    const uint32_t *phrase_slops;                     /* NULL (every phrase exact) or [n_phrases]: PhraseQuery::set_slop */
 } nidx_gpu_bm25_search_options_t;
 
 /* nidx_gpu_bm25_search with the collectors above; out_score is the BM25 score when ordering by score and 0

@@ -93,6 +93,7 @@ class Bm25SearchOptionsC(C.Structure):
         ("subquery_clauses", C.c_void_p),
         ("subquery_offsets", C.c_void_p),
         ("n_subqueries", C.c_uint32),
+        ("phrase_slops", C.c_void_p),
     ]
 
 

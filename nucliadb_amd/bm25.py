@@ -31,10 +31,12 @@ class Clause:
     term_set: Optional[Sequence[int]] = None
     # parse_excluded (keyword_parser.rs:93-105): every document OUTSIDE the union, AllQuery's 1.0 * boost
     complement: bool = False
-    # PhraseQuery(term_set) with slop 0: the terms at consecutive positions in this order, tf = occurrences,
-    # Bm25Weight::for_terms (the index must have been opened with positions)
+    # PhraseQuery(term_set): the terms at consecutive positions in this order (slop 0) or, with `slop` > 0, each within `slop`
+    # extra positions of the match so far (PhraseQuery::set_slop); tf = occurrences, Bm25Weight::for_terms (the index must have
+    # been opened with positions)
     phrase: bool = False
-    # a nested BooleanQuery (NIDX_BM25_SUBQUERY): its leaves — plain term clauses, at least one of them Must; the outer clause
+    slop: int = 0
+    # a nested BooleanQuery (NIDX_BM25_SUBQUERY): its leaves — clauses of any kind, nested queries included; the outer clause
     # contributes boost x the nested query's own score; `term` and `mode` are ignored
     subquery: Optional[Sequence["Clause"]] = None
 
@@ -220,24 +222,33 @@ class Bm25Searcher:
         set_comp: List[int] = []
         phrase_terms: List[int] = []
         phrase_offsets = [0]
-        sub_leaves: List[Clause] = []
+        phrase_slops: List[int] = []
+        sub_leaves: List[Tuple[int, int, int, float]] = []   # (term word, occur, mode, boost) of every nested query's leaves
         sub_offsets = [0]
-        for i, c in enumerate(flat):
-            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = c.term, c.occur, c.mode, c.boost
+
+        def lower(c: Clause) -> Tuple[int, int]:
+            """-> (term word, mode) of one clause; a nested query's own leaves are lowered first, so the queries of a tree are
+            listed children before parents (the order the library materialises them in)."""
             if c.subquery is not None:
-                cl[i].term = _lib.BM25_SUBQUERY | (len(sub_offsets) - 1)
-                sub_leaves.extend(c.subquery)
+                leaves = [(*lower(l), l) for l in c.subquery]
+                sub_leaves.extend((t, l.occur, m, l.boost) for t, m, l in leaves)
                 sub_offsets.append(len(sub_leaves))
-            elif c.term_set is not None and c.phrase:
-                cl[i].term = _lib.BM25_PHRASE | (len(phrase_offsets) - 1)
+                return _lib.BM25_SUBQUERY | (len(sub_offsets) - 2), c.mode
+            if c.term_set is not None and c.phrase:
                 phrase_terms.extend(int(t) for t in c.term_set)
                 phrase_offsets.append(len(phrase_terms))
-            elif c.term_set is not None:
-                cl[i].term = _lib.BM25_TERM_SET | (len(set_offsets) - 1)
-                cl[i].mode = _lib.CONST_SCORE
+                phrase_slops.append(int(c.slop))
+                return _lib.BM25_PHRASE | (len(phrase_offsets) - 2), c.mode
+            if c.term_set is not None:
                 set_terms.extend(int(t) for t in c.term_set)
                 set_offsets.append(len(set_terms))
                 set_comp.append(int(c.complement))
+                return _lib.BM25_TERM_SET | (len(set_offsets) - 2), _lib.CONST_SCORE
+            return c.term, c.mode
+
+        for i, c in enumerate(flat):
+            term, mode = lower(c)
+            cl[i].term, cl[i].occur, cl[i].mode, cl[i].boost = term, c.occur, mode, c.boost
         af = None
         if after is not None:
             af = (_lib.Bm25SearchAfterC * max(1, B))()
@@ -266,9 +277,11 @@ class Bm25Searcher:
         opt.phrase_terms = pt.ctypes.data if pt.size else None
         opt.phrase_offsets = po.ctypes.data
         opt.n_phrases = len(phrase_offsets) - 1
+        ps = np.ascontiguousarray(phrase_slops, dtype=np.uint32)
+        opt.phrase_slops = ps.ctypes.data if any(phrase_slops) else None
         sub_cl = (_lib.Bm25ClauseC * max(1, len(sub_leaves)))()
-        for i, c in enumerate(sub_leaves):
-            sub_cl[i].term, sub_cl[i].occur, sub_cl[i].mode, sub_cl[i].boost = c.term, c.occur, c.mode, c.boost
+        for i, (t, o, m, b) in enumerate(sub_leaves):
+            sub_cl[i].term, sub_cl[i].occur, sub_cl[i].mode, sub_cl[i].boost = t, o, m, b
         sub_off = np.ascontiguousarray(sub_offsets, dtype=np.uint64)
         opt.subquery_clauses = C.cast(sub_cl, C.c_void_p) if sub_leaves else None
         opt.subquery_offsets = sub_off.ctypes.data

@@ -12,6 +12,7 @@
 //   facet_count_kernel    FacetCollector (nidx_text/src/reader.rs:43-62,391-398; nidx_paragraph/src/reader.rs:244-348):
 //                         a facet's count = |postings(facet term) ∩ matching documents|; the scoring kernel leaves the
 //                         matching documents of a query as a bitset.
+#include <algorithm>
 #include "device_common.h"
 #include "kernels.h"
 
@@ -150,9 +151,40 @@ __device__ inline unsigned long long lower_bound_doc(const uint32_t *doc_ids, un
     return b;
 }
 
+// PhraseScorer with slop over one document (tantivy phrase_scorer.rs, PhraseQuery::set_slop: "the slop is a budget between all
+// terms ... works in both directions"): `left` = the matches so far as (position, budget used) pairs, ascending; against the
+// positions [rb, re) of the next term shifted by `shift` a pair matches when |left - right| + used <= slop; the last left value not
+// beyond `right` that still fits the budget is the one consumed ("there could be a better match"); the match moves on as
+// (right, used + distance), written over the head of `left`.  -> matches
+__device__ inline uint32_t slop_intersect(uint32_t *left, uint32_t n_left, const uint32_t *positions, unsigned long long rb, unsigned long long re,
+                                          uint32_t shift, uint32_t slop) {
+    uint32_t li = 0, count = 0;
+    unsigned long long ri = rb;
+    while (li < n_left && ri < re) {
+        uint32_t lv = left[2 * li], used = left[2 * li + 1];
+        const uint32_t rv = positions[ri] + shift;
+        uint32_t dist = lv > rv ? lv - rv : rv - lv;
+        if (dist + used <= slop) {
+            while (li + 1 < n_left) {
+                const uint32_t nv = left[2 * li + 2], nu = left[2 * li + 3];
+                if (nv > rv || rv - nv + nu > slop) break;
+                li++;
+                lv = nv, used = nu, dist = rv - nv;
+            }
+            left[2 * count] = rv;
+            left[2 * count + 1] = used + dist;
+            count++;
+            li++;
+            ri++;
+        } else if (lv < rv) li++;
+        else ri++;
+    }
+    return count;
+}
+
 __global__ __launch_bounds__(256) void phrase_match_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids,
                                                            const unsigned long long *pos_offsets, const uint32_t *positions, PhraseDev ph,
-                                                           uint32_t *tmp_tf) {
+                                                           uint32_t *tmp_tf, uint32_t *slop_left) {
     const unsigned long long b0 = term_offsets[ph.terms[ph.driver]], e0 = term_offsets[ph.terms[ph.driver] + 1];
     const unsigned long long i0 = b0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i0 >= e0) return;
@@ -168,7 +200,16 @@ __global__ __launch_bounds__(256) void phrase_match_kernel(const unsigned long l
         at[t] = i;
     }
     uint32_t count = 0;
-    if (all) {
+    if (all && ph.slop) {
+        // left = the first term's positions + (n_terms - 1) with no budget used, in its own region of the scratch list
+        const unsigned long long p0 = pos_offsets[at[0]], p1 = pos_offsets[at[0] + 1];
+        uint32_t *left = slop_left + 2 * (p0 - pos_offsets[term_offsets[ph.terms[0]]]);
+        uint32_t n_left = (uint32_t)(p1 - p0);
+        for (uint32_t i = 0; i < n_left; i++) left[2 * i] = positions[p0 + i] + (ph.n_terms - 1), left[2 * i + 1] = 0u;
+        for (uint32_t t = 1; t < ph.n_terms && n_left; t++)
+            n_left = slop_intersect(left, n_left, positions, pos_offsets[at[t]], pos_offsets[at[t] + 1], ph.n_terms - 1 - t, ph.slop);
+        count = n_left;
+    } else if (all) {
         for (unsigned long long pi = pos_offsets[i0]; pi < pos_offsets[i0 + 1]; pi++) {
             const uint32_t p = positions[pi];
             if (p < ph.driver) continue;  // the phrase would start before position 0
@@ -192,9 +233,11 @@ __global__ __launch_bounds__(256) void phrase_match_kernel(const unsigned long l
 }
 
 hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const unsigned long long *pos_offsets,
-                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, hipStream_t s) {
+                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, uint32_t *slop_left, hipStream_t s) {
     if (n_driver == 0) return hipSuccess;
-    hipLaunchKernelGGL(phrase_match_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, pos_offsets, positions, ph, tmp_tf);
+    if (ph.slop && (!slop_left || ph.n_terms < 2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(phrase_match_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, pos_offsets, positions, ph, tmp_tf,
+                       slop_left);
     return hipGetLastError();
 }
 
@@ -244,26 +287,69 @@ hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const u
 }
 
 // ---- nested BooleanQuery -> pre-scored posting list -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void subquery_match_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *words,
-                                                             const float *tf_cache, SubqueryDev sq, uint32_t *tmp_ok, uint32_t *tmp_score) {
-    const unsigned long long b0 = term_offsets[sq.term[sq.driver]], e0 = term_offsets[sq.term[sq.driver] + 1];
-    const unsigned long long i0 = b0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i0 >= e0) return;
-    const uint32_t d = doc_ids[i0];
-    uint32_t mask = 0, must_m = 0, not_m = 0;
+struct SubRange {
+    const uint32_t *ids, *words;
+    unsigned long long b, e;
+};
+
+__device__ inline SubRange sub_leaf_range(const SubqueryLists &L, uint32_t src) {
+    SubRange r;
+    if (src & BM25_AUX_TERM) {
+        const uint32_t a = src & ~BM25_AUX_TERM;
+        r.ids = L.aux_ids;
+        r.words = L.aux_words;
+        r.b = L.aux_begin[a];
+        r.e = r.b + L.aux_counts[a];
+    } else {
+        r.ids = L.doc_ids;
+        r.words = L.words;
+        r.b = L.term_offsets[src];
+        r.e = L.term_offsets[src + 1];
+    }
+    return r;
+}
+
+__device__ inline SubRange sub_candidates(const SubqueryLists &L, const SubqueryDev &sq) {
+    if (sq.driver == BM25_SUB_DRIVER_UNION) return SubRange{L.union_ids, nullptr, 0ull, (unsigned long long)*L.union_count};
+    return sub_leaf_range(L, sq.src[sq.driver]);
+}
+
+__global__ __launch_bounds__(256) void subquery_scatter_kernel(SubqueryLists L, uint32_t src, uint64_t *bits) {
+    const SubRange r = sub_leaf_range(L, src);
+    for (unsigned long long i = r.b + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.e; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t d = r.ids[i];
+        atomicOr(reinterpret_cast<unsigned long long *>(bits) + (d >> 6), 1ull << (d & 63));
+    }
+}
+
+hipError_t launch_subquery_scatter(const SubqueryLists &L, uint32_t src, unsigned long long upper_bound, uint64_t *bits, hipStream_t s) {
+    if (upper_bound == 0) return hipSuccess;
+    const unsigned long long blocks = std::min<unsigned long long>((upper_bound + 255) / 256, 4096);
+    hipLaunchKernelGGL(subquery_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, L, src, bits);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void subquery_match_kernel(SubqueryLists L, const float *tf_cache, SubqueryDev sq, uint32_t *tmp_ok, uint32_t *tmp_score) {
+    const SubRange cand = sub_candidates(L, sq);
+    const unsigned long long i0 = cand.b + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= cand.e) return;
+    const uint32_t d = cand.ids[i0];
+    uint32_t mask = 0, must_m = 0, not_m = 0, should_m = 0;
     uint32_t group_m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float acc = 0.f;   // the nested scorer's own sum, leaf by leaf
     for (uint32_t t = 0; t < sq.n; t++) {
         const uint32_t occur = sq.occur[t];
-        if (occur == 1) must_m |= 1u << t;
+        if (occur == 0) should_m |= 1u << t;
+        else if (occur == 1) must_m |= 1u << t;
         else if (occur == 2) not_m |= 1u << t;
-        else if (occur >= 3) group_m[(occur - 3) & 7] |= 1u << t;
+        else group_m[(occur - 3) & 7] |= 1u << t;
+        SubRange r = cand;
         unsigned long long i = i0;
         bool here = true;
         if (t != sq.driver) {
-            const unsigned long long b = term_offsets[sq.term[t]], e = term_offsets[sq.term[t] + 1];
-            i = lower_bound_doc(doc_ids, b, e, d);
-            here = i < e && doc_ids[i] == d;
+            r = sub_leaf_range(L, sq.src[t]);
+            i = lower_bound_doc(r.ids, r.b, r.e, d);
+            here = i < r.e && r.ids[i] == d;
         }
         if (!here) continue;
         mask |= 1u << t;
@@ -271,40 +357,46 @@ __global__ __launch_bounds__(256) void subquery_match_kernel(const unsigned long
         const uint32_t mode = sq.mode[t];
         if (mode == 2) acc += sq.weight[t];
         else {
-            const uint32_t w = words[i];
-            const float tf = mode == 0 ? (float)(w & 0xffffffu) : 1.0f;
-            acc += sq.weight[t] * (tf / (tf + tf_cache[w >> 24]));
+            const uint32_t w = r.words[i];
+            if (mode == 3) acc += sq.weight[t] * __uint_as_float(w);   // boost x the nested query's own score
+            else {
+                const float tf = mode == 0 ? (float)(w & 0xffffffu) : 1.0f;
+                acc += sq.weight[t] * (tf / (tf + tf_cache[w >> 24]));
+            }
         }
     }
     bool ok = (mask & must_m) == must_m && (mask & not_m) == 0;
-    for (int g = 0; g < 8; g++)
+    bool any_group = false;
+    for (int g = 0; g < 8; g++) {
+        any_group |= group_m[g] != 0;
         if (group_m[g] && (mask & group_m[g]) == 0) ok = false;
-    tmp_ok[i0 - b0] = ok ? 1u : 0u;
-    tmp_score[i0 - b0] = __float_as_uint(acc);
+    }
+    if (!must_m && !any_group && (mask & should_m) == 0) ok = false;   // only Should leaves: one of them has to hold the document
+    tmp_ok[i0 - cand.b] = ok ? 1u : 0u;
+    tmp_score[i0 - cand.b] = __float_as_uint(acc);
 }
 
-hipError_t launch_subquery_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *posting_words, const float *tf_cache,
-                                 const SubqueryDev &sq, uint32_t n_driver, uint32_t *tmp_ok, uint32_t *tmp_score, hipStream_t s) {
-    if (n_driver == 0) return hipSuccess;
-    hipLaunchKernelGGL(subquery_match_kernel, dim3((n_driver + 255) / 256), dim3(256), 0, s, term_offsets, doc_ids, posting_words, tf_cache, sq, tmp_ok,
-                       tmp_score);
+hipError_t launch_subquery_match(const SubqueryLists &L, const float *tf_cache, const SubqueryDev &sq, uint32_t n_cand_max, uint32_t *tmp_ok,
+                                 uint32_t *tmp_score, hipStream_t s) {
+    if (n_cand_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(subquery_match_kernel, dim3((n_cand_max + 255) / 256), dim3(256), 0, s, L, tf_cache, sq, tmp_ok, tmp_score);
     return hipGetLastError();
 }
 
-// matches -> ascending (doc, score bits) list; one block, running offset (the driver's postings are in doc order)
-__global__ __launch_bounds__(256) void subquery_compact_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids, SubqueryDev sq,
-                                                               const uint32_t *tmp_ok, const uint32_t *tmp_score, unsigned long long out_begin,
-                                                               uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count) {
+// matches -> ascending (doc, score bits) list; one block, running offset (the candidates are in doc order)
+__global__ __launch_bounds__(256) void subquery_compact_kernel(SubqueryLists L, SubqueryDev sq, const uint32_t *tmp_ok, const uint32_t *tmp_score,
+                                                               unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count) {
     __shared__ uint32_t wave_sum[4];
     __shared__ uint32_t base_s;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-    const unsigned long long b0 = term_offsets[sq.term[sq.driver]], e0 = term_offsets[sq.term[sq.driver] + 1];
-    const uint32_t n = (uint32_t)(e0 - b0);
+    const SubRange cand = sub_candidates(L, sq);
+    const uint32_t n = (uint32_t)(cand.e - cand.b);
     if (tid == 0) base_s = 0;
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n; i0 += 256) {
         const uint32_t i = i0 + (uint32_t)tid;
         const uint32_t c = i < n ? tmp_ok[i] : 0u;
+        const uint32_t d = c ? cand.ids[cand.b + i] : 0u, sc = c ? tmp_score[i] : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -316,8 +408,8 @@ __global__ __launch_bounds__(256) void subquery_compact_kernel(const unsigned lo
         uint32_t before = base_s;
         for (int w = 0; w < wib; w++) before += wave_sum[w];
         if (c) {
-            out_ids[out_begin + before + incl - 1] = doc_ids[b0 + i];
-            out_words[out_begin + before + incl - 1] = tmp_score[i];
+            out_ids[out_begin + before + incl - 1] = d;
+            out_words[out_begin + before + incl - 1] = sc;
         }
         __syncthreads();
         if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
@@ -326,11 +418,9 @@ __global__ __launch_bounds__(256) void subquery_compact_kernel(const unsigned lo
     if (tid == 0) *out_count = base_s;
 }
 
-hipError_t launch_subquery_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, const SubqueryDev &sq, const uint32_t *tmp_ok,
-                                   const uint32_t *tmp_score, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count,
-                                   hipStream_t s) {
-    hipLaunchKernelGGL(subquery_compact_kernel, dim3(1), dim3(256), 0, s, term_offsets, doc_ids, sq, tmp_ok, tmp_score, out_begin, out_ids, out_words,
-                       out_count);
+hipError_t launch_subquery_compact(const SubqueryLists &L, const SubqueryDev &sq, const uint32_t *tmp_ok, const uint32_t *tmp_score,
+                                   unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count, hipStream_t s) {
+    hipLaunchKernelGGL(subquery_compact_kernel, dim3(1), dim3(256), 0, s, L, sq, tmp_ok, tmp_score, out_begin, out_ids, out_words, out_count);
     return hipGetLastError();
 }
 

@@ -108,7 +108,7 @@ struct Bm25Index {
     // term dictionary (fuzzy expansion) and the scratch of the collectors
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
-    DevBuf s_phrase_tf, s_aux_tfs;
+    DevBuf s_phrase_tf, s_aux_tfs, s_slop_left, s_sub_bits, s_sub_union;
     DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
         s_facet_counts;
     DevBuf s_pf_stack, s_pf_lists, s_pf_result, s_pf_blocks, s_pf_total, s_pf_out;  // prefilter
@@ -450,6 +450,7 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                 }
                 case NIDX_FILTER_PUSH_PHRASE: {
                     PhraseDev ph;
+                    ph.slop = 0;
                     ph.n_terms = (uint32_t)(req->phrase_offsets[op.a + 1] - req->phrase_offsets[op.a]);
                     uint64_t best = ~0ull;
                     ph.driver = 0;
@@ -464,7 +465,7 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                         NIDX_HIP(idx->s_phrase_tf.reserve(best * 4));
                         NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
                                                      seg.pos_offsets.as<unsigned long long>(), seg.positions.as<uint32_t>(), ph, (uint32_t)best,
-                                                     idx->s_phrase_tf.as<uint32_t>(), st));
+                                                     idx->s_phrase_tf.as<uint32_t>(), nullptr, st));
                         NIDX_HIP(launch_phrase_bits(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), ph, (uint32_t)best,
                                                     idx->s_phrase_tf.as<uint32_t>(), slot(depth), st));
                     }
@@ -548,7 +549,21 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     if (n_phrases)
         for (const Bm25Segment &sg : idx->segs)
             if (sg.term_offsets_host[idx->n_terms] && !sg.pos_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase clause on an index opened without positions");
-    // nested BooleanQuerys (NIDX_BM25_SUBQUERY): plain term leaves, at most 16, at least one Must (the list that is walked)
+    for (uint32_t j = 0; j < n_phrases && opt->phrase_slops; j++)
+        if (opt->phrase_slops[j] && opt->phrase_offsets[j + 1] - opt->phrase_offsets[j] < 2)
+            return fail(NIDX_ERR_INVALID_ARGUMENT, "a phrase with slop has at least two terms");
+    // Bm25Weight::for_terms of a phrase: the idf of every term, summed in order
+    auto phrase_weight = [&](uint32_t j, float boost) {
+        float idf_sum = 0.0f;
+        for (uint64_t i = opt->phrase_offsets[j]; i < opt->phrase_offsets[j + 1]; i++) {
+            uint64_t df = 0;
+            for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[opt->phrase_terms[i] + 1] - sg.term_offsets_host[opt->phrase_terms[i]];
+            idf_sum += bm25_idf(df, idx->total_docs);
+        }
+        return idf_sum * (1.0f + kK1) * boost;
+    };
+    // nested BooleanQuerys (NIDX_BM25_SUBQUERY): up to 32 leaves each — terms of the dictionary, term sets, phrases, or nested queries
+    // with a LOWER index (the caller lists a tree's queries children first), so they are materialised in index order
     const uint32_t n_sub = opt->n_subqueries;
     if (n_sub && (!opt->subquery_offsets || !opt->subquery_clauses)) return fail(NIDX_ERR_INVALID_ARGUMENT, "sub-queries without clauses");
     std::vector<SubqueryDev> subs(n_sub);
@@ -560,21 +575,30 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         SubqueryDev &sq = subs[j];
         sq.n = (uint32_t)m;
         sq.driver = 0;
-        bool any_must = false;
         for (uint32_t t = 0; t < sq.n; t++) {
             const nidx_gpu_bm25_clause_t &cl = opt->subquery_clauses[opt->subquery_offsets[j] + t];
-            if (cl.term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY) || cl.term >= idx->n_terms)
-                return fail(NIDX_ERR_UNSUPPORTED, "the leaves of a nested query are plain terms of the dictionary");
             if (cl.occur < 0 || cl.occur > NIDX_OCCUR_SHOULD_GROUP + 7 || cl.mode < 0 || cl.mode > 2) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad clause in a nested query");
-            any_must |= cl.occur == NIDX_OCCUR_MUST;
-            uint64_t df = 0;
-            for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[cl.term + 1] - sg.term_offsets_host[cl.term];
-            sq.term[t] = cl.term;
             sq.occur[t] = (uint8_t)cl.occur;
-            sq.mode[t] = (uint8_t)cl.mode;
-            sq.weight[t] = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
+            if (cl.term & NIDX_BM25_TERM_SET) {   // ConstScorer(boost) over the union
+                const uint32_t a = cl.term & ~NIDX_BM25_TERM_SET;
+                if (a >= n_sets) return fail(NIDX_ERR_INVALID_ARGUMENT, "nested query %u: term set %u out of range", j, a);
+                sq.src[t] = BM25_AUX_TERM | a, sq.mode[t] = NIDX_CONST_SCORE, sq.weight[t] = cl.boost;
+            } else if (cl.term & NIDX_BM25_PHRASE) {
+                const uint32_t a = cl.term & ~NIDX_BM25_PHRASE;
+                if (a >= n_phrases) return fail(NIDX_ERR_INVALID_ARGUMENT, "nested query %u: phrase %u out of range", j, a);
+                sq.src[t] = BM25_AUX_TERM | (n_sets + a), sq.mode[t] = NIDX_TF_FREQ, sq.weight[t] = phrase_weight(a, cl.boost);
+            } else if (cl.term & NIDX_BM25_SUBQUERY) {
+                const uint32_t a = cl.term & ~NIDX_BM25_SUBQUERY;
+                if (a >= j) return fail(NIDX_ERR_INVALID_ARGUMENT, "nested query %u refers to nested query %u: children come first", j, a);
+                sq.src[t] = BM25_AUX_TERM | (n_sets + n_phrases + a), sq.mode[t] = 3, sq.weight[t] = cl.boost;
+            } else {
+                if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "nested query %u: term id %u out of range", j, cl.term);
+                uint64_t df = 0;
+                for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[cl.term + 1] - sg.term_offsets_host[cl.term];
+                sq.src[t] = cl.term, sq.mode[t] = (uint8_t)cl.mode;
+                sq.weight[t] = cl.mode == NIDX_CONST_SCORE ? cl.boost : bm25_idf(df, idx->total_docs) * (1.0f + kK1) * cl.boost;
+            }
         }
-        if (!any_must) return fail(NIDX_ERR_UNSUPPORTED, "a nested query needs at least one Must leaf (a pure disjunction is a required Should group of the outer query)");
     }
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
@@ -612,15 +636,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         if (!(cl.term & NIDX_BM25_TERM_SET) && (cl.term & NIDX_BM25_PHRASE)) {
             const uint32_t j = cl.term & ~NIDX_BM25_PHRASE;
             if (j >= n_phrases) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase %u out of range", j);
-            // Bm25Weight::for_terms: the idf of every term, summed in order
-            float idf_sum = 0.0f;
-            for (uint64_t i = opt->phrase_offsets[j]; i < opt->phrase_offsets[j + 1]; i++) {
-                uint64_t df = 0;
-                for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[opt->phrase_terms[i] + 1] - sg.term_offsets_host[opt->phrase_terms[i]];
-                idf_sum += bm25_idf(df, idx->total_docs);
-            }
             // the phrase's matches are materialised per segment as aux list n_sets + j, with their frequencies
-            dev_clauses[c] = Bm25ClauseDev{BM25_AUX_TERM | (n_sets + j), cl.occur, NIDX_TF_FREQ, idf_sum * (1.0f + kK1) * cl.boost};
+            dev_clauses[c] = Bm25ClauseDev{BM25_AUX_TERM | (n_sets + j), cl.occur, NIDX_TF_FREQ, phrase_weight(j, cl.boost)};
             continue;
         }
         if (cl.term & NIDX_BM25_TERM_SET) {
@@ -698,11 +715,12 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     std::vector<Bm25Work> &work = idx->w_work;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
-        // ---- term sets of this segment: union bitset -> ascending doc list (AutomatonWeight::scorer) ----
+        // ---- the aux lists of this segment, in dependency order: term sets (union bitset -> ascending doc list,
+        // AutomatonWeight::scorer), phrases, nested queries (children before parents); one host round trip for all their counts ----
         const uint32_t n_aux = n_sets + n_phrases + n_sub;
         std::vector<unsigned long long> aux_pairs(2 * (size_t)n_aux + 2, 0);  // [begin, end) per aux list into s_aux_ids
         std::vector<uint32_t> set_counts(n_aux, 0);
-        // layout of the aux arrays: the term sets first (upper bounds), then one region per phrase (driver term's df)
+        // layout of the aux arrays: one region per list, sized by an upper bound of its length
         std::vector<unsigned long long> out_off(n_aux + 1, 0);
         std::vector<PhraseDev> phrases(n_phrases);
         for (uint32_t j = 0; j < n_sets; j++) {
@@ -715,6 +733,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         for (uint32_t j = 0; j < n_phrases; j++) {
             PhraseDev &ph = phrases[j];
             ph.n_terms = (uint32_t)(opt->phrase_offsets[j + 1] - opt->phrase_offsets[j]);
+            ph.slop = opt->phrase_slops ? opt->phrase_slops[j] : 0u;
+            ph.driver = 0;
             uint64_t best = ~0ull;
             for (uint32_t t = 0; t < ph.n_terms; t++) {
                 ph.terms[t] = opt->phrase_terms[opt->phrase_offsets[j] + t];
@@ -723,70 +743,119 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             }
             out_off[n_sets + j + 1] = out_off[n_sets + j] + best;
         }
-        for (uint32_t j = 0; j < n_sub; j++) {   // the shortest Must leaf of this segment is the one that is walked
+        // nested queries: the candidates are the shortest Must leaf (by upper bound: an aux leaf's exact length is on the device only),
+        // else the union of the smallest required Should group, else the union of the Should leaves
+        struct SubPlan { uint32_t union_mask = 0; uint64_t n_cand_max = 0; };
+        std::vector<SubPlan> plans(n_sub);
+        uint64_t max_cand = 0;
+        bool any_union = false;
+        for (uint32_t j = 0; j < n_sub; j++) {
             SubqueryDev &sq = subs[j];
-            uint64_t best = ~0ull;
+            auto upper = [&](uint32_t t) -> uint64_t {
+                if (sq.src[t] & BM25_AUX_TERM) { const uint32_t a = sq.src[t] & ~BM25_AUX_TERM; return out_off[a + 1] - out_off[a]; }
+                return seg.term_offsets_host[sq.src[t] + 1] - seg.term_offsets_host[sq.src[t]];
+            };
+            uint64_t best = ~0ull, group_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, should_sum = 0;
+            uint32_t group_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, should_mask = 0;
+            bool any_must = false;
             for (uint32_t t = 0; t < sq.n; t++) {
-                if (sq.occur[t] != NIDX_OCCUR_MUST) continue;
-                const uint64_t df = seg.term_offsets_host[sq.term[t] + 1] - seg.term_offsets_host[sq.term[t]];
-                if (df < best) { best = df; sq.driver = t; }
+                const uint64_t ub = upper(t);
+                if (sq.occur[t] == NIDX_OCCUR_MUST) {
+                    any_must = true;
+                    if (ub < best) { best = ub; sq.driver = t; }
+                } else if (sq.occur[t] >= NIDX_OCCUR_SHOULD_GROUP) {
+                    group_sum[sq.occur[t] - NIDX_OCCUR_SHOULD_GROUP] += ub, group_mask[sq.occur[t] - NIDX_OCCUR_SHOULD_GROUP] |= 1u << t;
+                } else if (sq.occur[t] == NIDX_OCCUR_SHOULD) should_sum += ub, should_mask |= 1u << t;
             }
-            out_off[n_sets + n_phrases + j + 1] = out_off[n_sets + n_phrases + j] + best;
+            SubPlan &pl = plans[j];
+            if (any_must) pl.n_cand_max = best;
+            else {
+                sq.driver = BM25_SUB_DRIVER_UNION;
+                uint64_t sum = ~0ull;
+                for (int g = 0; g < 8; g++)
+                    if (group_mask[g] && group_sum[g] < sum) sum = group_sum[g], pl.union_mask = group_mask[g];
+                if (!pl.union_mask) sum = should_sum, pl.union_mask = should_mask;   // no positive leaf at all: nothing matches
+                pl.n_cand_max = pl.union_mask ? std::min<uint64_t>(sum, seg.n_docs) : 0;
+                any_union |= pl.union_mask != 0;
+            }
+            if (pl.n_cand_max > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "a posting list of one segment holds more than 2^32 - 1 postings");
+            max_cand = std::max(max_cand, pl.n_cand_max);
+            out_off[n_sets + n_phrases + j + 1] = out_off[n_sets + n_phrases + j] + pl.n_cand_max;
         }
+        const uint32_t words = (seg.n_docs + 63) / 64;
         if (n_aux) {
             NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
             NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
-            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_aux * 4));
-            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, (size_t)n_aux * 4, idx->stream));
+            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_aux * 4 + 4));   // + the count of the union candidates
+            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, (size_t)n_aux * 4 + 4, idx->stream));
+            NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_aux + 1) * 8));
+            NIDX_HIP(hipMemcpyAsync(idx->s_aux_out_off.p, out_off.data(), (size_t)(n_aux + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+        }
+        if (n_sets && words) {
+            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
+            NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, idx->stream));
+            for (uint32_t j = 0; j < n_sets; j++) {
+                const uint32_t nl = (uint32_t)(opt->term_set_offsets[j + 1] - opt->term_set_offsets[j]);
+                if (nl)
+                    NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
+                                                   idx->s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
+                                                   idx->s_set_bits.as<uint64_t>() + (size_t)j * words, idx->stream));
+                if (opt->term_set_complement && opt->term_set_complement[j])
+                    NIDX_HIP(launch_bitset_not(idx->s_set_bits.as<uint64_t>() + (size_t)j * words, words, seg.n_docs, idx->stream));
+            }
+            NIDX_HIP(launch_bitset_compact(idx->s_set_bits.as<uint64_t>(), words, n_sets, idx->s_aux_out_off.as<unsigned long long>(),
+                                           idx->s_aux_ids.as<uint32_t>(), idx->s_set_counts.as<uint32_t>(), idx->stream));
         }
         for (uint32_t j = 0; j < n_phrases; j++) {
             const uint64_t n_driver = out_off[n_sets + j + 1] - out_off[n_sets + j];
             if (n_driver == 0) continue;
             NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 4));
+            uint32_t *slop_left = nullptr;
+            if (phrases[j].slop) {
+                // PhraseScorer's `left` list per document: as many entries as the first term has positions in this segment
+                const uint64_t tb = seg.term_offsets_host[phrases[j].terms[0]], te = seg.term_offsets_host[phrases[j].terms[0] + 1];
+                unsigned long long pr[2] = {0, 0};
+                NIDX_HIP(hipMemcpyAsync(&pr[0], seg.pos_offsets.as<unsigned long long>() + tb, 8, hipMemcpyDeviceToHost, idx->stream));
+                NIDX_HIP(hipMemcpyAsync(&pr[1], seg.pos_offsets.as<unsigned long long>() + te, 8, hipMemcpyDeviceToHost, idx->stream));
+                NIDX_HIP(hipStreamSynchronize(idx->stream));
+                NIDX_HIP(idx->s_slop_left.reserve(std::max<uint64_t>(pr[1] - pr[0], 1) * 8));   // (position, budget used) pairs
+                slop_left = idx->s_slop_left.as<uint32_t>();
+            }
             NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.pos_offsets.as<unsigned long long>(),
-                                         seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, idx->s_phrase_tf.as<uint32_t>(), idx->stream));
+                                         seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, idx->s_phrase_tf.as<uint32_t>(), slop_left, idx->stream));
             NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], idx->s_phrase_tf.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(),
                                            out_off[n_sets + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
                                            idx->s_set_counts.as<uint32_t>() + n_sets + j, idx->stream));
         }
-        for (uint32_t j = 0; j < n_sub; j++) {
-            const uint64_t n_driver = out_off[n_sets + n_phrases + j + 1] - out_off[n_sets + n_phrases + j];
-            if (n_driver == 0) continue;
-            NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 8));   // [n_driver] match flags | [n_driver] score bits
-            uint32_t *tmp_ok = idx->s_phrase_tf.as<uint32_t>(), *tmp_score = tmp_ok + n_driver;
-            NIDX_HIP(launch_subquery_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), idx->tf_cache.as<float>(),
-                                           subs[j], (uint32_t)n_driver, tmp_ok, tmp_score, idx->stream));
-            NIDX_HIP(launch_subquery_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), subs[j], tmp_ok, tmp_score,
-                                             out_off[n_sets + n_phrases + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
-                                             idx->s_set_counts.as<uint32_t>() + n_sets + n_phrases + j, idx->stream));
-        }
-        if (n_phrases + n_sub) {
-            NIDX_HIP(hipMemcpyAsync(set_counts.data() + n_sets, idx->s_set_counts.as<uint32_t>() + n_sets, (size_t)(n_phrases + n_sub) * 4, hipMemcpyDeviceToHost, idx->stream));
-            NIDX_HIP(hipStreamSynchronize(idx->stream));
-        }
-        if (n_sets) {
-            const uint32_t words = (seg.n_docs + 63) / 64;
-            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
-            NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_sets + 1) * 8));
-            NIDX_HIP(hipMemcpyAsync(idx->s_aux_out_off.p, out_off.data(), (size_t)(n_sets + 1) * 8, hipMemcpyHostToDevice, idx->stream));
-            if (words) {
-                NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, idx->stream));
-                for (uint32_t j = 0; j < n_sets; j++) {
-                    const uint32_t nl = (uint32_t)(opt->term_set_offsets[j + 1] - opt->term_set_offsets[j]);
-                    if (nl)
-                        NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
-                                                       idx->s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
-                                                       idx->s_set_bits.as<uint64_t>() + (size_t)j * words, idx->stream));
-                    if (opt->term_set_complement && opt->term_set_complement[j])
-                        NIDX_HIP(launch_bitset_not(idx->s_set_bits.as<uint64_t>() + (size_t)j * words, words, seg.n_docs, idx->stream));
+        if (n_sub) {
+            NIDX_HIP(idx->s_phrase_tf.reserve(std::max<uint64_t>(max_cand, 1) * 8));   // [n] match flags | [n] score bits
+            if (any_union) {
+                NIDX_HIP(idx->s_sub_bits.reserve(std::max<size_t>(words, 1) * 8));
+                NIDX_HIP(idx->s_sub_union.reserve(std::max<uint64_t>(max_cand, 1) * 4));
+            }
+            SubqueryLists L{seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), idx->s_aux_ids.as<uint32_t>(),
+                            idx->s_aux_tfs.as<uint32_t>(), idx->s_aux_out_off.as<unsigned long long>(), idx->s_set_counts.as<uint32_t>(),
+                            idx->s_sub_union.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_aux};
+            for (uint32_t j = 0; j < n_sub; j++) {
+                const SubPlan &pl = plans[j];
+                if (pl.n_cand_max == 0) continue;
+                if (subs[j].driver == BM25_SUB_DRIVER_UNION) {
+                    NIDX_HIP(launch_bitset_fill(idx->s_sub_bits.as<uint64_t>(), words, seg.n_docs, 0, idx->stream));
+                    for (uint32_t t = 0; t < subs[j].n; t++)
+                        if (pl.union_mask >> t & 1) NIDX_HIP(launch_subquery_scatter(L, subs[j].src[t], pl.n_cand_max, idx->s_sub_bits.as<uint64_t>(), idx->stream));
+                    // out_off[0] == 0: the union list starts at the head of its own buffer
+                    NIDX_HIP(launch_bitset_compact(idx->s_sub_bits.as<uint64_t>(), words, 1, idx->s_aux_out_off.as<unsigned long long>(),
+                                                   idx->s_sub_union.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_aux, idx->stream));
                 }
-                NIDX_HIP(launch_bitset_compact(idx->s_set_bits.as<uint64_t>(), words, n_sets, idx->s_aux_out_off.as<unsigned long long>(),
-                                               idx->s_aux_ids.as<uint32_t>(), idx->s_set_counts.as<uint32_t>(), idx->stream));
-                NIDX_HIP(hipMemcpyAsync(set_counts.data(), idx->s_set_counts.p, (size_t)n_sets * 4, hipMemcpyDeviceToHost, idx->stream));
-                NIDX_HIP(hipStreamSynchronize(idx->stream));
+                uint32_t *tmp_ok = idx->s_phrase_tf.as<uint32_t>(), *tmp_score = tmp_ok + max_cand;
+                NIDX_HIP(launch_subquery_match(L, idx->tf_cache.as<float>(), subs[j], (uint32_t)pl.n_cand_max, tmp_ok, tmp_score, idx->stream));
+                NIDX_HIP(launch_subquery_compact(L, subs[j], tmp_ok, tmp_score, out_off[n_sets + n_phrases + j], idx->s_aux_ids.as<uint32_t>(),
+                                                 idx->s_aux_tfs.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_sets + n_phrases + j, idx->stream));
             }
         }
         if (n_aux) {
+            NIDX_HIP(hipMemcpyAsync(set_counts.data(), idx->s_set_counts.p, (size_t)n_aux * 4, hipMemcpyDeviceToHost, idx->stream));
+            NIDX_HIP(hipStreamSynchronize(idx->stream));
             for (uint32_t j = 0; j < n_aux; j++) {
                 aux_pairs[2 * j] = out_off[j];
                 aux_pairs[2 * j + 1] = out_off[j] + set_counts[j];

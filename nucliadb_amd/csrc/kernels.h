@@ -371,39 +371,59 @@ hipError_t launch_fuzzy_match(const uint8_t *dict_bytes, const unsigned long lon
 // set bits -> ascending ids (one block per bitset): out[out_offsets[b] ..), counts[b] = number written
 hipError_t launch_bitset_compact(const uint64_t *bits, uint32_t n_words, uint32_t n_sets, const unsigned long long *out_offsets,
                                  uint32_t *out, uint32_t *counts, hipStream_t s);
-// PhraseQuery (slop 0): for every posting i of the driver term (the rarest of the phrase) tmp_tf[i] = number of start
-// positions at which all terms follow each other in order (0 = the document does not match); then the matches are
-// compacted in document order into (out_ids, out_tfs)[out_begin ..) and *out_count is set.
+// PhraseQuery: for every posting i of the driver term (the rarest of the phrase) tmp_tf[i] = number of matches of the phrase in
+// that document (0 = the document does not match); then the matches are compacted in document order into (out_ids, out_tfs)[out_begin ..)
+// and *out_count is set.  slop 0: the number of start positions at which all terms follow each other in order.  slop > 0: tantivy's
+// PhraseScorer with slop (PhraseQuery::set_slop: a budget of position moves shared by all terms, in both directions) — the positions
+// of term i shifted by n_terms - 1 - i, the running `left` list of (position, budget used) pairs intersected term after term;
+// `left` lives in slop_left, one region of 2 words per position of terms[0].
 struct PhraseDev {
     uint32_t terms[8];     // phrase terms in order
     uint32_t n_terms;      // <= 8
     uint32_t driver;       // index into terms[] of the term whose postings are walked
+    uint32_t slop;
 };
 #define BM25_MAX_PHRASE_TERMS 8
 hipError_t launch_phrase_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const unsigned long long *pos_offsets,
-                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, hipStream_t s);
+                               const uint32_t *positions, PhraseDev ph, uint32_t n_driver, uint32_t *tmp_tf, uint32_t *slop_left, hipStream_t s);
 hipError_t launch_phrase_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, PhraseDev ph, const uint32_t *tmp_tf,
                                  const uint8_t *fieldnorm_ids, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_tfs,
                                  uint32_t *out_count, hipStream_t s);
-// A nested BooleanQuery of plain term leaves with at least one Must leaf (tantivy: a BooleanQuery inside a BooleanQuery — an AND
-// inside an OR, a negated conjunction, a conjunction inside an `Or` formula): its matches are materialised as one more aux list whose
-// posting word is the sub-score's f32 bits (clause mode 3 = pre-scored).  The driver Must leaf's postings are walked, one lane each,
-// the other leaves are probed by binary search; a document matches when every Must leaf holds it, no MustNot leaf does and every
-// required Should group has one that does; its score is the f32 sum of the scoring leaves that hold it, in leaf order.
-#define BM25_MAX_SUBQUERY_LEAVES 16
+// A nested BooleanQuery (tantivy: a BooleanQuery inside a BooleanQuery — an AND inside an OR, a negated conjunction, a disjunction
+// inside a conjunction inside a disjunction ..., a conjunction inside an `Or` formula): its matches are materialised as one more aux
+// list whose posting word is the sub-score's f32 bits (clause mode 3 = pre-scored).  A leaf is a posting list of the dictionary or an
+// aux list materialised before it — a term set, a phrase, or ANOTHER nested query (so trees of any depth are lists of lists).  The
+// candidates are the postings of one leaf (the shortest Must leaf) or, for a query without a Must leaf, the union of the members of
+// one required Should group / of all its Should leaves (scattered into a bitset and compacted); one lane per candidate probes every
+// leaf by binary search.  A document matches when every Must leaf holds it, no MustNot leaf does, every required Should group has a
+// member that does and — without Must leaves and groups — some Should leaf does; its score is the f32 sum of the scoring leaves that
+// hold it, in leaf order.  Aux list a lies at aux_ids[aux_begin[a] .. + aux_counts[a]) — both read on the device, so a chain of
+// nested queries is materialised without a host round trip between its levels.
+#define BM25_MAX_SUBQUERY_LEAVES 32
+#define BM25_SUB_DRIVER_UNION 0xffffffffu
 struct SubqueryDev {
     uint32_t n;        // leaves
-    uint32_t driver;   // index of the Must leaf that is walked (the shortest in this segment)
-    uint32_t term[BM25_MAX_SUBQUERY_LEAVES];
+    uint32_t driver;   // index of the leaf whose postings are the candidates, or BM25_SUB_DRIVER_UNION (the union list)
+    uint32_t src[BM25_MAX_SUBQUERY_LEAVES];    // term id, or BM25_AUX_TERM | aux list
     uint8_t occur[BM25_MAX_SUBQUERY_LEAVES];   // 0 should, 1 must, 2 must-not, 3 + g required Should group g
-    uint8_t mode[BM25_MAX_SUBQUERY_LEAVES];    // 0 stored tf, 1 tf == 1, 2 constant score
+    uint8_t mode[BM25_MAX_SUBQUERY_LEAVES];    // 0 stored tf, 1 tf == 1, 2 constant score, 3 pre-scored (word = f32 bits)
     float weight[BM25_MAX_SUBQUERY_LEAVES];
 };
-hipError_t launch_subquery_match(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *posting_words, const float *tf_cache,
-                                 const SubqueryDev &sq, uint32_t n_driver, uint32_t *tmp_ok, uint32_t *tmp_score, hipStream_t s);
-hipError_t launch_subquery_compact(const unsigned long long *term_offsets, const uint32_t *doc_ids, const SubqueryDev &sq, const uint32_t *tmp_ok,
-                                   const uint32_t *tmp_score, unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count,
-                                   hipStream_t s);
+struct SubqueryLists {   // what a leaf's `src` resolves against
+    const unsigned long long *term_offsets;
+    const uint32_t *doc_ids, *words;          // the segment's postings (word = tf | fieldnorm id << 24)
+    const uint32_t *aux_ids, *aux_words;      // the aux lists materialised so far
+    const unsigned long long *aux_begin;      // [n_aux] first entry of every aux list
+    const uint32_t *aux_counts;               // [n_aux] entries of every aux list
+    const uint32_t *union_ids, *union_count;  // the union candidates (driver == BM25_SUB_DRIVER_UNION)
+};
+// bits |= the documents of leaf `src` (one launch per member of the union)
+hipError_t launch_subquery_scatter(const SubqueryLists &L, uint32_t src, unsigned long long upper_bound, uint64_t *bits, hipStream_t s);
+// n_cand_max: a host-side upper bound of the candidates (the launch shape); the kernels read the exact number on the device
+hipError_t launch_subquery_match(const SubqueryLists &L, const float *tf_cache, const SubqueryDev &sq, uint32_t n_cand_max, uint32_t *tmp_ok,
+                                 uint32_t *tmp_score, hipStream_t s);
+hipError_t launch_subquery_compact(const SubqueryLists &L, const SubqueryDev &sq, const uint32_t *tmp_ok, const uint32_t *tmp_score,
+                                   unsigned long long out_begin, uint32_t *out_ids, uint32_t *out_words, uint32_t *out_count, hipStream_t s);
 // resident posting word: tfs[i] = tf | fieldnorm_ids[doc_ids[i]] << 24 (in place); *flag: bit 0 = a tf >= 2^24, bit 1 = a doc id >= n_docs
 hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
                                       uint32_t *flag, hipStream_t s);

@@ -25,6 +25,8 @@ PhraseQuery's (positions in HBM, phrase lists materialised on the device).
 """
 from __future__ import annotations
 
+import bisect
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
@@ -67,6 +69,15 @@ class Vocabulary:
 
     def lookup(self, term: str) -> Optional[int]:
         return self.ids.get(term)
+
+    def sorted_text_terms(self) -> Tuple[List[bytes], List[int]]:
+        """(term bytes ascending, their ids) of the text field's terms — the order tantivy's term dictionary keeps them in."""
+        cached = getattr(self, "_sorted", None)
+        if cached is None or cached[0] != len(self.ids):
+            rows = sorted((t.encode(), i) for t, i in self.ids.items() if not t.startswith("\x00"))
+            cached = (len(self.ids), [r[0] for r in rows], [r[1] for r in rows])
+            self._sorted = cached
+        return cached[1], cached[2]
 
 
 class TextSegment:
@@ -172,20 +183,12 @@ def _bitset(mask: np.ndarray) -> np.ndarray:
 
 def terms_in_range(vocab: "Vocabulary", lo: Optional[str], lo_incl: bool, hi: Optional[str], hi_incl: bool) -> List[int]:
     """The ids of the text field's terms inside a range of tantivy's RangeQuery (term bytes in lexicographic order; None = open end).
-    The pseudo terms of the other fields (their \x00 prefix) are not terms of the text field."""
-    lo_b = None if lo is None else lo.encode()
-    hi_b = None if hi is None else hi.encode()
-    out = []
-    for t, i in vocab.ids.items():
-        if t.startswith("\x00"):
-            continue
-        b = t.encode()
-        if lo_b is not None and (b < lo_b or (b == lo_b and not lo_incl)):
-            continue
-        if hi_b is not None and (b > hi_b or (b == hi_b and not hi_incl)):
-            continue
-        out.append(i)
-    return sorted(out)
+    The pseudo terms of the other fields (their \x00 prefix) are not terms of the text field.  The dictionary's text terms are kept
+    as one sorted table per vocabulary (rebuilt when it grew), the bounds are two bisections."""
+    keys, ids = vocab.sorted_text_terms()
+    i0 = 0 if lo is None else (bisect.bisect_left if lo_incl else bisect.bisect_right)(keys, lo.encode())
+    i1 = len(keys) if hi is None else (bisect.bisect_right if hi_incl else bisect.bisect_left)(keys, hi.encode())
+    return sorted(ids[i0:i1]) if i0 < i1 else []
 
 
 def deletion_terms(vocab: "Vocabulary", segment_seq: int, deletions: Sequence[Tuple[str, int]]) -> List[int]:
@@ -393,6 +396,7 @@ class QLeaf:
     # `[a TO b]` / `{a TO b}` / `[a TO *]`: (lower token or None, inclusive, upper token or None, inclusive) — a RangeQuery over the
     # text field's terms (byte order), scored ConstScorer(1.0)
     term_range: Optional[Tuple[Optional[str], bool, Optional[str], bool]] = None
+    slop: int = 0          # `"a b"~2`
 
 
 @dataclass
@@ -409,7 +413,7 @@ def parse_text_query(body: str):
     """-> QLeaf | QNode.  Grammar: clause := ['+' | '-'] (word | "phrase" | '(' query ')' | '*') ['^' number], words may
     carry a `text:` field prefix; clauses are joined by AND / OR / NOT or by juxtaposition (= AND: conjunction by default);
     AND binds tighter than OR.  Raises QuerySyntaxError on what tantivy's parser rejects (unbalanced quotes / parentheses,
-    a dangling operator, an unknown field, a range bound that is not one token; phrase slop is refused as NotImplementedError).
+    a dangling operator, an unknown field, a range bound that is not one token).  `"a b"~2` is a phrase with slop.
     Ranges: `[a TO b]` inclusive, `{a TO b}` exclusive, mixed brackets, `*` for an open end."""
     pos, n = 0, len(body)
 
@@ -447,7 +451,7 @@ def parse_text_query(body: str):
             b = parse_boost()
             if b != 1.0:
                 if isinstance(node, QLeaf):
-                    node = QLeaf(node.text, node.boost * b, node.all, node.term_range)
+                    node = QLeaf(node.text, node.boost * b, node.all, node.term_range, node.slop)
                 else:
                     node = QNode(node.op, node.children, node.boost * b)
             return node
@@ -457,9 +461,16 @@ def parse_text_query(body: str):
                 raise QuerySyntaxError("unbalanced quote")
             text = body[pos + 1:j]
             pos = j + 1
-            if pos < n and body[pos] == "~":
-                raise NotImplementedError("phrase slop")
-            return QLeaf(text, parse_boost())
+            slop = 0
+            if pos < n and body[pos] == "~":   # "a b"~2: PhraseQuery::set_slop
+                j = pos + 1
+                while j < n and body[j].isdigit():
+                    j += 1
+                if j == pos + 1:
+                    raise QuerySyntaxError("slop without a number")
+                slop = int(body[pos + 1:j])
+                pos = j
+            return QLeaf(text, parse_boost(), slop=slop)
         if c == "*":
             pos += 1
             return QLeaf("", parse_boost(), all=True)
@@ -575,29 +586,34 @@ def parse_text_query(body: str):
 
 
 def _scaled(leaf: "QLeaf", factor: float) -> "QLeaf":
-    return leaf if factor == 1.0 else QLeaf(leaf.text, leaf.boost * factor, leaf.all, leaf.term_range)
+    return leaf if factor == 1.0 else QLeaf(leaf.text, leaf.boost * factor, leaf.all, leaf.term_range, leaf.slop)
 
 
-def flatten_conjunction(node, nested: bool = True):
-    """The boolean tree as (Must leaves, MustNot leaves, [required OR groups], MustNot sub-trees, Must sub-trees).  A group
-    member is a leaf or — an AND inside an OR, `a OR (b AND c)` — a conjunction node that becomes a nested BooleanQuery
-    (NIDX_BM25_SUBQUERY); a negated conjunction `NOT (a AND b)` and a boosted one `(a b)^2` are sub-trees too.  A boost on an OR
-    group is carried by its members (tantivy multiplies the group's sum: equal for powers of two, else it may differ in the last
-    bit — the oracle follows the mirror).  nested = False: inside a nested query only leaves are left."""
+def flatten_conjunction(node):
+    """One BooleanQuery level of the boolean tree as (Must leaves, MustNot leaves, [required OR groups], MustNot sub-trees, Must
+    sub-trees).  A group member is a leaf or — an AND inside an OR, `a OR (b AND c)` — a (node, boost) pair that becomes a nested
+    BooleanQuery (NIDX_BM25_SUBQUERY); a negated expression `NOT (a AND b)`, `NOT (a OR (b c))` and a boosted conjunction
+    `(a b)^2` are sub-trees too.  A nested query's own children go through this function again, so the tree may be of any depth.
+    A boost on an OR group is carried by its members (tantivy multiplies the group's sum: equal for powers of two, else it may differ
+    in the last bit — the oracle follows the mirror)."""
     musts, nots, groups, not_subs, must_subs = [], [], [], [], []
 
-    def conj_like(nd) -> bool:
-        return isinstance(nd, QNode) and nd.op in ("and", "not")
+    def or_members(nd, factor, members):
+        for c in nd.children:
+            if isinstance(c, QLeaf):
+                members.append(_scaled(c, factor))
+            elif c.op == "or":
+                or_members(c, factor * c.boost, members)   # an OR inside an OR is the same group
+            else:   # a OR (b AND c), a OR (NOT b)
+                members.append((c, factor * (c.boost if c.op == "and" else 1.0)))
 
     def walk(nd, factor=1.0):
         if isinstance(nd, QLeaf):
             musts.append(_scaled(nd, factor))
         elif nd.op == "and":
-            if nd.boost * factor != 1.0 and nested:
+            if nd.boost * factor != 1.0:
                 must_subs.append((nd, nd.boost * factor))   # (a b)^2: BoostQuery over the conjunction's own sum
             else:
-                if nd.boost * factor != 1.0:
-                    raise NotImplementedError("a boosted conjunction nested two levels deep")
                 for ch in nd.children:
                     walk(ch)
         elif nd.op == "not":
@@ -606,28 +622,20 @@ def flatten_conjunction(node, nested: bool = True):
                 nots.append(inner)
             elif inner.op == "or" and all(isinstance(c, QLeaf) for c in inner.children):
                 nots.extend(inner.children)   # NOT (a OR b) = NOT a AND NOT b
-            elif inner.op == "and" and nested:
-                not_subs.append(inner)        # NOT (a AND b): a MustNot nested BooleanQuery
+            elif inner.op == "not":           # NOT (NOT x): a MustNot BooleanQuery[MustNot x], which matches nothing — excludes nothing
+                pass
             else:
-                raise NotImplementedError("negation of a nested boolean expression")
+                not_subs.append(inner)        # NOT (a AND b), NOT (a OR (b AND c)): a MustNot nested BooleanQuery
         elif nd.op == "or":
             members = []
-            for c in nd.children:
-                if isinstance(c, QLeaf):
-                    members.append(_scaled(c, nd.boost * factor))
-                elif conj_like(c) and nested:
-                    members.append((c, nd.boost * factor * (c.boost if c.op == "and" else 1.0)))   # a OR (b AND c), a OR (NOT b)
-                elif isinstance(c, QNode) and c.op == "or":
-                    for cc in c.children:   # an OR inside an OR is the same group
-                        if not isinstance(cc, QLeaf):
-                            raise NotImplementedError("nested boolean expression inside OR")
-                        members.append(_scaled(cc, nd.boost * factor * c.boost))
-                else:
-                    raise NotImplementedError("nested boolean expression inside OR")
+            or_members(nd, nd.boost * factor, members)
             groups.append(members)
 
     walk(node)
     return musts, nots, groups, not_subs, must_subs
+
+
+MAX_NESTED_LEAVES = 32   # BM25_MAX_SUBQUERY_LEAVES
 
 
 class TextSearcher:
@@ -660,63 +668,70 @@ class TextSearcher:
     def _leaf(self, leaf: "QLeaf", occur: int) -> Optional[Clause]:
         """One literal of the grammar through the text field's tokenizer: no token -> no clause, one -> TermQuery with
         frequencies, several -> PhraseQuery (QueryParser::compute_logical_ast_for_leaf)."""
+        if leaf.all:
+            return Clause(self._index.term(ALL_DOCS), occur, _lib.CONST_SCORE, leaf.boost)   # AllQuery
         if leaf.term_range is not None:
             # RangeQuery over the field's term dictionary: the union of the terms inside the bounds, ConstScorer(1.0) x boost
             ids = terms_in_range(self._index.vocab, *leaf.term_range)
-            if not ids:
+            if not len(ids):
                 return Clause(self._index.empty_term, occur, _lib.TF_FREQ, 1.0)   # matches nothing
             return Clause(0, occur, _lib.CONST_SCORE, leaf.boost, term_set=ids)
         words = tokenize(leaf.text)
         if not words:
             return None
         if len(words) > 1:
-            return Clause(0, occur, _lib.TF_FREQ, leaf.boost, term_set=[self._index.term(w) for w in words], phrase=True)
+            return Clause(0, occur, _lib.TF_FREQ, leaf.boost, term_set=[self._index.term(w) for w in words], phrase=True, slop=leaf.slop)
         return Clause(self._index.term(words[0]), occur, _lib.TF_FREQ, leaf.boost)
 
     def _subquery(self, node, occur: int, boost: float) -> Optional[Clause]:
-        """A conjunction (or a negation) below the top level as a nested BooleanQuery: Must / MustNot leaves and required OR
-        groups of single words; the kernels walk its shortest Must list, so it needs one."""
+        """A boolean expression below the level it sits in as a nested BooleanQuery (NIDX_BM25_SUBQUERY) whose leaves are the
+        clauses of ITS level — words, phrases, ranges and further nested queries."""
         inner = QNode(node.op, node.children) if isinstance(node, QNode) else node
-        musts, nots, groups, not_subs, must_subs = flatten_conjunction(inner, nested=False)
-        leaves: List[Clause] = []
-
-        def word(leaf, occ):
-            if leaf.term_range is not None:
-                raise NotImplementedError("a range inside a nested boolean expression")
-            if leaf.all:
-                return Clause(self._index.term(ALL_DOCS), occ, _lib.CONST_SCORE, leaf.boost)
-            words = tokenize(leaf.text)
-            if not words:
-                return None
-            if len(words) > 1:
-                raise NotImplementedError("a phrase inside a nested boolean expression")
-            return Clause(self._index.term(words[0]), occ, _lib.TF_FREQ, leaf.boost)
-
-        for leaf in musts:
-            c = word(leaf, _lib.OCCUR_MUST)
-            if c is not None:
-                leaves.append(c)
-        for g, members in enumerate(groups):
-            if g >= 8:
-                raise NotImplementedError("more than 8 OR groups in one nested query")
-            leaves += [c for c in (word(m, _lib.OCCUR_SHOULD_GROUP + g) for m in members) if c is not None]
-        for leaf in nots:
-            c = word(leaf, _lib.OCCUR_MUST_NOT)
-            if c is not None:
-                leaves.append(c)
-        if not any(l.occur == _lib.OCCUR_MUST for l in leaves):
-            if isinstance(node, QNode) and node.op == "not":   # `a OR (NOT b)`: BooleanQuery[MustNot b] matches nothing in tantivy
-                return None
-            raise NotImplementedError("a nested boolean expression without a required word")
-        if len(leaves) > 16:
-            raise NotImplementedError("more than 16 leaves in a nested boolean expression")
+        leaves, positive = self._boolean(inner)
+        if not positive:   # `a OR (NOT b)`: BooleanQuery[MustNot b] matches nothing in tantivy
+            return Clause(self._index.empty_term, occur, _lib.TF_FREQ, 1.0) if occur == _lib.OCCUR_MUST else None
+        if len(leaves) > MAX_NESTED_LEAVES:
+            raise ValueError(f"more than {MAX_NESTED_LEAVES} clauses in one nested boolean expression")
         return Clause(0, occur, _lib.TF_FREQ, boost, subquery=leaves)
+
+    def _boolean(self, ast) -> Tuple[List[Clause], bool]:
+        """The clauses of ONE BooleanQuery level (tantivy's QueryParser with set_conjunction_by_default, reader.rs:372-377):
+        juxtaposed literals are Must, `+` / `-` prefixes, AND / OR / NOT, parentheses, "phrases"[~slop], ranges, `text:` field
+        prefixes and `^boost`; flattened to Must / MustNot clauses and required Should groups (one per OR), whatever nests
+        deeper becomes a nested query.  -> (clauses, has a positive clause)"""
+        musts, nots, groups, not_subs, must_subs = flatten_conjunction(ast)
+        clauses: List[Clause] = []
+        positive = False
+        for nd, b in must_subs:   # a boosted conjunction: BoostQuery(BooleanQuery[Must ...])
+            c = self._subquery(QNode("and", nd.children), _lib.OCCUR_MUST, b)
+            if c is not None:
+                clauses.append(c)
+                positive = True
+        for leaf in musts:
+            c = self._leaf(leaf, _lib.OCCUR_MUST)
+            if c is not None:
+                clauses.append(c)
+                positive = True
+        for g, leaves in enumerate(groups):
+            occur = _lib.OCCUR_SHOULD_GROUP + g if g < 8 else _lib.OCCUR_SHOULD   # past 8 groups: a nested query of its own
+            members = [self._subquery(l[0], occur, l[1]) if isinstance(l, tuple) else self._leaf(l, occur) for l in leaves]
+            members = [m for m in members if m is not None]
+            if members:
+                clauses += members if g < 8 else [Clause(0, _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0, subquery=members)]
+                positive = True
+        for leaf in nots:
+            c = self._leaf(leaf, _lib.OCCUR_MUST_NOT)
+            if c is not None:
+                clauses.append(c)
+        for nd in not_subs:   # NOT (a AND b)
+            c = self._subquery(nd, _lib.OCCUR_MUST_NOT, 1.0)
+            if c is not None:
+                clauses.append(c)
+        return clauses, positive
 
     def _clauses(self, request: DocumentSearchRequest) -> List[Clause]:
         """create_query (search_query.rs:92-126): Must(main query) + Must(filters).  The main query is the body through
-        tantivy's QueryParser with set_conjunction_by_default (reader.rs:372-377): juxtaposed literals are Must, `+` / `-`
-        prefixes, AND / OR / NOT, parentheses, "phrases", `text:` field prefixes and `^boost`; the boolean tree is
-        flattened to Must / MustNot clauses and required Should groups (one per OR)."""
+        tantivy's QueryParser (see _boolean)."""
         body = self.adapt_text(request.body)
         clauses: List[Clause] = []
         if body == "":
@@ -729,39 +744,7 @@ class TextSearcher:
             if ast is None:
                 clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, 1.0))
             else:
-                musts, nots, groups, not_subs, must_subs = flatten_conjunction(ast)
-                positive = False
-                for nd, b in must_subs:   # a boosted conjunction: BoostQuery(BooleanQuery[Must ...])
-                    c = self._subquery(QNode("and", nd.children), _lib.OCCUR_MUST, b)
-                    if c is not None:
-                        clauses.append(c)
-                        positive = True
-                for leaf in musts:
-                    if leaf.all:
-                        clauses.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, leaf.boost))
-                        positive = True
-                        continue
-                    c = self._leaf(leaf, _lib.OCCUR_MUST)
-                    if c is not None:
-                        clauses.append(c)
-                        positive = True
-                for g, leaves in enumerate(groups):
-                    if g >= 8:
-                        raise NotImplementedError("more than 8 OR groups in one query")
-                    members = [self._subquery(l[0], _lib.OCCUR_SHOULD_GROUP + g, l[1]) if isinstance(l, tuple) else self._leaf(l, _lib.OCCUR_SHOULD_GROUP + g)
-                               for l in leaves]
-                    members = [m for m in members if m is not None]
-                    if members:
-                        clauses += members
-                        positive = True
-                for leaf in nots:
-                    c = self._leaf(leaf, _lib.OCCUR_MUST_NOT)
-                    if c is not None:
-                        clauses.append(c)
-                for nd in not_subs:   # NOT (a AND b)
-                    c = self._subquery(nd, _lib.OCCUR_MUST_NOT, 1.0)
-                    if c is not None:
-                        clauses.append(c)
+                clauses, positive = self._boolean(ast)
                 if not positive:  # only exclusions (or nothing survived the tokenizer): a BooleanQuery without a positive clause matches nothing
                     clauses.append(Clause(self._index.empty_term, _lib.OCCUR_MUST, _lib.TF_FREQ, 1.0))
         for lab in request.label_filter or []:
@@ -1013,72 +996,77 @@ class ParagraphSearcher:
         next_group = [1]   # group 0 is the keyword group
 
         def new_group() -> int:
+            """-> the occur code of the next required Should group; past the eighth: OCCUR_SHOULD, and the caller wraps the
+            members into a nested Should-only query under Occur::Must (which is what the group is in tantivy anyway)."""
             g = next_group[0]
             next_group[0] += 1
-            if g >= 8:
-                raise NotImplementedError("more than 8 required Should groups")
-            return G + g
+            return G + g if g < 8 else _lib.OCCUR_SHOULD
 
         def conj(expr):   # expr under Occur::Must
             if isinstance(expr, FormulaLiteral):
                 out.append(self._label(expr.label, _lib.OCCUR_MUST, boost))
             elif isinstance(expr, FormulaNot):
                 out.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
-                if isinstance(expr.operand, FormulaLiteral):
-                    out.append(self._label(expr.operand.label, _lib.OCCUR_MUST_NOT, boost))
-                elif isinstance(expr.operand, FormulaOp) and expr.operand.operator == "or" and all(isinstance(e, FormulaLiteral) for e in expr.operand.operands):
-                    out.extend(self._label(e.label, _lib.OCCUR_MUST_NOT, boost) for e in expr.operand.operands)   # Not(Or(..)) = none of them
-                else:   # Not(And(..)): BooleanQuery[Must AllQuery, MustNot BooleanQuery[Must ...]]
-                    out.append(nested(expr.operand, _lib.OCCUR_MUST_NOT))
+                out.extend(negated(expr.operand))
             elif isinstance(expr, FormulaOp) and expr.operator == "and":
                 for e in expr.operands:
                     conj(e)
             elif isinstance(expr, FormulaOp) and expr.operator == "or":
-                disj(expr, new_group())
+                occur = new_group()
+                members: List[Clause] = []
+                disj(expr, occur, members)
+                out.extend(members if occur != _lib.OCCUR_SHOULD else [Clause(0, _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0, subquery=members)])
             else:
                 raise TypeError(f"not a formula: {expr!r}")
 
+        def negated(operand) -> List[Clause]:
+            """The MustNot half of translate_not (query_io.rs:28-41: Not(x) = BooleanQuery[Must AllQuery, MustNot x])."""
+            if isinstance(operand, FormulaLiteral):
+                return [self._label(operand.label, _lib.OCCUR_MUST_NOT, boost)]
+            if isinstance(operand, FormulaOp) and operand.operator == "or" and all(isinstance(e, FormulaLiteral) for e in operand.operands):
+                return [self._label(e.label, _lib.OCCUR_MUST_NOT, boost) for e in operand.operands]   # Not(Or(..)) = none of them
+            return [nested(operand, _lib.OCCUR_MUST_NOT)]   # Not(And(..)), Not(Not(..)), Not(Or(And(..), ..))
+
         def nested(expr, occur: int) -> Clause:
-            """A conjunction or a negation below an `Or` (or a negated conjunction) as a nested BooleanQuery of label leaves
-            (translate_expression, query_io.rs:28-41: Not(x) = BooleanQuery[Must AllQuery, MustNot x])."""
+            """An expression below the level it sits in as a nested BooleanQuery (translate_expression recurses the same way): a
+            conjunction's operands are Must leaves, a negation is Must AllQuery + MustNot, a disjunction is a required Should
+            group; operands that are not literals nest again."""
             leaves: List[Clause] = []
             groups_in = [0]
 
             def inner(e):
                 if isinstance(e, FormulaLiteral):
                     leaves.append(self._label(e.label, _lib.OCCUR_MUST, boost))
-                elif isinstance(e, FormulaNot) and isinstance(e.operand, FormulaLiteral):
+                elif isinstance(e, FormulaNot):
                     leaves.append(Clause(self._index.term(ALL_DOCS), _lib.OCCUR_MUST, _lib.CONST_SCORE, boost))
-                    leaves.append(self._label(e.operand.label, _lib.OCCUR_MUST_NOT, boost))
+                    leaves.extend(negated(e.operand))
                 elif isinstance(e, FormulaOp) and e.operator == "and":
                     for x in e.operands:
                         inner(x)
-                elif isinstance(e, FormulaOp) and e.operator == "or" and all(isinstance(x, FormulaLiteral) for x in e.operands):
+                elif isinstance(e, FormulaOp) and e.operator == "or":
                     g = groups_in[0]
                     groups_in[0] += 1
-                    if g >= 8:
-                        raise NotImplementedError("more than 8 Or groups inside a nested formula")
-                    leaves.extend(self._label(x.label, G + g, boost) for x in e.operands)
+                    members: List[Clause] = []
+                    disj(e, G + g if g < 8 else _lib.OCCUR_SHOULD, members)
+                    leaves.extend(members if g < 8 else [Clause(0, _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0, subquery=members)])
                 else:
-                    raise NotImplementedError("a formula nested three levels deep")
+                    raise TypeError(f"not a formula: {e!r}")
 
             inner(expr)
-            if not any(l.occur == _lib.OCCUR_MUST for l in leaves):   # And(Or(a, b), Or(c, d)) below an Or: nothing to walk
-                raise NotImplementedError("a nested formula without a required literal")
-            if len(leaves) > 16:
-                raise NotImplementedError("more than 16 literals in a nested formula")
+            if len(leaves) > MAX_NESTED_LEAVES:
+                raise ValueError(f"more than {MAX_NESTED_LEAVES} literals in one level of a nested formula")
             return Clause(0, occur, _lib.TF_BASIC, 1.0, subquery=leaves)
 
-        def disj(expr, occur: int):   # expr as members of one required group
+        def disj(expr, occur: int, members: List[Clause]):   # expr as members of one required group
             if isinstance(expr, FormulaLiteral):
-                out.append(self._label(expr.label, occur, boost))
+                members.append(self._label(expr.label, occur, boost))
             elif isinstance(expr, FormulaOp) and expr.operator == "or":
                 for e in expr.operands:
-                    disj(e, occur)
+                    disj(e, occur, members)
             else:   # And(..) / Not(..) below an Or
-                out.append(nested(expr, occur))
+                members.append(nested(expr, occur))
 
-        def prefilter_sets(occur: int):
+        def prefilter_sets(occur: int, out: List[Clause]):
             fields = sorted({"\x00fid:" + rid + "/" + fid.lstrip("/") for rid, fid in prefilter.fields if fid is not None})
             resources = sorted({"\x00uuid:" + rid for rid, fid in prefilter.fields if fid is None})
             for keys in (fields, resources):   # SetQuery = TermSetQuery: ConstScorer over the union of the terms
@@ -1090,14 +1078,17 @@ class ParagraphSearcher:
         if request.filter_or and (request.filtering_formula is not None or some):
             g = new_group()
             if request.filtering_formula is not None:
-                disj(request.filtering_formula, g)
+                disj(request.filtering_formula, g, out)
             if some:
-                prefilter_sets(g)
+                prefilter_sets(g, out)
         else:
             if request.filtering_formula is not None:
                 conj(request.filtering_formula)
             if some:
-                prefilter_sets(new_group())
+                g = new_group()
+                members: List[Clause] = []
+                prefilter_sets(g, members)
+                out.extend(members if g != _lib.OCCUR_SHOULD else [Clause(0, _lib.OCCUR_MUST, _lib.TF_BASIC, 1.0, subquery=members)])
         return out
 
     def _filters(self, request: ParagraphSearchRequest, prefilter: Optional[PrefilterResult], boost: float) -> List[Clause]:

@@ -753,9 +753,46 @@ class Bm25Index:
         return od[:n].copy(), os_[:n].copy(), total.value
 
 
+def phrase_count_with_slop(pos_lists, slop: int) -> int:
+    """PhraseScorer::phrase_count for one document (tantivy 0.26 phrase_scorer.rs; PhraseQuery::set_slop's contract: "the slop can be
+    considered a budget between all terms ... slop works in both directions, so the order of the terms may change as long as they
+    respect the slop"): pos_lists[i] = ascending positions of the i-th term.  Term i's positions are shifted by n - 1 - i
+    (PostingsWithOffset), `left` starts as the first term's list with no budget used; against each next term a left value matches a
+    right value when |left - right| + used <= slop, a later left value not beyond right that still fits the budget is the better
+    match and is taken instead, the match continues as (right, used + distance); the length of the last list is the phrase
+    frequency.  slop 0 = the plain sorted-list intersection.
+    PARITY UNPINNED: the crate's source is not in /root/reference (Cargo.lock pins tantivy 0.26.1); this follows its documented
+    contract, the reference has no test with a slop."""
+    n = len(pos_lists)
+    left = [(p + (n - 1), 0) for p in pos_lists[0]]
+    for i in range(1, n):
+        right = [p + (n - 1 - i) for p in pos_lists[i]]
+        out = []
+        li = ri = 0
+        while li < len(left) and ri < len(right):
+            (lv, used), rv = left[li], right[ri]
+            if abs(lv - rv) + used <= slop:
+                while li + 1 < len(left) and left[li + 1][0] <= rv and rv - left[li + 1][0] + left[li + 1][1] <= slop:
+                    li += 1
+                lv, used = left[li]
+                out.append((rv, used + abs(lv - rv)))
+                li += 1
+                ri += 1
+            elif lv < rv:
+                li += 1
+            else:
+                ri += 1
+        left = out
+        if not left:
+            return 0
+    return len(left)
+
+
 def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
-    """BooleanQuerys nested inside the BooleanQuery (tantivy's QueryParser for `a OR (b AND c)`, `NOT (a AND b)`, `(a AND b)^2`; a
-    conjunction inside an `Or` filtering formula): clauses = (term, occur, mode, boost) leaves or ("sub", occur, boost, [leaves]).
+    """BooleanQuerys nested inside the BooleanQuery to any depth (tantivy's QueryParser for `a OR (b AND c)`, `NOT (a AND b)`,
+    `(a AND b)^2`, `a AND (b OR (c AND "d e"~1))`; nested filtering formulas): clauses = (term, occur, mode, boost) leaves,
+    ("sub", occur, boost, [clauses]) nested queries, ("set", occur, boost, [terms], complement) ConstScorer unions and
+    ("phrase", occur, boost, [terms], slop) PhraseQuerys.
     Document at a time in f32 like orc_bm25_search: a nested query matches by its own boolean structure, its score is the f32
     sum of its scoring leaves that hold the document (leaf order, from +0), the outer clause adds boost * that score at its
     position; TopDocs order (score desc by total order, doc asc).  -> (docaddr u64[], score f32[], total)"""
@@ -775,6 +812,35 @@ def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
         fn = cache[index.fieldnorm_ids[docs]]
         return docs, (w * (tf / (tf + fn))).astype(f32)
 
+    def set_scores(terms, boost, complement):
+        parts = [index.doc_ids[int(index.term_offsets[t]): int(index.term_offsets[t + 1])] for t in terms]
+        docs = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint32)
+        if complement:
+            docs = np.setdiff1d(np.arange(n_docs, dtype=np.uint32), docs)
+        return docs.astype(np.uint32), np.full(docs.size, f32(boost), f32)
+
+    def phrase_scores(terms, boost, slop):
+        lists = []
+        for t in terms:
+            b, e = int(index.term_offsets[t]), int(index.term_offsets[t + 1])
+            lists.append({int(index.doc_ids[i]): i for i in range(b, e)})
+        common = set(lists[0])
+        for l in lists[1:]:
+            common &= set(l)
+        idf_sum = f32(0.0)
+        for t in terms:   # Bm25Weight::for_terms
+            idf_sum = f32(idf_sum + f32(bm25_idf(int(index.term_offsets[t + 1]) - int(index.term_offsets[t]), n_docs)))
+        w = idf_sum * (f32(1.0) + K1) * f32(boost)
+        docs, sc = [], []
+        for d in sorted(common):
+            pos = [index.positions[int(index.pos_offsets[l[d]]): int(index.pos_offsets[l[d] + 1])].tolist() for l in lists]
+            tf = phrase_count_with_slop(pos, int(slop))
+            if tf:
+                tf = f32(tf)
+                docs.append(d)
+                sc.append(f32(w * (tf / (tf + cache[index.fieldnorm_ids[d]]))))
+        return np.array(docs, np.uint32), np.array(sc, f32)
+
     def boolean(cl):
         """-> dict doc -> f32 score of one BooleanQuery level (leaves only, or leaves + evaluated sub-queries)"""
         acc, mask, musts, nots, groups, plain = {}, {}, [], [], {}, []
@@ -784,6 +850,12 @@ def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
                 sub = boolean(leaves)
                 docs = np.fromiter(sorted(sub), np.uint32, len(sub))
                 sc = np.array([f32(boost) * sub[int(d)] for d in docs], f32)
+            elif c[0] == "set":
+                _, occur, boost, terms, complement = c
+                docs, sc = set_scores(terms, boost, complement)
+            elif c[0] == "phrase":
+                _, occur, boost, terms, slop = c
+                docs, sc = phrase_scores(terms, boost, slop)
             else:
                 term, occur, mode, boost = c
                 docs, sc = leaf_scores(term, mode, boost)

@@ -286,6 +286,86 @@ def test_nested_boolean_queries_match_the_oracle(orc, corpus):
     s.close()
 
 
+def _tree_to_oracle(c):
+    if c.subquery is not None:
+        return ("sub", c.occur, c.boost, [_tree_to_oracle(l) for l in c.subquery])
+    if c.term_set is not None and c.phrase:
+        return ("phrase", c.occur, c.boost, [int(t) for t in c.term_set], c.slop)
+    if c.term_set is not None:
+        return ("set", c.occur, c.boost, [int(t) for t in c.term_set], c.complement)
+    return (c.term, c.occur, c.mode, c.boost)
+
+
+def test_boolean_trees_of_any_depth_match_the_oracle(orc):
+    """Round 4: a leaf of a nested BooleanQuery may be a term set, a phrase (with or without slop) or ANOTHER nested query, and a
+    nested query needs no Must leaf (its candidates are then the union of one required Should group, or of its Should leaves) —
+    every shape tantivy's QueryParser can build for a parenthesised body (nidx_text/src/reader.rs:357-376) and every nesting of a
+    filtering formula (nidx_paragraph/src/search_query.rs:88-143, query_io.rs:28-66).  Random trees up to four levels deep,
+    materialised on the device children first, against the oracle's recursive document-at-a-time evaluation: doc addresses, ranks,
+    f32 score bits and Count."""
+    rng = np.random.default_rng(91)
+    vocab = 120
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    docs = [rng.choice(vocab, size=int(rng.integers(3, 40)), p=p) for _ in range(8000)]
+    alive = orc.bitset(8000, ones=np.nonzero(rng.random(8000) < 0.9)[0].tolist())
+    seg = Bm25Segment.from_term_docs(docs, vocab, alive=alive, with_positions=True)
+    s = Bm25Searcher.open([seg])
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive, seg.pos_offsets, seg.positions)
+    G = _lib.OCCUR_SHOULD_GROUP
+
+    def leaf(occur):
+        kind = rng.random()
+        boost = float(rng.choice([1.0, 0.5, 2.0, 3.0]))
+        if kind < 0.55:
+            return Clause(int(rng.integers(0, vocab)), occur, int(rng.choice([FREQ, BASIC, CONST])), boost)
+        if kind < 0.75:
+            return Clause(0, occur, CONST, boost, term_set=sorted(set(rng.integers(0, vocab, int(rng.integers(1, 5))).tolist())), complement=bool(rng.random() < 0.2))
+        return Clause(0, occur, FREQ, boost, term_set=rng.integers(0, 12, int(rng.integers(2, 4))).tolist(), phrase=True, slop=int(rng.choice([0, 0, 1, 3])))
+
+    def tree(depth, occur):
+        shape = rng.random()
+        if shape < 0.3:     # a conjunction: Must leaves, maybe exclusions
+            occurs = [M] * int(rng.integers(1, 4)) + [N] * int(rng.integers(0, 2))
+        elif shape < 0.55:  # a disjunction: only Should leaves (no list to walk: the union is materialised)
+            occurs = [S] * int(rng.integers(1, 5)) + [N] * int(rng.integers(0, 2))
+        elif shape < 0.75:  # required groups without a Must leaf
+            occurs = [G] * int(rng.integers(1, 3)) + [G + 1] * int(rng.integers(1, 3)) + [S] * int(rng.integers(0, 2))
+        else:               # everything
+            occurs = [int(rng.choice([S, M, N, G, G + 3])) for _ in range(int(rng.integers(2, 7)))]
+        kids = [tree(depth - 1, o) if depth > 0 and rng.random() < 0.45 else leaf(o) for o in occurs]
+        order = rng.permutation(len(kids))
+        return Clause(0, occur, boost=float(rng.choice([1.0, 0.5, 2.5])), subquery=[kids[i] for i in order])
+
+    queries = [
+        [Clause(0, M, subquery=[Clause(1, S), Clause(2, S)])],                                                     # (b OR c) as a nested query
+        [Clause(5, S), Clause(0, S, subquery=[Clause(1, M), Clause(0, M, subquery=[Clause(2, S), Clause(0, S, subquery=[Clause(3, M), Clause(4, M)])])])],
+        [Clause(0, S, subquery=[Clause(0, G, subquery=[Clause(1, M), Clause(2, M)]), Clause(0, G, subquery=[Clause(3, M), Clause(4, M)])])],
+        [Clause(0, M, subquery=[Clause(7, N)]), Clause(3, S)],                                                     # only exclusions: matches nothing
+        [Clause(0, S, subquery=[Clause(0, M, FREQ, 1.0, term_set=[0, 1], phrase=True, slop=1), Clause(0, M, CONST, 2.0, term_set=[5, 6, 7])]), Clause(90)],
+        [Clause(0, N, subquery=[Clause(0, S, subquery=[Clause(1, M), Clause(2, M)]), Clause(9, S)]), Clause(0, M, CONST, 1.0, term_set=[3], complement=True)],
+        [Clause(0, S, FREQ, 2.0, term_set=[0, 1, 2], phrase=True, slop=2), Clause(0, S, FREQ, 1.0, term_set=[1, 0], phrase=True, slop=2)],
+    ]
+    for _ in range(50):
+        q = [leaf(int(rng.choice([S, S, M, N]))) for _ in range(int(rng.integers(0, 3)))]
+        q += [tree(int(rng.integers(1, 4)), int(rng.choice([S, S, M, N, G]))) for _ in range(int(rng.integers(1, 3)))]
+        order = rng.permutation(len(q))
+        queries.append([q[i] for i in order])
+    for k in (20, 3):
+        r = s.search_batch_ex(queries, k)
+        for i, q in enumerate(queries):
+            wd, ws, wt = orc.bm25_nested_search(oidx, [_tree_to_oracle(c) for c in q], k)
+            n = int(r["count"][i])
+            assert r["total"][i] == wt, (i, r["total"][i], wt)
+            assert n == len(wd), (i, n, len(wd))
+            assert np.array_equal(r["docaddr"][i, :n], wd), (i, r["docaddr"][i, :n], wd)
+            assert np.array_equal(bits(r["score"][i, :n]), bits(ws)), (i, r["score"][i, :n], ws)
+    # the limits are errors, not wrong answers: 33 leaves in one nested query; a nested query that refers to a later one
+    with pytest.raises(_lib.NidxGpuError):
+        s.search_batch_ex([[Clause(0, S, subquery=[Clause(i, S) for i in range(33)])]], 5)
+    s.close()
+
+
 def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
     """nidx_gpu_bm25_search_submit / _wait: several batches in flight, waited for out of order, give what nidx_gpu_bm25_search gives
     for each; a fifth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term

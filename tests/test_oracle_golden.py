@@ -581,3 +581,57 @@ def test_nested_query_evaluator_equals_the_c_oracle_on_flat_queries():
         wd, ws, wt = idx.search(q, 25)
         gd, gs, gt = orc.bm25_nested_search(idx, q, 25)
         assert gt == wt and np.array_equal(gd, wd) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), q
+
+
+def test_nested_evaluator_sets_and_phrases_equal_the_c_oracle_and_slop_contract():
+    """The leaf kinds round 4 added to oracle.bm25_nested_search — ("set", ..) ConstScorer unions / complements and ("phrase", ..)
+    PhraseQuerys — evaluate at the top level exactly like the C oracle's term-set and phrase clauses (slop 0); the slop matcher is
+    then checked against PhraseQuery::set_slop's documented contract (a budget of moves shared by the terms, both directions:
+    "A B C"~1 matches "A X B C" and "A B X C", not "A X B X C"; "A B"~1 does not match "B A", ~2 does)."""
+    import numpy as np
+
+    from nucliadb_amd.bm25 import Bm25Segment
+    from oracle import oracle as orc
+
+    orc.build()
+    rng = np.random.default_rng(15)
+    vocab = 40
+    docs = [rng.integers(0, vocab, int(rng.integers(3, 30))) for _ in range(1500)]
+    seg = Bm25Segment.from_term_docs(docs, vocab, with_positions=True)
+    idx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, None, seg.pos_offsets, seg.positions)
+    for _ in range(40):
+        flat, nested = [], []
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 3))
+            occur, boost = int(rng.choice([0, 0, 1, 2, 3])), float(rng.choice([1.0, 0.5, 2.0]))
+            if kind == 0:
+                t, mode = int(rng.integers(0, vocab)), int(rng.choice([0, 1, 2]))
+                flat.append((t, occur, mode, boost))
+                nested.append((t, occur, mode, boost))
+            elif kind == 1:
+                terms, comp = sorted(set(rng.integers(0, vocab, int(rng.integers(1, 4))).tolist())), bool(rng.random() < 0.3)
+                flat.append((0, occur, 2, boost, terms, comp))
+                nested.append(("set", occur, boost, terms, comp))
+            else:
+                terms = rng.integers(0, vocab, int(rng.integers(2, 4))).tolist()
+                flat.append((0, occur, 0, boost, terms, False, True))
+                nested.append(("phrase", occur, boost, terms, 0))
+        wd, ws, _, wt, _ = idx.search_ex(flat, 30)
+        gd, gs, gt = orc.bm25_nested_search(idx, nested, 30)
+        assert gt == wt and np.array_equal(gd, wd) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), nested
+
+    def count(text, phrase, slop):
+        toks = text.split()
+        return orc.phrase_count_with_slop([[i for i, w in enumerate(toks) if w == p] for p in phrase.split()], slop)
+
+    assert count("a x b c", "a b c", 1) == 1 and count("a b x c", "a b c", 1) == 1 and count("a x b x c", "a b c", 1) == 0
+    assert count("a x b x c", "a b c", 2) == 1
+    assert count("b a", "a b", 1) == 0 and count("b a", "a b", 2) == 1 and count("a b", "a b", 0) == 1
+    assert count("a b a b", "a b", 0) == 2 and count("a c b", "a b", 1) == 1 and count("a c c b", "a b", 1) == 0
+    # slop 0 is the exact phrase for random documents
+    for _ in range(200):
+        toks = rng.integers(0, 4, int(rng.integers(2, 12))).tolist()
+        ph = rng.integers(0, 4, int(rng.integers(2, 4))).tolist()
+        exact = sum(1 for s in range(len(toks) - len(ph) + 1) if toks[s:s + len(ph)] == ph)
+        lists = [[i for i, w in enumerate(toks) if w == p] for p in ph]
+        assert orc.phrase_count_with_slop(lists, 0) == (exact if all(lists) else 0)

@@ -81,9 +81,21 @@ def test_tantivy_grammar_subset_parses_like_the_query_parser():
     for bad in ['"enough test', "enough test\"", "a AND", "a OR", "(a b", "a b)", "enough - test", "title:x", "a^"]:
         with pytest.raises(QuerySyntaxError):
             parse_text_query(bad)
-    for refused in ['"a b"~2']:
-        with pytest.raises(NotImplementedError):
-            flatten_conjunction(parse_text_query(refused))
+    # phrase slop (round 4): `"a b"~2` is a PhraseQuery with set_slop(2); a boost may follow
+    leaf = parse_text_query('"a b"~2^3')
+    assert (leaf.text, leaf.slop, leaf.boost) == ("a b", 2, 3.0) and parse_text_query('"a b"').slop == 0
+    with pytest.raises(QuerySyntaxError):
+        parse_text_query('"a b"~')
+    # deeper trees (round 4): every level of the tree flattens the same way, what nests below it is a (node, boost) member or a sub-tree
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("x (a OR (b (c OR (d e))))"))
+    inner = g[0][1][0]   # b (c OR (d e))
+    assert [l.text for l in m] == ["x"] and g[0][0].text == "a" and inner.op == "and"
+    m2, n2, g2, ns2, ms2 = flatten_conjunction(inner)
+    assert [l.text for l in m2] == ["b"] and g2[0][0].text == "c" and [l.text for l in g2[0][1][0].children] == ["d", "e"]
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("z NOT (a OR (b c))"))
+    assert [l.text for l in m] == ["z"] and not_subs[0].op == "or"
+    m, n, g, not_subs, must_subs = flatten_conjunction(parse_text_query("a OR (b OR (c d))"))   # an OR inside an OR: one group
+    assert g[0][0].text == "a" and g[0][1].text == "b" and g[0][2][0].op == "and"
     # ranges over the text field's terms: inclusive / exclusive / open ends, a field prefix, a boost; bounds are single tokens
     from nucliadb_amd.text import Vocabulary, terms_in_range
 
@@ -153,3 +165,63 @@ def test_tricky_resource_of_the_reference_at_the_host_level():
     assert parse_query("it's not that to", stop) == lit("to")
     assert parse_query("some ' document", stop) == lit("document")
     assert parse_query("important", stop) == lit("important")
+
+
+class _StubIndex:
+    """What TextSearcher / ParagraphSearcher need of an index to map a request to clauses (no device)."""
+
+    def __init__(self, words):
+        from nucliadb_amd.text import ALL_DOCS, NOT_REPEATED, Vocabulary
+
+        self.vocab = Vocabulary()
+        for w in list(words) + [ALL_DOCS, NOT_REPEATED]:
+            self.vocab.id(w)
+        self.empty_term = len(self.vocab.ids)
+
+    def term(self, w):
+        t = self.vocab.lookup(w)
+        return self.empty_term if t is None else t
+
+
+def _shape(c):
+    """A clause tree as nested tuples: ("sub", occur, [children]) / ("phrase", occur, slop) / ("set", occur, n) / (occur,)"""
+    if c.subquery is not None:
+        return ("sub", c.occur, [_shape(l) for l in c.subquery])
+    if c.term_set is not None and c.phrase:
+        return ("phrase", c.occur, c.slop)
+    if c.term_set is not None:
+        return ("set", c.occur, len(c.term_set))
+    return (c.occur,)
+
+
+def test_every_parsed_body_and_formula_maps_to_a_clause_tree():
+    """Round 4: nothing tantivy's QueryParser parses (nidx_text/src/reader.rs:357-376) and no nesting of a filtering formula
+    (nidx_paragraph/src/search_query.rs:88-143) is refused any more — the host mapping on a stub index: the tree of nested
+    BooleanQuerys each request becomes."""
+    from nucliadb_amd import _lib
+    from nucliadb_amd.text import (DocumentSearchRequest, FormulaLiteral as L, FormulaNot, FormulaOp, ParagraphSearcher, ParagraphSearchRequest,
+                                   TextSearcher)
+
+    M, S, N, G = _lib.OCCUR_MUST, _lib.OCCUR_SHOULD, _lib.OCCUR_MUST_NOT, _lib.OCCUR_SHOULD_GROUP
+    ts = TextSearcher(_StubIndex(list("abcdefgh")))
+    tree = lambda body: [_shape(c) for c in ts._clauses(DocumentSearchRequest(body=body))]
+    assert tree("a OR (b (c OR (d e)))") == [(G,), ("sub", G, [(M,), (G,), ("sub", G, [(M,), (M,)])])]
+    assert tree("a ((b OR c) (d OR e))") == [(M,), (G,), (G,), (G + 1,), (G + 1,)]                  # a conjunction flattens into its level
+    assert tree("h OR ((b OR c) (d OR e))") == [(G,), ("sub", G, [(G,), (G,), (G + 1,), (G + 1,)])]   # a nested query without a Must leaf
+    assert tree("a NOT (b OR (c d))") == [(M,), ("sub", N, [(G,), ("sub", G, [(M,), (M,)])])]
+    assert tree('a OR (b "c d"~2 [e TO g])') == [(G,), ("sub", G, [(M,), ("phrase", M, 2), ("set", M, 3)])]
+    assert tree("a OR (NOT b)") == [(G,)] and tree("(a (b c)^2)^3 OR d")[0][0] == "sub"
+    nine = " ".join(f"({x} OR h)" for x in "abcdefgh") + " (a OR b)"
+    t9 = tree(nine)
+    assert [x for x in t9 if x[0] == "sub"] == [("sub", M, [(S,), (S,)])] and len(t9) == 17       # the ninth group nests
+    with pytest.raises(ValueError):
+        tree("a OR (" + " ".join("abcdefgh"[i % 8] for i in range(33)) + ")")
+    ps = ParagraphSearcher(_StubIndex(["\x00label:/a", "\x00label:/b", "\x00label:/c", "\x00label:/d"]))
+    form = lambda f, **kw: [_shape(c) for c in ps._filter_query(ParagraphSearchRequest(body="", filtering_formula=f, **kw), None, 1.0)]
+    a, b, c, d = L("/a"), L("/b"), L("/c"), L("/d")
+    assert form(FormulaOp("or", [FormulaOp("and", [FormulaOp("or", [a, b]), FormulaOp("or", [c, d])]), a])) == \
+        [("sub", G + 1, [(G,), (G,), (G + 1,), (G + 1,)]), (G + 1,)]
+    assert form(FormulaNot(FormulaOp("or", [FormulaOp("and", [a, b]), c]))) == [(M,), ("sub", N, [("sub", G, [(M,), (M,)]), (G,)])]
+    assert form(FormulaNot(FormulaNot(a))) == [(M,), ("sub", N, [(M,), (N,)])]
+    deep = FormulaOp("and", [a, FormulaOp("or", [b, FormulaOp("and", [c, FormulaOp("or", [d, FormulaNot(FormulaOp("and", [a, b]))])])])])
+    assert form(deep) == [(M,), (G + 1,), ("sub", G + 1, [(M,), (G,), ("sub", G, [(M,), ("sub", N, [(M,), (M,)])])])]

@@ -415,9 +415,21 @@ def test_paragraph_filtering_formula_reference_cases():
     # a negated conjunction under And: everything but (/tantivy AND /label2)
     f = FormulaOp("and", [FormulaNot(FormulaOp("and", [FormulaLiteral("/tantivy"), FormulaLiteral("/label2")]))])
     assert s.search(req(f)).total == 4
-    with pytest.raises(NotImplementedError):   # no required literal to walk inside the nested query
-        s.search(req(FormulaOp("or", [FormulaOp("and", [FormulaOp("or", [FormulaLiteral("/a"), FormulaLiteral("/b")]),
-                                                          FormulaOp("or", [FormulaLiteral("/c"), FormulaLiteral("/d")])]), FormulaLiteral("/e")])))
+    # round 4: a nested query without a required literal (And of two Ors below an Or: the candidates are the union of one
+    # group), three and four levels, a negated disjunction of conjunctions, a double negation
+    L = FormulaLiteral
+    f = FormulaOp("or", [FormulaOp("and", [FormulaOp("or", [L("/tantivy"), L("/e/myentity")]), FormulaOp("or", [L("/label2"), L("/nope")])]), L("/e/myentity")])
+    assert s.search(req(f)).total == 2       # (/tantivy AND /label2) of resource 2, + the title
+    f = FormulaOp("or", [FormulaOp("and", [L("/l/mylabel"), FormulaOp("or", [FormulaOp("and", [L("/tantivy"), FormulaNot(L("/label2"))]), L("/e/myentity")])]), L("/nope")])
+    assert s.search(req(f)).total == 2       # mylabel AND ((tantivy AND NOT label2) OR myentity): the first body paragraph + the title
+    f = FormulaNot(FormulaOp("or", [FormulaOp("and", [L("/tantivy"), L("/label2")]), FormulaOp("and", [L("/l/mylabel"), L("/e/myentity")])]))
+    assert s.search(req(f)).total == 3
+    assert s.search(req(FormulaNot(FormulaNot(L("/tantivy"))))).total == 2
+    f = FormulaOp("and", [FormulaOp("or", [L("/tantivy"), FormulaOp("and", [L("/l/mylabel"), FormulaOp("or", [L("/label2"), FormulaOp("and", [L("/e/myentity"), L("/l/mylabel")])])])])])
+    assert s.search(req(f)).total == 4       # four levels: everything but the summary
+    # more than eight Or groups under an And: the ninth and later become nested queries of their own
+    many = FormulaOp("and", [FormulaOp("or", [L("/l/mylabel"), L(f"/x{i}")]) for i in range(10)])
+    assert s.search(req(many)).total == 4
     s.close()
 
 
@@ -494,6 +506,63 @@ def test_text_query_grammar_reference_cases():
     assert q("little NOT (little AND enough)").total == 1 and q("enough NOT (enough AND test)").total == 0
     one, boosted = q("enough test").results[0].score.bm25, q("(enough test)^2").results[0].score.bm25
     assert np.float32(boosted) == np.float32(one) * np.float32(2.0)
-    with pytest.raises(NotImplementedError):
-        q("a OR (b (c OR (d e)))")   # three levels
+    # round 4: three levels and more, nested queries without a required word, slop
+    assert q("mischievous OR (enough (prince OR (to test)))").total == 1 and q("mischievous OR (enough (prince OR (to mischievous)))").total == 0
+    assert q("(prince OR enough) AND (little OR (this (is OR was)))").total == 2
+    assert q("mischievous OR ((prince OR enough) (little OR test))").total == 2
+    assert q("NOT (prince OR (enough mischievous)) test").total == 1 and q("NOT (prince OR (enough test)) test").total == 0
+    assert q('"enough test"~1').total == 1 and q('"enough test"~0').total == 0 and q('"this test"~2').total == 0 and q('"this test"~3').total == 1
+    assert q('"test enough"~1').total == 0 and q('"test enough"~3').total == 1     # both words move: out of order costs the distance
+    assert q('prince OR ("is to"~1 test)').total == 2
+    s.close()
+
+
+def _to_oracle(c):
+    if c.subquery is not None:
+        return ("sub", c.occur, c.boost, [_to_oracle(l) for l in c.subquery])
+    if c.term_set is not None and c.phrase:
+        return ("phrase", c.occur, c.boost, [int(t) for t in c.term_set], c.slop)
+    if c.term_set is not None:
+        return ("set", c.occur, c.boost, [int(t) for t in c.term_set], c.complement)
+    return (c.term, c.occur, c.mode, c.boost)
+
+
+def test_ranges_deep_trees_and_slop_through_the_text_searcher_match_the_oracle(orc):
+    """TextSearcher.search on bodies tantivy's QueryParser accepts (nidx_text/src/reader.rs:357-376) whose clauses round 3 refused or
+    never sent to the device: range clauses (`[a TO b]`, `{a TO b}`, open ends, boosts — RangeQuery = ConstScorer over the terms
+    inside the bounds), boolean trees three and four levels deep, nested queries without a required word, ranges and phrases
+    inside nested queries, phrases with slop.  Ids, ranks, score bits and Count against the oracle's tree evaluation of the same
+    clause tree (orc.bm25_nested_search, pinned to the C oracle for every leaf kind in tests/test_oracle_golden.py)."""
+    rng = np.random.default_rng(77)
+    words = [f"w{i:02d}" for i in range(24)]
+    p = 1.0 / np.arange(1, len(words) + 1)
+    p /= p.sum()
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(3, 14)), p=p)) for _ in range(600)]
+    d = [TextDocument(_hex(i), "/a/body", t) for i, t in enumerate(texts)]
+    s = TextSearcher.open([TextSegment(d, Vocabulary())])
+    seg = s._index.searcher.segments[0]
+    oidx = orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, seg.alive, seg.pos_offsets, seg.positions)
+    bodies = [
+        "text:[w10 TO w20]", "{w10 TO w20}", "[w20 TO *]", "{* TO w02]", "[w10 TO w12]^2.5 w03", "w01 OR [w18 TO w23]", "[x TO z]", "w00 -[w05 TO w23]",
+        "w01 (w02 OR (w03 (w04 OR w05)))", "w09 OR (w02 (w03 OR (w04 w05)))", "NOT (w01 OR (w02 w03)) w04", "w09 OR ((w01 OR w02) (w03 OR w04))",
+        "w01 OR (w02 OR (w03 w04))", "(w01 (w02 OR w03))^2 OR w04", "w11 OR (w02 (w03 OR (w04 (w05 OR (w06 w00)))))",
+        "w12 OR (w02 [w10 TO w20])", 'w13 OR (w02 "w00 w01")', 'w14 OR ("w00 w01"~2 w02)', "w15 OR (w00 -(w01 OR (w02 w03)))",
+        '"w00 w01"~1', '"w00 w01 w02"~3', '"w01 w00"~2', '"w00 w01"~0', '("w00 w01"~1)^3 OR w20',
+        "w16 OR ((w00 OR [w20 TO w23]) (w01 OR \"w02 w03\"~1))",
+    ]
+    for body in bodies:
+        for k in (25, 3):
+            request = DocumentSearchRequest(body=body, result_per_page=k)
+            clauses = s._clauses(request)
+            r = s._index.searcher.search_batch_ex([clauses], k)
+            wd, ws, wt = orc.bm25_nested_search(oidx, [_to_oracle(c) for c in clauses], k)
+            n = int(r["count"][0])
+            assert r["total"][0] == wt and n == len(wd), (body, r["total"][0], wt)
+            assert np.array_equal(r["docaddr"][0, :n], wd), body
+            assert np.array_equal(r["score"][0, :n].view(np.uint32), ws.view(np.uint32)), body
+            resp = s.search(request)
+            assert resp.total == wt and [x.score.bm25 for x in resp.results] == [float(x) for x in ws[: len(resp.results)]], body
+    # every body above matches something except the empty range; the range clauses really are unions of several terms
+    assert s.search(DocumentSearchRequest(body="[x TO z]", result_per_page=5)).total == 0
+    assert s.search(DocumentSearchRequest(body="[w10 TO w20]", result_per_page=5)).total > s.search(DocumentSearchRequest(body="w10", result_per_page=5)).total > 0
     s.close()
