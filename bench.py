@@ -1107,16 +1107,64 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
         osegs.append(orc.Segment(x_host[bounds[s]: bounds[s + 1]], similarity=orc.SIM_COSINE, order=orc.ORDER_HASWELL,
                                  graph=orc.Hnsw.deserialize_v2(g, e)))
     build_s = time.time() - t0
-    # the device on the same segmented index through the host-buffer API (sequential segments + Fssc on the host)
+    # the device on the same segmented index: (a) nidx_gpu_vector_search_submit / _wait with three batches in flight — every segment's
+    # walks in ONE launch per batch (hnsw_search_segments_kernel), Fssc on the device, one transfer of k hits per query; (b) the
+    # blocking host-buffer entry point, which takes the same path one batch at a time; (c) the round-3 path for comparison: a launch,
+    # a transfer and a wait per segment, Fssc on the host (tunable serial_segments)
     qh = qpool[0].cpu().numpy()
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     hv, hsc, hc, hsg = np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32), np.zeros((B, k), np.uint32)
-    for i in range(3):
-        if i == 1:
-            t1 = time.perf_counter()
-        _lib.check(L.nidx_gpu_vector_search(hs, qh.ctypes.data, B, C.byref(p), None, hsg.ctypes.data, None, hv.ctypes.data, hsc.ctypes.data,
-                                            hc.ctypes.data, None))
-    gpu_qps = B * 2 / (time.perf_counter() - t1)
+
+    def blocking(n_batches):
+        for _ in range(n_batches):
+            _lib.check(L.nidx_gpu_vector_search(hs, qh.ctypes.data, B, C.byref(p), None, hsg.ctypes.data, None, hv.ctypes.data, hsc.ctypes.data,
+                                                hc.ctypes.data, None))
+
+    _lib.check(L.nidx_gpu_vector_set_tunable(hs, b"serial_segments", 1))
+    blocking(1)
+    t1 = time.perf_counter()
+    blocking(2)
+    serial_qps = B * 2 / (time.perf_counter() - t1)
+    serial_ids = (hsg.copy(), hv.copy(), hc.copy())
+    _lib.check(L.nidx_gpu_vector_set_tunable(hs, b"serial_segments", 0))
+    blocking(1)
+    t1 = time.perf_counter()
+    blocking(3)
+    gpu_qps = B * 3 / (time.perf_counter() - t1)
+    one_launch_equals_serial = bool(np.array_equal(hc, serial_ids[2]) and all(
+        np.array_equal(hsg[i, : hc[i]], serial_ids[0][i, : hc[i]]) and np.array_equal(hv[i, : hc[i]], serial_ids[1][i, : hc[i]]) for i in range(B)))
+    n_pool = qpool.shape[0]
+    nfl, n_timed = 3, 12
+    _lib.check(L.nidx_gpu_vector_set_tunable(hs, b"pipeline_depth", nfl))
+    outs = [[np.zeros((B, k), np.uint32) for _ in range(3)] + [np.zeros((B, k), np.float32), np.zeros(B, np.uint32)] for _ in range(nfl)]
+
+    def pipelined(n_batches):
+        tickets = []
+        for i in range(n_batches + nfl):
+            if i >= nfl:
+                o = outs[i % nfl]
+                _lib.check(L.nidx_gpu_vector_search_wait(hs, tickets[i - nfl], o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, o[3].ctypes.data,
+                                                         o[4].ctypes.data, None))
+            if i < n_batches:
+                t = C.c_uint64(0)
+                _lib.check(L.nidx_gpu_vector_search_submit(hs, qpool[i % n_pool].data_ptr(), B, d, C.byref(p), None, C.byref(t)))
+                tickets.append(t.value)
+
+    pipelined(nfl)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pipelined(n_timed)
+    pipe_qps = B * n_timed / (time.perf_counter() - t1)
+    # the walks' algorithmic bytes (evals x 4D + expansions x 256) from the oracle's counters on a sample of segments
+    walk_bytes = None
+    try:
+        sample = [osegs[i] for i in sorted({0, S // 2, S - 1})]
+        st = np.concatenate([sg_.hnsw_search_batch(qh[:64], k, threads=threads, want_stats=True)[3] for sg_ in sample]).astype(np.float64)
+        walk_bytes = float(st[:, 0].mean() * 4 * d + st[:, 1].mean() * 256)
+        walk_evals = float(st[:, 0].mean())
+    except Exception as e:  # noqa: BLE001 — the figure is an annotation
+        walk_evals = None
+        print("segment regime: no walk counters (%r)" % (e,), file=sys.stderr)
     L.nidx_gpu_vector_close(hs)
     nq = min(a.cpu_queries, max(threads * 4, 512))
     qs = qpool.reshape(-1, d)[:nq].cpu().numpy()
@@ -1130,6 +1178,14 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
     out = {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
            "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
+           "device_same_index_pipelined_queries_per_s": pipe_qps, "device_same_index_serial_segments_queries_per_s": serial_qps,
+           "one_launch_ids_identical_to_a_launch_per_segment": one_launch_equals_serial,
+           "device_entry": "nidx_gpu_vector_search_submit / _wait, %d batches of %d in flight, %d timed: one launch of %d x %d walks per batch + Fssc on the device" % (nfl, B, n_timed, B, S),
+           "device_walk": None if walk_bytes is None else {
+               "distance_evals_per_walk": walk_evals, "algorithmic_bytes_per_walk": walk_bytes, "walks_per_query": S,
+               "achieved_GBps": pipe_qps * S * walk_bytes / 1e9, "frac_of_hbm_peak": pipe_qps * S * walk_bytes / 1e9 / HBM_PEAK_GBS,
+               "queries_per_s_at_hbm_peak": HBM_PEAK_GBS * 1e9 / (S * walk_bytes),
+               "note": "every query walks every segment (Searcher::_search): %d walks x %.0f B; the flat index answers a query with one walk" % (S, walk_bytes)},
            "device_ids_identical_to_oracle": "%d/%d (the timed baseline sums in AVX2 order, the device in WAVE64 order: near-ties may flip)" % (same, m),
            "avx2_vs_wave64": score_bound(sc[:m], ss[:m], hc[:m], hsc[:m], same_l)}
     # recall@k of the REFERENCE'S OWN REGIME (every segment searched at ef = 30, merged by Fssc) against the exact scan of the
@@ -1225,6 +1281,19 @@ def bench_hnsw(a, L, dev, rank, world):
         "parity": head.get("parity"),
     }
     cfgd.update(extra)
+    # the figures of the nested blocks a reader of the top level needs, as scalars
+    seg_reg = (head.get("cpu") or {}).get("segment_regime") or {}
+    bm, hy = head.get("bm25") or {}, head.get("hybrid") or {}
+    cfgd.update({
+        "ef_upper": max(1, a.ef_upper), "build_ef_upper": max(1, a.build_ef_upper),
+        "bm25_postings_per_s": bm.get("value"), "bm25_queries_per_s": bm.get("queries_per_s"),
+        "bm25_roofline_frac": (bm.get("roofline") or {}).get("frac"), "bm25_kernel_ms": (bm.get("roofline") or {}).get("kernel_ms"),
+        "hybrid_queries_per_s": hy.get("value"),
+        "segment_regime_device_qps": seg_reg.get("device_same_index_pipelined_queries_per_s"),
+        "segment_regime_device_blocking_qps": seg_reg.get("device_same_index_host_buffer_queries_per_s"),
+        "segment_regime_device_frac_of_hbm_peak": (seg_reg.get("device_walk") or {}).get("frac_of_hbm_peak"),
+        "segment_regime_cpu_qps": seg_reg.get("value"), "segment_regime_segments": seg_reg.get("segments"),
+    })
     if second is not None:
         cfgd["uniform_corpus" if second["corpus"] == "uniform" else "second_corpus"] = {
             "workload": "hnsw: %d x %d-dim cosine (%s corpus), k=%d, batch=%d queries" % (n, d, second["corpus"], k, B),
@@ -1239,7 +1308,8 @@ def bench_hnsw(a, L, dev, rank, world):
                     "find the exact top-10 among near-ties, for the reference either; it is the worst-case access pattern (every neighbour unvisited)",
         }
     line = {
-        "metric": "queries/sec + recall@%d (768-dim cosine k-NN, HNSW M=30 ef=30, k=%d)" % (k, k),
+        "metric": "queries/sec + recall@%d (768-dim cosine k-NN, HNSW M=30 ef=30 ef_upper=%d build_ef_upper=%d, k=%d)" % (
+            k, max(1, a.ef_upper), max(1, a.build_ef_upper), k),
         "value": total_q / head["elapsed"],
         "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["elapsed"] / head["steps_timed"] * 1e3,
@@ -1376,7 +1446,7 @@ class Bm25Bench:
 
     K = 20
 
-    def __init__(self, a, L, dev, rank, n_docs, n_pool=4):
+    def __init__(self, a, L, dev, rank, n_docs, n_pool=32):
         from nucliadb_amd import _lib
         from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
 

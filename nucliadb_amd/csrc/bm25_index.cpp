@@ -1214,12 +1214,30 @@ int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu
     // (resize, not assign: the search zeroes the counts itself and nothing is read beyond a query's count)
     slot->r_docaddr.resize((size_t)nq * kk1), slot->r_score.resize((size_t)nq * kk1);
     slot->r_count.resize(nq), slot->r_total.resize(nq), slot->r_postings.resize(nq);
-    idx->swap_slot(*slot);
-    idx->async_slot = slot;
-    const int32_t rc = bm25_search_locked(idx, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
-                                          slot->r_total.data(), slot->r_postings.data());
-    idx->async_slot = nullptr;
-    idx->swap_slot(*slot);
+    // The index wears the slot's stream, events and staging while the batch is prepared; every way out of the search — an error
+    // code, a std::bad_alloc from its host vectors — takes them off again, and a failed batch leaves nothing queued on the slot's
+    // stream that could still read the staging the next submit rewrites.
+    struct WearSlot {
+        Bm25Index *idx;
+        Bm25Slot *slot;
+        bool ok = false;
+        WearSlot(Bm25Index *i, Bm25Slot *s) : idx(i), slot(s) {
+            idx->swap_slot(*slot);
+            idx->async_slot = slot;
+        }
+        ~WearSlot() {
+            if (!ok) (void)hipStreamSynchronize(idx->stream);
+            idx->async_slot = nullptr;
+            idx->swap_slot(*slot);
+        }
+    };
+    int32_t rc;
+    {
+        WearSlot worn(idx, slot);
+        rc = bm25_search_locked(idx, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
+                                slot->r_total.data(), slot->r_postings.data());
+        worn.ok = rc == NIDX_OK;
+    }
     if (rc != NIDX_OK) return rc;
     slot->busy = true;
     slot->ticket = idx->next_ticket++;

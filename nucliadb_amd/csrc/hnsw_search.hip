@@ -26,9 +26,10 @@ __device__ inline bool rows_equal(const SegDev &seg, uint32_t a, uint32_t b, int
     return __all(eq);
 }
 
-template <int NJ, int EVR, int MINW, int EFL>
-__global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One query's whole search in one workgroup.  Shared by the two launch forms below: one segment per launch (arguments in the
+// kernel-argument segment) and every HNSW segment of an index in ONE launch (arguments of block b's segment read from a table in HBM).
+template <int NJ, int EVR, int EFL>
+__device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a, const uint32_t qi, unsigned char *smem) {
     SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
     __shared__ uint32_t res_addr[64 * EFL];
@@ -37,7 +38,6 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
 
     const int lane = threadIdx.x & 63;
     const bool ctl = (nidx_tid() >> 6) == 0;
-    const uint32_t qi = blockIdx.x;
     const bool cosine = a.seg.similarity == 1;
     const int k = (int)a.k;
 
@@ -264,7 +264,34 @@ __global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a
 }
 
 template <int NJ, int EVR, int MINW, int EFL>
+__global__ __launch_bounds__(256, MINW) void hnsw_search_kernel(HnswSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    hnsw_search_body<NJ, EVR, EFL>(a, blockIdx.x, smem);
+}
+
+// Searcher::_search's loop over the segments (nidx_vector/src/searcher.rs:270-287) as ONE grid: block b walks query b % nq of
+// segment b / nq.  The reference's indexes ARE many segments (merges stop at 200 k records, nidx/src/settings.rs:258-278: 10 M vectors
+// = 50 segments); a launch per segment leaves the device idle behind the longest walk of each of them 50 times per batch.  Blocks
+// of one segment are neighbours, so its upper layers and hub rows stay in the L2 of the XCDs that walk it.
+template <int NJ, int EVR, int MINW, int EFL>
+__global__ __launch_bounds__(256, MINW) void hnsw_search_segments_kernel(const HnswSearchArgs *__restrict__ table, uint32_t nq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t s = blockIdx.x / nq;
+    const HnswSearchArgs a = table[s];   // uniform address, read-only: scalar loads
+    hnsw_search_body<NJ, EVR, EFL>(a, blockIdx.x - s * nq, smem);
+}
+
+template <int NJ, int EVR, int MINW, int EFL>
 static hipError_t launch_v(const HnswSearchArgs &a, int waves, hipStream_t s) {
+    if (a.seg_table) {
+        size_t smem = sizeof(SearchShared) + ((size_t)4 << a.vis_log2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_segments_kernel<NJ, EVR, MINW, EFL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hnsw_search_segments_kernel<NJ, EVR, MINW, EFL>), dim3(a.n_queries * a.n_table), dim3(64 * waves), smem, s,
+                           a.seg_table, a.n_queries);
+        return hipGetLastError();
+    }
     size_t smem = sizeof(SearchShared) + ((size_t)4 << a.vis_log2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&hnsw_search_kernel<NJ, EVR, MINW, EFL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -176,9 +176,35 @@ struct HnswSearchArgs {
     // 0 = 1, the reference's greedy descent (search.rs:318-324: k = 1 on the layers above 0).  Only the "ef_upper" tunable sets it: the
     // descent then keeps ef_upper results per upper layer and hands all of them to the next layer as entry points (<= 64).
     uint32_t ef_upper = 0;
+    // launch_hnsw_search only: nullptr, or n_table argument records in HBM — one per segment, every one with the launch shape
+    // (dp, k, vis_log2, ef_search, ef_upper, n_queries, eval_rows, min_waves) of this record: ONE grid of n_queries x n_table
+    // walks (hnsw_search_segments_kernel); the kernels never read these two fields
+    const HnswSearchArgs *seg_table = nullptr;
+    uint32_t n_table = 0;
 };
 #define NIDX_DUMP_STRIDE 512
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipStream_t s);
+
+// Fssc on the device (fssc_device.hip): the merge of every segment's hits of a query (searcher.rs:149-199).
+struct FsscSegDev {
+    const float *vectors;               // [n][dp] rows (the `seen` set compares vector bytes)
+    const uint32_t *para_of_vec;        // nullptr = identity
+    const unsigned long long *key_ids;  // [n_paragraphs] paragraph identity across segments; nullptr = (segment, paragraph)
+    const uint32_t *vec, *count;        // this segment's result rows [nq][k] and [nq]; count == nullptr: the segment was not searched
+    const float *score;
+    uint32_t dp, pad;
+};
+struct FsscArgs {
+    const FsscSegDev *segs;   // [n_segs] in HBM, index order
+    uint32_t n_segs, nq, k, dim;
+    int with_duplicates;
+    uint32_t *offered;        // with_duplicates == 0: scratch [nq][offered_stride][3] (score bits, segment, vector)
+    uint32_t offered_stride;  // >= the most candidates one query can be offered (searched segments x k)
+    uint32_t *out_seg, *out_para, *out_vec;   // [nq][k]
+    float *out_score;
+    uint32_t *out_count;      // [nq]
+};
+hipError_t launch_fssc_merge(const FsscArgs &a, hipStream_t s);
 
 // closest_up_nodes with the candidate pool and the visited set in HBM (hnsw_spill.hip): the exact fallback for the
 // queries whose walk outgrew the LDS structures of hnsw_search_kernel.

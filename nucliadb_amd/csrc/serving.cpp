@@ -6,12 +6,14 @@
 // therefore owns `depth` slots — a HIP stream, pinned staging and a device result block each — and a caller keeps several
 // batches in flight:  ticket = submit(batch i + 2);  wait(ticket of batch i);  ...
 //
-//   submit  stages the queries (host rows through pinned memory, or a device pointer as it is), launches every segment's search
-//           on the slot's stream into the slot's result block, queues ONE device-to-host transfer of the block
-//           ([flag words | per segment: vectors, scores, counts]) and returns;
-//   wait    blocks until the transfer has landed, re-runs — only when a segment's flag word says a bounded on-chip structure
-//           overflowed — that segment through the exact fallback (segment_search_exact), merges the segments with Fssc and
-//           fills the caller's arrays.
+//   submit  stages the queries (host rows through pinned memory, or a device pointer as it is), searches the segments on the
+//           slot's stream into the slot's result block — every segment that takes the plain HNSW arm in ONE launch of
+//           n_queries x n_segments walks (hnsw_search_segments_kernel: the reference's index at 10 M vectors IS 50 segments,
+//           nidx/src/settings.rs:258-278), the other arms one launch each — merges them per query on the device (Fssc,
+//           fssc_device.hip), queues ONE device-to-host transfer of [flag words | merged hits] and returns;
+//   wait    blocks until the transfer has landed and fills the caller's arrays; only when a segment's flag word says a bounded
+//           on-chip structure overflowed it fetches the per-segment rows, re-runs that segment through the exact fallback
+//           (segment_search_exact) and merges on the host (the same Fssc, csrc/vector_index.cpp: fssc_merge).
 //
 // Results are those of nidx_gpu_vector_search for the same batch (tests/test_serving_gpu.py).
 #include <condition_variable>
@@ -37,8 +39,11 @@ struct SearchSlot {
     uint64_t ticket = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    DevBuf d_queries, d_block, d_filter;
-    PinBuf pin_in, pin_out;
+    DevBuf d_queries, d_block, d_filter, d_tables, d_offered;
+    PinBuf pin_in, pin_out, pin_tables;
+    bool dirty = false;                      // work may be queued on `stream` / the flag words may be set: clean before reuse
+    bool merged = false;                     // the block carries the device Fssc's hits
+    size_t flag_bytes = 0;                   // flag words at the head of d_block
     // the batch in flight
     uint32_t nq = 0;
     nidx_gpu_vector_search_params_t params{};
@@ -71,8 +76,10 @@ void VectorIndex::pipeline_config(int32_t depth) {
 }
 
 namespace {
-// result block of a slot: [flag word per segment, padded to 16 words][per segment: nq*k vectors | nq*k scores | nq counts]
+// result block of a slot: [flag word per segment, padded to 16 words][merged hits: nq*k segments | paragraphs | vectors | scores,
+// nq counts][per segment: nq*k vectors | nq*k scores | nq counts]
 inline size_t flag_words(size_t S) { return (S + 15) / 16 * 16; }
+inline size_t merged_words(uint32_t nq, uint32_t k) { return (size_t)nq * k * 4 + nq; }
 inline size_t seg_words(uint32_t nq, uint32_t k) { return (size_t)nq * k * 2 + nq; }
 
 struct SlotRelease {   // hands the slot back on every exit path
@@ -80,6 +87,14 @@ struct SlotRelease {   // hands the slot back on every exit path
     SearchSlot *slot;
     ~SlotRelease() {
         if (!slot) return;
+        if (slot->dirty) {
+            // an error left the slot half way: nothing may still be queued that reads its staging, and the invariant "flag words are
+            // zero while the slot is idle" is restored before anybody else takes it
+            (void)hipStreamSynchronize(slot->stream);
+            if (slot->d_block.p) (void)hipMemsetAsync(slot->d_block.p, 0, std::min(slot->d_block.bytes, slot->flag_bytes), slot->stream);
+            (void)hipStreamSynchronize(slot->stream);
+            slot->dirty = false;
+        }
         std::lock_guard<std::mutex> lk(P.mu);
         slot->busy = slot->waiting = false;
         slot->ticket = 0;
@@ -140,6 +155,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
     sl.method.assign(S, 0);
     sl.d_seg_filter.assign(S, nullptr);
     sl.launched = false;
+    sl.merged = false;
     sl.dq = nullptr;
     if (nq > 0 && k > 0 && S > 0) {
         // ---- queries: a device pointer is searched where it lies; host rows go through the slot's pinned staging --------------
@@ -161,7 +177,9 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
             sl.dq = sl.d_queries.as<float>();
         }
         // ---- result block; its flag words are zero whenever the slot is idle (a flagged batch clears them in wait) -------------
-        const size_t fw = flag_words(S), sw = seg_words(nq, k), words = fw + S * sw;
+        const size_t fw = flag_words(S), mw = merged_words(nq, k), sw = seg_words(nq, k), words = fw + mw + S * sw;
+        sl.dirty = true;   // from here on work is queued on the slot's stream: an error path must drain it (SlotRelease)
+        sl.flag_bytes = fw * 4;
         if (words * 4 > sl.d_block.bytes) {
             NIDX_HIP(sl.d_block.reserve(words * 4));
             NIDX_HIP(hipMemsetAsync(sl.d_block.p, 0, fw * 4, sl.stream));
@@ -184,12 +202,26 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
             }
         }
         uint32_t *blk = sl.d_block.as<uint32_t>();
+        // the argument tables of the two table-driven kernels travel as one pinned block: [HnswSearchArgs x S | FsscSegDev x S]
+        const size_t hnsw_tab_bytes = (S * sizeof(HnswSearchArgs) + 63) & ~(size_t)63, tab_bytes = hnsw_tab_bytes + S * sizeof(FsscSegDev);
+        NIDX_HIP(sl.pin_tables.reserve(tab_bytes));
+        NIDX_HIP(sl.d_tables.reserve(tab_bytes));
+        HnswSearchArgs *h_hnsw = sl.pin_tables.as<HnswSearchArgs>();
+        FsscSegDev *h_fssc = reinterpret_cast<FsscSegDev *>(sl.pin_tables.as<unsigned char>() + hnsw_tab_bytes);
+        uint32_t n_hnsw = 0, n_searched = 0;
+        const bool one_launch = S > 1 && !getenv("NIDX_GPU_SEGMENT_LAUNCHES");   // the variable: a launch per segment (comparison)
         {
             // launches read index state (tunables, the scratch the scans stage through): under the index lock, which is held for
             // the launch calls only — never across a synchronisation
             std::lock_guard<std::mutex> lock(mu);
+            const uint32_t walks = one_launch ? nq * (uint32_t)std::min<size_t>(S, 64) : nq;   // the launch shape follows the grid
             for (size_t s = 0; s < S; s++) {
                 VectorSegment &seg = segs[s];
+                uint32_t *d_vec = blk + fw + mw + s * sw;
+                float *d_score = reinterpret_cast<float *>(d_vec + (size_t)nq * k);
+                uint32_t *d_count = d_vec + (size_t)nq * k * 2;
+                h_fssc[s] = FsscSegDev{seg.vectors.as<float>(), seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>(),
+                                       seg.key_ids.empty() ? nullptr : seg.key_ids_dev.as<unsigned long long>(), d_vec, nullptr, d_score, seg.dp, 0u};
                 const uint64_t *filt = segment_filters ? segment_filters[s] : nullptr;
                 // matching = |filter ∩ alive| (segment.rs:516-531)
                 const uint64_t matching = filt ? popcount_filter((uint32_t)s, filt) : seg.alive_count;
@@ -204,18 +236,52 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 }
                 if ((method == NIDX_METHOD_HNSW || method == NIDX_METHOD_RABITQ_HNSW) && !seg.has_graph)
                     return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %zu has no HNSW graph", s);
-                uint32_t *d_vec = blk + fw + s * sw;
-                float *d_score = reinterpret_cast<float *>(d_vec + (size_t)nq * k);
-                uint32_t *d_count = d_vec + (size_t)nq * k * 2;
+                h_fssc[s].count = d_count;
+                n_searched++;
+                sl.method[s] = method;
+                if (method == NIDX_METHOD_HNSW && one_launch) {
+                    // its walks join the one grid below
+                    h_hnsw[n_hnsw++] = hnsw_args((uint32_t)s, sl.dq, nq, walks, k, p.min_score, p.with_duplicates != 0, sl.d_seg_filter[s], d_vec, d_score,
+                                                 d_count, nullptr, default_vis_log2, blk + s);
+                    continue;
+                }
                 scan_matching_hint = matching;
                 const int32_t rc = segment_search_device((uint32_t)s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, method, sl.d_seg_filter[s],
                                                          d_vec, d_score, d_count, nullptr, default_vis_log2, sl.stream, blk + s);
                 scan_matching_hint = ~0ull;
                 if (rc != NIDX_OK) return rc;
-                sl.method[s] = method;
+            }
+            NIDX_HIP(hipMemcpyAsync(sl.d_tables.p, sl.pin_tables.p, tab_bytes, hipMemcpyHostToDevice, sl.stream));
+            if (n_hnsw) {
+                HnswSearchArgs a = h_hnsw[0];
+                a.seg_table = sl.d_tables.as<HnswSearchArgs>();
+                a.n_table = n_hnsw;
+                NIDX_HIP(launch_hnsw_search(a, waves_per_query, sl.stream));
             }
         }
-        NIDX_HIP(hipMemcpyAsync(sl.pin_out.p, sl.d_block.p, words * 4, hipMemcpyDeviceToHost, sl.stream));
+        // ---- Fssc on the device: the hits a caller gets are k per query, whatever the number of segments -------------------------
+        sl.merged = !getenv("NIDX_GPU_FSSC_HOST");   // the variable: merge on the host from the per-segment rows (comparison)
+        if (sl.merged) {
+            FsscArgs f;
+            f.segs = reinterpret_cast<const FsscSegDev *>(sl.d_tables.as<unsigned char>() + hnsw_tab_bytes);
+            f.n_segs = (uint32_t)S, f.nq = nq, f.k = k, f.dim = d;
+            f.with_duplicates = p.with_duplicates != 0;
+            f.offered = nullptr;
+            f.offered_stride = std::max<uint32_t>(n_searched, 1) * k;
+            if (!f.with_duplicates) {
+                NIDX_HIP(sl.d_offered.reserve((size_t)nq * f.offered_stride * 12));
+                f.offered = sl.d_offered.as<uint32_t>();
+            }
+            f.out_seg = blk + fw;
+            f.out_para = f.out_seg + (size_t)nq * k;
+            f.out_vec = f.out_para + (size_t)nq * k;
+            f.out_score = reinterpret_cast<float *>(f.out_vec + (size_t)nq * k);
+            f.out_count = f.out_vec + (size_t)nq * k * 2;
+            NIDX_HIP(launch_fssc_merge(f, sl.stream));
+            NIDX_HIP(hipMemcpyAsync(sl.pin_out.p, sl.d_block.p, (fw + mw) * 4, hipMemcpyDeviceToHost, sl.stream));
+        } else {
+            NIDX_HIP(hipMemcpyAsync(sl.pin_out.p, sl.d_block.p, words * 4, hipMemcpyDeviceToHost, sl.stream));
+        }
         NIDX_HIP(hipEventRecord(sl.done, sl.stream));
         sl.launched = true;
     }
@@ -243,30 +309,54 @@ int32_t VectorIndex::pipeline_wait(uint64_t ticket, uint32_t *out_segment, uint3
     for (uint32_t q = 0; q < nq; q++) out_count[q] = 0;
     if (!sl.launched) return NIDX_OK;
     NIDX_HIP(hipSetDevice(device));
-    NIDX_HIP(hipEventSynchronize(sl.done));
-    const size_t fw = flag_words(S), sw = seg_words(nq, k);
+    NIDX_HIP(hipEventSynchronize(sl.done));   // (a failure leaves the slot dirty: SlotRelease drains its stream)
+    const size_t fw = flag_words(S), mw = merged_words(nq, k), sw = seg_words(nq, k);
     uint32_t *host = sl.pin_out.as<uint32_t>();
     bool flagged = false;
-    for (size_t s = 0; s < S; s++) {
-        if (!host[s] || !sl.method[s]) continue;
-        flagged = true;
-        if (sl.method[s] != NIDX_METHOD_HNSW && sl.method[s] != NIDX_METHOD_RABITQ_HNSW) continue;
-        // a bounded on-chip structure overflowed for some query of this segment: the complete OpenSegment::search (larger visited
-        // table / HBM-resident walk for the flagged queries), synchronously, into the index's own block, then over the slot's rows
-        std::lock_guard<std::mutex> lock(mu);
-        const size_t bw = out_block_words(nq, k);
-        NIDX_HIP(scratch_out_block.reserve(bw * 4));
-        NIDX_HIP(pin_out.reserve(bw * 4));
-        uint32_t retried = 0;
-        const int32_t rc = segment_search_exact((uint32_t)s, sl.dq, nq, k, sl.params.min_score, sl.params.with_duplicates != 0, sl.method[s],
-                                                sl.d_seg_filter[s], scratch_out_block.as<uint32_t>(), pin_out.as<uint32_t>(), sl.stream, &retried);
-        if (rc != NIDX_OK) return rc;
-        memcpy(host + fw + s * sw, pin_out.p, sw * 4);
-        if (n_retried_out) *n_retried_out += retried;
-    }
-    if (flagged) {
+    for (size_t s = 0; s < S; s++)
+        if (host[s] && sl.method[s]) flagged = true;
+    if (!flagged) {
+        sl.dirty = false;   // everything queued has completed and no flag word is set
+        if (k == 0) return NIDX_OK;
+        if (sl.merged) {
+            // the device merged the segments: k hits per query in [segments | paragraphs | vectors | scores | counts]
+            const uint32_t *m = host + fw, *cnt = m + (size_t)nq * k * 4;
+            for (uint32_t q = 0; q < nq; q++) {
+                const uint32_t c = std::min(cnt[q], k);
+                out_count[q] = c;
+                const size_t at = (size_t)q * k;
+                if (out_segment) memcpy(out_segment + at, m + at, (size_t)c * 4);
+                if (out_paragraph) memcpy(out_paragraph + at, m + (size_t)nq * k + at, (size_t)c * 4);
+                if (out_vector) memcpy(out_vector + at, m + (size_t)nq * k * 2 + at, (size_t)c * 4);
+                if (out_score) memcpy(out_score + at, m + (size_t)nq * k * 3 + at, (size_t)c * 4);
+            }
+            return NIDX_OK;
+        }
+    } else {
+        if (sl.merged) {
+            // the merged hits rest on a walk that overflowed: fetch the per-segment rows, repair, merge again on the host
+            NIDX_HIP(hipMemcpyAsync(host + fw + mw, sl.d_block.as<uint32_t>() + fw + mw, S * sw * 4, hipMemcpyDeviceToHost, sl.stream));
+            NIDX_HIP(hipStreamSynchronize(sl.stream));
+        }
+        for (size_t s = 0; s < S; s++) {
+            if (!host[s] || !sl.method[s]) continue;
+            if (sl.method[s] != NIDX_METHOD_HNSW && sl.method[s] != NIDX_METHOD_RABITQ_HNSW) continue;
+            // a bounded on-chip structure overflowed for some query of this segment: the complete OpenSegment::search (larger visited
+            // table / HBM-resident walk for the flagged queries), synchronously, into the index's own block, then over the slot's rows
+            std::lock_guard<std::mutex> lock(mu);
+            const size_t bw = out_block_words(nq, k);
+            NIDX_HIP(scratch_out_block.reserve(bw * 4));
+            NIDX_HIP(pin_out.reserve(bw * 4));
+            uint32_t retried = 0;
+            const int32_t rc = segment_search_exact((uint32_t)s, sl.dq, nq, k, sl.params.min_score, sl.params.with_duplicates != 0, sl.method[s],
+                                                    sl.d_seg_filter[s], scratch_out_block.as<uint32_t>(), pin_out.as<uint32_t>(), sl.stream, &retried);
+            if (rc != NIDX_OK) return rc;
+            memcpy(host + fw + mw + s * sw, pin_out.p, sw * 4);
+            if (n_retried_out) *n_retried_out += retried;
+        }
         NIDX_HIP(hipMemsetAsync(sl.d_block.p, 0, fw * 4, sl.stream));
         NIDX_HIP(hipStreamSynchronize(sl.stream));
+        sl.dirty = false;
     }
     if (k == 0) return NIDX_OK;
     // Fssc across the segments (searcher.rs:149-199, 270-287)
@@ -274,7 +364,7 @@ int32_t VectorIndex::pipeline_wait(uint64_t ticket, uint32_t *out_segment, uint3
     std::vector<const float *> ps(S, nullptr);
     for (size_t s = 0; s < S; s++) {
         if (!sl.method[s]) continue;
-        const uint32_t *b = host + fw + s * sw;
+        const uint32_t *b = host + fw + mw + s * sw;
         pv[s] = b;
         ps[s] = reinterpret_cast<const float *>(b + (size_t)nq * k);
         pc[s] = b + (size_t)nq * k * 2;

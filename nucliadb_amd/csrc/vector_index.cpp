@@ -238,7 +238,13 @@ static int32_t open_segment(const nidx_gpu_vector_config_t &cfg, const nidx_gpu_
         NIDX_HIP(seg.alive.alloc((size_t)words * 8));
         NIDX_HIP(hipMemcpy(seg.alive.p, seg.alive_host.data(), (size_t)words * 8, hipMemcpyHostToDevice));
     }
-    if (in.paragraph_key_ids) seg.key_ids.assign(in.paragraph_key_ids, in.paragraph_key_ids + in.n_paragraphs);
+    if (in.paragraph_key_ids) {
+        seg.key_ids.assign(in.paragraph_key_ids, in.paragraph_key_ids + in.n_paragraphs);
+        if (in.n_paragraphs) {   // the device-side Fssc (fssc_device.hip) reads them too
+            NIDX_HIP(seg.key_ids_dev.alloc((size_t)in.n_paragraphs * 8));
+            NIDX_HIP(hipMemcpy(seg.key_ids_dev.p, seg.key_ids.data(), (size_t)in.n_paragraphs * 8, hipMemcpyHostToDevice));
+        }
+    }
     // vectors.quant
     seg.has_quant = false;
     if (in.quantized && in.n_vectors > 0) {
@@ -403,38 +409,49 @@ int32_t VectorIndex::scratch_release(hipStream_t st) {
     return NIDX_OK;
 }
 
+// The argument record of one segment's plain HNSW search; shape_nq = the walks of the launch it joins (the launch shape — rows in
+// flight, register budget — follows the grid, and every record of one table-driven launch carries the same one).
+HnswSearchArgs VectorIndex::hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t shape_nq, uint32_t k, float min_score,
+                                      bool with_duplicates, const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score,
+                                      uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2, uint32_t *d_flag_word) const {
+    const VectorSegment &seg = segs[s];
+    HnswSearchArgs a;
+    a.seg = seg.seg_dev(cfg.similarity);
+    a.g = seg.graph_dev();
+    a.queries = d_queries;
+    a.n_queries = nq;
+    a.filter = d_filter;
+    a.k = k;
+    a.min_score = min_score;
+    a.with_duplicates = with_duplicates ? 1 : 0;
+    a.vis_log2 = vis_log2;
+    a.out_vec = d_out_vec;
+    a.out_score = d_out_score;
+    a.out_count = d_out_count;
+    a.stats = d_stats;
+    a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
+    a.eval_rows = rows_for(shape_nq);
+    a.min_waves = waves_for(shape_nq);
+    a.entry_vec = nullptr;
+    a.entry_score = nullptr;
+    a.entry_count = nullptr;
+    a.dump_vec = nullptr;
+    a.dump_score = nullptr;
+    a.dump_count = nullptr;
+    a.flag_word = d_flag_word;
+    a.ef_search = ef_search;
+    a.ef_upper = ef_upper;
+    return a;
+}
+
 int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                                    bool with_duplicates, int method, const uint64_t *d_filter,
                                                    uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,
                                                    uint32_t *d_stats, uint32_t vis_log2, hipStream_t st, uint32_t *d_flag_word) {
     VectorSegment &seg = segs[s];
     if (method == NIDX_METHOD_HNSW) {
-        HnswSearchArgs a;
-        a.seg = seg.seg_dev(cfg.similarity);
-        a.g = seg.graph_dev();
-        a.queries = d_queries;
-        a.n_queries = nq;
-        a.filter = d_filter;
-        a.k = k;
-        a.min_score = min_score;
-        a.with_duplicates = with_duplicates ? 1 : 0;
-        a.vis_log2 = vis_log2;
-        a.out_vec = d_out_vec;
-        a.out_score = d_out_score;
-        a.out_count = d_out_count;
-        a.stats = d_stats;
-        a.multi = cfg.vector_cardinality == NIDX_CARDINALITY_MULTI ? 1 : 0;
-        a.eval_rows = rows_for(nq);
-        a.min_waves = waves_for(nq);
-        a.entry_vec = nullptr;
-        a.entry_score = nullptr;
-        a.entry_count = nullptr;
-        a.dump_vec = nullptr;
-        a.dump_score = nullptr;
-        a.dump_count = nullptr;
-        a.flag_word = d_flag_word;
-        a.ef_search = ef_search;
-        a.ef_upper = ef_upper;
+        const HnswSearchArgs a = hnsw_args(s, d_queries, nq, nq, k, min_score, with_duplicates, d_filter, d_out_vec, d_out_score, d_out_count, d_stats,
+                                           vis_log2, d_flag_word);
         NIDX_HIP(launch_hnsw_search(a, waves_per_query, st));
         return NIDX_OK;
     }
@@ -1159,6 +1176,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value, -1);
     else if (n == "coalesce_in_flight") idx->coalescer_config(-1, -1, value);
     else if (n == "pipeline_depth") idx->pipeline_config(value);
+    else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else if (n == "ef_search") {   // 0 = the reference's EF_SEARCH (30)
         if (value < 0 || value > NIDX_K_MAX) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_search must be in 0..%d", NIDX_K_MAX);
@@ -1226,6 +1244,15 @@ int32_t nidx_gpu_vector_search(nidx_gpu_vector_index_t *index, const float *quer
                                uint32_t *out_count, int32_t *out_method) try {
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || !params || !out_count || (n_queries && !queries)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (idx->segs.size() > 1 && !out_method && !idx->serial_segments && n_queries && params->k && params->k <= NIDX_K_MAX && params->method >= 0 &&
+        params->method <= 6) {
+        // Searcher::_search over several segments (searcher.rs:270-287): every segment in one pass of the device and Fssc there too
+        // (serving.cpp), instead of a launch, a transfer and a wait per segment
+        uint64_t ticket = 0;
+        const int32_t rc = idx->pipeline_submit(queries, n_queries, *params, segment_filters, true, &ticket);
+        if (rc != NIDX_OK) return rc;
+        return idx->pipeline_wait(ticket, out_segment, out_paragraph, out_vector, out_score, out_count, nullptr);
+    }
     return idx->search_host(queries, n_queries, *params, segment_filters, nullptr, out_segment, out_paragraph, out_vector,
                             out_score, out_count, out_method, nullptr);
 } NIDX_ABI_CATCH

@@ -30,6 +30,7 @@ struct VectorSegment {
     std::vector<uint64_t> alive_host;  // always present
     uint64_t alive_count = 0;
     std::vector<uint64_t> key_ids;     // Fssc identity of each paragraph (optional)
+    DevBuf key_ids_dev;                // the same in HBM (the device-side Fssc)
     // label / field-key posting lists for device-side filter formulas (optional)
     DevBuf f_offsets, f_ids;
     DevBuf f_key_bytes, f_key_offsets;   // the posting lists' keys, sorted bytewise (what label.fst / field.fst resolve)
@@ -90,6 +91,7 @@ struct VectorIndex {
     int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : min_waves; }
     uint32_t ef_search = 0;   // 0 = EF_SEARCH (hnsw/params.rs:46); tunable "ef_search"
     uint32_t ef_upper = 0;    // 0 = 1: the greedy descent of hnsw/search.rs:318-324; tunable "ef_upper"
+    bool serial_segments = false;   // tunable "serial_segments": the blocking search of a multi-segment index one segment at a time
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
     uint32_t build_ef_upper = 0;   // 0 = 1 (reference); tunable "build_ef_upper": a wider descent when inserting into very large flat graphs
@@ -107,6 +109,9 @@ struct VectorIndex {
                                   bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
                                   float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
                                   hipStream_t st, uint32_t *d_flag_word = nullptr);
+    HnswSearchArgs hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t shape_nq, uint32_t k, float min_score, bool with_duplicates,
+                             const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats,
+                             uint32_t vis_log2, uint32_t *d_flag_word) const;
     int32_t segment_search_device_scratch(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                           bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
                                           float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,

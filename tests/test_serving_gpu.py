@@ -187,7 +187,10 @@ def test_multi_segment_filters_and_cross_segment_duplicates(orc):
         none_match = [orc.bitset(700), orc.bitset(300), orc.bitset(1200)]
         for with_dup in (False, True):
             for f in (None, filters, none_match):
+                idx.tunable("serial_segments", 1)   # the blocking path one segment at a time, Fssc on the host
                 want = idx.search(q, k, _lib.METHOD_AUTO, with_dup, filters=f)
+                idx.tunable("serial_segments", 0)
+                assert same(idx.search(q, k, _lib.METHOD_AUTO, with_dup, filters=f), want), (with_dup, f is None)
                 rc, t1 = idx.submit(q.ctypes.data, q.shape[0], k, _lib.METHOD_AUTO, with_dup, filters=f)
                 assert rc == 0, _lib.last_error()
                 rc, t2 = idx.submit(q.ctypes.data, q.shape[0], k, _lib.METHOD_AUTO, with_dup, min_score=0.1, filters=f)
@@ -197,6 +200,70 @@ def test_multi_segment_filters_and_cross_segment_duplicates(orc):
                 rc, got2, _ = idx.wait(t2, q.shape[0], k)
                 assert same(got2, idx.search(q, k, _lib.METHOD_AUTO, with_dup, min_score=0.1, filters=f))
         assert not idx.search(q, k, _lib.METHOD_AUTO, filters=none_match)[4].any()
+    finally:
+        idx.close()
+
+
+def test_every_segment_in_one_launch_and_fssc_on_the_device(orc, monkeypatch):
+    """Searcher::_search over an index of many segments (nidx_vector/src/searcher.rs:270-287; the reference's 10 M index is 50
+    segments of 200 k, nidx/src/settings.rs:258-278): one launch walks (query x segment) work items from a table in HBM and the
+    device merges them per query (Fssc, searcher.rs:149-199).  Identical — segments, vectors, ranks, score bits — to the oracle's
+    sequential Searcher::_search, to the library's own segment-at-a-time path with the host-side Fssc (tunable serial_segments),
+    to a launch per segment (NIDX_GPU_SEGMENT_LAUNCHES) and to the host merge of the one launch (NIDX_GPU_FSSC_HOST); with the
+    reference's default with_duplicates = false (vector bytes seen in an earlier segment), shared paragraph keys across
+    segments, per-segment filters, an empty segment result, k from 1 to 70 and min_score."""
+    rng = np.random.default_rng(23)
+    d = 96
+    sizes = (900, 400, 1500, 64, 700, 1100, 350, 820, 5)
+    xs = [unit_rows(rng, n, d) for n in sizes]
+    xs[3][7] = xs[0][11]     # the same vector bytes in three segments
+    xs[6][1] = xs[0][11]
+    xs[5][100:104] = xs[2][40]
+    osegs, graphs = [], []
+    for x in xs:
+        o = orc.Segment(x, similarity=orc.SIM_COSINE, order=orc.ORDER_WAVE64)
+        graphs.append(bytes(o.build_graph(seed=3).serialize_v2(x.shape[0])[0]))
+        osegs.append(o)
+    key_ids, base = [], 0
+    for x in xs:
+        key_ids.append(np.arange(base, base + x.shape[0], dtype=np.uint64))
+        base += x.shape[0]
+    key_ids[4][33] = key_ids[1][20]   # one paragraph key in two segments
+    key_ids[7][5] = key_ids[2][40]
+    idx = Index(xs, graphs=graphs, key_ids=key_ids)
+    try:
+        q = np.ascontiguousarray(np.vstack([xs[0][11][None, :], xs[2][40][None, :], xs[1][20][None, :], xs[4][33][None, :], unit_rows(rng, 60, d)]))
+        B = q.shape[0]
+        for k, with_dup, min_score in ((10, True, -1.0), (10, False, -1.0), (1, False, -1.0), (70, False, -1.0), (25, True, 0.05), (12, False, 0.08)):
+            sg, sv, ss, sc = orc.searcher_search_batch(osegs, q, k, min_score=min_score, with_duplicates=with_dup, threads=4, para_keys=key_ids)
+            got = idx.search(q, k, _lib.METHOD_HNSW, with_dup, min_score=min_score)
+            assert np.array_equal(got[4], sc), (k, with_dup)
+            for i in range(B):
+                c = int(sc[i])
+                assert np.array_equal(got[0][i, :c], sg[i, :c]) and np.array_equal(got[2][i, :c], sv[i, :c]), (k, with_dup, i)
+                assert np.array_equal(got[3][i, :c].view(np.uint32), ss[i, :c].view(np.uint32)), (k, with_dup, i)
+            idx.tunable("serial_segments", 1)
+            serial = idx.search(q, k, _lib.METHOD_HNSW, with_dup, min_score=min_score)
+            idx.tunable("serial_segments", 0)
+            assert same(got, serial), (k, with_dup)
+            for var in ("NIDX_GPU_SEGMENT_LAUNCHES", "NIDX_GPU_FSSC_HOST"):
+                monkeypatch.setenv(var, "1")
+                assert same(idx.search(q, k, _lib.METHOD_HNSW, with_dup, min_score=min_score), got), (var, k, with_dup)
+                monkeypatch.delenv(var)
+        # per-segment filters: some segments drop out entirely (nothing matches), the others walk under their bitsets
+        filters = [orc.bitset(n, ones=np.nonzero(rng.random(n) < p)[0].tolist()) if p is not None else None
+                   for n, p in zip(sizes, (0.6, 0.0, None, 0.5, 0.7, 0.0, 0.9, None, 1.0))]
+        got = idx.search(q, 10, _lib.METHOD_AUTO, False, filters=filters)
+        idx.tunable("serial_segments", 1)
+        serial = idx.search(q, 10, _lib.METHOD_AUTO, False, filters=filters)
+        idx.tunable("serial_segments", 0)
+        assert same(got, serial) and got[4].min() > 0
+        # several batches in flight through the same slots
+        tickets = [idx.submit(q.ctypes.data, B, 10, _lib.METHOD_HNSW, False)[1] for _ in range(3)]
+        want = idx.search(q, 10, _lib.METHOD_HNSW, False)
+        for t in reversed(tickets):
+            rc, g, retried = idx.wait(t, B, 10)
+            assert rc == 0 and retried == 0 and same(g, want)
     finally:
         idx.close()
 
