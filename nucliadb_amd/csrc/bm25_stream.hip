@@ -30,7 +30,8 @@
 // one s_xor with a constant lane mask, two v_cndmask) — ~220 issues per 64 candidates instead of ~50 per candidate.
 // An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
-// LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 2 KiB per workgroup = 31 KiB: 5 workgroups per CU.
+// LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 3 KiB per workgroup (the quotient table) = 32 KiB:
+// 5 workgroups per CU.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -109,8 +110,10 @@ __device__ inline uint64_t bs_merge64(uint64_t top, uint64_t v) {
 // DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
 template <int KL, bool EXTRAS, bool DBG>
 __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
-    __shared__ float tf_cache[256];          // K1 * (1 - B + B * fieldnorm / avg)
-    __shared__ float inv1[256];              // 1 / (1 + tf_cache): the tf == 1 quotient, the same two f32 operations as the general form
+    // tf / (tf + K1 * (1 - B + B * fieldnorm / avg)) for tf = 1, 2, 3 and every fieldnorm id: the same two f32 operations as the
+    // general form, done once per workgroup — a posting of a short document almost always has one of these frequencies, and the IEEE
+    // division is ~16 instructions per row.  Larger frequencies take the division with the table of the index (a.tf_cache, L2-resident)
+    __shared__ float quot[3][256];
     __shared__ uint32_t bm_a_all[4][BS_A_WORDS];
     __shared__ uint32_t bm_b_all[4][BS_B_WORDS];
     __shared__ uint32_t list_doc_all[4][BS_CAP];
@@ -130,8 +133,9 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
     };
     {
         const float c = a.tf_cache[threadIdx.x];
-        tf_cache[threadIdx.x] = c;
-        inv1[threadIdx.x] = 1.0f / (1.0f + c);
+        quot[0][threadIdx.x] = 1.0f / (1.0f + c);
+        quot[1][threadIdx.x] = 2.0f / (2.0f + c);
+        quot[2][threadIdx.x] = 3.0f / (3.0f + c);
         clear_bitmaps();
     }
     __syncthreads();   // the only workgroup barrier
@@ -364,6 +368,25 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                         uint32_t d[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) d[r] = (ip + p)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
+                        if (p + 256u <= e) {
+                            // four full rows: nothing to bound; the four ds_or_rtn go out back to back (LDS operations of a wave execute in
+                            // order: row r still sees the bits of the rows before it) and a second posting of a document is looked for once
+                            uint32_t h[4], old[4];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                h[r] = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
+                                old[r] = __hip_atomic_fetch_or(&bm_a[h[r] >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            bool hit[4];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) hit[r] = __builtin_amdgcn_ubfe(old[r], h[r], 1u) != 0u;
+                            if (__ballot(hit[0] || hit[1] || hit[2] || hit[3])) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++)
+                                    if (hit[r]) __hip_atomic_fetch_or(&bm_b[(h[r] & 0x7ffu) >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             if (p + 64u * r >= e) break;
@@ -422,6 +445,92 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                             wn[r] = (wp + p)[256u + 64u * r + (uint32_t)lane];
                         }
                     }
+                    if (!EXTRAS && p + 256u <= e) {
+                        // ---- four full rows (the bulk of every clause): no bounds to test; the four bitmap probes and the four score
+                        // look-ups travel together, and the rare events — an involved posting, a candidate for the list — are looked for once
+                        // per group instead of once per row ----
+                        uint32_t h[4], bw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            h[r] = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
+                            if (probe) bw[r] = is_long ? bm_a[h[r] >> 5] : bm_b[(h[r] & 0x7ffu) >> 5];
+                        }
+                        float sc[4];
+                        if (mode == 2u) {   // ConstScorer(boost)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) sc[r] = wgt;
+                        } else {
+                            // every frequency of the group in 1 .. 3 (the usual case): the quotient comes from the table
+                            uint32_t t[4];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) t[r] = (w[r] & 0xffffffu) - 1u;   // (tf == 0 wraps to 2^24 - 1 and takes the division)
+                            if (mode == 1u) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) sc[r] = wgt * quot[0][w[r] >> 24];
+                            } else if (!__ballot((t[0] | t[1] | t[2] | t[3]) > 2u)) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) sc[r] = wgt * (&quot[0][0])[(t[r] << 8) + (w[r] >> 24)];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const float tf = (float)(w[r] & 0xffffffu);
+                                    sc[r] = wgt * (tf / (tf + a.tf_cache[w[r] >> 24]));
+                                }
+                            }
+                        }
+                        if (w_bits >> 31) {   // the oracle's sum starts at +0: -0 never leaves it
+#pragma unroll
+                            for (int r = 0; r < 4; r++) sc[r] = 0.f + sc[r];
+                        }
+                        bool inv[4] = {false, false, false, false};
+                        uint32_t n_final = 256u;
+                        if (probe) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) inv[r] = __builtin_amdgcn_ubfe(bw[r], h[r], 1u) != 0u;
+                            if (__ballot(inv[0] || inv[1] || inv[2] || inv[3])) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const unsigned long long inv_m = __ballot(inv[r]);
+                                    if (!inv_m || overflow) continue;
+                                    const uint32_t n_new = (uint32_t)__popcll(inv_m);
+                                    if (n_short + n_long + n_new > BS_CAP) {
+                                        overflow = true;
+                                        continue;
+                                    }
+                                    const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(inv_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)inv_m, 0u));
+                                    const uint32_t at = is_long ? BS_CAP - 1u - (n_long + rank) : n_short + rank;   // L's entries from the top down
+                                    if (inv[r]) {
+                                        if (is_long) __hip_atomic_fetch_or(&bm_b[(h[r] & 0x7ffu) >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        list_doc[at] = d[r];
+                                        list_score[at] = __float_as_uint(sc[r]);
+                                    }
+                                    if (is_long) n_long += n_new;
+                                    else n_short += n_new;
+                                    n_final -= n_new;
+                                }
+                                if (overflow) break;   // (the range is cut in half and retried: nothing of this group counts)
+                            }
+                        }
+                        if (row_ok) {
+                            matched += n_final;
+                            // most groups hold nothing the list wants once it is full: one float compare per posting before any key is built
+                            // (the k-th score is NaN while the list is not full: !(s < NaN) lets every score through to the exact test)
+                            const float kf = rank_key_score(kth);
+                            bool cnd[4];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) cnd[r] = !inv[r] && !(sc[r] < kf);
+                            if (__ballot(cnd[0] || cnd[1] || cnd[2] || cnd[3])) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    if (__ballot(cnd[r])) offer(rank_key(sc[r], d[r]), cnd[r]);
+                                    if (KL == 1 && (r & 1)) {   // the buffer holds what two rows can add on top of 63 left-overs
+                                        while (n_cand >= 64u) flush64();
+                                    }
+                                }
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         if (p + 64u * r >= e) break;
@@ -436,10 +545,10 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                         const uint32_t tfi = w[r] & 0xffffffu;
                         float sc;
                         if (mode == 2u) sc = wgt;   // ConstScorer(boost)
-                        else if (mode == 1u || !__ballot(in && tfi != 1u)) sc = wgt * inv1[fn];
+                        else if (mode == 1u || !__ballot(in && tfi != 1u)) sc = wgt * quot[0][fn];
                         else {
                             const float tf = (float)tfi;
-                            sc = wgt * (tf / (tf + tf_cache[fn]));
+                            sc = wgt * (tf / (tf + a.tf_cache[fn]));
                         }
                         if (w_bits >> 31) sc = 0.f + sc;   // the oracle's sum starts at +0: -0 never leaves it
                         const unsigned long long inv_m = __ballot(inv);
