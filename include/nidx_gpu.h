@@ -764,6 +764,12 @@ int32_t nidx_gpu_merge_facets(const nidx_gpu_facet_count_t *const *shard_facets,
 #define NIDX_SHARD_COMM_ID_BYTES 128
 typedef struct nidx_gpu_shard_comm nidx_gpu_shard_comm_t;
 int32_t nidx_gpu_shard_comm_unique_id(uint8_t *id_out /* [NIDX_SHARD_COMM_ID_BYTES] */);
+/* The same communicator over a second transport, for processes of ONE node that share a GPU (a test box has one): an id that
+ * names a POSIX shared-memory segment; nidx_gpu_shard_comm_init with it gathers through that segment (device -> segment, barrier,
+ * segment -> device) instead of ncclAllGather.  Packing, gather offsets, shard order and the merge kernels are the same code as
+ * over RCCL; every exchange first checks that all ranks brought the same block shape (over RCCL: NIDX_GPU_SHARD_COMM_CHECK=1).
+ * Not a product path: xGMI does not carry it. */
+int32_t nidx_gpu_shard_comm_unique_id_shm(uint8_t *id_out /* [NIDX_SHARD_COMM_ID_BYTES] */);
 int32_t nidx_gpu_shard_comm_init(const uint8_t *unique_id, int32_t rank, int32_t world, const uint8_t *shard_id, uint32_t shard_id_len,
                                  nidx_gpu_shard_comm_t **comm_out);
 void nidx_gpu_shard_comm_destroy(nidx_gpu_shard_comm_t *comm);

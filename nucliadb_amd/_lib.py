@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnidx_gpu.so")
+# NIDX_GPU_LIB: another build of the library (kernel A/B experiments on the GPU box); the product is the in-tree file
+LIB_PATH = os.environ.get("NIDX_GPU_LIB") or os.path.join(_HERE, "libnidx_gpu.so")
 
 NIDX_OK = 0
 NIDX_ERR_IO = -1
@@ -295,6 +296,7 @@ SIGNATURES = {
                                               C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nidx_gpu_merge_facets": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "nidx_gpu_shard_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "nidx_gpu_shard_comm_unique_id_shm": (C.c_int32, [C.c_void_p]),
     "nidx_gpu_shard_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "nidx_gpu_shard_comm_destroy": (None, [C.c_void_p]),
     "nidx_gpu_shard_exchange_merge_vector": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -44,7 +44,12 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 
 #define BS_A_WORDS 1024u   /* 32 Kibit */
 #define BS_B_WORDS 64u     /* 2 Kibit */
+#ifndef BS_CAP
 #define BS_CAP 192u        /* involved postings per doc range */
+#endif
+#ifndef BS_FAST_GROUPS
+#define BS_FAST_GROUPS 1   /* four full rows at a time on the bounds-free path */
+#endif
 #define BS_CAND 192u       /* 63 left over + two rows */
 #define BS_GROUPS 8
 
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                         uint32_t d[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) d[r] = (ip + p)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
-                        if (p + 256u <= e) {
+                        if (BS_FAST_GROUPS && p + 256u <= e) {
                             // four full rows: nothing to bound; the four ds_or_rtn go out back to back (LDS operations of a wave execute in
                             // order: row r still sees the bits of the rows before it) and a second posting of a document is looked for once
                             uint32_t h[4], old[4];
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                             wn[r] = (wp + p)[256u + 64u * r + (uint32_t)lane];
                         }
                     }
-                    if (!EXTRAS && p + 256u <= e) {
+                    if (BS_FAST_GROUPS && !EXTRAS && p + 256u <= e) {
                         // ---- four full rows (the bulk of every clause): no bounds to test; the four bitmap probes and the four score
                         // look-ups travel together, and the rare events — an involved posting, a candidate for the list — are looked for once
                         // per group instead of once per row ----

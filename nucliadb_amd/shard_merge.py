@@ -151,6 +151,13 @@ class ShardComm:
         _lib.check(_lib.lib().nidx_gpu_shard_comm_unique_id(buf))
         return bytes(buf)
 
+    @staticmethod
+    def unique_id_shm() -> bytes:
+        """An id of the shared-memory transport: ranks of one node that share a GPU (tests)."""
+        buf = (C.c_uint8 * _lib.SHARD_COMM_ID_BYTES)()
+        _lib.check(_lib.lib().nidx_gpu_shard_comm_unique_id_shm(buf))
+        return bytes(buf)
+
     def __init__(self, unique_id: bytes, rank: int, world: int, shard_id: bytes = b""):
         assert len(unique_id) == _lib.SHARD_COMM_ID_BYTES
         self.rank, self.world = rank, world

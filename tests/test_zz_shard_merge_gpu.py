@@ -197,3 +197,62 @@ def test_rccl_exchange_world_of_one(orc):
                 assert oc[q] == n and np.array_equal(ov[q, :n], bv[0, q, :n]) and np.array_equal(oa[q, :n], ba[0, q, :n]) and not orank[q, :n].any()
     finally:
         comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_exchange_between_processes(orc, world, tmp_path):
+    """nidx_gpu_shard_exchange_merge_{vector,bm25} with a communicator of more than one rank: `world` PROCESSES on the one GPU of the
+    box, the library's own exchange over its shared-memory transport (csrc/shard_comm.cpp: the same pack, in-place gather offsets,
+    shard order and merge kernels as over RCCL — only ncclAllGather itself is replaced).  Every rank must come back with the
+    merge of all ranks' lists: the oracle's merge_vector / merge_bm25 (shard_merge.rs:211-348) incl. tie order and shard-id order,
+    the date orders against kmerge restated; ranks that bring different block shapes get an error, not a hang."""
+    import os
+    import subprocess
+    import sys
+
+    import __graft_entry__ as g
+    from nucliadb_amd import _lib
+    from nucliadb_amd.shard_merge import ShardComm
+
+    g.build()
+    ident = ShardComm.unique_id_shm()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shard_exchange_worker.py")
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, ident.hex(), str(r), str(world), outs[r]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for x in procs:
+                x.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [np.load(o) for o in outs]
+    ids = SHARD_IDS[:world]
+    for case, (B, k, limit) in enumerate(((5, 10, 10), (257, 10, 4), (64, 7, 20))):
+        score, idn, count = _lists(world, B, k, 500 + case)
+        bs, ba, bv, bc = _bm25_lists(world, B, k, 600 + case)
+        for r in res:
+            ms, mi, mc = r["v%d_score" % case], r["v%d_id" % case], r["v%d_count" % case]
+            for q in range(B):
+                lists = [[(float(score[p, q, i]), int(idn[p, q, i])) for i in range(count[p, q])] for p in range(world)]
+                assert [(float(ms[q, i]), int(mi[q, i])) for i in range(mc[q])] == orc.merge_vector(lists, limit), (case, q)
+            os_, oa, orank, oc = r["b%d_score" % case], r["b%d_addr" % case], r["b%d_rank" % case], r["b%d_count" % case]
+            for q in range(B):
+                lists = [[(float(bs[p, q, i]), int(ba[p, q, i]), ids[p], p) for i in range(bc[p, q])] for p in range(world)]
+                want = orc.merge_bm25(lists, limit)
+                assert [(float(os_[q, i]), int(oa[q, i]), ids[int(orank[q, i])]) for i in range(oc[q])] == [(w[0], w[1], w[2]) for w in want], (case, q)
+            for name, sign in (("d", 1), ("a", -1)):
+                v = bv if sign == 1 else -bv
+                vl, vc, vv = r["%s%d_rank" % (name, case)], r["%s%d_count" % (name, case)], r["%s%d_value" % (name, case)]
+                for q in range(B):
+                    heads = [[int(v[p, q, i]) for i in range(bc[p, q])] for p in range(world)]
+                    assert [(int(vl[q, i]), int(vv[q, i])) for i in range(vc[q])] == _kmerge_strict(heads, limit, desc=(sign == 1)), (name, case, q)
+        for r in res[1:]:   # every rank holds the same merged lists
+            for key in res[0].files:
+                assert np.array_equal(r[key], res[0][key]), key
+    assert all(int(r["shape_error"][0]) == 1 for r in res)
