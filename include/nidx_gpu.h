@@ -319,6 +319,9 @@ int32_t nidx_gpu_vector_search_wait(nidx_gpu_vector_index_t *index, uint64_t tic
  * "coalesce_in_flight" (default 4) of them at a time: while batches are running the next one gathers, and it is closed when its
  * window ("coalesce_window_us", default 50, counted from the moment it starts gathering) has passed or it is full
  * ("coalesce_max_batch", default 1024) AND a slot is free — so under load the batch size adapts to the arrival rate.
+ * Admission: at most "coalesce_max_callers" (default 256, 0 = unbounded) requests are inside at once; further callers wait at
+ * the door and are let in as requests leave, or — tunable "coalesce_reject_when_full" = 1 — get NIDX_ERR_BUSY at once (what a
+ * gRPC front end turns into RESOURCE_EXHAUSTED): 1 024 blocked callers then see the latencies of 256, not a scheduler convoy.
  * Unfiltered; outputs are [k] rows.  Blocks until this query's hits are ready. */
 int32_t nidx_gpu_vector_search_one(nidx_gpu_vector_index_t *index, const float *query, uint32_t query_dimension,
                                    const nidx_gpu_vector_search_params_t *params, uint32_t *out_segment,

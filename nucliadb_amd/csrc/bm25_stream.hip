@@ -28,10 +28,10 @@
 // Candidates are not inserted one by one: they are appended to a 192-entry LDS buffer (ballot compaction) and merged 64 at a time
 // into the sorted list by a bitonic network that runs in the VALU (v_permlane32/16_swap + DPP; compare-exchange = one v_cmp_gt_u64,
 // one s_xor with a constant lane mask, two v_cndmask) — ~220 issues per 64 candidates instead of ~50 per candidate.
-// An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
+// An involved list that overflows (160 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
-// LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 3 KiB per workgroup (the quotient table) = 32 KiB:
-// 5 workgroups per CU.
+// LDS: 7 KiB per wave (A 4 KiB, B 256 B, involved list 1.25 KiB, candidates 1.5 KiB) + 3 KiB per workgroup (the quotient table) = 31 KiB:
+// 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (91 VGPRs) so that the registers allow them too.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -45,7 +45,10 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_A_WORDS 1024u   /* 32 Kibit */
 #define BS_B_WORDS 64u     /* 2 Kibit */
 #ifndef BS_CAP
-#define BS_CAP 192u        /* involved postings per doc range */
+#define BS_CAP 160u        /* involved postings per doc range */
+#endif
+#ifndef BS_MIN_WAVES
+#define BS_MIN_WAVES 5     /* waves per SIMD the k <= 64 kernel is compiled for: <= 96 VGPRs, five workgroups per CU (LDS allows five) */
 #endif
 #ifndef BS_FAST_GROUPS
 #define BS_FAST_GROUPS 1   /* four full rows at a time on the bounds-free path */
@@ -114,7 +117,7 @@ __device__ inline uint64_t bs_merge64(uint64_t top, uint64_t v) {
 
 // DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
 template <int KL, bool EXTRAS, bool DBG>
-__global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
+__global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
     // tf / (tf + K1 * (1 - B + B * fieldnorm / avg)) for tf = 1, 2, 3 and every fieldnorm id: the same two f32 operations as the
     // general form, done once per workgroup — a posting of a short document almost always has one of these frequencies, and the IEEE
     // division is ~16 instructions per row.  Larger frequencies take the division with the table of the index (a.tf_cache, L2-resident)
@@ -550,7 +553,8 @@ __global__ __launch_bounds__(256) void bm25_stream_kernel(Bm25Args a, const uint
                         const uint32_t tfi = w[r] & 0xffffffu;
                         float sc;
                         if (mode == 2u) sc = wgt;   // ConstScorer(boost)
-                        else if (mode == 1u || !__ballot(in && tfi != 1u)) sc = wgt * quot[0][fn];
+                        else if (mode == 1u) sc = wgt * quot[0][fn];
+                        else if (!__ballot(in && tfi - 1u > 2u)) sc = wgt * (&quot[0][0])[(in ? (tfi - 1u) << 8 : 0u) + fn];   // tf in 1 .. 3
                         else {
                             const float tf = (float)tfi;
                             sc = wgt * (tf / (tf + a.tf_cache[fn]));

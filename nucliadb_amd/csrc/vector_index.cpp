@@ -1175,6 +1175,8 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "coalesce_window_us") idx->coalescer_config(value, -1, -1);
     else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value, -1);
     else if (n == "coalesce_in_flight") idx->coalescer_config(-1, -1, value);
+    else if (n == "coalesce_max_callers") idx->coalescer_admission(std::max(0, (int)value), -1);   // 0 = unbounded
+    else if (n == "coalesce_reject_when_full") idx->coalescer_admission(-1, value != 0);
     else if (n == "pipeline_depth") idx->pipeline_config(value);
     else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));

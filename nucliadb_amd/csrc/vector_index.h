@@ -166,6 +166,7 @@ struct VectorIndex {
                        uint32_t *out_paragraph, uint32_t *out_vector, float *out_score, uint32_t *out_count);
     void coalescer_stats(uint64_t &batches, uint64_t &queries);
     void coalescer_config(int32_t window_us, int32_t max_batch, int32_t in_flight);
+    void coalescer_admission(int32_t max_callers, int32_t reject_when_full);
 };
 
 }  // namespace nidx

