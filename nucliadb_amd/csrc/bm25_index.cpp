@@ -901,9 +901,9 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 for (uint64_t c = c0; c < c1; c++)
                     for (uint64_t e = c + 1; e < c1; e++)
                         if (clauses[c].term == clauses[e].term) repeated += (double)postings_of(clauses[c]);
-                // the stream kernel resolves up to 160 involved postings per item without cutting its doc range: enough slices to keep
-                // the expected number (two postings per meeting) around 80
-                const double want = std::ceil((shared + repeated) * 2.0 / 80.0);
+                // the stream kernel resolves up to 192 involved postings per item without cutting its doc range: enough slices to keep
+                // the expected number (two postings per meeting) around 96
+                const double want = std::ceil((shared + repeated) * 2.0 / 96.0);
                 if (union_mode == 2) q_union[q] = 1;
                 else if (shared * 8.0 <= sum && want <= (double)BM25_MAX_SLICES) q_union[q] = 1;
                 if (q_union[q] && !lockstep_union) slices = (uint32_t)std::min<double>(BM25_MAX_SLICES, std::max<double>(slices, want));

@@ -28,9 +28,9 @@
 // Candidates are not inserted one by one: they are appended to a 192-entry LDS buffer (ballot compaction) and merged 64 at a time
 // into the sorted list by a bitonic network that runs in the VALU (v_permlane32/16_swap + DPP; compare-exchange = one v_cmp_gt_u64,
 // one s_xor with a constant lane mask, two v_cndmask) — ~220 issues per 64 candidates instead of ~50 per candidate.
-// An involved list that overflows (160 entries) cuts the slice's doc range in half and retries; what was already offered is offered
+// An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
-// LDS: 7 KiB per wave (A 4 KiB, B 256 B, involved list 1.25 KiB, candidates 1.5 KiB) + 3 KiB per workgroup (the quotient table) = 31 KiB:
+// LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 2 KiB per workgroup (the two score tables) = 31 KiB:
 // 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (91 VGPRs) so that the registers allow them too.
 #include "device_common.h"
 #include "kernels.h"
@@ -45,7 +45,13 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_A_WORDS 1024u   /* 32 Kibit */
 #define BS_B_WORDS 64u     /* 2 Kibit */
 #ifndef BS_CAP
-#define BS_CAP 160u        /* involved postings per doc range */
+#define BS_CAP 192u        /* involved postings per doc range */
+#endif
+#ifndef BS_QN
+#define BS_QN 1            /* rows of the quotient table: frequencies 1 .. BS_QN; 3 = the division's table stays in HBM/L2 (a.tf_cache) */
+#endif
+#ifndef BS_AHEAD
+#define BS_AHEAD 1         /* groups of four rows in flight ahead of the one being scored: 1 or 2 */
 #endif
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 5     /* waves per SIMD the k <= 64 kernel is compiled for: <= 96 VGPRs, five workgroups per CU (LDS allows five) */
@@ -121,7 +127,13 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
     // tf / (tf + K1 * (1 - B + B * fieldnorm / avg)) for tf = 1, 2, 3 and every fieldnorm id: the same two f32 operations as the
     // general form, done once per workgroup — a posting of a short document almost always has one of these frequencies, and the IEEE
     // division is ~16 instructions per row.  Larger frequencies take the division with the table of the index (a.tf_cache, L2-resident)
-    __shared__ float quot[3][256];
+    __shared__ float quot[BS_QN][256];
+#if BS_QN < 3
+    __shared__ float tf_cache_s[256];   // K1 * (1 - B + B * fieldnorm / avg) for the division
+#define BS_TFC(fn) tf_cache_s[fn]
+#else
+#define BS_TFC(fn) a.tf_cache[fn]
+#endif
     __shared__ uint32_t bm_a_all[4][BS_A_WORDS];
     __shared__ uint32_t bm_b_all[4][BS_B_WORDS];
     __shared__ uint32_t list_doc_all[4][BS_CAP];
@@ -141,9 +153,11 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
     };
     {
         const float c = a.tf_cache[threadIdx.x];
-        quot[0][threadIdx.x] = 1.0f / (1.0f + c);
-        quot[1][threadIdx.x] = 2.0f / (2.0f + c);
-        quot[2][threadIdx.x] = 3.0f / (3.0f + c);
+#pragma unroll
+        for (int t = 0; t < BS_QN; t++) quot[t][threadIdx.x] = (float)(t + 1) / ((float)(t + 1) + c);
+#if BS_QN < 3
+        tf_cache_s[threadIdx.x] = c;
+#endif
         clear_bitmaps();
     }
     __syncthreads();   // the only workgroup barrier
@@ -442,10 +456,32 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         wn[r] = (wp + s)[64u * r + (uint32_t)lane];
                     }
                 }
+#if BS_AHEAD == 2
+                uint32_t dnn[4] = {0u, 0u, 0u, 0u}, wnn[4] = {0u, 0u, 0u, 0u};   // the group after the next one
+                if (s + 256u < e) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        dnn[r] = (ip + s)[256u + 64u * r + (uint32_t)lane];
+                        wnn[r] = (wp + s)[256u + 64u * r + (uint32_t)lane];
+                    }
+                }
+#endif
                 for (uint32_t p = s; p < e && !overflow; p += 256u) {
                     uint32_t d[4], w[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) d[r] = dn[r], w[r] = wn[r];
+#if BS_AHEAD == 2
+                    // a single wave keeps little in flight (one group = 2 KiB): two groups travel while one is scored
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dn[r] = dnn[r], wn[r] = wnn[r];
+                    if (p + 512u < e) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            dnn[r] = (ip + p)[512u + 64u * r + (uint32_t)lane];
+                            wnn[r] = (wp + p)[512u + 64u * r + (uint32_t)lane];
+                        }
+                    }
+#else
                     if (p + 256u < e) {   // the next four rows travel while these are scored
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -453,6 +489,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             wn[r] = (wp + p)[256u + 64u * r + (uint32_t)lane];
                         }
                     }
+#endif
                     if (BS_FAST_GROUPS && !EXTRAS && p + 256u <= e) {
                         // ---- four full rows (the bulk of every clause): no bounds to test; the four bitmap probes and the four score
                         // look-ups travel together, and the rare events — an involved posting, a candidate for the list — are looked for once
@@ -475,14 +512,14 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             if (mode == 1u) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) sc[r] = wgt * quot[0][w[r] >> 24];
-                            } else if (!__ballot((t[0] | t[1] | t[2] | t[3]) > 2u)) {
+                            } else if (!__ballot((t[0] | t[1] | t[2] | t[3]) > (uint32_t)(BS_QN - 1))) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) sc[r] = wgt * (&quot[0][0])[(t[r] << 8) + (w[r] >> 24)];
                             } else {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
                                     const float tf = (float)(w[r] & 0xffffffu);
-                                    sc[r] = wgt * (tf / (tf + a.tf_cache[w[r] >> 24]));
+                                    sc[r] = wgt * (tf / (tf + BS_TFC(w[r] >> 24)));
                                 }
                             }
                         }
@@ -528,8 +565,14 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
 #pragma unroll
                             for (int r = 0; r < 4; r++) cnd[r] = !inv[r] && !(sc[r] < kf);
                             if (__ballot(cnd[0] || cnd[1] || cnd[2] || cnd[3])) {
+                                const uint32_t flushes = n_flush;
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
+                                    if (r == 2 && n_flush != flushes) {   // the bar rose under the first two rows: the other two face the new one
+                                        const float kf2 = rank_key_score(kth);
+                                        cnd[2] = cnd[2] && !(sc[2] < kf2);
+                                        cnd[3] = cnd[3] && !(sc[3] < kf2);
+                                    }
                                     if (__ballot(cnd[r])) offer(rank_key(sc[r], d[r]), cnd[r]);
                                     if (KL == 1 && (r & 1)) {   // the buffer holds what two rows can add on top of 63 left-overs
                                         while (n_cand >= 64u) flush64();
@@ -554,10 +597,10 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         float sc;
                         if (mode == 2u) sc = wgt;   // ConstScorer(boost)
                         else if (mode == 1u) sc = wgt * quot[0][fn];
-                        else if (!__ballot(in && tfi - 1u > 2u)) sc = wgt * (&quot[0][0])[(in ? (tfi - 1u) << 8 : 0u) + fn];   // tf in 1 .. 3
+                        else if (!__ballot(in && tfi - 1u > (uint32_t)(BS_QN - 1))) sc = wgt * (&quot[0][0])[(in ? (tfi - 1u) << 8 : 0u) + fn];   // tf in 1 .. BS_QN
                         else {
                             const float tf = (float)tfi;
-                            sc = wgt * (tf / (tf + a.tf_cache[fn]));
+                            sc = wgt * (tf / (tf + BS_TFC(fn)));
                         }
                         if (w_bits >> 31) sc = 0.f + sc;   // the oracle's sum starts at +0: -0 never leaves it
                         const unsigned long long inv_m = __ballot(inv);
@@ -639,15 +682,32 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                 const uint32_t my_doc = list_doc[live ? src : 0u];
                 const uint32_t my_sc = list_score[live ? src : 0u];
                 const uint32_t my_adds = (__builtin_amdgcn_ds_bpermute((int)(my_c << 2), (int)attr_l) & 0xff) != 2 ? 1u : 0u;   // a MustNot clause adds nothing
+                // Who shares my document?  Most involved postings are hash collisions of the bitmaps, alone with their document: instead of
+                // comparing every lane with every other (n_inv scalar round trips), the lanes drop their bit into one of 64 buckets by a
+                // hash of the document (the bitmaps' space is free now) and a lane only looks at its bucket mates — in lane order, which
+                // is clause order, so the f32 sum is built exactly as before.
+                unsigned long long *bucket = reinterpret_cast<unsigned long long *>(bm_a);
+                dirty = true;
+                bucket[lane] = 0ull;
+                bs_lds_order();
+                const uint32_t hb = (my_doc * 2654435761u) >> 26;
+                if (live) __hip_atomic_fetch_or(&bucket[hb], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bs_lds_order();
+                unsigned long long mates = live ? bucket[hb] : 0ull;   // (my own bit included)
+                const uint32_t my_ca = my_c | (my_adds << 8);
                 float acc = 0.f;
                 uint32_t mask = 0;
                 bool owner = live;
-                for (uint32_t j = 0; j < n_inv; j++) {
-                    const uint32_t dj = bs_rl(my_doc, (int)j), cj = bs_rl(my_c, (int)j);
-                    const float sj = __uint_as_float(bs_rl(my_sc, (int)j));
-                    const bool same = dj == my_doc;
-                    if (same && bs_rl(my_adds, (int)j)) acc += sj;
-                    if (same) mask |= 1u << cj;
+                while (__ballot(mates != 0ull)) {
+                    const bool has = mates != 0ull;
+                    const uint32_t j = has ? (uint32_t)__ffsll((long long)mates) - 1u : 0u;
+                    mates &= mates - 1ull;
+                    const uint32_t dj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)my_doc);
+                    const uint32_t caj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)my_ca);
+                    const float sj = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)my_sc));
+                    const bool same = has && dj == my_doc;
+                    if (same && (caj >> 8)) acc += sj;
+                    if (same) mask |= 1u << (caj & 0xffu);
                     if (same && j < (uint32_t)lane) owner = false;
                 }
                 bool ok = owner && mask_ok(mask);

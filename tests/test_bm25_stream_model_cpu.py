@@ -7,7 +7,7 @@ resolving the involved postings clause by clause reproduces the oracle's f32 sum
 merged in bulk with a stale threshold gives the same top-k as one insertion per candidate, and that cutting the doc range in half
 after an overflow and offering the already-final postings again is exact when later insertions ignore keys the list holds.
 
-The model follows the kernel's control flow and constants (hashes, bitmap sizes, the 160-entry involved list, 64-posting rows,
+The model follows the kernel's control flow and constants (hashes, bitmap sizes, the 192-entry involved list, 64-posting rows,
 four-row groups, the candidate buffer drained after rows 1 and 3 and behind a group) but not its instruction stream; per-posting
 scores come from the oracle itself (a one-clause query per term), so only the combination logic is under test."""
 import numpy as np
@@ -17,7 +17,7 @@ from nucliadb_amd import _lib
 from nucliadb_amd.bm25 import Bm25Segment
 
 S, M, N, G = _lib.OCCUR_SHOULD, _lib.OCCUR_MUST, _lib.OCCUR_MUST_NOT, _lib.OCCUR_SHOULD_GROUP
-A_BITS, B_BITS, CAP = 1 << 15, 1 << 11, 160
+A_BITS, B_BITS, CAP = 1 << 15, 1 << 11, 192
 
 
 def zipf_corpus(rng, n_docs, vocab, mean_len=24):
@@ -217,7 +217,7 @@ def test_the_stream_algorithm_equals_the_oracle_on_unions_and_boolean_mixes(inde
 
 
 def test_overflowing_involved_lists_are_retried_exactly(index):
-    """Dense and repeated terms: every posting of the shorter lists meets the longest one, the 160-entry list overflows, the doc range is
+    """Dense and repeated terms: every posting of the shorter lists meets the longest one, the 192-entry list overflows, the doc range is
     halved again and again and what was offered before is offered again."""
     FREQ = _lib.TF_FREQ
     retried = 0
