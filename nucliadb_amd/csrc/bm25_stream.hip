@@ -31,7 +31,7 @@
 // An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
 // LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 2 KiB per workgroup (the two score tables) = 31 KiB:
-// 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (91 VGPRs) so that the registers allow them too.
+// the registers (four waves per SIMD) allow four workgroups per CU.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -54,7 +54,7 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_AHEAD 1         /* groups of four rows in flight ahead of the one being scored: 1 or 2 */
 #endif
 #ifndef BS_MIN_WAVES
-#define BS_MIN_WAVES 5     /* waves per SIMD the k <= 64 kernel is compiled for: <= 96 VGPRs, five workgroups per CU (LDS allows five) */
+#define BS_MIN_WAVES 4     /* waves per SIMD the k <= 64 kernel is compiled for (5 = 96 VGPRs measured the same as 4 and spills three registers) */
 #endif
 #ifndef BS_FAST_GROUPS
 #define BS_FAST_GROUPS 1   /* four full rows at a time on the bounds-free path */
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
             if (!__ballot(wide[0] || wide[1])) break;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                step[t] = (right[t] - left[t] + G - 1u) / G;
+                step[t] = (right[t] - left[t] + G - 1u) >> g_log;   // (G = 1 << g_log)
                 probe[t] = left[t] + step[t] * li;
                 v[t] = ids[wide[t] && probe[t] < right[t] ? probe[t] : 0u];
             }
@@ -390,18 +390,23 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         uint32_t d[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) d[r] = (ip + p)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
-                        if (BS_FAST_GROUPS && p + 256u <= e) {
-                            // four full rows: nothing to bound; the four ds_or_rtn go out back to back (LDS operations of a wave execute in
-                            // order: row r still sees the bits of the rows before it) and a second posting of a document is looked for once
+                        if (BS_FAST_GROUPS) {
+                            // a group of up to four rows, the lanes behind the clause's end switched off: the four ds_or_rtn go out back to
+                            // back (LDS operations of a wave execute in order: row r still sees the bits of the rows before it) and a
+                            // second posting of a document is looked for once per group
+                            const uint32_t rem = e - p;
                             uint32_t h[4], old[4];
+                            bool in[4];
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
+                                in[r] = (uint32_t)lane + 64u * r < rem;
                                 h[r] = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
-                                old[r] = __hip_atomic_fetch_or(&bm_a[h[r] >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                old[r] = 0u;
+                                if (in[r]) old[r] = __hip_atomic_fetch_or(&bm_a[h[r] >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             bool hit[4];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) hit[r] = __builtin_amdgcn_ubfe(old[r], h[r], 1u) != 0u;
+                            for (int r = 0; r < 4; r++) hit[r] = in[r] && __builtin_amdgcn_ubfe(old[r], h[r], 1u) != 0u;
                             if (__ballot(hit[0] || hit[1] || hit[2] || hit[3])) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++)
@@ -490,13 +495,16 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         }
                     }
 #endif
-                    if (BS_FAST_GROUPS && !EXTRAS && p + 256u <= e) {
-                        // ---- four full rows (the bulk of every clause): no bounds to test; the four bitmap probes and the four score
-                        // look-ups travel together, and the rare events — an involved posting, a candidate for the list — are looked for once
-                        // per group instead of once per row ----
+                    if (BS_FAST_GROUPS && !EXTRAS) {
+                        // ---- a group of up to four rows, the lanes behind the clause's end switched off: the four bitmap probes and the
+                        // four score look-ups travel together, and the rare events — an involved posting, a candidate for the list — are
+                        // looked for once per group instead of once per row ----
+                        const uint32_t rem = e - p;
                         uint32_t h[4], bw[4] = {0u, 0u, 0u, 0u};
+                        bool in[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
+                            in[r] = (uint32_t)lane + 64u * r < rem;
                             h[r] = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
                             if (probe) bw[r] = is_long ? bm_a[h[r] >> 5] : bm_b[(h[r] & 0x7ffu) >> 5];
                         }
@@ -505,10 +513,10 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
 #pragma unroll
                             for (int r = 0; r < 4; r++) sc[r] = wgt;
                         } else {
-                            // every frequency of the group in 1 .. 3 (the usual case): the quotient comes from the table
+                            // every frequency of the group in 1 .. BS_QN (the usual case): the quotient comes from the table
                             uint32_t t[4];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) t[r] = (w[r] & 0xffffffu) - 1u;   // (tf == 0 wraps to 2^24 - 1 and takes the division)
+                            for (int r = 0; r < 4; r++) t[r] = in[r] ? (w[r] & 0xffffffu) - 1u : 0u;   // (tf == 0 wraps to 2^24 - 1 and takes the division)
                             if (mode == 1u) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) sc[r] = wgt * quot[0][w[r] >> 24];
@@ -528,10 +536,10 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             for (int r = 0; r < 4; r++) sc[r] = 0.f + sc[r];
                         }
                         bool inv[4] = {false, false, false, false};
-                        uint32_t n_final = 256u;
+                        uint32_t n_final = rem < 256u ? rem : 256u;
                         if (probe) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) inv[r] = __builtin_amdgcn_ubfe(bw[r], h[r], 1u) != 0u;
+                            for (int r = 0; r < 4; r++) inv[r] = in[r] && __builtin_amdgcn_ubfe(bw[r], h[r], 1u) != 0u;
                             if (__ballot(inv[0] || inv[1] || inv[2] || inv[3])) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             const float kf = rank_key_score(kth);
                             bool cnd[4];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) cnd[r] = !inv[r] && !(sc[r] < kf);
+                            for (int r = 0; r < 4; r++) cnd[r] = in[r] && !inv[r] && !(sc[r] < kf);
                             if (__ballot(cnd[0] || cnd[1] || cnd[2] || cnd[3])) {
                                 const uint32_t flushes = n_flush;
 #pragma unroll
