@@ -93,6 +93,7 @@ struct Bm25Slot {
 
 struct Bm25Index {
     int device = 0;
+    int n_cus = 256;   // compute units of the device (the work-item budget of one launch round follows it)
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::vector<Bm25Segment> segs;
@@ -103,6 +104,7 @@ struct Bm25Index {
     std::vector<uint32_t> w_item_first, w_item_list;
     std::vector<Bm25Work> w_work;
     std::vector<uint8_t> w_q_union;
+    std::vector<uint64_t> w_postings;
     DevBuf tf_cache;
     DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
@@ -154,6 +156,10 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     *index_out = nullptr;
     std::unique_ptr<Bm25Index> idx(new Bm25Index());
     NIDX_HIP(hipGetDevice(&idx->device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) == hipSuccess && cus > 0) idx->n_cus = cus;
+    }
     {
         // BM25 launches are short (~0.15 ms) and their callers wait for them; when they share the device with HNSW batches in flight
         // (the hybrid request: serving.cpp keeps several on their own streams) they should not queue behind those: highest priority
@@ -881,6 +887,23 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         item_first.assign(nq + 1, 0);
         q_union.assign(nq, 0);
         const double inv_docs = 1.0 / std::max<double>(1.0, (double)seg.n_docs);
+        // Postings per work item.  A launch lasts as long as its slowest item while every workgroup of it is resident at once (5 per CU,
+        // 4 items each); past that the tail of the grid runs as a second round.  So: the smallest slice between 1 024 and the default
+        // that still fits the batch into one round (the bench batch: ~1 900 instead of 2 048, its slowest items 7 % shorter); batches
+        // too large for one round keep the default.  NIDX_GPU_BM25_SLICE pins it.
+        uint64_t slice_now = slice_postings;
+        if (!getenv("NIDX_GPU_BM25_SLICE")) {
+            const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
+            std::vector<uint64_t> &pq = idx->w_postings;
+            pq.assign(nq, 0);
+            for (uint32_t q = 0; q < nq; q++)
+                for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) pq[q] += postings_of(clauses[c]);
+            for (uint64_t cand = 1024; cand < slice_postings; cand += 128) {
+                uint64_t items = 0;
+                for (uint32_t q = 0; q < nq && items <= budget; q++) items += std::max<uint64_t>(1, (pq[q] + cand - 1) / cand);
+                if (items <= budget) { slice_now = cand; break; }
+            }
+        }
         for (uint32_t q = 0; q < nq; q++) {
             item_first[q] = (uint32_t)work.size();
             const uint64_t c0 = clause_offsets[q], c1 = clause_offsets[q + 1];
@@ -893,7 +916,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 sum_sq += (double)l * (double)l;
                 if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
             }
-            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_postings - 1) / slice_postings));
+            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_now - 1) / slice_now));
             if (union_mode != 0 && plain && c1 > c0 && c1 - c0 <= BM25_FAST_CLAUSES && !force_wide) {
                 const double sum = (double)p, shared = (sum * sum - sum_sq) * 0.5 * inv_docs;
                 // the same term twice: those two lists meet in every document (the estimate above assumes independent lists)

@@ -31,7 +31,7 @@
 // An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
 // LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 2 KiB per workgroup (the two score tables) = 31 KiB:
-// the registers (four waves per SIMD) allow four workgroups per CU.
+// 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (<= 96 VGPRs) so that the registers allow them too.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -54,7 +54,7 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_AHEAD 1         /* groups of four rows in flight ahead of the one being scored: 1 or 2 */
 #endif
 #ifndef BS_MIN_WAVES
-#define BS_MIN_WAVES 4     /* waves per SIMD the k <= 64 kernel is compiled for (5 = 96 VGPRs measured the same as 4 and spills three registers) */
+#define BS_MIN_WAVES 5     /* waves per SIMD the k <= 64 kernel is compiled for: <= 96 VGPRs, so that the 1 061 workgroups of the bench batch are all resident (5 per CU = 1 280 slots; with 4 the last 37 run as a second round: 73 us instead of 57) */
 #endif
 #ifndef BS_FAST_GROUPS
 #define BS_FAST_GROUPS 1   /* four full rows at a time on the bounds-free path */
@@ -119,6 +119,33 @@ __device__ inline uint64_t bs_merge64(uint64_t top, uint64_t v) {
     v = bs_sort_stages<64>(v);            // ascending
     const uint64_t m = top > v ? top : v; // a descending and an ascending run, element by element: bitonic, holds the 64 best
     return bs_merge_steps<32>(m);
+}
+
+// The same network on one f32 per lane (ascending): a compare-exchange is the partner fetch, v_max, v_min and a select.
+template <int J>
+__device__ inline float bs_cmpx_f32(float v, unsigned long long take_max_mask) {
+    const bool tm = __builtin_amdgcn_inverse_ballot_w64(take_max_mask);
+    if constexpr (J >= 16) {
+        uint32_t a0 = __float_as_uint(v), a1 = a0;
+        if constexpr (J == 32) swap_pair32(a0, a1);
+        else swap_pair16(a0, a1);
+        const float x = __uint_as_float(a0), y = __uint_as_float(a1);   // {own, partner} in some order
+        return tm ? fmaxf(x, y) : fminf(x, y);
+    } else {
+        const float p = __uint_as_float(xor_partner_dpp<J>(__float_as_uint(v)));
+        return tm ? fmaxf(v, p) : fminf(v, p);
+    }
+}
+template <int K, int J>
+__device__ inline float bs_sort_steps_f32(float v) {
+    v = bs_cmpx_f32<J>(v, bs_sort_mask(K, J));
+    if constexpr (J > 1) return bs_sort_steps_f32<K, J / 2>(v);
+    else return v;
+}
+template <int K>
+__device__ inline float bs_sort_stages_f32(float v) {
+    if constexpr (K > 2) v = bs_sort_stages_f32<K / 2>(v);
+    return bs_sort_steps_f32<K, K / 2>(v);
 }
 
 // DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
@@ -343,6 +370,12 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         }
     };
 
+    // A bar under the candidates before the list has one: the first group of final postings of an item leaves every lane the best
+    // score it saw; the k-th largest of those 64 maxima is the k-th best of 64 real documents, hence never above the k-th best of
+    // the item — one f32 sort (~100 issues) instead of the three or four 64-key merges the list otherwise needs to climb there
+    // (every posting passes while it is empty, and a bar that is only refreshed by a merge lags behind the stream).
+    float bar = -INFINITY;
+    bool bar_set = false;
     uint32_t postings = 0, total = 0, n_ranges = 0;
     uint32_t cur_lo = lo_doc, cur_hi = hi_doc;
     uint32_t e_l = item_e_l;
@@ -568,7 +601,15 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             matched += n_final;
                             // most groups hold nothing the list wants once it is full: one float compare per posting before any key is built
                             // (the k-th score is NaN while the list is not full: !(s < NaN) lets every score through to the exact test)
-                            const float kf = rank_key_score(kth);
+                            if (KL == 1 && !bar_set) {
+                                float mx = -INFINITY;
+#pragma unroll
+                                for (int r = 0; r < 4; r++)
+                                    if (in[r] && !inv[r]) mx = fmaxf(mx, sc[r]);
+                                bar = lane_bcast_f32(bs_sort_stages_f32<64>(mx), 64 - k);   // -inf while fewer than k lanes saw a final posting
+                                bar_set = true;
+                            }
+                            const float kf = fmaxf(bar, rank_key_score(kth));   // (NaN while the list is not full: fmaxf keeps the bar)
                             bool cnd[4];
 #pragma unroll
                             for (int r = 0; r < 4; r++) cnd[r] = in[r] && !inv[r] && !(sc[r] < kf);
@@ -577,7 +618,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
                                     if (r == 2 && n_flush != flushes) {   // the bar rose under the first two rows: the other two face the new one
-                                        const float kf2 = rank_key_score(kth);
+                                        const float kf2 = fmaxf(bar, rank_key_score(kth));
                                         cnd[2] = cnd[2] && !(sc[2] < kf2);
                                         cnd[3] = cnd[3] && !(sc[3] < kf2);
                                     }
