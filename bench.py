@@ -455,9 +455,9 @@ def serialize_graph(L, h, seg=0):
 
 def pmc_traffic(kind, n, d, B, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r03_pmc_traffic.json — or the previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
+    (profiles/r04_pmc_traffic.json — or a previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
     cannot be read from inside this process)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 for e in json.load(f)["entries"]:
@@ -1498,10 +1498,12 @@ class Bm25Bench:
                                                       C.byref(self._opt), C.byref(t)))
         return t.value
 
-    def wait(self, ticket):
+    def wait(self, ticket, out=None):
+        """out: (docaddr u64 [B][K], score f32 [B][K], count u32 [B]) to fill instead of the bench's own arrays"""
         from nucliadb_amd import _lib
 
-        _lib.check(self.L.nidx_gpu_bm25_search_wait(self.searcher._handle, ticket, self.docaddr.ctypes.data, self.score.ctypes.data, self.count.ctypes.data,
+        da, sc, cn = out if out is not None else (self.docaddr, self.score, self.count)
+        _lib.check(self.L.nidx_gpu_bm25_search_wait(self.searcher._handle, ticket, da.ctypes.data, sc.ctypes.data, cn.ctypes.data,
                                                     self.total.ctypes.data, self.post.ctypes.data))
 
     def close(self):
@@ -1626,6 +1628,19 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
     n_pool = qpool.shape[0]
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
+    # the fusion of batch i (native host code, the GIL released) runs on a second host thread while batch i + 1 is waited for: its
+    # inputs are double-buffered, its result is collected one step later
+    from concurrent.futures import ThreadPoolExecutor
+
+    fuser = ThreadPoolExecutor(max_workers=1)
+    bm_out = [(np.zeros((B, kb), np.uint64), np.zeros((B, kb), np.float32), np.zeros(B, np.uint32)) for _ in range(2)]
+    fusing = []   # the job of the previous batch
+    low32 = np.uint64(0xFFFFFFFF)
+
+    def fuse(bo, vo):
+        # keyword list first, like nucliadb's fuse({"keyword": .., "semantic": ..}); ids = document numbers
+        return rrf_fuse_batch([(bo[0] & low32, bo[2], 1.0, bo[1]), (vo[0].astype(np.uint64), vo[2], 1.0, None)], k=60.0, window=k)
+
     in_flight = []
     bm_in_flight = []   # (batch, ticket): the keyword search runs one batch ahead too (nidx_gpu_bm25_search_submit / _wait)
     t_parts = {"vector_submit": 0.0, "bm25_submit_wait": 0.0, "vector_wait": 0.0, "fusion": 0.0}
@@ -1645,15 +1660,19 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         while len(bm_in_flight) < 2 and (i + len(bm_in_flight)) < last:
             bm_in_flight.append((i + len(bm_in_flight), bm.submit(i + len(bm_in_flight))))
         _bi, btk = bm_in_flight.pop(0)
-        bm.wait(btk)
+        bo = bm_out[i % 2]
+        bm.wait(btk, out=bo)
         kernel_ms.append(bm.kernel_ms())
         t2 = time.perf_counter()
         tk, j = in_flight.pop(0)
         hv_, hs_, hc_ = host_out[j]
         _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, None))
         t3 = time.perf_counter()
-        # keyword list first, like nucliadb's fuse({"keyword": .., "semantic": ..}); ids = document numbers
-        fused = rrf_fuse_batch([(bm.docaddr & np.uint64(0xFFFFFFFF), bm.count, 1.0, bm.score), (hv_.astype(np.uint64), hc_, 1.0, None)], k=60.0, window=k)
+        job = fuser.submit(fuse, bo, host_out[j])
+        fused = fusing.pop(0).result() if fusing else None   # batch i - 1, fused while this batch was waited for
+        fusing.append(job)
+        if i + 1 == last:   # the last batch of a region is fused inside it
+            fused = fusing.pop(0).result()
         t4 = time.perf_counter()
         t_parts["vector_submit"] += t1 - t0
         t_parts["bm25_submit_wait"] += t2 - t1
@@ -1688,6 +1707,7 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         "value": B * n_steps / elapsed, "unit": "hybrid queries/s", "steps": n_steps, "ms_per_step": elapsed / n_steps * 1e3,
         "workload": "hybrid: HNSW over the timed shard + BM25 over %d docs (vocab %d), batch=%d, RRF k=60, results (fused ids + scores) on the host" % (bm.n_docs, bm.vocab, B),
         "vector_batches_in_flight": nfl, "bm25_kernel_ms": float(np.mean(kernel_ms)),
+        "fusion": "nidx_gpu_rank_fusion_rrf (native, host) on a second host thread, one batch behind the searches; ms_per_step_parts.fusion = what the main loop still waits for it",
         "ms_per_step_parts": {kk_: v / n_steps * 1e3 for kk_, v in t_parts.items()},
         "cpu_baseline": None,
     }

@@ -389,9 +389,11 @@ int32_t nidx_gpu_vector_serialize_hnsw(const nidx_gpu_vector_index_t *index, uin
  * addresses) are read when index.map exists (InvertedIndexes::exists, inverted_index.rs:57-60) and every list in
  * them is a well-formed list of this paragraph store; otherwise — like segment::open when they are missing
  * (segment.rs:49-67) — the posting lists are rebuilt from the paragraph store (ParagraphInvertedIndexes::build,
- * paragraph.rs:68-103).  nidx_gpu_segment_dir_write / _merge write the three files (NIDX_GPU_SEGMENT_DIR_FST=0 in the
- * environment: neither written nor read — the reference then regenerates them on open).  The two containers are
- * third-party formats (fst 0.4.7, stream-vbyte 0.4.1) restated without the crates at hand: see fst_index.cpp.
+ * paragraph.rs:68-103).  nidx_gpu_segment_dir_write / _merge write the three files when NIDX_GPU_SEGMENT_DIR_FST=1 is in the
+ * environment; by default they leave them out — the reference regenerates them on open — because the two containers are
+ * third-party formats (fst 0.4.7, stream-vbyte 0.4.1) restated without the crates at hand (see fst_index.cpp): until the
+ * one-time check of INTEGRATION.md section 3 has been run against the crates, a directory without them is the safe one to
+ * hand to the stock searcher.  NIDX_GPU_SEGMENT_DIR_FST=0: neither written nor read.
  * A pre-migration directory — nodes.kv (DataStoreV1, data_store/v1.rs) and index.hnsw (DiskHnswV1, hnsw/disk/v1.rs), what
  * segment::open takes first when nodes.kv exists (segment.rs:41-57) and open_disk_hnsw falls back to (hnsw/disk.rs:25-32) —
  * is migrated in memory at open: its records and graph are re-laid out as the vectors.bin / paragraphs.bin / paragraphs.pos /

@@ -419,10 +419,17 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                     const unsigned long long base = ((unsigned long long)bs_rl((uint32_t)(b_l >> 32), c) << 32) | bs_rl((uint32_t)b_l, c);
                     const uint32_t s = bs_rl(s_l, c), e = bs_rl(e_l, c);
                     const uint32_t *ip = doc_ids + base;
+                    uint32_t dnx[4];   // the next group travels while this one is marked (a wave alone waits ~3 000 cycles for every load)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dnx[r] = (ip + s)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
                     for (uint32_t p = s; p < e; p += 256u) {
                         uint32_t d[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) d[r] = (ip + p)[64u * r + (uint32_t)lane];   // (the arrays are padded behind the last list)
+                        for (int r = 0; r < 4; r++) d[r] = dnx[r];
+                        if (p + 256u < e) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) dnx[r] = (ip + p)[256u + 64u * r + (uint32_t)lane];
+                        }
                         if (BS_FAST_GROUPS) {
                             // a group of up to four rows, the lanes behind the clause's end switched off: the four ds_or_rtn go out back to
                             // back (LDS operations of a wave execute in order: row r still sees the bits of the rows before it) and a

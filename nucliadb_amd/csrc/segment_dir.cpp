@@ -14,8 +14,8 @@
 // files when index.map is there (InvertedIndexes::exists, inverted_index.rs:57-60) and every list they hold passes the
 // checks below; otherwise — like segment::open when they are missing (segment.rs:49-67) — the posting lists are rebuilt
 // from the paragraph store, keyed the same way (ParagraphInvertedIndexes::build, inverted_index/paragraph.rs:68-103:
-// labels_key / FieldKey).  Writers emit the three files next to the stores (NIDX_GPU_SEGMENT_DIR_FST=0: neither written
-// nor read).
+// labels_key / FieldKey).  Writers emit the three files next to the stores when NIDX_GPU_SEGMENT_DIR_FST=1 (the default only
+// reads them; 0: neither written nor read).
 //
 // StoredParagraph is serialised with wincode configured to match bincode::config::standard() (utils.rs:25-28): little
 // endian, variable-length integers (u < 251: one byte; 251 + u16; 252 + u32; 253 + u64), a sequence or string = its
@@ -171,9 +171,17 @@ struct ListBuilder {
     }
 };
 
-bool fst_files_enabled() {
+// NIDX_GPU_SEGMENT_DIR_FST: unset = READ the three index files when they are there and well formed, do not WRITE them; 1 = write
+// them too; 0 = neither.  Writing is opt-in because the `fst` / `stream-vbyte` byte layouts are restated without the crates at hand
+// (parity unpinned): a directory written without them is one the stock searcher completes itself on open
+// (segment.rs:49-67), a directory written with a wrong one would be trusted.
+bool fst_files_readable() {
     const char *e = getenv("NIDX_GPU_SEGMENT_DIR_FST");
     return !(e && e[0] == '0');
+}
+bool fst_files_written() {
+    const char *e = getenv("NIDX_GPU_SEGMENT_DIR_FST");
+    return e && e[0] == '1';
 }
 
 int write_bytes(const std::string &path, const void *p, size_t n) {
@@ -308,7 +316,7 @@ int32_t nidx_gpu_segment_dir_open(const char *path, uint32_t dimension, nidx_gpu
     d->key_ids.resize(d->n_paragraphs);
     const uint8_t *data = d->para_data.p;
     const size_t dlen = d->para_data.len;
-    d->lists_from_files = fst_files_enabled() && load_index_files(d.get(), base);
+    d->lists_from_files = fst_files_readable() && load_index_files(d.get(), base);
     const bool rebuild = !d->lists_from_files;
     ListBuilder lb;
     for (uint32_t a = 0; a < d->n_paragraphs; a++) {
@@ -507,7 +515,7 @@ int32_t nidx_gpu_segment_dir_write(const char *path, const nidx_gpu_segment_dir_
         }
         if (write_file(base + "paragraphs.bin", data.data(), data.size())) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.bin", base.c_str());
         if (write_file(base + "paragraphs.pos", pos.data(), pos.size() * 4)) return fail(NIDX_ERR_IO, "cannot write %sparagraphs.pos", base.c_str());
-        if (fst_files_enabled() && write_index_files(base, built.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
+        if (fst_files_written() && write_index_files(base, built.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
     }
     if (c->quantized && c->quantized_len) {
         if (c->quantized_len != (uint64_t)c->n_vectors * (D / 8 + 8)) return fail(NIDX_ERR_INVALID_ARGUMENT, "quantized store has the wrong size");
@@ -605,7 +613,7 @@ int32_t nidx_gpu_segment_dir_merge(const char *path, uint32_t dimension, const n
         }
     }
     if (!vec.finish() || !pdata.finish() || !ppos.finish() || (quant && !quant->finish())) return fail(NIDX_ERR_IO, "cannot write the merged segment under %s", base.c_str());
-    if (fst_files_enabled() && write_index_files(base, lb.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
+    if (fst_files_written() && write_index_files(base, lb.lists)) return fail(NIDX_ERR_IO, "cannot write the inverted indexes under %s", base.c_str());
     // merge_indexes (segment.rs:137-167): the largest operand's graph is reused when none of its paragraphs is deleted — its
     // vectors are then the first rows of the merged store; the caller extends it (nidx_gpu_vector_extend_hnsw)
     const SegmentDir *first = dir_of(order[0]);

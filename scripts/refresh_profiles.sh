@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 3: re-measures the headline workload (bench.py default: 10 M x 768 cosine HNSW, batch 1024) on the GPU box and writes under
+# Round 4: re-measures the headline workload (bench.py default: 10 M x 768 cosine HNSW, batch 1024) on the GPU box and writes under
 # gpurun_out/final/: the bench line, and per corpus (clustered = the timed one, uniform = the second figure) the rocprofv3
 # --kernel-trace --stats summary plus the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes, --kernel-trace only) of the same
-# command with the side legs switched off.  scripts/make_pmc_traffic.py turns the summaries into profiles/r03_pmc_traffic.json.
+# command with the side legs switched off.  scripts/make_pmc_traffic.py turns the summaries into profiles/r04_pmc_traffic.json.
 # Usage (repo root, GPU box): bash scripts/refresh_profiles.sh [n_vectors]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

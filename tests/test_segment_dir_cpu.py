@@ -12,6 +12,13 @@ from nucliadb_amd.vector import SegmentDir, VectorSegment
 RID = [uuid.UUID(int=0x1000 + i) for i in range(4)]
 
 
+@pytest.fixture(autouse=True)
+def _write_index_files(monkeypatch):
+    """The writers leave field.fst / label.fst / index.map out unless asked (NIDX_GPU_SEGMENT_DIR_FST=1: their byte layouts are
+    restated without the crates at hand): the tests of this module exercise them, so they ask."""
+    monkeypatch.setenv("NIDX_GPU_SEGMENT_DIR_FST", "1")
+
+
 def corpus(rng, dimension=8):
     keys, labels, metadata = [], [], []
     fields = ["t/title", "t/title2", "a/body", "f/file/extra"]
@@ -384,6 +391,13 @@ def test_damaged_index_files_fall_back_to_the_rebuild(tmp_path, monkeypatch):
     other.mkdir()
     VectorSegment(keys, vectors, labels, metadata).save(str(other))
     assert sorted(os.listdir(other)) == ["paragraphs.bin", "paragraphs.pos", "vectors.bin"]
+    # the default (variable unset): files that are there are read, new directories are written without them
+    monkeypatch.delenv("NIDX_GPU_SEGMENT_DIR_FST")
+    assert reopen()
+    third = tmp_path / "default"
+    third.mkdir()
+    VectorSegment(keys, vectors, labels, metadata).save(str(third))
+    assert sorted(os.listdir(third)) == ["paragraphs.bin", "paragraphs.pos", "vectors.bin"]
 
 
 def test_fst_and_index_map_containers(orc):
