@@ -42,9 +42,6 @@ inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
 inline void futex_wake_all(std::atomic<uint32_t> *w) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
 }
-inline void futex_wake_one(std::atomic<uint32_t> *w) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
-}
 }  // namespace
 
 struct CoBatch {
@@ -75,13 +72,17 @@ struct Coalescer {
     uint64_t n_batches = 0, n_queries = 0;
     uint32_t window_us = 50, max_batch = 1024, max_in_flight = 4;
     // Admission: at most max_callers requests are inside the coalescer (joined, on the device or collecting their hits); the others
-    // wait at the door on ONE futex word and are let in one by one as requests leave — or are turned away (NIDX_ERR_BUSY) when the
-    // host prefers to shed load.  Without the bound 1 024 blocked callers (16 threads per core) all contend for batches, mutex and
-    // time slices at once: 100 k queries/s at p99 87 ms, where 256 callers get 318 k at p99 2.4 ms (round 3).
+    // wait at the door in ARRIVAL ORDER — a ticket each; ticket t enters once t - max_callers requests have left — or are turned
+    // away (NIDX_ERR_BUSY) when the host prefers to shed load.  Without the bound 1 024 blocked callers (16 threads per core) all
+    // contend for batches, mutex and time slices at once: 100 k queries/s at p99 87 ms, where 256 callers get 318 k at p99 2.4 ms
+    // (round 3).  The hand-over is targeted: a request that leaves wakes exactly the one waiter whose turn it makes (its own futex
+    // word), never the crowd; and a caller that comes straight back with its next request queues behind the waiters (a free-for-all
+    // door let the callers inside re-enter for ever while the woken ones found the door shut again: 10 k queries/s, p50 92 ms).
+    static constexpr uint32_t DOOR_SLOTS = 4096;
     std::atomic<uint32_t> max_callers{256};   // 0 = unbounded
     std::atomic<uint32_t> reject_when_full{0};
-    std::atomic<uint32_t> gate{0};            // futex word: bumped whenever a request leaves while somebody waits at the door
-    std::atomic<uint32_t> at_door{0};
+    std::atomic<uint64_t> next_ticket{0}, left{0};   // requests that took a ticket / that have left
+    std::unique_ptr<std::atomic<uint32_t>[]> door{new std::atomic<uint32_t>[DOOR_SLOTS]()};   // futex word of ticket t: door[t % DOOR_SLOTS]
     std::atomic<uint64_t> n_waited{0}, n_rejected{0};
 };
 
@@ -102,30 +103,39 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
     const auto t_in = std::chrono::steady_clock::now();
     auto t_joined = t_in, t_gathered = t_in, t_searched = t_in;
     // ---- admission (see Coalescer::max_callers) ----
-    for (bool waited = false;;) {
-        const uint32_t cap = c.max_callers.load(std::memory_order_relaxed);
-        uint32_t a = c.active.load(std::memory_order_relaxed);
-        if (cap == 0 || a < cap) {
-            if (c.active.compare_exchange_weak(a, a + 1, std::memory_order_acq_rel)) break;
-            continue;
-        }
-        if (c.reject_when_full.load(std::memory_order_relaxed)) {
+    {
+        const uint32_t cap0 = c.max_callers.load(std::memory_order_relaxed);
+        if (cap0 && c.reject_when_full.load(std::memory_order_relaxed) &&
+            c.next_ticket.load(std::memory_order_relaxed) - c.left.load(std::memory_order_relaxed) >= cap0) {
             c.n_rejected.fetch_add(1, std::memory_order_relaxed);
-            return fail(NIDX_ERR_BUSY, "%u single-query requests are already inside the coalescer (coalesce_max_callers)", cap);
+            return fail(NIDX_ERR_BUSY, "%u single-query requests are already inside the coalescer (coalesce_max_callers)", cap0);
         }
-        const uint32_t g = c.gate.load(std::memory_order_acquire);
-        c.at_door.fetch_add(1, std::memory_order_acq_rel);
-        if (c.active.load(std::memory_order_acquire) >= cap) futex_wait(&c.gate, g);   // (a request that left after `g` was read bumped the word)
-        c.at_door.fetch_sub(1, std::memory_order_acq_rel);
-        if (!waited) c.n_waited.fetch_add(1, std::memory_order_relaxed), waited = true;
+        const uint64_t t = c.next_ticket.fetch_add(1, std::memory_order_acq_rel);
+        std::atomic<uint32_t> &word = c.door[t % Coalescer::DOOR_SLOTS];
+        bool waited = false;
+        for (;;) {
+            const uint32_t cap = c.max_callers.load(std::memory_order_relaxed);
+            const uint32_t v = word.load(std::memory_order_acquire);
+            if (cap == 0 || t < c.left.load(std::memory_order_acquire) + cap) break;
+            waited = true;
+            futex_wait(&word, v);   // (the request whose leaving makes it this ticket's turn bumps the word first)
+        }
+        if (waited) c.n_waited.fetch_add(1, std::memory_order_relaxed);
+        c.active.fetch_add(1, std::memory_order_relaxed);
     }
     struct ActiveCount {
         Coalescer &c;
         ~ActiveCount() {
-            c.active.fetch_sub(1, std::memory_order_acq_rel);
-            if (c.at_door.load(std::memory_order_acquire)) {
-                c.gate.fetch_add(1, std::memory_order_release);
-                futex_wake_one(&c.gate);
+            c.active.fetch_sub(1, std::memory_order_relaxed);
+            const uint64_t gone = c.left.fetch_add(1, std::memory_order_acq_rel) + 1;
+            const uint32_t cap = c.max_callers.load(std::memory_order_relaxed);
+            if (cap) {   // ticket gone + cap - 1 may enter now: wake it if it is waiting (a bump nobody waits for costs nothing)
+                const uint64_t turn = gone + cap - 1;
+                if (turn < c.next_ticket.load(std::memory_order_acquire)) {
+                    std::atomic<uint32_t> &word = c.door[turn % Coalescer::DOOR_SLOTS];
+                    word.fetch_add(1, std::memory_order_release);
+                    futex_wake_all(&word);   // (tickets DOOR_SLOTS apart share a word: all of them look again)
+                }
             }
         }
     } active_count{c};
@@ -274,9 +284,11 @@ std::shared_ptr<Coalescer> make_coalescer() { return std::make_shared<Coalescer>
 
 void VectorIndex::coalescer_admission(int32_t max_callers, int32_t reject_when_full) {
     if (max_callers >= 0) {
-        coalescer->max_callers.store((uint32_t)max_callers, std::memory_order_relaxed);
-        coalescer->gate.fetch_add(1, std::memory_order_release);   // a raised bound lets the door look again
-        futex_wake_all(&coalescer->gate);
+        coalescer->max_callers.store((uint32_t)max_callers, std::memory_order_release);
+        for (uint32_t i = 0; i < Coalescer::DOOR_SLOTS; i++) {   // a raised bound lets everybody at the door look again
+            coalescer->door[i].fetch_add(1, std::memory_order_release);
+            futex_wake_all(&coalescer->door[i]);
+        }
     }
     if (reject_when_full >= 0) coalescer->reject_when_full.store(reject_when_full ? 1u : 0u, std::memory_order_relaxed);
 }
