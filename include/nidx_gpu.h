@@ -164,7 +164,7 @@ typedef struct {
  *                     paragraph addresses) = inverted_indexes.filter(formula), already ANDed
  *                     with nothing: the alive bitset is applied here (segment.rs:516-529)
  *   out_segment/out_paragraph/out_vector/out_score   [n_queries][k] (k <= 512: nucliadb's result_per_page = max(top_k, rank-fusion window, reranker window) <= 500;
- *                     the RaBitQ arms keep 256: larger pages take the exact arms); rows hold out_count[q] hits,
+ *                     every arm, the RaBitQ ones included); rows hold out_count[q] hits,
  *                     score descending (Fssc -> Vec, searcher.rs:156-161)
  *   out_method        NULL or [n_segments]: NIDX_METHOD_* chosen per segment (same for every query)
  * Errors: NIDX_ERR_INCONSISTENT_DIMENSIONS is raised by nidx_gpu_vector_search_dim. */

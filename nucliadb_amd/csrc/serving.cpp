@@ -229,7 +229,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 int method = p.method;
                 if (method == NIDX_METHOD_AUTO) {
                     // OpenSegment::_search (segment.rs:506-513,535-555), like search_host
-                    const bool rabitq = rabitq_enabled(seg) && k <= 256;
+                    const bool rabitq = rabitq_enabled(seg);
                     const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, rabitq);
                     method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
                                     : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);

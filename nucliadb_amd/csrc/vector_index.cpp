@@ -457,7 +457,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
     }
     if (method == NIDX_METHOD_RABITQ_HNSW || method == NIDX_METHOD_RABITQ_BRUTE_FORCE) {
         if (!seg.has_quant) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u has no quantized store", s);
-        if (k > 256) return fail(NIDX_ERR_UNSUPPORTED, "the RaBitQ arms keep at most 256 hits per query (got k=%u)", k);
+        if (k > NIDX_K_MAX) return fail(NIDX_ERR_UNSUPPORTED, "the RaBitQ arms keep at most %d hits per query (got k=%u)", NIDX_K_MAX, k);
         const bool hnsw = method == NIDX_METHOD_RABITQ_HNSW;
         const uint32_t nw = seg.dim / 64u;
         NIDX_HIP(scratch_rq.reserve((size_t)nq * sizeof(RabitqQueryDev)));
@@ -953,7 +953,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
         int method = p.method;
         if (method == NIDX_METHOD_AUTO) {
             // OpenSegment::_search (segment.rs:506-513,535-555): RaBitQ whenever the store has quantized vectors
-            const bool rabitq = rabitq_enabled(seg) && k <= 256;   // the RaBitQ kernels keep at most 256 hits: larger pages take the exact arms
+            const bool rabitq = rabitq_enabled(seg);   // (pages up to NIDX_K_MAX: the lists of the RaBitQ kernels are sized by k)
             const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, matching, k, rabitq);
             method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
                             : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);
@@ -1475,7 +1475,7 @@ static int32_t device_entry_method(VectorIndex *idx, uint32_t segment, const nid
     if (method == NIDX_METHOD_AUTO) {
         if (d_filter) return fail(NIDX_ERR_INVALID_ARGUMENT, "NIDX_METHOD_AUTO with a device filter: pick the method explicitly");
         // OpenSegment::_search (segment.rs:506-513,535-555), like search_host
-        const bool rabitq = idx->rabitq_enabled(seg) && params->k <= 256;
+        const bool rabitq = idx->rabitq_enabled(seg);
         const bool hnsw = seg.has_graph && use_hnsw(seg.n_paragraphs, seg.alive_count, params->k, rabitq);
         method = rabitq ? (hnsw ? NIDX_METHOD_RABITQ_HNSW : NIDX_METHOD_RABITQ_BRUTE_FORCE)
                         : (hnsw ? NIDX_METHOD_HNSW : NIDX_METHOD_BRUTE_FORCE);

@@ -120,7 +120,8 @@ def test_quantize_needs_a_quantizable_config():
 
 # ---- brute force, RaBitQ arm --------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,nq,k", [(1, 64, 1, 3), (70, 64, 3, 100), (5000, 128, 9, 10), (20000, 768, 12, 10),
-                                      (6000, 1024, 5, 1), (3000, 192, 4, 64), (2000, 2048, 3, 7), (4000, 256, 3, 256)])
+                                      (6000, 1024, 5, 1), (3000, 192, 4, 64), (2000, 2048, 3, 7), (4000, 256, 3, 256),
+                                      (5000, 128, 4, 300), (3000, 768, 3, 512)])   # pages up to NIDX_K_MAX (rabitq.rs:30-36 re-ranks up to 2 000)
 def test_rabitq_brute_force_matches_oracle(orc, n, d, nq, k):
     rng = np.random.default_rng(n + d)
     x = clustered(rng, n, d) if n > 100 else unit_rows(rng, n, d)
@@ -162,7 +163,7 @@ def test_rabitq_brute_force_filters_min_score_ties(orc):
 
 
 # ---- HNSW, RaBitQ arm ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5)])
+@pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5), (9000, 128, 300), (6000, 768, 512)])
 def test_rabitq_hnsw_matches_oracle(orc, n, d, k):
     rng = np.random.default_rng(n * 7 + d + k)
     x = clustered(rng, n, d, clusters=60, spread=0.3)
