@@ -514,6 +514,9 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     build_s = time.time() - t0
     if a.ef_upper > 1:
         _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", a.ef_upper))
+    for kv in filter(None, os.environ.get("NIDX_BENCH_TUNABLES", "").split(",")):   # A/B runs: name=value[,name=value] (launch-shape / measurement knobs)
+        name, _, val = kv.partition("=")
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, name.strip().encode(), int(val)))
 
     out_vec = torch.zeros((B, k), dtype=torch.int32, device=dev)
     out_score = torch.zeros((B, k), dtype=torch.float32, device=dev)

@@ -101,6 +101,10 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a, const 
     int pool_len = 0, n_res = 0;
     uint32_t vis_count = 0;
     uint64_t dropped_best = NIDX_EMPTY_KEY;
+    // The edge record of the candidate that will most likely be popped next — the best one left in the pool: a new neighbour rarely
+    // beats it, the pool holds the ef best nodes the layer search found — is requested while this expansion's rows are scored, so the
+    // next expansion starts without the edge round trip in front of its rows (wave 0; pf_word = word `lane` of pf_node's record).
+    uint32_t pf_node = 0xffffffffu, pf_word = 0;
     if (ctl && entry_mode) {
         // RaBitQ arm: the candidates are the re-ranked neighbours, scored with the raw vectors
         const int n_entry = (int)a.entry_count[qi];
@@ -162,7 +166,19 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a, const 
                     if (n_res < k) {
                         cont = 1;
                         uint32_t deg;
-                        uint32_t w = load_edge_word(a.g, c, 0, lane, deg);
+                        uint32_t w;
+                        if (c == pf_node) {
+                            w = pf_word;
+                            deg = lane_bcast_u32(w, 0);
+                            st.edge_hits++;
+                        } else {
+                            w = load_edge_word(a.g, c, 0, lane, deg);
+                        }
+                        if (a.closest_prefetch) {
+                            const uint64_t nk = pool_peek(sh.pool, pool_len, lane);
+                            pf_node = nk != NIDX_EMPTY_KEY ? rank_key_addr(nk) : 0xffffffffu;
+                            if (pf_node != 0xffffffffu) pf_word = a.g.l0[(size_t)pf_node * NIDX_L0_STRIDE + lane];
+                        }
                         bool is_edge = lane >= 1 && lane <= (int)deg;
                         bool fresh = is_edge && vis_insert(vis, a.vis_log2, w);
                         unsigned long long m = __ballot(fresh);

@@ -176,6 +176,9 @@ struct HnswSearchArgs {
     // 0 = 1, the reference's greedy descent (search.rs:318-324: k = 1 on the layers above 0).  Only the "ef_upper" tunable sets it: the
     // descent then keeps ef_upper results per upper layer and hands all of them to the next layer as entry points (<= 64).
     uint32_t ef_upper = 0;
+    // 1 (default): closest_up_nodes requests the edge record of the best candidate left in the pool while an expansion's rows are
+    // scored; 0 switches that off (measurement only: no result depends on it)
+    int closest_prefetch = 1;
     // launch_hnsw_search only: nullptr, or n_table argument records in HBM — one per segment, every one with the launch shape
     // (dp, k, vis_log2, ef_search, ef_upper, n_queries, eval_rows, min_waves) of this record: ONE grid of n_queries x n_table
     // walks (hnsw_search_segments_kernel); the kernels never read these two fields

@@ -441,6 +441,7 @@ HnswSearchArgs VectorIndex::hnsw_args(uint32_t s, const float *d_queries, uint32
     a.flag_word = d_flag_word;
     a.ef_search = ef_search;
     a.ef_upper = ef_upper;
+    a.closest_prefetch = closest_prefetch ? 1 : 0;
     return a;
 }
 
@@ -1178,6 +1179,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "coalesce_max_callers") idx->coalescer_admission(std::max(0, (int)value), -1);   // 0 = unbounded
     else if (n == "coalesce_reject_when_full") idx->coalescer_admission(-1, value != 0);
     else if (n == "pipeline_depth") idx->pipeline_config(value);
+    else if (n == "closest_prefetch") idx->closest_prefetch = value != 0;   // measurement knob of closest_up_nodes' edge prefetch: no result depends on it
     else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
     else if (n == "ef_search") {   // 0 = the reference's EF_SEARCH (30)

@@ -91,6 +91,7 @@ struct VectorIndex {
     int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : min_waves; }
     uint32_t ef_search = 0;   // 0 = EF_SEARCH (hnsw/params.rs:46); tunable "ef_search"
     uint32_t ef_upper = 0;    // 0 = 1: the greedy descent of hnsw/search.rs:318-324; tunable "ef_upper"
+    bool closest_prefetch = true;   // tunable "closest_prefetch" (measurement)
     bool serial_segments = false;   // tunable "serial_segments": the blocking search of a multi-segment index one segment at a time
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
