@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--scan-check-queries", type=int, default=4, help="hnsw: queries whose exact-scan ground truth is checked against the oracle's brute force")
     p.add_argument("--segment-regime", type=int, default=200_000,
                    help="cpu_baseline: also time the oracle over segments of this many records + Fssc (the reference's own regime, src/settings.rs:258-278); 0 = skip")
+    p.add_argument("--bf16-block-n", type=int, default=12_500_000,
+                   help="hnsw (one GPU): also time the bf16 matrix-core fallback scan (BASELINE.json configs[4]) on a uniform shard of this many "
+                        "x 1024-dim vectors after the headline legs and put the block into the line (0 = skip)")
     p.add_argument("--ref-build-n", type=int, default=50_000,
                    help="recall of the oracle's sequential HnswBuilder vs the device build on a clustered segment of this size (0 = skip)")
     p.add_argument("--batches-in-flight", type=int, default=3,
@@ -1256,6 +1259,13 @@ def bench_hnsw(a, L, dev, rank, world):
     kinds = ["clustered", "uniform"] if a.corpus == "both" else [a.corpus]
     head = hnsw_leg(a, L, dev, rank, world, kinds[0], True)
     second = hnsw_leg(a, L, dev, rank, world, kinds[1], False) if len(kinds) > 1 else None
+    bf16_blk = None
+    if world == 1 and a.bf16_block_n > 0:
+        try:
+            bf16_blk = bf16_block(a, L, dev)
+        except Exception as e:  # noqa: BLE001 — a side block: its failure must not cost the measured line
+            print("ERROR: bf16 block failed: %r" % (e,), file=sys.stderr)
+            FAILURES.append("bf16 block failed: %r" % (e,))
     if rank != 0:
         return
     total_q = world * B * head["steps_timed"]
@@ -1296,6 +1306,9 @@ def bench_hnsw(a, L, dev, rank, world):
         "segment_regime_device_blocking_qps": seg_reg.get("device_same_index_host_buffer_queries_per_s"),
         "segment_regime_device_frac_of_hbm_peak": (seg_reg.get("device_walk") or {}).get("frac_of_hbm_peak"),
         "segment_regime_cpu_qps": seg_reg.get("value"), "segment_regime_segments": seg_reg.get("segments"),
+        "bf16_fallback": bf16_blk,
+        "bf16_fallback_queries_per_s": (bf16_blk or {}).get("queries_per_s"), "bf16_fallback_tflops": ((bf16_blk or {}).get("roofline") or {}).get("achieved"),
+        "bf16_fallback_frac_of_bf16_peak": ((bf16_blk or {}).get("roofline") or {}).get("frac"),
     })
     if second is not None:
         cfgd["uniform_corpus" if second["corpus"] == "uniform" else "second_corpus"] = {
@@ -1337,6 +1350,76 @@ def bench_hnsw(a, L, dev, rank, world):
     if FAILURES:
         line["failures"] = FAILURES
     print(json.dumps(line))
+
+
+def bf16_block(a, L, dev):
+    """BASELINE.json configs[4] on one GPU's share: the batched brute-force fallback on the bf16 matrix cores (csrc/vector_bf16.hip:
+    tiled bf16 copy, MFMA 32x32x16, exact f32 re-score of the candidates) over `--bf16-block-n` x 1024-dim cosine vectors resident in
+    HBM, batch and k of the headline.  One launch at a time, HIP events on the launch stream; recall@k against the exact f32 scan."""
+    from nucliadb_amd import _lib
+
+    n, d, B, k = a.bf16_block_n, 1024, a.batch, a.k
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    t0 = time.time()
+    x = torch.empty((n, d), device=dev, dtype=torch.float32)
+    step = 1 << 20
+    for i in range(0, n, step):   # uniform(-1, 1) normalised (segment.rs:682-695), in pieces: no second 51 GB temporary
+        j = min(n, i + step)
+        x[i:j] = torch.rand((j - i, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        x[i:j] /= x[i:j].norm(dim=1, keepdim=True)
+    q = torch.rand((2, B, d), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    q /= q.norm(dim=2, keepdim=True)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    cfg = _lib.VectorConfigC(d, 1, 0, 0)
+    cseg = _lib.VectorSegmentC(x.data_ptr(), d * 4, n, None, n, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    t0 = time.time()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), C.byref(cseg), 1, C.byref(h)))
+    open_s = time.time() - t0
+    del x
+    torch.cuda.empty_cache()
+    ov = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    osc = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def search(qb, method):
+        p = _lib.VectorSearchParamsC(k, -1.0, 1, method)
+        _lib.check(L.nidx_gpu_vector_segment_search_device(h, 0, qb.data_ptr(), B, C.byref(p), None, ov.data_ptr(), osc.data_ptr(), oc.data_ptr(), None, stream))
+
+    try:
+        search(q[0], _lib.METHOD_BRUTE_FORCE_BF16)   # builds the tiled bf16 copy
+        torch.cuda.synchronize()
+        steps = 4
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record()
+            search(q[i & 1], _lib.METHOD_BRUTE_FORCE_BF16)
+            ev[i][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        rq = min(64, B)
+        search(q[0], _lib.METHOD_BRUTE_FORCE_BF16)
+        torch.cuda.synchronize()
+        got = ov[:rq].cpu().numpy().copy()
+        search(q[0], _lib.METHOD_BRUTE_FORCE)
+        torch.cuda.synchronize()
+        exact = ov[:rq].cpu().numpy()
+        recall = float(np.mean([len(set(got[i]) & set(exact[i])) / k for i in range(rq)]))
+    finally:
+        L.nidx_gpu_vector_close(h)
+    flops = 2.0 * n * d * B
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    return {"workload": "bf16 fallback: %d x %d-dim cosine (uniform corpus), k=%d, batch=%d queries, exact f32 re-score of the candidates" % (n, d, k, B),
+            "queries_per_s": B * steps / elapsed, "ms_per_batch": kernel_ms, "recall_at_%d_vs_exact_scan" % k: recall, "recall_queries": rq,
+            "corpus_gen_s": gen_s, "open_s": open_s,
+            "roofline": {"kernel": "bf16_scan_kernel + merge_topk_kernel + rescore_select_kernel", "bound": "mfma", "achieved": tf, "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms": kernel_ms,
+                         "hbm_frac_bf16_read_once": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
 def gather_ceiling():

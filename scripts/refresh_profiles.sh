@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for corpus in clustered uniform; do
-  BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0"
+  BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0 --bf16-block-n 0"
   # the PMC passes load the graph the trace pass built (rocprofv3 --pmc segfaults over the thousands of dispatches of a 10 M build)
   BENCH="$BENCH --graph-cache /tmp/nidx_graphs"
   [ $corpus = uniform ] && BENCH="$BENCH --batches-in-flight 1"   # the default run times this corpus one launch at a time
