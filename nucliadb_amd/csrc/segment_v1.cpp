@@ -149,6 +149,7 @@ int migrate_index_hnsw(const uint8_t *buf, size_t len, uint32_t n_nodes, std::ve
     struct Rec { std::vector<uint32_t> to; std::vector<float> w; };
     std::vector<std::vector<Rec>> nodes;   // [node][layer]
     const uint64_t index_end = len - 16;
+    uint64_t total_edges = 0;   // every edge owns 12 bytes of its own in a well-formed file
     for (uint64_t i = 0;; i++) {
         if (i >= n_nodes) { err = "index.hnsw: more nodes than the segment has vectors"; return -1; }
         const uint64_t indexing_pos = index_end - (i + 1) * 8;
@@ -163,6 +164,15 @@ int migrate_index_hnsw(const uint8_t *buf, size_t len, uint32_t n_nodes, std::ve
                 err = "index.hnsw: bad connexion list";
                 return -1;
             }
+            // the device layout's bounds, enforced WHILE reading: offsets of different layers and nodes may point at the same connexion
+            // bytes, so a small crafted file could otherwise expand to n_nodes x 256 x (len / 12) edges in host memory before the
+            // stride checks below ever ran (an out-of-memory denial of service from an on-disk file)
+            if (n_edges >= (l == 0 ? (uint64_t)NIDX_L0_STRIDE : (uint64_t)NIDX_UP_STRIDE)) {
+                err = l == 0 ? "index.hnsw: more layer-0 edges than the device layout holds" : "index.hnsw: more upper-layer edges than the device layout holds";
+                return -1;
+            }
+            total_edges += n_edges;
+            if (total_edges > len / 12) { err = "index.hnsw: connexion lists overlap (more edges than the file has bytes for)"; return -1; }
             Rec r;
             for (uint64_t e = 0; e < n_edges; e++) {
                 uint64_t to;
