@@ -1728,7 +1728,10 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         return rrf_fuse_batch([(bo[0] & low32, bo[2], 1.0, bo[1]), (vo[0].astype(np.uint64), vo[2], 1.0, None)], k=60.0, window=k)
 
     in_flight = []
-    bm_in_flight = []   # (batch, ticket): the keyword search runs one batch ahead too (nidx_gpu_bm25_search_submit / _wait)
+    # BM25 batches in flight: their launches wait for workgroup slots behind the walks that fill the device, so a scoring launch that
+    # takes 0.06 ms alone completes 0.2 - 0.3 ms after its submit; with three of the library's four tickets outstanding most of that latency is hidden (measured 2 / 3 / 4: 2.10 / 2.39 / 2.25 M hybrid queries/s)
+    bm_depth = int(os.environ.get("NIDX_BENCH_HYBRID_BM25_DEPTH", "3"))
+    bm_in_flight = []   # (batch, ticket): the keyword search runs batches ahead too (nidx_gpu_bm25_search_submit / _wait)
     t_parts = {"vector_submit": 0.0, "bm25_submit_wait": 0.0, "vector_wait": 0.0, "fusion": 0.0}
     kernel_ms = []
 
@@ -1743,10 +1746,10 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         while len(in_flight) < nfl and (i + len(in_flight)) < last:
             submit(i + len(in_flight))
         t1 = time.perf_counter()
-        while len(bm_in_flight) < 2 and (i + len(bm_in_flight)) < last:
+        while len(bm_in_flight) < bm_depth and (i + len(bm_in_flight)) < last:
             bm_in_flight.append((i + len(bm_in_flight), bm.submit(i + len(bm_in_flight))))
         _bi, btk = bm_in_flight.pop(0)
-        bo = bm_out[i % 2]
+        bo = bm_out[i % 2]   # (filled at wait time: two sets are enough whatever the submit depth)
         bm.wait(btk, out=bo)
         kernel_ms.append(bm.kernel_ms())
         t2 = time.perf_counter()
