@@ -44,6 +44,7 @@ struct SearchSlot {
     bool dirty = false;                      // work may be queued on `stream` / the flag words may be set: clean before reuse
     bool merged = false;                     // the block carries the device Fssc's hits
     size_t flag_bytes = 0;                   // flag words at the head of d_block
+    size_t mw = 0;                           // words of the merged region behind them (0: the batch is merged on the host)
     // the batch in flight
     uint32_t nq = 0;
     nidx_gpu_vector_search_params_t params{};
@@ -177,7 +178,12 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
             sl.dq = sl.d_queries.as<float>();
         }
         // ---- result block; its flag words are zero whenever the slot is idle (a flagged batch clears them in wait) -------------
-        const size_t fw = flag_words(S), mw = merged_words(nq, k), sw = seg_words(nq, k), words = fw + mw + S * sw;
+        // One plain segment (no cross-segment paragraph keys): Fssc is the identity on a falling score list, which the host checks while it
+        // copies the row (fssc_merge's fast path) — a merge kernel would only add a launch that, with other batches in flight, waits for
+        // workgroup slots behind their walks (8 us alone, 60 us in the hybrid trace) and a larger transfer.
+        sl.merged = !(S == 1 && segs[0].key_ids.empty()) && !getenv("NIDX_GPU_FSSC_HOST");   // the variable: merge on the host (comparison)
+        const size_t fw = flag_words(S), mw = sl.merged ? merged_words(nq, k) : 0, sw = seg_words(nq, k), words = fw + mw + S * sw;
+        sl.mw = mw;
         sl.dirty = true;   // from here on work is queued on the slot's stream: an error path must drain it (SlotRelease)
         sl.flag_bytes = fw * 4;
         if (words * 4 > sl.d_block.bytes) {
@@ -260,7 +266,6 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
             }
         }
         // ---- Fssc on the device: the hits a caller gets are k per query, whatever the number of segments -------------------------
-        sl.merged = !getenv("NIDX_GPU_FSSC_HOST");   // the variable: merge on the host from the per-segment rows (comparison)
         if (sl.merged) {
             FsscArgs f;
             f.segs = reinterpret_cast<const FsscSegDev *>(sl.d_tables.as<unsigned char>() + hnsw_tab_bytes);
@@ -310,7 +315,7 @@ int32_t VectorIndex::pipeline_wait(uint64_t ticket, uint32_t *out_segment, uint3
     if (!sl.launched) return NIDX_OK;
     NIDX_HIP(hipSetDevice(device));
     NIDX_HIP(hipEventSynchronize(sl.done));   // (a failure leaves the slot dirty: SlotRelease drains its stream)
-    const size_t fw = flag_words(S), mw = merged_words(nq, k), sw = seg_words(nq, k);
+    const size_t fw = flag_words(S), mw = sl.mw, sw = seg_words(nq, k);
     uint32_t *host = sl.pin_out.as<uint32_t>();
     bool flagged = false;
     for (size_t s = 0; s < S; s++)
