@@ -30,7 +30,7 @@
 // one s_xor with a constant lane mask, two v_cndmask) — ~220 issues per 64 candidates instead of ~50 per candidate.
 // An involved list that overflows (192 entries) cuts the slice's doc range in half and retries; what was already offered is offered
 // again, so from then on the item inserts serially and ignores keys the list already holds: exact for any input.
-// LDS: 7.25 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1.5 KiB) + 2 KiB per workgroup (the two score tables) = 31 KiB:
+// LDS: 6.75 KiB per wave (A 4 KiB, B 256 B, involved list 1.5 KiB, candidates 1 KiB) + 4 KiB per workgroup (the score tables) = 31 KiB:
 // 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (<= 96 VGPRs) so that the registers allow them too.
 #include "device_common.h"
 #include "kernels.h"
@@ -48,7 +48,7 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_CAP 192u        /* involved postings per doc range */
 #endif
 #ifndef BS_QN
-#define BS_QN 1            /* rows of the quotient table: frequencies 1 .. BS_QN; 3 = the division's table stays in HBM/L2 (a.tf_cache) */
+#define BS_QN 3            /* rows of the quotient table: frequencies 1 .. BS_QN */
 #endif
 #ifndef BS_AHEAD
 #define BS_AHEAD 1         /* groups of four rows in flight ahead of the one being scored: 1 or 2 */
@@ -59,7 +59,7 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #ifndef BS_FAST_GROUPS
 #define BS_FAST_GROUPS 1   /* four full rows at a time on the bounds-free path */
 #endif
-#define BS_CAND 192u       /* 63 left over + two rows */
+#define BS_CAND 128u       /* 63 left over + one row: the buffer is drained below 64 entries after every row */
 #define BS_GROUPS 8
 
 __device__ inline uint32_t bs_rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -155,12 +155,8 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
     // general form, done once per workgroup — a posting of a short document almost always has one of these frequencies, and the IEEE
     // division is ~16 instructions per row.  Larger frequencies take the division with the table of the index (a.tf_cache, L2-resident)
     __shared__ float quot[BS_QN][256];
-#if BS_QN < 3
-    __shared__ float tf_cache_s[256];   // K1 * (1 - B + B * fieldnorm / avg) for the division
+    __shared__ float tf_cache_s[256];   // K1 * (1 - B + B * fieldnorm / avg) for the division (from L2 the dependent loads cost 10 us per launch)
 #define BS_TFC(fn) tf_cache_s[fn]
-#else
-#define BS_TFC(fn) a.tf_cache[fn]
-#endif
     __shared__ uint32_t bm_a_all[4][BS_A_WORDS];
     __shared__ uint32_t bm_b_all[4][BS_B_WORDS];
     __shared__ uint32_t list_doc_all[4][BS_CAP];
@@ -182,9 +178,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         const float c = a.tf_cache[threadIdx.x];
 #pragma unroll
         for (int t = 0; t < BS_QN; t++) quot[t][threadIdx.x] = (float)(t + 1) / ((float)(t + 1) + c);
-#if BS_QN < 3
         tf_cache_s[threadIdx.x] = c;
-#endif
         clear_bitmaps();
     }
     __syncthreads();   // the only workgroup barrier
@@ -624,13 +618,12 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                                 const uint32_t flushes = n_flush;
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
-                                    if (r == 2 && n_flush != flushes) {   // the bar rose under the first two rows: the other two face the new one
+                                    if (r > 0 && n_flush != flushes) {   // the bar rose under the rows before: this one faces the new one
                                         const float kf2 = fmaxf(bar, rank_key_score(kth));
-                                        cnd[2] = cnd[2] && !(sc[2] < kf2);
-                                        cnd[3] = cnd[3] && !(sc[3] < kf2);
+                                        cnd[r] = cnd[r] && !(sc[r] < kf2);
                                     }
                                     if (__ballot(cnd[r])) offer(rank_key(sc[r], d[r]), cnd[r]);
-                                    if (KL == 1 && (r & 1)) {   // the buffer holds what two rows can add on top of 63 left-overs
+                                    if (KL == 1) {   // the buffer holds what one row can add on top of 63 left-overs
                                         while (n_cand >= 64u) flush64();
                                     }
                                 }
@@ -688,7 +681,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             // score is NaN while the list is not full: !(s < NaN) lets every score through to the exact test)
                             if (__ballot(ok && !(sc < rank_key_score(kth)))) offer(rank_key(sc, d[r]), ok);
                         }
-                        if (KL == 1 && r == 1) {   // the buffer holds what two rows can add on top of 63 left-overs
+                        if (KL == 1) {   // the buffer holds what one row can add on top of 63 left-overs
                             while (n_cand >= 64u) flush64();
                         }
                     }
@@ -774,11 +767,12 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                     while (n_cand >= 64u) flush64();
                 }
             } else if (n_inv) {
-                uint32_t *t_doc = bm_a, *t_acc = bm_a + 512;
-                // the masks live in the top third of the candidate buffer: fewer than 128 candidates are buffered while this phase runs
-                uint8_t *t_mask = reinterpret_cast<uint8_t *>(cand + 128);
-                for (uint32_t i = lane; i < 128u; i += 64) reinterpret_cast<uint4 *>(t_doc)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                if (lane < 32) reinterpret_cast<uint4 *>(t_mask)[lane] = make_uint4(0u, 0u, 0u, 0u);
+                // 256 slots for at most BS_CAP = 192 documents: the documents, their sums and their clause masks all live in the bitmaps' space
+                uint32_t *t_doc = bm_a, *t_acc = bm_a + 256;
+                uint8_t *t_mask = reinterpret_cast<uint8_t *>(bm_a + 512);
+                dirty = true;
+                reinterpret_cast<uint4 *>(t_doc)[lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (lane < 16) reinterpret_cast<uint4 *>(t_mask)[lane] = make_uint4(0u, 0u, 0u, 0u);
                 bs_lds_order();
                 for (int c = 0; c < C; c++) {
                     const bool is_l = c == L;
@@ -790,7 +784,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         const uint32_t st = live ? (is_l ? BS_CAP - 1u - i : i) : 0u;
                         const uint32_t doc = list_doc[st];
                         const float sc = __uint_as_float(list_score[st]);
-                        uint32_t slot = (doc * 2654435761u) >> 23;
+                        uint32_t slot = (doc * 2654435761u) >> 24;
                         bool pending = live, fresh = false;
                         while (__ballot(pending)) {
                             if (pending) {
@@ -803,7 +797,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                                     } else cur = expected;
                                 }
                                 if (cur == doc) pending = false;
-                                else slot = (slot + 1u) & 511u;
+                                else slot = (slot + 1u) & 255u;
                             }
                         }
                         if (live) {
@@ -815,7 +809,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         bs_lds_order();
                     }
                 }
-                for (uint32_t b0 = 0; b0 < 512u; b0 += 64) {
+                for (uint32_t b0 = 0; b0 < 256u; b0 += 64) {
                     const uint32_t slot = b0 + (uint32_t)lane;
                     const uint32_t doc = t_doc[slot];
                     bool ok = doc != ~0u && mask_ok((uint32_t)t_mask[slot]);

@@ -8,7 +8,8 @@ merged in bulk with a stale threshold gives the same top-k as one insertion per 
 after an overflow and offering the already-final postings again is exact when later insertions ignore keys the list holds.
 
 The model follows the kernel's control flow and constants (hashes, bitmap sizes, the 192-entry involved list, 64-posting rows,
-four-row groups, the candidate buffer drained after rows 1 and 3 and behind a group) but not its instruction stream; per-posting
+four-row groups, the 128-entry candidate buffer drained after every row, the bar taken from the lane maxima of the first group) but
+not its instruction stream; per-posting
 scores come from the oracle itself (a one-clause query per term), so only the combination logic is under test."""
 import numpy as np
 import pytest
@@ -47,6 +48,7 @@ class Model:
         self.single_ok = [self.mask_ok(1 << i) for i in range(C)]
         self.top, self.kth, self.thr = [], 0, 0      # sorted (descending) keys, at most 64
         self.cand, self.redo = [], False
+        self.bar = None                              # a lower bound of the item's k-th best score (f32), set by the first group
         self.flushes = self.ranges = 0
 
     def mask_ok(self, m):
@@ -66,7 +68,7 @@ class Model:
         keys = [x for x in keys if x > self.thr]
         if not self.redo:
             self.cand += keys
-            assert len(self.cand) <= 192
+            assert len(self.cand) <= 128
             return
         for x in keys:                       # after a retry: one by one, ignoring keys the list already holds
             if x > self.thr and x not in self.top:
@@ -107,6 +109,15 @@ class Model:
                     is_long = step == 0
                     docs, scores = self.cl[c][0][pos[c]:end[c]], self.cl[c][1][pos[c]:end[c]]
                     for g0 in range(0, len(docs), 256):
+                        if self.bar is None and self.single_ok[c]:
+                            # the bar before the list has one: the k-th largest of the 64 lane maxima of the first group's final postings
+                            lane_max = {}
+                            for j in range(g0, min(g0 + 256, len(docs))):
+                                d = docs[j]
+                                if not (probe and bool(A[h_of(d)] if is_long else B[h_of(d) & 0x7FF])):
+                                    lane_max[(j - g0) % 64] = max(lane_max.get((j - g0) % 64, np.float32(-np.inf)), np.float32(scores[j]))
+                            best = sorted(lane_max.values(), reverse=True)
+                            self.bar = best[self.k - 1] if len(best) >= self.k else np.float32(-np.inf)
                         for r in range(4):
                             row = slice(g0 + 64 * r, min(g0 + 64 * r + 64, len(docs)))
                             if row.start >= len(docs):
@@ -123,8 +134,8 @@ class Model:
                             if self.single_ok[c]:
                                 singles = [(d, s) for d, s, i in zip(docs[row], scores[row], inv) if not i]
                                 matched += len(singles)
-                                self.offer([rank_key(s, int(d)) for d, s in singles])
-                            if r == 1 and not self.redo:
+                                self.offer([rank_key(s, int(d)) for d, s in singles if not (np.float32(s) < self.bar)])
+                            if not self.redo:
                                 self.drain()
                         if overflow:
                             break
