@@ -71,7 +71,7 @@ struct Bm25Slot {
     uint64_t ticket = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf s_after, s_count, s_total, s_postings, s_key, s_in_q, s_in_w, s_outpack, s_qdone;
+    DevBuf s_after, s_count, s_total, s_postings, s_key, s_in_q, s_in_w, s_outpack;
     PinBuf h_in_q, h_in_w, h_outpack;
     // layout of h_outpack for the collect step
     uint32_t nq = 0, k = 0, kk = 0;
@@ -106,7 +106,7 @@ struct Bm25Index {
     std::vector<uint8_t> w_q_union;
     std::vector<uint64_t> w_postings;
     DevBuf tf_cache;
-    DevBuf s_after, s_count, s_total, s_postings, s_key, s_qdone;   // s_qdone: the fused merge's per-query counters (bm25_stream_kernel)
+    DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
@@ -126,7 +126,6 @@ struct Bm25Index {
         std::swap(stream, sl.stream), std::swap(ev0, sl.ev0), std::swap(ev1, sl.ev1);
         std::swap(s_after, sl.s_after), std::swap(s_count, sl.s_count), std::swap(s_total, sl.s_total), std::swap(s_postings, sl.s_postings);
         std::swap(s_key, sl.s_key), std::swap(s_in_q, sl.s_in_q), std::swap(s_in_w, sl.s_in_w), std::swap(s_outpack, sl.s_outpack);
-        std::swap(s_qdone, sl.s_qdone);
         std::swap(h_in_q, sl.h_in_q), std::swap(h_in_w, sl.h_in_w), std::swap(h_outpack, sl.h_outpack);
     }
     Bm25Index() = default;
@@ -1038,19 +1037,6 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             a.dbg = dbgbuf.as<unsigned long long>();
 
         }
-        // every item a union item of bm25_stream_kernel and k <= 64: the last item of a query merges its slices (no merge launch)
-        const bool fused_merge = n_union == nw && nw > 0 && kk <= 64 && !lockstep_union && !a.dbg && !getenv("NIDX_GPU_BM25_MERGE_LAUNCH");
-        if (fused_merge) {
-            NIDX_HIP(idx->s_qdone.reserve((size_t)nq * 4));
-            NIDX_HIP(hipMemsetAsync(idx->s_qdone.p, 0, (size_t)nq * 4, idx->stream));
-            a.q_done = idx->s_qdone.as<uint32_t>();
-            a.item_first = d_item_first;
-            a.fin_doc = reinterpret_cast<uint32_t *>(d_out + o_doc);
-            a.fin_score = reinterpret_cast<float *>(d_out + o_score);
-            a.fin_count = reinterpret_cast<uint32_t *>(d_out + o_count);
-            a.fin_total = reinterpret_cast<unsigned long long *>(d_out + o_total);
-            a.fin_postings = reinterpret_cast<unsigned long long *>(d_out + o_post);
-        }
         NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
         {
             const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
@@ -1070,7 +1056,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         mg.out_count = reinterpret_cast<uint32_t *>(d_out + o_count);
         mg.out_total = reinterpret_cast<unsigned long long *>(d_out + o_total);
         mg.out_postings = reinterpret_cast<unsigned long long *>(d_out + o_post);
-        if (!fused_merge) NIDX_HIP(launch_bm25_merge(mg, nq, idx->stream));
+        NIDX_HIP(launch_bm25_merge(mg, nq, idx->stream));
         if (n_slots)
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_pair_term.as<uint32_t>(),
                                         idx->s_pair_slot.as<int>(), (uint32_t)n_pairs, idx->s_match_bits.as<uint32_t>(), match_words,

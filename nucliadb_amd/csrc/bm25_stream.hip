@@ -148,63 +148,6 @@ __device__ inline float bs_sort_stages_f32(float v) {
     return bs_sort_steps_f32<K, K / 2>(v);
 }
 
-// ---- the per-query merge, by the item of the query that finishes last (TopDocs merges its per-segment collectors the same way; keys
-// are unique per query, so the k best of all slices are the same whoever merges them).  Out of line: it runs once per item and its
-// registers must not count against the streaming loops'. ----
-__device__ __noinline__ void bs_fused_merge(uint32_t *q_done, const uint32_t *item_first, const unsigned long long *out_key, const uint32_t *out_count,
-                                            const unsigned long long *out_total, const unsigned long long *out_postings, uint32_t *fin_doc, float *fin_score,
-                                            uint32_t *fin_count, unsigned long long *fin_total, unsigned long long *fin_postings, uint32_t q, uint32_t n_slices,
-                                            uint32_t k, uint64_t fin, uint32_t total, uint32_t postings, int lane) {
-    unsigned long long tot = total, pst = postings;
-    bool mine = n_slices == 1;
-    if (!mine) {
-        __threadfence();   // this item's list, count and totals are visible device-wide before the counter says so
-        uint32_t prev = 0;
-        if (lane == 0) prev = atomicAdd(&q_done[q], 1u);
-        prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
-        mine = prev + 1u == n_slices;
-        if (mine) {
-            __threadfence();
-            const uint32_t w0 = item_first[q];   // the slices of a query are consecutive work items
-            const uint32_t slots = n_slices * k;
-            fin = NIDX_EMPTY_KEY;
-            // (loads that go to L2: the lines were written by other CUs, and this CU's L1 may hold an older copy of a line two queries share)
-            for (uint32_t base = 0; base < slots; base += 64u) {
-                const uint32_t idx = base + (uint32_t)lane;
-                const uint32_t it = idx / k, pos = idx - it * k;
-                bool have = idx < slots;
-                if (have) have = pos < __hip_atomic_load(&out_count[w0 + it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t key = have ? __hip_atomic_load(&out_key[(size_t)(w0 + it) * k + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NIDX_EMPTY_KEY;
-                fin = bs_merge64(fin, key);
-            }
-            tot = 0, pst = 0;
-            for (uint32_t w = (uint32_t)lane; w < n_slices; w += 64u) {
-                tot += __hip_atomic_load(&out_total[w0 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pst += __hip_atomic_load(&out_postings[w0 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                tot += (unsigned long long)__shfl_xor((long long)tot, o, 64);
-                pst += (unsigned long long)__shfl_xor((long long)pst, o, 64);
-            }
-            if (lane == 0) q_done[q] = 0u;   // ready for the next launch
-        }
-    }
-    if (mine) {
-        const bool valid = fin != NIDX_EMPTY_KEY && (uint32_t)lane < k;
-        const uint32_t n_hits = (uint32_t)__popcll(__ballot(valid));
-        if ((uint32_t)lane < k) {
-            fin_doc[(size_t)q * k + lane] = valid ? rank_key_addr(fin) : 0xffffffffu;
-            fin_score[(size_t)q * k + lane] = valid ? rank_key_score(fin) : 0.f;
-        }
-        if (lane == 0) {
-            fin_count[q] = n_hits;
-            fin_total[q] = tot;
-            fin_postings[q] = pst;
-        }
-    }
-}
-
 // DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
 template <int KL, bool EXTRAS, bool DBG>
 __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
@@ -923,11 +866,6 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         a.out_count[item] = cnt;
         a.out_total[item] = total;
         a.out_postings[item] = postings;
-    }
-    if constexpr (KL == 1) {
-        if (a.q_done)
-            bs_fused_merge(a.q_done, a.item_first, a.out_key, a.out_count, a.out_total, a.out_postings, a.fin_doc, a.fin_score, a.fin_count, a.fin_total,
-                           a.fin_postings, q, n_slices, (uint32_t)k, top.l[0].key, total, postings, lane);
     }
 }
 

@@ -369,16 +369,6 @@ struct Bm25Args {
     const int *match_slot;                  // [n_queries] or nullptr
     uint32_t match_words;
     const Bm25UClause *uclauses;            // [n_clauses of the batch] (bm25_union_kernel), parallel to `clauses`
-    // bm25_stream_kernel, k <= 64, every item of the launch a union item: the per-query merge of the slices' lists (what
-    // bm25_merge_kernel does in a launch of its own) is done by whichever item of a query finishes last — one launch less in the
-    // chain H2D -> scoring -> merge -> D2H.  q_done: [n_queries] u32, zero at launch (the merging item zeroes its query's again);
-    // item_first: [n_queries + 1]; fin_*: the per-query outputs of Bm25MergeArgs.  nullptr = the merge runs as its own launch.
-    uint32_t *q_done = nullptr;
-    const uint32_t *item_first = nullptr;
-    uint32_t *fin_doc = nullptr;
-    float *fin_score = nullptr;
-    uint32_t *fin_count = nullptr;
-    unsigned long long *fin_total = nullptr, *fin_postings = nullptr;
 };
 #define BM25_AUX_TERM 0x80000000u
 struct Bm25MergeArgs {  // per query: merge the key lists of its work items [item_first[q], item_first[q + 1])

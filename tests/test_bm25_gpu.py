@@ -218,11 +218,6 @@ def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeyp
         mixed.append(q)
     for k in (20, 1, 64, 201, 501):
         compare(orc, seg, s, sparse + dense, k)
-    # batches whose every query is a union query (no empty one among them): for k <= 64 the last slice of a query to finish merges the
-    # query's slices inside the scoring launch (no bm25_merge_kernel launch); many-slice queries (dense terms) and one-slice ones
-    for k in (20, 1, 64, 65):
-        compare(orc, seg, s, dense[:-1] + sparse[:8], k)
-        compare(orc, seg, s, sparse, k)
     compare(orc, seg, s, mixed, 20)
     compare(orc, seg, s, mixed + sparse, 10)
     s.close()
