@@ -137,8 +137,10 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
 int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *name, int32_t value);
 
 /* NIDX_METHOD_BRUTE_FORCE_MFMA: the same exact scan as a dense GEMM on the f32 matrix cores (one
- * pass over the corpus per batch, k <= 16).  It sums in NIDX_ORDER_SERIAL_FMA, so its scores differ
- * from the other methods' (NIDX_ORDER_WAVE64) in the last bits: never chosen by AUTO.
+ * pass over the corpus per batch, k <= 64; pages of k <= 16 keep two workgroups per CU).  It sums in
+ * NIDX_ORDER_SERIAL_FMA, so its scores differ from the other methods' (NIDX_ORDER_WAVE64) in the last bits: never chosen
+ * by AUTO.  On a multi-vector segment both matrix-core scans keep k x (most vectors of one paragraph) vectors — that product
+ * is what the 64 / 32 bound applies to — and return each paragraph's best vector (segment.rs:582-593).
  * NIDX_METHOD_BRUTE_FORCE_BF16: the batched fallback on the bf16 matrix cores (k <= 32): candidates are
  * ranked with bf16 operands, the 32 best per query are re-scored from the f32 rows in
  * NIDX_ORDER_WAVE64 — returned scores are exact, the id set is the exact top-k up to bf16 ranking

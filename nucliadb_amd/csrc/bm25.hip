@@ -20,6 +20,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "wave_bitonic.h"
 
 namespace nidx {
 
@@ -806,13 +807,18 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
             top.l[i].key = e < (int)cnt && e < k ? m.item_key[(size_t)w0 * k + e] : NIDX_EMPTY_KEY;
         }
     } else {
-        // all the slices' keys side by side, 64 at a time: the loads of a chunk do not wait for any other list
+        // all the slices' keys side by side, 64 at a time: the loads of a chunk do not wait for any other list (nor for the item's
+        // count: the key is fetched beside it and dropped afterwards).  k <= 64: a chunk goes through the bitonic network of
+        // wave_bitonic.h — 27 compare-exchange steps whatever the keys — instead of up to 64 insertions one after the other
         const uint32_t slots = n_items * (uint32_t)k;
         for (uint32_t base = 64u * (uint32_t)wave; base < slots; base += 256) {
             const uint32_t idx = base + (uint32_t)lane;
-            const uint32_t it = idx / (uint32_t)k, pos = idx - it * (uint32_t)k;
-            const bool have = idx < slots && pos < m.item_count[w0 + (idx < slots ? it : 0u)];
-            consume(have ? m.item_key[(size_t)(w0 + it) * k + pos] : NIDX_EMPTY_KEY);
+            const uint32_t it = idx < slots ? idx / (uint32_t)k : 0u, pos = idx - it * (uint32_t)k;
+            const uint32_t cnt_i = m.item_count[w0 + it];
+            const uint64_t key_i = m.item_key[(size_t)(w0 + it) * k + (idx < slots ? pos : 0u)];
+            const uint64_t key = idx < slots && pos < cnt_i ? key_i : NIDX_EMPTY_KEY;
+            if constexpr (KL == 1) top.l[0].key = bs_merge64(top.l[0].key, key);
+            else consume(key);
         }
         if (wave > 0) {
 #pragma unroll
@@ -822,9 +828,15 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
     __syncthreads();
     if (wave != 0) return;
     if (n_items > 1) {
+        const uint32_t slots = n_items * (uint32_t)k;
         for (int w = 0; w < 3; w++) {
+            if (64u * (uint32_t)(w + 1) >= slots) break;   // that wave had no chunk
+            if constexpr (KL == 1) {
+                top.l[0].key = bs_merge_sorted(top.l[0].key, part[w][63 - lane]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < KL; i++) consume(part[w][64 * i + lane]);
+                for (int i = 0; i < KL; i++) consume(part[w][64 * i + lane]);
+            }
         }
     }
     uint32_t cnt = 0;

@@ -34,6 +34,7 @@
 // 5 workgroups per CU, and the k <= 64 kernel is compiled for five waves per SIMD (<= 96 VGPRs) so that the registers allow them too.
 #include "device_common.h"
 #include "kernels.h"
+#include "wave_bitonic.h"
 
 namespace nidx {
 
@@ -63,63 +64,6 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_GROUPS 8
 
 __device__ inline uint32_t bs_rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-
-// ---- the bitonic network on one 64-bit key per lane -----------------------------------------------------------------------------
-// compare-exchange with lane ^ J: lanes whose bit of TAKE_MAX is set keep the larger key, the others the smaller one
-template <int J>
-__device__ inline uint64_t bs_cmpx(uint64_t v, unsigned long long take_max_mask) {
-    const bool tm = __builtin_amdgcn_inverse_ballot_w64(take_max_mask);
-    if constexpr (J >= 16) {
-        uint32_t a0 = (uint32_t)v, a1 = a0, b0 = (uint32_t)(v >> 32), b1 = b0;
-        if constexpr (J == 32) {
-            swap_pair32(a0, a1);
-            swap_pair32(b0, b1);
-        } else {
-            swap_pair16(a0, a1);
-            swap_pair16(b0, b1);
-        }
-        const uint64_t x = ((uint64_t)b0 << 32) | a0, y = ((uint64_t)b1 << 32) | a1;   // {own, partner} in some order
-        return ((x > y) == tm) ? x : y;
-    } else {
-        const uint64_t p = ((uint64_t)xor_partner_dpp<J>((uint32_t)(v >> 32)) << 32) | xor_partner_dpp<J>((uint32_t)v);
-        return ((v > p) == tm) ? v : p;
-    }
-}
-constexpr unsigned long long bs_sort_mask(int K, int J) {   // ascending sort, stage K, substep J: who keeps the larger key
-    unsigned long long m = 0;
-    for (int l = 0; l < 64; l++)
-        if (((l & J) != 0) != ((l & K) != 0)) m |= 1ull << l;
-    return m;
-}
-constexpr unsigned long long bs_merge_mask(int J) {   // descending merge: the lane with the J bit clear keeps the larger key
-    unsigned long long m = 0;
-    for (int l = 0; l < 64; l++)
-        if ((l & J) == 0) m |= 1ull << l;
-    return m;
-}
-template <int K, int J>
-__device__ inline uint64_t bs_sort_steps(uint64_t v) {
-    v = bs_cmpx<J>(v, bs_sort_mask(K, J));
-    if constexpr (J > 1) return bs_sort_steps<K, J / 2>(v);
-    else return v;
-}
-template <int K>
-__device__ inline uint64_t bs_sort_stages(uint64_t v) {   // stages 2 .. K
-    if constexpr (K > 2) v = bs_sort_stages<K / 2>(v);
-    return bs_sort_steps<K, K / 2>(v);
-}
-template <int J>
-__device__ inline uint64_t bs_merge_steps(uint64_t v) {
-    v = bs_cmpx<J>(v, bs_merge_mask(J));
-    if constexpr (J > 1) return bs_merge_steps<J / 2>(v);
-    else return v;
-}
-// sorted (best first) list `top` of 64 keys and 64 unsorted keys `v` -> the 64 best of the 128, sorted
-__device__ inline uint64_t bs_merge64(uint64_t top, uint64_t v) {
-    v = bs_sort_stages<64>(v);            // ascending
-    const uint64_t m = top > v ? top : v; // a descending and an ascending run, element by element: bitonic, holds the 64 best
-    return bs_merge_steps<32>(m);
-}
 
 // The same network on one f32 per lane (ascending): a compare-exchange is the partner fetch, v_max, v_min and a select.
 template <int J>

@@ -54,10 +54,10 @@ struct MfmaScanArgs {
     const uint32_t *para_of_vec;
     int similarity;
     float min_score;
-    uint32_t k;             // <= 16
+    uint32_t k;             // <= NIDX_MFMA_KMAX
     uint64_t *partial;      // [n_queries][stripes][k]
 };
-#define NIDX_MFMA_KMAX 16
+#define NIDX_MFMA_KMAX 64
 hipError_t launch_serial_norms(const float *rows, uint32_t n, uint32_t dp, float *out, hipStream_t s);
 uint32_t mfma_scan_stripes(uint32_t n, uint32_t n_queries);
 hipError_t launch_mfma_scan(const MfmaScanArgs &a, uint32_t stripes, hipStream_t s);

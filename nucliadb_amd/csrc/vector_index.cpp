@@ -544,8 +544,29 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         return NIDX_OK;
     }
     const bool multi = seg.vmax > 1;
-    if (multi && (method == NIDX_METHOD_BRUTE_FORCE_MFMA || method == NIDX_METHOD_BRUTE_FORCE_BF16))
-        return fail(NIDX_ERR_UNSUPPORTED, "the matrix-core scans do not reduce multi-vector paragraphs: use NIDX_METHOD_BRUTE_FORCE");
+    // multi-vector paragraphs on the matrix-core scans: like the plain scan below, the k best paragraphs are covered by the k * vmax
+    // best vectors, which para_best_kernel reduces to one hit per paragraph (segment.rs:582-593)
+    const uint32_t k_page = k;
+    if (multi && (method == NIDX_METHOD_BRUTE_FORCE_MFMA || method == NIDX_METHOD_BRUTE_FORCE_BF16)) {
+        const uint32_t cap = method == NIDX_METHOD_BRUTE_FORCE_MFMA ? NIDX_MFMA_KMAX : NIDX_BF16_CAND;
+        if ((uint64_t)k * seg.vmax > cap)
+            return fail(NIDX_ERR_UNSUPPORTED, "result_per_page %u x %u vectors per paragraph exceeds the %u hits this matrix-core scan keeps", k,
+                        seg.vmax, cap);
+        k = k * seg.vmax;
+        NIDX_HIP(scratch_multi_vec.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_multi_score.reserve((size_t)nq * k * 4));
+        NIDX_HIP(scratch_multi_count.reserve((size_t)nq * 4));
+    }
+    // where the scan leaves its k best vectors: the caller's arrays, or the input of the per-paragraph reduction
+    uint32_t *const v_out_vec = multi ? scratch_multi_vec.as<uint32_t>() : d_out_vec;
+    float *const v_out_score = multi ? scratch_multi_score.as<float>() : d_out_score;
+    uint32_t *const v_out_count = multi ? scratch_multi_count.as<uint32_t>() : d_out_count;
+    auto reduce_paragraphs = [&]() -> int {
+        if (!multi) return NIDX_OK;
+        NIDX_HIP(launch_para_best(v_out_vec, v_out_score, v_out_count, nq, k, seg.para_of_vec.as<uint32_t>(), k_page, d_out_vec, d_out_score,
+                                  d_out_count, st));
+        return NIDX_OK;
+    };
     if (method == NIDX_METHOD_BRUTE_FORCE_MFMA) {
         if (k > NIDX_MFMA_KMAX) return fail(NIDX_ERR_UNSUPPORTED, "the MFMA scan keeps at most %d hits per query (got k=%u)", NIDX_MFMA_KMAX, k);
         if (cfg.similarity == NIDX_SIMILARITY_COSINE && !seg.norm2_serial.p) {
@@ -572,8 +593,8 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         m.k = k;
         m.partial = scratch_partial.as<uint64_t>();
         NIDX_HIP(launch_mfma_scan(m, stripes, st));
-        NIDX_HIP(launch_merge_topk(m.partial, nq, stripes, k, d_out_vec, d_out_score, d_out_count, st));
-        return NIDX_OK;
+        NIDX_HIP(launch_merge_topk(m.partial, nq, stripes, k, v_out_vec, v_out_score, v_out_count, st));
+        return reduce_paragraphs();
     }
     if (method == NIDX_METHOD_BRUTE_FORCE_BF16) {
         if (k > NIDX_BF16_CAND) return fail(NIDX_ERR_UNSUPPORTED, "the bf16 fallback re-scores %d candidates per query (got k=%u)", NIDX_BF16_CAND, k);
@@ -639,11 +660,11 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         r.similarity = cfg.similarity;
         r.min_score = min_score;
         r.k = k;
-        r.out_vec = d_out_vec;
-        r.out_score = d_out_score;
-        r.out_count = d_out_count;
+        r.out_vec = v_out_vec;
+        r.out_score = v_out_score;
+        r.out_count = v_out_count;
         NIDX_HIP(launch_rescore_select(r, st));
-        return NIDX_OK;
+        return reduce_paragraphs();
     }
     // brute force
     uint32_t nblk = scan_num_blocks(seg.n);

@@ -27,12 +27,15 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define MF_BN 128
 #define MF_BK 16
 #define MF_PITCH 12 /* floats per (row, parity) line: 8 + 4 pad => b128 reads hit 16 distinct slots */
-#define MF_KMAX 16
 
+// KMAX = 16: 70 KiB of LDS, two workgroups per CU (the k <= 16 pages the reference serves by default); KMAX = 64: the lists take
+// 64 KiB, one workgroup per CU — the same tile with pages up to a full wave of ranks (and k x vectors-per-paragraph of a multi-vector
+// segment, reduced to one hit per paragraph by para_best_kernel afterwards).
+template <int KMAX>
 struct MfmaShared {
     float q[2][2][MF_BM][MF_PITCH];  // [stage][k parity][query][k/2]
     float x[2][2][MF_BN][MF_PITCH];  // [stage][k parity][row][k/2]
-    uint64_t lists[MF_BM][MF_KMAX];  // per-query sorted top-k (rank keys), owned by the query's wave
+    uint64_t lists[MF_BM][KMAX];     // per-query sorted top-k (rank keys), owned by the query's wave
     uint64_t thr_key[MF_BM];         // k-th key (EMPTY while the list is short)
     float thr_score[MF_BM];          // its score (-inf while short)
     float q_qq[MF_BM], q_rinv[MF_BM];
@@ -78,8 +81,9 @@ __device__ inline void stage_store(float (&plane)[2][MF_BM][MF_PITCH], int tid, 
     }
 }
 
-__global__ __launch_bounds__(256, 2) void mfma_scan_kernel(MfmaScanArgs a) {
-    __shared__ MfmaShared sh;
+template <int KMAX>
+__global__ __launch_bounds__(256, (KMAX <= 16 ? 2 : 1)) void mfma_scan_kernel(MfmaScanArgs a) {
+    __shared__ MfmaShared<KMAX> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
     const uint32_t q0 = blockIdx.y * MF_BM;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void mfma_scan_kernel(MfmaScanArgs a) {
         sh.thr_key[tid] = NIDX_EMPTY_KEY;
         sh.thr_score[tid] = -INFINITY;
     }
-    for (int i = tid; i < MF_BM * MF_KMAX; i += 256) (&sh.lists[0][0])[i] = NIDX_EMPTY_KEY;
+    for (int i = tid; i < MF_BM * KMAX; i += 256) (&sh.lists[0][0])[i] = NIDX_EMPTY_KEY;
 
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t r0 = tile * MF_BN;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void mfma_scan_kernel(MfmaScanArgs a) {
                     const uint64_t nk_ = lane_bcast_u64(key, src);
                     if (!(nk_ > sh.thr_key[sq])) continue;  // an earlier insert of this round raised the bar
                     WaveSortedList l;
-                    l.key = lane < MF_KMAX ? sh.lists[sq][lane] : NIDX_EMPTY_KEY;
+                    l.key = lane < KMAX ? sh.lists[sq][lane] : NIDX_EMPTY_KEY;
                     l.insert(nk_, lane);
                     if (lane < k) sh.lists[sq][lane] = l.key;
                     uint64_t kth = l.at(k - 1);
@@ -227,7 +231,9 @@ uint32_t mfma_scan_stripes(uint32_t n, uint32_t n_queries) {
 
 hipError_t launch_mfma_scan(const MfmaScanArgs &a, uint32_t stripes, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
-    hipLaunchKernelGGL(mfma_scan_kernel, dim3(stripes, (a.n_queries + MF_BM - 1) / MF_BM), dim3(256), 0, s, a);
+    const dim3 grid(stripes, (a.n_queries + MF_BM - 1) / MF_BM);
+    if (a.k <= 16) hipLaunchKernelGGL(mfma_scan_kernel<16>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mfma_scan_kernel<NIDX_MFMA_KMAX>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -107,6 +107,55 @@ def test_multi_vector_brute_force_and_hnsw_match_oracle(orc, sim):
     assert bf[1][0, 0] == first[p7] + 1  # the later of the two identical vectors represents the paragraph
 
 
+@pytest.mark.parametrize("sim", [0, 1])
+def test_multi_vector_matrix_core_scans(orc, sim):
+    """The f32-MFMA scan (SERIAL_FMA order) on a multi-vector segment: k x vmax vectors, one hit per paragraph, bit-exact vs the
+    oracle in that order; the bf16 fallback: exact (WAVE64) scores of the vectors it returns, one hit per paragraph, the exact
+    scan's paragraphs up to bf16 ranking error."""
+    rng = np.random.default_rng(41 + sim)
+    n_para, d, vmax, k = 4000, 96, 3, 10
+    x, pov, first, num = make(rng, n_para, d, vmax)
+    p7 = int(np.nonzero(num >= 2)[0][5])
+    x[first[p7] + 1] = x[first[p7]]
+    nq = 140   # two query tiles of the MFMA scan
+    q = np.vstack([x[first[p7]][None, :], x[rng.integers(0, x.shape[0], nq - 1)] + rng.normal(size=(nq - 1, d)).astype(np.float32) * np.float32(0.1)])
+    alive = orc.bitset(n_para, ones=np.nonzero(rng.random(n_para) < 0.9)[0].tolist() + [p7])
+    filt = orc.bitset(n_para, ones=np.nonzero(rng.random(n_para) < 0.5)[0].tolist())
+    idx = Index(x, pov, n_para, sim, alive=alive)
+    try:
+        mf = idx.search(q, k, _lib.METHOD_BRUTE_FORCE_MFMA)
+        mf_f = idx.search(q, k, _lib.METHOD_BRUTE_FORCE_MFMA, min_score=0.3, filter_bits=filt)
+        mf21 = idx.search(q, 21, _lib.METHOD_BRUTE_FORCE_MFMA)   # 21 x 3 = 63 vectors: the wide lists
+        ex = idx.search(q, k, _lib.METHOD_BRUTE_FORCE)
+        bf = idx.search(q, k, _lib.METHOD_BRUTE_FORCE_BF16)      # 10 x 3 = 30 of the 32 candidates
+        with pytest.raises(_lib.NidxGpuError):
+            idx.search(q, 22, _lib.METHOD_BRUTE_FORCE_MFMA)      # 66 > 64
+        with pytest.raises(_lib.NidxGpuError):
+            idx.search(q, 11, _lib.METHOD_BRUTE_FORCE_BF16)      # 33 > 32
+    finally:
+        idx.close()
+    oseg = orc.Segment(x, similarity=sim, vec_paragraph=pov, para_first_vec=first, para_num_vec=num, alive=alive, n_paragraphs=n_para,
+                       order=orc.ORDER_SERIAL_FMA)
+    for i in list(range(12)) + [nq - 1]:
+        check(mf, oseg.brute_force(q[i], k), pov, i)
+        check(mf_f, oseg.brute_force(q[i], k, min_score=0.3, filter_bits=alive & filt), pov, i)
+        check(mf21, oseg.brute_force(q[i], 21), pov, i)
+    assert mf[1][0, 0] == first[p7] + 1
+    # bf16: exact scores of what it returns, sorted, distinct paragraphs, and the exact scan's paragraphs
+    op, ov, osc, oc = bf
+    assert np.array_equal(oc, ex[3])
+    same = 0
+    for i in range(nq):
+        c = int(oc[i])
+        assert len(set(op[i, :c].tolist())) == c and np.array_equal(op[i, :c], pov[ov[i, :c]])
+        keys = [(-float(osc[i, j]), int(ov[i, j])) for j in range(c)]
+        assert keys == sorted(keys)
+        for j in range(min(c, 3)):
+            assert bits([osc[i, j]])[0] == bits([orc.similarity(x[ov[i, j]], q[i], sim)])[0]
+        same += len(set(op[i, :c].tolist()) & set(ex[0][i, : ex[3][i]].tolist()))
+    assert same / float(ex[3].sum()) >= 0.99
+
+
 def test_multi_vector_rabitq_brute_force_matches_oracle(orc):
     rng = np.random.default_rng(23)
     n_para, d, vmax, k = 3000, 128, 3, 10

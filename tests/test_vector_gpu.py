@@ -325,7 +325,7 @@ def test_inconsistent_dimensions():
 # ---- a7 batched: the f32-MFMA GEMM scan (SERIAL_FMA order) ---------------------------------------------------
 @pytest.mark.parametrize("sim", [0, 1])
 @pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 3), (130, 20, 3, 10), (4000, 64, 9, 10), (20000, 768, 200, 10), (3000, 758, 5, 7),
-                                      (2500, 1024, 130, 16), (1200, 1536, 3, 5)])
+                                      (2500, 1024, 130, 16), (1200, 1536, 3, 5), (5000, 96, 140, 17), (9000, 768, 33, 64), (40, 32, 3, 64)])
 def test_mfma_scan_matches_oracle_serial_fma(orc, sim, n, d, nq, k):
     rng = np.random.default_rng(n * 17 + d)
     x = unit_rows(rng, n, d) if d > 8 else rng.normal(size=(n, d)).astype(np.float32)
@@ -360,6 +360,15 @@ def test_mfma_scan_filters_min_score_and_ties(orc):
                     assert oc[i] == len(wv), (sim, ms, i)
                     assert np.array_equal(ov[i, : oc[i]], wv)
                     assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws))
+
+
+def test_mfma_scan_page_bound():
+    """Pages above a full wave of ranks are refused, not truncated."""
+    rng = np.random.default_rng(3)
+    x = unit_rows(rng, 500, 32)
+    with pytest.raises(_lib.NidxGpuError) as e:
+        gpu_search(x, 0, x[:2], 65, method=_lib.METHOD_BRUTE_FORCE_MFMA)
+    assert e.value.code == _lib.NIDX_ERR_UNSUPPORTED
 
 
 def test_mfma_and_wave64_scans_agree_within_1e5():
