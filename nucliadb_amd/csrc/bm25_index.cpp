@@ -104,7 +104,9 @@ struct Bm25Index {
     std::vector<uint32_t> w_item_first, w_item_list;
     std::vector<Bm25Work> w_work;
     std::vector<uint8_t> w_q_union;
-    std::vector<uint64_t> w_postings;
+    std::vector<uint64_t> w_postings, w_clause_len;
+    std::vector<Bm25ClauseDev> w_dev_clauses;
+    std::vector<Bm25UClause> w_ucl;   // (entries of queries that are not union queries keep whatever they held: never read)
     DevBuf tf_cache;
     DevBuf s_after, s_count, s_total, s_postings, s_key;
     // term dictionary (fuzzy expansion) and the scratch of the collectors
@@ -609,7 +611,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
-    std::vector<Bm25ClauseDev> dev_clauses(n_clauses);
+    std::vector<Bm25ClauseDev> &dev_clauses = idx->w_dev_clauses;
+    dev_clauses.resize(n_clauses);
     uint32_t max_clauses = 0;
     for (uint32_t q = 0; q < nq; q++) {
         if (clause_offsets[q + 1] < clause_offsets[q]) return fail(NIDX_ERR_INVALID_ARGUMENT, "clause_offsets not monotone");
@@ -881,6 +884,14 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         // expected to share (independent lists: len_a * len_b / n_docs, summed over the pairs) is at most 1/8 of its postings — the union
         // kernels are exact for any input, that bound only keeps their slow paths rare.
         const double t_w0 = now_us();
+        // every clause's list length in this segment, looked up once (two random reads of an 8 MB table per plain term)
+        std::vector<uint64_t> &clen = idx->w_clause_len;
+        clen.resize(n_clauses);
+        for (uint64_t c = 0; c < n_clauses; c++) {
+            if (c + 16 < n_clauses && !(clauses[c + 16].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)))
+                __builtin_prefetch(&seg.term_offsets_host[clauses[c + 16].term]);
+            clen[c] = postings_of(clauses[c]);
+        }
         work.clear();
         std::vector<uint32_t> &item_first = idx->w_item_first;
         std::vector<uint8_t> &q_union = idx->w_q_union;
@@ -897,12 +908,22 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             std::vector<uint64_t> &pq = idx->w_postings;
             pq.assign(nq, 0);
             for (uint32_t q = 0; q < nq; q++)
-                for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) pq[q] += postings_of(clauses[c]);
-            for (uint64_t cand = 1024; cand < slice_postings; cand += 128) {
+                for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) pq[q] += clen[c];
+            // (the item count falls as the slice grows: bisection over the candidates, and a multiplication by the reciprocal instead of
+            // a 64-bit division per query and candidate — the count only steers this choice, the slicing below divides exactly)
+            auto fits = [&](uint64_t cand) {
+                const double inv = 1.0 / (double)cand;
                 uint64_t items = 0;
-                for (uint32_t q = 0; q < nq && items <= budget; q++) items += std::max<uint64_t>(1, (pq[q] + cand - 1) / cand);
-                if (items <= budget) { slice_now = cand; break; }
+                for (uint32_t q = 0; q < nq; q++) items += (uint64_t)((double)pq[q] * inv) + 1u;
+                return items <= budget;
+            };
+            uint64_t lo = 1024, hi = slice_postings;   // candidates lo, lo + 128, ..; hi is known to be acceptable (the default)
+            while (lo < hi) {
+                const uint64_t mid = lo + ((hi - lo) / 256) * 128;
+                if (fits(mid)) hi = mid;
+                else lo = mid + 128;
             }
+            slice_now = std::min<uint64_t>(hi, slice_postings);
         }
         for (uint32_t q = 0; q < nq; q++) {
             item_first[q] = (uint32_t)work.size();
@@ -911,7 +932,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             bool plain = true;
             double sum_sq = 0.0;
             for (uint64_t c = c0; c < c1; c++) {
-                const uint64_t l = postings_of(clauses[c]);
+                const uint64_t l = clen[c];
                 p += l;
                 sum_sq += (double)l * (double)l;
                 if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
@@ -923,7 +944,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 double repeated = 0.0;
                 for (uint64_t c = c0; c < c1; c++)
                     for (uint64_t e = c + 1; e < c1; e++)
-                        if (clauses[c].term == clauses[e].term) repeated += (double)postings_of(clauses[c]);
+                        if (clauses[c].term == clauses[e].term) repeated += (double)clen[c];
                 // the stream kernel resolves up to 192 involved postings per item without cutting its doc range: enough slices to keep
                 // the expected number (two postings per meeting) around 96
                 const double want = std::ceil((shared + repeated) * 2.0 / 96.0);
@@ -957,12 +978,13 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             }
         }
         // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
-        std::vector<Bm25UClause> ucl(n_union ? n_clauses : 0);
+        std::vector<Bm25UClause> &ucl = idx->w_ucl;
+        ucl.resize(n_union ? n_clauses : 0);
         for (uint32_t q = 0; q < nq && n_union; q++) {
             if (!q_union[q]) continue;
             for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) {
                 const uint64_t b = seg.term_offsets_host[clauses[c].term];
-                const uint64_t l = seg.term_offsets_host[clauses[c].term + 1] - b;
+                const uint64_t l = clen[c];
                 if (l > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "a posting list of one segment holds more than 2^32 - 1 postings");
                 ucl[c] = Bm25UClause{(uint32_t)b, (uint32_t)(b >> 32), (uint32_t)l, dev_clauses[c].weight,
                                      (uint32_t)dev_clauses[c].occur | ((uint32_t)dev_clauses[c].mode << 8), 0u, 0u, 0u};
