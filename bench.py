@@ -1402,6 +1402,26 @@ def bf16_block(a, L, dev):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        # the same batches with the other scan of the fallback (NIDX_GPU_BF16_APPEND: 1 / unset = floors + bf16_append_kernel, the
+        # default; 0 = bf16_scan_kernel with its candidate lists alone): both are the product, the environment picks
+        other_env = "0" if os.environ.get("NIDX_GPU_BF16_APPEND", "1") != "0" else "1"
+        saved_env = os.environ.get("NIDX_GPU_BF16_APPEND")
+        os.environ["NIDX_GPU_BF16_APPEND"] = other_env
+        try:
+            search(q[0], _lib.METHOD_BRUTE_FORCE_BF16)
+            torch.cuda.synchronize()
+            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+            for i in range(2):
+                ev2[i][0].record()
+                search(q[i & 1], _lib.METHOD_BRUTE_FORCE_BF16)
+                ev2[i][1].record()
+            torch.cuda.synchronize()
+            other_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev2]))
+        finally:
+            if saved_env is None:
+                os.environ.pop("NIDX_GPU_BF16_APPEND", None)
+            else:
+                os.environ["NIDX_GPU_BF16_APPEND"] = saved_env
         rq = min(64, B)
         search(q[0], _lib.METHOD_BRUTE_FORCE_BF16)
         torch.cuda.synchronize()
@@ -1417,7 +1437,10 @@ def bf16_block(a, L, dev):
     return {"workload": "bf16 fallback: %d x %d-dim cosine (uniform corpus), k=%d, batch=%d queries, exact f32 re-score of the candidates" % (n, d, k, B),
             "queries_per_s": B * steps / elapsed, "ms_per_batch": kernel_ms, "recall_at_%d_vs_exact_scan" % k: recall, "recall_queries": rq,
             "corpus_gen_s": gen_s, "open_s": open_s,
-            "roofline": {"kernel": "bf16_scan_kernel + merge_topk_kernel + rescore_select_kernel", "bound": "mfma", "achieved": tf, "peak": 2500.0,
+            "scan": "append" if other_env == "0" else "lists",
+            "ms_per_batch_other_scan": {"scan": "lists (NIDX_GPU_BF16_APPEND=0)" if other_env == "0" else "append (NIDX_GPU_BF16_APPEND=1)", "ms_per_batch": other_ms,
+                                        "frac": flops / (other_ms * 1e-3) / 1e12 / 2500.0},
+            "roofline": {"kernel": "bf16 fallback launches of one batch (sample passes, bf16_append_kernel / bf16_scan_kernel, merge_topk_kernel, rescore_select_kernel)", "bound": "mfma", "achieved": tf, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "algorithmic_flops_per_launch": flops, "kernel_ms": kernel_ms,
                          "hbm_frac_bf16_read_once": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 

@@ -73,6 +73,9 @@ struct Bf16ScanArgs {
     uint64_t *partial;                // [n_queries][stripes][NIDX_BF16_CAND]
     int debug;                        // diagnostics (env NIDX_GPU_BF16_DEBUG): 1 = no candidate admitted (GEMM time only)
     const float *floor_score;         // nullptr or [n_queries]: a score at least NIDX_BF16_CAND rows are known to reach (sample pass)
+    const uint32_t *run_if = nullptr; // bf16_scan_kernel: nullptr or [query blocks of 256]: a block whose word is 0 is skipped
+    uint32_t *overflow = nullptr;     // bf16_append_kernel: [query blocks of 256], ORed with 1 when a stripe of the block ran out of slots
+    uint32_t tile_step = 1;           // bf16_append_kernel: scan every tile_step-th corpus tile
 };
 struct RescoreArgs {
     const float *vectors;   // [n][dp] f32
@@ -91,7 +94,10 @@ struct RescoreArgs {
 // rows -> the tiled bf16 operand layout; norm2 != nullptr scales every row by 1 / sqrt(norm2[row]) (cosine)
 hipError_t launch_to_bf16_tiled(const float *in, const float *norm2, uint32_t n, uint32_t dp, uint32_t dp16, unsigned short *out, hipStream_t s);
 // floor[q] = the NIDX_BF16_CAND-th best score of query q's merged sample candidates (count < NIDX_BF16_CAND: -inf)
-hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, float *floor, hipStream_t s);
+hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, const float *prev, const uint32_t *overflow,
+                             float *floor, hipStream_t s);
+// the list-free scan (needs a floor per query): candidates appended to the [query][stripe][NIDX_BF16_CAND] block, which the caller zeroes first
+hipError_t launch_bf16_append(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s);
 hipError_t launch_bf16_row_mask(uint32_t n, const uint32_t *para_of_vec, const uint64_t *alive, const uint64_t *filter, uint64_t *out,
                                 hipStream_t s);
 uint32_t bf16_scan_stripes(uint32_t n, uint32_t n_queries);

@@ -177,6 +177,8 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_scan_kernel(Bf16ScanArgs a
     const uint32_t q0 = blockIdx.y * BF_BM;
     const uint32_t n_tiles = (a.n + BF_BN - 1) / BF_BN;
     const uint32_t nk = a.dp16 / BF_BK;
+    // the exact second opinion behind bf16_append_kernel: only the query blocks whose append pass ran out of slots are scanned again
+    if (a.run_if && a.run_if[blockIdx.y] == 0) return;
 
     if (tid < BF_BM) {
         const bool real = q0 + tid < a.n_queries && !(a.debug & 1);
@@ -334,6 +336,195 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_scan_kernel(Bf16ScanArgs a
     }
 }
 
+// ---- the same scan without candidate lists in LDS (round 4) -----------------------------------------------------------------------
+// With a floor per query (32 rows of a sample are known to reach it) a stripe holds only a handful of rows at or above it, so the
+// sorted lists — 64 KiB of LDS that pinned the pipeline above to 16-element K steps and one barrier per step — are not needed: a
+// row that reaches its query's floor is APPENDED to the query's 32 slots of this stripe (an LDS counter gives the position, the
+// key goes straight to HBM), and merge_topk_kernel sees the same [query][stripe][32] block as before.  A stripe that would need a
+// 33rd slot raises its query block's flag and bf16_scan_kernel (run_if) scans that block again with its lists: the result is the
+// list kernel's in every case.  What the freed LDS buys is the mainloop of the guide's 256 x 256 bf16 tile: BK = 64 (four of the
+// 8-KiB operand blocks per operand and stage), two 64-KiB stages, one s_waitcnt vmcnt(0) + barrier per stage = per 32 MFMAs of a
+// wave, and — no list belongs to a wave any more — 64 x 128 wave tiles (wave (w & 3, w >> 2): 2 + 4 fragment reads per 8 MFMAs
+// instead of 1 + 8).  tile_step > 1: only every tile_step-th corpus tile is scanned (the representative sample the floor of the
+// full pass comes from).
+#define BA_CHUNKS 4                                        /* K steps of 16 per stage */
+#define BA_OPERAND_BYTES (BA_CHUNKS * BF_BLOCK_BYTES)       /* 32 KiB */
+#define BA_STAGE_BYTES (2 * BA_OPERAND_BYTES)               /* [Q: 4 blocks][X: 4 blocks] */
+struct Bf16AppendShared {
+    __attribute__((aligned(16))) unsigned char stage[2][BA_STAGE_BYTES];
+    float thr[BF_BM];       // a row is a candidate iff score > thr (the largest float under the floor; +inf: padding query)
+    uint32_t cnt[BF_BM];    // candidates of the query in this stripe so far
+    uint32_t overflow;
+};
+
+__global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
+    Bf16AppendShared &sh = *reinterpret_cast<Bf16AppendShared *>(bf_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, half = lane >> 5;
+    const int wq = wave & 3, wr = wave >> 2;          // this wave: queries 64 wq.., tile rows 128 wr..
+    const uint32_t q0 = blockIdx.y * BF_BM;
+    const uint32_t step = a.tile_step ? a.tile_step : 1u;
+    const uint32_t n_tiles = ((a.n + BF_BN - 1) / BF_BN + step - 1) / step;   // tiles this pass visits: 0, step, 2 step, ..
+    const uint32_t nk = a.dp16 / BF_BK;
+    const uint32_t S = nk / BA_CHUNKS;                // stages per tile (dp16 is a multiple of 64)
+
+    if (tid < BF_BM) {
+        const bool real = q0 + tid < a.n_queries;
+        float t0 = INFINITY;
+        if (real) {
+            const float f = a.floor_score[q0 + tid];
+            t0 = -INFINITY;
+            if (f > -INFINITY) {
+                const int32_t k = total_key(f) - 1;                                           // the float just below f in total order
+                t0 = __builtin_bit_cast(float, k ^ (int32_t)(((uint32_t)(k >> 31)) >> 1));
+            }
+        }
+        sh.thr[tid] = t0;
+        sh.cnt[tid] = 0;
+    }
+    if (tid == 0) sh.overflow = 0;
+    __syncthreads();
+    // a query without a floor (fewer than 32 sampled rows passed the filter) would admit every row: leave the block to the list kernel
+    if (tid < BF_BM && sh.thr[tid] == -INFINITY) sh.overflow = 1u;
+    __syncthreads();
+    if (sh.overflow) {
+        if (tid == 0) atomicOr(&a.overflow[blockIdx.y], 1u);
+        return;
+    }
+
+    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t G = my_tiles * S;
+    // every wave copies 4 KiB of each operand per stage (four 1-KiB pieces each)
+    const unsigned char *const q_base = reinterpret_cast<const unsigned char *>(a.queries16) + (size_t)blockIdx.y * nk * BF_BLOCK_BYTES +
+                                        (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
+    const unsigned char *const x_base = reinterpret_cast<const unsigned char *>(a.vectors16) + (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
+    uint32_t is_s = 0, is_tile = blockIdx.x;          // the next stage to request
+    // pieces [p0, p1) of this wave's eight (0-3: query block, 4-7: corpus block) of the stage (is_tile, is_s); advance() moves to the next stage
+    auto issue_pieces = [&](int buf, int p0, int p1) __attribute__((always_inline)) {
+        const unsigned char *qs = q_base + (size_t)is_s * BA_OPERAND_BYTES;
+        const unsigned char *xs = x_base + ((size_t)is_tile * step * nk + (size_t)is_s * BA_CHUNKS) * BF_BLOCK_BYTES;
+        unsigned char *dst = &sh.stage[buf][0] + (uint32_t)wave * 4096u;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            if (p < p0 || p >= p1) continue;
+            if (p < 4) bf_glds16<0>(qs + p * 1024, dst + p * 1024);
+            else bf_glds16<0>(xs + (p - 4) * 1024, dst + BA_OPERAND_BYTES + (p - 4) * 1024);
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++is_s == S) {
+            is_s = 0;
+            is_tile += gridDim.x;
+        }
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        issue_pieces(buf, 0, 8);
+        advance();
+    };
+    floatx16 acc[8];   // [a = query half 0..1][t = row quarter 0..3]
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    const int frag = (half ^ ((li >> 3) & 1)) * 16;
+    const int a_off = (64 * wq + li) * 32 + frag, b_off = BA_OPERAND_BYTES + (128 * wr + li) * 32 + frag;
+
+    auto epilogue = [&](uint32_t tile) __attribute__((always_inline)) {   // `tile`: the corpus tile (already multiplied by step)
+        const uint32_t r0 = tile * BF_BN;
+        // (the lane coordinates go through an empty asm: otherwise hipcc hoists the ~60 per-query LDS / HBM addresses of this rare path
+        // out of the stage loop and spills the mainloop's registers to make room for them)
+        int half = lane >> 5, li = lane & 31;
+        asm volatile("" : "+v"(half), "+v"(li));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 okw;   // the row-mask bits of this wave's 128 tile rows, through the scalar cache
+        const uint64_t *mp = a.row_mask + (r0 >> 6) + 2 * wr;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(okw) : "s"(mp) : "memory");
+#pragma unroll
+        for (int qa = 0; qa < 2; qa++) {
+            const int qb = 64 * wq + 32 * qa;
+            float thr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) thr[r] = sh.thr[qb + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const floatx16 &c = acc[qa * 4 + t];
+                const bool row_ok = (okw[t] >> li) & 1u;
+                // the common case — no lane holds a candidate — costs one compare per value: the lane masks are ORed on the scalar side
+                unsigned long long any = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) any |= __ballot(c[r] > thr[r]);
+                if (!(any & __ballot(row_ok))) continue;
+                uint32_t mask = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) mask |= (row_ok && c[r] > thr[r]) ? (1u << r) : 0u;
+                const uint32_t row = r0 + (uint32_t)(128 * wr + 32 * t + li);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (!((mask >> r) & 1u)) continue;
+                    const int ql = qb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const uint32_t pos = atomicAdd(&sh.cnt[ql], 1u);
+                    if (pos < (uint32_t)BF_KP) a.partial[((size_t)(q0 + ql) * gridDim.x + blockIdx.x) * BF_KP + pos] = rank_key(c[r], row);
+                    else sh.overflow = 1u;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    };
+
+    __syncthreads();   // thresholds and counters
+    if (G) {
+        issue(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
+        __syncthreads();
+        uint32_t tile = blockIdx.x, s_now = 0;
+        for (uint32_t g = 0; g < G; g++) {
+            const int buf = (int)(g & 1u);
+            const bool more = g + 1 < G;
+            // The second wave of each SIMD (waves 4-7) requests its pieces after its first K step: one wave of a SIMD feeds the matrix
+            // core while the other one issues its eight 1-KiB pieces (measured at 4 M x 1024, batch 1 024: 9.35 ms against 9.87 ms with
+            // every wave requesting first; spreading the pieces over the K steps measured 9.88 / 10.2 ms)
+            const bool late = wave >= 4;
+            if (more && !late) issue_pieces(buf ^ 1, 0, 8);   // lands while this stage is multiplied
+            const unsigned char *base = &sh.stage[buf][0];
+            // the fragments of K step c + 1 are on their way from LDS while the matrix core works on step c (two register sets)
+            bf16x8 av[2][2], bv[2][4];
+            auto frags = [&](int c, int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qa = 0; qa < 2; qa++) av[set][qa] = *reinterpret_cast<const bf16x8 *>(base + c * BF_BLOCK_BYTES + a_off + qa * 32 * 32);
+#pragma unroll
+                for (int t = 0; t < 4; t++) bv[set][t] = *reinterpret_cast<const bf16x8 *>(base + c * BF_BLOCK_BYTES + b_off + t * 32 * 32);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int c = 0; c < BA_CHUNKS; c++) {
+                if (c + 1 < BA_CHUNKS) frags(c + 1, (c + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qa = 0; qa < 2; qa++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        acc[qa * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c & 1][qa], bv[c & 1][t], acc[qa * 4 + t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c == 0 && more && late) issue_pieces(buf ^ 1, 0, 8);
+            }
+            if (more) advance();
+            if (++s_now == S) {
+                epilogue(tile * step);
+                s_now = 0;
+                tile += gridDim.x;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);   // the next stage has landed (this wave's pieces; the barrier covers the others')
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && sh.overflow) atomicOr(&a.overflow[blockIdx.y], 1u);
+}
+
 // Stage 3: one wave per query re-scores its candidates exactly (WAVE64 order) and keeps the best k.
 template <int NJ>
 __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs a) {
@@ -388,15 +579,22 @@ hipError_t launch_to_bf16_tiled(const float *in, const float *norm2, uint32_t n,
     return hipGetLastError();
 }
 
+// floor[q] = the BF_KP-th best score of query q's merged candidates; prev != nullptr: never below prev[q], and prev[q] itself where
+// the query has fewer candidates or its block's pass ran out of slots (overflow[q / 256] != 0: that pass's lists are incomplete)
 __global__ __launch_bounds__(256) void bf16_floor_kernel(const float *__restrict__ cand_score, const uint32_t *__restrict__ cand_count, uint32_t n_queries,
-                                                         float *__restrict__ floor) {
+                                                         const float *__restrict__ prev, const uint32_t *__restrict__ overflow, float *__restrict__ floor) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n_queries) floor[q] = cand_count[q] >= BF_KP ? cand_score[(size_t)q * BF_KP + BF_KP - 1] : -INFINITY;
+    if (q >= n_queries) return;
+    const float p = prev ? prev[q] : -INFINITY;
+    float f = cand_count[q] >= BF_KP ? cand_score[(size_t)q * BF_KP + BF_KP - 1] : -INFINITY;
+    if (overflow && overflow[q / BF_BM]) f = -INFINITY;
+    floor[q] = fmaxf(f, p);
 }
 
-hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, float *floor, hipStream_t s) {
+hipError_t launch_bf16_floor(const float *cand_score, const uint32_t *cand_count, uint32_t n_queries, const float *prev, const uint32_t *overflow,
+                             float *floor, hipStream_t s) {
     if (n_queries == 0) return hipSuccess;
-    hipLaunchKernelGGL(bf16_floor_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, cand_score, cand_count, n_queries, floor);
+    hipLaunchKernelGGL(bf16_floor_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, cand_score, cand_count, n_queries, prev, overflow, floor);
     return hipGetLastError();
 }
 
@@ -423,6 +621,16 @@ hipError_t launch_bf16_scan(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bf16_scan_kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(BF_THREADS), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_append(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s) {
+    if (a.n_queries == 0) return hipSuccess;
+    if (a.n == 0 || (a.dp16 % 64u) || !a.floor_score || !a.overflow) return hipErrorInvalidValue;
+    const size_t smem = sizeof(Bf16AppendShared);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_append_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf16_append_kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(BF_THREADS), smem, s, a);
     return hipGetLastError();
 }
 

@@ -409,6 +409,51 @@ def test_bf16_fallback_scores_exact_and_recall(orc, sim, n, d, nq, k):
     assert hits / float(c_ex.sum()) >= 0.99
 
 
+@pytest.mark.parametrize("case", ["one_pass", "sampled_floor", "crowded_stripe", "filter_empties_the_floor"])
+def test_bf16_append_scan_equals_the_list_scan(orc, case):
+    """bf16_append_kernel (candidates appended under a per-query floor, no lists in LDS) against bf16_scan_kernel alone
+    (NIDX_GPU_BF16_APPEND=0): the same candidates, hence the same ids, counts and score bits — with one append pass, with the
+    floor tightened on a strided sample first, when a stripe holds more than 32 rows above the floor (the block falls back to the
+    list kernel) and when a filter leaves the sampled prefix without 32 rows (no floor: the block is left to the list kernel)."""
+    import os
+    rng = np.random.default_rng(77)
+    kwargs = {}
+    if case == "one_pass":
+        n, d, nq, k = 150000, 64, 140, 10
+    elif case == "sampled_floor":
+        n, d, nq, k = 220000, 64, 800, 10          # 4 query blocks -> 64 stripes: the prefix floor covers 196 k rows, so a strided pass comes first
+    elif case == "crowded_stripe":
+        n, d, nq, k = 120000, 64, 300, 32
+    else:
+        n, d, nq, k = 120000, 64, 70, 10
+    x = unit_rows(rng, n, d)
+    q = unit_rows(rng, nq, d)
+    if case == "crowded_stripe":                    # 3 000 near-copies of query 0 in consecutive rows far behind the sampled prefix
+        x[60000:63000] = q[0] + rng.normal(size=(3000, d)).astype(np.float32) * np.float32(0.01)
+        x[60000:63000] /= np.linalg.norm(x[60000:63000], axis=1, keepdims=True)
+    if case == "filter_empties_the_floor":
+        ones = np.nonzero(rng.random(n) < 0.3)[0]
+        ones = ones[ones >= 20000]                  # nothing of the sampled prefix passes
+        kwargs["filter_bits"] = orc.bitset(n, ones=ones.tolist())
+    old = os.environ.get("NIDX_GPU_BF16_APPEND")
+    try:
+        os.environ["NIDX_GPU_BF16_APPEND"] = "0"
+        v0, s0, c0 = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, **kwargs)
+        os.environ["NIDX_GPU_BF16_APPEND"] = "1"
+        v1, s1, c1 = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, **kwargs)
+    finally:
+        if old is None:
+            os.environ.pop("NIDX_GPU_BF16_APPEND", None)
+        else:
+            os.environ["NIDX_GPU_BF16_APPEND"] = old
+    assert np.array_equal(c0, c1)
+    for i in range(nq):
+        assert np.array_equal(v0[i, : c0[i]], v1[i, : c1[i]]), (case, i)
+        assert np.array_equal(bits(s0[i, : c0[i]]), bits(s1[i, : c1[i]]))
+    if case == "crowded_stripe":
+        assert set(v1[0, : c1[0]].tolist()) <= set(range(60000, 63000))
+
+
 def test_bf16_fallback_filter_and_min_score(orc):
     rng = np.random.default_rng(21)
     n, d, k = 8000, 128, 10
