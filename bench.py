@@ -355,7 +355,7 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved_tf / 157.3, "traffic": None, "algorithmic_flops_per_launch": alg_flops,
                 "hbm_GBps_algorithmic": achieved, "kernel_ms": kernel_ms,
             } if a.workload == "mfma" else {
-                "kernel": "bf16_scan_kernel + merge_topk_kernel + rescore_select_kernel", "bound": "mfma", "achieved": achieved_tf,
+                "kernel": "bf16 fallback launches of one batch (sample passes, bf16_append_kernel / bf16_scan_kernel, merge_topk_kernel, rescore_select_kernel)", "bound": "mfma", "achieved": achieved_tf,
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": None,
                 "algorithmic_flops_per_launch": alg_flops, "hbm_GBps_algorithmic_bf16": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9,
                 "hbm_frac": float(n) * d * 2 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kernel_ms,
