@@ -75,7 +75,11 @@ struct Bf16ScanArgs {
     const float *floor_score;         // nullptr or [n_queries]: a score at least NIDX_BF16_CAND rows are known to reach (sample pass)
     const uint32_t *run_if = nullptr; // bf16_scan_kernel: nullptr or [query blocks of 256]: a block whose word is 0 is skipped
     uint32_t *overflow = nullptr;     // bf16_append_kernel: [query blocks of 256], ORed with 1 when a stripe of the block ran out of slots
-    uint32_t tile_step = 1;           // bf16_append_kernel: scan every tile_step-th corpus tile
+    // bf16_append_kernel: round i of a workgroup = corpus tile blockIdx.x + i * gridDim.x
+    uint32_t round_step = 1;          // scan every round_step-th round (a sample pass)
+    uint32_t round_skip = 0;          // > 1: the full pass behind a sample pass of that round_step on the same grid: skip its rounds, go on from its slots
+    const uint32_t *skip_unless = nullptr;  // with round_skip: [query blocks]: non-zero = that sample ran out of slots: empty the slots, scan every round
+    uint32_t *cnt_inout = nullptr;    // [n_queries][stripes] candidates per slot group: written by a sample pass, read by the full pass behind it
 };
 struct RescoreArgs {
     const float *vectors;   // [n][dp] f32

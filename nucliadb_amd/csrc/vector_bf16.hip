@@ -345,8 +345,11 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_scan_kernel(Bf16ScanArgs a
 // list kernel's in every case.  What the freed LDS buys is the mainloop of the guide's 256 x 256 bf16 tile: BK = 64 (four of the
 // 8-KiB operand blocks per operand and stage), two 64-KiB stages, one s_waitcnt vmcnt(0) + barrier per stage = per 32 MFMAs of a
 // wave, and — no list belongs to a wave any more — 64 x 128 wave tiles (wave (w & 3, w >> 2): 2 + 4 fragment reads per 8 MFMAs
-// instead of 1 + 8).  tile_step > 1: only every tile_step-th corpus tile is scanned (the representative sample the floor of the
-// full pass comes from).
+// instead of 1 + 8).  A workgroup's tiles come in rounds (round i = tile blockIdx.x + i gridDim.x).  round_step > 1: only every
+// round_step-th round is scanned — the sample across the corpus the floor of the full pass comes from; the groups' counts go to
+// cnt_inout.  round_skip > 1 (the full pass after such a sample, same grid): those rounds are skipped and the sample's entries stay
+// in their slots — the workgroup first drops the ones under the tightened floor and goes on appending behind the rest; a query
+// block whose sample ran out of slots (skip_unless) empties its slots and scans every round.
 #define BA_CHUNKS 4                                        /* K steps of 16 per stage */
 #define BA_OPERAND_BYTES (BA_CHUNKS * BF_BLOCK_BYTES)       /* 32 KiB */
 #define BA_STAGE_BYTES (2 * BA_OPERAND_BYTES)               /* [Q: 4 blocks][X: 4 blocks] */
@@ -354,6 +357,7 @@ struct Bf16AppendShared {
     __attribute__((aligned(16))) unsigned char stage[2][BA_STAGE_BYTES];
     float thr[BF_BM];       // a row is a candidate iff score > thr (the largest float under the floor; +inf: padding query)
     uint32_t cnt[BF_BM];    // candidates of the query in this stripe so far
+    uint64_t keep[BF_THREADS / 64][BF_KP];   // a wave's staging row while it compacts the sample's entries of one query
     uint32_t overflow;
 };
 
@@ -365,8 +369,12 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
     const int li = lane & 31, half = lane >> 5;
     const int wq = wave & 3, wr = wave >> 2;          // this wave: queries 64 wq.., tile rows 128 wr..
     const uint32_t q0 = blockIdx.y * BF_BM;
-    const uint32_t step = a.tile_step ? a.tile_step : 1u;
-    const uint32_t n_tiles = ((a.n + BF_BN - 1) / BF_BN + step - 1) / step;   // tiles this pass visits: 0, step, 2 step, ..
+    const uint32_t rs = a.round_step ? a.round_step : 1u;
+    // the full pass behind a sample keeps the sample's entries unless that sample ran out of slots for this query block
+    const bool after_sample = a.round_skip > 1;
+    const bool keep_sample = after_sample && !(a.skip_unless && a.skip_unless[blockIdx.y]);
+    const uint32_t skip = keep_sample ? a.round_skip : 0u;
+    const uint32_t n_tiles = (a.n + BF_BN - 1) / BF_BN;
     const uint32_t nk = a.dp16 / BF_BK;
     const uint32_t S = nk / BA_CHUNKS;                // stages per tile (dp16 is a multiple of 64)
 
@@ -394,17 +402,45 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
         return;
     }
 
-    const uint32_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t rounds = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t my_tiles = skip ? rounds - (rounds + skip - 1) / skip : (rounds + rs - 1) / rs;
     const uint32_t G = my_tiles * S;
+    const uint32_t round0 = skip ? 1u : 0u;
+    auto next_round = [&](uint32_t r) __attribute__((always_inline)) {
+        r += rs;
+        if (skip && r % skip == 0) r++;
+        return r;
+    };
+    if (after_sample) {
+        // the slots of this stripe hold the sample's candidates (score >= the sample's floor): keep what also reaches the new floor,
+        // packed at the front of its group; the counters continue from there.  Wave w takes queries 32 w .. 32 w + 31.
+        __syncthreads();   // (thresholds)
+        for (int i = 0; i < 32; i++) {
+            const int ql = 32 * wave + i;
+            const uint32_t q = q0 + (uint32_t)ql;
+            if (q >= a.n_queries) break;
+            uint64_t *slots = a.partial + ((size_t)q * gridDim.x + blockIdx.x) * BF_KP;
+            uint32_t c = keep_sample ? a.cnt_inout[(size_t)q * gridDim.x + blockIdx.x] : 0u;
+            c = c < (uint32_t)BF_KP ? c : (uint32_t)BF_KP;
+            const uint64_t key = (uint32_t)lane < c ? slots[lane] : NIDX_EMPTY_KEY;
+            const bool kept = (uint32_t)lane < c && rank_key_score(key) > sh.thr[ql];
+            const unsigned long long m = __ballot(kept);
+            if (kept) sh.keep[wave][__popcll(m & ((1ull << lane) - 1ull))] = key;
+            const uint32_t n_kept = (uint32_t)__popcll(m);
+            if (lane < BF_KP) slots[lane] = (uint32_t)lane < n_kept ? sh.keep[wave][lane] : NIDX_EMPTY_KEY;
+            if (lane == 0) sh.cnt[ql] = n_kept;
+        }
+        __syncthreads();
+    }
     // every wave copies 4 KiB of each operand per stage (four 1-KiB pieces each)
     const unsigned char *const q_base = reinterpret_cast<const unsigned char *>(a.queries16) + (size_t)blockIdx.y * nk * BF_BLOCK_BYTES +
                                         (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
     const unsigned char *const x_base = reinterpret_cast<const unsigned char *>(a.vectors16) + (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
-    uint32_t is_s = 0, is_tile = blockIdx.x;          // the next stage to request
+    uint32_t is_s = 0, is_round = round0;             // the next stage to request
     // pieces [p0, p1) of this wave's eight (0-3: query block, 4-7: corpus block) of the stage (is_tile, is_s); advance() moves to the next stage
     auto issue_pieces = [&](int buf, int p0, int p1) __attribute__((always_inline)) {
         const unsigned char *qs = q_base + (size_t)is_s * BA_OPERAND_BYTES;
-        const unsigned char *xs = x_base + ((size_t)is_tile * step * nk + (size_t)is_s * BA_CHUNKS) * BF_BLOCK_BYTES;
+        const unsigned char *xs = x_base + (((size_t)blockIdx.x + (size_t)is_round * gridDim.x) * nk + (size_t)is_s * BA_CHUNKS) * BF_BLOCK_BYTES;
         unsigned char *dst = &sh.stage[buf][0] + (uint32_t)wave * 4096u;
 #pragma unroll
         for (int p = 0; p < 8; p++) {
@@ -416,7 +452,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
     auto advance = [&]() __attribute__((always_inline)) {
         if (++is_s == S) {
             is_s = 0;
-            is_tile += gridDim.x;
+            is_round = next_round(is_round);
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -431,7 +467,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
     const int frag = (half ^ ((li >> 3) & 1)) * 16;
     const int a_off = (64 * wq + li) * 32 + frag, b_off = BA_OPERAND_BYTES + (128 * wr + li) * 32 + frag;
 
-    auto epilogue = [&](uint32_t tile) __attribute__((always_inline)) {   // `tile`: the corpus tile (already multiplied by step)
+    auto epilogue = [&](uint32_t tile) __attribute__((always_inline)) {   // `tile`: the corpus tile
         const uint32_t r0 = tile * BF_BN;
         // (the lane coordinates go through an empty asm: otherwise hipcc hoists the ~60 per-query LDS / HBM addresses of this rare path
         // out of the stage loop and spills the mainloop's registers to make room for them)
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
         issue(0);
         __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
         __syncthreads();
-        uint32_t tile = blockIdx.x, s_now = 0;
+        uint32_t ep_round = round0, s_now = 0;
         for (uint32_t g = 0; g < G; g++) {
             const int buf = (int)(g & 1u);
             const bool more = g + 1 < G;
@@ -514,15 +550,18 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
             }
             if (more) advance();
             if (++s_now == S) {
-                epilogue(tile * step);
+                epilogue(blockIdx.x + ep_round * gridDim.x);
                 s_now = 0;
-                tile += gridDim.x;
+                ep_round = next_round(ep_round);
             }
             __builtin_amdgcn_s_waitcnt(0x0070);   // the next stage has landed (this wave's pieces; the barrier covers the others')
             __syncthreads();
         }
     }
     if (tid == 0 && sh.overflow) atomicOr(&a.overflow[blockIdx.y], 1u);
+    // a sample pass leaves its groups' counts for the full pass that goes on from them
+    if (a.cnt_inout && !after_sample && tid < BF_BM && q0 + tid < a.n_queries)
+        a.cnt_inout[(size_t)(q0 + tid) * gridDim.x + blockIdx.x] = sh.cnt[tid] < (uint32_t)BF_KP ? sh.cnt[tid] : (uint32_t)BF_KP;
 }
 
 // Stage 3: one wave per query re-scores its candidates exactly (WAVE64 order) and keeps the best k.

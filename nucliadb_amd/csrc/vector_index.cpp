@@ -650,8 +650,8 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         }
         // With a floor the scan needs no candidate lists: bf16_append_kernel (BK = 64 stages, 64 x 128 wave tiles) appends the rows that
         // reach it to the 32 slots of their (query, stripe).  A floor taken from R rows lets a pass over N rows expect 32 N / (R stripes)
-        // candidates per slot group; passes are sized for 8, so a floor from the 64 k-row prefix is first tightened on every step-th tile
-        // (a sample across the whole corpus, up to R stripes / 4 rows: a 16th of it with 64 stripes), then the full pass runs.  A
+        // candidates per slot group; passes are sized for 8, so a floor from the 64 k-row prefix is first tightened on a sample across the
+        // whole corpus (up to R stripes / 4 rows: a 16th of it with 64 stripes), then the full pass runs over the rest.  A
         // group that fills up anyway (clustered rows, a floor the filter emptied) flags its query block, and the list kernel scans
         // that block again: the candidates are the list kernel's in every case.  NIDX_GPU_BF16_APPEND=0 keeps the list kernel alone.
         const char *const append_env = getenv("NIDX_GPU_BF16_APPEND");
@@ -663,35 +663,45 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
             uint32_t *const flags_sample = scratch_bf16_flags.as<uint32_t>(), *const flags_full = flags_sample + qb;
             float *floor_next = scratch_floor2.as<float>();
             const size_t partial_bytes = (size_t)nq * stripes * NIDX_BF16_CAND * 8;
+            // A sample pass scans every rs-th ROUND of the full pass's own grid (round i of stripe x = tile x + i * stripes), so the full pass can
+            // skip exactly those rounds and go on from the sample's slots: its rows are not scanned twice.
+            NIDX_HIP(scratch_bf16_counts.reserve((size_t)nq * stripes * 4));
+            uint32_t last_rs = 0;
             for (;;) {
                 const uint64_t cap_rows = floor_rows * (uint64_t)stripes / 4u;   // rows a pass may cover under the current floor
-                if (cap_rows >= seg.n) break;
+                if (cap_rows + cap_rows / 4 >= seg.n) break;   // (up to 10 expected per group of 32 slots is still far from filling one)
                 // the least the full pass needs is a floor from n / (stripes / 4) rows; take more only when the current floor cannot carry that
                 const uint64_t want_rows = std::min<uint64_t>(cap_rows, std::max<uint64_t>((uint64_t)seg.n * 4u / stripes, floor_rows * 2u));
-                const uint32_t step = (uint32_t)((seg.n + want_rows - 1) / want_rows);
-                if (step < 2) break;
-                const uint32_t tiles_s = (n_tiles + step - 1) / step;
-                const uint32_t stripes_s = bf16_scan_stripes(tiles_s * 256u, nq);
-                if (stripes_s < stripes) break;   // too few tiles to spread: the full pass takes what comes
+                const uint32_t rs = (uint32_t)((seg.n + want_rows - 1) / want_rows);
+                const uint32_t rounds = (n_tiles + stripes - 1) / stripes;
+                if (rs < 2 || rounds < 2 * rs) break;   // too few rounds to take a sample of: the full pass takes what comes
+                const uint64_t rows_s = (uint64_t)((rounds + rs - 1) / rs) * stripes * 256u;   // (an upper bound)
+                if (rows_s > cap_rows) break;
                 NIDX_HIP(hipMemsetAsync(b.partial, 0, partial_bytes, st));
                 NIDX_HIP(hipMemsetAsync(flags_sample, 0, (size_t)qb * 4, st));
                 Bf16ScanArgs ap = b;
-                ap.tile_step = step;
+                ap.round_step = rs;
                 ap.overflow = flags_sample;
-                NIDX_HIP(launch_bf16_append(ap, stripes_s, st));
-                NIDX_HIP(launch_merge_topk(ap.partial, nq, stripes_s, NIDX_BF16_CAND, scratch_cand_vec.as<uint32_t>(), scratch_cand_score.as<float>(),
+                ap.cnt_inout = scratch_bf16_counts.as<uint32_t>();
+                NIDX_HIP(launch_bf16_append(ap, stripes, st));
+                NIDX_HIP(launch_merge_topk(ap.partial, nq, stripes, NIDX_BF16_CAND, scratch_cand_vec.as<uint32_t>(), scratch_cand_score.as<float>(),
                                            scratch_cand_count.as<uint32_t>(), st));
                 NIDX_HIP(launch_bf16_floor(scratch_cand_score.as<float>(), scratch_cand_count.as<uint32_t>(), nq, b.floor_score, flags_sample, floor_next, st));
                 float *const used = const_cast<float *>(b.floor_score);
                 b.floor_score = floor_next;
                 floor_next = used;
-                floor_rows = (uint64_t)tiles_s * 256u;
+                floor_rows = (uint64_t)(rounds / rs) * stripes * 256u;   // (a lower bound)
+                last_rs = rs;
             }
-            NIDX_HIP(hipMemsetAsync(b.partial, 0, partial_bytes, st));
+            if (!last_rs) NIDX_HIP(hipMemsetAsync(b.partial, 0, partial_bytes, st));   // (else the slots hold the last sample's candidates)
             NIDX_HIP(hipMemsetAsync(flags_full, 0, (size_t)qb * 4, st));
             Bf16ScanArgs ap = b;
-            ap.tile_step = 1;
             ap.overflow = flags_full;
+            if (last_rs) {
+                ap.round_skip = last_rs;
+                ap.skip_unless = flags_sample;
+                ap.cnt_inout = scratch_bf16_counts.as<uint32_t>();
+            }
             NIDX_HIP(launch_bf16_append(ap, stripes, st));
             b.run_if = flags_full;
         }

@@ -409,7 +409,7 @@ def test_bf16_fallback_scores_exact_and_recall(orc, sim, n, d, nq, k):
     assert hits / float(c_ex.sum()) >= 0.99
 
 
-@pytest.mark.parametrize("case", ["one_pass", "sampled_floor", "crowded_stripe", "filter_empties_the_floor"])
+@pytest.mark.parametrize("case", ["one_pass", "sampled_floor", "sampled_then_crowded", "crowded_sample", "crowded_stripe", "filter_empties_the_floor"])
 def test_bf16_append_scan_equals_the_list_scan(orc, case):
     """bf16_append_kernel (candidates appended under a per-query floor, no lists in LDS) against bf16_scan_kernel alone
     (NIDX_GPU_BF16_APPEND=0): the same candidates, hence the same ids, counts and score bits — with one append pass, with the
@@ -420,17 +420,23 @@ def test_bf16_append_scan_equals_the_list_scan(orc, case):
     kwargs = {}
     if case == "one_pass":
         n, d, nq, k = 150000, 64, 140, 10
-    elif case == "sampled_floor":
-        n, d, nq, k = 220000, 64, 800, 10          # 4 query blocks -> 64 stripes: the prefix floor covers 196 k rows, so a strided pass comes first
+    elif case in ("sampled_floor", "sampled_then_crowded", "crowded_sample"):
+        # 4 query blocks -> 64 stripes: the 64 k-row prefix floor carries 1.3 M rows, so every 12th round is sampled first and the full
+        # pass goes on from that sample's slots (and skips its rounds)
+        n, d, nq, k = 1500000, 64, 800, 10
     elif case == "crowded_stripe":
         n, d, nq, k = 120000, 64, 300, 32
     else:
         n, d, nq, k = 120000, 64, 70, 10
     x = unit_rows(rng, n, d)
     q = unit_rows(rng, nq, d)
-    if case == "crowded_stripe":                    # 3 000 near-copies of query 0 in consecutive rows far behind the sampled prefix
-        x[60000:63000] = q[0] + rng.normal(size=(3000, d)).astype(np.float32) * np.float32(0.01)
-        x[60000:63000] /= np.linalg.norm(x[60000:63000], axis=1, keepdims=True)
+    crowd = {"crowded_stripe": 60000, "sampled_then_crowded": 700000, "crowded_sample": 197000}.get(case)
+    if crowd is not None:
+        # 3 000 near-copies of query 0 in consecutive rows behind the sampled prefix: in rounds the full pass scans (its slots fill up:
+        # the list kernel takes the block), or — rows 197 k.. = round 12 — in a sampled round (the sample's slots fill up: the full
+        # pass drops them and scans every round)
+        x[crowd:crowd + 3000] = q[0] + rng.normal(size=(3000, d)).astype(np.float32) * np.float32(0.01)
+        x[crowd:crowd + 3000] /= np.linalg.norm(x[crowd:crowd + 3000], axis=1, keepdims=True)
     if case == "filter_empties_the_floor":
         ones = np.nonzero(rng.random(n) < 0.3)[0]
         ones = ones[ones >= 20000]                  # nothing of the sampled prefix passes
@@ -450,8 +456,8 @@ def test_bf16_append_scan_equals_the_list_scan(orc, case):
     for i in range(nq):
         assert np.array_equal(v0[i, : c0[i]], v1[i, : c1[i]]), (case, i)
         assert np.array_equal(bits(s0[i, : c0[i]]), bits(s1[i, : c1[i]]))
-    if case == "crowded_stripe":
-        assert set(v1[0, : c1[0]].tolist()) <= set(range(60000, 63000))
+    if crowd is not None:
+        assert set(v1[0, : c1[0]].tolist()) <= set(range(crowd, crowd + 3000))
 
 
 def test_bf16_fallback_filter_and_min_score(orc):
