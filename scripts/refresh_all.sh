@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: every bench.py workload once on the GPU box, each under rocprofv3 --kernel-trace --stats, summaries under gpurun_out/final/.
-# Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | bf16 | bm25stats | bm25 | others | all
+# Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | bf16 | hybrid | bm25stats | bm25 | others | all
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 PART=${1:-all}
@@ -22,6 +22,9 @@ if [ "$PART" = headline ] || [ "$PART" = all ]; then
 fi
 if [ "$PART" = bf16 ]; then   # BASELINE configs[4] on one GPU's share: per-kernel durations of the bf16 fallback
   prof bf16_12m5x1024 --workload bf16 --n-vectors 12500000 --dim 1024 --steps 5 --warmup 1 --cpu-queries 0 --recall-queries 16
+fi
+if [ "$PART" = hybrid ]; then   # BASELINE configs[2]: the BM25 launches beside the walks (in-contention trace)
+  prof hybrid --workload hybrid --steps 10 --warmup 2 --cpu-queries 0
 fi
 if [ "$PART" = bm25stats ]; then   # only the per-kernel durations of the BM25 launches, one batch at a time
   NIDX_BENCH_BM25_DEPTH=1 prof bm25_one_at_a_time --workload bm25 --cpu-queries 0 --steps 200
