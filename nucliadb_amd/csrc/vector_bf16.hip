@@ -12,6 +12,10 @@
 // row fell outside the approximate top-K' (bf16 rounding: relative 2^-9 per operand) — recall is
 // measured, not assumed (tests/test_vector_gpu.py).  This method is explicit
 // (NIDX_METHOD_BRUTE_FORCE_BF16), never chosen by the cost model.
+// Stage 1 has two forms with the same candidates: bf16_scan_kernel keeps sorted lists in LDS (any input, no floor needed);
+// bf16_append_kernel (round 4, below) needs a floor per query, keeps no lists and runs the wider pipeline — the host
+// (vector_index.cpp) seeds floors with the former on a prefix, tightens them with the latter on a sample, and falls back to the
+// former per query block.
 #include "device_common.h"
 #include <algorithm>
 #include <type_traits>
