@@ -44,7 +44,12 @@ extern "C" {
 
 /* Copies the calling thread's last error message (NUL terminated) and returns its length. */
 int32_t nidx_gpu_last_error(char *buf, size_t len);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any change of a signature OR of a struct the caller fills (a trailing field counts: the
+ * library reads it).  A binding compares nidx_gpu_abi_version() with the NIDX_GPU_ABI_VERSION it was compiled against when it loads
+ * the library and refuses a mismatch (nucliadb_amd/_lib.py does; INTEGRATION.md shows the Rust shim's check).
+ * 5: nidx_gpu_bm25_search_options_t.phrase_slops, nested-query leaves of any kind (round 4); up to 8 BM25 tickets, several
+ *    submitting threads, nidx_gpu_vector_open takes D > 3072 (round 5). */
+#define NIDX_GPU_ABI_VERSION 5
 int32_t nidx_gpu_abi_version(void);
 int32_t nidx_gpu_device_count(int32_t *count_out);
 /* Selects the HIP device used by handles opened afterwards on this thread (one process per GPU). */
@@ -128,8 +133,10 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
 
 /* Launch-shape knobs of the HNSW kernels (no effect on results): "waves_per_query" 1..4,
  * "eval_rows" 2..4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15, and the request coalescer's
- * "coalesce_window_us" / "coalesce_max_batch" / "coalesce_in_flight" and the serving pipeline's "pipeline_depth".  The kernel knobs are also read at
- * open from the environment as NIDX_GPU_<NAME>.
+ * "coalesce_window_us" / "coalesce_max_batch" / "coalesce_in_flight", the serving pipeline's "pipeline_depth" and "stage_threads" (0..16,
+ * default 3, process-wide; NIDX_GPU_STAGE_THREADS: helper threads that share the copy of a batch's host query rows into pinned staging
+ * with the submitting thread — 3 MiB per 1 024 x 768 batch, which one thread alone copies no faster than the device answers).  The
+ * kernel knobs are also read at open from the environment as NIDX_GPU_<NAME>.
  * One knob DOES change results: "ef_search" (0 = the reference's constant EF_SEARCH = 30, hnsw/params.rs:46; up to 512): the
  * layer-0 search keeps max(k, ef_search) candidates.  The reference reaches its recall at 10 M vectors by searching 50 segments
  * of <= 200 k records each at ef = 30 (searcher.rs:270-287); a flat graph over the same vectors matches that recall at a larger
@@ -518,6 +525,15 @@ typedef struct {
 
 typedef struct nidx_gpu_bm25_index nidx_gpu_bm25_index_t;
 
+/* Opens the segments of one index (open_index_with_deletions, nidx_tantivy/src/index_reader.rs:39-74).  tantivy searches them one
+ * after the other under one searcher.search with searcher-wide Bm25Weight statistics and merges by (score, DocAddress)
+ * (nidx_text/src/reader.rs:433-435, nidx_paragraph/src/reader.rs:244-348); the log-merge policy leaves several
+ * (nidx/src/settings.rs:246-253).  Here an index of several segments is resident as ONE posting layout, term-major across the
+ * segments over doc + base[segment] (base = running sum of n_docs): every search is one launch sequence whatever the number of
+ * segments, and the merge across segments is the scorer's own slice merge on the device.  DocAddresses in and out (hits, search-after
+ * cursors, prefilter results) and the `segment` arguments of nidx_gpu_bm25_set_fast_field / _apply_deletions keep naming the opened
+ * segments.  The segments together hold at most 2^32 - 1 documents.  NIDX_GPU_BM25_SEGMENT_LOOP=1 in the environment keeps one resident
+ * segment per opened segment and searches them in a host loop (round 4's path; the tests compare the two). */
 int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments,
                            nidx_gpu_bm25_index_t **index_out);
 void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index);
@@ -629,10 +645,13 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
  * nidx_paragraph/src/lib.rs:117-169, one call per request from src/searcher/shard_search.rs:176-248, for a caller that has batches):
  * submit prepares the batch (clause weights, work list, staging), queues the launches and ONE device-to-host transfer of the result
  * block on a stream of its own and returns; wait blocks until that block has landed and fills the caller's arrays exactly as
- * nidx_gpu_bm25_search_ex would have.  With two tickets outstanding the host side of batch i + 1 overlaps the kernels of batch i.  At most 4
- * tickets may be outstanding (NIDX_ERR_BUSY otherwise); a ticket is waited for once, from any thread.  A request the pipeline does not
- * cover — several segments, term sets, phrases, nested queries, facets, order by a fast field — runs to completion inside submit
- * (options.out_facet_counts / out_order_value are filled there) and wait only hands its hits over.  clauses / clause_offsets / options
+ * nidx_gpu_bm25_search_ex would have.  With two tickets outstanding the host side of batch i + 1 overlaps the kernels of batch i.  At most 8
+ * tickets may be outstanding (NIDX_ERR_BUSY otherwise); a ticket is waited for once, from any thread.  Several threads may submit at the
+ * same time: every ticket's batch is planned and launched on a context of its own (the planning of a batch costs the submitting thread
+ * more than its kernels cost the device).  An index of several segments goes through the pipeline like one of a single segment (it is
+ * resident as one term-major posting layout, see nidx_gpu_bm25_open).  A request the pipeline does not cover — term sets, phrases,
+ * nested queries, facets, order by a fast field — runs to completion inside submit (options.out_facet_counts / out_order_value are
+ * filled there) and wait only hands its hits over.  clauses / clause_offsets / options
  * need not outlive submit. */
 int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                     uint32_t n_queries, const nidx_gpu_bm25_search_options_t *options, uint64_t *ticket_out);

@@ -193,6 +193,8 @@ class Bm25SearchAfterC(C.Structure):
     _fields_ = [("has_after", C.c_int32), ("score", C.c_float), ("tie_break", C.c_int32), ("docaddr", C.c_uint64)]
 
 
+ABI_VERSION = 5   # include/nidx_gpu.h: NIDX_GPU_ABI_VERSION
+
 # name -> (restype, argtypes); the list every `-m "not gpu"` export test walks.
 SIGNATURES = {
     "nidx_gpu_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
@@ -347,6 +349,10 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        got = handle.nidx_gpu_abi_version()
+        if got != ABI_VERSION:   # a stale .so against newer struct layouts would read past the end of the caller's structs
+            raise ImportError(f"{LIB_PATH} speaks ABI version {got}, these bindings were written against {ABI_VERSION} "
+                              "(include/nidx_gpu.h: NIDX_GPU_ABI_VERSION): rebuild it with __graft_entry__.build()")
         _lib = handle
     return _lib
 

@@ -451,6 +451,42 @@ hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, co
     return hipGetLastError();
 }
 
+// ---- several tantivy segments as ONE resident posting layout -------------------------------------------------------------
+// An index of S segments (the log-merge policy leaves several, nidx/src/settings.rs:246-253) is searched by tantivy segment by
+// segment under one searcher.search (nidx_text/src/reader.rs:433-435).  Bm25Weight's statistics are searcher-wide, so a posting's
+// score does not depend on the segment it lives in, and TopDocs breaks score ties by DocAddress = (segment_ord, doc) — which is the
+// order of doc + base[segment] when base is the running sum of the segments' max_doc.  The resident layout is therefore term-major
+// ACROSS the segments: term t's list = its list in segment 0, then in segment 1 (+ base[1]), ...; every kernel of the scorer then
+// walks a multi-segment index exactly like one segment, in one launch, and the merge across segments is the slice merge.  This
+// kernel moves segment s's postings to their place: posting j of the segment lies in the list of term t = the last t with
+// seg_off[t] <= j and goes to dst_start[t] + (j - seg_off[t]).
+__global__ __launch_bounds__(256) void bm25_concat_postings_kernel(const unsigned long long *__restrict__ seg_off, uint32_t n_terms,
+                                                                   const unsigned long long *__restrict__ dst_start, const uint32_t *__restrict__ src_doc,
+                                                                   const uint32_t *__restrict__ src_tf, unsigned long long n_post, uint32_t doc_base,
+                                                                   uint32_t *__restrict__ dst_doc, uint32_t *__restrict__ dst_tf) {
+    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_post; j += (unsigned long long)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n_terms;   // the last t in [0, n_terms) with seg_off[t] <= j (seg_off[0] == 0)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (seg_off[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        const unsigned long long at = dst_start[lo] + (j - seg_off[lo]);
+        dst_doc[at] = src_doc[j] + doc_base;
+        dst_tf[at] = src_tf[j];
+    }
+}
+
+hipError_t launch_bm25_concat_postings(const unsigned long long *seg_off, uint32_t n_terms, const unsigned long long *dst_start, const uint32_t *src_doc,
+                                       const uint32_t *src_tf, unsigned long long n_post, uint32_t doc_base, uint32_t *dst_doc, uint32_t *dst_tf,
+                                       hipStream_t s) {
+    if (n_post == 0 || n_terms == 0) return hipSuccess;
+    const unsigned long long blocks = (n_post + 255ull) / 256ull;
+    hipLaunchKernelGGL(bm25_concat_postings_kernel, dim3((uint32_t)(blocks < 65536ull ? blocks : 65536ull)), dim3(256), 0, s, seg_off, n_terms, dst_start,
+                       src_doc, src_tf, n_post, doc_base, dst_doc, dst_tf);
+    return hipGetLastError();
+}
+
 // ---- facet counts -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void facet_count_kernel(const unsigned long long *term_offsets, const uint32_t *doc_ids,
                                                           const uint32_t *pair_term, const int *pair_slot, const uint32_t *match_bits,

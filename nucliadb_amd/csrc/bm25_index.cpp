@@ -14,6 +14,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 
 #include "device_common.h"
 #include "host_common.h"
@@ -64,24 +65,41 @@ struct Bm25Segment {
     }
 };
 
-// One batch in flight of nidx_gpu_bm25_search_submit / _wait: its own stream, events and staging — the buffers of the synchronous
-// path's set are swapped with a slot's while its batch is prepared and launched, so the search code below has one form.
-struct Bm25Slot {
-    bool busy = false, launched = false;
-    uint64_t ticket = 0;
+// Everything one search call writes: its stream and events, device scratch, pinned staging and the host planning vectors (kept for
+// their capacity).  The index has one for the blocking entries; every pipeline slot of nidx_gpu_bm25_search_submit / _wait has its own,
+// so several submitting threads prepare and launch their batches side by side (the segments they read are immutable while they do).
+struct Bm25Ctx {
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf s_after, s_count, s_total, s_postings, s_key, s_in_q, s_in_w, s_outpack;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the scoring kernels on `stream`
+    std::vector<uint32_t> w_item_first, w_item_list;
+    std::vector<Bm25Work> w_work;
+    std::vector<uint8_t> w_q_union;
+    std::vector<uint64_t> w_postings, w_clause_len;
+    std::vector<Bm25ClauseDev> w_dev_clauses;
+    std::vector<Bm25UClause> w_ucl;   // (entries of queries that are not union queries keep whatever they held: never read)
+    std::vector<Bm25AfterDev> w_after;
+    DevBuf s_after, s_count, s_total, s_postings, s_key;
+    DevBuf s_phrase_tf, s_aux_tfs, s_slop_left, s_sub_bits, s_sub_union;
+    DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
+        s_facet_counts;
+    // packed staging: [clauses | clause offsets], [item_first | work list] in; [doc | score | count | total | postings] out
+    DevBuf s_in_q, s_in_w, s_outpack;
     PinBuf h_in_q, h_in_w, h_outpack;
-    // layout of h_outpack for the collect step
-    uint32_t nq = 0, k = 0, kk = 0;
-    size_t o_doc = 0, o_score = 0, o_count = 0, o_total = 0, o_post = 0;
-    // a request the pipeline does not cover (several segments, term sets, phrases, nested queries, facets, order by a field) runs
-    // synchronously inside submit; its results wait here
-    std::vector<uint64_t> r_docaddr, r_total, r_postings;
-    std::vector<float> r_score;
-    std::vector<uint32_t> r_count;
-    ~Bm25Slot() {
+    float kernel_ms = 0.f;   // scoring kernels of the last call through this context
+    Bm25Ctx() = default;
+    Bm25Ctx(const Bm25Ctx &) = delete;
+    hipError_t init() {
+        // BM25 launches are short (~0.07 ms) and their callers wait for them; when they share the device with HNSW batches in flight
+        // (the hybrid request: serving.cpp keeps several on their own streams) they should not queue behind those: highest priority
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipEventCreate(&ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ev1);
+        return e;
+    }
+    // also the clean-up of an open that failed half way
+    ~Bm25Ctx() {
         if (stream) {
             (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
@@ -91,55 +109,62 @@ struct Bm25Slot {
     }
 };
 
+// One batch in flight of nidx_gpu_bm25_search_submit / _wait.
+struct Bm25Slot {
+    bool busy = false, preparing = false, launched = false;
+    uint64_t ticket = 0;
+    Bm25Ctx cx;
+    // layout of cx.h_outpack for the collect step
+    uint32_t nq = 0, k = 0, kk = 0;
+    size_t o_doc = 0, o_score = 0, o_count = 0, o_total = 0, o_post = 0;
+    // a request the pipeline does not cover (term sets, phrases, nested queries, facets, order by a field) runs synchronously inside
+    // submit; its results wait here
+    std::vector<uint64_t> r_docaddr, r_total, r_postings;
+    std::vector<float> r_score;
+    std::vector<uint32_t> r_count;
+};
+
+// What is kept of every segment the caller opened when the resident layout is the term-major concatenation (Bm25Index::seg_base)
+struct Bm25RealSegment {
+    uint32_t n_docs = 0;
+    std::vector<uint64_t> term_offsets_host;
+    std::vector<int64_t> fast_host[2];
+    bool has_fast[2] = {false, false};
+};
+
 struct Bm25Index {
     int device = 0;
     int n_cus = 256;   // compute units of the device (the work-item budget of one launch round follows it)
-    hipStream_t stream = nullptr;
-    std::mutex mu;
+    // mu: the blocking entries (they share `main`) and the mutators; rw: searches hold it shared, mutators (deletions, fast fields)
+    // exclusively; slots_mu: the slot table and tickets; ms_mu: last_kernel_ms
+    std::mutex mu, slots_mu, ms_mu;
+    std::shared_mutex rw;
+    // The resident segments.  One per opened segment — or, for an index of several segments, ONE: the term-major concatenation over
+    // doc + seg_base[segment] (bm25_aux.hip: bm25_concat_postings_kernel), which every kernel walks like a single segment.
     std::vector<Bm25Segment> segs;
+    std::vector<Bm25RealSegment> real;     // non-empty <=> concatenated
+    std::vector<uint32_t> seg_base;        // [n_real + 1] running sum of the real segments' n_docs
+    uint32_t n_segments = 0;               // segments the caller opened
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
-    std::vector<float> idf_of_term;   // Bm25Weight's idf per term over all segments, filled on first use (NaN = not yet)
-    // host scratch of a search call (kept for their capacity)
-    std::vector<uint32_t> w_item_first, w_item_list;
-    std::vector<Bm25Work> w_work;
-    std::vector<uint8_t> w_q_union;
-    std::vector<uint64_t> w_postings, w_clause_len;
-    std::vector<Bm25ClauseDev> w_dev_clauses;
-    std::vector<Bm25UClause> w_ucl;   // (entries of queries that are not union queries keep whatever they held: never read)
+    std::vector<float> idf_of_term;   // Bm25Weight's idf per term over all segments (filled at open)
+    Bm25Ctx main;
     DevBuf tf_cache;
-    DevBuf s_after, s_count, s_total, s_postings, s_key;
-    // term dictionary (fuzzy expansion) and the scratch of the collectors
+    // term dictionary (fuzzy expansion) and the scratch of the collectors (under mu, on main.stream)
     DevBuf dict_bytes, dict_offsets, s_fuzzy_q, s_fuzzy_flags;
     bool has_dict = false;
-    DevBuf s_phrase_tf, s_aux_tfs, s_slop_left, s_sub_bits, s_sub_union;
-    DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
-        s_facet_counts;
     DevBuf s_pf_stack, s_pf_lists, s_pf_result, s_pf_blocks, s_pf_total, s_pf_out;  // prefilter
-    // packed staging: [clauses | clause offsets], [item_first | work list] in; [doc | score | count | total | postings] out
-    DevBuf s_in_q, s_in_w, s_outpack;
-    PinBuf h_in_q, h_in_w, h_outpack;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scoring kernel on `stream`
     float last_kernel_ms = 0.f;
     std::vector<std::unique_ptr<Bm25Slot>> slots;   // nidx_gpu_bm25_search_submit / _wait
     uint64_t next_ticket = 1;
-    Bm25Slot *async_slot = nullptr;                 // set while a submit prepares its batch: launch, do not wait
-    void swap_slot(Bm25Slot &sl) {
-        std::swap(stream, sl.stream), std::swap(ev0, sl.ev0), std::swap(ev1, sl.ev1);
-        std::swap(s_after, sl.s_after), std::swap(s_count, sl.s_count), std::swap(s_total, sl.s_total), std::swap(s_postings, sl.s_postings);
-        std::swap(s_key, sl.s_key), std::swap(s_in_q, sl.s_in_q), std::swap(s_in_w, sl.s_in_w), std::swap(s_outpack, sl.s_outpack);
-        std::swap(h_in_q, sl.h_in_q), std::swap(h_in_w, sl.h_in_w), std::swap(h_outpack, sl.h_outpack);
-    }
     Bm25Index() = default;
     Bm25Index(const Bm25Index &) = delete;
-    // also the clean-up of an open that failed half way
-    ~Bm25Index() {
-        if (stream) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipStreamDestroy(stream);
-        }
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+    bool concatenated() const { return !real.empty(); }
+    // DocAddress of resident (segment, doc)
+    uint64_t docaddr(size_t resident_segment, uint32_t d) const {
+        if (real.empty()) return ((uint64_t)resident_segment << 32) | d;
+        const size_t s = (size_t)(std::upper_bound(seg_base.begin() + 1, seg_base.end(), d) - (seg_base.begin() + 1));
+        return ((uint64_t)s << 32) | (uint64_t)(d - seg_base[s]);
     }
 };
 
@@ -153,6 +178,196 @@ float nidx_gpu_bm25_idf(uint64_t doc_freq, uint64_t doc_count) { return bm25_idf
 uint32_t nidx_gpu_fieldnorm_from_id(uint8_t id) { return fieldnorm_from_id(id); }
 uint8_t nidx_gpu_fieldnorm_to_id(uint32_t fieldnorm) { return fieldnorm_to_id(fieldnorm); }
 
+// the host-side checks of one opened segment (the kernels index the fieldnorm table and the alive bitset with doc ids unchecked)
+static int32_t bm25_check_segment(const nidx_gpu_bm25_segment_t &in, uint32_t s) {
+    if (!in.term_offsets || (in.n_docs && !in.fieldnorm_ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL arrays", s);
+    const uint64_t n_post = in.term_offsets[in.n_terms];
+    if (n_post && (!in.doc_ids || !in.tfs)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL postings", s);
+    if (in.term_offsets[0] != 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets[0] != 0", s);
+    for (uint32_t t = 0; t < in.n_terms; t++)
+        if (in.term_offsets[t + 1] < in.term_offsets[t]) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets decrease at term %u", s, t);
+    uint32_t max_doc = 0;
+    for (uint64_t i = 0; i < n_post; i++) max_doc = std::max(max_doc, in.doc_ids[i]);
+    if (n_post && max_doc >= in.n_docs) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: posting doc id %u >= n_docs %u", s, max_doc, in.n_docs);
+    if (in.pos_offsets && n_post && in.pos_offsets[n_post] && !in.positions) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: pos_offsets without positions", s);
+    return NIDX_OK;
+}
+
+// resident posting word = tf | fieldnorm id << 24: the scorer reads the fieldnorm with the posting instead of one random cache line
+// per posting (bm25_aux.hip)
+static int32_t bm25_pack_words(Bm25Index *idx, Bm25Segment &seg, uint64_t n_post, uint32_t s) {
+    if (!n_post) return NIDX_OK;
+    hipStream_t st = idx->main.stream;
+    DevBuf flag;
+    NIDX_HIP(flag.alloc(4));
+    NIDX_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    NIDX_HIP(launch_bm25_pack_fieldnorm(seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(), n_post, seg.n_docs,
+                                        flag.as<uint32_t>(), st));
+    uint32_t f = 0;
+    NIDX_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, st));
+    NIDX_HIP(hipStreamSynchronize(st));
+    if (f & 1u) return fail(NIDX_ERR_UNSUPPORTED, "segment %u: a term frequency >= 2^24 does not fit the resident posting word", s);
+    if (f & 2u) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: a posting's doc id is >= n_docs", s);
+    return NIDX_OK;
+}
+
+// one opened segment -> one resident segment
+static int32_t bm25_upload_segment(Bm25Index *idx, const nidx_gpu_bm25_segment_t &in, Bm25Segment &seg, uint32_t s) {
+    seg.n_docs = in.n_docs;
+    seg.n_terms = in.n_terms;
+    seg.term_offsets_host.assign(in.term_offsets, in.term_offsets + in.n_terms + 1);
+    const uint64_t n_post = seg.term_offsets_host[in.n_terms];
+    NIDX_HIP(seg.term_offsets.alloc((size_t)(in.n_terms + 1) * 8));
+    NIDX_HIP(hipMemcpy(seg.term_offsets.p, in.term_offsets, (size_t)(in.n_terms + 1) * 8, hipMemcpyHostToDevice));
+    NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
+    NIDX_HIP(seg.tfs.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
+    if (n_post) {
+        NIDX_HIP(hipMemcpy(seg.doc_ids.p, in.doc_ids, n_post * 4, hipMemcpyHostToDevice));
+        NIDX_HIP(hipMemcpy(seg.tfs.p, in.tfs, n_post * 4, hipMemcpyHostToDevice));
+    }
+    NIDX_HIP(seg.fieldnorm_ids.alloc(std::max<size_t>(in.n_docs, 1)));
+    if (in.n_docs) NIDX_HIP(hipMemcpy(seg.fieldnorm_ids.p, in.fieldnorm_ids, in.n_docs, hipMemcpyHostToDevice));
+    if (int32_t rc = bm25_pack_words(idx, seg, n_post, s)) return rc;
+    seg.all_alive = in.alive_bitset == nullptr;
+    if (in.alive_bitset) {
+        size_t words = ((size_t)in.n_docs + 63) / 64;
+        NIDX_HIP(seg.alive.alloc(std::max<size_t>(words, 1) * 8));
+        if (words) NIDX_HIP(hipMemcpy(seg.alive.p, in.alive_bitset, words * 8, hipMemcpyHostToDevice));
+    }
+    if (in.pos_offsets && n_post) {
+        const uint64_t n_pos = in.pos_offsets[n_post];
+        NIDX_HIP(seg.pos_offsets.alloc((size_t)(n_post + 1) * 8));
+        NIDX_HIP(hipMemcpy(seg.pos_offsets.p, in.pos_offsets, (size_t)(n_post + 1) * 8, hipMemcpyHostToDevice));
+        NIDX_HIP(seg.positions.alloc(std::max<uint64_t>(n_pos, 1) * 4));
+        if (n_pos) NIDX_HIP(hipMemcpy(seg.positions.p, in.positions, n_pos * 4, hipMemcpyHostToDevice));
+    }
+    return NIDX_OK;
+}
+
+// S opened segments -> ONE resident segment, term-major across the segments over doc + seg_base[segment] (see
+// bm25_concat_postings_kernel).  The segments' postings pass through device scratch one segment at a time.
+static int32_t bm25_upload_concatenated(Bm25Index *idx, const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments) {
+    const uint32_t T = idx->n_terms;
+    hipStream_t st = idx->main.stream;
+    idx->real.resize(n_segments);
+    idx->seg_base.assign(n_segments + 1, 0);
+    uint64_t n_docs_all = 0, n_post_all = 0;
+    bool any_dead = false, all_pos = true;
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const nidx_gpu_bm25_segment_t &in = segments[s];
+        idx->real[s].n_docs = in.n_docs;
+        idx->real[s].term_offsets_host.assign(in.term_offsets, in.term_offsets + T + 1);
+        n_docs_all += in.n_docs;
+        if (n_docs_all > 0xffffffffull)
+            return fail(NIDX_ERR_UNSUPPORTED, "the segments of one index hold more than 2^32 - 1 documents together (doc ids are 32-bit on the device)");
+        idx->seg_base[s + 1] = (uint32_t)n_docs_all;
+        n_post_all += in.term_offsets[T];
+        any_dead |= in.alive_bitset != nullptr;
+        if (in.term_offsets[T] && !in.pos_offsets) all_pos = false;   // phrases need the positions of every segment
+    }
+    idx->segs.resize(1);
+    Bm25Segment &v = idx->segs[0];
+    v.n_docs = (uint32_t)n_docs_all;
+    v.n_terms = T;
+    std::vector<uint64_t> &voff = v.term_offsets_host;
+    voff.assign((size_t)T + 1, 0);
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const uint64_t *o = segments[s].term_offsets;
+        for (uint32_t t = 0; t <= T; t++) voff[t] += o[t];
+    }
+    NIDX_HIP(v.term_offsets.alloc((size_t)(T + 1) * 8));
+    NIDX_HIP(hipMemcpy(v.term_offsets.p, voff.data(), (size_t)(T + 1) * 8, hipMemcpyHostToDevice));
+    NIDX_HIP(v.doc_ids.alloc(std::max<size_t>(n_post_all, 1) * 4 + BM25_LIST_PAD_BYTES));
+    NIDX_HIP(v.tfs.alloc(std::max<size_t>(n_post_all, 1) * 4 + BM25_LIST_PAD_BYTES));
+    NIDX_HIP(v.fieldnorm_ids.alloc(std::max<size_t>(v.n_docs, 1)));
+    // where segment s's part of term t's list begins: the list's start + the lengths of the earlier segments' parts
+    std::vector<unsigned long long> cursor((size_t)std::max<uint32_t>(T, 1));
+    for (uint32_t t = 0; t < T; t++) cursor[t] = voff[t];
+    std::vector<unsigned long long> dst_start((size_t)std::max<uint32_t>(T, 1));
+    DevBuf t_off, t_dst, t_doc, t_tf;
+    NIDX_HIP(t_off.alloc((size_t)(T + 1) * 8));
+    NIDX_HIP(t_dst.alloc((size_t)std::max<uint32_t>(T, 1) * 8));
+    const bool with_pos = all_pos && n_post_all > 0;
+    std::vector<uint64_t> vpos_off;
+    std::vector<uint32_t> vpos;
+    if (with_pos) {
+        uint64_t n_pos_all = 0;
+        for (uint32_t s = 0; s < n_segments; s++)
+            if (segments[s].term_offsets[T]) n_pos_all += segments[s].pos_offsets[segments[s].term_offsets[T]];
+        vpos_off.assign((size_t)n_post_all + 1, 0);
+        vpos.resize((size_t)n_pos_all);
+    }
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const nidx_gpu_bm25_segment_t &in = segments[s];
+        const uint64_t *o = in.term_offsets;
+        const uint64_t n_post = o[T];
+        for (uint32_t t = 0; t < T; t++) {
+            dst_start[t] = cursor[t];
+            cursor[t] += o[t + 1] - o[t];
+        }
+        if (in.n_docs) NIDX_HIP(hipMemcpy(v.fieldnorm_ids.as<uint8_t>() + idx->seg_base[s], in.fieldnorm_ids, in.n_docs, hipMemcpyHostToDevice));
+        if (!n_post) continue;
+        NIDX_HIP(t_doc.reserve(n_post * 4));
+        NIDX_HIP(t_tf.reserve(n_post * 4));
+        NIDX_HIP(hipMemcpyAsync(t_off.p, o, (size_t)(T + 1) * 8, hipMemcpyHostToDevice, st));
+        NIDX_HIP(hipMemcpyAsync(t_dst.p, dst_start.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
+        NIDX_HIP(hipMemcpyAsync(t_doc.p, in.doc_ids, n_post * 4, hipMemcpyHostToDevice, st));
+        NIDX_HIP(hipMemcpyAsync(t_tf.p, in.tfs, n_post * 4, hipMemcpyHostToDevice, st));
+        NIDX_HIP(launch_bm25_concat_postings(t_off.as<unsigned long long>(), T, t_dst.as<unsigned long long>(), t_doc.as<uint32_t>(), t_tf.as<uint32_t>(),
+                                             n_post, idx->seg_base[s], v.doc_ids.as<uint32_t>(), v.tfs.as<uint32_t>(), st));
+        NIDX_HIP(hipStreamSynchronize(st));   // dst_start and the scratch are rewritten for the next segment
+        if (with_pos) {
+            // positions follow their postings: the positions of one (term, segment) run are contiguous in the source; the lengths are
+            // laid down here and summed below
+            for (uint32_t t = 0; t < T; t++)
+                for (uint64_t j = o[t]; j < o[t + 1]; j++) vpos_off[dst_start[t] + (j - o[t]) + 1] = in.pos_offsets[j + 1] - in.pos_offsets[j];
+        }
+    }
+    if (with_pos) {
+        for (uint64_t i = 0; i < n_post_all; i++) vpos_off[i + 1] += vpos_off[i];
+        for (uint32_t t = 0; t < T; t++) cursor[t] = voff[t];
+        for (uint32_t s = 0; s < n_segments; s++) {
+            const nidx_gpu_bm25_segment_t &in = segments[s];
+            const uint64_t *o = in.term_offsets;
+            for (uint32_t t = 0; t < T; t++) {
+                const uint64_t len = o[t + 1] - o[t];
+                if (len) {
+                    const uint64_t p0 = in.pos_offsets[o[t]], p1 = in.pos_offsets[o[t + 1]];
+                    if (p1 > p0) memcpy(vpos.data() + vpos_off[cursor[t]], in.positions + p0, (size_t)(p1 - p0) * 4);
+                }
+                cursor[t] += len;
+            }
+        }
+        NIDX_HIP(v.pos_offsets.alloc((size_t)(n_post_all + 1) * 8));
+        NIDX_HIP(hipMemcpy(v.pos_offsets.p, vpos_off.data(), (size_t)(n_post_all + 1) * 8, hipMemcpyHostToDevice));
+        NIDX_HIP(v.positions.alloc(std::max<uint64_t>(vpos.size(), 1) * 4));
+        if (!vpos.empty()) NIDX_HIP(hipMemcpy(v.positions.p, vpos.data(), vpos.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (int32_t rc = bm25_pack_words(idx, v, n_post_all, 0)) return rc;
+    v.all_alive = !any_dead;
+    if (any_dead) {
+        // the segments' alive bitsets, each shifted to its doc base
+        const size_t words = ((size_t)v.n_docs + 63) / 64;
+        std::vector<uint64_t> bits(std::max<size_t>(words, 1) + 1, 0);   // + 1: the spill word of the last shift
+        for (uint32_t s = 0; s < n_segments; s++) {
+            const nidx_gpu_bm25_segment_t &in = segments[s];
+            const uint32_t n = in.n_docs;
+            for (uint32_t i = 0; i < (n + 63) / 64; i++) {
+                uint64_t w = in.alive_bitset ? in.alive_bitset[i] : ~0ull;
+                const uint32_t left = n - i * 64;
+                if (left < 64) w &= (1ull << left) - 1ull;
+                const uint64_t bit = (uint64_t)idx->seg_base[s] + (uint64_t)i * 64;
+                const uint32_t sh = (uint32_t)(bit & 63);
+                bits[bit >> 6] |= w << sh;
+                if (sh) bits[(bit >> 6) + 1] |= w >> (64 - sh);
+            }
+        }
+        NIDX_HIP(v.alive.alloc(std::max<size_t>(words, 1) * 8));
+        if (words) NIDX_HIP(hipMemcpy(v.alive.p, bits.data(), words * 8, hipMemcpyHostToDevice));
+    }
+    return NIDX_OK;
+}
+
 int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_segments, nidx_gpu_bm25_index_t **index_out) try {
     if (!index_out || (n_segments && !segments)) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *index_out = nullptr;
@@ -162,77 +377,33 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) == hipSuccess && cus > 0) idx->n_cus = cus;
     }
-    {
-        // BM25 launches are short (~0.15 ms) and their callers wait for them; when they share the device with HNSW batches in flight
-        // (the hybrid request: serving.cpp keeps several on their own streams) they should not queue behind those: highest priority
-        int lo = 0, hi = 0;
-        NIDX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        NIDX_HIP(hipStreamCreateWithPriority(&idx->stream, hipStreamNonBlocking, hi));
-    }
-    NIDX_HIP(hipEventCreate(&idx->ev0));
-    NIDX_HIP(hipEventCreate(&idx->ev1));
-    idx->segs.resize(n_segments);
+    NIDX_HIP(idx->main.init());
+    idx->n_segments = n_segments;
     for (uint32_t s = 0; s < n_segments; s++) {
         const nidx_gpu_bm25_segment_t &in = segments[s];
-        Bm25Segment &seg = idx->segs[s];
-        if (!in.term_offsets || (in.n_docs && !in.fieldnorm_ids)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL arrays", s);
         if (s > 0 && in.n_terms != idx->n_terms)
             return fail(NIDX_ERR_INVALID_ARGUMENT, "every segment must use the same term-id space (n_terms differs)");
         idx->n_terms = in.n_terms;
-        seg.n_docs = in.n_docs;
-        seg.n_terms = in.n_terms;
-        seg.term_offsets_host.assign(in.term_offsets, in.term_offsets + in.n_terms + 1);
-        const uint64_t n_post = seg.term_offsets_host[in.n_terms];
-        if (n_post && (!in.doc_ids || !in.tfs)) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: NULL postings", s);
-        // the kernels index fieldnorm_ids / the alive bitset with these without a bounds check
-        if (seg.term_offsets_host[0] != 0) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets[0] != 0", s);
-        for (uint32_t t = 0; t < in.n_terms; t++)
-            if (seg.term_offsets_host[t + 1] < seg.term_offsets_host[t])
-                return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: term_offsets decrease at term %u", s, t);
-        uint32_t max_doc = 0;
-        for (uint64_t i = 0; i < n_post; i++) max_doc = std::max(max_doc, in.doc_ids[i]);
-        if (n_post && max_doc >= in.n_docs)
-            return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: posting doc id %u >= n_docs %u", s, max_doc, in.n_docs);
-        NIDX_HIP(seg.term_offsets.alloc((size_t)(in.n_terms + 1) * 8));
-        NIDX_HIP(hipMemcpy(seg.term_offsets.p, in.term_offsets, (size_t)(in.n_terms + 1) * 8, hipMemcpyHostToDevice));
-        NIDX_HIP(seg.doc_ids.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
-        NIDX_HIP(seg.tfs.alloc(std::max<size_t>(n_post, 1) * 4 + BM25_LIST_PAD_BYTES));
-        if (n_post) {
-            NIDX_HIP(hipMemcpy(seg.doc_ids.p, in.doc_ids, n_post * 4, hipMemcpyHostToDevice));
-            NIDX_HIP(hipMemcpy(seg.tfs.p, in.tfs, n_post * 4, hipMemcpyHostToDevice));
-        }
-        NIDX_HIP(seg.fieldnorm_ids.alloc(std::max<size_t>(in.n_docs, 1)));
-        if (in.n_docs) NIDX_HIP(hipMemcpy(seg.fieldnorm_ids.p, in.fieldnorm_ids, in.n_docs, hipMemcpyHostToDevice));
-        if (n_post) {
-            // resident posting word = tf | fieldnorm id << 24: the scorer reads the fieldnorm with the posting instead of one random
-            // cache line per posting (bm25_aux.hip)
-            DevBuf flag;
-            NIDX_HIP(flag.alloc(4));
-            NIDX_HIP(hipMemsetAsync(flag.p, 0, 4, idx->stream));
-            NIDX_HIP(launch_bm25_pack_fieldnorm(seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(), n_post, in.n_docs,
-                                                flag.as<uint32_t>(), idx->stream));
-            uint32_t f = 0;
-            NIDX_HIP(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, idx->stream));
-            NIDX_HIP(hipStreamSynchronize(idx->stream));
-            if (f & 1u) return fail(NIDX_ERR_UNSUPPORTED, "segment %u: a term frequency >= 2^24 does not fit the resident posting word", s);
-            if (f & 2u) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: a posting's doc id is >= n_docs", s);
-        }
-        seg.all_alive = in.alive_bitset == nullptr;
-        if (in.alive_bitset) {
-            size_t words = ((size_t)in.n_docs + 63) / 64;
-            NIDX_HIP(seg.alive.alloc(std::max<size_t>(words, 1) * 8));
-            if (words) NIDX_HIP(hipMemcpy(seg.alive.p, in.alive_bitset, words * 8, hipMemcpyHostToDevice));
-        }
-        if (in.pos_offsets && n_post) {
-            const uint64_t n_pos = in.pos_offsets[n_post];
-            if (n_pos && !in.positions) return fail(NIDX_ERR_INVALID_ARGUMENT, "segment %u: pos_offsets without positions", s);
-            NIDX_HIP(seg.pos_offsets.alloc((size_t)(n_post + 1) * 8));
-            NIDX_HIP(hipMemcpy(seg.pos_offsets.p, in.pos_offsets, (size_t)(n_post + 1) * 8, hipMemcpyHostToDevice));
-            NIDX_HIP(seg.positions.alloc(std::max<uint64_t>(n_pos, 1) * 4));
-            if (n_pos) NIDX_HIP(hipMemcpy(seg.positions.p, in.positions, n_pos * 4, hipMemcpyHostToDevice));
-        }
+        if (int32_t rc = bm25_check_segment(in, s)) return rc;
         idx->total_docs += in.n_docs;
         idx->total_tokens += in.total_num_tokens;
+    }
+    // NIDX_GPU_BM25_SEGMENT_LOOP=1 keeps one resident segment per opened segment and the search a loop over them (launches, a
+    // transfer and a host merge per segment): the path the one-launch layout is tested against
+    const char *loop_env = getenv("NIDX_GPU_BM25_SEGMENT_LOOP");
+    if (n_segments > 1 && !(loop_env && atoi(loop_env) != 0)) {
+        if (int32_t rc = bm25_upload_concatenated(idx.get(), segments, n_segments)) return rc;
+    } else {
+        idx->segs.resize(n_segments);
+        for (uint32_t s = 0; s < n_segments; s++)
+            if (int32_t rc = bm25_upload_segment(idx.get(), segments[s], idx->segs[s], s)) return rc;
+    }
+    // Bm25Weight's idf of every term from the searcher-wide statistics
+    idx->idf_of_term.resize(idx->n_terms);
+    for (uint32_t t = 0; t < idx->n_terms; t++) {
+        uint64_t df = 0;
+        for (const Bm25Segment &sg : idx->segs) df += sg.term_offsets_host[t + 1] - sg.term_offsets_host[t];
+        idx->idf_of_term[t] = bm25_idf(df, idx->total_docs);
     }
     float avg = idx->total_docs ? (float)idx->total_tokens / (float)idx->total_docs : 0.0f;
     float cache[256];
@@ -254,8 +425,9 @@ void nidx_gpu_bm25_close(nidx_gpu_bm25_index_t *index) {
 }
 
 int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out) try {
-    const Bm25Index *idx = reinterpret_cast<const Bm25Index *>(index);
+    Bm25Index *idx = const_cast<Bm25Index *>(reinterpret_cast<const Bm25Index *>(index));
     if (!idx || !ms_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->ms_mu);
     *ms_out = idx->last_kernel_ms;
     return NIDX_OK;
 } NIDX_ABI_CATCH
@@ -269,15 +441,10 @@ int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
-int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values) try {
-    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
-    if (!idx || segment >= idx->segs.size() || field > 1 || !values) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad fast field");
-    std::lock_guard<std::mutex> lock(idx->mu);
-    NIDX_HIP(hipSetDevice(idx->device));
-    Bm25Segment &seg = idx->segs[segment];
-    seg.fast_host[field].assign(values, values + seg.n_docs);
-    // dense ranks: equal values <=> equal ranks, order preserved
-    std::vector<int64_t> uniq(seg.fast_host[field]);
+// dense ranks of a fast field (equal values <=> equal ranks, order preserved) to HBM; the kernels order by rank
+static int32_t bm25_upload_fast_field(Bm25Segment &seg, uint32_t field) {
+    const std::vector<int64_t> &values = seg.fast_host[field];
+    std::vector<int64_t> uniq(values);
     std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     std::vector<uint32_t> rank(seg.n_docs);
@@ -287,6 +454,34 @@ int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segm
     if (seg.n_docs) NIDX_HIP(hipMemcpy(seg.order_key[field].p, rank.data(), (size_t)seg.n_docs * 4, hipMemcpyHostToDevice));
     seg.fast_uniq[field] = std::move(uniq);
     return NIDX_OK;
+}
+
+int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segment, uint32_t field, const int64_t *values) try {
+    Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
+    if (!idx || segment >= idx->n_segments || field > 1 || !values) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad fast field");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    std::unique_lock<std::shared_mutex> wlock(idx->rw);
+    NIDX_HIP(hipSetDevice(idx->device));
+    if (!idx->concatenated()) {
+        Bm25Segment &seg = idx->segs[segment];
+        seg.fast_host[field].assign(values, values + seg.n_docs);
+        return bm25_upload_fast_field(seg, field);
+    }
+    // concatenated layout: the ranks are taken over the values of ALL segments (order_by_fast_field compares values across
+    // segments), once every segment has registered the field; until then the field counts as not registered
+    Bm25RealSegment &rs = idx->real[segment];
+    rs.fast_host[field].assign(values, values + rs.n_docs);
+    rs.has_fast[field] = true;
+    Bm25Segment &v = idx->segs[0];
+    for (const Bm25RealSegment &r : idx->real)
+        if (!r.has_fast[field]) {
+            v.order_key[field].release();
+            return NIDX_OK;
+        }
+    v.fast_host[field].clear();
+    v.fast_host[field].reserve(v.n_docs);
+    for (const Bm25RealSegment &r : idx->real) v.fast_host[field].insert(v.fast_host[field].end(), r.fast_host[field].begin(), r.fast_host[field].end());
+    return bm25_upload_fast_field(v, field);
 } NIDX_ABI_CATCH
 
 int32_t nidx_gpu_bm25_set_dictionary(nidx_gpu_bm25_index_t *index, const uint8_t *bytes, const uint64_t *offsets) try {
@@ -328,12 +523,12 @@ int32_t nidx_gpu_bm25_fuzzy_terms(nidx_gpu_bm25_index_t *index, const uint8_t *q
     if (idx->n_terms == 0) return NIDX_OK;
     NIDX_HIP(idx->s_fuzzy_q.reserve(cp.size() * 4));
     NIDX_HIP(idx->s_fuzzy_flags.reserve(idx->n_terms));
-    NIDX_HIP(hipMemcpyAsync(idx->s_fuzzy_q.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice, idx->stream));
+    NIDX_HIP(hipMemcpyAsync(idx->s_fuzzy_q.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice, idx->main.stream));
     NIDX_HIP(launch_fuzzy_match(idx->dict_bytes.as<uint8_t>(), idx->dict_offsets.as<unsigned long long>(), idx->n_terms,
-                                idx->s_fuzzy_q.as<uint32_t>(), (uint32_t)cp.size(), prefix ? 1 : 0, idx->s_fuzzy_flags.as<uint8_t>(), idx->stream));
+                                idx->s_fuzzy_q.as<uint32_t>(), (uint32_t)cp.size(), prefix ? 1 : 0, idx->s_fuzzy_flags.as<uint8_t>(), idx->main.stream));
     std::vector<uint8_t> flags(idx->n_terms);
-    NIDX_HIP(hipMemcpyAsync(flags.data(), idx->s_fuzzy_flags.p, idx->n_terms, hipMemcpyDeviceToHost, idx->stream));
-    NIDX_HIP(hipStreamSynchronize(idx->stream));
+    NIDX_HIP(hipMemcpyAsync(flags.data(), idx->s_fuzzy_flags.p, idx->n_terms, hipMemcpyDeviceToHost, idx->main.stream));
+    NIDX_HIP(hipStreamSynchronize(idx->main.stream));
     uint32_t n = 0;
     for (uint32_t t = 0; t < idx->n_terms; t++)
         if (flags[t]) {
@@ -397,7 +592,7 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
         max_depth = std::max(max_depth, depth);
     }
     if (prog.n_ops && depth != 1) return fail(NIDX_ERR_INVALID_ARGUMENT, "filter program must leave exactly one bitset (leaves %d)", depth);
-    hipStream_t st = idx->stream;
+    hipStream_t st = idx->main.stream;
     if (prog.n_lists) {
         NIDX_HIP(idx->s_pf_lists.reserve((size_t)prog.n_lists * 4));
         NIDX_HIP(hipMemcpyAsync(idx->s_pf_lists.p, prog.lists, (size_t)prog.n_lists * 4, hipMemcpyHostToDevice, st));
@@ -470,12 +665,12 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
                     NIDX_HIP(launch_bitset_fill(slot(depth), words, n_bits, 0, st));
                     if (best) {
                         if (!seg.pos_offsets.p) return fail(NIDX_ERR_INVALID_ARGUMENT, "phrase filter on an index opened without positions");
-                        NIDX_HIP(idx->s_phrase_tf.reserve(best * 4));
+                        NIDX_HIP(idx->main.s_phrase_tf.reserve(best * 4));
                         NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
                                                      seg.pos_offsets.as<unsigned long long>(), seg.positions.as<uint32_t>(), ph, (uint32_t)best,
-                                                     idx->s_phrase_tf.as<uint32_t>(), nullptr, st));
+                                                     idx->main.s_phrase_tf.as<uint32_t>(), nullptr, st));
                         NIDX_HIP(launch_phrase_bits(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), ph, (uint32_t)best,
-                                                    idx->s_phrase_tf.as<uint32_t>(), slot(depth), st));
+                                                    idx->main.s_phrase_tf.as<uint32_t>(), slot(depth), st));
                     }
                     depth++;
                     break;
@@ -505,6 +700,8 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     if (n_copy) {
         NIDX_HIP(hipMemcpyAsync(out_docaddr, idx->s_pf_out.p, n_copy * 8, hipMemcpyDeviceToHost, st));
         NIDX_HIP(hipStreamSynchronize(st));
+        if (idx->concatenated())   // resident doc -> DocAddress of the segment it came from (ascending either way)
+            for (uint64_t i = 0; i < n_copy; i++) out_docaddr[i] = idx->docaddr(0, (uint32_t)out_docaddr[i]);
     }
     *n_matching = matched;
     if (num_docs) *num_docs = live;
@@ -513,9 +710,10 @@ int32_t nidx_gpu_bm25_prefilter(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
 
 }  // extern "C"
 
-// The search itself; the caller holds idx->mu.  With idx->async_slot set and a request the pipeline covers it returns after the
-// last asynchronous call (launches + the device-to-host transfer of the result block are queued on the slot's stream).
-static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
+// The search itself, on the context `cx` (the caller owns it for the duration and holds idx->rw shared).  With `async_slot` set and a
+// request the pipeline covers it returns after the last asynchronous call (launches + the device-to-host transfer of the result block
+// are queued on the slot's stream).
+static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_slot, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                   uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *out_docaddr, float *out_score,
                                   uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
     const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -611,7 +809,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     const uint64_t n_clauses = clause_offsets[nq];
     if (n_clauses && !clauses) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL clauses");
     // Bm25Weight per clause from searcher-wide statistics
-    std::vector<Bm25ClauseDev> &dev_clauses = idx->w_dev_clauses;
+    std::vector<Bm25ClauseDev> &dev_clauses = cx.w_dev_clauses;
     dev_clauses.resize(n_clauses);
     uint32_t max_clauses = 0;
     for (uint32_t q = 0; q < nq; q++) {
@@ -657,14 +855,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         if (cl.term >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "term id %u out of range", cl.term);
         float w = cl.boost;
         if (cl.mode != NIDX_CONST_SCORE) {
-            if (idx->idf_of_term.size() != idx->n_terms) idx->idf_of_term.assign(idx->n_terms, std::numeric_limits<float>::quiet_NaN());
-            float idf = idx->idf_of_term[cl.term];
-            if (idf != idf) {
-                uint64_t df = 0;
-                for (const Bm25Segment &s : idx->segs) df += s.term_offsets_host[cl.term + 1] - s.term_offsets_host[cl.term];
-                idf = idx->idf_of_term[cl.term] = bm25_idf(df, idx->total_docs);
-            }
-            w = idf * (1.0f + kK1) * cl.boost;
+            w = idx->idf_of_term[cl.term] * (1.0f + kK1) * cl.boost;
         }
         dev_clauses[c] = Bm25ClauseDev{cl.term, cl.occur, cl.mode, w};
     }
@@ -672,17 +863,35 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     // clauses and clause offsets travel as one pinned block
     const size_t cl_bytes = (std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev) + 7) & ~(size_t)7;
     const size_t inq_bytes = cl_bytes + (size_t)(nq + 1) * 8;
-    NIDX_HIP(idx->s_in_q.reserve(inq_bytes));
-    NIDX_HIP(idx->h_in_q.reserve(inq_bytes));
-    if (n_clauses) memcpy(idx->h_in_q.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
-    memcpy(idx->h_in_q.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
-    NIDX_HIP(hipMemcpyAsync(idx->s_in_q.p, idx->h_in_q.p, inq_bytes, hipMemcpyHostToDevice, idx->stream));
-    const Bm25ClauseDev *d_clauses = idx->s_in_q.as<Bm25ClauseDev>();
-    const unsigned long long *d_clause_offsets = reinterpret_cast<const unsigned long long *>(idx->s_in_q.as<unsigned char>() + cl_bytes);
+    NIDX_HIP(cx.s_in_q.reserve(inq_bytes));
+    NIDX_HIP(cx.h_in_q.reserve(inq_bytes));
+    if (n_clauses) memcpy(cx.h_in_q.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
+    memcpy(cx.h_in_q.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
+    NIDX_HIP(hipMemcpyAsync(cx.s_in_q.p, cx.h_in_q.p, inq_bytes, hipMemcpyHostToDevice, cx.stream));
+    const Bm25ClauseDev *d_clauses = cx.s_in_q.as<Bm25ClauseDev>();
+    const unsigned long long *d_clause_offsets = reinterpret_cast<const unsigned long long *>(cx.s_in_q.as<unsigned char>() + cl_bytes);
     static_assert(sizeof(Bm25AfterDev) == sizeof(nidx_gpu_bm25_search_after_t), "search-after layout");
     if (after) {
-        NIDX_HIP(idx->s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
-        NIDX_HIP(hipMemcpyAsync(idx->s_after.p, after, (size_t)nq * sizeof(Bm25AfterDev), hipMemcpyHostToDevice, idx->stream));
+        NIDX_HIP(cx.s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
+        const void *src = after;
+        if (idx->concatenated()) {
+            // the cursor's DocAddress in the resident numbering (segment_ord 0, doc + base): (segment, doc) order is kept.  A cursor
+            // beyond the end of its segment sits just before the next segment's first document.
+            cx.w_after.resize(nq);
+            const uint32_t S = idx->n_segments;
+            for (uint32_t q = 0; q < nq; q++) {
+                Bm25AfterDev c;
+                memcpy(&c, &after[q], sizeof(c));
+                const uint64_t seg = c.docaddr >> 32, d = c.docaddr & 0xffffffffull;
+                if (seg >= S) c.docaddr = 0xffffffffull;   // behind every document (resident doc ids are < 2^32 - 1 .. and compared strictly)
+                else if (d < idx->real[seg].n_docs) c.docaddr = (uint64_t)idx->seg_base[seg] + d;
+                else if (idx->seg_base[seg + 1] == 0) { if (c.tie_break == 1) c.tie_break = 0; c.docaddr = 0; }   // before every document
+                else c.docaddr = (uint64_t)idx->seg_base[seg + 1] - 1u;
+                cx.w_after[q] = c;
+            }
+            src = cx.w_after.data();
+        }
+        NIDX_HIP(hipMemcpyAsync(cx.s_after.p, src, (size_t)nq * sizeof(Bm25AfterDev), hipMemcpyHostToDevice, cx.stream));
     }
     // facets: one matching-document bitset per query that asks for counts
     std::vector<int> match_slot(nq, -1);
@@ -700,28 +909,28 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         }
     }
     if (n_slots) {
-        NIDX_HIP(idx->s_match_slot.reserve((size_t)nq * 4));
-        NIDX_HIP(idx->s_pair_term.reserve(n_pairs * 4));
-        NIDX_HIP(idx->s_pair_slot.reserve(n_pairs * 4));
-        NIDX_HIP(idx->s_facet_counts.reserve(n_pairs * 8));
-        NIDX_HIP(hipMemcpyAsync(idx->s_match_slot.p, match_slot.data(), (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(idx->s_pair_term.p, pair_term.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
-        NIDX_HIP(hipMemcpyAsync(idx->s_pair_slot.p, pair_slot.data(), n_pairs * 4, hipMemcpyHostToDevice, idx->stream));
-        NIDX_HIP(hipMemsetAsync(idx->s_facet_counts.p, 0, n_pairs * 8, idx->stream));
+        NIDX_HIP(cx.s_match_slot.reserve((size_t)nq * 4));
+        NIDX_HIP(cx.s_pair_term.reserve(n_pairs * 4));
+        NIDX_HIP(cx.s_pair_slot.reserve(n_pairs * 4));
+        NIDX_HIP(cx.s_facet_counts.reserve(n_pairs * 8));
+        NIDX_HIP(hipMemcpyAsync(cx.s_match_slot.p, match_slot.data(), (size_t)nq * 4, hipMemcpyHostToDevice, cx.stream));
+        NIDX_HIP(hipMemcpyAsync(cx.s_pair_term.p, pair_term.data(), n_pairs * 4, hipMemcpyHostToDevice, cx.stream));
+        NIDX_HIP(hipMemcpyAsync(cx.s_pair_slot.p, pair_slot.data(), n_pairs * 4, hipMemcpyHostToDevice, cx.stream));
+        NIDX_HIP(hipMemsetAsync(cx.s_facet_counts.p, 0, n_pairs * 8, cx.stream));
     }
     if (n_sets) {
         const uint64_t n_set_terms = opt->term_set_offsets[n_sets];
-        NIDX_HIP(idx->s_set_terms.reserve(std::max<uint64_t>(n_set_terms, 1) * 4));
-        if (n_set_terms) NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, opt->term_set_terms, n_set_terms * 4, hipMemcpyHostToDevice, idx->stream));
+        NIDX_HIP(cx.s_set_terms.reserve(std::max<uint64_t>(n_set_terms, 1) * 4));
+        if (n_set_terms) NIDX_HIP(hipMemcpyAsync(cx.s_set_terms.p, opt->term_set_terms, n_set_terms * 4, hipMemcpyHostToDevice, cx.stream));
     }
-    idx->last_kernel_ms = 0.f;
+    cx.kernel_ms = 0.f;
     const bool host_dbg = getenv("NIDX_GPU_BM25_DEBUG") != nullptr || getenv("NIDX_GPU_BM25_HOST_TRACE") != nullptr;
     auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_us();
     double t_work = 0, t_sync = 0, t_collect = 0;
     struct Hit { float score; uint64_t docaddr; int64_t value; };
     std::vector<std::vector<Hit>> merged(idx->segs.size() == 1 ? 0 : nq);
-    std::vector<Bm25Work> &work = idx->w_work;
+    std::vector<Bm25Work> &work = cx.w_work;
     for (size_t s = 0; s < idx->segs.size(); s++) {
         Bm25Segment &seg = idx->segs[s];
         // ---- the aux lists of this segment, in dependency order: term sets (union bitset -> ascending doc list,
@@ -793,84 +1002,84 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         }
         const uint32_t words = (seg.n_docs + 63) / 64;
         if (n_aux) {
-            NIDX_HIP(idx->s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
-            NIDX_HIP(idx->s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
-            NIDX_HIP(idx->s_set_counts.reserve((size_t)n_aux * 4 + 4));   // + the count of the union candidates
-            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, (size_t)n_aux * 4 + 4, idx->stream));
-            NIDX_HIP(idx->s_aux_out_off.reserve((size_t)(n_aux + 1) * 8));
-            NIDX_HIP(hipMemcpyAsync(idx->s_aux_out_off.p, out_off.data(), (size_t)(n_aux + 1) * 8, hipMemcpyHostToDevice, idx->stream));
+            NIDX_HIP(cx.s_aux_ids.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
+            NIDX_HIP(cx.s_aux_tfs.reserve(std::max<uint64_t>(out_off[n_aux], 1) * 4 + BM25_LIST_PAD_BYTES));
+            NIDX_HIP(cx.s_set_counts.reserve((size_t)n_aux * 4 + 4));   // + the count of the union candidates
+            NIDX_HIP(hipMemsetAsync(cx.s_set_counts.p, 0, (size_t)n_aux * 4 + 4, cx.stream));
+            NIDX_HIP(cx.s_aux_out_off.reserve((size_t)(n_aux + 1) * 8));
+            NIDX_HIP(hipMemcpyAsync(cx.s_aux_out_off.p, out_off.data(), (size_t)(n_aux + 1) * 8, hipMemcpyHostToDevice, cx.stream));
         }
         if (n_sets && words) {
-            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
-            NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, idx->stream));
+            NIDX_HIP(cx.s_set_bits.reserve(std::max<size_t>((size_t)n_sets * words, 1) * 8));
+            NIDX_HIP(launch_bitset_fill(cx.s_set_bits.as<uint64_t>(), n_sets * words, n_sets * words * 64u, 0, cx.stream));
             for (uint32_t j = 0; j < n_sets; j++) {
                 const uint32_t nl = (uint32_t)(opt->term_set_offsets[j + 1] - opt->term_set_offsets[j]);
                 if (nl)
                     NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(),
-                                                   idx->s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
-                                                   idx->s_set_bits.as<uint64_t>() + (size_t)j * words, idx->stream));
+                                                   cx.s_set_terms.as<uint32_t>() + opt->term_set_offsets[j], nl, seg.n_docs,
+                                                   cx.s_set_bits.as<uint64_t>() + (size_t)j * words, cx.stream));
                 if (opt->term_set_complement && opt->term_set_complement[j])
-                    NIDX_HIP(launch_bitset_not(idx->s_set_bits.as<uint64_t>() + (size_t)j * words, words, seg.n_docs, idx->stream));
+                    NIDX_HIP(launch_bitset_not(cx.s_set_bits.as<uint64_t>() + (size_t)j * words, words, seg.n_docs, cx.stream));
             }
-            NIDX_HIP(launch_bitset_compact(idx->s_set_bits.as<uint64_t>(), words, n_sets, idx->s_aux_out_off.as<unsigned long long>(),
-                                           idx->s_aux_ids.as<uint32_t>(), idx->s_set_counts.as<uint32_t>(), idx->stream));
+            NIDX_HIP(launch_bitset_compact(cx.s_set_bits.as<uint64_t>(), words, n_sets, cx.s_aux_out_off.as<unsigned long long>(),
+                                           cx.s_aux_ids.as<uint32_t>(), cx.s_set_counts.as<uint32_t>(), cx.stream));
         }
         for (uint32_t j = 0; j < n_phrases; j++) {
             const uint64_t n_driver = out_off[n_sets + j + 1] - out_off[n_sets + j];
             if (n_driver == 0) continue;
-            NIDX_HIP(idx->s_phrase_tf.reserve(n_driver * 4));
+            NIDX_HIP(cx.s_phrase_tf.reserve(n_driver * 4));
             uint32_t *slop_left = nullptr;
             if (phrases[j].slop) {
                 // PhraseScorer's `left` list per document: as many entries as the first term has positions in this segment
                 const uint64_t tb = seg.term_offsets_host[phrases[j].terms[0]], te = seg.term_offsets_host[phrases[j].terms[0] + 1];
                 unsigned long long pr[2] = {0, 0};
-                NIDX_HIP(hipMemcpyAsync(&pr[0], seg.pos_offsets.as<unsigned long long>() + tb, 8, hipMemcpyDeviceToHost, idx->stream));
-                NIDX_HIP(hipMemcpyAsync(&pr[1], seg.pos_offsets.as<unsigned long long>() + te, 8, hipMemcpyDeviceToHost, idx->stream));
-                NIDX_HIP(hipStreamSynchronize(idx->stream));
-                NIDX_HIP(idx->s_slop_left.reserve(std::max<uint64_t>(pr[1] - pr[0], 1) * 8));   // (position, budget used) pairs
-                slop_left = idx->s_slop_left.as<uint32_t>();
+                NIDX_HIP(hipMemcpyAsync(&pr[0], seg.pos_offsets.as<unsigned long long>() + tb, 8, hipMemcpyDeviceToHost, cx.stream));
+                NIDX_HIP(hipMemcpyAsync(&pr[1], seg.pos_offsets.as<unsigned long long>() + te, 8, hipMemcpyDeviceToHost, cx.stream));
+                NIDX_HIP(hipStreamSynchronize(cx.stream));
+                NIDX_HIP(cx.s_slop_left.reserve(std::max<uint64_t>(pr[1] - pr[0], 1) * 8));   // (position, budget used) pairs
+                slop_left = cx.s_slop_left.as<uint32_t>();
             }
             NIDX_HIP(launch_phrase_match(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.pos_offsets.as<unsigned long long>(),
-                                         seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, idx->s_phrase_tf.as<uint32_t>(), slop_left, idx->stream));
-            NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], idx->s_phrase_tf.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(),
-                                           out_off[n_sets + j], idx->s_aux_ids.as<uint32_t>(), idx->s_aux_tfs.as<uint32_t>(),
-                                           idx->s_set_counts.as<uint32_t>() + n_sets + j, idx->stream));
+                                         seg.positions.as<uint32_t>(), phrases[j], (uint32_t)n_driver, cx.s_phrase_tf.as<uint32_t>(), slop_left, cx.stream));
+            NIDX_HIP(launch_phrase_compact(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), phrases[j], cx.s_phrase_tf.as<uint32_t>(), seg.fieldnorm_ids.as<uint8_t>(),
+                                           out_off[n_sets + j], cx.s_aux_ids.as<uint32_t>(), cx.s_aux_tfs.as<uint32_t>(),
+                                           cx.s_set_counts.as<uint32_t>() + n_sets + j, cx.stream));
         }
         if (n_sub) {
-            NIDX_HIP(idx->s_phrase_tf.reserve(std::max<uint64_t>(max_cand, 1) * 8));   // [n] match flags | [n] score bits
+            NIDX_HIP(cx.s_phrase_tf.reserve(std::max<uint64_t>(max_cand, 1) * 8));   // [n] match flags | [n] score bits
             if (any_union) {
-                NIDX_HIP(idx->s_sub_bits.reserve(std::max<size_t>(words, 1) * 8));
-                NIDX_HIP(idx->s_sub_union.reserve(std::max<uint64_t>(max_cand, 1) * 4));
+                NIDX_HIP(cx.s_sub_bits.reserve(std::max<size_t>(words, 1) * 8));
+                NIDX_HIP(cx.s_sub_union.reserve(std::max<uint64_t>(max_cand, 1) * 4));
             }
-            SubqueryLists L{seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), idx->s_aux_ids.as<uint32_t>(),
-                            idx->s_aux_tfs.as<uint32_t>(), idx->s_aux_out_off.as<unsigned long long>(), idx->s_set_counts.as<uint32_t>(),
-                            idx->s_sub_union.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_aux};
+            SubqueryLists L{seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), seg.tfs.as<uint32_t>(), cx.s_aux_ids.as<uint32_t>(),
+                            cx.s_aux_tfs.as<uint32_t>(), cx.s_aux_out_off.as<unsigned long long>(), cx.s_set_counts.as<uint32_t>(),
+                            cx.s_sub_union.as<uint32_t>(), cx.s_set_counts.as<uint32_t>() + n_aux};
             for (uint32_t j = 0; j < n_sub; j++) {
                 const SubPlan &pl = plans[j];
                 if (pl.n_cand_max == 0) continue;
                 if (subs[j].driver == BM25_SUB_DRIVER_UNION) {
-                    NIDX_HIP(launch_bitset_fill(idx->s_sub_bits.as<uint64_t>(), words, seg.n_docs, 0, idx->stream));
+                    NIDX_HIP(launch_bitset_fill(cx.s_sub_bits.as<uint64_t>(), words, seg.n_docs, 0, cx.stream));
                     for (uint32_t t = 0; t < subs[j].n; t++)
-                        if (pl.union_mask >> t & 1) NIDX_HIP(launch_subquery_scatter(L, subs[j].src[t], pl.n_cand_max, idx->s_sub_bits.as<uint64_t>(), idx->stream));
+                        if (pl.union_mask >> t & 1) NIDX_HIP(launch_subquery_scatter(L, subs[j].src[t], pl.n_cand_max, cx.s_sub_bits.as<uint64_t>(), cx.stream));
                     // out_off[0] == 0: the union list starts at the head of its own buffer
-                    NIDX_HIP(launch_bitset_compact(idx->s_sub_bits.as<uint64_t>(), words, 1, idx->s_aux_out_off.as<unsigned long long>(),
-                                                   idx->s_sub_union.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_aux, idx->stream));
+                    NIDX_HIP(launch_bitset_compact(cx.s_sub_bits.as<uint64_t>(), words, 1, cx.s_aux_out_off.as<unsigned long long>(),
+                                                   cx.s_sub_union.as<uint32_t>(), cx.s_set_counts.as<uint32_t>() + n_aux, cx.stream));
                 }
-                uint32_t *tmp_ok = idx->s_phrase_tf.as<uint32_t>(), *tmp_score = tmp_ok + max_cand;
-                NIDX_HIP(launch_subquery_match(L, idx->tf_cache.as<float>(), subs[j], (uint32_t)pl.n_cand_max, tmp_ok, tmp_score, idx->stream));
-                NIDX_HIP(launch_subquery_compact(L, subs[j], tmp_ok, tmp_score, out_off[n_sets + n_phrases + j], idx->s_aux_ids.as<uint32_t>(),
-                                                 idx->s_aux_tfs.as<uint32_t>(), idx->s_set_counts.as<uint32_t>() + n_sets + n_phrases + j, idx->stream));
+                uint32_t *tmp_ok = cx.s_phrase_tf.as<uint32_t>(), *tmp_score = tmp_ok + max_cand;
+                NIDX_HIP(launch_subquery_match(L, idx->tf_cache.as<float>(), subs[j], (uint32_t)pl.n_cand_max, tmp_ok, tmp_score, cx.stream));
+                NIDX_HIP(launch_subquery_compact(L, subs[j], tmp_ok, tmp_score, out_off[n_sets + n_phrases + j], cx.s_aux_ids.as<uint32_t>(),
+                                                 cx.s_aux_tfs.as<uint32_t>(), cx.s_set_counts.as<uint32_t>() + n_sets + n_phrases + j, cx.stream));
             }
         }
         if (n_aux) {
-            NIDX_HIP(hipMemcpyAsync(set_counts.data(), idx->s_set_counts.p, (size_t)n_aux * 4, hipMemcpyDeviceToHost, idx->stream));
-            NIDX_HIP(hipStreamSynchronize(idx->stream));
+            NIDX_HIP(hipMemcpyAsync(set_counts.data(), cx.s_set_counts.p, (size_t)n_aux * 4, hipMemcpyDeviceToHost, cx.stream));
+            NIDX_HIP(hipStreamSynchronize(cx.stream));
             for (uint32_t j = 0; j < n_aux; j++) {
                 aux_pairs[2 * j] = out_off[j];
                 aux_pairs[2 * j + 1] = out_off[j] + set_counts[j];
             }
-            NIDX_HIP(idx->s_aux_off.reserve(aux_pairs.size() * 8));
-            NIDX_HIP(hipMemcpyAsync(idx->s_aux_off.p, aux_pairs.data(), aux_pairs.size() * 8, hipMemcpyHostToDevice, idx->stream));
+            NIDX_HIP(cx.s_aux_off.reserve(aux_pairs.size() * 8));
+            NIDX_HIP(hipMemcpyAsync(cx.s_aux_off.p, aux_pairs.data(), aux_pairs.size() * 8, hipMemcpyHostToDevice, cx.stream));
         }
         auto postings_of = [&](const nidx_gpu_bm25_clause_t &cl) -> uint64_t {
             if (cl.term & NIDX_BM25_TERM_SET) return set_counts[cl.term & ~NIDX_BM25_TERM_SET];
@@ -885,7 +1094,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         // kernels are exact for any input, that bound only keeps their slow paths rare.
         const double t_w0 = now_us();
         // every clause's list length in this segment, looked up once (two random reads of an 8 MB table per plain term)
-        std::vector<uint64_t> &clen = idx->w_clause_len;
+        std::vector<uint64_t> &clen = cx.w_clause_len;
         clen.resize(n_clauses);
         for (uint64_t c = 0; c < n_clauses; c++) {
             if (c + 16 < n_clauses && !(clauses[c + 16].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)))
@@ -893,8 +1102,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             clen[c] = postings_of(clauses[c]);
         }
         work.clear();
-        std::vector<uint32_t> &item_first = idx->w_item_first;
-        std::vector<uint8_t> &q_union = idx->w_q_union;
+        std::vector<uint32_t> &item_first = cx.w_item_first;
+        std::vector<uint8_t> &q_union = cx.w_q_union;
         item_first.assign(nq + 1, 0);
         q_union.assign(nq, 0);
         const double inv_docs = 1.0 / std::max<double>(1.0, (double)seg.n_docs);
@@ -905,7 +1114,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         uint64_t slice_now = slice_postings;
         if (!getenv("NIDX_GPU_BM25_SLICE")) {
             const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
-            std::vector<uint64_t> &pq = idx->w_postings;
+            std::vector<uint64_t> &pq = cx.w_postings;
             pq.assign(nq, 0);
             for (uint32_t q = 0; q < nq; q++)
                 for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) pq[q] += clen[c];
@@ -959,7 +1168,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         }
         const size_t nw = work.size();
         item_first[nq] = (uint32_t)nw;
-        std::vector<uint32_t> &item_list = idx->w_item_list;
+        std::vector<uint32_t> &item_list = cx.w_item_list;
         item_list.resize(nw);
         uint32_t n_union = 0, n_fast = 0, n_wide = 0, wide_max_clauses = 0;
         for (size_t w = 0; w < nw; w++)
@@ -978,7 +1187,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             }
         }
         // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
-        std::vector<Bm25UClause> &ucl = idx->w_ucl;
+        std::vector<Bm25UClause> &ucl = cx.w_ucl;
         ucl.resize(n_union ? n_clauses : 0);
         for (uint32_t q = 0; q < nq && n_union; q++) {
             if (!q_union[q]) continue;
@@ -991,38 +1200,38 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
             }
         }
         t_work += now_us() - t_w0;
-        NIDX_HIP(idx->s_key.reserve(nw * kk * 8));
+        NIDX_HIP(cx.s_key.reserve(nw * kk * 8));
         const size_t if_bytes = ((size_t)(nq + 1) * 4 + 31) & ~(size_t)31;   // 32-byte pieces: the clause table is read with 16-byte scalar loads
         const size_t work_bytes = (nw * sizeof(Bm25Work) + 31) & ~(size_t)31;
         const size_t items_bytes = (nw * 4 + 31) & ~(size_t)31;
         const size_t inw_bytes = if_bytes + work_bytes + items_bytes + ucl.size() * sizeof(Bm25UClause);
-        NIDX_HIP(idx->s_in_w.reserve(inw_bytes));
-        NIDX_HIP(idx->h_in_w.reserve(inw_bytes));
-        memcpy(idx->h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
-        memcpy(idx->h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
-        memcpy(idx->h_in_w.as<unsigned char>() + if_bytes + work_bytes, item_list.data(), nw * 4);
-        if (!ucl.empty()) memcpy(idx->h_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes, ucl.data(), ucl.size() * sizeof(Bm25UClause));
-        NIDX_HIP(hipMemcpyAsync(idx->s_in_w.p, idx->h_in_w.p, inw_bytes, hipMemcpyHostToDevice, idx->stream));
-        const uint32_t *d_item_first = idx->s_in_w.as<uint32_t>();
-        const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(idx->s_in_w.as<unsigned char>() + if_bytes);
-        const uint32_t *d_items = reinterpret_cast<const uint32_t *>(idx->s_in_w.as<unsigned char>() + if_bytes + work_bytes);
+        NIDX_HIP(cx.s_in_w.reserve(inw_bytes));
+        NIDX_HIP(cx.h_in_w.reserve(inw_bytes));
+        memcpy(cx.h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
+        memcpy(cx.h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
+        memcpy(cx.h_in_w.as<unsigned char>() + if_bytes + work_bytes, item_list.data(), nw * 4);
+        if (!ucl.empty()) memcpy(cx.h_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes, ucl.data(), ucl.size() * sizeof(Bm25UClause));
+        NIDX_HIP(hipMemcpyAsync(cx.s_in_w.p, cx.h_in_w.p, inw_bytes, hipMemcpyHostToDevice, cx.stream));
+        const uint32_t *d_item_first = cx.s_in_w.as<uint32_t>();
+        const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(cx.s_in_w.as<unsigned char>() + if_bytes);
+        const uint32_t *d_items = reinterpret_cast<const uint32_t *>(cx.s_in_w.as<unsigned char>() + if_bytes + work_bytes);
         // per-query outputs of the merge kernel, one block: doc u32 [nq][kk] | score f32 [nq][kk] | count u32 [nq] | total u64 [nq] | postings u64 [nq]
         const size_t o_doc = 0, o_score = (size_t)nq * kk * 4, o_count = o_score + (size_t)nq * kk * 4;
         const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, out_bytes = o_post + (size_t)nq * 8;
-        NIDX_HIP(idx->s_outpack.reserve(out_bytes));
-        NIDX_HIP(idx->h_outpack.reserve(out_bytes));
-        unsigned char *d_out = idx->s_outpack.as<unsigned char>();
-        NIDX_HIP(idx->s_count.reserve(nw * 4));
-        NIDX_HIP(idx->s_total.reserve(nw * 8));
-        NIDX_HIP(idx->s_postings.reserve(nw * 8));
+        NIDX_HIP(cx.s_outpack.reserve(out_bytes));
+        NIDX_HIP(cx.h_outpack.reserve(out_bytes));
+        unsigned char *d_out = cx.s_outpack.as<unsigned char>();
+        NIDX_HIP(cx.s_count.reserve(nw * 4));
+        NIDX_HIP(cx.s_total.reserve(nw * 8));
+        NIDX_HIP(cx.s_postings.reserve(nw * 8));
         const uint32_t match_words = (seg.n_docs + 31) / 32;
         if (n_slots) {
             const uint64_t bytes = (uint64_t)n_slots * std::max<uint32_t>(match_words, 1) * 4;
             if (bytes > (1ull << 30))
                 return fail(NIDX_ERR_UNSUPPORTED, "%u faceted queries over a %u-document segment need %llu bytes of match bitsets (limit 1 GiB): split the batch",
                             n_slots, seg.n_docs, (unsigned long long)bytes);
-            NIDX_HIP(idx->s_match_bits.reserve(bytes));
-            NIDX_HIP(hipMemsetAsync(idx->s_match_bits.p, 0, bytes, idx->stream));
+            NIDX_HIP(cx.s_match_bits.reserve(bytes));
+            NIDX_HIP(hipMemsetAsync(cx.s_match_bits.p, 0, bytes, cx.stream));
         }
         Bm25Args a;
         a.work = d_work;
@@ -1035,76 +1244,76 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
         a.tf_cache = idx->tf_cache.as<float>();
         a.clauses = d_clauses;
         a.clause_offsets = d_clause_offsets;
-        a.after = after ? idx->s_after.as<Bm25AfterDev>() : nullptr;
+        a.after = after ? cx.s_after.as<Bm25AfterDev>() : nullptr;
         a.k = kk;
         a.segment_ord = (uint32_t)s;
-        a.out_key = idx->s_key.as<unsigned long long>();
-        a.out_count = idx->s_count.as<uint32_t>();
-        a.out_total = idx->s_total.as<unsigned long long>();
-        a.out_postings = idx->s_postings.as<unsigned long long>();
-        a.aux_offsets = n_aux ? idx->s_aux_off.as<unsigned long long>() : nullptr;
-        a.aux_doc_ids = n_aux ? idx->s_aux_ids.as<uint32_t>() : nullptr;
-        a.aux_tfs = n_aux ? idx->s_aux_tfs.as<uint32_t>() : nullptr;
+        a.out_key = cx.s_key.as<unsigned long long>();
+        a.out_count = cx.s_count.as<uint32_t>();
+        a.out_total = cx.s_total.as<unsigned long long>();
+        a.out_postings = cx.s_postings.as<unsigned long long>();
+        a.aux_offsets = n_aux ? cx.s_aux_off.as<unsigned long long>() : nullptr;
+        a.aux_doc_ids = n_aux ? cx.s_aux_ids.as<uint32_t>() : nullptr;
+        a.aux_tfs = n_aux ? cx.s_aux_tfs.as<uint32_t>() : nullptr;
         a.order_key = order_field >= 0 ? seg.order_key[order_field].as<uint32_t>() : nullptr;
         a.order_desc = opt->order_desc ? 1 : 0;
-        a.match_bits = n_slots ? idx->s_match_bits.as<uint32_t>() : nullptr;
-        a.match_slot = n_slots ? idx->s_match_slot.as<int>() : nullptr;
+        a.match_bits = n_slots ? cx.s_match_bits.as<uint32_t>() : nullptr;
+        a.match_slot = n_slots ? cx.s_match_slot.as<int>() : nullptr;
         a.match_words = match_words;
-        a.uclauses = reinterpret_cast<const Bm25UClause *>(idx->s_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes);
+        a.uclauses = reinterpret_cast<const Bm25UClause *>(cx.s_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes);
         a.dbg = nullptr;
         DevBuf dbgbuf;
         if (getenv("NIDX_GPU_BM25_DEBUG")) {
             NIDX_HIP(dbgbuf.alloc((16 + 8 * nw) * 8));
-            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, (16 + 8 * nw) * 8, idx->stream));
+            NIDX_HIP(hipMemsetAsync(dbgbuf.p, 0, (16 + 8 * nw) * 8, cx.stream));
             a.dbg = dbgbuf.as<unsigned long long>();
 
         }
-        NIDX_HIP(hipEventRecord(idx->ev0, idx->stream));
+        NIDX_HIP(hipEventRecord(cx.ev0, cx.stream));
         {
             const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
-            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, idx->stream));
+            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, cx.stream));
         }
-        NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, idx->stream));
-        NIDX_HIP(hipEventRecord(idx->ev1, idx->stream));
+        NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, cx.stream));
+        NIDX_HIP(hipEventRecord(cx.ev1, cx.stream));
         Bm25MergeArgs mg;
         mg.item_first = d_item_first;
-        mg.item_key = idx->s_key.as<unsigned long long>();
-        mg.item_count = idx->s_count.as<uint32_t>();
-        mg.item_total = idx->s_total.as<unsigned long long>();
-        mg.item_postings = idx->s_postings.as<unsigned long long>();
+        mg.item_key = cx.s_key.as<unsigned long long>();
+        mg.item_count = cx.s_count.as<uint32_t>();
+        mg.item_total = cx.s_total.as<unsigned long long>();
+        mg.item_postings = cx.s_postings.as<unsigned long long>();
         mg.k = kk;
         mg.out_doc = reinterpret_cast<uint32_t *>(d_out + o_doc);
         mg.out_score = reinterpret_cast<float *>(d_out + o_score);
         mg.out_count = reinterpret_cast<uint32_t *>(d_out + o_count);
         mg.out_total = reinterpret_cast<unsigned long long *>(d_out + o_total);
         mg.out_postings = reinterpret_cast<unsigned long long *>(d_out + o_post);
-        NIDX_HIP(launch_bm25_merge(mg, nq, idx->stream));
+        NIDX_HIP(launch_bm25_merge(mg, nq, cx.stream));
         if (n_slots)
-            NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_pair_term.as<uint32_t>(),
-                                        idx->s_pair_slot.as<int>(), (uint32_t)n_pairs, idx->s_match_bits.as<uint32_t>(), match_words,
-                                        idx->s_facet_counts.as<unsigned long long>(), idx->stream));
-        NIDX_HIP(hipMemcpyAsync(idx->h_outpack.p, idx->s_outpack.p, out_bytes, hipMemcpyDeviceToHost, idx->stream));
-        const unsigned char *h_out = idx->h_outpack.as<unsigned char>();
+            NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_pair_term.as<uint32_t>(),
+                                        cx.s_pair_slot.as<int>(), (uint32_t)n_pairs, cx.s_match_bits.as<uint32_t>(), match_words,
+                                        cx.s_facet_counts.as<unsigned long long>(), cx.stream));
+        NIDX_HIP(hipMemcpyAsync(cx.h_outpack.p, cx.s_outpack.p, out_bytes, hipMemcpyDeviceToHost, cx.stream));
+        const unsigned char *h_out = cx.h_outpack.as<unsigned char>();
         const uint32_t *h_doc = reinterpret_cast<const uint32_t *>(h_out + o_doc);
         const float *h_score = reinterpret_cast<const float *>(h_out + o_score);
         const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + o_count);
         const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + o_total);
         const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + o_post);
-        if (idx->async_slot && idx->segs.size() == 1 && n_aux == 0 && n_slots == 0 && order_field < 0 && !a.dbg) {
+        if (async_slot && idx->segs.size() == 1 && n_aux == 0 && n_slots == 0 && order_field < 0 && !a.dbg) {
             // pipelined: the collect step runs in nidx_gpu_bm25_search_wait (the buffers are the slot's: swapped in by submit)
-            Bm25Slot &sl = *idx->async_slot;
+            Bm25Slot &sl = *async_slot;
             sl.launched = true;
             sl.nq = nq, sl.k = k, sl.kk = kk;
             sl.o_doc = o_doc, sl.o_score = o_score, sl.o_count = o_count, sl.o_total = o_total, sl.o_post = o_post;
             return NIDX_OK;
         }
         const double t_s0 = now_us();
-        NIDX_HIP(hipStreamSynchronize(idx->stream));
+        NIDX_HIP(hipStreamSynchronize(cx.stream));
         t_sync += now_us() - t_s0;
         const double t_c0 = now_us();
         float ms = 0.f;
-        NIDX_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
-        idx->last_kernel_ms += ms;
+        NIDX_HIP(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
+        cx.kernel_ms += ms;
         if (a.dbg) {
             unsigned long long d[9];
             NIDX_HIP(hipMemcpy(d, a.dbg, 72, hipMemcpyDeviceToHost));
@@ -1161,7 +1370,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
                 out_count[q] = n;
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t d = h_doc[(size_t)q * kk + i];
-                    if (out_docaddr) out_docaddr[(size_t)q * k + i] = ((uint64_t)s << 32) | d;
+                    if (out_docaddr) out_docaddr[(size_t)q * k + i] = idx->docaddr(s, d);
                     if (out_score) out_score[(size_t)q * k + i] = order_field >= 0 ? 0.f : h_score[(size_t)q * kk + i];
                     if (opt->out_order_value) opt->out_order_value[(size_t)q * k + i] = order_field >= 0 ? seg.fast_host[order_field][d] : 0;
                 }
@@ -1178,7 +1387,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, const nidx_gpu_bm25_clause_t *
     const double t_merge0 = now_us();
     if (n_slots) {
         std::vector<unsigned long long> fc(n_pairs);
-        NIDX_HIP(hipMemcpy(fc.data(), idx->s_facet_counts.p, n_pairs * 8, hipMemcpyDeviceToHost));
+        NIDX_HIP(hipMemcpy(fc.data(), cx.s_facet_counts.p, n_pairs * 8, hipMemcpyDeviceToHost));
         for (uint64_t p = 0; p < n_pairs; p++) opt->out_facet_counts[p] = fc[p];
     }
     const bool desc = opt->order_desc != 0;
@@ -1223,70 +1432,75 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !clause_offsets || !out_count || !opt) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
-    return bm25_search_locked(idx, clauses, clause_offsets, nq, opt, out_docaddr, out_score, out_count, out_total, out_postings);
+    std::shared_lock<std::shared_mutex> rlock(idx->rw);
+    const int32_t rc = bm25_search_locked(idx, idx->main, nullptr, clauses, clause_offsets, nq, opt, out_docaddr, out_score, out_count, out_total, out_postings);
+    {
+        std::lock_guard<std::mutex> ms(idx->ms_mu);
+        idx->last_kernel_ms = idx->main.kernel_ms;
+    }
+    return rc;
 } NIDX_ABI_CATCH
 
-// ---- pipelined form: the host side of batch i + 1 (clause weights, work list, staging) overlaps the kernels of batch i ----------
-#define NIDX_BM25_PIPELINE_DEPTH 4
+// ---- pipelined form: the host side of batch i + 1 (clause weights, work list, staging) overlaps the kernels of batch i; every slot
+// has a context of its own, so two or more threads may submit at the same time (the planning of a batch costs the submitting thread
+// more than its kernels cost the device) ----------
+#define NIDX_BM25_PIPELINE_DEPTH 8
 
 int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                     uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *ticket_out) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
     if (!idx || !clause_offsets || !opt || !ticket_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     *ticket_out = 0;
-    std::lock_guard<std::mutex> lock(idx->mu);
     NIDX_HIP(hipSetDevice(idx->device));
     Bm25Slot *slot = nullptr;
-    for (auto &s : idx->slots)
-        if (!s->busy) { slot = s.get(); break; }
-    if (!slot) {
-        if (idx->slots.size() >= NIDX_BM25_PIPELINE_DEPTH)
-            return fail(NIDX_ERR_BUSY, "all %d BM25 pipeline slots hold a ticket that has not been waited for", NIDX_BM25_PIPELINE_DEPTH);
-        std::unique_ptr<Bm25Slot> ns(new Bm25Slot());
-        int lo = 0, hi = 0;
-        NIDX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        NIDX_HIP(hipStreamCreateWithPriority(&ns->stream, hipStreamNonBlocking, hi));
-        NIDX_HIP(hipEventCreate(&ns->ev0));
-        NIDX_HIP(hipEventCreate(&ns->ev1));
-        idx->slots.push_back(std::move(ns));
-        slot = idx->slots.back().get();
+    {
+        std::lock_guard<std::mutex> lock(idx->slots_mu);
+        for (auto &s : idx->slots)
+            if (!s->busy && !s->preparing) { slot = s.get(); break; }
+        if (!slot) {
+            if (idx->slots.size() >= NIDX_BM25_PIPELINE_DEPTH)
+                return fail(NIDX_ERR_BUSY, "all %d BM25 pipeline slots hold a ticket that has not been waited for", NIDX_BM25_PIPELINE_DEPTH);
+            std::unique_ptr<Bm25Slot> ns(new Bm25Slot());
+            NIDX_HIP(ns->cx.init());
+            idx->slots.push_back(std::move(ns));
+            slot = idx->slots.back().get();
+        }
+        slot->preparing = true;
     }
-    const uint32_t k = opt->k;
-    slot->launched = false;
-    slot->nq = nq, slot->k = k;
-    // outputs of a request that runs synchronously inside this call
-    const size_t kk1 = std::max<uint32_t>(k, 1);
-    // (resize, not assign: the search zeroes the counts itself and nothing is read beyond a query's count)
-    slot->r_docaddr.resize((size_t)nq * kk1), slot->r_score.resize((size_t)nq * kk1);
-    slot->r_count.resize(nq), slot->r_total.resize(nq), slot->r_postings.resize(nq);
-    // The index wears the slot's stream, events and staging while the batch is prepared; every way out of the search — an error
-    // code, a std::bad_alloc from its host vectors — takes them off again, and a failed batch leaves nothing queued on the slot's
-    // stream that could still read the staging the next submit rewrites.
-    struct WearSlot {
+    // every way out of the preparation — an error code, a std::bad_alloc from its host vectors — gives the slot back, and a failed
+    // batch leaves nothing queued on the slot's stream that could still read the staging the next submit rewrites
+    struct Prepare {
         Bm25Index *idx;
         Bm25Slot *slot;
         bool ok = false;
-        WearSlot(Bm25Index *i, Bm25Slot *s) : idx(i), slot(s) {
-            idx->swap_slot(*slot);
-            idx->async_slot = slot;
-        }
-        ~WearSlot() {
-            if (!ok) (void)hipStreamSynchronize(idx->stream);
-            idx->async_slot = nullptr;
-            idx->swap_slot(*slot);
+        ~Prepare() {
+            if (!ok) (void)hipStreamSynchronize(slot->cx.stream);
+            std::lock_guard<std::mutex> lock(idx->slots_mu);
+            slot->preparing = false;
+            if (ok) {
+                slot->busy = true;
+                slot->ticket = idx->next_ticket++;
+            }
         }
     };
+    const uint32_t k = opt->k;
     int32_t rc;
     {
-        WearSlot worn(idx, slot);
-        rc = bm25_search_locked(idx, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
+        Prepare prep{idx, slot};
+        slot->launched = false;
+        slot->nq = nq, slot->k = k;
+        // outputs of a request that runs synchronously inside this call
+        const size_t kk1 = std::max<uint32_t>(k, 1);
+        // (resize, not assign: the search zeroes the counts itself and nothing is read beyond a query's count)
+        slot->r_docaddr.resize((size_t)nq * kk1), slot->r_score.resize((size_t)nq * kk1);
+        slot->r_count.resize(nq), slot->r_total.resize(nq), slot->r_postings.resize(nq);
+        std::shared_lock<std::shared_mutex> rlock(idx->rw);
+        rc = bm25_search_locked(idx, slot->cx, slot, clauses, clause_offsets, nq, opt, slot->r_docaddr.data(), slot->r_score.data(), slot->r_count.data(),
                                 slot->r_total.data(), slot->r_postings.data());
-        worn.ok = rc == NIDX_OK;
+        prep.ok = rc == NIDX_OK;
     }
     if (rc != NIDX_OK) return rc;
-    slot->busy = true;
-    slot->ticket = idx->next_ticket++;
-    *ticket_out = slot->ticket;
+    *ticket_out = slot->ticket;   // (set by ~Prepare; the slot is this thread's until its ticket is handed out)
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
@@ -1296,7 +1510,7 @@ int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket,
     if (!idx || !out_count) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     Bm25Slot *slot = nullptr;
     {
-        std::lock_guard<std::mutex> lock(idx->mu);
+        std::lock_guard<std::mutex> lock(idx->slots_mu);
         for (auto &s : idx->slots)
             if (s->busy && s->ticket == ticket && ticket != 0) { slot = s.get(); break; }
         if (!slot) return fail(NIDX_ERR_INVALID_ARGUMENT, "unknown ticket %llu (a ticket is waited for once)", (unsigned long long)ticket);
@@ -1306,34 +1520,36 @@ int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket,
         Bm25Index *idx;
         Bm25Slot *slot;
         ~Release() {
-            std::lock_guard<std::mutex> lock(idx->mu);
+            std::lock_guard<std::mutex> lock(idx->slots_mu);
             slot->busy = false;
         }
     } release{idx, slot};
     const uint32_t nq = slot->nq, k = slot->k;
     if (slot->launched) {
         NIDX_HIP(hipSetDevice(idx->device));
-        NIDX_HIP(hipStreamSynchronize(slot->stream));
+        NIDX_HIP(hipStreamSynchronize(slot->cx.stream));
         float ms = 0.f;
-        NIDX_HIP(hipEventElapsedTime(&ms, slot->ev0, slot->ev1));
+        NIDX_HIP(hipEventElapsedTime(&ms, slot->cx.ev0, slot->cx.ev1));
         {
-            std::lock_guard<std::mutex> lock(idx->mu);
-            idx->last_kernel_ms += ms;
+            std::lock_guard<std::mutex> lock(idx->ms_mu);
+            idx->last_kernel_ms = ms;
         }
-        const unsigned char *h_out = slot->h_outpack.as<unsigned char>();
+        const unsigned char *h_out = slot->cx.h_outpack.as<unsigned char>();
         const uint32_t *h_doc = reinterpret_cast<const uint32_t *>(h_out + slot->o_doc);
         const float *h_score = reinterpret_cast<const float *>(h_out + slot->o_score);
         const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + slot->o_count);
         const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + slot->o_total);
         const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + slot->o_post);
         const uint32_t kk = slot->kk;
-        for (uint32_t q = 0; q < nq; q++) {   // one segment: the device list is the answer
+        const bool cat = idx->concatenated();
+        for (uint32_t q = 0; q < nq; q++) {   // one resident segment: the device list is the answer
             if (out_total) out_total[q] = h_total[q];
             if (out_postings) out_postings[q] = h_post[q];
             const uint32_t n = k ? std::min<uint32_t>(h_count[q], k) : 0u;
             out_count[q] = n;
             for (uint32_t i = 0; i < n; i++) {
-                if (out_docaddr) out_docaddr[(size_t)q * k + i] = (uint64_t)h_doc[(size_t)q * kk + i];
+                const uint32_t d = h_doc[(size_t)q * kk + i];
+                if (out_docaddr) out_docaddr[(size_t)q * k + i] = cat ? idx->docaddr(0, d) : (uint64_t)d;
                 if (out_score) out_score[(size_t)q * k + i] = h_score[(size_t)q * kk + i];
             }
         }
@@ -1356,42 +1572,82 @@ int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket,
 int32_t nidx_gpu_bm25_apply_deletions(nidx_gpu_bm25_index_t *index, uint32_t segment, const uint32_t *terms, uint32_t n_terms,
                                       uint64_t *n_alive_out) try {
     Bm25Index *idx = reinterpret_cast<Bm25Index *>(index);
-    if (!idx || segment >= idx->segs.size() || (n_terms && !terms)) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
+    if (!idx || segment >= idx->n_segments || (n_terms && !terms)) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     std::lock_guard<std::mutex> lock(idx->mu);
+    std::unique_lock<std::shared_mutex> wlock(idx->rw);
     NIDX_HIP(hipSetDevice(idx->device));
-    Bm25Segment &seg = idx->segs[segment];
     for (uint32_t i = 0; i < n_terms; i++)
         if (terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "deletion term id %u out of range", terms[i]);
+    const bool cat = idx->concatenated();
+    Bm25Segment &seg = idx->segs[cat ? 0 : segment];
+    Bm25Ctx &cx = idx->main;
     const uint32_t words = (seg.n_docs + 63) / 64;
-    hipStream_t st = idx->stream;
+    hipStream_t st = cx.stream;
+    // the documents the count below is taken over: the segment's own (a doc-id range of the concatenated layout)
+    const uint32_t d0 = cat ? idx->seg_base[segment] : 0u, d1 = cat ? idx->seg_base[segment + 1] : seg.n_docs;
     if (n_terms && words) {
         if (seg.all_alive) {
             NIDX_HIP(seg.alive.alloc((size_t)words * 8));
             NIDX_HIP(launch_bitset_fill(seg.alive.as<uint64_t>(), words, seg.n_docs, 1, st));
             seg.all_alive = false;
         }
-        NIDX_HIP(idx->s_set_terms.reserve((size_t)n_terms * 4));
-        NIDX_HIP(hipMemcpyAsync(idx->s_set_terms.p, terms, (size_t)n_terms * 4, hipMemcpyHostToDevice, st));
-        NIDX_HIP(idx->s_set_bits.reserve((size_t)words * 8));
-        NIDX_HIP(launch_bitset_fill(idx->s_set_bits.as<uint64_t>(), words, seg.n_docs, 0, st));
-        NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), idx->s_set_terms.as<uint32_t>(),
-                                       n_terms, seg.n_docs, idx->s_set_bits.as<uint64_t>(), st));
-        NIDX_HIP(launch_bitset_binop(seg.alive.as<uint64_t>(), idx->s_set_bits.as<uint64_t>(), words, 2, st));
+        NIDX_HIP(cx.s_set_bits.reserve((size_t)words * 8));
+        NIDX_HIP(launch_bitset_fill(cx.s_set_bits.as<uint64_t>(), words, seg.n_docs, 0, st));
+        if (!cat) {
+            NIDX_HIP(cx.s_set_terms.reserve((size_t)n_terms * 4));
+            NIDX_HIP(hipMemcpyAsync(cx.s_set_terms.p, terms, (size_t)n_terms * 4, hipMemcpyHostToDevice, st));
+            NIDX_HIP(launch_bitset_scatter(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_set_terms.as<uint32_t>(),
+                                           n_terms, seg.n_docs, cx.s_set_bits.as<uint64_t>(), st));
+        } else {
+            // only THIS segment's part of every list: list i = [ranges[2 i], ranges[2 i + 1]) of the resident postings
+            std::vector<unsigned long long> ranges(2 * (size_t)n_terms + 1, 0);
+            std::vector<uint32_t> lists(n_terms);
+            for (uint32_t i = 0; i < n_terms; i++) {
+                const uint32_t t = terms[i];
+                unsigned long long at = seg.term_offsets_host[t];
+                for (uint32_t s = 0; s < segment; s++) at += idx->real[s].term_offsets_host[t + 1] - idx->real[s].term_offsets_host[t];
+                ranges[2 * i] = at;
+                ranges[2 * i + 1] = at + (idx->real[segment].term_offsets_host[t + 1] - idx->real[segment].term_offsets_host[t]);
+                lists[i] = 2 * i;
+            }
+            NIDX_HIP(cx.s_set_terms.reserve((size_t)n_terms * 4));
+            NIDX_HIP(cx.s_aux_off.reserve(ranges.size() * 8));
+            NIDX_HIP(hipMemcpyAsync(cx.s_set_terms.p, lists.data(), (size_t)n_terms * 4, hipMemcpyHostToDevice, st));
+            NIDX_HIP(hipMemcpyAsync(cx.s_aux_off.p, ranges.data(), ranges.size() * 8, hipMemcpyHostToDevice, st));
+            NIDX_HIP(launch_bitset_scatter(cx.s_aux_off.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_set_terms.as<uint32_t>(), n_terms,
+                                           seg.n_docs, cx.s_set_bits.as<uint64_t>(), st));
+            NIDX_HIP(hipStreamSynchronize(st));   // `ranges` / `lists` are pageable host memory
+        }
+        NIDX_HIP(launch_bitset_binop(seg.alive.as<uint64_t>(), cx.s_set_bits.as<uint64_t>(), words, 2, st));
         seg.n_alive = -1;
     }
     if (n_alive_out) {
-        if (seg.all_alive) *n_alive_out = seg.n_docs;
+        if (seg.all_alive) *n_alive_out = d1 - d0;
         else {
-            NIDX_HIP(idx->s_set_bits.reserve(std::max<size_t>(words, 1) * 8 + 8));
-            NIDX_HIP(idx->s_set_counts.reserve(8));
-            NIDX_HIP(hipMemsetAsync(idx->s_set_counts.p, 0, 8, st));
-            NIDX_HIP(launch_bitset_and_count(seg.alive.as<uint64_t>(), nullptr, idx->s_set_bits.as<uint64_t>(), words,
-                                             idx->s_set_counts.as<unsigned long long>(), st));
+            NIDX_HIP(cx.s_set_bits.reserve(std::max<size_t>(words, 1) * 8 + 8));
+            NIDX_HIP(cx.s_set_counts.reserve(8));
+            NIDX_HIP(hipMemsetAsync(cx.s_set_counts.p, 0, 8, st));
+            if (!cat) {
+                NIDX_HIP(launch_bitset_and_count(seg.alive.as<uint64_t>(), nullptr, cx.s_set_bits.as<uint64_t>(), words,
+                                                 cx.s_set_counts.as<unsigned long long>(), st));
+            } else {
+                // alive AND [d0, d1): the range as a bitset (ranks of an identity key would do the same; a fill + two shifts is less)
+                std::vector<uint64_t> mask(std::max<size_t>(words, 1), 0);
+                for (uint64_t d = d0; d < d1;) {
+                    if ((d & 63) == 0 && d + 64 <= d1) { mask[d >> 6] = ~0ull; d += 64; }
+                    else { mask[d >> 6] |= 1ull << (d & 63); d++; }
+                }
+                NIDX_HIP(cx.s_sub_bits.reserve(std::max<size_t>(words, 1) * 8));
+                NIDX_HIP(hipMemcpyAsync(cx.s_sub_bits.p, mask.data(), (size_t)words * 8, hipMemcpyHostToDevice, st));
+                NIDX_HIP(launch_bitset_and_count(cx.s_sub_bits.as<uint64_t>(), seg.alive.as<uint64_t>(), cx.s_set_bits.as<uint64_t>(), words,
+                                                 cx.s_set_counts.as<unsigned long long>(), st));
+                NIDX_HIP(hipStreamSynchronize(st));
+            }
             unsigned long long c = 0;
-            NIDX_HIP(hipMemcpyAsync(&c, idx->s_set_counts.p, 8, hipMemcpyDeviceToHost, st));
+            NIDX_HIP(hipMemcpyAsync(&c, cx.s_set_counts.p, 8, hipMemcpyDeviceToHost, st));
             NIDX_HIP(hipStreamSynchronize(st));
             *n_alive_out = c;
-            seg.n_alive = (int64_t)c;
+            if (!cat) seg.n_alive = (int64_t)c;
         }
     }
     NIDX_HIP(hipStreamSynchronize(st));

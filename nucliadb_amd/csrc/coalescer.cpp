@@ -106,22 +106,33 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
     // ---- admission (see Coalescer::max_callers) ----
     {
         const uint32_t cap0 = c.max_callers.load(std::memory_order_relaxed);
-        if (cap0 && c.reject_when_full.load(std::memory_order_relaxed) &&
-            c.next_ticket.load(std::memory_order_relaxed) - c.left.load(std::memory_order_relaxed) >= cap0) {
-            c.n_rejected.fetch_add(1, std::memory_order_relaxed);
-            return fail(NIDX_ERR_BUSY, "%u single-query requests are already inside the coalescer (coalesce_max_callers)", cap0);
+        if (cap0 && c.reject_when_full.load(std::memory_order_relaxed)) {
+            // `left` first: requests that leave between the two loads can only make the crowd look larger by the tickets taken
+            // meanwhile, never negative (the other order let `left` overtake the ticket count read before it: a huge unsigned
+            // difference and a spurious NIDX_ERR_BUSY on an idle coalescer)
+            const uint64_t gone0 = c.left.load(std::memory_order_seq_cst);
+            const int64_t inside = (int64_t)(c.next_ticket.load(std::memory_order_seq_cst) - gone0);
+            if (inside >= (int64_t)cap0) {
+                c.n_rejected.fetch_add(1, std::memory_order_relaxed);
+                return fail(NIDX_ERR_BUSY, "%u single-query requests are already inside the coalescer (coalesce_max_callers)", cap0);
+            }
         }
-        const uint64_t t = c.next_ticket.fetch_add(1, std::memory_order_acq_rel);
+        // the ticket / left hand-shake is a store-buffering pattern (a waiter publishes its ticket, then reads `left`; a leaver
+        // publishes `left`, then reads the tickets): sequentially consistent on both sides, so one of the two always sees the other
+        const uint64_t t = c.next_ticket.fetch_add(1, std::memory_order_seq_cst);
         std::atomic<uint32_t> &word = c.door[t % Coalescer::DOOR_SLOTS];
         bool waited = false;
         for (;;) {
-            const uint32_t cap = c.max_callers.load(std::memory_order_relaxed);
-            const uint32_t v = word.load(std::memory_order_acquire);
+            // the futex word BEFORE the cap and `left`: whoever changes either afterwards bumps the word (a leaver whose leaving
+            // makes it this ticket's turn; coalescer_admission when the cap changes), so the wait below returns at once instead of
+            // sleeping on a decision taken from stale values
+            const uint32_t v = word.load(std::memory_order_seq_cst);
+            const uint32_t cap = c.max_callers.load(std::memory_order_seq_cst);
             if (cap == 0) break;
             // a crowd of more than two doors' worth outside: half the door (every request needs a core to get in and out, and with
             // that many blocked threads the cores are the bottleneck: measured at 1 024 callers on 64 cores, door 128 serves 191 k
             // queries/s at p99 27 ms, door 256 153 k at 68 ms — while 256 callers want the whole 256: 340 k against 223 k)
-            const uint64_t gone = c.left.load(std::memory_order_acquire);
+            const uint64_t gone = c.left.load(std::memory_order_seq_cst);
             const uint32_t eff = c.next_ticket.load(std::memory_order_relaxed) - gone > 2ull * cap ? std::max(1u, cap / 2) : cap;
             if (t < gone + eff) break;
             waited = true;
@@ -134,12 +145,12 @@ int32_t VectorIndex::search_one(const float *query, const nidx_gpu_vector_search
         Coalescer &c;
         ~ActiveCount() {
             c.active.fetch_sub(1, std::memory_order_relaxed);
-            const uint64_t gone = c.left.fetch_add(1, std::memory_order_acq_rel) + 1;
-            const uint32_t cap = c.max_callers.load(std::memory_order_relaxed);
+            const uint64_t gone = c.left.fetch_add(1, std::memory_order_seq_cst) + 1;
+            const uint32_t cap = c.max_callers.load(std::memory_order_seq_cst);
             if (cap) {
                 // the tickets whose turn this makes — under the whole door and under the halved one (a waiter judges by the crowd it
                 // sees when it looks: both are told, so none sleeps through its turn) — are woken if they wait
-                const uint64_t tickets = c.next_ticket.load(std::memory_order_acquire);
+                const uint64_t tickets = c.next_ticket.load(std::memory_order_seq_cst);
                 const uint64_t turns[2] = {gone + cap - 1, gone + std::max(1u, cap / 2) - 1};
                 for (int i = 0; i < (turns[0] == turns[1] ? 1 : 2); i++) {
                     if (turns[i] >= tickets) continue;
@@ -299,9 +310,10 @@ std::shared_ptr<Coalescer> make_coalescer() {
 
 void VectorIndex::coalescer_admission(int32_t max_callers, int32_t reject_when_full) {
     if (max_callers >= 0) {
-        coalescer->max_callers.store((uint32_t)max_callers, std::memory_order_release);
-        for (uint32_t i = 0; i < Coalescer::DOOR_SLOTS; i++) {   // a raised bound lets everybody at the door look again
-            coalescer->door[i].fetch_add(1, std::memory_order_release);
+        coalescer->max_callers.store((uint32_t)max_callers, std::memory_order_seq_cst);
+        for (uint32_t i = 0; i < Coalescer::DOOR_SLOTS; i++) {   // a changed bound lets everybody at the door look again (the cap first,
+                                                                 // then the words: a waiter reads its word first, then the cap)
+            coalescer->door[i].fetch_add(1, std::memory_order_seq_cst);
             futex_wake_all(&coalescer->door[i]);
         }
     }

@@ -466,6 +466,10 @@ hipError_t launch_subquery_compact(const SubqueryLists &L, const SubqueryDev &sq
 // resident posting word: tfs[i] = tf | fieldnorm_ids[doc_ids[i]] << 24 (in place); *flag: bit 0 = a tf >= 2^24, bit 1 = a doc id >= n_docs
 hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
                                       uint32_t *flag, hipStream_t s);
+// several segments -> one term-major resident layout (bm25_aux.hip): segment postings [0, n_post) to dst_start[t] + (j - seg_off[t])
+hipError_t launch_bm25_concat_postings(const unsigned long long *seg_off, uint32_t n_terms, const unsigned long long *dst_start, const uint32_t *src_doc,
+                                       const uint32_t *src_tf, unsigned long long n_post, uint32_t doc_base, uint32_t *dst_doc, uint32_t *dst_tf,
+                                       hipStream_t s);
 // FacetCollector: counts[p] += |postings(term[p]) ∩ match bitset slot[p]|
 hipError_t launch_facet_count(const unsigned long long *term_offsets, const uint32_t *doc_ids, const uint32_t *pair_term,
                               const int *pair_slot, uint32_t n_pairs, const uint32_t *match_bits, uint32_t match_words,

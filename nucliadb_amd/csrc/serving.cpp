@@ -16,11 +16,14 @@
 //           (segment_search_exact) and merges on the host (the same Fssc, csrc/vector_index.cpp: fssc_merge).
 //
 // Results are those of nidx_gpu_vector_search for the same batch (tests/test_serving_gpu.py).
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "host_common.h"
 #include "vector_index.h"
@@ -33,6 +36,119 @@ namespace {
 // when it initialises, i.e. at the first HIP call of the process: this library's load is early enough for a host that links it.
 __attribute__((constructor)) void more_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 }  // namespace
+
+// ---- staging of host query rows ---------------------------------------------------------------------------------------------
+// The seam hands over HOST memory (VectorSearchRequest.vector: Vec<f32>, nidx_vector/src/request_types.rs:19-35), and a batch of
+// 1 024 x 768 rows is 3 MiB: copied row by row into the slot's pinned staging by the submitting thread alone that is ~0.3 ms — as long
+// as the device needs for the whole batch, so the copy, not the GPU, set the rate of the host-buffer entries (2.0 M queries/s against
+// 3.5 M from device-resident rows, round 4).  A few helper threads (process-wide, started on first use) share the rows of a batch with
+// the submitting thread in chunks; small batches are copied inline.
+namespace {
+struct StageJob {
+    const float *src;
+    float *dst;
+    uint32_t nq, d, dp, chunk_rows, n_chunks;
+    bool normalize;
+    std::atomic<uint32_t> next{0}, done{0};
+    uint32_t refs = 0;   // helper threads inside run() (under the pool's mutex)
+    void run() {         // claims chunks until none is left
+        for (;;) {
+            const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= n_chunks) return;
+            const uint32_t q0 = c * chunk_rows, q1 = std::min(nq, q0 + chunk_rows);
+            if (!normalize && d == dp) memcpy(dst + (size_t)q0 * dp, src + (size_t)q0 * d, (size_t)(q1 - q0) * d * 4);
+            else
+                for (uint32_t q = q0; q < q1; q++) {
+                    float *row = dst + (size_t)q * dp;
+                    if (normalize) normalize_row(src + (size_t)q * d, row, d);
+                    else memcpy(row, src + (size_t)q * d, (size_t)d * 4);
+                    for (uint32_t i = d; i < dp; i++) row[i] = 0.f;
+                }
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+};
+
+struct StagePool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<StageJob *> jobs;
+    std::vector<std::thread> threads;
+    bool stop = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
+            if (stop) return;
+            StageJob *j = jobs.front();
+            if (j->next.load(std::memory_order_relaxed) >= j->n_chunks) {   // every chunk is claimed: nothing left to help with
+                jobs.pop_front();
+                continue;
+            }
+            j->refs++;
+            lk.unlock();
+            j->run();
+            lk.lock();
+            if (--j->refs == 0) cv_done.notify_all();
+        }
+    }
+    void ensure(uint32_t n) {
+        std::lock_guard<std::mutex> lk(mu);
+        while (threads.size() < n) threads.emplace_back([this] { worker(); });
+    }
+    // copies the rows of `j` with the helpers' help; returns when every row is in place and no helper still looks at the job
+    void run(StageJob &j) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.push_back(&j);
+        }
+        cv_work.notify_all();
+        j.run();
+        std::unique_lock<std::mutex> lk(mu);
+        for (auto it = jobs.begin(); it != jobs.end(); ++it)
+            if (*it == &j) { jobs.erase(it); break; }
+        cv_done.wait(lk, [&] { return j.refs == 0; });
+        lk.unlock();
+        while (j.done.load(std::memory_order_acquire) < j.n_chunks) std::this_thread::yield();   // (all claimed, refs == 0: already true)
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+StagePool &stage_pool() {
+    static StagePool p;
+    return p;
+}
+std::atomic<int> g_stage_threads{-1};   // helpers besides the submitting thread; -1 = not yet read from the environment
+}  // namespace
+
+// dst[q][0..dp) = src[q][0..d) (normalised when the index normalises its queries), zero padded
+void stage_query_rows(const float *src, float *dst, uint32_t nq, uint32_t d, uint32_t dp, bool normalize) {
+    int helpers = g_stage_threads.load(std::memory_order_relaxed);
+    if (helpers < 0) {
+        const char *e = getenv("NIDX_GPU_STAGE_THREADS");
+        helpers = e ? std::max(0, std::min(atoi(e), 16)) : 3;
+        g_stage_threads.store(helpers, std::memory_order_relaxed);
+    }
+    StageJob j;
+    j.src = src, j.dst = dst, j.nq = nq, j.d = d, j.dp = dp, j.normalize = normalize;
+    j.chunk_rows = std::max<uint32_t>(1, (64u << 10) / (dp * 4u));   // ~64 KiB per chunk
+    j.n_chunks = (nq + j.chunk_rows - 1) / j.chunk_rows;
+    if (helpers == 0 || (size_t)nq * dp * 4 < ((size_t)256 << 10)) {
+        j.run();
+        return;
+    }
+    StagePool &P = stage_pool();
+    P.ensure((uint32_t)helpers);
+    P.run(j);
+}
+
+void set_stage_threads(int32_t n) { g_stage_threads.store(std::max(0, std::min(n, 16)), std::memory_order_relaxed); }
 
 struct SearchSlot {
     bool busy = false, waiting = false;
@@ -127,13 +243,17 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         std::unique_lock<std::mutex> lk(P.mu);
         for (;;) {
             // `depth` bounds the tickets outstanding, also after it was lowered below the number of slots that exist
+            // A blocking search (nidx_gpu_vector_search of a multi-segment index) may take one of 4 slots beyond the budget: its caller
+            // may itself hold `depth` tickets it has not waited for yet and would otherwise wait here for a slot only it can free;
+            // the extra slots are held by blocking calls alone, which give them back by themselves.
             uint32_t n_busy = 0;
             for (auto &s : P.slots) n_busy += s->busy ? 1u : 0u;
-            if (n_busy < P.depth)
+            const uint32_t budget = blocking ? P.depth + 4u : P.depth;
+            if (n_busy < budget)
                 for (auto &s : P.slots)
                     if (!s->busy) { slot = s.get(); break; }
             if (slot) break;
-            if (n_busy < P.depth) {
+            if (n_busy < budget) {
                 std::unique_ptr<SearchSlot> ns(new SearchSlot());
                 NIDX_HIP(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
                 NIDX_HIP(hipEventCreateWithFlags(&ns->done, hipEventDisableTiming));
@@ -167,12 +287,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         } else {
             NIDX_HIP(sl.pin_in.reserve((size_t)nq * dp * 4));
             float *qpad = sl.pin_in.as<float>();
-            for (uint32_t q = 0; q < nq; q++) {
-                float *row = qpad + (size_t)q * dp;
-                if (cfg.normalize_vectors) normalize_row(queries + (size_t)q * d, row, d);
-                else memcpy(row, queries + (size_t)q * d, (size_t)d * 4);
-                for (uint32_t i = d; i < dp; i++) row[i] = 0.f;
-            }
+            stage_query_rows(queries, qpad, nq, d, dp, cfg.normalize_vectors);
             NIDX_HIP(sl.d_queries.reserve((size_t)nq * dp * 4));
             NIDX_HIP(hipMemcpyAsync(sl.d_queries.p, qpad, (size_t)nq * dp * 4, hipMemcpyHostToDevice, sl.stream));
             sl.dq = sl.d_queries.as<float>();

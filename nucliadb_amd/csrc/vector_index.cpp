@@ -1002,12 +1002,7 @@ int32_t VectorIndex::search_host(const float *queries, uint32_t nq, const nidx_g
     const uint32_t dp = (d + 3u) & ~3u;
     NIDX_HIP(pin_in.reserve((size_t)nq * dp * 4));
     float *qpad = pin_in.as<float>();
-    for (uint32_t q = 0; q < nq; q++) {
-        float *row = qpad + (size_t)q * dp;
-        if (cfg.normalize_vectors) normalize_row(queries + (size_t)q * d, row, d);
-        else memcpy(row, queries + (size_t)q * d, (size_t)d * 4);
-        for (uint32_t i = d; i < dp; i++) row[i] = 0.f;
-    }
+    stage_query_rows(queries, qpad, nq, d, dp, cfg.normalize_vectors);
     NIDX_HIP(scratch_queries.reserve((size_t)nq * dp * 4));
     NIDX_HIP(hipMemcpyAsync(scratch_queries.p, qpad, (size_t)nq * dp * 4, hipMemcpyHostToDevice, stream));
     const size_t block_words = out_block_words(nq, k);
@@ -1186,7 +1181,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len) try {
     return (int32_t)have;
 } NIDX_ABI_CATCH
 
-int32_t nidx_gpu_abi_version(void) { return 4; }
+int32_t nidx_gpu_abi_version(void) { return NIDX_GPU_ABI_VERSION; }
 
 int32_t nidx_gpu_device_count(int32_t *count_out) try {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");
@@ -1259,6 +1254,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "coalesce_max_callers") idx->coalescer_admission(std::max(0, (int)value), -1);   // 0 = unbounded
     else if (n == "coalesce_reject_when_full") idx->coalescer_admission(-1, value != 0);
     else if (n == "pipeline_depth") idx->pipeline_config(value);
+    else if (n == "stage_threads") set_stage_threads(value);   // helper threads that share the copy of host query rows into pinned staging (process-wide; 0 = the caller alone)
     else if (n == "closest_prefetch") idx->closest_prefetch = value != 0;   // measurement knob of closest_up_nodes' edge prefetch: no result depends on it
     else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host
     else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));

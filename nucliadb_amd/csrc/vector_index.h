@@ -12,6 +12,9 @@ namespace nidx {
 
 bool use_hnsw(uint64_t total_nodes, uint64_t matching_nodes, uint64_t top_k, bool has_rabitq);
 void normalize_row(const float *in, float *out, uint32_t d);
+// serving.cpp: host query rows -> pinned staging (normalised / zero padded), shared with a few helper threads for large batches
+void stage_query_rows(const float *src, float *dst, uint32_t nq, uint32_t d, uint32_t dp, bool normalize);
+void set_stage_threads(int32_t n);
 
 // One OpenSegment in HBM (nidx_vector/src/segment.rs:288-357 Retriever + graph).
 struct VectorSegment {

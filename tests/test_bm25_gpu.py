@@ -368,7 +368,7 @@ def test_boolean_trees_of_any_depth_match_the_oracle(orc):
 
 def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
     """nidx_gpu_bm25_search_submit / _wait: several batches in flight, waited for out of order, give what nidx_gpu_bm25_search gives
-    for each; a fifth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term
+    for each; a ninth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term
     sets) run inside submit and still come back through wait."""
     import ctypes as C
 
@@ -379,13 +379,13 @@ def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
                for n in (64, 1, 200, 33)]
     want = [s.search_batch(b, 20) for b in batches]
     for _ in range(3):
-        tickets = [s.submit(b, 20) for b in batches]
+        tickets = [s.submit(b, 20) for b in batches + batches]
         with pytest.raises(_lib.NidxGpuError) as e:
             s.submit(batches[0], 20)
         assert "not been waited" in str(e.value)
-        for i in (2, 0, 3, 1):
+        for i in (2, 0, 7, 3, 5, 1, 6, 4):
             got = s.wait(tickets[i])
-            for g, w in zip(got, want[i]):
+            for g, w in zip(got, want[i % 4]):
                 assert np.array_equal(g.view(np.uint32) if g.dtype == np.float32 else g, w.view(np.uint32) if w.dtype == np.float32 else w), i
         out = np.zeros(1, np.uint32)
         assert _lib.lib().nidx_gpu_bm25_search_wait(s._handle, tickets[0], None, None, out.ctypes.data, None, None) == _lib.NIDX_ERR_INVALID_ARGUMENT

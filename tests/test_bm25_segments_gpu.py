@@ -1,0 +1,269 @@
+"""An index of SEVERAL tantivy segments (the log-merge policy leaves several: nidx/src/settings.rs:246-253) is resident as ONE
+term-major posting layout over doc + base[segment] and searched in one launch (csrc/bm25_index.cpp: bm25_upload_concatenated).
+tantivy searches the segments of an index under one searcher.search with searcher-wide Bm25Weight statistics and merges by
+(score, DocAddress) — nidx_text/src/reader.rs:433-435, nidx_paragraph/src/reader.rs:244-348 — so every answer must equal
+
+  * the answer of the same corpus opened as one segment (that path is pinned to the oracle by tests/test_bm25_gpu.py and
+    tests/test_bm25_aux_gpu.py) after mapping doc -> (segment, doc - base), and
+  * the answer of round 4's path: one resident segment per opened segment, a launch + transfer per segment and a host merge
+    (NIDX_GPU_BM25_SEGMENT_LOOP=1),
+
+bit for bit: doc addresses, ranks, score bits, totals, facet counts, order values — through every collector of the scorer."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from nucliadb_amd import _lib
+from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment, Clause, SearchAfter
+
+pytestmark = pytest.mark.gpu
+S, M, N = _lib.OCCUR_SHOULD, _lib.OCCUR_MUST, _lib.OCCUR_MUST_NOT
+FREQ, BASIC, CONST = _lib.TF_FREQ, _lib.TF_BASIC, _lib.CONST_SCORE
+VOCAB = 600
+
+
+def zipf_docs(rng, n_docs, vocab, mean_len=14):
+    lens = np.clip(np.round(rng.lognormal(np.log(mean_len), 0.6, n_docs)), 2, 400).astype(np.int64)
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    flat = rng.choice(vocab, size=int(lens.sum()), p=p)
+    return np.split(flat, np.cumsum(lens)[:-1])
+
+
+def bitset_of(mask):
+    words = np.zeros((mask.size + 63) // 64, np.uint64)
+    for i in np.nonzero(mask)[0]:
+        words[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    return words
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+class Split:
+    """One corpus opened three ways: whole, as segments (one launch), as segments (a loop over them)."""
+
+    def __init__(self, monkeypatch, docs, cuts, alive_mask=None, with_positions=False):
+        self.cuts = [0] + list(cuts) + [len(docs)]
+        self.base = np.array(self.cuts[:-1], np.int64)
+        am = alive_mask
+        self.whole_seg = Bm25Segment.from_term_docs(docs, VOCAB, alive=None if am is None else bitset_of(am), with_positions=with_positions)
+        self.part_segs = [Bm25Segment.from_term_docs(docs[a:b], VOCAB, alive=None if am is None or am[a:b].all() else bitset_of(am[a:b]),
+                                                     with_positions=with_positions) for a, b in zip(self.cuts[:-1], self.cuts[1:])]
+        monkeypatch.delenv("NIDX_GPU_BM25_SEGMENT_LOOP", raising=False)
+        self.whole = Bm25Searcher.open([self.whole_seg])
+        self.parts = Bm25Searcher.open(self.part_segs)
+        monkeypatch.setenv("NIDX_GPU_BM25_SEGMENT_LOOP", "1")
+        self.loop = Bm25Searcher.open(self.part_segs)
+        monkeypatch.delenv("NIDX_GPU_BM25_SEGMENT_LOOP", raising=False)
+
+    def to_whole(self, docaddr):
+        a = np.asarray(docaddr, np.uint64)
+        return (self.base[(a >> np.uint64(32)).astype(np.int64)] + (a & np.uint64(0xFFFFFFFF)).astype(np.int64)).astype(np.int64)
+
+    def to_parts(self, doc):
+        s = int(np.searchsorted(np.array(self.cuts[1:]), doc, side="right"))
+        return (s << 32) | (int(doc) - self.cuts[s])
+
+    def close(self):
+        for s in (self.whole, self.parts, self.loop):
+            s.close()
+
+    def check(self, queries, k, after_whole=None, **kw):
+        """search_batch_ex on the three searchers; `after_whole` are cursors in the whole corpus' numbering"""
+        aw = ap = None
+        if after_whole is not None:
+            aw = after_whole
+            ap = [None if a is None else SearchAfter(a.score, a.tie_break, self.to_parts(a.docaddr)) for a in after_whole]
+        rw = self.whole.search_batch_ex(queries, k, aw, **kw)
+        rp = self.parts.search_batch_ex(queries, k, ap, **kw)
+        rl = self.loop.search_batch_ex(queries, k, ap, **kw)
+        for name, r in (("one launch", rp), ("loop", rl)):
+            assert np.array_equal(r["total"], rw["total"]), name
+            assert np.array_equal(r["count"], rw["count"]), name
+            assert np.array_equal(r["postings"], rw["postings"]), name
+            for i in range(len(queries)):
+                n = int(rw["count"][i])
+                assert np.array_equal(self.to_whole(r["docaddr"][i, :n]), rw["docaddr"][i, :n].astype(np.int64)), (name, i)
+                assert np.array_equal(bits(r["score"][i, :n]), bits(rw["score"][i, :n])), (name, i)
+                assert np.array_equal(r["order_value"][i, :n], rw["order_value"][i, :n]), (name, i)
+            if rw["facet_counts"] is not None:
+                for a, b in zip(r["facet_counts"], rw["facet_counts"]):
+                    assert np.array_equal(a, b), name
+        assert np.array_equal(rp["docaddr"], rl["docaddr"])
+        return rw, rp
+
+
+@pytest.fixture(scope="module")
+def docs():
+    return zipf_docs(np.random.default_rng(20250925), 9000, VOCAB)
+
+
+def random_queries(rng, n, max_terms=6, top=300):
+    out = []
+    for _ in range(n):
+        q = [Clause(int(rng.integers(0, top)), int(rng.choice([S, S, S, M, N])), int(rng.choice([FREQ, BASIC, CONST])), float(rng.choice([1.0, 0.5, 2.0])))
+             for _ in range(int(rng.integers(1, max_terms + 1)))]
+        out.append(q)
+    return out
+
+
+def test_plain_queries_pages_and_cursors(monkeypatch, docs):
+    """OR / boolean queries at several page sizes; the log-merge shape (one large segment, some small ones, an EMPTY one); dead
+    documents in some segments only; search-after cursors (all three tie rules) that cross segment borders."""
+    rng = np.random.default_rng(1)
+    alive = rng.random(len(docs)) < 0.8
+    alive[:5200] = True   # the first segment has no deletions
+    sp = Split(monkeypatch, docs, [5200, 7900, 7900, 8500], alive)
+    queries = [[Clause(int(t), S, BASIC) for t in rng.integers(0, 40, 3)] for _ in range(40)]   # tf == 1: many exact score ties
+    queries += random_queries(rng, 60) + [[], [Clause(0), Clause(1), Clause(2)]]
+    for k in (1, 20, 64, 201):
+        sp.check(queries, k)
+    rw, _ = sp.check(queries, 30)
+    for rank, ties in ((7, [1] * len(queries)), (3, [0, 1, 2] * len(queries)), (29, [1, 2] * len(queries))):
+        after = [SearchAfter(float(rw["score"][i, rank]), int(ties[i]), int(rw["docaddr"][i, rank])) if rw["count"][i] > rank else None
+                 for i in range(len(queries))]
+        sp.check(queries, 20, after_whole=after)
+    # a cursor that names no document: past the end of a segment, in the empty segment, past the last segment
+    q = queries[:6]
+    sc = [float(rw["score"][i, 2]) for i in range(6)]
+    for addr in ((0 << 32) | 5200, (0 << 32) | 0xFFFFFFFE, (2 << 32) | 0, (2 << 32) | 17, (4 << 32) | 499, (4 << 32) | 500, (9 << 32) | 0):
+        ap = [SearchAfter(sc[i], 1, addr) for i in range(6)]
+        rp = sp.parts.search_batch_ex(q, 20, ap)
+        rl = sp.loop.search_batch_ex(q, 20, ap)
+        for name in ("docaddr", "count", "total"):
+            assert np.array_equal(rp[name], rl[name]), (hex(addr), name)
+        assert np.array_equal(bits(rp["score"]), bits(rl["score"])), hex(addr)
+    sp.close()
+
+
+def test_collectors_over_segments(monkeypatch, docs):
+    """TopDocs ordered by a fast field (ranks are taken over the values of ALL segments), facet counts, term sets and their
+    complements, phrases (with slop), nested queries — nidx_text/src/reader.rs:367-451, nidx_paragraph/src/reader.rs:244-348."""
+    rng = np.random.default_rng(2)
+    alive = rng.random(len(docs)) < 0.9
+    sp = Split(monkeypatch, docs, [300, 4100, 8800], alive, with_positions=True)
+    created = rng.integers(0, 50, len(docs)).astype(np.int64)        # many equal values: ties broken by DocAddress
+    modified = rng.integers(-10**12, 10**12, len(docs)).astype(np.int64)
+    for f, v in ((0, created), (1, modified)):
+        sp.whole.set_fast_field(0, f, v)
+        for s_ in (sp.parts, sp.loop):
+            for i, (a, b) in enumerate(zip(sp.cuts[:-1], sp.cuts[1:])):
+                s_.set_fast_field(i, f, v[a:b])
+    queries = random_queries(rng, 40)
+    for field in (0, 1):
+        for desc in (True, False):
+            sp.check(queries, 25, order_field=field, order_desc=desc)
+    facets = [[int(t) for t in rng.integers(0, 200, int(rng.integers(0, 5)))] for _ in queries]
+    sp.check(queries, 10, facets=facets)
+    ex = []
+    for _ in range(24):
+        q = [Clause(int(rng.integers(0, 200)))]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            q.append(Clause(0, int(rng.choice([S, M])), CONST, 0.5, term_set=[int(t) for t in rng.integers(0, VOCAB, 6)]))
+        elif kind == 1:
+            q.append(Clause(0, M, CONST, 1.0, term_set=[int(t) for t in rng.integers(0, 30, 2)], complement=True))
+        elif kind == 2:
+            a, b = (int(t) for t in rng.integers(0, 12, 2))
+            q.append(Clause(0, int(rng.choice([S, M])), FREQ, 1.0, term_set=[a, b], phrase=True, slop=int(rng.choice([0, 0, 2]))))
+        else:
+            q.append(Clause(0, S, FREQ, 2.0, subquery=[Clause(int(rng.integers(0, 60)), M), Clause(int(rng.integers(0, 60)), M),
+                                                       Clause(int(rng.integers(0, 200)), N)]))
+        ex.append(q)
+    ex.append([Clause(0, M, CONST, 1.0, term_set=[3], complement=True)])   # only a complement: every live document without term 3
+    sp.check(ex, 20)
+    sp.check(ex, 20, facets=[[1, 2, 3]] * len(ex))
+    sp.close()
+
+
+def test_deletions_and_prefilter_address_one_segment(monkeypatch, docs):
+    """nidx_gpu_bm25_apply_deletions(segment, terms) removes the documents of those posting lists IN THAT SEGMENT only
+    (open_index_with_deletions applies a deletion key to the segments older than it, nidx_tantivy/src/index_reader.rs:39-74);
+    the prefilter's DocAddresses name the opened segments."""
+    rng = np.random.default_rng(3)
+    sp = Split(monkeypatch, docs, [2500, 2600, 7000])
+    queries = random_queries(rng, 40)
+    for s_ in (sp.parts, sp.loop):
+        assert s_.apply_deletions(1, []) == 100
+    dead = np.zeros(len(docs), bool)
+    for seg, terms in ((2, [5, 9, 40]), (0, [7]), (2, [11]), (3, [2, 3])):
+        a, b = sp.cuts[seg], sp.cuts[seg + 1]
+        for d in range(a, b):
+            if np.isin(docs[d], terms).any():
+                dead[d] = True
+        want_alive = int((~dead[a:b]).sum())
+        for s_ in (sp.parts, sp.loop):
+            assert s_.apply_deletions(seg, terms) == want_alive
+    whole_dead = Bm25Searcher.open([Bm25Segment.from_term_docs(docs, VOCAB, alive=bitset_of(~dead))])
+    rw = whole_dead.search_batch_ex(queries, 20)
+    for s_ in (sp.parts, sp.loop):
+        r = s_.search_batch_ex(queries, 20)
+        assert np.array_equal(r["total"], rw["total"]) and np.array_equal(r["count"], rw["count"])
+        for i in range(len(queries)):
+            n = int(rw["count"][i])
+            assert np.array_equal(sp.to_whole(r["docaddr"][i, :n]), rw["docaddr"][i, :n].astype(np.int64)), i
+            assert np.array_equal(bits(r["score"][i, :n]), bits(rw["score"][i, :n])), i
+    ops = [(_lib.FILTER_PUSH_LISTS, 0, 2), (_lib.FILTER_PUSH_LISTS, 2, 3), (_lib.FILTER_NOT, 0, 0), (_lib.FILTER_AND, 0, 0)]
+    gw, lw = whole_dead.prefilter(ops, [4, 6, 1])
+    for s_ in (sp.parts, sp.loop):
+        g, l = s_.prefilter(ops, [4, 6, 1])
+        assert l == lw and np.array_equal(sp.to_whole(g), gw.astype(np.int64))
+    whole_dead.close()
+    sp.close()
+
+
+def test_pipeline_takes_several_segments_and_several_submitting_threads(monkeypatch, docs):
+    """nidx_gpu_bm25_search_submit / _wait on a multi-segment index go through the asynchronous path (round 4 fell back to the
+    blocking loop for anything but one segment), and two threads may submit at once: every slot plans and launches on a context
+    of its own."""
+    rng = np.random.default_rng(4)
+    sp = Split(monkeypatch, docs, [6000, 8200, 8700])
+    batches = [random_queries(rng, int(n), max_terms=4) for n in (64, 1, 200, 33, 128, 7)]
+    want = [sp.whole.search_batch(b, 20) for b in batches]
+
+    def same(got, w):
+        d, sc, c, t, p = got
+        assert np.array_equal(c, w[2]) and np.array_equal(t, w[3]) and np.array_equal(p, w[4])
+        for i in range(len(c)):
+            assert np.array_equal(sp.to_whole(d[i, : c[i]]), w[0][i, : c[i]].astype(np.int64))
+            assert np.array_equal(bits(sc[i, : c[i]]), bits(w[1][i, : c[i]]))
+
+    tickets = [sp.parts.submit(b, 20) for b in batches]
+    for i in (2, 0, 5, 3, 1, 4):
+        same(sp.parts.wait(tickets[i]), want[i])
+    errors = []
+
+    def worker(order):
+        try:
+            L = _lib.lib()
+            for rep in range(6):
+                for i in order:
+                    b = batches[i]
+                    offsets = np.zeros(len(b) + 1, np.uint64)
+                    flat = [c for q in b for c in q]
+                    offsets[1:] = np.cumsum([len(q) for q in b])
+                    cl = (_lib.Bm25ClauseC * max(1, len(flat)))()
+                    for j, c in enumerate(flat):
+                        cl[j].term, cl[j].occur, cl[j].mode, cl[j].boost = c.term, c.occur, c.mode, c.boost
+                    opt = _lib.Bm25SearchOptionsC()
+                    opt.k, opt.order_field = 20, -1
+                    t = C.c_uint64(0)
+                    _lib.check(L.nidx_gpu_bm25_search_submit(sp.parts._handle, cl, offsets.ctypes.data, len(b), C.byref(opt), C.byref(t)))
+                    d, sc = np.zeros((len(b), 20), np.uint64), np.zeros((len(b), 20), np.float32)
+                    c, tt, pp = np.zeros(len(b), np.uint32), np.zeros(len(b), np.uint64), np.zeros(len(b), np.uint64)
+                    _lib.check(L.nidx_gpu_bm25_search_wait(sp.parts._handle, t.value, d.ctypes.data, sc.ctypes.data, c.ctypes.data, tt.ctypes.data, pp.ctypes.data))
+                    same((d, sc, c, tt, pp), want[i])
+        except BaseException as e:   # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0], [2, 4, 0, 5, 1, 3])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+    sp.close()
