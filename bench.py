@@ -96,17 +96,60 @@ def parse():
     return p.parse_args()
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): this process becomes the launcher — N children
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per GPU, rank 0 prints the one JSON line (its stdout is
+    this process's).  Fewer than N GPUs is an error, not a silent 1-GPU run — unless NIDX_BENCH_SAME_DEVICE=1 (validation on a 1-GPU
+    box): every rank then shares GPU 0 and the library's exchange runs over its shared-memory transport."""
+    import socket
+    import subprocess
+
+    n = a.gpus
+    same = os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not same:
+        print("ERROR: --gpus %d but this node has %d GPU(s) visible (NIDX_BENCH_SAME_DEVICE=1 shares GPU 0 between the ranks: validation only)" % (n, have),
+              file=sys.stderr)
+        sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, left = 0, list(procs)
+    while left:
+        time.sleep(0.2)
+        for p_ in list(left):
+            code = p_.poll()
+            if code is None:
+                continue
+            left.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code
+                for q_ in left:   # one rank failed: the others would wait for it in a collective for ever
+                    q_.terminate()
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
+        # a launcher's WORLD_SIZE is the truth about the job; a flag that disagrees with it is a mistake worth a line on stderr
+        print("WARNING: --gpus %d but WORLD_SIZE=%d: running as %d rank(s)" % (a.gpus, world, world), file=sys.stderr)
         a.gpus = world
     if a.waves_per_query:
         os.environ["NIDX_GPU_WAVES_PER_QUERY"] = str(a.waves_per_query)
-    # NIDX_BENCH_SAME_DEVICE=1 (validation only): every rank uses GPU 0 and the collectives go over gloo,
-    # so the N>1 code path can be exercised on a single-GPU box.  The driver never sets it.
+    # NIDX_BENCH_SAME_DEVICE=1 (validation only): every rank uses GPU 0; torch.distributed (control traffic: query broadcast, barriers)
+    # goes over gloo and the DATA-PATH exchange over the library's shared-memory transport, so the N>1 code path — the library's own
+    # exchange included — can be exercised on a single-GPU box.  The driver never sets it.
     same_device = os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1"
     if same_device:
         local_rank = 0
@@ -505,7 +548,8 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     del x
     torch.cuda.empty_cache()
     t0 = time.time()
-    if not (gpath and os.path.exists(gpath)):
+    cached_used = bool(gpath and os.path.exists(gpath))
+    if not cached_used:
         if a.build_ef_upper > 1:
             _lib.check(L.nidx_gpu_vector_set_tunable(h, b"build_ef_upper", a.build_ef_upper))
         _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
@@ -515,6 +559,26 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             g_.tofile(gpath)
             del g_, _e
     build_s = time.time() - t0
+    build_blk = None
+    if not (gpath and cached_used):
+        # the build on the roofline (north_star: "build + k-NN query distance kernels"; HnswBuilder, hnsw/build.rs:28-167): the build
+        # kernels count their distance evaluations, expansions and the rows the neighbour-selection heuristic reads, like the search kernel
+        bst = (C.c_uint64 * 8)()
+        _lib.check(L.nidx_gpu_vector_build_stats(h, bst))
+        if int(bst[2]) != 2**64 - 1 and int(bst[1]) > 0:
+            secs = int(bst[1]) / 1e6
+            rows = int(bst[2]) + int(bst[4]) + int(bst[5])
+            alg = rows * 4.0 * d + int(bst[3]) * 256.0
+            build_blk = {
+                "nodes": int(bst[0]), "seconds_of_kernels": secs, "inserts_per_s": int(bst[0]) / secs,
+                "search_distance_evals_per_insert": int(bst[2]) / max(1, int(bst[0])), "search_expansions_per_insert": int(bst[3]) / max(1, int(bst[0])),
+                "select_rows_per_insert": int(bst[4]) / max(1, int(bst[0])), "prune_rows_per_insert": int(bst[5]) / max(1, int(bst[0])),
+                "reverse_link_appends_per_insert": int(bst[6]) / max(1, int(bst[0])), "prunes_per_insert": int(bst[7]) / max(1, int(bst[0])),
+                "roofline": {"kernel": "insert_search_kernel + select_link_kernel + reverse_link_kernel (whole build)", "bound": "hbm",
+                             "algorithmic_bytes": alg, "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+                             "definition": "(search evaluations + rows read by select_neighbours_heuristic and the reverse-link prunes) x 4 D + expansions x 256 B, "
+                                           "counted by the kernels, over the time from the first batch's launch to the last one's completion"},
+                "reference": "nidx_vector/src/hnsw/build.rs:57-166"}
     if a.ef_upper > 1:
         _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", a.ef_upper))
     for kv in filter(None, os.environ.get("NIDX_BENCH_TUNABLES", "").split(",")):   # A/B runs: name=value[,name=value] (launch-shape / measurement knobs)
@@ -540,8 +604,10 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         return int(f.value)
 
     comm = None
-    if world > 1 and not os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1":
-        # the product's own exchange (csrc/shard_comm.cpp: RCCL inside the library); torch.distributed only ships the 128-byte id
+    same_device = os.environ.get("NIDX_BENCH_SAME_DEVICE") == "1"
+    if world > 1:
+        # the product's own exchange (csrc/shard_comm.cpp: RCCL inside the library — or, when the ranks share one GPU for validation,
+        # the library's shared-memory transport: same pack / gather layout / merge kernels); torch.distributed only ships the 128-byte id
         from nucliadb_amd.shard_merge import ShardComm
 
         # (if the library's communicator cannot be set up on this node every rank falls back to the same exchange through
@@ -550,7 +616,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         idt = torch.zeros(_lib.SHARD_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         try:
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(ShardComm.unique_id()), dtype=torch.uint8))
+                idt.copy_(torch.frombuffer(bytearray(ShardComm.unique_id_shm() if same_device else ShardComm.unique_id()), dtype=torch.uint8))
         except Exception as e:
             print("WARNING: nidx_gpu_shard_comm_unique_id failed: %r" % (e,), file=sys.stderr)
             ok.zero_()
@@ -567,7 +633,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
                 comm = None
 
     def exchange_torch(out):
-        # the same exchange through torch.distributed (cross-check of the product path; the only path with NIDX_BENCH_SAME_DEVICE)
+        # the same exchange through torch.distributed (cross-check of the product path)
         from nucliadb_amd.shard_merge import exchange_and_merge_vector
 
         ov, osc, oc = out
@@ -665,14 +731,18 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     # steps of this workload are 6 ms: too short to time honestly), and `ms_per_step` is the mean over every timed step
     repeats, elapsed = 1, 0.0
     if a.steps > 0:
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            step(a.warmup + i)
-        drain()
-        barrier()
-        probe = time.perf_counter() - t0
-        repeats = max(1, int(np.ceil(a.min_timed_s / max(probe, 1e-6))))
+        # the pass count is sized from a WARM probe: the first pass over the pool runs up to 2 x slower than the steady state (cold
+        # TLBs / caches / clocks), and a count taken from it left the timed region at half the length asked for (round 4: 0.49 s)
+        probe = 0.0
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(a.warmup + i)
+            drain()
+            barrier()
+            probe = time.perf_counter() - t0
+        repeats = max(1, int(np.ceil(1.1 * a.min_timed_s / max(probe, 1e-6))))
         if world > 1:
             t = torch.tensor([repeats], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -778,7 +848,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
             "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "recall_hist": recall_hist, "evals": float(np.mean(evals_q)),
             "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
-            "build_s": build_s, "exchange_check": exchange_check, "library_exchange": comm is not None, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
+            "build_s": build_s, "exchange_check": exchange_check, "library_exchange": comm is not None, "exchange_transport": (None if comm is None else "shm" if same_device else "rccl"), "build": build_blk, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
         }
     if not headline:
         L.nidx_gpu_vector_close(h)
@@ -819,9 +889,54 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
                 t1 = time.perf_counter()
             _lib.check(L.nidx_gpu_vector_search(h, qh.ctypes.data, B, C.byref(p), None, None, None, hv.ctypes.data,
                                                 hs_.ctypes.data, hc.ctypes.data, None))
-        extra["host_buffer_queries_per_s"] = B * reps / (time.perf_counter() - t1)
+        extra["host_buffer_blocking_queries_per_s"] = B * reps / (time.perf_counter() - t1)
         if got0 is not None:
             extra["host_buffer_equals_device_entry"] = bool(np.array_equal(hv, got0[0].view(np.uint32)) and np.array_equal(hs_.view(np.uint32), got0[1].view(np.uint32)))
+        # (2b) what the seam really offers (VectorSearchRequest.vector: Vec<f32>, nidx_vector/src/request_types.rs:19-35): HOST query
+        # rows in, hits in host arrays out, through the same pipeline as `value` — nidx_gpu_vector_search_submit / _wait, `nfl` batches
+        # in flight; the rows are staged into pinned memory by the submitting thread and the library's helper threads, 3 MiB over
+        # PCIe per batch
+        if not do_exchange:
+            qhost = [qpool[i].cpu().numpy() for i in range(n_pool)]
+            tick = []
+
+            def host_step(i):
+                if len(tick) == nfl:
+                    t_, j_ = tick.pop(0)
+                    hv_, hs2_, hc_ = host_out[j_]
+                    _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
+                t = C.c_uint64(0)
+                _lib.check(L.nidx_gpu_vector_search_submit(h, qhost[i % n_pool].ctypes.data, B, d, C.byref(p_hnsw), None, C.byref(t)))
+                tick.append((t.value, i % nfl))
+
+            def host_drain():
+                while tick:
+                    t_, j_ = tick.pop(0)
+                    hv_, hs2_, hc_ = host_out[j_]
+                    _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
+
+            for i in range(max(4, a.warmup)):
+                host_step(i)
+            host_drain()
+            n_host = max(a.steps, int(steps_timed * 0.5))
+            t1 = time.perf_counter()
+            for i in range(n_host):
+                host_step(i)
+            host_drain()
+            dt_host = time.perf_counter() - t1
+            extra["host_buffer_queries_per_s"] = B * n_host / dt_host
+            extra["host_buffer_fraction_of_value"] = (B * n_host / dt_host) / (B * steps_timed / elapsed)
+            extra["host_buffer_entry"] = ("nidx_gpu_vector_search_submit / _wait: HOST query rows in (staged through pinned memory by the submitting "
+                                          "thread + the library's helper threads, 3 MiB over PCIe per batch), hits in host arrays out, %d batches in flight, %d timed" % (nfl, n_host))
+            if got0 is not None:
+                host_step(0)
+                host_drain()
+                hv_, hs2_, hc_ = host_out[0]
+                same_h = bool(np.array_equal(hc_, got0[2].view(np.uint32)) and np.array_equal(hv_, got0[0].view(np.uint32)) and
+                              np.array_equal(hs2_.view(np.uint32), got0[1].view(np.uint32)))
+                extra["host_buffer_pipelined_equals_device_entry"] = same_h
+                if not same_h:
+                    FAILURES.append("submit/wait from host rows delivered other hits than the device entry")
         # (3) the reference's request shape: one query per call from many blocking threads (shard_search.rs:139-153),
         # coalesced into batched launches by csrc/coalescer.cpp
         if a.single_query_calls > 0:
@@ -932,7 +1047,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     if a.bm25_block and world == 1:
         try:
             bm = Bm25Bench(a, L, dev, rank, n)
-            bm25_blk = bm.timed_block(rank)
+            bm25_blk = bm.timed_block(rank, dev)
             cpu_v = cpu.get("value") if isinstance(cpu, dict) else None
             cpu_b = (bm25_blk.get("cpu_baseline") or {}).get("queries_per_s")
             hybrid_blk = hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_v, cpu_b)
@@ -1079,6 +1194,8 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
             cpu["segment_regime"] = segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0)
             if cpu["segment_regime"].get("avx2_vs_wave64"):
                 parity["avx2_vs_wave64_segments"] = cpu["segment_regime"]["avx2_vs_wave64"]["status"]
+            if cpu["segment_regime"].get("device_vs_oracle_wave64"):
+                parity["segments_vs_oracle"] = cpu["segment_regime"]["device_vs_oracle_wave64"]
         except Exception as e:
             cpu["segment_regime"] = {"status": "failed: %r" % (e,)}
     # ---- (5) recall of the reference's sequential HnswBuilder vs the device's batch-synchronous build, same data and queries
@@ -1181,7 +1298,18 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
     m = min(B, nq)
     same_l = [bool(sc[i] == hc[i] and np.array_equal(sg[i, : sc[i]], hsg[i, : sc[i]]) and np.array_equal(sv[i, : sc[i]], hv[i, : sc[i]])) for i in range(m)]
     same = int(sum(same_l))
+    # bit parity AT THE TIMED SHAPE: the same Searcher::_search with the oracle summing in the device's WAVE64 order — segments,
+    # vector ids, ranks and score bits of the one-launch + device-Fssc path must be the oracle's (the AVX2-order run above is the
+    # timed CPU baseline; it may flip near-ties)
+    for sg_ in osegs:
+        sg_.order = orc.ORDER_WAVE64
+    wq = min(m, 256)
+    wsg, wsv, wss, wsc = orc.searcher_search_batch(osegs, qs[:wq], k, with_duplicates=True, threads=threads)
+    same_w = int(sum(bool(wsc[i] == hc[i] and np.array_equal(wsg[i, : wsc[i]], hsg[i, : wsc[i]]) and np.array_equal(wsv[i, : wsc[i]], hv[i, : wsc[i]]) and
+                          np.array_equal(wss[i, : wsc[i]].view(np.uint32), hsc[i, : wsc[i]].view(np.uint32))) for i in range(wq)))
     out = {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
+           "device_vs_oracle_wave64": {"queries": wq, "identical_segments_ids_ranks_score_bits": same_w, "status": "ok" if same_w == wq else "MISMATCH",
+                                       "oracle_order": "WAVE64", "reference": "nidx_vector/src/searcher.rs:149-199,270-287"},
            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
            "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
            "device_same_index_pipelined_queries_per_s": pipe_qps, "device_same_index_serial_segments_queries_per_s": serial_qps,
@@ -1286,7 +1414,7 @@ def bench_hnsw(a, L, dev, rank, world):
         "kernel_flags": head["flags"], "timed_launch_flags": head["timed_flags"], "timed_queries_re_run_exactly": head["timed_retried"],
         "timed_region": {"steps_per_pass": a.steps, "passes": head["repeats"], "steps_timed": head["steps_timed"], "seconds": head["elapsed"],
                          "entry": "nidx_gpu_vector_search_submit / _wait: device-resident queries in, hits in host arrays out" if world == 1 else
-                                  ("nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (RCCL inside the library)" if head.get("library_exchange")
+                                  ("nidx_gpu_vector_segment_search_device + nidx_gpu_shard_exchange_merge_vector (%s)" % ("RCCL inside the library" if head.get("exchange_transport") == "rccl" else "the library's shared-memory transport: the ranks share one GPU, validation") if head.get("library_exchange")
                                    else "nidx_gpu_vector_segment_search_device + the same exchange through torch.distributed (validation mode, or the library's communicator could not be set up)")},
         "corpus_gen_s": head["gen_s"], "open_s": head["open_s"], "hnsw_build_s": head["build_s"], "build_ef_upper": max(1, a.build_ef_upper),
         "parallelism": "shard-per-gpu x%d, RCCL all-gather of top-k" % world, "exchange_check": head["exchange_check"],
@@ -1297,6 +1425,24 @@ def bench_hnsw(a, L, dev, rank, world):
     # the figures of the nested blocks a reader of the top level needs, as scalars
     seg_reg = (head.get("cpu") or {}).get("segment_regime") or {}
     bm, hy = head.get("bm25") or {}, head.get("hybrid") or {}
+    bld = head.get("build") or {}
+    # (a record that keeps only the first scalars of `config` still carries every block's headline figure: these come first)
+    first = {
+        "workload": cfgd["workload"], "vectors_per_shard": n, "shards": world,
+        "recall_at_%d" % k: head["recall"], "recall_at_%d_reference_regime" % k: seg_reg.get("recall_at_%d" % k),
+        "host_buffer_queries_per_s": extra.get("host_buffer_queries_per_s"),
+        "bm25_postings_per_s": bm.get("value"), "bm25_roofline_frac": (bm.get("roofline") or {}).get("frac"),
+        "bm25_kernel_ms": (bm.get("roofline") or {}).get("kernel_ms"),
+        "bm25_multi_segment_postings_per_s": (bm.get("multi_segment") or {}).get("value"),
+        "hybrid_queries_per_s": hy.get("value"),
+        "segment_regime_device_qps": seg_reg.get("device_same_index_pipelined_queries_per_s"),
+        "segment_regime_device_frac_of_hbm_peak": (seg_reg.get("device_walk") or {}).get("frac_of_hbm_peak"),
+        "bf16_fallback_frac_of_bf16_peak": ((bf16_blk or {}).get("roofline") or {}).get("frac"),
+        "hnsw_build_s": head["build_s"], "hnsw_build_frac_of_hbm_peak": (bld.get("roofline") or {}).get("frac"),
+        "exchange_check": head["exchange_check"], "ef_upper": max(1, a.ef_upper),
+    }
+    cfgd = dict(first, **{kk_: v for kk_, v in cfgd.items() if kk_ not in first})
+    cfgd["build"] = bld or None
     cfgd.update({
         "ef_upper": max(1, a.ef_upper), "build_ef_upper": max(1, a.build_ef_upper),
         "bm25_postings_per_s": bm.get("value"), "bm25_queries_per_s": bm.get("queries_per_s"),
@@ -1618,13 +1764,157 @@ class Bm25Bench:
     def close(self):
         self.searcher.close()
 
+    def timed_pipeline(self, searcher, n_threads, depth, min_s=None):
+        """`n_threads` threads, each: submit / wait with `depth` tickets in flight over the prepared batches, for at least --steps steps
+        and --min-timed-s seconds -> (elapsed s, batches, postings scored, postings per batch)"""
+        import threading
+
+        from nucliadb_amd import _lib
+
+        a, B, k, L = self.a, self.B, self.K, self.L
+        min_s = min(a.min_timed_s, 1.0) if min_s is None else min_s
+        opt = _lib.Bm25SearchOptionsC()
+        opt.k, opt.order_field = k, -1
+        zero64 = np.zeros(1, np.uint64)
+        opt.term_set_offsets = opt.phrase_offsets = opt.subquery_offsets = zero64.ctypes.data
+        handle = searcher._handle
+        results = [None] * n_threads
+        start = threading.Barrier(n_threads + 1)
+        stop_at = [0.0]
+
+        def worker(w):
+            docaddr, score = np.zeros((B, k), np.uint64), np.zeros((B, k), np.float32)
+            count, total, post = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
+            pending, per_batch = [], []
+
+            def submit(i):
+                t = C.c_uint64(0)
+                _lib.check(L.nidx_gpu_bm25_search_submit(handle, self.prepared[i % len(self.prepared)], self.offsets.ctypes.data, B, C.byref(opt), C.byref(t)))
+                pending.append(t.value)
+
+            def wait_oldest():
+                _lib.check(L.nidx_gpu_bm25_search_wait(handle, pending.pop(0), docaddr.ctypes.data, score.ctypes.data, count.ctypes.data, total.ctypes.data,
+                                                       post.ctypes.data))
+                return float(post.sum())
+
+            try:
+                for i in range(4):   # the slots' buffers and streams exist before the clock starts
+                    submit(w + i * n_threads)
+                    if len(pending) >= depth:
+                        wait_oldest()
+                while pending:
+                    wait_oldest()
+                start.wait()
+                n = 0
+                while n * n_threads < a.steps or time.perf_counter() < stop_at[0]:
+                    submit(w + n * n_threads)
+                    if len(pending) >= depth:
+                        per_batch.append(wait_oldest())
+                    n += 1
+                while pending:
+                    per_batch.append(wait_oldest())
+                results[w] = (n, per_batch, time.perf_counter())
+            except BaseException as e:   # noqa: BLE001
+                results[w] = e
+                try:
+                    start.abort()
+                except Exception:
+                    pass
+
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
+        for t in ths:
+            t.start()
+        stop_at[0] = time.perf_counter() + 3600.0
+        start.wait()
+        t0 = time.perf_counter()
+        stop_at[0] = t0 + min_s
+        for t in ths:
+            t.join()
+        for r in results:
+            if isinstance(r, BaseException):
+                raise r
+        elapsed = max(r[2] for r in results) - t0
+        per_batch = [x for r in results for x in r[1]]
+        return elapsed, sum(r[0] for r in results), float(np.sum(per_batch)), per_batch
+
+    def split_by_merge_policy(self, dev):
+        """The same documents as the segments the log-merge policy leaves behind (nidx/src/settings.rs:246-253: merges run at >= 4
+        segments of a level and stop at 10 M records): one of 60 %, one of 30 %, four of 2.5 % -> [Bm25Segment]"""
+        from nucliadb_amd.bm25 import Bm25Segment
+
+        term_offsets, doc_ids, tfs, fieldnorm_ids, tokens = self.corpus
+        n = self.n_docs
+        cuts = [0, int(n * 0.6), int(n * 0.9)] + [int(n * (0.9 + 0.025 * i)) for i in range(1, 4)] + [n]
+        d_doc = torch.from_numpy(doc_ids.view(np.int32)).to(dev)
+        d_tf = torch.from_numpy(tfs.view(np.int32)).to(dev)
+        df = torch.from_numpy(np.diff(term_offsets.astype(np.int64))).to(dev)
+        term_of = torch.repeat_interleave(torch.arange(self.vocab, device=dev, dtype=torch.int32), df)
+        table = np.array([self.L.nidx_gpu_fieldnorm_from_id(i) for i in range(256)], dtype=np.int64)
+        parts = []
+        for a_, b_ in zip(cuts[:-1], cuts[1:]):
+            m = (d_doc >= a_) & (d_doc < b_)
+            pd = (d_doc[m] - a_).cpu().numpy().view(np.uint32)
+            pt = d_tf[m].cpu().numpy().view(np.uint32)
+            cnt = torch.bincount(term_of[m], minlength=self.vocab)
+            off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cnt, 0)]).cpu().numpy().astype(np.uint64)
+            fn = fieldnorm_ids[a_:b_]
+            # Bm25Weight's average field length is searcher-wide: only the SUM of the segments' token counts enters a score, so the
+            # last part takes the remainder of the whole's count and every score bit equals the one-segment index's
+            last = b_ == n
+            part_tokens = tokens - sum(p_.total_num_tokens for p_ in parts) if last else int(table[fn].sum())
+            parts.append(Bm25Segment(off, pd, pt, fn, part_tokens))
+            del m, cnt
+        del d_doc, d_tf, df, term_of
+        torch.cuda.empty_cache()
+        return parts, cuts
+
+    def multi_segment_leg(self, dev, one_segment_value, threads_n, depth):
+        """The same 10 M documents as SIX segments: opened as one term-major resident layout, searched in one launch sequence per batch
+        (csrc/bm25_index.cpp: bm25_upload_concatenated).  Hits must equal the one-segment index's (doc = base[segment] + doc)."""
+        from nucliadb_amd import _lib
+        from nucliadb_amd.bm25 import Bm25Searcher
+
+        a, B, k = self.a, self.B, self.K
+        t0 = time.time()
+        parts, cuts = self.split_by_merge_policy(dev)
+        split_s = time.time() - t0
+        t0 = time.time()
+        ms = Bm25Searcher.open(parts)
+        open_s = time.time() - t0
+        try:
+            base = np.asarray(cuts[:-1], np.int64)
+            self.search(0)
+            want = (self.docaddr.copy(), self.count.copy(), self.total.copy(), self.score.copy())
+            da, sc = np.zeros((B, k), np.uint64), np.zeros((B, k), np.float32)
+            cn, tt, pp = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
+            _lib.check(self.L.nidx_gpu_bm25_search(ms._handle, self.prepared[0], self.offsets.ctypes.data, B, k, None, da.ctypes.data, sc.ctypes.data,
+                                                   cn.ctypes.data, tt.ctypes.data, pp.ctypes.data))
+            same_ids = 0
+            for i in range(B):
+                c = int(cn[i])
+                g = base[(da[i, :c] >> np.uint64(32)).astype(np.int64)] + (da[i, :c] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                same_ids += int(c == int(want[1][i]) and tt[i] == want[2][i] and np.array_equal(g, want[0][i, :c].astype(np.int64)) and
+                                np.array_equal(sc[i, :c].view(np.uint32), want[3][i, :c].view(np.uint32)))
+            elapsed, n_steps, postings, _ = self.timed_pipeline(ms, threads_n, depth)
+            out = {"segments": [int(b_ - a_) for a_, b_ in zip(cuts[:-1], cuts[1:])], "value": postings / elapsed, "unit": "postings/s",
+                   "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value,
+                   "ratio_to_one_segment": postings / elapsed / one_segment_value if one_segment_value else None,
+                   "queries_identical_to_the_one_segment_index": same_ids, "queries": B, "split_s": split_s, "open_s": open_s,
+                   "note": "the log-merge policy's shape (nidx/src/settings.rs:246-253); documents, ranks, score bits and totals must equal the "
+                           "one-segment index's"}
+            if same_ids != B:
+                FAILURES.append("bm25 multi-segment: %d of %d queries return other hits than the one-segment index" % (B - same_ids, B))
+            return out
+        finally:
+            ms.close()
+
     def oracle_index(self):
         from oracle import oracle as orc
 
         orc.build()
         return orc.Bm25Index(*self.corpus)
 
-    def timed_block(self, rank):
+    def timed_block(self, rank, dev=None):
         """-> dict: value (postings/s end to end through the host-buffer entry point), roofline of the scoring kernel, cpu_baseline,
         parity of a sample against the oracle."""
         a, B, k = self.a, self.B, self.K
@@ -1632,44 +1922,17 @@ class Bm25Bench:
 
         for i in range(max(1, a.warmup)):
             self.search(i)
-        # the timed loop runs through the library's pipelined entry (nidx_gpu_bm25_search_submit / _wait), two batches in flight: the
-        # host side of batch i + 1 (clause weights, work list, staging) overlaps the kernels of batch i
-        opt = _lib.Bm25SearchOptionsC()
-        opt.k, opt.order_field = k, -1
-        zero64 = np.zeros(1, np.uint64)
-        opt.term_set_offsets = opt.phrase_offsets = opt.subquery_offsets = zero64.ctypes.data
+        # the timed loop runs through the library's pipelined entry (nidx_gpu_bm25_search_submit / _wait): `threads` submitting threads
+        # (the reference serves every request on a thread of its own, shard_search.rs:176-248) with `depth` batches in flight each —
+        # the host side of a batch (clause weights, work list, staging, ~8 runtime calls) costs its thread more than the kernels cost
+        # the device, and every ticket is planned and launched on a context of its own
         depth = int(os.environ.get("NIDX_BENCH_BM25_DEPTH", "2"))
-        pending = []
-
-        def submit(i):
-            t = C.c_uint64(0)
-            _lib.check(self.L.nidx_gpu_bm25_search_submit(self.searcher._handle, self.prepared[i % len(self.prepared)], self.offsets.ctypes.data, B,
-                                                          C.byref(opt), C.byref(t)))
-            pending.append(t.value)
-
-        def wait_oldest():
-            _lib.check(self.L.nidx_gpu_bm25_search_wait(self.searcher._handle, pending.pop(0), self.docaddr.ctypes.data, self.score.ctypes.data,
-                                                        self.count.ctypes.data, self.total.ctypes.data, self.post.ctypes.data))
-            return float(self.post.sum())
-
-        for i in range(4):   # the slots' buffers and streams exist before the clock starts
-            submit(i)
-            if len(pending) >= depth:
-                wait_oldest()
-        while pending:
-            wait_oldest()
-        post_per_batch = []
-        t0 = time.perf_counter()
-        n_steps = 0
-        while n_steps < a.steps or time.perf_counter() - t0 < min(a.min_timed_s, 1.0):
-            submit(n_steps)
-            if len(pending) >= depth:
-                post_per_batch.append(wait_oldest())
-            n_steps += 1
-        while pending:
-            post_per_batch.append(wait_oldest())
-        elapsed = time.perf_counter() - t0
-        postings = float(np.sum(post_per_batch))
+        threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "2")))
+        elapsed, n_steps, postings, post_per_batch = self.timed_pipeline(self.searcher, threads_n, depth)
+        one_thread = None
+        if threads_n > 1:
+            e1, n1, p1, _ = self.timed_pipeline(self.searcher, 1, depth)
+            one_thread = {"postings_per_s": p1 / e1, "queries_per_s": n1 * B / e1, "ms_per_step": e1 / n1 * 1e3}
         # the scoring kernel's duration: launches issued one at a time (events around overlapped launches also span their waits)
         kernel_ms, sync_ms = [], []
         for i in range(8):
@@ -1687,14 +1950,21 @@ class Bm25Bench:
             "workload": "bm25: %d docs, vocab %d Zipf(1.0), %d queries x 3 Should terms from rank band [100,100k], k=%d" % (self.n_docs, self.vocab, B, k),
             "postings_in_index": int(self.corpus[0][-1]), "postings_per_batch": float(np.mean(post_per_batch)),
             "corpus_gen_s": self.gen_s, "open_s": self.open_s,
-            "note": "value is end to end through the pipelined host-buffer entry points (nidx_gpu_bm25_search_submit / _wait, two batches in flight: "
-                    "clauses in, hits out over PCIe); the corpus is resident in HBM",
-            "batches_in_flight": depth, "synchronous_entry_ms_per_batch": float(np.mean(sync_ms)),
+            "note": "value is end to end through the pipelined host-buffer entry points (nidx_gpu_bm25_search_submit / _wait: clauses in, hits out over "
+                    "PCIe) from %d submitting thread(s) with %d batches in flight each; the corpus is resident in HBM" % (threads_n, depth),
+            "submitting_threads": threads_n, "batches_in_flight": depth * threads_n, "one_submitting_thread": one_thread,
+            "synchronous_entry_ms_per_batch": float(np.mean(sync_ms)),
             "roofline": {"kernel": "bm25 scoring kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
             "cpu_baseline": None,
         }
+        if rank == 0 and dev is not None and os.environ.get("NIDX_BENCH_BM25_SEGMENTS", "1") != "0":
+            try:
+                out["multi_segment"] = self.multi_segment_leg(dev, out["value"], threads_n, depth)
+            except Exception as e:  # noqa: BLE001 — a side leg
+                print("ERROR: bm25 multi-segment leg failed: %r" % (e,), file=sys.stderr)
+                FAILURES.append("bm25 multi-segment leg failed: %r" % (e,))
         if rank == 0 and a.cpu_queries > 0:
             from oracle import oracle as orc
 
@@ -1870,7 +2140,7 @@ def bench_hybrid(a, L, dev, rank, world):
 def bench_bm25(a, L, dev, rank, world):
     """--workload bm25: BASELINE.json's second metric on its own line."""
     bm = Bm25Bench(a, L, dev, rank, a.n_docs)
-    blk = bm.timed_block(rank)
+    blk = bm.timed_block(rank, dev)
     bm.close()
     if rank == 0:
         print(json.dumps({

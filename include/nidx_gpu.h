@@ -375,6 +375,15 @@ int32_t nidx_gpu_hnsw_graph_check(const uint8_t *graph, uint64_t graph_len, cons
  * concurrent inserts with M=30/M0=60/efC=100 (hnsw/params.rs:20-46).  Replaces any graph the
  * segment had.  Like the reference's rayon build the graph is not unique; parity is recall. */
 int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed);
+/* The work of the last nidx_gpu_vector_build_hnsw / _extend_hnsw of this index, counted by the build kernels the way the search
+ * kernel counts its own (measurement; HnswBuilder::insert, hnsw/build.rs:97-167): stats_out[8] =
+ *   [0] nodes inserted, [1] microseconds from the first batch's launch to the last one's completion,
+ *   [2] distance evaluations and [3] expansions of the construction searches (layer_search with ef = 100, build.rs:137-166),
+ *   [4] rows read by select_neighbours_heuristic over the new nodes' own candidate lists (build.rs:57-95, 104-108),
+ *   [5] rows read by the reverse-link prunes (build.rs:111-119), [6] reverse-link appends, [7] prunes.
+ * Algorithmic bytes of the build = ([2] + [4] + [5]) x 4 x dimension + [3] x 256.  [2] = ~0 when the build ran with
+ * NIDX_GPU_BUILD_STATS=0 (no counters). */
+int32_t nidx_gpu_vector_build_stats(nidx_gpu_vector_index_t *index, uint64_t *stats_out);
 /* segment::merge's graph reuse (segment.rs:137-167): the segment was opened with an hnsw.graph image of
  * its first hnsw_graph_nodes vectors (the largest, deletion-free operand of the merge); draw levels
  * for the remaining nodes from a fresh SmallRng::seed_from_u64(level_seed) (build.rs:50-55,

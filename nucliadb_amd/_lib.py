@@ -241,6 +241,7 @@ SIGNATURES = {
     "nidx_gpu_similarity": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]),
     "nidx_gpu_normalize": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nidx_gpu_vector_build_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "nidx_gpu_vector_build_stats": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "nidx_gpu_vector_extend_hnsw": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "nidx_gpu_vector_search_maxsim": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(VectorSearchParamsC), C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -39,7 +39,14 @@ struct BuildArgs {
     uint32_t ef_upper;          // results kept per layer ABOVE the node's top layer (0 = 1: the greedy descent of build.rs / search.rs)
     uint32_t *flags;            // [1] OR of NIDX_FLAG_*
     unsigned long long *dbg;    // nullptr or 5 counters: appends, prunes, prune cycles, total cycles, targets
+    // The build's work, counted like the search kernel's (a distance evaluation reads one row of 4 D bytes, an expansion
+    // one edge record): NIDX_BUILD_STAT_LINES cache lines of 8 counters — [0] evaluations and [1] expansions of the construction
+    // searches, [2] rows read by select_neighbours_heuristic on the new nodes' own lists, [3] rows read by the reverse-link prunes,
+    // [4] reverse-link appends, [5] prunes.  A workgroup / wave adds its totals once, to the line blockIdx selects (one line would
+    // serialise a few hundred thousand atomics per batch on one memory channel).
+    unsigned long long *stats;
 };
+#define STAT_LINE(blk) ((size_t)((blk) & (NIDX_BUILD_STAT_LINES - 1)) * 16)
 
 #define FOUND_STRIDE NIDX_BUILD_FOUND_STRIDE
 #define REQ_STRIDE NIDX_BUILD_REQ_STRIDE
@@ -98,6 +105,11 @@ __global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
         __syncthreads();
     }
     if (ctl && lane == 0 && st.flags) atomicOr(a.flags, st.flags);
+    if (ctl && lane == 0 && a.stats) {
+        unsigned long long *sl = a.stats + STAT_LINE(blockIdx.x);
+        atomicAdd(&sl[0], (unsigned long long)st.evals);
+        atomicAdd(&sl[1], (unsigned long long)st.expansions);
+    }
 }
 
 // Similarities of up to 4 candidate rows (in registers) against up to 4 stored rows: 16 dot products
@@ -159,7 +171,7 @@ __device__ inline void sims4x4(const SegDev &seg, const float4 (&cv)[4][NJ], con
 // decisions, in the same order, as the one-by-one loop.
 template <int NJ>
 __device__ inline int select_neighbours_wave(const SegDev &seg, const uint64_t *cand, int n, int k, uint64_t *out,
-                                             uint64_t *discard, bool cosine, int lane) {
+                                             uint64_t *discard, bool cosine, int lane, uint32_t &rows_read) {
     int n_res = 0, n_dis = 0;
     for (int i0 = 0; i0 < n && n_res < k; i0 += 4) {
         const int g = n - i0 < 4 ? n - i0 : 4;
@@ -177,6 +189,7 @@ __device__ inline int select_neighbours_wave(const SegDev &seg, const uint64_t *
             for (int j = 0; j < NJ; j++)
                 cv[t][j] = t < g ? load_row_chunk(seg.vectors + (size_t)caddr[t] * seg.dp, seg.dp, j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        rows_read += (uint32_t)g;
         bool fail[4] = {false, false, false, false};
         const int kept_before = n_res;
         for (int b = 0; b < kept_before; b += 4) {
@@ -186,6 +199,7 @@ __device__ inline int select_neighbours_wave(const SegDev &seg, const uint64_t *
             for (int t = 0; t < 4; t++) ys[t] = t < cnt ? rank_key_addr(out[b + t]) : 0u;
             float s[4][4];
             sims4x4<NJ>(seg, cv, cn, g, ys, cnt, cosine, lane, s);
+            rows_read += (uint32_t)cnt;
             bool all_failed = true;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -206,8 +220,10 @@ __device__ inline int select_neighbours_wave(const SegDev &seg, const uint64_t *
 #pragma unroll
             for (int c = 1; c < 4; c++)
                 if (c < g && !fail[c]) need = true;
-            if (need) sims4x4<NJ>(seg, cv, cn, g, ys, g, cosine, lane, sg);
-            else {
+            if (need) {
+                sims4x4<NJ>(seg, cv, cn, g, ys, g, cosine, lane, sg);
+                rows_read += (uint32_t)g;
+            } else {
 #pragma unroll
                 for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -271,7 +287,9 @@ __global__ __launch_bounds__(256) void select_link_kernel(BuildArgs a, uint32_t 
     const int layer = (int)a.slot_layer[slot];
     const int n = (int)a.found_len[slot];
     const uint64_t *cand = a.found + (size_t)slot * FOUND_STRIDE;
-    int m = select_neighbours_wave<NJ>(a.seg, cand, n, NIDX_M, s_out[wib], s_dis[wib], cosine, lane);
+    uint32_t rows_read = 0;
+    int m = select_neighbours_wave<NJ>(a.seg, cand, n, NIDX_M, s_out[wib], s_dis[wib], cosine, lane, rows_read);
+    if (lane == 0 && a.stats) atomicAdd(&a.stats[STAT_LINE(blockIdx.x) + 2], (unsigned long long)rows_read);
     // *layer.out[x] = neighbours (build.rs:108)
     uint32_t *rec = edge_record(a.g, x, layer);
     float *wrec = weight_record(a, x, layer);
@@ -319,6 +337,7 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
     // lane j holds edge j as a rank key (score = stored weight)
     uint64_t e = lane < deg ? rank_key(wrec[1 + lane], rec[1 + lane]) : 0ull;
     unsigned long long n_prune = 0, n_app = 0, cy_prune = 0;
+    uint32_t rows_read = 0;
     const unsigned long long t0 = clock64();
     for (uint32_t i = i0; i < n_req; i++) {
         uint64_t ki = keys[i];
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
         if (deg > mmax) {
             const unsigned long long tp = clock64();
             s_cand[wib][lane] = e;  // stored order
-            int m = select_neighbours_wave<NJ>(a.seg, s_cand[wib], deg, pm, s_out[wib], s_dis[wib], cosine, lane);
+            int m = select_neighbours_wave<NJ>(a.seg, s_cand[wib], deg, pm, s_out[wib], s_dis[wib], cosine, lane, rows_read);
             e = lane < m ? s_out[wib][lane] : 0ull;
             deg = m;
             n_prune++;
@@ -347,6 +366,12 @@ __global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const ui
         atomicAdd(&a.dbg[2], cy_prune);
         atomicAdd(&a.dbg[3], clock64() - t0);
         atomicAdd(&a.dbg[4], 1ull);
+    }
+    if (a.stats && lane == 0) {
+        unsigned long long *sl = a.stats + STAT_LINE(blockIdx.x);
+        if (rows_read) atomicAdd(&sl[3], (unsigned long long)rows_read);
+        atomicAdd(&sl[4], n_app);
+        if (n_prune) atomicAdd(&sl[5], n_prune);
     }
     if (lane == 0) rec[0] = (uint32_t)deg;
     if (lane < deg) {
@@ -399,6 +424,7 @@ hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s) {
     a.ef_upper = b.ef_upper;
     a.flags = b.flags;
     a.dbg = b.dbg;
+    a.stats = b.stats;
     int nj = (int)((a.seg.dp + 255u) / 256u);
 #define NIDX_BUILD_CASE(N) \
     return launch_batch<N>(a, b.n_slots, b.sort_tmp, b.sort_tmp_bytes, b.req_key_sorted, b.req_val_sorted, s)

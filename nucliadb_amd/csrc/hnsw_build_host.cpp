@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "host_common.h"
 #include "vector_index.h"
@@ -171,6 +172,18 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
         NIDX_HIP(hipMemsetAsync(d_dbg.p, 0, 40, stream));
         b.dbg = d_dbg.as<unsigned long long>();
     }
+    // work counters of this build (nidx_gpu_vector_build_stats); NIDX_GPU_BUILD_STATS=0 builds without them
+    DevBuf d_stats;
+    b.stats = nullptr;
+    {
+        const char *e = getenv("NIDX_GPU_BUILD_STATS");
+        if (!(e && atoi(e) == 0)) {
+            NIDX_HIP(d_stats.alloc((size_t)NIDX_BUILD_STAT_LINES * 16 * 8));
+            NIDX_HIP(hipMemsetAsync(d_stats.p, 0, d_stats.bytes, stream));
+            b.stats = d_stats.as<unsigned long long>();
+        }
+    }
+    const auto t_build0 = std::chrono::steady_clock::now();
     for (const Batch &bt : batches) {
         b.batch_start = bt.start;
         b.batch_size = bt.size;
@@ -191,6 +204,16 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     // nature); a candidate-pool overflow cannot happen below 412 exact ties and is reported
     if (flags & NIDX_FLAG_POOL_INEXACT) return fail(NIDX_ERR_INEXACT, "HNSW build: candidate pool overflow");
     last_build_flags = flags;
+    {
+        std::vector<unsigned long long> lines((size_t)NIDX_BUILD_STAT_LINES * 16, 0ull);
+        if (b.stats) NIDX_HIP(hipMemcpy(lines.data(), b.stats, lines.size() * 8, hipMemcpyDeviceToHost));
+        for (int c = 0; c < 8; c++) last_build_stats[c] = 0;
+        for (size_t l = 0; l < NIDX_BUILD_STAT_LINES; l++)
+            for (int c = 0; c < 6; c++) last_build_stats[2 + c] += lines[l * 16 + c];
+        last_build_stats[0] = n - n0;   // nodes inserted
+        last_build_stats[1] = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_build0).count();   // batches, launch to completion
+        if (!b.stats) last_build_stats[2] = ~0ull;   // built without counters
+    }
     seg.has_graph = true;
     seg.base_graph.reset();
     seg.base_nodes = 0;
@@ -205,6 +228,14 @@ extern "C" int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, ui
     VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
     if (!idx || segment >= idx->segs.size()) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     return idx->build_hnsw(segment, level_seed, false);
+} NIDX_ABI_CATCH
+
+extern "C" int32_t nidx_gpu_vector_build_stats(nidx_gpu_vector_index_t *index, uint64_t *stats_out) try {
+    VectorIndex *idx = reinterpret_cast<VectorIndex *>(index);
+    if (!idx || !stats_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    for (int c = 0; c < 8; c++) stats_out[c] = idx->last_build_stats[c];
+    return NIDX_OK;
 } NIDX_ABI_CATCH
 
 extern "C" int32_t nidx_gpu_vector_extend_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed) try {

@@ -305,7 +305,9 @@ struct BuildBatch {
     uint32_t ef_upper = 0;      // results kept per layer above the node's top layer (0 = 1: the reference's greedy descent)
     uint32_t *flags;            // [1]
     unsigned long long *dbg;    // nullptr or [5] (NIDX_GPU_BUILD_DEBUG)
+    unsigned long long *stats;  // nullptr or [NIDX_BUILD_STAT_LINES][16]: the build's work counters (hnsw_build.hip: BuildArgs::stats)
 };
+#define NIDX_BUILD_STAT_LINES 256
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
 hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
 

@@ -100,6 +100,7 @@ struct VectorIndex {
     uint32_t build_vis_log2 = 14;
     uint32_t build_ef_upper = 0;   // 0 = 1 (reference); tunable "build_ef_upper": a wider descent when inserting into very large flat graphs
     uint32_t last_build_flags = 0;
+    uint64_t last_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nidx_gpu_vector_build_stats
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_multi_vec, scratch_multi_score, scratch_multi_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
         scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count,

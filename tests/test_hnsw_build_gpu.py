@@ -237,3 +237,41 @@ def test_merge_with_graph_reuse(orc):
     t_full = time.time() - t0
     s2.close()
     assert t_full >= 1.5 * t_reuse, (t_full, t_reuse)             # segment/tests.rs:473-474
+
+
+def test_build_work_counters(monkeypatch):
+    """nidx_gpu_vector_build_stats: the build kernels count their own work the way the search kernel does (the figures behind the
+    build's roofline fraction in bench.py).  Counting must not change the graph: a build without counters (NIDX_GPU_BUILD_STATS=0)
+    gives the same hnsw.graph bytes; the counters obey the structure of HnswBuilder::insert (hnsw/build.rs:97-167): one
+    construction search per node reads at least its own candidates, every selected neighbour is one reverse-link request, a prune
+    needs an append first."""
+    import ctypes as C
+
+    rng = np.random.default_rng(11)
+    n, d = 6000, 96
+    x = clustered(rng, d, n // 160 + 1, 160)[:n]
+
+    def build(stats_on):
+        if stats_on:
+            monkeypatch.delenv("NIDX_GPU_BUILD_STATS", raising=False)
+        else:
+            monkeypatch.setenv("NIDX_GPU_BUILD_STATS", "0")
+        s = VectorSearcher.open(VectorConfig(d, Similarity.Cosine), [(seg_of(x), 1)])
+        s.build_hnsw(0, level_seed=2)
+        st = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib().nidx_gpu_vector_build_stats(s._handle, st))
+        graph, edges = s.serialize_hnsw(0)
+        s.close()
+        return [int(v) for v in st], bytes(graph), np.asarray(edges).tobytes()
+
+    st, g1, e1 = build(True)
+    st0, g0, e0 = build(False)
+    assert g1 == g0 and e1 == e0, "counting the work changed the graph"
+    assert st0[2] == 2**64 - 1 and st0[0] == n
+    nodes, usec, evals, expansions, sel_rows, prune_rows, appends, prunes = st
+    assert nodes == n and usec > 0
+    assert evals >= expansions > n             # every insertion expands at least its entry point on layer 0
+    assert evals / n > 100                     # ef_construction = 100 results are kept per layer: at least as many rows were scored
+    assert sel_rows >= n                       # the heuristic reads at least the best candidate of every (node, layer) list
+    assert 0 < appends <= 30 * (n + n // 20)   # at most M requests per (node, layer) slot
+    assert prunes <= appends and (prune_rows > 0) == (prunes > 0)

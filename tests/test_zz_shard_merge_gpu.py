@@ -256,3 +256,39 @@ def test_library_exchange_between_processes(orc, world, tmp_path):
             for key in res[0].files:
                 assert np.array_equal(r[key], res[0][key]), key
     assert all(int(r["shape_error"][0]) == 1 for r in res)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_and_runs_the_library_exchange():
+    """`python bench.py --gpus 2` without a launcher spawns its two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per
+    child); on this 1-GPU box NIDX_BENCH_SAME_DEVICE=1 lets them share GPU 0 with the DATA-PATH exchange running through the
+    library (nidx_gpu_shard_exchange_merge_vector over its shared-memory transport: pack, gather layout, shard order and merge
+    kernels are the RCCL path's own code).  The one JSON line must say n_gpus = 2, carry the recall of the MERGED hits against the
+    merged exact scan, and `exchange_check: ok` (overlapped pipeline == plain search -> exchange; library exchange == the same
+    exchange through torch.distributed).  Without the variable, asking for more GPUs than the node has is an error, not a 1-GPU run.
+    Merge semantics: nidx/src/searcher/shard_merge.rs:332-348."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n-vectors", "200000", "--corpus", "clustered", "--steps", "5", "--warmup", "2",
+            "--min-timed-s", "0.2", "--parity-queries", "0", "--scan-check-queries", "0", "--segment-regime", "0", "--bf16-block-n", "0", "--ref-build-n", "0",
+            "--single-query-calls", "0", "--cpu-queries", "0", "--bm25-block", "0", "--iso-recall", "0"]
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "NIDX_BENCH_SAME_DEVICE" in r.stderr, (r.returncode, r.stderr[-2000:])
+    r = subprocess.run(args, env=dict(env, NIDX_BENCH_SAME_DEVICE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["shards"] == 2 and line["config"]["corpus_vectors"] == 400000
+    assert line["config"]["exchange_check"] == "ok", line["config"]["exchange_check"]
+    assert "shared-memory transport" in line["config"]["timed_region"]["entry"], line["config"]["timed_region"]["entry"]
+    assert line["config"]["recall_at_10"] >= 0.9, line["config"]["recall_at_10"]
+    assert line["value"] > 0 and not line.get("failures"), line.get("failures")
