@@ -899,20 +899,25 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         if not do_exchange:
             qhost = [qpool[i].cpu().numpy() for i in range(n_pool)]
             tick = []
+            # one batch more in flight than the device-resident loop: a batch's upload (3 MiB over PCIe, then the hand-over from the copy
+            # engine to the compute queue) is part of its latency, and the device wants `nfl` walks' worth of launches co-resident
+            nfl_h = int(os.environ.get("NIDX_BENCH_HOST_IN_FLIGHT", str(nfl + 1)))
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl_h, 4)))
+            host_out_h = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl_h)]
 
             def host_step(i):
-                if len(tick) == nfl:
+                if len(tick) == nfl_h:
                     t_, j_ = tick.pop(0)
-                    hv_, hs2_, hc_ = host_out[j_]
+                    hv_, hs2_, hc_ = host_out_h[j_]
                     _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
                 t = C.c_uint64(0)
                 _lib.check(L.nidx_gpu_vector_search_submit(h, qhost[i % n_pool].ctypes.data, B, d, C.byref(p_hnsw), None, C.byref(t)))
-                tick.append((t.value, i % nfl))
+                tick.append((t.value, i % nfl_h))
 
             def host_drain():
                 while tick:
                     t_, j_ = tick.pop(0)
-                    hv_, hs2_, hc_ = host_out[j_]
+                    hv_, hs2_, hc_ = host_out_h[j_]
                     _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
 
             for i in range(max(4, a.warmup)):
@@ -927,11 +932,11 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             extra["host_buffer_queries_per_s"] = B * n_host / dt_host
             extra["host_buffer_fraction_of_value"] = (B * n_host / dt_host) / (B * steps_timed / elapsed)
             extra["host_buffer_entry"] = ("nidx_gpu_vector_search_submit / _wait: HOST query rows in (staged through pinned memory by the submitting "
-                                          "thread + the library's helper threads, 3 MiB over PCIe per batch), hits in host arrays out, %d batches in flight, %d timed" % (nfl, n_host))
+                                          "thread + the library's helper threads, 3 MiB over PCIe per batch), hits in host arrays out, %d batches in flight, %d timed" % (nfl_h, n_host))
             if got0 is not None:
                 host_step(0)
                 host_drain()
-                hv_, hs2_, hc_ = host_out[0]
+                hv_, hs2_, hc_ = host_out_h[0]
                 same_h = bool(np.array_equal(hc_, got0[2].view(np.uint32)) and np.array_equal(hv_, got0[0].view(np.uint32)) and
                               np.array_equal(hs2_.view(np.uint32), got0[1].view(np.uint32)))
                 extra["host_buffer_pipelined_equals_device_entry"] = same_h
@@ -2290,9 +2295,14 @@ def bench_rabitq(a, L, dev, rank, world):
                        "exact_hnsw_ms_per_batch": exact_hnsw_ms, "estimates_per_query": float(s[:, 0].mean()),
                        "expansions_per_query": float(s[:, 1].mean()), "rows_reranked_per_query": float(s[:, 2].mean()),
                        "kernel_flags": flags, "hnsw_build_s": build_s, "quantize_s": quant_s,
-                       "cycles_per_query": {"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
-                                            "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())}},
-            "roofline": {"kernel": "rabitq_hnsw_kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
+                       "walk_kernel": "rabitq_hnsw_kernel (one wave per query)" if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
+                                      "rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)",
+                       "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
+                                             "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
+                                            {"controller_predict_pop_and_waiting_for_the_fetcher": float(s[:, 4].mean()), "admission": float(s[:, 6].mean()),
+                                             "total": float(s[:, 7].mean())}),
+                       "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float(s[:, 5].mean())},
+            "roofline": {"kernel": "rabitq walk kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
             "cpu_baseline": cpu}))

@@ -93,6 +93,10 @@ struct Bm25Ctx {
         // (the hybrid request: serving.cpp keeps several on their own streams) they should not queue behind those: highest priority
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // NIDX_GPU_BM25_PRIORITY=0: default-priority streams (measurement: the runtime keeps its hardware queues per priority, and
+        // streams that share a hardware queue serialise)
+        if (const char *pe = getenv("NIDX_GPU_BM25_PRIORITY"))
+            if (atoi(pe) == 0) hi = 0;
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi);
         if (e == hipSuccess) e = hipEventCreate(&ev0);
         if (e == hipSuccess) e = hipEventCreate(&ev1);
@@ -863,13 +867,28 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
     // clauses and clause offsets travel as one pinned block
     const size_t cl_bytes = (std::max<size_t>(n_clauses, 1) * sizeof(Bm25ClauseDev) + 7) & ~(size_t)7;
     const size_t inq_bytes = cl_bytes + (size_t)(nq + 1) * 8;
-    NIDX_HIP(cx.s_in_q.reserve(inq_bytes));
-    NIDX_HIP(cx.h_in_q.reserve(inq_bytes));
-    if (n_clauses) memcpy(cx.h_in_q.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
-    memcpy(cx.h_in_q.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
-    NIDX_HIP(hipMemcpyAsync(cx.s_in_q.p, cx.h_in_q.p, inq_bytes, hipMemcpyHostToDevice, cx.stream));
-    const Bm25ClauseDev *d_clauses = cx.s_in_q.as<Bm25ClauseDev>();
-    const unsigned long long *d_clause_offsets = reinterpret_cast<const unsigned long long *>(cx.s_in_q.as<unsigned char>() + cl_bytes);
+    // One resident segment (the common case, several opened segments included): the clause block travels at the head of the work
+    // list's transfer — every dependent operation queued on a stream costs ~10 us of hand-over between the copy engine and the compute
+    // queue, and a batch's kernels are ~70 us.  The per-segment loop (NIDX_GPU_BM25_SEGMENT_LOOP) keeps two transfers: its clause block
+    // outlives the work lists.
+    const bool fused_in = idx->segs.size() == 1;
+    const size_t inq_al = (inq_bytes + 255) & ~(size_t)255;
+    const Bm25ClauseDev *d_clauses = nullptr;
+    const unsigned long long *d_clause_offsets = nullptr;
+    if (!fused_in) {
+        NIDX_HIP(cx.s_in_q.reserve(inq_bytes));
+        NIDX_HIP(cx.h_in_q.reserve(inq_bytes));
+        if (n_clauses) memcpy(cx.h_in_q.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
+        memcpy(cx.h_in_q.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
+        NIDX_HIP(hipMemcpyAsync(cx.s_in_q.p, cx.h_in_q.p, inq_bytes, hipMemcpyHostToDevice, cx.stream));
+        d_clauses = cx.s_in_q.as<Bm25ClauseDev>();
+        d_clause_offsets = reinterpret_cast<const unsigned long long *>(cx.s_in_q.as<unsigned char>() + cl_bytes);
+    }
+    // The merged hits are written by bm25_merge_kernel straight into the pinned result block (device-visible host memory: ~190 KB of
+    // fire-and-forget stores over PCIe per batch) instead of into HBM + a device-to-host transfer queued behind it: one dependent
+    // operation less per batch.  NIDX_GPU_BM25_ZERO_COPY_OUT=0 keeps the transfer (comparison).
+    bool zc_out = true;
+    if (const char *e = getenv("NIDX_GPU_BM25_ZERO_COPY_OUT")) zc_out = atoi(e) != 0;
     static_assert(sizeof(Bm25AfterDev) == sizeof(nidx_gpu_bm25_search_after_t), "search-after layout");
     if (after) {
         NIDX_HIP(cx.s_after.reserve((size_t)nq * sizeof(Bm25AfterDev)));
@@ -1205,22 +1224,37 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         const size_t work_bytes = (nw * sizeof(Bm25Work) + 31) & ~(size_t)31;
         const size_t items_bytes = (nw * 4 + 31) & ~(size_t)31;
         const size_t inw_bytes = if_bytes + work_bytes + items_bytes + ucl.size() * sizeof(Bm25UClause);
-        NIDX_HIP(cx.s_in_w.reserve(inw_bytes));
-        NIDX_HIP(cx.h_in_w.reserve(inw_bytes));
-        memcpy(cx.h_in_w.p, item_first.data(), (size_t)(nq + 1) * 4);
-        memcpy(cx.h_in_w.as<unsigned char>() + if_bytes, work.data(), nw * sizeof(Bm25Work));
-        memcpy(cx.h_in_w.as<unsigned char>() + if_bytes + work_bytes, item_list.data(), nw * 4);
-        if (!ucl.empty()) memcpy(cx.h_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes, ucl.data(), ucl.size() * sizeof(Bm25UClause));
-        NIDX_HIP(hipMemcpyAsync(cx.s_in_w.p, cx.h_in_w.p, inw_bytes, hipMemcpyHostToDevice, cx.stream));
-        const uint32_t *d_item_first = cx.s_in_w.as<uint32_t>();
-        const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(cx.s_in_w.as<unsigned char>() + if_bytes);
-        const uint32_t *d_items = reinterpret_cast<const uint32_t *>(cx.s_in_w.as<unsigned char>() + if_bytes + work_bytes);
+        const size_t w_at = fused_in ? inq_al : 0;   // the work list's place in the block: behind the clause block, or at its head
+        NIDX_HIP(cx.s_in_w.reserve(w_at + inw_bytes));
+        NIDX_HIP(cx.h_in_w.reserve(w_at + inw_bytes));
+        unsigned char *h_w = cx.h_in_w.as<unsigned char>() + w_at, *d_w = cx.s_in_w.as<unsigned char>() + w_at;
+        if (fused_in) {
+            if (n_clauses) memcpy(cx.h_in_w.p, dev_clauses.data(), n_clauses * sizeof(Bm25ClauseDev));
+            memcpy(cx.h_in_w.as<unsigned char>() + cl_bytes, clause_offsets, (size_t)(nq + 1) * 8);
+            d_clauses = cx.s_in_w.as<Bm25ClauseDev>();
+            d_clause_offsets = reinterpret_cast<const unsigned long long *>(cx.s_in_w.as<unsigned char>() + cl_bytes);
+        }
+        memcpy(h_w, item_first.data(), (size_t)(nq + 1) * 4);
+        memcpy(h_w + if_bytes, work.data(), nw * sizeof(Bm25Work));
+        memcpy(h_w + if_bytes + work_bytes, item_list.data(), nw * 4);
+        if (!ucl.empty()) memcpy(h_w + if_bytes + work_bytes + items_bytes, ucl.data(), ucl.size() * sizeof(Bm25UClause));
+        NIDX_HIP(hipMemcpyAsync(cx.s_in_w.p, cx.h_in_w.p, w_at + inw_bytes, hipMemcpyHostToDevice, cx.stream));
+        const uint32_t *d_item_first = reinterpret_cast<const uint32_t *>(d_w);
+        const Bm25Work *d_work = reinterpret_cast<const Bm25Work *>(d_w + if_bytes);
+        const uint32_t *d_items = reinterpret_cast<const uint32_t *>(d_w + if_bytes + work_bytes);
         // per-query outputs of the merge kernel, one block: doc u32 [nq][kk] | score f32 [nq][kk] | count u32 [nq] | total u64 [nq] | postings u64 [nq]
         const size_t o_doc = 0, o_score = (size_t)nq * kk * 4, o_count = o_score + (size_t)nq * kk * 4;
         const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, out_bytes = o_post + (size_t)nq * 8;
-        NIDX_HIP(cx.s_outpack.reserve(out_bytes));
         NIDX_HIP(cx.h_outpack.reserve(out_bytes));
-        unsigned char *d_out = cx.s_outpack.as<unsigned char>();
+        unsigned char *d_out = nullptr;
+        if (zc_out) {
+            void *dp = nullptr;
+            NIDX_HIP(hipHostGetDevicePointer(&dp, cx.h_outpack.p, 0));
+            d_out = static_cast<unsigned char *>(dp);
+        } else {
+            NIDX_HIP(cx.s_outpack.reserve(out_bytes));
+            d_out = cx.s_outpack.as<unsigned char>();
+        }
         NIDX_HIP(cx.s_count.reserve(nw * 4));
         NIDX_HIP(cx.s_total.reserve(nw * 8));
         NIDX_HIP(cx.s_postings.reserve(nw * 8));
@@ -1259,7 +1293,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         a.match_bits = n_slots ? cx.s_match_bits.as<uint32_t>() : nullptr;
         a.match_slot = n_slots ? cx.s_match_slot.as<int>() : nullptr;
         a.match_words = match_words;
-        a.uclauses = reinterpret_cast<const Bm25UClause *>(cx.s_in_w.as<unsigned char>() + if_bytes + work_bytes + items_bytes);
+        a.uclauses = reinterpret_cast<const Bm25UClause *>(d_w + if_bytes + work_bytes + items_bytes);
         a.dbg = nullptr;
         DevBuf dbgbuf;
         if (getenv("NIDX_GPU_BM25_DEBUG")) {
@@ -1292,7 +1326,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_pair_term.as<uint32_t>(),
                                         cx.s_pair_slot.as<int>(), (uint32_t)n_pairs, cx.s_match_bits.as<uint32_t>(), match_words,
                                         cx.s_facet_counts.as<unsigned long long>(), cx.stream));
-        NIDX_HIP(hipMemcpyAsync(cx.h_outpack.p, cx.s_outpack.p, out_bytes, hipMemcpyDeviceToHost, cx.stream));
+        if (!zc_out) NIDX_HIP(hipMemcpyAsync(cx.h_outpack.p, cx.s_outpack.p, out_bytes, hipMemcpyDeviceToHost, cx.stream));
         const unsigned char *h_out = cx.h_outpack.as<unsigned char>();
         const uint32_t *h_doc = reinterpret_cast<const uint32_t *>(h_out + o_doc);
         const float *h_score = reinterpret_cast<const float *>(h_out + o_score);

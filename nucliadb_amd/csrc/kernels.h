@@ -283,6 +283,9 @@ hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, u
                                uint64_t *planes, hipStream_t s);
 hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s);
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s);
+// several segments' walks in one launch: `table` (device, n_table records agreeing in shape with `shape`); block b = query b % nq of record b / nq
+bool rabitq_two_waves();   // false with NIDX_GPU_RABITQ_WAVES=1 (the one-wave kernel of rounds 1-4: no table-driven launch)
+hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s);
 
 // ---- HNSW build (hnsw_build.hip): one batch of concurrent inserts ----
 #define NIDX_BUILD_FOUND_STRIDE 128

@@ -21,6 +21,8 @@
 // every accepted row), so the 64 lanes are spent on the 60 neighbours of one expansion (one
 // 8+D/8-byte code per lane — no cross-lane reduction at all) and on the 64-wide raw dot products.
 // Bound: HBM latency/bytes (D/8+8 bytes per estimate, 4 D per re-ranked row, 256 B per expansion).
+#include <stdlib.h>
+
 #include "hnsw_device.h"
 
 namespace nidx {
@@ -831,6 +833,337 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     }
 }
 
+// ---- HNSW, RaBitQ arm, TWO waves per query (round 5) ------------------------------------------------------------------
+// The walk above is a chain of ~1 100 dependent expansions per query, and a lone wave pays every link in full: the edge record and
+// the neighbours' codes are two memory round trips (43 % of the walk's cycles), the admissions ~150 dependent instructions each
+// (36 %), with nothing to overlap either (one wave per SIMD at batch 1 024: 0.026 of the HBM roofline, rounds 1-4).  Here a
+// workgroup of two waves walks one query:
+//   wave 0, the controller  keeps the result set (RqLayer: the directory in its registers), pops, replays the admission rule
+//                           `score > ws || len < k` in edge order (search.rs:287-295) — the code of the one-wave kernel;
+//   wave 1, the fetcher     expands a node: edge record, the visited test-and-set of every neighbour (layer 0: the per-query
+//                           bitset in HBM, atomicOr; above: the LDS hash), the codes of the fresh ones, their estimates; it
+//                           leaves (address, estimate) of the fresh neighbours in edge order in LDS.
+// While the controller admits the neighbours of expansion i, the fetcher already expands the node the NEXT pop will return —
+// predicted exactly: the best of {best unexpanded entry of the result set, best admissible new neighbour}; the best new neighbour
+// that beats the current worst result is always admitted, and nothing admitted can rank above it.  The speculation is complete
+// (it sets the visited bits), so a confirmed one costs nothing more; the pop that follows the admissions verifies it, and a
+// mismatch — possible with exactly tied scores or when the ties side list decides — rolls it back: the fetcher clears exactly
+// the bits it set (nobody else writes this query's bitset) and expands the popped node instead.  Upper layers (k = 1, a handful
+// of expansions, the LDS hash has no removal) run without speculation.  The fetcher also keeps the edge record of the runner-up
+// candidate (read-only, so no rollback): when that node is expanded next, its fetch starts at the codes.
+// Results are the one-wave kernel's bit for bit — same admission replay on the same values in the same order; only the moment a
+// visited bit is set moves, never whether it is set when an expansion that was really popped tests it.
+#define RQ_NONE 0xffffffffu
+struct RqFetchBuf {      // one expansion, written by the fetcher
+    uint32_t node, n, flags, pad;
+    uint32_t addr[64];   // the fresh neighbours in edge order
+    float est[64];
+};
+struct RqCtl {
+    uint32_t pred, pred2, state, fetch_node, abort, ep, cache_node, pad;
+    uint32_t cache_w[64];   // the edge record (layer 0) of cache_node
+};
+enum { RQ_STATE_HIT = 0, RQ_STATE_MISS = 1, RQ_STATE_DONE = 2 };
+
+static size_t rq_smem2_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
+    return rq_smem_bytes(nw, dp, k, ef, true) + 2 * sizeof(RqFetchBuf) + sizeof(RqCtl);
+}
+
+// the best and (when it sits in the same chunk) second-best unexpanded key of the result set; 0 = none.  Changes nothing but the
+// hint dcur (chunks before it hold expanded keys only — still true afterwards).
+__device__ inline void rq_peek2(RqLayer &L, int lane, uint64_t &k1, uint64_t &k2) {
+    k1 = 0;
+    k2 = 0;
+    L.dcur = uni(L.dcur);
+    L.n_dir = uni(L.n_dir);
+    while (L.dcur < L.n_dir) {
+        const uint32_t meta = lane_u32(L.dir_meta, L.dcur);
+        const uint64_t mine = lane < (int)(meta >> 8) ? L.chunk(meta & 0xffu)[lane] : 0ull;
+        unsigned long long m = __ballot((mine & 1ull) != 0);
+        if (m) {
+            k1 = lane_u64(mine, __ffsll((long long)m) - 1);
+            m &= m - 1;
+            if (m) k2 = lane_u64(mine, __ffsll((long long)m) - 1);
+            return;
+        }
+        L.dcur++;
+    }
+}
+
+// the fetcher's expansion of `node` on `layer` -> out; node2 (layer 0, or RQ_NONE): its edge record is fetched along and kept
+template <int NW>
+__device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, RqCtl *ctl, RqFetchBuf *out, uint32_t node, uint32_t node2,
+                                int layer, uint32_t *gvis, const RabitqQueryDev &qc, uint32_t nw, uint32_t &vis_count, int lane) {
+    const bool pf = layer == 0 && node2 != RQ_NONE && node2 != node;
+    uint32_t w2 = 0;
+    if (pf) w2 = load_edge_raw(a.g, node2, 0, lane);
+    uint32_t w;
+    const uint32_t cnode = layer == 0 ? (uint32_t)uni((int)ctl->cache_node) : RQ_NONE;
+    if (cnode == node) w = ctl->cache_w[lane];
+    else w = load_edge_raw(a.g, node, layer, lane);
+    const uint32_t deg = lane_u32(w, 0);
+    const bool is_edge = lane >= 1 && lane <= (int)deg;
+    // the code of every neighbour is requested together with the visited test (one round trip); codes of visited ones are dropped
+    RqCode<NW> code;
+    const uint8_t *rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
+    if (is_edge) rq_load_code<NW>(rec, code);
+    bool fresh = false;
+    if (is_edge) {
+        if (layer > 0) fresh = vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, w);
+        else fresh = (atomicOr(&gvis[w >> 5], 1u << (w & 31)) & (1u << (w & 31))) == 0;
+    }
+    const unsigned long long fm = __ballot(fresh);
+    uint32_t oflags = 0;
+    if (layer > 0) {
+        vis_count += (uint32_t)__popcll(fm);
+        if (vis_count > (3u << RABITQ_UPPER_VIS_LOG2) / 4u) oflags = NIDX_FLAG_VISITED_OVERFLOW;
+    }
+    float est = 0.f, err = 0.f;
+    if (fresh) rq_score_code<NW>(code, rec, sh.planes, nw, qc, est, err);
+    (void)err;
+    const uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+    if (fresh) {
+        out->addr[pos] = w;
+        out->est[pos] = est;
+    }
+    if (lane == 0) {
+        out->node = node;
+        out->n = (uint32_t)__popcll(fm);
+        out->flags = oflags;
+    }
+    if (layer == 0) {
+        if (pf) ctl->cache_w[lane] = w2;
+        if (lane == 0) ctl->cache_node = pf ? node2 : RQ_NONE;
+    }
+}
+
+// undo a speculative layer-0 fetch that was not confirmed: clear exactly the visited bits it set; returns after they are cleared
+__device__ inline void rq_rollback(const RqFetchBuf *b, uint32_t *gvis, int lane) {
+    const uint32_t n = (uint32_t)uni((int)b->n);
+    uint32_t old = 0;
+    if ((uint32_t)lane < n) {
+        const uint32_t x = b->addr[lane];
+        old = atomicAnd(&gvis[x >> 5], ~(1u << (x & 31)));
+    }
+    asm volatile("" ::"v"(old));   // the returned words are waited for: the next fetch must find the bits cleared
+}
+
+template <int NW>
+__device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi, unsigned char *smem) {
+    const int lane = threadIdx.x & 63;
+    const bool w0 = (threadIdx.x >> 6) == 0;
+    const uint32_t nw = a.seg.dim / 64u;
+    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef);
+    RqFetchBuf *buf = reinterpret_cast<RqFetchBuf *>(reinterpret_cast<unsigned char *>(sh.vis) + ((size_t)4 << RABITQ_UPPER_VIS_LOG2));
+    RqCtl *ctl = reinterpret_cast<RqCtl *>(buf + 2);
+    {
+        const uint64_t *gp = a.planes + (size_t)qi * 4u * nw;
+        for (uint32_t i = threadIdx.x; i < 4u * nw; i += 128) sh.planes[i] = gp[i];
+        const float *gq = a.queries + (size_t)qi * a.seg.dp;
+        for (uint32_t i = threadIdx.x; i < a.seg.dp; i += 128) sh.q[i] = gq[i];
+    }
+    const RabitqQueryDev qc = a.qd[qi];
+    uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
+    uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;   // controller
+    uint32_t vis_count = 0;                                // fetcher (upper layers)
+    uint64_t cyc_ctl = 0, cyc_wait = 0, cyc_ins = 0;
+    const uint64_t t_start = clock64();
+    __syncthreads();
+
+    uint32_t ep = a.g.ep_node;
+    RqLayer L;
+    L.res = sh.res;
+    L.ties = sh.ties;
+    for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
+        const int kk = layer == 0 ? (int)a.ef : 1;
+        if (w0) {
+            L.init((int)rq_chunks((uint32_t)kk));
+            // the entry point is admitted unconditionally (search.rs:256-261) and is the first pop
+            float est, err;
+            rabitq_estimate<NW>(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
+            n_est++;
+            rq_admit(L, kk, est, ep, lane, flags);
+            uint32_t node = ep, next;
+            rq_pop(L, lane, node, next);
+            if (lane == 0) {
+                ctl->fetch_node = node;
+                ctl->pred = RQ_NONE;
+                ctl->pred2 = RQ_NONE;
+                ctl->abort = 0;
+            }
+        } else {
+            if (layer > 0) {
+                for (uint32_t i = lane; i < (1u << RABITQ_UPPER_VIS_LOG2); i += 64) sh.vis[i] = NIDX_VIS_EMPTY;
+                if (lane == 0) vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, ep);
+                vis_count = 1;
+            } else if (lane == 0) {
+                atomicOr(&gvis[ep >> 5], 1u << (ep & 31));
+                ctl->cache_node = RQ_NONE;
+            }
+        }
+        __syncthreads();
+        int cur = 0;
+        bool need_fetch = true;
+        for (;;) {
+            if (need_fetch) {
+                if (!w0) rq_fetch<NW>(a, sh, ctl, &buf[cur], (uint32_t)uni((int)ctl->fetch_node), RQ_NONE, layer, gvis, qc, nw, vis_count, lane);
+                const uint64_t tw = clock64();
+                __syncthreads();
+                cyc_wait += clock64() - tw;
+            }
+            // ---- the controller takes the expansion in buf[cur] and names the node the next pop will return ----
+            bool fresh = false;
+            float fest = 0.f;
+            uint32_t faddr = 0;
+            const uint64_t tc = clock64();
+            if (w0) {
+                const RqFetchBuf *b = &buf[cur];
+                const uint32_t fn = (uint32_t)uni((int)b->n), bflags = (uint32_t)uni((int)b->flags);
+                n_exp++;
+                if (bflags) {
+                    flags |= bflags;   // the upper-layer visited table is 3/4 full: this layer ends here (like the one-wave kernel)
+                    if (lane == 0) {
+                        ctl->abort = 1;
+                        ctl->pred = RQ_NONE;
+                        ctl->pred2 = RQ_NONE;
+                    }
+                } else {
+                    n_est += fn;
+                    fresh = (uint32_t)lane < fn;
+                    fest = fresh ? b->est[lane] : 0.f;
+                    faddr = fresh ? b->addr[lane] : 0u;
+                    uint32_t p1 = RQ_NONE, p2 = RQ_NONE;
+                    if (layer == 0) {
+                        L.len = uni(L.len);
+                        L.worst = uni64(L.worst);
+                        const float ws = rank_key_score(L.worst);
+                        const bool full = L.len >= kk;
+                        const uint64_t key_new = (fresh && (!full || fest > ws)) ? rq_key(fest, faddr, 1u) : 0ull;
+                        const uint64_t best_new = wave_max_u64(key_new);
+                        uint64_t pk1, pk2;
+                        rq_peek2(L, lane, pk1, pk2);
+                        uint64_t a1, a2;
+                        if (best_new > pk1) {
+                            a1 = best_new;
+                            a2 = pk1;
+                        } else {
+                            a1 = pk1;
+                            a2 = best_new > pk2 ? best_new : pk2;
+                        }
+                        if (a1) p1 = rq_addr(a1);
+                        if (a2) p2 = rq_addr(a2);
+                    }
+                    if (lane == 0) {
+                        ctl->pred = p1;
+                        ctl->pred2 = p2;
+                    }
+                }
+            }
+            cyc_ctl += clock64() - tc;
+            __syncthreads();
+            const uint32_t pred = (uint32_t)uni((int)ctl->pred);
+            const bool aborted = uni((int)ctl->abort) != 0;
+            if (!w0) {
+                if (pred != RQ_NONE) rq_fetch<NW>(a, sh, ctl, &buf[cur ^ 1], pred, (uint32_t)uni((int)ctl->pred2), layer, gvis, qc, nw, vis_count, lane);
+            } else {
+                uint32_t st = RQ_STATE_DONE, node = 0, next;
+                if (!aborted) {
+                    const uint64_t t3 = clock64();
+                    // `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295)
+                    unsigned long long todo = __ballot(fresh);
+                    while (todo) {
+                        todo = uni64(todo);
+                        L.len = uni(L.len);
+                        L.worst = uni64(L.worst);
+                        const float ws = rank_key_score(L.worst);
+                        if (L.len >= kk) {
+                            todo &= __ballot(fresh && fest > ws);
+                            if (!todo) break;
+                        }
+                        const int j = __ffsll((long long)todo) - 1;
+                        todo &= ~(1ull << j);
+                        const float sj = lane_f32(fest, j);
+                        if (sj > ws || L.len < kk) rq_admit(L, kk, sj, lane_u32(faddr, j), lane, flags);
+                    }
+                    const uint64_t t4 = clock64();
+                    cyc_ins += t4 - t3;
+                    if (rq_pop(L, lane, node, next)) st = node == pred ? RQ_STATE_HIT : RQ_STATE_MISS;
+                    cyc_ctl += clock64() - t4;
+                }
+                if (st == RQ_STATE_HIT) n_hit++;
+                if (lane == 0) {
+                    ctl->state = st;
+                    ctl->fetch_node = node;
+                }
+            }
+            const uint64_t tw2 = clock64();
+            __syncthreads();
+            cyc_wait += clock64() - tw2;
+            const uint32_t st = (uint32_t)uni((int)ctl->state);
+            if (st == RQ_STATE_HIT) {
+                cur ^= 1;
+                need_fetch = false;
+                continue;
+            }
+            if (!w0 && pred != RQ_NONE) rq_rollback(&buf[cur ^ 1], gvis, lane);   // (layer 0 only: pred is RQ_NONE above it)
+            if (st == RQ_STATE_DONE) break;
+            need_fetch = true;
+        }
+        if (w0) {
+            ep = rq_addr(lane_u64(L.dir_first, 0));  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
+            if (lane == 0) ctl->ep = ep;
+        }
+        __syncthreads();
+        ep = (uint32_t)uni((int)ctl->ep);
+    }
+    if (!w0) return;
+
+    // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363): the controller alone ----
+    Reranker rr;
+    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
+    for (int dch = 0; dch < uni(L.n_dir); dch++) {  // the chunks in rank order = the neighbours best first
+        const uint32_t meta = lane_u32(L.dir_meta, dch);
+        const bool ok = lane < (int)(meta >> 8);
+        uint32_t addr = 0;
+        float ub = 0.f;
+        if (ok) {
+            const uint64_t key = L.chunk(meta & 0xffu)[lane];
+            addr = rq_addr(key);
+            ub = rank_key_score(key) + rabitq_error(a.quant + (size_t)addr * a.rec_len, qc);
+        }
+        rr.feed(ok, addr, ub, lane);
+    }
+    rr.write(a.out_vec + (size_t)qi * a.k, a.out_score + (size_t)qi * a.k, a.out_count + qi, lane);
+    if (flags && a.flag_word && lane == 0) atomicOr(a.flag_word, flags);
+    if (a.stats && lane == 0) {
+        uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
+        o[NIDX_STAT_EVALS] = n_est;
+        o[NIDX_STAT_EXPANSIONS] = n_exp;
+        o[NIDX_STAT_VISITED] = rr.n_eval;
+        o[NIDX_STAT_FLAGS] = flags;
+        // the controller's cycles: prediction + pop / expansions whose fetch was speculated and confirmed / admissions; [7] = total incl. re-rank
+        o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_ctl + cyc_wait);
+        o[NIDX_STAT_EDGE_HITS] = n_hit;
+        o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
+        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(128) void rabitq_hnsw2_kernel(RabitqSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    rabitq_hnsw2_body<NW>(a, blockIdx.x, smem);
+}
+
+// every RaBitQ segment of an index in ONE launch: block b walks query b % n_queries of segment b / n_queries, whose arguments
+// come from a table in HBM (uniform address, read only: scalar loads) — like hnsw_search_segments_kernel
+template <int NW>
+__global__ __launch_bounds__(128) void rabitq_hnsw2_segments_kernel(const RabitqSearchArgs *table, uint32_t n_queries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RabitqSearchArgs &a = table[blockIdx.x / n_queries];
+    rabitq_hnsw2_body<NW>(a, blockIdx.x % n_queries, smem);
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -875,10 +1208,39 @@ hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s) {
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, 0, false);
     RQ_DISPATCH(launch_bf_nw, a.seg.dim / 64u, a, smem, s)
 }
+template <int NW>
+static hipError_t launch_hnsw2_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw2_kernel<NW>, dim3(a.n_queries), dim3(128), smem, s, a);
+    return hipGetLastError();
+}
+template <int NW>
+static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw2_segments_kernel<NW>, dim3(n_table * nq), dim3(128), smem, s, table, nq);
+    return hipGetLastError();
+}
+// NIDX_GPU_RABITQ_WAVES=1: the one-wave kernel of rounds 1-4 (comparison); default: two waves per query
+bool rabitq_two_waves() {
+    const char *e = getenv("NIDX_GPU_RABITQ_WAVES");
+    return !(e && atoi(e) == 1);
+}
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
+    if (rabitq_two_waves()) {
+        const size_t smem2 = rq_smem2_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef);
+        RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, a, smem2, s)
+    }
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
     RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
+}
+// `table` (device) holds n_table argument records that agree in dim / dp / k / ef / n_queries (`shape`: one of them, host side)
+hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s) {
+    if (n_table == 0 || shape.n_queries == 0) return hipSuccess;
+    const size_t smem2 = rq_smem2_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef);
+    RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
 }
 
 }  // namespace nidx

@@ -156,7 +156,8 @@ struct SearchSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     DevBuf d_queries, d_block, d_filter, d_tables, d_offered;
-    PinBuf pin_in, pin_out, pin_tables;
+    DevBuf d_rq, d_rq_vis, d_rq_entry, d_rq_table;   // RaBitQ segments of a one-launch batch: encoded queries, visited bitsets, entry points, argument table
+    PinBuf pin_in, pin_out, pin_tables, pin_rq_table;
     bool dirty = false;                      // work may be queued on `stream` / the flag words may be set: clean before reuse
     bool merged = false;                     // the block carries the device Fssc's hits
     size_t flag_bytes = 0;                   // flag words at the head of d_block
@@ -331,6 +332,17 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         FsscSegDev *h_fssc = reinterpret_cast<FsscSegDev *>(sl.pin_tables.as<unsigned char>() + hnsw_tab_bytes);
         uint32_t n_hnsw = 0, n_searched = 0;
         const bool one_launch = S > 1 && !getenv("NIDX_GPU_SEGMENT_LAUNCHES");   // the variable: a launch per segment (comparison)
+        // RaBitQ is the reference's default arm of a Dot index with D % 64 == 0 (config.rs:170-173, segment.rs:506-513): the walks of
+        // every such segment join ONE table-driven launch too (rabitq_hnsw2_segments_kernel), their closest_up_nodes the plain
+        // segments' grid in entry mode.  The visited bitsets of the launch (n_queries x vectors of those segments bits) stay under 4 GiB.
+        std::vector<uint32_t> rq_segs;
+        bool rq_one_launch = one_launch && rabitq_two_waves() && k <= NIDX_K_MAX;
+        if (rq_one_launch) {
+            uint64_t vis_words = 0;
+            for (size_t s = 0; s < S; s++)
+                if (segs[s].has_quant) vis_words += (segs[s].n + 31u) / 32u;
+            if (vis_words * 4ull * nq > (4ull << 30)) rq_one_launch = false;
+        }
         {
             // launches read index state (tunables, the scratch the scans stage through): under the index lock, which is held for
             // the launch calls only — never across a synchronisation
@@ -366,11 +378,55 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                                                  d_count, nullptr, default_vis_log2, blk + s);
                     continue;
                 }
+                if (method == NIDX_METHOD_RABITQ_HNSW && rq_one_launch && seg.has_quant) {
+                    rq_segs.push_back((uint32_t)s);   // launched together behind this loop
+                    continue;
+                }
                 scan_matching_hint = matching;
                 const int32_t rc = segment_search_device((uint32_t)s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, method, sl.d_seg_filter[s],
                                                          d_vec, d_score, d_count, nullptr, default_vis_log2, sl.stream, blk + s);
                 scan_matching_hint = ~0ull;
                 if (rc != NIDX_OK) return rc;
+            }
+            if (!rq_segs.empty()) {
+                const uint32_t dim = segs[rq_segs[0]].dim, nw = dim / 64u, n_rq = (uint32_t)rq_segs.size();
+                // the queries' 4-bit codes and constants once per batch (they depend on the query alone)
+                const size_t qd_bytes = ((size_t)nq * sizeof(RabitqQueryDev) + 63) & ~(size_t)63;
+                NIDX_HIP(sl.d_rq.reserve(qd_bytes + (size_t)nq * 4 * nw * 8));
+                RabitqQueryDev *d_qd = sl.d_rq.as<RabitqQueryDev>();
+                uint64_t *d_planes = reinterpret_cast<uint64_t *>(sl.d_rq.as<unsigned char>() + qd_bytes);
+                NIDX_HIP(launch_rabitq_query(sl.dq, nq, dp, dim, d_qd, d_planes, sl.stream));
+                uint64_t vis_words = 0;
+                for (uint32_t s : rq_segs) vis_words += (segs[s].n + 31u) / 32u;
+                NIDX_HIP(sl.d_rq_vis.reserve((size_t)vis_words * 4 * nq));
+                NIDX_HIP(hipMemsetAsync(sl.d_rq_vis.p, 0, (size_t)vis_words * 4 * nq, sl.stream));
+                const size_t entry_words = (size_t)nq * k * 2 + nq;   // per segment: vectors | scores | counts
+                NIDX_HIP(sl.d_rq_entry.reserve((size_t)n_rq * entry_words * 4));
+                NIDX_HIP(sl.pin_rq_table.reserve((size_t)n_rq * sizeof(RabitqSearchArgs)));
+                NIDX_HIP(sl.d_rq_table.reserve((size_t)n_rq * sizeof(RabitqSearchArgs)));
+                RabitqSearchArgs *h_rq = sl.pin_rq_table.as<RabitqSearchArgs>();
+                uint64_t vis_at = 0;
+                for (uint32_t i = 0; i < n_rq; i++) {
+                    const uint32_t s = rq_segs[i];
+                    uint32_t *e_vec = sl.d_rq_entry.as<uint32_t>() + (size_t)i * entry_words;
+                    float *e_score = reinterpret_cast<float *>(e_vec + (size_t)nq * k);
+                    uint32_t *e_count = e_vec + (size_t)nq * k * 2;
+                    RabitqSearchArgs r = rabitq_hnsw_args(s, sl.dq, nq, k, p.min_score, blk + s);
+                    r.qd = d_qd;
+                    r.planes = d_planes;
+                    r.visited = sl.d_rq_vis.as<uint32_t>() + vis_at * nq;
+                    vis_at += r.vis_words;
+                    r.out_vec = e_vec, r.out_score = e_score, r.out_count = e_count;
+                    h_rq[i] = r;
+                    // closest_up_nodes from the re-ranked entry points, on the raw query (search.rs:369-375): an entry-mode record of the grid
+                    uint32_t *d_vec = blk + fw + mw + (size_t)s * sw;
+                    HnswSearchArgs ha = hnsw_args(s, sl.dq, nq, walks, k, p.min_score, p.with_duplicates != 0, sl.d_seg_filter[s], d_vec,
+                                                  reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2, nullptr, default_vis_log2, blk + s);
+                    ha.entry_vec = e_vec, ha.entry_score = e_score, ha.entry_count = e_count;
+                    h_hnsw[n_hnsw++] = ha;
+                }
+                NIDX_HIP(hipMemcpyAsync(sl.d_rq_table.p, sl.pin_rq_table.p, (size_t)n_rq * sizeof(RabitqSearchArgs), hipMemcpyHostToDevice, sl.stream));
+                NIDX_HIP(launch_rabitq_hnsw_segments(sl.d_rq_table.as<RabitqSearchArgs>(), n_rq, h_rq[0], sl.stream));
             }
             NIDX_HIP(hipMemcpyAsync(sl.d_tables.p, sl.pin_tables.p, tab_bytes, hipMemcpyHostToDevice, sl.stream));
             if (n_hnsw) {

@@ -445,6 +445,36 @@ HnswSearchArgs VectorIndex::hnsw_args(uint32_t s, const float *d_queries, uint32
     return a;
 }
 
+// The argument record of one segment's RaBitQ walk (the HNSW arm, hnsw/search.rs:333-366); the caller fills in the per-launch
+// buffers: qd / planes (the encoded queries), visited (zeroed bitsets), out_* (the re-ranked entry points), stats.
+RabitqSearchArgs VectorIndex::rabitq_hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, uint32_t *d_flag_word) const {
+    const VectorSegment &seg = segs[s];
+    RabitqSearchArgs r;
+    r.seg = seg.seg_dev(cfg.similarity);
+    r.g = seg.graph_dev();
+    r.quant = seg.quant.as<uint8_t>();
+    r.rec_len = seg.dim / 8 + 8;
+    r.queries = d_queries;
+    r.qd = nullptr;
+    r.planes = nullptr;
+    r.n_queries = nq;
+    r.filter = nullptr;   // (the HNSW arm filters in closest_up_nodes)
+    r.para_first = nullptr;
+    r.para_num = nullptr;
+    r.n_paragraphs = seg.n_paragraphs;
+    r.k = k;
+    r.ef = std::min<uint32_t>(k * 100u, 2000u);   // last_layer_k = min(k * RERANKING_FACTOR, RERANKING_LIMIT) (hnsw/search.rs:333-340)
+    r.min_score = min_score;
+    r.visited = nullptr;
+    r.vis_words = (seg.n + 31u) / 32u;
+    r.out_vec = nullptr;
+    r.out_score = nullptr;
+    r.out_count = nullptr;
+    r.stats = nullptr;
+    r.flag_word = d_flag_word;
+    return r;
+}
+
 int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                                    bool with_duplicates, int method, const uint64_t *d_filter,
                                                    uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count,

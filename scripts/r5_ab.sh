@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round 5 A/B runs on the GPU box: one line per variant under gpurun_out/r5ab/.  Usage: bash scripts/r5_ab.sh [rabitq|bm25|hybrid|all]
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+PART=${1:-all}
+OUT=$ROOT/gpurun_out/r5ab
+mkdir -p $OUT
+cd $ROOT
+run() {  # name, env..., -- bench args
+  local name=$1; shift
+  local envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  env "${envs[@]}" timeout 400 python bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null
+  echo "$name rc=$? $(python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/$name.json"))
+    c = d.get("config", {})
+    r = d.get("roofline") or {}
+    print("value=%.4g ms_per_step=%.4g frac=%s kernel_ms=%s recall=%s one_thread=%s multi=%s" % (d["value"], d["ms_per_step"], r.get("frac"), r.get("kernel_ms"),
+          c.get("recall_at_10"), (c.get("one_submitting_thread") or {}).get("postings_per_s"), (c.get("multi_segment") or {}).get("value")))
+except Exception as e:
+    print("no line:", e)
+PY
+)"
+}
+if [ "$PART" = rabitq ] || [ "$PART" = all ]; then
+  run rabitq_2w -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 256
+  run rabitq_1w NIDX_GPU_RABITQ_WAVES=1 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
+fi
+if [ "$PART" = bm25 ] || [ "$PART" = all ]; then
+  run bm25_default -- --workload bm25 --cpu-queries 0 --steps 200
+  run bm25_prio0 NIDX_GPU_BM25_PRIORITY=0 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+  run bm25_copy_out NIDX_GPU_BM25_ZERO_COPY_OUT=0 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+  run bm25_depth4 NIDX_BENCH_BM25_DEPTH=4 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+fi

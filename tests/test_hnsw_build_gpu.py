@@ -239,7 +239,7 @@ def test_merge_with_graph_reuse(orc):
     assert t_full >= 1.5 * t_reuse, (t_full, t_reuse)             # segment/tests.rs:473-474
 
 
-def test_build_work_counters(monkeypatch):
+def test_build_work_counters(orc, monkeypatch):
     """nidx_gpu_vector_build_stats: the build kernels count their own work the way the search kernel does (the figures behind the
     build's roofline fraction in bench.py).  Counting must not change the graph: a build without counters (NIDX_GPU_BUILD_STATS=0)
     gives the same hnsw.graph bytes; the counters obey the structure of HnswBuilder::insert (hnsw/build.rs:97-167): one
@@ -273,5 +273,6 @@ def test_build_work_counters(monkeypatch):
     assert evals >= expansions > n             # every insertion expands at least its entry point on layer 0
     assert evals / n > 100                     # ef_construction = 100 results are kept per layer: at least as many rows were scored
     assert sel_rows >= n                       # the heuristic reads at least the best candidate of every (node, layer) list
-    assert 0 < appends <= 30 * (n + n // 20)   # at most M requests per (node, layer) slot
+    slots = int((orc.hnsw_levels(2, n).astype(np.int64) + 1).sum())   # a node of level L is inserted into L + 1 layers
+    assert 0 < appends <= 30 * slots           # at most M = 30 reverse-link requests per (node, layer)
     assert prunes <= appends and (prune_rows > 0) == (prunes > 0)

@@ -20,7 +20,7 @@ def unit_rows(rng, n, d):
 
 
 class Index:
-    def __init__(self, xs, sim=1, graphs=None, key_ids=None, alive=None, normalize=0):
+    def __init__(self, xs, sim=1, graphs=None, key_ids=None, alive=None, normalize=0, quantized=None):
         self.L = _lib.lib()
         d = xs[0].shape[1]
         self.d = d
@@ -33,7 +33,9 @@ class Index:
             self._keep.append(g)
             segs[s] = _lib.VectorSegmentC(x.ctypes.data, d * 4, x.shape[0], None, x.shape[0], g.ctypes.data if g is not None else None,
                                           g.size if g is not None else 0, 0, None, 0, alive[s].ctypes.data if alive and alive[s] is not None else None,
-                                          key_ids[s].ctypes.data if key_ids else None)
+                                          key_ids[s].ctypes.data if key_ids else None,
+                                          quantized[s].ctypes.data if quantized else None, quantized[s].size if quantized else 0)
+        self._keep.append(quantized)
         self.h = C.c_void_p()
         _lib.check(self.L.nidx_gpu_vector_open(C.byref(cfg), segs, len(xs), C.byref(self.h)))
 
@@ -264,6 +266,67 @@ def test_every_segment_in_one_launch_and_fssc_on_the_device(orc, monkeypatch):
         # several batches in flight through the same slots
         tickets = [idx.submit(q.ctypes.data, B, 10, _lib.METHOD_HNSW, False)[1] for _ in range(3)]
         want = idx.search(q, 10, _lib.METHOD_HNSW, False)
+        for t in reversed(tickets):
+            rc, g, retried = idx.wait(t, B, 10)
+            assert rc == 0 and retried == 0 and same(g, want)
+    finally:
+        idx.close()
+
+
+def test_rabitq_segments_share_one_launch(orc, monkeypatch):
+    """RaBitQ is the reference's default arm of a Dot index with D % 64 == 0 (nidx_vector/src/config.rs:170-173, segment.rs:506-513,
+    hnsw/search.rs:333-366): the walks of every RaBitQ segment of an index run in ONE table-driven launch (rabitq_hnsw2_segments_kernel,
+    two waves per walk), their closest_up_nodes in the plain segments' grid in entry mode, Fssc on the device.  Identical — segments,
+    vectors, ranks, score bits — to the oracle's Searcher::_search over the same quantized segments, to the segment-at-a-time path
+    (tunable serial_segments), to a launch per segment (NIDX_GPU_SEGMENT_LAUNCHES) and to the one-wave kernel of rounds 1-4
+    (NIDX_GPU_RABITQ_WAVES=1)."""
+    rng = np.random.default_rng(77)
+    d = 128
+    sizes = (3000, 1200, 2500, 800, 1700)
+
+    def clustered(n):
+        centers = unit_rows(rng, 30, d)
+        x = centers[rng.integers(0, 30, n)] + rng.normal(size=(n, d)).astype(np.float32) * np.float32(0.3 / np.sqrt(d))
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    xs = [clustered(n) for n in sizes]
+    xs[3][7] = xs[0][11]     # the same vector bytes in two segments (with_duplicates = false drops the later one)
+    osegs, graphs, quants = [], [], []
+    for x in xs:
+        qz = orc.rabitq_encode(x, orc.ORDER_WAVE64)
+        o = orc.Segment(x, similarity=orc.SIM_DOT, order=orc.ORDER_WAVE64, quantized=qz)
+        graphs.append(bytes(o.build_graph(seed=3).serialize_v2(x.shape[0])[0]))
+        osegs.append(o)
+        quants.append(np.ascontiguousarray(qz).reshape(-1))
+    idx = Index(xs, sim=0, graphs=graphs, quantized=quants)
+    try:
+        q = np.ascontiguousarray(np.vstack([xs[0][11][None, :], xs[2][40][None, :]] + [clustered(30)]))
+        B = q.shape[0]
+        for k, with_dup, min_score in ((10, True, -1.0), (10, False, -1.0), (3, False, 0.1), (40, True, -1.0)):
+            # the oracle routes every segment through OpenSegment::_search's cost model with has_rabitq = true: METHOD_AUTO here
+            sg, sv, ss, sc = orc.searcher_search_batch(osegs, q, k, min_score=min_score, with_duplicates=with_dup, threads=4)
+            auto = idx.search(q, k, _lib.METHOD_AUTO, with_dup, min_score=min_score)
+            assert np.array_equal(auto[4], sc), (k, with_dup)
+            for i in range(B):
+                c = int(sc[i])
+                assert np.array_equal(auto[0][i, :c], sg[i, :c]) and np.array_equal(auto[2][i, :c], sv[i, :c]), (k, with_dup, i)
+                assert np.array_equal(auto[3][i, :c].view(np.uint32), ss[i, :c].view(np.uint32)), (k, with_dup, i)
+            # every segment forced onto the RaBitQ walk: one launch == segment at a time == a launch per segment == the one-wave kernel
+            got = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
+            idx.tunable("serial_segments", 1)
+            serial = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
+            monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "1")
+            serial_one_wave = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
+            monkeypatch.delenv("NIDX_GPU_RABITQ_WAVES")
+            idx.tunable("serial_segments", 0)
+            assert same(got, serial), (k, with_dup)
+            assert same(serial_one_wave, serial), (k, with_dup)
+            for var in ("NIDX_GPU_SEGMENT_LAUNCHES", "NIDX_GPU_RABITQ_WAVES"):
+                monkeypatch.setenv(var, "1")
+                assert same(idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score), got), (var, k, with_dup)
+                monkeypatch.delenv(var)
+        tickets = [idx.submit(q.ctypes.data, B, 10, _lib.METHOD_RABITQ_HNSW, False)[1] for _ in range(3)]
+        want = idx.search(q, 10, _lib.METHOD_RABITQ_HNSW, False)
         for t in reversed(tickets):
             rc, g, retried = idx.wait(t, B, 10)
             assert rc == 0 and retried == 0 and same(g, want)
