@@ -2301,7 +2301,8 @@ def bench_rabitq(a, L, dev, rank, world):
                                              "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
                                             {"controller_predict_pop_and_waiting_for_the_fetcher": float(s[:, 4].mean()), "admission": float(s[:, 6].mean()),
                                              "total": float(s[:, 7].mean())}),
-                       "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float(s[:, 5].mean())},
+                       "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float((s[:, 5] & 0xFFFF).mean()),
+                       "expansions_with_edge_record_held_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float((s[:, 5] >> 16).mean())},
             "roofline": {"kernel": "rabitq walk kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},

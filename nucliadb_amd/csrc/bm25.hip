@@ -847,7 +847,19 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
         const bool valid = key != NIDX_EMPTY_KEY && e < k;
         cnt += (uint32_t)__popcll(__ballot(valid));
         if (e < k) {
-            m.out_doc[(size_t)q * k + e] = valid ? rank_key_addr(key) : 0xffffffffu;
+            uint32_t d = valid ? rank_key_addr(key) : 0xffffffffu;
+            if (m.seg_base) {
+                // DocAddress of a resident doc: the last segment whose first doc is <= d (empty segments share their base with the next)
+                uint32_t lo = 0, hi = m.n_seg;
+                while (valid && hi - lo > 1) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (m.seg_base[mid] <= d) lo = mid;
+                    else hi = mid;
+                }
+                if (valid) d -= m.seg_base[lo];
+                m.out_seg[(size_t)q * k + e] = lo;
+            }
+            m.out_doc[(size_t)q * k + e] = d;
             m.out_score[(size_t)q * k + e] = valid ? rank_key_score(key) : 0.f;
         }
     }

@@ -120,7 +120,7 @@ struct Bm25Slot {
     Bm25Ctx cx;
     // layout of cx.h_outpack for the collect step
     uint32_t nq = 0, k = 0, kk = 0;
-    size_t o_doc = 0, o_score = 0, o_count = 0, o_total = 0, o_post = 0;
+    size_t o_doc = 0, o_score = 0, o_count = 0, o_total = 0, o_post = 0, o_seg = 0;
     // a request the pipeline does not cover (term sets, phrases, nested queries, facets, order by a field) runs synchronously inside
     // submit; its results wait here
     std::vector<uint64_t> r_docaddr, r_total, r_postings;
@@ -148,6 +148,7 @@ struct Bm25Index {
     std::vector<Bm25Segment> segs;
     std::vector<Bm25RealSegment> real;     // non-empty <=> concatenated
     std::vector<uint32_t> seg_base;        // [n_real + 1] running sum of the real segments' n_docs
+    DevBuf d_seg_base;                     // the same in HBM: bm25_merge_kernel turns resident docs into (segment, doc)
     uint32_t n_segments = 0;               // segments the caller opened
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
@@ -269,6 +270,8 @@ static int32_t bm25_upload_concatenated(Bm25Index *idx, const nidx_gpu_bm25_segm
         any_dead |= in.alive_bitset != nullptr;
         if (in.term_offsets[T] && !in.pos_offsets) all_pos = false;   // phrases need the positions of every segment
     }
+    NIDX_HIP(idx->d_seg_base.alloc((size_t)(n_segments + 1) * 4));
+    NIDX_HIP(hipMemcpy(idx->d_seg_base.p, idx->seg_base.data(), (size_t)(n_segments + 1) * 4, hipMemcpyHostToDevice));
     idx->segs.resize(1);
     Bm25Segment &v = idx->segs[0];
     v.n_docs = (uint32_t)n_docs_all;
@@ -1244,7 +1247,9 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         const uint32_t *d_items = reinterpret_cast<const uint32_t *>(d_w + if_bytes + work_bytes);
         // per-query outputs of the merge kernel, one block: doc u32 [nq][kk] | score f32 [nq][kk] | count u32 [nq] | total u64 [nq] | postings u64 [nq]
         const size_t o_doc = 0, o_score = (size_t)nq * kk * 4, o_count = o_score + (size_t)nq * kk * 4;
-        const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, out_bytes = o_post + (size_t)nq * 8;
+        const size_t o_total = (o_count + (size_t)nq * 4 + 7) & ~(size_t)7, o_post = o_total + (size_t)nq * 8, o_seg = o_post + (size_t)nq * 8;
+        const bool cat = idx->concatenated();
+        const size_t out_bytes = o_seg + (cat ? (size_t)nq * kk * 4 : 0);   // concatenated layout: + segment u32 [nq][kk]
         NIDX_HIP(cx.h_outpack.reserve(out_bytes));
         unsigned char *d_out = nullptr;
         if (zc_out) {
@@ -1321,6 +1326,11 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         mg.out_count = reinterpret_cast<uint32_t *>(d_out + o_count);
         mg.out_total = reinterpret_cast<unsigned long long *>(d_out + o_total);
         mg.out_postings = reinterpret_cast<unsigned long long *>(d_out + o_post);
+        if (cat) {
+            mg.seg_base = idx->d_seg_base.as<uint32_t>();
+            mg.n_seg = idx->n_segments;
+            mg.out_seg = reinterpret_cast<uint32_t *>(d_out + o_seg);
+        }
         NIDX_HIP(launch_bm25_merge(mg, nq, cx.stream));
         if (n_slots)
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_pair_term.as<uint32_t>(),
@@ -1333,12 +1343,13 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         const uint32_t *h_count = reinterpret_cast<const uint32_t *>(h_out + o_count);
         const unsigned long long *h_total = reinterpret_cast<const unsigned long long *>(h_out + o_total);
         const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + o_post);
+        const uint32_t *h_seg = reinterpret_cast<const uint32_t *>(h_out + o_seg);   // (concatenated layout only)
         if (async_slot && idx->segs.size() == 1 && n_aux == 0 && n_slots == 0 && order_field < 0 && !a.dbg) {
             // pipelined: the collect step runs in nidx_gpu_bm25_search_wait (the buffers are the slot's: swapped in by submit)
             Bm25Slot &sl = *async_slot;
             sl.launched = true;
             sl.nq = nq, sl.k = k, sl.kk = kk;
-            sl.o_doc = o_doc, sl.o_score = o_score, sl.o_count = o_count, sl.o_total = o_total, sl.o_post = o_post;
+            sl.o_doc = o_doc, sl.o_score = o_score, sl.o_count = o_count, sl.o_total = o_total, sl.o_post = o_post, sl.o_seg = o_seg;
             return NIDX_OK;
         }
         const double t_s0 = now_us();
@@ -1403,10 +1414,12 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                 const uint32_t n = std::min<uint32_t>(h_count[q], k);
                 out_count[q] = n;
                 for (uint32_t i = 0; i < n; i++) {
-                    const uint32_t d = h_doc[(size_t)q * kk + i];
-                    if (out_docaddr) out_docaddr[(size_t)q * k + i] = idx->docaddr(s, d);
+                    const uint32_t d = h_doc[(size_t)q * kk + i];   // concatenated layout: already the doc inside its segment
+                    const uint32_t sg = cat ? h_seg[(size_t)q * kk + i] : (uint32_t)s;
+                    if (out_docaddr) out_docaddr[(size_t)q * k + i] = ((uint64_t)sg << 32) | d;
                     if (out_score) out_score[(size_t)q * k + i] = order_field >= 0 ? 0.f : h_score[(size_t)q * kk + i];
-                    if (opt->out_order_value) opt->out_order_value[(size_t)q * k + i] = order_field >= 0 ? seg.fast_host[order_field][d] : 0;
+                    if (opt->out_order_value)
+                        opt->out_order_value[(size_t)q * k + i] = order_field >= 0 ? seg.fast_host[order_field][cat ? idx->seg_base[sg] + d : d] : 0;
                 }
                 continue;
             }
@@ -1576,14 +1589,15 @@ int32_t nidx_gpu_bm25_search_wait(nidx_gpu_bm25_index_t *index, uint64_t ticket,
         const unsigned long long *h_post = reinterpret_cast<const unsigned long long *>(h_out + slot->o_post);
         const uint32_t kk = slot->kk;
         const bool cat = idx->concatenated();
+        const uint32_t *h_seg = reinterpret_cast<const uint32_t *>(h_out + slot->o_seg);   // (concatenated layout only)
         for (uint32_t q = 0; q < nq; q++) {   // one resident segment: the device list is the answer
             if (out_total) out_total[q] = h_total[q];
             if (out_postings) out_postings[q] = h_post[q];
             const uint32_t n = k ? std::min<uint32_t>(h_count[q], k) : 0u;
             out_count[q] = n;
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t d = h_doc[(size_t)q * kk + i];
-                if (out_docaddr) out_docaddr[(size_t)q * k + i] = cat ? idx->docaddr(0, d) : (uint64_t)d;
+                const uint64_t sg = cat ? h_seg[(size_t)q * kk + i] : 0u;   // (the merge kernel already split resident docs into segment, doc)
+                if (out_docaddr) out_docaddr[(size_t)q * k + i] = (sg << 32) | h_doc[(size_t)q * kk + i];
                 if (out_score) out_score[(size_t)q * k + i] = h_score[(size_t)q * kk + i];
             }
         }

@@ -435,6 +435,7 @@ hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s) {
     if (nj <= 6) NIDX_BUILD_CASE(6);
     if (nj <= 8) NIDX_BUILD_CASE(8);
     if (nj <= 12) NIDX_BUILD_CASE(12);
+    if (nj <= 16) NIDX_BUILD_CASE(16);   // D <= 4096
 #undef NIDX_BUILD_CASE
     return hipErrorInvalidValue;
 }

@@ -359,6 +359,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, int waves_per_query, hipS
     if (nj <= 6) return launch_wide<6>(a, waves_per_query, s);
     if (nj <= 8) return launch_wide<8>(a, waves_per_query, s);
     if (nj <= 12) return launch_wide<12>(a, waves_per_query, s);
+    if (nj <= 16) return launch_wide<16>(a, waves_per_query, s);   // D <= 4096
     return hipErrorInvalidValue;
 }
 

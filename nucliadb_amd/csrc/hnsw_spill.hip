@@ -235,6 +235,7 @@ hipError_t launch_hnsw_closest_spill(const HnswSpillArgs &a, hipStream_t s) {
     if (nj <= 6) return launch_spill_nj<6>(a, s);
     if (nj <= 8) return launch_spill_nj<8>(a, s);
     if (nj <= 12) return launch_spill_nj<12>(a, s);
+    if (nj <= 16) return launch_spill_nj<16>(a, s);
     return hipErrorInvalidValue;
 }
 

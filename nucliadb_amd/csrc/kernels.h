@@ -396,6 +396,11 @@ struct Bm25MergeArgs {  // per query: merge the key lists of its work items [ite
     float *out_score;                       // [n_queries][k] (meaningless when ordering by a fast field)
     uint32_t *out_count;
     unsigned long long *out_total, *out_postings;  // [n_queries]
+    // an index of several segments resident as one (bm25_index.cpp: bm25_upload_concatenated): seg_base[n_seg] = first resident doc of
+    // every opened segment; out_doc then is the doc id INSIDE its segment and out_seg [n_queries][k] the segment.  nullptr = one segment
+    const uint32_t *seg_base = nullptr;
+    uint32_t n_seg = 0;
+    uint32_t *out_seg = nullptr;
 };
 hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s);
 #define BM25_FAST_CLAUSES 8   /* queries of at most this many clauses take bm25_fast_kernel */

@@ -859,9 +859,11 @@ struct RqFetchBuf {      // one expansion, written by the fetcher
     uint32_t addr[64];   // the fresh neighbours in edge order
     float est[64];
 };
+#define RQ_EDGE_CACHE 3
 struct RqCtl {
-    uint32_t pred, pred2, state, fetch_node, abort, ep, cache_node, pad;
-    uint32_t cache_w[64];   // the edge record (layer 0) of cache_node
+    uint32_t pred, pred2, pred3, state, fetch_node, abort, ep, pad;
+    uint32_t cache_node[4];                 // the layer-0 edge records the fetcher holds (RQ_NONE = free)
+    uint32_t cache_w[RQ_EDGE_CACHE][64];
 };
 enum { RQ_STATE_HIT = 0, RQ_STATE_MISS = 1, RQ_STATE_DONE = 2 };
 
@@ -869,11 +871,12 @@ static size_t rq_smem2_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) 
     return rq_smem_bytes(nw, dp, k, ef, true) + 2 * sizeof(RqFetchBuf) + sizeof(RqCtl);
 }
 
-// the best and (when it sits in the same chunk) second-best unexpanded key of the result set; 0 = none.  Changes nothing but the
-// hint dcur (chunks before it hold expanded keys only — still true afterwards).
-__device__ inline void rq_peek2(RqLayer &L, int lane, uint64_t &k1, uint64_t &k2) {
+// the best and (when they sit in the same chunk) second- and third-best unexpanded keys of the result set; 0 = none.  Changes nothing
+// but the hint dcur (chunks before it hold expanded keys only — still true afterwards).
+__device__ inline void rq_peek3(RqLayer &L, int lane, uint64_t &k1, uint64_t &k2, uint64_t &k3) {
     k1 = 0;
     k2 = 0;
+    k3 = 0;
     L.dcur = uni(L.dcur);
     L.n_dir = uni(L.n_dir);
     while (L.dcur < L.n_dir) {
@@ -884,23 +887,63 @@ __device__ inline void rq_peek2(RqLayer &L, int lane, uint64_t &k1, uint64_t &k2
             k1 = lane_u64(mine, __ffsll((long long)m) - 1);
             m &= m - 1;
             if (m) k2 = lane_u64(mine, __ffsll((long long)m) - 1);
+            m &= m - 1;
+            if (m) k3 = lane_u64(mine, __ffsll((long long)m) - 1);
             return;
         }
         L.dcur++;
     }
 }
 
-// the fetcher's expansion of `node` on `layer` -> out; node2 (layer 0, or RQ_NONE): its edge record is fetched along and kept
+// the fetcher's expansion of `node` on `layer` -> out.  n2 / n3 (layer 0, or RQ_NONE): the candidates most likely to be expanded after
+// it — their edge records are requested along with this expansion's loads and kept in a three-record cache (read-only data: nothing to
+// roll back), so that an expansion whose node was foreseen starts at its neighbours' codes: one memory round trip instead of two.
 template <int NW>
-__device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, RqCtl *ctl, RqFetchBuf *out, uint32_t node, uint32_t node2,
-                                int layer, uint32_t *gvis, const RabitqQueryDev &qc, uint32_t nw, uint32_t &vis_count, int lane) {
-    const bool pf = layer == 0 && node2 != RQ_NONE && node2 != node;
-    uint32_t w2 = 0;
-    if (pf) w2 = load_edge_raw(a.g, node2, 0, lane);
+__device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, RqCtl *ctl, RqFetchBuf *out, uint32_t node, uint32_t n2, uint32_t n3,
+                                int layer, uint32_t *gvis, const RabitqQueryDev &qc, uint32_t nw, uint32_t &vis_count, uint32_t &cache_hits, int lane) {
     uint32_t w;
-    const uint32_t cnode = layer == 0 ? (uint32_t)uni((int)ctl->cache_node) : RQ_NONE;
-    if (cnode == node) w = ctl->cache_w[lane];
-    else w = load_edge_raw(a.g, node, layer, lane);
+    uint32_t pf_node[2] = {RQ_NONE, RQ_NONE}, pf_w[2] = {0u, 0u};
+    int pf_slot[2] = {-1, -1};
+    if (layer == 0) {
+        uint32_t cn[RQ_EDGE_CACHE];
+#pragma unroll
+        for (int i = 0; i < RQ_EDGE_CACHE; i++) cn[i] = (uint32_t)uni((int)ctl->cache_node[i]);
+        int hit = -1;
+#pragma unroll
+        for (int i = 0; i < RQ_EDGE_CACHE; i++)
+            if (cn[i] == node) hit = i;
+        // what to request ahead: n2 / n3 unless already held (or the node itself); they take the slots that hold neither of them
+        // (the record of `node` is read into registers first, so its slot is free too)
+        const uint32_t want[2] = {n2, n3 == n2 ? RQ_NONE : n3};
+        bool keep[RQ_EDGE_CACHE];
+#pragma unroll
+        for (int i = 0; i < RQ_EDGE_CACHE; i++) keep[i] = cn[i] != RQ_NONE && cn[i] != node && (cn[i] == want[0] || cn[i] == want[1]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (want[j] == RQ_NONE || want[j] == node) continue;
+            bool held = false;
+#pragma unroll
+            for (int i = 0; i < RQ_EDGE_CACHE; i++) held |= cn[i] == want[j];
+            if (held) continue;
+            int slot = -1;
+#pragma unroll
+            for (int i = RQ_EDGE_CACHE - 1; i >= 0; i--)
+                if (!keep[i]) slot = i;
+            if (slot < 0) continue;
+            keep[slot] = true;
+            pf_node[j] = want[j];
+            pf_slot[j] = slot;
+            pf_w[j] = load_edge_raw(a.g, want[j], 0, lane);
+        }
+        if (hit >= 0) {
+            w = ctl->cache_w[hit][lane];
+            cache_hits++;
+        } else {
+            w = load_edge_raw(a.g, node, 0, lane);
+        }
+    } else {
+        w = load_edge_raw(a.g, node, layer, lane);
+    }
     const uint32_t deg = lane_u32(w, 0);
     const bool is_edge = lane >= 1 && lane <= (int)deg;
     // the code of every neighbour is requested together with the visited test (one round trip); codes of visited ones are dropped
@@ -932,8 +975,12 @@ __device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, R
         out->flags = oflags;
     }
     if (layer == 0) {
-        if (pf) ctl->cache_w[lane] = w2;
-        if (lane == 0) ctl->cache_node = pf ? node2 : RQ_NONE;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (pf_slot[j] >= 0) {
+                ctl->cache_w[pf_slot[j]][lane] = pf_w[j];
+                if (lane == 0) ctl->cache_node[pf_slot[j]] = pf_node[j];
+            }
     }
 }
 
@@ -965,7 +1012,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
     const RabitqQueryDev qc = a.qd[qi];
     uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
     uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;   // controller
-    uint32_t vis_count = 0;                                // fetcher (upper layers)
+    uint32_t vis_count = 0, cache_hits = 0;                // fetcher (upper layers' visited count; layer-0 expansions whose edge record was held)
     uint64_t cyc_ctl = 0, cyc_wait = 0, cyc_ins = 0;
     const uint64_t t_start = clock64();
     __syncthreads();
@@ -989,6 +1036,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                 ctl->fetch_node = node;
                 ctl->pred = RQ_NONE;
                 ctl->pred2 = RQ_NONE;
+                ctl->pred3 = RQ_NONE;
                 ctl->abort = 0;
             }
         } else {
@@ -998,7 +1046,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                 vis_count = 1;
             } else if (lane == 0) {
                 atomicOr(&gvis[ep >> 5], 1u << (ep & 31));
-                ctl->cache_node = RQ_NONE;
+                for (int i = 0; i < 4; i++) ctl->cache_node[i] = RQ_NONE;
             }
         }
         __syncthreads();
@@ -1006,7 +1054,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
         bool need_fetch = true;
         for (;;) {
             if (need_fetch) {
-                if (!w0) rq_fetch<NW>(a, sh, ctl, &buf[cur], (uint32_t)uni((int)ctl->fetch_node), RQ_NONE, layer, gvis, qc, nw, vis_count, lane);
+                if (!w0) rq_fetch<NW>(a, sh, ctl, &buf[cur], (uint32_t)uni((int)ctl->fetch_node), RQ_NONE, RQ_NONE, layer, gvis, qc, nw, vis_count, cache_hits, lane);
                 const uint64_t tw = clock64();
                 __syncthreads();
                 cyc_wait += clock64() - tw;
@@ -1026,13 +1074,14 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                         ctl->abort = 1;
                         ctl->pred = RQ_NONE;
                         ctl->pred2 = RQ_NONE;
+                        ctl->pred3 = RQ_NONE;
                     }
                 } else {
                     n_est += fn;
                     fresh = (uint32_t)lane < fn;
                     fest = fresh ? b->est[lane] : 0.f;
                     faddr = fresh ? b->addr[lane] : 0u;
-                    uint32_t p1 = RQ_NONE, p2 = RQ_NONE;
+                    uint32_t p1 = RQ_NONE, p2 = RQ_NONE, p3 = RQ_NONE;
                     if (layer == 0) {
                         L.len = uni(L.len);
                         L.worst = uni64(L.worst);
@@ -1040,22 +1089,23 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                         const bool full = L.len >= kk;
                         const uint64_t key_new = (fresh && (!full || fest > ws)) ? rq_key(fest, faddr, 1u) : 0ull;
                         const uint64_t best_new = wave_max_u64(key_new);
-                        uint64_t pk1, pk2;
-                        rq_peek2(L, lane, pk1, pk2);
-                        uint64_t a1, a2;
-                        if (best_new > pk1) {
-                            a1 = best_new;
-                            a2 = pk1;
-                        } else {
-                            a1 = pk1;
-                            a2 = best_new > pk2 ? best_new : pk2;
-                        }
+                        uint64_t pk1, pk2, pk3;
+                        rq_peek3(L, lane, pk1, pk2, pk3);
+                        // the three best of {best new neighbour, pk1 >= pk2 >= pk3}: the first is the prediction, the others the
+                        // candidates whose edge records the fetcher requests ahead
+                        uint64_t a1, a2, a3;
+                        if (best_new > pk1) a1 = best_new, a2 = pk1, a3 = pk2;
+                        else if (best_new > pk2) a1 = pk1, a2 = best_new, a3 = pk2;
+                        else if (best_new > pk3) a1 = pk1, a2 = pk2, a3 = best_new;
+                        else a1 = pk1, a2 = pk2, a3 = pk3;
                         if (a1) p1 = rq_addr(a1);
                         if (a2) p2 = rq_addr(a2);
+                        if (a3) p3 = rq_addr(a3);
                     }
                     if (lane == 0) {
                         ctl->pred = p1;
                         ctl->pred2 = p2;
+                        ctl->pred3 = p3;
                     }
                 }
             }
@@ -1064,7 +1114,8 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
             const uint32_t pred = (uint32_t)uni((int)ctl->pred);
             const bool aborted = uni((int)ctl->abort) != 0;
             if (!w0) {
-                if (pred != RQ_NONE) rq_fetch<NW>(a, sh, ctl, &buf[cur ^ 1], pred, (uint32_t)uni((int)ctl->pred2), layer, gvis, qc, nw, vis_count, lane);
+                if (pred != RQ_NONE)
+                    rq_fetch<NW>(a, sh, ctl, &buf[cur ^ 1], pred, (uint32_t)uni((int)ctl->pred2), (uint32_t)uni((int)ctl->pred3), layer, gvis, qc, nw, vis_count, cache_hits, lane);
             } else {
                 uint32_t st = RQ_STATE_DONE, node = 0, next;
                 if (!aborted) {
@@ -1112,6 +1163,8 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
         if (w0) {
             ep = rq_addr(lane_u64(L.dir_first, 0));  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
             if (lane == 0) ctl->ep = ep;
+        } else if (lane == 0) {
+            ctl->pad = cache_hits;
         }
         __syncthreads();
         ep = (uint32_t)uni((int)ctl->ep);
@@ -1143,7 +1196,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
         o[NIDX_STAT_FLAGS] = flags;
         // the controller's cycles: prediction + pop / expansions whose fetch was speculated and confirmed / admissions; [7] = total incl. re-rank
         o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_ctl + cyc_wait);
-        o[NIDX_STAT_EDGE_HITS] = n_hit;
+        o[NIDX_STAT_EDGE_HITS] = (n_hit & 0xffffu) | ((uint32_t)uni((int)ctl->pad) << 16);   // confirmed speculations | expansions whose edge record was held
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
         o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
     }

@@ -297,7 +297,12 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         // One plain segment (no cross-segment paragraph keys): Fssc is the identity on a falling score list, which the host checks while it
         // copies the row (fssc_merge's fast path) — a merge kernel would only add a launch that, with other batches in flight, waits for
         // workgroup slots behind their walks (8 us alone, 60 us in the hybrid trace) and a larger transfer.
-        sl.merged = !(S == 1 && segs[0].key_ids.empty()) && !getenv("NIDX_GPU_FSSC_HOST");   // the variable: merge on the host (comparison)
+        // Fssc's `seen` set (with_duplicates = false, the default) compares a candidate with everything offered before it: on the device
+        // that is one wave scanning the offered list per candidate, O((segments x k)^2 / 64) dependent steps — fine at the 500 candidates
+        // of 50 segments x k = 10, seconds at nucliadb's page sizes (k up to 500).  Past 4 096 candidates per query the per-segment rows go
+        // to the host merge (a hash set there).
+        const bool big_dedup = p.with_duplicates == 0 && (uint64_t)S * k > 4096;
+        sl.merged = !(S == 1 && segs[0].key_ids.empty()) && !big_dedup && !getenv("NIDX_GPU_FSSC_HOST");   // the variable: merge on the host (comparison)
         const size_t fw = flag_words(S), mw = sl.merged ? merged_words(nq, k) : 0, sw = seg_words(nq, k), words = fw + mw + S * sw;
         sl.mw = mw;
         sl.dirty = true;   // from here on work is queued on the slot's stream: an error path must drain it (SlotRelease)

@@ -689,6 +689,7 @@ hipError_t launch_rescore_select(const RescoreArgs &a, hipStream_t s) {
     if (nj <= 6) { NIDX_RS_CASE(6); }
     if (nj <= 8) { NIDX_RS_CASE(8); }
     if (nj <= 12) { NIDX_RS_CASE(12); }
+    if (nj <= 16) { NIDX_RS_CASE(16); }
 #undef NIDX_RS_CASE
     return hipErrorInvalidValue;
 }

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -1112,6 +1113,7 @@ int32_t VectorIndex::fssc_merge(uint32_t nq, const nidx_gpu_vector_search_params
     // final sort leaves the kernel's order — the general loop below would copy the row unchanged.
     const bool one_plain_segment = S == 1 && seg_count[0] && segs[0].key_ids.empty();
     std::vector<Cand> buff, offered;
+    std::unordered_multimap<uint32_t, uint32_t> offered_by_score;   // score bits -> index into `offered`
     for (uint32_t q = 0; q < nq; q++) {
         if (one_plain_segment) {
             const uint32_t cnt = seg_count[0][q];
@@ -1133,6 +1135,7 @@ int32_t VectorIndex::fssc_merge(uint32_t nq, const nidx_gpu_vector_search_params
         }
         buff.clear();
         offered.clear();
+        offered_by_score.clear();
         for (size_t s = 0; s < S; s++) {
             if (!seg_count[s]) continue;
             for (uint32_t i = 0; i < seg_count[s][q]; i++) {
@@ -1145,15 +1148,21 @@ int32_t VectorIndex::fssc_merge(uint32_t nq, const nidx_gpu_vector_search_params
                 if (!p.with_duplicates) {
                     // Fssc.seen: vector bytes already offered.  Equal bytes imply equal score bits for
                     // one query, so rows are only fetched back on a bit-identical score.
+                    // (the candidates offered so far are found by their score bits through a hash: pages of 500 hits from 50
+                    // segments are 25 000 candidates per query, and a scan of all of them per candidate is 3 x 10^8 compares)
                     bool dup = false;
-                    for (const Cand &o : offered) {
-                        if (memcmp(&o.score, &c.score, 4) != 0) continue;
+                    uint32_t sbits;
+                    memcpy(&sbits, &c.score, 4);
+                    auto range = offered_by_score.equal_range(sbits);
+                    for (auto it = range.first; it != range.second && !dup; ++it) {
+                        const Cand &o = offered[it->second];
                         bool eq = false;
                         int32_t rc = rows_equal_host(o.seg, o.vec, c.seg, c.vec, eq);
                         if (rc != NIDX_OK) return rc;
-                        if (eq) { dup = true; break; }
+                        if (eq) dup = true;
                     }
                     if (dup) continue;
+                    offered_by_score.emplace(sbits, (uint32_t)offered.size());
                     offered.push_back(c);
                 }
                 if (buff.size() == k) {
@@ -1239,7 +1248,8 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
         return fail(NIDX_ERR_INVALID_CONFIGURATION, "Invalid configuration: unknown similarity %d", config->similarity);
     if (config->vector_cardinality != NIDX_CARDINALITY_SINGLE && config->vector_cardinality != NIDX_CARDINALITY_MULTI)
         return fail(NIDX_ERR_INVALID_CONFIGURATION, "unknown vector cardinality %d", config->vector_cardinality);
-    if (config->dimension > 3072) return fail(NIDX_ERR_UNSUPPORTED, "dimension > 3072 is not supported yet");
+    // (the kernels keep a query as dimension / 256 16-byte pieces per lane: up to 16 of them)
+    if (config->dimension > 4096) return fail(NIDX_ERR_UNSUPPORTED, "dimension > 4096 is not supported (got %u)", config->dimension);
     std::unique_ptr<VectorIndex> idx(new VectorIndex());
     idx->cfg = *config;
     // tuning knobs (not part of the ABI): workgroup shape and visited-table size of the HNSW kernels

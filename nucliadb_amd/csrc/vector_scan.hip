@@ -310,6 +310,7 @@ hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
     if (nj <= 6) return launch_scan_nj<6, false>(a, nblk, s);
     if (nj <= 8) return launch_scan_nj<8, false>(a, nblk, s);
     if (nj <= 12) return launch_scan_nj<12, false>(a, nblk, s);
+    if (nj <= 16) return launch_scan_nj<16, false>(a, nblk, s);
     return hipErrorInvalidValue;
 }
 

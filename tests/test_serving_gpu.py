@@ -236,7 +236,9 @@ def test_every_segment_in_one_launch_and_fssc_on_the_device(orc, monkeypatch):
     try:
         q = np.ascontiguousarray(np.vstack([xs[0][11][None, :], xs[2][40][None, :], xs[1][20][None, :], xs[4][33][None, :], unit_rows(rng, 60, d)]))
         B = q.shape[0]
-        for k, with_dup, min_score in ((10, True, -1.0), (10, False, -1.0), (1, False, -1.0), (70, False, -1.0), (25, True, 0.05), (12, False, 0.08)):
+        # (k = 500 without duplicates: 9 x 500 candidates per query exceed what the device Fssc de-duplicates — the host merge takes over)
+        for k, with_dup, min_score in ((10, True, -1.0), (10, False, -1.0), (1, False, -1.0), (70, False, -1.0), (25, True, 0.05), (12, False, 0.08),
+                                       (500, False, -1.0)):
             # the oracle's Searcher::_search routes every segment through OpenSegment::_search's cost model (brute force for the small
             # segments at large k): METHOD_AUTO here — the HNSW segments share the one launch, the others get a launch each
             sg, sv, ss, sc = orc.searcher_search_batch(osegs, q, k, min_score=min_score, with_duplicates=with_dup, threads=4, para_keys=key_ids)

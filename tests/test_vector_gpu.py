@@ -472,3 +472,34 @@ def test_bf16_fallback_filter_and_min_score(orc):
     for i in range(len(q)):
         assert np.array_equal(v_ex[i, : c_ex[i]], v_bf[i, : c_bf[i]])
         assert np.array_equal(bits(s_ex[i, : c_ex[i]]), bits(s_bf[i, : c_bf[i]]))
+
+
+@pytest.mark.parametrize("d", [3500, 4096])
+def test_wide_dimensions_match_oracle(orc, d):
+    """Dimensions above 3 072 (round 5: up to 4 096 — sixteen 16-byte pieces of a row per lane): the exact scan, the HNSW search over
+    an oracle-built graph and a filter-starved walk through the HBM-resident fallback equal the oracle bit for bit; beyond 4 096 the
+    open is refused.  The reference has no bound (nidx_vector/src/config.rs:170-173)."""
+    rng = np.random.default_rng(d)
+    n, nq, k = 1500, 6, 10
+    x = unit_rows(rng, n, d)
+    q = np.vstack([x[7][None, :], unit_rows(rng, nq - 1, d)])
+    oseg = orc.Segment(x, similarity=orc.SIM_COSINE, order=orc.ORDER_WAVE64)
+    gbytes = bytes(oseg.build_graph(seed=2).serialize_v2(n)[0])
+    for method, fn in ((_lib.METHOD_BRUTE_FORCE, oseg.brute_force), (_lib.METHOD_HNSW, oseg.hnsw_search)):
+        ov, osc, oc = gpu_search(x, 1, q, k, method=method, graph=gbytes)
+        for i in range(nq):
+            wv, ws = fn(q[i], k)
+            assert oc[i] == len(wv), (method, i)
+            assert np.array_equal(ov[i, : oc[i]], wv), (method, i, ov[i, : oc[i]], wv)
+            assert np.array_equal(bits(osc[i, : oc[i]]), bits(ws)), (method, i)
+    filt = orc.bitset(n, ones=list(range(0, n, 150)))
+    ov, osc, oc = gpu_search(x, 1, q, k, method=_lib.METHOD_HNSW, graph=gbytes, filter_bits=filt)
+    for i in range(nq):
+        wv, ws = oseg.hnsw_search(q[i], k, filter_bits=filt)
+        assert oc[i] == len(wv) and np.array_equal(ov[i, : oc[i]], wv) and np.array_equal(bits(osc[i, : oc[i]]), bits(ws)), i
+    L = _lib.lib()
+    cfg = _lib.VectorConfigC(4100, 1, 0, 0)
+    xs = np.zeros((2, 4100), np.float32)
+    seg = _lib.VectorSegmentC(xs.ctypes.data, 4100 * 4, 2, None, 2, None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    assert L.nidx_gpu_vector_open(C.byref(cfg), C.byref(seg), 1, C.byref(h)) == _lib.NIDX_ERR_UNSUPPORTED
