@@ -1901,8 +1901,11 @@ class Bm25Bench:
                 same_ids += int(c == int(want[1][i]) and tt[i] == want[2][i] and np.array_equal(g, want[0][i, :c].astype(np.int64)) and
                                 np.array_equal(sc[i, :c].view(np.uint32), want[3][i, :c].view(np.uint32)))
             elapsed, n_steps, postings, _ = self.timed_pipeline(ms, threads_n, depth)
+            # control: the one-segment index again, timed right after (clocks, allocator state and host threads as for the leg above)
+            e1, n1, p1, _ = self.timed_pipeline(self.searcher, threads_n, depth)
+            one_segment_value = p1 / e1
             out = {"segments": [int(b_ - a_) for a_, b_ in zip(cuts[:-1], cuts[1:])], "value": postings / elapsed, "unit": "postings/s",
-                   "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value,
+                   "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value, "one_segment_value_note": "the one-segment index timed again right after this leg",
                    "ratio_to_one_segment": postings / elapsed / one_segment_value if one_segment_value else None,
                    "queries_identical_to_the_one_segment_index": same_ids, "queries": B, "split_s": split_s, "open_s": open_s,
                    "note": "the log-merge policy's shape (nidx/src/settings.rs:246-253); documents, ranks, score bits and totals must equal the "
@@ -2299,10 +2302,11 @@ def bench_rabitq(a, L, dev, rank, world):
                                       "rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)",
                        "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
                                              "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
-                                            {"controller_predict_pop_and_waiting_for_the_fetcher": float(s[:, 4].mean()), "admission": float(s[:, 6].mean()),
+                                            {"fetcher_speculative_fetches": float(((s[:, 4] & 0xFFFF) << 8).mean()),
+                                             "controller_predict_pop_and_waiting_for_the_fetcher": float((((s[:, 4] >> 16) & 0xFFFF) << 8).mean()), "admission": float(s[:, 6].mean()),
                                              "total": float(s[:, 7].mean())}),
                        "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float((s[:, 5] & 0xFFFF).mean()),
-                       "expansions_with_edge_record_held_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float((s[:, 5] >> 16).mean())},
+                       "expansions_with_edge_record_held_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float(((s[:, 5] >> 16) & 0xFFFF).mean())},
             "roofline": {"kernel": "rabitq walk kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},

@@ -32,6 +32,15 @@ uint32_t scan_shared_stripes(uint32_t n, uint32_t n_queries, uint32_t dp, uint32
 hipError_t launch_scan_shared(const ScanArgs &a, uint32_t stripes, hipStream_t s);
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,
                              uint32_t *out_vec, float *out_score, uint32_t *out_count, hipStream_t s);
+// the register-tile scans / merges of several segments in one launch each (table-driven: blockIdx.z / .y = segment)
+struct ScanMergeTab {
+    const uint64_t *partial;
+    uint32_t *out_vec;
+    float *out_score;
+    uint32_t *out_count;
+};
+hipError_t launch_scan_segments(const ScanArgs *table, uint32_t n_seg, ScanArgs shape, uint32_t nblk, hipStream_t s);
+hipError_t launch_merge_topk_segments(const ScanMergeTab *table, uint32_t n_seg, uint32_t n_queries, uint32_t lists_per_query, uint32_t k, hipStream_t s);
 hipError_t launch_maxsim(const float *vectors, const float *norm2, uint32_t dp, int similarity, const float *queries,
                          const uint32_t *cand_qfirst, const uint32_t *cand_qnum, const uint32_t *cand_first, const uint32_t *cand_num,
                          uint32_t n_cand, float *out, hipStream_t s);
@@ -277,6 +286,7 @@ struct RabitqSearchArgs {
     uint32_t *out_count;
     uint32_t *stats;          // nullptr or [n_queries][NIDX_STAT_STRIDE]: estimates, expansions, rows re-ranked, flags
     uint32_t *flag_word = nullptr;  // nullptr or [1]: OR of the flags any query raised (see HnswSearchArgs)
+    uint32_t no_speculation = 0;    // two-wave walk, measurement: 1 = the fetcher never runs ahead of the controller
 };
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s);
 hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,

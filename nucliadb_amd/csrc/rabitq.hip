@@ -1013,9 +1013,11 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
     uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
     uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;   // controller
     uint32_t vis_count = 0, cache_hits = 0;                // fetcher (upper layers' visited count; layer-0 expansions whose edge record was held)
-    uint64_t cyc_ctl = 0, cyc_wait = 0, cyc_ins = 0;
+    uint64_t cyc_ctl = 0, cyc_wait = 0, cyc_ins = 0, cyc_fetch = 0;
     const uint64_t t_start = clock64();
     __syncthreads();
+    // NIDX_GPU_RABITQ_SPEC=0 (measurement): no speculation — the two waves take turns (admit + pop, then fetch)
+    const bool speculate = a.no_speculation == 0;
 
     uint32_t ep = a.g.ep_node;
     RqLayer L;
@@ -1082,7 +1084,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                     fest = fresh ? b->est[lane] : 0.f;
                     faddr = fresh ? b->addr[lane] : 0u;
                     uint32_t p1 = RQ_NONE, p2 = RQ_NONE, p3 = RQ_NONE;
-                    if (layer == 0) {
+                    if (layer == 0 && speculate) {
                         L.len = uni(L.len);
                         L.worst = uni64(L.worst);
                         const float ws = rank_key_score(L.worst);
@@ -1114,8 +1116,11 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
             const uint32_t pred = (uint32_t)uni((int)ctl->pred);
             const bool aborted = uni((int)ctl->abort) != 0;
             if (!w0) {
-                if (pred != RQ_NONE)
+                if (pred != RQ_NONE) {
+                    const uint64_t tf = clock64();
                     rq_fetch<NW>(a, sh, ctl, &buf[cur ^ 1], pred, (uint32_t)uni((int)ctl->pred2), (uint32_t)uni((int)ctl->pred3), layer, gvis, qc, nw, vis_count, cache_hits, lane);
+                    cyc_fetch += clock64() - tf;
+                }
             } else {
                 uint32_t st = RQ_STATE_DONE, node = 0, next;
                 if (!aborted) {
@@ -1165,6 +1170,7 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
             if (lane == 0) ctl->ep = ep;
         } else if (lane == 0) {
             ctl->pad = cache_hits;
+            ctl->cache_node[3] = (uint32_t)(cyc_fetch >> 8);   // (the fourth id slot is not a cache slot)
         }
         __syncthreads();
         ep = (uint32_t)uni((int)ctl->ep);
@@ -1195,7 +1201,8 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
         o[NIDX_STAT_VISITED] = rr.n_eval;
         o[NIDX_STAT_FLAGS] = flags;
         // the controller's cycles: prediction + pop / expansions whose fetch was speculated and confirmed / admissions; [7] = total incl. re-rank
-        o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_ctl + cyc_wait);
+        // (cycles / 256, 16 bits each) the fetcher's speculative fetches | the controller's prediction + pop + waiting for the fetcher
+        o[NIDX_STAT_CYC_CTL] = ((uint32_t)uni((int)ctl->cache_node[3]) & 0xffffu) | ((uint32_t)(((cyc_ctl + cyc_wait) >> 8) & 0xffffu) << 16);
         o[NIDX_STAT_EDGE_HITS] = (n_hit & 0xffffu) | ((uint32_t)uni((int)ctl->pad) << 16);   // confirmed speculations | expansions whose edge record was held
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
         o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
@@ -1276,6 +1283,10 @@ static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32
     return hipGetLastError();
 }
 // NIDX_GPU_RABITQ_WAVES=1: the one-wave kernel of rounds 1-4 (comparison); default: two waves per query
+static bool rabitq_no_speculation() {
+    const char *e = getenv("NIDX_GPU_RABITQ_SPEC");
+    return e && atoi(e) == 0;
+}
 bool rabitq_two_waves() {
     const char *e = getenv("NIDX_GPU_RABITQ_WAVES");
     return !(e && atoi(e) == 1);
@@ -1284,7 +1295,9 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
     if (rabitq_two_waves()) {
         const size_t smem2 = rq_smem2_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef);
-        RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, a, smem2, s)
+        RabitqSearchArgs b = a;
+        b.no_speculation = rabitq_no_speculation() ? 1u : 0u;
+        RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s)
     }
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
     RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)

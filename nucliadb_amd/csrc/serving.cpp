@@ -157,7 +157,8 @@ struct SearchSlot {
     hipEvent_t done = nullptr;
     DevBuf d_queries, d_block, d_filter, d_tables, d_offered;
     DevBuf d_rq, d_rq_vis, d_rq_entry, d_rq_table;   // RaBitQ segments of a one-launch batch: encoded queries, visited bitsets, entry points, argument table
-    PinBuf pin_in, pin_out, pin_tables, pin_rq_table;
+    DevBuf d_bf_partial, d_bf_table;                 // brute-force segments of a one-launch batch: per-block lists, argument tables
+    PinBuf pin_in, pin_out, pin_tables, pin_rq_table, pin_bf_table;
     bool dirty = false;                      // work may be queued on `stream` / the flag words may be set: clean before reuse
     bool merged = false;                     // the block carries the device Fssc's hits
     size_t flag_bytes = 0;                   // flag words at the head of d_block
@@ -340,7 +341,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         // RaBitQ is the reference's default arm of a Dot index with D % 64 == 0 (config.rs:170-173, segment.rs:506-513): the walks of
         // every such segment join ONE table-driven launch too (rabitq_hnsw2_segments_kernel), their closest_up_nodes the plain
         // segments' grid in entry mode.  The visited bitsets of the launch (n_queries x vectors of those segments bits) stay under 4 GiB.
-        std::vector<uint32_t> rq_segs;
+        std::vector<uint32_t> rq_segs, bf_segs;
         bool rq_one_launch = one_launch && rabitq_two_waves() && k <= NIDX_K_MAX;
         if (rq_one_launch) {
             uint64_t vis_words = 0;
@@ -387,11 +388,55 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                     rq_segs.push_back((uint32_t)s);   // launched together behind this loop
                     continue;
                 }
+                if (method == NIDX_METHOD_BRUTE_FORCE && one_launch && k <= NIDX_K_MAX && scan_takes_tile_kernel((uint32_t)s, nq, k, matching)) {
+                    bf_segs.push_back((uint32_t)s);   // their scans share one launch, their merges another
+                    continue;
+                }
                 scan_matching_hint = matching;
                 const int32_t rc = segment_search_device((uint32_t)s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, method, sl.d_seg_filter[s],
                                                          d_vec, d_score, d_count, nullptr, default_vis_log2, sl.stream, blk + s);
                 scan_matching_hint = ~0ull;
                 if (rc != NIDX_OK) return rc;
+            }
+            if (!bf_segs.empty()) {
+                // Brute-force segments (a selective filter sends every segment of an index there, segment.rs:506-555): ONE launch scans
+                // them all (blockIdx.z = segment), one more merges every segment's per-block lists.  The lists of the launch stay under
+                // 2 GiB; past that (pages of hundreds of hits over dozens of large segments) the segments keep a launch pair each.
+                uint32_t nblk = 1;
+                for (uint32_t s : bf_segs) nblk = std::max(nblk, scan_num_blocks(segs[s].n));
+                const size_t per_seg = (size_t)nq * nblk * k * 8, n_bf = bf_segs.size();
+                if (per_seg * n_bf > ((size_t)2 << 30)) {
+                    for (uint32_t s : bf_segs) {
+                        uint32_t *d_vec = blk + fw + mw + (size_t)s * sw;
+                        const uint64_t *filt = segment_filters ? segment_filters[s] : nullptr;
+                        scan_matching_hint = filt ? popcount_filter(s, filt) : segs[s].alive_count;
+                        const int32_t rc = segment_search_device(s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, NIDX_METHOD_BRUTE_FORCE, sl.d_seg_filter[s],
+                                                                 d_vec, reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2, nullptr,
+                                                                 default_vis_log2, sl.stream, blk + s);
+                        scan_matching_hint = ~0ull;
+                        if (rc != NIDX_OK) return rc;
+                    }
+                } else {
+                    const size_t scan_tab = (n_bf * sizeof(ScanArgs) + 63) & ~(size_t)63, tab = scan_tab + n_bf * sizeof(ScanMergeTab);
+                    NIDX_HIP(sl.d_bf_partial.reserve(per_seg * n_bf));
+                    NIDX_HIP(sl.pin_bf_table.reserve(tab));
+                    NIDX_HIP(sl.d_bf_table.reserve(tab));
+                    ScanArgs *h_scan = sl.pin_bf_table.as<ScanArgs>();
+                    ScanMergeTab *h_merge = reinterpret_cast<ScanMergeTab *>(sl.pin_bf_table.as<unsigned char>() + scan_tab);
+                    for (size_t i = 0; i < n_bf; i++) {
+                        const uint32_t s = bf_segs[i];
+                        uint32_t *d_vec = blk + fw + mw + (size_t)s * sw;
+                        ScanArgs a = scan_args(s, sl.dq, nq, k, p.min_score, sl.d_seg_filter[s]);
+                        a.partial = reinterpret_cast<uint64_t *>(sl.d_bf_partial.as<unsigned char>() + per_seg * i);
+                        a.qt = scan_query_tile(nq, a.dp, k);
+                        h_scan[i] = a;
+                        h_merge[i] = ScanMergeTab{a.partial, d_vec, reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2};
+                    }
+                    NIDX_HIP(hipMemcpyAsync(sl.d_bf_table.p, sl.pin_bf_table.p, tab, hipMemcpyHostToDevice, sl.stream));
+                    NIDX_HIP(launch_scan_segments(sl.d_bf_table.as<ScanArgs>(), (uint32_t)n_bf, h_scan[0], nblk, sl.stream));
+                    NIDX_HIP(launch_merge_topk_segments(reinterpret_cast<const ScanMergeTab *>(sl.d_bf_table.as<unsigned char>() + scan_tab), (uint32_t)n_bf, nq, nblk,
+                                                        k, sl.stream));
+                }
             }
             if (!rq_segs.empty()) {
                 const uint32_t dim = segs[rq_segs[0]].dim, nw = dim / 64u, n_rq = (uint32_t)rq_segs.size();

@@ -446,6 +446,37 @@ HnswSearchArgs VectorIndex::hnsw_args(uint32_t s, const float *d_queries, uint32
     return a;
 }
 
+// The argument record of one segment's register-tile exact scan (single-vector paragraphs); the caller sets `partial`.
+ScanArgs VectorIndex::scan_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, const uint64_t *d_filter) const {
+    const VectorSegment &seg = segs[s];
+    ScanArgs a;
+    a.vectors = seg.vectors.as<float>();
+    a.norm2 = seg.norm2.as<float>();
+    a.n = seg.n;
+    a.dp = seg.dp;
+    a.queries = d_queries;
+    a.n_queries = nq;
+    a.alive = seg.all_alive ? nullptr : seg.alive.as<uint64_t>();
+    a.filter = d_filter;
+    a.para_of_vec = seg.identity_para ? nullptr : seg.para_of_vec.as<uint32_t>();
+    a.similarity = cfg.similarity;
+    a.min_score = min_score;
+    a.k = k;
+    a.qt = 0;
+    a.partial = nullptr;
+    a.row_mask = nullptr;
+    return a;
+}
+// true when segment s's exact scan of this batch takes the register-tile kernel (the shared-row scan needs large batches over
+// mostly unfiltered rows: those are long launches of their own)
+bool VectorIndex::scan_takes_tile_kernel(uint32_t s, uint32_t nq, uint32_t k, uint64_t matching) const {
+    const VectorSegment &seg = segs[s];
+    if (seg.vmax > 1) return false;   // multi-vector paragraphs go through para_best_kernel: the per-segment path
+    if (const char *e = getenv("NIDX_GPU_SCAN_SHARED"))
+        if (atoi(e) == 0) return true;
+    return scan_shared_stripes(seg.n, nq, seg.dp, k, matching) == 0;
+}
+
 // The argument record of one segment's RaBitQ walk (the HNSW arm, hnsw/search.rs:333-366); the caller fills in the per-launch
 // buffers: qd / planes (the encoded queries), visited (zeroed bitsets), out_* (the re-ranked entry points), stats.
 RabitqSearchArgs VectorIndex::rabitq_hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, uint32_t *d_flag_word) const {

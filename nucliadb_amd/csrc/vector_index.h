@@ -114,6 +114,8 @@ struct VectorIndex {
                                   bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_vec,
                                   float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats, uint32_t vis_log2,
                                   hipStream_t st, uint32_t *d_flag_word = nullptr);
+    ScanArgs scan_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, const uint64_t *d_filter) const;
+    bool scan_takes_tile_kernel(uint32_t s, uint32_t nq, uint32_t k, uint64_t matching) const;
     RabitqSearchArgs rabitq_hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score, uint32_t *d_flag_word) const;
     HnswSearchArgs hnsw_args(uint32_t s, const float *d_queries, uint32_t nq, uint32_t shape_nq, uint32_t k, float min_score, bool with_duplicates,
                              const uint64_t *d_filter, uint32_t *d_out_vec, float *d_out_score, uint32_t *d_out_count, uint32_t *d_stats,

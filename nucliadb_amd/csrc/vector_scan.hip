@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void pair_similarity_kernel(const float *__res
 // scan + per-block top-k
 // ---------------------------------------------------------------------------------------------
 template <int NJ, int QT, int KL>
-__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
+__device__ inline void scan_topk_body(const ScanArgs &a) {
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;  // wave in block
     const uint32_t tile = blockIdx.y;
@@ -209,12 +209,26 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     }
 }
 
+template <int NJ, int QT, int KL>
+__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
+    scan_topk_body<NJ, QT, KL>(a);
+}
+// The exact scans of SEVERAL segments in one launch (a multi-segment index under a selective filter: OpenSegment::_search routes
+// every segment to brute force, segment.rs:506-555 — a launch pair per segment was 100 launches per batch on the reference's
+// 50-segment layout): blockIdx.z names the segment, whose arguments come from a table in HBM (uniform address: scalar loads).
+// Every record carries the same launch shape (dp, k, query tile, n_queries, grid); a block past a small segment's rows leaves
+// empty lists.
+template <int NJ, int QT, int KL>
+__global__ __launch_bounds__(256) void scan_topk_segments_kernel(const ScanArgs *table) {
+    scan_topk_body<NJ, QT, KL>(table[blockIdx.z]);
+}
+
 // merge per-block lists: one block per query
 template <int KL>
-__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ partial, uint32_t lists_per_query,
-                                                         uint32_t k, uint32_t *__restrict__ out_vec,
-                                                         float *__restrict__ out_score,
-                                                         uint32_t *__restrict__ out_count) {
+__device__ inline void merge_topk_body(const uint64_t *__restrict__ partial, uint32_t lists_per_query,
+                                       uint32_t k, uint32_t *__restrict__ out_vec,
+                                       float *__restrict__ out_score,
+                                       uint32_t *__restrict__ out_count) {
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x;
@@ -263,6 +277,17 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         if (lane == 0) out_count[q] = cnt;
     }
 }
+template <int KL>
+__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ partial, uint32_t lists_per_query, uint32_t k,
+                                                         uint32_t *__restrict__ out_vec, float *__restrict__ out_score,
+                                                         uint32_t *__restrict__ out_count) {
+    merge_topk_body<KL>(partial, lists_per_query, k, out_vec, out_score, out_count);
+}
+template <int KL>
+__global__ __launch_bounds__(256) void merge_topk_segments_kernel(const ScanMergeTab *table, uint32_t lists_per_query, uint32_t k) {
+    const ScanMergeTab t = table[blockIdx.y];
+    merge_topk_body<KL>(t.partial, lists_per_query, k, t.out_vec, t.out_score, t.out_count);
+}
 
 // ---------------------------------------------------------------------------------------------
 // host launchers
@@ -281,6 +306,24 @@ static hipError_t launch_scan_nj(const ScanArgs &a, uint32_t nblk, hipStream_t s
     } else {
         hipLaunchKernelGGL((scan_topk_kernel<NJ, (WIDE ? 8 : 4), 1>), dim3(nblk, (a.n_queries + 7) / 8), dim3(256), 0, s,
                            a);
+    }
+    return hipGetLastError();
+}
+
+template <int NJ, bool WIDE>
+static hipError_t launch_scan_segments_nj(const ScanArgs *table, uint32_t n_seg, const ScanArgs &a, uint32_t nblk, hipStream_t s) {
+    const uint32_t nq = a.n_queries;
+    if (a.k > 256) {
+        hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, 1, 8>), dim3(nblk, nq, n_seg), dim3(256), 0, s, table);
+    } else if (a.k > 64) {
+        if (a.qt == 1) hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, 1, 4>), dim3(nblk, nq, n_seg), dim3(256), 0, s, table);
+        else hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, 4, 4>), dim3(nblk, (nq + 3) / 4, n_seg), dim3(256), 0, s, table);
+    } else if (a.qt == 1) {
+        hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, 1, 1>), dim3(nblk, nq, n_seg), dim3(256), 0, s, table);
+    } else if (a.qt == 4 || !WIDE) {
+        hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, 4, 1>), dim3(nblk, (nq + 3) / 4, n_seg), dim3(256), 0, s, table);
+    } else {
+        hipLaunchKernelGGL((scan_topk_segments_kernel<NJ, (WIDE ? 8 : 4), 1>), dim3(nblk, (nq + 7) / 8, n_seg), dim3(256), 0, s, table);
     }
     return hipGetLastError();
 }
@@ -312,6 +355,31 @@ hipError_t launch_scan(ScanArgs a, uint32_t nblk, hipStream_t s) {
     if (nj <= 12) return launch_scan_nj<12, false>(a, nblk, s);
     if (nj <= 16) return launch_scan_nj<16, false>(a, nblk, s);
     return hipErrorInvalidValue;
+}
+
+// `table` (device): n_seg records that agree with `shape` (host: one of them, qt filled like launch_scan does) in dp, k, n_queries, qt;
+// every record's `partial` has room for [n_queries][nblk][k] keys.  The grid's y dimension carries the query tiles (<= 65 535).
+hipError_t launch_scan_segments(const ScanArgs *table, uint32_t n_seg, ScanArgs shape, uint32_t nblk, hipStream_t s) {
+    if (shape.k == 0 || shape.k > NIDX_K_MAX || n_seg == 0 || n_seg > 65535u) return hipErrorInvalidValue;
+    shape.qt = scan_query_tile(shape.n_queries, shape.dp, shape.k);
+    int nj = (int)((shape.dp + 255u) / 256u);
+    if (nj <= 1) return launch_scan_segments_nj<1, true>(table, n_seg, shape, nblk, s);
+    if (nj <= 2) return launch_scan_segments_nj<2, true>(table, n_seg, shape, nblk, s);
+    if (nj <= 3) return launch_scan_segments_nj<3, true>(table, n_seg, shape, nblk, s);
+    if (nj <= 4) return launch_scan_segments_nj<4, true>(table, n_seg, shape, nblk, s);
+    if (nj <= 6) return launch_scan_segments_nj<6, false>(table, n_seg, shape, nblk, s);
+    if (nj <= 8) return launch_scan_segments_nj<8, false>(table, n_seg, shape, nblk, s);
+    if (nj <= 12) return launch_scan_segments_nj<12, false>(table, n_seg, shape, nblk, s);
+    if (nj <= 16) return launch_scan_segments_nj<16, false>(table, n_seg, shape, nblk, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_merge_topk_segments(const ScanMergeTab *table, uint32_t n_seg, uint32_t n_queries, uint32_t lists_per_query, uint32_t k, hipStream_t s) {
+    if (n_seg == 0 || n_queries == 0) return hipSuccess;
+    if (k > 256) hipLaunchKernelGGL(merge_topk_segments_kernel<8>, dim3(n_queries, n_seg), dim3(256), 0, s, table, lists_per_query, k);
+    else if (k > 64) hipLaunchKernelGGL(merge_topk_segments_kernel<4>, dim3(n_queries, n_seg), dim3(256), 0, s, table, lists_per_query, k);
+    else hipLaunchKernelGGL(merge_topk_segments_kernel<1>, dim3(n_queries, n_seg), dim3(256), 0, s, table, lists_per_query, k);
+    return hipGetLastError();
 }
 
 hipError_t launch_merge_topk(const uint64_t *partial, uint32_t n_queries, uint32_t lists_per_query, uint32_t k,

@@ -257,6 +257,16 @@ def test_every_segment_in_one_launch_and_fssc_on_the_device(orc, monkeypatch):
                 monkeypatch.setenv(var, "1")
                 assert same(idx.search(q, k, _lib.METHOD_HNSW, with_dup, min_score=min_score), got), (var, k, with_dup)
                 monkeypatch.delenv(var)
+            # every segment forced onto the exact scan: ONE launch scans them all (scan_topk_segments_kernel), one more merges their per-block
+            # lists — against a launch pair per segment and the segment-at-a-time path
+            bf = idx.search(q, k, _lib.METHOD_BRUTE_FORCE, with_dup, min_score=min_score)
+            idx.tunable("serial_segments", 1)
+            bf_serial = idx.search(q, k, _lib.METHOD_BRUTE_FORCE, with_dup, min_score=min_score)
+            idx.tunable("serial_segments", 0)
+            assert same(bf, bf_serial), (k, with_dup)
+            monkeypatch.setenv("NIDX_GPU_SEGMENT_LAUNCHES", "1")
+            assert same(idx.search(q, k, _lib.METHOD_BRUTE_FORCE, with_dup, min_score=min_score), bf), (k, with_dup)
+            monkeypatch.delenv("NIDX_GPU_SEGMENT_LAUNCHES")
         # per-segment filters: some segments drop out entirely (nothing matches), the others walk under their bitsets
         filters = [orc.bitset(n, ones=np.nonzero(rng.random(n) < p)[0].tolist()) if p is not None else None
                    for n, p in zip(sizes, (0.6, 0.0, None, 0.5, 0.7, 0.0, 0.9, None, 1.0))]
