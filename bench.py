@@ -2298,15 +2298,15 @@ def bench_rabitq(a, L, dev, rank, world):
                        "exact_hnsw_ms_per_batch": exact_hnsw_ms, "estimates_per_query": float(s[:, 0].mean()),
                        "expansions_per_query": float(s[:, 1].mean()), "rows_reranked_per_query": float(s[:, 2].mean()),
                        "kernel_flags": flags, "hnsw_build_s": build_s, "quantize_s": quant_s,
-                       "walk_kernel": "rabitq_hnsw_kernel (one wave per query)" if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
+                       "walk_kernel": "rabitq_hnsw_kernel (one wave per query)" if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
                                       "rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)",
                        "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
-                                             "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else
+                                             "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
                                             {"fetcher_speculative_fetches": float(((s[:, 4] & 0xFFFF) << 8).mean()),
                                              "controller_predict_pop_and_waiting_for_the_fetcher": float((((s[:, 4] >> 16) & 0xFFFF) << 8).mean()), "admission": float(s[:, 6].mean()),
                                              "total": float(s[:, 7].mean())}),
-                       "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float((s[:, 5] & 0xFFFF).mean()),
-                       "expansions_with_edge_record_held_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "1" else float(((s[:, 5] >> 16) & 0xFFFF).mean())},
+                       "speculated_expansions_confirmed_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else float((s[:, 5] & 0xFFFF).mean()),
+                       "expansions_with_edge_record_held_per_query": None if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else float(((s[:, 5] >> 16) & 0xFFFF).mean())},
             "roofline": {"kernel": "rabitq walk kernel + hnsw_search_kernel (entry mode)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},

@@ -21,6 +21,7 @@
 // every accepted row), so the 64 lanes are spent on the 60 neighbours of one expansion (one
 // 8+D/8-byte code per lane — no cross-lane reduction at all) and on the 64-wide raw dot products.
 // Bound: HBM latency/bytes (D/8+8 bytes per estimate, 4 D per re-ranked row, 256 B per expansion).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "hnsw_device.h"
@@ -706,10 +707,8 @@ __device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node, uint32_t &ne
 }
 
 template <int NW>
-__global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ inline void rabitq_hnsw1_body(const RabitqSearchArgs &a, const uint32_t qi, unsigned char *smem) {
     const int lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
     const uint32_t nw = a.seg.dim / 64u;
     RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef);
     rq_load_query(sh, a, qi, nw, lane);
@@ -717,7 +716,11 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
     uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
     uint32_t n_est = 0, n_exp = 0, flags = 0;
     uint64_t cyc_pop = 0, cyc_vis = 0, cyc_est = 0, cyc_ins = 0;
-    const uint64_t t_start = clock64();
+    // (s_memtime is a scalar MEMORY instruction, ~100+ cycles each with its s_waitcnt: the cycle split is taken only when the caller asked
+    // for counters — the timed launches of bench.py do not)
+    const bool timing = a.stats != nullptr;
+    auto now = [&]() -> uint64_t { return timing ? (uint64_t)clock64() : 0ull; };
+    const uint64_t t_start = now();
 
     uint32_t ep = a.g.ep_node;
     RqLayer L;
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         }
         uint32_t node, next, pf_node = 0xffffffffu, pf_word = 0;
         for (;;) {
-            const uint64_t t0 = clock64();
+            const uint64_t t0 = now();
             if (!rq_pop(L, lane, node, next)) break;
             // edge record: one coalesced 256 B (128 B above layer 0) load, usually already here — the runner-up's
             // record is requested one expansion ahead
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
             if (next != 0xffffffffu) pf_word = load_edge_raw(a.g, next, layer, lane);
             const uint32_t deg = lane_u32(w, 0);
             const bool is_edge = lane >= 1 && lane <= (int)deg;
-            const uint64_t t1 = clock64();
+            const uint64_t t1 = now();
             cyc_pop += t1 - t0;
             // the code of every neighbour is requested together with the visited test (one round trip instead of
             // two); codes of already-visited neighbours are dropped
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
             }
             n_exp++;
             const unsigned long long fm = __ballot(fresh);
-            const uint64_t t2 = clock64();
+            const uint64_t t2 = now();
             cyc_vis += t2 - t1;
             if (layer > 0) {
                 vis_count += (uint32_t)__popcll(fm);
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
             float est = 0.f, err = 0.f;
             if (fresh) rq_score_code<NW>(code, rec, sh.planes, nw, qc, est, err);
             n_est += (uint32_t)__popcll(fm);
-            const uint64_t t3 = clock64();
+            const uint64_t t3 = now();
             cyc_est += t3 - t2;
             // `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295)
             unsigned long long todo = fm;
@@ -795,13 +798,13 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
                 const float sj = lane_f32(est, j);
                 if (sj > ws || L.len < kk) rq_admit(L, kk, sj, lane_u32(w, j), lane, flags);
             }
-            cyc_ins += clock64() - t3;
+            cyc_ins += now() - t3;
         }
         ep = rq_addr(lane_u64(L.dir_first, 0));  // layer result (k = 1) = next entry point; layer 0 keeps the whole list
     }
 
     // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
-    const uint64_t t_rr = clock64();
+    const uint64_t t_rr = now();
     Reranker rr;
     rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
     for (int dch = 0; dch < uni(L.n_dir); dch++) {  // the chunks in rank order = the neighbours best first
@@ -828,12 +831,27 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
         o[NIDX_STAT_CYC_CTL] = (uint32_t)(cyc_pop + cyc_vis);
         o[NIDX_STAT_EDGE_HITS] = (uint32_t)cyc_est;   // this kernel: cycles in the estimate phase
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
-        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
+        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(now() - t_start);
         (void)t_rr;
     }
 }
 
-// ---- HNSW, RaBitQ arm, TWO waves per query (round 5) ------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    rabitq_hnsw1_body<NW>(a, blockIdx.x, smem);
+}
+// every RaBitQ segment of an index in ONE launch (round 5): block b walks query b % n_queries of segment b / n_queries, whose
+// arguments come from a table in HBM (uniform address, read only: scalar loads) — like hnsw_search_segments_kernel.  RaBitQ is the
+// reference's default arm of a Dot index with D % 64 == 0 (config.rs:170-173): a launch per segment was 50 launches per batch on the
+// reference's 10 M-vector layout.
+template <int NW>
+__global__ __launch_bounds__(64) void rabitq_hnsw_segments_kernel(const RabitqSearchArgs *table, uint32_t n_queries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    rabitq_hnsw1_body<NW>(table[blockIdx.x / n_queries], blockIdx.x % n_queries, smem);
+}
+
+// ---- HNSW, RaBitQ arm, TWO waves per query (round 5; NOT the default: see the measurements below) ------------------------------
 // The walk above is a chain of ~1 100 dependent expansions per query, and a lone wave pays every link in full: the edge record and
 // the neighbours' codes are two memory round trips (43 % of the walk's cycles), the admissions ~150 dependent instructions each
 // (36 %), with nothing to overlap either (one wave per SIMD at batch 1 024: 0.026 of the HBM roofline, rounds 1-4).  Here a
@@ -852,7 +870,18 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_kernel(RabitqSearchArgs a) {
 // of expansions, the LDS hash has no removal) run without speculation.  The fetcher also keeps the edge record of the runner-up
 // candidate (read-only, so no rollback): when that node is expanded next, its fetch starts at the codes.
 // Results are the one-wave kernel's bit for bit — same admission replay on the same values in the same order; only the moment a
-// visited bit is set moves, never whether it is set when an expansion that was really popped tests it.
+// visited bit is set moves, never whether it is set when an expansion that was really popped tests it
+// (tests/test_rabitq_gpu.py, tests/test_serving_gpu.py::test_rabitq_segments_share_one_launch run both kernels).
+//
+// MEASURED (1 M x 768 clustered, batch 1 024, k = 10; gpurun_out/r5ab): the prediction is right for 99.2 % of the
+// expansions and 84 % of them find their edge record held — and the launch is SLOWER than the one-wave kernel's: 7.6 ms against 6.6 ms.
+// Per expansion (NIDX_GPU_RABITQ_DEBUG): the fetcher's expansion takes 4.3 k cycles and the controller's admissions + pop 3.6 k, but the
+// two stand at their second meeting point for another 2.1 k / 2.7 k cycles each — a meeting costs ~2 k cycles whatever implements it
+// (s_barrier, or two sequence words polled in LDS: 8.0 ms), with the waves on one SIMD or on two (a four-wave workgroup whose other
+// two waves leave at once), so the overlap the design was made for (4.3 k beside 3.6 k instead of behind it) is spent on the meetings,
+// and the prediction + hand-over add 1.7 k more.  The one-wave kernel therefore stays the default (NIDX_GPU_RABITQ_WAVES=2 selects this
+// one); what would help is fewer meetings per walk — a fetcher that runs several expansions ahead through a queue — which needs the
+// speculation to be exact more than one step ahead (it is not: the best new neighbour of expansion i + 1 is unknown at i).
 #define RQ_NONE 0xffffffffu
 struct RqFetchBuf {      // one expansion, written by the fetcher
     uint32_t node, n, flags, pad;
@@ -862,6 +891,7 @@ struct RqFetchBuf {      // one expansion, written by the fetcher
 #define RQ_EDGE_CACHE 3
 struct RqCtl {
     uint32_t pred, pred2, pred3, state, fetch_node, abort, ep, pad;
+    uint32_t seq[4];                        // [0] / [1]: meeting counts of the controller / the fetcher
     uint32_t cache_node[4];                 // the layer-0 edge records the fetcher holds (RQ_NONE = free)
     uint32_t cache_w[RQ_EDGE_CACHE][64];
 };
@@ -935,12 +965,14 @@ __device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, R
             pf_slot[j] = slot;
             pf_w[j] = load_edge_raw(a.g, want[j], 0, lane);
         }
-        if (hit >= 0) {
-            w = ctl->cache_w[hit][lane];
-            cache_hits++;
-        } else {
-            w = load_edge_raw(a.g, node, 0, lane);
-        }
+        // (two separate loads and a select of their VALUES: a select of the two addresses made the compiler emit one FLAT load behind an
+        // s_waitcnt vmcnt(0) — the records requested ahead just above had to land before this expansion's own loads could even start)
+        const uint32_t w_held = ctl->cache_w[hit >= 0 ? hit : 0][lane];
+        uint32_t w_mem = 0;
+        if (hit < 0) w_mem = load_edge_raw(a.g, node, 0, lane);
+        else cache_hits++;
+        asm volatile("" : "+v"(w_mem));   // keeps the two loads apart
+        w = hit >= 0 ? w_held : w_mem;
     } else {
         w = load_edge_raw(a.g, node, layer, lane);
     }
@@ -1014,10 +1046,33 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
     uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;   // controller
     uint32_t vis_count = 0, cache_hits = 0;                // fetcher (upper layers' visited count; layer-0 expansions whose edge record was held)
     uint64_t cyc_ctl = 0, cyc_wait = 0, cyc_ins = 0, cyc_fetch = 0;
-    const uint64_t t_start = clock64();
+    uint64_t dbg_b1 = 0, dbg_b2 = 0, dbg_nf = 0;   // this wave's cycles inside barrier 1 / barrier 2 / the need_fetch barrier (NIDX_GPU_RABITQ_DEBUG)
+    // (s_memtime is a scalar MEMORY instruction, ~100+ cycles each with its s_waitcnt: the cycle split is taken only when the caller asked
+    // for counters or the debug totals — the timed launches of bench.py do not)
+    const bool timing = a.stats != nullptr || a.dbg != nullptr;
+    auto now = [&]() -> uint64_t { return timing ? (uint64_t)clock64() : 0ull; };
+    const uint64_t t_start = now();
+    if (threadIdx.x == 0) ctl->seq[0] = ctl->seq[1] = 0;
     __syncthreads();
     // NIDX_GPU_RABITQ_SPEC=0 (measurement): no speculation — the two waves take turns (admit + pop, then fetch)
-    const bool speculate = a.no_speculation == 0;
+    const bool speculate = (a.no_speculation & 1u) == 0;
+    // The two waves meet twice per expansion: s_barrier.  NIDX_GPU_RABITQ_SPEC=2/3 meets through two sequence words in LDS instead — each
+    // wave publishes its count and polls the other's (measured slower: 8.0 ms against 7.6 ms).
+    const bool spin = (a.no_speculation & 2u) != 0;
+    uint32_t my_seq = 0;
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_u32;   // (a generic pointer made these FLAT accesses with system-scope bits)
+    lds_u32 *seqw = (lds_u32 *)(&ctl->seq[0]);
+    auto meet = [&]() {
+        if (!spin) {
+            __syncthreads();
+            return;
+        }
+        my_seq++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        seqw[w0 ? 0 : 1] = my_seq;
+        while ((uint32_t)uni((int)seqw[w0 ? 1 : 0]) < my_seq) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
 
     uint32_t ep = a.g.ep_node;
     RqLayer L;
@@ -1051,21 +1106,22 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                 for (int i = 0; i < 4; i++) ctl->cache_node[i] = RQ_NONE;
             }
         }
-        __syncthreads();
+        meet();
         int cur = 0;
         bool need_fetch = true;
         for (;;) {
             if (need_fetch) {
                 if (!w0) rq_fetch<NW>(a, sh, ctl, &buf[cur], (uint32_t)uni((int)ctl->fetch_node), RQ_NONE, RQ_NONE, layer, gvis, qc, nw, vis_count, cache_hits, lane);
-                const uint64_t tw = clock64();
-                __syncthreads();
-                cyc_wait += clock64() - tw;
+                const uint64_t tw = now();
+                meet();
+                cyc_wait += now() - tw;
+                dbg_nf += now() - tw;
             }
             // ---- the controller takes the expansion in buf[cur] and names the node the next pop will return ----
             bool fresh = false;
             float fest = 0.f;
             uint32_t faddr = 0;
-            const uint64_t tc = clock64();
+            const uint64_t tc = now();
             if (w0) {
                 const RqFetchBuf *b = &buf[cur];
                 const uint32_t fn = (uint32_t)uni((int)b->n), bflags = (uint32_t)uni((int)b->flags);
@@ -1111,20 +1167,22 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                     }
                 }
             }
-            cyc_ctl += clock64() - tc;
-            __syncthreads();
+            cyc_ctl += now() - tc;
+            const uint64_t tb1 = now();
+            meet();
+            dbg_b1 += now() - tb1;
             const uint32_t pred = (uint32_t)uni((int)ctl->pred);
             const bool aborted = uni((int)ctl->abort) != 0;
             if (!w0) {
                 if (pred != RQ_NONE) {
-                    const uint64_t tf = clock64();
+                    const uint64_t tf = now();
                     rq_fetch<NW>(a, sh, ctl, &buf[cur ^ 1], pred, (uint32_t)uni((int)ctl->pred2), (uint32_t)uni((int)ctl->pred3), layer, gvis, qc, nw, vis_count, cache_hits, lane);
-                    cyc_fetch += clock64() - tf;
+                    cyc_fetch += now() - tf;
                 }
             } else {
                 uint32_t st = RQ_STATE_DONE, node = 0, next;
                 if (!aborted) {
-                    const uint64_t t3 = clock64();
+                    const uint64_t t3 = now();
                     // `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295)
                     unsigned long long todo = __ballot(fresh);
                     while (todo) {
@@ -1141,10 +1199,10 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                         const float sj = lane_f32(fest, j);
                         if (sj > ws || L.len < kk) rq_admit(L, kk, sj, lane_u32(faddr, j), lane, flags);
                     }
-                    const uint64_t t4 = clock64();
+                    const uint64_t t4 = now();
                     cyc_ins += t4 - t3;
                     if (rq_pop(L, lane, node, next)) st = node == pred ? RQ_STATE_HIT : RQ_STATE_MISS;
-                    cyc_ctl += clock64() - t4;
+                    cyc_ctl += now() - t4;
                 }
                 if (st == RQ_STATE_HIT) n_hit++;
                 if (lane == 0) {
@@ -1152,9 +1210,10 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
                     ctl->fetch_node = node;
                 }
             }
-            const uint64_t tw2 = clock64();
-            __syncthreads();
-            cyc_wait += clock64() - tw2;
+            const uint64_t tw2 = now();
+            meet();
+            cyc_wait += now() - tw2;
+            dbg_b2 += now() - tw2;
             const uint32_t st = (uint32_t)uni((int)ctl->state);
             if (st == RQ_STATE_HIT) {
                 cur ^= 1;
@@ -1172,8 +1231,18 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
             ctl->pad = cache_hits;
             ctl->cache_node[3] = (uint32_t)(cyc_fetch >> 8);   // (the fourth id slot is not a cache slot)
         }
-        __syncthreads();
+        meet();
         ep = (uint32_t)uni((int)ctl->ep);
+    }
+    if (a.dbg && lane == 0) {   // [0..5] controller: barrier 1, barrier 2, fetch barrier, ctl, admissions, walks; [8..13] fetcher: the same barriers, fetches
+        unsigned long long *d = a.dbg + (w0 ? 0 : 8);
+        atomicAdd(&d[0], (unsigned long long)dbg_b1);
+        atomicAdd(&d[1], (unsigned long long)dbg_b2);
+        atomicAdd(&d[2], (unsigned long long)dbg_nf);
+        atomicAdd(&d[3], (unsigned long long)(w0 ? cyc_ctl : cyc_fetch));
+        atomicAdd(&d[4], (unsigned long long)cyc_ins);
+        atomicAdd(&d[5], 1ull);
+        atomicAdd(&d[6], (unsigned long long)(now() - t_start));
     }
     if (!w0) return;
 
@@ -1205,13 +1274,16 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
         o[NIDX_STAT_CYC_CTL] = ((uint32_t)uni((int)ctl->cache_node[3]) & 0xffffu) | ((uint32_t)(((cyc_ctl + cyc_wait) >> 8) & 0xffffu) << 16);
         o[NIDX_STAT_EDGE_HITS] = (n_hit & 0xffffu) | ((uint32_t)uni((int)ctl->pad) << 16);   // confirmed speculations | expansions whose edge record was held
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
-        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(clock64() - t_start);
+        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(now() - t_start);
     }
 }
 
+// (experiment NIDX_GPU_RABITQ_WG=256: the workgroup is launched with four waves of which two leave at once — the hardware deals the
+// waves of a workgroup round-robin over the CU's SIMDs, so the controller and the fetcher then surely sit on different SIMDs)
 template <int NW>
-__global__ __launch_bounds__(128) void rabitq_hnsw2_kernel(RabitqSearchArgs a) {
+__global__ __launch_bounds__(256) void rabitq_hnsw2_kernel(RabitqSearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x >= 128) return;
     rabitq_hnsw2_body<NW>(a, blockIdx.x, smem);
 }
 
@@ -1272,7 +1344,8 @@ template <int NW>
 static hipError_t launch_hnsw2_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rabitq_hnsw2_kernel<NW>, dim3(a.n_queries), dim3(128), smem, s, a);
+    const char *wg = getenv("NIDX_GPU_RABITQ_WG");
+    hipLaunchKernelGGL(rabitq_hnsw2_kernel<NW>, dim3(a.n_queries), dim3(wg && atoi(wg) == 256 ? 256 : 128), smem, s, a);
     return hipGetLastError();
 }
 template <int NW>
@@ -1282,21 +1355,48 @@ static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32
     hipLaunchKernelGGL(rabitq_hnsw2_segments_kernel<NW>, dim3(n_table * nq), dim3(128), smem, s, table, nq);
     return hipGetLastError();
 }
-// NIDX_GPU_RABITQ_WAVES=1: the one-wave kernel of rounds 1-4 (comparison); default: two waves per query
-static bool rabitq_no_speculation() {
-    const char *e = getenv("NIDX_GPU_RABITQ_SPEC");
-    return e && atoi(e) == 0;
+template <int NW>
+static hipError_t launch_hnsw1_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw_segments_kernel<NW>, dim3(n_table * nq), dim3(64), smem, s, table, nq);
+    return hipGetLastError();
 }
+// measurement switches of the two-wave walk -> RabitqSearchArgs::no_speculation: NIDX_GPU_RABITQ_SPEC=0: no speculation (bit 0);
+// =2: the waves meet through polled LDS words instead of s_barrier (bit 1); =3: both
+static uint32_t rabitq_walk_mode() {
+    const char *e = getenv("NIDX_GPU_RABITQ_SPEC");
+    if (!e) return 0u;
+    const int v = atoi(e);
+    return v == 0 ? 1u : v == 2 ? 2u : v == 3 ? 3u : 0u;
+}
+// NIDX_GPU_RABITQ_WAVES=2: the two-wave walk (slower on MI355X as measured, kept for the comparison); default: one wave per query
 bool rabitq_two_waves() {
     const char *e = getenv("NIDX_GPU_RABITQ_WAVES");
-    return !(e && atoi(e) == 1);
+    return e && atoi(e) == 2;
 }
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
     if (rabitq_two_waves()) {
         const size_t smem2 = rq_smem2_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef);
         RabitqSearchArgs b = a;
-        b.no_speculation = rabitq_no_speculation() ? 1u : 0u;
+        b.no_speculation = rabitq_walk_mode();
+        if (getenv("NIDX_GPU_RABITQ_DEBUG")) {
+            // measurement only: where the two waves of a walk spend their cycles (synchronises; prints one line per launch)
+            static unsigned long long *d_dbg = nullptr;
+            if (!d_dbg && hipMalloc(&d_dbg, 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipMemsetAsync(d_dbg, 0, 16 * 8, s);
+            b.dbg = d_dbg;
+            hipError_t e = [&]() -> hipError_t { RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s) }();
+            if (e != hipSuccess) return e;
+            unsigned long long h[16];
+            (void)hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            const double n = h[5] ? (double)h[5] : 1.0;
+            fprintf(stderr, "[rabitq dbg] per walk, controller: barrier1 %.0f barrier2 %.0f fetch-barrier %.0f ctl %.0f admissions %.0f walk %.0f | fetcher: barrier1 %.0f barrier2 %.0f "
+                            "fetch-barrier %.0f speculative fetches %.0f walk %.0f cycles\n", h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[14] / n);
+            return hipSuccess;
+        }
         RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s)
     }
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
@@ -1305,8 +1405,12 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
 // `table` (device) holds n_table argument records that agree in dim / dp / k / ef / n_queries (`shape`: one of them, host side)
 hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s) {
     if (n_table == 0 || shape.n_queries == 0) return hipSuccess;
-    const size_t smem2 = rq_smem2_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef);
-    RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
+    if (rabitq_two_waves()) {
+        const size_t smem2 = rq_smem2_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef);
+        RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
+    }
+    const size_t smem = rq_smem_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef, true);
+    RQ_DISPATCH(launch_hnsw1_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s)
 }
 
 }  // namespace nidx

@@ -339,10 +339,10 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         uint32_t n_hnsw = 0, n_searched = 0;
         const bool one_launch = S > 1 && !getenv("NIDX_GPU_SEGMENT_LAUNCHES");   // the variable: a launch per segment (comparison)
         // RaBitQ is the reference's default arm of a Dot index with D % 64 == 0 (config.rs:170-173, segment.rs:506-513): the walks of
-        // every such segment join ONE table-driven launch too (rabitq_hnsw2_segments_kernel), their closest_up_nodes the plain
+        // every such segment join ONE table-driven launch too (rabitq_hnsw_segments_kernel), their closest_up_nodes the plain
         // segments' grid in entry mode.  The visited bitsets of the launch (n_queries x vectors of those segments bits) stay under 4 GiB.
         std::vector<uint32_t> rq_segs, bf_segs;
-        bool rq_one_launch = one_launch && rabitq_two_waves() && k <= NIDX_K_MAX;
+        bool rq_one_launch = one_launch && k <= NIDX_K_MAX;
         if (rq_one_launch) {
             uint64_t vis_words = 0;
             for (size_t s = 0; s < S; s++)

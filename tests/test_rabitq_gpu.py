@@ -164,7 +164,10 @@ def test_rabitq_brute_force_filters_min_score_ties(orc):
 
 # ---- HNSW, RaBitQ arm ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5), (9000, 128, 300), (6000, 768, 512)])
-def test_rabitq_hnsw_matches_oracle(orc, n, d, k):
+@pytest.mark.parametrize("waves", ["1", "2"])
+def test_rabitq_hnsw_matches_oracle(orc, monkeypatch, n, d, k, waves):
+    """waves = 2: the two-wave walk (a fetcher wave expands the predicted next candidate, rollback on a mispredict) — the same bits."""
+    monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", waves)
     rng = np.random.default_rng(n * 7 + d + k)
     x = clustered(rng, n, d, clusters=60, spread=0.3)
     nq = 12

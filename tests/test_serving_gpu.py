@@ -287,11 +287,11 @@ def test_every_segment_in_one_launch_and_fssc_on_the_device(orc, monkeypatch):
 
 def test_rabitq_segments_share_one_launch(orc, monkeypatch):
     """RaBitQ is the reference's default arm of a Dot index with D % 64 == 0 (nidx_vector/src/config.rs:170-173, segment.rs:506-513,
-    hnsw/search.rs:333-366): the walks of every RaBitQ segment of an index run in ONE table-driven launch (rabitq_hnsw2_segments_kernel,
-    two waves per walk), their closest_up_nodes in the plain segments' grid in entry mode, Fssc on the device.  Identical — segments,
-    vectors, ranks, score bits — to the oracle's Searcher::_search over the same quantized segments, to the segment-at-a-time path
-    (tunable serial_segments), to a launch per segment (NIDX_GPU_SEGMENT_LAUNCHES) and to the one-wave kernel of rounds 1-4
-    (NIDX_GPU_RABITQ_WAVES=1)."""
+    hnsw/search.rs:333-366): the walks of every RaBitQ segment of an index run in ONE table-driven launch (rabitq_hnsw_segments_kernel),
+    their closest_up_nodes in the plain segments' grid in entry mode, Fssc on the device.  Identical — segments, vectors, ranks, score
+    bits — to the oracle's Searcher::_search over the same quantized segments, to the segment-at-a-time path (tunable
+    serial_segments), to a launch per segment (NIDX_GPU_SEGMENT_LAUNCHES) and to the two-wave walk (NIDX_GPU_RABITQ_WAVES=2: a fetcher
+    wave expands the predicted next candidate while the controller admits; exact, measured slower, not the default)."""
     rng = np.random.default_rng(77)
     d = 128
     sizes = (3000, 1200, 2500, 800, 1700)
@@ -323,18 +323,18 @@ def test_rabitq_segments_share_one_launch(orc, monkeypatch):
                 c = int(sc[i])
                 assert np.array_equal(auto[0][i, :c], sg[i, :c]) and np.array_equal(auto[2][i, :c], sv[i, :c]), (k, with_dup, i)
                 assert np.array_equal(auto[3][i, :c].view(np.uint32), ss[i, :c].view(np.uint32)), (k, with_dup, i)
-            # every segment forced onto the RaBitQ walk: one launch == segment at a time == a launch per segment == the one-wave kernel
+            # every segment forced onto the RaBitQ walk: one launch == segment at a time == a launch per segment == the two-wave walk
             got = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
             idx.tunable("serial_segments", 1)
             serial = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
-            monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "1")
-            serial_one_wave = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
+            monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "2")
+            serial_two_waves = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score)
             monkeypatch.delenv("NIDX_GPU_RABITQ_WAVES")
             idx.tunable("serial_segments", 0)
             assert same(got, serial), (k, with_dup)
-            assert same(serial_one_wave, serial), (k, with_dup)
-            for var in ("NIDX_GPU_SEGMENT_LAUNCHES", "NIDX_GPU_RABITQ_WAVES"):
-                monkeypatch.setenv(var, "1")
+            assert same(serial_two_waves, serial), (k, with_dup)
+            for var, val in (("NIDX_GPU_SEGMENT_LAUNCHES", "1"), ("NIDX_GPU_RABITQ_WAVES", "2")):
+                monkeypatch.setenv(var, val)
                 assert same(idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score), got), (var, k, with_dup)
                 monkeypatch.delenv(var)
         tickets = [idx.submit(q.ctypes.data, B, 10, _lib.METHOD_RABITQ_HNSW, False)[1] for _ in range(3)]
