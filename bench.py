@@ -721,6 +721,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     trace_acc = [0.0, 0.0, 0]
 
     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl, 4)))
+    _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_walks", nfl))
     for i in range(a.warmup):
         step(i)
     drain()
@@ -899,9 +900,9 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
         if not do_exchange:
             qhost = [qpool[i].cpu().numpy() for i in range(n_pool)]
             tick = []
-            # one batch more in flight than the device-resident loop: a batch's upload (3 MiB over PCIe, then the hand-over from the copy
-            # engine to the compute queue) is part of its latency, and the device wants `nfl` walks' worth of launches co-resident
-            nfl_h = int(os.environ.get("NIDX_BENCH_HOST_IN_FLIGHT", str(nfl + 1)))
+            # as many batches in flight as the device-resident loop (measured on the 10 M shard, scripts/r5_host.sh: 3 in flight 0.99 of
+            # `value`, 4: 0.94, 5: 0.86, 8: 0.75 — also with the library letting only three of them search at once, tunable pipeline_walks)
+            nfl_h = int(os.environ.get("NIDX_BENCH_HOST_IN_FLIGHT", str(nfl)))
             _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl_h, 4)))
             host_out_h = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl_h)]
 
@@ -2232,6 +2233,41 @@ def bench_rabitq(a, L, dev, rank, world):
         return el, float(np.mean([ev0[i].elapsed_time(ev1[i]) for i in range(a.steps)]))
 
     elapsed, k_ms = timed(_lib.METHOD_RABITQ_HNSW)
+    # the same batches through the serving pipeline (nidx_gpu_vector_search_submit / _wait, device-resident queries in, hits in host arrays
+    # out), three in flight: a walk is a chain of ~1 100 dependent expansions and one launch of 1 024 walks leaves three quarters of the
+    # wave slots empty — the next batches' walks take them
+    nfl_p = max(1, a.batches_in_flight)
+    _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl_p, 4)))
+    p_rq = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_RABITQ_HNSW)
+    hout = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl_p)]
+    tick = []
+
+    def pstep(i):
+        if len(tick) == nfl_p:
+            t_, j_ = tick.pop(0)
+            _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hout[j_][0].ctypes.data, hout[j_][1].ctypes.data, hout[j_][2].ctypes.data, None))
+        t = C.c_uint64(0)
+        _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[i % n_pool].data_ptr(), B, d, C.byref(p_rq), None, C.byref(t)))
+        tick.append((t.value, i % nfl_p))
+
+    def pdrain():
+        while tick:
+            t_, j_ = tick.pop(0)
+            _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hout[j_][0].ctypes.data, hout[j_][1].ctypes.data, hout[j_][2].ctypes.data, None))
+
+    for i in range(nfl_p + 1):
+        pstep(i)
+    pdrain()
+    n_pipe = max(a.steps, 3 * nfl_p)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(n_pipe):
+        pstep(i)
+    pdrain()
+    barrier()
+    pipe_elapsed = time.perf_counter() - t0
+    pipe_last = hout[(n_pipe - 1) % nfl_p][0].copy()
+    pipe_last_batch = (n_pipe - 1) % n_pool
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -2244,6 +2280,16 @@ def bench_rabitq(a, L, dev, rank, world):
     s = st.cpu().numpy().astype(np.int64)
     got = ov.cpu().numpy().copy()
     flags = int(np.bitwise_or.reduce(s[:, 3]))
+    if pipe_last_batch != 0:
+        search(qpool[pipe_last_batch], _lib.METHOD_RABITQ_HNSW)
+        torch.cuda.synchronize()
+        pipe_same = bool(np.array_equal(pipe_last, ov.cpu().numpy().view(np.uint32)))
+        search(qpool[0], _lib.METHOD_RABITQ_HNSW, with_stats=True)
+        torch.cuda.synchronize()
+    else:
+        pipe_same = bool(np.array_equal(pipe_last, got.view(np.uint32)))
+    if not pipe_same:
+        FAILURES.append("rabitq: submit / wait delivered other hits than the device entry")
     rec_len = d // 8 + 8
     alg = float((s[:, 0] * rec_len + s[:, 1] * 256 + s[:, 2] * 4 * d).sum())
     search(qpool[0], _lib.METHOD_HNSW)
@@ -2298,6 +2344,9 @@ def bench_rabitq(a, L, dev, rank, world):
                        "exact_hnsw_ms_per_batch": exact_hnsw_ms, "estimates_per_query": float(s[:, 0].mean()),
                        "expansions_per_query": float(s[:, 1].mean()), "rows_reranked_per_query": float(s[:, 2].mean()),
                        "kernel_flags": flags, "hnsw_build_s": build_s, "quantize_s": quant_s,
+                       "pipelined_queries_per_s": world * B * n_pipe / pipe_elapsed, "pipelined_batches_in_flight": nfl_p,
+                       "pipelined_frac_of_hbm_peak": alg * n_pipe / pipe_elapsed / 1e9 / HBM_PEAK_GBS,
+                       "pipelined_equals_one_launch_at_a_time": pipe_same,
                        "walk_kernel": "rabitq_hnsw_kernel (one wave per query)" if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
                                       "rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)",
                        "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),

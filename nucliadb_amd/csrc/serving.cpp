@@ -185,13 +185,27 @@ struct Pipeline {
     std::vector<std::unique_ptr<SearchSlot>> slots;
     uint32_t depth = 4;
     uint64_t next_ticket = 1;
+    // At most `walks` batches have their search launches on the device at once, however many tickets are outstanding: the launches of
+    // batch i wait (on the device, hipStreamWaitEvent) for the completion of batch i - walks.  Four or more 1 024-walk launches
+    // oversubscribe the wave slots (3.5 M queries/s with three in flight, < 2 M with four: DESIGN 4.1) — but a batch that arrives as
+    // HOST rows first spends ~0.1 ms in its upload, and with only `walks` tickets outstanding the device then runs one launch short
+    // for that long.  So: more tickets than walks; the uploads of the extra ones run ahead, their launches take their turn.
+    static constexpr uint32_t GATES = 32;
+    uint32_t walks = 3;
+    uint64_t launched = 0;            // batches whose launches were queued
+    hipEvent_t gate[GATES] = {};      // gate[i % GATES]: completion of batch i
+    ~Pipeline() {
+        for (hipEvent_t e : gate)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
 
 std::shared_ptr<Pipeline> make_pipeline() { return std::make_shared<Pipeline>(); }
 
-void VectorIndex::pipeline_config(int32_t depth) {
+void VectorIndex::pipeline_config(int32_t depth, int32_t walks) {
     std::lock_guard<std::mutex> lk(pipe->mu);
     if (depth >= 1) pipe->depth = (uint32_t)std::min(depth, 16);
+    if (walks >= 1) pipe->walks = (uint32_t)std::min(walks, 16);
 }
 
 namespace {
@@ -329,6 +343,14 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 at += w;
             }
         }
+        // this batch's turn on the device (see Pipeline::walks): its launches queue behind the completion of the batch `walks` before it
+        uint64_t my_seq = 0;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            my_seq = P.launched++;
+            if (my_seq >= P.walks && P.gate[(my_seq - P.walks) % Pipeline::GATES])
+                NIDX_HIP(hipStreamWaitEvent(sl.stream, P.gate[(my_seq - P.walks) % Pipeline::GATES], 0));
+        }
         uint32_t *blk = sl.d_block.as<uint32_t>();
         // the argument tables of the two table-driven kernels travel as one pinned block: [HnswSearchArgs x S | FsscSegDev x S]
         const size_t hnsw_tab_bytes = (S * sizeof(HnswSearchArgs) + 63) & ~(size_t)63, tab_bytes = hnsw_tab_bytes + S * sizeof(FsscSegDev);
@@ -342,7 +364,9 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         // every such segment join ONE table-driven launch too (rabitq_hnsw_segments_kernel), their closest_up_nodes the plain
         // segments' grid in entry mode.  The visited bitsets of the launch (n_queries x vectors of those segments bits) stay under 4 GiB.
         std::vector<uint32_t> rq_segs, bf_segs;
-        bool rq_one_launch = one_launch && k <= NIDX_K_MAX;
+        // (a single RaBitQ segment takes the same path: its scratch is the slot's own, so batches in flight overlap — the per-segment
+        // route stages through index-owned scratch, one batch at a time)
+        bool rq_one_launch = !getenv("NIDX_GPU_SEGMENT_LAUNCHES") && k <= NIDX_K_MAX;
         if (rq_one_launch) {
             uint64_t vis_words = 0;
             for (size_t s = 0; s < S; s++)
@@ -509,6 +533,12 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
             NIDX_HIP(hipMemcpyAsync(sl.pin_out.p, sl.d_block.p, words * 4, hipMemcpyDeviceToHost, sl.stream));
         }
         NIDX_HIP(hipEventRecord(sl.done, sl.stream));
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            hipEvent_t &g = P.gate[my_seq % Pipeline::GATES];
+            if (!g) NIDX_HIP(hipEventCreateWithFlags(&g, hipEventDisableTiming));
+            NIDX_HIP(hipEventRecord(g, sl.stream));
+        }
         sl.launched = true;
     }
     *ticket_out = sl.ticket;

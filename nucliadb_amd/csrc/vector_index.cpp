@@ -1325,6 +1325,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "coalesce_max_callers") idx->coalescer_admission(std::max(0, (int)value), -1);   // 0 = unbounded
     else if (n == "coalesce_reject_when_full") idx->coalescer_admission(-1, value != 0);
     else if (n == "pipeline_depth") idx->pipeline_config(value);
+    else if (n == "pipeline_walks") idx->pipeline_config(-1, value);   // batches whose search launches may run on the device at once (default 3); tickets beyond it upload ahead
     else if (n == "stage_threads") set_stage_threads(value);   // helper threads that share the copy of host query rows into pinned staging (process-wide; 0 = the caller alone)
     else if (n == "closest_prefetch") idx->closest_prefetch = value != 0;   // measurement knob of closest_up_nodes' edge prefetch: no result depends on it
     else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host

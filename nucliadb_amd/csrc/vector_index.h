@@ -160,7 +160,7 @@ struct VectorIndex {
                             const uint64_t *const *segment_filters, bool blocking, uint64_t *ticket_out);
     int32_t pipeline_wait(uint64_t ticket, uint32_t *out_segment, uint32_t *out_paragraph, uint32_t *out_vector, float *out_score,
                           uint32_t *out_count, uint32_t *n_retried_out);
-    void pipeline_config(int32_t depth);
+    void pipeline_config(int32_t depth, int32_t walks = -1);
     // evaluates `prog` for segment s into scratch_filter (already intersected with alive); returns |filter ∩ alive|
     int32_t eval_filter_program(uint32_t s, const nidx_gpu_filter_program_t &prog, uint64_t &matching);
     int32_t build_hnsw(uint32_t segment, uint64_t level_seed, bool extend = false);

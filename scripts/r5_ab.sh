@@ -18,7 +18,7 @@ try:
     d = json.load(open("$OUT/$name.json"))
     c = d.get("config", {})
     r = d.get("roofline") or {}
-    print("value=%.4g ms_per_step=%.4g frac=%s kernel_ms=%s recall=%s one_thread=%s multi=%s" % (d["value"], d["ms_per_step"], r.get("frac"), r.get("kernel_ms"),
+    print("value=%.4g ms_per_step=%.4g frac=%s kernel_ms=%s pipelined=%s recall=%s one_thread=%s multi=%s" % (d["value"], d["ms_per_step"], r.get("frac"), r.get("kernel_ms"), c.get("pipelined_queries_per_s"),
           c.get("recall_at_10"), (c.get("one_submitting_thread") or {}).get("postings_per_s"), (c.get("multi_segment") or {}).get("value")))
 except Exception as e:
     print("no line:", e)
