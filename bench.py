@@ -2014,6 +2014,17 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
 
     B, k, d, kb = a.batch, a.k, a.dim, bm.K
     n_pool = qpool.shape[0]
+    # The launch shape of the walks for a device they SHARE with the BM25 scorer: a walk workgroup normally holds 40 KiB of LDS and
+    # <= 128 VGPRs per lane, four of them fill a CU and no BM25 workgroup fits beside them — the two pipelines took turns (2.6 M hybrid
+    # queries/s).  With the <= 96-VGPR register class (tunable min_waves = 5) and a 2^12-slot visited table (vis_log2 = 12: 24 KiB per
+    # walk; a walk that fills it raises its flag and is re-run exactly, like always) a BM25 workgroup is co-resident on every CU and its
+    # instruction-bound rows run in the issue slots the latency-bound walks leave: 3.3 M (scripts/r5_ab.sh hybrid).  Results do not
+    # depend on either knob.  NIDX_BENCH_HYBRID_SHAPE=0 keeps the default shape (comparison).
+    shared_shape = os.environ.get("NIDX_BENCH_HYBRID_SHAPE", "1") != "0" and not os.environ.get("NIDX_BENCH_TUNABLES")
+    if shared_shape:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"min_waves", 5))
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"vis_log2", 12))
+    retried_total = [0]
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
     # the fusion of batch i (native host code, the GIL released) runs on a second host thread while batch i + 1 is waited for: its
@@ -2057,7 +2068,9 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         t2 = time.perf_counter()
         tk, j = in_flight.pop(0)
         hv_, hs_, hc_ = host_out[j]
-        _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, None))
+        r_ = C.c_uint32(0)
+        _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, C.byref(r_)))
+        retried_total[0] += r_.value
         t3 = time.perf_counter()
         job = fuser.submit(fuse, bo, host_out[j])
         fused = fusing.pop(0).result() if fusing else None   # batch i - 1, fused while this batch was waited for
@@ -2087,6 +2100,7 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
     for k_ in t_parts:
         t_parts[k_] = 0.0
     kernel_ms.clear()
+    retried_total[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n_steps):
@@ -2098,6 +2112,8 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         "value": B * n_steps / elapsed, "unit": "hybrid queries/s", "steps": n_steps, "ms_per_step": elapsed / n_steps * 1e3,
         "workload": "hybrid: HNSW over the timed shard + BM25 over %d docs (vocab %d), batch=%d, RRF k=60, results (fused ids + scores) on the host" % (bm.n_docs, bm.vocab, B),
         "vector_batches_in_flight": nfl, "bm25_kernel_ms": float(np.mean(kernel_ms)),
+        "walk_launch_shape": "min_waves = 5 (<= 96 VGPRs), vis_log2 = 12: a BM25 workgroup is co-resident with four walks on every CU" if shared_shape else "the library's default",
+        "vector_queries_re_run_exactly": retried_total[0],
         "fusion": "nidx_gpu_rank_fusion_rrf (native, host) on a second host thread, one batch behind the searches; ms_per_step_parts.fusion = what the main loop still waits for it",
         "ms_per_step_parts": {kk_: v / n_steps * 1e3 for kk_, v in t_parts.items()},
         "cpu_baseline": None,
@@ -2131,8 +2147,15 @@ def bench_hybrid(a, L, dev, rank, world):
     del x
     torch.cuda.empty_cache()
     t0 = time.time()
+    if a.build_ef_upper > 1:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"build_ef_upper", a.build_ef_upper))
     _lib.check(L.nidx_gpu_vector_build_hnsw(h, 0, 2))
     build_s = time.time() - t0
+    if a.ef_upper > 1:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"ef_upper", a.ef_upper))
+    for kv in filter(None, os.environ.get("NIDX_BENCH_TUNABLES", "").split(",")):   # A/B runs: name=value[,name=value]
+        name, _, val = kv.partition("=")
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, name.strip().encode(), int(val)))
     bm = Bm25Bench(a, L, dev, rank, n)
     blk = hybrid_block(a, L, dev, rank, h, qpool, bm, max(1, a.batches_in_flight), None, None)
     bm.close()

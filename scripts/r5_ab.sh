@@ -36,3 +36,10 @@ if [ "$PART" = bm25 ] || [ "$PART" = all ]; then
   run bm25_copy_out NIDX_GPU_BM25_ZERO_COPY_OUT=0 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
   run bm25_depth4 NIDX_BENCH_BM25_DEPTH=4 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
 fi
+if [ "$PART" = hybrid ]; then
+  run hybrid_default -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+  run hybrid_w5_v12 NIDX_BENCH_TUNABLES=min_waves=5,vis_log2=12 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+  run hybrid_prio0 NIDX_GPU_BM25_PRIORITY=0 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+  run hybrid_w5_v13_prio0 NIDX_GPU_BM25_PRIORITY=0 NIDX_BENCH_TUNABLES=min_waves=5 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+  run hybrid_w5_v12_prio0 NIDX_GPU_BM25_PRIORITY=0 NIDX_BENCH_TUNABLES=min_waves=5,vis_log2=12 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+fi
