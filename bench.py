@@ -748,13 +748,33 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             t = torch.tensor([repeats], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             repeats = int(t.item())
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps * repeats):
-        step(a.warmup + i)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # (a 20-step probe is mostly pipeline fill and drain — it ran at half the steady rate and the region sized from it came out at 0.55 s:
+    # the region is timed, and when it falls short of --min-timed-s it is sized again from its own rate and timed once more)
+    for _attempt in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps * repeats):
+            step(a.warmup + i)
+        drain()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        again = a.steps > 0 and elapsed < a.min_timed_s and _attempt < 2
+        if world > 1:
+            t = torch.tensor([1 if again else 0, repeats], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            again = bool(int(t[0].item()))
+        if not again:
+            break
+        repeats = max(repeats + 1, int(np.ceil(repeats * 1.15 * a.min_timed_s / max(elapsed, 1e-6))))
+        if world > 1:
+            t = torch.tensor([repeats], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
+        trace_acc[0] = trace_acc[1] = 0.0
+        trace_acc[2] = 0
+        retried_total[0] = 0
+        if do_exchange:
+            device_flags()
     if trace_steps and trace_acc[2]:
         print("[bench trace] rank %d: %d exchange steps: host time in search launch %.3f ms, in exchange %.3f ms per step; elapsed %.3f ms per step"
               % (rank, trace_acc[2], trace_acc[0] / trace_acc[2] * 1e3, trace_acc[1] / trace_acc[2] * 1e3, elapsed / max(1, a.steps * repeats) * 1e3), file=sys.stderr)
@@ -1901,12 +1921,18 @@ class Bm25Bench:
                 g = base[(da[i, :c] >> np.uint64(32)).astype(np.int64)] + (da[i, :c] & np.uint64(0xFFFFFFFF)).astype(np.int64)
                 same_ids += int(c == int(want[1][i]) and tt[i] == want[2][i] and np.array_equal(g, want[0][i, :c].astype(np.int64)) and
                                 np.array_equal(sc[i, :c].view(np.uint32), want[3][i, :c].view(np.uint32)))
-            elapsed, n_steps, postings, _ = self.timed_pipeline(ms, threads_n, depth)
-            # control: the one-segment index again, timed right after (clocks, allocator state and host threads as for the leg above)
-            e1, n1, p1, _ = self.timed_pipeline(self.searcher, threads_n, depth)
-            one_segment_value = p1 / e1
+            # two rounds of (this index, the one-segment index again as the control: clocks, allocator state and host threads as for the
+            # leg) — the submitting Python threads make single one-second figures wander by 10-20 %; the better round of each is kept
+            best, one_segment_value = None, 0.0
+            for _round in range(2):
+                r_ = self.timed_pipeline(ms, threads_n, depth)
+                if best is None or r_[2] / r_[0] > best[2] / best[0]:
+                    best = r_
+                e1, n1, p1, _ = self.timed_pipeline(self.searcher, threads_n, depth)
+                one_segment_value = max(one_segment_value, p1 / e1)
+            elapsed, n_steps, postings, _ = best
             out = {"segments": [int(b_ - a_) for a_, b_ in zip(cuts[:-1], cuts[1:])], "value": postings / elapsed, "unit": "postings/s",
-                   "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value, "one_segment_value_note": "the one-segment index timed again right after this leg",
+                   "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value, "one_segment_value_note": "the one-segment index timed again right after each round of this leg; the better of two rounds for both",
                    "ratio_to_one_segment": postings / elapsed / one_segment_value if one_segment_value else None,
                    "queries_identical_to_the_one_segment_index": same_ids, "queries": B, "split_s": split_s, "open_s": open_s,
                    "note": "the log-merge policy's shape (nidx/src/settings.rs:246-253); documents, ranks, score bits and totals must equal the "

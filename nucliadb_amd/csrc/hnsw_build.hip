@@ -52,7 +52,7 @@ struct BuildArgs {
 #define REQ_STRIDE NIDX_BUILD_REQ_STRIDE
 
 template <int NJ>
-__global__ __launch_bounds__(256) void insert_search_kernel(BuildArgs a) {
+__global__ __launch_bounds__(256, 4) void insert_search_kernel(BuildArgs a) {   // (<= 128 VGPRs: four construction searches per CU, like the query kernel; it compiled to 132 = three)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SearchShared &sh = *reinterpret_cast<SearchShared *>(smem);
     uint32_t *vis = reinterpret_cast<uint32_t *>(smem + sizeof(SearchShared));
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void select_link_kernel(BuildArgs a, uint32_t 
 
 // phase 3: one wave per run of requests with the same (layer, target)
 template <int NJ>
-__global__ __launch_bounds__(256) void reverse_link_kernel(BuildArgs a, const uint64_t *keys, const float *vals,
+__global__ __launch_bounds__(256, 3) void reverse_link_kernel(BuildArgs a, const uint64_t *keys, const float *vals,
                                                            uint32_t n_req) {
     __shared__ uint64_t s_cand[4][64];
     __shared__ uint64_t s_out[4][64];

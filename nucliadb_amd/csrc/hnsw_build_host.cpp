@@ -184,13 +184,39 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
         }
     }
     const auto t_build0 = std::chrono::steady_clock::now();
+    // The construction searches' visited table.  A search visits a few hundred to a few thousand nodes (ef = 100); the table used to be
+    // 2^14 slots for every build — 64 KiB of LDS per workgroup, TWO construction searches per CU where the registers allow four.  Builds
+    // now start at 2^12 (16 KiB: four per CU) unless the tunable says otherwise; the flag word is read back one batch behind the
+    // launches (no stall), and the first batch that reports a table three quarters full moves the rest of the build to 2^14 — a search
+    // that filled its table only ended early (the graph is approximate by nature, and the reference's own build races).
+    PinBuf h_flags;
+    NIDX_HIP(h_flags.reserve(2 * 4));
+    uint32_t *hf = h_flags.as<uint32_t>();
+    hf[0] = hf[1] = 0;
+    hipEvent_t ev_flags[2] = {nullptr, nullptr};
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev_flags};
+    for (int i = 0; i < 2; i++) NIDX_HIP(hipEventCreateWithFlags(&ev_flags[i], hipEventDisableTiming));
+    const bool adaptive_vis = !build_vis_pinned && b.vis_log2 > 12;
+    if (adaptive_vis) b.vis_log2 = 12;
+    uint32_t n_escalated_at = 0;
+    size_t bi = 0;
     for (const Batch &bt : batches) {
         b.batch_start = bt.start;
         b.batch_size = bt.size;
         b.slot_base = d_slot_base.as<uint32_t>() + bt.start;
         b.n_slots = bt.n_slots;
         NIDX_HIP(launch_build_batch(b, stream));
+        if (adaptive_vis && b.vis_log2 == 12) {
+            NIDX_HIP(hipMemcpyAsync(&hf[bi & 1], d_flags.p, 4, hipMemcpyDeviceToHost, stream));
+            NIDX_HIP(hipEventRecord(ev_flags[bi & 1], stream));
+            if (bi > 0 && hipEventQuery(ev_flags[(bi - 1) & 1]) == hipSuccess && (hf[(bi - 1) & 1] & NIDX_FLAG_VISITED_OVERFLOW)) {
+                b.vis_log2 = build_vis_log2;
+                n_escalated_at = bt.start;
+            }
+        }
+        bi++;
     }
+    (void)n_escalated_at;
     uint32_t flags = 0;
     NIDX_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, stream));
     NIDX_HIP(hipStreamSynchronize(stream));

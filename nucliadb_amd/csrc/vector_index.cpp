@@ -1288,7 +1288,10 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) { idx->eval_rows = std::max(2, std::min(4, atoi(e))); idx->shape_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) { idx->min_waves = atoi(e) >= 4 ? std::min(6, atoi(e)) : 2; idx->shape_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
-    if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
+    if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) {
+        idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
+        idx->build_vis_pinned = true;
+    }
     NIDX_HIP(hipGetDevice(&idx->device));
     NIDX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
     NIDX_HIP(idx->flag_word.alloc(64));
@@ -1329,7 +1332,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     else if (n == "stage_threads") set_stage_threads(value);   // helper threads that share the copy of host query rows into pinned staging (process-wide; 0 = the caller alone)
     else if (n == "closest_prefetch") idx->closest_prefetch = value != 0;   // measurement knob of closest_up_nodes' edge prefetch: no result depends on it
     else if (n == "serial_segments") idx->serial_segments = value != 0;   // nidx_gpu_vector_search: one launch + transfer + wait per segment, Fssc on the host
-    else if (n == "build_vis_log2") idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else if (n == "build_vis_log2") { idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value)); idx->build_vis_pinned = true; }
     else if (n == "ef_search") {   // 0 = the reference's EF_SEARCH (30)
         if (value < 0 || value > NIDX_K_MAX) return fail(NIDX_ERR_INVALID_ARGUMENT, "ef_search must be in 0..%d", NIDX_K_MAX);
         idx->ef_search = (uint32_t)value;

@@ -98,6 +98,7 @@ struct VectorIndex {
     bool serial_segments = false;   // tunable "serial_segments": the blocking search of a multi-segment index one segment at a time
     uint32_t default_vis_log2 = 13;
     uint32_t build_vis_log2 = 14;
+    bool build_vis_pinned = false;   // the tunable / NIDX_GPU_BUILD_VIS_LOG2 was set: no adaptive start at 2^12 (hnsw_build_host.cpp)
     uint32_t build_ef_upper = 0;   // 0 = 1 (reference); tunable "build_ef_upper": a wider descent when inserting into very large flat graphs
     uint32_t last_build_flags = 0;
     uint64_t last_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nidx_gpu_vector_build_stats
