@@ -501,9 +501,9 @@ def serialize_graph(L, h, seg=0):
 
 def pmc_traffic(kind, n, d, B, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r04_pmc_traffic.json — or a previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
+    (profiles/r05_pmc_traffic.json — or a previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
     cannot be read from inside this process)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 for e in json.load(f)["entries"]:

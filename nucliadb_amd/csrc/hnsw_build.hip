@@ -14,6 +14,8 @@
 //                                   record exceeds M_max (to prune_m = 95 %)
 // Nodes of one batch do not see each other (like two rayon workers racing), everything else is the
 // reference's rule.  Edge weights are kept beside the edges (hnsw.edges, disk/v2.rs:46-49).
+#include <stdlib.h>
+
 #include <hipcub/hipcub.hpp>
 
 #include "hnsw_device.h"
@@ -274,8 +276,8 @@ __device__ inline float *weight_record(const BuildArgs &a, uint32_t node, int la
 }
 
 // phase 2: one wave per slot
-template <int NJ>
-__global__ __launch_bounds__(256) void select_link_kernel(BuildArgs a, uint32_t n_slots) {
+template <int NJ, int MINW>
+__global__ __launch_bounds__(256, MINW) void select_link_kernel(BuildArgs a, uint32_t n_slots) {
     __shared__ uint64_t s_out[4][64];
     __shared__ uint64_t s_dis[4][128];
     const int lane = threadIdx.x & 63;
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(256) void select_link_kernel(BuildArgs a, uint32_t 
 }
 
 // phase 3: one wave per run of requests with the same (layer, target)
-template <int NJ>
-__global__ __launch_bounds__(256, 3) void reverse_link_kernel(BuildArgs a, const uint64_t *keys, const float *vals,
+template <int NJ, int MINW>
+__global__ __launch_bounds__(256, MINW) void reverse_link_kernel(BuildArgs a, const uint64_t *keys, const float *vals,
                                                            uint32_t n_req) {
     __shared__ uint64_t s_cand[4][64];
     __shared__ uint64_t s_out[4][64];
@@ -388,13 +390,19 @@ static hipError_t launch_batch(const BuildArgs &a, uint32_t n_slots, void *sort_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((insert_search_kernel<NJ>), dim3(a.batch_size), dim3(256), smem, s, a);
-    hipLaunchKernelGGL((select_link_kernel<NJ>), dim3((n_slots + 3) / 4), dim3(256), 0, s, a, n_slots);
+    // register budget of the two heuristic kernels (they are bound by the latency of the kept-row fetches: more waves per SIMD hide
+    // more of it, fewer registers spill): NIDX_GPU_BUILD_MINW = 2 | 3 (default) | 4 waves per SIMD
+    static const int minw = [] { const char *e = getenv("NIDX_GPU_BUILD_MINW"); const int v = e ? atoi(e) : 3; return v < 3 ? 2 : v > 3 ? 4 : 3; }();
+    if (minw == 4) hipLaunchKernelGGL((select_link_kernel<NJ, 4>), dim3((n_slots + 3) / 4), dim3(256), 0, s, a, n_slots);
+    else if (minw == 2) hipLaunchKernelGGL((select_link_kernel<NJ, 2>), dim3((n_slots + 3) / 4), dim3(256), 0, s, a, n_slots);
+    else hipLaunchKernelGGL((select_link_kernel<NJ, 3>), dim3((n_slots + 3) / 4), dim3(256), 0, s, a, n_slots);
     const uint32_t n_req = n_slots * REQ_STRIDE;
     e = hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_tmp_bytes, a.req_key, req_key_sorted, a.req_val,
                                            req_val_sorted, (int)n_req, 0, 64, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((reverse_link_kernel<NJ>), dim3((n_req + 3) / 4), dim3(256), 0, s, a, req_key_sorted,
-                       req_val_sorted, n_req);
+    if (minw == 4) hipLaunchKernelGGL((reverse_link_kernel<NJ, 4>), dim3((n_req + 3) / 4), dim3(256), 0, s, a, req_key_sorted, req_val_sorted, n_req);
+    else if (minw == 2) hipLaunchKernelGGL((reverse_link_kernel<NJ, 2>), dim3((n_req + 3) / 4), dim3(256), 0, s, a, req_key_sorted, req_val_sorted, n_req);
+    else hipLaunchKernelGGL((reverse_link_kernel<NJ, 3>), dim3((n_req + 3) / 4), dim3(256), 0, s, a, req_key_sorted, req_val_sorted, n_req);
     return hipGetLastError();
 }
 

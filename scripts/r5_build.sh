@@ -1,0 +1,14 @@
+#!/bin/bash
+# build-time A/B on the 10 M clustered shard (side blocks off): register budget of the heuristic kernels, visited-table size
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out/r5build
+ARGS="--corpus clustered --parity-queries 0 --scan-check-queries 0 --segment-regime 0 --bf16-block-n 0 --ref-build-n 0 --single-query-calls 0 --cpu-queries 0 --bm25-block 0 --iso-recall 0 --steps 5 --min-timed-s 0.2"
+for v in "3 0" "4 0" "2 0" "3 14"; do
+  set -- $v
+  if [ "$2" = 0 ]; then VIS=""; else VIS="NIDX_GPU_BUILD_VIS_LOG2=$2"; fi
+  env NIDX_GPU_BUILD_MINW=$1 $VIS timeout 300 python bench.py $ARGS > gpurun_out/r5build/b_$1_$2.json 2> gpurun_out/r5build/b_$1_$2.err
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r5build/b_$1_$2.json")); c=d["config"]; b=c["build"]
+print("minw=$1 vis=$2 build_s=%.2f kernels=%.2f frac=%.3f recall=%.4f evals/insert=%.0f" % (c["hnsw_build_s"], b["seconds_of_kernels"], b["roofline"]["frac"], c["recall_at_10"], b["search_distance_evals_per_insert"]))
+PY
+done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4: every bench.py workload once on the GPU box, each under rocprofv3 --kernel-trace --stats, summaries under gpurun_out/final/.
+# Round 4-5: every bench.py workload once on the GPU box, each under rocprofv3 --kernel-trace --stats, summaries under gpurun_out/final/.
 # Usage (repo root, GPU box): bash scripts/refresh_all.sh [part]   part = headline | bf16 | hybrid | bm25stats | bm25 | others | all
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

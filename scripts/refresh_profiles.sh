@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 4: re-measures the headline workload (bench.py default: 10 M x 768 cosine HNSW, batch 1024) on the GPU box and writes under
+# Round 4-5: re-measures the headline workload (bench.py default: 10 M x 768 cosine HNSW, batch 1024) on the GPU box and writes under
 # gpurun_out/final/: the bench line, and per corpus (clustered = the timed one, uniform = the second figure) the rocprofv3
 # --kernel-trace --stats summary plus the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes, --kernel-trace only) of the same
-# command with the side legs switched off.  scripts/make_pmc_traffic.py turns the summaries into profiles/r04_pmc_traffic.json.
+# command with the side legs switched off.  scripts/make_pmc_traffic.py turns the summaries into profiles/r05_pmc_traffic.json.
 # Usage (repo root, GPU box): bash scripts/refresh_profiles.sh [n_vectors]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for corpus in clustered uniform; do
-  BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0 --bf16-block-n 0"
+  BENCH="python $ROOT/bench.py --n-vectors $N --corpus $corpus --steps 10 --warmup 2 --cpu-queries 0 --parity-queries 0 --scan-check-queries 0 --ref-build-n 0 --single-query-calls 0 --recall-queries 0 --bf16-block-n 0 --bm25-block 0 --iso-recall 0"
   # the PMC passes load the graph the trace pass built (rocprofv3 --pmc segfaults over the thousands of dispatches of a 10 M build)
   BENCH="$BENCH --graph-cache /tmp/nidx_graphs"
   [ $corpus = uniform ] && BENCH="$BENCH --batches-in-flight 1"   # the default run times this corpus one launch at a time
