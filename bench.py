@@ -2396,8 +2396,12 @@ def bench_rabitq(a, L, dev, rank, world):
                        "pipelined_queries_per_s": world * B * n_pipe / pipe_elapsed, "pipelined_batches_in_flight": nfl_p,
                        "pipelined_frac_of_hbm_peak": alg * n_pipe / pipe_elapsed / 1e9 / HBM_PEAK_GBS,
                        "pipelined_equals_one_launch_at_a_time": pipe_same,
-                       "walk_kernel": "rabitq_hnsw_kernel (one wave per query)" if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
-                                      "rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)",
+                       "walk_kernel": ("rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)"
+                                       if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "2" else "rabitq_hnsw_kernel (one wave per query, rounds 1-4)"
+                                       if os.environ.get("NIDX_GPU_RABITQ_PIPE") == "0" else
+                                       "rabitq_hnsw3_kernel (one wave per query; the predicted next expansion's loads are in flight under the admissions)"),
+                       "expansions_with_loads_in_flight_under_the_admissions_per_query": (float(s[:, 5].mean()) if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2"
+                                                                                           and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else None),
                        "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
                                              "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
                                             {"fetcher_speculative_fetches": float(((s[:, 4] & 0xFFFF) << 8).mean()),

@@ -1296,6 +1296,263 @@ __global__ __launch_bounds__(128) void rabitq_hnsw2_segments_kernel(const Rabitq
     rabitq_hnsw2_body<NW>(a, blockIdx.x % n_queries, smem);
 }
 
+// ---- HNSW, RaBitQ arm, ONE wave per query with the next expansion's loads in flight under the admissions (round 5) --------------------
+// What the two-wave walk above was built for — the memory round trip of expansion i + 1 hidden behind the admissions of expansion i —
+// without a second wave and without meetings: a wave's own loads are asynchronous.  After the estimates of an expansion are known, the node
+// the next pop will return is predicted exactly as above (best of {best unexpanded entry of the result set, best admissible new
+// neighbour}); when its layer-0 edge record is already in registers (the records of the three best candidates are requested one
+// expansion ahead: read-only, 84 % of the expansions find theirs), the codes of its neighbours and their visited test-and-set are ISSUED
+// — and only then the admission rule is replayed for the current expansion's neighbours (LDS and scalar work, ~3 000 cycles): the
+// loads land meanwhile.  The pop verifies the prediction; a mismatch (exactly tied scores, the ties side list) clears exactly the bits
+// the speculative test-and-set set (nobody else writes this query's bitset) and expands the popped node the plain way.  Upper layers
+// (a handful of expansions, an LDS hash without removal) run the plain loop.  Results are the plain kernel's bit for bit.
+template <int NW>
+__device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32_t qi, unsigned char *smem) {
+    const int lane = threadIdx.x;
+    const uint32_t nw = a.seg.dim / 64u;
+    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef);
+    rq_load_query(sh, a, qi, nw, lane);
+    const RabitqQueryDev qc = a.qd[qi];
+    uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
+    uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;
+    uint64_t cyc_ins = 0;
+    const bool timing = a.stats != nullptr;
+    auto now = [&]() -> uint64_t { return timing ? (uint64_t)clock64() : 0ull; };
+    const uint64_t t_start = now();
+
+    uint32_t ep = a.g.ep_node;
+    RqLayer L;
+    L.res = sh.res;
+    L.ties = sh.ties;
+    // ---- upper layers: the plain loop (k = 1) ----
+    for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
+        L.init((int)rq_chunks(1u));
+        for (uint32_t i = lane; i < (1u << RABITQ_UPPER_VIS_LOG2); i += 64) sh.vis[i] = NIDX_VIS_EMPTY;
+        if (lane == 0) vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, ep);
+        uint32_t vis_count = 1;
+        {
+            float est, err;
+            rabitq_estimate<NW>(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
+            n_est++;
+            rq_admit(L, 1, est, ep, lane, flags);
+        }
+        uint32_t node, next;
+        for (;;) {
+            if (!rq_pop(L, lane, node, next)) break;
+            const uint32_t w = load_edge_raw(a.g, node, layer, lane);
+            const uint32_t deg = lane_u32(w, 0);
+            const bool is_edge = lane >= 1 && lane <= (int)deg;
+            RqCode<NW> code;
+            const uint8_t *rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
+            if (is_edge) rq_load_code<NW>(rec, code);
+            bool fresh = false;
+            if (is_edge) fresh = vis_insert(sh.vis, RABITQ_UPPER_VIS_LOG2, w);
+            n_exp++;
+            const unsigned long long fm = __ballot(fresh);
+            vis_count += (uint32_t)__popcll(fm);
+            if (vis_count > (3u << RABITQ_UPPER_VIS_LOG2) / 4u) {
+                flags |= NIDX_FLAG_VISITED_OVERFLOW;
+                break;
+            }
+            float est = 0.f, err = 0.f;
+            if (fresh) rq_score_code<NW>(code, rec, sh.planes, nw, qc, est, err);
+            n_est += (uint32_t)__popcll(fm);
+            unsigned long long todo = fm;
+            while (todo) {
+                todo = uni64(todo);
+                L.len = uni(L.len);
+                L.worst = uni64(L.worst);
+                const float ws = rank_key_score(L.worst);
+                if (L.len >= 1) {
+                    todo &= __ballot(fresh && est > ws);
+                    if (!todo) break;
+                }
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= ~(1ull << j);
+                const float sj = lane_f32(est, j);
+                if (sj > ws || L.len < 1) rq_admit(L, 1, sj, lane_u32(w, j), lane, flags);
+            }
+        }
+        ep = rq_addr(lane_u64(L.dir_first, 0));
+    }
+
+    // ---- layer 0 ----
+    {
+        const int kk = (int)a.ef;
+        L.init((int)rq_chunks((uint32_t)kk));
+        if (lane == 0) atomicOr(&gvis[ep >> 5], 1u << (ep & 31));
+        {
+            float est, err;
+            rabitq_estimate<NW>(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
+            n_est++;
+            rq_admit(L, kk, est, ep, lane, flags);
+        }
+        // edge records held in registers: hn* = node (wave-uniform), hw* = this lane's word of its record
+        uint32_t hn0 = RQ_NONE, hn1 = RQ_NONE, hn2 = RQ_NONE, hw0 = 0, hw1 = 0, hw2 = 0;
+        // the speculated expansion
+        bool have_spec = false, spec_edge = false;
+        uint32_t spec_node = RQ_NONE, spec_w = 0, spec_old = 0;
+        RqCode<NW> spec_code;
+        uint32_t node, next;
+        for (;;) {
+            if (!rq_pop(L, lane, node, next)) break;
+            uint32_t w;
+            bool is_edge, fresh = false;
+            RqCode<NW> code;
+            const uint8_t *rec;
+            if (have_spec && spec_node == node) {
+                // confirmed: its loads have been in flight since before the last admissions
+                w = spec_w;
+                is_edge = spec_edge;
+                rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
+                code = spec_code;
+                fresh = is_edge && (spec_old & (1u << (w & 31))) == 0;
+                n_hit++;
+            } else {
+                if (have_spec) {
+                    // not confirmed: clear exactly the bits the speculative test-and-set set; the returned words are waited for
+                    uint32_t old = 0;
+                    if (spec_edge && (spec_old & (1u << (spec_w & 31))) == 0) old = atomicAnd(&gvis[spec_w >> 5], ~(1u << (spec_w & 31)));
+                    asm volatile("" ::"v"(old));
+                }
+                const uint32_t w_held = node == hn0 ? hw0 : node == hn1 ? hw1 : hw2;
+                uint32_t w_mem = 0;
+                const bool held = node == hn0 || node == hn1 || node == hn2;
+                if (!held) w_mem = load_edge_raw(a.g, node, 0, lane);
+                w = held ? w_held : w_mem;
+                const uint32_t deg = lane_u32(w, 0);
+                is_edge = lane >= 1 && lane <= (int)deg;
+                rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
+                if (is_edge) rq_load_code<NW>(rec, code);
+                if (is_edge) fresh = (atomicOr(&gvis[w >> 5], 1u << (w & 31)) & (1u << (w & 31))) == 0;
+            }
+            have_spec = false;
+            n_exp++;
+            const unsigned long long fm = __ballot(fresh);
+            float est = 0.f, err = 0.f;
+            if (fresh) rq_score_code<NW>(code, rec, sh.planes, nw, qc, est, err);
+            n_est += (uint32_t)__popcll(fm);
+            // ---- the next pop, predicted; its expansion's loads issued before the admissions below ----
+            uint32_t p1 = RQ_NONE, p2 = RQ_NONE, p3 = RQ_NONE;
+            {
+                L.len = uni(L.len);
+                L.worst = uni64(L.worst);
+                const float ws = rank_key_score(L.worst);
+                const bool full = L.len >= kk;
+                const uint64_t key_new = (fresh && (!full || est > ws)) ? rq_key(est, w, 1u) : 0ull;
+                const uint64_t best_new = wave_max_u64(key_new);
+                uint64_t pk1, pk2, pk3;
+                rq_peek3(L, lane, pk1, pk2, pk3);
+                uint64_t a1, a2, a3;
+                if (best_new > pk1) a1 = best_new, a2 = pk1, a3 = pk2;
+                else if (best_new > pk2) a1 = pk1, a2 = best_new, a3 = pk2;
+                else if (best_new > pk3) a1 = pk1, a2 = pk2, a3 = best_new;
+                else a1 = pk1, a2 = pk2, a3 = pk3;
+                if (a1) p1 = rq_addr(a1);
+                if (a2) p2 = rq_addr(a2);
+                if (a3) p3 = rq_addr(a3);
+            }
+            if (p1 != RQ_NONE && (p1 == hn0 || p1 == hn1 || p1 == hn2)) {
+                spec_node = p1;
+                spec_w = p1 == hn0 ? hw0 : p1 == hn1 ? hw1 : hw2;
+                const uint32_t deg2 = lane_u32(spec_w, 0);
+                spec_edge = lane >= 1 && lane <= (int)deg2;
+                const uint8_t *rec2 = a.quant + (size_t)(spec_edge ? spec_w : 0u) * a.rec_len;
+                if (spec_edge) rq_load_code<NW>(rec2, spec_code);
+                spec_old = 0;
+                if (spec_edge) spec_old = atomicOr(&gvis[spec_w >> 5], 1u << (spec_w & 31));
+                have_spec = true;
+            }
+            // the records of the three candidates stay / come into the held set (a slot that holds none of them is overwritten)
+            {
+                const bool k0 = hn0 != RQ_NONE && (hn0 == p1 || hn0 == p2 || hn0 == p3);
+                const bool k1 = hn1 != RQ_NONE && (hn1 == p1 || hn1 == p2 || hn1 == p3);
+                const bool k2 = hn2 != RQ_NONE && (hn2 == p1 || hn2 == p2 || hn2 == p3);
+                bool f0 = !k0, f1 = !k1, f2 = !k2;
+                const uint32_t want[3] = {p1, p2, p3};
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t n = want[j];
+                    if (n == RQ_NONE || n == hn0 || n == hn1 || n == hn2) continue;
+                    if (j == 1 && n == want[0]) continue;
+                    if (j == 2 && (n == want[0] || n == want[1])) continue;
+                    if (f0) {
+                        hw0 = load_edge_raw(a.g, n, 0, lane);
+                        hn0 = n;
+                        f0 = false;
+                    } else if (f1) {
+                        hw1 = load_edge_raw(a.g, n, 0, lane);
+                        hn1 = n;
+                        f1 = false;
+                    } else if (f2) {
+                        hw2 = load_edge_raw(a.g, n, 0, lane);
+                        hn2 = n;
+                        f2 = false;
+                    }
+                }
+            }
+            // ---- `if similarity.score > ws.score || len < k` replayed in edge order (search.rs:287-295) ----
+            const uint64_t t3 = now();
+            unsigned long long todo = fm;
+            while (todo) {
+                todo = uni64(todo);
+                L.len = uni(L.len);
+                L.worst = uni64(L.worst);
+                const float ws = rank_key_score(L.worst);
+                if (L.len >= kk) {
+                    todo &= __ballot(fresh && est > ws);
+                    if (!todo) break;
+                }
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= ~(1ull << j);
+                const float sj = lane_f32(est, j);
+                if (sj > ws || L.len < kk) rq_admit(L, kk, sj, lane_u32(w, j), lane, flags);
+            }
+            cyc_ins += now() - t3;
+        }
+    }
+
+    // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
+    Reranker rr;
+    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
+    for (int dch = 0; dch < uni(L.n_dir); dch++) {
+        const uint32_t meta = lane_u32(L.dir_meta, dch);
+        const bool ok = lane < (int)(meta >> 8);
+        uint32_t addr = 0;
+        float ub = 0.f;
+        if (ok) {
+            const uint64_t key = L.chunk(meta & 0xffu)[lane];
+            addr = rq_addr(key);
+            ub = rank_key_score(key) + rabitq_error(a.quant + (size_t)addr * a.rec_len, qc);
+        }
+        rr.feed(ok, addr, ub, lane);
+    }
+    rr.write(a.out_vec + (size_t)qi * a.k, a.out_score + (size_t)qi * a.k, a.out_count + qi, lane);
+    if (flags && a.flag_word && lane == 0) atomicOr(a.flag_word, flags);
+    if (a.stats && lane == 0) {
+        uint32_t *o = a.stats + (size_t)qi * NIDX_STAT_STRIDE;
+        o[NIDX_STAT_EVALS] = n_est;
+        o[NIDX_STAT_EXPANSIONS] = n_exp;
+        o[NIDX_STAT_VISITED] = rr.n_eval;
+        o[NIDX_STAT_FLAGS] = flags;
+        o[NIDX_STAT_CYC_CTL] = 0;
+        o[NIDX_STAT_EDGE_HITS] = n_hit;   // expansions whose loads were in flight under the previous admissions
+        o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
+        o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(now() - t_start);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64) void rabitq_hnsw3_kernel(RabitqSearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    rabitq_hnsw3_body<NW>(a, blockIdx.x, smem);
+}
+template <int NW>
+__global__ __launch_bounds__(64) void rabitq_hnsw3_segments_kernel(const RabitqSearchArgs *table, uint32_t n_queries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    rabitq_hnsw3_body<NW>(table[blockIdx.x / n_queries], blockIdx.x % n_queries, smem);
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -1362,6 +1619,27 @@ static hipError_t launch_hnsw1_segments_nw(const RabitqSearchArgs *table, uint32
     hipLaunchKernelGGL(rabitq_hnsw_segments_kernel<NW>, dim3(n_table * nq), dim3(64), smem, s, table, nq);
     return hipGetLastError();
 }
+template <int NW>
+static hipError_t launch_hnsw3_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw3_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw3_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
+    return hipGetLastError();
+}
+template <int NW>
+static hipError_t launch_hnsw3_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw3_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rabitq_hnsw3_segments_kernel<NW>, dim3(n_table * nq), dim3(64), smem, s, table, nq);
+    return hipGetLastError();
+}
+// NIDX_GPU_RABITQ_PIPE=0: the plain one-wave walk (rounds 1-4); default: the walk with the next expansion's loads in flight under the
+// admissions (dimensions whose code fetch is unrolled: every D that is a multiple of 64 up to 2 048 except the odd word counts)
+static bool rabitq_pipelined(uint32_t nw) {
+    const char *e = getenv("NIDX_GPU_RABITQ_PIPE");
+    if (e && atoi(e) == 0) return false;
+    return nw == 2 || nw == 4 || nw == 6 || nw == 8 || nw == 12 || nw == 16 || nw == 24 || nw == 32;
+}
 // measurement switches of the two-wave walk -> RabitqSearchArgs::no_speculation: NIDX_GPU_RABITQ_SPEC=0: no speculation (bit 0);
 // =2: the waves meet through polled LDS words instead of s_barrier (bit 1); =3: both
 static uint32_t rabitq_walk_mode() {
@@ -1400,6 +1678,7 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
         RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s)
     }
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
+    if (rabitq_pipelined(a.seg.dim / 64u)) { RQ_DISPATCH(launch_hnsw3_nw, a.seg.dim / 64u, a, smem, s) }
     RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
 }
 // `table` (device) holds n_table argument records that agree in dim / dp / k / ef / n_queries (`shape`: one of them, host side)
@@ -1410,6 +1689,7 @@ hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n
         RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
     }
     const size_t smem = rq_smem_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef, true);
+    if (rabitq_pipelined(shape.seg.dim / 64u)) { RQ_DISPATCH(launch_hnsw3_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s) }
     RQ_DISPATCH(launch_hnsw1_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s)
 }
 

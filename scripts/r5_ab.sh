@@ -26,9 +26,9 @@ PY
 )"
 }
 if [ "$PART" = rabitq ] || [ "$PART" = all ]; then
-  run rabitq_1w -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 256
+  run rabitq_pipe -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 256
+  run rabitq_plain NIDX_GPU_RABITQ_PIPE=0 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
   run rabitq_2w_barrier NIDX_GPU_RABITQ_WAVES=2 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
-  run rabitq_2w_spin NIDX_GPU_RABITQ_WAVES=2 NIDX_GPU_RABITQ_SPEC=2 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
 fi
 if [ "$PART" = bm25 ] || [ "$PART" = all ]; then
   run bm25_default -- --workload bm25 --cpu-queries 0 --steps 200

@@ -164,10 +164,15 @@ def test_rabitq_brute_force_filters_min_score_ties(orc):
 
 # ---- HNSW, RaBitQ arm ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5), (9000, 128, 300), (6000, 768, 512)])
-@pytest.mark.parametrize("waves", ["1", "2"])
-def test_rabitq_hnsw_matches_oracle(orc, monkeypatch, n, d, k, waves):
-    """waves = 2: the two-wave walk (a fetcher wave expands the predicted next candidate, rollback on a mispredict) — the same bits."""
-    monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", waves)
+@pytest.mark.parametrize("walk", ["pipelined", "plain", "two_waves"])
+def test_rabitq_hnsw_matches_oracle(orc, monkeypatch, n, d, k, walk):
+    """The three walk kernels give the same bits: `pipelined` (default: one wave, the predicted next expansion's loads in flight under
+    the admissions, rollback on a mispredict), `plain` (rounds 1-4, NIDX_GPU_RABITQ_PIPE=0), `two_waves` (NIDX_GPU_RABITQ_WAVES=2: a
+    fetcher wave runs the predicted expansion)."""
+    if walk == "plain":
+        monkeypatch.setenv("NIDX_GPU_RABITQ_PIPE", "0")
+    elif walk == "two_waves":
+        monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "2")
     rng = np.random.default_rng(n * 7 + d + k)
     x = clustered(rng, n, d, clusters=60, spread=0.3)
     nq = 12

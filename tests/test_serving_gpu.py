@@ -333,7 +333,7 @@ def test_rabitq_segments_share_one_launch(orc, monkeypatch):
             idx.tunable("serial_segments", 0)
             assert same(got, serial), (k, with_dup)
             assert same(serial_two_waves, serial), (k, with_dup)
-            for var, val in (("NIDX_GPU_SEGMENT_LAUNCHES", "1"), ("NIDX_GPU_RABITQ_WAVES", "2")):
+            for var, val in (("NIDX_GPU_SEGMENT_LAUNCHES", "1"), ("NIDX_GPU_RABITQ_WAVES", "2"), ("NIDX_GPU_RABITQ_PIPE", "0")):
                 monkeypatch.setenv(var, val)
                 assert same(idx.search(q, k, _lib.METHOD_RABITQ_HNSW, with_dup, min_score=min_score), got), (var, k, with_dup)
                 monkeypatch.delenv(var)
