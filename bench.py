@@ -2402,7 +2402,9 @@ def bench_rabitq(a, L, dev, rank, world):
                                        "rabitq_hnsw3_kernel (one wave per query; the predicted next expansion's loads are in flight under the admissions)"),
                        "expansions_with_loads_in_flight_under_the_admissions_per_query": (float(s[:, 5].mean()) if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2"
                                                                                            and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else None),
-                       "cycles_per_query": ({"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
+                       "cycles_per_query": ({"admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())}
+                                            if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else
+                                            {"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),
                                              "admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())} if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" else
                                             {"fetcher_speculative_fetches": float(((s[:, 4] & 0xFFFF) << 8).mean()),
                                              "controller_predict_pop_and_waiting_for_the_fetcher": float((((s[:, 4] >> 16) & 0xFFFF) << 8).mean()), "admission": float(s[:, 6].mean()),
