@@ -1962,7 +1962,7 @@ class Bm25Bench:
         # the host side of a batch (clause weights, work list, staging, ~8 runtime calls) costs its thread more than the kernels cost
         # the device, and every ticket is planned and launched on a context of its own
         depth = int(os.environ.get("NIDX_BENCH_BM25_DEPTH", "2"))
-        threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "2")))
+        threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "6")))
         elapsed, n_steps, postings, post_per_batch = self.timed_pipeline(self.searcher, threads_n, depth)
         one_thread = None
         if threads_n > 1:

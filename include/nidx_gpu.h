@@ -654,7 +654,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
  * nidx_paragraph/src/lib.rs:117-169, one call per request from src/searcher/shard_search.rs:176-248, for a caller that has batches):
  * submit prepares the batch (clause weights, work list, staging), queues the launches and ONE device-to-host transfer of the result
  * block on a stream of its own and returns; wait blocks until that block has landed and fills the caller's arrays exactly as
- * nidx_gpu_bm25_search_ex would have.  With two tickets outstanding the host side of batch i + 1 overlaps the kernels of batch i.  At most 8
+ * nidx_gpu_bm25_search_ex would have.  With two tickets outstanding the host side of batch i + 1 overlaps the kernels of batch i.  At most 16
  * tickets may be outstanding (NIDX_ERR_BUSY otherwise); a ticket is waited for once, from any thread.  Several threads may submit at the
  * same time: every ticket's batch is planned and launched on a context of its own (the planning of a batch costs the submitting thread
  * more than its kernels cost the device).  An index of several segments goes through the pipeline like one of a single segment (it is

@@ -36,6 +36,13 @@ if [ "$PART" = bm25 ] || [ "$PART" = all ]; then
   run bm25_copy_out NIDX_GPU_BM25_ZERO_COPY_OUT=0 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
   run bm25_depth4 NIDX_BENCH_BM25_DEPTH=4 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
 fi
+if [ "$PART" = bm25t ]; then
+  for t in ${BM25_T:-2 3 4}; do
+    run bm25_threads$t NIDX_BENCH_BM25_THREADS=$t NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+  done
+  run bm25_threads4_depth1 NIDX_BENCH_BM25_THREADS=4 NIDX_BENCH_BM25_DEPTH=1 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+  run bm25_batch2048 NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --batch 2048 --cpu-queries 0 --steps 200
+fi
 if [ "$PART" = hybrid ]; then
   run hybrid_default -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
   run hybrid_w5_v12 NIDX_BENCH_TUNABLES=min_waves=5,vis_log2=12 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0

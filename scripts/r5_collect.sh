@@ -13,7 +13,7 @@ cat $F/summary_fetch_clustered.txt $F/summary_write_clustered.txt > $P/r05_pmc_h
 cat $F/summary_fetch_uniform.txt $F/summary_write_uniform.txt > $P/r05_pmc_hnsw10m_uniform.txt
 cp $F/bench_bm25.json $P/r05_bench_bm25.json
 cp $F/bench_bm25_one_at_a_time.json $P/r05_bench_bm25_one_at_a_time.json
-cat $F/kernel_stats_bm25_one_at_a_time.txt $F/kernel_stats_bm25_two_threads.txt > $P/r05_kernel_stats_bm25.txt
+cat $F/kernel_stats_bm25_one_at_a_time.txt $F/kernel_stats_bm25_pipelined.txt > $P/r05_kernel_stats_bm25.txt
 cp $F/bm25_batch_curve.txt $P/r05_bm25_batch_curve.txt
 cat gpurun_out/pmc_bm25/traffic_FETCH_SIZE.txt gpurun_out/pmc_bm25/traffic_WRITE_SIZE.txt > $P/r05_pmc_bm25.txt 2>/dev/null
 cp $F/bench_hybrid.json $P/r05_bench_hybrid.json

@@ -32,7 +32,7 @@ headline)
 bm25)
   export NIDX_BENCH_BM25_SEGMENTS=0
   NIDX_BENCH_BM25_DEPTH=1 NIDX_BENCH_BM25_THREADS=1 prof bm25_one_at_a_time --workload bm25 --cpu-queries 0 --steps 200
-  prof bm25_two_threads --workload bm25 --cpu-queries 0 --steps 200
+  prof bm25_pipelined --workload bm25 --cpu-queries 0 --steps 200
   timeout 400 bash $ROOT/scripts/pmc_bm25_traffic.sh < /dev/null > $OUT/pmc_bm25_traffic.log 2>&1
   timeout 500 bash $ROOT/scripts/bm25_batch_curve.sh 256 1024 4096 16384 < /dev/null > $OUT/bm25_batch_curve.txt 2>&1
   unset NIDX_BENCH_BM25_SEGMENTS

@@ -368,7 +368,7 @@ def test_boolean_trees_of_any_depth_match_the_oracle(orc):
 
 def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
     """nidx_gpu_bm25_search_submit / _wait: several batches in flight, waited for out of order, give what nidx_gpu_bm25_search gives
-    for each; a ninth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term
+    for each; a seventeenth outstanding ticket is NIDX_ERR_BUSY; a ticket is waited for once; requests the pipeline does not cover (term
     sets) run inside submit and still come back through wait."""
     import ctypes as C
 
@@ -379,11 +379,11 @@ def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
                for n in (64, 1, 200, 33)]
     want = [s.search_batch(b, 20) for b in batches]
     for _ in range(3):
-        tickets = [s.submit(b, 20) for b in batches + batches]
+        tickets = [s.submit(b, 20) for b in batches * 4]
         with pytest.raises(_lib.NidxGpuError) as e:
             s.submit(batches[0], 20)
         assert "not been waited" in str(e.value)
-        for i in (2, 0, 7, 3, 5, 1, 6, 4):
+        for i in (2, 0, 7, 13, 3, 15, 5, 1, 9, 6, 4, 8, 12, 10, 14, 11):
             got = s.wait(tickets[i])
             for g, w in zip(got, want[i % 4]):
                 assert np.array_equal(g.view(np.uint32) if g.dtype == np.float32 else g, w.view(np.uint32) if w.dtype == np.float32 else w), i
