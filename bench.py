@@ -2402,6 +2402,8 @@ def bench_rabitq(a, L, dev, rank, world):
                                        "rabitq_hnsw3_kernel (one wave per query; the predicted next expansion's loads are in flight under the admissions)"),
                        "expansions_with_loads_in_flight_under_the_admissions_per_query": (float(s[:, 5].mean()) if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2"
                                                                                            and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else None),
+                       "neighbours_asked_of_memory_per_query": (float(s[:, 4].mean()) if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2"
+                                                                and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else None),
                        "cycles_per_query": ({"admission": float(s[:, 6].mean()), "total": float(s[:, 7].mean())}
                                             if os.environ.get("NIDX_GPU_RABITQ_WAVES") != "2" and os.environ.get("NIDX_GPU_RABITQ_PIPE") != "0" else
                                             {"pop_edge_visited": float(s[:, 4].mean()), "estimates": float(s[:, 5].mean()),

@@ -17,7 +17,10 @@
 
 namespace nidx {
 
-static const uint32_t kMaxBatch = 8192;
+// A batch is at most 1/16 of the graph it searches (the ramp below) and at most this many nodes: 0.3 % of a 10 M graph.  Measured at 10 M x 768
+// clustered (scripts/r5_build2.sh): 8 192 -> 12.27 s of kernels, recall@10 0.9949; 16 384 -> 11.62 s, 0.9965; 32 768 -> 11.26 s, 0.9965 (the tail of
+// a launch and the sort / launch gaps are paid per batch).
+static const uint32_t kMaxBatch = 32768;
 
 int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     std::lock_guard<std::mutex> lock(mu);
@@ -108,13 +111,15 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
     std::vector<Batch> batches;
     std::vector<uint32_t> slot_base(n);
     uint32_t max_slots = 0;
+    uint32_t max_batch = kMaxBatch;
+    if (const char *e = getenv("NIDX_GPU_BUILD_MAX_BATCH")) max_batch = std::max<uint32_t>(32, (uint32_t)atoi(e));   // diagnostics
     for (uint32_t start = n0; start < n;) {
         // a batch's nodes do not see each other, so it stays a small fraction of the graph they search.
         // When extending, the appended rows may be a distribution of their own (another segment's
         // clusters): ramp on the number of NEW nodes already linked, not on the reused graph's size.
         uint32_t ramp = start / 16;
         if (extend) ramp = std::min<uint32_t>(ramp, std::max<uint32_t>(32, (start - n0) / 8));
-        uint32_t size = std::min<uint32_t>(std::min<uint32_t>(kMaxBatch, std::max<uint32_t>(1, ramp)), n - start);
+        uint32_t size = std::min<uint32_t>(std::min<uint32_t>(max_batch, std::max<uint32_t>(1, ramp)), n - start);
         uint32_t slots = 0;
         for (uint32_t i = start; i < start + size; i++) {
             slot_base[i] = slots;

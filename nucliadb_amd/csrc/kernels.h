@@ -288,6 +288,7 @@ struct RabitqSearchArgs {
     uint32_t *flag_word = nullptr;  // nullptr or [1]: OR of the flags any query raised (see HnswSearchArgs)
     uint32_t no_speculation = 0;    // two-wave walk, measurement: 1 = the fetcher never runs ahead of the controller
     unsigned long long *dbg = nullptr;   // two-wave walk, measurement: [16] cycle totals of the two waves (NIDX_GPU_RABITQ_DEBUG)
+    uint32_t seen_log2 = 0;         // pipelined walk: log2 words of the LDS cache of known-visited ids, 0 = none (rabitq_seen_log2())
 };
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s);
 hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,
@@ -296,6 +297,7 @@ hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s);
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s);
 // several segments' walks in one launch: `table` (device, n_table records agreeing in shape with `shape`); block b = query b % nq of record b / nq
 bool rabitq_two_waves();   // true with NIDX_GPU_RABITQ_WAVES=2 (the two-wave walk: measured slower, kept for comparison)
+uint32_t rabitq_seen_log2();   // 9; NIDX_GPU_RABITQ_SEEN=0 / 8...13 (measurement)
 hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s);
 
 // ---- HNSW build (hnsw_build.hip): one batch of concurrent inserts ----

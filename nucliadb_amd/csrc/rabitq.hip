@@ -432,7 +432,9 @@ __host__ __device__ inline size_t rq_list_bytes(uint32_t cap) { return (size_t)(
 // physical 64-key chunks of a two-level list of `cap` keys: every chunk but the last holds >= 32 keys
 __host__ __device__ inline uint32_t rq_chunks(uint32_t cap) { return cap / 32u + 2u < 64u ? cap / 32u + 2u : 64u; }
 
-__device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
+// (q_in_lds = false: the raw query stays in HBM / L2 — only the re-rank reads it, beside the rows it fetches anyway — and 4 dp bytes of LDS
+// are another resident walk per CU at ef = 1 000)
+__device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool q_in_lds = true) {
     RqShared s;
     size_t off = 0;
     s.planes = reinterpret_cast<uint64_t *>(smem + off);
@@ -445,21 +447,31 @@ __device__ inline RqShared rq_carve(unsigned char *smem, uint32_t nw, uint32_t d
     off += (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
     s.q = reinterpret_cast<float *>(smem + off);
-    off += (size_t)dp * 4;
+    if (q_in_lds) off += (size_t)dp * 4;
     s.vis = reinterpret_cast<uint32_t *>(smem + off);
     return s;
 }
-static size_t rq_smem_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool hnsw) {
+static size_t rq_smem_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef, bool hnsw, bool q_in_lds = true) {
     size_t off = (size_t)4 * nw * 8 + rq_list_bytes(k) + (size_t)rq_chunks(ef) * 512 + (size_t)RABITQ_TIE_CAP * 8;
     off = (off + 15) & ~(size_t)15;
-    off += (size_t)dp * 4;
+    if (q_in_lds) off += (size_t)dp * 4;
     if (hnsw) off += (size_t)4 << RABITQ_UPPER_VIS_LOG2;
     return off;
 }
 
-__device__ inline void rq_load_query(const RqShared &sh, const RabitqSearchArgs &a, uint32_t qi, uint32_t nw, int lane) {
+// LDS of rabitq_hnsw3_kernel (see its body)
+static size_t rq_smem3_bytes(uint32_t nw, uint32_t k, uint32_t ef, uint32_t seen_log2) {
+    size_t off = (size_t)4 * nw * 8 + rq_list_bytes(k) + (size_t)rq_chunks(ef) * 512 + (size_t)RABITQ_TIE_CAP * 8;
+    off = (off + 15) & ~(size_t)15;
+    if ((rq_chunks(ef) - 2u) * 512u < (4u << RABITQ_UPPER_VIS_LOG2)) off += (size_t)4 << RABITQ_UPPER_VIS_LOG2;
+    if (seen_log2) off += (size_t)4 << seen_log2;
+    return off;
+}
+
+__device__ inline void rq_load_query(const RqShared &sh, const RabitqSearchArgs &a, uint32_t qi, uint32_t nw, int lane, bool q_in_lds = true) {
     const uint64_t *gp = a.planes + (size_t)qi * 4u * nw;
     for (uint32_t i = lane; i < 4u * nw; i += 64) sh.planes[i] = gp[i];
+    if (!q_in_lds) return;
     const float *gq = a.queries + (size_t)qi * a.seg.dp;
     for (uint32_t i = lane; i < a.seg.dp; i += 64) sh.q[i] = gq[i];
 }
@@ -1310,11 +1322,18 @@ template <int NW>
 __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32_t qi, unsigned char *smem) {
     const int lane = threadIdx.x;
     const uint32_t nw = a.seg.dim / 64u;
-    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef);
-    rq_load_query(sh, a, qi, nw, lane);
+    // LDS of this kernel (rq_smem3_bytes): planes | best | res | ties | [upper-layer table, if res cannot lend the space] | [seen cache].
+    // The upper layers run with k = 1 — two chunks of `res` — so their visited table lives in the rest of `res` when that is large enough
+    // (ef >= 576); the raw query stays in HBM / L2 (only the re-rank reads it, beside the rows it fetches anyway).  At D = 768, ef = 1 000:
+    // 18.3 KiB + the cache (2 KiB) instead of 29.5 KiB: seven resident walks per CU instead of five.
+    RqShared sh = rq_carve(smem, nw, a.seg.dp, a.k, a.ef, false);
+    rq_load_query(sh, a, qi, nw, lane, false);
+    uint32_t *seen = sh.vis;   // (rq_carve: the region behind `ties`)
+    if ((rq_chunks(a.ef) - 2u) * 512u >= (4u << RABITQ_UPPER_VIS_LOG2)) sh.vis = reinterpret_cast<uint32_t *>(sh.res + 2 * 64);
+    else seen += 1u << RABITQ_UPPER_VIS_LOG2;
     const RabitqQueryDev qc = a.qd[qi];
     uint32_t *gvis = a.visited + (size_t)qi * a.vis_words;  // layer-0 visited bitset (zeroed by the host)
-    uint32_t n_est = 0, n_exp = 0, n_hit = 0, flags = 0;
+    uint32_t n_est = 0, n_exp = 0, n_hit = 0, n_ask = 0, flags = 0;
     uint64_t cyc_ins = 0;
     const bool timing = a.stats != nullptr;
     auto now = [&]() -> uint64_t { return timing ? (uint64_t)clock64() : 0ull; };
@@ -1381,6 +1400,16 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
         const int kk = (int)a.ef;
         L.init((int)rq_chunks((uint32_t)kk));
         if (lane == 0) atomicOr(&gvis[ep >> 5], 1u << (ep & 31));
+        // Of the ~60 neighbours an expansion tests, ~55 have been visited before; their test-and-set and their codes are most of what the walk asks
+        // of the memory system (1 024 bitsets of n bits do not fit the L2: three of four requests miss).  An LDS table of 2^seen_log2
+        // words is a direct-mapped cache of node ids KNOWN to be visited (entered only once the bit is surely set: when an expansion is
+        // no longer speculative).  A hit is exact — the lane skips the atomic and the code; a miss asks the bitset as before.
+        const uint32_t seen_log2 = a.seen_log2;   // 0: no cache
+        const bool use_seen = seen_log2 != 0;
+        if (use_seen)
+            for (uint32_t i = lane; i < (1u << seen_log2); i += 64) seen[i] = NIDX_VIS_EMPTY;
+        const uint32_t seen_shift = 32u - seen_log2;
+        auto seen_slot = [&](uint32_t v) -> uint32_t { return (v * 2654435761u) >> seen_shift; };
         {
             float est, err;
             rabitq_estimate<NW>(a.quant + (size_t)ep * a.rec_len, sh.planes, nw, qc, est, err);
@@ -1423,9 +1452,12 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
                 const uint32_t deg = lane_u32(w, 0);
                 is_edge = lane >= 1 && lane <= (int)deg;
                 rec = a.quant + (size_t)(is_edge ? w : 0u) * a.rec_len;
-                if (is_edge) rq_load_code<NW>(rec, code);
-                if (is_edge) fresh = (atomicOr(&gvis[w >> 5], 1u << (w & 31)) & (1u << (w & 31))) == 0;
+                const bool ask = is_edge && !(use_seen && seen[seen_slot(w)] == w);
+                if (ask) rq_load_code<NW>(rec, code);
+                if (ask) fresh = (atomicOr(&gvis[w >> 5], 1u << (w & 31)) & (1u << (w & 31))) == 0;
+                n_ask += (uint32_t)__popcll(__ballot(ask));
             }
+            if (use_seen && is_edge) seen[seen_slot(w)] = w;   // every neighbour of an expanded node is visited from here on
             have_spec = false;
             n_exp++;
             const unsigned long long fm = __ballot(fresh);
@@ -1458,9 +1490,11 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
                 const uint32_t deg2 = lane_u32(spec_w, 0);
                 spec_edge = lane >= 1 && lane <= (int)deg2;
                 const uint8_t *rec2 = a.quant + (size_t)(spec_edge ? spec_w : 0u) * a.rec_len;
-                if (spec_edge) rq_load_code<NW>(rec2, spec_code);
-                spec_old = 0;
-                if (spec_edge) spec_old = atomicOr(&gvis[spec_w >> 5], 1u << (spec_w & 31));
+                const bool ask = spec_edge && !(use_seen && seen[seen_slot(spec_w)] == spec_w);
+                if (ask) rq_load_code<NW>(rec2, spec_code);
+                spec_old = 0xffffffffu;   // a lane that does not ask knows its node visited
+                if (ask) spec_old = atomicOr(&gvis[spec_w >> 5], 1u << (spec_w & 31));
+                n_ask += (uint32_t)__popcll(__ballot(ask));
                 have_spec = true;
             }
             // the records of the three candidates stay / come into the held set (a slot that holds none of them is overwritten)
@@ -1514,7 +1548,7 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
 
     // ---- rerank_top over the ef neighbours, best estimate first (search.rs:354-363) ----
     Reranker rr;
-    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, sh.q);
+    rr.init(sh.best, (int)a.k, a.min_score, a.seg.vectors, a.seg.dp, a.queries + (size_t)qi * a.seg.dp);
     for (int dch = 0; dch < uni(L.n_dir); dch++) {
         const uint32_t meta = lane_u32(L.dir_meta, dch);
         const bool ok = lane < (int)(meta >> 8);
@@ -1535,7 +1569,7 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
         o[NIDX_STAT_EXPANSIONS] = n_exp;
         o[NIDX_STAT_VISITED] = rr.n_eval;
         o[NIDX_STAT_FLAGS] = flags;
-        o[NIDX_STAT_CYC_CTL] = 0;
+        o[NIDX_STAT_CYC_CTL] = n_ask;     // neighbours whose visited bit and code were asked of memory (the rest were known visited: LDS)
         o[NIDX_STAT_EDGE_HITS] = n_hit;   // expansions whose loads were in flight under the previous admissions
         o[NIDX_STAT_CYC_INS] = (uint32_t)cyc_ins;
         o[NIDX_STAT_CYC_TOTAL] = (uint32_t)(now() - t_start);
@@ -1648,6 +1682,17 @@ static uint32_t rabitq_walk_mode() {
     const int v = atoi(e);
     return v == 0 ? 1u : v == 2 ? 2u : v == 3 ? 3u : 0u;
 }
+// log2 of the pipelined walk's LDS cache of known-visited ids: 9 (512 ids, 2 KiB) by default; NIDX_GPU_RABITQ_SEEN=0: none (every neighbour
+// asks the bitset in HBM), 8 ... 13: that size — measurement.  1 M x 768, k = 10, three batches of 1 024 in flight (scripts/r5_ab.sh rqseen /
+// rqflight): no cache 50.1 k neighbours per query ask memory, 251 k queries/s; 2^9: 22.5 k, 276 k (286 k with six in flight); 2^10: 16.9 k,
+// 258 k; 2^11: 12.3 k, 240 k; 2^12: 9.2 k, 188 k — a launch alone takes the same 6.4 ms with any of them (the walk is bound by its wave's
+// instruction stream), what the sustained rate follows is the number of walks resident per CU (LDS: 8 / 7 / 7 / 6 / 4).
+uint32_t rabitq_seen_log2() {
+    const char *e = getenv("NIDX_GPU_RABITQ_SEEN");
+    if (!e) return 9u;
+    const int v = atoi(e);
+    return v <= 0 ? 0u : v < 8 ? 8u : v > 13 ? 13u : (uint32_t)v;
+}
 // NIDX_GPU_RABITQ_WAVES=2: the two-wave walk (slower on MI355X as measured, kept for the comparison); default: one wave per query
 bool rabitq_two_waves() {
     const char *e = getenv("NIDX_GPU_RABITQ_WAVES");
@@ -1678,7 +1723,12 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
         RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s)
     }
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
-    if (rabitq_pipelined(a.seg.dim / 64u)) { RQ_DISPATCH(launch_hnsw3_nw, a.seg.dim / 64u, a, smem, s) }
+    if (rabitq_pipelined(a.seg.dim / 64u)) {
+        RabitqSearchArgs b = a;
+        b.seen_log2 = rabitq_seen_log2();
+        const size_t smem3 = rq_smem3_bytes(a.seg.dim / 64u, a.k, a.ef, b.seen_log2);
+        RQ_DISPATCH(launch_hnsw3_nw, a.seg.dim / 64u, b, smem3, s)
+    }
     RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
 }
 // `table` (device) holds n_table argument records that agree in dim / dp / k / ef / n_queries (`shape`: one of them, host side)
@@ -1689,7 +1739,10 @@ hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n
         RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
     }
     const size_t smem = rq_smem_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef, true);
-    if (rabitq_pipelined(shape.seg.dim / 64u)) { RQ_DISPATCH(launch_hnsw3_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s) }
+    if (rabitq_pipelined(shape.seg.dim / 64u)) {
+        const size_t smem3 = rq_smem3_bytes(shape.seg.dim / 64u, shape.k, shape.ef, shape.seen_log2);   // (every record of the table: rabitq_seen_log2())
+        RQ_DISPATCH(launch_hnsw3_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem3, s)
+    }
     RQ_DISPATCH(launch_hnsw1_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s)
 }
 

@@ -497,6 +497,7 @@ RabitqSearchArgs VectorIndex::rabitq_hnsw_args(uint32_t s, const float *d_querie
     r.k = k;
     r.ef = std::min<uint32_t>(k * 100u, 2000u);   // last_layer_k = min(k * RERANKING_FACTOR, RERANKING_LIMIT) (hnsw/search.rs:333-340)
     r.min_score = min_score;
+    r.seen_log2 = rabitq_seen_log2();
     r.visited = nullptr;
     r.vis_words = (seg.n + 31u) / 32u;
     r.out_vec = nullptr;

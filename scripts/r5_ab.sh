@@ -27,6 +27,7 @@ PY
 }
 if [ "$PART" = rabitq ] || [ "$PART" = all ]; then
   run rabitq_pipe -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 256
+  run rabitq_no_seen NIDX_GPU_RABITQ_SEEN=0 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
   run rabitq_plain NIDX_GPU_RABITQ_PIPE=0 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
   run rabitq_2w_barrier NIDX_GPU_RABITQ_WAVES=2 -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
 fi
@@ -49,4 +50,24 @@ if [ "$PART" = hybrid ]; then
   run hybrid_prio0 NIDX_GPU_BM25_PRIORITY=0 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
   run hybrid_w5_v13_prio0 NIDX_GPU_BM25_PRIORITY=0 NIDX_BENCH_TUNABLES=min_waves=5 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
   run hybrid_w5_v12_prio0 NIDX_GPU_BM25_PRIORITY=0 NIDX_BENCH_TUNABLES=min_waves=5,vis_log2=12 -- --workload hybrid --steps 2000 --warmup 20 --cpu-queries 0
+fi
+if [ "$PART" = rqbatch ]; then
+  for b in 128 256 512 1024 2048; do
+    run rabitq_b$b -- --workload rabitq --n-vectors 1000000 --batch $b --steps 5 --warmup 1 --cpu-queries 0
+  done
+fi
+if [ "$PART" = bm25slice ]; then
+  for sl in 2048 2560 3072 4096 6144; do
+    run bm25_slice$sl NIDX_GPU_BM25_SLICE=$sl NIDX_BENCH_BM25_SEGMENTS=0 -- --workload bm25 --cpu-queries 0 --steps 200
+  done
+fi
+if [ "$PART" = rqseen ]; then
+  for v in 0 9 10 11 12; do
+    run rabitq_seen$v NIDX_GPU_RABITQ_SEEN=$v -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0
+  done
+fi
+if [ "$PART" = rqflight ]; then
+  for v in 0 9 10; do for f in 4 6; do
+    run rabitq_seen${v}_fl$f NIDX_GPU_RABITQ_SEEN=$v -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0 --batches-in-flight $f
+  done; done
 fi

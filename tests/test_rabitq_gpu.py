@@ -164,12 +164,15 @@ def test_rabitq_brute_force_filters_min_score_ties(orc):
 
 # ---- HNSW, RaBitQ arm ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(3000, 128, 10), (20000, 768, 10), (8000, 256, 1), (8000, 256, 30), (6000, 1024, 5), (9000, 128, 300), (6000, 768, 512)])
-@pytest.mark.parametrize("walk", ["pipelined", "plain", "two_waves"])
+@pytest.mark.parametrize("walk", ["pipelined", "pipelined_no_seen_cache", "plain", "two_waves"])
 def test_rabitq_hnsw_matches_oracle(orc, monkeypatch, n, d, k, walk):
     """The three walk kernels give the same bits: `pipelined` (default: one wave, the predicted next expansion's loads in flight under
-    the admissions, rollback on a mispredict), `plain` (rounds 1-4, NIDX_GPU_RABITQ_PIPE=0), `two_waves` (NIDX_GPU_RABITQ_WAVES=2: a
-    fetcher wave runs the predicted expansion)."""
-    if walk == "plain":
+    the admissions, rollback on a mispredict; neighbours known to be visited — an LDS cache of ids — ask neither the bitset nor their
+    code; NIDX_GPU_RABITQ_SEEN=0 switches that cache off), `plain` (rounds 1-4, NIDX_GPU_RABITQ_PIPE=0), `two_waves`
+    (NIDX_GPU_RABITQ_WAVES=2: a fetcher wave runs the predicted expansion)."""
+    if walk == "pipelined_no_seen_cache":
+        monkeypatch.setenv("NIDX_GPU_RABITQ_SEEN", "0")
+    elif walk == "plain":
         monkeypatch.setenv("NIDX_GPU_RABITQ_PIPE", "0")
     elif walk == "two_waves":
         monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "2")
