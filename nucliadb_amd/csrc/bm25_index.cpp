@@ -448,6 +448,15 @@ int32_t nidx_gpu_bm25_space_usage(const nidx_gpu_bm25_index_t *index, uint64_t *
     return NIDX_OK;
 } NIDX_ABI_CATCH
 
+// Before an exclusive operation rewrites what the scoring kernels read (alive bitsets, fast-field ranks): the batches already submitted
+// finish on the state they were planned against — a reopened searcher is a snapshot (nidx_tantivy/src/index_reader.rs:39-74).  The caller
+// holds idx->rw exclusively, so no submit is between its planning and its launches.
+static int32_t bm25_drain_tickets(Bm25Index *idx) {
+    std::lock_guard<std::mutex> lock(idx->slots_mu);
+    for (auto &s : idx->slots) NIDX_HIP(hipStreamSynchronize(s->cx.stream));
+    return NIDX_OK;
+}
+
 // dense ranks of a fast field (equal values <=> equal ranks, order preserved) to HBM; the kernels order by rank
 static int32_t bm25_upload_fast_field(Bm25Segment &seg, uint32_t field) {
     const std::vector<int64_t> &values = seg.fast_host[field];
@@ -468,6 +477,8 @@ int32_t nidx_gpu_bm25_set_fast_field(nidx_gpu_bm25_index_t *index, uint32_t segm
     if (!idx || segment >= idx->n_segments || field > 1 || !values) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad fast field");
     std::lock_guard<std::mutex> lock(idx->mu);
     std::unique_lock<std::shared_mutex> wlock(idx->rw);
+    NIDX_HIP(hipSetDevice(idx->device));
+    if (int32_t rc_drain = bm25_drain_tickets(idx)) return rc_drain;
     NIDX_HIP(hipSetDevice(idx->device));
     if (!idx->concatenated()) {
         Bm25Segment &seg = idx->segs[segment];
@@ -1623,6 +1634,8 @@ int32_t nidx_gpu_bm25_apply_deletions(nidx_gpu_bm25_index_t *index, uint32_t seg
     if (!idx || segment >= idx->n_segments || (n_terms && !terms)) return fail(NIDX_ERR_INVALID_ARGUMENT, "bad index/segment");
     std::lock_guard<std::mutex> lock(idx->mu);
     std::unique_lock<std::shared_mutex> wlock(idx->rw);
+    NIDX_HIP(hipSetDevice(idx->device));
+    if (int32_t rc_drain = bm25_drain_tickets(idx)) return rc_drain;
     NIDX_HIP(hipSetDevice(idx->device));
     for (uint32_t i = 0; i < n_terms; i++)
         if (terms[i] >= idx->n_terms) return fail(NIDX_ERR_INVALID_ARGUMENT, "deletion term id %u out of range", terms[i]);

@@ -267,3 +267,38 @@ def test_pipeline_takes_several_segments_and_several_submitting_threads(monkeypa
         t.join()
     assert not errors, errors[0]
     sp.close()
+
+
+def test_batches_in_flight_keep_the_searcher_they_were_submitted_to(monkeypatch, docs):
+    """A reopened searcher is a snapshot (open_index_with_deletions, nidx_tantivy/src/index_reader.rs:39-74): batches submitted
+    before nidx_gpu_bm25_apply_deletions answer with the documents alive at submit time, whatever the order in which they are
+    waited for; the next batch sees the deletions."""
+    rng = np.random.default_rng(5)
+    sp = Split(monkeypatch, docs, [5000, 7000])
+    batches = [random_queries(rng, 150, max_terms=4) for _ in range(6)]
+    before = [sp.whole.search_batch(b, 20) for b in batches]
+    seg, terms = 1, [0, 1, 2, 3, 4, 5, 6, 7]   # the most frequent terms: most queries lose hits
+    a, b_ = sp.cuts[seg], sp.cuts[seg + 1]
+    dead = np.zeros(len(docs), bool)
+    for d in range(a, b_):
+        if np.isin(docs[d], terms).any():
+            dead[d] = True
+    whole_dead = Bm25Searcher.open([Bm25Segment.from_term_docs(docs, VOCAB, alive=bitset_of(~dead))])
+    after = [whole_dead.search_batch(b, 20) for b in batches]
+    assert any(not np.array_equal(x[3], y[3]) for x, y in zip(before, after))   # the deletions do change totals
+
+    def same(got, w):
+        d, sc, c, t, p = got
+        assert np.array_equal(c, w[2]) and np.array_equal(t, w[3])
+        for i in range(len(c)):
+            assert np.array_equal(sp.to_whole(d[i, : c[i]]), w[0][i, : c[i]].astype(np.int64))
+            assert np.array_equal(bits(sc[i, : c[i]]), bits(w[1][i, : c[i]]))
+
+    tickets = [sp.parts.submit(b, 20) for b in batches]
+    assert sp.parts.apply_deletions(seg, terms) == int((~dead[a:b_]).sum())
+    later = [sp.parts.submit(b, 20) for b in batches]
+    for i in (3, 0, 5, 1, 4, 2):
+        same(sp.parts.wait(tickets[i]), before[i])
+        same(sp.parts.wait(later[i]), after[i])
+    whole_dead.close()
+    sp.close()
