@@ -46,6 +46,8 @@ rabitq)
   pmc rabitq_1m FETCH_SIZE --workload rabitq --n-vectors 1000000 --steps 3 --warmup 1 --cpu-queries 0 --batches-in-flight 1
   pmc rabitq_1m WRITE_SIZE --workload rabitq --n-vectors 1000000 --steps 3 --warmup 1 --cpu-queries 0 --batches-in-flight 1
   NIDX_GPU_RABITQ_WAVES=2 prof rabitq_1m_two_waves --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0 ;;
+hnsw1m)
+  prof hnsw1m --n-vectors 1000000 --corpus clustered --bf16-block-n 0 --bm25-block 0 --single-query-calls 0 --segment-regime 0 --ref-build-n 0 ;;
 others)
   prof hnsw1m --n-vectors 1000000 --corpus clustered --bf16-block-n 0 --bm25-block 0 --single-query-calls 0 --segment-regime 0 --ref-build-n 0
   prof scan_1m --workload scan --n-vectors 1000000 --steps 3 --warmup 1
