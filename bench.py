@@ -60,6 +60,8 @@ def parse():
                         "x 1024-dim vectors after the headline legs and put the block into the line (0 = skip)")
     p.add_argument("--ref-build-n", type=int, default=50_000,
                    help="recall of the oracle's sequential HnswBuilder vs the device build on a clustered segment of this size (0 = skip)")
+    p.add_argument("--rabitq-segments", type=int, default=5,
+                   help="--workload rabitq: also search the same vectors as this many quantized segments through the one-launch grid (0 / 1 = skip)")
     p.add_argument("--batches-in-flight", type=int, default=3,
                    help="hnsw: consecutive batches are launched on this many streams in turn, so the walk-length tail of one batch (a launch "
                         "lasts as long as its longest walk) overlaps the body of the next; 1 = strictly one launch at a time")
@@ -2208,6 +2210,75 @@ def bench_bm25(a, L, dev, rank, world):
             "roofline": blk["roofline"], "cpu_baseline": blk["cpu_baseline"]}))
 
 
+def rabitq_segments_leg(a, L, xh, qpool, nfl):
+    """The same vectors as `--rabitq-segments` quantized segments (Searcher::_search walks every open segment, searcher.rs:149-199): all
+    segments' RaBitQ walks of a batch in ONE launch (rabitq_hnsw3_segments_kernel) + the entry-mode walks + Fssc, pipelined; checked
+    against a launch per segment (NIDX_GPU_SEGMENT_LAUNCHES)."""
+    from nucliadb_amd import _lib
+
+    n, d, B, k, S = a.n_vectors, a.dim, a.batch, a.k, a.rabitq_segments
+    bounds = [n * i // S for i in range(S + 1)]
+    cfg = _lib.VectorConfigC(d, 0, 0, 0, 0)
+    csegs = (_lib.VectorSegmentC * S)()
+    for s_ in range(S):
+        rows = xh[bounds[s_]:bounds[s_ + 1]]
+        csegs[s_] = _lib.VectorSegmentC(rows.ctypes.data, d * 4, rows.shape[0], None, rows.shape[0], None, 0, 0, None, 0, None, None)
+    h = C.c_void_p()
+    _lib.check(L.nidx_gpu_vector_open(C.byref(cfg), csegs, S, C.byref(h)))
+    t0 = time.time()
+    for s_ in range(S):
+        _lib.check(L.nidx_gpu_vector_build_hnsw(h, s_, 2 + s_))
+        _lib.check(L.nidx_gpu_vector_quantize(h, s_))
+    build_s = time.time() - t0
+    _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl, 4)))
+    p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_RABITQ_HNSW)
+    n_pool = qpool.shape[0]
+    hout = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl)]
+    tick = []
+
+    def wait_oldest():
+        t_, j_ = tick.pop(0)
+        o = hout[j_]
+        _lib.check(L.nidx_gpu_vector_search_wait(h, t_, o[0].ctypes.data, None, o[1].ctypes.data, o[2].ctypes.data, o[3].ctypes.data, None))
+
+    def step(i):
+        if len(tick) == nfl:
+            wait_oldest()
+        t = C.c_uint64(0)
+        _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[i % n_pool].data_ptr(), B, d, C.byref(p), None, C.byref(t)))
+        tick.append((t.value, i % nfl))
+
+    def run(n_steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i)
+        while tick:
+            wait_oldest()
+        return time.perf_counter() - t0
+
+    run(nfl + 1)
+    n_steps = max(a.steps, 3 * nfl)
+    el = run(n_steps)
+    last = [x.copy() for x in hout[(n_steps - 1) % nfl]]
+    os.environ["NIDX_GPU_SEGMENT_LAUNCHES"] = "1"
+    try:
+        run(1)
+        el_per_segment = run(n_steps)
+        other = [x.copy() for x in hout[(n_steps - 1) % nfl]]
+    finally:
+        del os.environ["NIDX_GPU_SEGMENT_LAUNCHES"]
+    L.nidx_gpu_vector_close(h)
+    same = all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(last, other))
+    if not same:
+        FAILURES.append("rabitq segments: one launch for all segments delivered other hits than a launch per segment")
+    return {"segments": S, "records_per_segment": n // S, "queries_per_s": B * n_steps / el, "ms_per_step": el / n_steps * 1e3,
+            "launch_per_segment_queries_per_s": B * n_steps / el_per_segment, "one_launch_equals_a_launch_per_segment": same,
+            "batches_in_flight": nfl, "builds_and_quantize_s": build_s,
+            "entry": "nidx_gpu_vector_search_submit / _wait, METHOD_RABITQ_HNSW: every segment's walks of a batch in one launch (rabitq_hnsw3_segments_kernel), "
+                     "entry-mode walks in one launch (hnsw_search_segments_kernel), Fssc on the device; oracle parity of this path: tests/test_serving_gpu.py"}
+
+
 def bench_rabitq(a, L, dev, rank, world):
     """The RaBitQ arm of a Dot index: 1-bit codes + popcount estimates drive the HNSW walk with
     ef = min(100 k, 2000), the ef neighbours are re-ranked with the raw rows under the error bound, closest_up_nodes
@@ -2381,6 +2452,7 @@ def bench_rabitq(a, L, dev, rank, world):
                          "%d/%d id lists identical to the device's (the timed baseline sums in AVX2 order, the device in WAVE64 order: a near-tie "
                          "of the exact re-rank may flip; the parity tests run the oracle in WAVE64 order and are bit-exact)" % (nq, same, nq)}
     L.nidx_gpu_vector_close(h)
+    seg_leg = rabitq_segments_leg(a, L, xh, qpool, nfl_p) if rank == 0 and a.rabitq_segments > 1 else None
     if rank == 0:
         achieved = alg / (k_ms * 1e-3) / 1e9
         print(json.dumps({
@@ -2395,7 +2467,7 @@ def bench_rabitq(a, L, dev, rank, world):
                        "kernel_flags": flags, "hnsw_build_s": build_s, "quantize_s": quant_s,
                        "pipelined_queries_per_s": world * B * n_pipe / pipe_elapsed, "pipelined_batches_in_flight": nfl_p,
                        "pipelined_frac_of_hbm_peak": alg * n_pipe / pipe_elapsed / 1e9 / HBM_PEAK_GBS,
-                       "pipelined_equals_one_launch_at_a_time": pipe_same,
+                       "pipelined_equals_one_launch_at_a_time": pipe_same, "segments": seg_leg,
                        "walk_kernel": ("rabitq_hnsw2_kernel (two waves per query: the fetcher expands the predicted next candidate while the controller admits)"
                                        if os.environ.get("NIDX_GPU_RABITQ_WAVES") == "2" else "rabitq_hnsw_kernel (one wave per query, rounds 1-4)"
                                        if os.environ.get("NIDX_GPU_RABITQ_PIPE") == "0" else
