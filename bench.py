@@ -1100,6 +1100,23 @@ def single_query_latency(a, L, h, queries):
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     q = np.ascontiguousarray(queries, np.float32)
     out = {}
+
+    def host_cpu():   # (CPU seconds of this process, times the cgroup was throttled by its CPU quota)
+        import resource
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        thr = None
+        try:
+            for line in open("/sys/fs/cgroup/cpu.stat"):
+                if line.startswith("nr_throttled"):
+                    thr = int(line.split()[1])
+        except OSError:
+            pass
+        return ru.ru_utime + ru.ru_stime, thr
+
+    try:
+        out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        out["cgroup_cpu_max"] = None
     for th in (1, 64, 256, 1024):
         n = min(calls, 256) if th == 1 else max(calls, 48 * th)   # dozens of calls per thread: the start of a run is not its steady state
         lat = np.zeros(n, np.float32)
@@ -1108,12 +1125,39 @@ def single_query_latency(a, L, h, queries):
         _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, 2 * th, lat.ctypes.data, C.byref(el)))
         b0, q0 = C.c_uint64(0), C.c_uint64(0)
         L.nidx_gpu_vector_coalescer_stats(h, C.byref(b0), C.byref(q0))
+        c0, t0_ = host_cpu()
         _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), th, n, lat.ctypes.data, C.byref(el)))
+        c1, t1_ = host_cpu()
         b1, q1 = C.c_uint64(0), C.c_uint64(0)
         L.nidx_gpu_vector_coalescer_stats(h, C.byref(b1), C.byref(q1))
         out["threads_%d" % th] = {"calls": n, "p50_ms": float(np.percentile(lat, 50) / 1e3), "p99_ms": float(np.percentile(lat, 99) / 1e3),
                                   "queries_per_s": n / el.value,
-                                  "queries_per_launch": (q1.value - q0.value) / max(1, b1.value - b0.value)}
+                                  "queries_per_launch": (q1.value - q0.value) / max(1, b1.value - b0.value),
+                                  "host_cores_busy": (c1 - c0) / max(el.value, 1e-9),
+                                  "cgroup_throttled_periods": None if t0_ is None or t1_ is None else t1_ - t0_}
+    if os.environ.get("NIDX_BENCH_SQ_DOOR") == "1":   # tuning aid: the admission door (coalesce_max_callers) at 1 024 callers
+        door = []
+        for cap in (256, 512, 1024, 0):
+            _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_max_callers", cap))
+            for inflight in (4, 8):
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_in_flight", inflight))
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(4, inflight)))
+                n = 48 * 1024
+                lat = np.zeros(n, np.float32)
+                el = C.c_double(0)
+                b0, q0 = C.c_uint64(0), C.c_uint64(0)
+                L.nidx_gpu_vector_coalescer_stats(h, C.byref(b0), C.byref(q0))
+                c0, t0_ = host_cpu()
+                _lib.check(L.nidx_gpu_diag_single_query_latency(h, q.ctypes.data, q.shape[0], d, C.byref(p), 1024, n, lat.ctypes.data, C.byref(el)))
+                c1, t1_ = host_cpu()
+                b1, q1 = C.c_uint64(0), C.c_uint64(0)
+                L.nidx_gpu_vector_coalescer_stats(h, C.byref(b1), C.byref(q1))
+                door.append({"max_callers": cap, "in_flight": inflight, "queries_per_s": n / el.value, "p50_ms": float(np.percentile(lat, 50) / 1e3),
+                             "host_cores_busy": (c1 - c0) / max(el.value, 1e-9), "cgroup_throttled_periods": None if t0_ is None or t1_ is None else t1_ - t0_,
+                             "p99_ms": float(np.percentile(lat, 99) / 1e3), "queries_per_launch": (q1.value - q0.value) / max(1, b1.value - b0.value)})
+        out["door_sweep_1024_callers"] = door
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_max_callers", 256))
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"coalesce_in_flight", 4))
     if os.environ.get("NIDX_BENCH_SQ_SWEEP") == "1":   # tuning aid: the coalescer's window / batches in flight at 256 callers
         sweep = []
         for window in (10, 25, 50, 100):
