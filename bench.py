@@ -1089,6 +1089,15 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     return res
 
 
+def cpu_quota_cores():
+    """The container's CFS quota in cores (cgroup v2 cpu.max), or None: os.cpu_count() shows the machine's CPUs, not what this process may use."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def single_query_latency(a, L, h, queries):
     """nidx_gpu_vector_search_one from 1 / 64 / 256 / 1024 native threads (nidx_gpu_diag_single_query_latency: the reference's one
     blocking thread per request, shard_search.rs:139-153), coalesced by csrc/coalescer.cpp into batches that run through the serving
@@ -1246,7 +1255,7 @@ def oracle_legs(a, L, h, x_host, qpool, got0, exact0, kind):
         t0 = time.perf_counter()
         cv, cs, cc, cst = oseg.hnsw_search_batch(qs, k, threads=threads, want_stats=True)
         dt = time.perf_counter() - t0
-        cpu = {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+        cpu = {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port",
                "sample": "%d queries of the timed pool over the same %d x %d %s shard and device-built graph, oracle (C restatement of the "
                          "reference algorithm, AVX2-shaped f32 sums), one query per POSIX thread; flat = ONE segment; descent width ef_upper = %d like the timed device run" % (qs.shape[0], n, d, kind, max(1, a.ef_upper)),
                "distance_evals_per_query": float(cst[:, 0].mean())}
@@ -1379,7 +1388,7 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
     wsg, wsv, wss, wsc = orc.searcher_search_batch(osegs, qs[:wq], k, with_duplicates=True, threads=threads)
     same_w = int(sum(bool(wsc[i] == hc[i] and np.array_equal(wsg[i, : wsc[i]], hsg[i, : wsc[i]]) and np.array_equal(wsv[i, : wsc[i]], hv[i, : wsc[i]]) and
                           np.array_equal(wss[i, : wsc[i]].view(np.uint32), hsc[i, : wsc[i]].view(np.uint32))) for i in range(wq)))
-    out = {"value": nq / dt, "unit": "queries/s", "cores": threads, "segments": S, "records_per_segment": cap,
+    out = {"value": nq / dt, "unit": "queries/s", "cores": threads, "cpu_quota_cores": cpu_quota_cores(), "segments": S, "records_per_segment": cap,
            "device_vs_oracle_wave64": {"queries": wq, "identical_segments_ids_ranks_score_bits": same_w, "status": "ok" if same_w == wq else "MISMATCH",
                                        "oracle_order": "WAVE64", "reference": "nidx_vector/src/searcher.rs:149-199,270-287"},
            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
@@ -2061,7 +2070,7 @@ class Bm25Bench:
             t1 = time.perf_counter()
             od, os_, oc, ot = orc.bm25_search_daat_batch(oidx, queries, k, threads=threads)
             dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": done / dt, "unit": "postings/s", "queries_per_s": nq / dt, "cores": threads, "kind": "port",
+            out["cpu_baseline"] = {"value": done / dt, "unit": "postings/s", "queries_per_s": nq / dt, "cores": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port",
                                    "sample": "%d queries of batch 0 over the same %d-doc index, oracle document-at-a-time BM25 (tantivy-style union of the clause cursors, no block-max pruning), one query per POSIX thread" % (nq, self.n_docs)}
             # bit parity of the same sample: doc ids, ranks, score bits, Count
             ok = 0
@@ -2491,7 +2500,7 @@ def bench_rabitq(a, L, dev, rank, world):
             res = list(ex.map(lambda i: oseg.hnsw_search(qs[i], k), range(nq)))
             dt = time.perf_counter() - t0
         same = int(sum(np.array_equal(res[i][0], got[i][: len(res[i][0])]) for i in range(nq)))
-        cpu = {"value": nq / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+        cpu = {"value": nq / dt, "unit": "queries/s", "cores": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port",
                "sample": "%d queries of the same batch, oracle RaBitQ HNSW over the device-built graph and codes, one query per thread; "
                          "%d/%d id lists identical to the device's (the timed baseline sums in AVX2 order, the device in WAVE64 order: a near-tie "
                          "of the exact re-rank may flip; the parity tests run the oracle in WAVE64 order and are bit-exact)" % (nq, same, nq)}
@@ -2548,7 +2557,7 @@ def cpu_baseline(a, L, h, x_host, q0, q1):
     t0 = time.perf_counter()
     oseg.brute_force_batch(qs, k, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+    return {"value": qs.shape[0] / dt, "unit": "queries/s", "cores": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port",
             "sample": "%d queries of the same batch over the same %d x %d shard, oracle brute force (C restatement of the reference "
                       "algorithm, AVX2-shaped f32 sums), one query per thread" % (qs.shape[0], n, d)}
 
