@@ -1089,6 +1089,20 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     return res
 
 
+def host_cpu():
+    """(CPU seconds of this process so far, periods in which its cgroup was throttled by the CPU quota so far or None)"""
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    thr = None
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                thr = int(line.split()[1])
+    except OSError:
+        pass
+    return ru.ru_utime + ru.ru_stime, thr
+
+
 def cpu_quota_cores():
     """The container's CFS quota in cores (cgroup v2 cpu.max), or None: os.cpu_count() shows the machine's CPUs, not what this process may use."""
     try:
@@ -1109,18 +1123,6 @@ def single_query_latency(a, L, h, queries):
     p = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
     q = np.ascontiguousarray(queries, np.float32)
     out = {}
-
-    def host_cpu():   # (CPU seconds of this process, times the cgroup was throttled by its CPU quota)
-        import resource
-        ru = resource.getrusage(resource.RUSAGE_SELF)
-        thr = None
-        try:
-            for line in open("/sys/fs/cgroup/cpu.stat"):
-                if line.startswith("nr_throttled"):
-                    thr = int(line.split()[1])
-        except OSError:
-            pass
-        return ru.ru_utime + ru.ru_stime, thr
 
     try:
         out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
@@ -2018,7 +2020,11 @@ class Bm25Bench:
         # the device, and every ticket is planned and launched on a context of its own
         depth = int(os.environ.get("NIDX_BENCH_BM25_DEPTH", "2"))
         threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "6")))
+        cpu0, thr0 = host_cpu()
         elapsed, n_steps, postings, post_per_batch = self.timed_pipeline(self.searcher, threads_n, depth)
+        cpu1, thr1 = host_cpu()
+        host_load = {"host_cores_busy": (cpu1 - cpu0) / max(elapsed, 1e-9), "cpu_quota_cores": cpu_quota_cores(),
+                     "cgroup_throttled_periods": None if thr0 is None or thr1 is None else thr1 - thr0}
         one_thread = None
         if threads_n > 1:
             e1, n1, p1, _ = self.timed_pipeline(self.searcher, 1, depth)
@@ -2042,7 +2048,7 @@ class Bm25Bench:
             "corpus_gen_s": self.gen_s, "open_s": self.open_s,
             "note": "value is end to end through the pipelined host-buffer entry points (nidx_gpu_bm25_search_submit / _wait: clauses in, hits out over "
                     "PCIe) from %d submitting thread(s) with %d batches in flight each; the corpus is resident in HBM" % (threads_n, depth),
-            "submitting_threads": threads_n, "batches_in_flight": depth * threads_n, "one_submitting_thread": one_thread,
+            "submitting_threads": threads_n, "batches_in_flight": depth * threads_n, "host_load": host_load, "one_submitting_thread": one_thread,
             "synchronous_entry_ms_per_batch": float(np.mean(sync_ms)),
             "roofline": {"kernel": "bm25 scoring kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
