@@ -71,3 +71,8 @@ if [ "$PART" = rqflight ]; then
     run rabitq_seen${v}_fl$f NIDX_GPU_RABITQ_SEEN=$v -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0 --batches-in-flight $f
   done; done
 fi
+if [ "$PART" = rqlist ]; then
+  for v in 8 9 10; do for f in 3 6; do
+    run rabitq_seen${v}_fl$f NIDX_GPU_RABITQ_SEEN=$v -- --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 --cpu-queries 0 --batches-in-flight $f --rabitq-segments 0
+  done; done
+fi
