@@ -255,6 +255,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
     NIDX_HIP(hipSetDevice(device));
 
     SearchSlot *slot = nullptr;
+    bool crowded = false;
     {
         std::unique_lock<std::mutex> lk(P.mu);
         for (;;) {
@@ -284,7 +285,14 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         slot->busy = true;
         slot->waiting = false;
         slot->ticket = P.next_ticket++;
+        // other batches still on the device?  (their launches + this one's oversubscribe the workgroup slots: VectorIndex::crowded_launch)
+        for (auto &s : P.slots)
+            if (s.get() != slot && s->busy && s->launched && hipEventQuery(s->done) == hipErrorNotReady) crowded = true;
     }
+    struct CrowdedScope {
+        explicit CrowdedScope(bool on) { VectorIndex::set_crowded_launch(on); }
+        ~CrowdedScope() { VectorIndex::set_crowded_launch(false); }
+    } crowded_scope(crowded);
     SlotRelease release{P, slot};
     SearchSlot &sl = *slot;
     sl.nq = nq;
@@ -405,7 +413,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 if (method == NIDX_METHOD_HNSW && one_launch) {
                     // its walks join the one grid below
                     h_hnsw[n_hnsw++] = hnsw_args((uint32_t)s, sl.dq, nq, walks, k, p.min_score, p.with_duplicates != 0, sl.d_seg_filter[s], d_vec, d_score,
-                                                 d_count, nullptr, default_vis_log2, blk + s);
+                                                 d_count, nullptr, vis_for(walks), blk + s);
                     continue;
                 }
                 if (method == NIDX_METHOD_RABITQ_HNSW && rq_one_launch && seg.has_quant) {
@@ -418,7 +426,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 }
                 scan_matching_hint = matching;
                 const int32_t rc = segment_search_device((uint32_t)s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, method, sl.d_seg_filter[s],
-                                                         d_vec, d_score, d_count, nullptr, default_vis_log2, sl.stream, blk + s);
+                                                         d_vec, d_score, d_count, nullptr, vis_for(nq), sl.stream, blk + s);
                 scan_matching_hint = ~0ull;
                 if (rc != NIDX_OK) return rc;
             }
@@ -436,7 +444,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                         scan_matching_hint = filt ? popcount_filter(s, filt) : segs[s].alive_count;
                         const int32_t rc = segment_search_device(s, sl.dq, nq, k, p.min_score, p.with_duplicates != 0, NIDX_METHOD_BRUTE_FORCE, sl.d_seg_filter[s],
                                                                  d_vec, reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2, nullptr,
-                                                                 default_vis_log2, sl.stream, blk + s);
+                                                                 vis_for(nq), sl.stream, blk + s);
                         scan_matching_hint = ~0ull;
                         if (rc != NIDX_OK) return rc;
                     }
@@ -495,7 +503,7 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                     // closest_up_nodes from the re-ranked entry points, on the raw query (search.rs:369-375): an entry-mode record of the grid
                     uint32_t *d_vec = blk + fw + mw + (size_t)s * sw;
                     HnswSearchArgs ha = hnsw_args(s, sl.dq, nq, walks, k, p.min_score, p.with_duplicates != 0, sl.d_seg_filter[s], d_vec,
-                                                  reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2, nullptr, default_vis_log2, blk + s);
+                                                  reinterpret_cast<float *>(d_vec + (size_t)nq * k), d_vec + (size_t)nq * k * 2, nullptr, vis_for(walks), blk + s);
                     ha.entry_vec = e_vec, ha.entry_score = e_score, ha.entry_count = e_count;
                     h_hnsw[n_hnsw++] = ha;
                 }

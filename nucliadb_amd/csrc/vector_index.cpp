@@ -860,7 +860,10 @@ double trace_slow_us() {
 }
 namespace {
 thread_local double t_launch_us = 0, t_sync_us = 0;
+thread_local bool t_crowded_launch = false;
 }  // namespace
+bool VectorIndex::crowded_launch() { return t_crowded_launch; }
+void VectorIndex::set_crowded_launch(bool on) { t_crowded_launch = on; }
 
 int32_t VectorIndex::segment_search_exact(uint32_t s, const float *d_queries, uint32_t nq, uint32_t k, float min_score,
                                           bool with_duplicates, int method, const uint64_t *d_filter, uint32_t *d_out_block,
@@ -1288,7 +1291,7 @@ int32_t nidx_gpu_vector_open(const nidx_gpu_vector_config_t *config, const nidx_
     if (const char *e = getenv("NIDX_GPU_WAVES_PER_QUERY")) idx->waves_per_query = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("NIDX_GPU_EVAL_ROWS")) { idx->eval_rows = std::max(2, std::min(4, atoi(e))); idx->shape_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_MIN_WAVES")) { idx->min_waves = atoi(e) >= 4 ? std::min(6, atoi(e)) : 2; idx->shape_pinned = true; }
-    if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
+    if (const char *e = getenv("NIDX_GPU_VIS_LOG2")) { idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e))); idx->vis_pinned = true; }
     if (const char *e = getenv("NIDX_GPU_BUILD_VIS_LOG2")) {
         idx->build_vis_log2 = (uint32_t)std::max(10, std::min(15, atoi(e)));
         idx->build_vis_pinned = true;
@@ -1322,7 +1325,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
     else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
     else if (n == "min_waves") { idx->min_waves = value >= 4 ? std::min(6, (int)value) : 2; idx->shape_pinned = true; }
-    else if (n == "vis_log2") idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value));
+    else if (n == "vis_log2") { idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value)); idx->vis_pinned = true; }
     else if (n == "coalesce_window_us") idx->coalescer_config(value, -1, -1);
     else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value, -1);
     else if (n == "coalesce_in_flight") idx->coalescer_config(-1, -1, value);
