@@ -1570,7 +1570,7 @@ def bench_hnsw(a, L, dev, rank, world):
                      "traffic": head["traffic"], "traffic_source": head["traffic_src"],
                      "algorithmic_bytes_per_launch": head["alg_bytes"], "kernel_ms": head["alone_ms"],
                      "note": "one launch at a time (a launch lasts as long as its longest walk); the timed region keeps %d batches in flight, and a batch "
-                             "that finds others on the device is launched as hnsw_search_kernel<3,4,5,1> with a 2^12 visited table (five workgroups per CU "
+                             "that finds others on the device is launched as hnsw_search_kernel<3,2,5,1> with a 2^12 visited table (five workgroups per CU "
                              "instead of four; same hits): DESIGN.md 4.1" % head["nfl"],
                      "sustained": {"achieved": head["alg_bytes"] * head["steps_timed"] / head["elapsed"] / 1e9,
                                    "frac": head["alg_bytes"] * head["steps_timed"] / head["elapsed"] / 1e9 / HBM_PEAK_GBS,

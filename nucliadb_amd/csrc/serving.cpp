@@ -286,8 +286,10 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
         slot->waiting = false;
         slot->ticket = P.next_ticket++;
         // other batches still on the device?  (their launches + this one's oversubscribe the workgroup slots: VectorIndex::crowded_launch)
-        for (auto &s : P.slots)
-            if (s.get() != slot && s->busy && s->launched && hipEventQuery(s->done) == hipErrorNotReady) crowded = true;
+        // (asked only for the batches whose shape depends on it: small batches take the latency shape whatever else runs)
+        if (nq > 256)
+            for (auto &s : P.slots)
+                if (!crowded && s.get() != slot && s->busy && s->launched && hipEventQuery(s->done) == hipErrorNotReady) crowded = true;
     }
     struct CrowdedScope {
         explicit CrowdedScope(bool on) { VectorIndex::set_crowded_launch(on); }
