@@ -724,6 +724,11 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
 
     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl, 4)))
     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_walks", nfl))
+    # the exchange path overlaps its searches on streams of its own (nidx_gpu_vector_segment_search_device): the library cannot see them, so
+    # the bench says what the pipeline would have found out by itself (tunable "launch_shape"); back to automatic afterwards
+    crowded_by_hand = do_exchange and len(streams) > 1 and not os.environ.get("NIDX_BENCH_TUNABLES")
+    if crowded_by_hand:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"launch_shape", 1))
     for i in range(a.warmup):
         step(i)
     drain()
@@ -784,6 +789,8 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     # (N = 1); the device-entry launches of the exchange path leave the word for the poll below
     timed_flags = device_flags() if do_exchange else 0
     timed_retried = retried_total[0]
+    if crowded_by_hand:
+        _lib.check(L.nidx_gpu_vector_set_tunable(h, b"launch_shape", 0))
     exchange_check = None
     if do_exchange and a.steps > 0:
         # the overlapped pipeline must give what a plain search -> exchange of the same batch gives — and the library's RCCL
@@ -871,7 +878,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             "corpus": kind, "elapsed": elapsed, "kernel_ms": kernel_ms, "alone_ms": alone_ms, "nfl": nfl, "alg_bytes": alg_bytes, "achieved": achieved,
             "traffic": traffic, "traffic_src": traffic_src, "recall": recall, "recall_hist": recall_hist, "evals": float(np.mean(evals_q)),
             "expansions": float(np.mean(exp_q)), "edge_hits": float(np.mean(hits_q)), "flags": flags, "timed_flags": timed_flags, "gen_s": gen_s, "open_s": open_s,
-            "build_s": build_s, "exchange_check": exchange_check, "library_exchange": comm is not None, "exchange_transport": (None if comm is None else "shm" if same_device else "rccl"), "build": build_blk, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
+            "build_s": build_s, "exchange_check": exchange_check, "library_exchange": comm is not None, "exchange_transport": (None if comm is None else "shm" if same_device else "rccl"), "launch_shape_set_by_bench": crowded_by_hand, "build": build_blk, "steps_timed": steps_timed, "repeats": repeats, "timed_retried": timed_retried,
         }
     if not headline:
         L.nidx_gpu_vector_close(h)

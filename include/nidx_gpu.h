@@ -136,7 +136,11 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
  * "coalesce_window_us" / "coalesce_max_batch" / "coalesce_in_flight", the serving pipeline's "pipeline_depth" and "stage_threads" (0..16,
  * default 3, process-wide; NIDX_GPU_STAGE_THREADS: helper threads that share the copy of a batch's host query rows into pinned staging
  * with the submitting thread — 3 MiB per 1 024 x 768 batch, which one thread alone copies no faster than the device answers).  The
- * kernel knobs are also read at open from the environment as NIDX_GPU_<NAME>.
+ * kernel knobs are also read at open from the environment as NIDX_GPU_<NAME>.  "launch_shape": 0 (default) = a batch of more than 256
+ * queries submitted through the pipeline while other batches are still on the device takes the shape that holds five walks per CU instead
+ * of four (<= 96 VGPRs, 2^12-slot visited table: each walk a little slower, more of them resident), a batch that finds the device idle the
+ * faster walk; 1 = every large batch takes the crowded shape (for a caller that overlaps batches on streams of its own through
+ * nidx_gpu_vector_segment_search_device, which cannot see them); 2 = none does.  Setting "min_waves" / "eval_rows" / "vis_log2" pins a shape.
  * One knob DOES change results: "ef_search" (0 = the reference's constant EF_SEARCH = 30, hnsw/params.rs:46; up to 512): the
  * layer-0 search keeps max(k, ef_search) candidates.  The reference reaches its recall at 10 M vectors by searching 50 segments
  * of <= 200 k records each at ef = 30 (searcher.rs:270-287); a flat graph over the same vectors matches that recall at a larger

@@ -1325,6 +1325,7 @@ int32_t nidx_gpu_vector_set_tunable(nidx_gpu_vector_index_t *index, const char *
     if (n == "waves_per_query") idx->waves_per_query = std::max(1, std::min(4, (int)value));
     else if (n == "eval_rows") { idx->eval_rows = std::max(2, std::min(4, (int)value)); idx->shape_pinned = true; }
     else if (n == "min_waves") { idx->min_waves = value >= 4 ? std::min(6, (int)value) : 2; idx->shape_pinned = true; }
+    else if (n == "launch_shape") idx->launch_shape = (int)std::max<int64_t>(0, std::min<int64_t>(2, (int64_t)value));
     else if (n == "vis_log2") { idx->default_vis_log2 = (uint32_t)std::max(10, std::min(15, (int)value)); idx->vis_pinned = true; }
     else if (n == "coalesce_window_us") idx->coalescer_config(value, -1, -1);
     else if (n == "coalesce_max_batch") idx->coalescer_config(-1, value, -1);
@@ -1654,7 +1655,7 @@ int32_t nidx_gpu_vector_segment_search_device(nidx_gpu_vector_index_t *index, ui
     if (rc != NIDX_OK) return rc;
     return idx->segment_search_device(segment, d_queries, n_queries, params->k, params->min_score,
                                       params->with_duplicates != 0, method, d_filter, d_out_vector, d_out_score,
-                                      d_out_count, d_stats, idx->default_vis_log2, (hipStream_t)stream, idx->flag_word.as<uint32_t>());
+                                      d_out_count, d_stats, idx->vis_for(n_queries), (hipStream_t)stream, idx->flag_word.as<uint32_t>());
 } NIDX_ABI_CATCH
 
 int32_t nidx_gpu_vector_device_flags(nidx_gpu_vector_index_t *index, void *stream, uint32_t *flags_out) try {

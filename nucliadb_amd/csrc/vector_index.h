@@ -91,7 +91,7 @@ struct VectorIndex {
     // latency-bound, not occupancy-bound — four rows in flight per wave and the 256-VGPR budget measured 10-11 % faster there
     // (batch 1: 0.48 -> 0.43 ms, batch 64: 0.65 -> 0.57 ms at 1 M x 768); large batches keep 2 rows / 128 VGPRs (16 waves per CU)
     int rows_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 4 : eval_rows; }
-    int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : (!shape_pinned && crowded_launch()) ? 5 : min_waves; }
+    int waves_for(uint32_t nq) const { return (!shape_pinned && nq <= 256) ? 2 : (!shape_pinned && crowded_now()) ? 5 : min_waves; }
     // A large batch submitted while other batches are still on the device (serving.cpp sets this for the submitting thread): together
     // they oversubscribe the CUs' workgroup slots, and what counts then is how many walks a CU holds, not how fast one walk runs —
     // <= 96 VGPRs and a 2^12 visited table (16 KiB of LDS less) make it FIVE workgroups per CU instead of four.  Measured, 10 M x 768,
@@ -100,8 +100,12 @@ struct VectorIndex {
     // fills up flags its query, which is then re-run with the larger one as ever.
     static bool crowded_launch();
     static void set_crowded_launch(bool on);
+    // tunable "launch_shape": 0 = as above (the pipeline decides per batch), 1 = every large batch takes the crowded shape, 2 = none does — for
+    // a caller that keeps several batches in flight on streams of its own through nidx_gpu_vector_segment_search_device (which cannot see them)
+    int launch_shape = 0;
+    bool crowded_now() const { return launch_shape == 1 || (launch_shape == 0 && crowded_launch()); }
     bool vis_pinned = false;    // the tunable "vis_log2" / NIDX_GPU_VIS_LOG2 was set
-    uint32_t vis_for(uint32_t nq) const { return (!vis_pinned && !shape_pinned && nq > 256 && crowded_launch()) ? std::min<uint32_t>(default_vis_log2, 12u) : default_vis_log2; }
+    uint32_t vis_for(uint32_t nq) const { return (!vis_pinned && !shape_pinned && nq > 256 && crowded_now()) ? std::min<uint32_t>(default_vis_log2, 12u) : default_vis_log2; }
     uint32_t ef_search = 0;   // 0 = EF_SEARCH (hnsw/params.rs:46); tunable "ef_search"
     uint32_t ef_upper = 0;    // 0 = 1: the greedy descent of hnsw/search.rs:318-324; tunable "ef_upper"
     bool closest_prefetch = true;   // tunable "closest_prefetch" (measurement)

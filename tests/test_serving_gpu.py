@@ -346,6 +346,38 @@ def test_rabitq_segments_share_one_launch(orc, monkeypatch):
         idx.close()
 
 
+def test_launch_shapes_give_the_same_hits(flat):
+    """A large batch submitted while others are on the device takes the shape that holds five walks per CU (<= 96 VGPRs, 2^12-slot
+    visited table); "launch_shape" = 1 forces it for every large batch, 2 forbids it.  Hits are the oracle's in each case, and
+    batches in flight (the automatic choice) equal both."""
+    idx, x, oseg, rng = flat
+    k, B = 10, 600   # > 256 queries: the batch size from which the shape depends on what else runs
+    q = np.ascontiguousarray(np.vstack([x[40][None, :], unit_rows(rng, B - 1, x.shape[1])]))
+    results = {}
+    try:
+        for shape in (2, 1, 0):
+            idx.tunable("launch_shape", shape)
+            tickets = []
+            for _ in range(3):
+                rc, t = idx.submit(q.ctypes.data, B, k, _lib.METHOD_HNSW)
+                assert rc == 0, _lib.last_error()
+                tickets.append(t)
+            got = []
+            for t in tickets:
+                rc, g, _ = idx.wait(t, B, k)
+                assert rc == 0, _lib.last_error()
+                got.append(g)
+            assert same(got[0], got[1]) and same(got[0], got[2]), shape
+            results[shape] = got[0]
+    finally:
+        idx.tunable("launch_shape", 0)
+    assert same(results[0], results[1]) and same(results[0], results[2])
+    for i in range(0, B, 37):
+        ov, os_ = oseg.hnsw_search(q[i], k)
+        assert results[1][4][i] == len(ov) and np.array_equal(results[1][2][i, : len(ov)], ov)
+        assert np.array_equal(results[1][3][i, : len(ov)].view(np.uint32), os_.view(np.uint32))
+
+
 def test_flagged_walks_take_the_exact_fallback_inside_wait(flat):
     """A filter that admits one row in 300 under a forced HNSW search outgrows the on-chip pool: the launch raises its flag word and
     wait() re-runs the segment exactly (n_retried > 0), with the hits of the blocking entry point."""
