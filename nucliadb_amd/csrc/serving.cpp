@@ -169,7 +169,7 @@ struct SearchSlot {
     const float *dq = nullptr;               // the device rows the launches read
     std::vector<int> method;                 // per segment; 0 = not searched (nothing can match)
     std::vector<const uint64_t *> d_seg_filter;
-    bool launched = false;
+    std::atomic<bool> launched{false};   // (read by other submitters: are there batches on the device?)
     ~SearchSlot() {
         if (stream) {
             (void)hipStreamSynchronize(stream);
