@@ -40,6 +40,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FAILURES = []          # parity / consistency breaks found on the way: the line is still printed, the exit status is 1
+T_PROCESS_START = time.time()   # the headline line carries the wall-clock time of the whole run (`bench_wall_s`)
 
 
 def parse():
@@ -1587,6 +1588,7 @@ def bench_hnsw(a, L, dev, rank, world):
     }
     if FAILURES:
         line["failures"] = FAILURES
+    line["bench_wall_s"] = time.time() - T_PROCESS_START
     print(json.dumps(line))
 
 
