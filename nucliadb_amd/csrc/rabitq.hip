@@ -1315,8 +1315,10 @@ __global__ __launch_bounds__(128) void rabitq_hnsw2_segments_kernel(const Rabitq
 // neighbour}); when its layer-0 edge record is already in registers (the records of the three best candidates are requested one
 // expansion ahead: read-only, 84 % of the expansions find theirs), the codes of its neighbours and their visited test-and-set are ISSUED
 // — and only then the admission rule is replayed for the current expansion's neighbours (LDS and scalar work, ~3 000 cycles): the
-// loads land meanwhile.  The pop verifies the prediction; a mismatch (exactly tied scores, the ties side list) clears exactly the bits
-// the speculative test-and-set set (nobody else writes this query's bitset) and expands the popped node the plain way.  Upper layers
+// loads land meanwhile.  The pop verifies the prediction; a mismatch clears exactly the bits the speculative test-and-set set (nobody else
+// writes this query's bitset) and expands the popped node the plain way — a safety net: only nodes that were candidates one expansion ago
+// have their record in registers, and when such a node outranks every neighbour about to be admitted, the admissions can neither put
+// anything in front of it nor evict it (tests/test_rabitq_walk_model_cpu.py models this walk against the plain one, ties included).  Upper layers
 // (a handful of expansions, an LDS hash without removal) run the plain loop.  Results are the plain kernel's bit for bit.
 template <int NW>
 __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32_t qi, unsigned char *smem) {
