@@ -1274,10 +1274,31 @@ static inline int bm_obetter(bm_ohit_t a, bm_ohit_t b, int desc) {
     return a.docaddr < b.docaddr;
 }
 
-int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
-                       size_t k, const orc_search_after *after, uint32_t segment_ord,
-                       const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
-                       uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out) {
+/* The statistics Bm25Weight is built from (tantivy Bm25Weight::for_terms over a Bm25StatisticsProvider): for a Searcher they are
+ * SEARCHER-wide — total_num_docs = the sum of the segments' max_doc, total_num_tokens = the sum over the segments' inverted
+ * indexes, doc_freq(term) = the sum of the segments' doc_freq — and every segment is then scored with the same weight and the
+ * same fieldnorm cache (nidx_tantivy/src/index_reader.rs:39-74 opens all segments under one searcher; nidx_text/src/reader.rs:433-435
+ * and nidx_paragraph/src/reader.rs:290-292,330-332 call searcher.search once).  st == NULL: the segment is the whole index. */
+typedef struct {
+    const orc_bm25_index *segs;
+    size_t n_segs;
+    uint64_t total_docs;
+    float avg_fieldnorm;
+} bm25_stats;
+
+static uint64_t st_doc_freq(const bm25_stats *st, const orc_bm25_index *idx, uint32_t term) {
+    if (!st) return idx->term_offsets[term + 1] - idx->term_offsets[term];
+    uint64_t df = 0;
+    for (size_t s = 0; s < st->n_segs; s++)
+        if (term < st->segs[s].n_terms) df += st->segs[s].term_offsets[term + 1] - st->segs[s].term_offsets[term];
+    return df;
+}
+static uint64_t st_total_docs(const bm25_stats *st, const orc_bm25_index *idx) { return st ? st->total_docs : idx->n_docs; }
+
+static int bm25_segment_search(const orc_bm25_index *idx, const bm25_stats *st, const orc_bm25_clause *clauses, size_t n_clauses,
+                               size_t k, const orc_search_after *after, uint32_t segment_ord,
+                               const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
+                               uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out) {
     uint32_t n = idx->n_docs;
     float *acc = (float *)calloc(n ? n : 1, sizeof(float));
     uint8_t *should_hit = (uint8_t *)calloc(n ? n : 1, 1);
@@ -1287,7 +1308,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
     uint32_t *last_clause = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t)); /* term sets: a doc counts once per clause */
     uint8_t groups_present = 0;   /* required Should groups g = occur - ORC_OCCUR_SHOULD_GROUP (g < 8) that have clauses */
     float cache[256];
-    float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
+    float avg = st ? st->avg_fieldnorm : (idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f);
     orc_bm25_tf_cache(avg, cache);
     size_t n_must = 0, n_should = 0;
     if (match_bits_out) memset(match_bits_out, 0, (size_t)((n + 63) / 64) * 8);
@@ -1303,8 +1324,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
             /* PhraseQuery: walk the first term's postings, look the document up in the others', count the start positions */
             float idf_sum = 0.0f;
             for (size_t t = 0; t < n_lists; t++) {
-                uint64_t b = idx->term_offsets[cl->set_terms[t]], e = idx->term_offsets[cl->set_terms[t] + 1];
-                idf_sum += orc_bm25_idf(e - b, idx->n_docs);
+                idf_sum += orc_bm25_idf(st_doc_freq(st, idx, cl->set_terms[t]), st_total_docs(st, idx));
             }
             float weight = idf_sum * (1.0f + BM25_K1) * cl->boost;
             uint64_t b0 = idx->term_offsets[cl->set_terms[0]], e0 = idx->term_offsets[cl->set_terms[0] + 1];
@@ -1356,7 +1376,7 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
             uint32_t term = is_set ? cl->set_terms[t] : cl->term;
             uint64_t b = idx->term_offsets[term], e = idx->term_offsets[term + 1];
             float weight = 0.0f;
-            if (!is_set && cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(e - b, idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+            if (!is_set && cl->mode != ORC_CONST_SCORE) weight = orc_bm25_idf(st_doc_freq(st, idx, term), st_total_docs(st, idx)) * (1.0f + BM25_K1) * cl->boost;
             for (uint64_t i = b; i < e; i++) {
                 uint32_t d = idx->doc_ids[i];
                 if (is_set) {
@@ -1419,6 +1439,75 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
     if (total_out) *total_out = total;
     free(top); free(acc); free(should_hit); free(must_cnt); free(excluded); free(group_hit); free(last_clause);
     return (int)n_top;
+}
+
+int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                       size_t k, const orc_search_after *after, uint32_t segment_ord,
+                       const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
+                       uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out) {
+    return bm25_segment_search(idx, NULL, clauses, n_clauses, k, after, segment_ord, order_values, order_desc, match_bits_out,
+                               out_docaddr, out_score, out_order_value, total_out);
+}
+
+void orc_bm25_searcher_stats(const orc_bm25_index *segs, size_t n_segs, uint64_t *total_docs, uint64_t *total_tokens, float *avg_fieldnorm) {
+    uint64_t docs = 0, tokens = 0;
+    for (size_t s = 0; s < n_segs; s++) docs += segs[s].n_docs, tokens += segs[s].total_num_tokens;
+    if (total_docs) *total_docs = docs;
+    if (total_tokens) *total_tokens = tokens;
+    if (avg_fieldnorm) *avg_fieldnorm = docs ? (float)tokens / (float)docs : 0.0f;
+}
+
+uint64_t orc_bm25_searcher_doc_freq(const orc_bm25_index *segs, size_t n_segs, uint32_t term) {
+    bm25_stats st = {segs, n_segs, 0, 0.0f};
+    return st_doc_freq(&st, NULL, term);
+}
+
+/* searcher.search(query, (TopDocs, Count[, facets])) over all segments of an index: one weight from the searcher's statistics,
+ * collect_segment per segment (segment_ord = its position), merge_fruits — TopDocs keeps the k best by (score desc, DocAddress
+ * asc) resp. (fast value, DocAddress asc), Count adds up. */
+int orc_bm25_searcher_search_ex(const orc_bm25_index *segs, size_t n_segs, const orc_bm25_clause *clauses, size_t n_clauses,
+                                size_t k, const orc_search_after *after, const int64_t *const *order_values, int order_desc,
+                                uint64_t *const *match_bits_out, uint64_t *out_docaddr, float *out_score,
+                                int64_t *out_order_value, uint64_t *total_out) {
+    bm25_stats st = {segs, n_segs, 0, 0.0f};
+    orc_bm25_searcher_stats(segs, n_segs, &st.total_docs, NULL, &st.avg_fieldnorm);
+    bm_ohit_t *all = (bm_ohit_t *)malloc((n_segs * k + 1) * sizeof(bm_ohit_t));
+    uint64_t *d = (uint64_t *)malloc((k + 1) * sizeof(uint64_t));
+    float *sc = (float *)malloc((k + 1) * sizeof(float));
+    int64_t *ov = (int64_t *)calloc(k + 1, sizeof(int64_t));
+    size_t n_all = 0;
+    uint64_t total = 0;
+    const int by_value = order_values != NULL;
+    for (size_t s = 0; s < n_segs; s++) {
+        uint64_t t = 0;
+        int m = bm25_segment_search(&segs[s], &st, clauses, n_clauses, k, after, (uint32_t)s, by_value ? order_values[s] : NULL, order_desc,
+                                    match_bits_out ? match_bits_out[s] : NULL, d, sc, ov, &t);
+        total += t;
+        for (int i = 0; i < m; i++) { bm_ohit_t h = {sc[i], d[i], ov[i]}; all[n_all++] = h; }
+    }
+    /* merge_fruits: insertion sort by the collector's order (stable input order does not matter: DocAddresses are distinct) */
+    for (size_t i = 1; i < n_all; i++) {
+        bm_ohit_t h = all[i];
+        size_t j = i;
+        while (j > 0) {
+            int bt;
+            if (by_value) bt = bm_obetter(h, all[j - 1], order_desc);
+            else { bm_hit_t a = {h.score, h.docaddr}, b = {all[j - 1].score, all[j - 1].docaddr}; bt = bm_better(a, b); }
+            if (!bt) break;
+            all[j] = all[j - 1];
+            j--;
+        }
+        all[j] = h;
+    }
+    size_t n_out = n_all < k ? n_all : k;
+    for (size_t i = 0; i < n_out; i++) {
+        out_docaddr[i] = all[i].docaddr;
+        out_score[i] = all[i].score;
+        if (out_order_value) out_order_value[i] = all[i].value;
+    }
+    if (total_out) *total_out = total;
+    free(all); free(d); free(sc); free(ov);
+    return (int)n_out;
 }
 
 int orc_bm25_search(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
@@ -1572,11 +1661,11 @@ size_t orc_bm25_prefilter(const orc_bm25_index *idx, const orc_filter_op *ops, s
  * cursors advance together over ascending doc ids and every doc's clause scores are summed in clause
  * order — the same f32 arithmetic as the term-at-a-time loop above, without the dense accumulator.  Used
  * as the CPU baseline of bench.py (a dense 4*n_docs-byte accumulator per query would be a strawman). */
-int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
-                         size_t k, const orc_search_after *after, uint32_t segment_ord,
-                         uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+static int bm25_segment_search_daat(const orc_bm25_index *idx, const bm25_stats *st, const orc_bm25_clause *clauses, size_t n_clauses,
+                                    size_t k, const orc_search_after *after, uint32_t segment_ord,
+                                    uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
     float cache[256];
-    float avg = idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f;
+    float avg = st ? st->avg_fieldnorm : (idx->n_docs ? (float)idx->total_num_tokens / (float)idx->n_docs : 0.0f);
     orc_bm25_tf_cache(avg, cache);
     uint64_t *cur = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
     uint64_t *end = (uint64_t *)malloc((n_clauses ? n_clauses : 1) * sizeof(uint64_t));
@@ -1587,7 +1676,7 @@ int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *claus
         const orc_bm25_clause *cl = &clauses[c];
         cur[c] = idx->term_offsets[cl->term];
         end[c] = idx->term_offsets[cl->term + 1];
-        weight[c] = cl->mode == ORC_CONST_SCORE ? cl->boost : orc_bm25_idf(end[c] - cur[c], idx->n_docs) * (1.0f + BM25_K1) * cl->boost;
+        weight[c] = cl->mode == ORC_CONST_SCORE ? cl->boost : orc_bm25_idf(st_doc_freq(st, idx, cl->term), st_total_docs(st, idx)) * (1.0f + BM25_K1) * cl->boost;
         if (cl->occur == ORC_OCCUR_MUST) n_must++;
         if (cl->occur >= ORC_OCCUR_SHOULD_GROUP) groups_present |= (uint8_t)(1u << (cl->occur - ORC_OCCUR_SHOULD_GROUP));
     }
@@ -1637,6 +1726,41 @@ int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *claus
     if (total_out) *total_out = total;
     free(top); free(cur); free(end); free(weight);
     return (int)n_top;
+}
+
+int orc_bm25_search_daat(const orc_bm25_index *idx, const orc_bm25_clause *clauses, size_t n_clauses,
+                         size_t k, const orc_search_after *after, uint32_t segment_ord,
+                         uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+    return bm25_segment_search_daat(idx, NULL, clauses, n_clauses, k, after, segment_ord, out_docaddr, out_score, total_out);
+}
+
+/* orc_bm25_searcher_search_ex for plain term clauses ordered by score, document at a time per segment (benchmark-scale checks) */
+int orc_bm25_searcher_search_daat(const orc_bm25_index *segs, size_t n_segs, const orc_bm25_clause *clauses, size_t n_clauses,
+                                  size_t k, const orc_search_after *after, uint64_t *out_docaddr, float *out_score, uint64_t *total_out) {
+    bm25_stats st = {segs, n_segs, 0, 0.0f};
+    orc_bm25_searcher_stats(segs, n_segs, &st.total_docs, NULL, &st.avg_fieldnorm);
+    bm_hit_t *all = (bm_hit_t *)malloc((n_segs * k + 1) * sizeof(bm_hit_t));
+    uint64_t *d = (uint64_t *)malloc((k + 1) * sizeof(uint64_t));
+    float *sc = (float *)malloc((k + 1) * sizeof(float));
+    size_t n_all = 0;
+    uint64_t total = 0;
+    for (size_t s = 0; s < n_segs; s++) {
+        uint64_t t = 0;
+        int m = bm25_segment_search_daat(&segs[s], &st, clauses, n_clauses, k, after, (uint32_t)s, d, sc, &t);
+        total += t;
+        for (int i = 0; i < m; i++) { bm_hit_t h = {sc[i], d[i]}; all[n_all++] = h; }
+    }
+    for (size_t i = 1; i < n_all; i++) {
+        bm_hit_t h = all[i];
+        size_t j = i;
+        while (j > 0 && bm_better(h, all[j - 1])) { all[j] = all[j - 1]; j--; }
+        all[j] = h;
+    }
+    size_t n_out = n_all < k ? n_all : k;
+    for (size_t i = 0; i < n_out; i++) { out_docaddr[i] = all[i].docaddr; out_score[i] = all[i].score; }
+    if (total_out) *total_out = total;
+    free(all); free(d); free(sc);
+    return (int)n_out;
 }
 
 /* ------------------------------------------------------------------------------------------

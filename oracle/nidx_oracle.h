@@ -237,6 +237,25 @@ int orc_bm25_search_ex(const orc_bm25_index *idx, const orc_bm25_clause *clauses
                        const int64_t *order_values, int order_desc, uint64_t *match_bits_out,
                        uint64_t *out_docaddr, float *out_score, int64_t *out_order_value, uint64_t *total_out);
 
+/* ---- a searcher over SEVERAL segments of one index (tantivy Searcher::search; nidx_tantivy/src/index_reader.rs:39-74 opens every
+ * segment of the index under one searcher, nidx_text/src/reader.rs:433-435 and nidx_paragraph/src/reader.rs:290-292,330-332 search
+ * it once).  Term ids name the same term in every segment (a term a segment does not hold has an empty list there).
+ * Bm25Weight's statistics are searcher-wide: total_num_docs = sum of max_doc, total_num_tokens = sum over segments,
+ * doc_freq(term) = sum of the segments' doc_freq; every segment is scored with that weight and fieldnorm cache, its own
+ * fieldnorms and alive set; DocAddress = (segment_ord << 32) | doc with segment_ord = the position in `segs`; the
+ * search-after cursor is tested per document against that DocAddress (nidx_paragraph/src/reader.rs:350-390);
+ * merge_fruits keeps the k best by (score desc, DocAddress asc) or (fast value, DocAddress asc); Count adds up.
+ * order_values / match_bits_out: NULL or one pointer per segment. ---- */
+void orc_bm25_searcher_stats(const orc_bm25_index *segs, size_t n_segs, uint64_t *total_docs, uint64_t *total_tokens, float *avg_fieldnorm);
+uint64_t orc_bm25_searcher_doc_freq(const orc_bm25_index *segs, size_t n_segs, uint32_t term);
+int orc_bm25_searcher_search_ex(const orc_bm25_index *segs, size_t n_segs, const orc_bm25_clause *clauses, size_t n_clauses,
+                                size_t k, const orc_search_after *after, const int64_t *const *order_values, int order_desc,
+                                uint64_t *const *match_bits_out, uint64_t *out_docaddr, float *out_score,
+                                int64_t *out_order_value, uint64_t *total_out);
+/* the same for plain term clauses ordered by score, document at a time (no dense accumulator: benchmark-scale checks) */
+int orc_bm25_searcher_search_daat(const orc_bm25_index *segs, size_t n_segs, const orc_bm25_clause *clauses, size_t n_clauses,
+                                  size_t k, const orc_search_after *after, uint64_t *out_docaddr, float *out_score, uint64_t *total_out);
+
 /* Levenshtein automaton of FuzzyTermQuery (levenshtein_automata 0.2.1, nidx/Cargo.lock:2313; restated):
  * distance in unicode scalar values with a transposition of two adjacent characters costing one
  * (`transposition_cost_one = true`, fuzzy_parser.rs:73); prefix = build_prefix_dfa: SOME prefix of `term` is

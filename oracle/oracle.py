@@ -208,6 +208,17 @@ def lib():
     L.orc_fuzzy_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.orc_bm25_search_daat.restype = C.c_int
     L.orc_bm25_search_daat.argtypes = L.orc_bm25_search.argtypes
+    L.orc_bm25_searcher_stats.restype = None
+    L.orc_bm25_searcher_stats.argtypes = [C.POINTER(_Bm25Index), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.orc_bm25_searcher_doc_freq.restype = C.c_uint64
+    L.orc_bm25_searcher_doc_freq.argtypes = [C.POINTER(_Bm25Index), C.c_size_t, C.c_uint32]
+    L.orc_bm25_searcher_search_ex.restype = C.c_int
+    L.orc_bm25_searcher_search_ex.argtypes = [C.POINTER(_Bm25Index), C.c_size_t, C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t,
+                                              C.POINTER(_SearchAfter), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_uint64)]
+    L.orc_bm25_searcher_search_daat.restype = C.c_int
+    L.orc_bm25_searcher_search_daat.argtypes = [C.POINTER(_Bm25Index), C.c_size_t, C.POINTER(_Bm25Clause), C.c_size_t, C.c_size_t,
+                                                C.POINTER(_SearchAfter), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.orc_merge_vector.restype = C.c_size_t
     L.orc_merge_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     L.orc_merge_bm25.restype = C.c_size_t
@@ -788,17 +799,26 @@ def phrase_count_with_slop(pos_lists, slop: int) -> int:
     return len(left)
 
 
-def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
+def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0, stats=None):
     """BooleanQuerys nested inside the BooleanQuery to any depth (tantivy's QueryParser for `a OR (b AND c)`, `NOT (a AND b)`,
     `(a AND b)^2`, `a AND (b OR (c AND "d e"~1))`; nested filtering formulas): clauses = (term, occur, mode, boost) leaves,
     ("sub", occur, boost, [clauses]) nested queries, ("set", occur, boost, [terms], complement) ConstScorer unions and
     ("phrase", occur, boost, [terms], slop) PhraseQuerys.
     Document at a time in f32 like orc_bm25_search: a nested query matches by its own boolean structure, its score is the f32
     sum of its scoring leaves that hold the document (leaf order, from +0), the outer clause adds boost * that score at its
-    position; TopDocs order (score desc by total order, doc asc).  -> (docaddr u64[], score f32[], total)"""
+    position; TopDocs order (score desc by total order, doc asc).  -> (docaddr u64[], score f32[], total)
+    stats = (total_num_docs, average fieldnorm, doc_freq(term)) of the SEARCHER this segment belongs to (Bm25Searcher below);
+    None = the segment is the whole index."""
     f32 = np.float32
     n_docs = int(index.fieldnorm_ids.size)
-    avg = f32(index.total_num_tokens) / f32(n_docs) if n_docs else f32(0)
+    if stats is None:
+        stat_docs = n_docs
+        avg = f32(index.total_num_tokens) / f32(n_docs) if n_docs else f32(0)
+
+        def doc_freq(t):
+            return int(index.term_offsets[t + 1]) - int(index.term_offsets[t])
+    else:
+        stat_docs, avg, doc_freq = stats
     cache = bm25_tf_cache(float(avg))
     K1 = f32(1.2)
 
@@ -807,7 +827,7 @@ def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
         docs = index.doc_ids[b:e]
         if mode == 2:   # ConstScorer(boost)
             return docs, np.full(docs.size, f32(boost), f32)
-        w = f32(bm25_idf(e - b, n_docs)) * (f32(1.0) + K1) * f32(boost)
+        w = f32(bm25_idf(doc_freq(term), stat_docs)) * (f32(1.0) + K1) * f32(boost)
         tf = index.tfs[b:e].astype(f32) if mode == 0 else np.ones(docs.size, f32)
         fn = cache[index.fieldnorm_ids[docs]]
         return docs, (w * (tf / (tf + fn))).astype(f32)
@@ -829,7 +849,7 @@ def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
             common &= set(l)
         idf_sum = f32(0.0)
         for t in terms:   # Bm25Weight::for_terms
-            idf_sum = f32(idf_sum + f32(bm25_idf(int(index.term_offsets[t + 1]) - int(index.term_offsets[t]), n_docs)))
+            idf_sum = f32(idf_sum + f32(bm25_idf(doc_freq(t), stat_docs)))
         w = idf_sum * (f32(1.0) + K1) * f32(boost)
         docs, sc = [], []
         for d in sorted(common):
@@ -895,6 +915,71 @@ def bm25_nested_search(index: "Bm25Index", clauses, k, segment_ord=0):
         return (-b, d)
     top = sorted(res.items(), key=key)[:k]
     return (np.array([(segment_ord << 32) | d for d, _ in top], np.uint64), np.array([s_ for _, s_ in top], np.float32), len(res))
+
+
+class Bm25Searcher:
+    """tantivy's Searcher over the segments of ONE index (nidx_tantivy/src/index_reader.rs:39-74; searched once by
+    nidx_text/src/reader.rs:433-435 and nidx_paragraph/src/reader.rs:290-292,330-332): searcher-wide Bm25Weight statistics,
+    DocAddress = (segment position << 32) | doc, merge_fruits by (score desc, DocAddress asc) / (fast value, DocAddress asc).
+    segments: Bm25Index objects over the same term-id space."""
+
+    def __init__(self, segments):
+        self.segments = list(segments)
+        self._c = (_Bm25Index * max(len(self.segments), 1))(*[s.c() for s in self.segments])
+        docs, tokens, avg = C.c_uint64(), C.c_uint64(), C.c_float()
+        lib().orc_bm25_searcher_stats(self._c, len(self.segments), C.byref(docs), C.byref(tokens), C.byref(avg))
+        self.total_docs, self.total_tokens, self.avg_fieldnorm = docs.value, tokens.value, np.float32(avg.value)
+
+    def doc_freq(self, term: int) -> int:
+        return int(lib().orc_bm25_searcher_doc_freq(self._c, len(self.segments), int(term)))
+
+    def _refresh(self):   # alive sets may have been replaced on the Python objects
+        for i, s in enumerate(self.segments):
+            self._c[i] = s.c()
+
+    def search_ex(self, clauses, k, after=None, order_values=None, order_desc=True, want_match_bits=False, daat=False):
+        """clauses as Bm25Index.search_ex; after = (score, tie_break, docaddr) in the searcher's DocAddresses; order_values = one
+        int64 array per segment.  -> (docaddr, score, order values, total, [match bitset per segment] or None)"""
+        self._refresh()
+        cl, keep = self.segments[0]._clauses(clauses) if self.segments else ((_Bm25Clause * 1)(), [])
+        sa = _SearchAfter()
+        if after is not None:
+            sa.has_after, sa.score, sa.tie_break, sa.docaddr = 1, after[0], after[1], after[2]
+        od, os_, ov = np.empty(max(k, 1), np.uint64), np.empty(max(k, 1), np.float32), np.zeros(max(k, 1), np.int64)
+        total = C.c_uint64()
+        ns = len(self.segments)
+        if daat:
+            assert order_values is None and not want_match_bits
+            n = lib().orc_bm25_searcher_search_daat(self._c, ns, cl, len(clauses), k, C.byref(sa), _ptr(od), _ptr(os_), C.byref(total))
+            return od[:n].copy(), os_[:n].copy(), ov[:n].copy(), total.value, None
+        vals = vptr = None
+        if order_values is not None:
+            vals = [np.ascontiguousarray(v, dtype=np.int64) for v in order_values]
+            vptr = (C.c_void_p * max(ns, 1))(*[v.ctypes.data for v in vals])
+        mbs = mptr = None
+        if want_match_bits:
+            mbs = [np.zeros((s.fieldnorm_ids.size + 63) // 64 + 1, np.uint64) for s in self.segments]
+            mptr = (C.c_void_p * max(ns, 1))(*[m.ctypes.data for m in mbs])
+        n = lib().orc_bm25_searcher_search_ex(self._c, ns, cl, len(clauses), k, C.byref(sa), vptr, int(order_desc), mptr,
+                                              _ptr(od), _ptr(os_), _ptr(ov), C.byref(total))
+        return od[:n].copy(), os_[:n].copy(), ov[:n].copy(), total.value, mbs
+
+    def nested_search(self, clauses, k):
+        """bm25_nested_search per segment under the searcher's statistics, merged like TopDocs::merge_fruits"""
+        stats = (self.total_docs, self.avg_fieldnorm, self.doc_freq)
+        hits, total = [], 0
+        for si, seg in enumerate(self.segments):
+            d, sc, t = bm25_nested_search(seg, clauses, k, segment_ord=si, stats=stats)
+            total += t
+            hits += list(zip(d.tolist(), sc.tolist()))
+
+        def key(item):
+            d, s_ = item
+            b = int(np.float32(s_).view(np.int32))
+            b ^= (b >> 31) & 0x7FFFFFFF
+            return (-b, d)
+        top = sorted(hits, key=key)[:k]
+        return np.array([d for d, _ in top], np.uint64), np.array([s_ for _, s_ in top], np.float32), total
 
 
 def bm25_search_daat_batch(index: "Bm25Index", queries, k, threads=1):

@@ -1,14 +1,17 @@
 """An index of SEVERAL tantivy segments (the log-merge policy leaves several: nidx/src/settings.rs:246-253) is resident as ONE
 term-major posting layout over doc + base[segment] and searched in one launch (csrc/bm25_index.cpp: bm25_upload_concatenated).
 tantivy searches the segments of an index under one searcher.search with searcher-wide Bm25Weight statistics and merges by
-(score, DocAddress) — nidx_text/src/reader.rs:433-435, nidx_paragraph/src/reader.rs:244-348 — so every answer must equal
+(score, DocAddress) — nidx_tantivy/src/index_reader.rs:39-74, nidx_text/src/reader.rs:433-435, nidx_paragraph/src/reader.rs:244-348.
 
-  * the answer of the same corpus opened as one segment (that path is pinned to the oracle by tests/test_bm25_gpu.py and
-    tests/test_bm25_aux_gpu.py) after mapping doc -> (segment, doc - base), and
-  * the answer of round 4's path: one resident segment per opened segment, a launch + transfer per segment and a host merge
-    (NIDX_GPU_BM25_SEGMENT_LOOP=1),
+Every answer of the one-launch path is compared, bit for bit (doc addresses, ranks, score bits, totals, facet counts, order
+values), with
 
-bit for bit: doc addresses, ranks, score bits, totals, facet counts, order values — through every collector of the scorer."""
+  * THE ORACLE'S SEARCHER OVER THE SAME SEGMENTS (oracle.Bm25Searcher / orc_bm25_searcher_search_ex: searcher-wide doc_freq and
+    token totals, per-segment fieldnorms and alive sets, DocAddress = (segment_ord << 32) | doc, the collectors' merge_fruits,
+    cursors with the three tie rules) — the check proper;
+  * the same corpus opened as one segment, after mapping doc -> (segment, doc - base), and round 4's path (one resident segment
+    per opened segment, a launch + transfer per segment and a host merge: NIDX_GPU_BM25_SEGMENT_LOOP=1) — extras that tell a
+    layout bug from a statistics bug when something fails."""
 import ctypes as C
 import threading
 
@@ -72,14 +75,66 @@ class Split:
         for s in (self.whole, self.parts, self.loop):
             s.close()
 
-    def check(self, queries, k, after_whole=None, **kw):
-        """search_batch_ex on the three searchers; `after_whole` are cursors in the whole corpus' numbering"""
+    def oracle_searcher(self, orc, fast_fields=None, dead=None):
+        """oracle.Bm25Searcher over the opened segments; `dead` = documents (whole corpus numbering) deleted after the open"""
+        idx = []
+        for seg, a, b in zip(self.part_segs, self.cuts[:-1], self.cuts[1:]):
+            alive = seg.alive
+            if dead is not None and dead[a:b].any():
+                m = ~dead[a:b]
+                if seg.alive is not None:
+                    m &= np.unpackbits(np.asarray(seg.alive, np.uint64).view(np.uint8), bitorder="little")[: b - a].astype(bool)
+                alive = bitset_of(m)
+            idx.append(orc.Bm25Index(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, alive, seg.pos_offsets, seg.positions))
+        self.orc_fast = fast_fields   # field -> values over the whole corpus
+        return orc.Bm25Searcher(idx)
+
+    def check_oracle(self, osr, rp, queries, k, after_parts=None, order_field=-1, order_desc=True, facets=None):
+        """the one-launch answers `rp` against the oracle's searcher over the same segments"""
+        vals = None
+        if order_field >= 0:
+            v = self.orc_fast[order_field]
+            vals = [v[a:b] for a, b in zip(self.cuts[:-1], self.cuts[1:])]
+        for i, q in enumerate(queries):
+            after = None
+            if after_parts is not None and after_parts[i] is not None:
+                after = (after_parts[i].score, after_parts[i].tie_break, after_parts[i].docaddr)
+            tree = any(c.subquery is not None or (c.term_set is not None and c.phrase and c.slop) for c in q)
+            n = int(rp["count"][i])
+            if tree:   # nested queries / sloppy phrases: the numpy tree evaluator under the searcher's statistics (by score only)
+                assert after is None and vals is None and facets is None
+                wd, ws, wt = osr.nested_search([tree_to_oracle(c) for c in q], k)
+            else:
+                wd, ws, wv, wt, mb = osr.search_ex([flat_to_oracle(c) for c in q], k, after=after, order_values=vals, order_desc=order_desc,
+                                                   want_match_bits=facets is not None)
+                if vals is not None:
+                    assert np.array_equal(rp["order_value"][i, :n], wv), ("oracle order values", i)
+                if facets is not None:
+                    want = []
+                    for t in facets[i]:
+                        cnt = 0
+                        for seg, m, a, b in zip(self.part_segs, mb, self.cuts[:-1], self.cuts[1:]):
+                            match = np.unpackbits(m.view(np.uint8), bitorder="little")[: b - a].astype(bool)
+                            cnt += int(match[seg.doc_ids[int(seg.term_offsets[t]): int(seg.term_offsets[t + 1])]].sum())
+                        want.append(cnt)
+                    assert rp["facet_counts"][i].tolist() == want, ("oracle facets", i)
+            assert rp["total"][i] == wt, ("oracle total", i, rp["total"][i], wt)
+            assert n == len(wd), ("oracle count", i, n, len(wd))
+            assert np.array_equal(rp["docaddr"][i, :n], wd), ("oracle doc addresses", i, rp["docaddr"][i, :n], wd)
+            if vals is None:
+                assert np.array_equal(bits(rp["score"][i, :n]), bits(ws)), ("oracle score bits", i)
+
+    def check(self, queries, k, after_whole=None, osr=None, **kw):
+        """search_batch_ex on the three searchers; `after_whole` are cursors in the whole corpus' numbering; osr = the oracle's
+        searcher over the same segments: the one-launch answers are compared with it first"""
         aw = ap = None
         if after_whole is not None:
             aw = after_whole
             ap = [None if a is None else SearchAfter(a.score, a.tie_break, self.to_parts(a.docaddr)) for a in after_whole]
-        rw = self.whole.search_batch_ex(queries, k, aw, **kw)
         rp = self.parts.search_batch_ex(queries, k, ap, **kw)
+        if osr is not None:
+            self.check_oracle(osr, rp, queries, k, ap, **kw)
+        rw = self.whole.search_batch_ex(queries, k, aw, **kw)
         rl = self.loop.search_batch_ex(queries, k, ap, **kw)
         for name, r in (("one launch", rp), ("loop", rl)):
             assert np.array_equal(r["total"], rw["total"]), name
@@ -97,6 +152,22 @@ class Split:
         return rw, rp
 
 
+def flat_to_oracle(c):
+    if c.term_set is not None:
+        return (c.term, c.occur, c.mode, c.boost, [int(t) for t in c.term_set], bool(c.complement), bool(c.phrase))
+    return (c.term, c.occur, c.mode, c.boost)
+
+
+def tree_to_oracle(c):
+    if c.subquery is not None:
+        return ("sub", c.occur, c.boost, [tree_to_oracle(l) for l in c.subquery])
+    if c.term_set is not None and c.phrase:
+        return ("phrase", c.occur, c.boost, [int(t) for t in c.term_set], c.slop)
+    if c.term_set is not None:
+        return ("set", c.occur, c.boost, [int(t) for t in c.term_set], c.complement)
+    return (c.term, c.occur, c.mode, c.boost)
+
+
 @pytest.fixture(scope="module")
 def docs():
     return zipf_docs(np.random.default_rng(20250925), 9000, VOCAB)
@@ -111,22 +182,23 @@ def random_queries(rng, n, max_terms=6, top=300):
     return out
 
 
-def test_plain_queries_pages_and_cursors(monkeypatch, docs):
+def test_plain_queries_pages_and_cursors(monkeypatch, docs, orc):
     """OR / boolean queries at several page sizes; the log-merge shape (one large segment, some small ones, an EMPTY one); dead
     documents in some segments only; search-after cursors (all three tie rules) that cross segment borders."""
     rng = np.random.default_rng(1)
     alive = rng.random(len(docs)) < 0.8
     alive[:5200] = True   # the first segment has no deletions
     sp = Split(monkeypatch, docs, [5200, 7900, 7900, 8500], alive)
+    osr = sp.oracle_searcher(orc)
     queries = [[Clause(int(t), S, BASIC) for t in rng.integers(0, 40, 3)] for _ in range(40)]   # tf == 1: many exact score ties
     queries += random_queries(rng, 60) + [[], [Clause(0), Clause(1), Clause(2)]]
     for k in (1, 20, 64, 201):
-        sp.check(queries, k)
-    rw, _ = sp.check(queries, 30)
+        sp.check(queries, k, osr=osr)
+    rw, _ = sp.check(queries, 30, osr=osr)
     for rank, ties in ((7, [1] * len(queries)), (3, [0, 1, 2] * len(queries)), (29, [1, 2] * len(queries))):
         after = [SearchAfter(float(rw["score"][i, rank]), int(ties[i]), int(rw["docaddr"][i, rank])) if rw["count"][i] > rank else None
                  for i in range(len(queries))]
-        sp.check(queries, 20, after_whole=after)
+        sp.check(queries, 20, after_whole=after, osr=osr)
     # a cursor that names no document: past the end of a segment, in the empty segment, past the last segment
     q = queries[:6]
     sc = [float(rw["score"][i, 2]) for i in range(6)]
@@ -137,10 +209,11 @@ def test_plain_queries_pages_and_cursors(monkeypatch, docs):
         for name in ("docaddr", "count", "total"):
             assert np.array_equal(rp[name], rl[name]), (hex(addr), name)
         assert np.array_equal(bits(rp["score"]), bits(rl["score"])), hex(addr)
+        sp.check_oracle(osr, rp, q, 20, ap)   # the oracle compares DocAddresses as numbers: no segment needs to hold the cursor's document
     sp.close()
 
 
-def test_collectors_over_segments(monkeypatch, docs):
+def test_collectors_over_segments(monkeypatch, docs, orc):
     """TopDocs ordered by a fast field (ranks are taken over the values of ALL segments), facet counts, term sets and their
     complements, phrases (with slop), nested queries — nidx_text/src/reader.rs:367-451, nidx_paragraph/src/reader.rs:244-348."""
     rng = np.random.default_rng(2)
@@ -153,12 +226,13 @@ def test_collectors_over_segments(monkeypatch, docs):
         for s_ in (sp.parts, sp.loop):
             for i, (a, b) in enumerate(zip(sp.cuts[:-1], sp.cuts[1:])):
                 s_.set_fast_field(i, f, v[a:b])
+    osr = sp.oracle_searcher(orc, fast_fields={0: created, 1: modified})
     queries = random_queries(rng, 40)
     for field in (0, 1):
         for desc in (True, False):
-            sp.check(queries, 25, order_field=field, order_desc=desc)
+            sp.check(queries, 25, order_field=field, order_desc=desc, osr=osr)
     facets = [[int(t) for t in rng.integers(0, 200, int(rng.integers(0, 5)))] for _ in queries]
-    sp.check(queries, 10, facets=facets)
+    sp.check(queries, 10, facets=facets, osr=osr)
     ex = []
     for _ in range(24):
         q = [Clause(int(rng.integers(0, 200)))]
@@ -175,12 +249,14 @@ def test_collectors_over_segments(monkeypatch, docs):
                                                        Clause(int(rng.integers(0, 200)), N)]))
         ex.append(q)
     ex.append([Clause(0, M, CONST, 1.0, term_set=[3], complement=True)])   # only a complement: every live document without term 3
-    sp.check(ex, 20)
+    sp.check(ex, 20, osr=osr)
     sp.check(ex, 20, facets=[[1, 2, 3]] * len(ex))
+    flat = [q for q in ex if not any(c.subquery is not None or (c.phrase and c.slop) for c in q)]   # (facets: the C oracle's match bitsets)
+    sp.check(flat, 20, facets=[[1, 2, 3]] * len(flat), osr=osr)
     sp.close()
 
 
-def test_deletions_and_prefilter_address_one_segment(monkeypatch, docs):
+def test_deletions_and_prefilter_address_one_segment(monkeypatch, docs, orc):
     """nidx_gpu_bm25_apply_deletions(segment, terms) removes the documents of those posting lists IN THAT SEGMENT only
     (open_index_with_deletions applies a deletion key to the segments older than it, nidx_tantivy/src/index_reader.rs:39-74);
     the prefilter's DocAddresses name the opened segments."""
@@ -200,6 +276,9 @@ def test_deletions_and_prefilter_address_one_segment(monkeypatch, docs):
             assert s_.apply_deletions(seg, terms) == want_alive
     whole_dead = Bm25Searcher.open([Bm25Segment.from_term_docs(docs, VOCAB, alive=bitset_of(~dead))])
     rw = whole_dead.search_batch_ex(queries, 20)
+    # deleted documents stay in doc_freq and in the token totals (the statistics are the segments' own): the oracle's searcher
+    # over the same segments with the smaller alive sets
+    sp.check_oracle(sp.oracle_searcher(orc, dead=dead), sp.parts.search_batch_ex(queries, 20), queries, 20)
     for s_ in (sp.parts, sp.loop):
         r = s_.search_batch_ex(queries, 20)
         assert np.array_equal(r["total"], rw["total"]) and np.array_equal(r["count"], rw["count"])
@@ -216,7 +295,7 @@ def test_deletions_and_prefilter_address_one_segment(monkeypatch, docs):
     sp.close()
 
 
-def test_pipeline_takes_several_segments_and_several_submitting_threads(monkeypatch, docs):
+def test_pipeline_takes_several_segments_and_several_submitting_threads(monkeypatch, docs, orc):
     """nidx_gpu_bm25_search_submit / _wait on a multi-segment index go through the asynchronous path (round 4 fell back to the
     blocking loop for anything but one segment), and two threads may submit at once: every slot plans and launches on a context
     of its own."""
@@ -233,8 +312,11 @@ def test_pipeline_takes_several_segments_and_several_submitting_threads(monkeypa
             assert np.array_equal(bits(sc[i, : c[i]]), bits(w[1][i, : c[i]]))
 
     tickets = [sp.parts.submit(b, 20) for b in batches]
+    osr = sp.oracle_searcher(orc)
     for i in (2, 0, 5, 3, 1, 4):
-        same(sp.parts.wait(tickets[i]), want[i])
+        got = sp.parts.wait(tickets[i])
+        same(got, want[i])
+        sp.check_oracle(osr, {"docaddr": got[0], "score": got[1], "count": got[2], "total": got[3]}, batches[i], 20)
     errors = []
 
     def worker(order):
