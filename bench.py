@@ -1989,6 +1989,22 @@ class Bm25Bench:
                 g = base[(da[i, :c] >> np.uint64(32)).astype(np.int64)] + (da[i, :c] & np.uint64(0xFFFFFFFF)).astype(np.int64)
                 same_ids += int(c == int(want[1][i]) and tt[i] == want[2][i] and np.array_equal(g, want[0][i, :c].astype(np.int64)) and
                                 np.array_equal(sc[i, :c].view(np.uint32), want[3][i, :c].view(np.uint32)))
+            # a sample against THE ORACLE'S searcher over the same six segments (searcher-wide statistics, per-segment collectors,
+            # merge_fruits: oracle.Bm25Searcher) — the direct check; the one-segment comparison above is the extra
+            oracle_same = oracle_n = None
+            if self.a.cpu_queries > 0:
+                from oracle import oracle as orc
+
+                orc.build()
+                osr = orc.Bm25Searcher([orc.Bm25Index(p_.term_offsets, p_.doc_ids, p_.tfs, p_.fieldnorm_ids, p_.total_num_tokens) for p_ in parts])
+                oracle_n, oracle_same = min(64, B), 0
+                for i in range(oracle_n):
+                    wd, ws, _, wt, _ = osr.search_ex([(int(t), 0, 0, 1.0) for t in self.terms[0][i]], k, daat=True)
+                    c = int(cn[i])
+                    oracle_same += int(c == len(wd) and int(tt[i]) == wt and np.array_equal(da[i, :c], wd) and
+                                       np.array_equal(sc[i, :c].view(np.uint32), ws.view(np.uint32)))
+                if oracle_same != oracle_n:
+                    FAILURES.append("bm25 multi-segment: %d of %d sampled queries differ from the oracle's multi-segment searcher" % (oracle_n - oracle_same, oracle_n))
             # two rounds of (this index, the one-segment index again as the control: clocks, allocator state and host threads as for the
             # leg) — the submitting Python threads make single one-second figures wander by 10-20 %; the better round of each is kept
             best, one_segment_value = None, 0.0
@@ -2003,6 +2019,7 @@ class Bm25Bench:
                    "queries_per_s": n_steps * B / elapsed, "ms_per_step": elapsed / n_steps * 1e3, "one_segment_value": one_segment_value, "one_segment_value_note": "the one-segment index timed again right after each round of this leg; the better of two rounds for both",
                    "ratio_to_one_segment": postings / elapsed / one_segment_value if one_segment_value else None,
                    "queries_identical_to_the_one_segment_index": same_ids, "queries": B, "split_s": split_s, "open_s": open_s,
+                   "queries_identical_to_the_oracle_searcher": oracle_same, "oracle_sample": oracle_n,
                    "note": "the log-merge policy's shape (nidx/src/settings.rs:246-253); documents, ranks, score bits and totals must equal the "
                            "one-segment index's"}
             if same_ids != B:

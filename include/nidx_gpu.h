@@ -47,10 +47,18 @@ int32_t nidx_gpu_last_error(char *buf, size_t len);
 /* ABI version of this header; bumped on any change of a signature OR of a struct the caller fills (a trailing field counts: the
  * library reads it).  A binding compares nidx_gpu_abi_version() with the NIDX_GPU_ABI_VERSION it was compiled against when it loads
  * the library and refuses a mismatch (nucliadb_amd/_lib.py does; INTEGRATION.md shows the Rust shim's check).
- * 5: nidx_gpu_bm25_search_options_t.phrase_slops, nested-query leaves of any kind (round 4); up to 8 BM25 tickets, several
- *    submitting threads, nidx_gpu_vector_open takes D > 3072 (round 5). */
-#define NIDX_GPU_ABI_VERSION 5
+ * 5: nidx_gpu_bm25_search_options_t.phrase_slops, nested-query leaves of any kind (round 4); up to NIDX_GPU_BM25_MAX_TICKETS BM25
+ *    tickets, several submitting threads, nidx_gpu_vector_open takes D > 3072 (round 5).
+ * 6: nidx_gpu_build_features (round 6). */
+#define NIDX_GPU_ABI_VERSION 6
 int32_t nidx_gpu_abi_version(void);
+/* What this build of the library contains beyond the product paths: NIDX_GPU_FEATURE_RABITQ_EXPERIMENTS = the two-wave RaBitQ walk
+ * and the unrolled instances of the plain one (`make EXPERIMENTS=1`; measurement material, selected by NIDX_GPU_RABITQ_WAVES=2 /
+ * NIDX_GPU_RABITQ_PIPE=0 — without the feature the former is ignored and the latter runs the generic instance). */
+#define NIDX_GPU_FEATURE_RABITQ_EXPERIMENTS 1
+int32_t nidx_gpu_build_features(void);
+/* nidx_gpu_bm25_search_submit: tickets that may be outstanding per index before it returns NIDX_ERR_BUSY */
+#define NIDX_GPU_BM25_MAX_TICKETS 16
 int32_t nidx_gpu_device_count(int32_t *count_out);
 /* Selects the HIP device used by handles opened afterwards on this thread (one process per GPU). */
 int32_t nidx_gpu_set_device(int32_t device);

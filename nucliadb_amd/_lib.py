@@ -193,12 +193,14 @@ class Bm25SearchAfterC(C.Structure):
     _fields_ = [("has_after", C.c_int32), ("score", C.c_float), ("tie_break", C.c_int32), ("docaddr", C.c_uint64)]
 
 
-ABI_VERSION = 5   # include/nidx_gpu.h: NIDX_GPU_ABI_VERSION
+ABI_VERSION = 6   # include/nidx_gpu.h: NIDX_GPU_ABI_VERSION
+FEATURE_RABITQ_EXPERIMENTS = 1   # nidx_gpu_build_features()
 
 # name -> (restype, argtypes); the list every `-m "not gpu"` export test walks.
 SIGNATURES = {
     "nidx_gpu_last_error": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "nidx_gpu_abi_version": (C.c_int32, []),
+    "nidx_gpu_build_features": (C.c_int32, []),
     "nidx_gpu_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "nidx_gpu_set_device": (C.c_int32, [C.c_int32]),
     "nidx_gpu_vector_open": (C.c_int32, [C.POINTER(VectorConfigC), C.POINTER(VectorSegmentC), C.c_uint32, C.POINTER(C.c_void_p)]),

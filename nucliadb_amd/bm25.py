@@ -307,7 +307,7 @@ class Bm25Searcher:
 
     def submit(self, queries: Sequence[Sequence[Clause]], k: int) -> int:
         """nidx_gpu_bm25_search_submit for a batch of plain term clauses -> ticket; the host side of this batch overlaps the kernels of
-        the batches already in flight (at most 8 tickets outstanding; several threads may submit at once)."""
+        the batches already in flight (at most NIDX_GPU_BM25_MAX_TICKETS = 16 tickets outstanding; several threads may submit at once)."""
         B = len(queries)
         offsets = np.zeros(B + 1, dtype=np.uint64)
         flat = []

@@ -1502,7 +1502,7 @@ int32_t nidx_gpu_bm25_search_ex(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm2
 // ---- pipelined form: the host side of batch i + 1 (clause weights, work list, staging) overlaps the kernels of batch i; every slot
 // has a context of its own, so two or more threads may submit at the same time (the planning of a batch costs the submitting thread
 // more than its kernels cost the device) ----------
-#define NIDX_BM25_PIPELINE_DEPTH 16
+#define NIDX_BM25_PIPELINE_DEPTH NIDX_GPU_BM25_MAX_TICKETS   /* include/nidx_gpu.h */
 
 int32_t nidx_gpu_bm25_search_submit(nidx_gpu_bm25_index_t *index, const nidx_gpu_bm25_clause_t *clauses, const uint64_t *clause_offsets,
                                     uint32_t nq, const nidx_gpu_bm25_search_options_t *opt, uint64_t *ticket_out) try {

@@ -289,14 +289,22 @@ struct RabitqSearchArgs {
     uint32_t no_speculation = 0;    // two-wave walk, measurement: 1 = the fetcher never runs ahead of the controller
     unsigned long long *dbg = nullptr;   // two-wave walk, measurement: [16] cycle totals of the two waves (NIDX_GPU_RABITQ_DEBUG)
     uint32_t seen_log2 = 0;         // pipelined walk: log2 words of the LDS cache of known-visited ids, 0 = none (rabitq_seen_log2())
+    // hnsw: [n_queries][tie_stride] — where a walk keeps the evicted candidates that still tie with its worst result once the 64 in
+    // LDS are full (the reference's BinaryHeap is unbounded, hnsw/search.rs:252-299); rabitq_tie_stride(ef) entries per query always
+    // suffice (see RqLayer).  Not initialised by the host.  nullptr: such a walk raises NIDX_FLAG_POOL_INEXACT instead.
+    uint64_t *tie_spill = nullptr;
+    uint32_t tie_stride = 0;
 };
+inline uint32_t rabitq_tie_stride(uint32_t ef) { return (ef + 63u) / 64u * 64u + 64u; }
+bool rabitq_tie_spill_enabled();   // false with NIDX_GPU_RABITQ_TIE_SPILL=0 (tests: shows that a scenario does overflow the 64 ties in LDS)
 hipError_t launch_rabitq_encode(const float *vectors, uint32_t n, uint32_t dp, uint32_t dim, uint8_t *out, hipStream_t s);
 hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, uint32_t dim, RabitqQueryDev *qd,
                                uint64_t *planes, hipStream_t s);
 hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s);
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s);
 // several segments' walks in one launch: `table` (device, n_table records agreeing in shape with `shape`); block b = query b % nq of record b / nq
-bool rabitq_two_waves();   // true with NIDX_GPU_RABITQ_WAVES=2 (the two-wave walk: measured slower, kept for comparison)
+bool rabitq_two_waves();   // true with NIDX_GPU_RABITQ_WAVES=2 in a `make EXPERIMENTS=1` library (the two-wave walk: measured slower, kept for comparison)
+bool rabitq_has_experiments();
 uint32_t rabitq_seen_log2();   // 9; NIDX_GPU_RABITQ_SEEN=0 / 8...13 (measurement)
 hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s);
 

@@ -547,6 +547,14 @@ __global__ __launch_bounds__(64) void rabitq_bf_kernel(RabitqSearchArgs a) {
 // chunk, so every other chunk holds >= 32 keys and the directory never needs more than cap / 32 + 2 <= 64 lanes.
 struct RqLayer {
     uint64_t *res, *ties;
+    // Evicted ties beyond the 64 of `ties`: a per-query region in HBM (RabitqSearchArgs::tie_spill; nullptr = none).  It never needs
+    // more than ef entries: a tie is an entry evicted while its score still EQUALS the worst result's, the result set holds at
+    // most ef entries of one score when it is full, nothing of that score is admitted from then on (`similarity.score > ws.score`),
+    // and every entry of a lower score is stale for good (ws only rises) — so stale entries are dropped when the list is full and
+    // what is left, all of ONE score, fits ef slots.  The region only ever holds entries of one score (it is dropped as a whole when
+    // that score falls below ws).
+    uint64_t *spill;
+    int n_spill, spill_cap;
     uint64_t dir_first;      // lane d: first (best) key of chunk d
     uint32_t dir_meta;       // lane d: physical slot | fill << 8
     uint64_t free_mask;      // physical slots not in use
@@ -562,6 +570,7 @@ struct RqLayer {
         n_dir = 0;
         len = 0;
         n_ties = 0;
+        n_spill = 0;
         dcur = 0;
     }
     __device__ inline uint64_t *chunk(uint32_t phys) const { return res + (size_t)phys * 64; }
@@ -591,12 +600,39 @@ __device__ inline void rq_split(RqLayer &L, int d, int lane) {
     if (L.dcur > d) L.dcur++;
 }
 
+// The wave re-reads spill slots its lanes wrote a few instructions earlier: workgroup-scope accesses keep that coherent through the CU's L1
+__device__ inline uint64_t rq_ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void rq_st64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// The 64-entry list of evicted ties is full.  Entries whose score fell below the worst result's (`ws`) can never be expanded any more
+// (hnsw/search.rs:271-277: popping one ends the search, and nothing above it is left by then): they go.  If all 64 still tie with
+// ws they move to the query's region in HBM, which holds entries of that one score only.
+__device__ inline void rq_ties_make_room(RqLayer &L, float ws, int lane) {
+    const uint64_t t = L.ties[lane];
+    const bool keep = !(rank_key_score(t) < ws);
+    const unsigned long long m = __ballot(keep);
+    const int n_keep = __popcll(m);
+    if (n_keep < RABITQ_TIE_CAP) {
+        const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep) L.ties[at] = t;
+        L.n_ties = n_keep;
+        return;
+    }
+    if (!L.spill) return;
+    if (L.n_spill > 0 && rank_key_score(rq_ld64(L.spill)) < ws) L.n_spill = 0;   // the region's score fell behind: all of it is stale
+    if (L.n_spill + RABITQ_TIE_CAP > L.spill_cap) return;
+    rq_st64(L.spill + L.n_spill + lane, t);
+    L.n_spill += RABITQ_TIE_CAP;
+    L.n_ties = 0;
+}
+
 __device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, int lane, uint32_t &flags) {
     L.worst = uni64(L.worst);
     L.free_mask = uni64(L.free_mask);
     L.n_dir = uni(L.n_dir);
     L.len = uni(L.len);
     L.n_ties = uni(L.n_ties);
+    L.n_spill = uni(L.n_spill);
     L.dcur = uni(L.dcur);
     const uint64_t nk = rq_key(est, addr, 1u);
     if (L.n_dir == 0) {  // first key of the layer
@@ -664,11 +700,12 @@ __device__ inline void rq_admit(RqLayer &L, int kk, float est, uint32_t addr, in
         // the evicted entry is still a candidate only while its score is not below the worst result's
         const float ws = rank_key_score(L.worst);
         if (!(rank_key_score(ev) < ws)) {
+            if (L.n_ties == RABITQ_TIE_CAP) rq_ties_make_room(L, ws, lane);
             if (L.n_ties < RABITQ_TIE_CAP) {
                 if (lane == 0) L.ties[L.n_ties] = ev;
                 L.n_ties++;
             } else {
-                flags |= NIDX_FLAG_POOL_INEXACT;
+                flags |= NIDX_FLAG_POOL_INEXACT;   // (no spill region, or one smaller than ef: not reachable through the library)
             }
         }
     }
@@ -703,10 +740,32 @@ __device__ inline bool rq_pop(RqLayer &L, int lane, uint32_t &node, uint32_t &ne
         }
         L.dcur++;
     }
-    if (L.n_ties == 0) return false;
+    L.n_spill = uni(L.n_spill);
+    if (L.n_ties == 0 && L.n_spill == 0) return false;
     // best of the evicted ties
     uint64_t b = lane < L.n_ties ? L.ties[lane] : 0ull;
     const uint64_t best = wave_max_u64(b);
+    if (L.n_spill > 0) {
+        // ... and of those that were moved to HBM (keys are unique: the address is part of them)
+        uint64_t sb = 0ull;
+        int si = 0;
+        for (int i = lane; i < L.n_spill; i += 64) {
+            const uint64_t v = rq_ld64(L.spill + i);
+            if (v > sb) sb = v, si = i;
+        }
+        const uint64_t sbest = wave_max_u64(sb);
+        if (sbest > best) {
+            const int src = __ffsll((long long)__ballot(sb == sbest)) - 1;
+            const int idx = __shfl(si, src, 64);
+            const uint64_t last = rq_ld64(L.spill + (L.n_spill - 1));
+            if (lane == 0) rq_st64(L.spill + idx, last);
+            L.n_spill--;
+            if (rank_key_score(sbest) < rank_key_score(L.worst)) return false;  // `cs < ws => break` (search.rs:271-277)
+            node = rq_addr(sbest);
+            return true;
+        }
+    }
+    if (L.n_ties == 0) return false;   // (the region only held stale entries below the list's)
     const unsigned long long m = __ballot(b == best);
     const int idx = __ffsll((long long)m) - 1;
     const uint64_t last = L.ties[L.n_ties - 1];
@@ -738,6 +797,8 @@ __device__ inline void rabitq_hnsw1_body(const RabitqSearchArgs &a, const uint32
     RqLayer L;
     L.res = sh.res;
     L.ties = sh.ties;
+    L.spill = a.tie_spill ? a.tie_spill + (size_t)qi * a.tie_stride : nullptr;
+    L.spill_cap = (int)a.tie_stride;
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const int kk = layer == 0 ? (int)a.ef : 1;
         L.init((int)rq_chunks((uint32_t)kk));
@@ -863,6 +924,9 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_segments_kernel(const RabitqSe
     rabitq_hnsw1_body<NW>(table[blockIdx.x / n_queries], blockIdx.x % n_queries, smem);
 }
 
+#define RQ_NONE 0xffffffffu
+
+#ifdef NIDX_RABITQ_EXPERIMENTS   /* make EXPERIMENTS=1: the two-wave walk, measured slower (DESIGN-LOG: RaBitQ, round 5), kept for the comparison */
 // ---- HNSW, RaBitQ arm, TWO waves per query (round 5; NOT the default: see the measurements below) ------------------------------
 // The walk above is a chain of ~1 100 dependent expansions per query, and a lone wave pays every link in full: the edge record and
 // the neighbours' codes are two memory round trips (43 % of the walk's cycles), the admissions ~150 dependent instructions each
@@ -894,7 +958,6 @@ __global__ __launch_bounds__(64) void rabitq_hnsw_segments_kernel(const RabitqSe
 // and the prediction + hand-over add 1.7 k more.  The one-wave kernel therefore stays the default (NIDX_GPU_RABITQ_WAVES=2 selects this
 // one); what would help is fewer meetings per walk — a fetcher that runs several expansions ahead through a queue — which needs the
 // speculation to be exact more than one step ahead (it is not: the best new neighbour of expansion i + 1 is unknown at i).
-#define RQ_NONE 0xffffffffu
 struct RqFetchBuf {      // one expansion, written by the fetcher
     uint32_t node, n, flags, pad;
     uint32_t addr[64];   // the fresh neighbours in edge order
@@ -912,6 +975,7 @@ enum { RQ_STATE_HIT = 0, RQ_STATE_MISS = 1, RQ_STATE_DONE = 2 };
 static size_t rq_smem2_bytes(uint32_t nw, uint32_t dp, uint32_t k, uint32_t ef) {
     return rq_smem_bytes(nw, dp, k, ef, true) + 2 * sizeof(RqFetchBuf) + sizeof(RqCtl);
 }
+#endif  // NIDX_RABITQ_EXPERIMENTS
 
 // the best and (when they sit in the same chunk) second- and third-best unexpanded keys of the result set; 0 = none.  Changes nothing
 // but the hint dcur (chunks before it hold expanded keys only — still true afterwards).
@@ -940,6 +1004,7 @@ __device__ inline void rq_peek3(RqLayer &L, int lane, uint64_t &k1, uint64_t &k2
 // the fetcher's expansion of `node` on `layer` -> out.  n2 / n3 (layer 0, or RQ_NONE): the candidates most likely to be expanded after
 // it — their edge records are requested along with this expansion's loads and kept in a three-record cache (read-only data: nothing to
 // roll back), so that an expansion whose node was foreseen starts at its neighbours' codes: one memory round trip instead of two.
+#ifdef NIDX_RABITQ_EXPERIMENTS
 template <int NW>
 __device__ inline void rq_fetch(const RabitqSearchArgs &a, const RqShared &sh, RqCtl *ctl, RqFetchBuf *out, uint32_t node, uint32_t n2, uint32_t n3,
                                 int layer, uint32_t *gvis, const RabitqQueryDev &qc, uint32_t nw, uint32_t &vis_count, uint32_t &cache_hits, int lane) {
@@ -1090,6 +1155,8 @@ __device__ inline void rabitq_hnsw2_body(const RabitqSearchArgs &a, uint32_t qi,
     RqLayer L;
     L.res = sh.res;
     L.ties = sh.ties;
+    L.spill = a.tie_spill ? a.tie_spill + (size_t)qi * a.tie_stride : nullptr;
+    L.spill_cap = (int)a.tie_stride;
     for (int layer = (int)a.g.ep_layer; layer >= 0; layer--) {
         const int kk = layer == 0 ? (int)a.ef : 1;
         if (w0) {
@@ -1307,6 +1374,7 @@ __global__ __launch_bounds__(128) void rabitq_hnsw2_segments_kernel(const Rabitq
     const RabitqSearchArgs &a = table[blockIdx.x / n_queries];
     rabitq_hnsw2_body<NW>(a, blockIdx.x % n_queries, smem);
 }
+#endif  // NIDX_RABITQ_EXPERIMENTS
 
 // ---- HNSW, RaBitQ arm, ONE wave per query with the next expansion's loads in flight under the admissions (round 5) --------------------
 // What the two-wave walk above was built for — the memory round trip of expansion i + 1 hidden behind the admissions of expansion i —
@@ -1345,6 +1413,8 @@ __device__ inline void rabitq_hnsw3_body(const RabitqSearchArgs &a, const uint32
     RqLayer L;
     L.res = sh.res;
     L.ties = sh.ties;
+    L.spill = a.tie_spill ? a.tie_spill + (size_t)qi * a.tie_stride : nullptr;
+    L.spill_cap = (int)a.tie_stride;
     // ---- upper layers: the plain loop (k = 1) ----
     for (int layer = (int)a.g.ep_layer; layer >= 1; layer--) {
         L.init((int)rq_chunks(1u));
@@ -1633,6 +1703,7 @@ hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s) {
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, 0, false);
     RQ_DISPATCH(launch_bf_nw, a.seg.dim / 64u, a, smem, s)
 }
+#ifdef NIDX_RABITQ_EXPERIMENTS
 template <int NW>
 static hipError_t launch_hnsw2_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1648,6 +1719,7 @@ static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32
     hipLaunchKernelGGL(rabitq_hnsw2_segments_kernel<NW>, dim3(n_table * nq), dim3(128), smem, s, table, nq);
     return hipGetLastError();
 }
+#endif
 template <int NW>
 static hipError_t launch_hnsw1_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1678,7 +1750,7 @@ static bool rabitq_pipelined(uint32_t nw) {
 }
 // measurement switches of the two-wave walk -> RabitqSearchArgs::no_speculation: NIDX_GPU_RABITQ_SPEC=0: no speculation (bit 0);
 // =2: the waves meet through polled LDS words instead of s_barrier (bit 1); =3: both
-static uint32_t rabitq_walk_mode() {
+[[maybe_unused]] static uint32_t rabitq_walk_mode() {
     const char *e = getenv("NIDX_GPU_RABITQ_SPEC");
     if (!e) return 0u;
     const int v = atoi(e);
@@ -1697,11 +1769,34 @@ uint32_t rabitq_seen_log2() {
 }
 // NIDX_GPU_RABITQ_WAVES=2: the two-wave walk (slower on MI355X as measured, kept for the comparison); default: one wave per query
 bool rabitq_two_waves() {
+#ifdef NIDX_RABITQ_EXPERIMENTS
     const char *e = getenv("NIDX_GPU_RABITQ_WAVES");
     return e && atoi(e) == 2;
+#else
+    return false;   // (the two-wave walk is only in a `make EXPERIMENTS=1` library)
+#endif
 }
+bool rabitq_tie_spill_enabled() {
+    const char *e = getenv("NIDX_GPU_RABITQ_TIE_SPILL");
+    return !(e && atoi(e) == 0);
+}
+bool rabitq_has_experiments() {
+#ifdef NIDX_RABITQ_EXPERIMENTS
+    return true;
+#else
+    return false;
+#endif
+}
+// the plain one-wave walk: the product runs it for dimensions whose code fetch is not unrolled (NW = 0: D / 64 read at run time) and under
+// NIDX_GPU_RABITQ_PIPE=0 (parity tests); its unrolled instances are measurement material
+#ifdef NIDX_RABITQ_EXPERIMENTS
+#define RQ_DISPATCH_PLAIN(fn, nw, ...) RQ_DISPATCH(fn, nw, __VA_ARGS__)
+#else
+#define RQ_DISPATCH_PLAIN(fn, nw, ...) return fn<0>(__VA_ARGS__);
+#endif
 hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
+#ifdef NIDX_RABITQ_EXPERIMENTS
     if (rabitq_two_waves()) {
         const size_t smem2 = rq_smem2_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef);
         RabitqSearchArgs b = a;
@@ -1724,6 +1819,7 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
         }
         RQ_DISPATCH(launch_hnsw2_nw, a.seg.dim / 64u, b, smem2, s)
     }
+#endif
     const size_t smem = rq_smem_bytes(a.seg.dim / 64u, a.seg.dp, a.k, a.ef, true);
     if (rabitq_pipelined(a.seg.dim / 64u)) {
         RabitqSearchArgs b = a;
@@ -1731,21 +1827,23 @@ hipError_t launch_rabitq_hnsw(const RabitqSearchArgs &a, hipStream_t s) {
         const size_t smem3 = rq_smem3_bytes(a.seg.dim / 64u, a.k, a.ef, b.seen_log2);
         RQ_DISPATCH(launch_hnsw3_nw, a.seg.dim / 64u, b, smem3, s)
     }
-    RQ_DISPATCH(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
+    RQ_DISPATCH_PLAIN(launch_hnsw_nw, a.seg.dim / 64u, a, smem, s)
 }
 // `table` (device) holds n_table argument records that agree in dim / dp / k / ef / n_queries (`shape`: one of them, host side)
 hipError_t launch_rabitq_hnsw_segments(const RabitqSearchArgs *table, uint32_t n_table, const RabitqSearchArgs &shape, hipStream_t s) {
     if (n_table == 0 || shape.n_queries == 0) return hipSuccess;
+#ifdef NIDX_RABITQ_EXPERIMENTS
     if (rabitq_two_waves()) {
         const size_t smem2 = rq_smem2_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef);
         RQ_DISPATCH(launch_hnsw2_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem2, s)
     }
+#endif
     const size_t smem = rq_smem_bytes(shape.seg.dim / 64u, shape.seg.dp, shape.k, shape.ef, true);
     if (rabitq_pipelined(shape.seg.dim / 64u)) {
         const size_t smem3 = rq_smem3_bytes(shape.seg.dim / 64u, shape.k, shape.ef, shape.seen_log2);   // (every record of the table: rabitq_seen_log2())
         RQ_DISPATCH(launch_hnsw3_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem3, s)
     }
-    RQ_DISPATCH(launch_hnsw1_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s)
+    RQ_DISPATCH_PLAIN(launch_hnsw1_segments_nw, shape.seg.dim / 64u, table, n_table, shape.n_queries, smem, s)
 }
 
 }  // namespace nidx

@@ -156,7 +156,7 @@ struct SearchSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     DevBuf d_queries, d_block, d_filter, d_tables, d_offered;
-    DevBuf d_rq, d_rq_vis, d_rq_entry, d_rq_table;   // RaBitQ segments of a one-launch batch: encoded queries, visited bitsets, entry points, argument table
+    DevBuf d_rq, d_rq_vis, d_rq_ties, d_rq_entry, d_rq_table;   // RaBitQ segments of a one-launch batch: encoded queries, visited bitsets, entry points, argument table
     DevBuf d_bf_partial, d_bf_table;                 // brute-force segments of a one-launch batch: per-block lists, argument tables
     PinBuf pin_in, pin_out, pin_tables, pin_rq_table, pin_bf_table;
     bool dirty = false;                      // work may be queued on `stream` / the flag words may be set: clean before reuse
@@ -484,6 +484,8 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                 for (uint32_t s : rq_segs) vis_words += (segs[s].n + 31u) / 32u;
                 NIDX_HIP(sl.d_rq_vis.reserve((size_t)vis_words * 4 * nq));
                 NIDX_HIP(hipMemsetAsync(sl.d_rq_vis.p, 0, (size_t)vis_words * 4 * nq, sl.stream));
+                const uint32_t tie_stride = rabitq_tie_stride(std::min<uint32_t>(k * 100u, 2000u));   // (rabitq_hnsw_args: ef)
+                NIDX_HIP(sl.d_rq_ties.reserve((size_t)n_rq * nq * tie_stride * 8));
                 const size_t entry_words = (size_t)nq * k * 2 + nq;   // per segment: vectors | scores | counts
                 NIDX_HIP(sl.d_rq_entry.reserve((size_t)n_rq * entry_words * 4));
                 NIDX_HIP(sl.pin_rq_table.reserve((size_t)n_rq * sizeof(RabitqSearchArgs)));
@@ -500,6 +502,8 @@ int32_t VectorIndex::pipeline_submit(const float *queries, uint32_t nq, const ni
                     r.planes = d_planes;
                     r.visited = sl.d_rq_vis.as<uint32_t>() + vis_at * nq;
                     vis_at += r.vis_words;
+                    r.tie_stride = tie_stride;
+                    r.tie_spill = rabitq_tie_spill_enabled() ? sl.d_rq_ties.as<uint64_t>() + (size_t)i * nq * tie_stride : nullptr;
                     r.out_vec = e_vec, r.out_score = e_score, r.out_count = e_count;
                     h_rq[i] = r;
                     // closest_up_nodes from the re-ranked entry points, on the raw query (search.rs:369-375): an entry-mode record of the grid

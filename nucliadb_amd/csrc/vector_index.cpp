@@ -564,6 +564,10 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         const uint32_t slice = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (1ull << 30) / ((uint64_t)r.vis_words * 4)));
         NIDX_HIP(scratch_vis.reserve((size_t)slice * r.vis_words * 4));
         r.visited = scratch_vis.as<uint32_t>();
+        // evicted candidates that still tie with a walk's worst result, beyond the 64 it keeps in LDS (thousands of identical vectors)
+        r.tie_stride = rabitq_tie_stride(r.ef);
+        NIDX_HIP(scratch_ties.reserve((size_t)slice * r.tie_stride * 8));
+        r.tie_spill = rabitq_tie_spill_enabled() ? scratch_ties.as<uint64_t>() : nullptr;
         for (uint32_t q0 = 0; q0 < nq; q0 += slice) {
             const uint32_t cnt = std::min(slice, nq - q0);
             NIDX_HIP(hipMemsetAsync(scratch_vis.p, 0, (size_t)cnt * r.vis_words * 4, st));
@@ -1256,6 +1260,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len) try {
 } NIDX_ABI_CATCH
 
 int32_t nidx_gpu_abi_version(void) { return NIDX_GPU_ABI_VERSION; }
+int32_t nidx_gpu_build_features(void) { return nidx::rabitq_has_experiments() ? NIDX_GPU_FEATURE_RABITQ_EXPERIMENTS : 0; }
 
 int32_t nidx_gpu_device_count(int32_t *count_out) try {
     if (!count_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "count_out is NULL");

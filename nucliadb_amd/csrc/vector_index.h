@@ -118,7 +118,7 @@ struct VectorIndex {
     uint64_t last_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nidx_gpu_vector_build_stats
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_multi_vec, scratch_multi_score, scratch_multi_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,
-        scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_entry_vec, scratch_entry_score, scratch_entry_count,
+        scratch_stats, scratch_rq, scratch_planes, scratch_vis, scratch_ties, scratch_entry_vec, scratch_entry_score, scratch_entry_count,
         scratch_dump_vec, scratch_dump_score, scratch_dump_count, scratch_spill_pool, scratch_spill_cmax, scratch_spill_vis, scratch_spill_ids, scratch_rowmask, scratch_floor, scratch_floor2, scratch_bf16_flags, scratch_bf16_counts;
     uint64_t scan_matching_hint = ~0ull;  // paragraphs passing the current filter when the caller knows (search_host), ~0 = unknown
     uint64_t spill_queries = 0;  // queries re-run by the exact fallback since open (tunable "spill_queries" reads it)

@@ -28,8 +28,8 @@ def test_exports_every_declared_symbol(L):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/nidx_gpu.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.nidx_gpu_abi_version() == 5 == _lib.ABI_VERSION
-    assert "#define NIDX_GPU_ABI_VERSION 5" in open(os.path.join(ROOT, "include", "nidx_gpu.h")).read()
+    assert L.nidx_gpu_abi_version() == 6 == _lib.ABI_VERSION
+    assert "#define NIDX_GPU_ABI_VERSION 6" in open(os.path.join(ROOT, "include", "nidx_gpu.h")).read()
 
 
 def test_no_cpu_fallback_when_device_missing(L):

@@ -175,6 +175,8 @@ def test_rabitq_hnsw_matches_oracle(orc, monkeypatch, n, d, k, walk):
     elif walk == "plain":
         monkeypatch.setenv("NIDX_GPU_RABITQ_PIPE", "0")
     elif walk == "two_waves":
+        if not _lib.lib().nidx_gpu_build_features() & _lib.FEATURE_RABITQ_EXPERIMENTS:
+            pytest.skip("the two-wave walk is measurement material: only in a `make EXPERIMENTS=1` library")
         monkeypatch.setenv("NIDX_GPU_RABITQ_WAVES", "2")
     rng = np.random.default_rng(n * 7 + d + k)
     x = clustered(rng, n, d, clusters=60, spread=0.3)
@@ -241,3 +243,50 @@ def test_auto_routes_like_the_reference_and_recall(orc):
         assert off.search(q[:2], k, _lib.METHOD_AUTO)[3] == _lib.METHOD_HNSW
     finally:
         off.close()
+
+
+def spill_count(idx):
+    n = C.c_uint64()
+    _lib.check(_lib.lib().nidx_gpu_vector_spill_stats(idx.h, C.byref(n)))
+    return n.value
+
+
+def test_thousands_of_identical_vectors_more_evicted_ties_than_the_lds_list_holds(orc, monkeypatch):
+    """The reference's candidate heap is an unbounded BinaryHeap (hnsw/search.rs:252-299): an entry evicted from the result set
+    stays a candidate while its score still EQUALS the worst result's (`cs < ws` does not stop on it).  The walk keeps 64 such
+    entries in LDS; NucliaDB corpora hold many identical vectors (the reference carries RepCounter for them, search.rs:386-412),
+    and groups of hundreds of identical vectors at the bottom of a full result set produce more.  They go to a per-query region in
+    HBM (ef entries always suffice: csrc/rabitq.hip RqLayer) — the answer stays the oracle's bit for bit, without the exact
+    fallback.  NIDX_GPU_RABITQ_TIE_SPILL=0 takes the region away: the same queries then raise NIDX_FLAG_POOL_INEXACT (counted by
+    nidx_gpu_vector_spill_stats), which shows that this corpus does overflow the list."""
+    rng = np.random.default_rng(64)
+    d, groups, copies, k = 128, 36, 220, 10
+    base = unit_rows(rng, groups, d)
+    x = np.vstack([np.repeat(base, copies, axis=0), unit_rows(rng, 1500, d)]).astype(np.float32)
+    x = x[rng.permutation(x.shape[0])]
+    n = x.shape[0]
+    nq = 16
+    q = np.vstack([base[rng.integers(groups)] * np.float32(0.6) + unit_rows(rng, 1, d)[0] * np.float32(0.8) for _ in range(nq)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = q.astype(np.float32)
+    idx = Index(x)
+    try:
+        graph, edges = idx.build()
+        quant = idx.quantize()
+        before = spill_count(idx)
+        got = idx.search(q, k, _lib.METHOD_RABITQ_HNSW)[:3]
+        assert spill_count(idx) == before   # no query needed the fallback
+        got_nd = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, min_score=0.05, with_duplicates=False)[:3]
+        monkeypatch.setenv("NIDX_GPU_RABITQ_TIE_SPILL", "0")
+        before = spill_count(idx)
+        idx.search(q, k, _lib.METHOD_RABITQ_HNSW)
+        overflowed = spill_count(idx) - before
+        monkeypatch.delenv("NIDX_GPU_RABITQ_TIE_SPILL")
+    finally:
+        idx.close()
+    assert overflowed > 0, "the corpus does not overflow the 64-entry tie list: the test is vacuous"
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT, graph=orc.Hnsw.deserialize_v2(graph, edges), quantized=quant)
+    alive = orc.bitset(n, fill=True)
+    for i in range(nq):
+        same_hits(got, oseg.hnsw_search(q[i], k), i)
+        same_hits(got_nd, oseg.hnsw_search(q[i], k, min_score=0.05, with_duplicates=False, filter_bits=alive), i)
