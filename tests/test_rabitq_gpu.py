@@ -251,42 +251,74 @@ def spill_count(idx):
     return n.value
 
 
-def test_thousands_of_identical_vectors_more_evicted_ties_than_the_lds_list_holds(orc, monkeypatch):
+@pytest.mark.parametrize("k", [1, 3])
+def test_more_evicted_ties_than_the_lds_list_holds(orc, monkeypatch, k):
     """The reference's candidate heap is an unbounded BinaryHeap (hnsw/search.rs:252-299): an entry evicted from the result set
-    stays a candidate while its score still EQUALS the worst result's (`cs < ws` does not stop on it).  The walk keeps 64 such
-    entries in LDS; NucliaDB corpora hold many identical vectors (the reference carries RepCounter for them, search.rs:386-412),
-    and groups of hundreds of identical vectors at the bottom of a full result set produce more.  They go to a per-query region in
-    HBM (ef entries always suffice: csrc/rabitq.hip RqLayer) — the answer stays the oracle's bit for bit, without the exact
-    fallback.  NIDX_GPU_RABITQ_TIE_SPILL=0 takes the region away: the same queries then raise NIDX_FLAG_POOL_INEXACT (counted by
-    nidx_gpu_vector_spill_stats), which shows that this corpus does overflow the list."""
-    rng = np.random.default_rng(64)
-    d, groups, copies, k = 128, 36, 220, 10
-    base = unit_rows(rng, groups, d)
-    x = np.vstack([np.repeat(base, copies, axis=0), unit_rows(rng, 1500, d)]).astype(np.float32)
-    x = x[rng.permutation(x.shape[0])]
+    stays a candidate while its score still EQUALS the worst result's (`cs < ws` does not stop on it, search.rs:271-277).  The walk
+    keeps 64 such entries in LDS; identical vectors are common in NucliaDB corpora (the reference carries RepCounter for them,
+    search.rs:386-412), and a group of hundreds of identical vectors at the bottom of a full result set produces more.  They go to
+    a per-query region in HBM (ef entries always suffice: csrc/rabitq.hip RqLayer) — the answer is the oracle's bit for bit,
+    without the exact fallback.
+
+    The graph is made by hand so that the walk (ef = 100 k) depends on the LATE ties: the result set fills with identical copies
+    A_1 .. A_ef (equal estimates; among equal scores the lower address ranks first), 70 better nodes H then evict A_ef .. A_(ef-69)
+    one by one — all still tie with the worst result — and only the six evicted last (the 65th .. 70th tie) have an edge to z,
+    the true nearest neighbour.  NIDX_GPU_RABITQ_TIE_SPILL=0 takes the HBM region away: those queries then raise
+    NIDX_FLAG_POOL_INEXACT (counted by nidx_gpu_vector_spill_stats), which shows that the scenario does overflow the list."""
+    rng = np.random.default_rng(64 + k)
+    d, ef = 768, 100 * k
+    m = -(-(ef - 60 + 8) // 58)                  # fill expansions: A_1 .. A_m reveal 58 more copies each
+    n_a = 60 + 58 * m
+    q0 = unit_rows(rng, 1, d)[0]
+
+    def with_dot(t):                              # a unit vector with <q0, v> = t
+        r = unit_rows(rng, 1, d)[0]
+        r -= np.float32(r @ q0) * q0
+        r /= np.linalg.norm(r)
+        return (np.float32(t) * q0 + np.float32(np.sqrt(1.0 - t * t)) * r).astype(np.float32)
+
+    E, A0, H0, Z = 0, 1, 1 + n_a, 1 + n_a + 70    # addresses: e | A_1 .. A_n_a | H_1 .. H_70 | z
+    a_vec = with_dot(0.25)
+    x = np.vstack([with_dot(-0.3)[None], np.repeat(a_vec[None], n_a, axis=0), np.vstack([with_dot(0.55 + 0.002 * j) for j in range(70)]),
+                   with_dot(0.97)[None]]).astype(np.float32)
     n = x.shape[0]
-    nq = 16
-    q = np.vstack([base[rng.integers(groups)] * np.float32(0.6) + unit_rows(rng, 1, d)[0] * np.float32(0.8) for _ in range(nq)])
+    A = lambda i: A0 + i - 1                      # noqa: E731 — A_i, 1-based
+    edges = {v: [] for v in range(n)}
+    edges[E] = [A(i) for i in range(1, 61)]
+    for i in range(1, m + 1):
+        edges[A(i)] = [A(j) for j in range(60 + 58 * (i - 1) + 1, 60 + 58 * i + 1)]
+    edges[A(m + 1)] = [H0 + j for j in range(60)]
+    edges[A(m + 2)] = [H0 + j for j in range(60, 70)]
+    for i in range(m + 3, n_a + 1):
+        edges[A(i)] = [A(1), A(2)]                # nothing new
+    for i in range(ef - 69, ef - 63):             # the six copies evicted last
+        edges[A(i)] = [A(1), Z]
+    assert m + 2 < ef - 69
+    g = orc.Hnsw.new()
+    for v in range(n):
+        g.add_node(v, 0)
+    for v, e_ in edges.items():
+        g.set_edges(0, v, e_, [float(x[v] @ x[t]) for t in e_])
+    g.set_entry_point(E, 0)
+    graph, gedges = g.serialize_v2(n)
+    q = np.vstack([q0, q0 + unit_rows(rng, 1, d)[0] * np.float32(0.02), q0 + unit_rows(rng, 1, d)[0] * np.float32(0.02)]).astype(np.float32)
     q /= np.linalg.norm(q, axis=1, keepdims=True)
-    q = q.astype(np.float32)
-    idx = Index(x)
+    nq = q.shape[0]
+    idx = Index(x, graph=bytes(graph))
     try:
-        graph, edges = idx.build()
         quant = idx.quantize()
         before = spill_count(idx)
         got = idx.search(q, k, _lib.METHOD_RABITQ_HNSW)[:3]
-        assert spill_count(idx) == before   # no query needed the fallback
-        got_nd = idx.search(q, k, _lib.METHOD_RABITQ_HNSW, min_score=0.05, with_duplicates=False)[:3]
+        assert spill_count(idx) == before         # no query needed the fallback
         monkeypatch.setenv("NIDX_GPU_RABITQ_TIE_SPILL", "0")
-        before = spill_count(idx)
         idx.search(q, k, _lib.METHOD_RABITQ_HNSW)
         overflowed = spill_count(idx) - before
         monkeypatch.delenv("NIDX_GPU_RABITQ_TIE_SPILL")
     finally:
         idx.close()
-    assert overflowed > 0, "the corpus does not overflow the 64-entry tie list: the test is vacuous"
-    oseg = orc.Segment(x, similarity=orc.SIM_DOT, graph=orc.Hnsw.deserialize_v2(graph, edges), quantized=quant)
-    alive = orc.bitset(n, fill=True)
+    oseg = orc.Segment(x, similarity=orc.SIM_DOT, graph=orc.Hnsw.deserialize_v2(graph, gedges), quantized=quant)
     for i in range(nq):
-        same_hits(got, oseg.hnsw_search(q[i], k), i)
-        same_hits(got_nd, oseg.hnsw_search(q[i], k, min_score=0.05, with_duplicates=False, filter_bits=alive), i)
+        want = oseg.hnsw_search(q[i], k)
+        assert want[0][0] == Z, "the hand-made scenario does not lead the oracle to z: estimates out of the designed order?"
+        same_hits(got, want, i)
+    assert overflowed == nq, "the scenario does not overflow the 64-entry tie list: the test is vacuous"
