@@ -22,6 +22,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -1766,6 +1767,26 @@ def zipf_corpus_on_device(L, dev, n_docs, vocab, rank):
     return term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens
 
 
+_HOST_DRIVER = []
+
+
+def native_host_driver():
+    """bench_native/libnidx_bench_host.so (built by __graft_entry__.build()): the caller's submit / wait loops in native threads.
+    NIDX_BENCH_PYTHON_THREADS=1 keeps the Python threads of rounds 4-5 (comparison).  -> CDLL or None"""
+    if os.environ.get("NIDX_BENCH_PYTHON_THREADS") == "1":
+        return None
+    if not _HOST_DRIVER:
+        path = os.path.join(ROOT, "bench_native", "libnidx_bench_host.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "bench_native"), "-s"])
+        d = C.CDLL(path)
+        d.nidx_bench_bm25_pipeline.restype = C.c_int32
+        d.nidx_bench_bm25_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.c_uint64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_void_p, C.c_uint64]
+        _HOST_DRIVER.append(d)
+    return _HOST_DRIVER[0]
+
+
 def rrf_batch(vec_ids, vec_cnt, bm_ids, bm_cnt, k_out, k_rrf=60.0):
     """ReciprocalRankFusion (nucliadb rank_fusion.py:106-181) for a whole batch with numpy: both lists arrive ranked;
     score(d) = sum 1 / (k + rank); returns the k_out best fused ids per query."""
@@ -1872,6 +1893,21 @@ class Bm25Bench:
         zero64 = np.zeros(1, np.uint64)
         opt.term_set_offsets = opt.phrase_offsets = opt.subquery_offsets = zero64.ctypes.data
         handle = searcher._handle
+        drv = native_host_driver()
+        if drv is not None:
+            # the submitting threads are native (bench_native/host_driver.cpp: a client of include/nidx_gpu.h like the reference's Rust
+            # host, one blocking thread per request — shard_search.rs:139-153): six Python threads spent ~30 us per batch in the
+            # interpreter lock, more than a batch's kernels take
+            ptrs = (C.c_void_p * len(self.prepared))(*[C.addressof(p_) for p_ in self.prepared])
+            cap = 1 << 16
+            per = np.zeros(cap, np.float64)
+            el, nb, po = C.c_double(), C.c_uint64(), C.c_double()
+            rc = drv.nidx_bench_bm25_pipeline(C.cast(L.nidx_gpu_bm25_search_submit, C.c_void_p), C.cast(L.nidx_gpu_bm25_search_wait, C.c_void_p), handle, ptrs,
+                                              len(self.prepared), self.offsets.ctypes.data, B, C.byref(opt), n_threads, depth, int(a.steps), float(min_s),
+                                              C.byref(el), C.byref(nb), C.byref(po), per.ctypes.data, cap)
+            _lib.check(rc)
+            n = int(min(nb.value, cap))
+            return el.value, int(nb.value), float(po.value), per[:n].tolist()
         results = [None] * n_threads
         start = threading.Barrier(n_threads + 1)
         stop_at = [0.0]
@@ -2046,8 +2082,11 @@ class Bm25Bench:
         # (the reference serves every request on a thread of its own, shard_search.rs:176-248) with `depth` batches in flight each —
         # the host side of a batch (clause weights, work list, staging, ~8 runtime calls) costs its thread more than the kernels cost
         # the device, and every ticket is planned and launched on a context of its own
-        depth = int(os.environ.get("NIDX_BENCH_BM25_DEPTH", "2"))
-        threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "6")))
+        # twelve native submitting threads with one ticket each (the library allows sixteen tickets): measured round 6 on the bench batch,
+        # 6 x 2: 198 G postings/s, 8 x 2: 207, 10 x 1: 213, 12 x 1: 220, 14 x 1: 214 — what a thread pays per batch (~60 us of planning and
+        # runtime calls in submit, ~25 us in wait, the wake-up of a blocking synchronise) is what the extra threads hide
+        depth = int(os.environ.get("NIDX_BENCH_BM25_DEPTH", "1"))
+        threads_n = max(1, int(os.environ.get("NIDX_BENCH_BM25_THREADS", "12")))
         cpu0, thr0 = host_cpu()
         elapsed, n_steps, postings, post_per_batch = self.timed_pipeline(self.searcher, threads_n, depth)
         cpu1, thr1 = host_cpu()
@@ -2076,6 +2115,8 @@ class Bm25Bench:
             "corpus_gen_s": self.gen_s, "open_s": self.open_s,
             "note": "value is end to end through the pipelined host-buffer entry points (nidx_gpu_bm25_search_submit / _wait: clauses in, hits out over "
                     "PCIe) from %d submitting thread(s) with %d batches in flight each; the corpus is resident in HBM" % (threads_n, depth),
+            "submitting_threads_are": "Python threads (NIDX_BENCH_PYTHON_THREADS=1)" if native_host_driver() is None else
+                                      "native threads of bench_native/host_driver.cpp (a client of include/nidx_gpu.h, like the reference's Rust host)",
             "submitting_threads": threads_n, "batches_in_flight": depth * threads_n, "host_load": host_load, "one_submitting_thread": one_thread,
             "synchronous_entry_ms_per_batch": float(np.mean(sync_ms)),
             "roofline": {"kernel": "bm25 scoring kernel (+ bm25_merge_kernel)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -413,10 +413,13 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
         idx->idf_of_term[t] = bm25_idf(df, idx->total_docs);
     }
     float avg = idx->total_docs ? (float)idx->total_tokens / (float)idx->total_docs : 0.0f;
-    float cache[256];
+    // [0, 256): K1 * (1 - B + B * fieldnorm / avg) per fieldnorm id; [256 t, 256 t + 256), t = 1 .. 3: the quotient tf / (tf + that) for
+    // tf = t — the same two correctly rounded f32 operations the kernels would make per posting (bm25_stream.hip reads the four rows)
+    float cache[4 * 256];
     for (int id = 0; id < 256; id++) {
         float fieldnorm = (float)fieldnorm_from_id((uint8_t)id);
         cache[id] = kK1 * (1.0f - kB + kB * fieldnorm / avg);
+        for (int t = 1; t <= 3; t++) cache[256 * t + id] = (float)t / ((float)t + cache[id]);
     }
     NIDX_HIP(idx->tf_cache.alloc(sizeof(cache)));
     NIDX_HIP(hipMemcpy(idx->tf_cache.p, cache, sizeof(cache), hipMemcpyHostToDevice));
@@ -736,6 +739,14 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                                   uint32_t *out_count, uint64_t *out_total, uint64_t *out_postings) {
     const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     NIDX_HIP(hipSetDevice(idx->device));
+    // other tickets are out: this batch's launches will share the GPU with theirs (the throughput shape of the work list, below)
+    bool crowded = false;
+    if (async_slot) {
+        std::lock_guard<std::mutex> lock(idx->slots_mu);
+        for (auto &sl : idx->slots)
+            if (sl.get() != async_slot && (sl->busy || sl->preparing)) crowded = true;
+    }
+    if (const char *e = getenv("NIDX_GPU_BM25_CROWDED")) crowded = atoi(e) != 0;   // measurement: 0 / 1 pins the shape
     const uint32_t k = opt->k;
     const nidx_gpu_bm25_search_after_t *after = opt->after;
     for (uint32_t q = 0; q < nq; q++) {
@@ -1114,6 +1125,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             NIDX_HIP(cx.s_aux_off.reserve(aux_pairs.size() * 8));
             NIDX_HIP(hipMemcpyAsync(cx.s_aux_off.p, aux_pairs.data(), aux_pairs.size() * 8, hipMemcpyHostToDevice, cx.stream));
         }
+        const double t_seg0 = now_us();
         auto postings_of = [&](const nidx_gpu_bm25_clause_t &cl) -> uint64_t {
             if (cl.term & NIDX_BM25_TERM_SET) return set_counts[cl.term & ~NIDX_BM25_TERM_SET];
             if (cl.term & NIDX_BM25_PHRASE) return set_counts[n_sets + (cl.term & ~NIDX_BM25_PHRASE)];
@@ -1145,7 +1157,18 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         // that still fits the batch into one round (the bench batch: ~1 900 instead of 2 048, its slowest items 7 % shorter); batches
         // too large for one round keep the default.  NIDX_GPU_BM25_SLICE pins it.
         uint64_t slice_now = slice_postings;
-        if (!getenv("NIDX_GPU_BM25_SLICE")) {
+        // Other batches are resident (the pipelined entries know): the launch does not have to fill the GPU alone, and what counts is
+        // the work per posting.  With k = 20 a wave that filters n postings offers ~k ln(n / k) candidates to its list and merges them
+        // 64 at a time — candidates and merges are half of the kernel's vector instructions at ~1 900 postings per item and fall per
+        // posting as the item grows (measured, scripts/r6_bm25_probe.py: long lists 214 -> 248 G postings/s at 4 096).  So a union query is cut
+        // into the FEWEST slices of up to BM25_SLICE_CROWDED postings whose expected number of involved postings — true meetings and the
+        // collisions of the kernel's two bitmaps (bm25_stream.hip: 32 Kibit A, 2 Kibit B) — stays inside the 192-entry list:
+        // a balanced query keeps ~1 900 postings per slice (the bitmaps allow no more), a long list with two short ones gets ~8 000.
+        // A batch alone on the GPU (the blocking entries, the first ticket) keeps the latency shape below.
+        const bool crowded_shape = crowded && !getenv("NIDX_GPU_BM25_SLICE") && !lockstep_union;
+        if (crowded_shape) {
+            slice_now = BM25_SLICE_CROWDED;
+        } else if (!getenv("NIDX_GPU_BM25_SLICE")) {
             const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
             std::vector<uint64_t> &pq = cx.w_postings;
             pq.assign(nq, 0);
@@ -1189,7 +1212,23 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                         if (clauses[c].term == clauses[e].term) repeated += (double)clen[c];
                 // the stream kernel resolves up to 192 involved postings per item without cutting its doc range: enough slices to keep
                 // the expected number (two postings per meeting) around 96
-                const double want = std::ceil((shared + repeated) * 2.0 / 96.0);
+                double want = std::ceil((shared + repeated) * 2.0 / 96.0);
+                if (crowded_shape) {
+                    // involved postings of one of n slices: b = postings that find their bit of A set (short x long and short x short
+                    // collisions, two per true meeting), each sets a bit of B; every short posting then meets B with probability b / 2 048
+                    double l_max = 0.0;
+                    for (uint64_t c = c0; c < c1; c++) l_max = std::max(l_max, (double)clen[c]);
+                    const double s_all = sum - l_max, meet2 = (shared + repeated) * 2.0;
+                    double n = std::max(1.0, (double)slices);
+                    for (int it = 0; it < 24; it++) {
+                        const double ss = s_all / n, ll = l_max / n;
+                        const double b = ss * ll / 32768.0 + ss * ss / 65536.0 + meet2 / n;
+                        if (b * (1.0 + ss / 2048.0) <= 96.0) break;
+                        n = std::ceil(n * 1.25);
+                    }
+                    // (never fewer postings per slice than the latency shape would give: the estimate above is the only reason to cut finer)
+                    want = std::max(want, std::min(n, std::ceil(sum / 1024.0)));
+                }
                 if (union_mode == 2) q_union[q] = 1;
                 else if (shared * 8.0 <= sum && want <= (double)BM25_MAX_SLICES) q_union[q] = 1;
                 if (q_union[q] && !lockstep_union) slices = (uint32_t)std::min<double>(BM25_MAX_SLICES, std::max<double>(slices, want));
@@ -1233,6 +1272,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             }
         }
         t_work += now_us() - t_w0;
+        const double t_up0 = now_us();
         NIDX_HIP(cx.s_key.reserve(nw * kk * 8));
         const size_t if_bytes = ((size_t)(nq + 1) * 4 + 31) & ~(size_t)31;   // 32-byte pieces: the clause table is read with 16-byte scalar loads
         const size_t work_bytes = (nw * sizeof(Bm25Work) + 31) & ~(size_t)31;
@@ -1283,6 +1323,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             NIDX_HIP(cx.s_match_bits.reserve(bytes));
             NIDX_HIP(hipMemsetAsync(cx.s_match_bits.p, 0, bytes, cx.stream));
         }
+        const double t_up1 = now_us();
         Bm25Args a;
         a.work = d_work;
         a.n_docs = seg.n_docs;
@@ -1357,6 +1398,9 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         const uint32_t *h_seg = reinterpret_cast<const uint32_t *>(h_out + o_seg);   // (concatenated layout only)
         if (async_slot && idx->segs.size() == 1 && n_aux == 0 && n_slots == 0 && order_field < 0 && !a.dbg) {
             // pipelined: the collect step runs in nidx_gpu_bm25_search_wait (the buffers are the slot's: swapped in by submit)
+            if (host_dbg)
+                fprintf(stderr, "[bm25 host submit] total=%.0f us: clauses=%.0f set-up=%.0f work list=%.0f staging+upload=%.0f launches=%.0f\n", now_us() - t_entry,
+                        t_begin - t_entry, t_seg0 - t_begin, t_work, t_up1 - t_up0, now_us() - t_up1);
             Bm25Slot &sl = *async_slot;
             sl.launched = true;
             sl.nq = nq, sl.k = k, sl.kk = kk;

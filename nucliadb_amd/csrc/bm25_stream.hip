@@ -119,11 +119,16 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         if (lane < (int)(BS_B_WORDS / 4)) reinterpret_cast<uint4 *>(bm_b)[lane] = make_uint4(0u, 0u, 0u, 0u);
     };
     {
+        // (the index keeps the quotient rows behind the division's table, computed once at open: bm25_index.cpp)
+        static_assert(BS_QN <= 3, "the index stores the quotient rows of tf = 1 .. 3");
         const float c = a.tf_cache[threadIdx.x];
+        float qv[BS_QN];
 #pragma unroll
-        for (int t = 0; t < BS_QN; t++) quot[t][threadIdx.x] = (float)(t + 1) / ((float)(t + 1) + c);
-        tf_cache_s[threadIdx.x] = c;
+        for (int t = 0; t < BS_QN; t++) qv[t] = a.tf_cache[256 * (t + 1) + threadIdx.x];
         clear_bitmaps();
+#pragma unroll
+        for (int t = 0; t < BS_QN; t++) quot[t][threadIdx.x] = qv[t];
+        tf_cache_s[threadIdx.x] = c;
     }
     __syncthreads();   // the only workgroup barrier
     const uint32_t slot_in_grid = blockIdx.x * 4u + (uint32_t)wave;

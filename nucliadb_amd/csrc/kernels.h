@@ -373,6 +373,7 @@ struct Bm25UClause {
 };
 #define BM25_ITEM_THREADS 64      /* threads per work item (64 = one wave: no block barriers) */
 #define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
+#define BM25_SLICE_CROWDED 8192   /* ... of a union query when other batches are resident (bm25_index.cpp: crowded_shape) */
 #define BM25_MAX_SLICES 256
 struct Bm25Args {
     const Bm25Work *work;
@@ -382,7 +383,7 @@ struct Bm25Args {
     const uint32_t *tfs;              // posting words: tf | fieldnorm id << 24 (packed at open)
     const uint8_t *fieldnorm_ids;
     const uint64_t *alive;   // nullptr = all
-    const float *tf_cache;   // [256] K1*(1-B+B*fieldnorm/avg)
+    const float *tf_cache;   // [4][256]: K1*(1-B+B*fieldnorm/avg), then tf / (tf + that) for tf = 1, 2, 3
     const Bm25ClauseDev *clauses;
     const unsigned long long *clause_offsets;
     const Bm25AfterDev *after;  // nullptr or [n_queries]
