@@ -166,10 +166,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # (rank 0 alone runs the CPU-side legs after the timed region — oracle parity, cpu_baseline — while the others wait in the last
+        # barrier: a generous timeout, so that a slow host never turns a measured run into a watchdog abort)
+        from datetime import timedelta
+
         if same_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timedelta(minutes=60))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(minutes=60))
 
     from nucliadb_amd import _lib
 
@@ -933,7 +937,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             tick = []
             # as many batches in flight as the device-resident loop (measured on the 10 M shard, scripts/r5_host.sh: 3 in flight 0.99 of
             # `value`, 4: 0.94, 5: 0.86, 8: 0.75 — also with the library letting only three of them search at once, tunable pipeline_walks)
-            nfl_h = int(os.environ.get("NIDX_BENCH_HOST_IN_FLIGHT", str(nfl)))
+            nfl_h = int(os.environ.get("NIDX_BENCH_HOST_IN_FLIGHT", str(nfl if native_host_driver() is None else 4)))
             _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(nfl_h, 4)))
             host_out_h = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(nfl_h)]
 
@@ -952,22 +956,44 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
                     hv_, hs2_, hc_ = host_out_h[j_]
                     _lib.check(L.nidx_gpu_vector_search_wait(h, t_, None, None, hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data, None))
 
-            for i in range(max(4, a.warmup)):
-                host_step(i)
-            host_drain()
             n_host = max(a.steps, int(steps_timed * 0.5))
-            t1 = time.perf_counter()
-            for i in range(n_host):
-                host_step(i)
-            host_drain()
-            dt_host = time.perf_counter() - t1
+            drv = native_host_driver()
+            # two threads with two tickets each (measured round 6 at 4 M vectors, fraction of the device-resident rate: 1 thread x 3 tickets
+            # 0.86, 2 x 2 0.96, 3 x 2 0.92; a thread with ONE ticket stages its next batch only after its last one has landed: 3 x 1 0.64)
+            host_threads = max(1, int(os.environ.get("NIDX_BENCH_HOST_THREADS", "2")))
+            if drv is not None:
+                # the callers are native threads (bench_native/host_driver.cpp; the reference serves every request on a blocking thread of
+                # its own, shard_search.rs:139-153): the staging copy of one thread's batch (3 MiB into pinned memory) runs beside the
+                # others' waits, which one Python thread could not do — it spent a step's worth of time per batch in staging + glue
+                per_thread = max(1, -(-nfl_h // host_threads))
+                _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", max(per_thread * host_threads, 4)))
+                ptrs = (C.c_void_p * n_pool)(*[q_.ctypes.data for q_ in qhost])
+                el = C.c_double()
+                hv_, hs2_, hc_ = host_out_h[0]
+                _lib.check(drv.nidx_bench_vector_pipeline(C.cast(L.nidx_gpu_vector_search_submit, C.c_void_p), C.cast(L.nidx_gpu_vector_search_wait, C.c_void_p), h,
+                                                          ptrs, n_pool, B, d, C.byref(p_hnsw), host_threads, per_thread, max(4, a.warmup), n_host, C.byref(el),
+                                                          hv_.ctypes.data, hs2_.ctypes.data, hc_.ctypes.data))
+                dt_host = el.value
+                nfl_h = per_thread * host_threads
+            else:
+                host_threads = 1
+                for i in range(max(4, a.warmup)):
+                    host_step(i)
+                host_drain()
+                t1 = time.perf_counter()
+                for i in range(n_host):
+                    host_step(i)
+                host_drain()
+                dt_host = time.perf_counter() - t1
             extra["host_buffer_queries_per_s"] = B * n_host / dt_host
             extra["host_buffer_fraction_of_value"] = (B * n_host / dt_host) / (B * steps_timed / elapsed)
             extra["host_buffer_entry"] = ("nidx_gpu_vector_search_submit / _wait: HOST query rows in (staged through pinned memory by the submitting "
-                                          "thread + the library's helper threads, 3 MiB over PCIe per batch), hits in host arrays out, %d batches in flight, %d timed" % (nfl_h, n_host))
+                                          "thread + the library's helper threads, 3 MiB over PCIe per batch), hits in host arrays out, %d batches in flight "
+                                          "from %d %s submitting thread(s), %d timed" % (nfl_h, host_threads, "Python" if drv is None else "native", n_host))
             if got0 is not None:
-                host_step(0)
-                host_drain()
+                if drv is None:
+                    host_step(0)
+                    host_drain()
                 hv_, hs2_, hc_ = host_out_h[0]
                 same_h = bool(np.array_equal(hc_, got0[2].view(np.uint32)) and np.array_equal(hv_, got0[0].view(np.uint32)) and
                               np.array_equal(hs2_.view(np.uint32), got0[1].view(np.uint32)))
@@ -1565,7 +1591,13 @@ def bench_hnsw(a, L, dev, rank, world):
         "metric": "queries/sec + recall@%d (768-dim cosine k-NN, HNSW M=30 ef=30 ef_upper=%d build_ef_upper=%d, k=%d)" % (
             k, max(1, a.ef_upper), max(1, a.build_ef_upper), k),
         "value": total_q / head["elapsed"],
-        "unit": "queries/s (each against one %d-vector shard; %d shard(s) searched in parallel and merged)" % (n, world),
+        # N > 1: `value` counts a query once per shard it is searched in (the weak-scaling numerator: per-GPU work is fixed); the
+        # end-to-end rate of the %d-vector index — one merged answer per query — is merged_queries_per_s = value / n_gpus
+        "unit": ("queries/s against one %d-vector index" % n) if world == 1 else
+                ("SHARD-queries/s: every query is searched in all %d shards of %d vectors (one per GPU) and counted once per shard; "
+                 "merged answers per second over the %d-vector index = merged_queries_per_s" % (world, n, n * world)),
+        "merged_queries_per_s": B * head["steps_timed"] / head["elapsed"],
+        "corpus_vectors": n * world,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["elapsed"] / head["steps_timed"] * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": cfgd,
@@ -1780,6 +1812,9 @@ def native_host_driver():
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "bench_native"), "-s"])
         d = C.CDLL(path)
+        d.nidx_bench_vector_pipeline.restype = C.c_int32
+        d.nidx_bench_vector_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]
         d.nidx_bench_bm25_pipeline.restype = C.c_int32
         d.nidx_bench_bm25_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                                C.c_uint64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_void_p, C.c_uint64]

@@ -123,4 +123,75 @@ int32_t nidx_bench_bm25_pipeline(bm25_submit_fn submit_fn, bm25_wait_fn wait_fn,
     return rc.load();
 }
 
+// The same loop around nidx_gpu_vector_search_submit / _wait with HOST query rows (what every caller of the reference hands over:
+// VectorSearchRequest.vector, nidx_vector/src/request_types.rs:19-35): `threads` threads, `depth` tickets each, batches[i] = n_queries x
+// dimension f32 rows in ordinary host memory.  Runs exactly `steps` batches in total after `warm` untimed ones per thread.
+typedef int32_t (*vec_submit_fn)(nidx_gpu_vector_index_t *, const float *, uint32_t, uint32_t, const nidx_gpu_vector_search_params_t *, const uint64_t *const *, uint64_t *);
+typedef int32_t (*vec_wait_fn)(nidx_gpu_vector_index_t *, uint64_t, uint32_t *, uint32_t *, uint32_t *, float *, uint32_t *, uint32_t *);
+int32_t nidx_bench_vector_pipeline(vec_submit_fn submit_fn, vec_wait_fn wait_fn, nidx_gpu_vector_index_t *index, const float *const *batches,
+                                   uint32_t n_batches, uint32_t n_queries, uint32_t dimension, const nidx_gpu_vector_search_params_t *params,
+                                   uint32_t threads, uint32_t depth, uint32_t warm, uint64_t steps, double *elapsed_out, uint32_t *last_vec_out,
+                                   float *last_score_out, uint32_t *last_count_out) {
+    const uint32_t k = params->k > 0 ? params->k : 1;
+    std::atomic<int32_t> rc{0};
+    std::atomic<uint32_t> ready{0};
+    std::atomic<int> go{0};
+    std::atomic<uint64_t> next{0};
+    std::vector<double> t_end(threads, 0.0);
+    auto worker = [&](uint32_t w) {
+        std::vector<uint32_t> vec((size_t)n_queries * k), count(n_queries);
+        std::vector<float> score((size_t)n_queries * k);
+        std::deque<uint64_t> pending;
+        auto submit = [&](uint64_t i) -> bool {
+            uint64_t t = 0;
+            const int32_t r = submit_fn(index, batches[i % n_batches], n_queries, dimension, params, nullptr, &t);
+            if (r != 0) { int32_t z = 0; rc.compare_exchange_strong(z, r); return false; }
+            pending.push_back(t);
+            return true;
+        };
+        auto wait_oldest = [&]() -> bool {
+            const uint64_t t = pending.front();
+            pending.pop_front();
+            const int32_t r = wait_fn(index, t, nullptr, nullptr, vec.data(), score.data(), count.data(), nullptr);
+            if (r != 0) { int32_t z = 0; rc.compare_exchange_strong(z, r); return false; }
+            return true;
+        };
+        bool ok = true;
+        for (uint32_t i = 0; i < warm && ok; i++) {
+            ok = submit(w + (uint64_t)i * threads);
+            if (ok && pending.size() >= depth) ok = wait_oldest();
+        }
+        while (ok && !pending.empty()) ok = wait_oldest();
+        ready.fetch_add(1);
+        while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+        while (ok && rc.load() == 0) {
+            const uint64_t i = next.fetch_add(1);
+            if (i >= steps) break;
+            ok = submit(i);
+            if (ok && pending.size() >= depth) ok = wait_oldest();
+        }
+        while (ok && !pending.empty()) ok = wait_oldest();
+        if (!ok)
+            while (!pending.empty()) { (void)wait_fn(index, pending.front(), nullptr, nullptr, vec.data(), score.data(), count.data(), nullptr); pending.pop_front(); }
+        t_end[w] = now_s();
+        if (w == 0 && ok && last_vec_out) {   // one more batch (batch 0), handed back for the caller's comparison with the device-resident entry
+            if (submit(0) && wait_oldest()) {
+                memcpy(last_vec_out, vec.data(), vec.size() * 4);
+                memcpy(last_score_out, score.data(), score.size() * 4);
+                memcpy(last_count_out, count.data(), count.size() * 4);
+            }
+        }
+    };
+    std::vector<std::thread> ths;
+    for (uint32_t w = 0; w < threads; w++) ths.emplace_back(worker, w);
+    while (ready.load() < threads) std::this_thread::yield();
+    const double t0 = now_s();
+    go.store(1, std::memory_order_release);
+    for (auto &t : ths) t.join();
+    double end = t0;
+    for (uint32_t w = 0; w < threads; w++) end = t_end[w] > end ? t_end[w] : end;
+    if (elapsed_out) *elapsed_out = end - t0;
+    return rc.load();
+}
+
 }  // extern "C"
