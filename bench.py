@@ -571,7 +571,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     if not (gpath and cached_used):
         # the build on the roofline (north_star: "build + k-NN query distance kernels"; HnswBuilder, hnsw/build.rs:28-167): the build
         # kernels count their distance evaluations, expansions and the rows the neighbour-selection heuristic reads, like the search kernel
-        bst = (C.c_uint64 * 8)()
+        bst = (C.c_uint64 * 10)()
         _lib.check(L.nidx_gpu_vector_build_stats(h, bst))
         if int(bst[2]) != 2**64 - 1 and int(bst[1]) > 0:
             secs = int(bst[1]) / 1e6

@@ -49,7 +49,7 @@ int32_t nidx_gpu_last_error(char *buf, size_t len);
  * the library and refuses a mismatch (nucliadb_amd/_lib.py does; INTEGRATION.md shows the Rust shim's check).
  * 5: nidx_gpu_bm25_search_options_t.phrase_slops, nested-query leaves of any kind (round 4); up to NIDX_GPU_BM25_MAX_TICKETS BM25
  *    tickets, several submitting threads, nidx_gpu_vector_open takes D > 3072 (round 5).
- * 6: nidx_gpu_build_features (round 6). */
+ * 6: nidx_gpu_build_features; nidx_gpu_vector_build_stats fills ten words (round 6). */
 #define NIDX_GPU_ABI_VERSION 6
 int32_t nidx_gpu_abi_version(void);
 /* What this build of the library contains beyond the product paths: NIDX_GPU_FEATURE_RABITQ_EXPERIMENTS = the two-wave RaBitQ walk
@@ -143,7 +143,8 @@ int32_t nidx_gpu_vector_segment_records(const nidx_gpu_vector_index_t *index, ui
  * "eval_rows" 2..4, "min_waves" 2|4, "vis_log2" 10..15, "build_vis_log2" 10..15, and the request coalescer's
  * "coalesce_window_us" / "coalesce_max_batch" / "coalesce_in_flight", the serving pipeline's "pipeline_depth" and "stage_threads" (0..16,
  * default 3, process-wide; NIDX_GPU_STAGE_THREADS: helper threads that share the copy of a batch's host query rows into pinned staging
- * with the submitting thread — 3 MiB per 1 024 x 768 batch, which one thread alone copies no faster than the device answers).  The
+ * with the submitting thread — 3 MiB per 1 024 x 768 batch, which one thread alone copies no faster than the device answers; helpers that
+ * have started stay for the life of the process, so lowering the value only stops new ones from being started; a forked child starts its own).  The
  * kernel knobs are also read at open from the environment as NIDX_GPU_<NAME>.  "launch_shape": 0 (default) = a batch of more than 256
  * queries submitted through the pipeline while other batches are still on the device takes the shape that holds five walks per CU instead
  * of four (<= 96 VGPRs, 2^12-slot visited table: each walk a little slower, more of them resident), a batch that finds the device idle the
@@ -388,11 +389,14 @@ int32_t nidx_gpu_hnsw_graph_check(const uint8_t *graph, uint64_t graph_len, cons
  * segment had.  Like the reference's rayon build the graph is not unique; parity is recall. */
 int32_t nidx_gpu_vector_build_hnsw(nidx_gpu_vector_index_t *index, uint32_t segment, uint64_t level_seed);
 /* The work of the last nidx_gpu_vector_build_hnsw / _extend_hnsw of this index, counted by the build kernels the way the search
- * kernel counts its own (measurement; HnswBuilder::insert, hnsw/build.rs:97-167): stats_out[8] =
+ * kernel counts its own (measurement; HnswBuilder::insert, hnsw/build.rs:97-167): stats_out[10] (8 before ABI version 6) =
  *   [0] nodes inserted, [1] microseconds from the first batch's launch to the last one's completion,
  *   [2] distance evaluations and [3] expansions of the construction searches (layer_search with ef = 100, build.rs:137-166),
  *   [4] rows read by select_neighbours_heuristic over the new nodes' own candidate lists (build.rs:57-95, 104-108),
  *   [5] rows read by the reverse-link prunes (build.rs:111-119), [6] reverse-link appends, [7] prunes.
+ *   [8] the first node that was inserted with the large visited table of the construction searches (the build starts with a 2^12
+ *       table and moves to the configured one when a batch reports it three quarters full; 0 = it never did),
+ *   [9] the NIDX_FLAG_* the build ended with (bit 0: a construction search filled the LARGE table and ended early).
  * Algorithmic bytes of the build = ([2] + [4] + [5]) x 4 x dimension + [3] x 256.  [2] = ~0 when the build ran with
  * NIDX_GPU_BUILD_STATS=0 (no counters). */
 int32_t nidx_gpu_vector_build_stats(nidx_gpu_vector_index_t *index, uint64_t *stats_out);

@@ -398,7 +398,16 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     // NIDX_GPU_BM25_SEGMENT_LOOP=1 keeps one resident segment per opened segment and the search a loop over them (launches, a
     // transfer and a host merge per segment): the path the one-launch layout is tested against
     const char *loop_env = getenv("NIDX_GPU_BM25_SEGMENT_LOOP");
-    if (n_segments > 1 && !(loop_env && atoi(loop_env) != 0)) {
+    // Segments that disagree on positions (some indexed WithFreqsAndPositions, some not) keep their own resident layouts too: the one
+    // layout would have to drop the positions of ALL of them, and a phrase over a field only the positioned segments hold would fail.
+    bool some_pos = false, some_without = false;
+    for (uint32_t s = 0; s < n_segments; s++) {
+        if (!segments[s].term_offsets[idx->n_terms]) continue;   // (no postings: nothing to disagree about)
+        if (segments[s].pos_offsets) some_pos = true;
+        else some_without = true;
+    }
+    const bool mixed_positions = some_pos && some_without;
+    if (n_segments > 1 && !(loop_env && atoi(loop_env) != 0) && !mixed_positions) {
         if (int32_t rc = bm25_upload_concatenated(idx.get(), segments, n_segments)) return rc;
     } else {
         idx->segs.resize(n_segments);

@@ -406,6 +406,12 @@ static hipError_t launch_batch(const BuildArgs &a, uint32_t n_slots, void *sort_
     return hipGetLastError();
 }
 
+__global__ void flag_clear_kernel(uint32_t *word, uint32_t bits) { atomicAnd(word, ~bits); }
+hipError_t launch_flag_clear(uint32_t *word, uint32_t bits, hipStream_t s) {
+    hipLaunchKernelGGL(flag_clear_kernel, dim3(1), dim3(1), 0, s, word, bits);
+    return hipGetLastError();
+}
+
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes) {
     *bytes = 0;
     return hipcub::DeviceRadixSort::SortPairs(nullptr, *bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,

@@ -216,12 +216,15 @@ int32_t VectorIndex::build_hnsw(uint32_t si, uint64_t level_seed, bool extend) {
             NIDX_HIP(hipEventRecord(ev_flags[bi & 1], stream));
             if (bi > 0 && hipEventQuery(ev_flags[(bi - 1) & 1]) == hipSuccess && (hf[(bi - 1) & 1] & NIDX_FLAG_VISITED_OVERFLOW)) {
                 b.vis_log2 = build_vis_log2;
-                n_escalated_at = bt.start;
+                n_escalated_at = bt.start + bt.size;   // the first node inserted with the large table
+                // from here on the flag word describes the large table: the bit the small one raised is taken out (stream order: behind
+                // the batches launched so far, before the next one) — a build that still carries it at the end overflowed 2^vis_log2
+                NIDX_HIP(launch_flag_clear(d_flags.as<uint32_t>(), NIDX_FLAG_VISITED_OVERFLOW, stream));
             }
         }
         bi++;
     }
-    (void)n_escalated_at;
+    last_build_escalated_at = n_escalated_at;
     uint32_t flags = 0;
     NIDX_HIP(hipMemcpyAsync(&flags, d_flags.p, 4, hipMemcpyDeviceToHost, stream));
     NIDX_HIP(hipStreamSynchronize(stream));
@@ -266,6 +269,8 @@ extern "C" int32_t nidx_gpu_vector_build_stats(nidx_gpu_vector_index_t *index, u
     if (!idx || !stats_out) return fail(NIDX_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     for (int c = 0; c < 8; c++) stats_out[c] = idx->last_build_stats[c];
+    stats_out[8] = idx->last_build_escalated_at;
+    stats_out[9] = idx->last_build_flags;
     return NIDX_OK;
 } NIDX_ABI_CATCH
 

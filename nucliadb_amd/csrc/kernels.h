@@ -332,6 +332,7 @@ struct BuildBatch {
     unsigned long long *stats;  // nullptr or [NIDX_BUILD_STAT_LINES][16]: the build's work counters (hnsw_build.hip: BuildArgs::stats)
 };
 #define NIDX_BUILD_STAT_LINES 256
+hipError_t launch_flag_clear(uint32_t *word, uint32_t bits, hipStream_t s);   // *word &= ~bits, in stream order
 hipError_t build_sort_tmp_bytes(uint32_t max_req, size_t *bytes);
 hipError_t launch_build_batch(const BuildBatch &b, hipStream_t s);
 

@@ -23,6 +23,8 @@
 // Bound: HBM latency/bytes (D/8+8 bytes per estimate, 4 D per re-ranked row, 256 B per expansion).
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 #include "hnsw_device.h"
 
@@ -1671,16 +1673,29 @@ hipError_t launch_rabitq_query(const float *queries, uint32_t nq, uint32_t dp, u
     hipLaunchKernelGGL(rabitq_query_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, queries, nq, dp, dim, qd, planes);
     return hipGetLastError();
 }
+// The dynamic-LDS ceiling of a kernel is an attribute of the FUNCTION, process-wide, while launches of different indexes (other k,
+// ef, seen_log2: other sizes) come from different threads: it is only ever raised, under one lock, so a launch never finds it below
+// what it asked for (setting it before every launch let a smaller request of another thread slip in between set and launch).
+static hipError_t rq_allow_lds(const void *fn, size_t smem) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, size_t> allowed;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &cur = allowed[fn];
+    if (smem <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) cur = smem;
+    return e;
+}
 template <int NW>
 static hipError_t launch_bf_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_bf_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_bf_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_bf_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
     return hipGetLastError();
 }
 template <int NW>
 static hipError_t launch_hnsw_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_hnsw_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
     return hipGetLastError();
@@ -1706,7 +1721,7 @@ hipError_t launch_rabitq_bf(const RabitqSearchArgs &a, hipStream_t s) {
 #ifdef NIDX_RABITQ_EXPERIMENTS
 template <int NW>
 static hipError_t launch_hnsw2_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw2_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     const char *wg = getenv("NIDX_GPU_RABITQ_WG");
     hipLaunchKernelGGL(rabitq_hnsw2_kernel<NW>, dim3(a.n_queries), dim3(wg && atoi(wg) == 256 ? 256 : 128), smem, s, a);
@@ -1714,7 +1729,7 @@ static hipError_t launch_hnsw2_nw(const RabitqSearchArgs &a, size_t smem, hipStr
 }
 template <int NW>
 static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw2_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw2_segments_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_hnsw2_segments_kernel<NW>, dim3(n_table * nq), dim3(128), smem, s, table, nq);
     return hipGetLastError();
@@ -1722,21 +1737,21 @@ static hipError_t launch_hnsw2_segments_nw(const RabitqSearchArgs *table, uint32
 #endif
 template <int NW>
 static hipError_t launch_hnsw1_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw_segments_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_hnsw_segments_kernel<NW>, dim3(n_table * nq), dim3(64), smem, s, table, nq);
     return hipGetLastError();
 }
 template <int NW>
 static hipError_t launch_hnsw3_nw(const RabitqSearchArgs &a, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw3_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw3_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_hnsw3_kernel<NW>, dim3(a.n_queries), dim3(64), smem, s, a);
     return hipGetLastError();
 }
 template <int NW>
 static hipError_t launch_hnsw3_segments_nw(const RabitqSearchArgs *table, uint32_t n_table, uint32_t nq, size_t smem, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rabitq_hnsw3_segments_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = rq_allow_lds(reinterpret_cast<const void *>(&rabitq_hnsw3_segments_kernel<NW>), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rabitq_hnsw3_segments_kernel<NW>, dim3(n_table * nq), dim3(64), smem, s, table, nq);
     return hipGetLastError();

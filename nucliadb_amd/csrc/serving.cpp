@@ -16,6 +16,7 @@
 //           (segment_search_exact) and merges on the host (the same Fssc, csrc/vector_index.cpp: fssc_merge).
 //
 // Results are those of nidx_gpu_vector_search for the same batch (tests/test_serving_gpu.py).
+#include <pthread.h>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -111,18 +112,30 @@ struct StagePool {
         lk.unlock();
         while (j.done.load(std::memory_order_acquire) < j.n_chunks) std::this_thread::yield();   // (all claimed, refs == 0: already true)
     }
-    ~StagePool() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv_work.notify_all();
-        for (auto &t : threads) t.join();
-    }
 };
+// The pool lives on the heap and is never destroyed: no join at static destruction (a forked child would join threads it does not
+// have), and fork() is survived — the child inherits the object but none of its threads, and its mutex may be held by a thread that
+// does not exist there: the child's atfork handler drops the pointer (the object is leaked) and the next staging call starts a pool
+// of its own.  Python's multiprocessing forks by default.
+std::mutex g_pool_mu;
+StagePool *g_pool = nullptr;
+void pool_atfork_prepare() { g_pool_mu.lock(); }
+void pool_atfork_parent() { g_pool_mu.unlock(); }
+void pool_atfork_child() {
+    g_pool = nullptr;
+    g_pool_mu.unlock();
+}
 StagePool &stage_pool() {
-    static StagePool p;
-    return p;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool) {
+        static bool registered = false;
+        if (!registered) {
+            (void)pthread_atfork(pool_atfork_prepare, pool_atfork_parent, pool_atfork_child);
+            registered = true;
+        }
+        g_pool = new StagePool();
+    }
+    return *g_pool;
 }
 std::atomic<int> g_stage_threads{-1};   // helpers besides the submitting thread; -1 = not yet read from the environment
 }  // namespace

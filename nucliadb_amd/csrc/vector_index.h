@@ -115,6 +115,7 @@ struct VectorIndex {
     bool build_vis_pinned = false;   // the tunable / NIDX_GPU_BUILD_VIS_LOG2 was set: no adaptive start at 2^12 (hnsw_build_host.cpp)
     uint32_t build_ef_upper = 0;   // 0 = 1 (reference); tunable "build_ef_upper": a wider descent when inserting into very large flat graphs
     uint32_t last_build_flags = 0;
+    uint32_t last_build_escalated_at = 0;   // first node inserted with the large visited table (0: the 2^12 table held for the whole build)
     uint64_t last_build_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nidx_gpu_vector_build_stats
     // grow-only scratch, guarded by mu
     DevBuf scratch_fstack, scratch_flists, scratch_fcount, scratch_q16, scratch_cand_vec, scratch_cand_score, scratch_cand_count, scratch_multi_vec, scratch_multi_score, scratch_multi_count, scratch_qnorm, scratch_partial, scratch_queries, scratch_filter, scratch_out_vec, scratch_out_score, scratch_out_count,

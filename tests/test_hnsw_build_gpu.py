@@ -258,7 +258,7 @@ def test_build_work_counters(orc, monkeypatch):
             monkeypatch.setenv("NIDX_GPU_BUILD_STATS", "0")
         s = VectorSearcher.open(VectorConfig(d, Similarity.Cosine), [(seg_of(x), 1)])
         s.build_hnsw(0, level_seed=2)
-        st = (C.c_uint64 * 8)()
+        st = (C.c_uint64 * 10)()
         _lib.check(_lib.lib().nidx_gpu_vector_build_stats(s._handle, st))
         graph, edges = s.serialize_hnsw(0)
         s.close()
