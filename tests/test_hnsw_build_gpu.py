@@ -268,7 +268,8 @@ def test_build_work_counters(orc, monkeypatch):
     st0, g0, e0 = build(False)
     assert g1 == g0 and e1 == e0, "counting the work changed the graph"
     assert st0[2] == 2**64 - 1 and st0[0] == n
-    nodes, usec, evals, expansions, sel_rows, prune_rows, appends, prunes = st
+    nodes, usec, evals, expansions, sel_rows, prune_rows, appends, prunes, escalated_at, end_flags = st
+    assert escalated_at <= n and end_flags & ~1 == 0   # ([8]: first node inserted with the large visited table, [9]: the flags the build ended with)
     assert nodes == n and usec > 0
     assert evals >= expansions > n             # every insertion expands at least its entry point on layer 0
     assert evals / n > 100                     # ef_construction = 100 results are kept per layer: at least as many rows were scored
