@@ -1175,11 +1175,6 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         // a balanced query keeps ~1 900 postings per slice (the bitmaps allow no more), a long list with two short ones gets ~8 000.
         // A batch alone on the GPU (the blocking entries, the first ticket) keeps the latency shape below.
         const bool crowded_shape = crowded && !getenv("NIDX_GPU_BM25_SLICE") && !lockstep_union;
-        // NIDX_GPU_BM25_COOP=1: the union items of a plain batch go to bm25_coop_kernel (a workgroup per item)
-        static const int coop_env = [] { const char *e = getenv("NIDX_GPU_BM25_COOP"); return e ? atoi(e) : 0; }();
-        static const int coop_min = [] { const char *e = getenv("NIDX_GPU_BM25_COOP_MIN"); return e ? std::max(1, atoi(e)) : 4; }();
-        const bool coop = coop_env != 0 && !lockstep_union && union_mode != 0 && kk <= 64 && seg.all_alive && !after && order_field < 0 && n_slots == 0 &&
-                          !getenv("NIDX_GPU_BM25_DEBUG");
         if (crowded_shape) {
             slice_now = BM25_SLICE_CROWDED;
         } else if (!getenv("NIDX_GPU_BM25_SLICE")) {
@@ -1246,12 +1241,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                 if (union_mode == 2) q_union[q] = 1;
                 else if (shared * 8.0 <= sum && want <= (double)BM25_MAX_SLICES) q_union[q] = 1;
                 if (q_union[q] && !lockstep_union) slices = (uint32_t)std::min<double>(BM25_MAX_SLICES, std::max<double>(slices, want));
-                // a workgroup per item (bm25_coop.hip): four waves share an item of four times the postings under filters of four times the bits
-                // (a query of fewer than coop_min one-wave items stays with the one-wave kernel: four waves would each repeat its set-up)
-                if (q_union[q] && coop && slices >= (uint32_t)coop_min) {
-                    slices = (slices + 3u) / 4u;
-                    q_union[q] = 2;
-                }
+
             }
             const Bm25Work w{q, 0, slices, (uint32_t)c0, (uint32_t)(c1 - c0)};
             work.resize(work.size() + slices, w);
@@ -1263,12 +1253,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         std::vector<uint32_t> &item_list = cx.w_item_list;
         item_list.resize(nw);
         uint32_t n_union = 0, n_fast = 0, n_wide = 0, wide_max_clauses = 0;
-        uint32_t n_coop = 0;   // the items of bm25_coop_kernel come first, then bm25_stream_kernel's
         for (size_t w = 0; w < nw; w++)
-            if (q_union[work[w].query] == 2) item_list[n_coop++] = (uint32_t)w;
-        n_union = n_coop;
-        for (size_t w = 0; w < nw; w++)
-            if (q_union[work[w].query] == 1) item_list[n_union++] = (uint32_t)w;
+            if (q_union[work[w].query]) item_list[n_union++] = (uint32_t)w;
         if (n_union < nw) {
             for (size_t w = 0; w < nw; w++) {
                 const uint32_t nc = work[w].n_clauses;
@@ -1386,8 +1372,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         NIDX_HIP(hipEventRecord(cx.ev0, cx.stream));
         {
             const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
-            if (n_coop) NIDX_HIP(launch_bm25_coop(a, d_items, n_coop, cx.stream));
-            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items + n_coop, n_union - n_coop, extras, cx.stream));
+            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, cx.stream));
         }
         NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, cx.stream));
         NIDX_HIP(hipEventRecord(cx.ev1, cx.stream));

@@ -434,8 +434,6 @@ hipError_t launch_bm25_search(const Bm25Args &a, const uint32_t *fast_items, uin
 hipError_t launch_bm25_union(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s);
 // the same queries term at a time (bm25_stream.hip): the default; launch_bm25_union stays selectable for comparison
 hipError_t launch_bm25_stream(const Bm25Args &a, const uint32_t *items, uint32_t n_items, bool extras, hipStream_t s);
-// the same scoring with a workgroup per item (bm25_coop.hip): plain batches only — k <= 64, no alive set / cursor / order key / match bitset
-hipError_t launch_bm25_coop(const Bm25Args &a, const uint32_t *items, uint32_t n_items, hipStream_t s);
 
 // ---- BM25 surroundings (bm25_aux.hip) ----
 // FuzzyTermQuery's automaton over the whole term dictionary: flags[t] = 1 when term t is accepted
