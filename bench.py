@@ -511,7 +511,7 @@ def pmc_traffic(kind, n, d, B, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r05_pmc_traffic.json — or a previous round's — written by scripts/refresh_profiles.sh / make_pmc_traffic.py; counters
     cannot be read from inside this process)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 for e in json.load(f)["entries"]:
@@ -1395,7 +1395,15 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     pipelined(n_timed)
-    pipe_qps = B * n_timed / (time.perf_counter() - t1)
+    dt1 = time.perf_counter() - t1
+    pipe_qps = B * n_timed / dt1
+    # ... and again over a region of at least one second, sized from that rate (twelve batches are ~0.1 s)
+    n_long = max(n_timed, int(np.ceil(min(a.min_timed_s, 1.0) * n_timed / max(dt1, 1e-6))))
+    t1 = time.perf_counter()
+    pipelined(n_long)
+    dt_long = time.perf_counter() - t1
+    pipe_qps = B * n_long / dt_long
+    n_timed_regime = n_long
     # the walks' algorithmic bytes (evals x 4D + expansions x 256) from the oracle's counters on a sample of segments
     walk_bytes = None
     try:
@@ -1430,7 +1438,8 @@ def segment_regime_leg(a, L, x_host, qpool, kind, threads, exact0):
                                        "oracle_order": "WAVE64", "reference": "nidx_vector/src/searcher.rs:149-199,270-287"},
            "sample": "%d queries, oracle Searcher::_search: %d segments of <= %d records searched sequentially + Fssc, one query per POSIX thread" % (nq, S, cap),
            "segment_builds_s": build_s, "device_same_index_host_buffer_queries_per_s": gpu_qps,
-           "device_same_index_pipelined_queries_per_s": pipe_qps, "device_same_index_serial_segments_queries_per_s": serial_qps,
+           "device_same_index_pipelined_queries_per_s": pipe_qps, "device_same_index_pipelined_batches_timed": n_timed_regime,
+           "device_same_index_pipelined_timed_s": dt_long, "device_same_index_serial_segments_queries_per_s": serial_qps,
            "one_launch_ids_identical_to_a_launch_per_segment": one_launch_equals_serial,
            "device_entry": "nidx_gpu_vector_search_submit / _wait, %d batches of %d in flight, %d timed: one launch of %d x %d walks per batch + Fssc on the device" % (nfl, B, n_timed, B, S),
            "device_walk": None if walk_bytes is None else {
@@ -1558,6 +1567,11 @@ def bench_hnsw(a, L, dev, rank, world):
         "bf16_fallback_frac_of_bf16_peak": ((bf16_blk or {}).get("roofline") or {}).get("frac"),
         "hnsw_build_s": head["build_s"], "hnsw_build_frac_of_hbm_peak": (bld.get("roofline") or {}).get("frac"),
         "exchange_check": head["exchange_check"], "ef_upper": max(1, a.ef_upper),
+        # the same graph at the reference's own constants (ef_upper = 1: the greedy descent of hnsw/search.rs:318-324), first class
+        "reference_constants_queries_per_s": (head.get("reference_constants") or {}).get("queries_per_s"),
+        "reference_constants_recall_at_%d" % k: (head.get("reference_constants") or {}).get("recall_at_%d" % k),
+        "reference_constants_roofline_frac": ((head.get("reference_constants") or {}).get("roofline") or {}).get("frac"),
+        "reference_constants_sustained_frac": ((head.get("reference_constants") or {}).get("roofline") or {}).get("sustained_frac"),
     }
     cfgd = dict(first, **{kk_: v for kk_, v in cfgd.items() if kk_ not in first})
     cfgd["build"] = bld or None
