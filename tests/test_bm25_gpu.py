@@ -192,7 +192,7 @@ def test_general_kernel_on_narrow_queries(orc, corpus, monkeypatch):
     s.close()
 
 
-@pytest.mark.parametrize("union_mode", ["2", "4", "0"])
+@pytest.mark.parametrize("union_mode", ["2", "2-throughput-shape", "4", "0"])
 def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeypatch, union_mode):
     """The union kernels (postings are final unless a bitmap filter says their document may occur twice; those are resolved
     exactly) against the oracle, on query families that make their slow paths the common ones: NIDX_GPU_BM25_UNION=2 sends every
@@ -202,6 +202,11 @@ def test_union_kernel_and_hash_kernel_agree_with_the_oracle(orc, corpus, monkeyp
     uses them: the same answers from the hash kernels."""
     seg, vocab = corpus
     rng = np.random.default_rng(21)
+    if union_mode == "2-throughput-shape":
+        # the slicing a batch gets when other tickets are out (csrc/bm25_index.cpp crowded_shape: the fewest slices the bitmaps'
+        # collision estimate allows — on this small corpus whole queries in one item, the overflow / halve / retry path the rule)
+        monkeypatch.setenv("NIDX_GPU_BM25_CROWDED", "1")
+        union_mode = "2"
     monkeypatch.setenv("NIDX_GPU_BM25_UNION", union_mode)
     s = Bm25Searcher.open([seg])
     G = _lib.OCCUR_SHOULD_GROUP

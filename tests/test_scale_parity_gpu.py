@@ -114,7 +114,7 @@ def test_hnsw_and_scan_match_oracle_at_1m_x_768(orc, torch_dev, kind):
         L.nidx_gpu_vector_close(h)
 
 
-def test_bm25_matches_oracle_on_the_10m_doc_zipf_index(orc, torch_dev):
+def test_bm25_matches_oracle_on_the_10m_doc_zipf_index(orc, torch_dev, monkeypatch):
     import bench
     from nucliadb_amd.bm25 import Bm25Searcher, Bm25Segment
 
@@ -134,6 +134,17 @@ def test_bm25_matches_oracle_on_the_10m_doc_zipf_index(orc, torch_dev):
         count, total, post = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
         _lib.check(L.nidx_gpu_bm25_search(searcher._handle, cl, offsets.ctypes.data, B, k, None, docaddr.ctypes.data, score.ctypes.data,
                                           count.ctypes.data, total.ctypes.data, post.ctypes.data))
+        # the work list's throughput shape (what a batch gets when other tickets are out: the fewest slices the bitmaps' collision
+        # estimate allows, csrc/bm25_index.cpp crowded_shape) must give the same bits
+        monkeypatch.setenv("NIDX_GPU_BM25_CROWDED", "1")
+        d2, s2 = np.zeros((B, k), np.uint64), np.zeros((B, k), np.float32)
+        c2, t2, p2 = np.zeros(B, np.uint32), np.zeros(B, np.uint64), np.zeros(B, np.uint64)
+        _lib.check(L.nidx_gpu_bm25_search(searcher._handle, cl, offsets.ctypes.data, B, k, None, d2.ctypes.data, s2.ctypes.data, c2.ctypes.data, t2.ctypes.data,
+                                          p2.ctypes.data))
+        monkeypatch.delenv("NIDX_GPU_BM25_CROWDED")
+        assert np.array_equal(c2, count) and np.array_equal(t2, total) and np.array_equal(p2, post)
+        for i in range(B):
+            assert np.array_equal(d2[i, : count[i]], docaddr[i, : count[i]]) and np.array_equal(_bits(s2[i, : count[i]]), _bits(score[i, : count[i]])), i
         oidx = orc.Bm25Index(term_offsets, doc_ids, tfs, fieldnorm_ids, total_tokens)
         nq = 64
         queries = [[(int(t), 0, 0, 1.0) for t in terms[i]] for i in range(nq)]
