@@ -340,47 +340,62 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_scan_kernel(Bf16ScanArgs a
     }
 }
 
-// ---- the same scan without candidate lists in LDS (round 4) -----------------------------------------------------------------------
+// ---- the same scan without candidate lists in LDS (round 4; the mainloop is round 6's) -----------------------------------------------
 // With a floor per query (32 rows of a sample are known to reach it) a stripe holds only a handful of rows at or above it, so the
-// sorted lists — 64 KiB of LDS that pinned the pipeline above to 16-element K steps and one barrier per step — are not needed: a
-// row that reaches its query's floor is APPENDED to the query's 32 slots of this stripe (an LDS counter gives the position, the
-// key goes straight to HBM), and merge_topk_kernel sees the same [query][stripe][32] block as before.  A stripe that would need a
-// 33rd slot raises its query block's flag and bf16_scan_kernel (run_if) scans that block again with its lists: the result is the
-// list kernel's in every case.  What the freed LDS buys is the mainloop of the guide's 256 x 256 bf16 tile: BK = 64 (four of the
-// 8-KiB operand blocks per operand and stage), two 64-KiB stages, one s_waitcnt vmcnt(0) + barrier per stage = per 32 MFMAs of a
-// wave, and — no list belongs to a wave any more — 64 x 128 wave tiles (wave (w & 3, w >> 2): 2 + 4 fragment reads per 8 MFMAs
-// instead of 1 + 8).  A workgroup's tiles come in rounds (round i = tile blockIdx.x + i gridDim.x).  round_step > 1: only every
-// round_step-th round is scanned — the sample across the corpus the floor of the full pass comes from; the groups' counts go to
-// cnt_inout.  round_skip > 1 (the full pass after such a sample, same grid): those rounds are skipped and the sample's entries stay
-// in their slots — the workgroup first drops the ones under the tightened floor and goes on appending behind the rest; a query
-// block whose sample ran out of slots (skip_unless) empties its slots and scans every round.
-#define BA_CHUNKS 4                                        /* K steps of 16 per stage */
-#define BA_OPERAND_BYTES (BA_CHUNKS * BF_BLOCK_BYTES)       /* 32 KiB */
-#define BA_STAGE_BYTES (2 * BA_OPERAND_BYTES)               /* [Q: 4 blocks][X: 4 blocks] */
-struct Bf16AppendShared {
-    __attribute__((aligned(16))) unsigned char stage[2][BA_STAGE_BYTES];
-    float thr[BF_BM];       // a row is a candidate iff score > thr (the largest float under the floor; +inf: padding query)
-    uint32_t cnt[BF_BM];    // candidates of the query in this stripe so far
-    uint64_t keep[BF_THREADS / 64][BF_KP];   // a wave's staging row while it compacts the sample's entries of one query
+// sorted lists — 64 KiB of LDS — are not needed: a row that reaches its query's floor is APPENDED to the query's 32 slots of this
+// stripe (an LDS counter gives the position, the key goes straight to HBM), and merge_topk_kernel sees the same [query][stripe][32]
+// block as before.  A stripe that would need a 33rd slot raises its query block's flag and bf16_scan_kernel (run_if) scans that block
+// again with its lists: the result is the list kernel's in every case.  No list belongs to a wave any more, so the wave tiles are
+// 64 x 128 (wave (w & 3, w >> 2): 2 + 4 fragment reads per 8 MFMAs instead of 1 + 8).  A workgroup's tiles come in rounds (round i =
+// tile blockIdx.x + i gridDim.x).  round_step > 1: only every round_step-th round is scanned — the sample across the corpus the floor
+// of the full pass comes from; the groups' counts go to cnt_inout.  round_skip > 1 (the full pass after such a sample, same grid):
+// those rounds are skipped and the sample's entries stay in their slots — the workgroup first drops the ones under the tightened floor
+// and goes on appending behind the rest; a query block whose sample ran out of slots (skip_unless) empties its slots and scans every
+// round.
+//
+// Mainloop: a ring of 16-element K chunks.  Round 4's form (two 64-KiB stages of four chunks, `s_waitcnt vmcnt(0)` + barrier per stage)
+// requested a stage ONE stage ahead — 2 048 matrix-pipe cycles per SIMD, about a microsecond, less than a loaded HBM round trip — and its
+// waves were parked at that wait for a third of their cycles (profiles/r06_sq_counters_bf16_12m5x1024.txt).  Here the unit of staging is
+// the 16-KiB image of ONE chunk ([Q block 8 KiB][X block 8 KiB]; the HBM layout is unchanged), R of them form a ring, and a chunk is
+// requested R - KC chunks (6 x 512 pipe cycles) before it is read; nothing in the loop waits for vmcnt(0).  A barrier every KC chunks
+// publishes the next KC chunks; the fragment reads of chunk c and the two LDS-DMA pieces a wave requests per chunk sit in the issue gaps
+// between the 8 MFMAs of chunk c - 1 (two register sets), so the first MFMA after a barrier never waits for LDS.  Measured (12.5 M x 1024,
+// batch 1 024, three interleaved runs on one box): 24.24 ms per batch against 24.95 ms — the gain is small because the wait was not
+// latency: the ablations of profiles/r06_bf16_ablation.txt (library built with -DNIDX_BF16_ABLATE) show the requests alone (no MFMAs,
+// no fragment reads) take 0.6 of the batch and the MFMAs alone 0.65 — the LDS port (16 KiB of DMA writes at 64 B/clk + 48 KiB of
+// fragment reads at 256 B/clk = 448 of the 512 cycles a chunk's MFMAs take per SIMD pair) and the L2 -> LDS path at the clock the matrix
+// pipe's power leaves (1.6 GHz with every MFMA slot used) are what the 256 x 256 tile saturates.  Two shorter epilogues (eight v_max3 and
+// one compare per accumulator instead of sixteen compares; a zero C operand instead of clearing the accumulators) measured 5 % SLOWER.
+template <int R>
+struct Bf16RingShared {
+    __attribute__((aligned(16))) unsigned char slot[R][2 * BF_BLOCK_BYTES];
+    float thr[BF_BM];
+    uint32_t cnt[BF_BM];
+    uint64_t keep[BF_THREADS / 64][BF_KP];
     uint32_t overflow;
 };
 
+template <int KC, int R>
 __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs a) {
+    static_assert(R % KC == 0 && 2 * (R - 2 * KC) <= 15, "ring shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
-    Bf16AppendShared &sh = *reinterpret_cast<Bf16AppendShared *>(bf_smem);
+    Bf16RingShared<R> &sh = *reinterpret_cast<Bf16RingShared<R> *>(bf_smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, half = lane >> 5;
     const int wq = wave & 3, wr = wave >> 2;          // this wave: queries 64 wq.., tile rows 128 wr..
     const uint32_t q0 = blockIdx.y * BF_BM;
     const uint32_t rs = a.round_step ? a.round_step : 1u;
-    // the full pass behind a sample keeps the sample's entries unless that sample ran out of slots for this query block
     const bool after_sample = a.round_skip > 1;
     const bool keep_sample = after_sample && !(a.skip_unless && a.skip_unless[blockIdx.y]);
     const uint32_t skip = keep_sample ? a.round_skip : 0u;
     const uint32_t n_tiles = (a.n + BF_BN - 1) / BF_BN;
-    const uint32_t nk = a.dp16 / BF_BK;
-    const uint32_t S = nk / BA_CHUNKS;                // stages per tile (dp16 is a multiple of 64)
+    const uint32_t nk = a.dp16 / BF_BK;               // chunks per tile (a multiple of 4)
+#ifdef NIDX_BF16_ABLATE
+    const int abl = a.debug;   // experiment builds only (wrong results): 1 no requests, 2 no MFMAs, 4 no epilogue, 8 corpus from eight tiles, 16 no fragment reads, 32 no barriers
+#else
+    constexpr int abl = 0;
+#endif
 
     if (tid < BF_BM) {
         const bool real = q0 + tid < a.n_queries;
@@ -398,8 +413,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
     }
     if (tid == 0) sh.overflow = 0;
     __syncthreads();
-    // a query without a floor (fewer than 32 sampled rows passed the filter) would admit every row: leave the block to the list kernel
-    if (tid < BF_BM && sh.thr[tid] == -INFINITY) sh.overflow = 1u;
+    if (tid < BF_BM && sh.thr[tid] == -INFINITY) sh.overflow = 1u;   // a query without a floor: the block is the list kernel's
     __syncthreads();
     if (sh.overflow) {
         if (tid == 0) atomicOr(&a.overflow[blockIdx.y], 1u);
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
 
     const uint32_t rounds = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const uint32_t my_tiles = skip ? rounds - (rounds + skip - 1) / skip : (rounds + rs - 1) / rs;
-    const uint32_t G = my_tiles * S;
+    const uint32_t C = my_tiles * nk;                 // chunks of this workgroup's stream (even)
     const uint32_t round0 = skip ? 1u : 0u;
     auto next_round = [&](uint32_t r) __attribute__((always_inline)) {
         r += rs;
@@ -416,9 +430,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
         return r;
     };
     if (after_sample) {
-        // the slots of this stripe hold the sample's candidates (score >= the sample's floor): keep what also reaches the new floor,
-        // packed at the front of its group; the counters continue from there.  Wave w takes queries 32 w .. 32 w + 31.
-        __syncthreads();   // (thresholds)
+        __syncthreads();
         for (int i = 0; i < 32; i++) {
             const int ql = 32 * wave + i;
             const uint32_t q = q0 + (uint32_t)ql;
@@ -436,61 +448,62 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
         }
         __syncthreads();
     }
-    // every wave copies 4 KiB of each operand per stage (four 1-KiB pieces each)
-    const unsigned char *const q_base = reinterpret_cast<const unsigned char *>(a.queries16) + (size_t)blockIdx.y * nk * BF_BLOCK_BYTES +
-                                        (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
-    const unsigned char *const x_base = reinterpret_cast<const unsigned char *>(a.vectors16) + (uint32_t)wave * 4096u + (uint32_t)lane * 16u;
-    uint32_t is_s = 0, is_round = round0;             // the next stage to request
-    // pieces [p0, p1) of this wave's eight (0-3: query block, 4-7: corpus block) of the stage (is_tile, is_s); advance() moves to the next stage
-    auto issue_pieces = [&](int buf, int p0, int p1) __attribute__((always_inline)) {
-        const unsigned char *qs = q_base + (size_t)is_s * BA_OPERAND_BYTES;
-        const unsigned char *xs = x_base + (((size_t)blockIdx.x + (size_t)is_round * gridDim.x) * nk + (size_t)is_s * BA_CHUNKS) * BF_BLOCK_BYTES;
-        unsigned char *dst = &sh.stage[buf][0] + (uint32_t)wave * 4096u;
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            if (p < p0 || p >= p1) continue;
-            if (p < 4) bf_glds16<0>(qs + p * 1024, dst + p * 1024);
-            else bf_glds16<0>(xs + (p - 4) * 1024, dst + BA_OPERAND_BYTES + (p - 4) * 1024);
-        }
-    };
+
+    // ---- requests: every wave copies piece `wave` (1 KiB) of the chunk's query block and of its corpus block ----
+    const size_t tile_bytes = (size_t)nk * BF_BLOCK_BYTES;
+    const unsigned char *qp = reinterpret_cast<const unsigned char *>(a.queries16) + (size_t)blockIdx.y * tile_bytes + (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
+    const unsigned char *xp = reinterpret_cast<const unsigned char *>(a.vectors16) + ((size_t)blockIdx.x + (size_t)round0 * gridDim.x) * tile_bytes +
+                              (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
+    uint32_t is_kc = 0, is_round = round0, is_left = C;   // the next chunk to request; chunks not requested yet
+    uint32_t wr_off = 0, rd_off = 0;
+    constexpr uint32_t SLOT = 2 * BF_BLOCK_BYTES, RING = (uint32_t)R * SLOT;
+    auto issue_q = [&]() __attribute__((always_inline)) { if (!(abl & 1)) bf_glds16<0>(qp, &sh.slot[0][0] + wr_off + (uint32_t)wave * 1024u); };
+    auto issue_x = [&]() __attribute__((always_inline)) { if (!(abl & 1)) bf_glds16<0>(xp, &sh.slot[0][0] + wr_off + BF_BLOCK_BYTES + (uint32_t)wave * 1024u); };
+    // past the stream's last chunk the same chunk is requested again into a slot nobody reads: the counts behind `s_waitcnt vmcnt(N)` stay true to the end
     auto advance = [&]() __attribute__((always_inline)) {
-        if (++is_s == S) {
-            is_s = 0;
-            is_round = next_round(is_round);
+        wr_off = wr_off + SLOT == RING ? 0u : wr_off + SLOT;
+        if (is_left > 1) {
+            is_left--;
+            qp += BF_BLOCK_BYTES;
+            xp += BF_BLOCK_BYTES;
+            if (++is_kc == nk) {
+                is_kc = 0;
+                qp -= tile_bytes;
+                const uint32_t nr = next_round(is_round);
+                if ((abl & 8) && (nr & 7u) == 0) xp -= (size_t)8 * gridDim.x * tile_bytes;
+                xp += ((size_t)(nr - is_round) * gridDim.x - 1u) * tile_bytes;
+                is_round = nr;
+            }
         }
     };
-    auto issue = [&](int buf) __attribute__((always_inline)) {
-        issue_pieces(buf, 0, 8);
-        advance();
-    };
+
     floatx16 acc[8];   // [a = query half 0..1][t = row quarter 0..3]
 #pragma unroll
     for (int t = 0; t < 8; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     const int frag = (half ^ ((li >> 3) & 1)) * 16;
-    const int a_off = (64 * wq + li) * 32 + frag, b_off = BA_OPERAND_BYTES + (128 * wr + li) * 32 + frag;
+    const int a_off = (64 * wq + li) * 32 + frag, b_off = BF_BLOCK_BYTES + (128 * wr + li) * 32 + frag;
 
     auto epilogue = [&](uint32_t tile) __attribute__((always_inline)) {   // `tile`: the corpus tile
+        if (abl & 4) return;
         const uint32_t r0 = tile * BF_BN;
-        // (the lane coordinates go through an empty asm: otherwise hipcc hoists the ~60 per-query LDS / HBM addresses of this rare path
-        // out of the stage loop and spills the mainloop's registers to make room for them)
         int half = lane >> 5, li = lane & 31;
-        asm volatile("" : "+v"(half), "+v"(li));
+        asm volatile("" : "+v"(half), "+v"(li));   // (keeps hipcc from hoisting this rare path's addresses into the mainloop's registers)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 okw;   // the row-mask bits of this wave's 128 tile rows, through the scalar cache
+        u32x4 okw;
         const uint64_t *mp = a.row_mask + (r0 >> 6) + 2 * wr;
         asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(okw) : "s"(mp) : "memory");
 #pragma unroll
         for (int qa = 0; qa < 2; qa++) {
             const int qb = 64 * wq + 32 * qa;
-            float thr[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) thr[r] = sh.thr[qb + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const floatx16 &c = acc[qa * 4 + t];
                 const bool row_ok = (okw[t] >> li) & 1u;
+                float thr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) thr[r] = sh.thr[qb + (r & 3) + 8 * (r >> 2) + 4 * half];
                 // the common case — no lane holds a candidate — costs one compare per value: the lane masks are ORed on the scalar side
                 unsigned long long any = 0;
 #pragma unroll
@@ -517,53 +530,64 @@ __global__ __launch_bounds__(BF_THREADS, 1) void bf16_append_kernel(Bf16ScanArgs
     };
 
     __syncthreads();   // thresholds and counters
-    if (G) {
-        issue(0);
-        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0)
-        __syncthreads();
-        uint32_t ep_round = round0, s_now = 0;
-        for (uint32_t g = 0; g < G; g++) {
-            const int buf = (int)(g & 1u);
-            const bool more = g + 1 < G;
-            // The second wave of each SIMD (waves 4-7) requests its pieces after its first K step: one wave of a SIMD feeds the matrix
-            // core while the other one issues its eight 1-KiB pieces (measured at 4 M x 1024, batch 1 024: 9.35 ms against 9.87 ms with
-            // every wave requesting first; spreading the pieces over the K steps measured 9.88 / 10.2 ms)
-            const bool late = wave >= 4;
-            if (more && !late) issue_pieces(buf ^ 1, 0, 8);   // lands while this stage is multiplied
-            const unsigned char *base = &sh.stage[buf][0];
-            // the fragments of K step c + 1 are on their way from LDS while the matrix core works on step c (two register sets)
-            bf16x8 av[2][2], bv[2][4];
-            auto frags = [&](int c, int set) __attribute__((always_inline)) {
-#pragma unroll
-                for (int qa = 0; qa < 2; qa++) av[set][qa] = *reinterpret_cast<const bf16x8 *>(base + c * BF_BLOCK_BYTES + a_off + qa * 32 * 32);
-#pragma unroll
-                for (int t = 0; t < 4; t++) bv[set][t] = *reinterpret_cast<const bf16x8 *>(base + c * BF_BLOCK_BYTES + b_off + t * 32 * 32);
-            };
-            frags(0, 0);
-#pragma unroll
-            for (int c = 0; c < BA_CHUNKS; c++) {
-                if (c + 1 < BA_CHUNKS) frags(c + 1, (c + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int qa = 0; qa < 2; qa++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[qa * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c & 1][qa], bv[c & 1][t], acc[qa * 4 + t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c == 0 && more && late) issue_pieces(buf ^ 1, 0, 8);
-            }
-            if (more) advance();
-            if (++s_now == S) {
+    if (C) {
+        // s_waitcnt vmcnt(N) lgkmcnt(0) (gfx9 encoding: vmcnt [3:0], expcnt [6:4] = 7, lgkmcnt [11:8]): the pieces of the chunks this barrier
+        // publishes have landed, R - 2 KC later chunks stay in flight
+        constexpr int WAIT_BAR = 0x0070 | (2 * (R - 2 * KC));
+        constexpr int WAIT_LDS = 0xC07F;   // lgkmcnt(0) alone
+        for (int i = 0; i < R - KC; i++) {
+            issue_q();
+            issue_x();
+            advance();
+        }
+        bf16x8 av0[2] = {}, bv0[4] = {}, av1[2] = {}, bv1[4] = {};
+        uint32_t ep_round = round0, done_kc = 0;
+        // One chunk: [wait + barrier] then the 8 MFMAs of the PREVIOUS chunk (fragments pav / pbv) with this chunk's 6 fragment reads and 2 requests
+        // in their issue gaps.
+        auto chunk = [&](auto bar_tag, bf16x8 (&av)[2], bf16x8 (&bv)[4], bf16x8 (&pav)[2], bf16x8 (&pbv)[4], bool with_mma) __attribute__((always_inline)) {
+            constexpr bool bar = decltype(bar_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(bar ? WAIT_BAR : WAIT_LDS);
+            // the previous chunk's fragments are complete now; re-defining them keeps the compiler from waiting for them again behind the new reads
+            asm volatile("" : "+v"(pav[0]), "+v"(pav[1]), "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]));
+            if constexpr (bar) if (!(abl & 32)) __builtin_amdgcn_s_barrier();
+            const unsigned char *base = &sh.slot[0][0] + rd_off;
+            rd_off = rd_off + SLOT == RING ? 0u : rd_off + SLOT;
+            const bool with_reads = !(abl & 16);
+            with_mma = with_mma && !(abl & 2);
+#define BF_MMA(I) if (with_mma) acc[I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pav[(I) >> 2], pbv[(I) & 3], acc[I], 0, 0, 0)
+#define BF_GAP() __builtin_amdgcn_sched_barrier(0)
+            BF_MMA(0); if (with_reads) av[0] = *reinterpret_cast<const bf16x8 *>(base + a_off); BF_GAP();
+            BF_MMA(1); if (with_reads) av[1] = *reinterpret_cast<const bf16x8 *>(base + a_off + 32 * 32); BF_GAP();
+            BF_MMA(2); if (with_reads) bv[0] = *reinterpret_cast<const bf16x8 *>(base + b_off); BF_GAP();
+            BF_MMA(3); if (with_reads) bv[1] = *reinterpret_cast<const bf16x8 *>(base + b_off + 32 * 32); BF_GAP();
+            BF_MMA(4); if (with_reads) bv[2] = *reinterpret_cast<const bf16x8 *>(base + b_off + 2 * 32 * 32); BF_GAP();
+            BF_MMA(5); if (with_reads) bv[3] = *reinterpret_cast<const bf16x8 *>(base + b_off + 3 * 32 * 32); BF_GAP();
+            BF_MMA(6); issue_q(); BF_GAP();
+            BF_MMA(7); issue_x(); advance(); BF_GAP();
+#undef BF_MMA
+#undef BF_GAP
+            if (with_mma && ++done_kc == nk) {
                 epilogue(blockIdx.x + ep_round * gridDim.x);
-                s_now = 0;
+                done_kc = 0;
                 ep_round = next_round(ep_round);
             }
-            __builtin_amdgcn_s_waitcnt(0x0070);   // the next stage has landed (this wave's pieces; the barrier covers the others')
-            __syncthreads();
+        };
+        using Bar = std::true_type;
+        using Mid = std::integral_constant<bool, KC == 1>;   // an odd chunk has a barrier of its own only when every chunk is published alone
+        chunk(Bar{}, av0, bv0, av1, bv1, false);
+        for (uint32_t c = 1; c + 1 < C; c += 2) {
+            chunk(Mid{}, av1, bv1, av0, bv0, true);
+            chunk(Bar{}, av0, bv0, av1, bv1, true);
         }
+        chunk(Mid{}, av1, bv1, av0, bv0, true);
+        __builtin_amdgcn_s_waitcnt(0x0070);   // the last fragments; the requests that ran past the end of the stream
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1[i >> 2], bv1[i & 3], acc[i], 0, 0, 0);
+        epilogue(blockIdx.x + ep_round * gridDim.x);
+        __syncthreads();
     }
     if (tid == 0 && sh.overflow) atomicOr(&a.overflow[blockIdx.y], 1u);
-    // a sample pass leaves its groups' counts for the full pass that goes on from them
     if (a.cnt_inout && !after_sample && tid < BF_BM && q0 + tid < a.n_queries)
         a.cnt_inout[(size_t)(q0 + tid) * gridDim.x + blockIdx.x] = sh.cnt[tid] < (uint32_t)BF_KP ? sh.cnt[tid] : (uint32_t)BF_KP;
 }
@@ -667,14 +691,25 @@ hipError_t launch_bf16_scan(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t
     return hipGetLastError();
 }
 
+template <typename K, typename S>
+static hipError_t bf16_append_launch_as(K kernel, const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s) {
+    const size_t smem = sizeof(S);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(BF_THREADS), smem, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_bf16_append(const Bf16ScanArgs &a, uint32_t stripes, hipStream_t s) {
     if (a.n_queries == 0) return hipSuccess;
     if (a.n == 0 || (a.dp16 % 64u) || !a.floor_score || !a.overflow) return hipErrorInvalidValue;
-    const size_t smem = sizeof(Bf16AppendShared);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bf16_append_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf16_append_kernel, dim3(stripes, (a.n_queries + BF_BM - 1) / BF_BM), dim3(BF_THREADS), smem, s, a);
-    return hipGetLastError();
+    // NIDX_GPU_BF16_MAINLOOP=1: a ring of nine chunks with a barrier per chunk (measured 1 % behind the shipped ring of eight with a barrier per two)
+    static const int form = [] {
+        const char *e = getenv("NIDX_GPU_BF16_MAINLOOP");
+        return e ? atoi(e) : 2;
+    }();
+    if (form == 1) return bf16_append_launch_as<decltype(&bf16_append_kernel<1, 9>), Bf16RingShared<9>>(&bf16_append_kernel<1, 9>, a, stripes, s);
+    return bf16_append_launch_as<decltype(&bf16_append_kernel<2, 8>), Bf16RingShared<8>>(&bf16_append_kernel<2, 8>, a, stripes, s);
 }
 
 hipError_t launch_rescore_select(const RescoreArgs &a, hipStream_t s) {

@@ -723,6 +723,8 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
         // that block again: the candidates are the list kernel's in every case.  NIDX_GPU_BF16_APPEND=0 keeps the list kernel alone.
         const char *const append_env = getenv("NIDX_GPU_BF16_APPEND");
         const bool append_enabled = !(append_env && atoi(append_env) == 0);
+        int ablate = 0;
+        if (const char *e = getenv("NIDX_GPU_BF16_ABLATE")) ablate = atoi(e);   // (read by experiment builds of the ring kernel only)
         if (b.floor_score && append_enabled && stripes >= 32 && !b.debug) {
             const uint32_t qb = (nq + 255u) / 256u;
             NIDX_HIP(scratch_bf16_flags.reserve((size_t)qb * 8));
@@ -747,6 +749,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
                 NIDX_HIP(hipMemsetAsync(b.partial, 0, partial_bytes, st));
                 NIDX_HIP(hipMemsetAsync(flags_sample, 0, (size_t)qb * 4, st));
                 Bf16ScanArgs ap = b;
+                ap.debug = ablate;
                 ap.round_step = rs;
                 ap.overflow = flags_sample;
                 ap.cnt_inout = scratch_bf16_counts.as<uint32_t>();
@@ -763,6 +766,7 @@ int32_t VectorIndex::segment_search_device_scratch(uint32_t s, const float *d_qu
             if (!last_rs) NIDX_HIP(hipMemsetAsync(b.partial, 0, partial_bytes, st));   // (else the slots hold the last sample's candidates)
             NIDX_HIP(hipMemsetAsync(flags_full, 0, (size_t)qb * 4, st));
             Bf16ScanArgs ap = b;
+            ap.debug = ablate;
             ap.overflow = flags_full;
             if (last_rs) {
                 ap.round_skip = last_rs;
