@@ -451,6 +451,84 @@ hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, co
     return hipGetLastError();
 }
 
+// ---- per-term score floors (round 6) ------------------------------------------------------------------------------------------------
+// tantivy prunes a union of term scorers with block-max WAND (the reference's TopDocs collector calls for_each_pruning); the streaming
+// scorer's counterpart is a STATIC bound: out[t][j] = the smallest fieldnorm id f such that at least BM25_FLOOR_RANKS[j] of the first `cap`
+// postings of term t belong to documents of fieldnorm id <= f (255: fewer than that many postings).  The quotient tf / (tf + K(fieldnorm))
+// does not fall with tf and does not rise with the fieldnorm id, so at least that many documents score >= weight(t) * quotient(tf = 1, f)
+// on term t alone — and, sums of non-negative f32 terms never being below a term, in any query of Should clauses that holds t.  The host
+// turns the ids into a per-query floor under the k-th best score (bm25_index.cpp); a prefix of a list is enough for a bound, so long
+// lists cost `cap` postings.  One wave per term, a 256-bin histogram in LDS.
+__global__ __launch_bounds__(256) void bm25_term_floor_kernel(const unsigned long long *__restrict__ term_offsets, const uint32_t *__restrict__ words,
+                                                              uint32_t n_terms, uint32_t cap, uint8_t *__restrict__ out) {
+    __shared__ uint32_t hist_all[4][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *hist = hist_all[wave];
+    constexpr uint32_t ranks[BM25_FLOOR_NR] = BM25_FLOOR_RANKS;
+    for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < n_terms; t += gridDim.x * 4u) {
+        const unsigned long long b = term_offsets[t], e0 = term_offsets[t + 1];
+        const unsigned long long e = e0 - b > cap ? b + cap : e0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0u;
+        asm volatile("" ::: "memory");
+        for (unsigned long long p = b; p < e; p += 256u) {
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) w[r] = p + 64u * r + lane < e ? words[p + 64u * r + lane] : 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (p + 64u * r + lane < e) atomicAdd(&hist[w[r] >> 24], 1u);
+        }
+        asm volatile("" ::: "memory");
+        uint32_t c[4], incl = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c[i] = hist[4 * lane + i];
+            incl += c[i];
+        }
+        const uint32_t own = incl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t excl = incl - own;
+        uint32_t mine = 255u;
+#pragma unroll
+        for (int j = 0; j < BM25_FLOOR_NR; j++) {
+            const uint32_t r = ranks[j];
+            const unsigned long long m = __ballot(incl >= r);
+            uint32_t f = 255u;
+            if (m) {
+                const int L = __ffsll((long long)m) - 1;
+                uint32_t cum = excl, first = 3u;
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    cum += c[i];
+                    if (!found && cum >= r) {
+                        first = (uint32_t)i;
+                        found = true;
+                    }
+                }
+                f = (uint32_t)__shfl((int)(4u * (uint32_t)lane + first), L, 64);
+            }
+            if (lane == j) mine = f;
+        }
+        if (lane < BM25_FLOOR_NR) out[(size_t)t * BM25_FLOOR_NR + lane] = (uint8_t)mine;
+        asm volatile("" ::: "memory");
+    }
+}
+
+hipError_t launch_bm25_term_floors(const unsigned long long *term_offsets, const uint32_t *words, uint32_t n_terms, uint32_t cap, uint8_t *out,
+                                   hipStream_t s) {
+    if (n_terms == 0) return hipSuccess;
+    const uint32_t blocks = std::min<uint32_t>((n_terms + 3u) / 4u, 256u * 8u);
+    hipLaunchKernelGGL(bm25_term_floor_kernel, dim3(blocks), dim3(256), 0, s, term_offsets, words, n_terms, cap, out);
+    return hipGetLastError();
+}
+
 // ---- several tantivy segments as ONE resident posting layout -------------------------------------------------------------
 // An index of S segments (the log-merge policy leaves several, nidx/src/settings.rs:246-253) is searched by tantivy segment by
 // segment under one searcher.search (nidx_text/src/reader.rs:433-435).  Bm25Weight's statistics are searcher-wide, so a posting's

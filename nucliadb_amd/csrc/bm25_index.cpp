@@ -153,6 +153,11 @@ struct Bm25Index {
     uint64_t total_docs = 0, total_tokens = 0;
     uint32_t n_terms = 0;
     std::vector<float> idf_of_term;   // Bm25Weight's idf per term over all segments (filled at open)
+    // Score floors (bm25_aux.hip: bm25_term_floor_kernel): floor_fn[t][j] = fieldnorm id under which >= BM25_FLOOR_RANKS[j] postings of term t
+    // lie; quot1[id] = 1 / (1 + K(id)), the tf = 1 row of tf_cache.  Empty = no floors (several resident layouts, a quotient row that is not
+    // monotone, NIDX_GPU_BM25_FLOOR=0).
+    std::vector<uint8_t> floor_fn;
+    float quot1[256] = {};
     Bm25Ctx main;
     DevBuf tf_cache;
     // term dictionary (fuzzy expansion) and the scratch of the collectors (under mu, on main.stream)
@@ -432,6 +437,29 @@ int32_t nidx_gpu_bm25_open(const nidx_gpu_bm25_segment_t *segments, uint32_t n_s
     }
     NIDX_HIP(idx->tf_cache.alloc(sizeof(cache)));
     NIDX_HIP(hipMemcpy(idx->tf_cache.p, cache, sizeof(cache), hipMemcpyHostToDevice));
+    // Per-term score floors for the streaming scorer (one resident layout only).  They rest on the quotient being monotone: not below
+    // the tf = 1 row for larger frequencies, not rising with the fieldnorm id — checked on the very table the kernels read.
+    {
+        bool monotone = idx->total_docs > 0 && avg > 0.0f;
+        for (int id = 0; id < 256 && monotone; id++) {
+            idx->quot1[id] = cache[256 + id];
+            if (!(cache[256 + id] > 0.0f) || !(cache[512 + id] >= cache[256 + id]) || !(cache[768 + id] >= cache[512 + id])) monotone = false;
+            if (id > 0 && !(cache[256 + id] <= cache[256 + id - 1])) monotone = false;
+            if (id > 0 && !(cache[id] >= cache[id - 1])) monotone = false;   // K(fieldnorm id): what the division of tf > 3 adds to tf
+        }
+        const char *fe = getenv("NIDX_GPU_BM25_FLOOR");
+        if (monotone && idx->segs.size() == 1 && idx->n_terms && !(fe && atoi(fe) == 0)) {
+            Bm25Segment &sg = idx->segs[0];
+            DevBuf d_floor;
+            const size_t bytes = (size_t)idx->n_terms * BM25_FLOOR_NR;
+            NIDX_HIP(d_floor.alloc(bytes));
+            NIDX_HIP(launch_bm25_term_floors(sg.term_offsets.as<unsigned long long>(), sg.tfs.as<uint32_t>(), idx->n_terms, 1u << 16, d_floor.as<uint8_t>(),
+                                             idx->main.stream));
+            idx->floor_fn.resize(bytes);
+            NIDX_HIP(hipMemcpyAsync(idx->floor_fn.data(), d_floor.p, bytes, hipMemcpyDeviceToHost, idx->main.stream));
+            NIDX_HIP(hipStreamSynchronize(idx->main.stream));
+        }
+    }
     *index_out = reinterpret_cast<nidx_gpu_bm25_index_t *>(idx.release());
     return NIDX_OK;
 } NIDX_ABI_CATCH
@@ -1271,14 +1299,35 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         // the union kernel's clause table: list base / length / weight / attributes per clause of this segment
         std::vector<Bm25UClause> &ucl = cx.w_ucl;
         ucl.resize(n_union ? n_clauses : 0);
+        // A floor under the k-th best score of a query whose clauses are all Should terms (every document of any clause is a hit): clause c
+        // alone gives >= BM25_FLOOR_RANKS[j] >= k documents a score >= weight(c) * quotient(tf = 1, floor_fn[term][j]); the best clause's bound
+        // is the query's.  Only where nothing removes documents behind the scorer's back: no deletions, no cursor, no fast-field order
+        // (those launches run the kernel's EXTRAS form, which never reads the floor).
+        static const uint32_t floor_ranks[BM25_FLOOR_NR] = BM25_FLOOR_RANKS;
+        int floor_j = -1;
+        if (!idx->floor_fn.empty() && seg.all_alive && !after && order_field < 0)
+            for (int j = 0; j < BM25_FLOOR_NR && floor_j < 0; j++)
+                if (floor_ranks[j] >= kk) floor_j = j;
         for (uint32_t q = 0; q < nq && n_union; q++) {
             if (!q_union[q]) continue;
+            float q_floor = -INFINITY;
+            bool floor_ok = floor_j >= 0;
+            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1] && floor_ok; c++) {
+                const Bm25ClauseDev &dc = dev_clauses[c];
+                if (dc.occur != 0 || (dc.mode != NIDX_TF_FREQ && dc.mode != 1) || !(dc.weight > 0.0f) || !(dc.weight < INFINITY)) floor_ok = false;
+            }
+            for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1] && floor_ok; c++) {
+                const uint8_t fn = idx->floor_fn[(size_t)clauses[c].term * BM25_FLOOR_NR + (size_t)floor_j];
+                if (fn != 255u) q_floor = std::max(q_floor, dev_clauses[c].weight * idx->quot1[fn]);
+            }
+            uint32_t floor_bits;
+            memcpy(&floor_bits, &q_floor, 4);
             for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) {
                 const uint64_t b = seg.term_offsets_host[clauses[c].term];
                 const uint64_t l = clen[c];
                 if (l > 0xffffffffull) return fail(NIDX_ERR_UNSUPPORTED, "a posting list of one segment holds more than 2^32 - 1 postings");
                 ucl[c] = Bm25UClause{(uint32_t)b, (uint32_t)(b >> 32), (uint32_t)l, dev_clauses[c].weight,
-                                     (uint32_t)dev_clauses[c].occur | ((uint32_t)dev_clauses[c].mode << 8), 0u, 0u, 0u};
+                                     (uint32_t)dev_clauses[c].occur | ((uint32_t)dev_clauses[c].mode << 8), floor_bits, 0u, 0u};
             }
         }
         t_work += now_us() - t_w0;

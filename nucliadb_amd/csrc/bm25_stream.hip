@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
     const uint32_t *const tfs = a.tfs;
 
     // ---- lane c holds clause c ----
-    uint32_t len_l = 0, attr_l = 0, w_bits_l = 0;
+    uint32_t len_l = 0, attr_l = 0, w_bits_l = 0, floor_bits_l = 0xff800000u;
     unsigned long long b_l = 0;
     if (lane < C) {
         const Bm25UClause uc = a.uclauses[clause_first + lane];
@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         len_l = uc.len;
         attr_l = uc.attr;
         w_bits_l = __float_as_uint(uc.weight);
+        floor_bits_l = uc.floor_bits;
     }
+    // A score at least k documents of the QUERY are known to reach (bm25_index.cpp, from the per-term floors of bm25_aux.hip; -inf = none): a final
+    // posting below it is not among the k best of the query, let alone of this item, so it never becomes a candidate.  Postings AT the floor stay.
+    const float q_floor = EXTRAS ? -INFINITY : __uint_as_float(bs_rl(floor_bits_l, 0));
     const uint32_t occur_l = attr_l & 0xff;
     // the boolean structure as clause masks
     const uint32_t must_m = (uint32_t)__ballot(lane < C && occur_l == 1), not_m = (uint32_t)__ballot(lane < C && occur_l == 2),
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
     // score it saw; the k-th largest of those 64 maxima is the k-th best of 64 real documents, hence never above the k-th best of
     // the item — one f32 sort (~100 issues) instead of the three or four 64-key merges the list otherwise needs to climb there
     // (every posting passes while it is empty, and a bar that is only refreshed by a merge lags behind the stream).
-    float bar = -INFINITY;
+    float bar = q_floor;
     bool bar_set = false;
     uint32_t postings = 0, total = 0, n_ranges = 0;
     uint32_t cur_lo = lo_doc, cur_hi = hi_doc;
@@ -552,11 +556,13 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             // most groups hold nothing the list wants once it is full: one float compare per posting before any key is built
                             // (the k-th score is NaN while the list is not full: !(s < NaN) lets every score through to the exact test)
                             if (KL == 1 && !bar_set) {
-                                float mx = -INFINITY;
+                                if (!(q_floor > -INFINITY)) {   // (a query with a floor starts above anything the first group could tell)
+                                    float mx = -INFINITY;
 #pragma unroll
-                                for (int r = 0; r < 4; r++)
-                                    if (in[r] && !inv[r]) mx = fmaxf(mx, sc[r]);
-                                bar = lane_bcast_f32(bs_sort_stages_f32<64>(mx), 64 - k);   // -inf while fewer than k lanes saw a final posting
+                                    for (int r = 0; r < 4; r++)
+                                        if (in[r] && !inv[r]) mx = fmaxf(mx, sc[r]);
+                                    bar = lane_bcast_f32(bs_sort_stages_f32<64>(mx), 64 - k);   // -inf while fewer than k lanes saw a final posting
+                                }
                                 bar_set = true;
                             }
                             const float kf = fmaxf(bar, rank_key_score(kth));   // (NaN while the list is not full: fmaxf keeps the bar)

@@ -370,7 +370,9 @@ struct Bm25Work {  // one work item: query `query`, doc-id slice `slice` of `n_s
 struct Bm25UClause {
     uint32_t b_lo, b_hi, len;
     float weight;
-    uint32_t attr, pad0, pad1, pad2;
+    uint32_t attr;
+    uint32_t floor_bits;   // f32: a score at least k documents of the QUERY reach (the same value in every clause of a query; -inf = none): bm25_stream_kernel
+    uint32_t pad1, pad2;
 };
 #define BM25_ITEM_THREADS 64      /* threads per work item (64 = one wave: no block barriers) */
 #define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
@@ -499,6 +501,12 @@ hipError_t launch_subquery_compact(const SubqueryLists &L, const SubqueryDev &sq
 // resident posting word: tfs[i] = tf | fieldnorm_ids[doc_ids[i]] << 24 (in place); *flag: bit 0 = a tf >= 2^24, bit 1 = a doc id >= n_docs
 hipError_t launch_bm25_pack_fieldnorm(const uint32_t *doc_ids, uint32_t *tfs, const uint8_t *fieldnorm_ids, unsigned long long n, uint32_t n_docs,
                                       uint32_t *flag, hipStream_t s);
+// per-term score floors (bm25_aux.hip): out[t][j] = smallest fieldnorm id f with >= BM25_FLOOR_RANKS[j] of the first `cap` resident posting words of
+// term t at fieldnorm id <= f, 255 = none
+#define BM25_FLOOR_NR 18
+#define BM25_FLOOR_RANKS {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512}
+hipError_t launch_bm25_term_floors(const unsigned long long *term_offsets, const uint32_t *words, uint32_t n_terms, uint32_t cap, uint8_t *out,
+                                   hipStream_t s);
 // several segments -> one term-major resident layout (bm25_aux.hip): segment postings [0, n_post) to dst_start[t] + (j - seg_off[t])
 hipError_t launch_bm25_concat_postings(const unsigned long long *seg_off, uint32_t n_terms, const unsigned long long *dst_start, const uint32_t *src_doc,
                                        const uint32_t *src_tf, unsigned long long n_post, uint32_t doc_base, uint32_t *dst_doc, uint32_t *dst_tf,

@@ -413,3 +413,41 @@ def test_pipelined_search_equals_the_synchronous_one(orc, corpus):
     _lib.check(_lib.lib().nidx_gpu_bm25_search_wait(s._handle, t.value, d.ctypes.data, sc.ctypes.data, cnt.ctypes.data, None, None))
     assert cnt[0] == ref["count"][0] and np.array_equal(d[0, : cnt[0]], ref["docaddr"][0, : cnt[0]]) and np.array_equal(bits(sc[0, : cnt[0]]), bits(ref["score"][0, : cnt[0]]))
     s.close()
+
+
+def test_score_floor_changes_no_result(orc, corpus, monkeypatch):
+    """The streaming scorer starts every work item's bar at the query's score floor (bm25_index.cpp / bm25_aux.hip: at least k documents are
+    known to reach it).  Queries of Should terms with and without it, through the stream kernel for every query (NIDX_GPU_BM25_UNION=2) and
+    by the planner's own routing, against the oracle and against a searcher opened without floors."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(77)
+    queries = [[Clause(int(t), S, int(rng.choice([FREQ, BASIC])), float(rng.choice([1.0, 0.25, 4.0]))) for t in rng.integers(0, vocab, int(rng.integers(1, 7)))]
+               for _ in range(96)]
+    queries += [[Clause(0), Clause(1)], [Clause(4999), Clause(4998), Clause(2)], [Clause(17), Clause(17)]]
+    monkeypatch.setenv("NIDX_GPU_BM25_FLOOR", "0")
+    plain = Bm25Searcher.open([seg])
+    monkeypatch.delenv("NIDX_GPU_BM25_FLOOR")
+    floors = Bm25Searcher.open([seg])
+    for union in ("1", "2"):
+        monkeypatch.setenv("NIDX_GPU_BM25_UNION", union)
+        for k in (1, 20, 64, 201, 501):
+            compare(orc, seg, floors, queries, k)
+            a, b = floors.search_batch(queries, k), plain.search_batch(queries, k)
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
+    plain.close()
+    floors.close()
+
+
+def test_score_floor_with_every_posting_at_the_floor(orc, monkeypatch):
+    """documents of one length, tf = 1: every posting of a term scores exactly the floor; nothing may be dropped and the lowest doc ids win"""
+    rng = np.random.default_rng(5)
+    vocab = 40
+    docs = [rng.choice(vocab, size=8, replace=False) for _ in range(30000)]
+    seg = Bm25Segment.from_term_docs(docs, vocab)
+    s = Bm25Searcher.open([seg])
+    queries = [[Clause(int(t), S, BASIC)] for t in range(0, 40, 3)] + [[Clause(1, S, BASIC), Clause(2, S, BASIC), Clause(3, S, BASIC)], [Clause(5), Clause(6, boost=2.0)]]
+    monkeypatch.setenv("NIDX_GPU_BM25_UNION", "2")
+    for k in (1, 20, 64):
+        compare(orc, seg, s, queries, k)
+    s.close()
