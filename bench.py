@@ -685,7 +685,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
     ev_exchanged = [torch.cuda.Event() for _ in range(n_sets)]
     last_merged = [None]
     p_hnsw = _lib.VectorSearchParamsC(k, -1.0, 1, _lib.METHOD_HNSW)
-    host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(max(nfl, 12))]
+    host_out = [(np.zeros((B, k), np.uint32), np.zeros((B, k), np.float32), np.zeros(B, np.uint32)) for _ in range(max(nfl, 16))]
     nfl_now = [nfl]   # (the reference-constants leg below also times deeper pipelines)
     in_flight = []   # (ticket, host_out index)
     retried_total = [0]
@@ -1110,7 +1110,7 @@ def hnsw_leg(a, L, dev, rank, world, kind, headline):
             if not do_exchange and headline:
                 ref_consts["by_batches_in_flight"] = [{"batches_in_flight": ref_consts["batches_in_flight"], "queries_per_s": ref_consts["queries_per_s"],
                                                        "sustained_frac": ref_consts["roofline"]["sustained_frac"]}]
-                for deeper in (6, 10):
+                for deeper in (6, 10, 15):
                     nfl_now[0] = deeper
                     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_depth", deeper + 1))
                     _lib.check(L.nidx_gpu_vector_set_tunable(h, b"pipeline_walks", deeper))

@@ -1194,6 +1194,8 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         // that still fits the batch into one round (the bench batch: ~1 900 instead of 2 048, its slowest items 7 % shorter); batches
         // too large for one round keep the default.  NIDX_GPU_BM25_SLICE pins it.
         uint64_t slice_now = slice_postings;
+        uint64_t short_weight = 1;   // what a posting outside the query's longest clause counts when the slices are cut (the longest clause's count 1)
+        auto weigh = [&](uint64_t sum, uint64_t longest) { return longest + short_weight * (sum - longest); };
         // Other batches are resident (the pipelined entries know): the launch does not have to fill the GPU alone, and what counts is
         // the work per posting.  With k = 20 a wave that filters n postings offers ~k ln(n / k) candidates to its list and merges them
         // 64 at a time — candidates and merges are half of the kernel's vector instructions at ~1 900 postings per item and fall per
@@ -1207,10 +1209,19 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             slice_now = BM25_SLICE_CROWDED;
         } else if (!getenv("NIDX_GPU_BM25_SLICE")) {
             const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
+            // A launch alone lasts as long as its slowest item, so the items are cut to equal COST, not equal length: a posting of the
+            // longest clause is streamed once (phase 2), one of any other clause twice (marked in phase 1, scored in phase 3) and is far
+            // more often involved — 47 against 16 cycles per posting in the per-phase trace of the bench batch (NIDX_GPU_BM25_DEBUG,
+            // DESIGN-LOG R6.1): a posting of a shorter clause counts three.
             std::vector<uint64_t> &pq = cx.w_postings;
             pq.assign(nq, 0);
-            for (uint32_t q = 0; q < nq; q++)
-                for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) pq[q] += clen[c];
+            short_weight = 3;
+            if (const char *e = getenv("NIDX_GPU_BM25_SHORT_WEIGHT")) short_weight = (uint64_t)std::max(1, atoi(e));   // (measurement)
+            for (uint32_t q = 0; q < nq; q++) {
+                uint64_t sum = 0, longest = 0;
+                for (uint64_t c = clause_offsets[q]; c < clause_offsets[q + 1]; c++) sum += clen[c], longest = std::max<uint64_t>(longest, clen[c]);
+                pq[q] = weigh(sum, longest);
+            }
             // (the item count falls as the slice grows: bisection over the candidates, and a multiplication by the reciprocal instead of
             // a 64-bit division per query and candidate — the count only steers this choice, the slicing below divides exactly)
             auto fits = [&](uint64_t cand) {
@@ -1219,27 +1230,28 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                 for (uint32_t q = 0; q < nq; q++) items += (uint64_t)((double)pq[q] * inv) + 1u;
                 return items <= budget;
             };
-            uint64_t lo = 1024, hi = slice_postings;   // candidates lo, lo + 128, ..; hi is known to be acceptable (the default)
+            uint64_t lo = 1024, hi = slice_postings * (short_weight > 1 ? 2u : 1u);   // candidates lo, lo + 128, ..; hi: the default length (in weighted postings)
             while (lo < hi) {
                 const uint64_t mid = lo + ((hi - lo) / 256) * 128;
                 if (fits(mid)) hi = mid;
                 else lo = mid + 128;
             }
-            slice_now = std::min<uint64_t>(hi, slice_postings);
+            slice_now = hi;
         }
         for (uint32_t q = 0; q < nq; q++) {
             item_first[q] = (uint32_t)work.size();
             const uint64_t c0 = clause_offsets[q], c1 = clause_offsets[q + 1];
-            uint64_t p = 0;
+            uint64_t p = 0, p_longest = 0;
             bool plain = true;
             double sum_sq = 0.0;
             for (uint64_t c = c0; c < c1; c++) {
                 const uint64_t l = clen[c];
                 p += l;
+                p_longest = std::max(p_longest, l);
                 sum_sq += (double)l * (double)l;
                 if (clauses[c].term & (NIDX_BM25_TERM_SET | NIDX_BM25_PHRASE | NIDX_BM25_SUBQUERY)) plain = false;
             }
-            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (p + slice_now - 1) / slice_now));
+            uint32_t slices = (uint32_t)std::min<uint64_t>(BM25_MAX_SLICES, std::max<uint64_t>(1, (weigh(p, p_longest) + slice_now - 1) / slice_now));
             if (union_mode != 0 && plain && c1 > c0 && c1 - c0 <= BM25_FAST_CLAUSES && !force_wide) {
                 const double sum = (double)p, shared = (sum * sum - sum_sq) * 0.5 * inv_docs;
                 // the same term twice: those two lists meet in every document (the estimate above assumes independent lists)
