@@ -1207,6 +1207,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         const bool crowded_shape = crowded && !getenv("NIDX_GPU_BM25_SLICE") && !lockstep_union;
         if (crowded_shape) {
             slice_now = BM25_SLICE_CROWDED;
+            if (const char *e = getenv("NIDX_GPU_BM25_CROWDED_SLICE")) slice_now = (uint64_t)std::max(1024, atoi(e));   // (measurement)
         } else if (!getenv("NIDX_GPU_BM25_SLICE")) {
             const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
             // A launch alone lasts as long as its slowest item, so the items are cut to equal COST, not equal length: a posting of the
