@@ -16,4 +16,5 @@ cp $F/bench_pipeline_12m5.json $P/r06_bench_pipeline_12m5.json
 cp $F/bench_hnsw10m_crowded_shape.json $P/r06_bench_hnsw10m_crowded_shape.json
 cp $F/kernel_stats_hnsw10m_crowded_shape.txt $P/r06_kernel_stats_hnsw10m_crowded_shape.txt
 cat $F/pmc_hnsw10m_crowded_shape_FETCH_SIZE.txt $F/pmc_hnsw10m_crowded_shape_WRITE_SIZE.txt > $P/r06_pmc_hnsw10m_crowded_shape.txt
+[ -f $F/bench_bf16_12m5x1024.json ] && cp $F/bench_bf16_12m5x1024.json $P/r06_bench_bf16_12m5x1024.json && cp $F/kernel_stats_bf16_12m5x1024.txt $P/r06_kernel_stats_bf16_12m5x1024.txt
 ls $P | grep r06

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6: the evidence behind DESIGN.md's [measured] figures.  bash scripts/r6_profiles.sh [part ...]
-# parts: headline bm25 rabitq exchange crowded   (default: all).  Summaries land in gpurun_out/final6/ (scripts/r6_collect.sh -> profiles/r06_*).
+# parts: headline bm25 bf16 rabitq exchange crowded   (default: all but bf16).  Summaries land in gpurun_out/final6/ (scripts/r6_collect.sh -> profiles/r06_*).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final6
@@ -38,6 +38,8 @@ bm25)
   unset NIDX_BENCH_BM25_SEGMENTS
   ( cd $ROOT && timeout 400 python bench.py --workload bm25 --steps 200 > $OUT/bench_bm25.json 2> $OUT/bench_bm25.err )
   tail -c 300 $OUT/bench_bm25.json; echo ;;
+bf16)
+  prof bf16_12m5x1024 --workload bf16 --n-vectors 12500000 --dim 1024 --cpu-queries 0 --steps 5 --warmup 2 ;;
 rabitq)
   prof rabitq_1m --workload rabitq --n-vectors 1000000 --steps 5 --warmup 1 ;;
 exchange)
