@@ -1211,12 +1211,13 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         } else if (!getenv("NIDX_GPU_BM25_SLICE")) {
             const uint64_t budget = (uint64_t)idx->n_cus * 5u * 4u * 15u / 16u;
             // A launch alone lasts as long as its slowest item, so the items are cut to equal COST, not equal length: a posting of the
-            // longest clause is streamed once (phase 2), one of any other clause twice (marked in phase 1, scored in phase 3) and is far
-            // more often involved — 47 against 16 cycles per posting in the per-phase trace of the bench batch (NIDX_GPU_BM25_DEBUG,
-            // DESIGN-LOG R6.1): a posting of a shorter clause counts three.
+            // longest clause is streamed once (phase 2), one of any other clause twice (marked in phase 1, scored in phase 3).  Measured on
+            // the bench batch (scripts/r6_bm25_weight.sh): with one-bit bitmaps, when a third of the kernel went into falsely involved
+            // postings, weight 3 took a launch from 49.5 to 44.5 us; with the three-bit filter of bitmap A weights 1 .. 3 are within
+            // 2 us of each other (43.3 - 45.7) and 2 is kept.
             std::vector<uint64_t> &pq = cx.w_postings;
             pq.assign(nq, 0);
-            short_weight = 3;
+            short_weight = 2;
             if (const char *e = getenv("NIDX_GPU_BM25_SHORT_WEIGHT")) short_weight = (uint64_t)std::max(1, atoi(e));   // (measurement)
             for (uint32_t q = 0; q < nq; q++) {
                 uint64_t sum = 0, longest = 0;

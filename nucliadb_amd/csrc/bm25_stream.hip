@@ -64,6 +64,15 @@ __device__ inline void bs_lds_order() { asm volatile("" ::: "memory"); }
 #define BS_GROUPS 8
 
 __device__ inline uint32_t bs_rl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// Bitmap A is a blocked Bloom filter (round 6): a document owns the word h >> 5 (h = the 15-bit fold of its id, as before) and THREE bits inside
+// it, taken from the top of a multiplicative hash.  A posting "finds its document in A" when all three are set.  One LDS operation per posting
+// as before; at the ~650 - 1 300 marked documents of an item the false-positive rate falls from 2 - 4 % (one bit) to 0.2 - 0.6 %, and false
+// positives were 99 % of the involved postings (true meetings: about two per QUERY on the bench mix) and a third of the kernel's time
+// (profiles/r06_bm25_breakdown.txt section 8).
+__device__ inline uint32_t bs_a_mask(uint32_t d) {
+    const uint32_t g = d * 0x9E3779B1u;
+    return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u)) | (1u << ((g >> 17) & 31u));
+}
 
 // The same network on one f32 per lane (ascending): a compare-exchange is the partner fetch, v_max, v_min and a select.
 template <int J>
@@ -382,18 +391,19 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             // back (LDS operations of a wave execute in order: row r still sees the bits of the rows before it) and a
                             // second posting of a document is looked for once per group
                             const uint32_t rem = e - p;
-                            uint32_t h[4], old[4];
+                            uint32_t h[4], old[4], am[4];
                             bool in[4];
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 in[r] = (uint32_t)lane + 64u * r < rem;
                                 h[r] = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
                                 old[r] = 0u;
-                                if (in[r]) old[r] = __hip_atomic_fetch_or(&bm_a[h[r] >> 5], 1u << (h[r] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                am[r] = bs_a_mask(d[r]);
+                                if (in[r]) old[r] = __hip_atomic_fetch_or(&bm_a[h[r] >> 5], am[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             bool hit[4];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) hit[r] = in[r] && __builtin_amdgcn_ubfe(old[r], h[r], 1u) != 0u;
+                            for (int r = 0; r < 4; r++) hit[r] = in[r] && (old[r] & am[r]) == am[r];
                             if (__ballot(hit[0] || hit[1] || hit[2] || hit[3])) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++)
@@ -407,8 +417,9 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                             const bool in = (uint32_t)lane < e - (p + 64u * r);
                             const uint32_t h = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
                             uint32_t old = 0;
-                            if (in) old = __hip_atomic_fetch_or(&bm_a[h >> 5], 1u << (h & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const bool hit = in && __builtin_amdgcn_ubfe(old, h, 1u) != 0u;
+                            const uint32_t am = bs_a_mask(d[r]);
+                            if (in) old = __hip_atomic_fetch_or(&bm_a[h >> 5], am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const bool hit = in && (old & am) == am;
                             if (__ballot(hit)) {
                                 if (hit) __hip_atomic_fetch_or(&bm_b[(h & 0x7ffu) >> 5], 1u << (h & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
@@ -526,7 +537,18 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         uint32_t n_final = rem < 256u ? rem : 256u;
                         if (probe) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) inv[r] = in[r] && __builtin_amdgcn_ubfe(bw[r], h[r], 1u) != 0u;
+                            for (int r = 0; r < 4; r++) {
+                                if (is_long) {
+                                    const uint32_t am = bs_a_mask(d[r]);
+                                    inv[r] = in[r] && (bw[r] & am) == am;
+                                } else {
+                                    inv[r] = in[r] && __builtin_amdgcn_ubfe(bw[r], h[r], 1u) != 0u;
+                                }
+                            }
+#ifdef BS_ABLATE_NOINV   /* measurement only (wrong results): no posting is ever involved — the upper bound of what a sharper filter could save */
+#pragma unroll
+                            for (int r = 0; r < 4; r++) inv[r] = false;
+#endif
                             if (__ballot(inv[0] || inv[1] || inv[2] || inv[3])) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
@@ -594,7 +616,12 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
                         const uint32_t h = (d[r] ^ (d[r] >> 15)) & 0x7fffu;
                         if (probe) {
                             const uint32_t bw = is_long ? bm_a[h >> 5] : bm_b[(h & 0x7ffu) >> 5];
-                            inv = in && __builtin_amdgcn_ubfe(bw, h, 1u) != 0u;
+                            if (is_long) {
+                                const uint32_t am = bs_a_mask(d[r]);
+                                inv = in && (bw & am) == am;
+                            } else {
+                                inv = in && __builtin_amdgcn_ubfe(bw, h, 1u) != 0u;
+                            }
                         }
                         const uint32_t fn = w[r] >> 24;
                         const uint32_t tfi = w[r] & 0xffffffu;

@@ -93,17 +93,23 @@ class Model:
             if active:
                 L = max(active, key=lambda c: (n[c], -c))
                 probe = len(active) > 1
-                A, B = np.zeros(A_BITS, bool), np.zeros(B_BITS, bool)
+                A, B = np.zeros(A_BITS // 32, np.uint32), np.zeros(B_BITS, bool)
                 h_of = lambda d: (int(d) ^ (int(d) >> 15)) & 0x7FFF
+
+                def a_mask(d):   # bs_a_mask: three bits of the document's word, from the top of a multiplicative hash
+                    g = (int(d) * 0x9E3779B1) & 0xFFFFFFFF
+                    return (1 << (g >> 27)) | (1 << ((g >> 22) & 31)) | (1 << ((g >> 17) & 31))
+
+                in_a = lambda d: (int(A[h_of(d) >> 5]) & a_mask(d)) == a_mask(d)
                 if probe:                                             # phase 1: mark
                     for c in active:
                         if c == L:
                             continue
                         for d in self.cl[c][0][pos[c]:end[c]]:
                             h = h_of(d)
-                            if A[h]:
+                            if in_a(d):
                                 B[h & 0x7FF] = True
-                            A[h] = True
+                            A[h >> 5] |= np.uint32(a_mask(d))
                 inv_short, inv_long, matched, overflow = [], [], 0, False
                 for step, c in enumerate([L] + [c for c in active if c != L and probe]):   # phases 2 and 3
                     is_long = step == 0
@@ -114,7 +120,7 @@ class Model:
                             lane_max = {}
                             for j in range(g0, min(g0 + 256, len(docs))):
                                 d = docs[j]
-                                if not (probe and bool(A[h_of(d)] if is_long else B[h_of(d) & 0x7FF])):
+                                if not (probe and bool(in_a(d) if is_long else B[h_of(d) & 0x7FF])):
                                     lane_max[(j - g0) % 64] = max(lane_max.get((j - g0) % 64, np.float32(-np.inf)), np.float32(scores[j]))
                             best = sorted(lane_max.values(), reverse=True)
                             self.bar = best[self.k - 1] if len(best) >= self.k else np.float32(-np.inf)
@@ -122,7 +128,7 @@ class Model:
                             row = slice(g0 + 64 * r, min(g0 + 64 * r + 64, len(docs)))
                             if row.start >= len(docs):
                                 break
-                            inv = [probe and bool(A[h_of(d)] if is_long else B[h_of(d) & 0x7FF]) for d in docs[row]]
+                            inv = [probe and bool(in_a(d) if is_long else B[h_of(d) & 0x7FF]) for d in docs[row]]
                             if sum(inv) and len(inv_short) + len(inv_long) + sum(inv) > CAP:
                                 overflow = True
                                 break
