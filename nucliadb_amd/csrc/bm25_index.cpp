@@ -1265,15 +1265,19 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
                 // the expected number (two postings per meeting) around 96
                 double want = std::ceil((shared + repeated) * 2.0 / 96.0);
                 if (crowded_shape) {
-                    // involved postings of one of n slices: b = postings that find their bit of A set (short x long and short x short
-                    // collisions, two per true meeting), each sets a bit of B; every short posting then meets B with probability b / 2 048
+                    // involved postings of one of n slices: b = postings that find their three bits of A set (bm25_stream.hip: a document
+                    // owns one of 1 024 words and three of its bits; with lambda = marked documents per word a stranger passes with probability
+                    // ~ (27 / 32 768) (lambda^3 + 3 lambda^2 + lambda): the third moment of a Poisson count of three-bit marks) — the longest
+                    // clause's postings against the full filter, the shorter clauses' against the filter as it fills (a quarter of that) —
+                    // plus two per true meeting; each sets a bit of B, and every short posting then meets B with probability b / 2 048
                     double l_max = 0.0;
                     for (uint64_t c = c0; c < c1; c++) l_max = std::max(l_max, (double)clen[c]);
                     const double s_all = sum - l_max, meet2 = (shared + repeated) * 2.0;
                     double n = std::max(1.0, (double)slices);
                     for (int it = 0; it < 24; it++) {
-                        const double ss = s_all / n, ll = l_max / n;
-                        const double b = ss * ll / 32768.0 + ss * ss / 65536.0 + meet2 / n;
+                        const double ss = s_all / n, ll = l_max / n, lam = ss / 1024.0;
+                        const double p_a = std::min(1.0, (27.0 / 32768.0) * (lam * lam * lam + 3.0 * lam * lam + lam));
+                        const double b = ll * p_a + ss * p_a * 0.25 + meet2 / n;
                         if (b * (1.0 + ss / 2048.0) <= 96.0) break;
                         n = std::ceil(n * 1.25);
                     }

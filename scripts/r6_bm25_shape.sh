@@ -1,12 +1,14 @@
 #!/bin/bash
-# end-to-end BM25 rate against the throughput shape's slice length, now that score floors took the candidates out of the picture
+# end-to-end BM25 rate against the throughput shape's slice length (the planner's collision estimate follows the three-bit filter)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/bm25_shape
 mkdir -p $OUT
 cd $ROOT
+timeout 900 python -m pytest tests/test_bm25_gpu.py tests/test_scale_parity_gpu.py -x -q -m gpu > $OUT/tests.log 2>&1
+echo "tests: $(tail -1 $OUT/tests.log)"
 run() {
-  timeout 600 python bench.py --workload bm25 --cpu-queries 0 > $OUT/b_$1.json 2> $OUT/b_$1.err
+  NIDX_BENCH_BM25_SEGMENTS=0 timeout 600 python bench.py --workload bm25 --cpu-queries 0 > $OUT/b_$1.json 2> $OUT/b_$1.err
   python - <<PY
 import json
 try:
@@ -18,8 +20,8 @@ except Exception as e:
 PY
 }
 run auto
-NIDX_GPU_BM25_CROWDED=0 run latency_shape
-NIDX_GPU_BM25_CROWDED_SLICE=2048 run crowded2048
 NIDX_GPU_BM25_CROWDED_SLICE=4096 run crowded4096
 NIDX_GPU_BM25_CROWDED_SLICE=16384 run crowded16384
+NIDX_GPU_BM25_CROWDED_SLICE=32768 run crowded32768
+NIDX_GPU_BM25_CROWDED=1 run always_crowded
 run auto2
