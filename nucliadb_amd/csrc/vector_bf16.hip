@@ -704,10 +704,8 @@ hipError_t launch_bf16_append(const Bf16ScanArgs &a, uint32_t stripes, hipStream
     if (a.n_queries == 0) return hipSuccess;
     if (a.n == 0 || (a.dp16 % 64u) || !a.floor_score || !a.overflow) return hipErrorInvalidValue;
     // NIDX_GPU_BF16_MAINLOOP=1: a ring of nine chunks with a barrier per chunk (measured 1 % behind the shipped ring of eight with a barrier per two)
-    static const int form = [] {
-        const char *e = getenv("NIDX_GPU_BF16_MAINLOOP");
-        return e ? atoi(e) : 2;
-    }();
+    const char *fe = getenv("NIDX_GPU_BF16_MAINLOOP");
+    const int form = fe ? atoi(fe) : 2;
     if (form == 1) return bf16_append_launch_as<decltype(&bf16_append_kernel<1, 9>), Bf16RingShared<9>>(&bf16_append_kernel<1, 9>, a, stripes, s);
     return bf16_append_launch_as<decltype(&bf16_append_kernel<2, 8>), Bf16RingShared<8>>(&bf16_append_kernel<2, 8>, a, stripes, s);
 }

@@ -447,15 +447,21 @@ def test_bf16_append_scan_equals_the_list_scan(orc, case):
         v0, s0, c0 = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, **kwargs)
         os.environ["NIDX_GPU_BF16_APPEND"] = "1"
         v1, s1, c1 = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, **kwargs)
+        # the other shape of the append kernel's operand ring (nine chunks, a barrier per chunk): the same candidates again
+        os.environ["NIDX_GPU_BF16_MAINLOOP"] = "1"
+        v2, s2, c2 = gpu_search(x, 1, q, k, method=_lib.METHOD_BRUTE_FORCE_BF16, **kwargs)
     finally:
+        os.environ.pop("NIDX_GPU_BF16_MAINLOOP", None)
         if old is None:
             os.environ.pop("NIDX_GPU_BF16_APPEND", None)
         else:
             os.environ["NIDX_GPU_BF16_APPEND"] = old
-    assert np.array_equal(c0, c1)
+    assert np.array_equal(c0, c1) and np.array_equal(c0, c2)
     for i in range(nq):
         assert np.array_equal(v0[i, : c0[i]], v1[i, : c1[i]]), (case, i)
         assert np.array_equal(bits(s0[i, : c0[i]]), bits(s1[i, : c1[i]]))
+        assert np.array_equal(v0[i, : c0[i]], v2[i, : c2[i]]), (case, i)
+        assert np.array_equal(bits(s0[i, : c0[i]]), bits(s2[i, : c2[i]]))
     if crowd is not None:
         assert set(v1[0, : c1[0]].tolist()) <= set(range(crowd, crowd + 3000))
 
