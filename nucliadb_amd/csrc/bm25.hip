@@ -773,6 +773,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t q = blockIdx.x;
+    if (m.ablate == 2) return;
     const uint32_t w0 = m.item_first[q], w1 = m.item_first[q + 1];
     const int k = (int)m.k;
     const uint32_t n_items = w1 - w0;
@@ -840,6 +841,10 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(Bm25MergeArgs m) {
         }
     }
     uint32_t cnt = 0;
+    if (m.ablate == 3) {
+        if (top.mine(0) == 12345ull && lane == 0) m.out_count[q] = 1;   // (keeps the merge alive)
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < KL; i++) {
         const int e = 64 * i + lane;

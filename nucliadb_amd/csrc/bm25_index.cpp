@@ -79,6 +79,7 @@ struct Bm25Ctx {
     std::vector<Bm25UClause> w_ucl;   // (entries of queries that are not union queries keep whatever they held: never read)
     std::vector<Bm25AfterDev> w_after;
     DevBuf s_after, s_count, s_total, s_postings, s_key;
+    DevBuf s_fuse_done, s_fuse_key, s_fuse_count, s_fuse_total, s_fuse_postings;   // Bm25FusedMerge (s_fuse_done is zeroed when it grows and stays zero between launches)
     DevBuf s_phrase_tf, s_aux_tfs, s_slop_left, s_sub_bits, s_sub_union;
     DevBuf s_set_terms, s_set_bits, s_aux_off, s_aux_out_off, s_aux_ids, s_set_counts, s_match_bits, s_match_slot, s_pair_term, s_pair_slot,
         s_facet_counts;
@@ -1436,13 +1437,6 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             a.dbg = dbgbuf.as<unsigned long long>();
 
         }
-        NIDX_HIP(hipEventRecord(cx.ev0, cx.stream));
-        {
-            const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
-            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, cx.stream));
-        }
-        NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, cx.stream));
-        NIDX_HIP(hipEventRecord(cx.ev1, cx.stream));
         Bm25MergeArgs mg;
         mg.item_first = d_item_first;
         mg.item_key = cx.s_key.as<unsigned long long>();
@@ -1460,7 +1454,44 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             mg.n_seg = idx->n_segments;
             mg.out_seg = reinterpret_cast<uint32_t *>(d_out + o_seg);
         }
-        NIDX_HIP(launch_bm25_merge(mg, nq, cx.stream));
+        const char *ab = getenv("NIDX_GPU_BM25_ABLATE_MERGE");   // measurement (wrong hits): 1 no merge launch, 2 an empty one, 3 one that writes nothing
+        mg.ablate = ab ? atoi(ab) : 0;
+        // When every item of the batch goes through the stream kernel and k <= 64, the scoring launch merges as well (Bm25FusedMerge): the last wave
+        // of every query's slices does what bm25_merge_kernel would do in a launch of its own.  NIDX_GPU_BM25_FUSED_MERGE=0 keeps the two launches.
+        bool fused_merge = n_union == nw && nw > 0 && kk <= 64 && !lockstep_union && !a.dbg && mg.ablate == 0;
+        if (const char *fe = getenv("NIDX_GPU_BM25_FUSED_MERGE")) fused_merge = fused_merge && atoi(fe) != 0;
+        if (fused_merge) {
+            const size_t done_bytes = (size_t)nq * (BM25_FUSE_MAX_GROUPS + 1u) * 4;
+            if (cx.s_fuse_done.bytes < done_bytes) {
+                NIDX_HIP(cx.s_fuse_done.reserve(done_bytes));
+                NIDX_HIP(hipMemsetAsync(cx.s_fuse_done.p, 0, cx.s_fuse_done.bytes, cx.stream));
+            }
+            NIDX_HIP(cx.s_fuse_key.reserve((size_t)nq * BM25_FUSE_MAX_GROUPS * kk * 8));
+            NIDX_HIP(cx.s_fuse_count.reserve((size_t)nq * BM25_FUSE_MAX_GROUPS * 4));
+            NIDX_HIP(cx.s_fuse_total.reserve((size_t)nq * BM25_FUSE_MAX_GROUPS * 8));
+            NIDX_HIP(cx.s_fuse_postings.reserve((size_t)nq * BM25_FUSE_MAX_GROUPS * 8));
+            a.fm.done = cx.s_fuse_done.as<uint32_t>();
+            a.fm.g_key = cx.s_fuse_key.as<unsigned long long>();
+            a.fm.g_count = cx.s_fuse_count.as<uint32_t>();
+            a.fm.g_total = cx.s_fuse_total.as<unsigned long long>();
+            a.fm.g_postings = cx.s_fuse_postings.as<unsigned long long>();
+            a.fm.out_doc = mg.out_doc;
+            a.fm.out_score = mg.out_score;
+            a.fm.out_count = mg.out_count;
+            a.fm.out_total = mg.out_total;
+            a.fm.out_postings = mg.out_postings;
+            a.fm.seg_base = mg.seg_base;
+            a.fm.n_seg = mg.n_seg;
+            a.fm.out_seg = mg.out_seg;
+        }
+        NIDX_HIP(hipEventRecord(cx.ev0, cx.stream));
+        {
+            const bool extras = a.alive != nullptr || a.match_bits != nullptr || a.order_key != nullptr || a.after != nullptr;
+            NIDX_HIP((lockstep_union ? launch_bm25_union : launch_bm25_stream)(a, d_items, n_union, extras, cx.stream));
+        }
+        NIDX_HIP(launch_bm25_search(a, d_items + n_union, n_fast, d_items + n_union + n_fast, n_wide, wide_max_clauses, cx.stream));
+        NIDX_HIP(hipEventRecord(cx.ev1, cx.stream));
+        if (!fused_merge && mg.ablate != 1) NIDX_HIP(launch_bm25_merge(mg, nq, cx.stream));
         if (n_slots)
             NIDX_HIP(launch_facet_count(seg.term_offsets.as<unsigned long long>(), seg.doc_ids.as<uint32_t>(), cx.s_pair_term.as<uint32_t>(),
                                         cx.s_pair_slot.as<int>(), (uint32_t)n_pairs, cx.s_match_bits.as<uint32_t>(), match_words,

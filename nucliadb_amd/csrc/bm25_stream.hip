@@ -101,6 +101,103 @@ __device__ inline float bs_sort_stages_f32(float v) {
     return bs_sort_steps_f32<K, K / 2>(v);
 }
 
+// ---- the fused merge (kernels.h: Bm25FusedMerge) ----
+__device__ inline uint32_t bs_ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned long long bs_ld_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Cross-workgroup hand-over WITHOUT agent-scope fences.  On this part an agent-scope release is `buffer_wbl2` (the eight XCDs' L2s are not coherent
+// with each other: the fence writes a whole L2's dirty lines back) and costs the scoring launch a factor of five (230 us against 43, measured).
+// What the fence is for — making earlier NON-atomic stores visible, keeping later NON-atomic loads from stale lines — is not needed when every
+// value that crosses workgroups is moved by agent-scope atomic accesses (sc1: written through / read past the non-coherent levels, the LLVM AMDGPU
+// memory model's code for monotonic agent-scope stores and loads): the producer's atomic stores only have to be COMPLETE before its arrival is
+// (s_waitcnt vmcnt(0): what the workgroup-scope release fence below compiles to, and it pins the compiler's order), the consumer's atomic loads are
+// issued after its arrival returned.  bs_st_* / bs_ld_* are those accesses; nothing else crosses.
+__device__ inline void bs_st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void bs_st_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one more arrival at `counter`; true for the arrival that completes `n` (it resets the counter: nobody else touches it during this launch)
+__device__ inline bool bs_arrive_last(uint32_t *counter, uint32_t n, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's atomic stores have completed before its arrival is issued
+    uint32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = bs_rl(old, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the others' lists are read after the arrival returned
+    if (old + 1u != n) return false;
+    if (lane == 0) bs_st_u32(counter, 0u);
+    return true;
+}
+// `mine`: this item's sorted list (lane e = rank e, NIDX_EMPTY_KEY behind its end and at ranks >= k)
+__device__ inline void bs_fused_merge(const Bm25Args &a, uint32_t q, uint32_t item, uint32_t slice, uint32_t n_slices, uint64_t mine, unsigned long long total,
+                                      unsigned long long postings, int lane) {
+    const Bm25FusedMerge &f = a.fm;
+    const uint32_t k = a.k;
+    const uint32_t w0 = item - slice;   // the query's first work item (its slices are consecutive work items)
+    const uint32_t n_groups = (n_slices + BM25_FUSE_GROUP - 1u) / BM25_FUSE_GROUP, g = slice / BM25_FUSE_GROUP, g_first = g * BM25_FUSE_GROUP;
+    const uint32_t g_n = n_slices - g_first < BM25_FUSE_GROUP ? n_slices - g_first : BM25_FUSE_GROUP;
+    uint32_t *const cnt_q = f.done + (size_t)q * (BM25_FUSE_MAX_GROUPS + 1u);
+    const uint32_t rev = 63u - (uint32_t)lane;   // the other lists are read worst first (bs_merge_sorted)
+    uint64_t acc = mine;
+    if (g_n > 1u) {
+        if (!bs_arrive_last(cnt_q + 1u + g, g_n, lane)) return;
+#pragma unroll
+        for (uint32_t j = 0; j < BM25_FUSE_GROUP; j++) {
+            const uint32_t sl = g_first + j;
+            if (j >= g_n || sl == slice) continue;
+            const uint32_t w = w0 + sl;
+            const uint32_t c = bs_ld_u32(a.out_count + w);
+            const uint64_t key = rev < (c < k ? c : k) ? bs_ld_u64(a.out_key + (size_t)w * k + rev) : NIDX_EMPTY_KEY;
+            total += bs_ld_u64(a.out_total + w);
+            postings += bs_ld_u64(a.out_postings + w);
+            acc = bs_merge_sorted(acc, key);
+        }
+    }
+    if (n_groups > 1u) {
+        // the group's k best go to the query's table of group lists; the last group to arrive merges the table
+        const size_t at = (size_t)q * BM25_FUSE_MAX_GROUPS + g;
+        const bool valid = acc != NIDX_EMPTY_KEY && (uint32_t)lane < k;
+        const uint32_t c_mine = (uint32_t)__popcll(__ballot(valid));
+        if ((uint32_t)lane < k) bs_st_u64(f.g_key + at * k + (uint32_t)lane, acc);
+        if (lane == 0) {
+            bs_st_u32(f.g_count + at, c_mine);
+            bs_st_u64(f.g_total + at, total);
+            bs_st_u64(f.g_postings + at, postings);
+        }
+        if (!bs_arrive_last(cnt_q, n_groups, lane)) return;
+        acc = valid ? acc : NIDX_EMPTY_KEY;
+        for (uint32_t g2 = 0; g2 < n_groups; g2++) {
+            if (g2 == g) continue;
+            const size_t o = (size_t)q * BM25_FUSE_MAX_GROUPS + g2;
+            const uint32_t c = bs_ld_u32(f.g_count + o);
+            const uint64_t key = rev < c ? bs_ld_u64(f.g_key + o * k + rev) : NIDX_EMPTY_KEY;
+            total += bs_ld_u64(f.g_total + o);
+            postings += bs_ld_u64(f.g_postings + o);
+            acc = bs_merge_sorted(acc, key);
+        }
+    }
+    // what bm25_merge_kernel writes (bm25.hip)
+    const bool valid = acc != NIDX_EMPTY_KEY && (uint32_t)lane < k;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+    if ((uint32_t)lane < k) {
+        uint32_t d = valid ? rank_key_addr(acc) : 0xffffffffu;
+        if (f.seg_base) {
+            // DocAddress of a resident doc: the last segment whose first doc is <= d (empty segments share their base with the next)
+            uint32_t lo = 0, hi = f.n_seg;
+            while (valid && hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (f.seg_base[mid] <= d) lo = mid;
+                else hi = mid;
+            }
+            if (valid) d -= f.seg_base[lo];
+            f.out_seg[(size_t)q * k + (uint32_t)lane] = lo;
+        }
+        f.out_doc[(size_t)q * k + (uint32_t)lane] = d;
+        f.out_score[(size_t)q * k + (uint32_t)lane] = valid ? rank_key_score(acc) : 0.f;
+    }
+    if (lane == 0) {
+        f.out_count[q] = cnt;
+        f.out_total[q] = total;
+        f.out_postings[q] = postings;
+    }
+}
+
 // DBG: the per-item cycle trace of NIDX_GPU_BM25_DEBUG (a.dbg != nullptr) is a separate instantiation: none of its state in the product kernel
 template <int KL, bool EXTRAS, bool DBG>
 __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream_kernel(Bm25Args a, const uint32_t *items, uint32_t n_items) {
@@ -842,12 +939,27 @@ __global__ __launch_bounds__(256, (KL == 1 ? BS_MIN_WAVES : 4)) void bm25_stream
         const uint64_t key = top.mine(i);
         const bool valid = key != NIDX_EMPTY_KEY && e < k;
         cnt += (uint32_t)__popcll(__ballot(valid));
-        if (e < k) a.out_key[(size_t)item * k + e] = valid ? key : NIDX_EMPTY_KEY;
+        if (e < k) {
+            if (KL == 1 && a.fm.done) bs_st_u64(a.out_key + (size_t)item * k + e, valid ? key : NIDX_EMPTY_KEY);   // (read by another workgroup of this launch)
+            else a.out_key[(size_t)item * k + e] = valid ? key : NIDX_EMPTY_KEY;
+        }
     }
     if (lane == 0) {
-        a.out_count[item] = cnt;
-        a.out_total[item] = total;
-        a.out_postings[item] = postings;
+        if (KL == 1 && a.fm.done) {
+            bs_st_u32(a.out_count + item, cnt);
+            bs_st_u64(a.out_total + item, total);
+            bs_st_u64(a.out_postings + item, postings);
+        } else {
+            a.out_count[item] = cnt;
+            a.out_total[item] = total;
+            a.out_postings[item] = postings;
+        }
+    }
+    if constexpr (KL == 1) {
+        if (a.fm.done) {
+            const uint64_t key0 = top.mine(0);
+            bs_fused_merge(a, q, item, slice, n_slices, (key0 != NIDX_EMPTY_KEY && lane < k) ? key0 : NIDX_EMPTY_KEY, total, postings, lane);
+        }
     }
 }
 

@@ -378,6 +378,26 @@ struct Bm25UClause {
 #define BM25_SLICE_POSTINGS 2048  /* target postings per work item */
 #define BM25_SLICE_CROWDED 8192   /* ... of a union query when other batches are resident (bm25_index.cpp: crowded_shape) */
 #define BM25_MAX_SLICES 256
+// bm25_stream_kernel's fused merge (k <= 64, every item of the launch a stream item): the LAST wave to finish among a group of eight slices of
+// a query merges the group's lists, the last group to finish merges the groups' lists and writes what bm25_merge_kernel would have written —
+// no second launch behind the scoring kernel (3.4 us of every 30 us batch in the pipelined bench; scripts/r6_ab_merge.sh).  A wave merges at
+// most 7 + 31 lists whatever the query's length.  `done` holds the arrival counters ([n_queries][33]: the query's, then one per group); whoever
+// completes a count resets it, so the array is zero between launches.
+#define BM25_FUSE_GROUP 8u
+#define BM25_FUSE_MAX_GROUPS 32u   /* BM25_MAX_SLICES / BM25_FUSE_GROUP */
+struct Bm25FusedMerge {
+    uint32_t *done = nullptr;       // nullptr: bm25_merge_kernel merges
+    unsigned long long *g_key;      // [n_queries][32][k] the groups' lists
+    uint32_t *g_count;              // [n_queries][32]
+    unsigned long long *g_total, *g_postings;   // [n_queries][32]
+    uint32_t *out_doc;              // the merged hits, exactly as Bm25MergeArgs
+    float *out_score;
+    uint32_t *out_count;
+    unsigned long long *out_total, *out_postings;
+    const uint32_t *seg_base = nullptr;
+    uint32_t n_seg = 0;
+    uint32_t *out_seg = nullptr;
+};
 struct Bm25Args {
     const Bm25Work *work;
     uint32_t n_docs;
@@ -409,6 +429,7 @@ struct Bm25Args {
     const int *match_slot;                  // [n_queries] or nullptr
     uint32_t match_words;
     const Bm25UClause *uclauses;            // [n_clauses of the batch] (bm25_union_kernel), parallel to `clauses`
+    Bm25FusedMerge fm;                      // bm25_stream_kernel only
 };
 #define BM25_AUX_TERM 0x80000000u
 struct Bm25MergeArgs {  // per query: merge the key lists of its work items [item_first[q], item_first[q + 1])
@@ -426,6 +447,7 @@ struct Bm25MergeArgs {  // per query: merge the key lists of its work items [ite
     const uint32_t *seg_base = nullptr;
     uint32_t n_seg = 0;
     uint32_t *out_seg = nullptr;
+    int ablate = 0;   // measurement (NIDX_GPU_BM25_ABLATE_MERGE = 2 / 3): return at once / merge but write nothing
 };
 hipError_t launch_bm25_merge(const Bm25MergeArgs &m, uint32_t n_queries, hipStream_t s);
 #define BM25_FAST_CLAUSES 8   /* queries of at most this many clauses take bm25_fast_kernel */

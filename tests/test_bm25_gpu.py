@@ -451,3 +451,38 @@ def test_score_floor_with_every_posting_at_the_floor(orc, monkeypatch):
     for k in (1, 20, 64):
         compare(orc, seg, s, queries, k)
     s.close()
+
+
+def test_fused_merge_changes_no_result(orc, corpus, monkeypatch):
+    """k <= 64 and every query a term union: the scoring launch merges the slices itself (the last wave of every group of eight slices, then the
+    last group: kernels.h Bm25FusedMerge) instead of bm25_merge_kernel in a launch of its own.  One slice, a few, two levels (slices pinned to
+    256 postings: ~150 of them for the densest term), with and without extras (deletions), against the oracle and against the two-launch path."""
+    seg, vocab = corpus
+    rng = np.random.default_rng(99)
+    queries = [[Clause(int(t), S, int(rng.choice([FREQ, BASIC]))) for t in rng.integers(0, vocab, int(rng.integers(1, 5)))] for _ in range(60)]
+    queries += [[Clause(0), Clause(1), Clause(2)], [Clause(0)], [Clause(4999)], [Clause(3, boost=2.0), Clause(0)], []]
+    monkeypatch.setenv("NIDX_GPU_BM25_UNION", "2")   # every query through the stream kernel: the condition of the fused merge
+    s = Bm25Searcher.open([seg])
+    for slice_env in (None, "256", "1024"):
+        if slice_env is None:
+            monkeypatch.delenv("NIDX_GPU_BM25_SLICE", raising=False)
+        else:
+            monkeypatch.setenv("NIDX_GPU_BM25_SLICE", slice_env)
+        for k in (1, 20, 64):
+            monkeypatch.delenv("NIDX_GPU_BM25_FUSED_MERGE", raising=False)
+            compare(orc, seg, s, queries, k)
+            a = s.search_batch(queries, k)
+            a2 = s.search_batch(queries, k)   # the arrival counters are back at zero after a launch
+            monkeypatch.setenv("NIDX_GPU_BM25_FUSED_MERGE", "0")
+            b = s.search_batch(queries, k)
+            for x, y, z in zip(a, b, a2):
+                assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
+                assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(z).view(np.uint8))
+    s.close()
+    monkeypatch.delenv("NIDX_GPU_BM25_FUSED_MERGE", raising=False)
+    monkeypatch.setenv("NIDX_GPU_BM25_SLICE", "512")
+    alive = orc.bitset(seg.n_docs, ones=np.nonzero(rng.random(seg.n_docs) < 0.8)[0].tolist())
+    dead = Bm25Segment(seg.term_offsets, seg.doc_ids, seg.tfs, seg.fieldnorm_ids, seg.total_num_tokens, alive)
+    s = Bm25Searcher.open([dead])
+    compare(orc, dead, s, queries, 20)
+    s.close()
