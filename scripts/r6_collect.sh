@@ -6,7 +6,7 @@ F=gpurun_out/final6; P=profiles
 cp $F/bench_default.json $P/r06_bench_default.json
 cp $F/bench_bm25.json $P/r06_bench_bm25.json
 cp $F/bench_bm25_one_at_a_time.json $P/r06_bench_bm25_one_at_a_time.json
-cat $F/kernel_stats_bm25_one_at_a_time.txt $F/kernel_stats_bm25_pipelined.txt > $P/r06_kernel_stats_bm25.txt
+cat $F/kernel_stats_bm25_one_at_a_time.txt $F/kernel_stats_bm25_one_at_a_time_two_launches.txt $F/kernel_stats_bm25_pipelined.txt > $P/r06_kernel_stats_bm25.txt
 cat $F/pmc_bm25_FETCH_SIZE.txt $F/pmc_bm25_WRITE_SIZE.txt > $P/r06_pmc_bm25.txt
 cp $F/bm25_batch_curve.txt $P/r06_bm25_batch_curve.txt
 cp $F/bench_rabitq_1m.json $P/r06_bench_rabitq_1m.json

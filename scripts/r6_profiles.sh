@@ -31,6 +31,7 @@ headline)
 bm25)
   export NIDX_BENCH_BM25_SEGMENTS=0
   NIDX_BENCH_BM25_DEPTH=1 NIDX_BENCH_BM25_THREADS=1 prof bm25_one_at_a_time --workload bm25 --cpu-queries 0 --steps 200
+  NIDX_GPU_BM25_FUSED_MERGE=0 NIDX_BENCH_BM25_DEPTH=1 NIDX_BENCH_BM25_THREADS=1 prof bm25_one_at_a_time_two_launches --workload bm25 --cpu-queries 0 --steps 200
   prof bm25_pipelined --workload bm25 --cpu-queries 0 --steps 200
   pmc bm25 FETCH_SIZE --workload bm25 --steps 4 --warmup 1 --cpu-queries 0
   pmc bm25 WRITE_SIZE --workload bm25 --steps 4 --warmup 1 --cpu-queries 0
