@@ -1458,7 +1458,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
         mg.ablate = ab ? atoi(ab) : 0;
         // When every item of the batch goes through the stream kernel and k <= 64, the scoring launch merges as well (Bm25FusedMerge): the last wave
         // of every query's slices does what bm25_merge_kernel would do in a launch of its own.  NIDX_GPU_BM25_FUSED_MERGE=0 keeps the two launches.
-        bool fused_merge = n_union == nw && nw > 0 && kk <= 64 && !lockstep_union && !a.dbg && mg.ablate == 0;
+        bool fused_merge = n_union == nw && nw > 0 && kk <= 64 && !lockstep_union && !a.dbg && (mg.ablate == 0 || mg.ablate == 3);
         if (const char *fe = getenv("NIDX_GPU_BM25_FUSED_MERGE")) fused_merge = fused_merge && atoi(fe) != 0;
         if (fused_merge) {
             const size_t done_bytes = (size_t)nq * (BM25_FUSE_MAX_GROUPS + 1u) * 4;
@@ -1483,6 +1483,7 @@ static int32_t bm25_search_locked(Bm25Index *idx, Bm25Ctx &cx, Bm25Slot *async_s
             a.fm.seg_base = mg.seg_base;
             a.fm.n_seg = mg.n_seg;
             a.fm.out_seg = mg.out_seg;
+            a.fm.ablate = mg.ablate;
         }
         NIDX_HIP(hipEventRecord(cx.ev0, cx.stream));
         {

@@ -172,6 +172,10 @@ __device__ inline void bs_fused_merge(const Bm25Args &a, uint32_t q, uint32_t it
             acc = bs_merge_sorted(acc, key);
         }
     }
+    if (f.ablate == 3) {
+        if (acc == 12345ull && lane == 0) f.out_count[q] = 1;   // (keeps the merge alive)
+        return;
+    }
     // what bm25_merge_kernel writes (bm25.hip)
     const bool valid = acc != NIDX_EMPTY_KEY && (uint32_t)lane < k;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));

@@ -397,6 +397,7 @@ struct Bm25FusedMerge {
     const uint32_t *seg_base = nullptr;
     uint32_t n_seg = 0;
     uint32_t *out_seg = nullptr;
+    int ablate = 0;                 // measurement (NIDX_GPU_BM25_ABLATE_MERGE=3 with the fused merge): merge, write nothing
 };
 struct Bm25Args {
     const Bm25Work *work;
