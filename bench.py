@@ -2288,7 +2288,11 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
     from concurrent.futures import ThreadPoolExecutor
 
     fuser = ThreadPoolExecutor(max_workers=1)
-    bm_out = [(np.zeros((B, kb), np.uint64), np.zeros((B, kb), np.float32), np.zeros(B, np.uint32)) for _ in range(2)]
+    # BM25 batches in flight: their launches wait for workgroup slots behind the walks that fill the device, so a scoring launch that
+    # takes 0.06 ms alone completes 0.2 - 0.3 ms after its submit; with three tickets outstanding most of that latency is hidden
+    bm_depth = int(os.environ.get("NIDX_BENCH_HYBRID_BM25_DEPTH", "3"))
+    ring = bm_depth + 4   # the keyword leg runs at most three batches ahead of the fusion (the queue below holds two results)
+    bm_out = [(np.zeros((B, kb), np.uint64), np.zeros((B, kb), np.float32), np.zeros(B, np.uint32)) for _ in range(ring)]
     fusing = []   # the job of the previous batch
     low32 = np.uint64(0xFFFFFFFF)
 
@@ -2297,60 +2301,73 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         return rrf_fuse_batch([(bo[0] & low32, bo[2], 1.0, bo[1]), (vo[0].astype(np.uint64), vo[2], 1.0, None)], k=60.0, window=k)
 
     in_flight = []
-    # BM25 batches in flight: their launches wait for workgroup slots behind the walks that fill the device, so a scoring launch that
-    # takes 0.06 ms alone completes 0.2 - 0.3 ms after its submit; with three of the library's four tickets outstanding most of that latency is hidden (measured 2 / 3 / 4: 2.10 / 2.39 / 2.25 M hybrid queries/s)
-    bm_depth = int(os.environ.get("NIDX_BENCH_HYBRID_BM25_DEPTH", "3"))
-    bm_in_flight = []   # (batch, ticket): the keyword search runs batches ahead too (nidx_gpu_bm25_search_submit / _wait)
-    t_parts = {"vector_submit": 0.0, "bm25_submit_wait": 0.0, "vector_wait": 0.0, "fusion": 0.0}
+    t_parts = {"vector_submit": 0.0, "bm25_wait": 0.0, "vector_wait": 0.0, "fusion": 0.0}
     kernel_ms = []
+    import queue
+    import threading
 
     def submit(i):
         t = C.c_uint64(0)
         _lib.check(L.nidx_gpu_vector_search_submit(h, qpool[i % n_pool].data_ptr(), B, d, C.byref(p), None, C.byref(t)))
         in_flight.append((t.value, i % nfl))
 
-    def step(i, last):
-        # the vector batches run ahead of the keyword search of batch i; BM25 of batch i overlaps them on the device
-        t0 = time.perf_counter()
-        while len(in_flight) < nfl and (i + len(in_flight)) < last:
-            submit(i + len(in_flight))
-        t1 = time.perf_counter()
-        while len(bm_in_flight) < bm_depth and (i + len(bm_in_flight)) < last:
-            bm_in_flight.append((i + len(bm_in_flight), bm.submit(i + len(bm_in_flight))))
-        _bi, btk = bm_in_flight.pop(0)
-        bo = bm_out[i % 2]   # (filled at wait time: two sets are enough whatever the submit depth)
-        bm.wait(btk, out=bo)
-        kernel_ms.append(bm.kernel_ms())
-        t2 = time.perf_counter()
-        tk, j = in_flight.pop(0)
-        hv_, hs_, hc_ = host_out[j]
-        r_ = C.c_uint32(0)
-        _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, C.byref(r_)))
-        retried_total[0] += r_.value
-        t3 = time.perf_counter()
-        job = fuser.submit(fuse, bo, host_out[j])
-        fused = fusing.pop(0).result() if fusing else None   # batch i - 1, fused while this batch was waited for
-        fusing.append(job)
-        if i + 1 == last:   # the last batch of a region is fused inside it
-            fused = fusing.pop(0).result()
-        t4 = time.perf_counter()
-        t_parts["vector_submit"] += t1 - t0
-        t_parts["bm25_submit_wait"] += t2 - t1
-        t_parts["vector_wait"] += t3 - t2
-        t_parts["fusion"] += t4 - t3
+    def keyword_leg(n_steps, results):
+        # The keyword search of a hybrid request is a request thread of its own in the reference (src/searcher/shard_search.rs:139-153: the
+        # text / paragraph search and the vector search of one request run side by side): here one thread that keeps `bm_depth` BM25 batches
+        # in flight through nidx_gpu_bm25_search_submit / _wait (the calls release the interpreter lock) and hands every finished batch over
+        try:
+            pend, nxt = [], 0
+            for _ in range(n_steps):
+                while len(pend) < bm_depth and nxt < n_steps:
+                    pend.append((nxt, bm.submit(nxt)))
+                    nxt += 1
+                bi, tk = pend.pop(0)
+                bm.wait(tk, out=bm_out[bi % ring])
+                kernel_ms.append(bm.kernel_ms())
+                results.put(bi)
+        except BaseException as e:  # noqa: BLE001 — handed to the main loop
+            results.put(e)
+
+    def run_region(n_steps):
+        """n_steps hybrid batches -> the fused result of the last one"""
+        results = queue.Queue(maxsize=2)
+        leg = threading.Thread(target=keyword_leg, args=(n_steps, results), daemon=True)
+        leg.start()
+        fused = None
+        for i in range(n_steps):
+            t0 = time.perf_counter()
+            while len(in_flight) < nfl and (i + len(in_flight)) < n_steps:
+                submit(i + len(in_flight))
+            t1 = time.perf_counter()
+            tk, j = in_flight.pop(0)
+            hv_, hs_, hc_ = host_out[j]
+            r_ = C.c_uint32(0)
+            _lib.check(L.nidx_gpu_vector_search_wait(h, tk, None, None, hv_.ctypes.data, hs_.ctypes.data, hc_.ctypes.data, C.byref(r_)))
+            retried_total[0] += r_.value
+            t2 = time.perf_counter()
+            bi = results.get()
+            if isinstance(bi, BaseException):
+                raise bi
+            t3 = time.perf_counter()
+            job = fuser.submit(fuse, bm_out[bi % ring], host_out[j])
+            fused = fusing.pop(0).result() if fusing else None   # batch i - 1, fused while this batch was waited for
+            fusing.append(job)
+            if i + 1 == n_steps:   # the last batch of a region is fused inside it
+                fused = fusing.pop(0).result()
+            t4 = time.perf_counter()
+            t_parts["vector_submit"] += t1 - t0
+            t_parts["vector_wait"] += t2 - t1
+            t_parts["bm25_wait"] += t3 - t2
+            t_parts["fusion"] += t4 - t3
+        leg.join()
         return fused
 
-    for i in range(max(2, a.warmup)):
-        step(i, max(2, a.warmup))
+    run_region(max(2, a.warmup))
     torch.cuda.synchronize()
-    for k_ in t_parts:
-        t_parts[k_] = 0.0
-    kernel_ms.clear()
     # probe, then a region of at least min_timed_s
     n_steps = max(a.steps, 8)
     t0 = time.perf_counter()
-    for i in range(n_steps):
-        step(i, n_steps)
+    run_region(n_steps)
     probe = time.perf_counter() - t0
     n_steps = max(n_steps, int(np.ceil(n_steps * min(a.min_timed_s, 1.0) / max(probe, 1e-6))))
     for k_ in t_parts:
@@ -2359,8 +2376,7 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
     retried_total[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(n_steps):
-        step(i, n_steps)
+    run_region(n_steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     out = {
@@ -2371,6 +2387,7 @@ def hybrid_block(a, L, dev, rank, h, qpool, bm, nfl, cpu_vector_qps, cpu_bm25_qp
         "walk_launch_shape": "min_waves = 5 (<= 96 VGPRs), vis_log2 = 12: a BM25 workgroup is co-resident with four walks on every CU" if shared_shape else "the library's default",
         "vector_queries_re_run_exactly": retried_total[0],
         "fusion": "nidx_gpu_rank_fusion_rrf (native, host) on a second host thread, one batch behind the searches; ms_per_step_parts.fusion = what the main loop still waits for it",
+        "keyword_leg": "a host thread of its own (the reference runs the keyword and the vector search of a request side by side, shard_search.rs:139-153): %d BM25 batches in flight; ms_per_step_parts.bm25_wait = what the main loop still waits for it" % bm_depth,
         "ms_per_step_parts": {kk_: v / n_steps * 1e3 for kk_, v in t_parts.items()},
         "cpu_baseline": None,
     }
