@@ -738,7 +738,8 @@ int32_t nidx_gpu_bm25_apply_deletions(nidx_gpu_bm25_index_t *index, uint32_t seg
                                       uint64_t *n_alive_out);
 
 /* Device time (HIP events on the handle's stream) spent in the scoring kernel(s) of the last
- * nidx_gpu_bm25_search call, summed over segments. */
+ * nidx_gpu_bm25_search call, summed over segments.  For batches of term unions with k <= 64 the scoring launch
+ * also merges the doc-id slices of every query (no merge launch of its own behind it): that time is included. */
 int32_t nidx_gpu_bm25_last_kernel_ms(const nidx_gpu_bm25_index_t *index, float *ms_out);
 
 /* tantivy Bm25Weight pieces, exposed for the host query layer and for tests. */
